@@ -1,0 +1,362 @@
+/*
+ * nrt_oracle.c -- CPU restatement (plain C) of the reference's query-execution hot path.
+ * TEST INFRASTRUCTURE ONLY: see nrt_oracle.h for who may use it and for the parity status.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off; no -ffast-math: float op order is the spec)
+ */
+#include "nrt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * SmallFloat.intToByte4 / byte4ToInt  (org.apache.lucene.util.SmallFloat, Lucene 10.4.0;
+ * used by BM25Similarity.computeNorm and LENGTH_TABLE).  SURVEY.md Appendix A.1.
+ * ------------------------------------------------------------------------------------------ */
+static int32_t long_to_int4(int64_t i) {
+  /* numBits = 64 - Long.numberOfLeadingZeros(i) */
+  int num_bits = (i == 0) ? 0 : 64 - __builtin_clzll((unsigned long long)i);
+  if (num_bits < 4) {
+    return (int32_t)i; /* subnormal */
+  }
+  int shift = num_bits - 4;
+  int32_t encoded = (int32_t)((uint64_t)i >> shift); /* keep the 4 most significant bits */
+  encoded &= 0x07;                                   /* the top one is implicit */
+  encoded |= (shift + 1) << 3;                       /* 0 is reserved for subnormals */
+  return encoded;
+}
+
+static int64_t int4_to_long(int32_t i) {
+  int64_t bits = i & 0x07;
+  int shift = (int)((uint32_t)i >> 3) - 1;
+  if (shift == -1) return bits;
+  return (bits | 0x08) << shift;
+}
+
+/* MAX_INT4 = longToInt4(Integer.MAX_VALUE) = 231; NUM_FREE_VALUES = 255 - MAX_INT4 = 24 */
+static int32_t num_free_values(void) { return 255 - long_to_int4(2147483647LL); }
+
+int32_t nrt_oracle_int_to_byte4(int32_t i) {
+  int32_t nfv = num_free_values();
+  if (i < 0) return -1;
+  if (i < nfv) return i;
+  return (nfv + long_to_int4((int64_t)i - nfv)) & 0xFF;
+}
+
+int32_t nrt_oracle_byte4_to_int(int32_t b) {
+  int32_t nfv = num_free_values();
+  b &= 0xFF;
+  if (b < nfv) return b;
+  return (int32_t)(nfv + int4_to_long(b - nfv));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BM25Similarity (Lucene 10.4.0), default instance per SimilarityCreator.java:33,41.
+ *   idf   = (float) Math.log(1 + (docCount - docFreq + 0.5D) / (docFreq + 0.5D))
+ *   avgdl = (float) (sumTotalTermFreq / (double) docCount)
+ *   cache[i] = 1f / (k1 * ((1 - b) + b * LENGTH_TABLE[i] / avgdl))        (all float ops)
+ *   score = weight - weight / (1f + freq * normInverse)                  (all float ops)
+ * Explain text that pins the shape: src/test/java/com/yelp/nrtsearch/server/grpc/QueryTest.java
+ * :1003-1019.
+ * ------------------------------------------------------------------------------------------ */
+float nrt_oracle_bm25_idf(int64_t doc_count, int64_t doc_freq) {
+  double v = log(1.0 + ((double)(doc_count - doc_freq) + 0.5) / ((double)doc_freq + 0.5));
+  return (float)v;
+}
+
+float nrt_oracle_bm25_avgdl(int64_t sum_total_term_freq, int64_t doc_count) {
+  return (float)((double)sum_total_term_freq / (double)doc_count);
+}
+
+void nrt_oracle_bm25_norm_cache(float avgdl, float k1, float b, float out256[256]) {
+  for (int i = 0; i < 256; ++i) {
+    volatile float len = (float)nrt_oracle_byte4_to_int(i); /* LENGTH_TABLE[i] */
+    volatile float one_minus_b = 1.0f - b;
+    volatile float t = b * len;
+    t = t / avgdl;
+    t = one_minus_b + t;
+    t = k1 * t;
+    out256[i] = 1.0f / t;
+  }
+}
+
+float nrt_oracle_bm25_score(float weight, float freq, float norm_inverse) {
+  volatile float t = freq * norm_inverse; /* volatile: forbid contraction / reassociation */
+  t = 1.0f + t;
+  t = weight / t;
+  return weight - t;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Collector: LazyQueueTopScoreDocCollector.java:37-203 over Lucene's HitQueue
+ * (lessThan(a,b): a.score == b.score ? a.doc > b.doc : a.score < b.score  -- SURVEY A.5).
+ * totalHits / relation: this restatement drives the collector from an EXHAUSTIVE scorer, so
+ * totalHits is the exact count; the relation flips to GREATER_THAN_OR_EQUAL_TO exactly where
+ * the reference collector would start publishing a min competitive score (…Collector.java
+ * :176-199: totalHits > totalHitsThreshold and the queue is full).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { int32_t doc; float score; } hit_t;
+
+struct nrt_oracle_collector {
+  int32_t num_hits;
+  int32_t has_after;
+  int32_t after_doc_global;
+  float   after_score;
+  int32_t total_hits_threshold; /* already max(threshold, numHits), …Manager.java:102 */
+  int32_t doc_base;
+  int32_t after_doc_leaf;
+  int64_t total_hits;
+  int32_t relation_gte;
+  float   min_competitive;
+  int32_t size;
+  hit_t*  heap; /* 1-based binary min-heap under less_than */
+};
+
+static int less_than(const hit_t* a, const hit_t* b) {
+  if (a->score == b->score) return a->doc > b->doc;
+  return a->score < b->score;
+}
+
+static void heap_up(hit_t* h, int i) {
+  hit_t node = h[i];
+  int j = i >> 1;
+  while (j > 0 && less_than(&node, &h[j])) {
+    h[i] = h[j];
+    i = j;
+    j >>= 1;
+  }
+  h[i] = node;
+}
+
+static void heap_down(hit_t* h, int size, int i) {
+  hit_t node = h[i];
+  int j = i << 1, k = j + 1;
+  if (k <= size && less_than(&h[k], &h[j])) j = k;
+  while (j <= size && less_than(&h[j], &node)) {
+    h[i] = h[j];
+    i = j;
+    j = i << 1;
+    k = j + 1;
+    if (k <= size && less_than(&h[k], &h[j])) j = k;
+  }
+  h[i] = node;
+}
+
+nrt_oracle_collector* nrt_oracle_collector_new(int32_t num_hits, int32_t has_after, int32_t after_doc,
+                                               float after_score, int32_t total_hits_threshold) {
+  if (num_hits <= 0 || total_hits_threshold < 0) return NULL; /* …Manager.java:90-98 */
+  nrt_oracle_collector* c = (nrt_oracle_collector*)calloc(1, sizeof(*c));
+  c->num_hits = num_hits;
+  c->has_after = has_after;
+  c->after_doc_global = after_doc;
+  c->after_score = after_score;
+  c->total_hits_threshold = total_hits_threshold > num_hits ? total_hits_threshold : num_hits;
+  c->heap = (hit_t*)malloc(sizeof(hit_t) * ((size_t)num_hits + 1));
+  c->min_competitive = 0.0f;
+  nrt_oracle_collector_set_leaf(c, 0);
+  return c;
+}
+
+void nrt_oracle_collector_free(nrt_oracle_collector* c) {
+  if (!c) return;
+  free(c->heap);
+  free(c);
+}
+
+void nrt_oracle_collector_set_leaf(nrt_oracle_collector* c, int32_t doc_base) {
+  c->doc_base = doc_base;
+  c->after_doc_leaf = c->has_after ? c->after_doc_global - doc_base : 2147483647;
+}
+
+/* updateMinCompetitiveScore, …Collector.java:176-199 */
+static void update_min_competitive(nrt_oracle_collector* c) {
+  if (c->total_hits > c->total_hits_threshold) {
+    float top = (c->size == c->num_hits) ? c->heap[1].score : -INFINITY;
+    float local_min = nextafterf(top, INFINITY); /* Math.nextUp */
+    if (local_min > c->min_competitive) {
+      c->relation_gte = 1;
+      c->min_competitive = local_min;
+    }
+  }
+}
+
+void nrt_oracle_collector_collect(nrt_oracle_collector* c, int32_t doc, float score) {
+  int64_t hit_count_so_far = ++c->total_hits; /* :106 */
+  if (c->has_after &&
+      (score > c->after_score || (score == c->after_score && doc <= c->after_doc_leaf))) {
+    /* hit was collected on a previous page, :112-120 */
+    if (!c->relation_gte) update_min_competitive(c);
+    return;
+  }
+  float top_score = (c->size == c->num_hits) ? c->heap[1].score : -INFINITY; /* :122-127 */
+  if (score <= top_score) { /* :129-140: ties lose, docs arrive in increasing docid */
+    if (hit_count_so_far == (int64_t)c->total_hits_threshold + 1) update_min_competitive(c);
+    return;
+  }
+  /* collectCompetitiveHit, :146-156 */
+  if (c->size < c->num_hits) {
+    c->size++;
+    c->heap[c->size].doc = doc + c->doc_base;
+    c->heap[c->size].score = score;
+    heap_up(c->heap, c->size);
+  } else {
+    c->heap[1].doc = doc + c->doc_base;
+    c->heap[1].score = score;
+    heap_down(c->heap, c->size, 1);
+  }
+  update_min_competitive(c);
+}
+
+int32_t nrt_oracle_collector_topdocs(nrt_oracle_collector* c, int32_t* docs, float* scores,
+                                     int64_t* total_hits, int32_t* total_hits_is_lower_bound) {
+  /* TopDocsCollector.topDocs(): pop least-first into the tail => (score desc, doc asc) */
+  int32_t n = c->size;
+  hit_t* h = (hit_t*)malloc(sizeof(hit_t) * ((size_t)n + 1));
+  memcpy(h, c->heap, sizeof(hit_t) * ((size_t)n + 1));
+  int size = n;
+  for (int i = n - 1; i >= 0; --i) {
+    docs[i] = h[1].doc;
+    scores[i] = h[1].score;
+    h[1] = h[size];
+    size--;
+    if (size > 0) heap_down(h, size, 1);
+  }
+  free(h);
+  if (total_hits) *total_hits = c->total_hits;
+  if (total_hits_is_lower_bound) *total_hits_is_lower_bound = c->relation_gte;
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Exhaustive disjunction over one segment.  What is restated: the observable contract of
+ * IndexSearcher.search -> Weight.bulkScorer().score(leafCollector, liveDocs, 0, maxDoc) for a
+ * rewritten pure-SHOULD BooleanQuery of TermQuery clauses / a single TermQuery, reached from
+ * src/main/java/com/yelp/nrtsearch/server/handler/SearchHandler.java:1412-1413.
+ * ------------------------------------------------------------------------------------------ */
+#define ORACLE_WINDOW 4096
+
+void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                               int32_t n_terms, const nrt_oracle_term* terms,
+                               nrt_oracle_collector* collector) {
+  double acc[ORACLE_WINDOW];
+  uint8_t matched[ORACLE_WINDOW];
+  int64_t* cursor = (int64_t*)calloc((size_t)(n_terms > 0 ? n_terms : 1), sizeof(int64_t));
+  nrt_oracle_collector_set_leaf(collector, doc_base);
+
+  for (int32_t base = 0; base < max_doc; base += ORACLE_WINDOW) {
+    int32_t end = base + ORACLE_WINDOW;
+    if (end > max_doc) end = max_doc;
+    int any = 0;
+    for (int t = 0; t < n_terms; ++t) {
+      const nrt_oracle_term* tm = &terms[t];
+      int64_t p = cursor[t];
+      if (p < tm->n && tm->docids[p] < end) {
+        if (!any) {
+          memset(acc, 0, sizeof(double) * (size_t)(end - base));
+          memset(matched, 0, (size_t)(end - base));
+          any = 1;
+        }
+        for (; p < tm->n && tm->docids[p] < end; ++p) {
+          int32_t d = tm->docids[p];
+          float freq = tm->freqs ? (float)tm->freqs[p] : 1.0f;
+          uint8_t norm = tm->norms ? tm->norms[d] : (uint8_t)1;
+          float s = nrt_oracle_bm25_score(tm->weight, freq, tm->cache[norm]);
+          acc[d - base] += (double)s;
+          matched[d - base] = 1;
+        }
+        cursor[t] = p;
+      }
+    }
+    if (!any) continue;
+    for (int32_t d = base; d < end; ++d) {
+      if (!matched[d - base]) continue;
+      if (live_bits && !((live_bits[d >> 6] >> (d & 63)) & 1ULL)) continue;
+      nrt_oracle_collector_collect(collector, d, (float)acc[d - base]);
+    }
+  }
+  free(cursor);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * TopDocs.merge(0, topN, shardHits) with every shardIndex == -1 (…Manager.java:137-144).
+ * Lucene's merge pops a priority queue ordered by (score desc, shardIndex, doc asc); with equal
+ * shardIndex that is a stable global (score desc, doc asc) order, produced here by sorting.
+ * ------------------------------------------------------------------------------------------ */
+static int cmp_hit_desc(const void* pa, const void* pb) {
+  const hit_t* a = (const hit_t*)pa;
+  const hit_t* b = (const hit_t*)pb;
+  if (a->score > b->score) return -1;
+  if (a->score < b->score) return 1;
+  return (a->doc > b->doc) - (a->doc < b->doc);
+}
+
+int32_t nrt_oracle_topdocs_merge(int32_t top_n, int32_t n_lists, const int32_t* lens,
+                                 const int32_t* docs, const float* scores,
+                                 int32_t* out_docs, float* out_scores) {
+  int64_t total = 0;
+  for (int i = 0; i < n_lists; ++i) total += lens[i];
+  hit_t* all = (hit_t*)malloc(sizeof(hit_t) * (size_t)(total > 0 ? total : 1));
+  for (int64_t i = 0; i < total; ++i) {
+    all[i].doc = docs[i];
+    all[i].score = scores[i];
+  }
+  qsort(all, (size_t)total, sizeof(hit_t), cmp_hit_desc);
+  int32_t n = (int32_t)(total < top_n ? total : top_n);
+  for (int32_t i = 0; i < n; ++i) {
+    out_docs[i] = all[i].doc;
+    out_scores[i] = all[i].score;
+  }
+  free(all);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Vector similarity -> score.  Mapping table: src/main/java/com/yelp/nrtsearch/server/field/
+ * VectorFieldDef.java:77-88; formulas documented by the reference at docs/field_types/
+ * vector.rst:26-35 and mirrored by similarityToScore (VectorFieldDef.java:664-673).
+ * Lucene's VectorUtil accumulates in float in a JVM-dependent (scalar / Panama) order, so this
+ * scalar left-to-right float sum is one member of the tolerance class, not a
+ * bit-exact spec.
+ * ------------------------------------------------------------------------------------------ */
+float nrt_oracle_vector_score(int32_t sim, const float* q, const float* v, int32_t dim) {
+  if (sim == 2) { /* EUCLIDEAN: 1 / (1 + squareDistance) */
+    float d2 = 0.0f;
+    for (int i = 0; i < dim; ++i) {
+      volatile float diff = q[i] - v[i];
+      volatile float sq = diff * diff;
+      d2 = d2 + sq;
+    }
+    return 1.0f / (1.0f + d2);
+  }
+  float dot = 0.0f, nq = 0.0f, nv = 0.0f;
+  for (int i = 0; i < dim; ++i) {
+    volatile float p = q[i] * v[i];
+    dot = dot + p;
+    if (sim == 0) {
+      volatile float a = q[i] * q[i];
+      volatile float b = v[i] * v[i];
+      nq = nq + a;
+      nv = nv + b;
+    }
+  }
+  if (sim == 0) { /* COSINE: max((1 + cos) / 2, 0), cos = (float)(sum / sqrt((double)n1 * n2)) */
+    float c = (float)((double)dot / sqrt((double)nq * (double)nv));
+    float s = (1.0f + c) / 2.0f;
+    return s > 0.0f ? s : 0.0f;
+  }
+  if (sim == 1) { /* DOT_PRODUCT: max((1 + dot) / 2, 0) */
+    float s = (1.0f + dot) / 2.0f;
+    return s > 0.0f ? s : 0.0f;
+  }
+  /* MAXIMUM_INNER_PRODUCT: dot < 0 ? 1 / (1 - dot) : dot + 1 */
+  if (dot < 0.0f) return 1.0f / (1.0f - dot);
+  return dot + 1.0f;
+}
+
+/* QueryRescore.combine, src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-45 */
+float nrt_oracle_rescore_combine(float first_pass, int32_t matched, float second_pass,
+                                 double query_weight, double rescore_weight) {
+  if (!matched) return (float)(query_weight * (double)first_pass);
+  return (float)(query_weight * (double)first_pass + rescore_weight * (double)second_pass);
+}

@@ -1,0 +1,95 @@
+/*
+ * nrt_oracle.h -- CPU restatement of the nrtsearch / Lucene 10.4 query-execution hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under nrtsearch_amd/ may include, link or dlopen this.
+ * Allowed users: tests/, __graft_entry__.smoke(), and bench.py's cpu_baseline leg (as the
+ * checker / reported baseline, never as the thing shipped).
+ *
+ * Parity status: the scalar arithmetic (SmallFloat, idf, avgdl, norm cache, BM25 score) is
+ * PINNED against the reference's own golden values (tests/test_oracle_golden.py; SURVEY.md
+ * section 8c).  Multi-term double-accumulated sums, norm quantisation for long fields and kNN at
+ * d=768 are "parity unpinned": the reference holds no golden vector for them and Lucene 10.4.0
+ * itself (un-vendored Maven dependency, gradle/libs.versions.toml:7) cannot be run here.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) or, for logic that
+ * lives only inside lucene-core 10.4.0, the published Lucene class it restates.
+ */
+#ifndef NRT_ORACLE_H
+#define NRT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- SmallFloat (org.apache.lucene.util.SmallFloat, Lucene 10.4.0) ---- */
+int32_t nrt_oracle_int_to_byte4(int32_t i);   /* returns 0..255 */
+int32_t nrt_oracle_byte4_to_int(int32_t b);   /* b in 0..255 */
+
+/* ---- BM25Similarity (default instance: src/main/java/com/yelp/nrtsearch/server/similarity/
+ *      SimilarityCreator.java:33,41; k1 = 1.2f, b = 0.75f, discountOverlaps = true) ---- */
+float nrt_oracle_bm25_idf(int64_t doc_count, int64_t doc_freq);
+float nrt_oracle_bm25_avgdl(int64_t sum_total_term_freq, int64_t doc_count);
+void  nrt_oracle_bm25_norm_cache(float avgdl, float k1, float b, float out256[256]);
+float nrt_oracle_bm25_score(float weight, float freq, float norm_inverse);
+
+/* ---- top-k collector: restates src/main/java/org/apache/lucene/search/
+ *      LazyQueueTopScoreDocCollector.java:37-203 (== Lucene TopScoreDocCollector) ---- */
+typedef struct nrt_oracle_collector nrt_oracle_collector;
+
+nrt_oracle_collector* nrt_oracle_collector_new(int32_t num_hits, int32_t has_after, int32_t after_doc,
+                                               float after_score, int32_t total_hits_threshold);
+void nrt_oracle_collector_free(nrt_oracle_collector*);
+/* getLeafCollector(ctx): rebases `after` to the leaf (…Collector.java:73-84) */
+void nrt_oracle_collector_set_leaf(nrt_oracle_collector*, int32_t doc_base);
+/* LeafCollector.collect(doc) with scorer.score() == score (…Collector.java:103-144) */
+void nrt_oracle_collector_collect(nrt_oracle_collector*, int32_t leaf_doc, float score);
+/* TopDocsCollector.topDocs(): pops the queue into (score desc, doc asc). returns n_hits. */
+int32_t nrt_oracle_collector_topdocs(nrt_oracle_collector*, int32_t* docs, float* scores,
+                                     int64_t* total_hits, int32_t* total_hits_is_lower_bound);
+
+/* ---- one term's postings inside one segment, as the reference sees them through
+ *      PostingsEnum (docid ascending, freq) + NumericDocValues norms ---- */
+typedef struct {
+  const int32_t* docids;   /* ascending */
+  const int32_t* freqs;    /* NULL => freq == 1 (DOCS-only field, AtomFieldDef.java:123-126) */
+  int64_t        n;
+  float          weight;   /* boost * idf  (BM25Similarity.scorer) */
+  const uint8_t* norms;    /* max_doc bytes, NULL => norm value 1 (norms omitted) */
+  const float*   cache;    /* 256 floats: normInverse table for this field */
+} nrt_oracle_term;
+
+/*
+ * Exhaustive disjunction (pure SHOULD, minShouldMatch <= 1) over one segment, scored exactly as
+ * Lucene does: per (term, doc) float BM25 score, per doc the sum over matching terms accumulated
+ * in double then cast to float (MaxScoreBulkScorer / BooleanScorer / WANDScorer all do this; a
+ * single TermQuery returns the float itself, which the same cast reproduces), docs delivered to
+ * the collector in ascending docid order, deleted docs (live_bits) never delivered.
+ * Implemented as windowed term-at-a-time over 4096-doc windows (the shape of Lucene's
+ * MaxScoreBulkScorer inner window), so it is also a reasonable CPU baseline.
+ */
+void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                               int32_t n_terms, const nrt_oracle_term* terms,
+                               nrt_oracle_collector* collector);
+
+/* TopDocs.merge(0, topN, shardHits[]) with all shardIndex == -1: order (score desc, doc asc)
+ * (LazyQueueTopScoreDocCollectorManager.java:137-144).  Lists are concatenated in `docs/scores`
+ * with lengths `lens[n_lists]`.  Returns number of merged hits written. */
+int32_t nrt_oracle_topdocs_merge(int32_t top_n, int32_t n_lists, const int32_t* lens,
+                                 const int32_t* docs, const float* scores,
+                                 int32_t* out_docs, float* out_scores);
+
+/* ---- exact vector scoring (ExactVectorQuery.java:137-173 + VectorSimilarityFunction) ----
+ * sim: 0 cosine, 1 dot_product, 2 l2_norm (euclidean), 3 max_inner_product. */
+float nrt_oracle_vector_score(int32_t sim, const float* q, const float* v, int32_t dim);
+
+/* QueryRescorer.combine as overridden by QueryRescore.java:40-45:
+ * (float)(queryWeight * firstPass + rescoreWeight * secondPass), double arithmetic. */
+float nrt_oracle_rescore_combine(float first_pass, int32_t matched, float second_pass,
+                                 double query_weight, double rescore_weight);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

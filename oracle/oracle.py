@@ -1,0 +1,209 @@
+"""ctypes front-end of the CPU oracle (oracle/nrt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package nrtsearch_amd never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnrt_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "nrt_oracle.c")
+    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+class _Term(C.Structure):
+    _fields_ = [
+        ("docids", C.c_void_p),
+        ("freqs", C.c_void_p),
+        ("n", C.c_int64),
+        ("weight", C.c_float),
+        ("norms", C.c_void_p),
+        ("cache", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.nrt_oracle_int_to_byte4.restype = C.c_int32
+        L.nrt_oracle_int_to_byte4.argtypes = [C.c_int32]
+        L.nrt_oracle_byte4_to_int.restype = C.c_int32
+        L.nrt_oracle_byte4_to_int.argtypes = [C.c_int32]
+        L.nrt_oracle_bm25_idf.restype = C.c_float
+        L.nrt_oracle_bm25_idf.argtypes = [C.c_int64, C.c_int64]
+        L.nrt_oracle_bm25_avgdl.restype = C.c_float
+        L.nrt_oracle_bm25_avgdl.argtypes = [C.c_int64, C.c_int64]
+        L.nrt_oracle_bm25_norm_cache.restype = None
+        L.nrt_oracle_bm25_norm_cache.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.nrt_oracle_bm25_score.restype = C.c_float
+        L.nrt_oracle_bm25_score.argtypes = [C.c_float, C.c_float, C.c_float]
+        L.nrt_oracle_collector_new.restype = C.c_void_p
+        L.nrt_oracle_collector_new.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32]
+        L.nrt_oracle_collector_free.restype = None
+        L.nrt_oracle_collector_free.argtypes = [C.c_void_p]
+        L.nrt_oracle_collector_set_leaf.restype = None
+        L.nrt_oracle_collector_set_leaf.argtypes = [C.c_void_p, C.c_int32]
+        L.nrt_oracle_collector_collect.restype = None
+        L.nrt_oracle_collector_collect.argtypes = [C.c_void_p, C.c_int32, C.c_float]
+        L.nrt_oracle_collector_topdocs.restype = C.c_int32
+        L.nrt_oracle_collector_topdocs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nrt_oracle_search_segment.restype = None
+        L.nrt_oracle_search_segment.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.nrt_oracle_topdocs_merge.restype = C.c_int32
+        L.nrt_oracle_topdocs_merge.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nrt_oracle_vector_score.restype = C.c_float
+        L.nrt_oracle_vector_score.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.nrt_oracle_rescore_combine.restype = C.c_float
+        L.nrt_oracle_rescore_combine.argtypes = [C.c_float, C.c_int32, C.c_float, C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+# ---- scalar helpers ---------------------------------------------------------------------------
+def int_to_byte4(i: int) -> int:
+    return lib().nrt_oracle_int_to_byte4(int(i))
+
+
+def byte4_to_int(b: int) -> int:
+    return lib().nrt_oracle_byte4_to_int(int(b))
+
+
+def bm25_idf(doc_count: int, doc_freq: int) -> np.float32:
+    return np.float32(lib().nrt_oracle_bm25_idf(int(doc_count), int(doc_freq)))
+
+
+def bm25_avgdl(sum_ttf: int, doc_count: int) -> np.float32:
+    return np.float32(lib().nrt_oracle_bm25_avgdl(int(sum_ttf), int(doc_count)))
+
+
+def bm25_norm_cache(avgdl: float, k1: float = 1.2, b: float = 0.75) -> np.ndarray:
+    out = np.zeros(256, dtype=np.float32)
+    lib().nrt_oracle_bm25_norm_cache(C.c_float(avgdl), C.c_float(k1), C.c_float(b), out.ctypes.data)
+    return out
+
+
+def bm25_score(weight: float, freq: float, norm_inverse: float) -> np.float32:
+    return np.float32(lib().nrt_oracle_bm25_score(C.c_float(weight), C.c_float(freq), C.c_float(norm_inverse)))
+
+
+def vector_score(sim: int, q: np.ndarray, v: np.ndarray) -> np.float32:
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    return np.float32(lib().nrt_oracle_vector_score(int(sim), q.ctypes.data, v.ctypes.data, int(q.shape[0])))
+
+
+def rescore_combine(first: float, matched: bool, second: float, qw: float, rw: float) -> np.float32:
+    return np.float32(lib().nrt_oracle_rescore_combine(C.c_float(first), int(matched), C.c_float(second), qw, rw))
+
+
+# ---- collector --------------------------------------------------------------------------------
+class Collector:
+    """LazyQueueTopScoreDocCollector(numHits, after, totalHitsThreshold) driven one doc at a time."""
+
+    def __init__(self, num_hits: int, after: Optional[Tuple[int, float]] = None, total_hits_threshold: int = 1000):
+        self.num_hits = num_hits
+        has_after = after is not None
+        self._h = lib().nrt_oracle_collector_new(
+            num_hits, int(has_after), int(after[0]) if has_after else 0,
+            C.c_float(after[1] if has_after else 0.0), int(total_hits_threshold))
+        if not self._h:
+            raise ValueError("numHits must be > 0 and totalHitsThreshold >= 0")
+
+    def set_leaf(self, doc_base: int) -> None:
+        lib().nrt_oracle_collector_set_leaf(self._h, int(doc_base))
+
+    def collect(self, leaf_doc: int, score: float) -> None:
+        lib().nrt_oracle_collector_collect(self._h, int(leaf_doc), C.c_float(score))
+
+    def topdocs(self):
+        docs = np.zeros(self.num_hits, dtype=np.int32)
+        scores = np.zeros(self.num_hits, dtype=np.float32)
+        total = C.c_int64(0)
+        gte = C.c_int32(0)
+        n = lib().nrt_oracle_collector_topdocs(self._h, docs.ctypes.data, scores.ctypes.data, C.byref(total), C.byref(gte))
+        return docs[:n].copy(), scores[:n].copy(), int(total.value), bool(gte.value)
+
+    def close(self) -> None:
+        if self._h:
+            lib().nrt_oracle_collector_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def topdocs_merge(top_n: int, lists: Sequence[Tuple[np.ndarray, np.ndarray]]):
+    lens = np.asarray([len(d) for d, _ in lists], dtype=np.int32)
+    docs = np.concatenate([np.asarray(d, np.int32) for d, _ in lists]) if lists else np.zeros(0, np.int32)
+    scores = np.concatenate([np.asarray(s, np.float32) for _, s in lists]) if lists else np.zeros(0, np.float32)
+    od = np.zeros(max(top_n, 1), np.int32)
+    os_ = np.zeros(max(top_n, 1), np.float32)
+    n = lib().nrt_oracle_topdocs_merge(int(top_n), len(lists), lens.ctypes.data, docs.ctypes.data, scores.ctypes.data,
+                                       od.ctypes.data, os_.ctypes.data)
+    return od[:n].copy(), os_[:n].copy()
+
+
+# ---- whole-index search (single collector over all leaves == one Lucene slice) -----------------
+def bm25_query_stats(corpus, term_ids: Sequence[int], boosts: Optional[Sequence[float]] = None,
+                     k1: float = 1.2, b: float = 0.75):
+    """Index-global CollectionStatistics/TermStatistics -> (weights float32[n], cache float32[256])."""
+    avgdl = bm25_avgdl(corpus.sum_total_term_freq, corpus.doc_count)
+    cache = bm25_norm_cache(float(avgdl), k1, b)
+    weights = np.zeros(len(term_ids), dtype=np.float32)
+    for i, t in enumerate(term_ids):
+        df = corpus.doc_freq.get(int(t), 0)
+        idf = bm25_idf(corpus.doc_count, max(df, 0)) if df > 0 else np.float32(0.0)
+        boost = np.float32(1.0 if boosts is None else boosts[i])
+        weights[i] = np.float32(boost * idf)
+    return weights, cache
+
+
+def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequence[float]] = None,
+                after: Optional[Tuple[int, float]] = None, total_hits_threshold: int = 1000,
+                segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False):
+    """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr))
+    executed as ONE slice (one collector visiting the leaves in docBase order)."""
+    weights, cache = bm25_query_stats(corpus, term_ids, boosts)
+    col = Collector(k, after, total_hits_threshold)
+    seg_ids = range(len(corpus.segments)) if segments is None else segments
+    keep = []
+    for si in seg_ids:
+        seg = corpus.segments[si]
+        arr = (_Term * max(len(term_ids), 1))()
+        n_present = 0
+        for i, t in enumerate(term_ids):
+            d, f = seg.postings(int(t))
+            if len(d) == 0:
+                continue
+            d = np.ascontiguousarray(d, dtype=np.int32)
+            f = np.ascontiguousarray(f, dtype=np.int32)
+            keep.append((d, f))
+            arr[n_present].docids = d.ctypes.data
+            arr[n_present].freqs = None if omit_freqs else f.ctypes.data
+            arr[n_present].n = len(d)
+            arr[n_present].weight = float(weights[i])
+            arr[n_present].norms = None if omit_norms else seg.norms.ctypes.data
+            arr[n_present].cache = cache.ctypes.data
+            n_present += 1
+        live = seg.live_bits.ctypes.data if seg.live_bits is not None else None
+        lib().nrt_oracle_search_segment(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr), col._h)
+    res = col.topdocs()
+    col.close()
+    return res

@@ -1,0 +1,225 @@
+"""Pins the CPU oracle against every golden value the reference's own tests hold for the hot path
+(SURVEY.md section 8c).  All paths below are relative to /root/reference."""
+import numpy as np
+import pytest
+
+f32 = np.float32
+
+
+# ---- SmallFloat (Lucene-recall values re-derived in SURVEY Appendix A.1) -----------------------
+def test_smallfloat_known_values(oracle):
+    assert oracle.int_to_byte4(23) == 23 and oracle.byte4_to_int(23) == 23      # NUM_FREE_VALUES = 24
+    assert oracle.int_to_byte4(24) == 24 and oracle.byte4_to_int(24) == 24
+    for length, byte, decoded in [(100, 57, 96), (1000, 87, 984), (100000, 140, 98328)]:
+        assert oracle.int_to_byte4(length) == byte
+        assert oracle.byte4_to_int(byte) == decoded
+    assert oracle.byte4_to_int(255) == 2013265944
+    assert oracle.int_to_byte4(2147483647) == 255
+
+
+def test_smallfloat_roundtrip_monotone(oracle):
+    prev = -1
+    for b in range(256):
+        v = oracle.byte4_to_int(b)
+        assert v > prev                      # strictly increasing decode table (LENGTH_TABLE)
+        assert oracle.int_to_byte4(v) == b   # decode then encode is the identity
+        prev = v
+    # encoding rounds down: every length maps to the largest representable value <= length
+    for length in list(range(0, 3000)) + [4000, 65535, 10**6, 10**9]:
+        b = oracle.int_to_byte4(length)
+        assert oracle.byte4_to_int(b) <= length
+        if b < 255:
+            assert oracle.byte4_to_int(b + 1) > length
+
+
+def test_vectorised_int_to_byte4_matches_scalar(oracle):
+    from nrtsearch_amd.synth import int_to_byte4
+
+    lens = np.concatenate([np.arange(0, 5000), [2**k + d for k in range(3, 31) for d in (-1, 0, 1)]])
+    got = int_to_byte4(lens)
+    exp = np.array([oracle.int_to_byte4(int(v)) for v in lens], dtype=np.uint8)
+    assert np.array_equal(got, exp)
+
+
+# ---- src/test/java/com/yelp/nrtsearch/server/grpc/SearchStateTest.java:43-63,117 ---------------
+def test_search_state_last_score(oracle):
+    # docs: "first vendor" (dl 2), "second vendor review" (dl 3); TermQuery vendor_name:vendor
+    N, n = 2, 2
+    idf = oracle.bm25_idf(N, n)
+    avgdl = oracle.bm25_avgdl(2 + 3, N)
+    assert avgdl == f32(2.5)
+    cache = oracle.bm25_norm_cache(avgdl)
+    s0 = oracle.bm25_score(idf, 1.0, cache[oracle.int_to_byte4(2)])
+    s1 = oracle.bm25_score(idf, 1.0, cache[oracle.int_to_byte4(3)])
+    assert s0 > s1                                  # lastDocId == 1: the longer doc ranks last
+    assert abs(float(s1) - 0.0766057) <= 1e-7       # assertEquals(0.0766057, lastScore, 1e-7)
+    assert s1 == f32(0.0766057)                     # and it is that float exactly
+
+
+# ---- src/test/java/com/yelp/nrtsearch/server/grpc/QueryTest.java:1003-1019 (explain tree) ------
+def test_query_explain_tree(oracle):
+    idf1 = oracle.bm25_idf(2, 1)
+    idf2 = oracle.bm25_idf(2, 2)
+    assert idf1 == f32(0.6931472)
+    assert idf2 == f32(0.18232156)
+    weight = f32(idf1 + idf2)                       # phrase weight = sum of idfs (float)
+    assert weight == f32(0.87546873)
+    avgdl = oracle.bm25_avgdl(8, 2)                 # dl = avgdl = 4
+    cache = oracle.bm25_norm_cache(avgdl)
+    ninv = cache[oracle.int_to_byte4(4)]
+    # explain's tf = freq / (freq + k1 * (1 - b + b * dl / avgdl)) in float
+    k1, b = f32(1.2), f32(0.75)
+    tf = f32(1.0) / (f32(1.0) + k1 * ((f32(1) - b) + b * f32(4.0) / f32(4.0)))
+    assert f32(tf) == f32(0.45454544)
+    score = oracle.bm25_score(weight, 1.0, ninv)
+    assert score == f32(0.3979403)
+
+
+# ---- src/test/java/com/yelp/nrtsearch/server/similarity/SimilarityTest.java:115-135 ------------
+def test_similarity_test_scores(oracle):
+    # vendor_name docs: ["first vendor","first again"] and ["second vendor","second again"], dl = 4
+    avgdl = oracle.bm25_avgdl(8, 2)
+    cache = oracle.bm25_norm_cache(avgdl)
+    ninv = cache[oracle.int_to_byte4(4)]
+    vendor = oracle.bm25_score(oracle.bm25_idf(2, 2), 1.0, ninv)    # both docs
+    first = oracle.bm25_score(oracle.bm25_idf(2, 1), 2.0, ninv)     # doc1 only, freq 2
+    assert abs(float(vendor) - 0.0828734) < 1e-7
+    # doc2 = custom 11.11 + classic 0.5 + BM25(vendor); doc1 adds BM25(first); sums in double
+    doc2 = f32(float(f32(11.11)) + 0.5 + float(vendor))
+    doc1 = f32(float(f32(11.11)) + float(f32(0.5)) + float(vendor) + float(first))
+    assert abs(float(doc2) - 11.692873) <= 1e-4
+    # testDefaultSimilarity hit 0: the classic "first" clause is absent for field vendor_name;
+    # 12.12609 = 11.11 + 0.5 + 0.0828734 + 0.433217
+    assert abs(float(doc1) - 12.12609) <= 1e-4
+
+
+# ---- docker-compose fixture: config C1 known answer -------------------------------
+def test_docker_compose_known_answer(oracle):
+    # vendor_name: "first vendor", "second vendor"; N=2, dl=2, avgdl=2
+    avgdl = oracle.bm25_avgdl(4, 2)
+    cache = oracle.bm25_norm_cache(avgdl)
+    ninv = cache[oracle.int_to_byte4(2)]
+    assert ninv == f32(f32(1.0) / f32(1.2))
+    s_first = oracle.bm25_score(oracle.bm25_idf(2, 1), 1.0, ninv)
+    s_vendor = oracle.bm25_score(oracle.bm25_idf(2, 2), 1.0, ninv)
+    assert abs(float(s_first) - 0.3150669) < 1e-7
+    assert abs(float(s_vendor) - 0.0828734) < 1e-7
+    doc0 = f32(float(s_first) + float(s_vendor))
+    assert abs(float(doc0) - 0.3979403) < 1e-7
+
+
+# ---- src/test/java/com/yelp/nrtsearch/server/script/ScoreScriptTest.java:456-460 ---------------
+def test_score_script_test_values(oracle):
+    avgdl = oracle.bm25_avgdl(8, 2)
+    cache = oracle.bm25_norm_cache(avgdl)
+    ninv = cache[oracle.int_to_byte4(4)]
+    both = float(oracle.bm25_score(oracle.bm25_idf(2, 2), 1.0, ninv)) + float(oracle.bm25_score(oracle.bm25_idf(2, 1), 2.0, ninv))
+    assert abs(both - 0.516) <= 1e-3
+    assert abs(float(oracle.bm25_score(oracle.bm25_idf(2, 2), 1.0, ninv)) - 0.0828) <= 1e-3
+
+
+# ---- src/test/java/com/yelp/nrtsearch/server/grpc/QueryTest.java:398-441 (QueryRescorer) -------
+def test_query_rescore_combine(oracle):
+    assert oracle.rescore_combine(5.0, True, 10.0, 1.0, 4.0) == f32(45.0)
+    assert oracle.rescore_combine(5.0, False, 10.0, 1.0, 4.0) == f32(5.0)
+
+
+# ---- collector semantics: src/main/java/org/apache/lucene/search/LazyQueueTopScoreDocCollector.java
+def test_collector_ties_prefer_lower_doc(oracle):
+    # TotalHitsThresholdTest.java:43-51,72-99: equal scores => ascending docid, EQUAL_TO with 3 hits
+    c = oracle.Collector(2, None, 1000)
+    for d in range(3):
+        c.collect(d, 1.0)
+    docs, scores, total, gte = c.topdocs()
+    assert docs.tolist() == [0, 1] and total == 3 and not gte
+
+
+def test_collector_threshold_relation(oracle):
+    c = oracle.Collector(2, None, 2)            # threshold = max(2, numHits)
+    for d in range(5):
+        c.collect(d, float(d))
+    docs, scores, total, gte = c.topdocs()
+    assert docs.tolist() == [4, 3] and total == 5 and gte
+    c = oracle.Collector(2, None, 2**31 - 1)    # COMPLETE mode: exact
+    for d in range(5):
+        c.collect(d, float(d))
+    assert c.topdocs()[2:] == (5, False)
+
+
+def test_collector_search_after(oracle):
+    # RelevanceCollectorITest.java:117-190: paging by `after` yields no duplicate and no gap
+    rng = np.random.default_rng(5)
+    scores = rng.integers(0, 6, size=200).astype(np.float32)  # many ties
+    def page(after):
+        c = oracle.Collector(7, after, 1000)
+        for d, s in enumerate(scores):
+            c.collect(d, float(s))
+        return c.topdocs()
+    seen = []
+    after = None
+    while True:
+        docs, sc, total, _ = page(after)
+        assert total == 200
+        if len(docs) == 0:
+            break
+        seen += list(zip(sc.tolist(), docs.tolist()))
+        after = (int(docs[-1]), float(sc[-1]))
+    expect = sorted([(float(s), d) for d, s in enumerate(scores)], key=lambda t: (-t[0], t[1]))
+    assert seen == expect
+
+
+def test_collector_argument_checks(oracle):
+    # LazyQueueTopScoreDocCollectorManager.java:90-98
+    with pytest.raises(ValueError):
+        oracle.Collector(0, None, 10)
+    with pytest.raises(ValueError):
+        oracle.Collector(5, None, -1)
+
+
+def test_topdocs_merge_order(oracle):
+    a = (np.array([10, 3], np.int32), np.array([2.0, 1.0], np.float32))
+    b = (np.array([7, 1], np.int32), np.array([2.0, 1.0], np.float32))
+    d, s = oracle.topdocs_merge(3, [a, b])
+    assert d.tolist() == [7, 10, 1] and s.tolist() == [2.0, 2.0, 1.0]
+
+
+# ---- vector similarity maps: docs/field_types/vector.rst:26-35; VectorFieldDef.java:664-673 -----
+def test_vector_score_maps(oracle):
+    q = np.array([1.0, 0.0, 0.0], np.float32)
+    v = np.array([0.0, 1.0, 0.0], np.float32)
+    assert oracle.vector_score(0, q, v) == f32(0.5)        # cosine 0 -> (1+0)/2
+    assert oracle.vector_score(0, q, q) == f32(1.0)
+    assert oracle.vector_score(0, q, -q) == f32(0.0)
+    assert oracle.vector_score(1, q, q) == f32(1.0)        # dot of unit vectors
+    assert oracle.vector_score(2, q, v) == f32(1.0 / 3.0)  # 1/(1+2)
+    assert oracle.vector_score(3, q, -2 * q) == f32(1.0 / 3.0)   # mip: dot=-2 -> 1/(1+2)
+    assert oracle.vector_score(3, q, 2 * q) == f32(3.0)          # mip: dot=2 -> 3
+
+
+def test_segment_search_matches_bruteforce(oracle):
+    from nrtsearch_amd import synth
+
+    corpus = synth.build_corpus(20000, [1, 2, 7, 40, 300], n_segments=3, delete_fraction=0.05)
+    terms = [1, 7, 300]
+    docs, scores, total, gte = oracle.search_bm25(corpus, terms, 50, total_hits_threshold=2**31 - 1)
+    # brute force in numpy with float32 ops + float64 sums
+    w, cache = oracle.bm25_query_stats(corpus, terms)
+    allhits = []
+    for seg in corpus.segments:
+        acc = np.zeros(seg.max_doc, np.float64)
+        m = np.zeros(seg.max_doc, bool)
+        for wi, t in zip(w, terms):
+            d, f = seg.postings(t)
+            ninv = cache[seg.norms[d]]
+            s = wi - wi / (f32(1.0) + f.astype(np.float32) * ninv)
+            assert s.dtype == np.float32
+            acc[d] += s.astype(np.float64)
+            m[d] = True
+        live = np.unpackbits(seg.live_bits.view(np.uint8), bitorder="little")[: seg.max_doc].astype(bool)
+        m &= live
+        idx = np.nonzero(m)[0]
+        allhits += [(float(f32(acc[i])), int(i) + seg.doc_base) for i in idx]
+    allhits.sort(key=lambda t: (-t[0], t[1]))
+    assert total == len(allhits) and not gte
+    assert docs.tolist() == [d for _, d in allhits[:50]]
+    assert scores.tolist() == [s for s, _ in allhits[:50]]
