@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec + p50 latency of the BM25 top-k hot path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches one rank per GPU with torch.distributed.run.  A *step* is one pass of the hot path
+over one batch of `--batch` synthetic queries (postings already resident in HBM): plan upload,
+postings-scan kernel, top-k merge kernel, results back on the host (N = 1) or RCCL all-gather of
+the per-GPU top-k + merge on every rank (N > 1).  Rank 0 prints ONE JSON line.
+
+Workload at N = 1 = BASELINE.json config C3 (10M docs, 5-term BM25 disjunction, top-1000); for
+N > 1 the same index is sharded by contiguous docid range over the ranks (strong scaling).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_POSTING = 8          # docid u32 + (freq|norm) u32: what the scan kernel must read
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="queries per step")
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "SMOKE"])
+    ap.add_argument("--docs", type=int, default=0, help="override the number of docs (debug)")
+    ap.add_argument("--target-items", type=int, default=0)
+    ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=192, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(corpus, query_ranks, k, n_queries):
+    """The CPU oracle (exhaustive windowed term-at-a-time, oracle/nrt_oracle.c) on the host cores:
+    a reported baseline next to the GPU number, not a target.  Bounded sample of the same queries."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle
+
+    oracle.build()
+    cores = os.cpu_count() or 1
+    sample = [query_ranks[i % len(query_ranks)].tolist() for i in range(n_queries)]
+    oracle.search_bm25(corpus, sample[0], k)  # warm the library / page in the postings
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:  # ctypes releases the GIL inside the C call
+        list(ex.map(lambda t: oracle.search_bm25(corpus, t, k), sample))
+    dt = time.perf_counter() - t0
+    return {"value": round(n_queries / dt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_queries} queries of the same query set, exhaustive windowed TAAT + heap "
+                      f"(oracle/nrt_oracle.c, no dynamic pruning; NOT JVM Lucene), {cores} threads, {dt:.1f}s"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+        args.gpus = world
+
+    import torch  # first: its bundled HIP runtime must be the one libnrtgpu.so binds to
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+
+    from nrtsearch_amd import _lib, api, build, synth, workload
+
+    build.build()
+    w = {"C2": workload.C2, "C3": workload.C3, "SMOKE": workload.SMOKE}[args.workload]
+    if args.docs:
+        w.n_docs = args.docs
+    B = args.batch
+    n_distinct = max(B, (w.n_queries // B) * B)
+    qranks = synth.make_queries(n_distinct, w.n_terms, w.max_rank)
+    t_build = time.perf_counter()
+    corpus = workload.build_shard_corpus(w, qranks, world, rank)
+    t_build = time.perf_counter() - t_build
+
+    flags = _lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0
+    ctx = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True, flags=flags)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    searcher = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    queries = workload.boolean_queries(qranks)
+    mgr = api.TopScoreDocCollectorManager(w.k)  # default totalHitsThreshold = 1000
+    batches = [api.PreparedBatch(searcher, queries[i: i + B], [mgr] * B) for i in range(0, n_distinct, B)]
+    ppq = workload.postings_per_query(corpus.doc_freq, qranks)   # index-global P per query
+
+    k_stride = (w.k + 15) // 16 * 16
+    if world > 1:
+        d_keys = torch.zeros((B, k_stride), dtype=torch.int64, device="cuda")
+        d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        d_hits = torch.zeros((B,), dtype=torch.int64, device="cuda")
+        g_keys = torch.zeros((world, B, k_stride), dtype=torch.int64, device="cuda")
+        g_cnt = torch.zeros((world, B), dtype=torch.int32, device="cuda")
+        g_hits = torch.zeros((world, B), dtype=torch.int64, device="cuda")
+        ks = [w.k] * B
+        thr = [api.TOTAL_HITS_THRESHOLD] * B
+
+    last = {}
+
+    def step(i):
+        pb = batches[i % len(batches)]
+        if world == 1:
+            pb.run()
+            last["td"] = pb
+        else:
+            pb.run_device(k_stride, d_keys.data_ptr(), d_cnt.data_ptr(), d_hits.data_ptr())
+            # final exchange of SURVEY 8e: RCCL all-gather of the per-GPU top-k over xGMI ...
+            dist.all_gather_into_tensor(g_keys, d_keys)
+            dist.all_gather_into_tensor(g_cnt, d_cnt)
+            dist.all_gather_into_tensor(g_hits, d_hits)
+            torch.cuda.synchronize()
+            # ... then TopDocs.merge on every rank
+            last["td"] = api.merge_topk_device(ctx, world, B, k_stride, g_keys.data_ptr(), g_cnt.data_ptr(),
+                                               g_hits.data_ptr(), ks, thr)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.reset_stats()
+    fence()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        step(args.warmup + i)
+        lat.append(time.perf_counter() - ts)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = ctx.stats()
+    n_q = args.steps * B
+    qps = n_q / elapsed
+    # dominant kernel: bm25_scan_kernel.  achieved = algorithmic bytes per launch / avg launch time,
+    # measured with HIP events on the library's own stream (collect_timing).
+    launches = max(1, st["scan_launches"])
+    scan_ms = st["scan_ms"] / launches
+    bytes_per_launch = st["scan_postings"] / launches * BYTES_PER_POSTING
+    achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("workload") == args.workload and rec.get("batch") == B and world == 1:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "queries/sec, 10M-doc 5-term BM25 top-1000" if args.workload == "C3" else f"queries/sec, {w.name}",
+        "value": round(qps, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "p50_latency_ms": round(statistics.median(lat) * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": w.name,
+            "n_docs": w.n_docs, "terms_per_query": w.n_terms, "k": w.k, "batch_queries": B,
+            "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
+            "segments_per_gpu": len(corpus.segments),
+            "sharding": "contiguous docid ranges, 1 process per GPU" + (", RCCL all-gather of per-GPU top-k + merge" if world > 1 else ""),
+            "mean_postings_per_query": float(ppq.mean()),
+            "scan_items_per_step": st["scan_items"] / max(1, st["batches"]),
+            "prefetch": not args.no_prefetch,
+            "corpus_build_s": round(t_build, 1),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "bm25_scan_kernel",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "bytes_per_posting": BYTES_PER_POSTING,
+            "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "avg_launch_ms": round(scan_ms, 4),
+            "merge_ms_per_step": round(st["merge_ms"] / max(1, st["batches"]), 4),
+            "host_plan_ms_per_step": round(st["host_plan_ms"] / max(1, st["batches"]), 4),
+            "traffic": traffic,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
+        out["cpu_baseline"] = cpu_baseline(corpus, qranks, w.k, args.cpu_queries)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+/*
+ * nrtgpu.h -- C ABI of the MI355X-native query-execution path for nrtsearch.
+ *
+ * This is the drop-in boundary: everything nrtsearch does below
+ *   searcher.search(query, collectorManager)
+ *     src/main/java/com/yelp/nrtsearch/server/handler/SearchHandler.java:1412-1413 (single query)
+ *     src/main/java/com/yelp/nrtsearch/server/handler/SearchHandler.java:556        (per retriever)
+ * for an eligible query (pure-SHOULD BooleanQuery of TermQuery clauses / single TermQuery under
+ * the default BM25Similarity, or an exact float vector query) is replaced by calls into this
+ * library.  The reference has no native boundary of its own (pure JVM); the JNI / FFM stub a
+ * maintainer adds on the Java side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns NRTGPU_OK (0) or a negative nrtgpu_status; nrtgpu_last_error()
+ *    returns a thread-local UTF-8 message for the last failure on the calling thread.
+ *  - thread-safety: any number of host threads may call the search / knn / rescore functions
+ *    concurrently on one ctx (SEARCH-pool threads, src/main/java/com/yelp/nrtsearch/server/
+ *    concurrent/ExecutorFactory.java:80-117).  Segment lifecycle calls for one nrtgpu_seg must not
+ *    race with each other; releasing a segment that a running search uses is undefined.
+ *  - ownership: input pointers are borrowed for the duration of the call; outputs are written
+ *    into caller-allocated arrays of the stated capacity.  No callbacks into the caller.
+ *  - plain C types only: no torch / HIP types cross this boundary.
+ *  - there is NO CPU fallback inside the library: with no usable gfx950 device nrtgpu_create
+ *    fails with NRTGPU_ERR_HIP; NRTGPU_ERR_UNSUPPORTED tells the caller to run its own
+ *    (Lucene) path for that query.
+ */
+#ifndef NRTGPU_H
+#define NRTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NRTGPU_OK = 0,
+  NRTGPU_ERR_INVALID_ARG = -1, /* IllegalArgumentException in the reference (e.g. numHits <= 0) */
+  NRTGPU_ERR_HIP = -2,         /* device / runtime failure -> IOException -> gRPC INTERNAL */
+  NRTGPU_ERR_OOM = -3,
+  NRTGPU_ERR_UNSUPPORTED = -4, /* shape not handled on device: caller falls back to Lucene */
+  NRTGPU_ERR_STATE = -5        /* lifecycle misuse (e.g. search on an unsealed segment) */
+} nrtgpu_status;
+
+typedef struct nrtgpu_ctx nrtgpu_ctx;
+typedef struct nrtgpu_seg nrtgpu_seg;
+
+/* Limits of the device fast path (queries outside them get NRTGPU_ERR_UNSUPPORTED). */
+#define NRTGPU_MAX_K 1024          /* numHits handled by the LDS top-k */
+#define NRTGPU_MAX_TERMS 32        /* SHOULD clauses per query */
+#define NRTGPU_TILE_DOCS 8192      /* docs per LDS accumulator tile */
+
+typedef struct {
+  int32_t device_id;        /* HIP device ordinal this ctx owns (one process per GPU) */
+  int32_t max_batch;        /* max queries per batch call; 0 => 1024 */
+  int32_t target_items;     /* work items (query x doc-range) aimed for per batch; 0 => auto */
+  int32_t collect_timing;   /* !=0: bracket the scan kernel with HIP events (nrtgpu_get_stats) */
+  int32_t flags;            /* NRTGPU_FLAG_* */
+  int32_t reserved;
+} nrtgpu_config;
+
+#define NRTGPU_FLAG_NO_PREFETCH 1  /* scan kernel without the one-tile-ahead posting prefetch (A/B) */
+
+const char* nrtgpu_version(void);
+const char* nrtgpu_last_error(void);
+
+int  nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out);
+void nrtgpu_destroy(nrtgpu_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * Segment store: a read-only columnar replica of one immutable Lucene segment's scoring data,
+ * filled through Lucene's public reader APIs at searcher-refresh / warm time
+ * (hook: ShardSearcherFactory.newSearcher, src/main/java/com/yelp/nrtsearch/server/index/
+ * ShardState.java:506-527; keyed by the segment core CacheKey on the Java side).
+ * --------------------------------------------------------------------------------------------- */
+int  nrtgpu_segment_begin(nrtgpu_ctx* ctx, int32_t max_doc, int32_t device_hint, nrtgpu_seg** out);
+/* norms of one field: leaf.getNormValues(field) as bytes (SmallFloat.intToByte4 of the field
+ * length); NULL => norms omitted, norm value 1 for every doc (AtomFieldDef.java:123-126). */
+int  nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id, const uint8_t* norm_bytes);
+/* postings of n_terms terms of one field: TermsEnum/PostingsEnum flattened column-major.
+ * term_hash identifies a term (any injective 64-bit id chosen by the caller); offsets has
+ * n_terms+1 entries into docids/freqs; docids ascending within a term; freqs NULL => all 1
+ * (IndexOptions.DOCS).  May be called several times per segment/field. */
+int  nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64_t n_terms, const int64_t* term_hash,
+                              const int64_t* offsets, const int32_t* docids, const int32_t* freqs);
+/* float vectors of one field (leaf.getFloatVectorValues): n rows of `dim` fp32, row-major;
+ * ord_to_doc NULL => ordinal == docid (dense). */
+int  nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int32_t dim, int32_t n,
+                                const int32_t* ord_to_doc, const float* row_major);
+/* builds the per-term doc-range tables; the segment becomes searchable */
+int  nrtgpu_segment_seal(nrtgpu_seg* seg);
+/* leaf.getLiveDocs() as 64-bit words, bit d set = doc d live; NULL => all live.  May be called
+ * again after seal (only liveDocs change between reader versions of one segment). */
+int  nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words);
+void nrtgpu_segment_release(nrtgpu_seg* seg);
+/* bytes of HBM held by the segment (diagnostics) */
+int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg);
+
+/* ---------------------------------------------------------------------------------------------
+ * BM25 disjunction search.  Replaces, for one IndexSearcher.search call: per-leaf
+ * Weight.scorerSupplier(ctx).bulkScorer().score(leafCollector, liveDocs, 0, maxDoc) (postings
+ * traversal + BM25Similarity SimScorer + double-accumulated disjunction sum), the
+ * TopScoreDocCollector / LazyQueueTopScoreDocCollector (src/main/java/org/apache/lucene/search/
+ * LazyQueueTopScoreDocCollector.java:103-199) and CollectorManager.reduce == TopDocs.merge
+ * (LazyQueueTopScoreDocCollectorManager.java:137-144).
+ * Index-global statistics stay on the host: the caller passes weight = boost * idf and the
+ * 256-entry normInverse cache of BM25Similarity.scorer() (helpers below compute both).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t field_id;
+  int32_t cache_slot;     /* which 256-float table of nrtgpu_bm25_query.norm_cache this term uses */
+  int64_t term_hash;
+  float   weight;         /* boost * idf, float (BM25Similarity.scorer) */
+  float   reserved;
+} nrtgpu_term;
+
+typedef struct {
+  int32_t n_terms;                 /* 1..NRTGPU_MAX_TERMS SHOULD clauses (duplicates allowed) */
+  const nrtgpu_term* terms;
+  int32_t n_caches;                /* number of 256-float tables in norm_cache (one per field) */
+  const float* norm_cache;         /* n_caches * 256 floats */
+  int32_t k;                       /* numHits, 1..NRTGPU_MAX_K  (DocCollector.java:79-114) */
+  int32_t total_hits_threshold;    /* >= 0; INT32_MAX => exact count (ScoreMode.COMPLETE) */
+  int32_t has_after;               /* searchAfter (LazyQueueTopScoreDocCollector.java:112-120) */
+  int32_t after_doc;               /* global docid of the last hit of the previous page */
+  float   after_score;
+  int32_t min_should_match;        /* 0 or 1 only */
+} nrtgpu_bm25_query;
+
+typedef struct {
+  int32_t  n_hits;                     /* out: hits written, <= k */
+  int32_t  capacity;                   /* in : capacity of docs/scores (>= k) */
+  int32_t* docs;                       /* out: global docids (doc_base + leaf doc) */
+  float*   scores;                     /* out: (score desc, doc asc) */
+  int64_t  total_hits;                 /* out: exact number of live matching docs */
+  int32_t  total_hits_is_lower_bound;  /* out: 1 == GREATER_THAN_OR_EQUAL_TO */
+} nrtgpu_topdocs;
+
+int  nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                        const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);
+/* n_queries independent searches over the same leaves in one device pass */
+int  nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                              const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out);
+
+/* Device-resident variant for the multi-GPU path (one process per GPU): results stay
+ * in HBM as packed keys so the caller can RCCL all-gather them without a host round trip.
+ *   d_keys  : n_queries * k_stride uint64 (device), key = (float_bits(score) << 32) | (0xFFFFFFFF - doc),
+ *             sorted descending == (score desc, doc asc); unused tail slots are 0
+ *   d_counts: n_queries uint32 (device) hits per query
+ *   d_hits  : n_queries uint64 (device) exact total hits per query
+ * Returns after the work is enqueued AND complete on the library's stream (synchronous). */
+int  nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                     int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits);
+/* TopDocs.merge of n_lists per-GPU results laid out as the all-gather leaves them:
+ * d_keys_in[list][query][k_stride], d_counts_in[list][query], d_hits_in[list][query] (device).
+ * Writes host-side topdocs (docs/scores/total_hits/relation) for each query. */
+int  nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride,
+                              const void* d_keys_in, const void* d_counts_in, const void* d_hits_in,
+                              const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-side restatements the Java shim would otherwise take from Lucene objects
+ * (BM25Similarity.scorer(boost, collectionStats, termStats); SmallFloat; slices()).
+ * --------------------------------------------------------------------------------------------- */
+int32_t nrtgpu_int_to_byte4(int32_t length);
+int32_t nrtgpu_byte4_to_int(int32_t norm_byte);
+float   nrtgpu_bm25_idf(int64_t doc_count, int64_t doc_freq);
+float   nrtgpu_bm25_avgdl(int64_t sum_total_term_freq, int64_t doc_count);
+void    nrtgpu_bm25_norm_cache(float avgdl, float k1, float b, float* out256);
+/* MyIndexSearcher.slices / slicesForShards (src/main/java/com/yelp/nrtsearch/server/search/
+ * MyIndexSearcher.java:79-208).  leaf i has max_docs[i] / num_docs[i] (live) docs and docBase
+ * doc_bases[i].  Writes slice_of_leaf[i] = slice index (slices ordered as the reference orders
+ * them) and returns the number of slices; with virtual_shards > 1 also writes shard_of_leaf[i]
+ * (may be NULL). */
+int32_t nrtgpu_slices(int32_t n_leaves, const int32_t* max_docs, const int32_t* num_docs, const int32_t* doc_bases,
+                      int32_t virtual_shards, int32_t slice_max_docs, int32_t slice_max_segments,
+                      int32_t* slice_of_leaf, int32_t* shard_of_leaf);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics (maps onto SearchResponse.Diagnostics / profile fields).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t batches;            /* batch calls completed */
+  int64_t queries;
+  int64_t scan_launches;      /* postings-scan kernel launches */
+  double  scan_ms;            /* sum of HIP-event durations of those launches (collect_timing) */
+  int64_t scan_postings;      /* sum over launches of postings in the scanned term ranges */
+  int64_t scan_items;
+  double  merge_ms;
+  double  host_plan_ms;       /* host time spent building launch plans */
+} nrtgpu_stats;
+int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
+void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRTGPU_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of libnrtgpu.so -- the same C ABI (include/nrtgpu.h) the Java JNI/FFM shim binds.
+
+Fails loudly: there is no Python / CPU implementation behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnrtgpu.so")
+
+NRTGPU_OK = 0
+NRTGPU_ERR_INVALID_ARG = -1
+NRTGPU_ERR_HIP = -2
+NRTGPU_ERR_OOM = -3
+NRTGPU_ERR_UNSUPPORTED = -4
+NRTGPU_ERR_STATE = -5
+NRTGPU_MAX_K = 1024
+NRTGPU_MAX_TERMS = 32
+NRTGPU_TILE_DOCS = 8192
+NRTGPU_FLAG_NO_PREFETCH = 1
+
+# every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
+ABI_SYMBOLS = [
+    "nrtgpu_version", "nrtgpu_last_error", "nrtgpu_create", "nrtgpu_destroy",
+    "nrtgpu_segment_begin", "nrtgpu_segment_add_field_norms", "nrtgpu_segment_add_terms",
+    "nrtgpu_segment_add_vectors", "nrtgpu_segment_seal", "nrtgpu_segment_set_live_docs",
+    "nrtgpu_segment_release", "nrtgpu_segment_device_bytes",
+    "nrtgpu_search_bm25", "nrtgpu_search_bm25_batch", "nrtgpu_search_bm25_batch_device",
+    "nrtgpu_merge_topk_device",
+    "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
+    "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_get_stats", "nrtgpu_reset_stats",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("max_batch", C.c_int32), ("target_items", C.c_int32),
+                ("collect_timing", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Term(C.Structure):
+    _fields_ = [("field_id", C.c_int32), ("cache_slot", C.c_int32), ("term_hash", C.c_int64),
+                ("weight", C.c_float), ("reserved", C.c_float)]
+
+
+class Bm25Query(C.Structure):
+    _fields_ = [("n_terms", C.c_int32), ("terms", C.POINTER(Term)), ("n_caches", C.c_int32),
+                ("norm_cache", C.POINTER(C.c_float)), ("k", C.c_int32), ("total_hits_threshold", C.c_int32),
+                ("has_after", C.c_int32), ("after_doc", C.c_int32), ("after_score", C.c_float),
+                ("min_should_match", C.c_int32)]
+
+
+class TopDocs(C.Structure):
+    _fields_ = [("n_hits", C.c_int32), ("capacity", C.c_int32), ("docs", C.POINTER(C.c_int32)),
+                ("scores", C.POINTER(C.c_float)), ("total_hits", C.c_int64),
+                ("total_hits_is_lower_bound", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("batches", C.c_int64), ("queries", C.c_int64), ("scan_launches", C.c_int64),
+                ("scan_ms", C.c_double), ("scan_postings", C.c_int64), ("scan_items", C.c_int64),
+                ("merge_ms", C.c_double), ("host_plan_ms", C.c_double)]
+
+
+class NrtGpuError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"nrtgpu error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library; raises if it has not been built (python -m nrtsearch_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m nrtsearch_amd.build` "
+            "(hipcc, gfx950). There is no Python/CPU fallback for the query path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.nrtgpu_version.restype = C.c_char_p
+    L.nrtgpu_last_error.restype = C.c_char_p
+    L.nrtgpu_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.nrtgpu_destroy.argtypes = [vp]
+    L.nrtgpu_destroy.restype = None
+    L.nrtgpu_segment_begin.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.nrtgpu_segment_add_field_norms.argtypes = [vp, i32, vp]
+    L.nrtgpu_segment_add_terms.argtypes = [vp, i32, i64, vp, vp, vp, vp]
+    L.nrtgpu_segment_add_vectors.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.nrtgpu_segment_seal.argtypes = [vp]
+    L.nrtgpu_segment_set_live_docs.argtypes = [vp, vp, i32]
+    L.nrtgpu_segment_release.argtypes = [vp]
+    L.nrtgpu_segment_release.restype = None
+    L.nrtgpu_segment_device_bytes.argtypes = [vp]
+    L.nrtgpu_segment_device_bytes.restype = i64
+    L.nrtgpu_search_bm25.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), C.POINTER(TopDocs)]
+    L.nrtgpu_search_bm25_batch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, C.POINTER(TopDocs)]
+    L.nrtgpu_search_bm25_batch_device.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, vp, vp, vp]
+    L.nrtgpu_merge_topk_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(TopDocs)]
+    L.nrtgpu_int_to_byte4.argtypes = [i32]
+    L.nrtgpu_byte4_to_int.argtypes = [i32]
+    L.nrtgpu_bm25_idf.argtypes = [i64, i64]
+    L.nrtgpu_bm25_idf.restype = f32
+    L.nrtgpu_bm25_avgdl.argtypes = [i64, i64]
+    L.nrtgpu_bm25_avgdl.restype = f32
+    L.nrtgpu_bm25_norm_cache.argtypes = [f32, f32, f32, vp]
+    L.nrtgpu_bm25_norm_cache.restype = None
+    L.nrtgpu_slices.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.nrtgpu_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.nrtgpu_reset_stats.argtypes = [vp]
+    L.nrtgpu_reset_stats.restype = None
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != NRTGPU_OK:
+        raise NrtGpuError(rc, load().nrtgpu_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,405 @@
+"""Host-side mirror of the reference's operator surface for the accelerated path.
+
+Names and argument meaning follow Lucene / nrtsearch so the parity tests read like the reference's
+own tests:
+
+  reference                                                         here
+  ---------------------------------------------------------------   ---------------------------
+  org.apache.lucene.search.TermQuery / BoostQuery / BooleanQuery     TermQuery / BoostQuery / BooleanQuery
+  BM25Similarity.scorer(boost, collectionStats, termStats)           BM25Similarity.scorer
+  TopScoreDocCollectorManager(numHits, after, totalHitsThreshold)    TopScoreDocCollectorManager
+     (S/search/collectors/RelevanceCollector.java:63-68)
+  IndexSearcher.search(Query, CollectorManager)                      GpuIndexSearcher.search
+     (S/handler/SearchHandler.java:1412-1413)
+  TopDocs / TotalHits.Relation                                       TopDocs
+
+Everything numeric happens behind the C ABI (include/nrtgpu.h) on the GPU; this module only
+marshals.  It has no CPU implementation of the query path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import NrtGpuError  # noqa: F401  (re-export)
+
+INT_MAX = 2**31 - 1
+TOTAL_HITS_THRESHOLD = 1000  # S/search/SearchRequestProcessor.java:102
+
+
+# ---- queries (only the shapes eligible for the device route) ------------------------
+@dataclasses.dataclass(frozen=True)
+class TermQuery:
+    field: int
+    term: int  # injective 64-bit id of the term (the Java shim hashes the BytesRef)
+
+
+@dataclasses.dataclass(frozen=True)
+class BoostQuery:
+    query: TermQuery
+    boost: float
+
+
+@dataclasses.dataclass(frozen=True)
+class BooleanQuery:
+    """Pure-SHOULD disjunction (S/query/QueryNodeMapper.java:257-283)."""
+
+    should: Tuple[Union[TermQuery, BoostQuery], ...]
+    minimum_number_should_match: int = 0
+
+
+Query = Union[TermQuery, BoostQuery, BooleanQuery]
+
+
+class UnsupportedQuery(Exception):
+    """The rewritten query is not eligible for the device route: run the CPU (Lucene) path."""
+
+
+@dataclasses.dataclass
+class ScoreDoc:
+    doc: int
+    score: float
+
+
+@dataclasses.dataclass
+class TopScoreDocCollectorManager:
+    num_hits: int
+    after: Optional[ScoreDoc] = None
+    total_hits_threshold: int = TOTAL_HITS_THRESHOLD
+
+
+@dataclasses.dataclass
+class TopDocs:
+    docs: np.ndarray            # int32 global docids
+    scores: np.ndarray          # float32
+    total_hits: int
+    relation_gte: bool          # True == TotalHits.Relation.GREATER_THAN_OR_EQUAL_TO
+
+
+# ---- statistics / similarity ---------------------------------------------------------------------
+@dataclasses.dataclass
+class CollectionStatistics:
+    doc_count: int
+    sum_total_term_freq: int
+
+
+class IndexStatistics:
+    """Index-global statistics the searcher reads from the top-level reader."""
+
+    def __init__(self):
+        self.fields: Dict[int, CollectionStatistics] = {}
+        self.doc_freq: Dict[Tuple[int, int], int] = {}
+
+    @classmethod
+    def from_corpus(cls, corpus, field: int = 0) -> "IndexStatistics":
+        st = cls()
+        st.fields[field] = CollectionStatistics(corpus.doc_count, corpus.sum_total_term_freq)
+        for t, df in corpus.doc_freq.items():
+            st.doc_freq[(field, int(t))] = int(df)
+        return st
+
+
+class BM25Similarity:
+    """Default similarity of the reference (S/similarity/SimilarityCreator.java:33,41)."""
+
+    def __init__(self, k1: float = 1.2, b: float = 0.75):
+        self.k1, self.b = float(k1), float(b)
+
+    def idf(self, doc_freq: int, doc_count: int) -> np.float32:
+        return np.float32(_lib.load().nrtgpu_bm25_idf(int(doc_count), int(doc_freq)))
+
+    def avgdl(self, cs: CollectionStatistics) -> np.float32:
+        return np.float32(_lib.load().nrtgpu_bm25_avgdl(int(cs.sum_total_term_freq), int(cs.doc_count)))
+
+    def norm_cache(self, cs: CollectionStatistics) -> np.ndarray:
+        out = np.zeros(256, dtype=np.float32)
+        _lib.load().nrtgpu_bm25_norm_cache(C.c_float(float(self.avgdl(cs))), C.c_float(self.k1), C.c_float(self.b),
+                                          out.ctypes.data)
+        return out
+
+    def scorer(self, boost: float, cs: CollectionStatistics, doc_freq: int) -> Tuple[np.float32, np.ndarray]:
+        """-> (weight = boost * idf, normInverse cache[256])."""
+        idf = self.idf(doc_freq, cs.doc_count)
+        return np.float32(np.float32(boost) * idf), self.norm_cache(cs)
+
+
+# ---- device context / segment store --------------------------------------------------------------
+class GpuContext:
+    def __init__(self, device_id: int = 0, max_batch: int = 1024, target_items: int = 0,
+                 collect_timing: bool = False, flags: int = 0):
+        L = _lib.load()
+        cfg = _lib.Config(device_id, max_batch, target_items, int(collect_timing), flags, 0)
+        h = C.c_void_p()
+        _lib.check(L.nrtgpu_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.max_batch = max_batch
+
+    def stats(self) -> dict:
+        st = _lib.Stats()
+        _lib.check(_lib.load().nrtgpu_get_stats(self._h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in _lib.Stats._fields_}
+
+    def reset_stats(self) -> None:
+        _lib.load().nrtgpu_reset_stats(self._h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.load().nrtgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuSegment:
+    """HBM-resident columnar replica of one immutable segment."""
+
+    def __init__(self, ctx: GpuContext, max_doc: int, doc_base: int = 0):
+        self.ctx, self.max_doc, self.doc_base = ctx, int(max_doc), int(doc_base)
+        h = C.c_void_p()
+        _lib.check(_lib.load().nrtgpu_segment_begin(ctx._h, self.max_doc, 0, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_data(cls, ctx: GpuContext, seg, field: int = 0, omit_norms: bool = False,
+                  omit_freqs: bool = False) -> "GpuSegment":
+        """Upload a synth.SegmentData (what the Java side reads through PostingsEnum / norms)."""
+        g = cls(ctx, seg.max_doc, seg.doc_base)
+        g.add_field_norms(field, None if omit_norms else seg.norms)
+        g.add_terms(field, seg.term_ids, seg.offsets, seg.docids, None if omit_freqs else seg.freqs)
+        g.seal()
+        if seg.live_bits is not None:
+            g.set_live_docs(seg.live_bits)
+        return g
+
+    def add_field_norms(self, field: int, norms: Optional[np.ndarray]) -> None:
+        p = None
+        if norms is not None:
+            norms = np.ascontiguousarray(norms, dtype=np.uint8)
+            assert norms.shape[0] == self.max_doc
+            p = norms.ctypes.data
+        _lib.check(_lib.load().nrtgpu_segment_add_field_norms(self._h, int(field), p))
+
+    def add_terms(self, field: int, term_ids, offsets, docids, freqs) -> None:
+        term_ids = np.ascontiguousarray(term_ids, dtype=np.int64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        docids = np.ascontiguousarray(docids, dtype=np.int32)
+        fp = None
+        if freqs is not None:
+            freqs = np.ascontiguousarray(freqs, dtype=np.int32)
+            fp = freqs.ctypes.data
+        _lib.check(_lib.load().nrtgpu_segment_add_terms(self._h, int(field), len(term_ids), term_ids.ctypes.data,
+                                                        offsets.ctypes.data, docids.ctypes.data, fp))
+
+    def add_vectors(self, field: int, vectors: np.ndarray, ord_to_doc: Optional[np.ndarray] = None) -> None:
+        vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        op = None
+        if ord_to_doc is not None:
+            ord_to_doc = np.ascontiguousarray(ord_to_doc, dtype=np.int32)
+            op = ord_to_doc.ctypes.data
+        _lib.check(_lib.load().nrtgpu_segment_add_vectors(self._h, int(field), vectors.shape[1], vectors.shape[0],
+                                                          op, vectors.ctypes.data))
+
+    def seal(self) -> None:
+        _lib.check(_lib.load().nrtgpu_segment_seal(self._h))
+
+    def set_live_docs(self, bits: Optional[np.ndarray]) -> None:
+        if bits is None:
+            _lib.check(_lib.load().nrtgpu_segment_set_live_docs(self._h, None, 0))
+            return
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        _lib.check(_lib.load().nrtgpu_segment_set_live_docs(self._h, bits.ctypes.data, len(bits)))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(_lib.load().nrtgpu_segment_device_bytes(self._h))
+
+    def release(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.load().nrtgpu_segment_release(self._h)
+            self._h = None
+
+
+# ---- searcher ------------------------------------------------------------------------------------
+def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int]:
+    """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost)], msm."""
+    def one(q) -> Tuple[int, int, float]:
+        if isinstance(q, TermQuery):
+            return (q.field, q.term, 1.0)
+        if isinstance(q, BoostQuery) and isinstance(q.query, TermQuery):
+            return (q.query.field, q.query.term, float(q.boost))
+        raise UnsupportedQuery(f"clause {q!r} is not a (boosted) TermQuery")
+
+    if isinstance(query, BooleanQuery):
+        if query.minimum_number_should_match > 1:
+            raise UnsupportedQuery("minimumNumberShouldMatch > 1")
+        if not query.should:
+            raise UnsupportedQuery("empty BooleanQuery")
+        return [one(c) for c in query.should], query.minimum_number_should_match
+    return [one(query)], 0
+
+
+class _Marshalled:
+    """Keeps the ctypes arrays of a batch alive for the duration of the call."""
+
+    def __init__(self, n: int):
+        self.queries = (_lib.Bm25Query * n)()
+        self.keep: list = []
+
+
+class GpuIndexSearcher:
+    """IndexSearcher over GPU-resident leaves: search(query, collectorManager) -> TopDocs."""
+
+    def __init__(self, ctx: GpuContext, leaves: Sequence[GpuSegment], stats: IndexStatistics,
+                 similarity: Optional[BM25Similarity] = None):
+        self.ctx, self.leaves, self.stats = ctx, list(leaves), stats
+        self.similarity = similarity or BM25Similarity()
+        n = len(self.leaves)
+        self._segs = (C.c_void_p * max(n, 1))(*[l._h for l in self.leaves])
+        self._bases = (C.c_int32 * max(n, 1))(*[l.doc_base for l in self.leaves])
+        self._cache_memo: Dict[int, np.ndarray] = {}
+
+    def _norm_cache(self, field: int) -> np.ndarray:
+        c = self._cache_memo.get(field)
+        if c is None:
+            c = self.similarity.norm_cache(self.stats.fields[field])
+            self._cache_memo[field] = c
+        return c
+
+    def _marshal(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> _Marshalled:
+        m = _Marshalled(len(queries))
+        for qi, (query, mgr) in enumerate(zip(queries, managers)):
+            clauses, msm = _flatten(query)
+            fields: List[int] = []
+            terms = (_lib.Term * len(clauses))()
+            for ti, (field, term, boost) in enumerate(clauses):
+                if field not in self.stats.fields:
+                    raise UnsupportedQuery(f"no statistics for field {field}")
+                if field not in fields:
+                    fields.append(field)
+                df = self.stats.doc_freq.get((field, term), 0)
+                cs = self.stats.fields[field]
+                w = np.float32(np.float32(boost) * self.similarity.idf(df, cs.doc_count)) if df > 0 else np.float32(0)
+                terms[ti] = _lib.Term(field, fields.index(field), term, float(w), 0.0)
+            cache = np.concatenate([self._norm_cache(f) for f in fields]).astype(np.float32)
+            m.keep += [terms, cache]
+            q = m.queries[qi]
+            q.n_terms = len(clauses)
+            q.terms = terms
+            q.n_caches = len(fields)
+            q.norm_cache = cache.ctypes.data_as(C.POINTER(C.c_float))
+            q.k = int(mgr.num_hits)
+            q.total_hits_threshold = int(mgr.total_hits_threshold)
+            q.has_after = int(mgr.after is not None)
+            q.after_doc = int(mgr.after.doc) if mgr.after is not None else 0
+            q.after_score = float(mgr.after.score) if mgr.after is not None else 0.0
+            q.min_should_match = int(msm)
+        return m
+
+    def search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> List[TopDocs]:
+        n = len(queries)
+        m = self._marshal(queries, managers)
+        outs = (_lib.TopDocs * n)()
+        bufs = []
+        for qi, mgr in enumerate(managers):
+            cap = max(int(mgr.num_hits), 1)
+            d = np.zeros(cap, dtype=np.int32)
+            s = np.zeros(cap, dtype=np.float32)
+            bufs.append((d, s))
+            outs[qi].capacity = cap
+            outs[qi].docs = d.ctypes.data_as(C.POINTER(C.c_int32))
+            outs[qi].scores = s.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_search_bm25_batch(self.ctx._h, self._segs, self._bases, len(self.leaves),
+                                                        m.queries, n, outs))
+        res = []
+        for qi in range(n):
+            nh = outs[qi].n_hits
+            d, s = bufs[qi]
+            res.append(TopDocs(d[:nh].copy(), s[:nh].copy(), int(outs[qi].total_hits),
+                               bool(outs[qi].total_hits_is_lower_bound)))
+        return res
+
+    def search(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
+        return self.search_batch([query], [manager])[0]
+
+
+# ---- pre-marshalled batches (bench / serving loop: no Python work inside the timed region) --------
+class PreparedBatch:
+    """A batch of queries marshalled once; `run()` is a single C-ABI call."""
+
+    def __init__(self, searcher: GpuIndexSearcher, queries: Sequence[Query],
+                 managers: Sequence[TopScoreDocCollectorManager]):
+        self.searcher = searcher
+        self.n = len(queries)
+        self._m = searcher._marshal(queries, managers)
+        self.k = max(int(m.num_hits) for m in managers)
+        self._outs = (_lib.TopDocs * self.n)()
+        self.docs = np.zeros((self.n, self.k), dtype=np.int32)
+        self.scores = np.zeros((self.n, self.k), dtype=np.float32)
+        for qi in range(self.n):
+            self._outs[qi].capacity = self.k
+            self._outs[qi].docs = self.docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+            self._outs[qi].scores = self.scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+
+    def run(self) -> None:
+        s = self.searcher
+        _lib.check(_lib.load().nrtgpu_search_bm25_batch(s.ctx._h, s._segs, s._bases, len(s.leaves),
+                                                        self._m.queries, self.n, self._outs))
+
+    def run_device(self, k_stride: int, d_keys: int, d_counts: int, d_hits: int) -> None:
+        """Results stay in HBM (device pointers as ints) for the RCCL all-gather."""
+        s = self.searcher
+        _lib.check(_lib.load().nrtgpu_search_bm25_batch_device(
+            s.ctx._h, s._segs, s._bases, len(s.leaves), self._m.queries, self.n, int(k_stride),
+            C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits)))
+
+    def topdocs(self, qi: int) -> TopDocs:
+        o = self._outs[qi]
+        return TopDocs(self.docs[qi, : o.n_hits].copy(), self.scores[qi, : o.n_hits].copy(), int(o.total_hits),
+                       bool(o.total_hits_is_lower_bound))
+
+
+def merge_topk_device(ctx: GpuContext, n_lists: int, n_queries: int, k_stride: int, d_keys: int, d_counts: int,
+                      d_hits: int, ks: Sequence[int], thresholds: Sequence[int]) -> List[TopDocs]:
+    """TopDocs.merge of all-gathered per-GPU results (device pointers as ints)."""
+    ks_a = np.ascontiguousarray(ks, dtype=np.int32)
+    th_a = np.ascontiguousarray(thresholds, dtype=np.int32)
+    outs = (_lib.TopDocs * n_queries)()
+    kmax = int(ks_a.max())
+    docs = np.zeros((n_queries, kmax), dtype=np.int32)
+    scores = np.zeros((n_queries, kmax), dtype=np.float32)
+    for qi in range(n_queries):
+        outs[qi].capacity = kmax
+        outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+        outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+    _lib.check(_lib.load().nrtgpu_merge_topk_device(ctx._h, n_lists, n_queries, k_stride, C.c_void_p(d_keys),
+                                                    C.c_void_p(d_counts), C.c_void_p(d_hits), ks_a.ctypes.data,
+                                                    th_a.ctypes.data, outs))
+    return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(),
+                    int(outs[qi].total_hits), bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n_queries)]
+
+
+def slices(max_docs: Sequence[int], num_docs: Optional[Sequence[int]] = None, virtual_shards: int = 1,
+           slice_max_docs: int = 250_000, slice_max_segments: int = 5):
+    """MyIndexSearcher.slices / slicesForShards (S/search/MyIndexSearcher.java:79-208).
+    -> (slices as lists of leaf indices in the reference's slice order, shard_of_leaf)."""
+    n = len(max_docs)
+    md = np.ascontiguousarray(max_docs, dtype=np.int32)
+    nd = np.ascontiguousarray(num_docs if num_docs is not None else max_docs, dtype=np.int32)
+    sl = np.full(max(n, 1), -1, dtype=np.int32)
+    sh = np.full(max(n, 1), -1, dtype=np.int32)
+    ns = _lib.load().nrtgpu_slices(n, md.ctypes.data, nd.ctypes.data, None, int(virtual_shards), int(slice_max_docs),
+                                   int(slice_max_segments), sl.ctypes.data, sh.ctypes.data)
+    if ns < 0:
+        _lib.check(ns)
+    out: List[List[int]] = [[] for _ in range(ns)]
+    for i in range(n):
+        out[sl[i]].append(i)
+    return out, sh[:n].tolist()

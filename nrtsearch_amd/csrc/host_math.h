@@ -1,0 +1,196 @@
+// host_math.h -- host-side restatements the Java shim would take from Lucene objects:
+// SmallFloat, BM25Similarity statistics, MyIndexSearcher.slices.  Product code (not the oracle):
+// kept independent of oracle/ on purpose; tests cross-check the two.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace nrtgpu {
+namespace hostmath {
+
+// org.apache.lucene.util.SmallFloat (Lucene 10.4.0): 4-bit-mantissa float-like encoding of
+// non-negative ints; the first NUM_FREE_VALUES (24) values are stored exactly.
+inline int32_t long_to_int4(int64_t i) {
+  const int num_bits = (i == 0) ? 0 : 64 - __builtin_clzll((unsigned long long)i);
+  if (num_bits < 4) return (int32_t)i;
+  const int shift = num_bits - 4;
+  int32_t encoded = (int32_t)((uint64_t)i >> shift);
+  encoded &= 0x07;
+  encoded |= (shift + 1) << 3;
+  return encoded;
+}
+inline int64_t int4_to_long(int32_t i) {
+  const int64_t bits = i & 0x07;
+  const int shift = (int)((uint32_t)i >> 3) - 1;
+  return shift == -1 ? bits : ((bits | 0x08) << shift);
+}
+constexpr int32_t kNumFreeValues = 24;  // 255 - longToInt4(Integer.MAX_VALUE)
+inline int32_t int_to_byte4(int32_t i) {
+  if (i < 0) return -1;
+  if (i < kNumFreeValues) return i;
+  return (kNumFreeValues + long_to_int4((int64_t)i - kNumFreeValues)) & 0xFF;
+}
+inline int32_t byte4_to_int(int32_t b) {
+  b &= 0xFF;
+  if (b < kNumFreeValues) return b;
+  return (int32_t)(kNumFreeValues + int4_to_long(b - kNumFreeValues));
+}
+
+// BM25Similarity (k1 = 1.2f, b = 0.75f by default; /root/reference/src/main/java/com/yelp/nrtsearch/
+// server/similarity/SimilarityCreator.java:33).  Statistics are index-global.
+inline float bm25_idf(int64_t doc_count, int64_t doc_freq) {
+  return (float)std::log(1.0 + ((double)(doc_count - doc_freq) + 0.5) / ((double)doc_freq + 0.5));
+}
+inline float bm25_avgdl(int64_t sum_total_term_freq, int64_t doc_count) {
+  return (float)((double)sum_total_term_freq / (double)doc_count);
+}
+// cache[i] = 1f / (k1 * ((1 - b) + b * LENGTH_TABLE[i] / avgdl)), fp32 in this association.
+// (compiled with -ffp-contract=off; volatile keeps every intermediate a rounded float)
+inline void bm25_norm_cache(float avgdl, float k1, float b, float* out256) {
+  for (int i = 0; i < 256; ++i) {
+    volatile float len = (float)byte4_to_int(i);
+    volatile float omb = 1.0f - b;
+    volatile float t = b * len;
+    t = t / avgdl;
+    t = omb + t;
+    t = k1 * t;
+    out256[i] = 1.0f / t;
+  }
+}
+
+// java.util.PriorityQueue restated (binary heap, siftUp/siftDown exactly as OpenJDK) so that
+// ties are broken the way the reference breaks them in MyIndexSearcher.slicesForShards.
+template <class T, class Less>
+class JavaPriorityQueue {
+ public:
+  explicit JavaPriorityQueue(Less less) : less_(less) {}
+  bool empty() const { return q_.empty(); }
+  size_t size() const { return q_.size(); }
+  void add(const T& x) {
+    q_.push_back(x);
+    size_t k = q_.size() - 1;
+    while (k > 0) {  // siftUp
+      const size_t parent = (k - 1) >> 1;
+      if (!less_(x, q_[parent])) break;  // comparator.compare(x, e) >= 0
+      q_[k] = q_[parent];
+      k = parent;
+    }
+    q_[k] = x;
+  }
+  T poll() {
+    T result = q_[0];
+    const size_t n = q_.size() - 1;
+    T x = q_[n];
+    q_.pop_back();
+    if (n > 0) {  // siftDown(0, x)
+      size_t k = 0;
+      const size_t half = n >> 1;
+      while (k < half) {
+        size_t child = (k << 1) + 1;
+        const size_t right = child + 1;
+        if (right < n && less_(q_[right], q_[child])) child = right;  // compare(c, right) > 0
+        if (!less_(q_[child], x)) break;                             // compare(x, c) <= 0
+        q_[k] = q_[child];
+        k = child;
+      }
+      q_[k] = x;
+    }
+    return result;
+  }
+
+ private:
+  std::vector<T> q_;
+  Less less_;
+};
+
+struct LeafInfo {
+  int32_t index;     // position in the reader's leaf list
+  int32_t max_doc;
+  int32_t num_docs;  // live docs
+  int32_t doc_base;
+};
+
+// MyIndexSearcher.slices(leaves, maxDocsPerSlice, maxSegmentsPerSlice)
+// (/root/reference/src/main/java/com/yelp/nrtsearch/server/search/MyIndexSearcher.java:163-208).
+// Returns slices as lists of leaf indices (each sorted by docBase, :202).
+inline std::vector<std::vector<int32_t>> slices(std::vector<LeafInfo> leaves, int32_t max_docs_per_slice,
+                                                int32_t max_segments_per_slice, const std::vector<LeafInfo>& all) {
+  std::stable_sort(leaves.begin(), leaves.end(),
+                   [](const LeafInfo& a, const LeafInfo& b) { return a.max_doc > b.max_doc; });
+  std::vector<std::vector<int32_t>> grouped;
+  int64_t doc_sum = 0;
+  int cur = -1;
+  for (const LeafInfo& l : leaves) {
+    if (l.max_doc > max_docs_per_slice) {
+      grouped.push_back({l.index});
+    } else {
+      if (cur < 0) {
+        grouped.push_back({l.index});
+        cur = (int)grouped.size() - 1;
+      } else {
+        grouped[cur].push_back(l.index);
+      }
+      doc_sum += l.max_doc;
+      if ((int32_t)grouped[cur].size() >= max_segments_per_slice || doc_sum > max_docs_per_slice) {
+        cur = -1;
+        doc_sum = 0;
+      }
+    }
+  }
+  for (auto& g : grouped)
+    std::stable_sort(g.begin(), g.end(), [&](int32_t a, int32_t b) { return all[a].doc_base < all[b].doc_base; });
+  return grouped;
+}
+
+// MyIndexSearcher.slicesForShards (…MyIndexSearcher.java:117-160): LPT over live docs into
+// `virtual_shards` containers, slices per shard, slices ordered by max docs descending.
+inline std::vector<std::vector<int32_t>> slices_for_shards(const std::vector<LeafInfo>& all, int32_t virtual_shards,
+                                                           int32_t max_docs_per_slice, int32_t max_segments_per_slice,
+                                                           std::vector<int32_t>* shard_of_leaf) {
+  std::vector<std::vector<int32_t>> out;
+  if (all.empty()) return out;
+  std::vector<LeafInfo> sorted = all;
+  std::stable_sort(sorted.begin(), sorted.end(),
+                   [](const LeafInfo& a, const LeafInfo& b) { return a.num_docs > b.num_docs; });
+  struct Shard { int32_t id; int64_t num_docs; std::vector<LeafInfo> leaves; };
+  std::vector<Shard> shards((size_t)virtual_shards);
+  auto shard_less = [&shards](int32_t a, int32_t b) { return shards[a].num_docs < shards[b].num_docs; };
+  JavaPriorityQueue<int32_t, decltype(shard_less)> pq(shard_less);
+  for (int32_t i = 0; i < virtual_shards; ++i) {
+    shards[i].id = i;
+    shards[i].num_docs = 0;
+    pq.add(i);
+  }
+  for (const LeafInfo& l : sorted) {
+    const int32_t s = pq.poll();
+    shards[s].leaves.push_back(l);
+    shards[s].num_docs += l.num_docs;
+    pq.add(s);
+  }
+  if (shard_of_leaf) shard_of_leaf->assign(all.size(), -1);
+  struct SliceAndSize { std::vector<int32_t> leaves; int64_t num_docs; };
+  std::vector<SliceAndSize> pool;
+  auto slice_greater = [&pool](int32_t a, int32_t b) { return pool[a].num_docs > pool[b].num_docs; };
+  JavaPriorityQueue<int32_t, decltype(slice_greater)> sorted_slices(slice_greater);
+  while (!pq.empty()) {
+    const int32_t s = pq.poll();
+    if (shards[s].leaves.empty()) continue;
+    if (shard_of_leaf)
+      for (const LeafInfo& l : shards[s].leaves) (*shard_of_leaf)[l.index] = s;
+    auto shard_slices = slices(shards[s].leaves, max_docs_per_slice, max_segments_per_slice, all);
+    for (auto& sl : shard_slices) {
+      int64_t md = 0;  // LeafSlice.getMaxDocs(): sum of partition maxDocs
+      for (int32_t li : sl) md += all[li].max_doc;
+      pool.push_back({sl, md});
+      sorted_slices.add((int32_t)pool.size() - 1);
+    }
+  }
+  while (!sorted_slices.empty()) out.push_back(pool[sorted_slices.poll()].leaves);
+  return out;
+}
+
+}  // namespace hostmath
+}  // namespace nrtgpu

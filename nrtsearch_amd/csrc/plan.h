@@ -1,0 +1,76 @@
+// plan.h -- launch-plan records shared by the host runtime and the gfx950 kernels.
+// A "plan" is what one batch call uploads: per query, per (query, doc-range) work item, per
+// (item, term) posting columns.  Names follow the reference's domain: leaves/segments, postings,
+// slices (here: items), collectors.
+#pragma once
+#include <stdint.h>
+
+namespace nrtgpu {
+
+constexpr int kTileDocs = 8192;     // docs per LDS accumulator tile (fp64 accumulators: 64 KiB)
+constexpr int kTileShift = 13;
+constexpr int kScanThreads = 512;   // 8 wave64 per workgroup, 2 workgroups per CU
+constexpr int kCandCap = 1280;      // scan: LDS candidate slots (10 KiB) = kMaxK + kFloodStep
+constexpr int kFloodStep = 256;     // scan: docs collected between compactions while flooding
+constexpr int kMergeCap = 1536;     // merge: candidate slots = kMaxK + kScanThreads
+constexpr int kLdsCaches = 2;       // normInverse tables kept in LDS per item (one per field)
+constexpr int kMaxK = 1024;
+constexpr int kMaxTerms = 32;
+
+// One query term inside one segment: where its posting columns live in HBM.
+struct alignas(16) DTerm {
+  const uint32_t* docids;    // docid column (all terms of the upload group, concatenated)
+  const uint32_t* fnorm;     // freq column with the doc's norm byte folded in: (freq << 8) | norm
+  const uint32_t* cell_off;  // (n_cells + 1) posting offsets relative to `start`, one per doc-range cell
+  uint64_t start;            // index of the term's first posting in the columns
+  uint32_t count;            // postings of the term in this segment (docFreq within the leaf)
+  uint32_t shift;            // cell = tile >> shift (0 for dense terms: one cell per tile)
+  float    weight;           // boost * idf
+  uint32_t cache_off;        // offset in floats of the term's 256-entry normInverse table
+  uint32_t cache_slot;       // per-query table index (tables < kLdsCaches are staged in LDS)
+  uint32_t pad0;
+};
+static_assert(sizeof(DTerm) == 64, "DTerm layout");
+
+// One work item: one query over a contiguous tile range of one segment (the analogue of a
+// LeafReaderContextPartition handled by one collector).
+struct alignas(16) DItem {
+  const uint64_t* live_bits;  // nullptr => every doc live
+  uint32_t query;             // batch-local query index
+  uint32_t term_begin;        // first DTerm of this item
+  uint32_t n_terms;
+  uint32_t tile_begin, tile_end;
+  uint32_t max_doc;
+  int32_t  doc_base;
+  uint32_t cache_off;         // offset in floats of the query's first normInverse table
+  uint32_t n_caches;
+  uint32_t pad0, pad1, pad2;
+};
+static_assert(sizeof(DItem) == 64, "DItem layout");
+
+struct alignas(16) DQuery {
+  uint32_t k;
+  uint32_t has_after;
+  int32_t  after_doc;      // global docid
+  float    after_score;
+  uint32_t item_begin;     // items of this query are [item_begin, item_begin + n_items)
+  uint32_t n_items;
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(DQuery) == 32, "DQuery layout");
+
+// Packed hit: larger key == better hit under Lucene's HitQueue order (score desc, doc asc).
+// Scores are >= 0 (BM25 weights are non-negative) so float bits order like the floats.
+__host__ __device__ inline uint64_t pack_key(float score, uint32_t global_doc) {
+  union { float f; uint32_t u; } c;
+  c.f = score;
+  return ((uint64_t)c.u << 32) | (uint64_t)(0xFFFFFFFFu - global_doc);
+}
+__host__ __device__ inline float key_score(uint64_t key) {
+  union { float f; uint32_t u; } c;
+  c.u = (uint32_t)(key >> 32);
+  return c.f;
+}
+__host__ __device__ inline uint32_t key_doc(uint64_t key) { return 0xFFFFFFFFu - (uint32_t)key; }
+
+}  // namespace nrtgpu

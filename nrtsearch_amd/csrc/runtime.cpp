@@ -1,0 +1,909 @@
+// runtime.cpp -- host runtime behind the C ABI of include/nrtgpu.h (compiled with hipcc).
+//
+// Owns: the device context (one per process/GPU), the segment store (read-only columnar replica of
+// each Lucene segment's scoring data in HBM), batch launch plans, the per-call workspaces
+// ("slots": stream + pinned staging + device scratch) and the result unpacking.
+// There is deliberately no CPU execution path here: without a gfx950 device nrtgpu_create fails.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nrtgpu.h"
+#include "host_math.h"
+#include "plan.h"
+
+namespace nrtgpu {
+void launch_bm25_scan(hipStream_t stream, bool pipelined, uint32_t n_items, const DItem* items, const DTerm* terms,
+                      const DQuery* queries, const float* caches, unsigned long long* theta_g,
+                      uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride);
+void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
+                       const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
+                       const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
+                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out);
+void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,
+                       uint32_t* fnorm, uint64_t n, uint32_t* overflow);
+}  // namespace nrtgpu
+
+using namespace nrtgpu;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(_e == hipErrorOutOfMemory ? NRTGPU_ERR_OOM : NRTGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                  hipGetErrorString(_e), __FILE__, __LINE__);                                      \
+  } while (0)
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------------
+// growable device / pinned buffers
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// segment store
+// ------------------------------------------------------------------------------------------------
+struct TermEntry {
+  uint32_t group;      // which upload group holds the columns
+  uint64_t start;      // first posting in the group's columns
+  uint32_t count;
+  uint32_t shift;      // doc-range cell = tile >> shift
+  uint64_t cell_start; // first entry of the term's cell table inside the group's table buffer
+};
+
+struct TermGroup {
+  uint32_t* d_docids = nullptr;
+  uint32_t* d_freqs = nullptr;   // raw freq column, only between add_terms and seal (nullptr => freq == 1)
+  uint32_t* d_fnorm = nullptr;   // (freq << 8) | norm byte, built at seal
+  uint32_t* d_cells = nullptr;   // concatenated per-term cell tables
+  bool has_freqs = false;
+  uint64_t n_postings = 0;
+};
+
+struct FieldData {
+  uint8_t* d_norms = nullptr;    // nullptr => norms omitted
+  std::unordered_map<int64_t, TermEntry> dict;
+  std::vector<TermGroup> groups;
+  float* d_vectors = nullptr;
+  int32_t* d_ord_to_doc = nullptr;
+  int32_t dim = 0, n_vec = 0;
+};
+
+struct nrtgpu_ctx;
+struct nrtgpu_seg {
+  nrtgpu_ctx* ctx = nullptr;
+  int32_t max_doc = 0;
+  uint32_t n_tiles = 0;
+  bool sealed = false;
+  std::map<int32_t, FieldData> fields;
+  uint64_t* d_live = nullptr;
+  int64_t device_bytes = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-call workspace
+// ------------------------------------------------------------------------------------------------
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  PinBuf h_plan;     // host staging of the plan blob
+  DevBuf d_plan;     // device copy
+  DevBuf d_work;     // theta + item outputs + merge outputs
+  PinBuf h_out;      // merged results on the host
+  bool busy = false;
+};
+
+struct nrtgpu_ctx {
+  nrtgpu_config cfg{};
+  int device = 0;
+  int n_cus = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::unique_ptr<Slot>> slots;
+  std::mutex stats_mu;
+  nrtgpu_stats stats{};
+};
+
+static const int kSlots = 4;
+
+static int acquire_slot(nrtgpu_ctx* ctx, Slot** out) {
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  for (;;) {
+    for (auto& s : ctx->slots) {
+      if (!s->busy) {
+        s->busy = true;
+        *out = s.get();
+        return 0;
+      }
+    }
+    ctx->cv.wait(lk);
+  }
+}
+static void release_slot(nrtgpu_ctx* ctx, Slot* s) {
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    s->busy = false;
+  }
+  ctx->cv.notify_one();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI: context
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* nrtgpu_version(void) { return "nrtgpu 0.1 (gfx950)"; }
+extern "C" const char* nrtgpu_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
+  if (!out) return fail(NRTGPU_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  nrtgpu_config c{};
+  if (cfg) c = *cfg;
+  if (c.max_batch <= 0) c.max_batch = 1024;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    return fail(NRTGPU_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (c.device_id < 0 || c.device_id >= n_dev) return fail(NRTGPU_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", c.device_id, n_dev);
+  HIP_TRY(hipSetDevice(c.device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, c.device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NRTGPU_ERR_HIP, "device %d is %s; kernels are built for gfx950 only", c.device_id, prop.gcnArchName);
+  auto ctx = std::make_unique<nrtgpu_ctx>();
+  ctx->cfg = c;
+  ctx->device = c.device_id;
+  ctx->n_cus = prop.multiProcessorCount;
+  for (int i = 0; i < kSlots; ++i) {
+    auto s = std::make_unique<Slot>();
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    HIP_TRY(hipEventCreate(&s->ev2));
+    ctx->slots.push_back(std::move(s));
+  }
+  *out = ctx.release();
+  return NRTGPU_OK;
+}
+
+extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (auto& s : ctx->slots) {
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    s->h_plan.release();
+    s->d_plan.release();
+    s->d_work.release();
+    s->h_out.release();
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev2) (void)hipEventDestroy(s->ev2);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+  }
+  delete ctx;
+}
+
+extern "C" int nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out) {
+  if (!ctx || !out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->stats_mu);
+  *out = ctx->stats;
+  return NRTGPU_OK;
+}
+extern "C" void nrtgpu_reset_stats(nrtgpu_ctx* ctx) {
+  if (!ctx) return;
+  std::lock_guard<std::mutex> lk(ctx->stats_mu);
+  ctx->stats = nrtgpu_stats{};
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI: segment lifecycle
+// ------------------------------------------------------------------------------------------------
+static int dev_alloc(nrtgpu_seg* seg, void** p, size_t bytes) {
+  HIP_TRY(hipMalloc(p, bytes));
+  seg->device_bytes += (int64_t)bytes;
+  return 0;
+}
+
+extern "C" int nrtgpu_segment_begin(nrtgpu_ctx* ctx, int32_t max_doc, int32_t /*device_hint*/, nrtgpu_seg** out) {
+  if (!ctx || !out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (max_doc <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "max_doc must be > 0, got %d", max_doc);
+  auto* seg = new nrtgpu_seg();
+  seg->ctx = ctx;
+  seg->max_doc = max_doc;
+  seg->n_tiles = (uint32_t)(((int64_t)max_doc + kTileDocs - 1) / kTileDocs);
+  *out = seg;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id, const uint8_t* norm_bytes) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return fail(NRTGPU_ERR_STATE, "segment already sealed");
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  FieldData& f = seg->fields[field_id];
+  if (f.d_norms) {
+    (void)hipFree(f.d_norms);
+    f.d_norms = nullptr;
+  }
+  if (!norm_bytes) return NRTGPU_OK;  // norms omitted: norm value 1 everywhere
+  void* p = nullptr;
+  if (int rc = dev_alloc(seg, &p, (size_t)seg->max_doc + 64)) return rc;
+  f.d_norms = (uint8_t*)p;
+  HIP_TRY(hipMemcpy(f.d_norms, norm_bytes, (size_t)seg->max_doc, hipMemcpyHostToDevice));
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64_t n_terms, const int64_t* term_hash,
+                                        const int64_t* offsets, const int32_t* docids, const int32_t* freqs) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return fail(NRTGPU_ERR_STATE, "segment already sealed");
+  if (n_terms < 0 || (n_terms > 0 && (!term_hash || !offsets))) return fail(NRTGPU_ERR_INVALID_ARG, "bad term arrays");
+  if (n_terms == 0) return NRTGPU_OK;
+  const int64_t total = offsets[n_terms];
+  if (offsets[0] != 0 || total < 0) return fail(NRTGPU_ERR_INVALID_ARG, "offsets must start at 0 and be non-negative");
+  if (total > 0 && !docids) return fail(NRTGPU_ERR_INVALID_ARG, "docids is NULL");
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  FieldData& f = seg->fields[field_id];
+
+  // doc-range cell tables: per term, posting offset at each cell boundary (cell = 2^shift tiles).
+  // Dense terms get one cell per tile; sparse terms coarser cells so a table never exceeds ~1/8
+  // of the term's postings.
+  std::vector<uint32_t> cells;
+  std::vector<TermEntry> entries((size_t)n_terms);
+  for (int64_t t = 0; t < n_terms; ++t) {
+    const int64_t lo = offsets[t], hi = offsets[t + 1];
+    if (hi < lo || hi > total) return fail(NRTGPU_ERR_INVALID_ARG, "offsets not monotone at term %lld", (long long)t);
+    const int64_t cnt = hi - lo;
+    if (cnt > 0xFFFFFFFFll) return fail(NRTGPU_ERR_UNSUPPORTED, "term with more than 2^32 postings");
+    uint32_t shift = 0;
+    const uint64_t budget = std::max<int64_t>(1, cnt / 8);
+    while (((uint64_t)(seg->n_tiles - 1) >> shift) + 1 > budget && shift < 31) ++shift;
+    const uint32_t n_cells = (uint32_t)(((uint64_t)(seg->n_tiles - 1) >> shift) + 1);
+    TermEntry& e = entries[(size_t)t];
+    e.group = (uint32_t)f.groups.size();
+    e.start = (uint64_t)lo;
+    e.count = (uint32_t)cnt;
+    e.shift = shift;
+    e.cell_start = cells.size();
+    const int cell_doc_shift = kTileShift + (int)shift;
+    int64_t p = lo;
+    int32_t prev = -1;
+    for (uint32_t c = 0; c < n_cells; ++c) {
+      cells.push_back((uint32_t)(p - lo));
+      const int64_t bound = ((int64_t)(c + 1)) << cell_doc_shift;  // first doc of the next cell
+      while (p < hi && (int64_t)docids[p] < bound) {
+        const int32_t d = docids[p];
+        if (d <= prev || d >= seg->max_doc)
+          return fail(NRTGPU_ERR_INVALID_ARG, "docids of term %lld not strictly ascending in [0,max_doc)", (long long)t);
+        prev = d;
+        ++p;
+      }
+    }
+    if (p != hi) return fail(NRTGPU_ERR_INVALID_ARG, "docids of term %lld exceed max_doc", (long long)t);
+    cells.push_back((uint32_t)cnt);
+  }
+  for (int64_t t = 0; t < n_terms; ++t)
+    if (f.dict.count(term_hash[t])) return fail(NRTGPU_ERR_INVALID_ARG, "term %lld added twice to field %d", (long long)term_hash[t], field_id);
+
+  TermGroup g;
+  g.n_postings = (uint64_t)total;
+  void* p = nullptr;
+  const size_t col_bytes = (size_t)total * 4 + 64;  // +64: 16-byte group loads may run past the end
+  if (int rc = dev_alloc(seg, &p, col_bytes)) return rc;
+  g.d_docids = (uint32_t*)p;
+  HIP_TRY(hipMemset(g.d_docids, 0, col_bytes));
+  if (total) HIP_TRY(hipMemcpy(g.d_docids, docids, (size_t)total * 4, hipMemcpyHostToDevice));
+  if (freqs) {
+    if (int rc = dev_alloc(seg, &p, col_bytes)) return rc;
+    g.d_freqs = (uint32_t*)p;
+    g.has_freqs = true;
+    HIP_TRY(hipMemset(g.d_freqs, 0, col_bytes));
+    if (total) HIP_TRY(hipMemcpy(g.d_freqs, freqs, (size_t)total * 4, hipMemcpyHostToDevice));
+  }
+  if (int rc = dev_alloc(seg, &p, cells.size() * 4 + 64)) return rc;
+  g.d_cells = (uint32_t*)p;
+  HIP_TRY(hipMemcpy(g.d_cells, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
+  f.groups.push_back(g);
+  for (int64_t t = 0; t < n_terms; ++t) f.dict.emplace(term_hash[t], entries[(size_t)t]);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int32_t dim, int32_t n,
+                                          const int32_t* ord_to_doc, const float* row_major) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return fail(NRTGPU_ERR_STATE, "segment already sealed");
+  if (dim <= 0 || n < 0 || (n > 0 && !row_major)) return fail(NRTGPU_ERR_INVALID_ARG, "bad vector arguments");
+  if (n > seg->max_doc) return fail(NRTGPU_ERR_INVALID_ARG, "more vectors (%d) than docs (%d)", n, seg->max_doc);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  FieldData& f = seg->fields[field_id];
+  if (f.d_vectors) return fail(NRTGPU_ERR_STATE, "vectors of field %d already added", field_id);
+  f.dim = dim;
+  f.n_vec = n;
+  if (n == 0) return NRTGPU_OK;
+  void* p = nullptr;
+  if (int rc = dev_alloc(seg, &p, (size_t)n * dim * 4 + 256)) return rc;
+  f.d_vectors = (float*)p;
+  HIP_TRY(hipMemcpy(f.d_vectors, row_major, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+  if (ord_to_doc) {
+    if (int rc = dev_alloc(seg, &p, (size_t)n * 4)) return rc;
+    f.d_ord_to_doc = (int32_t*)p;
+    HIP_TRY(hipMemcpy(f.d_ord_to_doc, ord_to_doc, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return NRTGPU_OK;
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  // fold every posting's field-norm byte into its freq word: fnorm = (freq << 8) | norm
+  uint32_t* d_overflow = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_overflow, 4));
+  HIP_TRY(hipMemset(d_overflow, 0, 4));
+  int rc = NRTGPU_OK;
+  for (auto& kv : seg->fields) {
+    FieldData& f = kv.second;
+    for (auto& g : f.groups) {
+      if (g.d_fnorm) continue;
+      void* p = nullptr;
+      const size_t col_bytes = (size_t)g.n_postings * 4 + 64;
+      if ((rc = dev_alloc(seg, &p, col_bytes))) break;
+      g.d_fnorm = (uint32_t*)p;
+      hipError_t e = hipMemset(g.d_fnorm, 0, col_bytes);
+      if (e == hipSuccess) {
+        launch_fold_norms(nullptr, g.d_docids, g.d_freqs, f.d_norms, g.d_fnorm, g.n_postings, d_overflow);
+        e = hipGetLastError();
+      }
+      if (e != hipSuccess) {
+        rc = fail(NRTGPU_ERR_HIP, "fold_norms failed: %s", hipGetErrorString(e));
+        break;
+      }
+    }
+    if (rc) break;
+  }
+  uint32_t overflow = 0;
+  if (!rc) {
+    hipError_t e = hipMemcpy(&overflow, d_overflow, 4, hipMemcpyDeviceToHost);  // also syncs the null stream
+    if (e != hipSuccess) rc = fail(NRTGPU_ERR_HIP, "seal: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_overflow);
+  if (rc) return rc;
+  if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^24 does not fit the packed freq|norm column");
+  for (auto& kv : seg->fields)
+    for (auto& g : kv.second.groups)
+      if (g.d_freqs) {  // raw freq column no longer needed
+        (void)hipFree(g.d_freqs);
+        g.d_freqs = nullptr;
+        seg->device_bytes -= (int64_t)((size_t)g.n_postings * 4 + 64);
+      }
+  seg->sealed = true;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  const int32_t need = (seg->max_doc + 63) / 64;
+  if (!bits) {
+    if (seg->d_live) (void)hipFree(seg->d_live);
+    seg->d_live = nullptr;
+    return NRTGPU_OK;
+  }
+  if (n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "live bits: %d words given, %d needed", n_words, need);
+  if (!seg->d_live) {
+    void* p = nullptr;
+    if (int rc = dev_alloc(seg, &p, (size_t)need * 8)) return rc;
+    seg->d_live = (uint64_t*)p;
+  }
+  HIP_TRY(hipMemcpy(seg->d_live, bits, (size_t)need * 8, hipMemcpyHostToDevice));
+  return NRTGPU_OK;
+}
+
+extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
+  if (!seg) return;
+  (void)hipSetDevice(seg->ctx->device);
+  for (auto& kv : seg->fields) {
+    FieldData& f = kv.second;
+    if (f.d_norms) (void)hipFree(f.d_norms);
+    if (f.d_vectors) (void)hipFree(f.d_vectors);
+    if (f.d_ord_to_doc) (void)hipFree(f.d_ord_to_doc);
+    for (auto& g : f.groups) {
+      if (g.d_docids) (void)hipFree(g.d_docids);
+      if (g.d_freqs) (void)hipFree(g.d_freqs);
+      if (g.d_fnorm) (void)hipFree(g.d_fnorm);
+      if (g.d_cells) (void)hipFree(g.d_cells);
+    }
+  }
+  if (seg->d_live) (void)hipFree(seg->d_live);
+  delete seg;
+}
+
+extern "C" int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg) { return seg ? seg->device_bytes : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// plan building
+// ------------------------------------------------------------------------------------------------
+struct HostPlan {
+  std::vector<DQuery> queries;
+  std::vector<DItem> items;
+  std::vector<DTerm> terms;
+  std::vector<float> caches;
+  std::vector<uint32_t> list_idx;   // per query: item indices (merge input lists)
+  std::vector<uint32_t> q_base, q_nlists, q_k;
+  uint32_t k_stride = 0;
+  int64_t postings = 0;             // postings in the scanned term ranges (algorithmic work)
+};
+
+static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+static int validate_query(const nrtgpu_bm25_query& q, int qi) {
+  // LazyQueueTopScoreDocCollectorManager.java:90-98
+  if (q.k <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: numHits must be > 0; got %d", qi, q.k);
+  if (q.total_hits_threshold < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: totalHitsThreshold must be >= 0, got %d", qi, q.total_hits_threshold);
+  if (q.k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: numHits %d > %d", qi, q.k, NRTGPU_MAX_K);
+  if (q.n_terms <= 0 || !q.terms) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: no terms", qi);
+  if (q.n_terms > NRTGPU_MAX_TERMS) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d clauses > %d", qi, q.n_terms, NRTGPU_MAX_TERMS);
+  if (q.min_should_match > 1) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: minimumNumberShouldMatch %d", qi, q.min_should_match);
+  if (q.n_caches <= 0 || !q.norm_cache) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: norm_cache missing", qi);
+  for (int t = 0; t < q.n_terms; ++t) {
+    if (q.terms[t].cache_slot < 0 || q.terms[t].cache_slot >= q.n_caches)
+      return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: cache_slot out of range", qi, t);
+    if (!(q.terms[t].weight >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: weight must be >= 0", qi, t);
+  }
+  return 0;
+}
+
+static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp) {
+  uint32_t kmax = 1;
+  for (int qi = 0; qi < n_queries; ++qi) {
+    if (int rc = validate_query(queries[qi], qi)) return rc;
+    kmax = std::max<uint32_t>(kmax, (uint32_t)queries[qi].k);
+  }
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+    if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);
+    if (segs[si]->ctx != ctx) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d belongs to another context", si);
+  }
+  hp.k_stride = round_up(kmax, 16);
+  hp.queries.resize((size_t)n_queries);
+  hp.q_k.resize((size_t)n_queries);
+
+  // pass 1: resolve terms per (query, segment); remember posting counts
+  struct QS { uint32_t term_begin, n_terms; int32_t seg; int64_t postings; uint32_t cache_off, n_caches; };
+  std::vector<std::vector<QS>> per_query((size_t)n_queries);
+  int64_t total_postings = 0;
+  for (int qi = 0; qi < n_queries; ++qi) {
+    const nrtgpu_bm25_query& q = queries[qi];
+    const uint32_t cache_base = (uint32_t)hp.caches.size();
+    hp.caches.insert(hp.caches.end(), q.norm_cache, q.norm_cache + (size_t)q.n_caches * 256);
+    for (int si = 0; si < n_segs; ++si) {
+      const nrtgpu_seg* seg = segs[si];
+      QS qs{(uint32_t)hp.terms.size(), 0, si, 0, cache_base, (uint32_t)q.n_caches};
+      for (int t = 0; t < q.n_terms; ++t) {
+        const nrtgpu_term& qt = q.terms[t];
+        auto fit = seg->fields.find(qt.field_id);
+        if (fit == seg->fields.end()) continue;
+        const FieldData& f = fit->second;
+        auto it = f.dict.find(qt.term_hash);
+        if (it == f.dict.end() || it->second.count == 0) continue;
+        const TermEntry& e = it->second;
+        const TermGroup& g = f.groups[e.group];
+        DTerm d{};
+        d.docids = g.d_docids;
+        d.fnorm = g.d_fnorm;
+        d.cell_off = g.d_cells + e.cell_start;
+        d.start = e.start;
+        d.count = e.count;
+        d.shift = e.shift;
+        d.weight = qt.weight;
+        d.cache_off = cache_base + (uint32_t)qt.cache_slot * 256u;
+        d.cache_slot = (uint32_t)qt.cache_slot;
+        hp.terms.push_back(d);
+        qs.n_terms++;
+        qs.postings += e.count;
+      }
+      if (qs.n_terms > 0) {
+        per_query[(size_t)qi].push_back(qs);
+        total_postings += qs.postings;
+      }
+    }
+  }
+  hp.postings = total_postings;
+
+  // pass 2: cut every (query, segment) into doc-range items of roughly equal posting volume
+  int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : 4 * 2 * (int64_t)std::max(ctx->n_cus, 1);
+  const int64_t min_item_postings = 1 << 16;
+  const int64_t per_item = std::max<int64_t>(min_item_postings, total_postings / std::max<int64_t>(1, target_items));
+  struct Pending { uint32_t rank; uint32_t query; DItem item; };
+  std::vector<Pending> pend;
+  for (int qi = 0; qi < n_queries; ++qi) {
+    uint32_t rank = 0;
+    for (const QS& qs : per_query[(size_t)qi]) {
+      const nrtgpu_seg* seg = segs[qs.seg];
+      int64_t n_it = (qs.postings + per_item - 1) / per_item;
+      n_it = std::max<int64_t>(1, std::min<int64_t>(n_it, seg->n_tiles));
+      const uint32_t tiles_per = (uint32_t)((seg->n_tiles + n_it - 1) / n_it);
+      for (uint32_t tb = 0; tb < seg->n_tiles; tb += tiles_per) {
+        DItem it{};
+        it.live_bits = seg->d_live;
+        it.query = (uint32_t)qi;
+        it.term_begin = qs.term_begin;
+        it.n_terms = qs.n_terms;
+        it.tile_begin = tb;
+        it.tile_end = std::min<uint32_t>(seg->n_tiles, tb + tiles_per);
+        it.max_doc = (uint32_t)seg->max_doc;
+        it.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
+        it.cache_off = qs.cache_off;
+        it.n_caches = qs.n_caches;
+        pend.push_back({rank++, (uint32_t)qi, it});
+      }
+    }
+  }
+  // chunk-major launch order: the first doc range of every query runs before any second range,
+  // so later ranges start from the theta the earlier ones published.
+  std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.rank < b.rank; });
+  hp.items.resize(pend.size());
+  std::vector<std::vector<uint32_t>> lists((size_t)n_queries);
+  for (size_t i = 0; i < pend.size(); ++i) {
+    hp.items[i] = pend[i].item;
+    lists[pend[i].query].push_back((uint32_t)i);
+  }
+  hp.q_base.resize((size_t)n_queries);
+  hp.q_nlists.resize((size_t)n_queries);
+  for (int qi = 0; qi < n_queries; ++qi) {
+    const nrtgpu_bm25_query& q = queries[qi];
+    hp.q_base[(size_t)qi] = (uint32_t)hp.list_idx.size();
+    hp.q_nlists[(size_t)qi] = (uint32_t)lists[(size_t)qi].size();
+    hp.list_idx.insert(hp.list_idx.end(), lists[(size_t)qi].begin(), lists[(size_t)qi].end());
+    hp.q_k[(size_t)qi] = (uint32_t)q.k;
+    DQuery& dq = hp.queries[(size_t)qi];
+    dq.k = (uint32_t)q.k;
+    dq.has_after = q.has_after ? 1u : 0u;
+    dq.after_doc = q.after_doc;
+    dq.after_score = q.after_score;
+    dq.item_begin = hp.q_base[(size_t)qi];
+    dq.n_items = hp.q_nlists[(size_t)qi];
+  }
+  return 0;
+}
+
+// layout helper: carve 256-byte aligned regions out of one blob
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+struct DeviceRun {
+  // device pointers valid until the slot is reused
+  uint64_t* out_keys = nullptr;
+  uint32_t* out_counts = nullptr;
+  uint64_t* out_hits = nullptr;
+};
+
+// Enqueue plan upload + scan + merge on the slot's stream.  Merge output goes to (ext_keys,
+// ext_counts, ext_hits) when given (device-resident variant), else into the slot's scratch.
+static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
+                          uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run) {
+  const size_t n_items = hp.items.size();
+  Carver pc;
+  const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
+  const size_t o_items = pc.take(n_items * sizeof(DItem));
+  const size_t o_terms = pc.take(hp.terms.size() * sizeof(DTerm));
+  const size_t o_caches = pc.take(hp.caches.size() * sizeof(float));
+  const size_t o_lidx = pc.take(hp.list_idx.size() * 4);
+  const size_t o_qbase = pc.take(hp.q_base.size() * 4);
+  const size_t o_qnl = pc.take(hp.q_nlists.size() * 4);
+  const size_t o_qk = pc.take(hp.q_k.size() * 4);
+  const size_t plan_bytes = pc.off;
+  if (int rc = slot->h_plan.reserve(plan_bytes)) return rc;
+  if (int rc = slot->d_plan.reserve(plan_bytes)) return rc;
+  char* hb = (char*)slot->h_plan.p;
+  memcpy(hb + o_queries, hp.queries.data(), hp.queries.size() * sizeof(DQuery));
+  if (n_items) memcpy(hb + o_items, hp.items.data(), n_items * sizeof(DItem));
+  if (!hp.terms.empty()) memcpy(hb + o_terms, hp.terms.data(), hp.terms.size() * sizeof(DTerm));
+  memcpy(hb + o_caches, hp.caches.data(), hp.caches.size() * sizeof(float));
+  if (!hp.list_idx.empty()) memcpy(hb + o_lidx, hp.list_idx.data(), hp.list_idx.size() * 4);
+  memcpy(hb + o_qbase, hp.q_base.data(), hp.q_base.size() * 4);
+  memcpy(hb + o_qnl, hp.q_nlists.data(), hp.q_nlists.size() * 4);
+  memcpy(hb + o_qk, hp.q_k.data(), hp.q_k.size() * 4);
+
+  Carver wc;
+  const size_t o_theta = wc.take((size_t)n_queries * 8);
+  const size_t o_ikeys = wc.take(n_items * (size_t)hp.k_stride * 8);
+  const size_t o_icnt = wc.take(n_items * 4);
+  const size_t o_ihits = wc.take(n_items * 8);
+  const size_t o_okeys = wc.take((size_t)n_queries * k_stride_out * 8);
+  const size_t o_ocnt = wc.take((size_t)n_queries * 4);
+  const size_t o_ohits = wc.take((size_t)n_queries * 8);
+  if (int rc = slot->d_work.reserve(wc.off)) return rc;
+  char* db = (char*)slot->d_plan.p;
+  char* wb = (char*)slot->d_work.p;
+
+  hipStream_t st = slot->stream;
+  HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(wb + o_theta, 0, (size_t)n_queries * 8, st));
+  const bool timing = ctx->cfg.collect_timing != 0;
+  if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
+  launch_bm25_scan(st, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, (uint32_t)n_items, (const DItem*)(db + o_items), (const DTerm*)(db + o_terms),
+                   (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
+                   (unsigned long long*)(wb + o_theta), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
+                   (uint64_t*)(wb + o_ihits), hp.k_stride);
+  if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
+  uint64_t* okeys = ext_keys ? ext_keys : (uint64_t*)(wb + o_okeys);
+  uint32_t* ocnt = ext_counts ? ext_counts : (uint32_t*)(wb + o_ocnt);
+  uint64_t* ohits = ext_hits ? ext_hits : (uint64_t*)(wb + o_ohits);
+  launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)(wb + o_ikeys), (const uint32_t*)(wb + o_icnt),
+                    (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
+                    (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
+                    k_stride_out);
+  if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
+  HIP_TRY(hipGetLastError());
+  run->out_keys = okeys;
+  run->out_counts = ocnt;
+  run->out_hits = ohits;
+  return 0;
+}
+
+static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, double plan_ms) {
+  float scan_ms = 0.f, merge_ms = 0.f;
+  if (ctx->cfg.collect_timing) {
+    (void)hipEventElapsedTime(&scan_ms, slot->ev0, slot->ev1);
+    (void)hipEventElapsedTime(&merge_ms, slot->ev1, slot->ev2);
+  }
+  std::lock_guard<std::mutex> lk(ctx->stats_mu);
+  ctx->stats.batches += 1;
+  ctx->stats.queries += n_queries;
+  ctx->stats.scan_launches += hp.items.empty() ? 0 : 1;
+  ctx->stats.scan_ms += scan_ms;
+  ctx->stats.merge_ms += merge_ms;
+  ctx->stats.scan_postings += hp.postings;
+  ctx->stats.scan_items += (int64_t)hp.items.size();
+  ctx->stats.host_plan_ms += plan_ms;
+}
+
+// relation: GREATER_THAN_OR_EQUAL_TO exactly where LazyQueueTopScoreDocCollector would have started
+// publishing a min competitive score: totalHits > max(threshold, numHits) and the queue is full
+// (LazyQueueTopScoreDocCollector.java:176-199, …Manager.java:102).
+static inline int32_t relation_gte(int64_t total_hits, int32_t n_hits, int32_t k, int32_t threshold) {
+  const int64_t thr = std::max<int64_t>(threshold, k);
+  return (total_hits > thr && n_hits == k) ? 1 : 0;
+}
+
+static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, const int32_t k, const int32_t threshold,
+                           nrtgpu_topdocs* out) {
+  const int32_t cap = out->capacity > 0 ? out->capacity : k;
+  const int32_t m = std::min<int32_t>((int32_t)n, cap);
+  for (int32_t i = 0; i < m; ++i) {
+    if (out->docs) out->docs[i] = (int32_t)key_doc(keys[i]);
+    if (out->scores) out->scores[i] = key_score(keys[i]);
+  }
+  out->n_hits = m;
+  out->total_hits = (int64_t)hits;
+  out->total_hits_is_lower_bound = relation_gte((int64_t)hits, (int32_t)n, k, threshold);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI: search
+// ------------------------------------------------------------------------------------------------
+extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                        nrtgpu_topdocs* out) {
+  if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
+  if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  HostPlan hp;
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  const double plan_ms = now_ms() - t0;
+
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  DeviceRun run;
+  if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run)) return rc;
+  const size_t kb = (size_t)n_queries * hp.k_stride * 8, cb = (size_t)n_queries * 4, hb = (size_t)n_queries * 8;
+  Carver oc;
+  const size_t o_k = oc.take(kb), o_c = oc.take(cb), o_h = oc.take(hb);
+  if (int rc = slot->h_out.reserve(oc.off)) return rc;
+  char* ho = (char*)slot->h_out.p;
+  HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipStreamSynchronize(slot->stream));
+  const uint64_t* keys = (const uint64_t*)(ho + o_k);
+  const uint32_t* cnts = (const uint32_t*)(ho + o_c);
+  const uint64_t* hits = (const uint64_t*)(ho + o_h);
+  for (int qi = 0; qi < n_queries; ++qi)
+    unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, &out[qi]);
+  account(ctx, slot, hp, n_queries, plan_ms);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                  const nrtgpu_bm25_query* q, nrtgpu_topdocs* out) {
+  return nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, q, 1, out);
+}
+
+extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                               int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                               int32_t k_stride, void* d_keys, void* d_counts, void* d_hits) {
+  if (!ctx || !queries || !d_keys || !d_counts || !d_hits || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
+  if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  HostPlan hp;
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  if (k_stride < (int32_t)hp.k_stride && k_stride < NRTGPU_MAX_K) {
+    for (int qi = 0; qi < n_queries; ++qi)
+      if (queries[qi].k > k_stride) return fail(NRTGPU_ERR_INVALID_ARG, "k_stride %d smaller than numHits %d", k_stride, queries[qi].k);
+  }
+  const double plan_ms = now_ms() - t0;
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  DeviceRun run;
+  if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
+                              (uint64_t*)d_hits, &run))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(slot->stream));
+  account(ctx, slot, hp, n_queries, plan_ms);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride,
+                                        const void* d_keys_in, const void* d_counts_in, const void* d_hits_in,
+                                        const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
+  if (!ctx || !d_keys_in || !d_counts_in || !d_hits_in || !ks || !total_hits_thresholds || !out)
+    return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_lists <= 0 || n_queries <= 0 || k_stride <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad sizes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int qi = 0; qi < n_queries; ++qi)
+    if (ks[qi] <= 0 || ks[qi] > NRTGPU_MAX_K || ks[qi] > k_stride) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: bad k %d", qi, ks[qi]);
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  // plan blob: list_idx (n_queries * n_lists), q_base, q_nlists, q_k
+  const size_t nq = (size_t)n_queries, nl = (size_t)n_lists;
+  Carver pc;
+  const size_t o_lidx = pc.take(nq * nl * 4), o_qbase = pc.take(nq * 4), o_qnl = pc.take(nq * 4), o_qk = pc.take(nq * 4);
+  if (int rc = slot->h_plan.reserve(pc.off)) return rc;
+  if (int rc = slot->d_plan.reserve(pc.off)) return rc;
+  char* hb = (char*)slot->h_plan.p;
+  uint32_t* lidx = (uint32_t*)(hb + o_lidx);
+  uint32_t* qbase = (uint32_t*)(hb + o_qbase);
+  uint32_t* qnl = (uint32_t*)(hb + o_qnl);
+  uint32_t* qk = (uint32_t*)(hb + o_qk);
+  for (size_t q = 0; q < nq; ++q) {
+    qbase[q] = (uint32_t)(q * nl);
+    qnl[q] = (uint32_t)nl;
+    qk[q] = (uint32_t)ks[q];
+    for (size_t l = 0; l < nl; ++l) lidx[q * nl + l] = (uint32_t)(l * nq + q);
+  }
+  Carver wc;
+  const size_t o_okeys = wc.take(nq * (size_t)k_stride * 8), o_ocnt = wc.take(nq * 4), o_ohits = wc.take(nq * 8);
+  if (int rc = slot->d_work.reserve(wc.off)) return rc;
+  if (int rc = slot->h_out.reserve(wc.off)) return rc;
+  char* db = (char*)slot->d_plan.p;
+  char* wb = (char*)slot->d_work.p;
+  char* ho = (char*)slot->h_out.p;
+  hipStream_t st = slot->stream;
+  HIP_TRY(hipMemcpyAsync(db, hb, pc.off, hipMemcpyHostToDevice, st));
+  launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)d_keys_in, (const uint32_t*)d_counts_in,
+                    (const uint64_t*)d_hits_in, (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
+                    (const uint32_t*)(db + o_qnl), (uint32_t)k_stride, (const uint32_t*)(db + o_qk),
+                    (uint64_t*)(wb + o_okeys), (uint32_t*)(wb + o_ocnt), (uint64_t*)(wb + o_ohits), (uint32_t)k_stride);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ho, wb, wc.off, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t* keys = (const uint64_t*)(ho + o_okeys);
+  const uint32_t* cnts = (const uint32_t*)(ho + o_ocnt);
+  const uint64_t* hits = (const uint64_t*)(ho + o_ohits);
+  for (int qi = 0; qi < n_queries; ++qi)
+    unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], total_hits_thresholds[qi], &out[qi]);
+  return NRTGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI: host-side restatements
+// ------------------------------------------------------------------------------------------------
+extern "C" int32_t nrtgpu_int_to_byte4(int32_t length) { return hostmath::int_to_byte4(length); }
+extern "C" int32_t nrtgpu_byte4_to_int(int32_t b) { return hostmath::byte4_to_int(b); }
+extern "C" float nrtgpu_bm25_idf(int64_t doc_count, int64_t doc_freq) { return hostmath::bm25_idf(doc_count, doc_freq); }
+extern "C" float nrtgpu_bm25_avgdl(int64_t sttf, int64_t doc_count) { return hostmath::bm25_avgdl(sttf, doc_count); }
+extern "C" void nrtgpu_bm25_norm_cache(float avgdl, float k1, float b, float* out256) { hostmath::bm25_norm_cache(avgdl, k1, b, out256); }
+
+extern "C" int32_t nrtgpu_slices(int32_t n_leaves, const int32_t* max_docs, const int32_t* num_docs, const int32_t* doc_bases,
+                                 int32_t virtual_shards, int32_t slice_max_docs, int32_t slice_max_segments,
+                                 int32_t* slice_of_leaf, int32_t* shard_of_leaf) {
+  if (n_leaves < 0 || (n_leaves > 0 && (!max_docs || !slice_of_leaf))) return fail(NRTGPU_ERR_INVALID_ARG, "bad leaf arrays");
+  std::vector<hostmath::LeafInfo> all((size_t)n_leaves);
+  int32_t base = 0;
+  for (int32_t i = 0; i < n_leaves; ++i) {
+    all[(size_t)i] = {i, max_docs[i], num_docs ? num_docs[i] : max_docs[i], doc_bases ? doc_bases[i] : base};
+    base += max_docs[i];
+  }
+  std::vector<std::vector<int32_t>> sl;
+  std::vector<int32_t> shard;
+  if (virtual_shards > 1) {
+    sl = hostmath::slices_for_shards(all, virtual_shards, slice_max_docs, slice_max_segments, &shard);
+  } else {
+    sl = hostmath::slices(all, slice_max_docs, slice_max_segments, all);
+  }
+  for (size_t s = 0; s < sl.size(); ++s)
+    for (int32_t li : sl[s]) slice_of_leaf[li] = (int32_t)s;
+  if (shard_of_leaf)
+    for (int32_t i = 0; i < n_leaves; ++i) shard_of_leaf[i] = virtual_shards > 1 ? shard[(size_t)i] : 0;
+  return (int32_t)sl.size();
+}

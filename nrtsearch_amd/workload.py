@@ -1,0 +1,83 @@
+"""Benchmark / smoke workloads: the BASELINE.json configurations as code.
+
+C3 (north star): 10M docs, 5-term SHOULD disjunction, BM25, top-1000, default totalHitsThreshold.
+A rank of an N-GPU job owns a contiguous docid range of the index (large segments are split by
+docid range) cut into tiered segments; statistics stay index-global.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Sequence
+
+import numpy as np
+
+from . import api, synth
+
+
+@dataclasses.dataclass
+class Workload:
+    name: str
+    n_docs: int
+    n_terms: int
+    k: int
+    n_queries: int          # size of the query set the batches cycle through
+    segments_per_shard: int
+    max_rank: int = 10000
+
+
+C2 = Workload("C2: 1M docs, Zipf terms, 2-term BooleanQuery BM25 top-100", 1_000_000, 2, 100, 4096, 6)
+C3 = Workload("C3: 10M docs, 5-term disjunction BM25 top-1000", 10_000_000, 5, 1000, 4096, 10)
+SMOKE = Workload("smoke: 200k docs, 3-term disjunction top-100", 200_000, 3, 100, 8, 3, max_rank=2000)
+
+
+def shard_range(n_docs: int, world: int, rank: int):
+    """Contiguous docid range of `rank` (tile-aligned so no doc tile straddles two GPUs)."""
+    tile = 8192
+    per = ((n_docs + world - 1) // world + tile - 1) // tile * tile
+    lo = min(n_docs, rank * per)
+    hi = min(n_docs, lo + per)
+    return lo, hi
+
+
+def build_shard_corpus(w: Workload, queries: np.ndarray, world: int = 1, rank: int = 0, seed: int = 1234):
+    """Corpus restricted to this rank's docid range, with index-global statistics."""
+    ranks = sorted(set(int(r) for r in queries.reshape(-1)))
+    lens = synth.doc_lengths(w.n_docs, seed)
+    norms_all = synth.int_to_byte4(lens)
+    lo, hi = shard_range(w.n_docs, world, rank)
+    sizes = synth.tiered_segment_sizes(hi - lo, w.segments_per_shard) if hi > lo else []
+    bases = np.concatenate([[lo], lo + np.cumsum(sizes)]).astype(np.int64)
+    per_docs: List[List[np.ndarray]] = [[] for _ in sizes]
+    per_freqs: List[List[np.ndarray]] = [[] for _ in sizes]
+    doc_freq = {}
+    for r in ranks:
+        d, f = synth.term_postings(w.n_docs, r, seed)
+        doc_freq[r] = int(len(d))
+        cuts = np.searchsorted(d, bases)
+        for s in range(len(sizes)):
+            a, b = int(cuts[s]), int(cuts[s + 1])
+            per_docs[s].append((d[a:b] - bases[s]).astype(np.int32))
+            per_freqs[s].append(f[a:b])
+    segments = []
+    for s, size in enumerate(sizes):
+        counts = np.asarray([len(x) for x in per_docs[s]], dtype=np.int64)
+        segments.append(synth.SegmentData(
+            max_doc=int(size), doc_base=int(bases[s]), norms=norms_all[bases[s]: bases[s] + size].copy(),
+            term_ids=np.asarray(ranks, dtype=np.int64),
+            offsets=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64),
+            docids=np.ascontiguousarray(np.concatenate(per_docs[s]), dtype=np.int32),
+            freqs=np.ascontiguousarray(np.concatenate(per_freqs[s]), dtype=np.int32)))
+    return synth.Corpus(n_docs=w.n_docs, doc_count=w.n_docs, sum_total_term_freq=int(lens.astype(np.int64).sum()),
+                        segments=segments, doc_freq=doc_freq)
+
+
+def boolean_queries(query_ranks: np.ndarray) -> List[api.Query]:
+    out = []
+    for row in query_ranks:
+        cl = tuple(api.TermQuery(0, int(t)) for t in row)
+        out.append(cl[0] if len(cl) == 1 else api.BooleanQuery(cl))
+    return out
+
+
+def postings_per_query(corpus_doc_freq, query_ranks: np.ndarray) -> np.ndarray:
+    return np.asarray([sum(corpus_doc_freq[int(t)] for t in row) for row in query_ranks], dtype=np.int64)

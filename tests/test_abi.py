@@ -1,0 +1,136 @@
+"""CPU-only checks of the drop-in boundary: the library builds, loads, exports every symbol that
+include/nrtgpu.h declares, fails loudly without a GPU, and its host-side restatements (SmallFloat,
+BM25 statistics, slices) agree with the oracle / the reference's own tests."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nrtsearch_amd import _lib, api, build
+from tests.conftest import has_gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nrtgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nrtgpu_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(lib):
+    declared = _declared_symbols()
+    assert declared == sorted(_lib.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/nrtgpu.h but not exported"
+
+
+def test_version_string(lib):
+    assert b"gfx950" in lib.nrtgpu_version()
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_create_fails_loudly_without_gpu(lib):
+    h = C.c_void_p()
+    rc = lib.nrtgpu_create(None, C.byref(h))
+    assert rc == _lib.NRTGPU_ERR_HIP and not h
+    assert b"no CPU fallback" in lib.nrtgpu_last_error()
+    with pytest.raises(_lib.NrtGpuError):
+        api.GpuContext()
+
+
+def test_struct_sizes_match_header(lib):
+    # layout pinned on both sides of the boundary (x86-64 SysV)
+    assert C.sizeof(_lib.Config) == 24
+    assert C.sizeof(_lib.Term) == 24
+    assert C.sizeof(_lib.Bm25Query) == 56
+    assert C.sizeof(_lib.TopDocs) == 40
+    assert C.sizeof(_lib.Stats) == 64
+
+
+def test_host_smallfloat_matches_oracle(lib, oracle):
+    for v in list(range(0, 5000)) + [2**k + d for k in range(3, 31) for d in (-1, 0, 1)] + [2**31 - 1]:
+        assert lib.nrtgpu_int_to_byte4(v) == oracle.int_to_byte4(v)
+    for b in range(256):
+        assert lib.nrtgpu_byte4_to_int(b) == oracle.byte4_to_int(b)
+
+
+def test_host_bm25_statistics_match_oracle(lib, oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = int(rng.integers(1, 10**8))
+        df = int(rng.integers(1, n + 1))
+        assert np.float32(lib.nrtgpu_bm25_idf(n, df)) == oracle.bm25_idf(n, df)
+        sttf = int(rng.integers(n, 400 * n))
+        assert np.float32(lib.nrtgpu_bm25_avgdl(sttf, n)) == oracle.bm25_avgdl(sttf, n)
+    for avgdl in (2.0, 2.5, 4.0, 80.3, 1234.5):
+        got = np.zeros(256, np.float32)
+        lib.nrtgpu_bm25_norm_cache(C.c_float(avgdl), C.c_float(1.2), C.c_float(0.75), got.ctypes.data)
+        assert np.array_equal(got, oracle.bm25_norm_cache(avgdl))
+
+
+def test_similarity_golden_through_api(lib):
+    # SearchStateTest.java:117 through the product-side helpers (not the oracle)
+    sim = api.BM25Similarity()
+    cs = api.CollectionStatistics(doc_count=2, sum_total_term_freq=5)
+    w, cache = sim.scorer(1.0, cs, doc_freq=2)
+    ninv = cache[lib.nrtgpu_int_to_byte4(3)]
+    score = np.float32(w - w / (np.float32(1.0) + np.float32(1.0) * ninv))
+    assert score == np.float32(0.0766057)
+
+
+# ---- MyIndexSearcher.slices: src/test/java/com/yelp/nrtsearch/server/search/MyIndexSearcherTest.java
+def test_slices_packing_rules(lib):
+    # segments > sliceMaxDocs get their own slice; others packed until > maxDocs or >= maxSegments
+    sl, _ = api.slices([300_000, 10, 260_000, 20, 30, 40, 50, 60], slice_max_docs=250_000, slice_max_segments=5)
+    assert sl[0] == [0] and sl[1] == [2]
+    # sorted by maxDoc desc: 60,50,40,30,20 fill one 5-segment slice (leaves sorted by docBase inside), 10 is left
+    assert sl[2] == [3, 4, 5, 6, 7] and sl[3] == [1]
+    # docSum > maxDocsPerSlice closes the group
+    sl, _ = api.slices([100, 100, 100, 100], slice_max_docs=150, slice_max_segments=5)
+    assert sl == [[0, 1], [2, 3]]
+    assert api.slices([], slice_max_docs=10, slice_max_segments=5)[0] == []
+
+
+def test_virtual_shards_lpt(lib):
+    # greedy LPT on live docs (MyIndexSearcher.java:117-140): every leaf in exactly one shard, balanced
+    sizes = [5_000_000, 2_500_000, 1_250_000, 625_000, 312_500, 156_250, 78_125, 78_125]
+    sl, shard = api.slices(sizes, virtual_shards=4, slice_max_docs=250_000, slice_max_segments=5)
+    assert sorted(i for s in sl for i in s) == list(range(len(sizes)))
+    assert len(set(shard)) == 4
+    load = [sum(sizes[i] for i in range(len(sizes)) if shard[i] == s) for s in range(4)]
+    assert max(load) == 5_000_000            # the big segment alone
+    # slices ordered largest first (…:154-158)
+    tot = [sum(sizes[i] for i in s) for s in sl]
+    assert tot == sorted(tot, reverse=True)
+
+
+# ---- golden vectors: MyIndexSearcherTest.java:150-180 and MyIndexSearcherVirtualShardsTest.java:68-109
+def _shape(sizes, **kw):
+    sl, _ = api.slices(sizes, **kw)
+    return [sum(sizes[i] for i in s) for s in sl], [len(s) for s in sl]
+
+
+def test_reference_slice_golden_vectors(lib):
+    ten = [10] * 10
+    assert _shape(ten, slice_max_docs=25, slice_max_segments=10)[1] == [3, 3, 3, 1]       # testSliceDocsLimit
+    assert _shape(ten, slice_max_docs=1000, slice_max_segments=4)[1] == [4, 4, 2]        # testSliceSegmentsLimit
+    cases = [
+        (dict(virtual_shards=4, slice_max_docs=10000, slice_max_segments=100), [10] * 7, [20, 20, 20, 10], [2, 2, 2, 1]),
+        (dict(virtual_shards=4, slice_max_docs=10000, slice_max_segments=100), [10, 10], [10, 10], [1, 1]),
+        (dict(virtual_shards=4, slice_max_docs=10000, slice_max_segments=100), [], [], []),
+        (dict(virtual_shards=3, slice_max_docs=10000, slice_max_segments=100), list(range(1, 10)), [16, 15, 14], [3, 3, 3]),
+        (dict(virtual_shards=2, slice_max_docs=25, slice_max_segments=100), [10] * 9, [30, 30, 20, 10], [3, 3, 2, 1]),
+        (dict(virtual_shards=3, slice_max_docs=10000, slice_max_segments=2), [10, 10, 10, 10, 10, 10, 5, 4, 3],
+         [20, 20, 20, 5, 4, 3], [2, 2, 2, 1, 1, 1]),
+    ]
+    for kw, sizes, docs, segs in cases:
+        assert _shape(sizes, **kw) == (docs, segs), (kw, sizes)

@@ -1,0 +1,319 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle: docids/ranks, scores and hit
+counts must be bit-exact (integer / fp32-bit comparisons, no tolerance).  Needs a real MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nrtsearch_amd import _lib, api, synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+INT_MAX = 2**31 - 1
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _dump(name, payload):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, f"parity_fail_{name}.json"), "w") as f:
+            json.dump(payload, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+    except Exception:
+        pass
+
+
+def assert_same(name, got: api.TopDocs, exp, k, threshold):
+    edocs, escores, etotal, egte = exp
+    ok = (got.docs.tolist() == edocs.tolist()
+          and got.scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist()
+          and got.total_hits == etotal and got.relation_gte == egte)
+    if not ok:
+        nd = min(len(got.docs), len(edocs))
+        first = next((i for i in range(nd) if got.docs[i] != edocs[i] or
+                      got.scores[i].view(np.uint32) != escores[i].view(np.uint32)), nd)
+        _dump(name, dict(k=k, threshold=threshold, first_mismatch=first, n_got=len(got.docs), n_exp=len(edocs),
+                         got_docs=got.docs[max(0, first - 3): first + 5], exp_docs=edocs[max(0, first - 3): first + 5],
+                         got_scores=got.scores[max(0, first - 3): first + 5], exp_scores=escores[max(0, first - 3): first + 5],
+                         got_total=got.total_hits, exp_total=etotal, got_gte=got.relation_gte, exp_gte=egte))
+    assert got.total_hits == etotal, f"{name}: totalHits {got.total_hits} != {etotal}"
+    assert got.relation_gte == egte, f"{name}: relation"
+    assert got.docs.tolist() == edocs.tolist(), f"{name}: docids/ranks differ"
+    assert got.scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist(), f"{name}: score bits differ"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.GpuContext(device_id=0, max_batch=4096)
+    yield c
+    c.close()
+
+
+class Index:
+    """A synthetic corpus uploaded to the GPU + its searcher."""
+
+    def __init__(self, ctx, corpus, **kw):
+        self.corpus = corpus
+        self.leaves = [api.GpuSegment.from_data(ctx, s, **kw) for s in corpus.segments]
+        self.searcher = api.GpuIndexSearcher(ctx, self.leaves, api.IndexStatistics.from_corpus(corpus))
+
+    def close(self):
+        for l in self.leaves:
+            l.release()
+
+
+def bq(terms, boosts=None):
+    cl = []
+    for i, t in enumerate(terms):
+        q = api.TermQuery(0, int(t))
+        if boosts is not None:
+            q = api.BoostQuery(q, float(boosts[i]))
+        cl.append(q)
+    return cl[0] if len(cl) == 1 else api.BooleanQuery(tuple(cl))
+
+
+@pytest.fixture(scope="module")
+def mid(ctx):
+    ranks = [1, 2, 3, 5, 8, 13, 40, 100, 333, 1000, 5000, 9999]
+    corpus = synth.build_corpus(300_000, ranks, n_segments=4, delete_fraction=0.02)
+    ix = Index(ctx, corpus)
+    yield ix
+    ix.close()
+
+
+# ---- the reference's own golden values, now through the device -----------------------------------
+def _tiny_index(ctx, docs_terms, lengths):
+    """docs_terms: {term_id: [(doc, freq), ...]}."""
+    term_ids = sorted(docs_terms)
+    offs, d, f = [0], [], []
+    for t in term_ids:
+        for doc, fr in docs_terms[t]:
+            d.append(doc)
+            f.append(fr)
+        offs.append(len(d))
+    seg = synth.SegmentData(max_doc=len(lengths), doc_base=0, norms=synth.int_to_byte4(np.array(lengths)),
+                            term_ids=np.array(term_ids, np.int64), offsets=np.array(offs, np.int64),
+                            docids=np.array(d, np.int32), freqs=np.array(f, np.int32))
+    corpus = synth.Corpus(n_docs=len(lengths), doc_count=len(lengths), sum_total_term_freq=int(sum(lengths)),
+                          segments=[seg], doc_freq={t: len(docs_terms[t]) for t in term_ids})
+    return Index(ctx, corpus)
+
+
+def test_docker_compose_known_answer(ctx):
+    # docker-compose-config/docs.csv + search.json: "first vendor", "second vendor";
+    # query vendor_name:first OR vendor_name:vendor -> doc 0 (0.3979403), doc 1 (0.0828734)
+    FIRST, SECOND, VENDOR = 11, 12, 13
+    ix = _tiny_index(ctx, {FIRST: [(0, 1)], SECOND: [(1, 1)], VENDOR: [(0, 1), (1, 1)]}, [2, 2])
+    td = ix.searcher.search(bq([FIRST, VENDOR]), api.TopScoreDocCollectorManager(100))
+    assert td.docs.tolist() == [0, 1] and td.total_hits == 2 and not td.relation_gte
+    assert abs(float(td.scores[0]) - 0.3979403) < 1e-7 and abs(float(td.scores[1]) - 0.0828734) < 1e-7
+    ix.close()
+
+
+def test_search_state_golden(ctx):
+    # SearchStateTest.java:43-63,117: lastDocId 1, lastScore 0.0766057
+    VENDOR = 7
+    ix = _tiny_index(ctx, {VENDOR: [(0, 1), (1, 1)], 8: [(0, 1)], 9: [(1, 1)], 10: [(1, 1)]}, [2, 3])
+    td = ix.searcher.search(bq([VENDOR]), api.TopScoreDocCollectorManager(10))
+    assert td.docs.tolist() == [0, 1]
+    assert td.scores[1] == f32(0.0766057)
+    ix.close()
+
+
+def test_similarity_test_bm25_component(ctx):
+    # SimilarityTest.java:115-120: "first" freq 2 in doc 0, "vendor" in both, dl 4 -> 0.433217 + 0.0828734
+    FIRST, VENDOR = 1, 2
+    ix = _tiny_index(ctx, {FIRST: [(0, 2)], VENDOR: [(0, 1), (1, 1)], 3: [(0, 1)], 4: [(1, 2)], 5: [(1, 1)]}, [4, 4])
+    td = ix.searcher.search(bq([FIRST, VENDOR]), api.TopScoreDocCollectorManager(10))
+    assert td.docs.tolist() == [0, 1]
+    assert abs(float(td.scores[0]) - (12.12609 - 11.11 - 0.5)) < 1e-4
+    assert abs(float(td.scores[1]) - 0.0828734) < 1e-7
+    ix.close()
+
+
+# ---- randomized parity vs the oracle ---------------------------------------------------------------
+@pytest.mark.parametrize("k", [1, 10, 100, 1000, 1024])
+def test_disjunction_parity(mid, oracle, k):
+    rng = np.random.default_rng(k)
+    ranks = sorted(mid.corpus.doc_freq)
+    queries, mgrs, exps = [], [], []
+    for i in range(24):
+        n = int(rng.integers(1, 6))
+        terms = rng.choice(ranks, size=n, replace=False).tolist()
+        thr = [1000, INT_MAX, 0, 10][i % 4]
+        queries.append(bq(terms))
+        mgrs.append(api.TopScoreDocCollectorManager(k, None, thr))
+        exps.append((terms, thr, oracle.search_bm25(mid.corpus, terms, k, total_hits_threshold=thr)))
+    got = mid.searcher.search_batch(queries, mgrs)
+    for i, (terms, thr, exp) in enumerate(exps):
+        assert_same(f"disj_k{k}_{i}", got[i], exp, k, thr)
+
+
+def test_single_query_call_equals_batch(mid, oracle):
+    terms = [1, 40, 1000]
+    exp = oracle.search_bm25(mid.corpus, terms, 50)
+    got = mid.searcher.search(bq(terms), api.TopScoreDocCollectorManager(50))
+    assert_same("single", got, exp, 50, 1000)
+
+
+def test_boosts_and_duplicate_clauses(mid, oracle):
+    terms, boosts = [2, 2, 13, 333], [1.0, 2.5, 0.25, 7.0]
+    exp = oracle.search_bm25(mid.corpus, terms, 200, boosts=boosts, total_hits_threshold=INT_MAX)
+    got = mid.searcher.search(bq(terms, boosts), api.TopScoreDocCollectorManager(200, None, INT_MAX))
+    assert_same("boosts", got, exp, 200, INT_MAX)
+
+
+def test_missing_term_and_no_hits(mid, oracle):
+    got = mid.searcher.search(bq([777777]), api.TopScoreDocCollectorManager(10))
+    assert len(got.docs) == 0 and got.total_hits == 0 and not got.relation_gte
+    exp = oracle.search_bm25(mid.corpus, [777777, 9999], 10)
+    got = mid.searcher.search(bq([777777, 9999]), api.TopScoreDocCollectorManager(10))
+    assert_same("missing", got, exp, 10, 1000)
+
+
+def test_k_larger_than_matches(mid, oracle):
+    exp = oracle.search_bm25(mid.corpus, [9999], 1000)
+    got = mid.searcher.search(bq([9999]), api.TopScoreDocCollectorManager(1000))
+    assert len(exp[0]) < 1000
+    assert_same("k_gt_matches", got, exp, 1000, 1000)
+
+
+def test_search_after_paging(mid, oracle):
+    # RelevanceCollectorITest.java:117-190: pages concatenate to the full ranking, no dup, no gap
+    terms = [3, 100]
+    full = oracle.search_bm25(mid.corpus, terms, 1000, total_hits_threshold=INT_MAX)
+    after, seen_docs, seen_scores = None, [], []
+    for page in range(6):
+        mgr = api.TopScoreDocCollectorManager(37, after, INT_MAX)
+        got = mid.searcher.search(bq(terms), mgr)
+        exp = oracle.search_bm25(mid.corpus, terms, 37, after=(after.doc, after.score) if after else None,
+                                 total_hits_threshold=INT_MAX)
+        assert_same(f"after_{page}", got, exp, 37, INT_MAX)
+        seen_docs += got.docs.tolist()
+        seen_scores += got.scores.tolist()
+        after = api.ScoreDoc(int(got.docs[-1]), float(got.scores[-1]))
+    assert seen_docs == full[0][: len(seen_docs)].tolist()
+    assert seen_scores == full[1][: len(seen_scores)].tolist()
+
+
+def test_ties_rank_by_docid(ctx, oracle):
+    # TotalHitsThresholdTest.java:43-51,72-99: equal scores => ascending docid.  ATOM-like field:
+    # freqs and norms omitted => every matching doc has the same score.
+    corpus = synth.build_corpus(100_000, [2, 50], n_segments=2)
+    ix = Index(ctx, corpus, omit_norms=True, omit_freqs=True)
+    for terms, k in [([2], 100), ([2, 50], 1000), ([50], 7)]:
+        exp = oracle.search_bm25(corpus, terms, k, omit_norms=True, omit_freqs=True, total_hits_threshold=INT_MAX)
+        got = ix.searcher.search(bq(terms), api.TopScoreDocCollectorManager(k, None, INT_MAX))
+        assert_same(f"ties_{terms}", got, exp, k, INT_MAX)
+        if len(terms) == 1:
+            assert len(set(got.scores.tolist())) == 1 and got.docs.tolist() == sorted(got.docs.tolist())
+    ix.close()
+
+
+def test_ragged_shapes(ctx, oracle):
+    # max_doc not a multiple of the tile, one-doc segment, postings only in the last tile
+    for n_docs, nseg in [(1, 1), (8191, 1), (8193, 1), (20_000, 3), (70_001, 5)]:
+        corpus = synth.build_corpus(n_docs, [1, 3, 9], n_segments=nseg, delete_fraction=0.1 if n_docs > 1 else 0.0)
+        ix = Index(ctx, corpus)
+        for terms in ([1], [1, 3, 9]):
+            exp = oracle.search_bm25(corpus, terms, 64, total_hits_threshold=INT_MAX)
+            got = ix.searcher.search(bq(terms), api.TopScoreDocCollectorManager(64, None, INT_MAX))
+            assert_same(f"ragged_{n_docs}_{len(terms)}", got, exp, 64, INT_MAX)
+        ix.close()
+
+
+def test_chunking_and_prefetch_invariance(mid, oracle):
+    # the result must not depend on how the doc space is cut into items nor on the kernel variant
+    terms = [1, 5, 100, 5000]
+    exp = oracle.search_bm25(mid.corpus, terms, 1000)
+    for target_items, flags in [(1, 0), (64, 0), (4096, 0), (0, _lib.NRTGPU_FLAG_NO_PREFETCH), (4096, _lib.NRTGPU_FLAG_NO_PREFETCH)]:
+        c2 = api.GpuContext(0, 64, target_items=target_items, flags=flags)
+        leaves = [api.GpuSegment.from_data(c2, s) for s in mid.corpus.segments]
+        sr = api.GpuIndexSearcher(c2, leaves, api.IndexStatistics.from_corpus(mid.corpus))
+        got = sr.search(bq(terms), api.TopScoreDocCollectorManager(1000))
+        assert_same(f"chunk_{target_items}_{flags}", got, exp, 1000, 1000)
+        for l in leaves:
+            l.release()
+        c2.close()
+
+
+def test_many_fields_use_global_cache_path(ctx, oracle):
+    # 3 fields => the third normInverse table is read from HBM instead of LDS
+    corpus = synth.build_corpus(50_000, [1, 4, 20], n_segments=1)
+    seg = corpus.segments[0]
+    g = api.GpuSegment(ctx, seg.max_doc, 0)
+    stats = api.IndexStatistics()
+    for field in range(3):
+        g.add_field_norms(field, seg.norms)
+        g.add_terms(field, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+        stats.fields[field] = api.CollectionStatistics(corpus.doc_count, corpus.sum_total_term_freq * (field + 1))
+        for t, df in corpus.doc_freq.items():
+            stats.doc_freq[(field, t)] = df
+    g.seal()
+    sr = api.GpuIndexSearcher(ctx, [g], stats)
+    q = api.BooleanQuery((api.TermQuery(0, 1), api.TermQuery(1, 4), api.TermQuery(2, 20)))
+    got = sr.search(q, api.TopScoreDocCollectorManager(100, None, INT_MAX))
+    # oracle: same three terms, each with its own field statistics
+    from oracle import oracle as o
+    col = o.Collector(100, None, INT_MAX)
+    import ctypes as C
+    arr = (o._Term * 3)()
+    keep = []
+    for i, (field, t) in enumerate([(0, 1), (1, 4), (2, 20)]):
+        d, f = seg.postings(t)
+        d = np.ascontiguousarray(d); f = np.ascontiguousarray(f)
+        cs = stats.fields[field]
+        cache = o.bm25_norm_cache(float(o.bm25_avgdl(cs.sum_total_term_freq, cs.doc_count)))
+        keep += [d, f, cache]
+        arr[i].docids, arr[i].freqs, arr[i].n = d.ctypes.data, f.ctypes.data, len(d)
+        arr[i].weight = float(o.bm25_idf(cs.doc_count, corpus.doc_freq[t]))
+        arr[i].norms, arr[i].cache = seg.norms.ctypes.data, cache.ctypes.data
+    o.lib().nrt_oracle_search_segment(seg.max_doc, 0, None, 3, C.byref(arr), col._h)
+    assert_same("fields3", got, col.topdocs(), 100, INT_MAX)
+    g.release()
+
+
+def test_argument_errors(mid):
+    # LazyQueueTopScoreDocCollectorManager.java:90-98 -> IllegalArgumentException
+    with pytest.raises(api.NrtGpuError) as e:
+        mid.searcher.search(bq([1]), api.TopScoreDocCollectorManager(0))
+    assert e.value.code == _lib.NRTGPU_ERR_INVALID_ARG
+    with pytest.raises(api.NrtGpuError) as e:
+        mid.searcher.search(bq([1]), api.TopScoreDocCollectorManager(10, None, -1))
+    assert e.value.code == _lib.NRTGPU_ERR_INVALID_ARG
+    with pytest.raises(api.NrtGpuError) as e:   # beyond the device fast path: caller falls back to Lucene
+        mid.searcher.search(bq([1]), api.TopScoreDocCollectorManager(5000))
+    assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
+    with pytest.raises(api.UnsupportedQuery):
+        mid.searcher.search(api.BooleanQuery((api.TermQuery(0, 1), api.TermQuery(0, 2)), 2),
+                            api.TopScoreDocCollectorManager(5))
+
+
+def test_unsealed_segment_is_a_state_error(ctx):
+    g = api.GpuSegment(ctx, 10, 0)
+    st = api.IndexStatistics()
+    st.fields[0] = api.CollectionStatistics(10, 40)
+    st.doc_freq[(0, 1)] = 1
+    sr = api.GpuIndexSearcher(ctx, [g], st)
+    with pytest.raises(api.NrtGpuError) as e:
+        sr.search(bq([1]), api.TopScoreDocCollectorManager(5))
+    assert e.value.code == _lib.NRTGPU_ERR_STATE
+    g.release()
+
+
+def test_live_docs_update_after_seal(ctx, oracle):
+    corpus = synth.build_corpus(40_000, [1, 6], n_segments=1)
+    ix = Index(ctx, corpus)
+    exp = oracle.search_bm25(corpus, [1, 6], 20, total_hits_threshold=INT_MAX)
+    assert_same("live0", ix.searcher.search(bq([1, 6]), api.TopScoreDocCollectorManager(20, None, INT_MAX)), exp, 20, INT_MAX)
+    # delete the current top hit: only liveDocs change between reader versions of one segment
+    top = int(exp[0][0])
+    bits = np.full((40_000 + 63) // 64, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    bits[top >> 6] &= ~np.uint64(1 << (top & 63))
+    corpus.segments[0].live_bits = bits
+    ix.leaves[0].set_live_docs(bits)
+    exp2 = oracle.search_bm25(corpus, [1, 6], 20, total_hits_threshold=INT_MAX)
+    got2 = ix.searcher.search(bq([1, 6]), api.TopScoreDocCollectorManager(20, None, INT_MAX))
+    assert top not in got2.docs.tolist() and exp2[2] == exp[2] - 1
+    assert_same("live1", got2, exp2, 20, INT_MAX)
+    ix.close()
