@@ -69,8 +69,8 @@ __device__ __forceinline__ double unmatched_value() { return __longlong_as_doubl
 // Keep the k best candidates, raise theta, publish it for the other items of the same query
 // (the analogue of LazyMaxScoreAccumulator.accumulate, /root/reference/src/main/java/org/apache/
 // lucene/search/LazyMaxScoreAccumulator.java:53-57).  Uniform call; ends synchronised.
-__device__ __noinline__ void scan_compact(ScanSmem& s, uint32_t k, unsigned long long* theta_g) {
-  const uint32_t n = s.cnt;
+// `n` must be the caller's barrier-protected snapshot of s.cnt; returns the new count (uniform).
+__device__ __noinline__ uint32_t scan_compact(ScanSmem& s, uint32_t n, uint32_t k, unsigned long long* theta_g) {
   uint64_t thr = 0;
   const uint32_t m = topk_compact<kScanThreads, kCandCap>(s.cand, n, k, &s.sc, &thr);
   if (n > k && threadIdx.x == 0) {
@@ -79,6 +79,7 @@ __device__ __noinline__ void scan_compact(ScanSmem& s, uint32_t k, unsigned long
     atomicMax(theta_g, (unsigned long long)thr);
   }
   __syncthreads();
+  return m;
 }
 
 // One 4-posting group: which term, where, and (once loaded) its two column words.
@@ -305,9 +306,11 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DTerm* __restrict__
 
     // ---- (4) collect the competitive docs into the LDS candidate buffer
     const uint32_t tc = s.tile_cand;
-    if (tc > 0) {  // uniform
-      if (s.cnt + tc > (uint32_t)kCandCap) scan_compact(s, k, my_theta_g);  // raises theta
-      const bool flood = (s.cnt + tc > (uint32_t)kCandCap);                 // uniform (cnt re-read after a barrier)
+    uint32_t cnt0 = s.cnt;
+    __syncthreads();  // (B2) every thread holds the same (tc, cnt0) before anyone appends
+    if (tc > 0) {     // uniform
+      if (cnt0 + tc > (uint32_t)kCandCap) cnt0 = scan_compact(s, cnt0, k, my_theta_g);  // raises theta
+      const bool flood = (cnt0 + tc > (uint32_t)kCandCap);                               // uniform
       if (!flood) {
 #pragma unroll 1
         for (int j = 0; j < kPerThread; ++j) {
@@ -340,7 +343,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DTerm* __restrict__
           __syncthreads();
           const uint32_t c = s.cnt;
           __syncthreads();  // everyone has read cnt before the next step appends
-          if (c > (uint32_t)(kCandCap - kFloodStep)) scan_compact(s, k, my_theta_g);
+          if (c > (uint32_t)(kCandCap - kFloodStep)) scan_compact(s, c, k, my_theta_g);
         }
       }
     }
@@ -350,7 +353,11 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DTerm* __restrict__
 
   // ---- item epilogue: final top-k of the item, hit count
   __syncthreads();
-  if (s.cnt > k) scan_compact(s, k, my_theta_g);
+  {
+    const uint32_t c = s.cnt;
+    __syncthreads();
+    if (c > k) scan_compact(s, c, k, my_theta_g);
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) my_hits += __shfl_xor(my_hits, d, 64);
   if (lane_id() == 0 && my_hits) atomicAdd(&s.hits, my_hits);
@@ -378,8 +385,7 @@ struct MergeSmem {
   uint32_t pad;
 };
 
-__device__ __noinline__ void merge_compact(MergeSmem& s, uint32_t k) {
-  const uint32_t n = s.cnt;
+__device__ __noinline__ void merge_compact(MergeSmem& s, uint32_t n, uint32_t k) {
   uint64_t thr = 0;
   const uint32_t m = topk_compact<kScanThreads, kMergeCap>(s.cand, n, k, &s.sc, &thr);
   if (n > k && threadIdx.x == 0) {
@@ -424,11 +430,15 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
       __syncthreads();
       const uint32_t cn = s.cnt;
       __syncthreads();
-      if (cn > (uint32_t)(kMergeCap - kScanThreads)) merge_compact(s, k);
+      if (cn > (uint32_t)(kMergeCap - kScanThreads)) merge_compact(s, cn, k);
     }
   }
   __syncthreads();
-  if (s.cnt > k) merge_compact(s, k);
+  {
+    const uint32_t c = s.cnt;
+    __syncthreads();
+    if (c > k) merge_compact(s, c, k);
+  }
   const uint32_t n = s.cnt;
   uint32_t n2 = 1;
   while (n2 < n) n2 <<= 1;

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""One-process GPU sweep (no torch): builds the C3 corpus once, checks parity at full size against
+the oracle on a few queries, then times kernel variants / chunkings / batch sizes through the C ABI.
+Prints one JSON line per variant; everything is flushed so a crash shows how far it got."""
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from nrtsearch_amd import _lib, api, synth, workload  # noqa: E402
+
+
+def log(*a):
+    print(*a, flush=True)
+
+
+def checksum(pb, n):
+    h = 0
+    for qi in range(n):
+        td = pb.topdocs(qi)
+        h = zlib.crc32(td.docs.tobytes(), h)
+        h = zlib.crc32(td.scores.tobytes(), h)
+        h = zlib.crc32(np.int64(td.total_hits).tobytes(), h)
+    return h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--queries", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--oracle-queries", type=int, default=6)
+    ap.add_argument("--variants", default="0:0:1024,0:1:1024,1024:0:1024,8192:0:1024,0:0:256,0:0:64,0:0:1",
+                    help="comma list of target_items:flags:batch")
+    args = ap.parse_args()
+
+    w = workload.C3
+    w.n_docs = args.docs
+    t0 = time.time()
+    qr = synth.make_queries(args.queries, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr)
+    ppq = workload.postings_per_query(corpus.doc_freq, qr)
+    log(json.dumps({"event": "corpus", "docs": w.n_docs, "postings": corpus.total_postings, "build_s": round(time.time() - t0, 1),
+                    "mean_P": float(ppq.mean())}))
+    queries = workload.boolean_queries(qr)
+    mgr = api.TopScoreDocCollectorManager(w.k)
+    ref_sum = {}
+    for vi, v in enumerate(args.variants.split(",")):
+        ti, fl, B = (int(x) for x in v.split(":"))
+        ctx = api.GpuContext(0, max_batch=max(B, 8), target_items=ti, collect_timing=True, flags=fl)
+        leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        if vi == 0 and args.oracle_queries:
+            from oracle import oracle
+            n = args.oracle_queries
+            got = sr.search_batch(queries[:n], [mgr] * n)
+            bad = 0
+            for qi in range(n):
+                d, s_, tot, gte = oracle.search_bm25(corpus, qr[qi].tolist(), w.k)
+                ok = (got[qi].docs.tolist() == d.tolist() and got[qi].scores.view(np.uint32).tolist() == s_.view(np.uint32).tolist()
+                      and got[qi].total_hits == tot and got[qi].relation_gte == gte)
+                bad += (not ok)
+                if not ok:
+                    log(json.dumps({"event": "MISMATCH", "query": qi, "got_total": got[qi].total_hits, "exp_total": tot,
+                                    "got_n": len(got[qi].docs), "exp_n": len(d),
+                                    "first_docs_got": got[qi].docs[:5].tolist(), "first_docs_exp": d[:5].tolist()}))
+            log(json.dumps({"event": "oracle_parity_full_size", "queries": n, "mismatches": bad}))
+        nb = max(1, min(4, args.queries // B))
+        pbs = [api.PreparedBatch(sr, queries[i * B:(i + 1) * B], [mgr] * B) for i in range(nb)]
+        pbs[0].run()  # warm
+        cs = checksum(pbs[0], B)
+        key = B
+        if key in ref_sum and ref_sum[key] != cs:
+            log(json.dumps({"event": "CHECKSUM_MISMATCH", "variant": v}))
+        ref_sum.setdefault(key, cs)
+        ctx.reset_stats()
+        lat = []
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            ts = time.perf_counter()
+            pbs[i % nb].run()
+            lat.append(time.perf_counter() - ts)
+        dt = time.perf_counter() - t1
+        st = ctx.stats()
+        L = max(1, st["scan_launches"])
+        scan_ms = st["scan_ms"] / L
+        bytes_l = st["scan_postings"] / L * 8
+        log(json.dumps({"event": "variant", "target_items": ti, "flags": fl, "batch": B, "qps": round(args.steps * B / dt, 1),
+                        "ms_per_step": round(dt / args.steps * 1e3, 3), "p50_ms": round(float(np.median(lat)) * 1e3, 3),
+                        "scan_ms": round(scan_ms, 3), "merge_ms": round(st["merge_ms"] / L, 3),
+                        "plan_ms": round(st["host_plan_ms"] / L, 3), "items": st["scan_items"] / L,
+                        "GBps_scan": round(bytes_l / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else None,
+                        "checksum": cs}))
+        for l in leaves:
+            l.release()
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()
