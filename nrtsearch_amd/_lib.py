@@ -18,7 +18,7 @@ NRTGPU_ERR_UNSUPPORTED = -4
 NRTGPU_ERR_STATE = -5
 NRTGPU_MAX_K = 1024
 NRTGPU_MAX_TERMS = 32
-NRTGPU_TILE_DOCS = 8192
+NRTGPU_TILE_DOCS = 768
 NRTGPU_FLAG_NO_PREFETCH = 1
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "nrtgpu_merge_topk_device",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_get_stats", "nrtgpu_reset_stats",
+    "nrtgpu_get_scan_profile",
 ]
 
 
@@ -114,6 +115,7 @@ def load() -> C.CDLL:
     L.nrtgpu_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.nrtgpu_reset_stats.argtypes = [vp]
     L.nrtgpu_reset_stats.restype = None
+    L.nrtgpu_get_scan_profile.argtypes = [vp, vp]
     _lib = L
     return L
 

@@ -143,6 +143,14 @@ class GpuContext:
         _lib.check(_lib.load().nrtgpu_get_stats(self._h, C.byref(st)))
         return {n: getattr(st, n) for n, _ in _lib.Stats._fields_}
 
+    def scan_profile(self) -> dict:
+        out = np.zeros(16, dtype=np.float64)
+        _lib.check(_lib.load().nrtgpu_get_scan_profile(self._h, out.ctypes.data))
+        names = ["acc_cycles", "waitA_cycles", "sweep_cycles", "waitC_cycles", "slow_cycles", "slow_entries",
+                 "compactions", "tiles", "first_instrs", "dense_instrs", "flat_instrs", "exact_iters",
+                 "collects", "maybe_subtiles", "r14", "r15"]
+        return dict(zip(names, out.tolist()))
+
     def reset_stats(self) -> None:
         _lib.load().nrtgpu_reset_stats(self._h)
 

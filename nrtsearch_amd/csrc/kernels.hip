@@ -17,9 +17,11 @@
 // the LDS tile; the sum of a few fp32 values is exact in fp64, hence order-independent) and the
 // sum is rounded once to fp32.
 //
-// HBM layout: per upload group two u32 columns, docid[] and fnorm[] = (freq << 8) | normByte, both
-// read with coalesced 16 B/lane non-temporal loads; the per-doc norm gather of the reference
-// (norms.longValue() per posting) is paid once at seal time instead of per query.
+// HBM layout: per upload group two u32 columns, docid[] and code[] (freq and the doc's norm byte
+// folded into one word at seal time), both read with coalesced 16 B/lane non-temporal loads; the
+// per-doc norm gather of the reference (norms.longValue() per posting) is paid once at seal.
+// Scoring: (freq, norm byte) is a tiny domain, so each item builds the BM25 scores of its densest
+// terms once (same float ops, bit-exact) into LDS tables and a posting costs one table read.
 // Roofline: HBM.  Bytes the kernel must move per posting = 4 (docid) + 4 (freq|norm) = 8.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,169 +38,272 @@ typedef const NRT_GLOBAL uint32_t* gu32_ptr;
 typedef const NRT_GLOBAL float* gf32_ptr;
 
 constexpr uint64_t kUnmatched = 0x8000000000000000ull;  // -0.0: "no term matched this doc yet"
-constexpr int kPerThread = kTileDocs / kScanThreads;     // 16 accumulator slots per thread
-constexpr int kPrefetch = 2;                             // posting groups per thread loaded one tile ahead
 
+
+// Work decomposition (v6): a workgroup is 8 AUTONOMOUS waves.  Wave w of an item walks the 512-doc
+// sub-tiles w, w+8, w+16, ... of each part on its own: load postings -> fp64 accumulate into its
+// private 4 KiB LDS sub-tile -> sweep it -> collect competitive docs into the workgroup's shared
+// candidate buffer.  No workgroup barrier in steady state: 16 waves per CU sit at different points
+// of that chain and hide each other's LDS / HBM latency.  Per-term metadata of a sub-tile lives in
+// lane registers (lane l <-> term l) and is exchanged with wave shuffles.  Barriers happen only at a
+// rendezvous when the shared candidate buffer overflows (top-k compaction) and between parts.
 struct ScanSmem {
-  double   acc[kTileDocs];                 // fp64 score accumulators of the current doc tile (64 KiB)
-  uint64_t cand[kCandCap];                 // competitive hits (packed keys), unordered (10 KiB)
-  float    cache[kLdsCaches][256];         // BM25 normInverse tables of the query's first fields
-  uint64_t t_docids[kMaxTerms];            // global addresses (kept as integers: LDS strips address spaces)
-  uint64_t t_fnorm[kMaxTerms];
-  uint64_t t_celloff[kMaxTerms];
-  uint64_t t_cache[kMaxTerms];             // global normInverse table (fields beyond kLdsCaches)
-  uint64_t t_lo[kMaxTerms];                // [t_lo, t_hi): the term's postings inside the columns
-  uint64_t t_hi[kMaxTerms];
-  float    t_weight[kMaxTerms];
-  uint32_t t_shift[kMaxTerms];
-  uint32_t t_slot[kMaxTerms];              // cache table index
-  uint64_t g_start[2][kMaxTerms];          // first 4-posting group of the term in the tile (parity buffered)
-  uint32_t g_prefix[2][kMaxTerms + 1];     // groups of terms 0..t-1 in the tile
+  double   acc[kScanWaves][kTileDocs];     // fp64 score accumulators: one 512-doc sub-tile per wave (32 KiB)
+  uint64_t cand[kCandCap];                 // competitive hits of the item (packed keys), unordered (16 KiB)
+  float    tab[kTabTerms][kTabEntries];    // BM25 score of (freq, norm byte) for the item's densest terms
+  float    cache[kLdsCaches][256];         // BM25 normInverse tables of the query's fields (division path)
+  float    t_weight[kMaxTerms];            // division path: per term of the current part
+  uint32_t t_slot[kMaxTerms];
+  // wave-private view of the wave's current sub-tile, written by lanes 0..31 (lane l <-> term l):
+  alignas(16) uint32_t w_incl[kScanWaves][kMaxTerms];     // 8-posting pairs of terms 0..l (inclusive prefix)
+  alignas(16) uint32_t w_rec[kScanWaves][kMaxTerms][4];   // addr_d lo, addr_d hi, delta16, meta
+  uint32_t w_before[kScanWaves][kMaxTerms];               // pairs of terms 0..l-1
   TopkScratch sc;
-  uint64_t theta;      // packed key of the k-th best hit seen so far (0 = none)
-  uint32_t cnt;        // valid entries in cand
-  uint32_t tile_cand;  // competitive hits found in the current tile
-  uint32_t hits;       // live matching docs of this item
+  uint64_t theta;        // packed key of the k-th best hit seen so far (0 = none)
+  uint32_t cnt;          // valid entries in cand
+  uint32_t tile_cand;    // rendezvous: competitive hits still parked in the accumulators
+  uint32_t hits;         // live matching docs of this item
+  uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet at the rendezvous
+  uint32_t done;         // waves that finished the current part
   uint32_t pad;
+  uint64_t prof[16];     // instrumented variant only (ABL == 7)
 };
-static_assert(sizeof(ScanSmem) <= 80 * 1024, "two scan workgroups must fit in one CU's 160 KiB LDS");
+static_assert(sizeof(ScanSmem) <= 160 * 1024, "the scan workgroup owns one CU's 160 KiB LDS");
+
+constexpr int kSlots = kTileDocs / 64;  // accumulator slots per lane
 
 __device__ __forceinline__ uint64_t dbl_bits(double d) { return (uint64_t)__double_as_longlong(d); }
 __device__ __forceinline__ double unmatched_value() { return __longlong_as_double((long long)kUnmatched); }
 
-// Keep the k best candidates, raise theta, publish it for the other items of the same query
-// (the analogue of LazyMaxScoreAccumulator.accumulate, /root/reference/src/main/java/org/apache/
-// lucene/search/LazyMaxScoreAccumulator.java:53-57).  Uniform call; ends synchronised.
-// `n` must be the caller's barrier-protected snapshot of s.cnt; returns the new count (uniform).
-__device__ __noinline__ uint32_t scan_compact(ScanSmem& s, uint32_t n, uint32_t k, unsigned long long* theta_g) {
-  uint64_t thr = 0;
-  const uint32_t m = topk_compact<kScanThreads, kCandCap>(s.cand, n, k, &s.sc, &thr);
-  if (n > k && threadIdx.x == 0) {
-    s.cnt = m;
-    if (thr > s.theta) s.theta = thr;
-    atomicMax(theta_g, (unsigned long long)thr);
-  }
-  __syncthreads();
-  return m;
+// BM25Similarity SimScorer.score(freq, norm): weight - weight / (1f + freq * normInverse),
+// one IEEE rounding per operation (no contraction, correctly rounded division).
+__device__ __forceinline__ float bm25_score(float w, float freq, float ninv) {
+  const float prod = freq * ninv;
+  const float den = 1.0f + prod;
+  const float quo = w / den;
+  return w - quo;
 }
 
-// One 4-posting group: which term, where, and (once loaded) its two column words.
+// Inclusive prefix sum over lanes 0..31 with DPP row shifts (VALU only, no LDS-pipe traffic).
+__device__ __forceinline__ uint32_t scan32_dpp(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1, 3
+  return x;
+}
+
+// Per-term view of one sub-tile, built by lane l for term l and published in the wave's LDS table.
+//   meta: 16-byte groups (bits 0-19) | first valid posting (20-22) | last valid + 1 (23-25) |
+//         score table (26-28, 7 = none) | coarse cell: postings may lie outside the sub-tile (29)
+// A lane processes a PAIR of consecutive groups (8 postings) per instruction.
+constexpr uint32_t kMetaGroups = 0xFFFFFu;
+
+// Lane-as-term: posting range [lo, hi) of my term in a sub-tile -> table entry; returns the number of
+// pair-instructions lanes of the whole sub-tile (wave-uniform).
+__device__ __forceinline__ uint32_t subtile_build(ScanSmem& s, uint32_t wave, uint32_t lane, uint64_t my_docids,
+                                                  uint32_t my_delta16, uint64_t my_lo, uint32_t my_flags, uint32_t lo,
+                                                  uint32_t hi, bool use) {
+  uint32_t ng = 0, first = 0, last = 0;
+  uint64_t gs = my_lo >> 2;  // empty range: a group that is always safe to (pre)load
+  if (use && hi > lo) {
+    const uint64_t a = my_lo + lo, b = my_lo + hi;
+    gs = a >> 2;
+    ng = (uint32_t)(((b + 3) >> 2) - gs);
+    first = (uint32_t)(a & 3u);
+    last = ((uint32_t)(b - 1) & 3u) + 1u;
+  }
+  const uint64_t addr_d = my_docids + gs * 16u;
+  const uint32_t np = (ng + 1u) >> 1;  // pairs
+  const uint32_t incl = scan32_dpp(np);
+  if (lane < (uint32_t)kMaxTerms) {
+    s.w_incl[wave][lane] = incl;
+    s.w_before[wave][lane] = incl - np;
+    u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16, ng | (first << 20) | (last << 23) | (my_flags << 26)};
+    *(u32x4*)&s.w_rec[wave][lane][0] = rec;
+  }
+  return (uint32_t)__builtin_amdgcn_readlane((int)incl, kMaxTerms - 1);
+}
+
+// One pair of 4-posting groups: docids, score codes, and which (term, pair-in-term) it is.
 struct Group {
-  u32x4 d4, f4;
-  uint32_t t;
-  bool valid;
+  u32x4 d4[2], c4[2];
+  uint32_t p;     // pair index inside the term's range of this sub-tile
+  uint32_t meta;  // the term's meta
+  uint32_t term;  // term index inside the part (division path only)
 };
 
-__device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t par, uint32_t n_terms, uint32_t v,
+// Locate flattened pair v of the sub-tile (clamped so the loads are always legal) through the wave's
+// LDS table and load its column words (2 x 16 B per column).  No control flow around the loads.
+__device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wave, uint32_t n_terms, uint32_t v,
                                                   uint32_t total, Group& gr) {
-  gr.valid = v < total;
-  gr.t = 0;
-  if (gr.valid) {
-    uint32_t t = 0;
-    while (v >= s.g_prefix[par][t + 1]) ++t;
-    const uint64_t g = s.g_start[par][t] + (v - s.g_prefix[par][t]);
-    gr.t = t;
-    gr.d4 = __builtin_nontemporal_load((gvec_ptr)s.t_docids[t] + g);
-    gr.f4 = __builtin_nontemporal_load((gvec_ptr)s.t_fnorm[t] + g);
+  const uint32_t vc = min(v, max(total, 1u) - 1u);
+  const u32x4 p0 = *(const u32x4*)&s.w_incl[wave][0];
+  const u32x4 p1 = *(const u32x4*)&s.w_incl[wave][4];
+  uint32_t t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t += (vc >= ((i < 4) ? p0[i] : p1[i - 4])) ? 1u : 0u;  // terms 0..7, branchless
+  if (n_terms > 8) {  // uniform; long disjunctions continue with a scalar-style walk
+    while (t < n_terms - 1u && vc >= s.w_incl[wave][t]) ++t;
   }
-  (void)n_terms;
+  t = min(t, n_terms - 1u);  // total == 0: every prefix compares true
+  const u32x4 rec = *(const u32x4*)&s.w_rec[wave][t][0];
+  const uint32_t p = (total != 0u) ? vc - s.w_before[wave][t] : 0u;
+  const uint64_t ad = (((uint64_t)rec[1] << 32) | rec[0]) + (uint64_t)p * 32u;
+  const uint64_t ac = ad + (uint64_t)rec[2] * 16u;
+  gr.p = p;
+  gr.meta = rec[3];
+  gr.term = t;
+  gr.d4[0] = __builtin_nontemporal_load((gvec_ptr)ad);
+  gr.d4[1] = __builtin_nontemporal_load((gvec_ptr)ad + 1);
+  gr.c4[0] = __builtin_nontemporal_load((gvec_ptr)ac);
+  gr.c4[1] = __builtin_nontemporal_load((gvec_ptr)ac + 1);
 }
 
-// BM25Similarity SimScorer.score(freq, norm) for the 4 postings of a group + fp64 accumulate.
-__device__ __forceinline__ void group_score(ScanSmem& s, uint32_t par, const Group& gr, uint32_t v, uint32_t base,
+// Adds the 8 postings of a pair into the wave's sub-tile.  Fast path: score = one LDS table read,
+// accumulator address = one shift-add.
+template <int ABL>
+__device__ __forceinline__ void group_score(ScanSmem& s, double* acc, const Group& gr, bool valid, uint32_t base,
                                             uint32_t tile_len) {
-  if (!gr.valid) return;
-  const uint32_t t = gr.t;
-  const uint64_t g = s.g_start[par][t] + (v - s.g_prefix[par][t]);
-  const uint64_t lo = s.t_lo[t], hi = s.t_hi[t];
-  const float w = s.t_weight[t];
-  const uint32_t slot = s.t_slot[t];
-  const uint64_t idx0 = g << 2;
+  if (!__any(valid)) return;  // wave-uniform
+  const uint32_t meta = gr.meta;
+  const uint32_t ng = meta & kMetaGroups;
+  const uint32_t first = (meta >> 20) & 7u, last = (meta >> 23) & 7u;
+  // valid postings: interior groups are full, the term's first / last group may start / end mid-group,
+  // the second group of the last pair may not exist
+  const uint32_t k0 = 2u * gr.p;
+  uint32_t m0 = ((1u << ((k0 + 1u == ng) ? last : 4u)) - 1u) & ~((1u << ((k0 == 0u) ? first : 0u)) - 1u);
+  uint32_t m1 = (1u << ((k0 + 2u == ng) ? last : 4u)) - 1u;
+  m0 = (k0 < ng) ? m0 : 0u;
+  m1 = (k0 + 1u < ng) ? m1 : 0u;
+  uint32_t vmask = valid ? (m0 | (m1 << 4)) : 0u;
+  const uint32_t tab = (meta >> 26) & 7u;
+  // byte offset of the doc's accumulator inside the wave's sub-tile: (doc - base) * 8 in one op
+  const uint32_t nbase8 = 0u - base * 8u;
+  uint32_t off[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint64_t idx = idx0 + (uint64_t)j;
-    const uint32_t rel = gr.d4[j] - base;  // unsigned: docs below the tile wrap to huge values
-    if (idx >= lo && idx < hi && rel < tile_len) {
-      const uint32_t fn = gr.f4[j];
-      const uint32_t nb = fn & 255u;
-      const float ninv = (slot < (uint32_t)kLdsCaches) ? s.cache[slot][nb] : ((gf32_ptr)s.t_cache[t])[nb];
-      const float freq = (float)(int32_t)(fn >> 8);
-      // BM25Similarity: weight - weight / (1f + freq * normInverse), one rounding per op
-      const float prod = freq * ninv;
-      const float den = 1.0f + prod;
-      const float quo = w / den;
-      const float sc = w - quo;
-      unsafeAtomicAdd(&s.acc[rel], (double)sc);
+  for (int j = 0; j < 8; ++j) off[j] = (gr.d4[j >> 2][j & 3] << 3) + nbase8;  // unsigned: out-of-tile docs wrap to huge values
+  if (__any((meta >> 29) & 1u)) {
+    // sparse terms share one posting range between several sub-tiles (coarse cells): doc-range filter
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (off[j] >= tile_len * 8u) vmask &= ~(1u << j);
+  }
+  // postings the score table cannot serve: freq > kTabMaxFreq / norm >= kTabNorms (sign bit of the
+  // code) or a term without a table.  They are rare: handled per lane after the table path.
+  uint32_t emask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) emask |= (gr.c4[j >> 2][j & 3] >> 31) << j;
+  emask = (tab == 7u) ? 0xFFu : emask;
+  const uint32_t tmask = vmask & ~emask;  // served by the table
+  const uint32_t gmask = vmask & emask;   // need the division
+  if (ABL == 2) {
+    asm volatile("" ::"v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[7]), "v"(vmask));
+    return;
+  }
+  {
+    const char* tb = (const char*)(&s.tab[0][0] + (tab == 7u ? 0u : tab) * (uint32_t)kTabEntries);
+    char* const accb = (char*)acc;
+    float sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sc[j] = *(const float*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
+    if (__all(tmask == 0xFFu)) {  // wave-uniform: only full pairs, all table-served
+#pragma unroll
+      for (int j = 0; j < 8; ++j) unsafeAtomicAdd((double*)(accb + off[j]), (double)sc[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((tmask >> j) & 1u) unsafeAtomicAdd((double*)(accb + off[j]), (double)sc[j]);
+    }
+  }
+  if (__any(gmask != 0u)) {
+    // division path: long docs / high freqs / terms without a score table (a few lanes)
+    const float w = s.t_weight[gr.term];
+    const float* cache = &s.cache[s.t_slot[gr.term]][0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t c = gr.c4[j >> 2][j & 3];
+      const uint32_t f = (c >> 31) ? ((c >> 8) & 0x7FFFFFu) : (c >> 9);
+      const uint32_t nb = (c >> 31) ? (c & 255u) : ((c >> 2) & 127u);
+      if ((gmask >> j) & 1u)
+        unsafeAtomicAdd((double*)((char*)acc + off[j]), (double)bm25_score(w, (float)(int32_t)f, cache[nb]));
     }
   }
 }
 
-// Posting ranges of every term for one doc tile, in two halves so the cell-table loads can be in
-// flight while wave 0 does its share of the accumulate phase.  Wave 0 only (tid < 64).
-__device__ __forceinline__ void tile_cells_load(const ScanSmem& s, uint32_t n_terms, uint32_t tile, bool in_range,
-                                                uint32_t& lo, uint32_t& hi) {
-  const uint32_t tid = threadIdx.x;
-  lo = 0;
-  hi = 0;
-  if (in_range && tid < n_terms) {
-    const gu32_ptr co = (gu32_ptr)s.t_celloff[tid];
-    const uint32_t cell = tile >> s.t_shift[tid];
-    lo = co[cell];
-    hi = co[cell + 1];
-  }
-}
-__device__ __forceinline__ void tile_tables_store(ScanSmem& s, uint32_t par, uint32_t lo, uint32_t hi) {
-  const uint32_t tid = threadIdx.x;
-  uint32_t ng = 0;
-  if (hi > lo) {  // only lanes < n_terms can have hi > lo
-    const uint64_t a = s.t_lo[tid] + lo, b = s.t_lo[tid] + hi;
-    const uint64_t gs = a >> 2, ge = (b + 3) >> 2;
-    s.g_start[par][tid] = gs;
-    ng = (uint32_t)(ge - gs);
-  }
-  uint32_t incl = ng;
+// Workgroup-wide rendezvous body: keep the k best of (candidate buffer UNION the candidates the
+// waves still have parked in their sub-tiles), publish theta.  Every thread calls it; cmask / slot
+// addressing describe this thread's parked candidates (none for a wave that is past its last
+// sub-tile).  Contains barriers; returns with the buffer consistent and cmask consumed.
+__device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, uint32_t cmask, uint32_t gdoc0, uint32_t k,
+                                                   unsigned long long* theta_g) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  uint32_t ncand = (uint32_t)__popc(cmask);
 #pragma unroll
-  for (int d = 1; d < kMaxTerms; d <<= 1) {
-    const uint32_t o = __shfl_up(incl, d, 64);
-    if (tid >= (uint32_t)d) incl += o;
+  for (int d = 32; d > 0; d >>= 1) ncand += __shfl_xor(ncand, d, 64);
+  if (lane == 0 && ncand) atomicAdd(&s.tile_cand, ncand);
+  const uint32_t cnt0 = s.cnt;
+  __syncthreads();  // every thread holds the same cnt0; tile_cand complete
+  const uint32_t tc = s.tile_cand;
+  uint64_t thr = 0;
+  if (cnt0 + tc > k) {  // uniform
+    thr = topk_kth_union<kScanThreads>(s.cand, cnt0, k, &s.sc, [&](auto&& f) {
+      uint32_t m = cmask;
+      while (m) {
+        const int j = __ffs((int)m) - 1;
+        m &= m - 1u;
+        f(pack_key((float)acc[lane + 64u * (uint32_t)j], gdoc0 + lane + 64u * (uint32_t)j));
+      }
+    });
+    const uint32_t kept = topk_keep_ge<kScanThreads, kCandCap>(s.cand, cnt0, thr, &s.sc);
+    if (tid == 0) {
+      s.cnt = kept;
+      if (thr > s.theta) s.theta = thr;
+      atomicMax(theta_g, (unsigned long long)thr);  // LazyMaxScoreAccumulator.accumulate analogue
+      s.prof[6] += 1;
+    }
+    __syncthreads();
   }
-  if (tid < (uint32_t)kMaxTerms) s.g_prefix[par][tid + 1] = incl;
-  if (tid == 0) s.g_prefix[par][0] = 0;
+#pragma unroll 1
+  for (int j = 0; j < kSlots; ++j) {  // parked candidates that made the cut (fits: <= k in total)
+    bool want = (cmask >> j) & 1u;
+    uint64_t key = 0;
+    if (want) {
+      key = pack_key((float)acc[lane + 64u * (uint32_t)j], gdoc0 + lane + 64u * (uint32_t)j);
+      acc[lane + 64u * (uint32_t)j] = unmatched_value();
+      want = key >= thr;
+    }
+    topk_append(s.cand, &s.cnt, want, key);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    s.tile_cand = 0;
+    s.rz_flag = 0;
+  }
+  __syncthreads();
 }
 
-// PIPE = true: the first kPrefetch posting groups of tile j+1 are loaded before tile j is swept, so
-// their HBM latency hides under the LDS-bound sweep.  PIPE = false: plain per-tile phases (kept for
-// A/B measurement; results are identical).
-template <bool PIPE>
+// PIPE = true: the first kPf posting groups per lane of the wave's next sub-tile are loaded before
+// the current one is swept.  ABL: timing ablations / instrumentation.
+template <bool PIPE, int ABL>
 __global__ __launch_bounds__(kScanThreads, 4)
-void bm25_scan_kernel(const DItem* __restrict__ items, const DTerm* __restrict__ terms,
-                      const DQuery* __restrict__ queries, const float* __restrict__ caches,
-                      unsigned long long* __restrict__ theta_g, uint64_t* __restrict__ item_keys,
-                      uint32_t* __restrict__ item_counts, uint64_t* __restrict__ item_hits,
-                      uint32_t k_stride) {
+void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts,
+                      const DTerm* __restrict__ terms, const DQuery* __restrict__ queries,
+                      const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
+                      uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
+                      uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof) {
   __shared__ ScanSmem s;
   const uint32_t tid = threadIdx.x;
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  double* const acc = &s.acc[wave][0];
   const DItem item = items[blockIdx.x];
   const DQuery q = queries[item.query];
-  const uint32_t n_terms = item.n_terms;
   const uint32_t k = q.k;
   unsigned long long* const my_theta_g = theta_g + item.query;
-  const NRT_GLOBAL uint64_t* const live_bits = (const NRT_GLOBAL uint64_t*)item.live_bits;
 
-  // ---- item prologue: clear the tile, stage the term table and the normInverse tables in LDS
-  for (uint32_t i = tid; i < (uint32_t)kTileDocs; i += kScanThreads) s.acc[i] = unmatched_value();
-  if (tid < n_terms) {
-    const DTerm t = terms[item.term_begin + tid];
-    s.t_docids[tid] = (uint64_t)t.docids;
-    s.t_fnorm[tid] = (uint64_t)t.fnorm;
-    s.t_celloff[tid] = (uint64_t)t.cell_off;
-    s.t_cache[tid] = (uint64_t)(caches + t.cache_off);
-    s.t_lo[tid] = t.start;
-    s.t_hi[tid] = t.start + t.count;
-    s.t_weight[tid] = t.weight;
-    s.t_shift[tid] = t.shift;
-    s.t_slot[tid] = t.cache_slot;
-  }
+  // ---- item prologue: clear the sub-tiles, stage the normInverse tables, build the score tables
+  for (int j = 0; j < kSlots; ++j) acc[lane + 64u * (uint32_t)j] = unmatched_value();
   {
     const uint32_t n_lds = min(item.n_caches, (uint32_t)kLdsCaches) * 256u;
     for (uint32_t i = tid; i < n_lds; i += kScanThreads) (&s.cache[0][0])[i] = caches[item.cache_off + i];
@@ -208,147 +313,239 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DTerm* __restrict__
     s.cnt = 0;
     s.tile_cand = 0;
     s.hits = 0;
-  }
-  uint32_t my_hits = 0;
-  __syncthreads();
-  if (tid < 64) {
-    uint32_t lo, hi;
-    tile_cells_load(s, n_terms, item.tile_begin, true, lo, hi);
-    tile_tables_store(s, item.tile_begin & 1u, lo, hi);
+    s.rz_flag = 0;
+    s.done = 0;
+    for (int i = 0; i < 16; ++i) s.prof[i] = 0;
   }
   __syncthreads();
-
-  Group pf[kPrefetch];
-#pragma unroll
-  for (int r = 0; r < kPrefetch; ++r) pf[r].valid = false;
-  if (PIPE) {
-    const uint32_t par0 = item.tile_begin & 1u;
-    const uint32_t total0 = s.g_prefix[par0][n_terms];
-#pragma unroll
-    for (int r = 0; r < kPrefetch; ++r) group_locate_load(s, par0, n_terms, tid + (uint32_t)r * kScanThreads, total0, pf[r]);
+  for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
+    const float w = items[blockIdx.x].tab_weight[slot];  // (indexing the register copy would spill it)
+    const float* cache = &s.cache[items[blockIdx.x].tab_cache[slot]][0];
+    for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kScanThreads)
+      s.tab[slot][e] = bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]);  // row 0 (freq 0) never read
   }
+  uint32_t my_hits = 0;    // per-lane count (general sweep)
+  uint32_t wave_hits = 0;  // wave-uniform count (simple sweep), added once by lane 0
 
-  for (uint32_t tile = item.tile_begin; tile < item.tile_end; ++tile) {
-    const uint32_t par = tile & 1u;
-    const uint32_t base = tile << kTileShift;
-    const uint32_t tile_len = min((uint32_t)kTileDocs, item.max_doc - base);
-    const uint32_t total_groups = s.g_prefix[par][n_terms];  // written before the last barrier
-
-    // ---- (1) wave 0: start fetching the posting ranges of the NEXT tile and the shared theta
-    uint32_t next_lo = 0, next_hi = 0;
-    uint64_t theta_shared = 0;
-    if (tid < 64) {
-      tile_cells_load(s, n_terms, tile + 1, tile + 1 < item.tile_end, next_lo, next_hi);
-      if (tid == 0) theta_shared = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t pi = 0; pi < item.n_parts; ++pi) {
+    const DPart part = parts[item.part_begin + pi];
+    const uint32_t n_terms = part.n_terms;
+    const NRT_GLOBAL uint64_t* const live_bits = (const NRT_GLOBAL uint64_t*)part.live_bits;
+    const bool simple = (live_bits == nullptr) && !q.has_after;  // uniform: no deletes, no searchAfter
+    __syncthreads();  // previous part fully done (all waves passed its final rendezvous); tables built
+    // lane l of every wave looks after term min(l, n_terms - 1) of this part (registers)
+    const DTerm mt = terms[part.term_begin + min(lane, n_terms - 1u)];
+    const uint64_t my_docids = (uint64_t)mt.docids, my_lo = mt.start;
+    const uint32_t my_delta16 = (uint32_t)(((uint64_t)mt.fnorm - (uint64_t)mt.docids) >> 4);  // same allocation
+    const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
+    const uint32_t my_shift = mt.shift;
+    const uint32_t my_flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | ((mt.shift != 0 ? 1u : 0u) << 3);
+    const bool has_term = lane < n_terms;
+    if (tid < n_terms) {
+      s.t_weight[tid] = mt.weight;
+      s.t_slot[tid] = mt.cache_slot;
     }
+    if (tid == 0) s.done = 0;
+    __syncthreads();
 
-    // ---- (2) stream the postings: coalesced 16 B/lane column loads, fp32 BM25, fp64 LDS accumulate
-    if (total_groups != 0) {
-      uint32_t v = tid;
-      if (PIPE) {
-#pragma unroll
-        for (int r = 0; r < kPrefetch; ++r) group_score(s, par, pf[r], tid + (uint32_t)r * kScanThreads, base, tile_len);
-        v = tid + (uint32_t)kPrefetch * kScanThreads;
-      }
-      for (; v < total_groups; v += 2 * kScanThreads) {
-        Group a, b;
-        group_locate_load(s, par, n_terms, v, total_groups, a);
-        group_locate_load(s, par, n_terms, v + kScanThreads, total_groups, b);
-        group_score(s, par, a, v, base, tile_len);
-        group_score(s, par, b, v + kScanThreads, base, tile_len);
-      }
+    const uint32_t last_tile = part.tile_end - 1u;
+    uint32_t sub = part.tile_begin + wave;  // this wave's sub-tiles: sub, sub + 8, ...
+    // software pipeline state: the wave's LDS table describes sub-tile `sub` (total_groups pairs),
+    // (nlo, nhi) are the cell values of sub + 8, pf holds the first 64 pairs of `sub`
+    uint32_t nlo, nhi;
+    uint32_t total_groups;
+    {
+      const uint32_t c0 = min(sub, last_tile) >> my_shift;
+      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, my_cells[c0], my_cells[c0 + 1],
+                                   has_term && sub < part.tile_end);
+      const uint32_t c1 = min(sub + kScanWaves, last_tile) >> my_shift;
+      nlo = my_cells[c1];
+      nhi = my_cells[c1 + 1];
     }
-    if (tid < 64) {
-      tile_tables_store(s, par ^ 1u, next_lo, next_hi);
-      if (tid == 0 && theta_shared > s.theta) s.theta = theta_shared;
-    }
-    __syncthreads();  // (A) accumulators complete; next tile's tables visible
+    Group pf;
+    if (PIPE) group_locate_load(s, wave, n_terms, lane, total_groups, pf);
+    uint32_t cmask = 0;   // candidates parked in my sub-tile (only after a failed reservation)
+    uint32_t gdoc0 = 0;   // global docid of slot 0 of my current sub-tile
 
-    if (PIPE) {  // next tile's first groups: in flight while this tile is swept
-      const uint32_t total_next = s.g_prefix[par ^ 1u][n_terms];
-#pragma unroll
-      for (int r = 0; r < kPrefetch; ++r) group_locate_load(s, par ^ 1u, n_terms, tid + (uint32_t)r * kScanThreads, total_next, pf[r]);
-    }
-    if (total_groups == 0) continue;  // uniform: no posting of any term falls in this tile
+    for (; sub < part.tile_end; sub += kScanWaves) {
+      const uint32_t base = sub * (uint32_t)kTileDocs;
+      const uint32_t tile_len = min((uint32_t)kTileDocs, part.max_doc - base);
+      gdoc0 = (uint32_t)(part.doc_base + (int32_t)base);
+      uint64_t tp0 = 0, tp1 = 0, tp2 = 0;
+      if (ABL == 7 && tid == 0) tp0 = __builtin_readcyclecounter();
 
-    // ---- (3) sweep the tile: count hits, find competitive docs, reset non-competitive slots
-    const uint64_t theta = s.theta;
-    uint32_t cmask = 0, ncand = 0;
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-      const uint32_t i = tid + (uint32_t)j * kScanThreads;
-      const double a = s.acc[i];
-      const uint64_t bits = dbl_bits(a);
-      if (bits != kUnmatched) {
-        const uint32_t doc = base + i;
-        bool live = true;
-        if (live_bits) live = (live_bits[doc >> 6] >> (doc & 63u)) & 1ull;
-        bool cand = false;
-        if (live) {
-          ++my_hits;  // totalHits counts every collected doc, also those skipped by `after`
-          const float sc = (float)a;
-          const uint32_t gdoc = (uint32_t)(item.doc_base + (int32_t)doc);
-          const bool skip = q.has_after && (sc > q.after_score || (sc == q.after_score && (int32_t)gdoc <= q.after_doc));
-          if (!skip) cand = pack_key(sc, gdoc) > theta;
+      // ---- (1) stream the postings: coalesced 32 B/lane column loads, table-lookup BM25, fp64 LDS accumulate
+      const uint32_t cur_groups = total_groups;
+      if (cur_groups != 0) {
+        if (!PIPE) group_locate_load(s, wave, n_terms, lane, cur_groups, pf);
+        group_score<ABL>(s, acc, pf, lane < cur_groups, base, tile_len);
+        if (ABL == 7 && tid == 0) s.prof[8] += 1;
+        for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // wave-uniform trip count
+          Group a;
+          group_locate_load(s, wave, n_terms, vb + lane, cur_groups, a);
+          group_score<ABL>(s, acc, a, vb + lane < cur_groups, base, tile_len);
+          if (ABL == 7 && tid == 0) s.prof[10] += 1;
         }
-        if (cand) {
-          cmask |= 1u << j;
-          ++ncand;
+      }
+
+      // ---- (2) start the next sub-tile's traffic: its table, its first posting pairs, the cells after it, theta
+      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, nlo, nhi,
+                                   has_term && sub + kScanWaves < part.tile_end);
+      {
+        const uint32_t c2 = min(sub + 2u * kScanWaves, last_tile) >> my_shift;
+        nlo = my_cells[c2];
+        nhi = my_cells[c2 + 1];
+      }
+      // theta: this item's (LDS) and the other items' of the query (LazyMaxScoreAccumulator analogue)
+      const uint64_t theta_shared = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (PIPE) group_locate_load(s, wave, n_terms, lane, total_groups, pf);
+      if (ABL == 7 && tid == 0) {
+        tp1 = __builtin_readcyclecounter();
+        s.prof[0] += tp1 - tp0;
+        s.prof[7] += 1;
+      }
+
+      if (cur_groups != 0 && ABL != 4) {
+        // ---- (3) sweep my sub-tile: count hits, reset every slot that cannot be competitive.
+        //      A slot whose fp32 score reaches theta's score stays in place (mmask) for the exact path.
+        const uint64_t theta_l = s.theta;
+        uint32_t mmask = 0;
+        uint64_t theta = theta_l;
+        unsigned long long any_maybe = 0;  // wave-uniform
+        if (simple) {
+          // "fp32 score could reach theta's score" as ONE signed 64-bit compare on the fp64 bits:
+          // non-negative doubles order like their bit patterns, the "unmatched" pattern (-0.0) is
+          // INT64_MIN, and half a float ulp below theta's score is a conservative cut
+          const long long thr_bits = __double_as_longlong((double)key_score(theta_l)) - (1ll << 28);
+#pragma unroll
+          for (int h = 0; h < kSlots / 4; ++h) {
+            double a[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) a[jj] = acc[lane + 64u * (uint32_t)(h * 4 + jj)];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = h * 4 + jj;
+              const bool matched = dbl_bits(a[jj]) != kUnmatched;
+              wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(matched));
+              const bool maybe = __double_as_longlong(a[jj]) >= thr_bits;  // implies matched
+              any_maybe |= __builtin_amdgcn_ballot_w64(maybe);
+              if (matched & !maybe) acc[lane + 64u * (uint32_t)j] = unmatched_value();
+            }
+          }
         } else {
-          s.acc[i] = unmatched_value();
+          any_maybe = ~0ull;  // deletes / searchAfter: every slot goes through the exact path
         }
-      }
-    }
+        if (theta_shared > theta) theta = theta_shared;
+        if (ABL == 7 && tid == 0 && any_maybe != 0ull) s.prof[13] += 1;
+        if (any_maybe != 0ull) {  // wave-uniform: which of my slots were left in place? (one batched re-read)
+          if (simple) {
+            double a[kSlots];
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) ncand += __shfl_xor(ncand, d, 64);
-    if (lane_id() == 0 && ncand) atomicAdd(&s.tile_cand, ncand);
-    __syncthreads();  // (B)
-
-    // ---- (4) collect the competitive docs into the LDS candidate buffer
-    const uint32_t tc = s.tile_cand;
-    uint32_t cnt0 = s.cnt;
-    __syncthreads();  // (B2) every thread holds the same (tc, cnt0) before anyone appends
-    if (tc > 0) {     // uniform
-      if (cnt0 + tc > (uint32_t)kCandCap) cnt0 = scan_compact(s, cnt0, k, my_theta_g);  // raises theta
-      const bool flood = (cnt0 + tc > (uint32_t)kCandCap);                               // uniform
-      if (!flood) {
-#pragma unroll 1
-        for (int j = 0; j < kPerThread; ++j) {
-          const uint32_t i = tid + (uint32_t)j * kScanThreads;
-          bool want = (cmask >> j) & 1u;
-          uint64_t key = 0;
-          if (want) {
-            key = pack_key((float)s.acc[i], (uint32_t)(item.doc_base + (int32_t)(base + i)));
-            s.acc[i] = unmatched_value();
-            want = key > s.theta;
+            for (int j = 0; j < kSlots; ++j) a[j] = acc[lane + 64u * (uint32_t)j];
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(dbl_bits(a[j]) != kUnmatched) << j;
+          } else {
+            mmask = (1u << kSlots) - 1u;
           }
-          topk_append(s.cand, &s.cnt, want, key);
         }
-      } else {
-        // start of an item: more competitive docs than buffer space; collect kFloodStep docs at a
-        // time and compact (raising theta) whenever the next step might not fit
-#pragma unroll 1
-        for (int jj = 0; jj < kPerThread * (kScanThreads / kFloodStep); ++jj) {
-          const int j = jj / (kScanThreads / kFloodStep);
-          const uint32_t part = (uint32_t)jj % (kScanThreads / kFloodStep);
-          const uint32_t i = tid + (uint32_t)j * kScanThreads;
-          bool want = ((cmask >> j) & 1u) && (tid / kFloodStep == part);
-          uint64_t key = 0;
-          if (want) {
-            key = pack_key((float)s.acc[i], (uint32_t)(item.doc_base + (int32_t)(base + i)));
-            s.acc[i] = unmatched_value();
-            want = key > s.theta;
+        while (__any(mmask != 0)) {  // exact path: a few iterations once theta has converged
+          if (ABL == 7 && tid == 0) s.prof[11] += 1;
+          if (mmask) {
+            const int j = __ffs((int)mmask) - 1;
+            mmask &= mmask - 1u;
+            const uint32_t i = lane + 64u * (uint32_t)j;
+            const double a = acc[i];
+            if (dbl_bits(a) != kUnmatched) {
+              const uint32_t doc = base + i;
+              bool live = true;
+              if (!simple && live_bits) live = (live_bits[doc >> 6] >> (doc & 63u)) & 1ull;
+              bool cand = false;
+              if (live) {
+                if (!simple) ++my_hits;  // totalHits counts every collected doc, also those skipped by `after`
+                const float sc = (float)a;
+                const uint32_t gdoc = gdoc0 + i;
+                const bool skip = q.has_after && (sc > q.after_score || (sc == q.after_score && (int32_t)gdoc <= q.after_doc));
+                if (!skip) cand = pack_key(sc, gdoc) > theta;
+              }
+              if (cand) cmask |= 1u << j;
+              else acc[i] = unmatched_value();
+            }
           }
-          topk_append(s.cand, &s.cnt, want, key);
-          __syncthreads();
-          const uint32_t c = s.cnt;
-          __syncthreads();  // everyone has read cnt before the next step appends
-          if (c > (uint32_t)(kCandCap - kFloodStep)) scan_compact(s, c, k, my_theta_g);
+        }
+
+        // ---- (4) optimistic collect: reserve slots in the shared buffer for the whole wave
+        if (ABL != 3 && __any(cmask != 0)) {
+          if (ABL == 7 && tid == 0) s.prof[12] += 1;
+          const uint32_t mine = (uint32_t)__popc(cmask);
+          uint32_t incl = mine;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += o;
+          }
+          const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          uint32_t wbase = (uint32_t)kCandCap;  // "does not fit"
+          if (lane == 0) {
+            // CAS loop: only a reservation that fits ever changes cnt
+            uint32_t old = s.cnt;
+            for (;;) {
+              if (old + wave_total > (uint32_t)kCandCap) {
+                __hip_atomic_store(&s.rz_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+              }
+              const uint32_t prev = atomicCAS(&s.cnt, old, old + wave_total);
+              if (prev == old) {
+                wbase = old;
+                break;
+              }
+              old = prev;
+            }
+          }
+          wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+          if (wbase + wave_total <= (uint32_t)kCandCap) {
+            uint32_t pos = wbase + incl - mine;
+            while (cmask) {
+              const int j = __ffs((int)cmask) - 1;
+              cmask &= cmask - 1u;
+              const uint32_t i = lane + 64u * (uint32_t)j;
+              s.cand[pos++] = pack_key((float)acc[i], gdoc0 + i);
+              acc[i] = unmatched_value();
+            }
+          }
+        }
+      }
+      if (ABL == 7 && tid == 0) {
+        tp2 = __builtin_readcyclecounter();
+        s.prof[2] += tp2 - tp1;
+      }
+
+      // ---- (5) rendezvous: somebody's candidates did not fit -> the whole workgroup compacts
+      if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {  // wave-uniform; seen at the next sub-tile boundary at the latest
+        uint64_t tr = 0;
+        if (ABL == 7 && tid == 0) tr = __builtin_readcyclecounter();
+        __syncthreads();  // R1: all 8 waves (running ones here, finished ones in the drain loop below)
+        rendezvous_compact(s, acc, cmask, gdoc0, k, my_theta_g);
+        cmask = 0;
+        if (ABL == 7 && tid == 0) {
+          s.prof[4] += __builtin_readcyclecounter() - tr;
+          s.prof[5] += 1;
         }
       }
     }
-    __syncthreads();  // (C)
-    if (tid == 0) s.tile_cand = 0;  // next reader is after the next tile's barriers
+
+    // ---- part epilogue: this wave is out of sub-tiles; keep serving rendezvous until all waves are
+    if (lane == 0) atomicAdd(&s.done, 1u);
+    for (;;) {
+      __syncthreads();  // R1 (pairs with the running waves' rendezvous barrier)
+      const uint32_t flag = __hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t done = __hip_atomic_load(&s.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (flag) {
+        rendezvous_compact(s, acc, 0u, 0u, k, my_theta_g);  // ends with a barrier: flag/done re-read safely
+        continue;
+      }
+      __syncthreads();  // everyone has read (flag, done) before anybody changes them again
+      if (done == (uint32_t)kScanWaves) break;
+    }
   }
 
   // ---- item epilogue: final top-k of the item, hit count
@@ -356,11 +553,15 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DTerm* __restrict__
   {
     const uint32_t c = s.cnt;
     __syncthreads();
-    if (c > k) scan_compact(s, c, k, my_theta_g);
+    if (c > k) {
+      uint64_t thr = 0;
+      const uint32_t m = topk_compact<kScanThreads, kCandCap>(s.cand, c, k, &s.sc, &thr);
+      if (tid == 0) s.cnt = m;
+    }
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) my_hits += __shfl_xor(my_hits, d, 64);
-  if (lane_id() == 0 && my_hits) atomicAdd(&s.hits, my_hits);
+  if (lane == 0 && (my_hits + wave_hits)) atomicAdd(&s.hits, my_hits + wave_hits);
   __syncthreads();
   const uint32_t n = s.cnt;
   uint64_t* out = item_keys + (size_t)blockIdx.x * k_stride;
@@ -368,6 +569,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DTerm* __restrict__
   if (tid == 0) {
     item_counts[blockIdx.x] = n;
     item_hits[blockIdx.x] = s.hits;
+    if (ABL == 7 && item_prof)
+      for (int i = 0; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
   }
 }
 
@@ -453,10 +656,12 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// fold_norms_kernel (seal time): fnorm[p] = (freq[p] << 8) | norms[docid[p]].
+// fold_norms_kernel (seal time): per posting the score code of (freq, norm byte of the doc):
+//   freq <= kTabMaxFreq && norm < kTabNorms : ((freq << 7) | norm) << 2   (byte offset into a score table)
+//   otherwise                               : 0x80000000 | freq << 8 | norm
 // freqs == nullptr => freq 1 (IndexOptions.DOCS); norms == nullptr => norm byte 1 (norms omitted,
 // /root/reference/src/main/java/com/yelp/nrtsearch/server/field/AtomFieldDef.java:123-126).
-// Sets *overflow when a freq does not fit 24 bits (the segment then stays on the CPU path).
+// Sets *overflow when a freq does not fit 23 bits (the segment then stays on the CPU path).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void fold_norms_kernel(const uint32_t* __restrict__ docids, const uint32_t* __restrict__ freqs,
@@ -466,22 +671,32 @@ void fold_norms_kernel(const uint32_t* __restrict__ docids, const uint32_t* __re
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
     const uint32_t f = freqs ? freqs[p] : 1u;
     const uint32_t nb = norms ? (uint32_t)norms[docids[p]] : 1u;
-    if (f >= (1u << 24)) *overflow = 1u;
-    fnorm[p] = (f << 8) | nb;
+    if (f >= (1u << 23)) *overflow = 1u;
+    fnorm[p] = (f >= 1u && f <= (uint32_t)kTabMaxFreq && nb < (uint32_t)kTabNorms) ? (((f << 7) | nb) << 2)
+                                                                                  : (0x80000000u | (f << 8) | nb);
   }
 }
 
 // ---- launchers (called from runtime.cpp) ---------------------------------------------------------
-void launch_bm25_scan(hipStream_t stream, bool pipelined, uint32_t n_items, const DItem* items, const DTerm* terms,
-                      const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                      uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride) {
+void launch_bm25_scan(hipStream_t stream, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
+                      const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
+                      uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride,
+                      uint64_t* item_prof) {
   if (n_items == 0) return;
-  if (pipelined)
-    hipLaunchKernelGGL(bm25_scan_kernel<true>, dim3(n_items), dim3(kScanThreads), 0, stream, items, terms, queries,
-                       caches, theta_g, item_keys, item_counts, item_hits, k_stride);
-  else
-    hipLaunchKernelGGL(bm25_scan_kernel<false>, dim3(n_items), dim3(kScanThreads), 0, stream, items, terms, queries,
-                       caches, theta_g, item_keys, item_counts, item_hits, k_stride);
+#define NRT_LAUNCH(P, A)                                                                                     \
+  hipLaunchKernelGGL((bm25_scan_kernel<P, A>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
+                     caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof)
+  if (!pipelined) { NRT_LAUNCH(false, 0); return; }
+  switch (ablation) {
+    case 1: NRT_LAUNCH(true, 1); break;
+    case 2: NRT_LAUNCH(true, 2); break;
+    case 3: NRT_LAUNCH(true, 3); break;
+    case 4: NRT_LAUNCH(true, 4); break;
+    case 5: NRT_LAUNCH(true, 5); break;
+    case 7: NRT_LAUNCH(true, 7); break;
+    default: NRT_LAUNCH(true, 0); break;
+  }
+#undef NRT_LAUNCH
 }
 
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,

@@ -7,44 +7,62 @@
 
 namespace nrtgpu {
 
-constexpr int kTileDocs = 8192;     // docs per LDS accumulator tile (fp64 accumulators: 64 KiB)
-constexpr int kTileShift = 13;
-constexpr int kScanThreads = 512;   // 8 wave64 per workgroup, 2 workgroups per CU
-constexpr int kCandCap = 1280;      // scan: LDS candidate slots (10 KiB) = kMaxK + kFloodStep
-constexpr int kFloodStep = 256;     // scan: docs collected between compactions while flooding
-constexpr int kMergeCap = 1536;     // merge: candidate slots = kMaxK + kScanThreads
+constexpr int kTileDocs = 768;      // docs per wave-private LDS accumulator sub-tile (fp64: 6 KiB per wave)
+constexpr int kScanThreads = 1024;  // 16 autonomous wave64 per workgroup, 1 workgroup per CU (whole 160 KiB LDS)
+constexpr int kScanWaves = kScanThreads / 64;
+constexpr int kCandCap = 1920;      // scan: LDS candidate slots (15 KiB)
+constexpr int kMergeCap = 2048;     // merge: candidate slots = kMaxK + kScanThreads
 constexpr int kLdsCaches = 2;       // normInverse tables kept in LDS per item (one per field)
+// Score tables: for the kTabTerms densest terms of a query the BM25 score of every
+// (freq <= kTabMaxFreq, norm byte < kTabNorms) pair is computed once per item into LDS, so scoring a
+// posting is one LDS read.  Other (freq, norm) pairs / terms take the division path.
+constexpr int kTabTerms = 5;
+constexpr int kTabMaxFreq = 12;
+constexpr int kTabNorms = 128;
+constexpr int kTabEntries = (kTabMaxFreq + 1) * kTabNorms;  // row 0 (freq 0) unused
 constexpr int kMaxK = 1024;
 constexpr int kMaxTerms = 32;
 
 // One query term inside one segment: where its posting columns live in HBM.
 struct alignas(16) DTerm {
   const uint32_t* docids;    // docid column (all terms of the upload group, concatenated)
-  const uint32_t* fnorm;     // freq column with the doc's norm byte folded in: (freq << 8) | norm
+  const uint32_t* fnorm;     // score-code column: byte offset ((freq << 7 | norm) << 2) into a score table when
+                             // freq <= kTabMaxFreq and norm < kTabNorms, else 0x80000000 | freq << 8 | norm
   const uint32_t* cell_off;  // (n_cells + 1) posting offsets relative to `start`, one per doc-range cell
   uint64_t start;            // index of the term's first posting in the columns
   uint32_t count;            // postings of the term in this segment (docFreq within the leaf)
   uint32_t shift;            // cell = tile >> shift (0 for dense terms: one cell per tile)
   float    weight;           // boost * idf
   uint32_t cache_off;        // offset in floats of the term's 256-entry normInverse table
-  uint32_t cache_slot;       // per-query table index (tables < kLdsCaches are staged in LDS)
-  uint32_t pad0;
+  uint32_t cache_slot;       // per-query normInverse table index (< kLdsCaches)
+  uint32_t tab_slot;         // score table of this term in the item's LDS (< kTabTerms) or 0xFFFFFFFF
 };
 static_assert(sizeof(DTerm) == 64, "DTerm layout");
 
-// One work item: one query over a contiguous tile range of one segment (the analogue of a
-// LeafReaderContextPartition handled by one collector).
-struct alignas(16) DItem {
+// One part of a work item: a contiguous tile range of one segment (a LeafReaderContextPartition).
+struct alignas(16) DPart {
   const uint64_t* live_bits;  // nullptr => every doc live
-  uint32_t query;             // batch-local query index
-  uint32_t term_begin;        // first DTerm of this item
+  uint32_t term_begin;        // first DTerm of (query, segment); terms sorted by postings, densest first
   uint32_t n_terms;
   uint32_t tile_begin, tile_end;
   uint32_t max_doc;
   int32_t  doc_base;
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(DPart) == 48, "DPart layout");
+
+// One work item == one workgroup == one collector: a query over a list of parts visited in docBase
+// order, sharing one candidate buffer / theta -- the analogue of a Lucene LeafSlice
+// (/root/reference/src/main/java/com/yelp/nrtsearch/server/search/MyIndexSearcher.java:163-208).
+struct alignas(16) DItem {
+  uint32_t query;             // batch-local query index
+  uint32_t part_begin;
+  uint32_t n_parts;
   uint32_t cache_off;         // offset in floats of the query's first normInverse table
   uint32_t n_caches;
-  uint32_t pad0, pad1, pad2;
+  uint32_t n_tabs;            // score tables to build (<= kTabTerms)
+  float    tab_weight[kTabTerms];
+  uint32_t tab_cache[kTabTerms];  // normInverse table of each score table
 };
 static_assert(sizeof(DItem) == 64, "DItem layout");
 

@@ -24,9 +24,10 @@
 #include "plan.h"
 
 namespace nrtgpu {
-void launch_bm25_scan(hipStream_t stream, bool pipelined, uint32_t n_items, const DItem* items, const DTerm* terms,
-                      const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                      uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride);
+void launch_bm25_scan(hipStream_t stream, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
+                      const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
+                      uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride,
+                      uint64_t* item_prof);
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
@@ -120,7 +121,8 @@ struct TermEntry {
 struct TermGroup {
   uint32_t* d_docids = nullptr;
   uint32_t* d_freqs = nullptr;   // raw freq column, only between add_terms and seal (nullptr => freq == 1)
-  uint32_t* d_fnorm = nullptr;   // (freq << 8) | norm byte, built at seal
+  uint32_t* d_fnorm = nullptr;   // score-code column (same allocation as d_docids), filled at seal
+  bool folded = false;
   uint32_t* d_cells = nullptr;   // concatenated per-term cell tables
   bool has_freqs = false;
   uint64_t n_postings = 0;
@@ -168,6 +170,7 @@ struct nrtgpu_ctx {
   std::vector<std::unique_ptr<Slot>> slots;
   std::mutex stats_mu;
   nrtgpu_stats stats{};
+  double prof[16] = {0};
 };
 
 static const int kSlots = 4;
@@ -259,6 +262,13 @@ extern "C" void nrtgpu_reset_stats(nrtgpu_ctx* ctx) {
   if (!ctx) return;
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
   ctx->stats = nrtgpu_stats{};
+  for (double& p : ctx->prof) p = 0;
+}
+extern "C" int nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16) {
+  if (!ctx || !out16) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->stats_mu);
+  for (int i = 0; i < 16; ++i) out16[i] = ctx->prof[i];
+  return NRTGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,12 +340,12 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
     e.count = (uint32_t)cnt;
     e.shift = shift;
     e.cell_start = cells.size();
-    const int cell_doc_shift = kTileShift + (int)shift;
+    const int64_t cell_docs = (int64_t)kTileDocs << shift;  // a cell covers 2^shift sub-tiles
     int64_t p = lo;
     int32_t prev = -1;
     for (uint32_t c = 0; c < n_cells; ++c) {
       cells.push_back((uint32_t)(p - lo));
-      const int64_t bound = ((int64_t)(c + 1)) << cell_doc_shift;  // first doc of the next cell
+      const int64_t bound = (int64_t)(c + 1) * cell_docs;  // first doc of the next cell
       while (p < hi && (int64_t)docids[p] < bound) {
         const int32_t d = docids[p];
         if (d <= prev || d >= seg->max_doc)
@@ -353,10 +363,14 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
   TermGroup g;
   g.n_postings = (uint64_t)total;
   void* p = nullptr;
-  const size_t col_bytes = (size_t)total * 4 + 64;  // +64: 16-byte group loads may run past the end
-  if (int rc = dev_alloc(seg, &p, col_bytes)) return rc;
+  // one allocation per upload group: [docid column | code column], each padded to a multiple of
+  // 16 bytes plus 64 (16-byte group loads may run past the end); the kernel addresses the code column
+  // as docid column + a per-term constant
+  const size_t col_bytes = (((size_t)total * 4 + 15) & ~(size_t)15) + 64;
+  if (int rc = dev_alloc(seg, &p, 2 * col_bytes)) return rc;
   g.d_docids = (uint32_t*)p;
-  HIP_TRY(hipMemset(g.d_docids, 0, col_bytes));
+  g.d_fnorm = (uint32_t*)((char*)p + col_bytes);
+  HIP_TRY(hipMemset(p, 0, 2 * col_bytes));
   if (total) HIP_TRY(hipMemcpy(g.d_docids, docids, (size_t)total * 4, hipMemcpyHostToDevice));
   if (freqs) {
     if (int rc = dev_alloc(seg, &p, col_bytes)) return rc;
@@ -409,16 +423,10 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   for (auto& kv : seg->fields) {
     FieldData& f = kv.second;
     for (auto& g : f.groups) {
-      if (g.d_fnorm) continue;
-      void* p = nullptr;
-      const size_t col_bytes = (size_t)g.n_postings * 4 + 64;
-      if ((rc = dev_alloc(seg, &p, col_bytes))) break;
-      g.d_fnorm = (uint32_t*)p;
-      hipError_t e = hipMemset(g.d_fnorm, 0, col_bytes);
-      if (e == hipSuccess) {
-        launch_fold_norms(nullptr, g.d_docids, g.d_freqs, f.d_norms, g.d_fnorm, g.n_postings, d_overflow);
-        e = hipGetLastError();
-      }
+      if (g.folded) continue;
+      launch_fold_norms(nullptr, g.d_docids, g.d_freqs, f.d_norms, g.d_fnorm, g.n_postings, d_overflow);
+      hipError_t e = hipGetLastError();
+      g.folded = true;
       if (e != hipSuccess) {
         rc = fail(NRTGPU_ERR_HIP, "fold_norms failed: %s", hipGetErrorString(e));
         break;
@@ -433,13 +441,13 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   }
   (void)hipFree(d_overflow);
   if (rc) return rc;
-  if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^24 does not fit the packed freq|norm column");
+  if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^23 does not fit the packed freq|norm column");
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
       if (g.d_freqs) {  // raw freq column no longer needed
         (void)hipFree(g.d_freqs);
         g.d_freqs = nullptr;
-        seg->device_bytes -= (int64_t)((size_t)g.n_postings * 4 + 64);
+        seg->device_bytes -= (int64_t)((((size_t)g.n_postings * 4 + 15) & ~(size_t)15) + 64);
       }
   seg->sealed = true;
   return NRTGPU_OK;
@@ -475,7 +483,6 @@ extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
     for (auto& g : f.groups) {
       if (g.d_docids) (void)hipFree(g.d_docids);
       if (g.d_freqs) (void)hipFree(g.d_freqs);
-      if (g.d_fnorm) (void)hipFree(g.d_fnorm);
       if (g.d_cells) (void)hipFree(g.d_cells);
     }
   }
@@ -491,6 +498,7 @@ extern "C" int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg) { return s
 struct HostPlan {
   std::vector<DQuery> queries;
   std::vector<DItem> items;
+  std::vector<DPart> parts;
   std::vector<DTerm> terms;
   std::vector<float> caches;
   std::vector<uint32_t> list_idx;   // per query: item indices (merge input lists)
@@ -510,6 +518,7 @@ static int validate_query(const nrtgpu_bm25_query& q, int qi) {
   if (q.n_terms > NRTGPU_MAX_TERMS) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d clauses > %d", qi, q.n_terms, NRTGPU_MAX_TERMS);
   if (q.min_should_match > 1) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: minimumNumberShouldMatch %d", qi, q.min_should_match);
   if (q.n_caches <= 0 || !q.norm_cache) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: norm_cache missing", qi);
+  if (q.n_caches > kLdsCaches) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d scored fields > %d", qi, q.n_caches, kLdsCaches);
   for (int t = 0; t < q.n_terms; ++t) {
     if (q.terms[t].cache_slot < 0 || q.terms[t].cache_slot >= q.n_caches)
       return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: cache_slot out of range", qi, t);
@@ -517,6 +526,10 @@ static int validate_query(const nrtgpu_bm25_query& q, int qi) {
   }
   return 0;
 }
+
+// Cost model for cutting a query into work items: postings streamed + a per-tile constant for the
+// accumulator sweep (in posting equivalents).
+static const int64_t kTileCostPostings = 48;
 
 static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                       const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp) {
@@ -534,17 +547,44 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
   hp.queries.resize((size_t)n_queries);
   hp.q_k.resize((size_t)n_queries);
 
-  // pass 1: resolve terms per (query, segment); remember posting counts
-  struct QS { uint32_t term_begin, n_terms; int32_t seg; int64_t postings; uint32_t cache_off, n_caches; };
+  // pass 1: resolve terms per (query, segment), densest term first; remember posting counts
+  struct QS { uint32_t term_begin, n_terms; int32_t seg; int64_t postings; };
+  struct QTabs { uint32_t n; float weight[kTabTerms]; uint32_t cache[kTabTerms]; };
   std::vector<std::vector<QS>> per_query((size_t)n_queries);
-  int64_t total_postings = 0;
+  std::vector<uint32_t> cache_base((size_t)n_queries);
+  std::vector<QTabs> qtabs((size_t)n_queries);
+  int64_t total_postings = 0, total_cost = 0;
+  std::vector<int64_t> term_total;
+  std::vector<int32_t> tab_of_term;
   for (int qi = 0; qi < n_queries; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
-    const uint32_t cache_base = (uint32_t)hp.caches.size();
+    cache_base[(size_t)qi] = (uint32_t)hp.caches.size();
     hp.caches.insert(hp.caches.end(), q.norm_cache, q.norm_cache + (size_t)q.n_caches * 256);
+    // score tables go to the clauses with the most postings over the searched leaves
+    term_total.assign((size_t)q.n_terms, 0);
+    for (int t = 0; t < q.n_terms; ++t)
+      for (int si = 0; si < n_segs; ++si) {
+        auto fit = segs[si]->fields.find(q.terms[t].field_id);
+        if (fit == segs[si]->fields.end()) continue;
+        auto it = fit->second.dict.find(q.terms[t].term_hash);
+        if (it != fit->second.dict.end()) term_total[(size_t)t] += it->second.count;
+      }
+    tab_of_term.assign((size_t)q.n_terms, -1);
+    QTabs& qt_ = qtabs[(size_t)qi];
+    qt_.n = 0;
+    for (int r = 0; r < kTabTerms && r < q.n_terms; ++r) {
+      int best = -1;
+      for (int t = 0; t < q.n_terms; ++t)
+        if (tab_of_term[(size_t)t] < 0 && term_total[(size_t)t] > 0 && (best < 0 || term_total[(size_t)t] > term_total[(size_t)best])) best = t;
+      if (best < 0) break;
+      tab_of_term[(size_t)best] = (int32_t)qt_.n;
+      qt_.weight[qt_.n] = q.terms[best].weight;
+      qt_.cache[qt_.n] = (uint32_t)q.terms[best].cache_slot;
+      qt_.n++;
+    }
     for (int si = 0; si < n_segs; ++si) {
       const nrtgpu_seg* seg = segs[si];
-      QS qs{(uint32_t)hp.terms.size(), 0, si, 0, cache_base, (uint32_t)q.n_caches};
+      QS qs{(uint32_t)hp.terms.size(), 0, si, 0};
       for (int t = 0; t < q.n_terms; ++t) {
         const nrtgpu_term& qt = q.terms[t];
         auto fit = seg->fields.find(qt.field_id);
@@ -562,56 +602,89 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
         d.count = e.count;
         d.shift = e.shift;
         d.weight = qt.weight;
-        d.cache_off = cache_base + (uint32_t)qt.cache_slot * 256u;
+        d.cache_off = cache_base[(size_t)qi] + (uint32_t)qt.cache_slot * 256u;
         d.cache_slot = (uint32_t)qt.cache_slot;
+        d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
         hp.terms.push_back(d);
         qs.n_terms++;
         qs.postings += e.count;
       }
       if (qs.n_terms > 0) {
+        std::stable_sort(hp.terms.begin() + qs.term_begin, hp.terms.end(),
+                         [](const DTerm& a, const DTerm& b) { return a.count > b.count; });
         per_query[(size_t)qi].push_back(qs);
         total_postings += qs.postings;
+        total_cost += qs.postings + (int64_t)seg->n_tiles * kTileCostPostings;
       }
     }
   }
   hp.postings = total_postings;
 
-  // pass 2: cut every (query, segment) into doc-range items of roughly equal posting volume
-  int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : 4 * 2 * (int64_t)std::max(ctx->n_cus, 1);
-  const int64_t min_item_postings = 1 << 16;
-  const int64_t per_item = std::max<int64_t>(min_item_postings, total_postings / std::max<int64_t>(1, target_items));
-  struct Pending { uint32_t rank; uint32_t query; DItem item; };
+  // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
+  // may span several segments (like a LeafSlice) and a large segment may be cut by tile range.
+  const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : 4 * 2 * (int64_t)std::max(ctx->n_cus, 1);
+  const int64_t min_item_cost = 1 << 17;
+  const int64_t per_item = std::max<int64_t>(min_item_cost, total_cost / std::max<int64_t>(1, target_items));
+  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; };
   std::vector<Pending> pend;
   for (int qi = 0; qi < n_queries; ++qi) {
-    uint32_t rank = 0;
+    int64_t q_cost = 0;
+    for (const QS& qs : per_query[(size_t)qi]) q_cost += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
+    if (q_cost == 0) continue;
+    const int64_t n_it = std::max<int64_t>(1, (q_cost + per_item / 2) / per_item);
+    const double budget = (double)q_cost / (double)n_it;
+    Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0};
+    double filled = 0.0;
     for (const QS& qs : per_query[(size_t)qi]) {
       const nrtgpu_seg* seg = segs[qs.seg];
-      int64_t n_it = (qs.postings + per_item - 1) / per_item;
-      n_it = std::max<int64_t>(1, std::min<int64_t>(n_it, seg->n_tiles));
-      const uint32_t tiles_per = (uint32_t)((seg->n_tiles + n_it - 1) / n_it);
-      for (uint32_t tb = 0; tb < seg->n_tiles; tb += tiles_per) {
-        DItem it{};
-        it.live_bits = seg->d_live;
-        it.query = (uint32_t)qi;
-        it.term_begin = qs.term_begin;
-        it.n_terms = qs.n_terms;
-        it.tile_begin = tb;
-        it.tile_end = std::min<uint32_t>(seg->n_tiles, tb + tiles_per);
-        it.max_doc = (uint32_t)seg->max_doc;
-        it.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
-        it.cache_off = qs.cache_off;
-        it.n_caches = qs.n_caches;
-        pend.push_back({rank++, (uint32_t)qi, it});
+      const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
+      uint32_t tb = 0;
+      while (tb < seg->n_tiles) {
+        double room = budget - filled;
+        uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tile_cost + 0.5));
+        take = std::min<uint32_t>(take, seg->n_tiles - tb);
+        DPart p{};
+        p.live_bits = seg->d_live;
+        p.term_begin = qs.term_begin;
+        p.n_terms = qs.n_terms;
+        p.tile_begin = tb;
+        p.tile_end = tb + take;
+        p.max_doc = (uint32_t)seg->max_doc;
+        p.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
+        hp.parts.push_back(p);
+        cur.n_parts++;
+        cur.cost += (int64_t)(take * tile_cost);
+        filled += take * tile_cost;
+        tb += take;
+        if (filled >= budget * 0.999) {  // item full: close it
+          pend.push_back(cur);
+          cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0};
+          filled = 0.0;
+        }
       }
     }
+    if (cur.n_parts > 0) pend.push_back(cur);
   }
-  // chunk-major launch order: the first doc range of every query runs before any second range,
-  // so later ranges start from the theta the earlier ones published.
-  std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.rank < b.rank; });
+  // longest-processing-time-first launch order: the hardware dispatcher hands out workgroups in
+  // index order, so big items start first and small ones fill the tail
+  // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
+  std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.cost > b.cost; });
   hp.items.resize(pend.size());
   std::vector<std::vector<uint32_t>> lists((size_t)n_queries);
   for (size_t i = 0; i < pend.size(); ++i) {
-    hp.items[i] = pend[i].item;
+    DItem it{};
+    it.query = pend[i].query;
+    it.part_begin = pend[i].part_begin;
+    it.n_parts = pend[i].n_parts;
+    it.cache_off = cache_base[pend[i].query];
+    it.n_caches = (uint32_t)queries[pend[i].query].n_caches;
+    const QTabs& qt_ = qtabs[pend[i].query];
+    it.n_tabs = qt_.n;
+    for (uint32_t r = 0; r < qt_.n; ++r) {
+      it.tab_weight[r] = qt_.weight[r];
+      it.tab_cache[r] = qt_.cache[r];
+    }
+    hp.items[i] = it;
     lists[pend[i].query].push_back((uint32_t)i);
   }
   hp.q_base.resize((size_t)n_queries);
@@ -648,6 +721,8 @@ struct DeviceRun {
   uint64_t* out_keys = nullptr;
   uint32_t* out_counts = nullptr;
   uint64_t* out_hits = nullptr;
+  uint64_t* prof = nullptr;   // instrumented variant: 8 counters per item
+  size_t n_items = 0;
 };
 
 // Enqueue plan upload + scan + merge on the slot's stream.  Merge output goes to (ext_keys,
@@ -658,6 +733,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   Carver pc;
   const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
   const size_t o_items = pc.take(n_items * sizeof(DItem));
+  const size_t o_parts = pc.take(hp.parts.size() * sizeof(DPart));
   const size_t o_terms = pc.take(hp.terms.size() * sizeof(DTerm));
   const size_t o_caches = pc.take(hp.caches.size() * sizeof(float));
   const size_t o_lidx = pc.take(hp.list_idx.size() * 4);
@@ -670,6 +746,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   char* hb = (char*)slot->h_plan.p;
   memcpy(hb + o_queries, hp.queries.data(), hp.queries.size() * sizeof(DQuery));
   if (n_items) memcpy(hb + o_items, hp.items.data(), n_items * sizeof(DItem));
+  if (!hp.parts.empty()) memcpy(hb + o_parts, hp.parts.data(), hp.parts.size() * sizeof(DPart));
   if (!hp.terms.empty()) memcpy(hb + o_terms, hp.terms.data(), hp.terms.size() * sizeof(DTerm));
   memcpy(hb + o_caches, hp.caches.data(), hp.caches.size() * sizeof(float));
   if (!hp.list_idx.empty()) memcpy(hb + o_lidx, hp.list_idx.data(), hp.list_idx.size() * 4);
@@ -685,6 +762,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_okeys = wc.take((size_t)n_queries * k_stride_out * 8);
   const size_t o_ocnt = wc.take((size_t)n_queries * 4);
   const size_t o_ohits = wc.take((size_t)n_queries * 8);
+  const int ablation = (ctx->cfg.flags >> 8) & 15;
+  const size_t o_prof = wc.take(ablation == 7 ? n_items * 128 : 0);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   char* db = (char*)slot->d_plan.p;
   char* wb = (char*)slot->d_work.p;
@@ -694,10 +773,10 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   HIP_TRY(hipMemsetAsync(wb + o_theta, 0, (size_t)n_queries * 8, st));
   const bool timing = ctx->cfg.collect_timing != 0;
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
-  launch_bm25_scan(st, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, (uint32_t)n_items, (const DItem*)(db + o_items), (const DTerm*)(db + o_terms),
+  launch_bm25_scan(st, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
                    (unsigned long long*)(wb + o_theta), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
-                   (uint64_t*)(wb + o_ihits), hp.k_stride);
+                   (uint64_t*)(wb + o_ihits), hp.k_stride, ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
   uint64_t* okeys = ext_keys ? ext_keys : (uint64_t*)(wb + o_okeys);
   uint32_t* ocnt = ext_counts ? ext_counts : (uint32_t*)(wb + o_ocnt);
@@ -711,6 +790,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   run->out_keys = okeys;
   run->out_counts = ocnt;
   run->out_hits = ohits;
+  run->prof = ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr;
+  run->n_items = n_items;
   return 0;
 }
 
@@ -786,6 +867,13 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   const uint64_t* hits = (const uint64_t*)(ho + o_h);
   for (int qi = 0; qi < n_queries; ++qi)
     unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, &out[qi]);
+  if (run.prof && run.n_items) {
+    std::vector<uint64_t> hp_prof(run.n_items * 16);
+    HIP_TRY(hipMemcpy(hp_prof.data(), run.prof, hp_prof.size() * 8, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(ctx->stats_mu);
+    for (size_t i = 0; i < run.n_items; ++i)
+      for (int j = 0; j < 16; ++j) ctx->prof[j] += (double)hp_prof[i * 16 + j];
+  }
   account(ctx, slot, hp, n_queries, plan_ms);
   return NRTGPU_OK;
 }

@@ -97,7 +97,7 @@ def main():
                         "scan_ms": round(scan_ms, 3), "merge_ms": round(st["merge_ms"] / L, 3),
                         "plan_ms": round(st["host_plan_ms"] / L, 3), "items": st["scan_items"] / L,
                         "GBps_scan": round(bytes_l / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else None,
-                        "checksum": cs}))
+                        "checksum": cs, "profile": ctx.scan_profile() if ((fl >> 8) & 15) == 7 else None}))
         for l in leaves:
             l.release()
         ctx.close()

@@ -237,8 +237,13 @@ def test_chunking_and_prefetch_invariance(mid, oracle):
         c2.close()
 
 
-def test_many_fields_use_global_cache_path(ctx, oracle):
-    # 3 fields => the third normInverse table is read from HBM instead of LDS
+def test_two_fields_parity_three_fields_fall_back(ctx, oracle):
+    # two scored fields: both normInverse tables live in LDS; a third field is beyond the device
+    # fast path (NRTGPU_ERR_UNSUPPORTED -> the caller runs Lucene)
+    import ctypes as C
+
+    from oracle import oracle as o
+
     corpus = synth.build_corpus(50_000, [1, 4, 20], n_segments=1)
     seg = corpus.segments[0]
     g = api.GpuSegment(ctx, seg.max_doc, 0)
@@ -251,25 +256,28 @@ def test_many_fields_use_global_cache_path(ctx, oracle):
             stats.doc_freq[(field, t)] = df
     g.seal()
     sr = api.GpuIndexSearcher(ctx, [g], stats)
-    q = api.BooleanQuery((api.TermQuery(0, 1), api.TermQuery(1, 4), api.TermQuery(2, 20)))
+    clauses = [(0, 1), (1, 4), (1, 20), (0, 20)]
+    q = api.BooleanQuery(tuple(api.TermQuery(f, t) for f, t in clauses))
     got = sr.search(q, api.TopScoreDocCollectorManager(100, None, INT_MAX))
-    # oracle: same three terms, each with its own field statistics
-    from oracle import oracle as o
     col = o.Collector(100, None, INT_MAX)
-    import ctypes as C
-    arr = (o._Term * 3)()
+    arr = (o._Term * len(clauses))()
     keep = []
-    for i, (field, t) in enumerate([(0, 1), (1, 4), (2, 20)]):
+    for i, (field, t) in enumerate(clauses):
         d, f = seg.postings(t)
-        d = np.ascontiguousarray(d); f = np.ascontiguousarray(f)
+        d = np.ascontiguousarray(d)
+        f = np.ascontiguousarray(f)
         cs = stats.fields[field]
         cache = o.bm25_norm_cache(float(o.bm25_avgdl(cs.sum_total_term_freq, cs.doc_count)))
         keep += [d, f, cache]
         arr[i].docids, arr[i].freqs, arr[i].n = d.ctypes.data, f.ctypes.data, len(d)
         arr[i].weight = float(o.bm25_idf(cs.doc_count, corpus.doc_freq[t]))
         arr[i].norms, arr[i].cache = seg.norms.ctypes.data, cache.ctypes.data
-    o.lib().nrt_oracle_search_segment(seg.max_doc, 0, None, 3, C.byref(arr), col._h)
-    assert_same("fields3", got, col.topdocs(), 100, INT_MAX)
+    o.lib().nrt_oracle_search_segment(seg.max_doc, 0, None, len(clauses), C.byref(arr), col._h)
+    assert_same("fields2", got, col.topdocs(), 100, INT_MAX)
+    q3 = api.BooleanQuery((api.TermQuery(0, 1), api.TermQuery(1, 4), api.TermQuery(2, 20)))
+    with pytest.raises(api.NrtGpuError) as e:
+        sr.search(q3, api.TopScoreDocCollectorManager(100))
+    assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
     g.release()
 
 
