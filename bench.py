@@ -33,6 +33,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="queries per step")
+    ap.add_argument("--host-threads", type=int, default=2,
+                    help="N=1 only: host threads submitting steps (plan building of step i+1 overlaps the kernels of step i)")
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "SMOKE"])
     ap.add_argument("--docs", type=int, default=0, help="override the number of docs (debug)")
     ap.add_argument("--target-items", type=int, default=0)
@@ -109,9 +111,10 @@ def main():
         d_keys = torch.zeros((B, k_stride), dtype=torch.int64, device="cuda")
         d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
         d_hits = torch.zeros((B,), dtype=torch.int64, device="cuda")
-        g_keys = torch.zeros((world, B, k_stride), dtype=torch.int64, device="cuda")
-        g_cnt = torch.zeros((world, B), dtype=torch.int32, device="cuda")
-        g_hits = torch.zeros((world, B), dtype=torch.int64, device="cuda")
+        # all-gather outputs in concatenation form: rank r's rows are [r * B, (r + 1) * B)
+        g_keys = torch.zeros((world * B, k_stride), dtype=torch.int64, device="cuda")
+        g_cnt = torch.zeros((world * B,), dtype=torch.int32, device="cuda")
+        g_hits = torch.zeros((world * B,), dtype=torch.int64, device="cuda")
         ks = [w.k] * B
         thr = [api.TOTAL_HITS_THRESHOLD] * B
 
@@ -144,11 +147,28 @@ def main():
     ctx.reset_stats()
     fence()
     lat = []
+    n_thr = max(1, args.host_threads) if world == 1 else 1  # collectives must be issued in one order
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ts = time.perf_counter()
-        step(args.warmup + i)
-        lat.append(time.perf_counter() - ts)
+    if n_thr == 1:
+        for i in range(args.steps):
+            ts = time.perf_counter()
+            step(args.warmup + i)
+            lat.append(time.perf_counter() - ts)
+    else:
+        # the C ABI is thread-safe (one workspace + HIP stream per in-flight call); ctypes drops the GIL
+        import threading
+
+        def worker(tix):
+            for i in range(tix, args.steps, n_thr):
+                ts = time.perf_counter()
+                batches[(args.warmup + i) % len(batches)].run()
+                lat.append(time.perf_counter() - ts)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -197,6 +217,7 @@ def main():
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": st["scan_items"] / max(1, st["batches"]),
             "prefetch": not args.no_prefetch,
+            "host_threads": n_thr,
             "corpus_build_s": round(t_build, 1),
         },
         "roofline": {

@@ -168,6 +168,8 @@ struct nrtgpu_ctx {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<std::unique_ptr<Slot>> slots;
+  std::mutex gpu_mu;    // device execution of one batch at a time: a scan kernel wants the whole GPU,
+                        // overlapping two only stretches both (host-side planning/unpacking still overlap)
   std::mutex stats_mu;
   nrtgpu_stats stats{};
   double prof[16] = {0};
@@ -556,18 +558,25 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
   int64_t total_postings = 0, total_cost = 0;
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term;
+  std::vector<const TermEntry*> found;
+  std::vector<const FieldData*> found_field;
   for (int qi = 0; qi < n_queries; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
     cache_base[(size_t)qi] = (uint32_t)hp.caches.size();
     hp.caches.insert(hp.caches.end(), q.norm_cache, q.norm_cache + (size_t)q.n_caches * 256);
-    // score tables go to the clauses with the most postings over the searched leaves
+    // one dictionary lookup per (clause, leaf); score tables go to the clauses with the most postings
+    found.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
+    found_field.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
     term_total.assign((size_t)q.n_terms, 0);
     for (int t = 0; t < q.n_terms; ++t)
       for (int si = 0; si < n_segs; ++si) {
         auto fit = segs[si]->fields.find(q.terms[t].field_id);
         if (fit == segs[si]->fields.end()) continue;
         auto it = fit->second.dict.find(q.terms[t].term_hash);
-        if (it != fit->second.dict.end()) term_total[(size_t)t] += it->second.count;
+        if (it == fit->second.dict.end() || it->second.count == 0) continue;
+        found[(size_t)t * n_segs + si] = &it->second;
+        found_field[(size_t)t * n_segs + si] = &fit->second;
+        term_total[(size_t)t] += it->second.count;
       }
     tab_of_term.assign((size_t)q.n_terms, -1);
     QTabs& qt_ = qtabs[(size_t)qi];
@@ -587,12 +596,10 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
       QS qs{(uint32_t)hp.terms.size(), 0, si, 0};
       for (int t = 0; t < q.n_terms; ++t) {
         const nrtgpu_term& qt = q.terms[t];
-        auto fit = seg->fields.find(qt.field_id);
-        if (fit == seg->fields.end()) continue;
-        const FieldData& f = fit->second;
-        auto it = f.dict.find(qt.term_hash);
-        if (it == f.dict.end() || it->second.count == 0) continue;
-        const TermEntry& e = it->second;
+        const TermEntry* ep = found[(size_t)t * n_segs + si];
+        if (!ep) continue;
+        const TermEntry& e = *ep;
+        const FieldData& f = *found_field[(size_t)t * n_segs + si];
         const TermGroup& g = f.groups[e.group];
         DTerm d{};
         d.docids = g.d_docids;
@@ -622,7 +629,10 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
 
   // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
   // may span several segments (like a LeafSlice) and a large segment may be cut by tile range.
-  const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : 4 * 2 * (int64_t)std::max(ctx->n_cus, 1);
+  // Measured on MI355X (one 16-wave workgroup per CU): every extra item of a query costs a cold
+  // top-k start, so a query is cut only when it alone would take longer than its fair share of the
+  // batch on one CU.  target_items == 0 => one share per CU.
+  const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : (int64_t)std::max(ctx->n_cus, 1);
   const int64_t min_item_cost = 1 << 17;
   const int64_t per_item = std::max<int64_t>(min_item_cost, total_cost / std::max<int64_t>(1, target_items));
   struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; };
@@ -852,16 +862,19 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   acquire_slot(ctx, &slot);
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
   DeviceRun run;
-  if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run)) return rc;
   const size_t kb = (size_t)n_queries * hp.k_stride * 8, cb = (size_t)n_queries * 4, hb = (size_t)n_queries * 8;
   Carver oc;
   const size_t o_k = oc.take(kb), o_c = oc.take(cb), o_h = oc.take(hb);
   if (int rc = slot->h_out.reserve(oc.off)) return rc;
   char* ho = (char*)slot->h_out.p;
-  HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
-  HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
-  HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
-  HIP_TRY(hipStreamSynchronize(slot->stream));
+  {
+    std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run)) return rc;
+    HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipStreamSynchronize(slot->stream));
+  }
   const uint64_t* keys = (const uint64_t*)(ho + o_k);
   const uint32_t* cnts = (const uint32_t*)(ho + o_c);
   const uint64_t* hits = (const uint64_t*)(ho + o_h);
@@ -902,10 +915,13 @@ extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg
   acquire_slot(ctx, &slot);
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
   DeviceRun run;
-  if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
-                              (uint64_t*)d_hits, &run))
-    return rc;
-  HIP_TRY(hipStreamSynchronize(slot->stream));
+  {
+    std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
+                                (uint64_t*)d_hits, &run))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(slot->stream));
+  }
   account(ctx, slot, hp, n_queries, plan_ms);
   return NRTGPU_OK;
 }

@@ -1,0 +1,53 @@
+"""One process per GPU: index sharding and the final exchange of SURVEY.md section 8e.
+
+  * partition: rank r owns a contiguous docid range (tile aligned) of the index -- large segments are
+    cut by docid range, exactly what Lucene 10's LeafReaderContextPartition allows
+    (/root/reference/src/main/java/com/yelp/nrtsearch/server/search/MyIndexSearcher.java:172-187);
+    BM25 statistics stay index-global (idf/avgdl are computed once on the host, never per GPU).
+  * exchange: every rank holds, per query, its local top-k as packed keys
+    (float_bits(score) << 32 | 0xFFFFFFFF - global_doc) plus counts and hit totals; ONE RCCL
+    all-gather per array (torch.distributed backend "nccl" == RCCL over xGMI) puts all ranks'
+    lists next to each other and every rank runs the same TopDocs.merge kernel
+    (LazyQueueTopScoreDocCollectorManager.java:137-144).  No other data-path collective.
+
+The same code runs on CPU tensors with the gloo backend (tests/test_dist_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+
+def pack_keys(docs: np.ndarray, scores: np.ndarray, k_stride: int) -> np.ndarray:
+    """(score desc, doc asc) hits -> int64[k_stride] packed keys, unused tail 0 (device layout)."""
+    out = np.zeros(k_stride, dtype=np.uint64)
+    n = len(docs)
+    bits = np.asarray(scores, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    out[:n] = (bits << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - np.asarray(docs, dtype=np.uint64))
+    return out.view(np.int64)
+
+
+def unpack_keys(keys: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
+    u = np.asarray(keys[:n]).view(np.uint64)
+    docs = (np.uint64(0xFFFFFFFF) - (u & np.uint64(0xFFFFFFFF))).astype(np.int32)
+    scores = (u >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    return docs, scores
+
+
+def all_gather_topk(keys, counts, hits):
+    """keys [B, k_stride] int64, counts [B] int32, hits [B] int64 (same device on every rank)
+    -> gathered ([W, B, k_stride], [W, B], [W, B]) on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    b = keys.shape[0]
+    # concatenation form (world * B rows): accepted by both RCCL and gloo
+    g_keys = torch.empty((world * b,) + tuple(keys.shape[1:]), dtype=keys.dtype, device=keys.device)
+    g_cnt = torch.empty((world * b,), dtype=counts.dtype, device=counts.device)
+    g_hits = torch.empty((world * b,), dtype=hits.dtype, device=hits.device)
+    dist.all_gather_into_tensor(g_keys, keys.contiguous())
+    dist.all_gather_into_tensor(g_cnt, counts.contiguous())
+    dist.all_gather_into_tensor(g_hits, hits.contiguous())
+    return g_keys.view((world, b) + tuple(keys.shape[1:])), g_cnt.view(world, b), g_hits.view(world, b)
