@@ -160,6 +160,33 @@ int  nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_querie
                               const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * Exact (brute-force) float vector search.  Replaces ExactFloatVectorQuery's scorer loop
+ * (src/main/java/com/yelp/nrtsearch/server/query/vector/ExactVectorQuery.java:137-173: score =
+ * VectorSimilarityFunction.compare(query, docVector) * boost for every doc that has a vector) plus
+ * the top-k collector behind it; also the exact reading of the `knn` request path (recall 1.0;
+ * compare against ExactFloatVectorQuery, not HNSW).
+ *   sim: 0 cosine, 1 dot_product (unit vectors; also "normalized_cosine"), 2 l2_norm, 3 max_inner_product
+ *        (mapping: src/main/java/com/yelp/nrtsearch/server/field/VectorFieldDef.java:77-88)
+ *   queries: n_queries * dim fp32, row-major (already normalised by the caller where the field asks
+ *        for it, VectorFieldDef.java:564-573)
+ * Scores are fp32 sums in MFMA order: equal to Lucene within 1e-5 relative (Lucene's own order
+ * depends on the JVM's vector width); docids ranked by (score desc, doc asc).
+ * --------------------------------------------------------------------------------------------- */
+int  nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                      int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k,
+                      float boost, nrtgpu_topdocs* out /* n_queries */);
+
+/* Vector rescorer: RescoreOperation.rescore(hits, ctx) of a QueryRescore whose rescoreQuery is an exact
+ * vector query (src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-57): every
+ * first-pass hit gets combined = (float)(queryWeight * first + rescoreWeight * vectorScore) (double
+ * arithmetic; hits without a vector keep queryWeight * first), hits are re-sorted by (score desc,
+ * doc asc) and trimmed to `window`.  docs are global docids; doc_bases maps them to segments. */
+int  nrtgpu_rescore_vectors(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                            int32_t field_id, int32_t sim, const float* query, int32_t dim, float boost,
+                            const int32_t* docs, const float* first_scores, int32_t n, double query_weight,
+                            double rescore_weight, int32_t window, nrtgpu_topdocs* out);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side restatements the Java shim would otherwise take from Lucene objects
  * (BM25Similarity.scorer(boost, collectionStats, termStats); SmallFloat; slices()).
  * --------------------------------------------------------------------------------------------- */

@@ -337,6 +337,49 @@ class GpuIndexSearcher:
     def search(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
         return self.search_batch([query], [manager])[0]
 
+    # ---- vectors: ExactFloatVectorQuery / vector rescorer ------------------------------------------
+    SIMILARITY = {"cosine": 0, "dot_product": 1, "normalized_cosine": 1, "l2_norm": 2, "max_inner_product": 3}
+
+    def knn_exact(self, field: int, similarity: str, queries: np.ndarray, k: int, boost: float = 1.0) -> List[TopDocs]:
+        """Brute-force exact vector search over every doc with a vector (S/query/vector/ExactVectorQuery.java)."""
+        queries = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        if similarity == "normalized_cosine":  # unit-normalised query + dot product (VectorFieldDef.java:568-573)
+            queries = queries / np.linalg.norm(queries, axis=1, keepdims=True).astype(np.float32)
+            queries = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = queries.shape
+        outs = (_lib.TopDocs * nq)()
+        docs = np.zeros((nq, k), dtype=np.int32)
+        scores = np.zeros((nq, k), dtype=np.float32)
+        for qi in range(nq):
+            outs[qi].capacity = k
+            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_knn_exact(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
+                                                self.SIMILARITY[similarity], queries.ctypes.data, nq, dim, int(k),
+                                                C.c_float(boost), outs))
+        return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
+                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
+
+    def rescore_vectors(self, hits: TopDocs, field: int, similarity: str, query: np.ndarray, window: int,
+                        query_weight: float = 1.0, rescore_weight: float = 1.0, boost: float = 1.0) -> TopDocs:
+        """RescoreOperation.rescore with a QueryRescore whose rescoreQuery is an exact vector query
+        (S/rescore/QueryRescore.java:40-57)."""
+        query = np.ascontiguousarray(query, dtype=np.float32)
+        d = np.ascontiguousarray(hits.docs, dtype=np.int32)
+        s = np.ascontiguousarray(hits.scores, dtype=np.float32)
+        out = _lib.TopDocs()
+        od = np.zeros(max(window, 1), dtype=np.int32)
+        os_ = np.zeros(max(window, 1), dtype=np.float32)
+        out.capacity = window
+        out.docs = od.ctypes.data_as(C.POINTER(C.c_int32))
+        out.scores = os_.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_rescore_vectors(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
+                                                      self.SIMILARITY[similarity], query.ctypes.data, len(query),
+                                                      C.c_float(boost), d.ctypes.data, s.ctypes.data, len(d),
+                                                      float(query_weight), float(rescore_weight), int(window),
+                                                      C.byref(out)))
+        return TopDocs(od[: out.n_hits].copy(), os_[: out.n_hits].copy(), hits.total_hits, hits.relation_gte)
+
 
 # ---- pre-marshalled batches (bench / serving loop: no Python work inside the timed region) --------
 class PreparedBatch:
@@ -411,3 +454,27 @@ def slices(max_docs: Sequence[int], num_docs: Optional[Sequence[int]] = None, vi
     for i in range(n):
         out[sl[i]].append(i)
     return out, sh[:n].tolist()
+
+
+# ---- blenders (multi-retriever; O(k) host work that stays in Java in the reference) ----------------
+def weighted_rrf_blend(retriever_hits: Sequence[np.ndarray], boosts: Optional[Sequence[float]] = None, k: int = 60,
+                       start_hit: int = 0, top_hits: int = 10) -> TopDocs:
+    """WeightedRrfBlenderOperation.mergeHits + BlenderOperation.sortAndPaginate
+    (S/search/multiretriever/blender/operation/WeightedRrfBlenderOperation.java:53-78,
+    .../score/WeightedRRFScoreDoc.java:62,75): score(doc) = sum over retrievers of boost / (k + rank),
+    rank 1-based, accumulated in fp32 in retriever declaration order.  Equal scores are returned in
+    docid order here (the reference leaves ties to its heap's order)."""
+    if k < 1:
+        raise ValueError(f"k must be >= 1, got: {k}")
+    if top_hits == 0 or start_hit > top_hits:
+        return TopDocs(np.zeros(0, np.int32), np.zeros(0, np.float32), 0, True)
+    merged: Dict[int, np.float32] = {}
+    for ri, docs in enumerate(retriever_hits):
+        w = np.float32(1.0 if boosts is None else boosts[ri])
+        for i, doc in enumerate(np.asarray(docs).tolist()):
+            contrib = np.float32(w / np.float32(k + i + 1))
+            merged[doc] = np.float32(merged[doc] + contrib) if doc in merged else contrib
+    order = sorted(merged.items(), key=lambda kv: (-float(kv[1]), kv[0]))[: min(top_hits, len(merged))]
+    page = order[min(start_hit, len(order)):]
+    return TopDocs(np.asarray([d for d, _ in page], np.int32), np.asarray([s for _, s in page], np.float32),
+                   len(merged), True)

@@ -1,0 +1,257 @@
+// knn.hip -- exact (brute-force) float vector search and vector rescoring on gfx950.
+//
+// Replaces, for ExactFloatVectorQuery / the brute-force reading of KnnFloatVectorQuery:
+//   /root/reference/src/main/java/com/yelp/nrtsearch/server/query/vector/ExactVectorQuery.java:137-173
+//   (VectorValuesScorer.score() = VectorSimilarityFunction.compare(query, doc vector) * boost for
+//   EVERY doc that has a vector) + the TopScoreDocCollector behind it, and for the rescore tail
+//   /root/reference/src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-57.
+// Similarity -> score mapping: VectorFieldDef.java:77-88 / docs/field_types/vector.rst:26-35.
+//
+// knn_score_kernel: C[32 docs x 32 queries] tiles on the matrix cores with the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: an fp32 fma chain, no reduced precision).  The query panel (<= 32
+// queries x dim) sits in LDS in MFMA-operand order; vector rows stream from HBM once per batch of
+// <= 32 queries (roofline: HBM, N * dim * 4 bytes per batch; MFMA-bound only above ~40 queries).
+// Float summation order differs from Lucene's (which itself depends on the JVM's SIMD width), so
+// scores carry a tolerance (tests: 1e-5 relative), docids/ranks are compared modulo that.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.h"
+#include "topk.hiph"
+
+namespace nrtgpu {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKnnThreads = 512;  // 8 waves, each owns 32 docs per step
+constexpr int kKnnQ = 32;         // queries per launch (MFMA tile width)
+
+// out[i] = sum_k v[i][k]^2 (fp32, sequential chunks) -- used by cosine.
+__global__ __launch_bounds__(256) void knn_row_norms_kernel(const float* __restrict__ vecs, int32_t dim, int64_t n,
+                                                            float* __restrict__ norm2) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (row >= n) return;
+  const float* v = vecs + row * dim;
+  float s = 0.f;
+  for (int32_t k = (int32_t)lane; k < dim; k += 64) s += v[k] * v[k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) norm2[row] = s;
+}
+
+__device__ __forceinline__ float knn_map_score(int sim, float dot, float nq, float nv, float boost) {
+  float s;
+  if (sim == 0) {  // COSINE: max((1 + cos) / 2, 0), cos = (float)(dot / sqrt((double)nq * nv))
+    const float c = (float)((double)dot / sqrt((double)nq * (double)nv));
+    s = fmaxf((1.0f + c) / 2.0f, 0.0f);
+  } else if (sim == 1) {  // DOT_PRODUCT: max((1 + dot) / 2, 0)
+    s = fmaxf((1.0f + dot) / 2.0f, 0.0f);
+  } else if (sim == 2) {  // EUCLIDEAN: 1 / (1 + |q - v|^2), |q - v|^2 = nq + nv - 2 dot
+    const float d2 = fmaxf(nq + nv - 2.0f * dot, 0.0f);
+    s = 1.0f / (1.0f + d2);
+  } else {  // MAXIMUM_INNER_PRODUCT
+    s = dot < 0.0f ? 1.0f / (1.0f - dot) : dot + 1.0f;
+  }
+  return s * boost;
+}
+
+// Scores docs [row_begin, row_end) of one segment against <= 32 queries; hits with key > theta[q]
+// are appended to query q's candidate list.  dim must be a multiple of 8.
+//   qpanel : n_q * dim floats (row-major), qnorm2 : n_q floats
+//   cand   : n_q lists of `cap` keys, cand_cnt : n_q counters (may exceed cap => overflow, host redoes)
+__global__ __launch_bounds__(kKnnThreads, 2)
+void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ vnorm2,
+                      const int32_t* __restrict__ ord_to_doc, const uint64_t* __restrict__ live_bits,
+                      int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
+                      const float* __restrict__ qpanel, const float* __restrict__ qnorm2, int32_t n_q, int32_t sim,
+                      float boost, const unsigned long long* __restrict__ theta, uint64_t* __restrict__ cand,
+                      uint32_t* __restrict__ cand_cnt, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* qs = (f32x4*)smem;  // [dim/8][2][32] float4: chunk c, half h, query n -> q[n][8c + 4h .. +4]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n = lane & 31u, h = lane >> 5;
+  const int32_t chunks = dim >> 3;
+  for (int32_t i = (int32_t)tid; i < chunks * 64; i += kKnnThreads) {
+    const int32_t c = i >> 6, hh = (i >> 5) & 1, q = i & 31;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < n_q) v = *(const f32x4*)(qpanel + (int64_t)q * dim + 8 * c + 4 * hh);
+    qs[i] = v;
+  }
+  __syncthreads();
+  const float nq = (int32_t)n < n_q ? qnorm2[n] : 0.f;
+  const unsigned long long th = (int32_t)n < n_q ? theta[n] : ~0ull;
+
+  const int64_t rows_per_block = (int64_t)(kKnnThreads / 64) * 32;
+  for (int64_t r0 = row_begin + (int64_t)blockIdx.x * rows_per_block + (int64_t)wave * 32; r0 < row_end;
+       r0 += (int64_t)gridDim.x * rows_per_block) {
+    // A operand: lane (n, h) streams row r0 + n (clamped), floats 8c + 4h .. +4 per chunk
+    const int64_t row = min(r0 + (int64_t)n, row_end - 1);
+    const f32x4* vp = (const f32x4*)(vecs + row * dim) + h;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 a_next = __builtin_nontemporal_load(vp);
+    for (int32_t c = 0; c < chunks; ++c) {
+      const f32x4 a = a_next;
+      if (c + 1 < chunks) a_next = __builtin_nontemporal_load(vp + 2 * (c + 1));
+      const f32x4 b = qs[c * 64 + (int32_t)lane];  // (h, n) == lane order
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+    }
+    // D layout: col (query) = lane & 31, row (doc in tile) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if ((int32_t)n < n_q) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int64_t drow = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * (int32_t)h;
+        if (drow < row_end) {
+          const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
+          bool live = true;
+          if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+          if (live) {
+            const float sc = knn_map_score(sim, acc[reg], nq, vnorm2[drow], boost);
+            const uint64_t key = pack_key(sc, (uint32_t)(doc_base + ldoc));
+            if (key > th) {
+              const uint32_t pos = atomicAdd(&cand_cnt[n], 1u);
+              if (pos < cap) cand[(size_t)n * cap + pos] = key;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Per query: top-k of (running top-k  UNION  the round's candidate list) -> running top-k (sorted),
+// theta[q] = k-th key once k hits are known.  One workgroup per query.
+struct KnnSelSmem {
+  uint64_t cand[kMergeCap];
+  TopkScratch sc;
+  uint64_t theta;
+  uint32_t cnt;
+  uint32_t pad;
+};
+
+__global__ __launch_bounds__(kScanThreads)
+void knn_select_kernel(uint64_t* __restrict__ topk, uint32_t* __restrict__ topk_cnt, uint32_t k_stride, uint32_t k,
+                       const uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt, uint32_t cap,
+                       unsigned long long* __restrict__ theta, uint32_t* __restrict__ overflow) {
+  __shared__ KnnSelSmem s;
+  const uint32_t tid = threadIdx.x, q = blockIdx.x;
+  if (tid == 0) {
+    s.theta = 0;
+    s.cnt = 0;
+  }
+  __syncthreads();
+  const uint32_t n_prev = topk_cnt[q];
+  const uint32_t n_raw = cand_cnt[q];
+  if (n_raw > cap && tid == 0) *overflow = 1u;  // the host shrinks the round and repeats it
+  const uint32_t n_cand = min(n_raw, cap);
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint64_t* src = pass == 0 ? topk + (size_t)q * k_stride : cand + (size_t)q * cap;
+    const uint32_t c = pass == 0 ? n_prev : n_cand;
+    for (uint32_t off = 0; off < c; off += kScanThreads) {
+      const uint32_t i = off + tid;
+      const uint64_t key = (i < c) ? src[i] : 0;
+      const bool want = (i < c) && (key > s.theta);
+      topk_append(s.cand, &s.cnt, want, key);
+      __syncthreads();
+      const uint32_t cn = s.cnt;
+      __syncthreads();
+      if (cn > (uint32_t)(kMergeCap - kScanThreads)) {
+        uint64_t thr = 0;
+        const uint32_t m = topk_compact<kScanThreads, kMergeCap>(s.cand, cn, k, &s.sc, &thr);
+        if (tid == 0) {
+          s.cnt = m;
+          if (thr > s.theta) s.theta = thr;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t c = s.cnt;
+    __syncthreads();
+    if (c > k) {
+      uint64_t thr = 0;
+      const uint32_t m = topk_compact<kScanThreads, kMergeCap>(s.cand, c, k, &s.sc, &thr);
+      if (tid == 0) s.cnt = m;
+      __syncthreads();
+    }
+  }
+  const uint32_t n = s.cnt;
+  uint32_t n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (uint32_t i = n + tid; i < n2; i += kScanThreads) s.cand[i] = 0;
+  bitonic_sort_desc<kScanThreads>(s.cand, n2);
+  uint64_t* out = topk + (size_t)q * k_stride;
+  for (uint32_t i = tid; i < k_stride; i += kScanThreads) out[i] = (i < n) ? s.cand[i] : 0;
+  if (tid == 0) {
+    topk_cnt[q] = n;
+    cand_cnt[q] = 0;
+    if (n == k) theta[q] = s.cand[k - 1];
+  }
+}
+
+// Rescore: one wave per candidate doc: exact similarity of the query vector with the doc's vector
+// (vec_row[i] = row of candidate i in this segment's matrix, < 0: no vector => "second pass does
+// not match"), combined as QueryRescore.combine: (float)(qw * first + rw * second) in double.
+__global__ __launch_bounds__(256)
+void rescore_vectors_kernel(const float* __restrict__ vecs, const float* __restrict__ vnorm2, int32_t dim,
+                            const float* __restrict__ query, float qnorm2, int32_t sim, float boost,
+                            const int64_t* __restrict__ vec_row, const float* __restrict__ first_scores, int32_t n,
+                            double qw, double rw, float* __restrict__ out_scores) {
+  const int32_t i = (int32_t)(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const uint32_t lane = threadIdx.x & 63u;
+  if (i >= n) return;
+  const int64_t row = vec_row[i];
+  float second = 0.f;
+  if (row >= 0) {
+    const float* v = vecs + row * dim;
+    float dot = 0.f;
+    for (int32_t k = (int32_t)lane; k < dim; k += 64) dot += v[k] * query[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) dot += __shfl_xor(dot, d, 64);
+    second = knn_map_score(sim, dot, qnorm2, vnorm2[row], boost);
+  }
+  if (lane == 0) {
+    const double comb = row >= 0 ? qw * (double)first_scores[i] + rw * (double)second : qw * (double)first_scores[i];
+    out_scores[i] = (float)comb;
+  }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float* norm2) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(knn_row_norms_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, vecs, dim, n, norm2);
+}
+size_t knn_score_lds_bytes(int32_t dim) { return (size_t)(dim >> 3) * 64 * 16; }
+int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
+                     const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
+                     const float* qpanel, const float* qnorm2, int32_t n_q, int32_t sim, float boost,
+                     const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap) {
+  if (row_end <= row_begin) return 0;
+  const size_t lds = knn_score_lds_bytes(dim);
+  hipError_t e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(knn_score_kernel, dim3(blocks), dim3(kKnnThreads), lds, st, vecs, vnorm2, ord_to_doc, live_bits, dim,
+                     row_begin, row_end, doc_base, qpanel, qnorm2, n_q, sim, boost, theta, cand, cand_cnt, cap);
+  return 0;
+}
+void launch_knn_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,
+                       const uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, unsigned long long* theta,
+                       uint32_t* overflow) {
+  hipLaunchKernelGGL(knn_select_kernel, dim3(n_q), dim3(kScanThreads), 0, st, topk, topk_cnt, k_stride, k, cand, cand_cnt,
+                     cap, theta, overflow);
+}
+void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnorm2, int32_t dim, const float* query,
+                            float qnorm2, int32_t sim, float boost, const int64_t* vec_row, const float* first_scores,
+                            int32_t n, double qw, double rw, float* out_scores) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(rescore_vectors_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, vecs, vnorm2, dim, query,
+                     qnorm2, sim, boost, vec_row, first_scores, n, qw, rw, out_scores);
+}
+
+}  // namespace nrtgpu

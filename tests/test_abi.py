@@ -134,3 +134,24 @@ def test_reference_slice_golden_vectors(lib):
     ]
     for kw, sizes, docs, segs in cases:
         assert _shape(sizes, **kw) == (docs, segs), (kw, sizes)
+
+
+# ---- blender: src/test/java/com/yelp/nrtsearch/server/search/MultiRetrieverSearchTest.java:410-497 ------
+def test_weighted_rrf_blend_golden():
+    # one retriever: RRF score at rank r is 1/(60+r) +- 1e-5
+    td = api.weighted_rrf_blend([np.array([7, 3, 9])], top_hits=10)
+    assert td.docs.tolist() == [7, 3, 9]
+    for r, s in enumerate(td.scores.tolist(), start=1):
+        assert abs(s - 1.0 / (60 + r)) <= 1e-5
+    # docs found by both retrievers outrank 1/61
+    td = api.weighted_rrf_blend([np.array([1, 2, 3]), np.array([3, 4, 1])], top_hits=10)
+    both = {1, 3}
+    assert set(td.docs[:2].tolist()) == both and all(s > 1.0 / 61 for s in td.scores[:2].tolist())
+    assert td.total_hits == 4 and td.relation_gte
+    # boosts / pagination / k validation (WeightedRRFScoreDocTest.java)
+    td = api.weighted_rrf_blend([np.array([5]), np.array([6])], boosts=[1.0, 3.0], top_hits=2)
+    assert td.docs.tolist() == [6, 5] and abs(float(td.scores[0]) - 3.0 / 61) < 1e-6
+    assert api.weighted_rrf_blend([np.array([1, 2, 3])], start_hit=1, top_hits=3).docs.tolist() == [2, 3]
+    assert len(api.weighted_rrf_blend([np.array([1])], top_hits=0).docs) == 0
+    with pytest.raises(ValueError):
+        api.weighted_rrf_blend([np.array([1])], k=0)

