@@ -41,6 +41,10 @@ def parse_args():
     ap.add_argument("--no-prefetch", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=192, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the multi-GPU path (device-resident top-k -> all-gather -> merge) even at world size 1")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="debug, 1 GPU: index only rank 0's docid range of an N-GPU job (per-rank step time at --gpus N)")
     return ap.parse_args()
 
 
@@ -94,7 +98,8 @@ def main():
     n_distinct = max(B, (w.n_queries // B) * B)
     qranks = synth.make_queries(n_distinct, w.n_terms, w.max_rank)
     t_build = time.perf_counter()
-    corpus = workload.build_shard_corpus(w, qranks, world, rank)
+    shard_world, shard_rank = (args.emulate_world, 0) if (args.emulate_world > 1 and world == 1) else (world, rank)
+    corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank)
     t_build = time.perf_counter() - t_build
 
     flags = _lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0
@@ -107,34 +112,75 @@ def main():
     ppq = workload.postings_per_query(corpus.doc_freq, qranks)   # index-global P per query
 
     k_stride = (w.k + 15) // 16 * 16
-    if world > 1:
-        d_keys = torch.zeros((B, k_stride), dtype=torch.int64, device="cuda")
-        d_cnt = torch.zeros((B,), dtype=torch.int32, device="cuda")
-        d_hits = torch.zeros((B,), dtype=torch.int64, device="cuda")
+    use_dist = world > 1 or args.force_dist
+    NB = 3  # device result buffers in flight between the scan threads and the exchange thread
+    if use_dist:
+        bufs = [(torch.zeros((B, k_stride), dtype=torch.int64, device="cuda"),
+                 torch.zeros((B,), dtype=torch.int32, device="cuda"),
+                 torch.zeros((B,), dtype=torch.int64, device="cuda")) for _ in range(NB)]
         # all-gather outputs in concatenation form: rank r's rows are [r * B, (r + 1) * B)
         g_keys = torch.zeros((world * B, k_stride), dtype=torch.int64, device="cuda")
         g_cnt = torch.zeros((world * B,), dtype=torch.int32, device="cuda")
         g_hits = torch.zeros((world * B,), dtype=torch.int64, device="cuda")
-        ks = [w.k] * B
-        thr = [api.TOTAL_HITS_THRESHOLD] * B
+        merger = api.PreparedMerge(ctx, world, B, k_stride, [w.k] * B, [api.TOTAL_HITS_THRESHOLD] * B)
+
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
 
     last = {}
+    lat = []
 
-    def step(i):
-        pb = batches[i % len(batches)]
-        if world == 1:
-            pb.run()
-            last["td"] = pb
-        else:
-            pb.run_device(k_stride, d_keys.data_ptr(), d_cnt.data_ptr(), d_hits.data_ptr())
-            # final exchange of SURVEY 8e: RCCL all-gather of the per-GPU top-k over xGMI ...
-            dist.all_gather_into_tensor(g_keys, d_keys)
-            dist.all_gather_into_tensor(g_cnt, d_cnt)
-            dist.all_gather_into_tensor(g_hits, d_hits)
-            torch.cuda.synchronize()
-            # ... then TopDocs.merge on every rank
-            last["td"] = api.merge_topk_device(ctx, world, B, k_stride, g_keys.data_ptr(), g_cnt.data_ptr(),
-                                               g_hits.data_ptr(), ks, thr)
+    def run_steps(first, count, record):
+        """`count` steps starting at batch index `first`.  The C ABI is thread-safe (one workspace + HIP
+        stream per in-flight call, ctypes drops the GIL), so plan building of step i+1 overlaps the
+        kernels of step i.  Multi-GPU: scan threads leave each rank's top-k in HBM; this thread issues
+        the collectives in step order (RCCL all-gather over xGMI) and runs TopDocs.merge on every rank."""
+        if not use_dist:
+            n_thr = max(1, args.host_threads)
+
+            def worker(tix):
+                for i in range(tix, count, n_thr):
+                    ts = time.perf_counter()
+                    pb = batches[(first + i) % len(batches)]
+                    pb.run()
+                    if record:
+                        lat.append(time.perf_counter() - ts)
+                    last["td"] = pb
+
+            if n_thr == 1:
+                worker(0)
+            else:
+                threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+                for t in threads:
+                    t.start()
+                for t in threads:
+                    t.join()
+            return
+        free = [threading.Semaphore(1) for _ in range(NB)]
+        t_start = [0.0] * count
+
+        def produce(i):
+            b = i % NB
+            free[b].acquire()          # the exchange thread has gathered this buffer's previous contents
+            t_start[i] = time.perf_counter()
+            keys, cnt, hits = bufs[b]
+            batches[(first + i) % len(batches)].run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())
+            return b
+
+        with ThreadPoolExecutor(max_workers=max(1, args.host_threads)) as ex:  # FIFO: steps start in order
+            futs = [ex.submit(produce, i) for i in range(count)]
+            for i in range(count):
+                b = futs[i].result()
+                keys, cnt, hits = bufs[b]
+                dist.all_gather_into_tensor(g_keys, keys) if world > 1 else g_keys.copy_(keys)
+                dist.all_gather_into_tensor(g_cnt, cnt) if world > 1 else g_cnt.copy_(cnt)
+                dist.all_gather_into_tensor(g_hits, hits) if world > 1 else g_hits.copy_(hits)
+                torch.cuda.current_stream().synchronize()   # only this stream: the next scan keeps running
+                free[b].release()
+                merger.run(g_keys.data_ptr(), g_cnt.data_ptr(), g_hits.data_ptr())
+                if record:
+                    lat.append(time.perf_counter() - t_start[i])
+        last["td"] = merger
 
     def fence():
         torch.cuda.synchronize()
@@ -142,33 +188,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup, False)
     ctx.reset_stats()
     fence()
-    lat = []
-    n_thr = max(1, args.host_threads) if world == 1 else 1  # collectives must be issued in one order
+    n_thr = max(1, args.host_threads)
     t0 = time.perf_counter()
-    if n_thr == 1:
-        for i in range(args.steps):
-            ts = time.perf_counter()
-            step(args.warmup + i)
-            lat.append(time.perf_counter() - ts)
-    else:
-        # the C ABI is thread-safe (one workspace + HIP stream per in-flight call); ctypes drops the GIL
-        import threading
-
-        def worker(tix):
-            for i in range(tix, args.steps, n_thr):
-                ts = time.perf_counter()
-                batches[(args.warmup + i) % len(batches)].run()
-                lat.append(time.perf_counter() - ts)
-
-        threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+    run_steps(args.warmup, args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -190,7 +215,7 @@ def main():
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            if rec.get("workload") == args.workload and rec.get("batch") == B and world == 1:
+            if rec.get("workload") == args.workload and rec.get("batch") == B and world == 1 and shard_world == 1:
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -213,7 +238,8 @@ def main():
             "n_docs": w.n_docs, "terms_per_query": w.n_terms, "k": w.k, "batch_queries": B,
             "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
             "segments_per_gpu": len(corpus.segments),
-            "sharding": "contiguous docid ranges, 1 process per GPU" + (", RCCL all-gather of per-GPU top-k + merge" if world > 1 else ""),
+            "sharding": "contiguous docid ranges, 1 process per GPU" + (", RCCL all-gather of per-GPU top-k + merge" if use_dist else "")
+                        + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": st["scan_items"] / max(1, st["batches"]),
             "prefetch": not args.no_prefetch,

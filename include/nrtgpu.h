@@ -56,7 +56,7 @@ typedef struct {
   int32_t target_items;     /* work items (query x doc-range) aimed for per batch; 0 => auto */
   int32_t collect_timing;   /* !=0: bracket the scan kernel with HIP events (nrtgpu_get_stats) */
   int32_t flags;            /* NRTGPU_FLAG_* */
-  int32_t reserved;
+  int32_t host_threads;     /* planner threads used inside one batch call (term-dictionary lookups); 0 => 4 */
 } nrtgpu_config;
 
 #define NRTGPU_FLAG_NO_PREFETCH 1  /* scan kernel without the one-tile-ahead posting prefetch (A/B) */

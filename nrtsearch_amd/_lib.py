@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnrtgpu.so")
+LIB_PATH = os.environ.get("NRTGPU_LIB_PATH") or os.path.join(_HERE, "libnrtgpu.so")  # override: A/B builds of the kernels
 
 NRTGPU_OK = 0
 NRTGPU_ERR_INVALID_ARG = -1
@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
 
 class Config(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("max_batch", C.c_int32), ("target_items", C.c_int32),
-                ("collect_timing", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("collect_timing", C.c_int32), ("flags", C.c_int32), ("host_threads", C.c_int32)]
 
 
 class Term(C.Structure):

@@ -130,9 +130,9 @@ class BM25Similarity:
 # ---- device context / segment store --------------------------------------------------------------
 class GpuContext:
     def __init__(self, device_id: int = 0, max_batch: int = 1024, target_items: int = 0,
-                 collect_timing: bool = False, flags: int = 0):
+                 collect_timing: bool = False, flags: int = 0, host_threads: int = 0):
         L = _lib.load()
-        cfg = _lib.Config(device_id, max_batch, target_items, int(collect_timing), flags, 0)
+        cfg = _lib.Config(device_id, max_batch, target_items, int(collect_timing), flags, host_threads)
         h = C.c_void_p()
         _lib.check(L.nrtgpu_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -417,24 +417,42 @@ class PreparedBatch:
                        bool(o.total_hits_is_lower_bound))
 
 
+class PreparedMerge:
+    """TopDocs.merge of all-gathered per-GPU results, output arrays marshalled once; `run()` is a
+    single C-ABI call (nrtgpu_merge_topk_device).  List l of query q is row l * n_queries + q of the
+    gathered arrays (all_gather_into_tensor concatenation order)."""
+
+    def __init__(self, ctx: GpuContext, n_lists: int, n_queries: int, k_stride: int, ks: Sequence[int],
+                 thresholds: Sequence[int]):
+        self.ctx, self.n_lists, self.n, self.k_stride = ctx, int(n_lists), int(n_queries), int(k_stride)
+        self._ks = np.ascontiguousarray(ks, dtype=np.int32)
+        self._thr = np.ascontiguousarray(thresholds, dtype=np.int32)
+        kmax = int(self._ks.max())
+        self._outs = (_lib.TopDocs * self.n)()
+        self.docs = np.zeros((self.n, kmax), dtype=np.int32)
+        self.scores = np.zeros((self.n, kmax), dtype=np.float32)
+        for qi in range(self.n):
+            self._outs[qi].capacity = kmax
+            self._outs[qi].docs = self.docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+            self._outs[qi].scores = self.scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+
+    def run(self, d_keys: int, d_counts: int, d_hits: int) -> None:
+        _lib.check(_lib.load().nrtgpu_merge_topk_device(
+            self.ctx._h, self.n_lists, self.n, self.k_stride, C.c_void_p(d_keys), C.c_void_p(d_counts),
+            C.c_void_p(d_hits), self._ks.ctypes.data, self._thr.ctypes.data, self._outs))
+
+    def topdocs(self, qi: int) -> TopDocs:
+        o = self._outs[qi]
+        return TopDocs(self.docs[qi, : o.n_hits].copy(), self.scores[qi, : o.n_hits].copy(), int(o.total_hits),
+                       bool(o.total_hits_is_lower_bound))
+
+
 def merge_topk_device(ctx: GpuContext, n_lists: int, n_queries: int, k_stride: int, d_keys: int, d_counts: int,
                       d_hits: int, ks: Sequence[int], thresholds: Sequence[int]) -> List[TopDocs]:
     """TopDocs.merge of all-gathered per-GPU results (device pointers as ints)."""
-    ks_a = np.ascontiguousarray(ks, dtype=np.int32)
-    th_a = np.ascontiguousarray(thresholds, dtype=np.int32)
-    outs = (_lib.TopDocs * n_queries)()
-    kmax = int(ks_a.max())
-    docs = np.zeros((n_queries, kmax), dtype=np.int32)
-    scores = np.zeros((n_queries, kmax), dtype=np.float32)
-    for qi in range(n_queries):
-        outs[qi].capacity = kmax
-        outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
-        outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
-    _lib.check(_lib.load().nrtgpu_merge_topk_device(ctx._h, n_lists, n_queries, k_stride, C.c_void_p(d_keys),
-                                                    C.c_void_p(d_counts), C.c_void_p(d_hits), ks_a.ctypes.data,
-                                                    th_a.ctypes.data, outs))
-    return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(),
-                    int(outs[qi].total_hits), bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n_queries)]
+    pm = PreparedMerge(ctx, n_lists, n_queries, k_stride, ks, thresholds)
+    pm.run(d_keys, d_counts, d_hits)
+    return [pm.topdocs(qi) for qi in range(n_queries)]
 
 
 def slices(max_docs: Sequence[int], num_docs: Optional[Sequence[int]] = None, virtual_shards: int = 1,

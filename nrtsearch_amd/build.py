@@ -23,15 +23,17 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra=()) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, extra=(), out: str = OUT) -> str:
+    """extra: additional hipcc flags (e.g. -DNRT_SCAN_WAVES=12 -DNRT_TILE_DOCS=1024 for an A/B build
+    written to `out`; NRTGPU_LIB_PATH makes nrtsearch_amd._lib load it)."""
+    if not force and out == OUT and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    cmd = [hipcc] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -40,20 +40,19 @@ typedef const NRT_GLOBAL float* gf32_ptr;
 constexpr uint64_t kUnmatched = 0x8000000000000000ull;  // -0.0: "no term matched this doc yet"
 
 
-// Work decomposition (v6): a workgroup is 8 AUTONOMOUS waves.  Wave w of an item walks the 512-doc
-// sub-tiles w, w+8, w+16, ... of each part on its own: load postings -> fp64 accumulate into its
-// private 4 KiB LDS sub-tile -> sweep it -> collect competitive docs into the workgroup's shared
-// candidate buffer.  No workgroup barrier in steady state: 16 waves per CU sit at different points
-// of that chain and hide each other's LDS / HBM latency.  Per-term metadata of a sub-tile lives in
-// lane registers (lane l <-> term l) and is exchanged with wave shuffles.  Barriers happen only at a
-// rendezvous when the shared candidate buffer overflows (top-k compaction) and between parts.
+// Work decomposition: a workgroup is 16 AUTONOMOUS waves and owns one CU (all 160 KiB of LDS).  The
+// sub-tiles (768 docs) of an item's parts form one sequence; wave w walks sub-tiles w, w+16, ... of it
+// on its own: load postings -> fp64 accumulate into its private 6 KiB LDS sub-tile -> collect the
+// competitive docs into the workgroup's shared candidate buffer.  No workgroup barrier in steady
+// state (not even between parts): 16 waves sit at different points of that chain and hide each
+// other's LDS / HBM latency.  Per-term metadata of a sub-tile lives in lane registers (lane l <-> term
+// l) and in a small wave-private LDS table.  Barriers happen only at a rendezvous when the shared
+// candidate buffer overflows (top-k compaction) and at the end of the item.
 struct ScanSmem {
-  double   acc[kScanWaves][kTileDocs];     // fp64 score accumulators: one 512-doc sub-tile per wave (32 KiB)
-  uint64_t cand[kCandCap];                 // competitive hits of the item (packed keys), unordered (16 KiB)
+  double   acc[kScanWaves][kTileDocs];     // fp64 score accumulators: one sub-tile per wave (96 KiB)
+  uint64_t cand[kCandCap];                 // competitive hits of the item (packed keys), unordered (15 KiB)
   float    tab[kTabTerms][kTabEntries];    // BM25 score of (freq, norm byte) for the item's densest terms
   float    cache[kLdsCaches][256];         // BM25 normInverse tables of the query's fields (division path)
-  float    t_weight[kMaxTerms];            // division path: per term of the current part
-  uint32_t t_slot[kMaxTerms];
   // wave-private view of the wave's current sub-tile, written by lanes 0..31 (lane l <-> term l):
   alignas(16) uint32_t w_incl[kScanWaves][kMaxTerms];     // 8-posting pairs of terms 0..l (inclusive prefix)
   alignas(16) uint32_t w_rec[kScanWaves][kMaxTerms][4];   // addr_d lo, addr_d hi, delta16, meta
@@ -64,13 +63,14 @@ struct ScanSmem {
   uint32_t tile_cand;    // rendezvous: competitive hits still parked in the accumulators
   uint32_t hits;         // live matching docs of this item
   uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet at the rendezvous
-  uint32_t done;         // waves that finished the current part
+  uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kCandCap
   uint32_t pad;
   uint64_t prof[16];     // instrumented variant only (ABL == 7)
+  double   dummy[64];    // per-lane sink for invalid postings; always holds the "unmatched" marker (see group_prepare)
 };
 static_assert(sizeof(ScanSmem) <= 160 * 1024, "the scan workgroup owns one CU's 160 KiB LDS");
 
-constexpr int kSlots = kTileDocs / 64;  // accumulator slots per lane
+constexpr int kSlots = kTileDocs / 64;  // accumulator slots per lane (dense sweep)
 
 __device__ __forceinline__ uint64_t dbl_bits(double d) { return (uint64_t)__double_as_longlong(d); }
 __device__ __forceinline__ double unmatched_value() { return __longlong_as_double((long long)kUnmatched); }
@@ -94,33 +94,40 @@ __device__ __forceinline__ uint32_t scan32_dpp(uint32_t x) {
   return x;
 }
 
+// Inclusive prefix sum over all 64 lanes (lane 63 ends up with the wave total).
+__device__ __forceinline__ uint32_t scan64_dpp(uint32_t x) {
+  x = scan32_dpp(x);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 // Per-term view of one sub-tile, built by lane l for term l and published in the wave's LDS table.
-//   meta: 16-byte groups (bits 0-19) | first valid posting (20-22) | last valid + 1 (23-25) |
+// The term's postings of the sub-tile are seen through a window of 16-byte groups (4 postings each):
+//   meta: end (bits 0-22): postings [first, end) of the window belong to the sub-tile | first (23-25) |
 //         score table (26-28, 7 = none) | coarse cell: postings may lie outside the sub-tile (29)
 // A lane processes a PAIR of consecutive groups (8 postings) per instruction.
-constexpr uint32_t kMetaGroups = 0xFFFFFu;
+constexpr uint32_t kMetaEnd = 0x7FFFFFu;
 
 // Lane-as-term: posting range [lo, hi) of my term in a sub-tile -> table entry; returns the number of
-// pair-instructions lanes of the whole sub-tile (wave-uniform).
+// pair-instruction lanes of the whole sub-tile (wave-uniform).
 __device__ __forceinline__ uint32_t subtile_build(ScanSmem& s, uint32_t wave, uint32_t lane, uint64_t my_docids,
                                                   uint32_t my_delta16, uint64_t my_lo, uint32_t my_flags, uint32_t lo,
                                                   uint32_t hi, bool use) {
-  uint32_t ng = 0, first = 0, last = 0;
+  uint32_t end = 0, first = 0;
   uint64_t gs = my_lo >> 2;  // empty range: a group that is always safe to (pre)load
   if (use && hi > lo) {
-    const uint64_t a = my_lo + lo, b = my_lo + hi;
+    const uint64_t a = my_lo + lo;
     gs = a >> 2;
-    ng = (uint32_t)(((b + 3) >> 2) - gs);
     first = (uint32_t)(a & 3u);
-    last = ((uint32_t)(b - 1) & 3u) + 1u;
+    end = first + (hi - lo);
   }
   const uint64_t addr_d = my_docids + gs * 16u;
-  const uint32_t np = (ng + 1u) >> 1;  // pairs
+  const uint32_t np = (end + 7u) >> 3;  // pairs
   const uint32_t incl = scan32_dpp(np);
   if (lane < (uint32_t)kMaxTerms) {
     s.w_incl[wave][lane] = incl;
     s.w_before[wave][lane] = incl - np;
-    u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16, ng | (first << 20) | (last << 23) | (my_flags << 26)};
+    u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16, end | (first << 23) | (my_flags << 26)};
     *(u32x4*)&s.w_rec[wave][lane][0] = rec;
   }
   return (uint32_t)__builtin_amdgcn_readlane((int)incl, kMaxTerms - 1);
@@ -129,7 +136,7 @@ __device__ __forceinline__ uint32_t subtile_build(ScanSmem& s, uint32_t wave, ui
 // One pair of 4-posting groups: docids, score codes, and which (term, pair-in-term) it is.
 struct Group {
   u32x4 d4[2], c4[2];
-  uint32_t p;     // pair index inside the term's range of this sub-tile
+  uint32_t p;     // pair index inside the term's window of this sub-tile
   uint32_t meta;  // the term's meta
   uint32_t term;  // term index inside the part (division path only)
 };
@@ -161,27 +168,30 @@ __device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wa
   gr.c4[1] = __builtin_nontemporal_load((gvec_ptr)ac + 1);
 }
 
-// Adds the 8 postings of a pair into the wave's sub-tile.  Fast path: score = one LDS table read,
-// accumulator address = one shift-add.
+// Scoring a pair of groups happens in two steps so that the registers holding the loaded column
+// words can be recycled for the next sub-tile's loads in between:
+//   group_prepare: per posting the byte offset of its doc's accumulator (off) and its BM25 score (sc,
+//                  one LDS table read; division only for postings / terms no table serves) + validity
+//   group_commit_add: one fp64 LDS atomic per posting.
+// Invalid postings of a pair (outside the term's window / the sub-tile) are redirected instead of
+// predicated: they add -0.0 to the lane's dummy slot, which holds the "unmatched" marker -0.0 forever
+// (-0.0 + -0.0 == -0.0), so neither the adds nor the collecting swaps need per-posting control flow
+// (a conditionally executed returning LDS op makes the compiler wait for each result at the end of
+// its branch) and a dummy never looks like a matched doc.
 template <int ABL>
-__device__ __forceinline__ void group_score(ScanSmem& s, double* acc, const Group& gr, bool valid, uint32_t base,
-                                            uint32_t tile_len) {
-  if (!__any(valid)) return;  // wave-uniform
+__device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group& gr, bool valid, uint32_t base,
+                                                  uint32_t tile_len, uint32_t dummy_off, const DTerm* __restrict__ part_terms,
+                                                  uint32_t (&off)[8], float (&sc)[8]) {
   const uint32_t meta = gr.meta;
-  const uint32_t ng = meta & kMetaGroups;
-  const uint32_t first = (meta >> 20) & 7u, last = (meta >> 23) & 7u;
-  // valid postings: interior groups are full, the term's first / last group may start / end mid-group,
-  // the second group of the last pair may not exist
-  const uint32_t k0 = 2u * gr.p;
-  uint32_t m0 = ((1u << ((k0 + 1u == ng) ? last : 4u)) - 1u) & ~((1u << ((k0 == 0u) ? first : 0u)) - 1u);
-  uint32_t m1 = (1u << ((k0 + 2u == ng) ? last : 4u)) - 1u;
-  m0 = (k0 < ng) ? m0 : 0u;
-  m1 = (k0 + 1u < ng) ? m1 : 0u;
-  uint32_t vmask = valid ? (m0 | (m1 << 4)) : 0u;
+  // valid postings of my pair: window positions [first, end) intersected with [8p, 8p + 8)
+  const int idx0 = (int)(gr.p * 8u);
+  const int lo_cut = (int)((meta >> 23) & 7u) - idx0, hi_cut = (int)(meta & kMetaEnd) - idx0;
+  const uint32_t hm = (1u << (uint32_t)min(max(hi_cut, 0), 8)) - 1u;
+  const uint32_t lm = (1u << (uint32_t)min(max(lo_cut, 0), 8)) - 1u;
+  uint32_t vmask = valid ? (hm & ~lm) : 0u;
   const uint32_t tab = (meta >> 26) & 7u;
   // byte offset of the doc's accumulator inside the wave's sub-tile: (doc - base) * 8 in one op
   const uint32_t nbase8 = 0u - base * 8u;
-  uint32_t off[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) off[j] = (gr.d4[j >> 2][j & 3] << 3) + nbase8;  // unsigned: out-of-tile docs wrap to huge values
   if (__any((meta >> 29) & 1u)) {
@@ -191,59 +201,63 @@ __device__ __forceinline__ void group_score(ScanSmem& s, double* acc, const Grou
       if (off[j] >= tile_len * 8u) vmask &= ~(1u << j);
   }
   // postings the score table cannot serve: freq > kTabMaxFreq / norm >= kTabNorms (sign bit of the
-  // code) or a term without a table.  They are rare: handled per lane after the table path.
-  uint32_t emask = 0;
+  // code) or a term without a table.  Rare: one OR-reduction decides whether anybody in the wave
+  // needs the division at all.
+  uint32_t cor = gr.c4[0][0] | gr.c4[0][1] | gr.c4[0][2];
+  cor |= gr.c4[0][3] | gr.c4[1][0];
+  cor |= gr.c4[1][1] | gr.c4[1][2];
+  cor |= gr.c4[1][3];
+  const bool special = vmask != 0u && ((cor >> 31) != 0u || tab == 7u);
+  const char* tb = (const char*)&s.tab[0][0] + (tab == 7u ? 0u : tab) * (uint32_t)(kTabEntries * 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) emask |= (gr.c4[j >> 2][j & 3] >> 31) << j;
-  emask = (tab == 7u) ? 0xFFu : emask;
-  const uint32_t tmask = vmask & ~emask;  // served by the table
-  const uint32_t gmask = vmask & emask;   // need the division
-  if (ABL == 2) {
-    asm volatile("" ::"v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[7]), "v"(vmask));
-    return;
-  }
-  {
-    const char* tb = (const char*)(&s.tab[0][0] + (tab == 7u ? 0u : tab) * (uint32_t)kTabEntries);
-    char* const accb = (char*)acc;
-    float sc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sc[j] = *(const float*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
-    if (__all(tmask == 0xFFu)) {  // wave-uniform: only full pairs, all table-served
-#pragma unroll
-      for (int j = 0; j < 8; ++j) unsafeAtomicAdd((double*)(accb + off[j]), (double)sc[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if ((tmask >> j) & 1u) unsafeAtomicAdd((double*)(accb + off[j]), (double)sc[j]);
-    }
-  }
-  if (__any(gmask != 0u)) {
-    // division path: long docs / high freqs / terms without a score table (a few lanes)
-    const float w = s.t_weight[gr.term];
-    const float* cache = &s.cache[s.t_slot[gr.term]][0];
+  for (int j = 0; j < 8; ++j) sc[j] = *(const float*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
+  if (__any(special)) {
+    // long docs / high freqs / terms without a score table (a few lanes)
+    const float w = part_terms[gr.term].weight;
+    const float* cache = &s.cache[part_terms[gr.term].cache_slot][0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t c = gr.c4[j >> 2][j & 3];
-      const uint32_t f = (c >> 31) ? ((c >> 8) & 0x7FFFFFu) : (c >> 9);
-      const uint32_t nb = (c >> 31) ? (c & 255u) : ((c >> 2) & 127u);
-      if ((gmask >> j) & 1u)
-        unsafeAtomicAdd((double*)((char*)acc + off[j]), (double)bm25_score(w, (float)(int32_t)f, cache[nb]));
+      const bool esc = (c >> 31) != 0u;
+      const uint32_t f = esc ? ((c >> 8) & 0x7FFFFFu) : (c >> 9);
+      const uint32_t nb = esc ? (c & 255u) : ((c >> 2) & 127u);
+      if (((vmask >> j) & 1u) && (esc || tab == 7u)) sc[j] = bm25_score(w, (float)(int32_t)f, cache[nb]);
     }
   }
+  if (!__all(vmask == 0xFFu)) {  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool v = (vmask >> j) & 1u;
+      off[j] = v ? off[j] : dummy_off;
+      sc[j] = v ? sc[j] : -0.0f;
+    }
+  }
+  return vmask;
 }
 
-// Workgroup-wide rendezvous body: keep the k best of (candidate buffer UNION the candidates the
-// waves still have parked in their sub-tiles), publish theta.  Every thread calls it; cmask / slot
-// addressing describe this thread's parked candidates (none for a wave that is past its last
-// sub-tile).  Contains barriers; returns with the buffer consistent and cmask consumed.
-__device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, uint32_t cmask, uint32_t gdoc0, uint32_t k,
+// One fp64 LDS atomic per posting (invalid ones were redirected by group_prepare).
+__device__ __forceinline__ void group_commit_add(char* accb, const uint32_t (&off)[8], const float (&sc)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) unsafeAtomicAdd((double*)(accb + off[j]), (double)sc[j]);
+}
+
+// Workgroup-wide rendezvous body: keep the k best of (candidate buffer UNION the candidates a wave
+// still has parked in its sub-tile), publish theta.  Every thread calls it.  A wave whose reservation
+// failed (`parked`) has reset every non-competitive slot of its sub-tile, so its parked candidates are
+// exactly the slots still matched; other waves have none.  Contains barriers; returns with the buffer
+// consistent and nothing parked.
+__device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, bool parked, uint32_t gdoc0, uint32_t k,
                                                    unsigned long long* theta_g) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  uint32_t ncand = (uint32_t)__popc(cmask);
+  uint32_t cmask = 0;
+  if (parked) {  // wave-uniform
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) ncand += __shfl_xor(ncand, d, 64);
+    for (int j = 0; j < kSlots; ++j) cmask |= (uint32_t)(dbl_bits(acc[lane + 64u * (uint32_t)j]) != kUnmatched) << j;
+  }
+  const uint32_t ncand = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp((uint32_t)__popc(cmask)), 63);
   if (lane == 0 && ncand) atomicAdd(&s.tile_cand, ncand);
-  const uint32_t cnt0 = s.cnt;
+  const uint32_t cnt_raw = s.cnt;
+  const uint32_t cnt0 = cnt_raw > (uint32_t)kCandCap ? s.cnt_valid : cnt_raw;  // failed reservations inflate cnt
   __syncthreads();  // every thread holds the same cnt0; tile_cand complete
   const uint32_t tc = s.tile_cand;
   uint64_t thr = 0;
@@ -263,6 +277,9 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, uin
       atomicMax(theta_g, (unsigned long long)thr);  // LazyMaxScoreAccumulator.accumulate analogue
       s.prof[6] += 1;
     }
+    __syncthreads();
+  } else {
+    if (tid == 0) s.cnt = cnt0;
     __syncthreads();
   }
 #pragma unroll 1
@@ -284,10 +301,41 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, uin
   __syncthreads();
 }
 
-// PIPE = true: the first kPf posting groups per lane of the wave's next sub-tile are loaded before
-// the current one is swept.  ABL: timing ablations / instrumentation.
+// Out-of-line entry: the compaction needs many registers of its own; as a call it costs the walk
+// nothing (live values are saved around the call, a few times per item) instead of inflating the
+// register demand of the whole kernel.  The LDS pointer keeps its address space across the call.
+typedef __attribute__((address_space(3))) ScanSmem* lds_smem_ptr;
+__device__ __noinline__ void rendezvous_call(lds_smem_ptr sp, uint32_t wave, bool parked, uint32_t gdoc0, uint32_t k,
+                                             unsigned long long* theta_g) {
+  ScanSmem& s = *(ScanSmem*)sp;
+  rendezvous_compact(s, &s.acc[wave][0], parked, gdoc0, k, theta_g);
+}
+
+// Reserve room for the wave's `mine`-per-lane candidates in the shared buffer: one DPP scan and ONE
+// LDS atomic.  Returns the lane's first slot, or kCandCap when the wave's candidates do not fit
+// (rz_flag raised: the caller leaves them parked in its sub-tile and the whole workgroup meets at
+// the rendezvous).  cnt only grows between rendezvous, so exactly the first reservation that crosses
+// the end has base <= kCandCap: everything below its base is completely written -> cnt_valid.
+__device__ __forceinline__ uint32_t reserve_candidates(ScanSmem& s, uint32_t lane, uint32_t mine) {
+  const uint32_t incl = scan64_dpp(mine);
+  const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t wbase = 0;
+  if (lane == 0) {
+    wbase = atomicAdd(&s.cnt, wave_total);
+    if (wbase + wave_total > (uint32_t)kCandCap) {
+      if (wbase <= (uint32_t)kCandCap) s.cnt_valid = wbase;
+      __hip_atomic_store(&s.rz_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+  if (wbase + wave_total > (uint32_t)kCandCap) return (uint32_t)kCandCap;
+  return wbase + incl - mine;
+}
+
+// PIPE = true: the first posting pair per lane of the wave's next sub-tile is loaded before the
+// current one is collected.  ABL == 7: instrumented variant (event counters per item).
 template <bool PIPE, int ABL>
-__global__ __launch_bounds__(kScanThreads, 4)
+__global__ __launch_bounds__(kScanThreads, kScanWaves / 4)
 void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts,
                       const DTerm* __restrict__ terms, const DQuery* __restrict__ queries,
                       const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
@@ -297,6 +345,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
   double* const acc = &s.acc[wave][0];
+  char* const accb = (char*)acc;
+  const uint32_t dummy_off = (uint32_t)((char*)&s.dummy[lane] - accb);  // wraps: LDS byte addresses are 32-bit
   const DItem item = items[blockIdx.x];
   const DQuery q = queries[item.query];
   const uint32_t k = q.k;
@@ -314,9 +364,10 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     s.tile_cand = 0;
     s.hits = 0;
     s.rz_flag = 0;
-    s.done = 0;
+    s.cnt_valid = 0;
     for (int i = 0; i < 16; ++i) s.prof[i] = 0;
   }
+  if (tid < 64) s.dummy[tid] = unmatched_value();
   __syncthreads();
   for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
     const float w = items[blockIdx.x].tab_weight[slot];  // (indexing the register copy would spill it)
@@ -324,71 +375,87 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kScanThreads)
       s.tab[slot][e] = bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]);  // row 0 (freq 0) never read
   }
+  __syncthreads();  // tables complete; from here on the waves run on their own
   uint32_t my_hits = 0;    // per-lane count (general sweep)
-  uint32_t wave_hits = 0;  // wave-uniform count (simple sweep), added once by lane 0
+  uint32_t wave_hits = 0;  // wave-uniform count, added once by lane 0
+  uint32_t phase = 0;      // sub-tiles of the item's earlier parts, mod kScanWaves: the round-robin continues across parts
+  // A rendezvous interrupts the walk: the wave leaves its loops (so that the compaction code is not
+  // inside them, holding every loop register live), and afterwards resumes at (pi, resume_sub) by
+  // re-running the part prologue.
+  constexpr uint32_t kNoResume = 0xFFFFFFFFu;
+  uint32_t pi = 0, resume_sub = kNoResume;
+  bool parked = false;     // wave-uniform: my candidates did not fit the shared buffer (they wait in my sub-tile)
+  uint32_t gdoc0 = 0;      // global docid of slot 0 of my current sub-tile
 
-  for (uint32_t pi = 0; pi < item.n_parts; ++pi) {
+  for (;;) {  // epochs between rendezvous
+  bool interrupted = false;
+  for (; pi < item.n_parts; ++pi) {
     const DPart part = parts[item.part_begin + pi];
+    // this wave's sub-tiles of the part: sub, sub + kScanWaves, ...
+    uint32_t sub = part.tile_begin + (wave >= phase ? wave - phase : wave + (uint32_t)kScanWaves - phase);
+    if (resume_sub != kNoResume) sub = resume_sub;
+    resume_sub = kNoResume;
+    const uint32_t next_phase = (phase + (part.tile_end - part.tile_begin)) % (uint32_t)kScanWaves;
+    if (sub >= part.tile_end) {  // wave-uniform: nothing (left) for this wave in this part
+      phase = next_phase;
+      continue;
+    }
     const uint32_t n_terms = part.n_terms;
+    const DTerm* const part_terms = terms + part.term_begin;
     const NRT_GLOBAL uint64_t* const live_bits = (const NRT_GLOBAL uint64_t*)part.live_bits;
     const bool simple = (live_bits == nullptr) && !q.has_after;  // uniform: no deletes, no searchAfter
-    __syncthreads();  // previous part fully done (all waves passed its final rendezvous); tables built
-    // lane l of every wave looks after term min(l, n_terms - 1) of this part (registers)
-    const DTerm mt = terms[part.term_begin + min(lane, n_terms - 1u)];
+    // lane l looks after term min(l, n_terms - 1) of this part (registers)
+    const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     const uint64_t my_docids = (uint64_t)mt.docids, my_lo = mt.start;
     const uint32_t my_delta16 = (uint32_t)(((uint64_t)mt.fnorm - (uint64_t)mt.docids) >> 4);  // same allocation
     const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
     const uint32_t my_shift = mt.shift;
     const uint32_t my_flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | ((mt.shift != 0 ? 1u : 0u) << 3);
     const bool has_term = lane < n_terms;
-    if (tid < n_terms) {
-      s.t_weight[tid] = mt.weight;
-      s.t_slot[tid] = mt.cache_slot;
-    }
-    if (tid == 0) s.done = 0;
-    __syncthreads();
 
     const uint32_t last_tile = part.tile_end - 1u;
-    uint32_t sub = part.tile_begin + wave;  // this wave's sub-tiles: sub, sub + 8, ...
     // software pipeline state: the wave's LDS table describes sub-tile `sub` (total_groups pairs),
-    // (nlo, nhi) are the cell values of sub + 8, pf holds the first 64 pairs of `sub`
+    // (nlo, nhi) are the cell values of sub + 16, pf holds the first 64 pairs of `sub`
     uint32_t nlo, nhi;
     uint32_t total_groups;
     {
-      const uint32_t c0 = min(sub, last_tile) >> my_shift;
-      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, my_cells[c0], my_cells[c0 + 1],
-                                   has_term && sub < part.tile_end);
+      const uint32_t c0 = sub >> my_shift;
+      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, my_cells[c0], my_cells[c0 + 1], has_term);
       const uint32_t c1 = min(sub + kScanWaves, last_tile) >> my_shift;
       nlo = my_cells[c1];
       nhi = my_cells[c1 + 1];
     }
     Group pf;
     if (PIPE) group_locate_load(s, wave, n_terms, lane, total_groups, pf);
-    uint32_t cmask = 0;   // candidates parked in my sub-tile (only after a failed reservation)
-    uint32_t gdoc0 = 0;   // global docid of slot 0 of my current sub-tile
 
     for (; sub < part.tile_end; sub += kScanWaves) {
       const uint32_t base = sub * (uint32_t)kTileDocs;
       const uint32_t tile_len = min((uint32_t)kTileDocs, part.max_doc - base);
       gdoc0 = (uint32_t)(part.doc_base + (int32_t)base);
-      uint64_t tp0 = 0, tp1 = 0, tp2 = 0;
-      if (ABL == 7 && tid == 0) tp0 = __builtin_readcyclecounter();
+      if (ABL == 7 && tid == 0) s.prof[7] += 1;
 
-      // ---- (1) stream the postings: coalesced 32 B/lane column loads, table-lookup BM25, fp64 LDS accumulate
+      // ---- (1) score the postings: coalesced 32 B/lane column loads (already in flight), table-lookup BM25
       const uint32_t cur_groups = total_groups;
+      const bool sparse = simple && cur_groups <= 64u;  // wave-uniform: collect through the postings instead of a sweep
+      uint32_t off[8];
+      float sc[8];
       if (cur_groups != 0) {
-        if (!PIPE) group_locate_load(s, wave, n_terms, lane, cur_groups, pf);
-        group_score<ABL>(s, acc, pf, lane < cur_groups, base, tile_len);
-        if (ABL == 7 && tid == 0) s.prof[8] += 1;
-        for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // wave-uniform trip count
+        for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // dense sub-tile: pairs beyond the first 64 (wave-uniform trip count)
           Group a;
+          uint32_t off2[8];
+          float sc2[8];
           group_locate_load(s, wave, n_terms, vb + lane, cur_groups, a);
-          group_score<ABL>(s, acc, a, vb + lane < cur_groups, base, tile_len);
+          group_prepare<ABL>(s, a, vb + lane < cur_groups, base, tile_len, dummy_off, part_terms, off2, sc2);
+          group_commit_add(accb, off2, sc2);
           if (ABL == 7 && tid == 0) s.prof[10] += 1;
         }
+        if (!PIPE) group_locate_load(s, wave, n_terms, lane, cur_groups, pf);
+        group_prepare<ABL>(s, pf, lane < cur_groups, base, tile_len, dummy_off, part_terms, off, sc);
+        if (ABL == 7 && tid == 0) s.prof[8] += 1;
       }
 
-      // ---- (2) start the next sub-tile's traffic: its table, its first posting pairs, the cells after it, theta
+      // ---- (2) start the next sub-tile's traffic (the column words in pf are consumed): its table, its
+      //      first posting pairs, the cells after it, theta
       total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, nlo, nhi,
                                    has_term && sub + kScanWaves < part.tile_end);
       {
@@ -399,157 +466,158 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       // theta: this item's (LDS) and the other items' of the query (LazyMaxScoreAccumulator analogue)
       const uint64_t theta_shared = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (PIPE) group_locate_load(s, wave, n_terms, lane, total_groups, pf);
-      if (ABL == 7 && tid == 0) {
-        tp1 = __builtin_readcyclecounter();
-        s.prof[0] += tp1 - tp0;
-        s.prof[7] += 1;
-      }
 
-      if (cur_groups != 0 && ABL != 4) {
-        // ---- (3) sweep my sub-tile: count hits, reset every slot that cannot be competitive.
-        //      A slot whose fp32 score reaches theta's score stays in place (mmask) for the exact path.
+      if (cur_groups != 0) {
         const uint64_t theta_l = s.theta;
-        uint32_t mmask = 0;
-        uint64_t theta = theta_l;
-        unsigned long long any_maybe = 0;  // wave-uniform
-        if (simple) {
-          // "fp32 score could reach theta's score" as ONE signed 64-bit compare on the fp64 bits:
-          // non-negative doubles order like their bit patterns, the "unmatched" pattern (-0.0) is
-          // INT64_MIN, and half a float ulp below theta's score is a conservative cut
-          const long long thr_bits = __double_as_longlong((double)key_score(theta_l)) - (1ll << 28);
+        const uint64_t theta = theta_shared > theta_l ? theta_shared : theta_l;
+        // "fp32 score could reach theta's score" as ONE signed 64-bit compare on the fp64 bits:
+        // non-negative doubles order like their bit patterns, the "unmatched" pattern (-0.0) is
+        // INT64_MIN, and half a float ulp below theta's score is a conservative cut
+        const long long thr_bits = __double_as_longlong((double)key_score(theta_l)) - (1ll << 28);
+        if (sparse) {
+          // ---- (3s) accumulate, then collect through the postings: each posting swaps the "unmatched"
+          //      marker into its doc's slot.  LDS executes a wave's operations in order, so the first
+          //      posting of a doc to do so receives the doc's complete score and is its collector;
+          //      the others (and invalid postings, on the dummy slot) receive the marker.  No sweep.
+          if (ABL == 7 && tid == 0) s.prof[9] += 1;
+          double a[8];
 #pragma unroll
-          for (int h = 0; h < kSlots / 4; ++h) {
-            double a[4];
+          for (int j = 0; j < 8; ++j) a[j] = unmatched_value();
+          if (lane < cur_groups) {  // one region for all 16 LDS operations: idle lanes stay out of the LDS pipe
+            group_commit_add(accb, off, sc);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) a[jj] = acc[lane + 64u * (uint32_t)(h * 4 + jj)];
+            for (int j = 0; j < 8; ++j)
+              a[j] = __longlong_as_double((long long)atomicExch((unsigned long long*)(accb + off[j]), (unsigned long long)kUnmatched));
+          }
+          unsigned long long any_maybe = 0;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const int j = h * 4 + jj;
-              const bool matched = dbl_bits(a[jj]) != kUnmatched;
-              wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(matched));
-              const bool maybe = __double_as_longlong(a[jj]) >= thr_bits;  // implies matched
-              any_maybe |= __builtin_amdgcn_ballot_w64(maybe);
-              if (matched & !maybe) acc[lane + 64u * (uint32_t)j] = unmatched_value();
+          for (int j = 0; j < 8; ++j) {
+            wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(dbl_bits(a[j]) != kUnmatched));
+            any_maybe |= __builtin_amdgcn_ballot_w64(__double_as_longlong(a[j]) >= thr_bits);
+          }
+          if (any_maybe != 0ull) {  // wave-uniform; rare once theta has converged
+            if (ABL == 7 && tid == 0) s.prof[13] += 1;
+            uint32_t cmask = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (__double_as_longlong(a[j]) >= thr_bits && pack_key((float)a[j], gdoc0 + (off[j] >> 3)) > theta) cmask |= 1u << j;
+            if (__any(cmask != 0)) {
+              if (ABL == 7 && tid == 0) s.prof[12] += 1;
+              uint32_t pos = reserve_candidates(s, lane, (uint32_t)__popc(cmask));
+              if (pos < (uint32_t)kCandCap) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                  if ((cmask >> j) & 1u) s.cand[pos++] = pack_key((float)a[j], gdoc0 + (off[j] >> 3));
+              } else {
+                parked = true;  // back into my sub-tile: the rendezvous that follows this iteration takes them from there
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                  if ((cmask >> j) & 1u) *(double*)(accb + off[j]) = a[j];
+              }
             }
           }
         } else {
-          any_maybe = ~0ull;  // deletes / searchAfter: every slot goes through the exact path
-        }
-        if (theta_shared > theta) theta = theta_shared;
-        if (ABL == 7 && tid == 0 && any_maybe != 0ull) s.prof[13] += 1;
-        if (any_maybe != 0ull) {  // wave-uniform: which of my slots were left in place? (one batched re-read)
-          if (simple) {
-            double a[kSlots];
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) a[j] = acc[lane + 64u * (uint32_t)j];
-#pragma unroll
-            for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(dbl_bits(a[j]) != kUnmatched) << j;
-          } else {
-            mmask = (1u << kSlots) - 1u;
-          }
-        }
-        while (__any(mmask != 0)) {  // exact path: a few iterations once theta has converged
+          // ---- (3d) accumulate, then dense sweep of my sub-tile: count hits, reset every slot that cannot
+          //      be competitive.  A slot whose fp32 score reaches theta's score stays in place (mmask)
+          //      for the exact path.
           if (ABL == 7 && tid == 0) s.prof[11] += 1;
-          if (mmask) {
-            const int j = __ffs((int)mmask) - 1;
-            mmask &= mmask - 1u;
-            const uint32_t i = lane + 64u * (uint32_t)j;
-            const double a = acc[i];
-            if (dbl_bits(a) != kUnmatched) {
-              const uint32_t doc = base + i;
-              bool live = true;
-              if (!simple && live_bits) live = (live_bits[doc >> 6] >> (doc & 63u)) & 1ull;
-              bool cand = false;
-              if (live) {
-                if (!simple) ++my_hits;  // totalHits counts every collected doc, also those skipped by `after`
-                const float sc = (float)a;
-                const uint32_t gdoc = gdoc0 + i;
-                const bool skip = q.has_after && (sc > q.after_score || (sc == q.after_score && (int32_t)gdoc <= q.after_doc));
-                if (!skip) cand = pack_key(sc, gdoc) > theta;
-              }
-              if (cand) cmask |= 1u << j;
-              else acc[i] = unmatched_value();
-            }
-          }
-        }
-
-        // ---- (4) optimistic collect: reserve slots in the shared buffer for the whole wave
-        if (ABL != 3 && __any(cmask != 0)) {
-          if (ABL == 7 && tid == 0) s.prof[12] += 1;
-          const uint32_t mine = (uint32_t)__popc(cmask);
-          uint32_t incl = mine;
+          if (lane < cur_groups) group_commit_add(accb, off, sc);
+          uint32_t mmask = 0;
+          unsigned long long any_maybe = 0;  // wave-uniform
+          if (simple) {
 #pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= (uint32_t)d) incl += o;
+            for (int h = 0; h < kSlots / 4; ++h) {
+              double a[4];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) a[jj] = acc[lane + 64u * (uint32_t)(h * 4 + jj)];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const int j = h * 4 + jj;
+                const bool matched = dbl_bits(a[jj]) != kUnmatched;
+                wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(matched));
+                const bool maybe = __double_as_longlong(a[jj]) >= thr_bits;  // implies matched
+                any_maybe |= __builtin_amdgcn_ballot_w64(maybe);
+                if (matched & !maybe) acc[lane + 64u * (uint32_t)j] = unmatched_value();
+              }
+            }
+          } else {
+            any_maybe = ~0ull;  // deletes / searchAfter: every slot goes through the exact path
           }
-          const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-          uint32_t wbase = (uint32_t)kCandCap;  // "does not fit"
-          if (lane == 0) {
-            // CAS loop: only a reservation that fits ever changes cnt
-            uint32_t old = s.cnt;
-            for (;;) {
-              if (old + wave_total > (uint32_t)kCandCap) {
-                __hip_atomic_store(&s.rz_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
-              }
-              const uint32_t prev = atomicCAS(&s.cnt, old, old + wave_total);
-              if (prev == old) {
-                wbase = old;
-                break;
-              }
-              old = prev;
+          if (any_maybe != 0ull) {  // wave-uniform: which of my slots were left in place? (one batched re-read)
+            if (ABL == 7 && tid == 0) s.prof[13] += 1;
+            if (simple) {
+              double a[kSlots];
+#pragma unroll
+              for (int j = 0; j < kSlots; ++j) a[j] = acc[lane + 64u * (uint32_t)j];
+#pragma unroll
+              for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(dbl_bits(a[j]) != kUnmatched) << j;
+            } else {
+              mmask = (1u << kSlots) - 1u;
             }
           }
-          wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-          if (wbase + wave_total <= (uint32_t)kCandCap) {
-            uint32_t pos = wbase + incl - mine;
-            while (cmask) {
-              const int j = __ffs((int)cmask) - 1;
-              cmask &= cmask - 1u;
+          uint32_t cmask = 0;
+          while (__any(mmask != 0)) {  // exact path: a few iterations once theta has converged
+            if (mmask) {
+              const int j = __ffs((int)mmask) - 1;
+              mmask &= mmask - 1u;
               const uint32_t i = lane + 64u * (uint32_t)j;
-              s.cand[pos++] = pack_key((float)acc[i], gdoc0 + i);
-              acc[i] = unmatched_value();
+              const double a = acc[i];
+              if (dbl_bits(a) != kUnmatched) {
+                const uint32_t doc = base + i;
+                bool live = true;
+                if (!simple && live_bits) live = (live_bits[doc >> 6] >> (doc & 63u)) & 1ull;
+                bool cand = false;
+                if (live) {
+                  if (!simple) ++my_hits;  // totalHits counts every collected doc, also those skipped by `after`
+                  const float sc = (float)a;
+                  const uint32_t gdoc = gdoc0 + i;
+                  const bool skip = q.has_after && (sc > q.after_score || (sc == q.after_score && (int32_t)gdoc <= q.after_doc));
+                  if (!skip) cand = pack_key(sc, gdoc) > theta;
+                }
+                if (cand) cmask |= 1u << j;
+                else acc[i] = unmatched_value();
+              }
+            }
+          }
+          if (__any(cmask != 0)) {
+            if (ABL == 7 && tid == 0) s.prof[12] += 1;
+            uint32_t pos = reserve_candidates(s, lane, (uint32_t)__popc(cmask));
+            if (pos < (uint32_t)kCandCap) {
+              while (cmask) {
+                const int j = __ffs((int)cmask) - 1;
+                cmask &= cmask - 1u;
+                const uint32_t i = lane + 64u * (uint32_t)j;
+                s.cand[pos++] = pack_key((float)acc[i], gdoc0 + i);
+                acc[i] = unmatched_value();
+              }
+            } else {
+              parked = true;
             }
           }
         }
       }
-      if (ABL == 7 && tid == 0) {
-        tp2 = __builtin_readcyclecounter();
-        s.prof[2] += tp2 - tp1;
-      }
 
-      // ---- (5) rendezvous: somebody's candidates did not fit -> the whole workgroup compacts
-      if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {  // wave-uniform; seen at the next sub-tile boundary at the latest
-        uint64_t tr = 0;
-        if (ABL == 7 && tid == 0) tr = __builtin_readcyclecounter();
-        __syncthreads();  // R1: all 8 waves (running ones here, finished ones in the drain loop below)
-        rendezvous_compact(s, acc, cmask, gdoc0, k, my_theta_g);
-        cmask = 0;
-        if (ABL == 7 && tid == 0) {
-          s.prof[4] += __builtin_readcyclecounter() - tr;
-          s.prof[5] += 1;
-        }
+      // ---- (4) somebody's candidates did not fit (seen at the next sub-tile boundary at the latest):
+      //      leave the walk for the rendezvous
+      if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {  // wave-uniform
+        resume_sub = sub + (uint32_t)kScanWaves;
+        interrupted = true;
+        break;
       }
     }
+    if (interrupted) break;
+    phase = next_phase;
+  }
 
-    // ---- part epilogue: this wave is out of sub-tiles; keep serving rendezvous until all waves are
-    if (lane == 0) atomicAdd(&s.done, 1u);
-    for (;;) {
-      __syncthreads();  // R1 (pairs with the running waves' rendezvous barrier)
-      const uint32_t flag = __hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const uint32_t done = __hip_atomic_load(&s.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (flag) {
-        rendezvous_compact(s, acc, 0u, 0u, k, my_theta_g);  // ends with a barrier: flag/done re-read safely
-        continue;
-      }
-      __syncthreads();  // everyone has read (flag, done) before anybody changes them again
-      if (done == (uint32_t)kScanWaves) break;
-    }
+  // ---- rendezvous point: waves that are out of sub-tiles wait here for the others
+  __syncthreads();  // R1: all waves -- interrupted ones and finished ones
+  if (!__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // nobody asked: everybody is finished
+  rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, my_theta_g);  // ends with barriers: the flag is re-read safely
+  parked = false;
+  if (ABL == 7 && tid == 0) s.prof[5] += 1;
   }
 
   // ---- item epilogue: final top-k of the item, hit count
-  __syncthreads();
   {
     const uint32_t c = s.cnt;
     __syncthreads();
@@ -687,15 +755,8 @@ void launch_bm25_scan(hipStream_t stream, bool pipelined, int ablation, uint32_t
   hipLaunchKernelGGL((bm25_scan_kernel<P, A>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
                      caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof)
   if (!pipelined) { NRT_LAUNCH(false, 0); return; }
-  switch (ablation) {
-    case 1: NRT_LAUNCH(true, 1); break;
-    case 2: NRT_LAUNCH(true, 2); break;
-    case 3: NRT_LAUNCH(true, 3); break;
-    case 4: NRT_LAUNCH(true, 4); break;
-    case 5: NRT_LAUNCH(true, 5); break;
-    case 7: NRT_LAUNCH(true, 7); break;
-    default: NRT_LAUNCH(true, 0); break;
-  }
+  if (ablation == 7) NRT_LAUNCH(true, 7);
+  else NRT_LAUNCH(true, 0);
 #undef NRT_LAUNCH
 }
 

@@ -7,9 +7,19 @@
 
 namespace nrtgpu {
 
-constexpr int kTileDocs = 768;      // docs per wave-private LDS accumulator sub-tile (fp64: 6 KiB per wave)
-constexpr int kScanThreads = 1024;  // 16 autonomous wave64 per workgroup, 1 workgroup per CU (whole 160 KiB LDS)
-constexpr int kScanWaves = kScanThreads / 64;
+// Workgroup shape of the scan: waves x docs-per-sub-tile must fit 96 KiB of fp64 accumulators
+// (16 x 768 or 12 x 1024); a build-time choice (-DNRT_SCAN_WAVES / -DNRT_TILE_DOCS).
+#ifndef NRT_SCAN_WAVES
+#define NRT_SCAN_WAVES 16
+#endif
+#ifndef NRT_TILE_DOCS
+#define NRT_TILE_DOCS 768
+#endif
+constexpr int kTileDocs = NRT_TILE_DOCS;        // docs per wave-private LDS accumulator sub-tile (fp64)
+constexpr int kScanWaves = NRT_SCAN_WAVES;      // autonomous wave64 per workgroup, 1 workgroup per CU (whole 160 KiB LDS)
+constexpr int kScanThreads = kScanWaves * 64;
+static_assert(kScanWaves % 4 == 0 && kTileDocs % 64 == 0 && kTileDocs / 64 <= 16, "scan workgroup shape");
+static_assert(kScanWaves * kTileDocs * 8 <= 96 * 1024, "accumulators exceed their LDS share");
 constexpr int kCandCap = 1920;      // scan: LDS candidate slots (15 KiB)
 constexpr int kMergeCap = 2048;     // merge: candidate slots = kMaxK + kScanThreads
 constexpr int kLdsCaches = 2;       // normInverse tables kept in LDS per item (one per field)

@@ -16,6 +16,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -139,9 +140,46 @@ struct TermGroup {
   uint64_t n_postings = 0;
 };
 
+// Read-only open-addressing view of a field's term dictionary (built at seal): the planner does
+// one lookup per (query clause, leaf), ~50k per batch, so a probe should touch one cache line.
+struct FlatDict {
+  struct Cell { int64_t key; uint32_t idx; uint32_t used; };
+  std::vector<Cell> cells;
+  std::vector<TermEntry> entries;
+  uint32_t shift = 64;
+  static inline uint64_t mix(int64_t k) { return (uint64_t)k * 0x9E3779B97F4A7C15ull; }
+  void build(const std::unordered_map<int64_t, TermEntry>& d) {
+    size_t cap = 16;
+    uint32_t bits = 4;
+    while (cap < d.size() * 2 + 2) { cap <<= 1; ++bits; }
+    cells.assign(cap, Cell{0, 0, 0});
+    entries.clear();
+    entries.reserve(d.size());
+    shift = 64 - bits;
+    for (const auto& kv : d) {
+      size_t h = (size_t)(mix(kv.first) >> shift);
+      while (cells[h].used) h = (h + 1) & (cap - 1);
+      cells[h] = Cell{kv.first, (uint32_t)entries.size(), 1u};
+      entries.push_back(kv.second);
+    }
+  }
+  inline const TermEntry* find(int64_t key) const {
+    if (cells.empty()) return nullptr;
+    const size_t mask = cells.size() - 1;
+    size_t h = (size_t)(mix(key) >> shift);
+    for (;;) {
+      const Cell& c = cells[h];
+      if (!c.used) return nullptr;
+      if (c.key == key) return &entries[c.idx];
+      h = (h + 1) & mask;
+    }
+  }
+};
+
 struct FieldData {
   uint8_t* d_norms = nullptr;    // nullptr => norms omitted
-  std::unordered_map<int64_t, TermEntry> dict;
+  std::unordered_map<int64_t, TermEntry> dict;   // build-time (duplicate detection); searches use `flat`
+  FlatDict flat;
   std::vector<TermGroup> groups;
   float* d_vectors = nullptr;
   float* d_vnorm2 = nullptr;            // |v|^2 per row (cosine / euclidean)
@@ -466,6 +504,7 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   (void)hipFree(d_overflow);
   if (rc) return rc;
   if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^23 does not fit the packed freq|norm column");
+  for (auto& kv : seg->fields) kv.second.flat.build(kv.second.dict);
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
       if (g.d_freqs) {  // raw freq column no longer needed
@@ -556,51 +595,53 @@ static int validate_query(const nrtgpu_bm25_query& q, int qi) {
 // accumulator sweep (in posting equivalents).
 static const int64_t kTileCostPostings = 48;
 
-static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp) {
-  uint32_t kmax = 1;
-  for (int qi = 0; qi < n_queries; ++qi) {
-    if (int rc = validate_query(queries[qi], qi)) return rc;
-    kmax = std::max<uint32_t>(kmax, (uint32_t)queries[qi].k);
-  }
-  for (int si = 0; si < n_segs; ++si) {
-    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
-    if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);
-    if (segs[si]->ctx != ctx) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d belongs to another context", si);
-  }
-  hp.k_stride = round_up(kmax, 16);
-  hp.queries.resize((size_t)n_queries);
-  hp.q_k.resize((size_t)n_queries);
+struct QS { uint32_t term_begin, n_terms; int32_t seg; int64_t postings; };
+struct QTabs { uint32_t n; float weight[kTabTerms]; uint32_t cache[kTabTerms]; };
+struct PlanPiece {
+  std::vector<DTerm> terms;
+  std::vector<float> caches;
+  int64_t postings = 0, cost = 0;
+};
 
-  // pass 1: resolve terms per (query, segment), densest term first; remember posting counts
-  struct QS { uint32_t term_begin, n_terms; int32_t seg; int64_t postings; };
-  struct QTabs { uint32_t n; float weight[kTabTerms]; uint32_t cache[kTabTerms]; };
-  std::vector<std::vector<QS>> per_query((size_t)n_queries);
-  std::vector<uint32_t> cache_base((size_t)n_queries);
-  std::vector<QTabs> qtabs((size_t)n_queries);
-  int64_t total_postings = 0, total_cost = 0;
+// Pass 1 of the planner for queries [q_begin, q_end): one dictionary lookup per (clause, leaf); score
+// tables go to the clauses with the most postings; terms of a (query, leaf) sorted densest first.
+// Offsets (term_begin, cache offsets) are relative to the piece.
+static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const nrtgpu_bm25_query* queries, int q_begin,
+                            int q_end, PlanPiece& pc, std::vector<std::vector<QS>>& per_query,
+                            std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term;
   std::vector<const TermEntry*> found;
+  std::vector<const FieldData*> fld((size_t)n_segs, nullptr);
   std::vector<const FieldData*> found_field;
-  for (int qi = 0; qi < n_queries; ++qi) {
+  int32_t fld_id = 0;
+  bool fld_valid = false;
+  for (int qi = q_begin; qi < q_end; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
-    cache_base[(size_t)qi] = (uint32_t)hp.caches.size();
-    hp.caches.insert(hp.caches.end(), q.norm_cache, q.norm_cache + (size_t)q.n_caches * 256);
-    // one dictionary lookup per (clause, leaf); score tables go to the clauses with the most postings
+    cache_base[(size_t)qi] = (uint32_t)pc.caches.size();
+    pc.caches.insert(pc.caches.end(), q.norm_cache, q.norm_cache + (size_t)q.n_caches * 256);
     found.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
     found_field.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
     term_total.assign((size_t)q.n_terms, 0);
-    for (int t = 0; t < q.n_terms; ++t)
-      for (int si = 0; si < n_segs; ++si) {
-        auto fit = segs[si]->fields.find(q.terms[t].field_id);
-        if (fit == segs[si]->fields.end()) continue;
-        auto it = fit->second.dict.find(q.terms[t].term_hash);
-        if (it == fit->second.dict.end() || it->second.count == 0) continue;
-        found[(size_t)t * n_segs + si] = &it->second;
-        found_field[(size_t)t * n_segs + si] = &fit->second;
-        term_total[(size_t)t] += it->second.count;
+    for (int t = 0; t < q.n_terms; ++t) {
+      if (!fld_valid || fld_id != q.terms[t].field_id) {  // per-leaf field lookup hoisted out of the clause loop
+        fld_id = q.terms[t].field_id;
+        fld_valid = true;
+        for (int si = 0; si < n_segs; ++si) {
+          auto fit = segs[si]->fields.find(fld_id);
+          fld[(size_t)si] = fit == segs[si]->fields.end() ? nullptr : &fit->second;
+        }
       }
+      for (int si = 0; si < n_segs; ++si) {
+        const FieldData* f = fld[(size_t)si];
+        if (!f) continue;
+        const TermEntry* e = f->flat.find(q.terms[t].term_hash);
+        if (!e || e->count == 0) continue;
+        found[(size_t)t * n_segs + si] = e;
+        found_field[(size_t)t * n_segs + si] = f;
+        term_total[(size_t)t] += e->count;
+      }
+    }
     tab_of_term.assign((size_t)q.n_terms, -1);
     QTabs& qt_ = qtabs[(size_t)qi];
     qt_.n = 0;
@@ -614,9 +655,10 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
       qt_.cache[qt_.n] = (uint32_t)q.terms[best].cache_slot;
       qt_.n++;
     }
+    per_query[(size_t)qi].reserve((size_t)n_segs);
     for (int si = 0; si < n_segs; ++si) {
       const nrtgpu_seg* seg = segs[si];
-      QS qs{(uint32_t)hp.terms.size(), 0, si, 0};
+      QS qs{(uint32_t)pc.terms.size(), 0, si, 0};
       for (int t = 0; t < q.n_terms; ++t) {
         const nrtgpu_term& qt = q.terms[t];
         const TermEntry* ep = found[(size_t)t * n_segs + si];
@@ -635,18 +677,75 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
         d.cache_off = cache_base[(size_t)qi] + (uint32_t)qt.cache_slot * 256u;
         d.cache_slot = (uint32_t)qt.cache_slot;
         d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
-        hp.terms.push_back(d);
+        pc.terms.push_back(d);
         qs.n_terms++;
         qs.postings += e.count;
       }
       if (qs.n_terms > 0) {
-        std::stable_sort(hp.terms.begin() + qs.term_begin, hp.terms.end(),
+        std::stable_sort(pc.terms.begin() + qs.term_begin, pc.terms.end(),
                          [](const DTerm& a, const DTerm& b) { return a.count > b.count; });
         per_query[(size_t)qi].push_back(qs);
-        total_postings += qs.postings;
-        total_cost += qs.postings + (int64_t)seg->n_tiles * kTileCostPostings;
+        pc.postings += qs.postings;
+        pc.cost += qs.postings + (int64_t)seg->n_tiles * kTileCostPostings;
       }
     }
+  }
+}
+
+static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp) {
+  uint32_t kmax = 1;
+  for (int qi = 0; qi < n_queries; ++qi) {
+    if (int rc = validate_query(queries[qi], qi)) return rc;
+    kmax = std::max<uint32_t>(kmax, (uint32_t)queries[qi].k);
+  }
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+    if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);
+    if (segs[si]->ctx != ctx) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d belongs to another context", si);
+  }
+  hp.k_stride = round_up(kmax, 16);
+  hp.queries.resize((size_t)n_queries);
+  hp.q_k.resize((size_t)n_queries);
+
+  // pass 1: resolve terms per (query, segment), densest term first; remember posting counts.
+  // Queries are independent here, so the batch is cut into contiguous chunks resolved by
+  // cfg.host_threads planner threads and concatenated (offsets rebased) afterwards.
+  std::vector<std::vector<QS>> per_query((size_t)n_queries);
+  std::vector<uint32_t> cache_base((size_t)n_queries);
+  std::vector<QTabs> qtabs((size_t)n_queries);
+  int n_thr = ctx->cfg.host_threads > 0 ? ctx->cfg.host_threads : 4;
+  n_thr = std::max(1, std::min(n_thr, n_queries / 64));
+  std::vector<PlanPiece> pieces((size_t)n_thr);
+  auto chunk_begin = [&](int t) { return (int)((int64_t)n_queries * t / n_thr); };
+  auto work = [&](int t) {
+    resolve_queries(segs, n_segs, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t], per_query, cache_base, qtabs);
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  int64_t total_postings = 0, total_cost = 0;
+  {
+    size_t nt = 0, nc = 0;
+    for (const PlanPiece& pc : pieces) { nt += pc.terms.size(); nc += pc.caches.size(); }
+    hp.terms.reserve(nt);
+    hp.caches.reserve(nc);
+  }
+  for (int t = 0; t < n_thr; ++t) {
+    PlanPiece& pc = pieces[(size_t)t];
+    const uint32_t term_base = (uint32_t)hp.terms.size(), c_base = (uint32_t)hp.caches.size();
+    for (DTerm& d : pc.terms) d.cache_off += c_base;
+    hp.terms.insert(hp.terms.end(), pc.terms.begin(), pc.terms.end());
+    hp.caches.insert(hp.caches.end(), pc.caches.begin(), pc.caches.end());
+    for (int qi = chunk_begin(t); qi < chunk_begin(t + 1); ++qi) {
+      cache_base[(size_t)qi] += c_base;
+      for (QS& qs : per_query[(size_t)qi]) qs.term_begin += term_base;
+    }
+    total_postings += pc.postings;
+    total_cost += pc.cost;
   }
   hp.postings = total_postings;
 
@@ -857,10 +956,11 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
                            nrtgpu_topdocs* out) {
   const int32_t cap = out->capacity > 0 ? out->capacity : k;
   const int32_t m = std::min<int32_t>((int32_t)n, cap);
-  for (int32_t i = 0; i < m; ++i) {
-    if (out->docs) out->docs[i] = (int32_t)key_doc(keys[i]);
-    if (out->scores) out->scores[i] = key_score(keys[i]);
-  }
+  // two plain loops (vectorisable): doc = ~low word, score = high word reinterpreted
+  if (int32_t* __restrict__ docs = out->docs)
+    for (int32_t i = 0; i < m; ++i) docs[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)keys[i]);
+  if (uint32_t* __restrict__ sc = (uint32_t*)out->scores)
+    for (int32_t i = 0; i < m; ++i) sc[i] = (uint32_t)(keys[i] >> 32);
   out->n_hits = m;
   out->total_hits = (int64_t)hits;
   out->total_hits_is_lower_bound = relation_gte((int64_t)hits, (int32_t)n, k, threshold);

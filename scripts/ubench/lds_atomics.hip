@@ -32,6 +32,11 @@ __global__ __launch_bounds__(512, 4) void k(uint32_t iters, uint64_t* out, uint3
     else if (MODE == 6) sum += acc[idx];                           // plain read b64
     else if (MODE == 7) atomicOr((unsigned long long*)&acc64[idx], 1ull << (it & 63));  // ds_or_b64
     else if (MODE == 8) atomicMax((unsigned long long*)&acc64[idx], (unsigned long long)x); // ds_max_u64
+    else if (MODE == 9) sum += unsafeAtomicAdd(&acc[idx], 1.0);   // ds_add_rtn_f64
+    else if (MODE == 10) sum += (double)atomicExch((unsigned long long*)&acc64[idx], (unsigned long long)x);  // ds_wrxchg_rtn_b64
+    else if (MODE == 11) { if (tid & 1) unsafeAtomicAdd(&acc[idx], 1.0); }          // ds_add_f64, half the lanes
+    else if (MODE == 12) { if (tid & 1) sum += unsafeAtomicAdd(&acc[idx], 1.0); }   // ds_add_rtn_f64, half the lanes
+    else if (MODE == 13) { if ((tid & 3) == 0) unsafeAtomicAdd(&acc[idx], 1.0); }   // ds_add_f64, quarter of the lanes
   }
   __syncthreads();
   if (tid == 0) out[blockIdx.x] = (uint64_t)acc[0] + (uint64_t)sum + pad[0];
@@ -64,6 +69,7 @@ int main() {
   for (uint32_t spread : {0u, 2u}) {
     run<0>("ds_add_f64", spread); run<1>("ds_add_u64", spread); run<2>("ds_add_f32", spread); run<3>("ds_add_u32", spread);
     run<4>("rmw_b64", spread); run<5>("write_b64", spread); run<6>("read_b64", spread); run<7>("ds_or_b64", spread); run<8>("ds_max_u64", spread);
+    run<9>("ds_add_rtn_f64", spread); run<10>("ds_xchg_rtn64", spread); run<11>("add_f64_half", spread); run<12>("add_rtn_half", spread); run<13>("add_f64_quart", spread);
   }
   return 0;
 }
