@@ -48,7 +48,7 @@ typedef struct nrtgpu_seg nrtgpu_seg;
 /* Limits of the device fast path (queries outside them get NRTGPU_ERR_UNSUPPORTED). */
 #define NRTGPU_MAX_K 1024          /* numHits handled by the LDS top-k */
 #define NRTGPU_MAX_TERMS 32        /* SHOULD clauses per query */
-#define NRTGPU_TILE_DOCS 768       /* docs per wave-private LDS accumulator sub-tile */
+#define NRTGPU_TILE_DOCS 1024      /* docs per wave-private LDS accumulator sub-tile */
 
 typedef struct {
   int32_t device_id;        /* HIP device ordinal this ctx owns (one process per GPU) */
@@ -219,7 +219,7 @@ typedef struct {
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
-#define NRTGPU_FLAG_PROFILE (7 << 8)  /* instrumented scan kernel: per-phase shader-clock counters */
+#define NRTGPU_FLAG_PROFILE (7 << 8)  /* instrumented scan kernel: per-item phase cycle and event counters of wave 0 (nrtgpu_get_scan_profile) */
 /* sums over all items since the last reset, instrumented kernel only (thread 0 of each workgroup,
  * shader-clock cycles): [0] accumulate, [1] wait at barrier A, [2] sweep+collect, [3] wait at
  * barrier C, [4] slow path, [5] slow-path entries, [6] compactions, [7] tiles, [8] issue of the

@@ -18,7 +18,7 @@ NRTGPU_ERR_UNSUPPORTED = -4
 NRTGPU_ERR_STATE = -5
 NRTGPU_MAX_K = 1024
 NRTGPU_MAX_TERMS = 32
-NRTGPU_TILE_DOCS = 768
+NRTGPU_TILE_DOCS = 1024
 NRTGPU_FLAG_NO_PREFETCH = 1
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)

@@ -146,9 +146,10 @@ class GpuContext:
     def scan_profile(self) -> dict:
         out = np.zeros(16, dtype=np.float64)
         _lib.check(_lib.load().nrtgpu_get_scan_profile(self._h, out.ctypes.data))
-        names = ["acc_cycles", "waitA_cycles", "sweep_cycles", "waitC_cycles", "slow_cycles", "slow_entries",
-                 "compactions", "tiles", "first_instrs", "dense_instrs", "flat_instrs", "exact_iters",
-                 "collects", "maybe_subtiles", "r14", "r15"]
+        # counters of wave 0 of every item, summed over the items since reset_stats (NRTGPU_FLAG_PROFILE)
+        names = ["prologue_cycles", "rendezvous_wait_cycles", "rendezvous_cycles", "walk_cycles", "epilogue_cycles",
+                 "rendezvous", "compactions", "subtiles", "subtiles_with_postings", "sparse_subtiles", "extra_groups",
+                 "dense_subtiles", "candidate_subtiles", "maybe_subtiles", "r14", "r15"]
         return dict(zip(names, out.tolist()))
 
     def reset_stats(self) -> None:

@@ -24,7 +24,7 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra=(), out: str = OUT) -> str:
-    """extra: additional hipcc flags (e.g. -DNRT_SCAN_WAVES=12 -DNRT_TILE_DOCS=1024 for an A/B build
+    """extra: additional hipcc flags (e.g. -DNRT_SCAN_WAVES=16 -DNRT_TILE_DOCS=768 for an A/B build
     written to `out`; NRTGPU_LIB_PATH makes nrtsearch_amd._lib load it)."""
     if not force and out == OUT and not _stale():
         return OUT

@@ -39,6 +39,12 @@ typedef const NRT_GLOBAL float* gf32_ptr;
 
 constexpr uint64_t kUnmatched = 0x8000000000000000ull;  // -0.0: "no term matched this doc yet"
 
+// LDS byte addresses as plain 32-bit integers: the accumulator address of a posting is then ONE
+// shift-add from its docid, with no pointer arithmetic left for the LDS instruction.
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_char_ptr)p; }
+__device__ __forceinline__ char* lds_ptr(uint32_t a) { return (char*)(lds_char_ptr)(uintptr_t)a; }
+
 
 // Work decomposition: a workgroup is 16 AUTONOMOUS waves and owns one CU (all 160 KiB of LDS).  The
 // sub-tiles (768 docs) of an item's parts form one sequence; wave w walks sub-tiles w, w+16, ... of it
@@ -64,7 +70,7 @@ struct ScanSmem {
   uint32_t hits;         // live matching docs of this item
   uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet at the rendezvous
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kCandCap
-  uint32_t pad;
+  uint32_t next_tile;    // next unassigned sub-tile of the item (flattened over its parts)
   uint64_t prof[16];     // instrumented variant only (ABL == 7)
   double   dummy[64];    // per-lane sink for invalid postings; always holds the "unmatched" marker (see group_prepare)
 };
@@ -112,7 +118,7 @@ constexpr uint32_t kMetaEnd = 0x7FFFFFu;
 // pair-instruction lanes of the whole sub-tile (wave-uniform).
 __device__ __forceinline__ uint32_t subtile_build(ScanSmem& s, uint32_t wave, uint32_t lane, uint64_t my_docids,
                                                   uint32_t my_delta16, uint64_t my_lo, uint32_t my_flags, uint32_t lo,
-                                                  uint32_t hi, bool use) {
+                                                  uint32_t hi, bool use, uint32_t (&pre)[8]) {
   uint32_t end = 0, first = 0;
   uint64_t gs = my_lo >> 2;  // empty range: a group that is always safe to (pre)load
   if (use && hi > lo) {
@@ -130,6 +136,9 @@ __device__ __forceinline__ uint32_t subtile_build(ScanSmem& s, uint32_t wave, ui
     u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16, end | (first << 23) | (my_flags << 26)};
     *(u32x4*)&s.w_rec[wave][lane][0] = rec;
   }
+  // the prefixes of the first 8 terms as wave-uniform scalars: locating a pair needs no LDS round trip
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pre[i] = (uint32_t)__builtin_amdgcn_readlane((int)incl, i);
   return (uint32_t)__builtin_amdgcn_readlane((int)incl, kMaxTerms - 1);
 }
 
@@ -144,13 +153,11 @@ struct Group {
 // Locate flattened pair v of the sub-tile (clamped so the loads are always legal) through the wave's
 // LDS table and load its column words (2 x 16 B per column).  No control flow around the loads.
 __device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wave, uint32_t n_terms, uint32_t v,
-                                                  uint32_t total, Group& gr) {
+                                                  uint32_t total, const uint32_t (&pre)[8], Group& gr) {
   const uint32_t vc = min(v, max(total, 1u) - 1u);
-  const u32x4 p0 = *(const u32x4*)&s.w_incl[wave][0];
-  const u32x4 p1 = *(const u32x4*)&s.w_incl[wave][4];
   uint32_t t = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) t += (vc >= ((i < 4) ? p0[i] : p1[i - 4])) ? 1u : 0u;  // terms 0..7, branchless
+  for (int i = 0; i < 8; ++i) t += (vc >= pre[i]) ? 1u : 0u;  // terms 0..7, branchless, scalar operands
   if (n_terms > 8) {  // uniform; long disjunctions continue with a scalar-style walk
     while (t < n_terms - 1u && vc >= s.w_incl[wave][t]) ++t;
   }
@@ -179,8 +186,8 @@ __device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wa
 // (a conditionally executed returning LDS op makes the compiler wait for each result at the end of
 // its branch) and a dummy never looks like a matched doc.
 template <int ABL>
-__device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group& gr, bool valid, uint32_t base,
-                                                  uint32_t tile_len, uint32_t dummy_off, const DTerm* __restrict__ part_terms,
+__device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group& gr, bool valid, uint32_t acc_addr, uint32_t base,
+                                                  uint32_t tile_len, uint32_t dummy_addr, const DTerm* __restrict__ part_terms,
                                                   uint32_t (&off)[8], float (&sc)[8]) {
   const uint32_t meta = gr.meta;
   // valid postings of my pair: window positions [first, end) intersected with [8p, 8p + 8)
@@ -190,15 +197,16 @@ __device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group
   const uint32_t lm = (1u << (uint32_t)min(max(lo_cut, 0), 8)) - 1u;
   uint32_t vmask = valid ? (hm & ~lm) : 0u;
   const uint32_t tab = (meta >> 26) & 7u;
-  // byte offset of the doc's accumulator inside the wave's sub-tile: (doc - base) * 8 in one op
-  const uint32_t nbase8 = 0u - base * 8u;
+  // LDS address of the doc's accumulator in the wave's sub-tile: acc + (doc - base) * 8 in one op
+  const uint32_t abase = acc_addr - base * 8u;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) off[j] = (gr.d4[j >> 2][j & 3] << 3) + nbase8;  // unsigned: out-of-tile docs wrap to huge values
+  for (int j = 0; j < 8; ++j) off[j] = (gr.d4[j >> 2][j & 3] << 3) + abase;
   if (__any((meta >> 29) & 1u)) {
     // sparse terms share one posting range between several sub-tiles (coarse cells): doc-range filter
+    // (unsigned: docs below the sub-tile wrap to huge values)
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (off[j] >= tile_len * 8u) vmask &= ~(1u << j);
+      if (off[j] - acc_addr >= tile_len * 8u) vmask &= ~(1u << j);
   }
   // postings the score table cannot serve: freq > kTabMaxFreq / norm >= kTabNorms (sign bit of the
   // code) or a term without a table.  Rare: one OR-reduction decides whether anybody in the wave
@@ -210,7 +218,10 @@ __device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group
   const bool special = vmask != 0u && ((cor >> 31) != 0u || tab == 7u);
   const char* tb = (const char*)&s.tab[0][0] + (tab == 7u ? 0u : tab) * (uint32_t)(kTabEntries * 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) sc[j] = *(const float*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
+  for (int j = 0; j < 8; ++j) {
+    if (ABL == 1) sc[j] = __uint_as_float((gr.c4[j >> 2][j & 3] & 0x1FFCu) | 0x3F000000u);  // timing ablation: no table read
+    else sc[j] = *(const float*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
+  }
   if (__any(special)) {
     // long docs / high freqs / terms without a score table (a few lanes)
     const float w = part_terms[gr.term].weight;
@@ -227,18 +238,18 @@ __device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group
   if (!__all(vmask == 0xFFu)) {  // wave-uniform
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool v = (vmask >> j) & 1u;
-      off[j] = v ? off[j] : dummy_off;
-      sc[j] = v ? sc[j] : -0.0f;
+      const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)vmask, j, 1);  // all ones: valid (bit-field extract + 2 bit-field inserts)
+      off[j] = (off[j] & t) | (dummy_addr & ~t);
+      sc[j] = __uint_as_float((__float_as_uint(sc[j]) & t) | (0x80000000u & ~t));
     }
   }
   return vmask;
 }
 
 // One fp64 LDS atomic per posting (invalid ones were redirected by group_prepare).
-__device__ __forceinline__ void group_commit_add(char* accb, const uint32_t (&off)[8], const float (&sc)[8]) {
+__device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const float (&sc)[8]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) unsafeAtomicAdd((double*)(accb + off[j]), (double)sc[j]);
+  for (int j = 0; j < 8; ++j) unsafeAtomicAdd((double*)lds_ptr(off[j]), (double)sc[j]);
 }
 
 // Workgroup-wide rendezvous body: keep the k best of (candidate buffer UNION the candidates a wave
@@ -332,6 +343,41 @@ __device__ __forceinline__ uint32_t reserve_candidates(ScanSmem& s, uint32_t lan
   return wbase + incl - mine;
 }
 
+// Sparse collect of one pair's swapped-out slot values a[j] (the "unmatched" marker where this
+// posting is not its doc's collector): count the hits, send the competitive docs to the shared
+// candidate buffer.  Returns true when they did not fit and were parked back into the sub-tile.
+template <int ABL>
+__device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, uint32_t lane, const double (&a)[8],
+                                                const uint32_t (&off)[8], long long thr_bits, uint64_t theta,
+                                                uint32_t gdoc0, uint32_t& wave_hits) {
+  unsigned long long any_maybe = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(dbl_bits(a[j]) != kUnmatched));
+    any_maybe |= __builtin_amdgcn_ballot_w64(__double_as_longlong(a[j]) >= thr_bits);
+  }
+  if (any_maybe == 0ull) return false;  // wave-uniform; the steady state once theta has converged
+  if (ABL == 7 && threadIdx.x == 0) s.prof[13] += 1;
+  uint32_t cmask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (__double_as_longlong(a[j]) >= thr_bits && pack_key((float)a[j], gdoc0 + ((off[j] - acc_addr) >> 3)) > theta) cmask |= 1u << j;
+  if (!__any(cmask != 0)) return false;
+  if (ABL == 7 && threadIdx.x == 0) s.prof[12] += 1;
+  uint32_t pos = reserve_candidates(s, lane, (uint32_t)__popc(cmask));
+  if (pos < (uint32_t)kCandCap) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if ((cmask >> j) & 1u) s.cand[pos++] = pack_key((float)a[j], gdoc0 + ((off[j] - acc_addr) >> 3));
+    return false;
+  }
+  // back into my sub-tile: the rendezvous that follows this iteration takes them from there
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if ((cmask >> j) & 1u) *(double*)lds_ptr(off[j]) = a[j];
+  return true;
+}
+
 // PIPE = true: the first posting pair per lane of the wave's next sub-tile is loaded before the
 // current one is collected.  ABL == 7: instrumented variant (event counters per item).
 template <bool PIPE, int ABL>
@@ -345,13 +391,15 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
   double* const acc = &s.acc[wave][0];
-  char* const accb = (char*)acc;
-  const uint32_t dummy_off = (uint32_t)((char*)&s.dummy[lane] - accb);  // wraps: LDS byte addresses are 32-bit
+  const uint32_t acc_addr = lds_addr(acc), dummy_addr = lds_addr(&s.dummy[lane]);
   const DItem item = items[blockIdx.x];
   const DQuery q = queries[item.query];
   const uint32_t k = q.k;
   unsigned long long* const my_theta_g = theta_g + item.query;
+  const bool multi_item = q.n_items > 1;  // uniform: only then is there anybody to share theta with
 
+  uint64_t t_start = 0, t_walk = 0;
+  if (ABL == 7) t_start = __builtin_readcyclecounter();
   // ---- item prologue: clear the sub-tiles, stage the normInverse tables, build the score tables
   for (int j = 0; j < kSlots; ++j) acc[lane + 64u * (uint32_t)j] = unmatched_value();
   {
@@ -365,7 +413,9 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     s.hits = 0;
     s.rz_flag = 0;
     s.cnt_valid = 0;
+    s.next_tile = 3u * (uint32_t)kScanWaves;  // every wave starts with three sub-tiles
     for (int i = 0; i < 16; ++i) s.prof[i] = 0;
+    s.prof[15] = ~0ull;
   }
   if (tid < 64) s.dummy[tid] = unmatched_value();
   __syncthreads();
@@ -376,30 +426,37 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       s.tab[slot][e] = bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]);  // row 0 (freq 0) never read
   }
   __syncthreads();  // tables complete; from here on the waves run on their own
+  if (ABL == 7) {
+    t_walk = __builtin_readcyclecounter();
+    if (tid == 0) s.prof[0] += t_walk - t_start;
+  }
   uint32_t my_hits = 0;    // per-lane count (general sweep)
   uint32_t wave_hits = 0;  // wave-uniform count, added once by lane 0
-  uint32_t phase = 0;      // sub-tiles of the item's earlier parts, mod kScanWaves: the round-robin continues across parts
+  // The sub-tiles of the item's parts form one sequence g = 0, 1, ... (part.tile_offset + tile index in the
+  // part).  Waves take them DYNAMICALLY from a shared counter: the hardware favours the oldest waves,
+  // with a static split the youngest ones finish ~20% later while the others idle.  A wave always holds
+  // three indices: g_cur (table built, first pairs loaded), g_nxt (cells loaded), g_nxt2 (just taken).
   // A rendezvous interrupts the walk: the wave leaves its loops (so that the compaction code is not
-  // inside them, holding every loop register live), and afterwards resumes at (pi, resume_sub) by
-  // re-running the part prologue.
-  constexpr uint32_t kNoResume = 0xFFFFFFFFu;
-  uint32_t pi = 0, resume_sub = kNoResume;
+  // inside them, holding every loop register live) and afterwards resumes at g_cur by re-running the
+  // part prologue -- the same path as entering a new part.
+  uint32_t g_cur = wave, g_nxt = wave + (uint32_t)kScanWaves, g_nxt2 = wave + 2u * (uint32_t)kScanWaves;
+  uint32_t pi = 0;
   bool parked = false;     // wave-uniform: my candidates did not fit the shared buffer (they wait in my sub-tile)
   uint32_t gdoc0 = 0;      // global docid of slot 0 of my current sub-tile
 
   for (;;) {  // epochs between rendezvous
   bool interrupted = false;
-  for (; pi < item.n_parts; ++pi) {
-    const DPart part = parts[item.part_begin + pi];
-    // this wave's sub-tiles of the part: sub, sub + kScanWaves, ...
-    uint32_t sub = part.tile_begin + (wave >= phase ? wave - phase : wave + (uint32_t)kScanWaves - phase);
-    if (resume_sub != kNoResume) sub = resume_sub;
-    resume_sub = kNoResume;
-    const uint32_t next_phase = (phase + (part.tile_end - part.tile_begin)) % (uint32_t)kScanWaves;
-    if (sub >= part.tile_end) {  // wave-uniform: nothing (left) for this wave in this part
-      phase = next_phase;
-      continue;
+  for (;;) {  // parts
+    DPart part;
+    for (;; ++pi) {  // the part that holds g_cur (indices only grow)
+      if (pi >= item.n_parts) break;
+      part = parts[item.part_begin + pi];
+      if (g_cur < part.tile_offset + (part.tile_end - part.tile_begin)) break;
     }
+    if (pi >= item.n_parts) break;  // this wave is out of sub-tiles
+    const uint32_t g0 = part.tile_offset, gn = g0 + (part.tile_end - part.tile_begin);
+    // tile index inside the segment of a flattened index of this part: g - g0 + tile_begin
+    const uint32_t tile_bias = part.tile_begin - g0;
     const uint32_t n_terms = part.n_terms;
     const DTerm* const part_terms = terms + part.term_begin;
     const NRT_GLOBAL uint64_t* const live_bits = (const NRT_GLOBAL uint64_t*)part.live_bits;
@@ -414,114 +471,118 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     const bool has_term = lane < n_terms;
 
     const uint32_t last_tile = part.tile_end - 1u;
-    // software pipeline state: the wave's LDS table describes sub-tile `sub` (total_groups pairs),
-    // (nlo, nhi) are the cell values of sub + 16, pf holds the first 64 pairs of `sub`
+    // software pipeline state: the wave's LDS table and `pre` describe sub-tile g_cur (total_groups
+    // pairs), (nlo, nhi) are the cell values of g_nxt, pf holds the first 64 pairs of g_cur
     uint32_t nlo, nhi;
     uint32_t total_groups;
+    uint32_t pre[8];  // wave-uniform: pair prefixes of terms 0..7 of the table's sub-tile
     {
-      const uint32_t c0 = sub >> my_shift;
-      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, my_cells[c0], my_cells[c0 + 1], has_term);
-      const uint32_t c1 = min(sub + kScanWaves, last_tile) >> my_shift;
+      const uint32_t c0 = (g_cur + tile_bias) >> my_shift;
+      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, my_cells[c0], my_cells[c0 + 1], has_term, pre);
+      const uint32_t c1 = min(g_nxt + tile_bias, last_tile) >> my_shift;  // (clamped: g_nxt may belong to a later part)
       nlo = my_cells[c1];
       nhi = my_cells[c1 + 1];
     }
     Group pf;
-    if (PIPE) group_locate_load(s, wave, n_terms, lane, total_groups, pf);
+    group_locate_load(s, wave, n_terms, lane, total_groups, pre, pf);
+    // theta of the query's other items (LazyMaxScoreAccumulator analogue): read one sub-tile ahead of its
+    // use -- it is only a filter, a stale value costs a few extra candidates, never a result
+    uint64_t theta_other = 0, theta_other_next = 0;
 
-    for (; sub < part.tile_end; sub += kScanWaves) {
-      const uint32_t base = sub * (uint32_t)kTileDocs;
+    for (;;) {  // sub-tiles of this part
+      const uint32_t base = (g_cur + tile_bias) * (uint32_t)kTileDocs;
       const uint32_t tile_len = min((uint32_t)kTileDocs, part.max_doc - base);
       gdoc0 = (uint32_t)(part.doc_base + (int32_t)base);
       if (ABL == 7 && tid == 0) s.prof[7] += 1;
 
       // ---- (1) score the postings: coalesced 32 B/lane column loads (already in flight), table-lookup BM25
       const uint32_t cur_groups = total_groups;
-      const bool sparse = simple && cur_groups <= 64u;  // wave-uniform: collect through the postings instead of a sweep
-      uint32_t off[8];
-      float sc[8];
+      // wave-uniform: sub-tiles of up to one (16 waves: registers) or two pair-instructions per lane are
+      // collected through the postings instead of a sweep
+      constexpr bool kTwoGroups = kScanWaves <= 12;
+      const bool sparse = simple && cur_groups <= (kTwoGroups ? 128u : 64u);
+      const bool second = kTwoGroups && cur_groups > 64u;  // the sub-tile has a second instruction's worth of pairs
+      const bool act = lane < cur_groups, act2 = second && 64u + lane < cur_groups;
+      uint32_t off[8], off2[8];
+      float sc[8], sc2[8];
       if (cur_groups != 0) {
-        for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // dense sub-tile: pairs beyond the first 64 (wave-uniform trip count)
-          Group a;
-          uint32_t off2[8];
-          float sc2[8];
-          group_locate_load(s, wave, n_terms, vb + lane, cur_groups, a);
-          group_prepare<ABL>(s, a, vb + lane < cur_groups, base, tile_len, dummy_off, part_terms, off2, sc2);
-          group_commit_add(accb, off2, sc2);
-          if (ABL == 7 && tid == 0) s.prof[10] += 1;
+        if (sparse) {
+          if (second) {
+            Group a;
+            group_locate_load(s, wave, n_terms, 64u + lane, cur_groups, pre, a);
+            group_prepare<ABL>(s, a, 64u + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, sc2);
+            if (ABL == 7 && tid == 0) s.prof[10] += 1;
+          }
+        } else {
+          for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // dense sub-tile: pairs beyond the first 64 (wave-uniform trip count)
+            Group a;
+            group_locate_load(s, wave, n_terms, vb + lane, cur_groups, pre, a);
+            group_prepare<ABL>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, sc2);
+            if (vb + lane < cur_groups) group_commit_add(off2, sc2);
+            if (ABL == 7 && tid == 0) s.prof[10] += 1;
+          }
         }
-        if (!PIPE) group_locate_load(s, wave, n_terms, lane, cur_groups, pf);
-        group_prepare<ABL>(s, pf, lane < cur_groups, base, tile_len, dummy_off, part_terms, off, sc);
+        group_prepare<ABL>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, sc);
         if (ABL == 7 && tid == 0) s.prof[8] += 1;
       }
 
-      // ---- (2) start the next sub-tile's traffic (the column words in pf are consumed): its table, its
-      //      first posting pairs, the cells after it, theta
-      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, nlo, nhi,
-                                   has_term && sub + kScanWaves < part.tile_end);
+      // ---- (2a) the next sub-tile's table (the column words in pf are consumed), the cells after it, theta
+      total_groups = subtile_build(s, wave, lane, my_docids, my_delta16, my_lo, my_flags, nlo, nhi, has_term && g_nxt < gn, pre);
       {
-        const uint32_t c2 = min(sub + 2u * kScanWaves, last_tile) >> my_shift;
+        const uint32_t c2 = min(g_nxt2 + tile_bias, last_tile) >> my_shift;
         nlo = my_cells[c2];
         nhi = my_cells[c2 + 1];
       }
-      // theta: this item's (LDS) and the other items' of the query (LazyMaxScoreAccumulator analogue)
-      const uint64_t theta_shared = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (PIPE) group_locate_load(s, wave, n_terms, lane, total_groups, pf);
+      uint32_t g_new = 0;  // take one more sub-tile; the counter's answer is needed at the end of this iteration
+      if (lane == 0) g_new = atomicAdd(&s.next_tile, 1u);
+      theta_other = theta_other_next;
+      if (multi_item) theta_other_next = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+      // ---- (3) fp64 LDS accumulate; sparse sub-tiles: then each posting swaps the "unmatched" marker into
+      //      its doc's slot.  LDS executes a wave's operations in order, so the first posting of a doc to
+      //      do so receives the doc's complete score and is its collector; the others (and invalid
+      //      postings, on the dummy slot) receive the marker.  No sweep.  Idle lanes stay out of the
+      //      LDS pipe; every add of the sub-tile precedes every swap.
+      double a[8], a2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = a2[j] = unmatched_value();
+      if (cur_groups != 0) {
+        if (act && ABL != 2 && ABL != 4) group_commit_add(off, sc);
+        if (sparse && ABL != 2 && ABL != 3) {
+          if (act2) group_commit_add(off2, sc2);
+          if (act) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              a[j] = __longlong_as_double((long long)atomicExch((unsigned long long*)lds_ptr(off[j]), (unsigned long long)kUnmatched));
+          }
+          if (act2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              a2[j] = __longlong_as_double((long long)atomicExch((unsigned long long*)lds_ptr(off2[j]), (unsigned long long)kUnmatched));
+          }
+        }
+      }
+
+      // ---- (2b) the next sub-tile's first posting pairs: in flight while this one is collected
+      group_locate_load(s, wave, n_terms, lane, total_groups, pre, pf);
+      if (!PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A/B: no overlap of the column loads
 
       if (cur_groups != 0) {
         const uint64_t theta_l = s.theta;
-        const uint64_t theta = theta_shared > theta_l ? theta_shared : theta_l;
+        const uint64_t theta = theta_other > theta_l ? theta_other : theta_l;
         // "fp32 score could reach theta's score" as ONE signed 64-bit compare on the fp64 bits:
         // non-negative doubles order like their bit patterns, the "unmatched" pattern (-0.0) is
         // INT64_MIN, and half a float ulp below theta's score is a conservative cut
         const long long thr_bits = __double_as_longlong((double)key_score(theta_l)) - (1ll << 28);
         if (sparse) {
-          // ---- (3s) accumulate, then collect through the postings: each posting swaps the "unmatched"
-          //      marker into its doc's slot.  LDS executes a wave's operations in order, so the first
-          //      posting of a doc to do so receives the doc's complete score and is its collector;
-          //      the others (and invalid postings, on the dummy slot) receive the marker.  No sweep.
+          // ---- (4s) collect through the postings
           if (ABL == 7 && tid == 0) s.prof[9] += 1;
-          double a[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] = unmatched_value();
-          if (lane < cur_groups) {  // one region for all 16 LDS operations: idle lanes stay out of the LDS pipe
-            group_commit_add(accb, off, sc);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              a[j] = __longlong_as_double((long long)atomicExch((unsigned long long*)(accb + off[j]), (unsigned long long)kUnmatched));
-          }
-          unsigned long long any_maybe = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(dbl_bits(a[j]) != kUnmatched));
-            any_maybe |= __builtin_amdgcn_ballot_w64(__double_as_longlong(a[j]) >= thr_bits);
-          }
-          if (any_maybe != 0ull) {  // wave-uniform; rare once theta has converged
-            if (ABL == 7 && tid == 0) s.prof[13] += 1;
-            uint32_t cmask = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (__double_as_longlong(a[j]) >= thr_bits && pack_key((float)a[j], gdoc0 + (off[j] >> 3)) > theta) cmask |= 1u << j;
-            if (__any(cmask != 0)) {
-              if (ABL == 7 && tid == 0) s.prof[12] += 1;
-              uint32_t pos = reserve_candidates(s, lane, (uint32_t)__popc(cmask));
-              if (pos < (uint32_t)kCandCap) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                  if ((cmask >> j) & 1u) s.cand[pos++] = pack_key((float)a[j], gdoc0 + (off[j] >> 3));
-              } else {
-                parked = true;  // back into my sub-tile: the rendezvous that follows this iteration takes them from there
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                  if ((cmask >> j) & 1u) *(double*)(accb + off[j]) = a[j];
-              }
-            }
-          }
+          parked = collect_swapped<ABL>(s, acc_addr, lane, a, off, thr_bits, theta, gdoc0, wave_hits);
+          if (second) parked |= collect_swapped<ABL>(s, acc_addr, lane, a2, off2, thr_bits, theta, gdoc0, wave_hits);
         } else {
-          // ---- (3d) accumulate, then dense sweep of my sub-tile: count hits, reset every slot that cannot
-          //      be competitive.  A slot whose fp32 score reaches theta's score stays in place (mmask)
-          //      for the exact path.
+          // ---- (4d) dense sweep of my sub-tile: count hits, reset every slot that cannot be competitive.
+          //      A slot whose fp32 score reaches theta's score stays in place (mmask) for the exact path.
           if (ABL == 7 && tid == 0) s.prof[11] += 1;
-          if (lane < cur_groups) group_commit_add(accb, off, sc);
           uint32_t mmask = 0;
           unsigned long long any_maybe = 0;  // wave-uniform
           if (simple) {
@@ -597,24 +658,43 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         }
       }
 
-      // ---- (4) somebody's candidates did not fit (seen at the next sub-tile boundary at the latest):
-      //      leave the walk for the rendezvous
+      // ---- (5) advance.  Somebody's candidates did not fit (seen at the next sub-tile boundary at the
+      //      latest): leave the walk for the rendezvous
+      g_cur = g_nxt;
+      g_nxt = g_nxt2;
+      g_nxt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
       if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {  // wave-uniform
-        resume_sub = sub + (uint32_t)kScanWaves;
         interrupted = true;
         break;
       }
+      if (g_cur >= gn) break;  // the next sub-tile lies in a later part (or past the item)
     }
     if (interrupted) break;
-    phase = next_phase;
   }
 
   // ---- rendezvous point: waves that are out of sub-tiles wait here for the others
+  uint64_t t_r0 = 0;
+  if (ABL == 7) {
+    t_r0 = __builtin_readcyclecounter();
+    if (!interrupted && lane == 0) {  // this wave is out of work: spread of the waves' finish times
+      atomicMax((unsigned long long*)&s.prof[14], (unsigned long long)(t_r0 - t_walk));
+      atomicMin((unsigned long long*)&s.prof[15], (unsigned long long)(t_r0 - t_walk));
+    }
+  }
   __syncthreads();  // R1: all waves -- interrupted ones and finished ones
+  if (ABL == 7 && tid == 0) s.prof[1] += __builtin_readcyclecounter() - t_r0;  // wave 0 waiting for the others
   if (!__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // nobody asked: everybody is finished
   rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, my_theta_g);  // ends with barriers: the flag is re-read safely
   parked = false;
-  if (ABL == 7 && tid == 0) s.prof[5] += 1;
+  if (ABL == 7 && tid == 0) {
+    s.prof[5] += 1;
+    s.prof[2] += __builtin_readcyclecounter() - t_r0;  // rendezvous incl. the wait
+  }
+  }
+  uint64_t t_epi = 0;
+  if (ABL == 7) {
+    t_epi = __builtin_readcyclecounter();
+    if (tid == 0) s.prof[3] += t_epi - t_walk;  // walk + rendezvous
   }
 
   // ---- item epilogue: final top-k of the item, hit count
@@ -637,8 +717,10 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   if (tid == 0) {
     item_counts[blockIdx.x] = n;
     item_hits[blockIdx.x] = s.hits;
-    if (ABL == 7 && item_prof)
+    if (ABL == 7 && item_prof) {
+      s.prof[4] += __builtin_readcyclecounter() - t_epi;  // epilogue
       for (int i = 0; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
+    }
   }
 }
 
@@ -755,8 +837,14 @@ void launch_bm25_scan(hipStream_t stream, bool pipelined, int ablation, uint32_t
   hipLaunchKernelGGL((bm25_scan_kernel<P, A>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
                      caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof)
   if (!pipelined) { NRT_LAUNCH(false, 0); return; }
-  if (ablation == 7) NRT_LAUNCH(true, 7);
-  else NRT_LAUNCH(true, 0);
+  switch (ablation) {
+    case 1: NRT_LAUNCH(true, 1); break;  // 1-4: timing ablations (wrong results), see the kernel
+    case 2: NRT_LAUNCH(true, 2); break;
+    case 3: NRT_LAUNCH(true, 3); break;
+    case 4: NRT_LAUNCH(true, 4); break;
+    case 7: NRT_LAUNCH(true, 7); break;
+    default: NRT_LAUNCH(true, 0); break;
+  }
 #undef NRT_LAUNCH
 }
 

@@ -7,13 +7,14 @@
 
 namespace nrtgpu {
 
-// Workgroup shape of the scan: waves x docs-per-sub-tile must fit 96 KiB of fp64 accumulators
-// (16 x 768 or 12 x 1024); a build-time choice (-DNRT_SCAN_WAVES / -DNRT_TILE_DOCS).
+// Workgroup shape of the scan: waves x docs-per-sub-tile must fit 96 KiB of fp64 accumulators.
+// 12 x 1024 (3 waves per SIMD, 168 VGPRs each) measured faster than 16 x 768 (4 per SIMD, 128 VGPRs:
+// spills) on MI355X; a build-time choice (-DNRT_SCAN_WAVES / -DNRT_TILE_DOCS).
 #ifndef NRT_SCAN_WAVES
-#define NRT_SCAN_WAVES 16
+#define NRT_SCAN_WAVES 12
 #endif
 #ifndef NRT_TILE_DOCS
-#define NRT_TILE_DOCS 768
+#define NRT_TILE_DOCS 1024
 #endif
 constexpr int kTileDocs = NRT_TILE_DOCS;        // docs per wave-private LDS accumulator sub-tile (fp64)
 constexpr int kScanWaves = NRT_SCAN_WAVES;      // autonomous wave64 per workgroup, 1 workgroup per CU (whole 160 KiB LDS)
@@ -57,7 +58,8 @@ struct alignas(16) DPart {
   uint32_t tile_begin, tile_end;
   uint32_t max_doc;
   int32_t  doc_base;
-  uint32_t pad0, pad1;
+  uint32_t tile_offset;       // sub-tiles of the item's earlier parts: the item's sub-tiles form one sequence
+  uint32_t pad1;
 };
 static_assert(sizeof(DPart) == 48, "DPart layout");
 

@@ -757,7 +757,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
   const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : (int64_t)std::max(ctx->n_cus, 1);
   const int64_t min_item_cost = 1 << 17;
   const int64_t per_item = std::max<int64_t>(min_item_cost, total_cost / std::max<int64_t>(1, target_items));
-  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; };
+  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; };
   std::vector<Pending> pend;
   for (int qi = 0; qi < n_queries; ++qi) {
     int64_t q_cost = 0;
@@ -765,7 +765,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     if (q_cost == 0) continue;
     const int64_t n_it = std::max<int64_t>(1, (q_cost + per_item / 2) / per_item);
     const double budget = (double)q_cost / (double)n_it;
-    Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0};
+    Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
     double filled = 0.0;
     for (const QS& qs : per_query[(size_t)qi]) {
       const nrtgpu_seg* seg = segs[qs.seg];
@@ -783,14 +783,16 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
         p.tile_end = tb + take;
         p.max_doc = (uint32_t)seg->max_doc;
         p.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
+        p.tile_offset = cur.tiles;
         hp.parts.push_back(p);
         cur.n_parts++;
+        cur.tiles += take;
         cur.cost += (int64_t)(take * tile_cost);
         filled += take * tile_cost;
         tb += take;
         if (filled >= budget * 0.999) {  // item full: close it
           pend.push_back(cur);
-          cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0};
+          cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
           filled = 0.0;
         }
       }

@@ -32,7 +32,7 @@ SMOKE = Workload("smoke: 200k docs, 3-term disjunction top-100", 200_000, 3, 100
 
 def shard_range(n_docs: int, world: int, rank: int):
     """Contiguous docid range of `rank` (tile-aligned so no doc tile straddles two GPUs)."""
-    tile = 768
+    tile = 1024
     per = ((n_docs + world - 1) // world + tile - 1) // tile * tile
     lo = min(n_docs, rank * per)
     hi = min(n_docs, lo + per)

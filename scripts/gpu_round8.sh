@@ -5,12 +5,12 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 V="${1:-0:0:1024,0:1:1024,0:1792:1024}"
-echo "== pytest gpu (16x768) =="
+echo "== pytest gpu (default 12x1024) =="
 timeout 500 python -m pytest tests -m gpu -q -x --timeout 120 2>&1 | tail -4
-echo "== sweep 16x768 =="
-timeout 600 python scripts/gpu_sweep.py --docs 10000000 --queries 2048 --steps 4 --oracle-queries 3 --variants "$V" 2>&1 | cut -c1-1200
-echo "== pytest gpu (12x1024) =="
-NRTGPU_LIB_PATH=$PWD/nrtsearch_amd/libnrtgpu_12x1024.so timeout 500 python -m pytest tests -m gpu -q -x --timeout 120 2>&1 | tail -4
-echo "== sweep 12x1024 =="
-NRTGPU_LIB_PATH=$PWD/nrtsearch_amd/libnrtgpu_12x1024.so timeout 600 python scripts/gpu_sweep.py --docs 10000000 --queries 2048 --steps 4 --oracle-queries 3 --variants "$V" 2>&1 | cut -c1-1200
+echo "== sweep default 12x1024 =="
+timeout 600 python scripts/gpu_sweep.py --docs 10000000 --queries 2048 --steps 10 --oracle-queries 3 --variants "$V" 2>&1 | cut -c1-1200
+echo "== pytest gpu (alt 16x768) =="
+NRTGPU_LIB_PATH=$PWD/nrtsearch_amd/libnrtgpu_16x768.so timeout 500 python -m pytest tests -m gpu -q -x --timeout 120 2>&1 | tail -4
+echo "== sweep alt 16x768 =="
+NRTGPU_LIB_PATH=$PWD/nrtsearch_amd/libnrtgpu_16x768.so timeout 600 python scripts/gpu_sweep.py --docs 10000000 --queries 2048 --steps 10 --oracle-queries 3 --variants "$V" 2>&1 | cut -c1-1200
 echo "== done =="

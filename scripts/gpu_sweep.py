@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--queries", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--oracle-queries", type=int, default=6)
+    ap.add_argument("--world", type=int, default=1, help="index only rank 0's docid range of a WORLD-GPU job")
     ap.add_argument("--variants", default="0:0:1024,0:1:1024,1024:0:1024,8192:0:1024,0:0:256,0:0:64,0:0:1",
                     help="comma list of target_items:flags:batch")
     args = ap.parse_args()
@@ -45,7 +46,7 @@ def main():
     w.n_docs = args.docs
     t0 = time.time()
     qr = synth.make_queries(args.queries, w.n_terms, w.max_rank)
-    corpus = workload.build_shard_corpus(w, qr)
+    corpus = workload.build_shard_corpus(w, qr, args.world, 0)
     ppq = workload.postings_per_query(corpus.doc_freq, qr)
     log(json.dumps({"event": "corpus", "docs": w.n_docs, "postings": corpus.total_postings, "build_s": round(time.time() - t0, 1),
                     "mean_P": float(ppq.mean())}))

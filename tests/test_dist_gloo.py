@@ -70,13 +70,13 @@ def test_shard_ranges_cover_the_index():
     sys.path.insert(0, ROOT)
     from nrtsearch_amd import workload
 
-    for n_docs in (1, 767, 768, 10_000_000, 50_000_001):
+    for n_docs in (1, 1023, 1024, 10_000_000, 50_000_001):
         for world in (1, 2, 4, 8):
             ranges = [workload.shard_range(n_docs, world, r) for r in range(world)]
             assert ranges[0][0] == 0 and ranges[-1][1] == n_docs
             for (a, b), (c, d) in zip(ranges, ranges[1:]):
                 assert b == c and a <= b
-            assert all(a % 768 == 0 for a, b in ranges if b > a)   # non-empty ranges start on a sub-tile boundary
+            assert all(a % 1024 == 0 for a, b in ranges if b > a)   # non-empty ranges start on a sub-tile boundary
 
 
 def test_key_packing_roundtrip_and_order():

@@ -212,7 +212,7 @@ def test_ties_rank_by_docid(ctx, oracle):
 
 def test_ragged_shapes(ctx, oracle):
     # max_doc around multiples of the 768-doc sub-tile and of a 16-wave round (12288), one-doc segment
-    for n_docs, nseg in [(1, 1), (767, 1), (768, 1), (769, 1), (12_289, 1), (20_000, 3), (70_001, 5)]:
+    for n_docs, nseg in [(1, 1), (767, 1), (768, 1), (769, 1), (1023, 1), (1024, 1), (1025, 1), (12_289, 1), (16_385, 1), (20_000, 3), (70_001, 5)]:
         corpus = synth.build_corpus(n_docs, [1, 3, 9], n_segments=nseg, delete_fraction=0.1 if n_docs > 1 else 0.0)
         ix = Index(ctx, corpus)
         for terms in ([1], [1, 3, 9]):
