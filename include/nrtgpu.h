@@ -59,7 +59,8 @@ typedef struct {
   int32_t host_threads;     /* planner threads used inside one batch call (term-dictionary lookups); 0 => 4 */
 } nrtgpu_config;
 
-#define NRTGPU_FLAG_NO_PREFETCH 1  /* scan kernel without the one-tile-ahead posting prefetch (A/B) */
+#define NRTGPU_FLAG_NO_PREFETCH 1     /* scan kernel without the one-tile-ahead posting prefetch (A/B) */
+#define NRTGPU_FLAG_NO_FIXED_POINT 2  /* always accumulate in fp64 (A/B; results are identical either way) */
 
 const char* nrtgpu_version(void);
 const char* nrtgpu_last_error(void);
@@ -216,15 +217,17 @@ typedef struct {
   int64_t scan_items;
   double  merge_ms;
   double  host_plan_ms;       /* host time spent building launch plans */
+  int64_t fixed_point_launches; /* scan launches that accumulated in exact fixed point (the others: fp64) */
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
 #define NRTGPU_FLAG_PROFILE (7 << 8)  /* instrumented scan kernel: per-item phase cycle and event counters of wave 0 (nrtgpu_get_scan_profile) */
-/* sums over all items since the last reset, instrumented kernel only (thread 0 of each workgroup,
- * shader-clock cycles): [0] accumulate, [1] wait at barrier A, [2] sweep+collect, [3] wait at
- * barrier C, [4] slow path, [5] slow-path entries, [6] compactions, [7] tiles, [8] issue of the
- * next tile's loads, [9] branch-free sweep, [10] exact path + collect, [11] densest term done,
- * [12..15] reserved */
+/* sums over all items since the last reset, instrumented kernel only (wave 0 of each workgroup;
+ * cycles = shader clock): [0] prologue cycles, [1] cycles waiting at the rendezvous barrier,
+ * [2] rendezvous cycles incl. that wait, [3] walk cycles, [4] epilogue cycles, [5] rendezvous,
+ * [6] compactions, [7] sub-tiles, [8] sub-tiles with postings, [9] sparse (collected through the
+ * postings), [10] extra pair instructions, [11] dense (swept), [12] sub-tiles with candidates,
+ * [13] sub-tiles with a possibly competitive doc, [14] last wave's finish cycle, [15] first wave's */
 int  nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16);
 
 #ifdef __cplusplus

@@ -20,6 +20,7 @@ NRTGPU_MAX_K = 1024
 NRTGPU_MAX_TERMS = 32
 NRTGPU_TILE_DOCS = 1024
 NRTGPU_FLAG_NO_PREFETCH = 1
+NRTGPU_FLAG_NO_FIXED_POINT = 2
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
 ABI_SYMBOLS = [
@@ -61,7 +62,7 @@ class TopDocs(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("batches", C.c_int64), ("queries", C.c_int64), ("scan_launches", C.c_int64),
                 ("scan_ms", C.c_double), ("scan_postings", C.c_int64), ("scan_items", C.c_int64),
-                ("merge_ms", C.c_double), ("host_plan_ms", C.c_double)]
+                ("merge_ms", C.c_double), ("host_plan_ms", C.c_double), ("fixed_point_launches", C.c_int64)]
 
 
 class NrtGpuError(RuntimeError):

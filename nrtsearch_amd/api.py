@@ -149,7 +149,8 @@ class GpuContext:
         # counters of wave 0 of every item, summed over the items since reset_stats (NRTGPU_FLAG_PROFILE)
         names = ["prologue_cycles", "rendezvous_wait_cycles", "rendezvous_cycles", "walk_cycles", "epilogue_cycles",
                  "rendezvous", "compactions", "subtiles", "subtiles_with_postings", "sparse_subtiles", "extra_groups",
-                 "dense_subtiles", "candidate_subtiles", "maybe_subtiles", "r14", "r15"]
+                 "dense_subtiles", "candidate_subtiles", "maybe_subtiles", "last_wave_finish_cycles",
+                 "first_wave_finish_cycles"]
         return dict(zip(names, out.tolist()))
 
     def reset_stats(self) -> None:

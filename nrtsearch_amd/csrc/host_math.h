@@ -49,6 +49,15 @@ inline float bm25_avgdl(int64_t sum_total_term_freq, int64_t doc_count) {
 }
 // cache[i] = 1f / (k1 * ((1 - b) + b * LENGTH_TABLE[i] / avgdl)), fp32 in this association.
 // (compiled with -ffp-contract=off; volatile keeps every intermediate a rounded float)
+// BM25Similarity SimScorer.score(freq, norm) with Java's float op order (this header is compiled
+// with -ffp-contract=off): weight - weight / (1f + freq * normInverse).
+inline float bm25_score(float weight, float freq, float norm_inverse) {
+  const float prod = freq * norm_inverse;
+  const float den = 1.0f + prod;
+  const float quo = weight / den;
+  return weight - quo;
+}
+
 inline void bm25_norm_cache(float avgdl, float k1, float b, float* out256) {
   for (int i = 0; i < 256; ++i) {
     volatile float len = (float)byte4_to_int(i);

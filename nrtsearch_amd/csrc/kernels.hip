@@ -37,7 +37,44 @@ typedef const NRT_GLOBAL u32x4* gvec_ptr;
 typedef const NRT_GLOBAL uint32_t* gu32_ptr;
 typedef const NRT_GLOBAL float* gf32_ptr;
 
-constexpr uint64_t kUnmatched = 0x8000000000000000ull;  // -0.0: "no term matched this doc yet"
+// Accumulators.  One 64-bit LDS slot per doc of a wave's sub-tile, in one of two exact representations
+// chosen per batch by the host (runtime.cpp: fixed_scale_of_term):
+//   fp64  (FX = false): the double sum of the fp32 term scores, as the reference computes it
+//                       ("unmatched" marker: -0.0, which no sum of non-negative scores produces)
+//   fixed (FX = true):  the same sum as an integer multiple of 2^-fx_E: every term score is a positive
+//                       integer < 2^32 at its own scale and enters shifted left by DTerm.fx_shift; the sum
+//                       stays below 2^53, so converting it to double is exact and (float) rounds it exactly
+//                       like the reference's (float)(double sum).  Marker: 0.  ds_add_u64 costs half of
+//                       ds_add_f64 in the LDS pipe (profiles/: 10 vs 19 cycles per wave instruction).
+constexpr uint64_t kUnmatchedF64 = 0x8000000000000000ull;  // -0.0
+template <bool FX>
+__device__ __forceinline__ constexpr uint64_t acc_marker() { return FX ? 0ull : kUnmatchedF64; }
+
+// fp32 score of an accumulator value (the one rounding of the reference's (float) sum)
+template <bool FX>
+__device__ __forceinline__ float acc_score(uint64_t a, int fx_E) {
+  if (FX) return (float)ldexp((double)a, -fx_E);  // a < 2^53: exact conversion, exact scaling
+  return (float)__longlong_as_double((long long)a);
+}
+
+// "the fp32 score could reach theta's score" as ONE 64-bit compare against this value: signed compare
+// of the double's bits (non-negative doubles order like their bit patterns, the marker -0.0 is
+// INT64_MIN) / unsigned compare of the fixed-point sum (>= 1 keeps the marker 0 out).  The cut lies
+// at least half a float ulp below theta's score, so no doc whose sum rounds up to it is lost.
+template <bool FX>
+__device__ __forceinline__ uint64_t acc_threshold(uint64_t theta_key, int fx_E) {
+  const double th = (double)key_score(theta_key);
+  if (FX) {
+    const double cut = ldexp(th * (1.0 - 1.0 / 8388608.0), fx_E);  // one float ulp below, scaled
+    const uint64_t t = (uint64_t)cut;
+    return t > 1ull ? t : 1ull;
+  }
+  return (uint64_t)(__double_as_longlong(th) - (1ll << 28));
+}
+template <bool FX>
+__device__ __forceinline__ bool acc_reaches(uint64_t a, uint64_t thr) {
+  return FX ? (a >= thr) : ((long long)a >= (long long)thr);
+}
 
 // LDS byte addresses as plain 32-bit integers: the accumulator address of a posting is then ONE
 // shift-add from its docid, with no pointer arithmetic left for the LDS instruction.
@@ -45,19 +82,19 @@ typedef __attribute__((address_space(3))) char* lds_char_ptr;
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_char_ptr)p; }
 __device__ __forceinline__ char* lds_ptr(uint32_t a) { return (char*)(lds_char_ptr)(uintptr_t)a; }
 
-
-// Work decomposition: a workgroup is 16 AUTONOMOUS waves and owns one CU (all 160 KiB of LDS).  The
-// sub-tiles (768 docs) of an item's parts form one sequence; wave w walks sub-tiles w, w+16, ... of it
-// on its own: load postings -> fp64 accumulate into its private 6 KiB LDS sub-tile -> collect the
-// competitive docs into the workgroup's shared candidate buffer.  No workgroup barrier in steady
-// state (not even between parts): 16 waves sit at different points of that chain and hide each
-// other's LDS / HBM latency.  Per-term metadata of a sub-tile lives in lane registers (lane l <-> term
-// l) and in a small wave-private LDS table.  Barriers happen only at a rendezvous when the shared
-// candidate buffer overflows (top-k compaction) and at the end of the item.
+// Work decomposition: a workgroup is kScanWaves AUTONOMOUS waves and owns one CU (all 160 KiB of LDS).
+// The sub-tiles (kTileDocs docs) of an item's parts form one sequence from which the waves help
+// themselves; each wave on its own: load postings -> accumulate into its private LDS sub-tile ->
+// collect the competitive docs into the workgroup's shared candidate buffer.  No workgroup barrier in
+// steady state (not even between parts): the waves sit at different points of that chain and hide
+// each other's LDS / HBM latency.  Per-term metadata of a sub-tile lives in lane registers (lane l <->
+// term l) and in a small wave-private LDS table.  Barriers happen only at a rendezvous when the
+// shared candidate buffer overflows (top-k compaction) and at the end of the item.
 struct ScanSmem {
-  double   acc[kScanWaves][kTileDocs];     // fp64 score accumulators: one sub-tile per wave (96 KiB)
+  uint64_t acc[kScanWaves][kTileDocs];     // score accumulators: one sub-tile per wave (96 KiB)
   uint64_t cand[kCandCap];                 // competitive hits of the item (packed keys), unordered (15 KiB)
-  float    tab[kTabTerms][kTabEntries];    // BM25 score of (freq, norm byte) for the item's densest terms
+  uint32_t tab[kTabTerms][kTabEntries];    // BM25 score of (freq, norm byte) for the item's densest terms:
+                                           // fp32 bits, or the fixed-point integer at the term's scale
   float    cache[kLdsCaches][256];         // BM25 normInverse tables of the query's fields (division path)
   // wave-private view of the wave's current sub-tile, written by lanes 0..31 (lane l <-> term l):
   alignas(16) uint32_t w_incl[kScanWaves][kMaxTerms];     // 8-posting pairs of terms 0..l (inclusive prefix)
@@ -65,6 +102,7 @@ struct ScanSmem {
   uint32_t w_before[kScanWaves][kMaxTerms];               // pairs of terms 0..l-1
   TopkScratch sc;
   uint64_t theta;        // packed key of the k-th best hit seen so far (0 = none)
+  uint64_t thr;          // acc_threshold(theta): what the walk compares accumulators with
   uint32_t cnt;          // valid entries in cand
   uint32_t tile_cand;    // rendezvous: competitive hits still parked in the accumulators
   uint32_t hits;         // live matching docs of this item
@@ -72,14 +110,11 @@ struct ScanSmem {
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kCandCap
   uint32_t next_tile;    // next unassigned sub-tile of the item (flattened over its parts)
   uint64_t prof[16];     // instrumented variant only (ABL == 7)
-  double   dummy[64];    // per-lane sink for invalid postings; always holds the "unmatched" marker (see group_prepare)
+  uint64_t dummy[64];    // per-lane sink for invalid postings; always holds the marker (see group_prepare)
 };
 static_assert(sizeof(ScanSmem) <= 160 * 1024, "the scan workgroup owns one CU's 160 KiB LDS");
 
 constexpr int kSlots = kTileDocs / 64;  // accumulator slots per lane (dense sweep)
-
-__device__ __forceinline__ uint64_t dbl_bits(double d) { return (uint64_t)__double_as_longlong(d); }
-__device__ __forceinline__ double unmatched_value() { return __longlong_as_double((long long)kUnmatched); }
 
 // BM25Similarity SimScorer.score(freq, norm): weight - weight / (1f + freq * normInverse),
 // one IEEE rounding per operation (no contraction, correctly rounded division).
@@ -88,6 +123,12 @@ __device__ __forceinline__ float bm25_score(float w, float freq, float ninv) {
   const float den = 1.0f + prod;
   const float quo = w / den;
   return w - quo;
+}
+// the value a posting adds: fp32 bits, or the score as an integer at the term's scale (exact: the host
+// chose the scale so that every score of the term is an integer below 2^32 after it)
+template <bool FX>
+__device__ __forceinline__ uint32_t score_value(float sc, int fx_scale) {
+  return FX ? (uint32_t)ldexpf(sc, fx_scale) : __float_as_uint(sc);
 }
 
 // Inclusive prefix sum over lanes 0..31 with DPP row shifts (VALU only, no LDS-pipe traffic).
@@ -109,10 +150,11 @@ __device__ __forceinline__ uint32_t scan64_dpp(uint32_t x) {
 
 // Per-term view of one sub-tile, built by lane l for term l and published in the wave's LDS table.
 // The term's postings of the sub-tile are seen through a window of 16-byte groups (4 postings each):
-//   meta: end (bits 0-22): postings [first, end) of the window belong to the sub-tile | first (23-25) |
-//         score table (26-28, 7 = none) | coarse cell: postings may lie outside the sub-tile (29)
+//   meta: end (bits 0-21): postings [first, end) of the window belong to the sub-tile | first (22-23) |
+//         score table (24-26, 7 = none) | coarse cell: postings may lie outside the sub-tile (27) |
+//         fixed-point shift of the term (28-31)
 // A lane processes a PAIR of consecutive groups (8 postings) per instruction.
-constexpr uint32_t kMetaEnd = 0x7FFFFFu;
+constexpr uint32_t kMetaEnd = 0x3FFFFFu;
 
 // Lane-as-term: posting range [lo, hi) of my term in a sub-tile -> table entry; returns the number of
 // pair-instruction lanes of the whole sub-tile (wave-uniform).
@@ -133,7 +175,7 @@ __device__ __forceinline__ uint32_t subtile_build(ScanSmem& s, uint32_t wave, ui
   if (lane < (uint32_t)kMaxTerms) {
     s.w_incl[wave][lane] = incl;
     s.w_before[wave][lane] = incl - np;
-    u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16, end | (first << 23) | (my_flags << 26)};
+    u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16, end | (first << 22) | (my_flags << 24)};
     *(u32x4*)&s.w_rec[wave][lane][0] = rec;
   }
   // the prefixes of the first 8 terms as wave-uniform scalars: locating a pair needs no LDS round trip
@@ -177,31 +219,31 @@ __device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wa
 
 // Scoring a pair of groups happens in two steps so that the registers holding the loaded column
 // words can be recycled for the next sub-tile's loads in between:
-//   group_prepare: per posting the byte offset of its doc's accumulator (off) and its BM25 score (sc,
-//                  one LDS table read; division only for postings / terms no table serves) + validity
-//   group_commit_add: one fp64 LDS atomic per posting.
+//   group_prepare:    per posting the LDS address of its doc's accumulator (off) and the value it adds
+//                     (val: one LDS table read; division only for postings / terms no table serves)
+//   group_commit_add: one LDS atomic per posting.
 // Invalid postings of a pair (outside the term's window / the sub-tile) are redirected instead of
-// predicated: they add -0.0 to the lane's dummy slot, which holds the "unmatched" marker -0.0 forever
-// (-0.0 + -0.0 == -0.0), so neither the adds nor the collecting swaps need per-posting control flow
-// (a conditionally executed returning LDS op makes the compiler wait for each result at the end of
-// its branch) and a dummy never looks like a matched doc.
-template <int ABL>
-__device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group& gr, bool valid, uint32_t acc_addr, uint32_t base,
-                                                  uint32_t tile_len, uint32_t dummy_addr, const DTerm* __restrict__ part_terms,
-                                                  uint32_t (&off)[8], float (&sc)[8]) {
+// predicated: they add a neutral value (-0.0 / 0) to the lane's dummy slot, which therefore holds the
+// "unmatched" marker forever, so neither the adds nor the collecting swaps need per-posting control
+// flow (a conditionally executed returning LDS op makes the compiler wait for each result at the end
+// of its branch) and a dummy never looks like a matched doc.
+template <bool FX, int ABL>
+__device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr, bool valid, uint32_t acc_addr, uint32_t base,
+                                              uint32_t tile_len, uint32_t dummy_addr, const DTerm* __restrict__ part_terms,
+                                              uint32_t (&off)[8], uint32_t (&val)[8]) {
   const uint32_t meta = gr.meta;
   // valid postings of my pair: window positions [first, end) intersected with [8p, 8p + 8)
   const int idx0 = (int)(gr.p * 8u);
-  const int lo_cut = (int)((meta >> 23) & 7u) - idx0, hi_cut = (int)(meta & kMetaEnd) - idx0;
+  const int lo_cut = (int)((meta >> 22) & 3u) - idx0, hi_cut = (int)(meta & kMetaEnd) - idx0;
   const uint32_t hm = (1u << (uint32_t)min(max(hi_cut, 0), 8)) - 1u;
   const uint32_t lm = (1u << (uint32_t)min(max(lo_cut, 0), 8)) - 1u;
   uint32_t vmask = valid ? (hm & ~lm) : 0u;
-  const uint32_t tab = (meta >> 26) & 7u;
+  const uint32_t tab = (meta >> 24) & 7u;
   // LDS address of the doc's accumulator in the wave's sub-tile: acc + (doc - base) * 8 in one op
   const uint32_t abase = acc_addr - base * 8u;
 #pragma unroll
   for (int j = 0; j < 8; ++j) off[j] = (gr.d4[j >> 2][j & 3] << 3) + abase;
-  if (__any((meta >> 29) & 1u)) {
+  if (__any((meta >> 27) & 1u)) {
     // sparse terms share one posting range between several sub-tiles (coarse cells): doc-range filter
     // (unsigned: docs below the sub-tile wrap to huge values)
 #pragma unroll
@@ -219,12 +261,13 @@ __device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group
   const char* tb = (const char*)&s.tab[0][0] + (tab == 7u ? 0u : tab) * (uint32_t)(kTabEntries * 4);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (ABL == 1) sc[j] = __uint_as_float((gr.c4[j >> 2][j & 3] & 0x1FFCu) | 0x3F000000u);  // timing ablation: no table read
-    else sc[j] = *(const float*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
+    if (ABL == 1) val[j] = (gr.c4[j >> 2][j & 3] & 0x1FFCu) | 0x3F000000u;  // timing ablation: no table read
+    else val[j] = *(const uint32_t*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
   }
   if (__any(special)) {
     // long docs / high freqs / terms without a score table (a few lanes)
     const float w = part_terms[gr.term].weight;
+    const int fx_scale = part_terms[gr.term].fx_scale;
     const float* cache = &s.cache[part_terms[gr.term].cache_slot][0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -232,24 +275,28 @@ __device__ __forceinline__ uint32_t group_prepare(const ScanSmem& s, const Group
       const bool esc = (c >> 31) != 0u;
       const uint32_t f = esc ? ((c >> 8) & 0x7FFFFFu) : (c >> 9);
       const uint32_t nb = esc ? (c & 255u) : ((c >> 2) & 127u);
-      if (((vmask >> j) & 1u) && (esc || tab == 7u)) sc[j] = bm25_score(w, (float)(int32_t)f, cache[nb]);
+      if (((vmask >> j) & 1u) && (esc || tab == 7u)) val[j] = score_value<FX>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
     }
   }
   if (!__all(vmask == 0xFFu)) {  // wave-uniform
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)vmask, j, 1);  // all ones: valid (bit-field extract + 2 bit-field inserts)
+      const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)vmask, j, 1);  // all ones: valid
       off[j] = (off[j] & t) | (dummy_addr & ~t);
-      sc[j] = __uint_as_float((__float_as_uint(sc[j]) & t) | (0x80000000u & ~t));
+      val[j] = FX ? (val[j] & t) : ((val[j] & t) | (0x80000000u & ~t));  // neutral element: 0 / -0.0f
     }
   }
-  return vmask;
 }
 
-// One fp64 LDS atomic per posting (invalid ones were redirected by group_prepare).
-__device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const float (&sc)[8]) {
+// One LDS atomic per posting (invalid ones were redirected by group_prepare): ds_add_f64 of the fp32
+// score widened to double, or ds_add_u64 of the term's fixed-point integer shifted into the query's scale.
+template <bool FX>
+__device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const uint32_t (&val)[8], uint32_t fx_shift) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) unsafeAtomicAdd((double*)lds_ptr(off[j]), (double)sc[j]);
+  for (int j = 0; j < 8; ++j) {
+    if (FX) atomicAdd((unsigned long long*)lds_ptr(off[j]), (unsigned long long)val[j] << fx_shift);
+    else unsafeAtomicAdd((double*)lds_ptr(off[j]), (double)__uint_as_float(val[j]));
+  }
 }
 
 // Workgroup-wide rendezvous body: keep the k best of (candidate buffer UNION the candidates a wave
@@ -257,13 +304,14 @@ __device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const
 // failed (`parked`) has reset every non-competitive slot of its sub-tile, so its parked candidates are
 // exactly the slots still matched; other waves have none.  Contains barriers; returns with the buffer
 // consistent and nothing parked.
-__device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, bool parked, uint32_t gdoc0, uint32_t k,
-                                                   unsigned long long* theta_g) {
+template <bool FX>
+__device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, bool parked, uint32_t gdoc0, uint32_t k,
+                                                   int fx_E, unsigned long long* theta_g) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   uint32_t cmask = 0;
   if (parked) {  // wave-uniform
 #pragma unroll
-    for (int j = 0; j < kSlots; ++j) cmask |= (uint32_t)(dbl_bits(acc[lane + 64u * (uint32_t)j]) != kUnmatched) << j;
+    for (int j = 0; j < kSlots; ++j) cmask |= (uint32_t)(acc[lane + 64u * (uint32_t)j] != acc_marker<FX>()) << j;
   }
   const uint32_t ncand = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp((uint32_t)__popc(cmask)), 63);
   if (lane == 0 && ncand) atomicAdd(&s.tile_cand, ncand);
@@ -278,13 +326,16 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, boo
       while (m) {
         const int j = __ffs((int)m) - 1;
         m &= m - 1u;
-        f(pack_key((float)acc[lane + 64u * (uint32_t)j], gdoc0 + lane + 64u * (uint32_t)j));
+        f(pack_key(acc_score<FX>(acc[lane + 64u * (uint32_t)j], fx_E), gdoc0 + lane + 64u * (uint32_t)j));
       }
     });
     const uint32_t kept = topk_keep_ge<kScanThreads, kCandCap>(s.cand, cnt0, thr, &s.sc);
     if (tid == 0) {
       s.cnt = kept;
-      if (thr > s.theta) s.theta = thr;
+      if (thr > s.theta) {
+        s.theta = thr;
+        s.thr = acc_threshold<FX>(thr, fx_E);
+      }
       atomicMax(theta_g, (unsigned long long)thr);  // LazyMaxScoreAccumulator.accumulate analogue
       s.prof[6] += 1;
     }
@@ -298,8 +349,8 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, boo
     bool want = (cmask >> j) & 1u;
     uint64_t key = 0;
     if (want) {
-      key = pack_key((float)acc[lane + 64u * (uint32_t)j], gdoc0 + lane + 64u * (uint32_t)j);
-      acc[lane + 64u * (uint32_t)j] = unmatched_value();
+      key = pack_key(acc_score<FX>(acc[lane + 64u * (uint32_t)j], fx_E), gdoc0 + lane + 64u * (uint32_t)j);
+      acc[lane + 64u * (uint32_t)j] = acc_marker<FX>();
       want = key >= thr;
     }
     topk_append(s.cand, &s.cnt, want, key);
@@ -317,9 +368,10 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, double* acc, boo
 // register demand of the whole kernel.  The LDS pointer keeps its address space across the call.
 typedef __attribute__((address_space(3))) ScanSmem* lds_smem_ptr;
 __device__ __noinline__ void rendezvous_call(lds_smem_ptr sp, uint32_t wave, bool parked, uint32_t gdoc0, uint32_t k,
-                                             unsigned long long* theta_g) {
+                                             bool fixed, int fx_E, unsigned long long* theta_g) {
   ScanSmem& s = *(ScanSmem*)sp;
-  rendezvous_compact(s, &s.acc[wave][0], parked, gdoc0, k, theta_g);
+  if (fixed) rendezvous_compact<true>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g);
+  else rendezvous_compact<false>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g);
 }
 
 // Reserve room for the wave's `mine`-per-lane candidates in the shared buffer: one DPP scan and ONE
@@ -343,44 +395,45 @@ __device__ __forceinline__ uint32_t reserve_candidates(ScanSmem& s, uint32_t lan
   return wbase + incl - mine;
 }
 
-// Sparse collect of one pair's swapped-out slot values a[j] (the "unmatched" marker where this
-// posting is not its doc's collector): count the hits, send the competitive docs to the shared
-// candidate buffer.  Returns true when they did not fit and were parked back into the sub-tile.
-template <int ABL>
-__device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, uint32_t lane, const double (&a)[8],
-                                                const uint32_t (&off)[8], long long thr_bits, uint64_t theta,
+// Sparse collect of one pair's swapped-out slot values a[j] (the marker where this posting is not its
+// doc's collector): count the hits, send the competitive docs to the shared candidate buffer.
+// Returns true when they did not fit and were parked back into the sub-tile.
+template <bool FX, int ABL>
+__device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, uint32_t lane, const uint64_t (&a)[8],
+                                                const uint32_t (&off)[8], uint64_t thr, uint64_t theta, int fx_E,
                                                 uint32_t gdoc0, uint32_t& wave_hits) {
   unsigned long long any_maybe = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(dbl_bits(a[j]) != kUnmatched));
-    any_maybe |= __builtin_amdgcn_ballot_w64(__double_as_longlong(a[j]) >= thr_bits);
+    wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(a[j] != acc_marker<FX>()));
+    any_maybe |= __builtin_amdgcn_ballot_w64(acc_reaches<FX>(a[j], thr));
   }
-  if (any_maybe == 0ull) return false;  // wave-uniform; the steady state once theta has converged
+  if (any_maybe == 0ull || ABL == 6) return false;  // wave-uniform; the steady state once theta has converged
   if (ABL == 7 && threadIdx.x == 0) s.prof[13] += 1;
   uint32_t cmask = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if (__double_as_longlong(a[j]) >= thr_bits && pack_key((float)a[j], gdoc0 + ((off[j] - acc_addr) >> 3)) > theta) cmask |= 1u << j;
+    if (acc_reaches<FX>(a[j], thr) && pack_key(acc_score<FX>(a[j], fx_E), gdoc0 + ((off[j] - acc_addr) >> 3)) > theta) cmask |= 1u << j;
   if (!__any(cmask != 0)) return false;
   if (ABL == 7 && threadIdx.x == 0) s.prof[12] += 1;
   uint32_t pos = reserve_candidates(s, lane, (uint32_t)__popc(cmask));
   if (pos < (uint32_t)kCandCap) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if ((cmask >> j) & 1u) s.cand[pos++] = pack_key((float)a[j], gdoc0 + ((off[j] - acc_addr) >> 3));
+      if ((cmask >> j) & 1u) s.cand[pos++] = pack_key(acc_score<FX>(a[j], fx_E), gdoc0 + ((off[j] - acc_addr) >> 3));
     return false;
   }
   // back into my sub-tile: the rendezvous that follows this iteration takes them from there
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if ((cmask >> j) & 1u) *(double*)lds_ptr(off[j]) = a[j];
+    if ((cmask >> j) & 1u) *(uint64_t*)lds_ptr(off[j]) = a[j];
   return true;
 }
 
-// PIPE = true: the first posting pair per lane of the wave's next sub-tile is loaded before the
-// current one is collected.  ABL == 7: instrumented variant (event counters per item).
-template <bool PIPE, int ABL>
+// FX: accumulator representation (see above).  PIPE = true: the first posting pair per lane of the
+// wave's next sub-tile is loaded before the current one is collected.  ABL: 7 = instrumented variant
+// (event counters per item), 1-4 = timing ablations (wrong results).
+template <bool FX, bool PIPE, int ABL>
 __global__ __launch_bounds__(kScanThreads, kScanWaves / 4)
 void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts,
                       const DTerm* __restrict__ terms, const DQuery* __restrict__ queries,
@@ -390,24 +443,26 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   __shared__ ScanSmem s;
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  double* const acc = &s.acc[wave][0];
+  uint64_t* const acc = &s.acc[wave][0];
   const uint32_t acc_addr = lds_addr(acc), dummy_addr = lds_addr(&s.dummy[lane]);
   const DItem item = items[blockIdx.x];
   const DQuery q = queries[item.query];
   const uint32_t k = q.k;
+  const int fx_E = item.fx_E;
   unsigned long long* const my_theta_g = theta_g + item.query;
   const bool multi_item = q.n_items > 1;  // uniform: only then is there anybody to share theta with
 
   uint64_t t_start = 0, t_walk = 0;
   if (ABL == 7) t_start = __builtin_readcyclecounter();
   // ---- item prologue: clear the sub-tiles, stage the normInverse tables, build the score tables
-  for (int j = 0; j < kSlots; ++j) acc[lane + 64u * (uint32_t)j] = unmatched_value();
+  for (int j = 0; j < kSlots; ++j) acc[lane + 64u * (uint32_t)j] = acc_marker<FX>();
   {
     const uint32_t n_lds = min(item.n_caches, (uint32_t)kLdsCaches) * 256u;
     for (uint32_t i = tid; i < n_lds; i += kScanThreads) (&s.cache[0][0])[i] = caches[item.cache_off + i];
   }
   if (tid == 0) {
     s.theta = 0;
+    s.thr = acc_threshold<FX>(0, fx_E);
     s.cnt = 0;
     s.tile_cand = 0;
     s.hits = 0;
@@ -417,13 +472,14 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     for (int i = 0; i < 16; ++i) s.prof[i] = 0;
     s.prof[15] = ~0ull;
   }
-  if (tid < 64) s.dummy[tid] = unmatched_value();
+  if (tid < 64) s.dummy[tid] = acc_marker<FX>();
   __syncthreads();
   for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
     const float w = items[blockIdx.x].tab_weight[slot];  // (indexing the register copy would spill it)
+    const int scale = items[blockIdx.x].tab_scale[slot];
     const float* cache = &s.cache[items[blockIdx.x].tab_cache[slot]][0];
-    for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kScanThreads)
-      s.tab[slot][e] = bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]);  // row 0 (freq 0) never read
+    for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kScanThreads)  // row 0 (freq 0) never read
+      s.tab[slot][e] = score_value<FX>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
   }
   __syncthreads();  // tables complete; from here on the waves run on their own
   if (ABL == 7) {
@@ -467,7 +523,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     const uint32_t my_delta16 = (uint32_t)(((uint64_t)mt.fnorm - (uint64_t)mt.docids) >> 4);  // same allocation
     const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
     const uint32_t my_shift = mt.shift;
-    const uint32_t my_flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | ((mt.shift != 0 ? 1u : 0u) << 3);
+    const uint32_t my_flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | ((mt.shift != 0 ? 1u : 0u) << 3) |
+                              ((FX ? mt.fx_shift : 0u) << 4);
     const bool has_term = lane < n_terms;
 
     const uint32_t last_tile = part.tile_end - 1u;
@@ -504,25 +561,28 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       const bool second = kTwoGroups && cur_groups > 64u;  // the sub-tile has a second instruction's worth of pairs
       const bool act = lane < cur_groups, act2 = second && 64u + lane < cur_groups;
       uint32_t off[8], off2[8];
-      float sc[8], sc2[8];
+      uint32_t val[8], val2[8];
+      uint32_t sh = 0, sh2 = 0;
       if (cur_groups != 0) {
         if (sparse) {
           if (second) {
             Group a;
             group_locate_load(s, wave, n_terms, 64u + lane, cur_groups, pre, a);
-            group_prepare<ABL>(s, a, 64u + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, sc2);
+            group_prepare<FX, ABL>(s, a, 64u + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
+            sh2 = a.meta >> 28;
             if (ABL == 7 && tid == 0) s.prof[10] += 1;
           }
         } else {
           for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // dense sub-tile: pairs beyond the first 64 (wave-uniform trip count)
             Group a;
             group_locate_load(s, wave, n_terms, vb + lane, cur_groups, pre, a);
-            group_prepare<ABL>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, sc2);
-            if (vb + lane < cur_groups) group_commit_add(off2, sc2);
+            group_prepare<FX, ABL>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
+            if (vb + lane < cur_groups) group_commit_add<FX>(off2, val2, a.meta >> 28);
             if (ABL == 7 && tid == 0) s.prof[10] += 1;
           }
         }
-        group_prepare<ABL>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, sc);
+        group_prepare<FX, ABL>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, val);
+        sh = pf.meta >> 28;
         if (ABL == 7 && tid == 0) s.prof[8] += 1;
       }
 
@@ -538,27 +598,25 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       theta_other = theta_other_next;
       if (multi_item) theta_other_next = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-      // ---- (3) fp64 LDS accumulate; sparse sub-tiles: then each posting swaps the "unmatched" marker into
-      //      its doc's slot.  LDS executes a wave's operations in order, so the first posting of a doc to
-      //      do so receives the doc's complete score and is its collector; the others (and invalid
+      // ---- (3) LDS accumulate; sparse sub-tiles: then each posting swaps the "unmatched" marker into its
+      //      doc's slot.  LDS executes a wave's operations in order, so the first posting of a doc to do
+      //      so receives the doc's complete score and is its collector; the others (and invalid
       //      postings, on the dummy slot) receive the marker.  No sweep.  Idle lanes stay out of the
       //      LDS pipe; every add of the sub-tile precedes every swap.
-      double a[8], a2[8];
+      uint64_t a[8], a2[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = a2[j] = unmatched_value();
+      for (int j = 0; j < 8; ++j) a[j] = a2[j] = acc_marker<FX>();
       if (cur_groups != 0) {
-        if (act && ABL != 2 && ABL != 4) group_commit_add(off, sc);
+        if (act && ABL != 2 && ABL != 4) group_commit_add<FX>(off, val, sh);
         if (sparse && ABL != 2 && ABL != 3) {
-          if (act2) group_commit_add(off2, sc2);
+          if (act2) group_commit_add<FX>(off2, val2, sh2);
           if (act) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              a[j] = __longlong_as_double((long long)atomicExch((unsigned long long*)lds_ptr(off[j]), (unsigned long long)kUnmatched));
+            for (int j = 0; j < 8; ++j) a[j] = atomicExch((unsigned long long*)lds_ptr(off[j]), (unsigned long long)acc_marker<FX>());
           }
           if (act2) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              a2[j] = __longlong_as_double((long long)atomicExch((unsigned long long*)lds_ptr(off2[j]), (unsigned long long)kUnmatched));
+            for (int j = 0; j < 8; ++j) a2[j] = atomicExch((unsigned long long*)lds_ptr(off2[j]), (unsigned long long)acc_marker<FX>());
           }
         }
       }
@@ -570,15 +628,12 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       if (cur_groups != 0) {
         const uint64_t theta_l = s.theta;
         const uint64_t theta = theta_other > theta_l ? theta_other : theta_l;
-        // "fp32 score could reach theta's score" as ONE signed 64-bit compare on the fp64 bits:
-        // non-negative doubles order like their bit patterns, the "unmatched" pattern (-0.0) is
-        // INT64_MIN, and half a float ulp below theta's score is a conservative cut
-        const long long thr_bits = __double_as_longlong((double)key_score(theta_l)) - (1ll << 28);
+        const uint64_t thr = s.thr;  // acc_threshold(theta_l), kept next to theta by the rendezvous
         if (sparse) {
           // ---- (4s) collect through the postings
           if (ABL == 7 && tid == 0) s.prof[9] += 1;
-          parked = collect_swapped<ABL>(s, acc_addr, lane, a, off, thr_bits, theta, gdoc0, wave_hits);
-          if (second) parked |= collect_swapped<ABL>(s, acc_addr, lane, a2, off2, thr_bits, theta, gdoc0, wave_hits);
+          parked = collect_swapped<FX, ABL>(s, acc_addr, lane, a, off, thr, theta, fx_E, gdoc0, wave_hits);
+          if (second) parked |= collect_swapped<FX, ABL>(s, acc_addr, lane, a2, off2, thr, theta, fx_E, gdoc0, wave_hits);
         } else {
           // ---- (4d) dense sweep of my sub-tile: count hits, reset every slot that cannot be competitive.
           //      A slot whose fp32 score reaches theta's score stays in place (mmask) for the exact path.
@@ -588,17 +643,17 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
           if (simple) {
 #pragma unroll
             for (int h = 0; h < kSlots / 4; ++h) {
-              double a[4];
+              uint64_t v[4];
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) a[jj] = acc[lane + 64u * (uint32_t)(h * 4 + jj)];
+              for (int jj = 0; jj < 4; ++jj) v[jj] = acc[lane + 64u * (uint32_t)(h * 4 + jj)];
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
                 const int j = h * 4 + jj;
-                const bool matched = dbl_bits(a[jj]) != kUnmatched;
+                const bool matched = v[jj] != acc_marker<FX>();
                 wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(matched));
-                const bool maybe = __double_as_longlong(a[jj]) >= thr_bits;  // implies matched
+                const bool maybe = acc_reaches<FX>(v[jj], thr);  // implies matched
                 any_maybe |= __builtin_amdgcn_ballot_w64(maybe);
-                if (matched & !maybe) acc[lane + 64u * (uint32_t)j] = unmatched_value();
+                if (matched & !maybe) acc[lane + 64u * (uint32_t)j] = acc_marker<FX>();
               }
             }
           } else {
@@ -607,11 +662,11 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
           if (any_maybe != 0ull) {  // wave-uniform: which of my slots were left in place? (one batched re-read)
             if (ABL == 7 && tid == 0) s.prof[13] += 1;
             if (simple) {
-              double a[kSlots];
+              uint64_t v[kSlots];
 #pragma unroll
-              for (int j = 0; j < kSlots; ++j) a[j] = acc[lane + 64u * (uint32_t)j];
+              for (int j = 0; j < kSlots; ++j) v[j] = acc[lane + 64u * (uint32_t)j];
 #pragma unroll
-              for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(dbl_bits(a[j]) != kUnmatched) << j;
+              for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(v[j] != acc_marker<FX>()) << j;
             } else {
               mmask = (1u << kSlots) - 1u;
             }
@@ -622,21 +677,21 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
               const int j = __ffs((int)mmask) - 1;
               mmask &= mmask - 1u;
               const uint32_t i = lane + 64u * (uint32_t)j;
-              const double a = acc[i];
-              if (dbl_bits(a) != kUnmatched) {
+              const uint64_t v = acc[i];
+              if (v != acc_marker<FX>()) {
                 const uint32_t doc = base + i;
                 bool live = true;
                 if (!simple && live_bits) live = (live_bits[doc >> 6] >> (doc & 63u)) & 1ull;
                 bool cand = false;
                 if (live) {
                   if (!simple) ++my_hits;  // totalHits counts every collected doc, also those skipped by `after`
-                  const float sc = (float)a;
+                  const float sc = acc_score<FX>(v, fx_E);
                   const uint32_t gdoc = gdoc0 + i;
                   const bool skip = q.has_after && (sc > q.after_score || (sc == q.after_score && (int32_t)gdoc <= q.after_doc));
                   if (!skip) cand = pack_key(sc, gdoc) > theta;
                 }
                 if (cand) cmask |= 1u << j;
-                else acc[i] = unmatched_value();
+                else acc[i] = acc_marker<FX>();
               }
             }
           }
@@ -648,8 +703,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
                 const int j = __ffs((int)cmask) - 1;
                 cmask &= cmask - 1u;
                 const uint32_t i = lane + 64u * (uint32_t)j;
-                s.cand[pos++] = pack_key((float)acc[i], gdoc0 + i);
-                acc[i] = unmatched_value();
+                s.cand[pos++] = pack_key(acc_score<FX>(acc[i], fx_E), gdoc0 + i);
+                acc[i] = acc_marker<FX>();
               }
             } else {
               parked = true;
@@ -684,7 +739,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   __syncthreads();  // R1: all waves -- interrupted ones and finished ones
   if (ABL == 7 && tid == 0) s.prof[1] += __builtin_readcyclecounter() - t_r0;  // wave 0 waiting for the others
   if (!__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // nobody asked: everybody is finished
-  rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, my_theta_g);  // ends with barriers: the flag is re-read safely
+  rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, FX, fx_E, my_theta_g);  // ends with barriers: the flag is re-read safely
   parked = false;
   if (ABL == 7 && tid == 0) {
     s.prof[5] += 1;
@@ -828,23 +883,30 @@ void fold_norms_kernel(const uint32_t* __restrict__ docids, const uint32_t* __re
 }
 
 // ---- launchers (called from runtime.cpp) ---------------------------------------------------------
-void launch_bm25_scan(hipStream_t stream, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
+void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride,
                       uint64_t* item_prof) {
   if (n_items == 0) return;
-#define NRT_LAUNCH(P, A)                                                                                     \
-  hipLaunchKernelGGL((bm25_scan_kernel<P, A>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
+#define NRT_LAUNCH(F, P, A)                                                                                  \
+  hipLaunchKernelGGL((bm25_scan_kernel<F, P, A>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
                      caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof)
-  if (!pipelined) { NRT_LAUNCH(false, 0); return; }
+#define NRT_LAUNCH_FX(P, A)            \
+  do {                                 \
+    if (fixed_point) NRT_LAUNCH(true, P, A); \
+    else NRT_LAUNCH(false, P, A);      \
+  } while (0)
+  if (!pipelined) { NRT_LAUNCH_FX(false, 0); return; }
   switch (ablation) {
-    case 1: NRT_LAUNCH(true, 1); break;  // 1-4: timing ablations (wrong results), see the kernel
-    case 2: NRT_LAUNCH(true, 2); break;
-    case 3: NRT_LAUNCH(true, 3); break;
-    case 4: NRT_LAUNCH(true, 4); break;
-    case 7: NRT_LAUNCH(true, 7); break;
-    default: NRT_LAUNCH(true, 0); break;
+    case 1: NRT_LAUNCH(false, true, 1); break;  // 1-4: timing ablations of the fp64 kernel (wrong results)
+    case 2: NRT_LAUNCH(false, true, 2); break;
+    case 3: NRT_LAUNCH(false, true, 3); break;
+    case 4: NRT_LAUNCH(false, true, 4); break;
+    case 6: NRT_LAUNCH(false, true, 6); break;  // no candidate handling in sparse sub-tiles
+    case 7: NRT_LAUNCH_FX(true, 7); break;
+    default: NRT_LAUNCH_FX(true, 0); break;
   }
+#undef NRT_LAUNCH_FX
 #undef NRT_LAUNCH
 }
 

@@ -47,6 +47,8 @@ struct alignas(16) DTerm {
   uint32_t cache_off;        // offset in floats of the term's 256-entry normInverse table
   uint32_t cache_slot;       // per-query normInverse table index (< kLdsCaches)
   uint32_t tab_slot;         // score table of this term in the item's LDS (< kTabTerms) or 0xFFFFFFFF
+  int32_t  fx_scale;         // fixed-point batches: the term's scores are integers < 2^32 after * 2^fx_scale ...
+  uint32_t fx_shift;         // ... and enter the query's common scale 2^-fx_E shifted left by fx_shift
 };
 static_assert(sizeof(DTerm) == 64, "DTerm layout");
 
@@ -75,8 +77,11 @@ struct alignas(16) DItem {
   uint32_t n_tabs;            // score tables to build (<= kTabTerms)
   float    tab_weight[kTabTerms];
   uint32_t tab_cache[kTabTerms];  // normInverse table of each score table
+  int32_t  tab_scale[kTabTerms];  // fixed-point batches: fx_scale of each score table's term
+  int32_t  fx_E;                  // fixed-point batches: accumulators hold score * 2^fx_E
+  uint32_t pad0, pad1;
 };
-static_assert(sizeof(DItem) == 64, "DItem layout");
+static_assert(sizeof(DItem) == 96, "DItem layout");
 
 struct alignas(16) DQuery {
   uint32_t k;

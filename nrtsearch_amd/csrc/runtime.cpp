@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <climits>
+#include <cmath>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -25,7 +27,7 @@
 #include "plan.h"
 
 namespace nrtgpu {
-void launch_bm25_scan(hipStream_t stream, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
+void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride,
                       uint64_t* item_prof);
@@ -178,6 +180,7 @@ struct FlatDict {
 
 struct FieldData {
   uint8_t* d_norms = nullptr;    // nullptr => norms omitted
+  uint32_t max_norm = 1;         // largest norm byte of the field in this segment (longest doc); 1 when omitted
   std::unordered_map<int64_t, TermEntry> dict;   // build-time (duplicate detection); searches use `flat`
   FlatDict flat;
   std::vector<TermGroup> groups;
@@ -358,6 +361,9 @@ extern "C" int nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id,
   if (int rc = dev_alloc(seg, &p, (size_t)seg->max_doc + 64)) return rc;
   f.d_norms = (uint8_t*)p;
   HIP_TRY(hipMemcpy(f.d_norms, norm_bytes, (size_t)seg->max_doc, hipMemcpyHostToDevice));
+  uint32_t mx = 0;
+  for (int32_t d = 0; d < seg->max_doc; ++d) mx = std::max<uint32_t>(mx, norm_bytes[d]);
+  f.max_norm = mx;
   return NRTGPU_OK;
 }
 
@@ -569,6 +575,7 @@ struct HostPlan {
   std::vector<uint32_t> q_base, q_nlists, q_k;
   uint32_t k_stride = 0;
   int64_t postings = 0;             // postings in the scanned term ranges (algorithmic work)
+  bool fixed_point = false;         // every query of the batch passed the fixed-point range analysis
 };
 
 static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
@@ -596,7 +603,21 @@ static int validate_query(const nrtgpu_bm25_query& q, int qi) {
 static const int64_t kTileCostPostings = 48;
 
 struct QS { uint32_t term_begin, n_terms; int32_t seg; int64_t postings; };
-struct QTabs { uint32_t n; float weight[kTabTerms]; uint32_t cache[kTabTerms]; };
+struct QTabs { uint32_t n; float weight[kTabTerms]; uint32_t cache[kTabTerms]; int32_t scale[kTabTerms]; int32_t fx_E; };
+static const int32_t kNoFixed = INT32_MIN;  // QTabs.fx_E: the query needs the fp64 accumulators
+
+// Fixed-point eligibility of one query term: every score the term can produce in these
+// segments must be a positive integer below 2^32 after scaling by 2^E_t.  Scores grow with freq and
+// shrink with the norm byte, so the smallest one is score(1, largest norm byte present) and the
+// weight bounds them from above.  Returns false when the range does not fit.
+static bool fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale) {
+  const float s_min = nrtgpu::hostmath::bm25_score(weight, 1.0f, cache256[max_norm & 255u]);
+  if (!(s_min > 0.0f) || !std::isnormal(s_min) || !std::isnormal(weight)) return false;
+  const int e_min = std::ilogb(s_min), e_w = std::ilogb(weight);
+  if (e_w - e_min > 7) return false;  // 24 mantissa bits + 8 binades of range fill the 32-bit table entry
+  *scale = 23 - e_min;
+  return *scale > -64 && *scale < 64;
+}
 struct PlanPiece {
   std::vector<DTerm> terms;
   std::vector<float> caches;
@@ -610,7 +631,7 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
                             int q_end, PlanPiece& pc, std::vector<std::vector<QS>>& per_query,
                             std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs) {
   std::vector<int64_t> term_total;
-  std::vector<int32_t> tab_of_term;
+  std::vector<int32_t> tab_of_term, term_scale;
   std::vector<const TermEntry*> found;
   std::vector<const FieldData*> fld((size_t)n_segs, nullptr);
   std::vector<const FieldData*> found_field;
@@ -642,9 +663,27 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
         term_total[(size_t)t] += e->count;
       }
     }
+    // fixed-point analysis: per clause the scale of its scores, per query the common scale
+    term_scale.assign((size_t)q.n_terms, 0);
+    bool fx_ok = true;
+    int32_t fx_E = kNoFixed;
+    for (int t = 0; t < q.n_terms && fx_ok; ++t) {
+      if (term_total[(size_t)t] == 0) continue;  // matches nothing here
+      uint32_t max_norm = 0;
+      for (int si = 0; si < n_segs; ++si)
+        if (const FieldData* f = found_field[(size_t)t * n_segs + si]) max_norm = std::max(max_norm, f->max_norm);
+      int32_t sc = 0;
+      fx_ok = fixed_scale_of_term(q.terms[t].weight, q.norm_cache + (size_t)q.terms[t].cache_slot * 256, max_norm, &sc);
+      term_scale[(size_t)t] = sc;
+      if (fx_ok) fx_E = std::max(fx_E, sc);
+    }
+    for (int t = 0; t < q.n_terms && fx_ok; ++t)  // 32-bit entries shifted into the common scale, summed over
+      if (term_total[(size_t)t] != 0 && fx_E - term_scale[(size_t)t] > 15) fx_ok = false;  // <= 32 clauses: < 2^53
+    if (!fx_ok) fx_E = kNoFixed;
     tab_of_term.assign((size_t)q.n_terms, -1);
     QTabs& qt_ = qtabs[(size_t)qi];
     qt_.n = 0;
+    qt_.fx_E = fx_E;
     for (int r = 0; r < kTabTerms && r < q.n_terms; ++r) {
       int best = -1;
       for (int t = 0; t < q.n_terms; ++t)
@@ -653,6 +692,7 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
       tab_of_term[(size_t)best] = (int32_t)qt_.n;
       qt_.weight[qt_.n] = q.terms[best].weight;
       qt_.cache[qt_.n] = (uint32_t)q.terms[best].cache_slot;
+      qt_.scale[qt_.n] = term_scale[(size_t)best];
       qt_.n++;
     }
     per_query[(size_t)qi].reserve((size_t)n_segs);
@@ -677,6 +717,8 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
         d.cache_off = cache_base[(size_t)qi] + (uint32_t)qt.cache_slot * 256u;
         d.cache_slot = (uint32_t)qt.cache_slot;
         d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
+        d.fx_scale = term_scale[(size_t)t];
+        d.fx_shift = fx_ok ? (uint32_t)(fx_E - term_scale[(size_t)t]) : 0u;
         pc.terms.push_back(d);
         qs.n_terms++;
         qs.postings += e.count;
@@ -748,6 +790,9 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     total_cost += pc.cost;
   }
   hp.postings = total_postings;
+  hp.fixed_point = (ctx->cfg.flags & NRTGPU_FLAG_NO_FIXED_POINT) == 0;
+  for (int qi = 0; qi < n_queries && hp.fixed_point; ++qi)
+    if (!per_query[(size_t)qi].empty() && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
 
   // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
   // may span several segments (like a LeafSlice) and a large segment may be cut by tile range.
@@ -814,9 +859,11 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     it.n_caches = (uint32_t)queries[pend[i].query].n_caches;
     const QTabs& qt_ = qtabs[pend[i].query];
     it.n_tabs = qt_.n;
+    it.fx_E = qt_.fx_E;
     for (uint32_t r = 0; r < qt_.n; ++r) {
       it.tab_weight[r] = qt_.weight[r];
       it.tab_cache[r] = qt_.cache[r];
+      it.tab_scale[r] = qt_.scale[r];
     }
     hp.items[i] = it;
     lists[pend[i].query].push_back((uint32_t)i);
@@ -907,7 +954,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   HIP_TRY(hipMemsetAsync(wb + o_theta, 0, (size_t)n_queries * 8, st));
   const bool timing = ctx->cfg.collect_timing != 0;
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
-  launch_bm25_scan(st, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
+  launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
                    (unsigned long long*)(wb + o_theta), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
                    (uint64_t*)(wb + o_ihits), hp.k_stride, ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr);
@@ -939,6 +986,7 @@ static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_q
   ctx->stats.batches += 1;
   ctx->stats.queries += n_queries;
   ctx->stats.scan_launches += hp.items.empty() ? 0 : 1;
+  ctx->stats.fixed_point_launches += (!hp.items.empty() && hp.fixed_point) ? 1 : 0;
   ctx->stats.scan_ms += scan_ms;
   ctx->stats.merge_ms += merge_ms;
   ctx->stats.scan_postings += hp.postings;

@@ -237,6 +237,41 @@ def test_chunking_and_prefetch_invariance(mid, oracle):
         c2.close()
 
 
+def test_fixed_point_and_fp64_accumulators_agree(mid, oracle):
+    # the scan accumulates in exact fixed point when the host's range analysis allows it, else in fp64
+    # (like the reference's double sum); both must give the oracle's bits
+    cases = [([1, 5, 100, 5000], None), ([2, 3, 13, 40, 333], [1.0, 0.5, 3.0, 2.0, 1.5]), ([9999], None)]
+    for flags, want_fixed in [(0, True), (_lib.NRTGPU_FLAG_NO_FIXED_POINT, False)]:
+        c2 = api.GpuContext(0, 64, flags=flags)
+        leaves = [api.GpuSegment.from_data(c2, s) for s in mid.corpus.segments]
+        sr = api.GpuIndexSearcher(c2, leaves, api.IndexStatistics.from_corpus(mid.corpus))
+        for terms, boosts in cases:
+            exp = oracle.search_bm25(mid.corpus, terms, 1000, boosts=boosts)
+            got = sr.search(bq(terms, boosts), api.TopScoreDocCollectorManager(1000))
+            assert_same(f"acc_{flags}_{terms[0]}", got, exp, 1000, 1000)
+        st = c2.stats()
+        assert (st["fixed_point_launches"] == st["scan_launches"]) == want_fixed and st["scan_launches"] == len(cases)
+        for l in leaves:
+            l.release()
+        c2.close()
+
+
+def test_wide_score_range_falls_back_to_fp64(mid, oracle):
+    # boosts 2^20 apart: the term scores do not fit one fixed-point scale -> fp64 accumulators, same answer
+    terms, boosts = [1, 100, 5000], [1.0, 1048576.0, 3.0]
+    c2 = api.GpuContext(0, 64)
+    leaves = [api.GpuSegment.from_data(c2, s) for s in mid.corpus.segments]
+    sr = api.GpuIndexSearcher(c2, leaves, api.IndexStatistics.from_corpus(mid.corpus))
+    exp = oracle.search_bm25(mid.corpus, terms, 100, boosts=boosts, total_hits_threshold=INT_MAX)
+    got = sr.search(bq(terms, boosts), api.TopScoreDocCollectorManager(100, None, INT_MAX))
+    assert_same("wide_range", got, exp, 100, INT_MAX)
+    st = c2.stats()
+    assert st["scan_launches"] == 1 and st["fixed_point_launches"] == 0
+    for l in leaves:
+        l.release()
+    c2.close()
+
+
 def test_two_fields_parity_three_fields_fall_back(ctx, oracle):
     # two scored fields: both normInverse tables live in LDS; a third field is beyond the device
     # fast path (NRTGPU_ERR_UNSUPPORTED -> the caller runs Lucene)
