@@ -7,10 +7,11 @@
 //   /root/reference/src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-57.
 // Similarity -> score mapping: VectorFieldDef.java:77-88 / docs/field_types/vector.rst:26-35.
 //
-// knn_score_kernel: C[32 docs x 32 queries] tiles on the matrix cores with the exact-fp32 MFMA
-// (v_mfma_f32_32x32x2_f32: an fp32 fma chain, no reduced precision).  The query panel (<= 32
-// queries x dim) sits in LDS in MFMA-operand order; vector rows stream from HBM once per batch of
-// <= 32 queries (roofline: HBM, N * dim * 4 bytes per batch; MFMA-bound only above ~40 queries).
+// knn_score_kernel: C[16 docs x 16 queries] tiles on the matrix cores with the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: an fp32 fma chain, no reduced precision), two query panels.  The query
+// panel (<= 32 queries x dim) sits in LDS in MFMA-operand order; vector rows stream from HBM once per
+// batch of <= 32 queries (roofline: HBM, N * dim * 4 bytes per batch; the fp32 matrix rate equals the
+// HBM rate at 32 queries and is twice it at <= 16).
 // Float summation order differs from Lucene's (which itself depends on the JVM's SIMD width), so
 // scores carry a tolerance (tests: 1e-5 relative), docids/ranks are compared modulo that.
 #include <hip/hip_runtime.h>
@@ -24,8 +25,8 @@ namespace nrtgpu {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kKnnThreads = 512;  // 8 waves, each owns 32 docs per step
-constexpr int kKnnQ = 32;         // queries per launch (MFMA tile width)
+constexpr int kKnnThreads = 1024;  // 16 waves (one workgroup per CU: the query panel takes up to 160 KiB of LDS), each owns 32 docs per step
+constexpr int kKnnDepth = 8;       // 16-byte row chunks in flight per lane (HBM latency x bandwidth needs ~100 B per lane)
 
 // out[i] = sum_k v[i][k]^2 (fp32, sequential chunks) -- used by cosine.
 __global__ __launch_bounds__(256) void knn_row_norms_kernel(const float* __restrict__ vecs, int32_t dim, int64_t n,
@@ -58,10 +59,14 @@ __device__ __forceinline__ float knn_map_score(int sim, float dot, float nq, flo
 }
 
 // Scores docs [row_begin, row_end) of one segment against <= 32 queries; hits with key > theta[q]
-// are appended to query q's candidate list.  dim must be a multiple of 8.
+// are appended to query q's candidate list.  dim must be a multiple of 16.
 //   qpanel : n_q * dim floats (row-major), qnorm2 : n_q floats
 //   cand   : n_q lists of `cap` keys, cand_cnt : n_q counters (may exceed cap => overflow, host redoes)
-__global__ __launch_bounds__(kKnnThreads, 2)
+// Tiling: v_mfma_f32_16x16x4_f32, C[16 docs x 16 queries] per instruction, two query panels.  A operand:
+// lane l supplies row (l & 15), k = 4 * (l >> 4) .. +4 of a 16-float chunk, i.e. FOUR lanes read 64
+// contiguous bytes of one row per load instruction (the 32x32x2 shape would give 32: half a cache line
+// per request), kKnnDepth chunks in flight per lane.
+__global__ __launch_bounds__(kKnnThreads, 1)
 void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ vnorm2,
                       const int32_t* __restrict__ ord_to_doc, const uint64_t* __restrict__ live_bits,
                       int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
@@ -69,52 +74,99 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
                       float boost, const unsigned long long* __restrict__ theta, uint64_t* __restrict__ cand,
                       uint32_t* __restrict__ cand_cnt, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  f32x4* qs = (f32x4*)smem;  // [dim/8][2][32] float4: chunk c, half h, query n -> q[n][8c + 4h .. +4]
+  f32x4* qs = (f32x4*)smem;  // [dim/16][2][64] float4: chunk c, panel p, lane (j, kk) -> q[j + 16p][16c + 4kk .. +4]
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t n = lane & 31u, h = lane >> 5;
-  const int32_t chunks = dim >> 3;
-  for (int32_t i = (int32_t)tid; i < chunks * 64; i += kKnnThreads) {
-    const int32_t c = i >> 6, hh = (i >> 5) & 1, q = i & 31;
+  const uint32_t j = lane & 15u, kk = lane >> 4;
+  const int32_t chunks = dim >> 4;
+  for (int32_t i = (int32_t)tid; i < chunks * 128; i += kKnnThreads) {
+    const int32_t c = i >> 7, p = (i >> 6) & 1, l = i & 63;
+    const int32_t q = (l & 15) + 16 * p;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q < n_q) v = *(const f32x4*)(qpanel + (int64_t)q * dim + 8 * c + 4 * hh);
+    if (q < n_q) v = *(const f32x4*)(qpanel + (int64_t)q * dim + 16 * c + 4 * (l >> 4));
     qs[i] = v;
   }
   __syncthreads();
-  const float nq = (int32_t)n < n_q ? qnorm2[n] : 0.f;
-  const unsigned long long th = (int32_t)n < n_q ? theta[n] : ~0ull;
-
-  const int64_t rows_per_block = (int64_t)(kKnnThreads / 64) * 32;
-  for (int64_t r0 = row_begin + (int64_t)blockIdx.x * rows_per_block + (int64_t)wave * 32; r0 < row_end;
-       r0 += (int64_t)gridDim.x * rows_per_block) {
-    // A operand: lane (n, h) streams row r0 + n (clamped), floats 8c + 4h .. +4 per chunk
-    const int64_t row = min(r0 + (int64_t)n, row_end - 1);
-    const f32x4* vp = (const f32x4*)(vecs + row * dim) + h;
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x4 a_next = __builtin_nontemporal_load(vp);
-    for (int32_t c = 0; c < chunks; ++c) {
-      const f32x4 a = a_next;
-      if (c + 1 < chunks) a_next = __builtin_nontemporal_load(vp + 2 * (c + 1));
-      const f32x4 b = qs[c * 64 + (int32_t)lane];  // (h, n) == lane order
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
-    }
-    // D layout: col (query) = lane & 31, row (doc in tile) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if ((int32_t)n < n_q) {
+  const bool two_panels = n_q > 16;  // uniform
+  // D layout (per panel): query col = lane & 15 (+ 16p), doc row in tile = 4 * (lane >> 4) + reg
+  float nq[2], th_lo[2];
+  unsigned long long th[2];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int64_t drow = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * (int32_t)h;
-        if (drow < row_end) {
-          const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
-          bool live = true;
-          if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
-          if (live) {
-            const float sc = knn_map_score(sim, acc[reg], nq, vnorm2[drow], boost);
-            const uint64_t key = pack_key(sc, (uint32_t)(doc_base + ldoc));
-            if (key > th) {
-              const uint32_t pos = atomicAdd(&cand_cnt[n], 1u);
-              if (pos < cap) cand[(size_t)n * cap + pos] = key;
+  for (int p = 0; p < 2; ++p) {
+    const int32_t q = (int32_t)j + 16 * p;
+    nq[p] = q < n_q ? qnorm2[q] : 0.f;
+    th[p] = q < n_q ? theta[q] : ~0ull;
+    // cheap rejection before the exact (double) score mapping: a score more than 2^-16 relative below
+    // theta's cannot become competitive through the mapping's rounding
+    th_lo[p] = key_score(th[p]) * (1.0f - 1.0f / 65536.0f);
+  }
+
+  const int64_t rows_per_block = (int64_t)(kKnnThreads / 64) * 16;
+  for (int64_t r0 = row_begin + (int64_t)blockIdx.x * rows_per_block + (int64_t)wave * 16; r0 < row_end;
+       r0 += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t row = min(r0 + (int64_t)j, row_end - 1);  // clamped: loads are unconditional
+    const f32x4* vp = (const f32x4*)(vecs + row * dim) + kk;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 abuf[kKnnDepth];
+#pragma unroll
+    for (int i = 0; i < kKnnDepth; ++i) abuf[i] = vp[4 * min(i, chunks - 1)];
+    for (int32_t c0 = 0; c0 < chunks; c0 += kKnnDepth) {
+#pragma unroll
+      for (int i = 0; i < kKnnDepth; ++i) {
+        const int32_t c = c0 + i;
+        const f32x4 a = abuf[i];
+        abuf[i] = vp[4 * min(c + kKnnDepth, chunks - 1)];
+        if (c < chunks) {  // wave-uniform
+          const f32x4 b0 = qs[c * 128 + (int32_t)lane];
+          if (two_panels) {  // two independent accumulation chains, interleaved
+            const f32x4 b1 = qs[c * 128 + 64 + (int32_t)lane];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1[0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b1[2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b1[3], acc1, 0, 0, 0);
+          } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int32_t q = (int32_t)j + 16 * p;
+      if (q < n_q) {
+        const float inv_nq = nq[p] > 0.f ? 1.0f / sqrtf(nq[p]) : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int64_t drow = r0 + 4 * (int32_t)kk + reg;
+          if (drow < row_end) {
+            const float dot = p == 0 ? acc0[reg] : acc1[reg];
+            const float nv = vnorm2[drow];
+            // fp32 estimate of the score (monotone maps): only near-competitive docs take the exact path
+            float est;
+            if (sim == 0) est = fmaxf((1.0f + dot * inv_nq * (1.0f / sqrtf(nv))) * 0.5f, 0.0f);
+            else est = knn_map_score(sim, dot, nq[p], nv, 1.0f);
+            if (est * boost >= th_lo[p]) {
+              const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
+              bool live = true;
+              if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+              uint64_t key = 0;  // 0 = "nothing": never above a theta
+              if (live) key = pack_key(knn_map_score(sim, dot, nq[p], nv, boost), (uint32_t)(doc_base + ldoc));
+              if (th[p] == 0ull) {
+                // no theta yet (the query's first round, never longer than the list): every row is a
+                // candidate and owns slot (row - row_begin) -- no counter traffic at all
+                const uint64_t pos = (uint64_t)(drow - row_begin);
+                if (pos < cap) cand[(size_t)q * cap + pos] = key;
+                if (drow == row_end - 1) cand_cnt[q] = (uint32_t)min<int64_t>(row_end - row_begin, (int64_t)cap);
+              } else if (key > th[p]) {
+                const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
+                if (pos < cap) cand[(size_t)q * cap + pos] = key;
+              }
             }
           }
         }
@@ -227,7 +279,7 @@ void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_
   if (n == 0) return;
   hipLaunchKernelGGL(knn_row_norms_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, vecs, dim, n, norm2);
 }
-size_t knn_score_lds_bytes(int32_t dim) { return (size_t)(dim >> 3) * 64 * 16; }
+size_t knn_score_lds_bytes(int32_t dim) { return (size_t)(dim >> 4) * 128 * 16; }
 int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
                      const float* qpanel, const float* qnorm2, int32_t n_q, int32_t sim, float boost,

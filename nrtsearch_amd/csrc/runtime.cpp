@@ -1165,7 +1165,7 @@ extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || k <= 0 || dim <= 0 || sim < 0 || sim > 3) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
-  if (dim % 8 != 0 || dim > 1280) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 8, <= 1280)", dim);
+  if (dim % 16 != 0 || dim > 1280) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 1280)", dim);
   HIP_TRY(hipSetDevice(ctx->device));
   for (int si = 0; si < n_segs; ++si) {
     if (!segs[si] || !segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
@@ -1212,7 +1212,7 @@ extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
       int64_t r = 0, round = 1 << 16;
       while (r < f.n_vec) {
         const int64_t re = std::min<int64_t>(f.n_vec, r + std::min<int64_t>(round, kKnnCap));
-        const uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, 2 * (int64_t)std::max(ctx->n_cus, 1));
+        const uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
         const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, seg->d_live, dim, r, re,
                                        doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
                                        sim, boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
