@@ -908,8 +908,11 @@ struct DeviceRun {
 
 // Enqueue plan upload + scan + merge on the slot's stream.  Merge output goes to (ext_keys,
 // ext_counts, ext_hits) when given (device-resident variant), else into the slot's scratch.
+// `gpu` (unlocked on entry) is taken only once the plan has reached the device: the upload of this
+// batch overlaps the kernels of the batch another host thread has in flight.
 static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
-                          uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run) {
+                          uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
+                          std::unique_lock<std::mutex>& gpu) {
   const size_t n_items = hp.items.size();
   Carver pc;
   const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
@@ -952,6 +955,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   hipStream_t st = slot->stream;
   HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(wb + o_theta, 0, (size_t)n_queries * 8, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  gpu.lock();
   const bool timing = ctx->cfg.collect_timing != 0;
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
@@ -1041,13 +1046,15 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   if (int rc = slot->h_out.reserve(oc.off)) return rc;
   char* ho = (char*)slot->h_out.p;
   {
-    std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
-    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run)) return rc;
-    HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
-    HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
-    HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
-    HIP_TRY(hipStreamSynchronize(slot->stream));
+    std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
+    HIP_TRY(hipStreamSynchronize(slot->stream));  // kernels done: the next batch may have the device ...
   }
+  // ... while this one's results travel to the host
+  HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipStreamSynchronize(slot->stream));
   const uint64_t* keys = (const uint64_t*)(ho + o_k);
   const uint32_t* cnts = (const uint32_t*)(ho + o_c);
   const uint64_t* hits = (const uint64_t*)(ho + o_h);
@@ -1089,9 +1096,9 @@ extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
   DeviceRun run;
   {
-    std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+    std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
-                                (uint64_t*)d_hits, &run))
+                                (uint64_t*)d_hits, &run, gpu))
       return rc;
     HIP_TRY(hipStreamSynchronize(slot->stream));
   }
