@@ -223,3 +223,44 @@ def test_segment_search_matches_bruteforce(oracle):
     assert total == len(allhits) and not gte
     assert docs.tolist() == [d for _, d in allhits[:50]]
     assert scores.tolist() == [s for s, _ in allhits[:50]]
+
+
+# ---- tests/golden: the catalogue of the reference's golden values and the frozen oracle fixture ----------
+def _golden(name):
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)) as f:
+        return json.load(f)
+
+
+def test_reference_vector_catalogue(oracle):
+    g = _golden("reference_vectors.json")
+    v = g["bm25_scalar"][0]        # SearchStateTest.java:117
+    idf = oracle.bm25_idf(v["doc_count"], v["doc_freq"])
+    cache = oracle.bm25_norm_cache(oracle.bm25_avgdl(v["sum_total_term_freq"], v["doc_count"]))
+    s = oracle.bm25_score(idf, float(v["freq"]), cache[oracle.int_to_byte4(v["field_length"])])
+    assert abs(float(s) - v["expected_score"]) <= v["tolerance"] and s == f32(v["expected_score"])
+    v = g["bm25_scalar"][1]        # QueryTest.java:1003-1019
+    assert oracle.bm25_idf(2, 1) == f32(v["idf_n1"]) and oracle.bm25_idf(2, 2) == f32(v["idf_n2"])
+    cache = oracle.bm25_norm_cache(f32(v["avgdl"]))
+    w = f32(f32(v["idf_n1"]) + f32(v["idf_n2"]))
+    assert oracle.bm25_score(w, 1.0, cache[oracle.int_to_byte4(v["field_length"])]) == f32(v["expected_score"])
+    v = g["rescore"][0]            # QueryTest.java:398-441
+    assert oracle.rescore_combine(v["first"], True, v["second"], v["query_weight"], v["rescore_weight"]) == f32(v["expected"])
+    for length, byte, decoded in g["smallfloat"][0]["pairs_length_byte_decoded"]:
+        assert oracle.int_to_byte4(length) == byte and oracle.byte4_to_int(byte) == decoded
+    assert oracle.byte4_to_int(255) == g["smallfloat"][0]["byte4_to_int_255"]
+
+
+def test_oracle_matches_its_frozen_fixture(oracle):
+    from nrtsearch_amd import synth
+
+    g = _golden("oracle_small_corpus.json")
+    sp = g["spec"]
+    corpus = synth.build_corpus(sp["n_docs"], sp["ranks"], n_segments=sp["n_segments"],
+                                delete_fraction=sp["delete_fraction"], seed=sp["seed"])
+    for c in g["cases"]:
+        docs, scores, total, gte = oracle.search_bm25(corpus, c["terms"], c["k"], boosts=c.get("boosts"),
+                                                      total_hits_threshold=c["threshold"])
+        assert docs.tolist() == c["docs"] and scores.view(np.uint32).tolist() == c["score_bits"]
+        assert int(total) == c["total_hits"] and bool(gte) == c["relation_gte"]

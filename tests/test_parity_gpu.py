@@ -237,6 +237,24 @@ def test_chunking_and_prefetch_invariance(mid, oracle):
         c2.close()
 
 
+def test_frozen_oracle_fixture_through_the_device(ctx):
+    # tests/golden/oracle_small_corpus.json: file-based expectation (no live oracle involved)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_small_corpus.json")) as f:
+        g = json.load(f)
+    sp = g["spec"]
+    corpus = synth.build_corpus(sp["n_docs"], sp["ranks"], n_segments=sp["n_segments"],
+                                delete_fraction=sp["delete_fraction"], seed=sp["seed"])
+    ix = Index(ctx, corpus)
+    try:
+        for c in g["cases"]:
+            got = ix.searcher.search(bq(c["terms"], c.get("boosts")), api.TopScoreDocCollectorManager(c["k"], None, c["threshold"]))
+            assert got.docs.tolist() == c["docs"]
+            assert got.scores.view(np.uint32).tolist() == c["score_bits"]
+            assert got.total_hits == c["total_hits"] and got.relation_gte == c["relation_gte"]
+    finally:
+        ix.close()
+
+
 def test_fixed_point_and_fp64_accumulators_agree(mid, oracle):
     # the scan accumulates in exact fixed point when the host's range analysis allows it, else in fp64
     # (like the reference's double sum); both must give the oracle's bits
