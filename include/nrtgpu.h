@@ -126,6 +126,11 @@ typedef struct {
   int32_t after_doc;               /* global docid of the last hit of the previous page */
   float   after_score;
   int32_t min_should_match;        /* 0 or 1 only */
+  float   min_competitive_score;   /* Scorable.setMinCompetitiveScore across shards: a lower bound of the k-th best
+                                    * score of the WHOLE search this call is one shard of (other GPUs' results so
+                                    * far, LazyMaxScoreAccumulator).  Docs scoring strictly below it are counted in
+                                    * total_hits but not collected; 0 = none */
+  int32_t reserved;
 } nrtgpu_bm25_query;
 
 typedef struct {

@@ -50,7 +50,7 @@ class Bm25Query(C.Structure):
     _fields_ = [("n_terms", C.c_int32), ("terms", C.POINTER(Term)), ("n_caches", C.c_int32),
                 ("norm_cache", C.POINTER(C.c_float)), ("k", C.c_int32), ("total_hits_threshold", C.c_int32),
                 ("has_after", C.c_int32), ("after_doc", C.c_int32), ("after_score", C.c_float),
-                ("min_should_match", C.c_int32)]
+                ("min_should_match", C.c_int32), ("min_competitive_score", C.c_float), ("reserved", C.c_int32)]
 
 
 class TopDocs(C.Structure):

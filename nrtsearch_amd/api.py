@@ -70,6 +70,8 @@ class TopScoreDocCollectorManager:
     num_hits: int
     after: Optional[ScoreDoc] = None
     total_hits_threshold: int = TOTAL_HITS_THRESHOLD
+    # Scorable.setMinCompetitiveScore fed from outside this searcher (other shards of the same search)
+    min_competitive_score: float = 0.0
 
 
 @dataclasses.dataclass
@@ -311,6 +313,7 @@ class GpuIndexSearcher:
             q.after_doc = int(mgr.after.doc) if mgr.after is not None else 0
             q.after_score = float(mgr.after.score) if mgr.after is not None else 0.0
             q.min_should_match = int(msm)
+            q.min_competitive_score = float(mgr.min_competitive_score)
         return m
 
     def search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> List[TopDocs]:

@@ -461,8 +461,11 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     for (uint32_t i = tid; i < n_lds; i += kScanThreads) (&s.cache[0][0])[i] = caches[item.cache_off + i];
   }
   if (tid == 0) {
-    s.theta = 0;
-    s.thr = acc_threshold<FX>(0, fx_E);
+    // what is known about the query's k-th best hit before this item starts: the caller's
+    // min_competitive_score and whatever the query's other items have published since
+    const uint64_t theta0 = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s.theta = theta0;
+    s.thr = acc_threshold<FX>(theta0, fx_E);
     s.cnt = 0;
     s.tile_cand = 0;
     s.hits = 0;

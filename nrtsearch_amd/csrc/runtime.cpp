@@ -573,6 +573,7 @@ struct HostPlan {
   std::vector<float> caches;
   std::vector<uint32_t> list_idx;   // per query: item indices (merge input lists)
   std::vector<uint32_t> q_base, q_nlists, q_k;
+  std::vector<uint64_t> theta_init;  // per query: key below which nothing is collected (min_competitive_score)
   uint32_t k_stride = 0;
   int64_t postings = 0;             // postings in the scanned term ranges (algorithmic work)
   bool fixed_point = false;         // every query of the batch passed the fixed-point range analysis
@@ -595,6 +596,7 @@ static int validate_query(const nrtgpu_bm25_query& q, int qi) {
       return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: cache_slot out of range", qi, t);
     if (!(q.terms[t].weight >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: weight must be >= 0", qi, t);
   }
+  if (!(q.min_competitive_score >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: min_competitive_score must be >= 0", qi);
   return 0;
 }
 
@@ -749,6 +751,9 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
   hp.k_stride = round_up(kmax, 16);
   hp.queries.resize((size_t)n_queries);
   hp.q_k.resize((size_t)n_queries);
+  hp.theta_init.resize((size_t)n_queries);
+  for (int qi = 0; qi < n_queries; ++qi)  // lowest key with that score: a doc scoring exactly the bound still passes
+    hp.theta_init[(size_t)qi] = queries[qi].min_competitive_score > 0.0f ? pack_key(queries[qi].min_competitive_score, 0xFFFFFFFFu) : 0ull;
 
   // pass 1: resolve terms per (query, segment), densest term first; remember posting counts.
   // Queries are independent here, so the batch is cut into contiguous chunks resolved by
@@ -924,6 +929,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_qbase = pc.take(hp.q_base.size() * 4);
   const size_t o_qnl = pc.take(hp.q_nlists.size() * 4);
   const size_t o_qk = pc.take(hp.q_k.size() * 4);
+  const size_t o_theta = pc.take(hp.theta_init.size() * 8);  // uploaded with the plan, then updated by the kernel
   const size_t plan_bytes = pc.off;
   if (int rc = slot->h_plan.reserve(plan_bytes)) return rc;
   if (int rc = slot->d_plan.reserve(plan_bytes)) return rc;
@@ -937,9 +943,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_qbase, hp.q_base.data(), hp.q_base.size() * 4);
   memcpy(hb + o_qnl, hp.q_nlists.data(), hp.q_nlists.size() * 4);
   memcpy(hb + o_qk, hp.q_k.data(), hp.q_k.size() * 4);
+  memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
 
   Carver wc;
-  const size_t o_theta = wc.take((size_t)n_queries * 8);
   const size_t o_ikeys = wc.take(n_items * (size_t)hp.k_stride * 8);
   const size_t o_icnt = wc.take(n_items * 4);
   const size_t o_ihits = wc.take(n_items * 8);
@@ -954,14 +960,13 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
 
   hipStream_t st = slot->stream;
   HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(wb + o_theta, 0, (size_t)n_queries * 8, st));
   HIP_TRY(hipStreamSynchronize(st));
   gpu.lock();
   const bool timing = ctx->cfg.collect_timing != 0;
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
-                   (unsigned long long*)(wb + o_theta), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
+                   (unsigned long long*)(db + o_theta), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
                    (uint64_t*)(wb + o_ihits), hp.k_stride, ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
   uint64_t* okeys = ext_keys ? ext_keys : (uint64_t*)(wb + o_okeys);

@@ -255,6 +255,25 @@ def test_frozen_oracle_fixture_through_the_device(ctx):
         ix.close()
 
 
+def test_min_competitive_score_from_other_shards(mid, oracle):
+    # Scorable.setMinCompetitiveScore fed from outside (the k-th best score other shards already hold): docs
+    # scoring strictly below the bound are counted but not collected; everything at or above it is unchanged
+    terms = [1, 5, 100, 5000]
+    plain = mid.searcher.search(bq(terms), api.TopScoreDocCollectorManager(1000))
+    assert_same("mcs_plain", plain, oracle.search_bm25(mid.corpus, terms, 1000), 1000, 1000)
+    for rank in (10, 400, 999):
+        bound = float(plain.scores[rank])
+        got = mid.searcher.search(bq(terms), api.TopScoreDocCollectorManager(1000, None, 1000, bound))
+        keep = plain.scores >= np.float32(bound)
+        assert got.docs.tolist() == plain.docs[keep].tolist()
+        assert got.scores.view(np.uint32).tolist() == plain.scores[keep].view(np.uint32).tolist()
+        assert got.total_hits == plain.total_hits
+    none = mid.searcher.search(bq(terms), api.TopScoreDocCollectorManager(1000, None, 1000, float(plain.scores[0]) * 2))
+    assert len(none.docs) == 0 and none.total_hits == plain.total_hits
+    with pytest.raises(_lib.NrtGpuError):
+        mid.searcher.search(bq(terms), api.TopScoreDocCollectorManager(10, None, 1000, -1.0))
+
+
 def test_fixed_point_and_fp64_accumulators_agree(mid, oracle):
     # the scan accumulates in exact fixed point when the host's range analysis allows it, else in fp64
     # (like the reference's double sum); both must give the oracle's bits
