@@ -230,8 +230,8 @@ void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
 /* sums over all items since the last reset, instrumented kernel only (wave 0 of each workgroup;
  * cycles = shader clock): [0] prologue cycles, [1] cycles waiting at the rendezvous barrier,
  * [2] rendezvous cycles incl. that wait, [3] walk cycles, [4] epilogue cycles, [5] rendezvous,
- * [6] compactions, [7] sub-tiles, [8] sub-tiles with postings, [9] sparse (collected through the
- * postings), [10] extra pair instructions, [11] dense (swept), [12] sub-tiles with candidates,
+ * [6] compactions, [7] sub-tiles, [8] rendezvous: selection cycles, [9] sparse sub-tiles (collected
+ * through the postings), [10] rendezvous: keep cycles, [11] rendezvous: publish + append cycles, [12] sub-tiles with candidates,
  * [13] sub-tiles with a possibly competitive doc, [14] last wave's finish cycle, [15] first wave's */
 int  nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16);
 

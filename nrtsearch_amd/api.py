@@ -150,8 +150,8 @@ class GpuContext:
         _lib.check(_lib.load().nrtgpu_get_scan_profile(self._h, out.ctypes.data))
         # counters of wave 0 of every item, summed over the items since reset_stats (NRTGPU_FLAG_PROFILE)
         names = ["prologue_cycles", "rendezvous_wait_cycles", "rendezvous_cycles", "walk_cycles", "epilogue_cycles",
-                 "rendezvous", "compactions", "subtiles", "subtiles_with_postings", "sparse_subtiles", "extra_groups",
-                 "dense_subtiles", "candidate_subtiles", "maybe_subtiles", "last_wave_finish_cycles",
+                 "rendezvous", "compactions", "subtiles", "rz_select_cycles", "sparse_subtiles", "rz_keep_cycles",
+                 "rz_publish_append_cycles", "candidate_subtiles", "maybe_subtiles", "last_wave_finish_cycles",
                  "first_wave_finish_cycles"]
         return dict(zip(names, out.tolist()))
 

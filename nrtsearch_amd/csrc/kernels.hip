@@ -306,8 +306,10 @@ __device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const
 // consistent and nothing parked.
 template <bool FX>
 __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, bool parked, uint32_t gdoc0, uint32_t k,
-                                                   int fx_E, unsigned long long* theta_g) {
+                                                   int fx_E, unsigned long long* theta_g, bool prof) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  uint64_t t0 = 0, t1 = 0, t2 = 0;
+  if (prof) t0 = __builtin_readcyclecounter();
   uint32_t cmask = 0;
   if (parked) {  // wave-uniform
 #pragma unroll
@@ -329,7 +331,9 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
         f(pack_key(acc_score<FX>(acc[lane + 64u * (uint32_t)j], fx_E), gdoc0 + lane + 64u * (uint32_t)j));
       }
     });
+    if (prof) t1 = __builtin_readcyclecounter();
     const uint32_t kept = topk_keep_ge<kScanThreads, kCandCap>(s.cand, cnt0, thr, &s.sc);
+    if (prof) t2 = __builtin_readcyclecounter();
     if (tid == 0) {
       s.cnt = kept;
       if (thr > s.theta) {
@@ -359,6 +363,11 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
   if (tid == 0) {
     s.tile_cand = 0;
     s.rz_flag = 0;
+    if (prof) {  // instrumented runs: phases of the rendezvous replace three event counters
+      s.prof[8] += t1 - t0;                                // parked scan + k-th selection
+      s.prof[10] += t2 - t1;                               // keep the survivors
+      s.prof[11] += __builtin_readcyclecounter() - t2;     // publish, append parked, reset
+    }
   }
   __syncthreads();
 }
@@ -368,10 +377,10 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
 // register demand of the whole kernel.  The LDS pointer keeps its address space across the call.
 typedef __attribute__((address_space(3))) ScanSmem* lds_smem_ptr;
 __device__ __noinline__ void rendezvous_call(lds_smem_ptr sp, uint32_t wave, bool parked, uint32_t gdoc0, uint32_t k,
-                                             bool fixed, int fx_E, unsigned long long* theta_g) {
+                                             bool fixed, int fx_E, unsigned long long* theta_g, bool prof) {
   ScanSmem& s = *(ScanSmem*)sp;
-  if (fixed) rendezvous_compact<true>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g);
-  else rendezvous_compact<false>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g);
+  if (fixed) rendezvous_compact<true>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g, prof);
+  else rendezvous_compact<false>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g, prof);
 }
 
 // Reserve room for the wave's `mine`-per-lane candidates in the shared buffer: one DPP scan and ONE
@@ -573,7 +582,6 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
             group_locate_load(s, wave, n_terms, 64u + lane, cur_groups, pre, a);
             group_prepare<FX, ABL>(s, a, 64u + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
             sh2 = a.meta >> 28;
-            if (ABL == 7 && tid == 0) s.prof[10] += 1;
           }
         } else {
           for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // dense sub-tile: pairs beyond the first 64 (wave-uniform trip count)
@@ -581,12 +589,10 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
             group_locate_load(s, wave, n_terms, vb + lane, cur_groups, pre, a);
             group_prepare<FX, ABL>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
             if (vb + lane < cur_groups) group_commit_add<FX>(off2, val2, a.meta >> 28);
-            if (ABL == 7 && tid == 0) s.prof[10] += 1;
           }
         }
         group_prepare<FX, ABL>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, val);
         sh = pf.meta >> 28;
-        if (ABL == 7 && tid == 0) s.prof[8] += 1;
       }
 
       // ---- (2a) the next sub-tile's table (the column words in pf are consumed), the cells after it, theta
@@ -640,7 +646,6 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         } else {
           // ---- (4d) dense sweep of my sub-tile: count hits, reset every slot that cannot be competitive.
           //      A slot whose fp32 score reaches theta's score stays in place (mmask) for the exact path.
-          if (ABL == 7 && tid == 0) s.prof[11] += 1;
           uint32_t mmask = 0;
           unsigned long long any_maybe = 0;  // wave-uniform
           if (simple) {
@@ -742,7 +747,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   __syncthreads();  // R1: all waves -- interrupted ones and finished ones
   if (ABL == 7 && tid == 0) s.prof[1] += __builtin_readcyclecounter() - t_r0;  // wave 0 waiting for the others
   if (!__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // nobody asked: everybody is finished
-  rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, FX, fx_E, my_theta_g);  // ends with barriers: the flag is re-read safely
+  rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, FX, fx_E, my_theta_g, ABL == 7);  // ends with barriers: the flag is re-read safely
   parked = false;
   if (ABL == 7 && tid == 0) {
     s.prof[5] += 1;
