@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--no-prefetch", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=192, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N>1: do not share score bounds between the GPUs' shards (A/B; results are identical)")
+    ap.add_argument("--debug-same-gpu", action="store_true",
+                    help="debug: run an N-rank job with every rank on GPU 0 (gloo, collectives staged through the host)")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the multi-GPU path (device-resident top-k -> all-gather -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -85,10 +89,23 @@ def main():
     import torch  # first: its bundled HIP runtime must be the one libnrtgpu.so binds to
     import torch.distributed as dist
 
+    if args.debug_same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.debug_same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def all_gather(dst, src):
+        if args.debug_same_gpu:   # gloo: stage through the host
+            tmp = torch.empty(dst.shape, dtype=dst.dtype)
+            dist.all_gather_into_tensor(tmp, src.cpu())
+            dst.copy_(tmp)
+        else:
+            dist.all_gather_into_tensor(dst, src)
 
     import numpy as np
 
@@ -117,6 +134,18 @@ def main():
 
     k_stride = (w.k + 15) // 16 * 16
     use_dist = world > 1 or args.force_dist
+    exchange_name = None
+    if world > 1 and not args.no_exchange:
+        # cross-GPU bound exchange (include/nrtgpu.h): one shared-memory table per job, opened by every rank
+        import uuid
+        box = [f"/nrtgpu_bench_{uuid.uuid4().hex[:16]}" if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        exchange_name = box[0]
+        try:
+            ctx.exchange_open(exchange_name, world, rank)
+        except Exception as e:   # a rank without the table only misses the pruning; results do not depend on it
+            print(f"[rank {rank}] bound exchange unavailable: {e}", file=sys.stderr, flush=True)
+        dist.barrier()
     NB = 3  # device result buffers in flight between the scan threads and the exchange thread
     if use_dist:
         bufs = [(torch.zeros((B, k_stride), dtype=torch.int64, device="cuda"),
@@ -168,7 +197,8 @@ def main():
             free[b].acquire()          # the exchange thread has gathered this buffer's previous contents
             t_start[i] = time.perf_counter()
             keys, cnt, hits = bufs[b]
-            batches[(first + i) % len(batches)].run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())
+            batches[(first + i) % len(batches)].run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(),
+                                                           epoch=(first + i) if exchange_name else -1)
             return b
 
         with ThreadPoolExecutor(max_workers=max(1, args.host_threads)) as ex:  # FIFO: steps start in order
@@ -176,9 +206,9 @@ def main():
             for i in range(count):
                 b = futs[i].result()
                 keys, cnt, hits = bufs[b]
-                dist.all_gather_into_tensor(g_keys, keys) if world > 1 else g_keys.copy_(keys)
-                dist.all_gather_into_tensor(g_cnt, cnt) if world > 1 else g_cnt.copy_(cnt)
-                dist.all_gather_into_tensor(g_hits, hits) if world > 1 else g_hits.copy_(hits)
+                all_gather(g_keys, keys) if world > 1 else g_keys.copy_(keys)
+                all_gather(g_cnt, cnt) if world > 1 else g_cnt.copy_(cnt)
+                all_gather(g_hits, hits) if world > 1 else g_hits.copy_(hits)
                 torch.cuda.current_stream().synchronize()   # only this stream: the next scan keeps running
                 free[b].release()
                 merger.run(g_keys.data_ptr(), g_cnt.data_ptr(), g_hits.data_ptr())
@@ -201,7 +231,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.debug_same_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -243,6 +273,7 @@ def main():
             "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
             "segments_per_gpu": len(corpus.segments),
             "sharding": "contiguous docid ranges, 1 process per GPU" + (", RCCL all-gather of per-GPU top-k + merge" if use_dist else "")
+                        + (", score-bound exchange between shards" if exchange_name else "")
                         + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": st["scan_items"] / max(1, st["batches"]),
@@ -273,6 +304,10 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if exchange_name:
+            ctx.exchange_close()
+            if rank == 0 and os.path.exists("/dev/shm" + exchange_name):
+                os.unlink("/dev/shm" + exchange_name)
         dist.destroy_process_group()
 
 

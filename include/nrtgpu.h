@@ -158,6 +158,22 @@ int  nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, co
 int  nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                      int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                                      int32_t k_stride, void* d_keys, void* d_counts, void* d_hits);
+/* Cross-GPU bound exchange (the LazyMaxScoreAccumulator idea across processes, SURVEY 8e "optional cross-GPU
+ * theta sharing").  When one search is sharded over `world` GPUs, every shard alone would converge on the
+ * k-th best of ITS docs.  With an exchange open, each shard publishes a score that at least ceil(k / world)
+ * of its docs reach; once all shards have published, at least k docs of the search reach the smallest of
+ * them, so no shard needs to collect anything below it.  Results of the merged search are unchanged
+ * (tests/test_exchange_gpu.py); shards return fewer low-ranked hits.
+ * The table lives in POSIX shared memory `shm_name` (every rank passes the same name; rank 0 should
+ * unlink stale files first), mapped into each process's GPU.  Ranks must synchronise once between
+ * nrtgpu_exchange_open and their first search.  Batches are matched across ranks by `epoch` (same
+ * queries in the same order on every rank, epochs increasing; ranks may run up to 6 epochs apart). */
+int  nrtgpu_exchange_open(nrtgpu_ctx* ctx, const char* shm_name, int32_t world, int32_t rank);
+void nrtgpu_exchange_close(nrtgpu_ctx* ctx);
+int  nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                           int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                           int32_t k_stride, void* d_keys, void* d_counts, void* d_hits, int64_t epoch);
+
 /* TopDocs.merge of n_lists per-GPU results laid out as the all-gather leaves them:
  * d_keys_in[list][query][k_stride], d_counts_in[list][query], d_hits_in[list][query] (device).
  * Writes host-side topdocs (docs/scores/total_hits/relation) for each query. */

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "nrtgpu_segment_add_vectors", "nrtgpu_segment_seal", "nrtgpu_segment_set_live_docs",
     "nrtgpu_segment_release", "nrtgpu_segment_device_bytes",
     "nrtgpu_search_bm25", "nrtgpu_search_bm25_batch", "nrtgpu_search_bm25_batch_device",
+    "nrtgpu_search_bm25_batch_device_epoch", "nrtgpu_exchange_open", "nrtgpu_exchange_close",
     "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_rescore_vectors",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_get_stats", "nrtgpu_reset_stats",
@@ -103,6 +104,10 @@ def load() -> C.CDLL:
     L.nrtgpu_search_bm25.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), C.POINTER(TopDocs)]
     L.nrtgpu_search_bm25_batch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, C.POINTER(TopDocs)]
     L.nrtgpu_search_bm25_batch_device.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, vp, vp, vp]
+    L.nrtgpu_search_bm25_batch_device_epoch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, vp, vp, vp, i64]
+    L.nrtgpu_exchange_open.argtypes = [vp, C.c_char_p, i32, i32]
+    L.nrtgpu_exchange_close.argtypes = [vp]
+    L.nrtgpu_exchange_close.restype = None
     L.nrtgpu_merge_topk_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(TopDocs)]
     L.nrtgpu_knn_exact.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, f32, C.POINTER(TopDocs)]
     L.nrtgpu_rescore_vectors.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, f32, vp, vp, i32, C.c_double, C.c_double, i32,

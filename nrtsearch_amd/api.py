@@ -140,6 +140,13 @@ class GpuContext:
         self._h = h
         self.max_batch = max_batch
 
+    def exchange_open(self, shm_name: str, world: int, rank: int) -> None:
+        """Cross-GPU bound exchange (include/nrtgpu.h); synchronise the ranks once before the first search."""
+        _lib.check(_lib.load().nrtgpu_exchange_open(self._h, shm_name.encode(), int(world), int(rank)))
+
+    def exchange_close(self) -> None:
+        _lib.load().nrtgpu_exchange_close(self._h)
+
     def stats(self) -> dict:
         st = _lib.Stats()
         _lib.check(_lib.load().nrtgpu_get_stats(self._h, C.byref(st)))
@@ -409,12 +416,13 @@ class PreparedBatch:
         _lib.check(_lib.load().nrtgpu_search_bm25_batch(s.ctx._h, s._segs, s._bases, len(s.leaves),
                                                         self._m.queries, self.n, self._outs))
 
-    def run_device(self, k_stride: int, d_keys: int, d_counts: int, d_hits: int) -> None:
-        """Results stay in HBM (device pointers as ints) for the RCCL all-gather."""
+    def run_device(self, k_stride: int, d_keys: int, d_counts: int, d_hits: int, epoch: int = -1) -> None:
+        """Results stay in HBM (device pointers as ints) for the RCCL all-gather.  epoch >= 0: take part in
+        the context's cross-GPU bound exchange (GpuContext.exchange_open) as that batch number."""
         s = self.searcher
-        _lib.check(_lib.load().nrtgpu_search_bm25_batch_device(
+        _lib.check(_lib.load().nrtgpu_search_bm25_batch_device_epoch(
             s.ctx._h, s._segs, s._bases, len(s.leaves), self._m.queries, self.n, int(k_stride),
-            C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits)))
+            C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits), int(epoch)))
 
     def topdocs(self, qi: int) -> TopDocs:
         o = self._outs[qi]

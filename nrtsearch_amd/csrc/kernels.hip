@@ -299,6 +299,38 @@ __device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const
   }
 }
 
+// Quantile exchange between the items of one query (its slices on this GPU).  max(k-th best of each
+// item) -- what LazyMaxScoreAccumulator shares -- is a weak bound when a query is cut m ways: every
+// item converges on its own 1/m of the docs.  Instead each item publishes a score that at least
+// ceil(k / m) of ITS docs reach; once all m have published, at least k docs of the query reach the
+// smallest of them, so nothing below it can enter the merged top-k.  One wave: returns that bound as a
+// theta key (low word 0: a doc scoring exactly the bound still passes), or 0 while a peer is silent.
+__device__ __forceinline__ uint64_t peers_bound(const unsigned long long* peers, uint32_t n_peers, uint32_t lane) {
+  uint32_t inv = 0;  // max over peers of ~score word; an unpublished peer (0) saturates it
+  for (uint32_t j = lane; j < n_peers; j += 64u)
+    inv = max(inv, ~(uint32_t)(__hip_atomic_load(peers + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32));
+  inv = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32(inv), 63);
+  return inv == 0xFFFFFFFFu ? 0ull : (uint64_t)(~inv) << 32;
+}
+
+// The same between the shards of one search on different GPUs (plan.h: DExchange): this rank's entry is
+// refreshed with `local` (what its own items know together; any published value is a valid bound, so a
+// plain store suffices), then the smallest of all ranks' entries of this epoch is the search-wide bound.
+__device__ __forceinline__ uint64_t exchange_bound(const DExchange& x, uint32_t query, uint64_t local, uint32_t lane) {
+  if (local != 0ull && lane == 0)
+    __hip_atomic_store(x.slot + (size_t)x.rank * x.stride + query, ((unsigned long long)x.tag << 32) | (local >> 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint32_t inv = 0;
+  for (uint32_t r = lane; r < x.world; r += 64u) {
+    unsigned long long e = (r == x.rank) ? (((unsigned long long)x.tag << 32) | (local >> 32))
+                                         : __hip_atomic_load(x.slot + (size_t)r * x.stride + query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t hi = (uint32_t)(e >> 32) == x.tag ? (uint32_t)e : 0u;  // another epoch's entry: silent
+    inv = max(inv, ~hi);
+  }
+  inv = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32(inv), 63);
+  return inv == 0xFFFFFFFFu ? 0ull : (uint64_t)(~inv) << 32;
+}
+
 // Workgroup-wide rendezvous body: keep the k best of (candidate buffer UNION the candidates a wave
 // still has parked in its sub-tile), publish theta.  Every thread calls it.  A wave whose reservation
 // failed (`parked`) has reset every non-competitive slot of its sub-tile, so its parked candidates are
@@ -306,8 +338,12 @@ __device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const
 // consistent and nothing parked.
 template <bool FX>
 __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, bool parked, uint32_t gdoc0, uint32_t k,
-                                                   int fx_E, unsigned long long* theta_g, bool prof) {
+                                                   int fx_E, unsigned long long* theta_g, unsigned long long* peers,
+                                                   uint32_t n_peers, uint32_t my_peer, const DExchange* xch, uint32_t query,
+                                                   bool prof) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  // slices of the whole search: this query's items here times the shards on other GPUs
+  const uint32_t n_shares = n_peers * (xch ? xch->world : 1u);
   uint64_t t0 = 0, t1 = 0, t2 = 0;
   if (prof) t0 = __builtin_readcyclecounter();
   uint32_t cmask = 0;
@@ -330,7 +366,8 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
         m &= m - 1u;
         f(pack_key(acc_score<FX>(acc[lane + 64u * (uint32_t)j], fx_E), gdoc0 + lane + 64u * (uint32_t)j));
       }
-    });
+    }, n_shares > 1u ? (k + n_shares - 1u) / n_shares : 0u);
+    const uint32_t q2_hi = s.sc.q2_hi;  // (stable until the next selection)
     if (prof) t1 = __builtin_readcyclecounter();
     const uint32_t kept = topk_keep_ge<kScanThreads, kCandCap>(s.cand, cnt0, thr, &s.sc);
     if (prof) t2 = __builtin_readcyclecounter();
@@ -341,7 +378,16 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
         s.thr = acc_threshold<FX>(thr, fx_E);
       }
       atomicMax(theta_g, (unsigned long long)thr);  // LazyMaxScoreAccumulator.accumulate analogue
+      if (n_shares > 1u && q2_hi != 0u) atomicMax(peers + my_peer, ((unsigned long long)q2_hi << 32) | 1ull);
       s.prof[6] += 1;
+    }
+    if (n_shares > 1u && tid < 64u) {  // wave 0 (uniform inside it): what the search's slices know together
+      uint64_t pb = peers_bound(peers, n_peers, lane);  // this GPU's items (all of them must have published)
+      if (xch) pb = exchange_bound(*xch, query, pb, lane);
+      if (tid == 0 && pb > s.theta) {
+        s.theta = pb;
+        s.thr = acc_threshold<FX>(pb, fx_E);
+      }
     }
     __syncthreads();
   } else {
@@ -377,10 +423,11 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
 // register demand of the whole kernel.  The LDS pointer keeps its address space across the call.
 typedef __attribute__((address_space(3))) ScanSmem* lds_smem_ptr;
 __device__ __noinline__ void rendezvous_call(lds_smem_ptr sp, uint32_t wave, bool parked, uint32_t gdoc0, uint32_t k,
-                                             bool fixed, int fx_E, unsigned long long* theta_g, bool prof) {
+                                             bool fixed, int fx_E, unsigned long long* theta_g, unsigned long long* peers,
+                                             uint32_t n_peers, uint32_t my_peer, const DExchange* xch, uint32_t query, bool prof) {
   ScanSmem& s = *(ScanSmem*)sp;
-  if (fixed) rendezvous_compact<true>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g, prof);
-  else rendezvous_compact<false>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g, prof);
+  if (fixed) rendezvous_compact<true>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g, peers, n_peers, my_peer, xch, query, prof);
+  else rendezvous_compact<false>(s, &s.acc[wave][0], parked, gdoc0, k, fx_E, theta_g, peers, n_peers, my_peer, xch, query, prof);
 }
 
 // Reserve room for the wave's `mine`-per-lane candidates in the shared buffer: one DPP scan and ONE
@@ -447,6 +494,7 @@ __global__ __launch_bounds__(kScanThreads, kScanWaves / 4)
 void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts,
                       const DTerm* __restrict__ terms, const DQuery* __restrict__ queries,
                       const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
+                      unsigned long long* __restrict__ quant_g, const DExchange* __restrict__ xch,
                       uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
                       uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof) {
   __shared__ ScanSmem s;
@@ -485,6 +533,14 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     s.prof[15] = ~0ull;
   }
   if (tid < 64) s.dummy[tid] = acc_marker<FX>();
+  if ((multi_item || xch) && tid < 64u) {  // wave 0: what the search's other slices have published together so far
+    uint64_t pb = peers_bound(quant_g + q.item_begin, q.n_items, lane);
+    if (xch) pb = exchange_bound(*xch, item.query, pb, lane);
+    if (tid == 0 && pb > s.theta) {
+      s.theta = pb;
+      s.thr = acc_threshold<FX>(pb, fx_E);
+    }
+  }
   __syncthreads();
   for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
     const float w = items[blockIdx.x].tab_weight[slot];  // (indexing the register copy would spill it)
@@ -747,7 +803,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   __syncthreads();  // R1: all waves -- interrupted ones and finished ones
   if (ABL == 7 && tid == 0) s.prof[1] += __builtin_readcyclecounter() - t_r0;  // wave 0 waiting for the others
   if (!__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // nobody asked: everybody is finished
-  rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, FX, fx_E, my_theta_g, ABL == 7);  // ends with barriers: the flag is re-read safely
+  rendezvous_call((lds_smem_ptr)&s, wave, parked, gdoc0, k, FX, fx_E, my_theta_g, quant_g + q.item_begin, q.n_items,
+                  item.peer_slot - q.item_begin, xch, item.query, ABL == 7);  // ends with barriers: the flag is re-read safely
   parked = false;
   if (ABL == 7 && tid == 0) {
     s.prof[5] += 1;
@@ -893,12 +950,12 @@ void fold_norms_kernel(const uint32_t* __restrict__ docids, const uint32_t* __re
 // ---- launchers (called from runtime.cpp) ---------------------------------------------------------
 void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                      uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride,
-                      uint64_t* item_prof) {
+                      unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
+                      uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof) {
   if (n_items == 0) return;
 #define NRT_LAUNCH(F, P, A)                                                                                  \
   hipLaunchKernelGGL((bm25_scan_kernel<F, P, A>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
-                     caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof)
+                     caches, theta_g, quant_g, xch, item_keys, item_counts, item_hits, k_stride, item_prof)
 #define NRT_LAUNCH_FX(P, A)            \
   do {                                 \
     if (fixed_point) NRT_LAUNCH(true, P, A); \

@@ -79,7 +79,8 @@ struct alignas(16) DItem {
   uint32_t tab_cache[kTabTerms];  // normInverse table of each score table
   int32_t  tab_scale[kTabTerms];  // fixed-point batches: fx_scale of each score table's term
   int32_t  fx_E;                  // fixed-point batches: accumulators hold score * 2^fx_E
-  uint32_t pad0, pad1;
+  uint32_t peer_slot;             // this item's slot among the query's items [DQuery.item_begin, + n_items)
+  uint32_t pad1;
 };
 static_assert(sizeof(DItem) == 96, "DItem layout");
 
@@ -93,6 +94,17 @@ struct alignas(16) DQuery {
   uint32_t pad0, pad1;
 };
 static_assert(sizeof(DQuery) == 32, "DQuery layout");
+
+// Cross-GPU bound exchange of one batch (nrtgpu_exchange_open): entry (rank r, query q) of the batch's
+// slot holds (tag << 32) | score word that at least ceil(k / world) docs of rank r's shard reach.
+constexpr int kExchangeSlots = 8;
+struct alignas(16) DExchange {
+  unsigned long long* slot;  // this batch's [world][stride] entries (host-mapped, system scope)
+  uint32_t world, rank;
+  uint32_t stride;           // entries per rank (max_batch)
+  uint32_t tag;              // epoch tag, != 0
+};
+static_assert(sizeof(DExchange) == 32, "DExchange layout");
 
 // Packed hit: larger key == better hit under Lucene's HitQueue order (score desc, doc asc).
 // Scores are >= 0 (BM25 weights are non-negative) so float bits order like the floats.

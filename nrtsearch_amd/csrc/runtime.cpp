@@ -5,11 +5,15 @@
 // ("slots": stream + pinned staging + device scratch) and the result unpacking.
 // There is deliberately no CPU execution path here: without a gfx950 device nrtgpu_create fails.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <climits>
 #include <cmath>
 #include <chrono>
@@ -29,8 +33,8 @@
 namespace nrtgpu {
 void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                      uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride,
-                      uint64_t* item_prof);
+                      unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
+                      uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
@@ -227,6 +231,11 @@ struct nrtgpu_ctx {
   std::mutex stats_mu;
   nrtgpu_stats stats{};
   double prof[16] = {0};
+  // cross-GPU bound exchange (nrtgpu_exchange_open)
+  void* xch_host = nullptr;                 // mmap of the shared table
+  unsigned long long* xch_dev = nullptr;    // the same memory as the GPU sees it
+  size_t xch_bytes = 0;
+  int32_t xch_world = 0, xch_rank = 0;
 };
 
 static const int kSlots = 4;
@@ -291,8 +300,56 @@ extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
   return NRTGPU_OK;
 }
 
+extern "C" void nrtgpu_exchange_close(nrtgpu_ctx* ctx) {
+  if (!ctx || !ctx->xch_host) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  (void)hipHostUnregister(ctx->xch_host);
+  (void)munmap(ctx->xch_host, ctx->xch_bytes);
+  ctx->xch_host = nullptr;
+  ctx->xch_dev = nullptr;
+  ctx->xch_bytes = 0;
+  ctx->xch_world = 0;
+}
+
+extern "C" int nrtgpu_exchange_open(nrtgpu_ctx* ctx, const char* shm_name, int32_t world, int32_t rank) {
+  if (!ctx || !shm_name || !shm_name[0]) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (world < 2 || world > 64 || rank < 0 || rank >= world) return fail(NRTGPU_ERR_INVALID_ARG, "bad world %d / rank %d", world, rank);
+  if (ctx->xch_host) return fail(NRTGPU_ERR_STATE, "an exchange is already open on this context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t stride = (size_t)ctx->cfg.max_batch;
+  const size_t bytes = ((size_t)kExchangeSlots * (size_t)world * stride * 8 + 4095) & ~(size_t)4095;
+  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return fail(NRTGPU_ERR_HIP, "shm_open(%s) failed: %s", shm_name, strerror(errno));
+  if (ftruncate(fd, (off_t)bytes) != 0) {
+    close(fd);
+    return fail(NRTGPU_ERR_HIP, "ftruncate(%s, %zu) failed: %s", shm_name, bytes, strerror(errno));
+  }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return fail(NRTGPU_ERR_HIP, "mmap(%s) failed: %s", shm_name, strerror(errno));
+  // my own rows start silent (tag 0 never matches an epoch tag); the other ranks clear theirs
+  unsigned long long* t = (unsigned long long*)p;
+  for (int sl = 0; sl < kExchangeSlots; ++sl)
+    memset(t + ((size_t)sl * world + rank) * stride, 0, stride * 8);
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  void* dp = nullptr;
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, p, 0);
+  if (e != hipSuccess) {
+    (void)munmap(p, bytes);
+    return fail(NRTGPU_ERR_HIP, "mapping the exchange table into the GPU failed: %s", hipGetErrorString(e));
+  }
+  ctx->xch_host = p;
+  ctx->xch_dev = (unsigned long long*)dp;
+  ctx->xch_bytes = bytes;
+  ctx->xch_world = world;
+  ctx->xch_rank = rank;
+  return NRTGPU_OK;
+}
+
 extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
   if (!ctx) return;
+  nrtgpu_exchange_close(ctx);
   (void)hipSetDevice(ctx->device);
   for (auto& s : ctx->slots) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -870,6 +927,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
       it.tab_cache[r] = qt_.cache[r];
       it.tab_scale[r] = qt_.scale[r];
     }
+    it.peer_slot = (uint32_t)lists[pend[i].query].size();  // rebased by the query's list offset below
     hp.items[i] = it;
     lists[pend[i].query].push_back((uint32_t)i);
   }
@@ -880,6 +938,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     hp.q_base[(size_t)qi] = (uint32_t)hp.list_idx.size();
     hp.q_nlists[(size_t)qi] = (uint32_t)lists[(size_t)qi].size();
     hp.list_idx.insert(hp.list_idx.end(), lists[(size_t)qi].begin(), lists[(size_t)qi].end());
+    for (uint32_t ii : lists[(size_t)qi]) hp.items[ii].peer_slot += hp.q_base[(size_t)qi];
     hp.q_k[(size_t)qi] = (uint32_t)q.k;
     DQuery& dq = hp.queries[(size_t)qi];
     dq.k = (uint32_t)q.k;
@@ -917,7 +976,7 @@ struct DeviceRun {
 // batch overlaps the kernels of the batch another host thread has in flight.
 static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
                           uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
-                          std::unique_lock<std::mutex>& gpu) {
+                          std::unique_lock<std::mutex>& gpu, int64_t epoch = -1) {
   const size_t n_items = hp.items.size();
   Carver pc;
   const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
@@ -930,6 +989,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_qnl = pc.take(hp.q_nlists.size() * 4);
   const size_t o_qk = pc.take(hp.q_k.size() * 4);
   const size_t o_theta = pc.take(hp.theta_init.size() * 8);  // uploaded with the plan, then updated by the kernel
+  const size_t o_quant = pc.take(hp.list_idx.size() * 8);    // per item: published quantile bound (zeros)
+  const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
+  const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
   const size_t plan_bytes = pc.off;
   if (int rc = slot->h_plan.reserve(plan_bytes)) return rc;
   if (int rc = slot->d_plan.reserve(plan_bytes)) return rc;
@@ -944,6 +1006,18 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_qnl, hp.q_nlists.data(), hp.q_nlists.size() * 4);
   memcpy(hb + o_qk, hp.q_k.data(), hp.q_k.size() * 4);
   memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
+  memset(hb + o_quant, 0, hp.list_idx.size() * 8);
+  if (use_xch) {
+    DExchange x{};
+    const size_t stride = (size_t)ctx->cfg.max_batch;
+    x.slot = ctx->xch_dev + (size_t)(epoch % kExchangeSlots) * (size_t)ctx->xch_world * stride;
+    x.world = (uint32_t)ctx->xch_world;
+    x.rank = (uint32_t)ctx->xch_rank;
+    x.stride = (uint32_t)stride;
+    x.tag = (uint32_t)(epoch + 1);  // never 0
+    if (x.tag == 0) x.tag = 1;
+    memcpy(hb + o_xch, &x, sizeof(x));
+  }
 
   Carver wc;
   const size_t o_ikeys = wc.take(n_items * (size_t)hp.k_stride * 8);
@@ -966,7 +1040,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
-                   (unsigned long long*)(db + o_theta), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
+                   (unsigned long long*)(db + o_theta), (unsigned long long*)(db + o_quant),
+                   use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
                    (uint64_t*)(wb + o_ihits), hp.k_stride, ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
   uint64_t* okeys = ext_keys ? ext_keys : (uint64_t*)(wb + o_okeys);
@@ -1084,6 +1159,14 @@ extern "C" int nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs
 extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                                int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                                                int32_t k_stride, void* d_keys, void* d_counts, void* d_hits) {
+  return nrtgpu_search_bm25_batch_device_epoch(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts,
+                                               d_hits, -1);
+}
+
+extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                                     int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
+                                                     int64_t epoch) {
   if (!ctx || !queries || !d_keys || !d_counts || !d_hits || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
   if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
@@ -1103,7 +1186,7 @@ extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
-                                (uint64_t*)d_hits, &run, gpu))
+                                (uint64_t*)d_hits, &run, gpu, epoch))
       return rc;
     HIP_TRY(hipStreamSynchronize(slot->stream));
   }

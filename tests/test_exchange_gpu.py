@@ -1,0 +1,149 @@
+"""Cross-GPU bound exchange (nrtgpu_exchange_open): two processes, each scanning its docid shard of one index
+on the same MI355X with the shared-memory exchange open, must merge to exactly the whole-index answer --
+shards may return fewer low-ranked hits, never lose one of the merged top-k."""
+import os
+import subprocess
+import sys
+import tempfile
+import uuid
+
+import numpy as np
+import pytest
+
+from nrtsearch_amd import synth, workload
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+N_DOCS, N_QUERIES, K, WORLD = 1_500_000, 48, 1000, 2
+
+
+def _run_ranks(shm_name, epochs):
+    with tempfile.TemporaryDirectory() as d:
+        procs, outs = [], []
+        for r in range(WORLD):
+            out = os.path.join(d, f"rank{r}.npz")
+            outs.append(out)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_exchange_worker.py"), str(r), str(WORLD),
+                                           shm_name, d, out, str(N_DOCS), str(N_QUERIES), str(K), str(epochs)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+        for p, log in zip(procs, logs):
+            assert p.returncode == 0, log[-2000:]
+        return [dict(np.load(o)) for o in outs]
+
+
+def _lists(res, qi):
+    out = []
+    for r in res:
+        n = int(r["cnt"][qi])
+        keys = r["keys"][qi, :n]
+        docs = (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int32)
+        scores = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
+        out.append((docs, scores))
+    return out
+
+
+@pytest.mark.parametrize("exchange", [False, True])
+def test_two_shards_merge_to_the_whole_index_answer(oracle, exchange):
+    w = workload.Workload("exchange test", N_DOCS, 5, K, N_QUERIES, 4)
+    qr = synth.make_queries(N_QUERIES, w.n_terms, w.max_rank)
+    full = workload.build_shard_corpus(w, qr, 1, 0)
+    name = f"/nrtgpu_test_{uuid.uuid4().hex[:12]}" if exchange else "-"
+    try:
+        res = _run_ranks(name, epochs=3)
+    finally:
+        if exchange and os.path.exists("/dev/shm" + name):
+            os.unlink("/dev/shm" + name)
+    returned = []
+    for qi in range(N_QUERIES):
+        edocs, escores, etotal, _ = oracle.search_bm25(full, qr[qi].tolist(), K)
+        docs, scores = oracle.topdocs_merge(K, _lists(res, qi))
+        assert docs.tolist() == edocs.tolist(), f"query {qi}: merged docids differ"
+        assert scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist()
+        assert int(sum(int(r["hits"][qi]) for r in res)) == etotal
+        returned.append(sum(int(r["cnt"][qi]) for r in res))
+    print("exchange" if exchange else "plain", "mean hits returned per query by the two shards:", float(np.mean(returned)))
+    if not exchange:
+        assert min(returned) >= K
+
+
+def test_exchange_table_written_and_honoured():
+    """One process plays rank 0 of 2; the test writes rank 1's rows by hand.  Checks the table protocol (slot,
+    tag, own-row publication) and that a peer's published bound prunes rank 0's result without changing hits."""
+    import torch  # noqa: F401  (HIP runtime first)
+
+    from nrtsearch_amd import api
+
+    n_q, world, max_batch, slots = 32, 2, 64, 8
+    w = workload.Workload("exchange table test", 1_200_000, 5, K, n_q, 4)
+    qr = synth.make_queries(n_q, w.n_terms, w.max_rank)
+    shard0 = workload.build_shard_corpus(w, qr, world, 0)
+    ctx = api.GpuContext(0, max_batch=max_batch)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in shard0.segments]
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(shard0))
+    queries = workload.boolean_queries(qr)
+    plain = sr.search_batch(queries, [api.TopScoreDocCollectorManager(K)] * n_q)
+    name = f"/nrtgpu_test_{uuid.uuid4().hex[:12]}"
+    try:
+        ctx.exchange_open(name, world, 0)
+        table = np.memmap("/dev/shm" + name, dtype=np.uint64, mode="r+", shape=(slots, world, max_batch))
+        pb = api.PreparedBatch(sr, queries, [api.TopScoreDocCollectorManager(K)] * n_q)
+        k_stride = (K + 15) // 16 * 16
+        import torch
+
+        keys = torch.zeros((n_q, k_stride), dtype=torch.int64, device="cuda")
+        cnt = torch.zeros((n_q,), dtype=torch.int32, device="cuda")
+        hits = torch.zeros((n_q,), dtype=torch.int64, device="cuda")
+
+        def run(epoch):
+            pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=epoch)
+            torch.cuda.synchronize()
+            return keys.cpu().numpy().view(np.uint64), cnt.cpu().numpy(), hits.cpu().numpy()
+
+        # epoch 3, peer silent: nothing may be pruned; rank 0 publishes into slot 3, row 0, tag 4
+        kk, cc, hh = run(3)
+        assert cc.tolist() == [len(p.docs) for p in plain]
+        mine = np.array(table[3, 0, :n_q])
+        pub = (mine >> np.uint64(32)) == np.uint64(4)
+        assert pub.any()                                   # queries that met a rendezvous have published
+        for qi in np.nonzero(pub)[0]:
+            bound = np.uint32(mine[qi] & np.uint64(0xFFFFFFFF)).view(np.float32)
+            assert (plain[qi].scores >= bound).sum() >= K // world      # >= ceil(k / world) of my docs reach it
+        # epoch 4, the peer "publishes" a high bound under the right tag -> the merged bound is min(mine, peer's)
+        # epoch 5: the same values under a stale tag -> ignored
+        for epoch, tag_ok in ((4, True), (5, False)):
+            peer_bound = np.array([p.scores[K // 4] for p in plain], dtype=np.float32)   # plausible: my own rank-250 score
+            tag = np.uint64(epoch + 1 if tag_ok else epoch)
+            table[epoch % slots, 1, :n_q] = (tag << np.uint64(32)) | peer_bound.view(np.uint32).astype(np.uint64)
+            table.flush()
+            kk, cc, hh = run(epoch)
+            differs = 0
+            own = np.array(table[epoch % slots, 0, :n_q])
+            ob = (own & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32)
+            for qi in range(n_q):
+                n = int(cc[qi])
+                docs = (np.uint64(0xFFFFFFFF) - (kk[qi, :n] & np.uint64(0xFFFFFFFF))).astype(np.int32)
+                scores = (kk[qi, :n] >> np.uint64(32)).astype(np.uint32).view(np.float32)
+                assert hh[qi] == plain[qi].total_hits
+                if not tag_ok:
+                    assert docs.tolist() == plain[qi].docs.tolist()
+                    continue
+                # everything at or above the exchanged bound min(mine, peer's) is returned, in the same order;
+                # below it the shard may return any docs it collected before the bound arrived
+                published = (own[qi] >> np.uint64(32)) == np.uint64(epoch + 1)
+                floor = min(ob[qi], peer_bound[qi]) if published else np.float32(np.inf)
+                keep_p = plain[qi].scores >= floor
+                keep_g = scores >= floor
+                assert docs[keep_g].tolist() == plain[qi].docs[keep_p].tolist()
+                assert keep_g[: int(keep_g.sum())].all()             # the kept part is the head of the list
+                differs += int(docs.tolist() != plain[qi].docs.tolist())
+            if tag_ok:
+                assert differs > 0   # the bound took effect: below it the tail is what was collected before it arrived
+        del table
+    finally:
+        ctx.exchange_close()
+        if os.path.exists("/dev/shm" + name):
+            os.unlink("/dev/shm" + name)
+        for l in leaves:
+            l.release()
+        ctx.close()
