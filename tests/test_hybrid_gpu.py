@@ -1,0 +1,85 @@
+"""Config C5's shape at test size -- BM25 recall + exact-vector rescore through the device, against the
+oracle's restatement of QueryRescore (src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-57)
+-- and the thread-safety the C ABI promises to the SEARCH pool (concurrent batch calls on one context)."""
+import threading
+
+import numpy as np
+import pytest
+
+from nrtsearch_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+VEC_FIELD, DIM = 7, 64
+
+
+@pytest.fixture(scope="module")
+def hybrid():
+    rng = np.random.default_rng(11)
+    ranks = [1, 3, 8, 20, 60, 300, 2000]
+    corpus = synth.build_corpus(60_000, ranks, n_segments=3)
+    ctx = api.GpuContext(0, max_batch=256)
+    leaves, vecs = [], []
+    for seg in corpus.segments:
+        g = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
+        g.add_field_norms(0, seg.norms)
+        g.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+        v = rng.standard_normal((seg.max_doc, DIM)).astype(np.float32)
+        g.add_vectors(VEC_FIELD, v)
+        g.seal()
+        leaves.append(g)
+        vecs.append(v)
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    yield dict(corpus=corpus, ctx=ctx, leaves=leaves, vecs=vecs, sr=sr, rng=rng, ranks=ranks)
+    for g in leaves:
+        g.release()
+    ctx.close()
+
+
+def _bq(terms):
+    return api.BooleanQuery(tuple(api.TermQuery(0, int(t)) for t in terms))
+
+
+def test_bm25_recall_then_vector_rescore(hybrid, oracle):
+    bases = [s.doc_base for s in hybrid["corpus"].segments]
+    for terms, recall, window in [([1, 20, 300], 200, 50), ([3, 8, 60, 2000], 1000, 100)]:
+        q = hybrid["rng"].standard_normal(DIM).astype(np.float32)
+        first = hybrid["sr"].search(_bq(terms), api.TopScoreDocCollectorManager(recall))
+        edocs, escores, _, _ = oracle.search_bm25(hybrid["corpus"], terms, recall)
+        assert first.docs.tolist() == edocs.tolist()                       # the recall stage is bit-exact
+        assert first.scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist()
+        got = hybrid["sr"].rescore_vectors(first, VEC_FIELD, "cosine", q, window=window, query_weight=1.0, rescore_weight=2.5)
+        exp = []
+        for doc, f in zip(edocs.tolist(), escores.tolist()):
+            si = max(i for i, b in enumerate(bases) if b <= doc)
+            second = float(oracle.vector_score(0, q, hybrid["vecs"][si][doc - bases[si]]))
+            exp.append((float(oracle.rescore_combine(f, True, second, 1.0, 2.5)), doc))
+        exp.sort(key=lambda t: (-t[0], t[1]))
+        assert len(got.docs) == window
+        assert np.allclose(got.scores, [s for s, _ in exp[:window]], rtol=1e-5, atol=1e-6)
+        assert len(set(got.docs.tolist()) & set(d for _, d in exp[:window])) >= window - 1   # modulo one near-tie
+
+
+def test_concurrent_batch_calls_from_many_threads(hybrid, oracle):
+    term_sets = [[1, 20], [3, 60, 300], [8, 2000], [1, 3, 8, 20, 60], [300], [20, 2000, 1], [60, 8], [3, 1, 300, 2000]]
+    expected = [oracle.search_bm25(hybrid["corpus"], t, 100) for t in term_sets]
+    errors = []
+
+    def worker(tix):
+        try:
+            for it in range(6):
+                order = [(tix + it + j) % len(term_sets) for j in range(len(term_sets))]
+                res = hybrid["sr"].search_batch([_bq(term_sets[i]) for i in order], [api.TopScoreDocCollectorManager(100)] * len(order))
+                for i, r in zip(order, res):
+                    ed, es, et, eg = expected[i]
+                    if (r.docs.tolist() != ed.tolist() or r.scores.view(np.uint32).tolist() != es.view(np.uint32).tolist()
+                            or r.total_hits != et or r.relation_gte != eg):
+                        errors.append((tix, it, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tix, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
