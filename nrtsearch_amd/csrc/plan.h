@@ -21,7 +21,7 @@ constexpr int kScanWaves = NRT_SCAN_WAVES;      // autonomous wave64 per workgro
 constexpr int kScanThreads = kScanWaves * 64;
 static_assert(kScanWaves % 4 == 0 && kTileDocs % 64 == 0 && kTileDocs / 64 <= 16, "scan workgroup shape");
 static_assert(kScanWaves * kTileDocs * 8 <= 96 * 1024, "accumulators exceed their LDS share");
-constexpr int kCandCap = kScanWaves <= 12 ? 2176 : 1920;  // scan: LDS candidate slots (what the LDS budget leaves: 17 / 15 KiB)
+constexpr int kCandCap = (kScanWaves == 12) ? 2176 : 1920;  // scan: LDS candidate slots (what the LDS budget leaves: 17 / 15 KiB)
 constexpr int kMergeCap = 2048;     // merge: candidate slots = kMaxK + kScanThreads
 constexpr int kLdsCaches = 2;       // normInverse tables kept in LDS per item (one per field)
 // Score tables: for the kTabTerms densest terms of a query the BM25 score of every
