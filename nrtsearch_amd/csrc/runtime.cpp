@@ -1317,7 +1317,7 @@ extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
                           (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
                           (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov));
         r = re;
-        round *= 4;
+        round = std::min<int64_t>(round * 4, kKnnCap);  // (unbounded growth overflowed after 24 rounds: > 6M rows hung)
       }
     }
     HIP_TRY(hipGetLastError());

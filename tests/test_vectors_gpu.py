@@ -160,6 +160,27 @@ def test_vector_rescore_matches_queryrescore(ctx, oracle):
         g.release()
 
 
+def test_knn_segment_with_more_than_24_rounds(ctx):
+    # 6.6M rows in ONE segment = 26 rounds of <= 256k rows (the round size once overflowed after 24 and hung)
+    rng = np.random.default_rng(9)
+    n, dim = 6_600_000, 16
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    g = api.GpuSegment(ctx, n, 0)
+    g.add_vectors(0, vecs)
+    g.seal()
+    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+    qs = rng.standard_normal((3, dim)).astype(np.float32)
+    got = sr.knn_exact(0, "max_inner_product", qs, 10)
+    for qi in range(3):
+        dots = vecs @ qs[qi]
+        scores = np.where(dots < 0, 1.0 / (1.0 - dots), dots + 1.0).astype(np.float32)
+        order = np.lexsort((np.arange(n), -scores))[:10]
+        assert np.allclose(got[qi].scores, scores[order], rtol=1e-5, atol=1e-6)
+        assert len(set(got[qi].docs.tolist()) & set(order.tolist())) >= 9
+        assert got[qi].total_hits == n
+    g.release()
+
+
 def test_knn_unsupported_dimension_falls_back(ctx):
     g = api.GpuSegment(ctx, 10, 0)
     g.add_vectors(0, np.ones((10, 3), np.float32))   # d = 3 as in VectorFieldDefTest: not a multiple of 8
