@@ -292,9 +292,10 @@ __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr
 // score widened to double, or ds_add_u64 of the term's fixed-point integer shifted into the query's scale.
 template <bool FX>
 __device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const uint32_t (&val)[8], uint32_t fx_shift) {
+  const uint32_t fx_mult = 1u << fx_shift;  // entry << shift as one 32 x 32 -> 64 multiply (no 64-bit operand to set up)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (FX) atomicAdd((unsigned long long*)lds_ptr(off[j]), (unsigned long long)val[j] << fx_shift);
+    if (FX) atomicAdd((unsigned long long*)lds_ptr(off[j]), (unsigned long long)val[j] * (unsigned long long)fx_mult);  // v_mad_u64_u32
     else unsafeAtomicAdd((double*)lds_ptr(off[j]), (double)__uint_as_float(val[j]));
   }
 }

@@ -40,5 +40,5 @@ for k, d in agg.items():
                   open(sys.argv[2], "w"))
 PY
 echo "== knn bench =="
-cd $ROOT && timeout 600 python scripts/gpu_knn_bench.py 2>&1 | tee gpurun_out/knn_bench.log
+cd $ROOT && timeout 200 python scripts/gpu_knn_bench.py 2>&1 | tee gpurun_out/knn_bench.log
 echo "== done =="
