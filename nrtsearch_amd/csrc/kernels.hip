@@ -131,6 +131,13 @@ __device__ __forceinline__ uint32_t score_value(float sc, int fx_scale) {
   return FX ? (uint32_t)ldexpf(sc, fx_scale) : __float_as_uint(sc);
 }
 
+// (mask & a) | (~mask & b) in one instruction (the compiler expands the C expression to three)
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+
 // Inclusive prefix sum over lanes 0..31 with DPP row shifts (VALU only, no LDS-pipe traffic).
 __device__ __forceinline__ uint32_t scan32_dpp(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
@@ -281,9 +288,10 @@ __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr
   if (!__all(vmask == 0xFFu)) {  // wave-uniform
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)vmask, j, 1);  // all ones: valid
-      off[j] = (off[j] & t) | (dummy_addr & ~t);
-      val[j] = FX ? (val[j] & t) : ((val[j] & t) | (0x80000000u & ~t));  // neutral element: 0 / -0.0f
+      // three instructions per posting: bit-field extract (all ones: valid), bit-field insert, and / insert
+      const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)vmask, j, 1);
+      off[j] = bfi(t, off[j], dummy_addr);
+      val[j] = FX ? (val[j] & t) : bfi(t, val[j], 0x80000000u);  // neutral element: 0 / -0.0f
     }
   }
 }
