@@ -148,6 +148,14 @@ int  nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const in
 int  nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                               const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out);
 
+/* The same single search, but concurrent callers (the SEARCH / gRPC pool's threads, each blocked in its own
+ * call: SearchHandler.java:1412 runs on the request thread) are coalesced by the library into device batches:
+ * a caller that finds no batch forming waits `linger_us` (default 150) for company, then runs everybody's
+ * queries over the same leaves as one batch.  No extra thread; results identical to nrtgpu_search_bm25. */
+int  nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                  const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);
+int  nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us);
+
 /* Device-resident variant for the multi-GPU path (one process per GPU): results stay
  * in HBM as packed keys so the caller can RCCL all-gather them without a host round trip.
  *   d_keys  : n_queries * k_stride uint64 (device), key = (float_bits(score) << 32) | (0xFFFFFFFF - doc),
@@ -241,6 +249,12 @@ typedef struct {
   int64_t fixed_point_launches; /* scan launches that accumulated in exact fixed point (the others: fp64) */
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
+/* Closed-loop load generator (C concurrent clients): `clients` native threads each issue one query at a
+ * time through nrtgpu_search_bm25_coalesced for duration_ms, cycling through `queries`.
+ * out4 = {completed queries, elapsed seconds, p50 latency ms, p99 latency ms}. */
+int  nrtgpu_bench_closed_loop(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                              const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t clients, int32_t duration_ms,
+                              double* out4);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
 #define NRTGPU_FLAG_PROFILE (7 << 8)  /* instrumented scan kernel: per-item phase cycle and event counters of wave 0 (nrtgpu_get_scan_profile) */
 /* sums over all items since the last reset, instrumented kernel only (wave 0 of each workgroup;

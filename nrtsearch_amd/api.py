@@ -349,6 +349,21 @@ class GpuIndexSearcher:
     def search(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
         return self.search_batch([query], [manager])[0]
 
+    def search_coalesced(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
+        """Blocking single search meant to be called from many threads at once: the library merges
+        concurrent callers into device batches (nrtgpu_search_bm25_coalesced)."""
+        m = self._marshal([query], [manager])
+        cap = max(int(manager.num_hits), 1)
+        d = np.zeros(cap, dtype=np.int32)
+        s = np.zeros(cap, dtype=np.float32)
+        out = _lib.TopDocs()
+        out.capacity = cap
+        out.docs = d.ctypes.data_as(C.POINTER(C.c_int32))
+        out.scores = s.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_search_bm25_coalesced(self.ctx._h, self._segs, self._bases, len(self.leaves),
+                                                            m.queries, C.byref(out)))
+        return TopDocs(d[: out.n_hits].copy(), s[: out.n_hits].copy(), int(out.total_hits), bool(out.total_hits_is_lower_bound))
+
     # ---- vectors: ExactFloatVectorQuery / vector rescorer ------------------------------------------
     SIMILARITY = {"cosine": 0, "dot_product": 1, "normalized_cosine": 1, "l2_norm": 2, "max_inner_product": 3}
 

@@ -231,6 +231,13 @@ struct nrtgpu_ctx {
   std::mutex stats_mu;
   nrtgpu_stats stats{};
   double prof[16] = {0};
+  // request coalescing (nrtgpu_search_bm25_coalesced)
+  std::mutex co_mu;
+  std::condition_variable co_cv;
+  std::vector<struct CoRequest*> co_pending;  // waiting for a leader
+  struct CoRequest* co_leader = nullptr;      // the caller lingering for / about to run the next batch
+  int co_inflight = 0;                        // coalesced batches executing right now
+  int32_t co_linger_us = 150;
   // cross-GPU bound exchange (nrtgpu_exchange_open)
   void* xch_host = nullptr;                 // mmap of the shared table
   unsigned long long* xch_dev = nullptr;    // the same memory as the GPU sees it
@@ -1154,6 +1161,171 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
 extern "C" int nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                   const nrtgpu_bm25_query* q, nrtgpu_topdocs* out) {
   return nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, q, 1, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Request coalescing: concurrent single-query callers (the SEARCH pool's threads) are merged into
+// device batches leader/follower style -- no extra thread.  The first caller to find no lingering
+// leader becomes one: it waits co_linger_us (or until max_batch requests are pending), takes every
+// pending request that searches the same leaves, runs them as one batch and wakes their callers.
+// Later arrivals elect the next leader, so two batches are in flight and planning overlaps kernels.
+// ------------------------------------------------------------------------------------------------
+struct CoRequest {
+  const nrtgpu_seg* const* segs;
+  const int32_t* doc_bases;
+  int32_t n_segs;
+  const nrtgpu_bm25_query* q;
+  nrtgpu_topdocs* out;
+  int rc = 0;
+  bool done = false;   // results (or the error) are in place
+  bool lead = false;   // promoted: this caller lingers for and runs the next batch
+  std::string err;
+  std::condition_variable cv;  // every caller sleeps on its own: no thundering herd at hundreds of callers
+};
+
+static bool same_leaves(const CoRequest* a, const CoRequest* b) {
+  if (a->n_segs != b->n_segs) return false;
+  if (a->n_segs == 0) return true;
+  if (memcmp(a->segs, b->segs, (size_t)a->n_segs * sizeof(void*)) != 0) return false;
+  if ((a->doc_bases == nullptr) != (b->doc_bases == nullptr)) return false;
+  return !a->doc_bases || memcmp(a->doc_bases, b->doc_bases, (size_t)a->n_segs * 4) == 0;
+}
+
+extern "C" int nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us) {
+  if (!ctx || linger_us < 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad coalescing arguments");
+  std::lock_guard<std::mutex> lk(ctx->co_mu);
+  ctx->co_linger_us = linger_us;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                            int32_t n_segs, const nrtgpu_bm25_query* q, nrtgpu_topdocs* out) {
+  if (!ctx || !q || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_segs must be >= 0");
+  if (int rc = validate_query(*q, 0)) return rc;  // a bad request must not fail its batch mates
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+    if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);
+    if (segs[si]->ctx != ctx) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d belongs to another context", si);
+  }
+  CoRequest me{segs, doc_bases, n_segs, q, out};
+  std::vector<CoRequest*> batch;
+  {
+    std::unique_lock<std::mutex> lk(ctx->co_mu);
+    ctx->co_pending.push_back(&me);
+    if (ctx->co_leader) {  // follower: the lingering leader takes this request (or a later one does)
+      if ((int32_t)ctx->co_pending.size() >= ctx->cfg.max_batch) ctx->co_leader->cv.notify_one();
+      me.cv.wait(lk, [&] { return me.done || me.lead; });
+      if (me.done) {
+        if (me.rc != 0) g_last_error = me.err;
+        return me.rc;
+      }
+    } else {
+      ctx->co_leader = &me;
+    }
+    // leader: linger for company; then leave as soon as the device can take the batch (two in flight: the
+    // planning and copies of one overlap the kernels of the other) -- while it cannot, waiting only grows
+    // the batch.  Woken by a full queue or a finishing batch.
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(ctx->co_linger_us);
+    for (;;) {
+      if ((int32_t)ctx->co_pending.size() >= ctx->cfg.max_batch) break;
+      const bool late = std::chrono::steady_clock::now() >= deadline;
+      if (late && ctx->co_inflight < 2) break;
+      if (late) me.cv.wait(lk);
+      else me.cv.wait_until(lk, deadline);
+    }
+    // take my request and every pending one over the same leaves (up to max_batch)
+    std::vector<CoRequest*> rest;
+    batch.push_back(&me);
+    for (CoRequest* r : ctx->co_pending) {
+      if (r == &me) continue;
+      if ((int32_t)batch.size() < ctx->cfg.max_batch && same_leaves(&me, r)) batch.push_back(r);
+      else rest.push_back(r);
+    }
+    ctx->co_pending.swap(rest);
+    ctx->co_leader = nullptr;
+    if (!ctx->co_pending.empty()) {  // hand the lead to the oldest request left behind
+      ctx->co_leader = ctx->co_pending.front();
+      ctx->co_leader->lead = true;
+      ctx->co_leader->cv.notify_one();
+    }
+    ctx->co_inflight++;
+  }
+  // run the batch outside the lock
+  std::vector<nrtgpu_bm25_query> qs(batch.size());
+  std::vector<nrtgpu_topdocs> outs(batch.size());
+  for (size_t i = 0; i < batch.size(); ++i) {
+    qs[i] = *batch[i]->q;
+    outs[i] = *batch[i]->out;
+  }
+  const int rc = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data());
+  const std::string err = rc ? g_last_error : std::string();
+  {
+    // (notified under the lock: a woken caller cannot return -- and free its request -- before we are done with it)
+    std::lock_guard<std::mutex> lk(ctx->co_mu);
+    for (size_t i = 0; i < batch.size(); ++i) {
+      if (rc == 0) *batch[i]->out = outs[i];
+      batch[i]->rc = rc;
+      batch[i]->err = err;
+      batch[i]->done = true;
+      if (batch[i] != &me) batch[i]->cv.notify_one();
+    }
+    ctx->co_inflight--;
+    if (ctx->co_leader) ctx->co_leader->cv.notify_one();  // a lingering leader may be waiting for the device
+  }
+  return rc;
+}
+
+// Closed-loop load generator (diagnostics; SURVEY 8d's "C concurrent clients"): `clients` native threads each
+// issue one query at a time through nrtgpu_search_bm25_coalesced for duration_ms, cycling through `queries`.
+// out[0] = completed queries, out[1] = seconds, out[2] = p50 latency ms, out[3] = p99 latency ms.
+extern "C" int nrtgpu_bench_closed_loop(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                        int32_t clients, int32_t duration_ms, double* out4) {
+  if (!ctx || !queries || !out4 || n_queries <= 0 || clients <= 0 || duration_ms <= 0)
+    return fail(NRTGPU_ERR_INVALID_ARG, "bad closed-loop arguments");
+  std::vector<std::vector<float>> lat((size_t)clients);
+  std::vector<int> rcs((size_t)clients, 0);
+  std::vector<std::string> errs((size_t)clients);
+  const auto t_begin = std::chrono::steady_clock::now();
+  const auto t_stop = t_begin + std::chrono::milliseconds(duration_ms);
+  auto client = [&](int c) {
+    int32_t kmax = 1;
+    for (int i = 0; i < n_queries; ++i) kmax = std::max(kmax, queries[i].k);
+    std::vector<int32_t> docs((size_t)kmax);
+    std::vector<float> scores((size_t)kmax);
+    size_t i = (size_t)c * 7919u;
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (t0 >= t_stop) break;
+      nrtgpu_topdocs o{};
+      o.capacity = kmax;
+      o.docs = docs.data();
+      o.scores = scores.data();
+      const int rc = nrtgpu_search_bm25_coalesced(ctx, segs, doc_bases, n_segs, &queries[i % (size_t)n_queries], &o);
+      if (rc != 0) {
+        rcs[(size_t)c] = rc;
+        errs[(size_t)c] = g_last_error;
+        break;
+      }
+      lat[(size_t)c].push_back(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      ++i;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int c = 0; c < clients; ++c) pool.emplace_back(client, c);
+  for (auto& t : pool) t.join();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  for (int c = 0; c < clients; ++c)
+    if (rcs[(size_t)c] != 0) return fail(rcs[(size_t)c], "client %d: %s", c, errs[(size_t)c].c_str());
+  std::vector<float> all;
+  for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+  std::sort(all.begin(), all.end());
+  out4[0] = (double)all.size();
+  out4[1] = secs;
+  out4[2] = all.empty() ? 0.0 : all[all.size() / 2];
+  out4[3] = all.empty() ? 0.0 : all[(size_t)((double)all.size() * 0.99)];
+  return NRTGPU_OK;
 }
 
 extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,

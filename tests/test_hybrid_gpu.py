@@ -83,3 +83,36 @@ def test_concurrent_batch_calls_from_many_threads(hybrid, oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_coalesced_single_searches_from_many_threads(hybrid, oracle):
+    # what the gRPC / SEARCH pool threads do: one blocking search each; the library merges them into batches
+    term_sets = [[1, 20], [3, 60, 300], [8, 2000], [1, 3, 8, 20, 60], [300], [20, 2000, 1], [60, 8], [3, 1, 300, 2000]]
+    expected = [oracle.search_bm25(hybrid["corpus"], t, 100) for t in term_sets]
+    errors = []
+    hybrid["ctx"].reset_stats()
+
+    def worker(tix):
+        try:
+            for it in range(25):
+                i = (tix * 7 + it) % len(term_sets)
+                r = hybrid["sr"].search_coalesced(_bq(term_sets[i]), api.TopScoreDocCollectorManager(100))
+                ed, es, et, eg = expected[i]
+                if (r.docs.tolist() != ed.tolist() or r.scores.view(np.uint32).tolist() != es.view(np.uint32).tolist()
+                        or r.total_hits != et or r.relation_gte != eg):
+                    errors.append((tix, it, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tix, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(32)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    st = hybrid["ctx"].stats()
+    assert st["queries"] == 32 * 25
+    assert st["batches"] < st["queries"]          # callers were merged into batches
+    # an invalid request fails alone, with its own message
+    with pytest.raises(Exception):
+        hybrid["sr"].search_coalesced(_bq([1, 20]), api.TopScoreDocCollectorManager(0))
