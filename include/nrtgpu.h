@@ -168,9 +168,9 @@ int  nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* s
                                      int32_t k_stride, void* d_keys, void* d_counts, void* d_hits);
 /* Cross-GPU bound exchange (the LazyMaxScoreAccumulator idea across processes, SURVEY 8e "optional cross-GPU
  * theta sharing").  When one search is sharded over `world` GPUs, every shard alone would converge on the
- * k-th best of ITS docs.  With an exchange open, each shard publishes a score that at least ceil(k / world)
- * of its docs reach; once all shards have published, at least k docs of the search reach the smallest of
- * them, so no shard needs to collect anything below it.  Results of the merged search are unchanged
+ * k-th best of ITS docs.  With an exchange open, each shard publishes a score that at least
+ * ceil(k / (world - 1)) of its docs reach; the entries of any world - 1 shards then cover k docs, so a shard
+ * needs to collect nothing below the smallest entry of the OTHER shards.  Results of the merged search are unchanged
  * (tests/test_exchange_gpu.py); shards return fewer low-ranked hits.
  * The table lives in POSIX shared memory `shm_name` (every rank passes the same name; rank 0 should
  * unlink stale files first), mapped into each process's GPU.  Ranks must synchronise once between

@@ -322,17 +322,19 @@ __device__ __forceinline__ uint64_t peers_bound(const unsigned long long* peers,
   return inv == 0xFFFFFFFFu ? 0ull : (uint64_t)(~inv) << 32;
 }
 
-// The same between the shards of one search on different GPUs (plan.h: DExchange): this rank's entry is
-// refreshed with `local` (what its own items know together; any published value is a valid bound, so a
-// plain store suffices), then the smallest of all ranks' entries of this epoch is the search-wide bound.
+// The same between the shards of one search on different GPUs (plan.h: DExchange).  Every rank publishes
+// a score that at least ceil(k / (world - 1)) of its docs reach, so the entries of ANY world - 1 ranks
+// cover k docs: a rank bounds itself by the smallest entry of the OTHER ranks and does not have to wait
+// for its own first compaction.  `local` (what this rank's items know together about that quantile) is
+// stored into the rank's own entry; any published value is valid, so a plain store suffices.
 __device__ __forceinline__ uint64_t exchange_bound(const DExchange& x, uint32_t query, uint64_t local, uint32_t lane) {
   if (local != 0ull && lane == 0)
     __hip_atomic_store(x.slot + (size_t)x.rank * x.stride + query, ((unsigned long long)x.tag << 32) | (local >> 32),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   uint32_t inv = 0;
   for (uint32_t r = lane; r < x.world; r += 64u) {
-    unsigned long long e = (r == x.rank) ? (((unsigned long long)x.tag << 32) | (local >> 32))
-                                         : __hip_atomic_load(x.slot + (size_t)r * x.stride + query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (r == x.rank) continue;
+    const unsigned long long e = __hip_atomic_load(x.slot + (size_t)r * x.stride + query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t hi = (uint32_t)(e >> 32) == x.tag ? (uint32_t)e : 0u;  // another epoch's entry: silent
     inv = max(inv, ~hi);
   }
@@ -351,8 +353,9 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
                                                    uint32_t n_peers, uint32_t my_peer, const DExchange* xch, uint32_t query,
                                                    bool prof) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  // slices of the whole search: this query's items here times the shards on other GPUs
-  const uint32_t n_shares = n_peers * (xch ? xch->world : 1u);
+  // how many slices must together cover k docs: this query's items here, times (with an exchange) the
+  // world - 1 OTHER ranks whose entries bound a rank
+  const uint32_t n_shares = n_peers * (xch ? xch->world - 1u : 1u);
   uint64_t t0 = 0, t1 = 0, t2 = 0;
   if (prof) t0 = __builtin_readcyclecounter();
   uint32_t cmask = 0;
@@ -392,7 +395,7 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
     }
     if (n_shares > 1u && tid < 64u) {  // wave 0 (uniform inside it): what the search's slices know together
       uint64_t pb = peers_bound(peers, n_peers, lane);  // this GPU's items (all of them must have published)
-      if (xch) pb = exchange_bound(*xch, query, pb, lane);
+      if (xch) pb = exchange_bound(*xch, query, pb, lane);  // publish it, bound myself by the other GPUs' entries
       if (tid == 0 && pb > s.theta) {
         s.theta = pb;
         s.thr = acc_threshold<FX>(pb, fx_E);
