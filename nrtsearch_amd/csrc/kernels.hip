@@ -312,12 +312,14 @@ __device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const
 // item) -- what LazyMaxScoreAccumulator shares -- is a weak bound when a query is cut m ways: every
 // item converges on its own 1/m of the docs.  Instead each item publishes a score that at least
 // ceil(k / m) of ITS docs reach; once all m have published, at least k docs of the query reach the
-// smallest of them, so nothing below it can enter the merged top-k.  One wave: returns that bound as a
-// theta key (low word 0: a doc scoring exactly the bound still passes), or 0 while a peer is silent.
-__device__ __forceinline__ uint64_t peers_bound(const unsigned long long* peers, uint32_t n_peers, uint32_t lane) {
+// smallest of them, so nothing below it can enter the merged top-k.  With three or more items the
+// quantile is ceil(k / (m - 1)) instead and an item bounds itself by the OTHER items (`skip`): it needs
+// no compaction of its own first.  One wave: returns that bound as a theta key (low word 0: a doc
+// scoring exactly the bound still passes), or 0 while a peer is silent.
+__device__ __forceinline__ uint64_t peers_bound(const unsigned long long* peers, uint32_t n_peers, uint32_t lane, uint32_t skip) {
   uint32_t inv = 0;  // max over peers of ~score word; an unpublished peer (0) saturates it
   for (uint32_t j = lane; j < n_peers; j += 64u)
-    inv = max(inv, ~(uint32_t)(__hip_atomic_load(peers + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32));
+    if (j != skip) inv = max(inv, ~(uint32_t)(__hip_atomic_load(peers + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32));
   inv = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32(inv), 63);
   return inv == 0xFFFFFFFFu ? 0ull : (uint64_t)(~inv) << 32;
 }
@@ -353,9 +355,10 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
                                                    uint32_t n_peers, uint32_t my_peer, const DExchange* xch, uint32_t query,
                                                    bool prof) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  // how many slices must together cover k docs: this query's items here, times (with an exchange) the
-  // world - 1 OTHER ranks whose entries bound a rank
-  const uint32_t n_shares = n_peers * (xch ? xch->world - 1u : 1u);
+  // how many slices must together cover k docs: with an exchange this query's items here times the
+  // world - 1 OTHER ranks whose entries bound a rank; without, the OTHER items (all of them if only two)
+  const bool others_only = !xch && n_peers >= 3u;
+  const uint32_t n_shares = xch ? n_peers * (xch->world - 1u) : (others_only ? n_peers - 1u : n_peers);
   uint64_t t0 = 0, t1 = 0, t2 = 0;
   if (prof) t0 = __builtin_readcyclecounter();
   uint32_t cmask = 0;
@@ -394,7 +397,7 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
       s.prof[6] += 1;
     }
     if (n_shares > 1u && tid < 64u) {  // wave 0 (uniform inside it): what the search's slices know together
-      uint64_t pb = peers_bound(peers, n_peers, lane);  // this GPU's items (all of them must have published)
+      uint64_t pb = peers_bound(peers, n_peers, lane, others_only ? my_peer : ~0u);  // this GPU's items
       if (xch) pb = exchange_bound(*xch, query, pb, lane);  // publish it, bound myself by the other GPUs' entries
       if (tid == 0 && pb > s.theta) {
         s.theta = pb;
@@ -546,7 +549,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   }
   if (tid < 64) s.dummy[tid] = acc_marker<FX>();
   if ((multi_item || xch) && tid < 64u) {  // wave 0: what the search's other slices have published together so far
-    uint64_t pb = peers_bound(quant_g + q.item_begin, q.n_items, lane);
+    uint64_t pb = peers_bound(quant_g + q.item_begin, q.n_items, lane, (!xch && q.n_items >= 3u) ? item.peer_slot - q.item_begin : ~0u);
     if (xch) pb = exchange_bound(*xch, item.query, pb, lane);
     if (tid == 0 && pb > s.theta) {
       s.theta = pb;
