@@ -25,7 +25,7 @@ namespace nrtgpu {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kKnnThreads = 1024;  // 16 waves (one workgroup per CU: the query panel takes up to 160 KiB of LDS), each owns 32 docs per step
+constexpr int kKnnThreads = 1024;  // 16 waves (one workgroup per CU: the query panel takes up to 160 KiB of LDS), each owns 16 docs per step
 constexpr int kKnnDepth = 8;       // 16-byte row chunks in flight per lane (HBM latency x bandwidth needs ~100 B per lane)
 
 // out[i] = sum_k v[i][k]^2 (fp32, sequential chunks) -- used by cosine.

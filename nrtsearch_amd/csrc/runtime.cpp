@@ -865,7 +865,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
 
   // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
   // may span several segments (like a LeafSlice) and a large segment may be cut by tile range.
-  // Measured on MI355X (one 16-wave workgroup per CU): every extra item of a query costs a cold
+  // Measured on MI355X (one workgroup per CU): every extra item of a query costs a cold
   // top-k start, so a query is cut only when it alone would take longer than its fair share of the
   // batch on one CU.  target_items == 0 => one share per CU.
   const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : (int64_t)std::max(ctx->n_cus, 1);
