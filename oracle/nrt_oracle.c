@@ -279,6 +279,191 @@ void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The same disjunction with dynamic pruning: the algorithm family of Lucene's
+ * MaxScoreBulkScorer (lucene-core 10.4.0; chosen for a top-level pure-SHOULD BooleanQuery under
+ * ScoreMode.TOP_SCORES), driven by the min competitive score the
+ * collector publishes (src/main/java/org/apache/lucene/search/LazyQueueTopScoreDocCollector.java
+ * :168-171, :188-192 -> Scorable.setMinCompetitiveScore).
+ *
+ * Per 4096-doc window (Lucene's INNER_WINDOW_SIZE): every clause gets an upper bound for the
+ * window from per-block maxima (128 postings per block, the granularity of Lucene's level-0
+ * impacts); clauses are ordered by that bound; the longest prefix whose bounds sum below the min
+ * competitive score is "non-essential".  Essential clauses are scored term-at-a-time into the
+ * window; for each doc they matched, non-essential clauses are advanced to the doc from the
+ * largest bound down, and the doc is dropped as soon as partial + remaining bounds cannot reach
+ * the min competitive score.  Docs matched only by non-essential clauses are never visited.
+ *
+ * Safe: the top-k (docs and scores) equals nrt_oracle_search_segment's; totalHits becomes a
+ * lower bound (the collector has flagged GREATER_THAN_OR_EQUAL_TO before any pruning can start,
+ * since pruning needs min_competitive > 0).  This is NOT a line-level restatement of Lucene's
+ * outer-window selection or of its totalHits value (unpinned); it is the pruned CPU
+ * baseline SURVEY 8d asks to have timed beside the GPU.
+ * ------------------------------------------------------------------------------------------ */
+#define ORACLE_BLOCK 128
+
+void nrt_oracle_block_max(const nrt_oracle_term* tm, float* out) {
+  int64_t nb = (tm->n + ORACLE_BLOCK - 1) / ORACLE_BLOCK;
+  for (int64_t b = 0; b < nb; ++b) {
+    int64_t lo = b * ORACLE_BLOCK, hi = lo + ORACLE_BLOCK;
+    if (hi > tm->n) hi = tm->n;
+    float m = 0.0f;
+    for (int64_t p = lo; p < hi; ++p) {
+      float freq = tm->freqs ? (float)tm->freqs[p] : 1.0f;
+      uint8_t norm = tm->norms ? tm->norms[tm->docids[p]] : (uint8_t)1;
+      float s = nrt_oracle_bm25_score(tm->weight, freq, tm->cache[norm]);
+      if (s > m) m = s;
+    }
+    out[b] = m;
+  }
+}
+
+/* first index >= p whose docid is >= target (exponential then binary search) */
+static int64_t advance_to(const int32_t* d, int64_t p, int64_t n, int32_t target) {
+  if (p >= n || d[p] >= target) return p;
+  int64_t lo = p, step = 1;
+  while (lo + step < n && d[lo + step] < target) {
+    lo += step;
+    step <<= 1;
+  }
+  int64_t hi = lo + step < n ? lo + step : n;
+  while (hi - lo > 1) {
+    int64_t mid = lo + ((hi - lo) >> 1);
+    if (d[mid] < target) lo = mid; else hi = mid;
+  }
+  return hi;
+}
+
+void nrt_oracle_search_segment_maxscore(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                                        int32_t n_terms, const nrt_oracle_term* terms,
+                                        const float* const* block_max,
+                                        nrt_oracle_collector* collector, int64_t* postings_scored) {
+  enum { MAXT = 64 };
+  double acc[ORACLE_WINDOW];
+  uint8_t matched[ORACLE_WINDOW];
+  int64_t cursor[MAXT], blk[MAXT];
+  float win_max[MAXT];
+  int order[MAXT];
+  double bound[MAXT + 1]; /* bound[j] = sum of win_max over order[0..j-1] */
+  int64_t scored = 0;
+  if (n_terms > MAXT) n_terms = MAXT;
+  for (int t = 0; t < n_terms; ++t) cursor[t] = blk[t] = 0;
+  nrt_oracle_collector_set_leaf(collector, doc_base);
+
+  for (int32_t base = 0; base < max_doc; base += ORACLE_WINDOW) {
+    int32_t end = base + ORACLE_WINDOW;
+    if (end > max_doc) end = max_doc;
+    /* upper bound of every clause inside [base, end) */
+    for (int t = 0; t < n_terms; ++t) {
+      const nrt_oracle_term* tm = &terms[t];
+      int64_t nb = (tm->n + ORACLE_BLOCK - 1) / ORACLE_BLOCK;
+      int64_t b = blk[t];
+      for (; b < nb; ++b) { /* skip blocks that end before the window */
+        int64_t last = (b + 1) * ORACLE_BLOCK - 1;
+        if (last >= tm->n) last = tm->n - 1;
+        if (tm->docids[last] >= base) break;
+      }
+      blk[t] = b;
+      float m = 0.0f;
+      for (; b < nb && tm->docids[b * ORACLE_BLOCK] < end; ++b)
+        if (block_max[t][b] > m) m = block_max[t][b];
+      win_max[t] = m;
+      order[t] = t;
+    }
+    for (int i = 1; i < n_terms; ++i) { /* ascending by bound */
+      int o = order[i], j = i - 1;
+      for (; j >= 0 && win_max[order[j]] > win_max[o]; --j) order[j + 1] = order[j];
+      order[j + 1] = o;
+    }
+    bound[0] = 0.0;
+    for (int j = 0; j < n_terms; ++j) bound[j + 1] = bound[j] + (double)win_max[order[j]];
+    float theta = collector->min_competitive;
+    int ne = 0; /* clauses order[0..ne-1] are non-essential */
+    while (ne < n_terms && (float)bound[ne + 1] < theta) ++ne;
+    if (ne == n_terms) continue; /* nothing in this window can be competitive */
+
+    int any = 0;
+    for (int j = ne; j < n_terms; ++j) {
+      int t = order[j];
+      const nrt_oracle_term* tm = &terms[t];
+      int64_t p = advance_to(tm->docids, cursor[t], tm->n, base);
+      if (p < tm->n && tm->docids[p] < end) {
+        if (!any) {
+          memset(acc, 0, sizeof(double) * (size_t)(end - base));
+          memset(matched, 0, (size_t)(end - base));
+          any = 1;
+        }
+        for (; p < tm->n && tm->docids[p] < end; ++p) {
+          int32_t d = tm->docids[p];
+          float freq = tm->freqs ? (float)tm->freqs[p] : 1.0f;
+          uint8_t norm = tm->norms ? tm->norms[d] : (uint8_t)1;
+          acc[d - base] += (double)nrt_oracle_bm25_score(tm->weight, freq, tm->cache[norm]);
+          matched[d - base] = 1;
+          ++scored;
+        }
+      }
+      cursor[t] = p;
+    }
+    if (!any) continue;
+    for (int32_t d = base; d < end; ++d) {
+      if (!matched[d - base]) continue;
+      if (live_bits && !((live_bits[d >> 6] >> (d & 63)) & 1ULL)) continue;
+      double score = acc[d - base];
+      int competitive = 1;
+      for (int j = ne - 1; j >= 0; --j) {
+        if ((float)(score + bound[j + 1]) < collector->min_competitive) {
+          competitive = 0;
+          break;
+        }
+        int t = order[j];
+        const nrt_oracle_term* tm = &terms[t];
+        int64_t p = advance_to(tm->docids, cursor[t], tm->n, d);
+        cursor[t] = p;
+        if (p < tm->n && tm->docids[p] == d) {
+          float freq = tm->freqs ? (float)tm->freqs[p] : 1.0f;
+          uint8_t norm = tm->norms ? tm->norms[d] : (uint8_t)1;
+          score += (double)nrt_oracle_bm25_score(tm->weight, freq, tm->cache[norm]);
+          ++scored;
+        }
+      }
+      if (competitive) nrt_oracle_collector_collect(collector, d, (float)score);
+    }
+  }
+  if (postings_scored) *postings_scored += scored;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Many independent searches on the host cores: one collector per query visiting its leaves in
+ * docBase order (one Lucene slice per query), queries spread over OpenMP threads.  This is the
+ * timed region of bench.py's cpu_baseline leg -- no Python inside it.
+ * ------------------------------------------------------------------------------------------ */
+void nrt_oracle_search_batch(int32_t n_queries, const int64_t* leaf_offsets,
+                             const nrt_oracle_leaf* leaves, int32_t k, int32_t total_hits_threshold,
+                             int32_t maxscore, int32_t n_threads, int32_t* out_docs, float* out_scores,
+                             int32_t* out_n, int64_t* out_total_hits, int32_t* out_gte,
+                             int64_t* postings_scored) {
+  int64_t scored_all = 0;
+  if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : scored_all)
+  for (int32_t q = 0; q < n_queries; ++q) {
+    nrt_oracle_collector* c = nrt_oracle_collector_new(k, 0, 0, 0.0f, total_hits_threshold);
+    int64_t scored = 0;
+    for (int64_t j = leaf_offsets[q]; j < leaf_offsets[q + 1]; ++j) {
+      const nrt_oracle_leaf* lf = &leaves[j];
+      if (maxscore)
+        nrt_oracle_search_segment_maxscore(lf->max_doc, lf->doc_base, lf->live_bits, lf->n_terms, lf->terms,
+                                           lf->block_max, c, &scored);
+      else
+        nrt_oracle_search_segment(lf->max_doc, lf->doc_base, lf->live_bits, lf->n_terms, lf->terms, c);
+    }
+    out_n[q] = nrt_oracle_collector_topdocs(c, out_docs + (int64_t)q * k, out_scores + (int64_t)q * k,
+                                            &out_total_hits[q], &out_gte[q]);
+    nrt_oracle_collector_free(c);
+    scored_all += scored;
+  }
+  if (postings_scored) *postings_scored = scored_all;
+}
+
+/* ------------------------------------------------------------------------------------------
  * TopDocs.merge(0, topN, shardHits) with every shardIndex == -1 (…Manager.java:137-144).
  * Lucene's merge pops a priority queue ordered by (score desc, shardIndex, doc asc); with equal
  * shardIndex that is a stable global (score desc, doc asc) order, produced here by sorting.

@@ -73,6 +73,37 @@ void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t
                                int32_t n_terms, const nrt_oracle_term* terms,
                                nrt_oracle_collector* collector);
 
+/*
+ * The same search with MaxScore dynamic pruning (the algorithm family of Lucene's
+ * MaxScoreBulkScorer): identical top-k, totalHits a lower bound.
+ * block_max[t] = per-128-posting-block maximum score of clause t (nrt_oracle_block_max; the role
+ * of Lucene's level-0 impacts, computed once per (term, weight) outside any timed region).
+ * *postings_scored (may be NULL) is incremented by the postings actually scored.
+ */
+void nrt_oracle_block_max(const nrt_oracle_term* term, float* out /* ceil(n / 128) */);
+void nrt_oracle_search_segment_maxscore(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                                        int32_t n_terms, const nrt_oracle_term* terms,
+                                        const float* const* block_max,
+                                        nrt_oracle_collector* collector, int64_t* postings_scored);
+
+/* One leaf of one query, prepared by the caller (block_max may be NULL when maxscore == 0). */
+typedef struct {
+  int32_t max_doc;
+  int32_t doc_base;
+  const uint64_t* live_bits;
+  int32_t n_terms;
+  const nrt_oracle_term* terms;
+  const float* const* block_max;
+} nrt_oracle_leaf;
+
+/* n_queries independent searches (leaves[leaf_offsets[q] .. leaf_offsets[q+1]) in docBase order,
+ * one collector each) over n_threads OpenMP threads; outputs are [n_queries][k]. */
+void nrt_oracle_search_batch(int32_t n_queries, const int64_t* leaf_offsets,
+                             const nrt_oracle_leaf* leaves, int32_t k, int32_t total_hits_threshold,
+                             int32_t maxscore, int32_t n_threads, int32_t* out_docs, float* out_scores,
+                             int32_t* out_n, int64_t* out_total_hits, int32_t* out_gte,
+                             int64_t* postings_scored);
+
 /* TopDocs.merge(0, topN, shardHits[]) with all shardIndex == -1: order (score desc, doc asc)
  * (LazyQueueTopScoreDocCollectorManager.java:137-144).  Lists are concatenated in `docs/scores`
  * with lengths `lens[n_lists]`.  Returns number of merged hits written. */

@@ -35,6 +35,17 @@ class _Term(C.Structure):
     ]
 
 
+class _Leaf(C.Structure):
+    _fields_ = [
+        ("max_doc", C.c_int32),
+        ("doc_base", C.c_int32),
+        ("live_bits", C.c_void_p),
+        ("n_terms", C.c_int32),
+        ("terms", C.c_void_p),
+        ("block_max", C.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -66,6 +77,15 @@ def lib():
         L.nrt_oracle_collector_topdocs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.nrt_oracle_search_segment.restype = None
         L.nrt_oracle_search_segment.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.nrt_oracle_block_max.restype = None
+        L.nrt_oracle_block_max.argtypes = [C.c_void_p, C.c_void_p]
+        L.nrt_oracle_search_segment_maxscore.restype = None
+        L.nrt_oracle_search_segment_maxscore.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nrt_oracle_search_batch.restype = None
+        L.nrt_oracle_search_batch.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
         L.nrt_oracle_topdocs_merge.restype = C.c_int32
         L.nrt_oracle_topdocs_merge.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.nrt_oracle_vector_score.restype = C.c_float
@@ -175,19 +195,38 @@ def bm25_query_stats(corpus, term_ids: Sequence[int], boosts: Optional[Sequence[
     return weights, cache
 
 
+_block_max_cache: dict = {}
+
+
+def _block_max(corpus, si: int, term_id: int, term_struct, key_extra) -> np.ndarray:
+    """Per-128-posting-block max score of one clause (index-time impacts in Lucene; cached here)."""
+    key = (id(corpus), si, int(term_id), key_extra)
+    bm = _block_max_cache.get(key)
+    if bm is None:
+        bm = np.zeros((int(term_struct.n) + 127) // 128, dtype=np.float32)
+        lib().nrt_oracle_block_max(C.byref(term_struct), bm.ctypes.data)
+        _block_max_cache[key] = bm
+    return bm
+
+
 def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequence[float]] = None,
                 after: Optional[Tuple[int, float]] = None, total_hits_threshold: int = 1000,
-                segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False):
+                segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False,
+                maxscore: bool = False, stats: Optional[dict] = None):
     """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr))
-    executed as ONE slice (one collector visiting the leaves in docBase order)."""
+    executed as ONE slice (one collector visiting the leaves in docBase order).
+    maxscore=True runs the dynamically pruned scorer (same top-k, totalHits a lower bound);
+    stats["postings_scored"] then accumulates the postings it touched."""
     weights, cache = bm25_query_stats(corpus, term_ids, boosts)
     col = Collector(k, after, total_hits_threshold)
     seg_ids = range(len(corpus.segments)) if segments is None else segments
     keep = []
+    scored = C.c_int64(0)
     for si in seg_ids:
         seg = corpus.segments[si]
         arr = (_Term * max(len(term_ids), 1))()
         n_present = 0
+        present_ids = []
         for i, t in enumerate(term_ids):
             d, f = seg.postings(int(t))
             if len(d) == 0:
@@ -201,9 +240,74 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
             arr[n_present].weight = float(weights[i])
             arr[n_present].norms = None if omit_norms else seg.norms.ctypes.data
             arr[n_present].cache = cache.ctypes.data
+            present_ids.append(int(t))
             n_present += 1
         live = seg.live_bits.ctypes.data if seg.live_bits is not None else None
-        lib().nrt_oracle_search_segment(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr), col._h)
+        if maxscore:
+            bms = [_block_max(corpus, si, present_ids[j], arr[j],
+                              (float(arr[j].weight), omit_norms, omit_freqs)) for j in range(n_present)]
+            ptrs = (C.c_void_p * max(n_present, 1))(*[b.ctypes.data for b in bms])
+            lib().nrt_oracle_search_segment_maxscore(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr),
+                                                     C.byref(ptrs), col._h, C.byref(scored))
+        else:
+            lib().nrt_oracle_search_segment(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr), col._h)
+    if stats is not None:
+        stats["postings_scored"] = stats.get("postings_scored", 0) + int(scored.value)
     res = col.topdocs()
     col.close()
     return res
+
+
+class PreparedBatch:
+    """Queries resolved to per-leaf clause arrays once (Weight creation + impacts, untimed), so that
+    run() is a single C call: n_queries searches over n_threads OpenMP threads."""
+
+    def __init__(self, corpus, queries: Sequence[Sequence[int]], k: int, total_hits_threshold: int = 1000):
+        self.k, self.thr, self.nq = int(k), int(total_hits_threshold), len(queries)
+        self._keep = []
+        leaves = []
+        offsets = [0]
+        for term_ids in queries:
+            weights, cache = bm25_query_stats(corpus, term_ids)
+            self._keep.append(cache)
+            for si, seg in enumerate(corpus.segments):
+                arr = (_Term * max(len(term_ids), 1))()
+                bms = []
+                n_present = 0
+                for i, t in enumerate(term_ids):
+                    d, f = seg.postings(int(t))
+                    if len(d) == 0:
+                        continue
+                    arr[n_present].docids = d.ctypes.data
+                    arr[n_present].freqs = f.ctypes.data
+                    arr[n_present].n = len(d)
+                    arr[n_present].weight = float(weights[i])
+                    arr[n_present].norms = seg.norms.ctypes.data
+                    arr[n_present].cache = cache.ctypes.data
+                    bms.append(_block_max(corpus, si, int(t), arr[n_present], (float(weights[i]), False, False)))
+                    n_present += 1
+                ptrs = (C.c_void_p * max(n_present, 1))(*[b.ctypes.data for b in bms])
+                self._keep += [arr, ptrs]
+                lf = _Leaf()
+                lf.max_doc, lf.doc_base = seg.max_doc, seg.doc_base
+                lf.live_bits = seg.live_bits.ctypes.data if seg.live_bits is not None else None
+                lf.n_terms = n_present
+                lf.terms = C.cast(arr, C.c_void_p)
+                lf.block_max = C.cast(ptrs, C.c_void_p)
+                leaves.append(lf)
+            offsets.append(len(leaves))
+        self._corpus = corpus
+        self._leaves = (_Leaf * max(len(leaves), 1))(*leaves)
+        self._offsets = np.asarray(offsets, dtype=np.int64)
+
+    def run(self, maxscore: bool, n_threads: int):
+        docs = np.zeros((self.nq, self.k), np.int32)
+        scores = np.zeros((self.nq, self.k), np.float32)
+        n = np.zeros(self.nq, np.int32)
+        total = np.zeros(self.nq, np.int64)
+        gte = np.zeros(self.nq, np.int32)
+        scored = C.c_int64(0)
+        lib().nrt_oracle_search_batch(self.nq, self._offsets.ctypes.data, C.byref(self._leaves), self.k, self.thr,
+                                      int(maxscore), int(n_threads), docs.ctypes.data, scores.ctypes.data,
+                                      n.ctypes.data, total.ctypes.data, gte.ctypes.data, C.byref(scored))
+        return docs, scores, n, total, gte, int(scored.value)
