@@ -93,6 +93,13 @@ int  nrtgpu_segment_seal(nrtgpu_seg* seg);
 /* leaf.getLiveDocs() as 64-bit words, bit d set = doc d live; NULL => all live.  May be called
  * again after seal (only liveDocs change between reader versions of one segment). */
 int  nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words);
+/* Non-scoring clauses as doc-set masks (FILTER / MUST_NOT of the BooleanQuery built at
+ * src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:257-283).  The shim materialises the
+ * clause's per-leaf DocIdSet (what LRUQueryCache caches) as 64-bit words, bit d set = doc d matches,
+ * and registers it under an id > 0 of its choosing; queries name ids (nrtgpu_bm25_query.filter_mask /
+ * must_not_mask).  bits == NULL drops the mask.  Like set_live_docs: not concurrently with searches
+ * over this segment. */
+int  nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const uint64_t* bits, int32_t n_words);
 void nrtgpu_segment_release(nrtgpu_seg* seg);
 /* bytes of HBM held by the segment (diagnostics) */
 int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg);
@@ -130,6 +137,11 @@ typedef struct {
                                     * score of the WHOLE search this call is one shard of (other GPUs' results so
                                     * far, LazyMaxScoreAccumulator).  Docs scoring strictly below it are counted in
                                     * total_hits but not collected; 0 = none */
+  int32_t filter_mask;             /* 0 = none; else hits must lie in this registered mask on every segment: a
+                                    * FILTER clause next to the SHOULD clauses with minimumNumberShouldMatch = 1,
+                                    * or "+(should clauses) #filter" -- either way a hit matches >= 1 scoring
+                                    * clause and the filter adds nothing to the score */
+  int32_t must_not_mask;           /* 0 = none; else hits must NOT lie in this mask (MUST_NOT clause) */
   int32_t reserved;
 } nrtgpu_bm25_query;
 
@@ -215,6 +227,17 @@ int  nrtgpu_rescore_vectors(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, cons
                             int32_t field_id, int32_t sim, const float* query, int32_t dim, float boost,
                             const int32_t* docs, const float* first_scores, int32_t n, double query_weight,
                             double rescore_weight, int32_t window, nrtgpu_topdocs* out);
+
+/* Hybrid tail (config C5): BM25 recall, then the vector rescorer over each query's hits, then the window --
+ * on one stream, the first-pass hits never leave HBM (no host round trip between
+ * SearchHandler.java:1412-1413 and RescoreTask.java:47-50).  Results are those of nrtgpu_search_bm25_batch
+ * followed per query by nrtgpu_rescore_vectors(query_vectors[q]); total_hits / relation are the first
+ * pass's (QueryRescorer keeps them).  Weights and boost must be >= 0 (else NRTGPU_ERR_UNSUPPORTED). */
+int  nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t field_id, int32_t sim,
+                                const float* query_vectors /* n_queries * dim */, int32_t dim, float boost,
+                                double query_weight, double rescore_weight, int32_t window,
+                                nrtgpu_topdocs* out /* n_queries, capacity >= window */);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side restatements the Java shim would otherwise take from Lucene objects

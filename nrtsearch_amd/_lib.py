@@ -27,11 +27,11 @@ ABI_SYMBOLS = [
     "nrtgpu_version", "nrtgpu_last_error", "nrtgpu_create", "nrtgpu_destroy",
     "nrtgpu_segment_begin", "nrtgpu_segment_add_field_norms", "nrtgpu_segment_add_terms",
     "nrtgpu_segment_add_vectors", "nrtgpu_segment_seal", "nrtgpu_segment_set_live_docs",
-    "nrtgpu_segment_release", "nrtgpu_segment_device_bytes",
+    "nrtgpu_segment_set_mask", "nrtgpu_segment_release", "nrtgpu_segment_device_bytes",
     "nrtgpu_search_bm25", "nrtgpu_search_bm25_batch", "nrtgpu_search_bm25_batch_device",
     "nrtgpu_search_bm25_batch_device_epoch", "nrtgpu_exchange_open", "nrtgpu_exchange_close",
     "nrtgpu_search_bm25_coalesced", "nrtgpu_set_coalescing", "nrtgpu_bench_closed_loop",
-    "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_rescore_vectors",
+    "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_get_stats", "nrtgpu_reset_stats",
     "nrtgpu_get_scan_profile",
@@ -52,7 +52,8 @@ class Bm25Query(C.Structure):
     _fields_ = [("n_terms", C.c_int32), ("terms", C.POINTER(Term)), ("n_caches", C.c_int32),
                 ("norm_cache", C.POINTER(C.c_float)), ("k", C.c_int32), ("total_hits_threshold", C.c_int32),
                 ("has_after", C.c_int32), ("after_doc", C.c_int32), ("after_score", C.c_float),
-                ("min_should_match", C.c_int32), ("min_competitive_score", C.c_float), ("reserved", C.c_int32)]
+                ("min_should_match", C.c_int32), ("min_competitive_score", C.c_float), ("filter_mask", C.c_int32),
+                ("must_not_mask", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TopDocs(C.Structure):
@@ -98,6 +99,7 @@ def load() -> C.CDLL:
     L.nrtgpu_segment_add_vectors.argtypes = [vp, i32, i32, i32, vp, vp]
     L.nrtgpu_segment_seal.argtypes = [vp]
     L.nrtgpu_segment_set_live_docs.argtypes = [vp, vp, i32]
+    L.nrtgpu_segment_set_mask.argtypes = [vp, i32, vp, i32]
     L.nrtgpu_segment_release.argtypes = [vp]
     L.nrtgpu_segment_release.restype = None
     L.nrtgpu_segment_device_bytes.argtypes = [vp]
@@ -116,6 +118,8 @@ def load() -> C.CDLL:
     L.nrtgpu_knn_exact.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, f32, C.POINTER(TopDocs)]
     L.nrtgpu_rescore_vectors.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, f32, vp, vp, i32, C.c_double, C.c_double, i32,
                                          C.POINTER(TopDocs)]
+    L.nrtgpu_search_hybrid_batch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, i32, vp, i32, f32,
+                                             C.c_double, C.c_double, i32, C.POINTER(TopDocs)]
     L.nrtgpu_int_to_byte4.argtypes = [i32]
     L.nrtgpu_byte4_to_int.argtypes = [i32]
     L.nrtgpu_bm25_idf.argtypes = [i64, i64]

@@ -45,11 +45,22 @@ class BoostQuery:
 
 
 @dataclasses.dataclass(frozen=True)
+class MaskFilter:
+    """A non-scoring clause whose per-leaf doc set is resident as a mask (GpuSegment.set_mask): what a
+    FILTER / MUST_NOT clause is once LRUQueryCache holds its DocIdSet."""
+
+    mask_id: int
+
+
+@dataclasses.dataclass(frozen=True)
 class BooleanQuery:
-    """Pure-SHOULD disjunction (S/query/QueryNodeMapper.java:257-283)."""
+    """SHOULD disjunction of term clauses, optionally narrowed by one FILTER and one MUST_NOT clause
+    (S/query/QueryNodeMapper.java:257-283)."""
 
     should: Tuple[Union[TermQuery, BoostQuery], ...]
     minimum_number_should_match: int = 0
+    filter: Tuple[MaskFilter, ...] = ()
+    must_not: Tuple[MaskFilter, ...] = ()
 
 
 Query = Union[TermQuery, BoostQuery, BooleanQuery]
@@ -236,6 +247,14 @@ class GpuSegment:
         bits = np.ascontiguousarray(bits, dtype=np.uint64)
         _lib.check(_lib.load().nrtgpu_segment_set_live_docs(self._h, bits.ctypes.data, len(bits)))
 
+    def set_mask(self, mask_id: int, bits: Optional[np.ndarray]) -> None:
+        """Doc set of a non-scoring clause (uint64 words, bit d = doc d matches); None drops it."""
+        if bits is None:
+            _lib.check(_lib.load().nrtgpu_segment_set_mask(self._h, int(mask_id), None, 0))
+            return
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        _lib.check(_lib.load().nrtgpu_segment_set_mask(self._h, int(mask_id), bits.ctypes.data, len(bits)))
+
     @property
     def device_bytes(self) -> int:
         return int(_lib.load().nrtgpu_segment_device_bytes(self._h))
@@ -247,8 +266,9 @@ class GpuSegment:
 
 
 # ---- searcher ------------------------------------------------------------------------------------
-def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int]:
-    """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost)], msm."""
+def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int]:
+    """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost)], msm,
+    filter mask id, must_not mask id (0 = none)."""
     def one(q) -> Tuple[int, int, float]:
         if isinstance(q, TermQuery):
             return (q.field, q.term, 1.0)
@@ -261,8 +281,16 @@ def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int]:
             raise UnsupportedQuery("minimumNumberShouldMatch > 1")
         if not query.should:
             raise UnsupportedQuery("empty BooleanQuery")
-        return [one(c) for c in query.should], query.minimum_number_should_match
-    return [one(query)], 0
+        if len(query.filter) > 1 or len(query.must_not) > 1:
+            raise UnsupportedQuery("more than one FILTER / MUST_NOT clause (combine them into one mask)")
+        if query.filter and query.minimum_number_should_match < 1:
+            # with a FILTER clause Lucene makes the SHOULD clauses optional: filter-only docs would be hits of score 0
+            raise UnsupportedQuery("FILTER with minimumNumberShouldMatch = 0")
+        if any(not isinstance(c, MaskFilter) or c.mask_id <= 0 for c in query.filter + query.must_not):
+            raise UnsupportedQuery("FILTER / MUST_NOT clauses must be resident masks")
+        return ([one(c) for c in query.should], query.minimum_number_should_match,
+                query.filter[0].mask_id if query.filter else 0, query.must_not[0].mask_id if query.must_not else 0)
+    return [one(query)], 0, 0, 0
 
 
 class _Marshalled:
@@ -295,7 +323,7 @@ class GpuIndexSearcher:
     def _marshal(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> _Marshalled:
         m = _Marshalled(len(queries))
         for qi, (query, mgr) in enumerate(zip(queries, managers)):
-            clauses, msm = _flatten(query)
+            clauses, msm, filter_mask, must_not_mask = _flatten(query)
             fields: List[int] = []
             terms = (_lib.Term * len(clauses))()
             for ti, (field, term, boost) in enumerate(clauses):
@@ -321,6 +349,8 @@ class GpuIndexSearcher:
             q.after_score = float(mgr.after.score) if mgr.after is not None else 0.0
             q.min_should_match = int(msm)
             q.min_competitive_score = float(mgr.min_competitive_score)
+            q.filter_mask = int(filter_mask)
+            q.must_not_mask = int(must_not_mask)
         return m
 
     def search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> List[TopDocs]:
@@ -406,6 +436,28 @@ class GpuIndexSearcher:
                                                       float(query_weight), float(rescore_weight), int(window),
                                                       C.byref(out)))
         return TopDocs(od[: out.n_hits].copy(), os_[: out.n_hits].copy(), hits.total_hits, hits.relation_gte)
+
+    def search_hybrid_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager], field: int,
+                            similarity: str, query_vectors: np.ndarray, window: int, query_weight: float = 1.0,
+                            rescore_weight: float = 1.0, boost: float = 1.0) -> List[TopDocs]:
+        """search() followed by the vector rescorer for every query, fused on the device (config C5)."""
+        n = len(queries)
+        qv = np.ascontiguousarray(np.atleast_2d(query_vectors), dtype=np.float32)
+        if qv.shape[0] != n:
+            raise ValueError("one query vector per query")
+        m = self._marshal(queries, managers)
+        outs = (_lib.TopDocs * n)()
+        docs = np.zeros((n, max(window, 1)), dtype=np.int32)
+        scores = np.zeros((n, max(window, 1)), dtype=np.float32)
+        for qi in range(n):
+            outs[qi].capacity = window
+            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_search_hybrid_batch(
+            self.ctx._h, self._segs, self._bases, len(self.leaves), m.queries, n, int(field), self.SIMILARITY[similarity],
+            qv.ctypes.data, qv.shape[1], C.c_float(boost), float(query_weight), float(rescore_weight), int(window), outs))
+        return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
+                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n)]
 
 
 # ---- pre-marshalled batches (bench / serving loop: no Python work inside the timed region) --------

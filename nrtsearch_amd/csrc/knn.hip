@@ -274,6 +274,74 @@ void rescore_vectors_kernel(const float* __restrict__ vecs, const float* __restr
   }
 }
 
+// Hybrid tail: the sorted first-pass hits of one query stay in HBM and are
+// rescored in place of a host round trip -- one workgroup per query, one wave per hit: doc -> (leaf, row),
+// exact similarity with the query's vector (same lane order and reduction as rescore_vectors_kernel, so
+// both paths give the same bits), QueryRescore.combine in double, then QueryRescorer's sort
+// (combined score desc, doc asc) in LDS and the window.
+constexpr int kHybridThreads = 1024;
+__global__ __launch_bounds__(kHybridThreads)
+void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32_t* __restrict__ first_counts,
+                           uint32_t k_stride, const DVecSeg* __restrict__ segs, int32_t n_segs, int32_t dim,
+                           const float* __restrict__ qvecs, const float* __restrict__ qnorm2, int32_t sim, float boost,
+                           double qw, double rw, uint32_t window, uint64_t* __restrict__ out_keys,
+                           uint32_t* __restrict__ out_counts, uint32_t w_stride) {
+  __shared__ uint64_t cand[1024];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n = min(first_counts[q], 1024u);
+  const float* qv = qvecs + (size_t)q * dim;
+  const float nq = qnorm2[q];
+  for (uint32_t i = wave; i < n; i += (uint32_t)(kHybridThreads / 64)) {
+    const uint64_t key = first_keys[(size_t)q * k_stride + i];
+    const uint32_t gdoc = 0xFFFFFFFFu - (uint32_t)key;
+    const float first = key_score(key);
+    int64_t row = -1;
+    const float* v = nullptr;
+    float nv = 0.f;
+    for (int32_t si = 0; si < n_segs; ++si) {  // wave-uniform
+      const DVecSeg sg = segs[si];
+      const int64_t local = (int64_t)gdoc - (int64_t)sg.doc_base;
+      if (local < 0 || local >= (int64_t)sg.max_doc) continue;
+      if (sg.vecs) {
+        if (!sg.ord_to_doc) {
+          if (local < (int64_t)sg.n_vec) row = local;
+        } else {  // lower_bound over the leaf's ascending ord -> doc map
+          int32_t lo = 0, hi = sg.n_vec;
+          while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            if (sg.ord_to_doc[mid] < (int32_t)local) lo = mid + 1; else hi = mid;
+          }
+          if (lo < sg.n_vec && sg.ord_to_doc[lo] == (int32_t)local) row = lo;
+        }
+        if (row >= 0) {
+          v = sg.vecs + row * dim;
+          nv = sg.vnorm2[row];
+        }
+      }
+      break;
+    }
+    float second = 0.f;
+    if (row >= 0) {
+      float dot = 0.f;
+      for (int32_t k = (int32_t)lane; k < dim; k += 64) dot += v[k] * qv[k];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) dot += __shfl_xor(dot, d, 64);
+      second = knn_map_score(sim, dot, nq, nv, boost);
+    }
+    if (lane == 0) {
+      const double comb = row >= 0 ? qw * (double)first + rw * (double)second : qw * (double)first;
+      cand[i] = pack_key((float)comb, gdoc);
+    }
+  }
+  uint32_t n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (uint32_t i = n + tid; i < n2; i += (uint32_t)kHybridThreads) cand[i] = 0;
+  bitonic_sort_desc<kHybridThreads>(cand, n2);  // starts with a barrier
+  const uint32_t m = min(n, window);
+  for (uint32_t i = tid; i < w_stride; i += (uint32_t)kHybridThreads) out_keys[(size_t)q * w_stride + i] = i < m ? cand[i] : 0;
+  if (tid == 0) out_counts[q] = m;
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float* norm2) {
   if (n == 0) return;
@@ -304,6 +372,14 @@ void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnor
   if (n == 0) return;
   hipLaunchKernelGGL(rescore_vectors_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, vecs, vnorm2, dim, query,
                      qnorm2, sim, boost, vec_row, first_scores, n, qw, rw, out_scores);
+}
+void launch_hybrid_rescore(hipStream_t st, uint32_t n_queries, const uint64_t* first_keys, const uint32_t* first_counts,
+                           uint32_t k_stride, const DVecSeg* segs, int32_t n_segs, int32_t dim, const float* qvecs,
+                           const float* qnorm2, int32_t sim, float boost, double qw, double rw, uint32_t window,
+                           uint64_t* out_keys, uint32_t* out_counts, uint32_t w_stride) {
+  if (n_queries == 0) return;
+  hipLaunchKernelGGL(hybrid_rescore_kernel, dim3(n_queries), dim3(kHybridThreads), 0, st, first_keys, first_counts, k_stride,
+                     segs, n_segs, dim, qvecs, qnorm2, sim, boost, qw, rw, window, out_keys, out_counts, w_stride);
 }
 
 }  // namespace nrtgpu

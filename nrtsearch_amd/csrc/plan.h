@@ -108,6 +108,15 @@ static_assert(sizeof(DExchange) == 32, "DExchange layout");
 
 // Packed hit: larger key == better hit under Lucene's HitQueue order (score desc, doc asc).
 // Scores are >= 0 (BM25 weights are non-negative) so float bits order like the floats.
+// One leaf's vector field as the hybrid tail sees it (doc -> row lookups happen on the device).
+struct DVecSeg {
+  const float* vecs;          // n_vec x dim fp32, row-major; nullptr: the leaf has no vectors for the field
+  const float* vnorm2;        // |v|^2 per row
+  const int32_t* ord_to_doc;  // ascending; nullptr: row == docid
+  int32_t doc_base, max_doc, n_vec, pad;
+};
+static_assert(sizeof(DVecSeg) == 40, "DVecSeg layout");
+
 __host__ __device__ inline uint64_t pack_key(float score, uint32_t global_doc) {
   union { float f; uint32_t u; } c;
   c.f = score;

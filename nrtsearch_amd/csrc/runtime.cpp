@@ -52,6 +52,10 @@ void launch_knn_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* t
 void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnorm2, int32_t dim, const float* query,
                             float qnorm2, int32_t sim, float boost, const int64_t* vec_row, const float* first_scores,
                             int32_t n, double qw, double rw, float* out_scores);
+void launch_hybrid_rescore(hipStream_t st, uint32_t n_queries, const uint64_t* first_keys, const uint32_t* first_counts,
+                           uint32_t k_stride, const DVecSeg* segs, int32_t n_segs, int32_t dim, const float* qvecs,
+                           const float* qnorm2, int32_t sim, float boost, double qw, double rw, uint32_t window,
+                           uint64_t* out_keys, uint32_t* out_counts, uint32_t w_stride);
 }  // namespace nrtgpu
 
 using namespace nrtgpu;
@@ -204,7 +208,22 @@ struct nrtgpu_seg {
   std::map<int32_t, FieldData> fields;
   uint64_t* d_live = nullptr;
   int64_t device_bytes = 0;
+  // FILTER / MUST_NOT clauses as doc-set masks: host copies of the registered masks and of liveDocs,
+  // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use
+  std::vector<uint64_t> h_live;                      // empty = all live
+  std::map<int32_t, std::vector<uint64_t>> masks;
+  mutable std::mutex accept_mu;
+  mutable std::map<std::pair<int32_t, int32_t>, uint64_t*> accept;
 };
+
+static void drop_accept_sets(nrtgpu_seg* seg) {
+  std::lock_guard<std::mutex> lk(seg->accept_mu);
+  for (auto& kv : seg->accept) {
+    (void)hipFree(kv.second);
+    seg->device_bytes -= (int64_t)((seg->max_doc + 63) / 64) * 8;
+  }
+  seg->accept.clear();
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-call workspace
@@ -215,6 +234,8 @@ struct Slot {
   PinBuf h_plan;     // host staging of the plan blob
   DevBuf d_plan;     // device copy
   DevBuf d_work;     // theta + item outputs + merge outputs
+  DevBuf d_aux;      // hybrid tail: leaf table, query vectors, rescored windows
+  PinBuf h_aux;
   PinBuf h_out;      // merged results on the host
   bool busy = false;
 };
@@ -363,6 +384,8 @@ extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
     s->h_plan.release();
     s->d_plan.release();
     s->d_work.release();
+    s->d_aux.release();
+    s->h_aux.release();
     s->h_out.release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -590,12 +613,15 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
   HIP_TRY(hipSetDevice(seg->ctx->device));
   const int32_t need = (seg->max_doc + 63) / 64;
+  drop_accept_sets(seg);
   if (!bits) {
     if (seg->d_live) (void)hipFree(seg->d_live);
     seg->d_live = nullptr;
+    seg->h_live.clear();
     return NRTGPU_OK;
   }
   if (n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "live bits: %d words given, %d needed", n_words, need);
+  seg->h_live.assign(bits, bits + need);
   if (!seg->d_live) {
     void* p = nullptr;
     if (int rc = dev_alloc(seg, &p, (size_t)need * 8)) return rc;
@@ -605,9 +631,73 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
   return NRTGPU_OK;
 }
 
+extern "C" int nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const uint64_t* bits, int32_t n_words) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (mask_id <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "mask id must be > 0, got %d", mask_id);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  const int32_t need = (seg->max_doc + 63) / 64;
+  drop_accept_sets(seg);
+  if (!bits) {
+    seg->masks.erase(mask_id);
+    return NRTGPU_OK;
+  }
+  if (n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "mask %d: %d words given, %d needed", mask_id, n_words, need);
+  seg->masks[mask_id].assign(bits, bits + need);
+  return NRTGPU_OK;
+}
+
+// The doc set a query's hits must lie in: liveDocs & FILTER mask & ~MUST_NOT mask, resident in HBM.
+// (0, 0) is liveDocs itself.  Built and uploaded on first use, then shared by every query that names
+// the same pair (the role LRUQueryCache plays for Lucene's non-scoring clauses).
+static int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out) {
+  if (filter_mask == 0 && must_not_mask == 0) {
+    *out = seg->d_live;
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(seg->accept_mu);
+  const auto key = std::make_pair(filter_mask, must_not_mask);
+  auto it = seg->accept.find(key);
+  if (it != seg->accept.end()) {
+    *out = it->second;
+    return 0;
+  }
+  const std::vector<uint64_t>* f = nullptr;
+  const std::vector<uint64_t>* mn = nullptr;
+  if (filter_mask) {
+    auto m = seg->masks.find(filter_mask);
+    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "filter mask %d is not resident on a segment", filter_mask);
+    f = &m->second;
+  }
+  if (must_not_mask) {
+    auto m = seg->masks.find(must_not_mask);
+    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "must_not mask %d is not resident on a segment", must_not_mask);
+    mn = &m->second;
+  }
+  const size_t need = (size_t)(seg->max_doc + 63) / 64;
+  std::vector<uint64_t> w(need);
+  for (size_t i = 0; i < need; ++i) {
+    uint64_t v = seg->h_live.empty() ? ~0ull : seg->h_live[i];
+    if (f) v &= (*f)[i];
+    if (mn) v &= ~(*mn)[i];
+    w[i] = v;
+  }
+  void* p = nullptr;
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  if (hipMalloc(&p, need * 8) != hipSuccess) return fail(NRTGPU_ERR_OOM, "hipMalloc(%zu) for an accept set failed", need * 8);
+  if (hipMemcpy(p, w.data(), need * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p);
+    return fail(NRTGPU_ERR_HIP, "upload of an accept set failed");
+  }
+  const_cast<nrtgpu_seg*>(seg)->device_bytes += (int64_t)need * 8;
+  seg->accept[key] = (uint64_t*)p;
+  *out = (uint64_t*)p;
+  return 0;
+}
+
 extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
   if (!seg) return;
   (void)hipSetDevice(seg->ctx->device);
+  drop_accept_sets(seg);
   for (auto& kv : seg->fields) {
     FieldData& f = kv.second;
     if (f.d_norms) (void)hipFree(f.d_norms);
@@ -661,6 +751,7 @@ static int validate_query(const nrtgpu_bm25_query& q, int qi) {
     if (!(q.terms[t].weight >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: weight must be >= 0", qi, t);
   }
   if (!(q.min_competitive_score >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: min_competitive_score must be >= 0", qi);
+  if (q.filter_mask < 0 || q.must_not_mask < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: mask ids must be >= 0", qi);
   return 0;
 }
 
@@ -884,13 +975,15 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     for (const QS& qs : per_query[(size_t)qi]) {
       const nrtgpu_seg* seg = segs[qs.seg];
       const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
+      const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
+      if (int rc = accept_set_of(seg, queries[qi].filter_mask, queries[qi].must_not_mask, &accept)) return rc;
       uint32_t tb = 0;
       while (tb < seg->n_tiles) {
         double room = budget - filled;
         uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tile_cost + 0.5));
         take = std::min<uint32_t>(take, seg->n_tiles - tb);
         DPart p{};
-        p.live_bits = seg->d_live;
+        p.live_bits = accept;
         p.term_begin = qs.term_begin;
         p.n_terms = qs.n_terms;
         p.tile_begin = tb;
@@ -1153,6 +1246,103 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     std::lock_guard<std::mutex> lk(ctx->stats_mu);
     for (size_t i = 0; i < run.n_items; ++i)
       for (int j = 0; j < 16; ++j) ctx->prof[j] += (double)hp_prof[i * 16 + j];
+  }
+  account(ctx, slot, hp, n_queries, plan_ms);
+  return NRTGPU_OK;
+}
+
+// Hybrid tail: BM25 recall -> exact-vector rescore -> window, one stream, no host round trip between
+// the stages (RescoreTask.java:47-50 -> QueryRescore.java:39-57 applied to the hits of
+// SearchHandler.java:1412-1413).  Same results as nrtgpu_search_bm25_batch followed per query by
+// nrtgpu_rescore_vectors.
+extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                          int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                          int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost,
+                                          double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out) {
+  if (!ctx || !queries || !out || !query_vectors || (n_segs > 0 && (!segs || !doc_bases)))
+    return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
+  if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
+  if (dim <= 0 || sim < 0 || sim > 3 || window <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad rescore arguments");
+  if (!(query_weight >= 0.0) || !(rescore_weight >= 0.0) || !(boost >= 0.0f))
+    return fail(NRTGPU_ERR_UNSUPPORTED, "hybrid tail: negative weights (combined scores must stay >= 0)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  HostPlan hp;
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  const double plan_ms = now_ms() - t0;
+  for (int si = 0; si < n_segs; ++si) {
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
+      return fail(NRTGPU_ERR_INVALID_ARG, "vector dimension mismatch");
+  }
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  hipStream_t st = slot->stream;
+  const uint32_t w_stride = round_up((uint32_t)std::min<int32_t>(window, NRTGPU_MAX_K), 16);
+  const size_t nq = (size_t)n_queries;
+  Carver ac;
+  const size_t o_segs = ac.take((size_t)std::max(n_segs, 1) * sizeof(DVecSeg)), o_qv = ac.take(nq * (size_t)dim * 4),
+               o_qn = ac.take(nq * 4);
+  const size_t in_bytes = ac.off;
+  const size_t o_wk = ac.take(nq * w_stride * 8), o_wc = ac.take(nq * 4);
+  if (int rc = slot->d_aux.reserve(ac.off)) return rc;
+  const size_t kb = nq * w_stride * 8, cb = nq * 4, hb = nq * 8;
+  Carver hc;
+  const size_t oh_in = hc.take(in_bytes), oh_k = hc.take(kb), oh_c = hc.take(cb), oh_fc = hc.take(cb), oh_h = hc.take(hb);
+  if (int rc = slot->h_aux.reserve(hc.off)) return rc;
+  char* ha = (char*)slot->h_aux.p;
+  char* da = (char*)slot->d_aux.p;
+  DVecSeg* hs = (DVecSeg*)(ha + oh_in + o_segs);
+  for (int si = 0; si < n_segs; ++si) {
+    DVecSeg v{};
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors) {
+      v.vecs = fit->second.d_vectors;
+      v.vnorm2 = fit->second.d_vnorm2;
+      v.ord_to_doc = fit->second.d_ord_to_doc;
+      v.n_vec = fit->second.n_vec;
+    }
+    v.doc_base = doc_bases[si];
+    v.max_doc = segs[si]->max_doc;
+    hs[si] = v;
+  }
+  memcpy(ha + oh_in + o_qv, query_vectors, nq * (size_t)dim * 4);
+  float* hqn = (float*)(ha + oh_in + o_qn);
+  for (size_t q = 0; q < nq; ++q) {  // |q|^2 in the order nrtgpu_rescore_vectors uses
+    const float* qv = query_vectors + q * (size_t)dim;
+    float qn = 0.f;
+    for (int d = 0; d < dim; ++d) {
+      volatile float p2 = qv[d] * qv[d];
+      qn = qn + p2;
+    }
+    hqn[q] = qn;
+  }
+  HIP_TRY(hipMemcpyAsync(da, ha + oh_in, in_bytes, hipMemcpyHostToDevice, st));
+  DeviceRun run;
+  {
+    std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
+    launch_hybrid_rescore(st, (uint32_t)n_queries, run.out_keys, run.out_counts, hp.k_stride, (const DVecSeg*)(da + o_segs), n_segs,
+                          dim, (const float*)(da + o_qv), (const float*)(da + o_qn), sim, boost, query_weight, rescore_weight,
+                          (uint32_t)window, (uint64_t*)(da + o_wk), (uint32_t*)(da + o_wc), w_stride);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  HIP_TRY(hipMemcpyAsync(ha + oh_k, da + o_wk, kb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ha + oh_c, da + o_wc, cb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ha + oh_fc, run.out_counts, cb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ha + oh_h, run.out_hits, hb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t* keys = (const uint64_t*)(ha + oh_k);
+  const uint32_t* cnts = (const uint32_t*)(ha + oh_c);
+  const uint32_t* first_cnts = (const uint32_t*)(ha + oh_fc);
+  const uint64_t* hits = (const uint64_t*)(ha + oh_h);
+  for (int qi = 0; qi < n_queries; ++qi) {
+    // QueryRescorer keeps the first pass's TotalHits; the window only trims the hits
+    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi], std::min<int32_t>(window, NRTGPU_MAX_K), queries[qi].total_hits_threshold, &out[qi]);
+    out[qi].total_hits_is_lower_bound = relation_gte((int64_t)hits[qi], (int32_t)first_cnts[qi], queries[qi].k, queries[qi].total_hits_threshold);
   }
   account(ctx, slot, hp, n_queries, plan_ms);
   return NRTGPU_OK;

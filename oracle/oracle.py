@@ -212,11 +212,16 @@ def _block_max(corpus, si: int, term_id: int, term_struct, key_extra) -> np.ndar
 def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequence[float]] = None,
                 after: Optional[Tuple[int, float]] = None, total_hits_threshold: int = 1000,
                 segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False,
-                maxscore: bool = False, stats: Optional[dict] = None):
+                maxscore: bool = False, stats: Optional[dict] = None,
+                accept: Optional[Sequence[Optional[np.ndarray]]] = None):
     """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr))
     executed as ONE slice (one collector visiting the leaves in docBase order).
     maxscore=True runs the dynamically pruned scorer (same top-k, totalHits a lower bound);
-    stats["postings_scored"] then accumulates the postings it touched."""
+    stats["postings_scored"] then accumulates the postings it touched.
+    accept[si] (uint64 words) replaces leaf si's liveDocs as the acceptDocs handed to the bulk scorer:
+    liveDocs & FILTER doc set & ~MUST_NOT doc set -- what BooleanWeight's conjunction of a FILTER clause
+    with the SHOULD disjunction (minimumNumberShouldMatch = 1) and its ReqExclScorer let through; such
+    clauses add nothing to the score."""
     weights, cache = bm25_query_stats(corpus, term_ids, boosts)
     col = Collector(k, after, total_hits_threshold)
     seg_ids = range(len(corpus.segments)) if segments is None else segments
@@ -243,6 +248,10 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
             present_ids.append(int(t))
             n_present += 1
         live = seg.live_bits.ctypes.data if seg.live_bits is not None else None
+        if accept is not None and accept[si] is not None:
+            acc_bits = np.ascontiguousarray(accept[si], dtype=np.uint64)
+            keep.append(acc_bits)
+            live = acc_bits.ctypes.data
         if maxscore:
             bms = [_block_max(corpus, si, present_ids[j], arr[j],
                               (float(arr[j].weight), omit_norms, omit_freqs)) for j in range(n_present)]

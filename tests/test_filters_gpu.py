@@ -1,0 +1,106 @@
+"""FILTER / MUST_NOT clauses as resident doc-set masks through the C ABI, against
+the oracle run with acceptDocs = liveDocs & filter & ~must_not.  Bit-exact, like every BM25 test."""
+import numpy as np
+import pytest
+
+from nrtsearch_amd import _lib, api, synth
+from oracle import oracle
+
+from tests.test_parity_gpu import Index, assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def random_mask(max_doc, density, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bits = np.zeros(((max_doc + 63) // 64) * 64, dtype=bool)
+    bits[:max_doc] = rng.random(max_doc) < density
+    return np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+
+
+def accept_of(seg, f, mn):
+    n = (seg.max_doc + 63) // 64
+    w = seg.live_bits.copy() if seg.live_bits is not None else np.full(n, ~np.uint64(0), dtype=np.uint64)
+    if f is not None:
+        w &= f
+    if mn is not None:
+        w &= ~mn
+    return w
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.GpuContext(device_id=0, max_batch=256)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("deletes", [0.0, 0.03])
+def test_filter_and_must_not_masks(ctx, deletes):
+    ranks = [1, 2, 4, 9, 30, 120, 700, 4000]
+    corpus = synth.build_corpus(200_000, ranks, n_segments=3, delete_fraction=deletes)
+    ix = Index(ctx, corpus)
+    try:
+        masks = {}
+        for si, (seg, leaf) in enumerate(zip(corpus.segments, ix.leaves)):
+            masks[(si, 7)] = random_mask(seg.max_doc, 0.30, 100 + si)   # a selective filter
+            masks[(si, 9)] = random_mask(seg.max_doc, 0.05, 200 + si)   # an exclusion list
+            masks[(si, 11)] = random_mask(seg.max_doc, 0.0005, 300 + si)  # nearly empty filter
+            for mid in (7, 9, 11):
+                leaf.set_mask(mid, masks[(si, mid)])
+        should = tuple(api.TermQuery(0, r) for r in (2, 30, 700))
+        terms = [2, 30, 700]
+        cases = [
+            ("filter", (7,), ()), ("must_not", (), (9,)), ("both", (7,), (9,)), ("tiny_filter", (11,), ()),
+            ("same_mask_both_ways", (7,), (7,)),
+        ]
+        for name, f, mn in cases:
+            for k, thr in ((10, 1000), (200, 1000), (50, 2**31 - 1)):
+                q = api.BooleanQuery(should, 1, tuple(api.MaskFilter(i) for i in f), tuple(api.MaskFilter(i) for i in mn))
+                got = ix.searcher.search(q, api.TopScoreDocCollectorManager(k, None, thr))
+                acc = [accept_of(seg, masks[(si, f[0])] if f else None, masks[(si, mn[0])] if mn else None)
+                       for si, seg in enumerate(corpus.segments)]
+                exp = oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, accept=acc)
+                assert_same(f"mask_{name}_{k}_{deletes}", got, exp, k, thr)
+                if name == "same_mask_both_ways":
+                    assert got.total_hits == 0 and len(got.docs) == 0
+        # a batch mixing masked and unmasked queries over the same leaves
+        qs = [api.BooleanQuery(should, 1, (api.MaskFilter(7),)), api.BooleanQuery(should), api.BooleanQuery(should, 0, (), (api.MaskFilter(9),))]
+        mg = [api.TopScoreDocCollectorManager(100)] * 3
+        res = ix.searcher.search_batch(qs, mg)
+        accs = [[accept_of(s, masks[(si, 7)], None) for si, s in enumerate(corpus.segments)], None,
+                [accept_of(s, None, masks[(si, 9)]) for si, s in enumerate(corpus.segments)]]
+        for i in range(3):
+            assert_same(f"mask_batch_{i}", res[i], oracle.search_bm25(corpus, terms, 100, accept=accs[i]), 100, 1000)
+        # new liveDocs invalidate the combined sets
+        if deletes:
+            for leaf in ix.leaves:
+                leaf.set_live_docs(None)
+            got = ix.searcher.search(qs[0], mg[0])
+            acc = [masks[(si, 7)] for si in range(len(corpus.segments))]
+            assert_same("mask_after_live_reset", got, oracle.search_bm25(corpus, terms, 100, accept=acc), 100, 1000)
+    finally:
+        ix.close()
+
+
+def test_mask_errors(ctx):
+    corpus = synth.build_corpus(5_000, [3, 50], n_segments=1)
+    ix = Index(ctx, corpus)
+    try:
+        should = (api.TermQuery(0, 3), api.TermQuery(0, 50))
+        with pytest.raises(_lib.NrtGpuError) as e:   # mask not resident: the caller runs the CPU path
+            ix.searcher.search(api.BooleanQuery(should, 1, (api.MaskFilter(5),)), api.TopScoreDocCollectorManager(10))
+        assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
+        with pytest.raises(api.UnsupportedQuery):    # Lucene would add score-0 hits for filter-only docs
+            ix.searcher.search(api.BooleanQuery(should, 0, (api.MaskFilter(5),)), api.TopScoreDocCollectorManager(10))
+        with pytest.raises(_lib.NrtGpuError) as e:
+            ix.leaves[0].set_mask(0, np.zeros(100, np.uint64))
+        assert e.value.code == _lib.NRTGPU_ERR_INVALID_ARG
+        with pytest.raises(_lib.NrtGpuError):
+            ix.leaves[0].set_mask(5, np.zeros(3, np.uint64))   # too few words
+        ix.leaves[0].set_mask(5, random_mask(5_000, 0.5, 1))
+        ix.leaves[0].set_mask(5, None)                          # dropped again
+        with pytest.raises(_lib.NrtGpuError):
+            ix.searcher.search(api.BooleanQuery(should, 1, (api.MaskFilter(5),)), api.TopScoreDocCollectorManager(10))
+    finally:
+        ix.close()

@@ -39,6 +39,74 @@ def _bq(terms):
     return api.BooleanQuery(tuple(api.TermQuery(0, int(t)) for t in terms))
 
 
+def test_fused_tail_equals_two_calls(hybrid, oracle):
+    """nrtgpu_search_hybrid_batch == search + rescore_vectors per query, bit for bit (same arithmetic, the
+    hits just never leave the device), for all similarities; then against the CPU restatement."""
+    sr, rng = hybrid["sr"], hybrid["rng"]
+    term_sets = [[1, 20, 300], [3, 8, 60, 2000], [2000], [1, 3, 8, 20, 60], [300, 2000]]
+    for sim, recall, window, qw, rw in [("cosine", 1000, 100, 1.0, 2.5), ("l2_norm", 200, 200, 0.5, 4.0),
+                                        ("max_inner_product", 64, 10, 1.0, 1.0), ("dot_product", 1000, 1000, 0.0, 1.0)]:
+        qs = [_bq(t) for t in term_sets]
+        mg = [api.TopScoreDocCollectorManager(recall)] * len(qs)
+        qv = rng.standard_normal((len(qs), DIM)).astype(np.float32)
+        if sim == "dot_product":
+            qv /= np.linalg.norm(qv, axis=1, keepdims=True)
+        fused = sr.search_hybrid_batch(qs, mg, VEC_FIELD, sim, qv, window, qw, rw)
+        for i, q in enumerate(qs):
+            first = sr.search(q, mg[i])
+            two = sr.rescore_vectors(first, VEC_FIELD, sim, qv[i], window, qw, rw)
+            assert fused[i].docs.tolist() == two.docs.tolist(), (sim, i)
+            assert fused[i].scores.view(np.uint32).tolist() == two.scores.view(np.uint32).tolist(), (sim, i)
+            assert fused[i].total_hits == first.total_hits and fused[i].relation_gte == first.relation_gte
+    bases = [s.doc_base for s in hybrid["corpus"].segments]
+    terms = [3, 8, 60, 2000]
+    q = rng.standard_normal(DIM).astype(np.float32)
+    got = sr.search_hybrid_batch([_bq(terms)], [api.TopScoreDocCollectorManager(500)], VEC_FIELD, "cosine", q[None, :], 50, 1.0, 3.0)[0]
+    edocs, escores, etotal, _ = oracle.search_bm25(hybrid["corpus"], terms, 500)
+    exp = []
+    for doc, f in zip(edocs.tolist(), escores.tolist()):
+        si = max(i for i, b in enumerate(bases) if b <= doc)
+        second = float(oracle.vector_score(0, q, hybrid["vecs"][si][doc - bases[si]]))
+        exp.append((float(oracle.rescore_combine(f, True, second, 1.0, 3.0)), doc))
+    exp.sort(key=lambda t: (-t[0], t[1]))
+    assert got.total_hits == etotal and len(got.docs) == 50
+    assert np.allclose(got.scores, [s for s, _ in exp[:50]], rtol=1e-5, atol=1e-6)
+    assert len(set(got.docs.tolist()) & set(d for _, d in exp[:50])) >= 49
+
+
+def test_fused_tail_sparse_vectors_and_errors():
+    """Leaves where only some docs have a vector (ord -> doc map) and one leaf without the field."""
+    rng = np.random.default_rng(5)
+    corpus = synth.build_corpus(30_000, [2, 9, 70], n_segments=3)
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves = []
+    try:
+        for si, seg in enumerate(corpus.segments):
+            g = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
+            g.add_field_norms(0, seg.norms)
+            g.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+            if si != 1:   # leaf 1 has no vectors: its hits keep queryWeight * first
+                have = np.flatnonzero(rng.random(seg.max_doc) < 0.6).astype(np.int32)
+                g.add_vectors(VEC_FIELD, rng.standard_normal((len(have), DIM)).astype(np.float32), have)
+            g.seal()
+            leaves.append(g)
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        qs = [_bq([2, 70]), _bq([9])]
+        mg = [api.TopScoreDocCollectorManager(300)] * 2
+        qv = rng.standard_normal((2, DIM)).astype(np.float32)
+        fused = sr.search_hybrid_batch(qs, mg, VEC_FIELD, "cosine", qv, 40, 1.0, 2.0)
+        for i in range(2):
+            two = sr.rescore_vectors(sr.search(qs[i], mg[i]), VEC_FIELD, "cosine", qv[i], 40, 1.0, 2.0)
+            assert fused[i].docs.tolist() == two.docs.tolist()
+            assert fused[i].scores.view(np.uint32).tolist() == two.scores.view(np.uint32).tolist()
+        with pytest.raises(Exception):   # negative weights would break the key order: refused, the caller runs two calls
+            sr.search_hybrid_batch(qs, mg, VEC_FIELD, "cosine", qv, 40, -1.0, 2.0)
+    finally:
+        for g in leaves:
+            g.release()
+        ctx.close()
+
+
 def test_bm25_recall_then_vector_rescore(hybrid, oracle):
     bases = [s.doc_base for s in hybrid["corpus"].segments]
     for terms, recall, window in [([1, 20, 300], 200, 50), ([3, 8, 60, 2000], 1000, 100)]:
