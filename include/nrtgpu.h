@@ -132,7 +132,11 @@ typedef struct {
   int32_t has_after;               /* searchAfter (LazyQueueTopScoreDocCollector.java:112-120) */
   int32_t after_doc;               /* global docid of the last hit of the previous page */
   float   after_score;
-  int32_t min_should_match;        /* 0 or 1 only */
+  int32_t min_should_match;        /* minimumNumberShouldMatch (QueryNodeMapper.java:259-261): 0 and 1 are the plain
+                                    * disjunction; > 1: only docs matched by that many clauses are hits, the score
+                                    * is still the sum over all matching clauses (what Lucene's WANDScorer returns).
+                                    * > 1 needs the fixed-point accumulators for the whole batch, else
+                                    * NRTGPU_ERR_UNSUPPORTED; not accepted by nrtgpu_search_bm25_coalesced */
   float   min_competitive_score;   /* Scorable.setMinCompetitiveScore across shards: a lower bound of the k-th best
                                     * score of the WHOLE search this call is one shard of (other GPUs' results so
                                     * far, LazyMaxScoreAccumulator).  Docs scoring strictly below it are counted in

@@ -277,8 +277,6 @@ def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int]
         raise UnsupportedQuery(f"clause {q!r} is not a (boosted) TermQuery")
 
     if isinstance(query, BooleanQuery):
-        if query.minimum_number_should_match > 1:
-            raise UnsupportedQuery("minimumNumberShouldMatch > 1")
         if not query.should:
             raise UnsupportedQuery("empty BooleanQuery")
         if len(query.filter) > 1 or len(query.must_not) > 1:

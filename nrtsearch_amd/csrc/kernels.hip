@@ -298,13 +298,20 @@ __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr
 
 // One LDS atomic per posting (invalid ones were redirected by group_prepare): ds_add_f64 of the fp32
 // score widened to double, or ds_add_u64 of the term's fixed-point integer shifted into the query's scale.
+// cnt_hi != 0 (minimumNumberShouldMatch variant, FX only): every valid posting (its entry is a positive
+// integer; redirected ones add 0) also adds one to the clause count kept above the score sum.
 template <bool FX>
-__device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const uint32_t (&val)[8], uint32_t fx_shift) {
+__device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const uint32_t (&val)[8], uint32_t fx_shift,
+                                                 uint32_t cnt_hi = 0) {
   const uint32_t fx_mult = 1u << fx_shift;  // entry << shift as one 32 x 32 -> 64 multiply (no 64-bit operand to set up)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (FX) atomicAdd((unsigned long long*)lds_ptr(off[j]), (unsigned long long)val[j] * (unsigned long long)fx_mult);  // v_mad_u64_u32
-    else unsafeAtomicAdd((double*)lds_ptr(off[j]), (double)__uint_as_float(val[j]));
+    if (FX) {
+      const unsigned long long c = (unsigned long long)(val[j] != 0u ? cnt_hi : 0u) << 32;  // the multiply's addend
+      atomicAdd((unsigned long long*)lds_ptr(off[j]), (unsigned long long)val[j] * (unsigned long long)fx_mult + c);  // v_mad_u64_u32
+    } else {
+      unsafeAtomicAdd((double*)lds_ptr(off[j]), (double)__uint_as_float(val[j]));
+    }
   }
 }
 
@@ -523,6 +530,12 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   const int fx_E = item.fx_E;
   unsigned long long* const my_theta_g = theta_g + item.query;
   const bool multi_item = q.n_items > 1;  // uniform: only then is there anybody to share theta with
+  // ABL == 8 (fixed point only): the variant for batches with minimumNumberShouldMatch > 1 queries.  Such a
+  // query's postings also count clauses in the accumulator's top bits; all its sub-tiles take the general
+  // sweep, whose exact path drops docs with too few clauses and strips the count.
+  constexpr bool kMsm = FX && ABL == 8;
+  const uint32_t msm = kMsm ? q.min_should_match : 0u;
+  const uint32_t cnt_hi = (kMsm && msm > 1u) ? (1u << (kMsmCountShift - 32)) : 0u;
 
   uint64_t t_start = 0, t_walk = 0;
   if (ABL == 7) t_start = __builtin_readcyclecounter();
@@ -599,7 +612,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     const uint32_t n_terms = part.n_terms;
     const DTerm* const part_terms = terms + part.term_begin;
     const NRT_GLOBAL uint64_t* const live_bits = (const NRT_GLOBAL uint64_t*)part.live_bits;
-    const bool simple = (live_bits == nullptr) && !q.has_after;  // uniform: no deletes, no searchAfter
+    const bool simple = (live_bits == nullptr) && !q.has_after && cnt_hi == 0u;  // uniform: no deletes, no searchAfter, no clause counting
     // lane l looks after term min(l, n_terms - 1) of this part (registers)
     const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     const uint64_t my_docids = (uint64_t)mt.docids, my_lo = mt.start;
@@ -659,7 +672,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
             Group a;
             group_locate_load(s, wave, n_terms, vb + lane, cur_groups, pre, a);
             group_prepare<FX, ABL>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
-            if (vb + lane < cur_groups) group_commit_add<FX>(off2, val2, a.meta >> 28);
+            if (vb + lane < cur_groups) group_commit_add<FX>(off2, val2, a.meta >> 28, cnt_hi);
           }
         }
         group_prepare<FX, ABL>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, val);
@@ -687,7 +700,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = a2[j] = acc_marker<FX>();
       if (cur_groups != 0) {
-        if (act && ABL != 2 && ABL != 4) group_commit_add<FX>(off, val, sh);
+        if (act && ABL != 2 && ABL != 4) group_commit_add<FX>(off, val, sh, cnt_hi);
         if (sparse && ABL != 2 && ABL != 3) {
           if (act2) group_commit_add<FX>(off2, val2, sh2);
           if (act) {
@@ -756,11 +769,15 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
               const int j = __ffs((int)mmask) - 1;
               mmask &= mmask - 1u;
               const uint32_t i = lane + 64u * (uint32_t)j;
-              const uint64_t v = acc[i];
+              uint64_t v = acc[i];
               if (v != acc_marker<FX>()) {
                 const uint32_t doc = base + i;
                 bool live = true;
                 if (!simple && live_bits) live = (live_bits[doc >> 6] >> (doc & 63u)) & 1ull;
+                if (kMsm && cnt_hi != 0u) {  // a hit needs msm matching clauses; from here on v is the bare score sum
+                  live = live && (uint32_t)(v >> kMsmCountShift) >= msm;
+                  v &= (1ull << kMsmCountShift) - 1ull;
+                }
                 bool cand = false;
                 if (live) {
                   if (!simple) ++my_hits;  // totalHits counts every collected doc, also those skipped by `after`
@@ -769,8 +786,12 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
                   const bool skip = q.has_after && (sc > q.after_score || (sc == q.after_score && (int32_t)gdoc <= q.after_doc));
                   if (!skip) cand = pack_key(sc, gdoc) > theta;
                 }
-                if (cand) cmask |= 1u << j;
-                else acc[i] = acc_marker<FX>();
+                if (cand) {
+                  cmask |= 1u << j;
+                  if (kMsm && cnt_hi != 0u) acc[i] = v;  // stays in place for the candidate copy / the rendezvous: without the count
+                } else {
+                  acc[i] = acc_marker<FX>();
+                }
               }
             }
           }
@@ -976,6 +997,7 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int 
     if (fixed_point) NRT_LAUNCH(true, P, A); \
     else NRT_LAUNCH(false, P, A);      \
   } while (0)
+  if (ablation == 8) { NRT_LAUNCH(true, true, 8); return; }  // minimumNumberShouldMatch > 1 somewhere in the batch (fixed point only)
   if (!pipelined) { NRT_LAUNCH_FX(false, 0); return; }
   switch (ablation) {
     case 1: NRT_LAUNCH(false, true, 1); break;  // 1-4: timing ablations of the fp64 kernel (wrong results)

@@ -91,9 +91,13 @@ struct alignas(16) DQuery {
   float    after_score;
   uint32_t item_begin;     // items of this query are [item_begin, item_begin + n_items)
   uint32_t n_items;
-  uint32_t pad0, pad1;
+  uint32_t min_should_match;  // > 1: only docs matched by that many clauses are hits (count-carrying kernel variant)
+  uint32_t pad1;
 };
 static_assert(sizeof(DQuery) == 32, "DQuery layout");
+// minimumNumberShouldMatch > 1: the fixed-point accumulator carries the number of matching clauses above
+// the score sum (sum < 2^52: 32 clauses x 2^32 x 2^15)
+constexpr int kMsmCountShift = 56;
 
 // Cross-GPU bound exchange of one batch (nrtgpu_exchange_open): entry (rank r, query q) of the batch's
 // slot holds (tag << 32) | score word that at least ceil(k / world) docs of rank r's shard reach.

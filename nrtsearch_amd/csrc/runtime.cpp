@@ -731,6 +731,7 @@ struct HostPlan {
   uint32_t k_stride = 0;
   int64_t postings = 0;             // postings in the scanned term ranges (algorithmic work)
   bool fixed_point = false;         // every query of the batch passed the fixed-point range analysis
+  bool clause_counting = false;     // some query has minimumNumberShouldMatch > 1: count-carrying kernel variant
 };
 
 static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
@@ -742,7 +743,7 @@ static int validate_query(const nrtgpu_bm25_query& q, int qi) {
   if (q.k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: numHits %d > %d", qi, q.k, NRTGPU_MAX_K);
   if (q.n_terms <= 0 || !q.terms) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: no terms", qi);
   if (q.n_terms > NRTGPU_MAX_TERMS) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d clauses > %d", qi, q.n_terms, NRTGPU_MAX_TERMS);
-  if (q.min_should_match > 1) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: minimumNumberShouldMatch %d", qi, q.min_should_match);
+  if (q.min_should_match < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: minimumNumberShouldMatch %d", qi, q.min_should_match);
   if (q.n_caches <= 0 || !q.norm_cache) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: norm_cache missing", qi);
   if (q.n_caches > kLdsCaches) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d scored fields > %d", qi, q.n_caches, kLdsCaches);
   for (int t = 0; t < q.n_terms; ++t) {
@@ -953,6 +954,14 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
   hp.fixed_point = (ctx->cfg.flags & NRTGPU_FLAG_NO_FIXED_POINT) == 0;
   for (int qi = 0; qi < n_queries && hp.fixed_point; ++qi)
     if (!per_query[(size_t)qi].empty() && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
+  // minimumNumberShouldMatch > 1 (QueryNodeMapper.java:259-261): the clause count rides in the fixed-point
+  // accumulator, so the whole batch must be in fixed-point mode; otherwise the caller runs Lucene's WANDScorer
+  hp.clause_counting = false;
+  for (int qi = 0; qi < n_queries; ++qi)
+    if (queries[qi].min_should_match > 1) hp.clause_counting = true;
+  if (hp.clause_counting && !hp.fixed_point)
+    return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 needs the fixed-point accumulators (weights of a query in "
+                                        "this batch span too many binades, or NRTGPU_FLAG_NO_FIXED_POINT is set)");
 
   // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
   // may span several segments (like a LeafSlice) and a large segment may be cut by tile range.
@@ -1047,6 +1056,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     dq.after_score = q.after_score;
     dq.item_begin = hp.q_base[(size_t)qi];
     dq.n_items = hp.q_nlists[(size_t)qi];
+    dq.min_should_match = (uint32_t)std::max(q.min_should_match, 0);
   }
   return 0;
 }
@@ -1126,7 +1136,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_okeys = wc.take((size_t)n_queries * k_stride_out * 8);
   const size_t o_ocnt = wc.take((size_t)n_queries * 4);
   const size_t o_ohits = wc.take((size_t)n_queries * 8);
-  const int ablation = (ctx->cfg.flags >> 8) & 15;
+  const int ablation = hp.clause_counting ? 8 : ((ctx->cfg.flags >> 8) & 15);
   const size_t o_prof = wc.take(ablation == 7 ? n_items * 128 : 0);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   char* db = (char*)slot->d_plan.p;
@@ -1393,6 +1403,8 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
   if (!ctx || !q || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_segs must be >= 0");
   if (int rc = validate_query(*q, 0)) return rc;  // a bad request must not fail its batch mates
+  if (q->min_should_match > 1)  // whether it can run depends on the whole batch (fixed-point mode): use the batch call
+    return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 is not coalesced");
   for (int si = 0; si < n_segs; ++si) {
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
     if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);

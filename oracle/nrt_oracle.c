@@ -239,6 +239,16 @@ int32_t nrt_oracle_collector_topdocs(nrt_oracle_collector* c, int32_t* docs, flo
 void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
                                int32_t n_terms, const nrt_oracle_term* terms,
                                nrt_oracle_collector* collector) {
+  nrt_oracle_search_segment_msm(max_doc, doc_base, live_bits, n_terms, terms, 1, collector);
+}
+
+/* BooleanQuery.Builder.setMinimumNumberShouldMatch(n) (src/main/java/com/yelp/nrtsearch/server/query/
+ * QueryNodeMapper.java:259-261): a doc is a hit iff at least n SHOULD clauses match it (every clause
+ * counts, also a repeated term); its score is still the sum over ALL its matching clauses (Lucene's
+ * WANDScorer / MinShouldMatchSumScorer contract).  n <= 1 is the plain disjunction. */
+void nrt_oracle_search_segment_msm(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                                   int32_t n_terms, const nrt_oracle_term* terms, int32_t min_should_match,
+                                   nrt_oracle_collector* collector) {
   double acc[ORACLE_WINDOW];
   uint8_t matched[ORACLE_WINDOW];
   int64_t* cursor = (int64_t*)calloc((size_t)(n_terms > 0 ? n_terms : 1), sizeof(int64_t));
@@ -263,14 +273,15 @@ void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t
           uint8_t norm = tm->norms ? tm->norms[d] : (uint8_t)1;
           float s = nrt_oracle_bm25_score(tm->weight, freq, tm->cache[norm]);
           acc[d - base] += (double)s;
-          matched[d - base] = 1;
+          matched[d - base]++;
         }
         cursor[t] = p;
       }
     }
     if (!any) continue;
+    const int need = min_should_match > 1 ? min_should_match : 1;
     for (int32_t d = base; d < end; ++d) {
-      if (!matched[d - base]) continue;
+      if (matched[d - base] < need) continue;
       if (live_bits && !((live_bits[d >> 6] >> (d & 63)) & 1ULL)) continue;
       nrt_oracle_collector_collect(collector, d, (float)acc[d - base]);
     }

@@ -73,6 +73,12 @@ void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t
                                int32_t n_terms, const nrt_oracle_term* terms,
                                nrt_oracle_collector* collector);
 
+/* The same with minimumNumberShouldMatch (QueryNodeMapper.java:259-261): hits need that many matching
+ * clauses, scores still sum every matching clause. */
+void nrt_oracle_search_segment_msm(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                                   int32_t n_terms, const nrt_oracle_term* terms, int32_t min_should_match,
+                                   nrt_oracle_collector* collector);
+
 /*
  * The same search with MaxScore dynamic pruning (the algorithm family of Lucene's
  * MaxScoreBulkScorer): identical top-k, totalHits a lower bound.

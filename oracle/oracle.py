@@ -77,6 +77,9 @@ def lib():
         L.nrt_oracle_collector_topdocs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.nrt_oracle_search_segment.restype = None
         L.nrt_oracle_search_segment.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.nrt_oracle_search_segment_msm.restype = None
+        L.nrt_oracle_search_segment_msm.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                                    C.c_void_p]
         L.nrt_oracle_block_max.restype = None
         L.nrt_oracle_block_max.argtypes = [C.c_void_p, C.c_void_p]
         L.nrt_oracle_search_segment_maxscore.restype = None
@@ -213,7 +216,7 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
                 after: Optional[Tuple[int, float]] = None, total_hits_threshold: int = 1000,
                 segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False,
                 maxscore: bool = False, stats: Optional[dict] = None,
-                accept: Optional[Sequence[Optional[np.ndarray]]] = None):
+                accept: Optional[Sequence[Optional[np.ndarray]]] = None, min_should_match: int = 0):
     """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr))
     executed as ONE slice (one collector visiting the leaves in docBase order).
     maxscore=True runs the dynamically pruned scorer (same top-k, totalHits a lower bound);
@@ -258,6 +261,9 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
             ptrs = (C.c_void_p * max(n_present, 1))(*[b.ctypes.data for b in bms])
             lib().nrt_oracle_search_segment_maxscore(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr),
                                                      C.byref(ptrs), col._h, C.byref(scored))
+        elif min_should_match > 1:
+            lib().nrt_oracle_search_segment_msm(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr),
+                                                int(min_should_match), col._h)
         else:
             lib().nrt_oracle_search_segment(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr), col._h)
     if stats is not None:

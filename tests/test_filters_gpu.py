@@ -104,3 +104,73 @@ def test_mask_errors(ctx):
             ix.searcher.search(api.BooleanQuery(should, 1, (api.MaskFilter(5),)), api.TopScoreDocCollectorManager(10))
     finally:
         ix.close()
+
+
+# ---- minimumNumberShouldMatch > 1 (clause count carried in the fixed-point accumulators) ----------------
+@pytest.mark.parametrize("deletes", [0.0, 0.02])
+def test_minimum_should_match(ctx, deletes):
+    ranks = [1, 2, 3, 6, 15, 50, 400]
+    corpus = synth.build_corpus(250_000, ranks, n_segments=3, delete_fraction=deletes)
+    ix = Index(ctx, corpus)
+    try:
+        terms = [1, 3, 6, 15, 400]
+        should = tuple(api.TermQuery(0, t) for t in terms)
+        for msm in (2, 3, 5, 6):
+            for k, thr in ((10, 1000), (1000, 1000), (100, 2**31 - 1)):
+                got = ix.searcher.search(api.BooleanQuery(should, msm), api.TopScoreDocCollectorManager(k, None, thr))
+                exp = oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, min_should_match=msm)
+                assert_same(f"msm{msm}_{k}_{deletes}", got, exp, k, thr)
+                if msm == 6:
+                    assert got.total_hits == 0
+        # a repeated clause counts twice (every clause is its own scorer)
+        dup = [2, 2, 50]
+        got = ix.searcher.search(api.BooleanQuery(tuple(api.TermQuery(0, t) for t in dup), 2), api.TopScoreDocCollectorManager(50))
+        assert_same("msm_dup", got, oracle.search_bm25(corpus, dup, 50, min_should_match=2), 50, 1000)
+        # boosted clauses, paging
+        boosts = [1.0, 2.5, 0.5, 3.0, 1.0]
+        bq_ = api.BooleanQuery(tuple(api.BoostQuery(api.TermQuery(0, t), b) for t, b in zip(terms, boosts)), 2)
+        first = ix.searcher.search(bq_, api.TopScoreDocCollectorManager(40))
+        assert_same("msm_boost_p1", first, oracle.search_bm25(corpus, terms, 40, boosts=boosts, min_should_match=2), 40, 1000)
+        after = api.ScoreDoc(int(first.docs[-1]), float(first.scores[-1]))
+        second = ix.searcher.search(bq_, api.TopScoreDocCollectorManager(40, after))
+        assert_same("msm_boost_p2", second,
+                    oracle.search_bm25(corpus, terms, 40, boosts=boosts, min_should_match=2, after=(after.doc, after.score)), 40, 1000)
+        # a batch mixing counted and plain queries, and a mask next to the count
+        masks = [random_mask(s.max_doc, 0.4, 900 + i) for i, s in enumerate(corpus.segments)]
+        for leaf, m in zip(ix.leaves, masks):
+            leaf.set_mask(3, m)
+        qs = [api.BooleanQuery(should, 3), api.BooleanQuery(should), api.BooleanQuery(should, 2, (api.MaskFilter(3),)),
+              api.TermQuery(0, 50)]
+        res = ix.searcher.search_batch(qs, [api.TopScoreDocCollectorManager(200)] * 4)
+        acc = [accept_of(s, masks[i], None) for i, s in enumerate(corpus.segments)]
+        assert_same("msm_batch0", res[0], oracle.search_bm25(corpus, terms, 200, min_should_match=3), 200, 1000)
+        assert_same("msm_batch1", res[1], oracle.search_bm25(corpus, terms, 200), 200, 1000)
+        assert_same("msm_batch2", res[2], oracle.search_bm25(corpus, terms, 200, min_should_match=2, accept=acc), 200, 1000)
+        assert_same("msm_batch3", res[3], oracle.search_bm25(corpus, [50], 200), 200, 1000)
+        assert ctx.stats()["fixed_point_launches"] > 0
+        # weights too far apart for the fixed-point accumulators: refused, the caller runs Lucene
+        wide = api.BooleanQuery((api.BoostQuery(api.TermQuery(0, 1), 1e-6), api.BoostQuery(api.TermQuery(0, 400), 1e6)), 2)
+        with pytest.raises(_lib.NrtGpuError) as e:
+            ix.searcher.search(wide, api.TopScoreDocCollectorManager(10))
+        assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
+        with pytest.raises(_lib.NrtGpuError) as e:   # depends on the whole batch: not coalesced
+            ix.searcher.search_coalesced(api.BooleanQuery(should, 2), api.TopScoreDocCollectorManager(10))
+        assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
+    finally:
+        ix.close()
+
+
+def test_minimum_should_match_full_tiles(ctx):
+    """Dense terms over many sub-tiles and several items per query (k-th best shared between items)."""
+    ranks = [1, 2, 3, 4, 5]
+    corpus = synth.build_corpus(1_500_000, ranks, n_segments=2)
+    c2 = api.GpuContext(device_id=0, max_batch=64, target_items=64)
+    ix = Index(c2, corpus)
+    try:
+        for msm, k in ((2, 1000), (4, 100), (5, 10)):
+            got = ix.searcher.search(api.BooleanQuery(tuple(api.TermQuery(0, t) for t in ranks), msm),
+                                     api.TopScoreDocCollectorManager(k))
+            assert_same(f"msm_dense_{msm}", got, oracle.search_bm25(corpus, ranks, k, min_should_match=msm), k, 1000)
+    finally:
+        ix.close()
+        c2.close()
