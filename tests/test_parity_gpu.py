@@ -364,8 +364,8 @@ def test_argument_errors(mid):
     with pytest.raises(api.NrtGpuError) as e:   # beyond the device fast path: caller falls back to Lucene
         mid.searcher.search(bq([1]), api.TopScoreDocCollectorManager(5000))
     assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
-    with pytest.raises(api.UnsupportedQuery):
-        mid.searcher.search(api.BooleanQuery((api.TermQuery(0, 1), api.TermQuery(0, 2)), 2),
+    with pytest.raises(api.UnsupportedQuery):   # a nested clause is not an eligible shape
+        mid.searcher.search(api.BooleanQuery((api.BooleanQuery((api.TermQuery(0, 1),)), api.TermQuery(0, 2))),
                             api.TopScoreDocCollectorManager(5))
 
 
