@@ -222,6 +222,17 @@ int  nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
                       int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k,
                       float boost, nrtgpu_topdocs* out /* n_queries */);
 
+/* The `knn` request path (KnnQuery -> NrtKnnFloatVectorQuery, src/main/java/com/yelp/nrtsearch/server/field/
+ * VectorFieldDef.java:564-594, executed at search/KnnUtils.java:56) answered exactly: the k nearest docs among
+ * those the pre-filter accepts (filter_mask: a resident mask, 0 = none; liveDocs always apply), optionally only
+ * docs whose unboosted score is >= min_score (the MinThresholdQuery wrapped around the knn query at
+ * VectorFieldDef.java:591-594; the caller converts similarityThreshold with similarityToScore, :664-673;
+ * 0 = none), scores multiplied by boost afterwards.  total_hits = hits returned, as for the rewritten
+ * knn query.  Recall is 1.0 where the reference's HNSW walk is approximate. */
+int  nrtgpu_knn_search(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                       int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k,
+                       float boost, int32_t filter_mask, float min_score, nrtgpu_topdocs* out /* n_queries */);
+
 /* Vector rescorer: RescoreOperation.rescore(hits, ctx) of a QueryRescore whose rescoreQuery is an exact
  * vector query (src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-57): every
  * first-pass hit gets combined = (float)(queryWeight * first + rescoreWeight * vectorScore) (double

@@ -415,6 +415,27 @@ class GpuIndexSearcher:
         return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
                         bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
 
+    def knn_search(self, field: int, similarity: str, queries: np.ndarray, k: int, boost: float = 1.0,
+                   filter: Optional[MaskFilter] = None, min_score: float = 0.0) -> List[TopDocs]:
+        """The `knn` request path (KnnQuery with filter and similarity threshold) answered by exact search."""
+        queries = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        if similarity == "normalized_cosine":
+            queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True).astype(np.float32), dtype=np.float32)
+        nq, dim = queries.shape
+        outs = (_lib.TopDocs * nq)()
+        docs = np.zeros((nq, k), dtype=np.int32)
+        scores = np.zeros((nq, k), dtype=np.float32)
+        for qi in range(nq):
+            outs[qi].capacity = k
+            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_knn_search(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
+                                                 self.SIMILARITY[similarity], queries.ctypes.data, nq, dim, int(k),
+                                                 C.c_float(boost), int(filter.mask_id) if filter else 0,
+                                                 C.c_float(min_score), outs))
+        return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
+                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
+
     def rescore_vectors(self, hits: TopDocs, field: int, similarity: str, query: np.ndarray, window: int,
                         query_weight: float = 1.0, rescore_weight: float = 1.0, boost: float = 1.0) -> TopDocs:
         """RescoreOperation.rescore with a QueryRescore whose rescoreQuery is an exact vector query

@@ -1628,9 +1628,13 @@ extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_
 static const uint32_t kKnnCap = 1u << 18;   // candidate keys per query and round (2 MiB)
 static const int kKnnMaxQ = 32;
 
-extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-                                int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
-                                int32_t k, float boost, nrtgpu_topdocs* out) {
+// Shared by the two vector entry points.  knn_request = false: ExactVectorQuery (every doc with a vector
+// matches, boost inside the score).  knn_request = true: the `knn` request path -- pre-filter mask, score
+// threshold on the unboosted score (MinThresholdQuery's MinScoreWrapper), boost applied afterwards,
+// totalHits = the docs returned.
+static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                    int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
+                    int32_t k, float boost, bool knn_request, int32_t filter_mask, float min_score, nrtgpu_topdocs* out) {
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || k <= 0 || dim <= 0 || sim < 0 || sim > 3) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
@@ -1670,6 +1674,11 @@ extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
     HIP_TRY(hipMemcpyAsync(wb + o_q, queries + (size_t)q0 * dim, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(wb + o_qn, qn.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(wb + o_th, 0, wc.off - o_th > 0 ? (o_cd - o_th) : 0, st));  // theta, topk, counters
+    if (knn_request && min_score > 0.0f) {  // start theta just below the lowest key of that score: score >= min_score passes
+      std::vector<uint64_t> th0((size_t)nq, pack_key(min_score, 0xFFFFFFFFu) - 1ull);
+      HIP_TRY(hipMemcpyAsync(wb + o_th, th0.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
+    }
     int64_t total_vec = 0;
     for (int si = 0; si < n_segs; ++si) {
       const nrtgpu_seg* seg = segs[si];
@@ -1677,14 +1686,17 @@ extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
       if (fit == seg->fields.end() || !fit->second.d_vectors) continue;
       const FieldData& f = fit->second;
       total_vec += f.n_vec;
+      const uint64_t* accept = seg->d_live;
+      if (knn_request)
+        if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
       // rounds never exceed the candidate capacity, so a list cannot overflow; theta tightens between rounds
       int64_t r = 0, round = 1 << 16;
       while (r < f.n_vec) {
         const int64_t re = std::min<int64_t>(f.n_vec, r + std::min<int64_t>(round, kKnnCap));
         const uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
-        const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, seg->d_live, dim, r, re,
+        const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
                                        doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
-                                       sim, boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
+                                       sim, knn_request ? 1.0f : boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
                                        (uint32_t*)(wb + o_cc), kKnnCap);
         if (e) return fail(NRTGPU_ERR_HIP, "knn_score launch: %s", hipGetErrorString((hipError_t)e));
         launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), k_stride, (uint32_t)k,
@@ -1712,9 +1724,33 @@ extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
       o->n_hits = m;
       o->total_hits = total_vec;   // every doc with a vector matches an exact vector query (deletes not subtracted)
       o->total_hits_is_lower_bound = 0;
+      if (knn_request) {
+        o->total_hits = m;  // the rewritten knn query matches exactly the docs it returns
+        if (boost != 1.0f && o->scores) {
+          for (int32_t i = 0; i < m; ++i) o->scores[i] = o->scores[i] * boost;
+          // distinct scores can round to one product: restore (score desc, doc asc) among equals
+          if (o->docs)
+            for (int32_t i = 1; i < m; ++i)
+              for (int32_t j = i; j > 0 && o->scores[j - 1] == o->scores[j] && o->docs[j - 1] > o->docs[j]; --j) std::swap(o->docs[j - 1], o->docs[j]);
+        }
+      }
     }
   }
   return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
+                                int32_t k, float boost, nrtgpu_topdocs* out) {
+  return knn_impl(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, false, 0, 0.0f, out);
+}
+
+extern "C" int nrtgpu_knn_search(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                 int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
+                                 int32_t k, float boost, int32_t filter_mask, float min_score, nrtgpu_topdocs* out) {
+  if (filter_mask < 0 || !(min_score >= 0.0f) || !(boost > 0.0f))
+    return fail(NRTGPU_ERR_INVALID_ARG, "knn search: filter_mask >= 0, min_score >= 0 and boost > 0 expected");
+  return knn_impl(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, true, filter_mask, min_score, out);
 }
 
 extern "C" int nrtgpu_rescore_vectors(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,

@@ -190,3 +190,52 @@ def test_knn_unsupported_dimension_falls_back(ctx):
         sr.knn_exact(0, "cosine", np.ones((1, 3), np.float32), 5)
     assert e.value.code == -4
     g.release()
+
+
+def test_knn_search_prefilter_and_threshold(ctx, oracle):
+    """The `knn` request path answered exactly: pre-filter mask (KnnFloatVectorQuery's filter), score threshold
+    on the unboosted score (MinThresholdQuery, MinThresholdQuery.java:201), boost afterwards."""
+    rng = np.random.default_rng(99)
+    dim = 64
+    segs = make_segments(rng, [4000, 2500, 900], dim, sparse_ords=True, deletes=True)
+    leaves = upload(ctx, segs)
+    masks = []
+    for (base, vecs, o2d, live, max_doc), leaf in zip(segs, leaves):
+        m = rng.random(max_doc) < 0.25
+        masks.append(m)
+        padded = np.zeros(((max_doc + 63) // 64) * 64, dtype=bool)
+        padded[:max_doc] = m
+        leaf.set_mask(4, np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1))
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics())
+    queries = rng.standard_normal((3, dim)).astype(np.float32)
+    for sim_name, sim in (("cosine", 0), ("l2_norm", 2)):
+        for use_filter in (False, True):
+            osegs = []
+            for (b, v, o, l, max_doc), m in zip(segs, masks):
+                acc = np.ones(max_doc, bool) if l is None else l.copy()
+                if use_filter:
+                    acc &= m
+                osegs.append((b, v, o, acc))
+            for qi in range(len(queries)):
+                full, _ = brute_force(oracle, sim, queries[qi], osegs, 10**9)
+                thr = full[60][0]          # a threshold that cuts the list inside the top 100
+                for k, min_score, boost in ((20, 0.0, 1.0), (100, thr, 1.0), (100, thr, 2.0), (100, full[0][0] * 2 + 1, 1.0)):
+                    got = sr.knn_search(3, sim_name, queries[qi], k, boost=boost, filter=api.MaskFilter(4) if use_filter else None,
+                                        min_score=min_score)[0]
+                    exp = [(float(np.float32(s) * np.float32(boost)), d) for s, d in full if s >= min_score][:k]
+                    if min_score > 0 and exp:   # near the threshold the MFMA score may fall on either side
+                        lo = [e for e in exp if e[0] / boost >= min_score * (1 + 1e-4) + L2_ATOL]
+                        assert len(lo) <= len(got.docs) <= len([s for s, _ in full if s >= min_score * (1 - 1e-4) - L2_ATOL][:k])
+                        exp = exp[: len(got.docs)]
+                        if len(exp) < len(got.docs):
+                            continue
+                    check_hits(got, exp, sim)
+                    assert got.total_hits == len(got.docs)
+                    if use_filter:
+                        for d in got.docs.tolist():
+                            si = max(i for i, sg in enumerate(segs) if sg[0] <= d)
+                            assert masks[si][d - segs[si][0]]
+    with pytest.raises(api.NrtGpuError):
+        sr.knn_search(3, "cosine", queries[0], 10, filter=api.MaskFilter(77))   # mask not resident
+    for g in leaves:
+        g.release()
