@@ -61,6 +61,7 @@ typedef struct {
 
 #define NRTGPU_FLAG_NO_PREFETCH 1     /* scan kernel without the one-tile-ahead posting prefetch (A/B) */
 #define NRTGPU_FLAG_NO_FIXED_POINT 2  /* always accumulate in fp64 (A/B; results are identical either way) */
+#define NRTGPU_FLAG_NO_MASK_VARIANT 4   /* A/B: docs outside liveDocs / a mask are checked one by one (general sweep) */
 
 const char* nrtgpu_version(void);
 const char* nrtgpu_last_error(void);

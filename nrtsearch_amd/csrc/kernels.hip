@@ -73,8 +73,17 @@ __device__ __forceinline__ uint64_t acc_threshold(uint64_t theta_key, int fx_E) 
 }
 template <bool FX>
 __device__ __forceinline__ bool acc_reaches(uint64_t a, uint64_t thr) {
-  return FX ? (a >= thr) : ((long long)a >= (long long)thr);
+  return (long long)a >= (long long)thr;  // fixed-point sums stay below 2^53: signed works for both, and keeps kAccDead out
 }
+// Masked variant (deletes / FILTER / MUST_NOT as a doc-set mask): the slot of a doc outside the mask is
+// poisoned before its sub-tile is scored -- a value that absorbs every add and is negative as int64
+// (fixed point: the top bit above any sum; fp64: -infinity) -- so such docs are neither hits nor
+// candidates, at a cost per sub-tile instead of per posting.  A hit is then a slot that is neither the
+// marker nor poisoned: one signed compare.
+template <bool FX>
+__device__ __forceinline__ constexpr uint64_t acc_dead() { return FX ? 0x8000000000000000ull : 0xFFF0000000000000ull; }
+template <bool FX>
+__device__ __forceinline__ bool acc_is_hit(uint64_t a) { return FX ? ((long long)a > 0ll) : ((long long)a >= 0ll); }
 
 // LDS byte addresses as plain 32-bit integers: the accumulator address of a posting is then ONE
 // shift-add from its docid, with no pointer arithmetic left for the LDS instruction.
@@ -473,6 +482,34 @@ __device__ __forceinline__ uint32_t reserve_candidates(ScanSmem& s, uint32_t lan
   return wbase + incl - mine;
 }
 
+// Write `value` into the slots of my sub-tile whose docs are outside the mask.  live_word: lane l < 32 holds
+// bits [32 l, 32 l + 32) of the sub-tile's 1024 mask bits (set = inside), other lanes all ones.  A few docs
+// outside (deletes): one LDS write per such doc; many (a selective filter): every lane visits its 16 slots.
+// Out of line (like the rendezvous): inlined into the walk's loop it costs the loop ~30 spilled registers.
+typedef __attribute__((address_space(3))) uint64_t* lds_u64_ptr;
+__device__ __noinline__ void mark_outside(lds_u64_ptr acc, uint32_t lane, uint32_t live_word, uint64_t value) {
+  uint32_t dead = ~live_word;
+  const uint32_t most = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32((uint32_t)__popc(dead)), 63);
+  if (most == 0u) return;
+  if (most <= 6u) {
+    while (__any(dead != 0u)) {
+      if (dead) {
+        const uint32_t b = (uint32_t)__ffs((int)dead) - 1u;
+        dead &= dead - 1u;
+        acc[lane * 32u + b] = value;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {  // slot lane + 64 j is bit (lane & 31) of word 2 j + (lane >> 5)
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)live_word, 2 * j);
+      const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)live_word, 2 * j + 1);
+      const uint32_t w = lane < 32u ? w0 : w1;
+      if (!((w >> (lane & 31u)) & 1u)) acc[lane + 64u * (uint32_t)j] = value;  // (slots inside the mask may hold parked candidates)
+    }
+  }
+}
+
 // Sparse collect of one pair's swapped-out slot values a[j] (the marker where this posting is not its
 // doc's collector): count the hits, send the competitive docs to the shared candidate buffer.
 // Returns true when they did not fit and were parked back into the sub-tile.
@@ -483,7 +520,7 @@ __device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, 
   unsigned long long any_maybe = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(a[j] != acc_marker<FX>()));
+    wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ABL == 9 ? acc_is_hit<FX>(a[j]) : a[j] != acc_marker<FX>()));
     any_maybe |= __builtin_amdgcn_ballot_w64(acc_reaches<FX>(a[j], thr));
   }
   if (any_maybe == 0ull || ABL == 6) return false;  // wave-uniform; the steady state once theta has converged
@@ -612,7 +649,25 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     const uint32_t n_terms = part.n_terms;
     const DTerm* const part_terms = terms + part.term_begin;
     const NRT_GLOBAL uint64_t* const live_bits = (const NRT_GLOBAL uint64_t*)part.live_bits;
-    const bool simple = (live_bits == nullptr) && !q.has_after && cnt_hi == 0u;  // uniform: no deletes, no searchAfter, no clause counting
+    // uniform: no searchAfter, no clause counting, and no doc-set mask -- unless this is the masked variant
+    // (ABL == 9), which poisons the slots outside the mask instead of checking every matched doc
+    constexpr bool kMask = ABL == 9;
+    const bool simple = (live_bits == nullptr || kMask) && !q.has_after && cnt_hi == 0u;
+    const bool masked = kMask && live_bits != nullptr && simple;
+    const uint32_t mask_words = ((part.max_doc + 63u) >> 6) << 1;  // 32-bit words of the part's mask
+    auto mask_word_of = [&](uint32_t g) -> uint32_t {  // lane l < 32: bits of docs [32 l, 32 l + 32) of sub-tile g
+      const uint32_t wi = (g + tile_bias) * (uint32_t)(kTileDocs / 32) + lane;
+      return (lane < (uint32_t)(kTileDocs / 32) && wi < mask_words) ? ((const NRT_GLOBAL uint32_t*)live_bits)[wi] : 0xFFFFFFFFu;
+    };
+    // The mask bits of the current sub-tile are kept in LDS, not in registers (the walk has none to spare): in
+    // row 0 of the score tables (freq 0: written when the tables are built, never read), 32 words per wave.
+    static_assert(kScanWaves * 32 <= kTabTerms * kTabNorms, "mask words of all waves fit the unused table rows");
+    uint32_t* const w_mask = &s.tab[wave >> 2][(wave & 3u) * 32u];
+    if (masked) {  // (entering a part, or resuming after a rendezvous: the sub-tile holds markers only)
+      const uint32_t w = mask_word_of(g_cur);
+      if (lane < 32u) w_mask[lane] = w;
+      mark_outside((lds_u64_ptr)acc, lane, w, acc_dead<FX>());
+    }
     // lane l looks after term min(l, n_terms - 1) of this part (registers)
     const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     const uint64_t my_docids = (uint64_t)mt.docids, my_lo = mt.start;
@@ -741,7 +796,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
                 const int j = h * 4 + jj;
-                const bool matched = v[jj] != acc_marker<FX>();
+                const bool matched = kMask ? acc_is_hit<FX>(v[jj]) : v[jj] != acc_marker<FX>();
                 wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(matched));
                 const bool maybe = acc_reaches<FX>(v[jj], thr);  // implies matched
                 any_maybe |= __builtin_amdgcn_ballot_w64(maybe);
@@ -758,7 +813,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 #pragma unroll
               for (int j = 0; j < kSlots; ++j) v[j] = acc[lane + 64u * (uint32_t)j];
 #pragma unroll
-              for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(v[j] != acc_marker<FX>()) << j;
+              for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(kMask ? acc_is_hit<FX>(v[j]) : v[j] != acc_marker<FX>()) << j;
             } else {
               mmask = (1u << kSlots) - 1u;
             }
@@ -815,6 +870,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 
       // ---- (5) advance.  Somebody's candidates did not fit (seen at the next sub-tile boundary at the
       //      latest): leave the walk for the rendezvous
+      if (masked)  // un-poison: only parked candidates may stay
+        mark_outside((lds_u64_ptr)acc, lane, lane < 32u ? w_mask[lane] : 0xFFFFFFFFu, acc_marker<FX>());
       g_cur = g_nxt;
       g_nxt = g_nxt2;
       g_nxt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
@@ -823,6 +880,11 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         break;
       }
       if (g_cur >= gn) break;  // the next sub-tile lies in a later part (or past the item)
+      if (masked) {  // poison the next sub-tile: nothing of it has been added yet
+        const uint32_t w = mask_word_of(g_cur);
+        if (lane < 32u) w_mask[lane] = w;
+        mark_outside((lds_u64_ptr)acc, lane, w, acc_dead<FX>());
+      }
     }
     if (interrupted) break;
   }
@@ -997,7 +1059,8 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int 
     if (fixed_point) NRT_LAUNCH(true, P, A); \
     else NRT_LAUNCH(false, P, A);      \
   } while (0)
-  if (ablation == 8) { NRT_LAUNCH(true, true, 8); return; }  // minimumNumberShouldMatch > 1 somewhere in the batch (fixed point only)
+  if (ablation == 8) { NRT_LAUNCH(true, true, 8); return; }
+  if (ablation == 9) { NRT_LAUNCH_FX(true, 9); return; }  // some part carries a doc-set mask (deletes / FILTER / MUST_NOT)  // minimumNumberShouldMatch > 1 somewhere in the batch (fixed point only)
   if (!pipelined) { NRT_LAUNCH_FX(false, 0); return; }
   switch (ablation) {
     case 1: NRT_LAUNCH(false, true, 1); break;  // 1-4: timing ablations of the fp64 kernel (wrong results)

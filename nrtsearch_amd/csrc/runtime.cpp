@@ -732,6 +732,7 @@ struct HostPlan {
   int64_t postings = 0;             // postings in the scanned term ranges (algorithmic work)
   bool fixed_point = false;         // every query of the batch passed the fixed-point range analysis
   bool clause_counting = false;     // some query has minimumNumberShouldMatch > 1: count-carrying kernel variant
+  bool masked = false;              // some part reads a doc-set mask (liveDocs / FILTER / MUST_NOT)
 };
 
 static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
@@ -993,6 +994,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
         take = std::min<uint32_t>(take, seg->n_tiles - tb);
         DPart p{};
         p.live_bits = accept;
+        if (accept) hp.masked = true;
         p.term_begin = qs.term_begin;
         p.n_terms = qs.n_terms;
         p.tile_begin = tb;
@@ -1136,7 +1138,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_okeys = wc.take((size_t)n_queries * k_stride_out * 8);
   const size_t o_ocnt = wc.take((size_t)n_queries * 4);
   const size_t o_ohits = wc.take((size_t)n_queries * 8);
-  const int ablation = hp.clause_counting ? 8 : ((ctx->cfg.flags >> 8) & 15);
+  // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
+  const int flag_variant = (ctx->cfg.flags >> 8) & 15;
+  const int ablation = hp.clause_counting ? 8 : ((hp.masked && flag_variant == 0 && !(ctx->cfg.flags & NRTGPU_FLAG_NO_MASK_VARIANT)) ? 9 : flag_variant);
   const size_t o_prof = wc.take(ablation == 7 ? n_items * 128 : 0);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   char* db = (char*)slot->d_plan.p;

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Query shapes beside the headline one, at C3 size through the C ABI: 1 % deletes (SURVEY 8d's live_bits
+variant), a FILTER mask, MUST_NOT, minimumNumberShouldMatch, and the fused BM25 -> vector-rescore tail
+(C5's shape on a smaller matrix).  Every shape is checked against the oracle on a few queries first.
+Prints one JSON line per shape."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from nrtsearch_amd import api, synth, workload  # noqa: E402
+
+
+def log(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def bits_of(mask):
+    n = len(mask)
+    padded = np.zeros(((n + 63) // 64) * 64, dtype=bool)
+    padded[:n] = mask
+    return np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--oracle-queries", type=int, default=3)
+    ap.add_argument("--vec-docs", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--skip-hybrid", action="store_true")
+    ap.add_argument("--flags", type=int, default=0)
+    args = ap.parse_args()
+    from oracle import oracle
+
+    w = workload.C3
+    w.n_docs = args.docs
+    B = args.batch
+    qr = synth.make_queries(B, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr, 1, 0)
+    ppq = workload.postings_per_query(corpus.doc_freq, qr)
+    rng = np.random.default_rng(5)
+    live = [rng.random(s.max_doc) >= 0.01 for s in corpus.segments]
+    filt = [rng.random(s.max_doc) < 0.30 for s in corpus.segments]
+    excl = [rng.random(s.max_doc) < 0.05 for s in corpus.segments]
+    ctx = api.GpuContext(0, max_batch=B, collect_timing=True, flags=args.flags)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    for leaf, f, e in zip(leaves, filt, excl):
+        leaf.set_mask(1, bits_of(f))
+        leaf.set_mask(2, bits_of(e))
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    mgr = api.TopScoreDocCollectorManager(w.k)
+
+    def should(row):
+        return tuple(api.TermQuery(0, int(t)) for t in row)
+
+    all_live = [np.ones(s.max_doc, bool) for s in corpus.segments]
+    shapes = [
+        ("plain", lambda r: api.BooleanQuery(should(r)), dict(), False, all_live),
+        ("deletes_1pct", lambda r: api.BooleanQuery(should(r)), dict(), True, live),
+        ("filter_30pct", lambda r: api.BooleanQuery(should(r), 1, (api.MaskFilter(1),)), dict(), False, filt),
+        ("must_not_5pct", lambda r: api.BooleanQuery(should(r), 0, (), (api.MaskFilter(2),)), dict(), False, [~e for e in excl]),
+        ("min_should_match_2", lambda r: api.BooleanQuery(should(r), 2), dict(min_should_match=2), False, all_live),
+        ("min_should_match_3", lambda r: api.BooleanQuery(should(r), 3), dict(min_should_match=3), False, all_live),
+    ]
+    for name, mk, okw, use_live, acc in shapes:
+        for leaf, lv in zip(leaves, live):
+            leaf.set_live_docs(bits_of(lv) if use_live else None)
+        queries = [mk(r) for r in qr]
+        bad = 0
+        got = sr.search_batch(queries[: args.oracle_queries], [mgr] * args.oracle_queries)
+        for qi in range(args.oracle_queries):
+            d, s_, tot, gte = oracle.search_bm25(corpus, qr[qi].tolist(), w.k, accept=[bits_of(a) for a in acc], **okw)
+            ok = (got[qi].docs.tolist() == d.tolist() and got[qi].scores.view(np.uint32).tolist() == s_.view(np.uint32).tolist()
+                  and got[qi].total_hits == tot and got[qi].relation_gte == gte)
+            bad += not ok
+        pb = api.PreparedBatch(sr, queries, [mgr] * B)
+        pb.run()
+        ctx.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pb.run()
+        dt = (time.perf_counter() - t0) / args.steps
+        st = ctx.stats()
+        scan_ms = st["scan_ms"] / max(1, st["scan_launches"])
+        log(shape=name, oracle_mismatches=int(bad), batch=B, ms_per_batch=round(dt * 1e3, 3), qps=round(B / dt, 1),
+            scan_ms=round(scan_ms, 3), gbps_9B=round(9.0 * float(ppq.sum()) / scan_ms / 1e6, 1),
+            fixed_point=st["fixed_point_launches"] == st["scan_launches"])
+    for leaf in leaves:
+        leaf.release()
+    ctx.close()
+
+    if args.skip_hybrid:
+        return
+    # ---- hybrid tail: BM25 recall-1000 -> cosine rescore -> top-100, fused vs two calls per query
+    n, dim = args.vec_docs, args.dim
+    w.n_docs = n
+    corpus = workload.build_shard_corpus(w, qr, 1, 0)
+    ctx = api.GpuContext(0, max_batch=B, collect_timing=True)
+    leaves = []
+    t0 = time.time()
+    for seg in corpus.segments:
+        g = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
+        g.add_field_norms(0, seg.norms)
+        g.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+        g.add_vectors(7, rng.standard_normal((seg.max_doc, dim), dtype=np.float32))
+        g.seal()
+        leaves.append(g)
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    queries = [api.BooleanQuery(should(r)) for r in qr]
+    qv = rng.standard_normal((B, dim), dtype=np.float32)
+    mg = [mgr] * B
+    fused = sr.search_hybrid_batch(queries, mg, 7, "cosine", qv, 100, 1.0, 2.0)
+    bad = 0
+    for qi in range(4):
+        two = sr.rescore_vectors(sr.search(queries[qi], mgr), 7, "cosine", qv[qi], 100, 1.0, 2.0)
+        bad += not (two.docs.tolist() == fused[qi].docs.tolist()
+                    and two.scores.view(np.uint32).tolist() == fused[qi].scores.view(np.uint32).tolist())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sr.search_hybrid_batch(queries, mg, 7, "cosine", qv, 100, 1.0, 2.0)
+    dt_f = (time.perf_counter() - t0) / args.steps
+    t0 = time.perf_counter()
+    first = sr.search_batch(queries, mg)
+    t1 = time.perf_counter()
+    for qi in range(64):
+        sr.rescore_vectors(first[qi], 7, "cosine", qv[qi], 100, 1.0, 2.0)
+    dt_r = (time.perf_counter() - t1) / 64
+    log(shape="hybrid_tail", docs=n, dim=dim, batch=B, fused_vs_two_calls_mismatches=int(bad),
+        fused_ms_per_batch=round(dt_f * 1e3, 3), fused_qps=round(B / dt_f, 1),
+        two_calls_ms_per_batch=round((t1 - t0) * 1e3 + dt_r * 1e3 * B, 3), rescore_call_ms=round(dt_r * 1e3, 3),
+        gathered_mb_per_batch=round(B * 1000 * dim * 4 / 1e6, 1))
+
+
+if __name__ == "__main__":
+    main()
