@@ -61,6 +61,7 @@ typedef struct {
 
 #define NRTGPU_FLAG_NO_PREFETCH 1     /* scan kernel without the one-tile-ahead posting prefetch (A/B) */
 #define NRTGPU_FLAG_NO_FIXED_POINT 2  /* always accumulate in fp64 (A/B; results are identical either way) */
+#define NRTGPU_FLAG_NO_LIVE_FOLD 8     /* A/B: liveDocs stay a mask read by the scan instead of being folded into the posting columns */
 #define NRTGPU_FLAG_NO_MASK_VARIANT 4   /* A/B: docs outside liveDocs / a mask are checked one by one (general sweep) */
 
 const char* nrtgpu_version(void);

@@ -22,6 +22,7 @@ NRTGPU_TILE_DOCS = 1024
 NRTGPU_FLAG_NO_PREFETCH = 1
 NRTGPU_FLAG_NO_FIXED_POINT = 2
 NRTGPU_FLAG_NO_MASK_VARIANT = 4
+NRTGPU_FLAG_NO_LIVE_FOLD = 8
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
 ABI_SYMBOLS = [

@@ -289,9 +289,11 @@ __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr
     for (int j = 0; j < 8; ++j) {
       const uint32_t c = gr.c4[j >> 2][j & 3];
       const bool esc = (c >> 31) != 0u;
-      const uint32_t f = esc ? ((c >> 8) & 0x7FFFFFu) : (c >> 9);
+      const uint32_t f = esc ? ((c >> 8) & 0x3FFFFFu) : ((c >> 9) & 15u);
+      const bool dead = esc ? ((c >> 30) & 1u) != 0u : (c >> 20) != 0u;  // posting of a deleted doc (apply_live_kernel)
       const uint32_t nb = esc ? (c & 255u) : ((c >> 2) & 127u);
-      if (((vmask >> j) & 1u) && (esc || tab == 7u)) val[j] = score_value<FX>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
+      if (((vmask >> j) & 1u) && (esc || tab == 7u))
+        val[j] = dead ? (FX ? 0u : 0x80000000u) : score_value<FX>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
     }
   }
   if (!__all(vmask == 0xFFu)) {  // wave-uniform
@@ -482,32 +484,45 @@ __device__ __forceinline__ uint32_t reserve_candidates(ScanSmem& s, uint32_t lan
   return wbase + incl - mine;
 }
 
-// Write `value` into the slots of my sub-tile whose docs are outside the mask.  live_word: lane l < 32 holds
-// bits [32 l, 32 l + 32) of the sub-tile's 1024 mask bits (set = inside), other lanes all ones.  A few docs
-// outside (deletes): one LDS write per such doc; many (a selective filter): every lane visits its 16 slots.
-// Out of line (like the rendezvous): inlined into the walk's loop it costs the loop ~30 spilled registers.
-typedef __attribute__((address_space(3))) uint64_t* lds_u64_ptr;
-__device__ __noinline__ void mark_outside(lds_u64_ptr acc, uint32_t lane, uint32_t live_word, uint64_t value) {
-  uint32_t dead = ~live_word;
-  const uint32_t most = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32((uint32_t)__popc(dead)), 63);
-  if (most == 0u) return;
-  if (most <= 6u) {
-    while (__any(dead != 0u)) {
-      if (dead) {
-        const uint32_t b = (uint32_t)__ffs((int)dead) - 1u;
-        dead &= dead - 1u;
-        acc[lane * 32u + b] = value;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kSlots; ++j) {  // slot lane + 64 j is bit (lane & 31) of word 2 j + (lane >> 5)
-      const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)live_word, 2 * j);
-      const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)live_word, 2 * j + 1);
-      const uint32_t w = lane < 32u ? w0 : w1;
-      if (!((w >> (lane & 31u)) & 1u)) acc[lane + 64u * (uint32_t)j] = value;  // (slots inside the mask may hold parked candidates)
-    }
-  }
+// Write `value` into the slots of my sub-tile whose docs are outside the mask, without spending vector
+// registers or vector-memory waits on it (the walk has neither to spare: a vector load here would make
+// the wave wait for its prefetched postings as well).  Slot lane + 64 j belongs to doc 64 j + lane of the
+// sub-tile, i.e. to bit `lane` of the mask's 64-bit word j: the complement of that word IS the execution
+// mask of the store.  The 16 words arrive by scalar loads (two of 64 bytes); per word: three scalar
+// instructions and one LDS store.  `mask_tile` points at the sub-tile's 128 mask bytes (uniform; the
+// arrays are padded, runtime.cpp, so the last sub-tile of a segment may read past max_doc).
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <int OFF>
+__device__ __forceinline__ void store_where_clear(uint64_t word, uint32_t addr, uint64_t value) {
+  uint64_t saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_andn2_b64 exec, exec, %1\n\tds_write_b64 %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved) : "s"(word), "v"(addr), "v"(value), "n"(OFF) : "memory");
+}
+template <int CHUNK>
+__device__ __forceinline__ void mark_outside_half(const void* mask_tile, uint32_t addr, uint64_t value) {
+  u32x16 w;
+  asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(mask_tile), "n"(CHUNK * 64) : "memory");
+#define NRT_WORD(i) (((uint64_t)w[2 * (i) + 1] << 32) | (uint64_t)w[2 * (i)])
+  store_where_clear<(CHUNK * 8 + 0) * 512>(NRT_WORD(0), addr, value);
+  store_where_clear<(CHUNK * 8 + 1) * 512>(NRT_WORD(1), addr, value);
+  store_where_clear<(CHUNK * 8 + 2) * 512>(NRT_WORD(2), addr, value);
+  store_where_clear<(CHUNK * 8 + 3) * 512>(NRT_WORD(3), addr, value);
+  store_where_clear<(CHUNK * 8 + 4) * 512>(NRT_WORD(4), addr, value);
+  store_where_clear<(CHUNK * 8 + 5) * 512>(NRT_WORD(5), addr, value);
+  store_where_clear<(CHUNK * 8 + 6) * 512>(NRT_WORD(6), addr, value);
+  store_where_clear<(CHUNK * 8 + 7) * 512>(NRT_WORD(7), addr, value);
+#undef NRT_WORD
+}
+__device__ __forceinline__ void mark_outside(const void* mask_tile, uint32_t acc_addr, uint32_t lane, uint64_t value) {
+  const uint32_t addr = acc_addr + lane * 8u;
+  // the stored value as an opaque register pair: as a plain constant the compiler merges it with the walk's
+  // other uses of the marker, keeps that pair alive through the whole loop, spills it and reloads it
+  // from scratch (with a full vector-memory wait) at every use
+  uint32_t lo, hi;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo), "=v"(hi) : "s"((uint32_t)value), "s"((uint32_t)(value >> 32)));
+  value = ((uint64_t)hi << 32) | (uint64_t)lo;
+  mark_outside_half<0>(mask_tile, addr, value);
+  mark_outside_half<1>(mask_tile, addr, value);  // (sub-tiles of 1024 docs: 16 words; other shapes do not use the masked variant)
 }
 
 // Sparse collect of one pair's swapped-out slot values a[j] (the marker where this posting is not its
@@ -611,8 +626,10 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     const float w = items[blockIdx.x].tab_weight[slot];  // (indexing the register copy would spill it)
     const int scale = items[blockIdx.x].tab_scale[slot];
     const float* cache = &s.cache[items[blockIdx.x].tab_cache[slot]][0];
-    for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kScanThreads)  // row 0 (freq 0) never read
-      s.tab[slot][e] = score_value<FX>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
+    // row 0 (freq 0) serves the postings of deleted docs (apply_live_kernel): the neutral element of the sum
+    for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kScanThreads)
+      s.tab[slot][e] = e < (uint32_t)kTabNorms ? (FX ? 0u : 0x80000000u)
+                                               : score_value<FX>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
   }
   __syncthreads();  // tables complete; from here on the waves run on their own
   if (ABL == 7) {
@@ -651,23 +668,17 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     const NRT_GLOBAL uint64_t* const live_bits = (const NRT_GLOBAL uint64_t*)part.live_bits;
     // uniform: no searchAfter, no clause counting, and no doc-set mask -- unless this is the masked variant
     // (ABL == 9), which poisons the slots outside the mask instead of checking every matched doc
-    constexpr bool kMask = ABL == 9;
+    constexpr bool kMask = ABL == 9 && kTileDocs == 1024;
     const bool simple = (live_bits == nullptr || kMask) && !q.has_after && cnt_hi == 0u;
     const bool masked = kMask && live_bits != nullptr && simple;
-    const uint32_t mask_words = ((part.max_doc + 63u) >> 6) << 1;  // 32-bit words of the part's mask
-    auto mask_word_of = [&](uint32_t g) -> uint32_t {  // lane l < 32: bits of docs [32 l, 32 l + 32) of sub-tile g
-      const uint32_t wi = (g + tile_bias) * (uint32_t)(kTileDocs / 32) + lane;
-      return (lane < (uint32_t)(kTileDocs / 32) && wi < mask_words) ? ((const NRT_GLOBAL uint32_t*)live_bits)[wi] : 0xFFFFFFFFu;
+    auto mask_tile_of = [&](uint32_t g) -> const void* {  // the 128 mask bytes of sub-tile g, as a uniform address
+      const uint64_t a = (uint64_t)part.live_bits + (uint64_t)(g + tile_bias) * (uint64_t)(kTileDocs / 8);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+      return (const void*)(((uint64_t)hi << 32) | (uint64_t)lo);
     };
-    // The mask bits of the current sub-tile are kept in LDS, not in registers (the walk has none to spare): in
-    // row 0 of the score tables (freq 0: written when the tables are built, never read), 32 words per wave.
-    static_assert(kScanWaves * 32 <= kTabTerms * kTabNorms, "mask words of all waves fit the unused table rows");
-    uint32_t* const w_mask = &s.tab[wave >> 2][(wave & 3u) * 32u];
-    if (masked) {  // (entering a part, or resuming after a rendezvous: the sub-tile holds markers only)
-      const uint32_t w = mask_word_of(g_cur);
-      if (lane < 32u) w_mask[lane] = w;
-      mark_outside((lds_u64_ptr)acc, lane, w, acc_dead<FX>());
-    }
+    if (masked)  // (entering a part, or resuming after a rendezvous: the sub-tile holds markers only)
+      mark_outside(mask_tile_of(g_cur), acc_addr, lane, acc_dead<FX>());
     // lane l looks after term min(l, n_terms - 1) of this part (registers)
     const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     const uint64_t my_docids = (uint64_t)mt.docids, my_lo = mt.start;
@@ -796,7 +807,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
                 const int j = h * 4 + jj;
-                const bool matched = kMask ? acc_is_hit<FX>(v[jj]) : v[jj] != acc_marker<FX>();
+                const bool matched = ABL == 9 ? acc_is_hit<FX>(v[jj]) : v[jj] != acc_marker<FX>();
                 wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(matched));
                 const bool maybe = acc_reaches<FX>(v[jj], thr);  // implies matched
                 any_maybe |= __builtin_amdgcn_ballot_w64(maybe);
@@ -813,7 +824,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 #pragma unroll
               for (int j = 0; j < kSlots; ++j) v[j] = acc[lane + 64u * (uint32_t)j];
 #pragma unroll
-              for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(kMask ? acc_is_hit<FX>(v[j]) : v[j] != acc_marker<FX>()) << j;
+              for (int j = 0; j < kSlots; ++j) mmask |= (uint32_t)(ABL == 9 ? acc_is_hit<FX>(v[j]) : v[j] != acc_marker<FX>()) << j;
             } else {
               mmask = (1u << kSlots) - 1u;
             }
@@ -870,8 +881,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 
       // ---- (5) advance.  Somebody's candidates did not fit (seen at the next sub-tile boundary at the
       //      latest): leave the walk for the rendezvous
-      if (masked)  // un-poison: only parked candidates may stay
-        mark_outside((lds_u64_ptr)acc, lane, lane < 32u ? w_mask[lane] : 0xFFFFFFFFu, acc_marker<FX>());
+      if (masked) mark_outside(mask_tile_of(g_cur), acc_addr, lane, acc_marker<FX>());  // un-poison: only parked candidates may stay
       g_cur = g_nxt;
       g_nxt = g_nxt2;
       g_nxt2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
@@ -880,11 +890,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         break;
       }
       if (g_cur >= gn) break;  // the next sub-tile lies in a later part (or past the item)
-      if (masked) {  // poison the next sub-tile: nothing of it has been added yet
-        const uint32_t w = mask_word_of(g_cur);
-        if (lane < 32u) w_mask[lane] = w;
-        mark_outside((lds_u64_ptr)acc, lane, w, acc_dead<FX>());
-      }
+      if (masked) mark_outside(mask_tile_of(g_cur), acc_addr, lane, acc_dead<FX>());  // poison the next sub-tile: nothing of it has been added yet
     }
     if (interrupted) break;
   }
@@ -1039,13 +1045,47 @@ void fold_norms_kernel(const uint32_t* __restrict__ docids, const uint32_t* __re
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
     const uint32_t f = freqs ? freqs[p] : 1u;
     const uint32_t nb = norms ? (uint32_t)norms[docids[p]] : 1u;
-    if (f >= (1u << 23)) *overflow = 1u;
+    if (f >= (1u << 22)) *overflow = 1u;
     fnorm[p] = (f >= 1u && f <= (uint32_t)kTabMaxFreq && nb < (uint32_t)kTabNorms) ? (((f << 7) | nb) << 2)
                                                                                   : (0x80000000u | (f << 8) | nb);
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// apply_live_kernel (when liveDocs change): the postings of deleted docs are re-coded so that they score
+// the neutral element -- the scan then needs no per-doc liveness test at all.  A posting of a doc whose
+// bit in `live` is clear becomes
+//   table form   ((f << 7) | nb) << 2          ->  (f << 20) | (nb << 2)      (row 0 of every score table)
+//   escape form  0x80000000 | f << 8 | nb      ->  the same with bit 30 set
+// and reverts when the doc is live again (live == nullptr: every doc).  freq keeps its place in the word,
+// so nothing else has to be stored.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void apply_live_kernel(const uint32_t* __restrict__ docids, uint32_t* __restrict__ fnorm, uint64_t n,
+                       const uint64_t* __restrict__ live) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    uint32_t c = fnorm[p];
+    const bool esc = (c >> 31) != 0u;
+    // back to the live form
+    if (esc) c &= ~0x40000000u;
+    else if ((c >> 20) != 0u) c = (((c >> 20) & 15u) << 9) | (c & 0x1FCu);
+    bool is_live = true;
+    if (live) {
+      const uint32_t d = docids[p];
+      is_live = (live[d >> 6] >> (d & 63u)) & 1ull;
+    }
+    if (!is_live) c = esc ? (c | 0x40000000u) : ((((c >> 9) & 15u) << 20) | (c & 0x1FCu));
+    fnorm[p] = c;
+  }
+}
+
 // ---- launchers (called from runtime.cpp) ---------------------------------------------------------
+void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fnorm, uint64_t n, const uint64_t* live) {
+  if (n == 0) return;
+  const uint64_t blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(apply_live_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, docids, fnorm, n, live);
+}
 void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,

@@ -41,6 +41,7 @@ void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* i
                        uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out);
 void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,
                        uint32_t* fnorm, uint64_t n, uint32_t* overflow);
+void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fnorm, uint64_t n, const uint64_t* live);
 void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float* norm2);
 int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
@@ -211,10 +212,13 @@ struct nrtgpu_seg {
   // FILTER / MUST_NOT clauses as doc-set masks: host copies of the registered masks and of liveDocs,
   // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use
   std::vector<uint64_t> h_live;                      // empty = all live
+  bool live_folded = false;  // the posting columns carry the current liveDocs (apply_live_kernel): the scan needs no mask for them
   std::map<int32_t, std::vector<uint64_t>> masks;
   mutable std::mutex accept_mu;
   mutable std::map<std::pair<int32_t, int32_t>, uint64_t*> accept;
 };
+
+static const size_t kMaskPadBytes = 256;  // doc-set masks are readable one sub-tile (128 bytes) past max_doc
 
 static void drop_accept_sets(nrtgpu_seg* seg) {
   std::lock_guard<std::mutex> lk(seg->accept_mu);
@@ -566,6 +570,8 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
   return NRTGPU_OK;
 }
 
+static int fold_live_docs(nrtgpu_seg* seg);
+
 extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
   if (seg->sealed) return NRTGPU_OK;
@@ -596,7 +602,7 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   }
   (void)hipFree(d_overflow);
   if (rc) return rc;
-  if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^23 does not fit the packed freq|norm column");
+  if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^22 does not fit the packed freq|norm column");
   for (auto& kv : seg->fields) kv.second.flat.build(kv.second.dict);
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
@@ -606,6 +612,22 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
         seg->device_bytes -= (int64_t)((((size_t)g.n_postings * 4 + 15) & ~(size_t)15) + 64);
       }
   seg->sealed = true;
+  if (seg->d_live) return fold_live_docs(seg);  // liveDocs set before the seal
+  return NRTGPU_OK;
+}
+
+// Re-code the posting columns for the segment's current liveDocs (kernels.hip: apply_live_kernel).  One pass
+// over the segment's postings per reader version instead of a liveness test per matched doc per query.
+static int fold_live_docs(nrtgpu_seg* seg) {
+  seg->live_folded = false;
+  if (seg->ctx->cfg.flags & NRTGPU_FLAG_NO_LIVE_FOLD) return NRTGPU_OK;
+  if (!seg->sealed) return NRTGPU_OK;  // seal folds
+  for (auto& kv : seg->fields)
+    for (auto& g : kv.second.groups)
+      launch_apply_live(nullptr, g.d_docids, g.d_fnorm, g.n_postings, seg->d_live);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  seg->live_folded = seg->d_live != nullptr;
   return NRTGPU_OK;
 }
 
@@ -618,17 +640,18 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
     if (seg->d_live) (void)hipFree(seg->d_live);
     seg->d_live = nullptr;
     seg->h_live.clear();
-    return NRTGPU_OK;
+    return fold_live_docs(seg);
   }
   if (n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "live bits: %d words given, %d needed", n_words, need);
   seg->h_live.assign(bits, bits + need);
-  if (!seg->d_live) {
+  if (!seg->d_live) {  // padded: the masked scan variant reads whole sub-tiles (128 bytes) of the mask
     void* p = nullptr;
-    if (int rc = dev_alloc(seg, &p, (size_t)need * 8)) return rc;
+    if (int rc = dev_alloc(seg, &p, (size_t)need * 8 + kMaskPadBytes)) return rc;
     seg->d_live = (uint64_t*)p;
+    HIP_TRY(hipMemset((char*)p + (size_t)need * 8, 0, kMaskPadBytes));
   }
   HIP_TRY(hipMemcpy(seg->d_live, bits, (size_t)need * 8, hipMemcpyHostToDevice));
-  return NRTGPU_OK;
+  return fold_live_docs(seg);
 }
 
 extern "C" int nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const uint64_t* bits, int32_t n_words) {
@@ -651,7 +674,7 @@ extern "C" int nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const u
 // the same pair (the role LRUQueryCache plays for Lucene's non-scoring clauses).
 static int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out) {
   if (filter_mask == 0 && must_not_mask == 0) {
-    *out = seg->d_live;
+    *out = seg->live_folded ? nullptr : seg->d_live;
     return 0;
   }
   std::lock_guard<std::mutex> lk(seg->accept_mu);
@@ -674,7 +697,7 @@ static int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t mus
     mn = &m->second;
   }
   const size_t need = (size_t)(seg->max_doc + 63) / 64;
-  std::vector<uint64_t> w(need);
+  std::vector<uint64_t> w(need + kMaskPadBytes / 8, 0ull);  // padded like liveDocs
   for (size_t i = 0; i < need; ++i) {
     uint64_t v = seg->h_live.empty() ? ~0ull : seg->h_live[i];
     if (f) v &= (*f)[i];
@@ -683,8 +706,8 @@ static int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t mus
   }
   void* p = nullptr;
   HIP_TRY(hipSetDevice(seg->ctx->device));
-  if (hipMalloc(&p, need * 8) != hipSuccess) return fail(NRTGPU_ERR_OOM, "hipMalloc(%zu) for an accept set failed", need * 8);
-  if (hipMemcpy(p, w.data(), need * 8, hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMalloc(&p, w.size() * 8) != hipSuccess) return fail(NRTGPU_ERR_OOM, "hipMalloc(%zu) for an accept set failed", w.size() * 8);
+  if (hipMemcpy(p, w.data(), w.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(p);
     return fail(NRTGPU_ERR_HIP, "upload of an accept set failed");
   }
@@ -1690,8 +1713,8 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       if (fit == seg->fields.end() || !fit->second.d_vectors) continue;
       const FieldData& f = fit->second;
       total_vec += f.n_vec;
-      const uint64_t* accept = seg->d_live;
-      if (knn_request)
+      const uint64_t* accept = seg->d_live;  // (vectors are not re-coded for liveDocs: always the mask)
+      if (knn_request && filter_mask != 0)
         if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
       // rounds never exceed the candidate capacity, so a list cannot overflow; theta tightens between rounds
       int64_t r = 0, round = 1 << 16;

@@ -174,3 +174,41 @@ def test_minimum_should_match_full_tiles(ctx):
     finally:
         ix.close()
         c2.close()
+
+
+# ---- deletes: folded into the posting columns by default; the mask paths stay reachable by flag ---------
+@pytest.mark.parametrize("flags", [0, _lib.NRTGPU_FLAG_NO_LIVE_FOLD, _lib.NRTGPU_FLAG_NO_LIVE_FOLD | _lib.NRTGPU_FLAG_NO_MASK_VARIANT,
+                                   _lib.NRTGPU_FLAG_NO_FIXED_POINT, _lib.NRTGPU_FLAG_NO_FIXED_POINT | _lib.NRTGPU_FLAG_NO_LIVE_FOLD])
+def test_deletes_all_routes(flags):
+    """liveDocs three ways -- re-coded postings (default), the masked scan variant, the per-doc check -- and in
+    both accumulator modes: same bits.  8 clauses: some have no score table (division path), long docs and high
+    freqs take the escape code."""
+    ranks = [1, 2, 3, 5, 9, 17, 60, 250, 1200]
+    corpus = synth.build_corpus(220_000, ranks, n_segments=3, delete_fraction=0.05)
+    c = api.GpuContext(device_id=0, max_batch=64, flags=flags)
+    ix = Index(c, corpus)
+    try:
+        for terms in ([1, 2, 3, 5, 9, 17, 60, 250], [2, 60, 1200], [1], [1200]):
+            for k, thr in ((10, 1000), (1000, 1000), (100, 2**31 - 1)):
+                got = ix.searcher.search(api.BooleanQuery(tuple(api.TermQuery(0, t) for t in terms)) if len(terms) > 1
+                                         else api.TermQuery(0, terms[0]), api.TopScoreDocCollectorManager(k, None, thr))
+                assert_same(f"del_{flags}_{len(terms)}_{k}", got, oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr), k, thr)
+        # a later reader version deletes more; then one without deletes (not possible in Lucene, allowed here)
+        rng = np.random.Generator(np.random.PCG64(3))
+        for seg, leaf in zip(corpus.segments, ix.leaves):
+            alive = np.unpackbits(seg.live_bits.view(np.uint8), bitorder="little")[: seg.max_doc].astype(bool)
+            alive &= rng.random(seg.max_doc) >= 0.10
+            padded = np.zeros(((seg.max_doc + 63) // 64) * 64, dtype=bool)
+            padded[: seg.max_doc] = alive
+            seg.live_bits = np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+            leaf.set_live_docs(seg.live_bits)
+        terms = [1, 3, 9, 60, 250, 1200]
+        q = api.BooleanQuery(tuple(api.TermQuery(0, t) for t in terms))
+        assert_same(f"del2_{flags}", ix.searcher.search(q, api.TopScoreDocCollectorManager(300)), oracle.search_bm25(corpus, terms, 300), 300, 1000)
+        for seg, leaf in zip(corpus.segments, ix.leaves):
+            seg.live_bits = None
+            leaf.set_live_docs(None)
+        assert_same(f"del3_{flags}", ix.searcher.search(q, api.TopScoreDocCollectorManager(300)), oracle.search_bm25(corpus, terms, 300), 300, 1000)
+    finally:
+        ix.close()
+        c.close()
