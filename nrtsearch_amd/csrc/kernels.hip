@@ -528,14 +528,23 @@ __device__ __forceinline__ void mark_outside(const void* mask_tile, uint32_t acc
 // Sparse collect of one pair's swapped-out slot values a[j] (the marker where this posting is not its
 // doc's collector): count the hits, send the competitive docs to the shared candidate buffer.
 // Returns true when they did not fit and were parked back into the sub-tile.
+// ABL == 8 (clause counting): a total is a hit when it reaches hit_floor (minimumNumberShouldMatch in the count
+// bits; 1 for a query of the batch that does not count), and its score sum is what score_hi_mask leaves.
 template <bool FX, int ABL>
-__device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, uint32_t lane, const uint64_t (&a)[8],
+__device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, uint32_t lane, uint64_t (&a)[8],
                                                 const uint32_t (&off)[8], uint64_t thr, uint64_t theta, int fx_E,
-                                                uint32_t gdoc0, uint32_t& wave_hits) {
+                                                uint32_t gdoc0, uint32_t& wave_hits, uint64_t hit_floor = 0,
+                                                uint32_t score_hi_mask = 0xFFFFFFFFu) {
   unsigned long long any_maybe = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ABL == 9 ? acc_is_hit<FX>(a[j]) : a[j] != acc_marker<FX>()));
+    if (ABL == 8) {
+      const bool hit = a[j] >= hit_floor;
+      wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
+      a[j] = hit ? (a[j] & (((uint64_t)score_hi_mask << 32) | 0xFFFFFFFFull)) : 0ull;  // from here on: bare sums, non-hits gone
+    } else {
+      wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ABL == 9 ? acc_is_hit<FX>(a[j]) : a[j] != acc_marker<FX>()));
+    }
     any_maybe |= __builtin_amdgcn_ballot_w64(acc_reaches<FX>(a[j], thr));
   }
   if (any_maybe == 0ull || ABL == 6) return false;  // wave-uniform; the steady state once theta has converged
@@ -588,6 +597,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   constexpr bool kMsm = FX && ABL == 8;
   const uint32_t msm = kMsm ? q.min_should_match : 0u;
   const uint32_t cnt_hi = (kMsm && msm > 1u) ? (1u << (kMsmCountShift - 32)) : 0u;
+  const uint64_t hit_floor = cnt_hi ? (uint64_t)msm << kMsmCountShift : 1ull;
+  const uint32_t score_hi_mask = cnt_hi ? (1u << (kMsmCountShift - 32)) - 1u : 0xFFFFFFFFu;
 
   uint64_t t_start = 0, t_walk = 0;
   if (ABL == 7) t_start = __builtin_readcyclecounter();
@@ -669,7 +680,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     // uniform: no searchAfter, no clause counting, and no doc-set mask -- unless this is the masked variant
     // (ABL == 9), which poisons the slots outside the mask instead of checking every matched doc
     constexpr bool kMask = ABL == 9 && kTileDocs == 1024;
-    const bool simple = (live_bits == nullptr || kMask) && !q.has_after && cnt_hi == 0u;
+    const bool simple = (live_bits == nullptr || kMask) && !q.has_after;
     const bool masked = kMask && live_bits != nullptr && simple;
     auto mask_tile_of = [&](uint32_t g) -> const void* {  // the 128 mask bytes of sub-tile g, as a uniform address
       const uint64_t a = (uint64_t)part.live_bits + (uint64_t)(g + tile_bias) * (uint64_t)(kTileDocs / 8);
@@ -718,7 +729,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       const uint32_t cur_groups = total_groups;
       // wave-uniform: sub-tiles of up to one (16 waves: registers) or two pair-instructions per lane are
       // collected through the postings instead of a sweep
-      constexpr bool kTwoGroups = kScanWaves <= 12;
+      constexpr bool kTwoGroups = kScanWaves <= 12 && ABL != 9;  // (the masked variant has no registers for a second pair instruction)
       const bool sparse = simple && cur_groups <= (kTwoGroups ? 128u : 64u);
       const bool second = kTwoGroups && cur_groups > 64u;  // the sub-tile has a second instruction's worth of pairs
       const bool act = lane < cur_groups, act2 = second && 64u + lane < cur_groups;
@@ -768,7 +779,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       if (cur_groups != 0) {
         if (act && ABL != 2 && ABL != 4) group_commit_add<FX>(off, val, sh, cnt_hi);
         if (sparse && ABL != 2 && ABL != 3) {
-          if (act2) group_commit_add<FX>(off2, val2, sh2);
+          if (act2) group_commit_add<FX>(off2, val2, sh2, cnt_hi);
           if (act) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = atomicExch((unsigned long long*)lds_ptr(off[j]), (unsigned long long)acc_marker<FX>());
@@ -791,8 +802,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         if (sparse) {
           // ---- (4s) collect through the postings
           if (ABL == 7 && tid == 0) s.prof[9] += 1;
-          parked = collect_swapped<FX, ABL>(s, acc_addr, lane, a, off, thr, theta, fx_E, gdoc0, wave_hits);
-          if (second) parked |= collect_swapped<FX, ABL>(s, acc_addr, lane, a2, off2, thr, theta, fx_E, gdoc0, wave_hits);
+          parked = collect_swapped<FX, ABL>(s, acc_addr, lane, a, off, thr, theta, fx_E, gdoc0, wave_hits, hit_floor, score_hi_mask);
+          if (second) parked |= collect_swapped<FX, ABL>(s, acc_addr, lane, a2, off2, thr, theta, fx_E, gdoc0, wave_hits, hit_floor, score_hi_mask);
         } else {
           // ---- (4d) dense sweep of my sub-tile: count hits, reset every slot that cannot be competitive.
           //      A slot whose fp32 score reaches theta's score stays in place (mmask) for the exact path.
@@ -807,6 +818,15 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
                 const int j = h * 4 + jj;
+                if (kMsm) {  // clause counting: a hit needs its count; what stays in place is the bare sum
+                  const bool touched = v[jj] != 0ull, hit = v[jj] >= hit_floor;
+                  const uint64_t sum = v[jj] & (((uint64_t)score_hi_mask << 32) | 0xFFFFFFFFull);
+                  wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
+                  const bool maybe = hit && acc_reaches<FX>(sum, thr);
+                  any_maybe |= __builtin_amdgcn_ballot_w64(maybe);
+                  if (touched) acc[lane + 64u * (uint32_t)j] = maybe ? sum : 0ull;
+                  continue;
+                }
                 const bool matched = ABL == 9 ? acc_is_hit<FX>(v[jj]) : v[jj] != acc_marker<FX>();
                 wave_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(matched));
                 const bool maybe = acc_reaches<FX>(v[jj], thr);  // implies matched
@@ -840,7 +860,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
                 const uint32_t doc = base + i;
                 bool live = true;
                 if (!simple && live_bits) live = (live_bits[doc >> 6] >> (doc & 63u)) & 1ull;
-                if (kMsm && cnt_hi != 0u) {  // a hit needs msm matching clauses; from here on v is the bare score sum
+                if (kMsm && cnt_hi != 0u && !simple) {  // (the simple sweep has done this already) a hit needs msm clauses; then v is the bare sum
                   live = live && (uint32_t)(v >> kMsmCountShift) >= msm;
                   v &= (1ull << kMsmCountShift) - 1ull;
                 }
@@ -854,7 +874,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
                 }
                 if (cand) {
                   cmask |= 1u << j;
-                  if (kMsm && cnt_hi != 0u) acc[i] = v;  // stays in place for the candidate copy / the rendezvous: without the count
+                  if (kMsm && cnt_hi != 0u && !simple) acc[i] = v;  // stays in place for the candidate copy / the rendezvous: without the count
                 } else {
                   acc[i] = acc_marker<FX>();
                 }

@@ -124,19 +124,44 @@ def main():
         two = sr.rescore_vectors(sr.search(queries[qi], mgr), 7, "cosine", qv[qi], 100, 1.0, 2.0)
         bad += not (two.docs.tolist() == fused[qi].docs.tolist()
                     and two.scores.view(np.uint32).tolist() == fused[qi].scores.view(np.uint32).tolist())
+    # timed through the C ABI with the queries marshalled once (no Python work in the timed region)
+    import ctypes as C
+    from nrtsearch_amd import _lib
+    L = _lib.load()
+    m = sr._marshal(queries, mg)
+    outs = (_lib.TopDocs * B)()
+    od = np.zeros((B, 1000), np.int32)
+    os_ = np.zeros((B, 1000), np.float32)
+    for qi in range(B):
+        outs[qi].capacity = 1000
+        outs[qi].docs = od[qi].ctypes.data_as(C.POINTER(C.c_int32))
+        outs[qi].scores = os_[qi].ctypes.data_as(C.POINTER(C.c_float))
+
+    def fused():
+        _lib.check(L.nrtgpu_search_hybrid_batch(ctx._h, sr._segs, sr._bases, len(leaves), m.queries, B, 7, 0, qv.ctypes.data, dim,
+                                                C.c_float(1.0), 1.0, 2.0, 100, outs))
+
+    def first_pass():
+        _lib.check(L.nrtgpu_search_bm25_batch(ctx._h, sr._segs, sr._bases, len(leaves), m.queries, B, outs))
+
+    fused(); first_pass()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sr.search_hybrid_batch(queries, mg, 7, "cosine", qv, 100, 1.0, 2.0)
+        fused()
     dt_f = (time.perf_counter() - t0) / args.steps
     t0 = time.perf_counter()
-    first = sr.search_batch(queries, mg)
+    for _ in range(args.steps):
+        first_pass()
+    dt_1 = (time.perf_counter() - t0) / args.steps
+    first = sr.search_batch(queries[:64], mg[:64])
     t1 = time.perf_counter()
     for qi in range(64):
         sr.rescore_vectors(first[qi], 7, "cosine", qv[qi], 100, 1.0, 2.0)
     dt_r = (time.perf_counter() - t1) / 64
     log(shape="hybrid_tail", docs=n, dim=dim, batch=B, fused_vs_two_calls_mismatches=int(bad),
-        fused_ms_per_batch=round(dt_f * 1e3, 3), fused_qps=round(B / dt_f, 1),
-        two_calls_ms_per_batch=round((t1 - t0) * 1e3 + dt_r * 1e3 * B, 3), rescore_call_ms=round(dt_r * 1e3, 3),
+        fused_ms_per_batch=round(dt_f * 1e3, 3), fused_qps=round(B / dt_f, 1), first_pass_only_ms=round(dt_1 * 1e3, 3),
+        tail_ms=round((dt_f - dt_1) * 1e3, 3), tail_gather_gbps=round(B * 1000 * dim * 4 / max(dt_f - dt_1, 1e-9) / 1e9, 1),
+        two_calls_ms_per_batch=round(dt_1 * 1e3 + dt_r * 1e3 * B, 3), rescore_call_ms=round(dt_r * 1e3, 3),
         gathered_mb_per_batch=round(B * 1000 * dim * 4 / 1e6, 1))
 
 
