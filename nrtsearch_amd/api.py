@@ -57,10 +57,11 @@ class BooleanQuery:
     """SHOULD disjunction of term clauses, optionally narrowed by one FILTER and one MUST_NOT clause
     (S/query/QueryNodeMapper.java:257-283)."""
 
-    should: Tuple[Union[TermQuery, BoostQuery], ...]
+    should: Tuple[Union[TermQuery, BoostQuery], ...] = ()
     minimum_number_should_match: int = 0
     filter: Tuple[MaskFilter, ...] = ()
     must_not: Tuple[MaskFilter, ...] = ()
+    must: Tuple[Union[TermQuery, BoostQuery], ...] = ()   # MatchQuery with operator MUST (QueryNodeMapper.java:369-373)
 
 
 Query = Union[TermQuery, BoostQuery, BooleanQuery]
@@ -266,6 +267,10 @@ class GpuSegment:
 
 
 # ---- searcher ------------------------------------------------------------------------------------
+def _unsupported(msg: str):
+    raise UnsupportedQuery(msg)
+
+
 def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int]:
     """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost)], msm,
     filter mask id, must_not mask id (0 = none)."""
@@ -277,6 +282,14 @@ def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int]
         raise UnsupportedQuery(f"clause {q!r} is not a (boosted) TermQuery")
 
     if isinstance(query, BooleanQuery):
+        if query.must:
+            # a conjunction of term clauses matches the docs all of them match and sums all their scores
+            # (ConjunctionScorer: double sum, one cast): the disjunction with minimumNumberShouldMatch = n
+            if query.should:
+                raise UnsupportedQuery("MUST and SHOULD term clauses mixed")
+            return ([one(c) for c in query.must], len(query.must),
+                    query.filter[0].mask_id if query.filter else 0, query.must_not[0].mask_id if query.must_not else 0) \
+                if len(query.filter) <= 1 and len(query.must_not) <= 1 else _unsupported("more than one FILTER / MUST_NOT clause")
         if not query.should:
             raise UnsupportedQuery("empty BooleanQuery")
         if len(query.filter) > 1 or len(query.must_not) > 1:

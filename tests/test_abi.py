@@ -155,3 +155,24 @@ def test_weighted_rrf_blend_golden():
     assert len(api.weighted_rrf_blend([np.array([1])], top_hits=0).docs) == 0
     with pytest.raises(ValueError):
         api.weighted_rrf_blend([np.array([1])], k=0)
+
+
+def test_query_eligibility_mapping():
+    """Host logic only: which rewritten queries the mirror sends to the device and how."""
+    from nrtsearch_amd import api
+    t = [api.TermQuery(0, i) for i in (3, 5, 8)]
+    assert api._flatten(t[0]) == ([(0, 3, 1.0)], 0, 0, 0)
+    assert api._flatten(api.BoostQuery(t[1], 2.0)) == ([(0, 5, 2.0)], 0, 0, 0)
+    assert api._flatten(api.BooleanQuery(tuple(t), 2)) == ([(0, 3, 1.0), (0, 5, 1.0), (0, 8, 1.0)], 2, 0, 0)
+    assert api._flatten(api.BooleanQuery(tuple(t), 1, (api.MaskFilter(4),), (api.MaskFilter(9),)))[2:] == (4, 9)
+    # a pure-MUST conjunction of terms is the disjunction that needs every clause
+    assert api._flatten(api.BooleanQuery(must=tuple(t)))[1] == 3
+    assert api._flatten(api.BooleanQuery(must=tuple(t), filter=(api.MaskFilter(2),)))[1:] == (3, 2, 0)
+    import pytest
+    for bad in (api.BooleanQuery(tuple(t), 0, (api.MaskFilter(4),)),              # FILTER + optional SHOULD: score-0 hits
+                api.BooleanQuery(tuple(t[:1]), must=tuple(t[1:])),                 # MUST and SHOULD mixed
+                api.BooleanQuery((api.BooleanQuery(tuple(t)),)),                    # nested clause
+                api.BooleanQuery(tuple(t), 1, (api.MaskFilter(1), api.MaskFilter(2))),
+                api.BooleanQuery(())):
+        with pytest.raises(api.UnsupportedQuery):
+            api._flatten(bad)

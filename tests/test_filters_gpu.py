@@ -212,3 +212,16 @@ def test_deletes_all_routes(flags):
     finally:
         ix.close()
         c.close()
+
+
+def test_must_conjunction_of_terms(ctx):
+    """MatchQuery with operator MUST: every term required, scores of all of them summed."""
+    corpus = synth.build_corpus(150_000, [1, 2, 4, 30], n_segments=2, delete_fraction=0.01)
+    ix = Index(ctx, corpus)
+    try:
+        for terms in ([1, 2], [1, 2, 4], [2, 4, 30]):
+            q = api.BooleanQuery(must=tuple(api.TermQuery(0, t) for t in terms))
+            got = ix.searcher.search(q, api.TopScoreDocCollectorManager(100))
+            assert_same(f"must_{len(terms)}", got, oracle.search_bm25(corpus, terms, 100, min_should_match=len(terms)), 100, 1000)
+    finally:
+        ix.close()
