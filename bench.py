@@ -56,6 +56,28 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes
+    expose 256 hardware threads but grant 16 CPUs; more threads than that only oversubscribe)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:            # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(corpus, query_ranks, k, n_queries):
     """The CPU oracle (oracle/nrt_oracle.c) on the host cores: a reported baseline next to the GPU
     number, not a target.  Bounded sample of the same queries; the timed region is one C call
@@ -65,8 +87,8 @@ def cpu_baseline(corpus, query_ranks, k, n_queries):
     from oracle import oracle
 
     oracle.build()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_queries = min(max(n_queries, 8 * cores), len(query_ranks))   # keep every thread busy for several queries
+    cores = usable_cpus()
+    n_queries = min(max(n_queries // 2, 32 * cores), len(query_ranks))   # every thread busy for tens of queries
     sample = [query_ranks[i].tolist() for i in range(n_queries)]
     pb = oracle.PreparedBatch(corpus, sample, k)              # weights + impacts: index / Weight time, untimed
     n_ex = max(1, n_queries // 4)
