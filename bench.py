@@ -88,7 +88,7 @@ def cpu_baseline(corpus, query_ranks, k, n_queries):
 
     oracle.build()
     cores = usable_cpus()
-    n_queries = min(max(n_queries // 2, 32 * cores), len(query_ranks))   # every thread busy for tens of queries
+    n_queries = min(max(n_queries, 64 * cores), len(query_ranks))   # every thread busy for tens of queries (~15 s of CPU work)
     sample = [query_ranks[i].tolist() for i in range(n_queries)]
     pb = oracle.PreparedBatch(corpus, sample, k)              # weights + impacts: index / Weight time, untimed
     n_ex = max(1, n_queries // 4)
