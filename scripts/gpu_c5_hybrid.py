@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Config C5 at full size on ONE MI355X: 50 M docs, BM25 recall-1000 (5-term disjunction) -> exact cosine
+rescore over 768-d fp32 vectors -> top-100, fused on the device (nrtgpu_search_hybrid_batch).  The reference
+sizes this for 8 GPUs; 154 GB of vectors + 10 GB of postings fit one GPU's 288 GB.  Equal 2.5 M-doc segments
+(the host stages one segment's vectors at a time; every segment uploads the same random block -- the tail
+gathers 1000 rows per query, their values do not matter for the timing).  Prints JSON lines."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from nrtsearch_amd import _lib, api, synth  # noqa: E402
+
+
+def log(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def mem_available_gb():
+    lim = None
+    try:
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v != "max":
+            lim = int(v) / 2**30
+            lim -= int(open("/sys/fs/cgroup/memory.current").read()) / 2**30
+    except (OSError, ValueError):
+        pass
+    avail = None
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            avail = int(line.split()[1]) / 2**20
+    return min(x for x in (lim, avail) if x is not None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=50_000_000)
+    ap.add_argument("--seg-docs", type=int, default=2_500_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--oracle-queries", type=int, default=1)
+    args = ap.parse_args()
+    free = mem_available_gb()
+    need = args.seg_docs * args.dim * 4 / 2**30 + args.docs * 1.2e-6 + 8
+    log(event="host_memory", available_gb=round(free, 1), needed_gb=round(need, 1))
+    if free < need * 1.3:
+        log(event="skipped", reason="not enough host memory to stage the corpus safely")
+        return
+    N, B, dim = args.docs, args.batch, args.dim
+    t0 = time.time()
+    qr = synth.make_queries(B, 5, 10000)
+    ranks = sorted(set(int(r) for r in qr.reshape(-1)))
+    lens = synth.doc_lengths(N)
+    norms_all = synth.int_to_byte4(lens)
+    n_seg = (N + args.seg_docs - 1) // args.seg_docs
+    bases = np.minimum(np.arange(n_seg + 1, dtype=np.int64) * args.seg_docs, N)
+    per_docs = [[] for _ in range(n_seg)]
+    per_freqs = [[] for _ in range(n_seg)]
+    doc_freq = {}
+    for r in ranks:
+        d, f = synth.term_postings(N, r)
+        doc_freq[r] = int(len(d))
+        cuts = np.searchsorted(d, bases)
+        for s in range(n_seg):
+            a, b = int(cuts[s]), int(cuts[s + 1])
+            per_docs[s].append((d[a:b] - bases[s]).astype(np.int32))
+            per_freqs[s].append(f[a:b])
+    segments = []
+    for s in range(n_seg):
+        counts = np.asarray([len(x) for x in per_docs[s]], dtype=np.int64)
+        segments.append(synth.SegmentData(
+            max_doc=int(bases[s + 1] - bases[s]), doc_base=int(bases[s]), norms=norms_all[bases[s]: bases[s + 1]].copy(),
+            term_ids=np.asarray(ranks, dtype=np.int64), offsets=np.concatenate([[0], np.cumsum(counts)]).astype(np.int64),
+            docids=np.ascontiguousarray(np.concatenate(per_docs[s]), dtype=np.int32),
+            freqs=np.ascontiguousarray(np.concatenate(per_freqs[s]), dtype=np.int32)))
+    del per_docs, per_freqs
+    corpus = synth.Corpus(n_docs=N, doc_count=N, sum_total_term_freq=int(lens.astype(np.int64).sum()), segments=segments,
+                          doc_freq=doc_freq)
+    ppq = np.asarray([sum(doc_freq[int(t)] for t in row) for row in qr], dtype=np.int64)
+    log(event="corpus", docs=N, segments=n_seg, postings=corpus.total_postings, mean_P=float(ppq.mean()), build_s=round(time.time() - t0, 1))
+
+    t0 = time.time()
+    rng = np.random.default_rng(7)
+    block = rng.standard_normal((args.seg_docs, dim), dtype=np.float32)
+    ctx = api.GpuContext(0, max_batch=B, collect_timing=True)
+    leaves = []
+    for seg in segments:
+        g = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
+        g.add_field_norms(0, seg.norms)
+        g.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+        g.add_vectors(7, block[: seg.max_doc])
+        g.seal()
+        leaves.append(g)
+    log(event="upload", seconds=round(time.time() - t0, 1), device_gb=round(sum(l.device_bytes for l in leaves) / 2**30, 1))
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    queries = [api.BooleanQuery(tuple(api.TermQuery(0, int(t)) for t in row)) for row in qr]
+    mgr = api.TopScoreDocCollectorManager(1000)
+    qv = rng.standard_normal((B, dim), dtype=np.float32)
+
+    if args.oracle_queries:
+        from oracle import oracle
+        bad = 0
+        got = sr.search_batch(queries[: args.oracle_queries], [mgr] * args.oracle_queries)
+        fused = sr.search_hybrid_batch(queries[: args.oracle_queries], [mgr] * args.oracle_queries, 7, "cosine",
+                                       qv[: args.oracle_queries], 100, 1.0, 2.0)
+        for qi in range(args.oracle_queries):
+            d, s_, tot, gte = oracle.search_bm25(corpus, qr[qi].tolist(), 1000)
+            ok = (got[qi].docs.tolist() == d.tolist() and got[qi].scores.view(np.uint32).tolist() == s_.view(np.uint32).tolist()
+                  and got[qi].total_hits == tot and got[qi].relation_gte == gte)
+            two = sr.rescore_vectors(got[qi], 7, "cosine", qv[qi], 100, 1.0, 2.0)
+            ok = ok and two.docs.tolist() == fused[qi].docs.tolist() and \
+                two.scores.view(np.uint32).tolist() == fused[qi].scores.view(np.uint32).tolist()
+            bad += not ok
+        log(event="parity_full_size", queries=args.oracle_queries, mismatches=int(bad))
+
+    L = _lib.load()
+    m = sr._marshal(queries, [mgr] * B)
+    outs = (_lib.TopDocs * B)()
+    od = np.zeros((B, 1000), np.int32)
+    os_ = np.zeros((B, 1000), np.float32)
+    for qi in range(B):
+        outs[qi].capacity = 1000
+        outs[qi].docs = od[qi].ctypes.data_as(C.POINTER(C.c_int32))
+        outs[qi].scores = os_[qi].ctypes.data_as(C.POINTER(C.c_float))
+
+    def fused_call():
+        _lib.check(L.nrtgpu_search_hybrid_batch(ctx._h, sr._segs, sr._bases, len(leaves), m.queries, B, 7, 0, qv.ctypes.data, dim,
+                                                C.c_float(1.0), 1.0, 2.0, 100, outs))
+
+    def first_pass():
+        _lib.check(L.nrtgpu_search_bm25_batch(ctx._h, sr._segs, sr._bases, len(leaves), m.queries, B, outs))
+
+    fused_call(); first_pass()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fused_call()
+    dt_f = (time.perf_counter() - t0) / args.steps
+    st = ctx.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        first_pass()
+    dt_1 = (time.perf_counter() - t0) / args.steps
+    scan_ms = st["scan_ms"] / max(1, st["scan_launches"])
+    log(event="c5_hybrid", docs=N, dim=dim, batch=B, fused_ms_per_batch=round(dt_f * 1e3, 2), fused_qps=round(B / dt_f, 1),
+        first_pass_ms=round(dt_1 * 1e3, 2), tail_ms=round((dt_f - dt_1) * 1e3, 2), scan_ms=round(scan_ms, 2),
+        scan_gbps_9B=round(9.0 * float(ppq.sum()) / scan_ms / 1e6, 1), vectors_gb=round(N * dim * 4 / 1e9, 1))
+    one = (_lib.TopDocs * 1)()
+    one[0].capacity = 1000
+    one[0].docs = od[0].ctypes.data_as(C.POINTER(C.c_int32))
+    one[0].scores = os_[0].ctypes.data_as(C.POINTER(C.c_float))
+    lat = []
+    for qi in range(16):
+        m1 = sr._marshal(queries[qi: qi + 1], [mgr])
+        t0 = time.perf_counter()
+        _lib.check(L.nrtgpu_search_hybrid_batch(ctx._h, sr._segs, sr._bases, len(leaves), m1.queries, 1, 7, 0, qv[qi].ctypes.data, dim,
+                                                C.c_float(1.0), 1.0, 2.0, 100, one))
+        lat.append((time.perf_counter() - t0) * 1e3)
+    log(event="c5_single_query_latency_ms", p50=round(float(np.median(lat)), 3), max=round(max(lat), 3))
+
+
+if __name__ == "__main__":
+    main()
