@@ -225,3 +225,32 @@ def test_must_conjunction_of_terms(ctx):
             assert_same(f"must_{len(terms)}", got, oracle.search_bm25(corpus, terms, 100, min_should_match=len(terms)), 100, 1000)
     finally:
         ix.close()
+
+
+def test_mask_with_search_after_and_min_competitive(ctx):
+    """A masked query that also pages (searchAfter takes the per-doc path inside the masked variant) or carries
+    a min competitive score from another shard."""
+    corpus = synth.build_corpus(180_000, [1, 3, 12, 90], n_segments=3, delete_fraction=0.02)
+    ix = Index(ctx, corpus)
+    try:
+        masks = [random_mask(s.max_doc, 0.5, 40 + i) for i, s in enumerate(corpus.segments)]
+        for leaf, m in zip(ix.leaves, masks):
+            leaf.set_mask(6, m)
+        acc = [accept_of(s, masks[i], None) for i, s in enumerate(corpus.segments)]
+        terms = [1, 12, 90]
+        q = api.BooleanQuery(tuple(api.TermQuery(0, t) for t in terms), 1, (api.MaskFilter(6),))
+        p1 = ix.searcher.search(q, api.TopScoreDocCollectorManager(60))
+        assert_same("mask_page1", p1, oracle.search_bm25(corpus, terms, 60, accept=acc), 60, 1000)
+        after = api.ScoreDoc(int(p1.docs[-1]), float(p1.scores[-1]))
+        p2 = ix.searcher.search(q, api.TopScoreDocCollectorManager(60, after))
+        assert_same("mask_page2", p2, oracle.search_bm25(corpus, terms, 60, accept=acc, after=(after.doc, after.score)), 60, 1000)
+        assert not set(p1.docs.tolist()) & set(p2.docs.tolist())
+        # a bound from elsewhere: everything strictly below it is counted but not collected
+        bound = float(p1.scores[30])
+        got = ix.searcher.search(q, api.TopScoreDocCollectorManager(60, None, 1000, bound))
+        exp = oracle.search_bm25(corpus, terms, 60, accept=acc)
+        keep = exp[1] >= np.float32(bound)
+        assert got.docs[: keep.sum()].tolist() == exp[0][keep].tolist()
+        assert got.total_hits == exp[2]
+    finally:
+        ix.close()
