@@ -496,7 +496,7 @@ template <int OFF>
 __device__ __forceinline__ void store_where_clear(uint64_t word, uint32_t addr, uint64_t value) {
   uint64_t saved;
   asm volatile("s_mov_b64 %0, exec\n\ts_andn2_b64 exec, exec, %1\n\tds_write_b64 %2, %3 offset:%4\n\ts_mov_b64 exec, %0"
-               : "=&s"(saved) : "s"(word), "v"(addr), "v"(value), "n"(OFF) : "memory");
+               : "=&s"(saved) : "s"(word), "v"(addr), "v"(value), "n"(OFF) : "memory", "scc");
 }
 template <int CHUNK>
 __device__ __forceinline__ void mark_outside_half(const void* mask_tile, uint32_t addr, uint64_t value) {
