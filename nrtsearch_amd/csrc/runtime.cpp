@@ -819,10 +819,19 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
   std::vector<const FieldData*> found_field;
   int32_t fld_id = 0;
   bool fld_valid = false;
+  size_t prev_cache_off = 0, prev_cache_len = 0;
   for (int qi = q_begin; qi < q_end; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
-    cache_base[(size_t)qi] = (uint32_t)pc.caches.size();
-    pc.caches.insert(pc.caches.end(), q.norm_cache, q.norm_cache + (size_t)q.n_caches * 256);
+    // consecutive queries over the same fields carry identical normInverse tables: keep one copy
+    const size_t cache_len = (size_t)q.n_caches * 256;
+    if (prev_cache_len == cache_len && memcmp(pc.caches.data() + prev_cache_off, q.norm_cache, cache_len * sizeof(float)) == 0) {
+      cache_base[(size_t)qi] = (uint32_t)prev_cache_off;
+    } else {
+      prev_cache_off = pc.caches.size();
+      prev_cache_len = cache_len;
+      cache_base[(size_t)qi] = (uint32_t)prev_cache_off;
+      pc.caches.insert(pc.caches.end(), q.norm_cache, q.norm_cache + cache_len);
+    }
     found.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
     found_field.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
     term_total.assign((size_t)q.n_terms, 0);
@@ -906,8 +915,14 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
         qs.postings += e.count;
       }
       if (qs.n_terms > 0) {
-        std::stable_sort(pc.terms.begin() + qs.term_begin, pc.terms.end(),
-                         [](const DTerm& a, const DTerm& b) { return a.count > b.count; });
+        // densest clause first; stable insertion sort (a handful of clauses; std::stable_sort allocates per call)
+        DTerm* tb = pc.terms.data() + qs.term_begin;
+        for (uint32_t i = 1; i < qs.n_terms; ++i) {
+          const DTerm key = tb[i];
+          uint32_t j = i;
+          for (; j > 0 && tb[j - 1].count < key.count; --j) tb[j] = tb[j - 1];
+          tb[j] = key;
+        }
         per_query[(size_t)qi].push_back(qs);
         pc.postings += qs.postings;
         pc.cost += qs.postings + (int64_t)seg->n_tiles * kTileCostPostings;
@@ -935,6 +950,8 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
   for (int qi = 0; qi < n_queries; ++qi)  // lowest key with that score: a doc scoring exactly the bound still passes
     hp.theta_init[(size_t)qi] = queries[qi].min_competitive_score > 0.0f ? pack_key(queries[qi].min_competitive_score, 0xFFFFFFFFu) : 0ull;
 
+  static const bool plan_trace = getenv("NRTGPU_PLAN_TRACE") != nullptr;  // debug aid: phase times on stderr
+  const double tp0 = plan_trace ? now_ms() : 0.0;
   // pass 1: resolve terms per (query, segment), densest term first; remember posting counts.
   // Queries are independent here, so the batch is cut into contiguous chunks resolved by
   // cfg.host_threads planner threads and concatenated (offsets rebased) afterwards.
@@ -954,6 +971,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     work(0);
     for (auto& th : pool) th.join();
   }
+  const double tp1 = plan_trace ? now_ms() : 0.0;
   int64_t total_postings = 0, total_cost = 0;
   {
     size_t nt = 0, nc = 0;
@@ -987,6 +1005,7 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 needs the fixed-point accumulators (weights of a query in "
                                         "this batch span too many binades, or NRTGPU_FLAG_NO_FIXED_POINT is set)");
 
+  const double tp2 = plan_trace ? now_ms() : 0.0;
   // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
   // may span several segments (like a LeafSlice) and a large segment may be cut by tile range.
   // Measured on MI355X (one workgroup per CU): every extra item of a query costs a cold
@@ -1083,6 +1102,9 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
     dq.n_items = hp.q_nlists[(size_t)qi];
     dq.min_should_match = (uint32_t)std::max(q.min_should_match, 0);
   }
+  if (plan_trace)
+    fprintf(stderr, "[nrtgpu plan] %d queries: resolve %.3f ms (%d threads), concat %.3f, cut+items %.3f; %zu terms %zu parts %zu items\n",
+            n_queries, tp1 - tp0, n_thr, tp2 - tp1, now_ms() - tp2, hp.terms.size(), hp.parts.size(), hp.items.size());
   return 0;
 }
 
