@@ -4,8 +4,8 @@
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
 driver launches one rank per GPU with torch.distributed.run.  A *step* is one pass of the hot path
 over one batch of `--batch` synthetic queries (postings already resident in HBM): plan upload,
-postings-scan kernel, top-k merge kernel, results back on the host (N = 1) or RCCL all-gather of
-the per-GPU top-k + merge on every rank (N > 1).  Rank 0 prints ONE JSON line.
+postings-scan kernel, top-k merge kernel, results back on the host (N = 1) or RCCL all-to-all of
+the per-GPU top-k, each rank merging its slice of the batch's queries (N > 1).  Rank 0 prints ONE JSON line.
 
 Workload at N = 1 = BASELINE.json config C3 (10M docs, 5-term BM25 disjunction, top-1000); for
 N > 1 the same index is sharded by contiguous docid range over the ranks (strong scaling).
@@ -49,8 +49,10 @@ def parse_args():
                     help="N>1: do not share score bounds between the GPUs' shards (A/B; results are identical)")
     ap.add_argument("--debug-same-gpu", action="store_true",
                     help="debug: run an N-rank job with every rank on GPU 0 (gloo, collectives staged through the host)")
+    ap.add_argument("--all-gather", action="store_true",
+                    help="N>1: all-gather + merge on every rank instead of the all-to-all split reduce (A/B)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="debug: take the multi-GPU path (device-resident top-k -> all-gather -> merge) even at world size 1")
+                    help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="debug, 1 GPU: index only rank 0's docid range of an N-GPU job (per-rank step time at --gpus N)")
     return ap.parse_args()
@@ -142,6 +144,14 @@ def main():
         else:
             dist.all_gather_into_tensor(dst, src)
 
+    def all_to_all(dst, src):
+        if args.debug_same_gpu:
+            tmp = torch.empty(dst.shape, dtype=dst.dtype)
+            dist.all_to_all_single(tmp, src.cpu())
+            dst.copy_(tmp)
+        else:
+            dist.all_to_all_single(dst, src)
+
     import numpy as np
 
     from nrtsearch_amd import _lib, api, build, synth, workload
@@ -186,11 +196,17 @@ def main():
         bufs = [(torch.zeros((B, k_stride), dtype=torch.int64, device="cuda"),
                  torch.zeros((B,), dtype=torch.int32, device="cuda"),
                  torch.zeros((B,), dtype=torch.int64, device="cuda")) for _ in range(NB)]
-        # all-gather outputs in concatenation form: rank r's rows are [r * B, (r + 1) * B)
-        g_keys = torch.zeros((world * B, k_stride), dtype=torch.int64, device="cuda")
-        g_cnt = torch.zeros((world * B,), dtype=torch.int32, device="cuda")
-        g_hits = torch.zeros((world * B,), dtype=torch.int64, device="cuda")
-        merger = api.PreparedMerge(ctx, world, B, k_stride, [w.k] * B, [api.TOTAL_HITS_THRESHOLD] * B)
+        # The reduce is split between the ranks: an all-to-all hands rank r every rank's lists for ITS B / world
+        # queries (rows [j * B/world, (j + 1) * B/world) of the output came from rank j) and rank r merges only
+        # those -- 1/world of the bytes and of the merge work of all-gather + merge-everywhere.  Fallback when the
+        # batch does not divide: all-gather (rank r's rows are [r * B, (r + 1) * B)), every rank merges everything.
+        split_reduce = (B % world == 0) and not args.all_gather
+        rows = B if split_reduce else world * B
+        g_keys = torch.zeros((rows, k_stride), dtype=torch.int64, device="cuda")
+        g_cnt = torch.zeros((rows,), dtype=torch.int32, device="cuda")
+        g_hits = torch.zeros((rows,), dtype=torch.int64, device="cuda")
+        mq = B // world if split_reduce else B
+        merger = api.PreparedMerge(ctx, world, mq, k_stride, [w.k] * mq, [api.TOTAL_HITS_THRESHOLD] * mq)
 
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -202,7 +218,8 @@ def main():
         """`count` steps starting at batch index `first`.  The C ABI is thread-safe (one workspace + HIP
         stream per in-flight call, ctypes drops the GIL), so plan building of step i+1 overlaps the
         kernels of step i.  Multi-GPU: scan threads leave each rank's top-k in HBM; this thread issues
-        the collectives in step order (RCCL all-gather over xGMI) and runs TopDocs.merge on every rank."""
+        the collectives in step order (RCCL all-to-all over xGMI: every rank receives the lists for its slice of
+        the batch's queries) and runs TopDocs.merge for that slice."""
         if not use_dist:
             n_thr = max(1, args.host_threads)
 
@@ -241,9 +258,10 @@ def main():
             for i in range(count):
                 b = futs[i].result()
                 keys, cnt, hits = bufs[b]
-                all_gather(g_keys, keys) if world > 1 else g_keys.copy_(keys)
-                all_gather(g_cnt, cnt) if world > 1 else g_cnt.copy_(cnt)
-                all_gather(g_hits, hits) if world > 1 else g_hits.copy_(hits)
+                exchange = all_to_all if split_reduce else all_gather
+                exchange(g_keys, keys) if world > 1 else g_keys.copy_(keys)
+                exchange(g_cnt, cnt) if world > 1 else g_cnt.copy_(cnt)
+                exchange(g_hits, hits) if world > 1 else g_hits.copy_(hits)
                 torch.cuda.current_stream().synchronize()   # only this stream: the next scan keeps running
                 free[b].release()
                 merger.run(g_keys.data_ptr(), g_cnt.data_ptr(), g_hits.data_ptr())
@@ -307,7 +325,7 @@ def main():
             "n_docs": w.n_docs, "terms_per_query": w.n_terms, "k": w.k, "batch_queries": B,
             "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
             "segments_per_gpu": len(corpus.segments),
-            "sharding": "contiguous docid ranges, 1 process per GPU" + (", RCCL all-gather of per-GPU top-k + merge" if use_dist else "")
+            "sharding": "contiguous docid ranges, 1 process per GPU" + (", RCCL all-to-all of per-GPU top-k, each rank merges its slice of the batch" if use_dist else "")
                         + (", score-bound exchange between shards" if exchange_name else "")
                         + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),

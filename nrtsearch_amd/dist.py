@@ -5,10 +5,13 @@
     (/root/reference/src/main/java/com/yelp/nrtsearch/server/search/MyIndexSearcher.java:172-187);
     BM25 statistics stay index-global (idf/avgdl are computed once on the host, never per GPU).
   * exchange: every rank holds, per query, its local top-k as packed keys
-    (float_bits(score) << 32 | 0xFFFFFFFF - global_doc) plus counts and hit totals; ONE RCCL
-    all-gather per array (torch.distributed backend "nccl" == RCCL over xGMI) puts all ranks'
-    lists next to each other and every rank runs the same TopDocs.merge kernel
-    (LazyQueueTopScoreDocCollectorManager.java:137-144).  No other data-path collective.
+    (float_bits(score) << 32 | 0xFFFFFFFF - global_doc) plus counts and hit totals.  The batch's queries are
+    split evenly between the ranks for the reduce: ONE RCCL all-to-all per array (torch.distributed backend
+    "nccl" == RCCL; xGMI is point-to-point, which is what an all-to-all wants) hands rank r every rank's lists
+    for ITS slice of the queries, and rank r runs TopDocs.merge (LazyQueueTopScoreDocCollectorManager.java
+    :137-144) for that slice only -- each rank moves and merges 1/W of what an all-gather + merge-everywhere
+    would.  all_gather_topk is the fallback when the batch does not divide by the world size.
+    No other data-path collective.
 
 The same code runs on CPU tensors with the gloo backend (tests/test_dist_gloo.py).
 """
@@ -51,3 +54,23 @@ def all_gather_topk(keys, counts, hits):
     dist.all_gather_into_tensor(g_cnt, counts.contiguous())
     dist.all_gather_into_tensor(g_hits, hits.contiguous())
     return g_keys.view((world, b) + tuple(keys.shape[1:])), g_cnt.view(world, b), g_hits.view(world, b)
+
+
+def all_to_all_topk(keys, counts, hits):
+    """keys [B, k_stride] int64, counts [B] int32, hits [B] int64 with B % world == 0.  Rank r receives every
+    rank's lists for queries [r * B/W, (r + 1) * B/W): ([W, B/W, k_stride], [W, B/W], [W, B/W])."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    b = keys.shape[0]
+    if b % world != 0:
+        raise ValueError(f"batch of {b} queries does not divide by world size {world}")
+    o_keys = torch.empty_like(keys)
+    o_cnt = torch.empty_like(counts)
+    o_hits = torch.empty_like(hits)
+    dist.all_to_all_single(o_keys, keys.contiguous())
+    dist.all_to_all_single(o_cnt, counts.contiguous())
+    dist.all_to_all_single(o_hits, hits.contiguous())
+    per = b // world
+    return o_keys.view((world, per) + tuple(keys.shape[1:])), o_cnt.view(world, per), o_hits.view(world, per)

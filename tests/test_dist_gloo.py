@@ -45,6 +45,18 @@ def _worker(rank: int, world: int, port: int, ret):
                 ed, es, etotal, _ = oracle.search_bm25(full, qr[qi].tolist(), k, total_hits_threshold=2**31 - 1)
                 ok &= md.tolist() == ed.tolist() and ms.view(np.uint32).tolist() == es.view(np.uint32).tolist()
                 ok &= int(g_hits[:, qi].sum()) == etotal
+        # the all-to-all form (what bench.py uses when the batch divides by the world size): every rank merges its
+        # own slice of the queries and must reproduce the single-process answers for that slice
+        a_keys, a_cnt, a_hits = nd.all_to_all_topk(torch.from_numpy(keys), torch.from_numpy(cnt), torch.from_numpy(hits))
+        per = w.n_queries // world
+        full = workload.build_shard_corpus(w, qr, 1, 0)
+        for j in range(per):
+            qi = rank * per + j
+            lists = [nd.unpack_keys(a_keys[r, j].numpy(), int(a_cnt[r, j])) for r in range(world)]
+            md, ms = oracle.topdocs_merge(k, lists)
+            ed, es, etotal, _ = oracle.search_bm25(full, qr[qi].tolist(), k, total_hits_threshold=2**31 - 1)
+            ok &= md.tolist() == ed.tolist() and ms.view(np.uint32).tolist() == es.view(np.uint32).tolist()
+            ok &= int(a_hits[:, j].sum()) == etotal
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
