@@ -201,6 +201,18 @@ def main():
         # those -- 1/world of the bytes and of the merge work of all-gather + merge-everywhere.  Fallback when the
         # batch does not divide: all-gather (rank r's rows are [r * B, (r + 1) * B)), every rank merges everything.
         split_reduce = (B % world == 0) and not args.all_gather
+        if split_reduce and world > 1:   # probe the collective once; every rank must take the same path
+            ok = 1
+            try:
+                probe = torch.zeros((world * 2,), dtype=torch.int64, device="cuda")
+                all_to_all(torch.empty_like(probe), probe)
+                torch.cuda.synchronize()
+            except Exception as e:   # noqa: BLE001
+                print(f"[rank {rank}] all_to_all_single unavailable ({e}); using all-gather", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if args.debug_same_gpu else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            split_reduce = bool(flag.item())
         rows = B if split_reduce else world * B
         g_keys = torch.zeros((rows, k_stride), dtype=torch.int64, device="cuda")
         g_cnt = torch.zeros((rows,), dtype=torch.int32, device="cuda")
@@ -325,7 +337,8 @@ def main():
             "n_docs": w.n_docs, "terms_per_query": w.n_terms, "k": w.k, "batch_queries": B,
             "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
             "segments_per_gpu": len(corpus.segments),
-            "sharding": "contiguous docid ranges, 1 process per GPU" + (", RCCL all-to-all of per-GPU top-k, each rank merges its slice of the batch" if use_dist else "")
+            "sharding": "contiguous docid ranges, 1 process per GPU" + ((", RCCL all-to-all of per-GPU top-k, each rank merges its slice of the batch" if split_reduce else
+                                                                           ", RCCL all-gather of per-GPU top-k + merge on every rank") if use_dist else "")
                         + (", score-bound exchange between shards" if exchange_name else "")
                         + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
