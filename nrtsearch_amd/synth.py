@@ -201,3 +201,23 @@ def make_vectors(n: int, dim: int, seed: int = 777, normalize: bool = False) -> 
     if normalize:
         v /= np.linalg.norm(v, axis=1, keepdims=True).astype(np.float32)
     return v
+
+
+def random_mask(max_doc: int, density: float, seed: int) -> np.ndarray:
+    """Doc set of a synthetic non-scoring clause as uint64 words (bit d set = doc d matches), PCG64(seed)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bits = np.zeros(((max_doc + 63) // 64) * 64, dtype=bool)
+    bits[:max_doc] = rng.random(max_doc) < density
+    return np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+
+
+def accept_words(seg: SegmentData, filter_words: Optional[np.ndarray] = None,
+                 must_not_words: Optional[np.ndarray] = None) -> np.ndarray:
+    """liveDocs & FILTER & ~MUST_NOT of one segment as uint64 words (what the bulk scorer accepts)."""
+    n = (seg.max_doc + 63) // 64
+    w = seg.live_bits.copy() if seg.live_bits is not None else np.full(n, ~np.uint64(0), dtype=np.uint64)
+    if filter_words is not None:
+        w &= filter_words
+    if must_not_words is not None:
+        w &= ~must_not_words
+    return w

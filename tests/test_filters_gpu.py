@@ -11,21 +11,11 @@ from tests.test_parity_gpu import Index, assert_same
 pytestmark = pytest.mark.gpu
 
 
-def random_mask(max_doc, density, seed):
-    rng = np.random.Generator(np.random.PCG64(seed))
-    bits = np.zeros(((max_doc + 63) // 64) * 64, dtype=bool)
-    bits[:max_doc] = rng.random(max_doc) < density
-    return np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+random_mask = synth.random_mask
 
 
 def accept_of(seg, f, mn):
-    n = (seg.max_doc + 63) // 64
-    w = seg.live_bits.copy() if seg.live_bits is not None else np.full(n, ~np.uint64(0), dtype=np.uint64)
-    if f is not None:
-        w &= f
-    if mn is not None:
-        w &= ~mn
-    return w
+    return synth.accept_words(seg, f, mn)
 
 
 @pytest.fixture(scope="module")

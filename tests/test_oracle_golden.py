@@ -259,8 +259,14 @@ def test_oracle_matches_its_frozen_fixture(oracle):
     sp = g["spec"]
     corpus = synth.build_corpus(sp["n_docs"], sp["ranks"], n_segments=sp["n_segments"],
                                 delete_fraction=sp["delete_fraction"], seed=sp["seed"])
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(here, "make_oracle_fixtures.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert len(g["cases"]) >= 10
     for c in g["cases"]:
-        docs, scores, total, gte = oracle.search_bm25(corpus, c["terms"], c["k"], boosts=c.get("boosts"),
-                                                      total_hits_threshold=c["threshold"])
+        (docs, scores, total, gte), _ = gen.run_case(corpus, c)
         assert docs.tolist() == c["docs"] and scores.view(np.uint32).tolist() == c["score_bits"]
         assert int(total) == c["total_hits"] and bool(gte) == c["relation_gte"]

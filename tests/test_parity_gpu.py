@@ -246,8 +246,22 @@ def test_frozen_oracle_fixture_through_the_device(ctx):
                                 delete_fraction=sp["delete_fraction"], seed=sp["seed"])
     ix = Index(ctx, corpus)
     try:
-        for c in g["cases"]:
-            got = ix.searcher.search(bq(c["terms"], c.get("boosts")), api.TopScoreDocCollectorManager(c["k"], None, c["threshold"]))
+        for ci, c in enumerate(g["cases"]):
+            q = bq(c["terms"], c.get("boosts"))
+            if "msm" in c or "filter" in c or "must_not" in c:   # masks: PCG64(seed + 100 * segment), as the generator
+                ids = {}
+                for name in ("filter", "must_not"):
+                    if name in c:
+                        ids[name] = 50 + 2 * ci + (name == "must_not")
+                        for i, (seg, leaf) in enumerate(zip(corpus.segments, ix.leaves)):
+                            leaf.set_mask(ids[name], synth.random_mask(seg.max_doc, c[name]["density"], c[name]["seed"] + 100 * i))
+                cl = q.should if isinstance(q, api.BooleanQuery) else (q,)
+                q = api.BooleanQuery(cl, c.get("msm", 0), (api.MaskFilter(ids["filter"]),) if "filter" in ids else (),
+                                     (api.MaskFilter(ids["must_not"]),) if "must_not" in ids else ())
+            after = None
+            if "after" in c:
+                after = api.ScoreDoc(c["after"]["doc"], float(np.uint32(c["after"]["score_bits"]).view(np.float32)))
+            got = ix.searcher.search(q, api.TopScoreDocCollectorManager(c["k"], after, c["threshold"]))
             assert got.docs.tolist() == c["docs"]
             assert got.scores.view(np.uint32).tolist() == c["score_bits"]
             assert got.total_hits == c["total_hits"] and got.relation_gte == c["relation_gte"]
