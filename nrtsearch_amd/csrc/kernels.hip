@@ -533,7 +533,7 @@ __device__ __forceinline__ void mark_outside(const void* mask_tile, uint32_t acc
 template <bool FX, int ABL>
 __device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, uint32_t lane, uint64_t (&a)[8],
                                                 const uint32_t (&off)[8], uint64_t thr, uint64_t theta, int fx_E,
-                                                uint32_t gdoc0, uint32_t& wave_hits, uint64_t hit_floor = 0,
+                                                uint32_t gdoc0, uint32_t& wave_hits, uint64_t after_key, uint64_t hit_floor = 0,
                                                 uint32_t score_hi_mask = 0xFFFFFFFFu) {
   unsigned long long any_maybe = 0;
 #pragma unroll
@@ -552,7 +552,10 @@ __device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, 
   uint32_t cmask = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    if (acc_reaches<FX>(a[j], thr) && pack_key(acc_score<FX>(a[j], fx_E), gdoc0 + ((off[j] - acc_addr) >> 3)) > theta) cmask |= 1u << j;
+    if (acc_reaches<FX>(a[j], thr)) {
+      const uint64_t key = pack_key(acc_score<FX>(a[j], fx_E), gdoc0 + ((off[j] - acc_addr) >> 3));
+      if (key > theta && key < after_key) cmask |= 1u << j;  // (at or above after_key: already on an earlier page)
+    }
   if (!__any(cmask != 0)) return false;
   if (ABL == 7 && threadIdx.x == 0) s.prof[12] += 1;
   uint32_t pos = reserve_candidates(s, lane, (uint32_t)__popc(cmask));
@@ -591,6 +594,10 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   const int fx_E = item.fx_E;
   unsigned long long* const my_theta_g = theta_g + item.query;
   const bool multi_item = q.n_items > 1;  // uniform: only then is there anybody to share theta with
+  // searchAfter (LazyQueueTopScoreDocCollector.java:112-120): a hit is skipped when score > afterScore or
+  // (score == afterScore and doc <= afterDoc) -- in key order exactly "key >= key(afterScore, afterDoc)".  It is
+  // still a hit (totalHits counts it), so paging only narrows the candidate test and needs no path of its own.
+  const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
   // ABL == 8 (fixed point only): the variant for batches with minimumNumberShouldMatch > 1 queries.  Such a
   // query's postings also count clauses in the accumulator's top bits; all its sub-tiles take the general
   // sweep, whose exact path drops docs with too few clauses and strips the count.
@@ -680,7 +687,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     // uniform: no searchAfter, no clause counting, and no doc-set mask -- unless this is the masked variant
     // (ABL == 9), which poisons the slots outside the mask instead of checking every matched doc
     constexpr bool kMask = ABL == 9 && kTileDocs == 1024;
-    const bool simple = (live_bits == nullptr || kMask) && !q.has_after;
+    const bool simple = live_bits == nullptr || kMask;  // (searchAfter only filters candidates: after_key)
     const bool masked = kMask && live_bits != nullptr && simple;
     auto mask_tile_of = [&](uint32_t g) -> const void* {  // the 128 mask bytes of sub-tile g, as a uniform address
       const uint64_t a = (uint64_t)part.live_bits + (uint64_t)(g + tile_bias) * (uint64_t)(kTileDocs / 8);
@@ -802,8 +809,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         if (sparse) {
           // ---- (4s) collect through the postings
           if (ABL == 7 && tid == 0) s.prof[9] += 1;
-          parked = collect_swapped<FX, ABL>(s, acc_addr, lane, a, off, thr, theta, fx_E, gdoc0, wave_hits, hit_floor, score_hi_mask);
-          if (second) parked |= collect_swapped<FX, ABL>(s, acc_addr, lane, a2, off2, thr, theta, fx_E, gdoc0, wave_hits, hit_floor, score_hi_mask);
+          parked = collect_swapped<FX, ABL>(s, acc_addr, lane, a, off, thr, theta, fx_E, gdoc0, wave_hits, after_key, hit_floor, score_hi_mask);
+          if (second) parked |= collect_swapped<FX, ABL>(s, acc_addr, lane, a2, off2, thr, theta, fx_E, gdoc0, wave_hits, after_key, hit_floor, score_hi_mask);
         } else {
           // ---- (4d) dense sweep of my sub-tile: count hits, reset every slot that cannot be competitive.
           //      A slot whose fp32 score reaches theta's score stays in place (mmask) for the exact path.
@@ -869,8 +876,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
                   if (!simple) ++my_hits;  // totalHits counts every collected doc, also those skipped by `after`
                   const float sc = acc_score<FX>(v, fx_E);
                   const uint32_t gdoc = gdoc0 + i;
-                  const bool skip = q.has_after && (sc > q.after_score || (sc == q.after_score && (int32_t)gdoc <= q.after_doc));
-                  if (!skip) cand = pack_key(sc, gdoc) > theta;
+                  const uint64_t key = pack_key(sc, gdoc);
+                  cand = key > theta && key < after_key;  // at or above after_key: collected on an earlier page
                 }
                 if (cand) {
                   cmask |= 1u << j;

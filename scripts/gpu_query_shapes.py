@@ -70,19 +70,26 @@ def main():
         ("must_not_5pct", lambda r: api.BooleanQuery(should(r), 0, (), (api.MaskFilter(2),)), dict(), False, [~e for e in excl]),
         ("min_should_match_2", lambda r: api.BooleanQuery(should(r), 2), dict(min_should_match=2), False, all_live),
         ("min_should_match_3", lambda r: api.BooleanQuery(should(r), 3), dict(min_should_match=3), False, all_live),
+        ("page_2_search_after", lambda r: api.BooleanQuery(should(r)), dict(), False, all_live),
     ]
     for name, mk, okw, use_live, acc in shapes:
         for leaf, lv in zip(leaves, live):
             leaf.set_live_docs(bits_of(lv) if use_live else None)
         queries = [mk(r) for r in qr]
+        mgrs = [mgr] * B
+        if name.startswith("page_2"):   # searchAfter the last hit of every query's first page
+            first = sr.search_batch(queries, mgrs)
+            mgrs = [api.TopScoreDocCollectorManager(w.k, api.ScoreDoc(int(f.docs[-1]), float(f.scores[-1]))) for f in first]
         bad = 0
-        got = sr.search_batch(queries[: args.oracle_queries], [mgr] * args.oracle_queries)
+        got = sr.search_batch(queries[: args.oracle_queries], mgrs[: args.oracle_queries])
         for qi in range(args.oracle_queries):
+            if name.startswith("page_2"):
+                okw = dict(after=(mgrs[qi].after.doc, mgrs[qi].after.score))
             d, s_, tot, gte = oracle.search_bm25(corpus, qr[qi].tolist(), w.k, accept=[bits_of(a) for a in acc], **okw)
             ok = (got[qi].docs.tolist() == d.tolist() and got[qi].scores.view(np.uint32).tolist() == s_.view(np.uint32).tolist()
                   and got[qi].total_hits == tot and got[qi].relation_gte == gte)
             bad += not ok
-        pb = api.PreparedBatch(sr, queries, [mgr] * B)
+        pb = api.PreparedBatch(sr, queries, mgrs)
         pb.run()
         ctx.reset_stats()
         t0 = time.perf_counter()
