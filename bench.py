@@ -4,8 +4,8 @@
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
 driver launches one rank per GPU with torch.distributed.run.  A *step* is one pass of the hot path
 over one batch of `--batch` synthetic queries (postings already resident in HBM): plan upload,
-postings-scan kernel, top-k merge kernel, results back on the host (N = 1) or RCCL all-to-all of
-the per-GPU top-k, each rank merging its slice of the batch's queries (N > 1).  Rank 0 prints ONE JSON line.
+postings-scan kernel, top-k merge kernel, results back on the host (N = 1) or RCCL all-gather of
+the per-GPU top-k + merge on every rank (N > 1; --all-to-all: each rank merges a slice of the batch).  Rank 0 prints ONE JSON line.
 
 Workload at N = 1 = BASELINE.json config C3 (10M docs, 5-term BM25 disjunction, top-1000); for
 N > 1 the same index is sharded by contiguous docid range over the ranks (strong scaling).
@@ -49,8 +49,9 @@ def parse_args():
                     help="N>1: do not share score bounds between the GPUs' shards (A/B; results are identical)")
     ap.add_argument("--debug-same-gpu", action="store_true",
                     help="debug: run an N-rank job with every rank on GPU 0 (gloo, collectives staged through the host)")
-    ap.add_argument("--all-gather", action="store_true",
-                    help="N>1: all-gather + merge on every rank instead of the all-to-all split reduce (A/B)")
+    ap.add_argument("--all-to-all", action="store_true",
+                    help="N>1: split the reduce between the ranks (all-to-all, each rank merges its slice of the batch) "
+                         "instead of the north star's all-gather + merge on every rank")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -196,11 +197,12 @@ def main():
         bufs = [(torch.zeros((B, k_stride), dtype=torch.int64, device="cuda"),
                  torch.zeros((B,), dtype=torch.int32, device="cuda"),
                  torch.zeros((B,), dtype=torch.int64, device="cuda")) for _ in range(NB)]
-        # The reduce is split between the ranks: an all-to-all hands rank r every rank's lists for ITS B / world
-        # queries (rows [j * B/world, (j + 1) * B/world) of the output came from rank j) and rank r merges only
-        # those -- 1/world of the bytes and of the merge work of all-gather + merge-everywhere.  Fallback when the
-        # batch does not divide: all-gather (rank r's rows are [r * B, (r + 1) * B)), every rank merges everything.
-        split_reduce = (B % world == 0) and not args.all_gather
+        # Default (BASELINE.json's north star): RCCL all-gather of every rank's top-k (rank r's rows are
+        # [r * B, (r + 1) * B)), every rank merges everything and holds every answer.  --all-to-all splits the reduce
+        # instead: rank r receives every rank's lists for ITS B / world queries (rows [j * B/world, (j + 1) * B/world)
+        # came from rank j) and merges only those -- 1/world of the bytes and of the merge work; the exchange stage
+        # is overlapped with the scans either way, so this changes latency, not throughput.
+        split_reduce = (B % world == 0) and args.all_to_all
         if split_reduce and world > 1:   # probe the collective once; every rank must take the same path
             ok = 1
             try:
@@ -230,8 +232,7 @@ def main():
         """`count` steps starting at batch index `first`.  The C ABI is thread-safe (one workspace + HIP
         stream per in-flight call, ctypes drops the GIL), so plan building of step i+1 overlaps the
         kernels of step i.  Multi-GPU: scan threads leave each rank's top-k in HBM; this thread issues
-        the collectives in step order (RCCL all-to-all over xGMI: every rank receives the lists for its slice of
-        the batch's queries) and runs TopDocs.merge for that slice."""
+        the collectives in step order (RCCL all-gather over xGMI, or --all-to-all) and runs TopDocs.merge."""
         if not use_dist:
             n_thr = max(1, args.host_threads)
 

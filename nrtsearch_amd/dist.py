@@ -5,12 +5,12 @@
     (/root/reference/src/main/java/com/yelp/nrtsearch/server/search/MyIndexSearcher.java:172-187);
     BM25 statistics stay index-global (idf/avgdl are computed once on the host, never per GPU).
   * exchange: every rank holds, per query, its local top-k as packed keys
-    (float_bits(score) << 32 | 0xFFFFFFFF - global_doc) plus counts and hit totals.  The batch's queries are
-    split evenly between the ranks for the reduce: ONE RCCL all-to-all per array (torch.distributed backend
-    "nccl" == RCCL; xGMI is point-to-point, which is what an all-to-all wants) hands rank r every rank's lists
-    for ITS slice of the queries, and rank r runs TopDocs.merge (LazyQueueTopScoreDocCollectorManager.java
-    :137-144) for that slice only -- each rank moves and merges 1/W of what an all-gather + merge-everywhere
-    would.  all_gather_topk is the fallback when the batch does not divide by the world size.
+    (float_bits(score) << 32 | 0xFFFFFFFF - global_doc) plus counts and hit totals; ONE RCCL
+    all-gather per array (torch.distributed backend "nccl" == RCCL over xGMI) puts all ranks'
+    lists next to each other and every rank runs the same TopDocs.merge kernel
+    (LazyQueueTopScoreDocCollectorManager.java:137-144): all_gather_topk.  all_to_all_topk is the split
+    form of the same reduce: rank r receives every rank's lists for ITS slice of the batch's queries and
+    merges only those (1/W of the bytes and of the merge work; xGMI is point-to-point).
     No other data-path collective.
 
 The same code runs on CPU tensors with the gloo backend (tests/test_dist_gloo.py).
