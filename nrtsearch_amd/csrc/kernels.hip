@@ -1,7 +1,9 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the BM25 hot path.
 //
 //   fold_norms_kernel  seal-time: folds each posting's field-norm byte into its freq word
+//   apply_live_kernel  per reader version: re-codes the postings of deleted docs to score the neutral element
 //   bm25_scan_kernel   postings traversal + BM25Similarity + disjunction sum + per-item top-k
+//                      (variants: clause counting for minimumNumberShouldMatch, doc-set masks for FILTER / MUST_NOT)
 //   merge_topk_kernel  TopDocs.merge of per-item (or per-GPU) top-k lists + final ordering
 //
 // What they replace in the reference (all inside lucene-core 10.4.0, reached from
@@ -13,9 +15,10 @@
 //
 // Arithmetic contract (bit-exact with Java): every BM25 op is a separate
 // IEEE fp32 operation (this TU is compiled with -ffp-contract=off and without fast-math, so
-// `/` is the correctly rounded division), per-doc term scores are added in fp64 (ds_add_f64 into
-// the LDS tile; the sum of a few fp32 values is exact in fp64, hence order-independent) and the
-// sum is rounded once to fp32.
+// `/` is the correctly rounded division), per-doc term scores are added exactly -- in fp64 (ds_add_f64
+// into the LDS tile; the sum of a few fp32 values is exact in fp64, hence order-independent) or as
+// fixed-point integers at a per-query scale (ds_add_u64; see "Accumulators" below) -- and the sum is
+// rounded once to fp32.
 //
 // HBM layout: per upload group two u32 columns, docid[] and code[] (freq and the doc's norm byte
 // folded into one word at seal time), both read with coalesced 16 B/lane non-temporal loads; the
@@ -573,8 +576,10 @@ __device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, 
 }
 
 // FX: accumulator representation (see above).  PIPE = true: the first posting pair per lane of the
-// wave's next sub-tile is loaded before the current one is collected.  ABL: 7 = instrumented variant
-// (event counters per item), 1-4 = timing ablations (wrong results).
+// wave's next sub-tile is loaded before the current one is collected.  ABL selects the variant:
+// 0 = the scan; 8 = clause counting (minimumNumberShouldMatch > 1, fixed point only); 9 = doc-set masks
+// (FILTER / MUST_NOT, liveDocs that are not folded into the postings); 7 = instrumented (event counters
+// per item); 1-4, 6 = timing ablations (wrong results).
 template <bool FX, bool PIPE, int ABL>
 __global__ __launch_bounds__(kScanThreads, kScanWaves / 4)
 void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts,
