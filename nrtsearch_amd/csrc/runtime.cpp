@@ -262,6 +262,7 @@ struct nrtgpu_ctx {
   std::vector<struct CoRequest*> co_pending;  // waiting for a leader
   struct CoRequest* co_leader = nullptr;      // the caller lingering for / about to run the next batch
   int co_inflight = 0;                        // coalesced batches executing right now
+  int co_inflight_queries = 0;                // ... and how many queries they hold
   int32_t co_linger_us = 150;
   // cross-GPU bound exchange (nrtgpu_exchange_open)
   void* xch_host = nullptr;                 // mmap of the shared table
@@ -1429,7 +1430,12 @@ struct CoRequest {
   bool done = false;   // results (or the error) are in place
   bool lead = false;   // promoted: this caller lingers for and runs the next batch
   std::string err;
-  std::condition_variable cv;  // every caller sleeps on its own: no thundering herd at hundreds of callers
+  // Every caller sleeps on its own condition variable AND its own mutex: a finished batch wakes hundreds of
+  // callers, and if they all had to re-acquire the coalescer's lock to leave their wait (and again to submit
+  // their next request) the lock handoffs alone would cost more than the batch's kernels.  done / lead are
+  // written under `m`; the lingering leader is the one waiter that uses `cv` with the coalescer's lock.
+  std::mutex m;
+  std::condition_variable cv;
 };
 
 static bool same_leaves(const CoRequest* a, const CoRequest* b) {
@@ -1466,22 +1472,34 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     ctx->co_pending.push_back(&me);
     if (ctx->co_leader) {  // follower: the lingering leader takes this request (or a later one does)
       if ((int32_t)ctx->co_pending.size() >= ctx->cfg.max_batch) ctx->co_leader->cv.notify_one();
-      me.cv.wait(lk, [&] { return me.done || me.lead; });
+      lk.unlock();
+      {
+        std::unique_lock<std::mutex> mine(me.m);
+        me.cv.wait(mine, [&] { return me.done || me.lead; });
+      }
       if (me.done) {
         if (me.rc != 0) g_last_error = me.err;
         return me.rc;
       }
+      lk.lock();  // promoted: continue as the leader
     } else {
       ctx->co_leader = &me;
     }
-    // leader: linger for company; then leave as soon as the device can take the batch (two in flight: the
-    // planning and copies of one overlap the kernels of the other) -- while it cannot, waiting only grows
-    // the batch.  Woken by a full queue or a finishing batch.
+    // leader: linger for company, then leave when the device is idle.  While one batch is running a second one
+    // leaves only if it is big enough to be worth overlapping (planning and copies of one then hide behind the
+    // kernels of the other: >= kCoOverlapMin queries, or twice the running batch); a smaller one waits for the
+    // running batch's callers to come back and join it -- below a few hundred queries device time per query
+    // falls so steeply with the batch size that one cohort of C callers beats two alternating cohorts of C / 2
+    // even with the device idle between its batches (measured: 64 callers 18.2 k -> 23.9 k queries/s).  Never
+    // more than two in flight.  Woken by a full queue or a finishing batch.
+    constexpr int32_t kCoOverlapMin = 192;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(ctx->co_linger_us);
     for (;;) {
-      if ((int32_t)ctx->co_pending.size() >= ctx->cfg.max_batch) break;
+      const int32_t waiting = (int32_t)ctx->co_pending.size();
+      if (waiting >= ctx->cfg.max_batch) break;
       const bool late = std::chrono::steady_clock::now() >= deadline;
-      if (late && ctx->co_inflight < 2) break;
+      if (late && (ctx->co_inflight == 0 ||
+                   (ctx->co_inflight == 1 && (waiting >= 2 * ctx->co_inflight_queries || waiting >= kCoOverlapMin)))) break;
       if (late) me.cv.wait(lk);
       else me.cv.wait_until(lk, deadline);
     }
@@ -1496,11 +1514,14 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     ctx->co_pending.swap(rest);
     ctx->co_leader = nullptr;
     if (!ctx->co_pending.empty()) {  // hand the lead to the oldest request left behind
-      ctx->co_leader = ctx->co_pending.front();
-      ctx->co_leader->lead = true;
-      ctx->co_leader->cv.notify_one();
+      CoRequest* next = ctx->co_pending.front();
+      ctx->co_leader = next;
+      std::lock_guard<std::mutex> theirs(next->m);
+      next->lead = true;
+      next->cv.notify_one();
     }
     ctx->co_inflight++;
+    ctx->co_inflight_queries += (int)batch.size();
   }
   // run the batch outside the lock
   std::vector<nrtgpu_bm25_query> qs(batch.size());
@@ -1511,19 +1532,28 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
   }
   const int rc = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data());
   const std::string err = rc ? g_last_error : std::string();
-  {
-    // (notified under the lock: a woken caller cannot return -- and free its request -- before we are done with it)
-    std::lock_guard<std::mutex> lk(ctx->co_mu);
-    for (size_t i = 0; i < batch.size(); ++i) {
-      if (rc == 0) *batch[i]->out = outs[i];
-      batch[i]->rc = rc;
-      batch[i]->err = err;
-      batch[i]->done = true;
-      if (batch[i] != &me) batch[i]->cv.notify_one();
+  for (size_t i = 0; i < batch.size(); ++i) {
+    CoRequest* r = batch[i];
+    if (r == &me) {
+      if (rc == 0) *out = outs[i];
+      continue;
     }
+    // (notified under the request's own lock: the woken caller cannot return -- and free its request -- before
+    // we are done with it, and it contends with nobody but us)
+    std::lock_guard<std::mutex> theirs(r->m);
+    if (rc == 0) *r->out = outs[i];
+    r->rc = rc;
+    if (rc != 0) r->err = err;
+    r->done = true;
+    r->cv.notify_one();
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->co_mu);
     ctx->co_inflight--;
+    ctx->co_inflight_queries -= (int)batch.size();
     if (ctx->co_leader) ctx->co_leader->cv.notify_one();  // a lingering leader may be waiting for the device
   }
+  if (rc != 0) g_last_error = err;
   return rc;
 }
 
