@@ -1503,12 +1503,17 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
       if (late) me.cv.wait(lk);
       else me.cv.wait_until(lk, deadline);
     }
-    // take my request and every pending one over the same leaves (up to max_batch)
+    // take my request and every pending one over the same leaves (up to max_batch).  A big cohort that finds the
+    // device idle is cut in two, so that from now on the host work of one half (planning, copies, waking its
+    // callers) hides behind the kernels of the other.
+    int32_t cap = ctx->cfg.max_batch;
+    if (ctx->co_inflight == 0 && (int32_t)ctx->co_pending.size() >= 2 * kCoOverlapMin && (int32_t)ctx->co_pending.size() < cap)
+      cap = ((int32_t)ctx->co_pending.size() + 1) / 2;
     std::vector<CoRequest*> rest;
     batch.push_back(&me);
     for (CoRequest* r : ctx->co_pending) {
       if (r == &me) continue;
-      if ((int32_t)batch.size() < ctx->cfg.max_batch && same_leaves(&me, r)) batch.push_back(r);
+      if ((int32_t)batch.size() < cap && same_leaves(&me, r)) batch.push_back(r);
       else rest.push_back(r);
     }
     ctx->co_pending.swap(rest);
