@@ -170,7 +170,11 @@ def main():
     t_build = time.perf_counter() - t_build
 
     flags = _lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0
-    ctx = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True, flags=flags)
+    # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
+    # (the node's ranks share the host; 4 is the library's default and enough at one rank)
+    planner_threads = max(1, min(4, usable_cpus() // max(1, world * max(1, args.host_threads))))
+    ctx = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True, flags=flags,
+                         host_threads=planner_threads)
     leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
     searcher = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
     queries = workload.boolean_queries(qranks)
@@ -344,7 +348,7 @@ def main():
                         + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": st["scan_items"] / max(1, st["batches"]),
-            "prefetch": not args.no_prefetch,
+            "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
             "host_threads": n_thr,
             "corpus_build_s": round(t_build, 1),
         },
