@@ -263,6 +263,7 @@ struct nrtgpu_ctx {
   struct CoRequest* co_leader = nullptr;      // the caller lingering for / about to run the next batch
   int co_inflight = 0;                        // coalesced batches executing right now
   int co_inflight_queries = 0;                // ... and how many queries they hold
+  int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
   int32_t co_linger_us = 150;
   // cross-GPU bound exchange (nrtgpu_exchange_open)
   void* xch_host = nullptr;                 // mmap of the shared table
@@ -1493,7 +1494,10 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     // even with the device idle between its batches (measured: 64 callers 18.2 k -> 23.9 k queries/s).  Never
     // more than two in flight.  Woken by a full queue or a finishing batch.
     constexpr int32_t kCoOverlapMin = 192;
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(ctx->co_linger_us);
+    // (a caller that was alone last time and is alone now does not linger: a single stream of requests pays
+    // no batching latency)
+    const bool alone = ctx->co_last_batch <= 1 && ctx->co_pending.size() == 1 && ctx->co_inflight == 0;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(alone ? 0 : ctx->co_linger_us);
     for (;;) {
       const int32_t waiting = (int32_t)ctx->co_pending.size();
       if (waiting >= ctx->cfg.max_batch) break;
@@ -1527,6 +1531,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     }
     ctx->co_inflight++;
     ctx->co_inflight_queries += (int)batch.size();
+    ctx->co_last_batch = (int)batch.size();
   }
   // run the batch outside the lock
   std::vector<nrtgpu_bm25_query> qs(batch.size());
