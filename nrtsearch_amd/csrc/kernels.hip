@@ -424,6 +424,10 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
         s.theta = pb;
         s.thr = acc_threshold<FX>(pb, fx_E);
       }
+      // The bound holds for the whole query (at least k of its docs reach it), so the query's other items get it
+      // right away through theta_g -- every wave reads that once per sub-tile -- instead of at their own next
+      // compaction, which comes the later the better their bound already is.
+      if (tid == 0 && pb != 0ull) atomicMax(theta_g, (unsigned long long)pb);
     }
     __syncthreads();
   } else {

@@ -1018,11 +1018,35 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
   const int64_t per_item = std::max<int64_t>(min_item_cost, total_cost / std::max<int64_t>(1, target_items));
   struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; };
   std::vector<Pending> pend;
+  std::vector<int64_t> q_costs((size_t)n_queries, 0), q_items((size_t)n_queries, 0);
+  int64_t n_live = 0, n_items_total = 0;
   for (int qi = 0; qi < n_queries; ++qi) {
-    int64_t q_cost = 0;
-    for (const QS& qs : per_query[(size_t)qi]) q_cost += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
+    for (const QS& qs : per_query[(size_t)qi]) q_costs[(size_t)qi] += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
+    if (q_costs[(size_t)qi] == 0) continue;
+    ++n_live;
+    q_items[(size_t)qi] = std::max<int64_t>(1, (q_costs[(size_t)qi] + per_item / 2) / per_item);
+    n_items_total += q_items[(size_t)qi];
+  }
+  // A small batch is cut into EXACTLY one item per CU: rounding each query on its own gives a few items more
+  // than CUs, and near-equal items then run in two rounds with most CUs idle in the second (64 queries: 273
+  // items on 256 CUs).  Largest-remainder apportionment of the CUs over the queries by cost.
+  if (n_live > 0 && n_live * 2 <= target_items && n_items_total > target_items && total_cost >= target_items * min_item_cost) {
+    std::vector<std::pair<double, int>> frac;
+    int64_t given = 0;
+    for (int qi = 0; qi < n_queries; ++qi) {
+      if (q_costs[(size_t)qi] == 0) continue;
+      const double share = (double)q_costs[(size_t)qi] * (double)target_items / (double)total_cost;
+      q_items[(size_t)qi] = std::max<int64_t>(1, (int64_t)share);
+      given += q_items[(size_t)qi];
+      frac.emplace_back(share - std::floor(share), qi);
+    }
+    std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    for (size_t i = 0; i < frac.size() && given < target_items; ++i, ++given) q_items[(size_t)frac[i].second]++;
+  }
+  for (int qi = 0; qi < n_queries; ++qi) {
+    const int64_t q_cost = q_costs[(size_t)qi];
     if (q_cost == 0) continue;
-    const int64_t n_it = std::max<int64_t>(1, (q_cost + per_item / 2) / per_item);
+    const int64_t n_it = q_items[(size_t)qi];
     const double budget = (double)q_cost / (double)n_it;
     Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
     double filled = 0.0;
@@ -1059,7 +1083,21 @@ static int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
         }
       }
     }
-    if (cur.n_parts > 0) pend.push_back(cur);
+    if (cur.n_parts > 0) {
+      // A short remainder (the tile rounding of the items before it) does not become an item of its own: it would
+      // finish without a single compaction, never publish its quantile, and with one peer silent the bound
+      // exchange between the query's items never forms (kernels.hip: peers_bound).  It joins the item before it.
+      if (!pend.empty() && pend.back().query == (uint32_t)qi && (double)cur.cost < 0.5 * budget &&
+          pend.back().part_begin + pend.back().n_parts == cur.part_begin) {
+        Pending& prev = pend.back();
+        for (uint32_t pi2 = 0; pi2 < cur.n_parts; ++pi2) hp.parts[cur.part_begin + pi2].tile_offset += prev.tiles;
+        prev.n_parts += cur.n_parts;
+        prev.tiles += cur.tiles;
+        prev.cost += cur.cost;
+      } else {
+        pend.push_back(cur);
+      }
+    }
   }
   // longest-processing-time-first launch order: the hardware dispatcher hands out workgroups in
   // index order, so big items start first and small ones fill the tail
