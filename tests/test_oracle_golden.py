@@ -225,6 +225,49 @@ def test_segment_search_matches_bruteforce(oracle):
     assert scores.tolist() == [s for s, _ in allhits[:50]]
 
 
+def test_query_shapes_match_bruteforce(oracle):
+    """minimumNumberShouldMatch, FILTER / MUST_NOT doc sets, searchAfter and repeated clauses of the oracle
+    against an independent numpy restatement (float32 term scores, float64 sums, one cast, HitQueue order)."""
+    from nrtsearch_amd import synth
+
+    corpus = synth.build_corpus(30000, [1, 2, 5, 11, 60, 400], n_segments=3, delete_fraction=0.03)
+    fm = [synth.random_mask(s.max_doc, 0.4, 70 + i) for i, s in enumerate(corpus.segments)]
+    mn = [synth.random_mask(s.max_doc, 0.1, 80 + i) for i, s in enumerate(corpus.segments)]
+
+    def brute(terms, msm, use_f, use_mn):
+        w, cache = oracle.bm25_query_stats(corpus, terms)
+        hits = []
+        for si, seg in enumerate(corpus.segments):
+            acc = np.zeros(seg.max_doc, np.float64)
+            cnt = np.zeros(seg.max_doc, np.int32)
+            for wi, t in zip(w, terms):          # a repeated term is two clauses: counted and scored twice
+                d, f = seg.postings(t)
+                acc[d] += (wi - wi / (f32(1.0) + f.astype(np.float32) * cache[seg.norms[d]])).astype(np.float64)
+                cnt[d] += 1
+            ok = cnt >= max(msm, 1)
+            for words, keep in ((seg.live_bits, True), (fm[si] if use_f else None, True), (mn[si] if use_mn else None, False)):
+                if words is not None:
+                    bits = np.unpackbits(words.view(np.uint8), bitorder="little")[: seg.max_doc].astype(bool)
+                    ok &= bits if keep else ~bits
+            hits += [(float(f32(acc[i])), int(i) + seg.doc_base) for i in np.nonzero(ok)[0]]
+        hits.sort(key=lambda t: (-t[0], t[1]))
+        return hits
+
+    for terms, msm, use_f, use_mn in (([1, 5, 60], 2, False, False), ([1, 2, 5, 11, 400], 4, True, False),
+                                      ([2, 2, 60], 2, False, True), ([1, 11, 60, 400], 1, True, True)):
+        acc = [synth.accept_words(s, fm[i] if use_f else None, mn[i] if use_mn else None) for i, s in enumerate(corpus.segments)] \
+            if (use_f or use_mn) else None
+        exp = brute(terms, msm, use_f, use_mn)
+        docs, scores, total, gte = oracle.search_bm25(corpus, terms, 40, total_hits_threshold=2**31 - 1, min_should_match=msm, accept=acc)
+        assert total == len(exp) and not gte
+        assert docs.tolist() == [d for _, d in exp[:40]] and scores.tolist() == [s for s, _ in exp[:40]]
+        # page 2: searchAfter the 25th hit
+        if len(exp) > 30:
+            after = (exp[24][1], exp[24][0])
+            d2, s2, t2, _ = oracle.search_bm25(corpus, terms, 10, total_hits_threshold=2**31 - 1, min_should_match=msm, accept=acc, after=after)
+            assert d2.tolist() == [d for _, d in exp[25:35]] and s2.tolist() == [s for s, _ in exp[25:35]] and t2 == len(exp)
+
+
 # ---- tests/golden: the catalogue of the reference's golden values and the frozen oracle fixture ----------
 def _golden(name):
     import json
