@@ -93,7 +93,10 @@ int  nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int32_t dim, 
 /* builds the per-term doc-range tables; the segment becomes searchable */
 int  nrtgpu_segment_seal(nrtgpu_seg* seg);
 /* leaf.getLiveDocs() as 64-bit words, bit d set = doc d live; NULL => all live.  May be called
- * again after seal (only liveDocs change between reader versions of one segment). */
+ * again after seal (only liveDocs change between reader versions of one segment).  Costs one device
+ * pass over the segment's postings: the postings of deleted docs are re-coded to score the neutral
+ * element, so searches pay nothing per query for deletes.  Not concurrently with searches over this
+ * segment. */
 int  nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words);
 /* Non-scoring clauses as doc-set masks (FILTER / MUST_NOT of the BooleanQuery built at
  * src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:257-283).  The shim materialises the
