@@ -95,15 +95,16 @@ int  nrtgpu_segment_seal(nrtgpu_seg* seg);
 /* leaf.getLiveDocs() as 64-bit words, bit d set = doc d live; NULL => all live.  May be called
  * again after seal (only liveDocs change between reader versions of one segment).  Costs one device
  * pass over the segment's postings: the postings of deleted docs are re-coded to score the neutral
- * element, so searches pay nothing per query for deletes.  Not concurrently with searches over this
- * segment. */
+ * element, so searches pay nothing per query for deletes.  Thread-safe against searches: the call waits for
+ * the searches running over this segment and later ones wait for it (they see the new liveDocs; one
+ * liveDocs version per segment handle at a time). */
 int  nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words);
 /* Non-scoring clauses as doc-set masks (FILTER / MUST_NOT of the BooleanQuery built at
  * src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:257-283).  The shim materialises the
  * clause's per-leaf DocIdSet (what LRUQueryCache caches) as 64-bit words, bit d set = doc d matches,
  * and registers it under an id > 0 of its choosing; queries name ids (nrtgpu_bm25_query.filter_mask /
- * must_not_mask).  bits == NULL drops the mask.  Like set_live_docs: not concurrently with searches
- * over this segment. */
+ * must_not_mask).  bits == NULL drops the mask.  Like set_live_docs: excludes itself from the searches
+ * running over this segment. */
 int  nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const uint64_t* bits, int32_t n_words);
 void nrtgpu_segment_release(nrtgpu_seg* seg);
 /* bytes of HBM held by the segment (diagnostics) */

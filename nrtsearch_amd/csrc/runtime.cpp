@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -213,9 +214,29 @@ struct nrtgpu_seg {
   // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use
   std::vector<uint64_t> h_live;                      // empty = all live
   bool live_folded = false;  // the posting columns carry the current liveDocs (apply_live_kernel): the scan needs no mask for them
+  // searches hold this shared from planning until their kernels have finished; set_live_docs / set_mask take it
+  // exclusively, so a reader-version change never rewrites columns or masks under a running scan
+  mutable std::shared_mutex content_mu;
   std::map<int32_t, std::vector<uint64_t>> masks;
   mutable std::mutex accept_mu;
   mutable std::map<std::pair<int32_t, int32_t>, uint64_t*> accept;
+};
+
+// Shared locks on the content of every (distinct) segment of a call, taken in address order.
+struct SegReadLocks {
+  std::vector<const nrtgpu_seg*> held;
+  SegReadLocks(const nrtgpu_seg* const* segs, int32_t n) {
+    for (int32_t i = 0; i < n; ++i)
+      if (segs && segs[i]) held.push_back(segs[i]);
+    std::sort(held.begin(), held.end());
+    held.erase(std::unique(held.begin(), held.end()), held.end());
+    for (const nrtgpu_seg* s : held) s->content_mu.lock_shared();
+  }
+  ~SegReadLocks() {
+    for (const nrtgpu_seg* s : held) s->content_mu.unlock_shared();
+  }
+  SegReadLocks(const SegReadLocks&) = delete;
+  SegReadLocks& operator=(const SegReadLocks&) = delete;
 };
 
 static const size_t kMaskPadBytes = 256;  // doc-set masks are readable one sub-tile (128 bytes) past max_doc
@@ -635,6 +656,7 @@ static int fold_live_docs(nrtgpu_seg* seg) {
 
 extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  std::unique_lock<std::shared_mutex> content(seg->content_mu);  // waits for the searches running over this segment
   HIP_TRY(hipSetDevice(seg->ctx->device));
   const int32_t need = (seg->max_doc + 63) / 64;
   drop_accept_sets(seg);
@@ -659,6 +681,7 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
 extern "C" int nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const uint64_t* bits, int32_t n_words) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
   if (mask_id <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "mask id must be > 0, got %d", mask_id);
+  std::unique_lock<std::shared_mutex> content(seg->content_mu);  // waits for the searches running over this segment
   HIP_TRY(hipSetDevice(seg->ctx->device));
   const int32_t need = (seg->max_doc + 63) / 64;
   drop_accept_sets(seg);
@@ -1312,6 +1335,9 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   HIP_TRY(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   HostPlan hp;
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
   if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
   const double plan_ms = now_ms() - t0;
 
@@ -1368,6 +1394,9 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   HIP_TRY(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   HostPlan hp;
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
   if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
   const double plan_ms = now_ms() - t0;
   for (int si = 0; si < n_segs; ++si) {
@@ -1674,6 +1703,9 @@ extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtg
   HIP_TRY(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   HostPlan hp;
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
   if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
   if (k_stride < (int32_t)hp.k_stride && k_stride < NRTGPU_MAX_K) {
     for (int qi = 0; qi < n_queries; ++qi)
@@ -1767,6 +1799,9 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
   if (dim % 16 != 0 || dim > 1280) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 1280)", dim);
   HIP_TRY(hipSetDevice(ctx->device));
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
+  SegReadLocks content(segs, n_segs);  // liveDocs / masks stay as they are until the kernels have finished
   for (int si = 0; si < n_segs; ++si) {
     if (!segs[si] || !segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
     auto fit = segs[si]->fields.find(field_id);

@@ -244,3 +244,64 @@ def test_mask_with_search_after_and_min_competitive(ctx):
         assert got.total_hits == exp[2]
     finally:
         ix.close()
+
+
+def test_live_docs_change_while_searching(ctx):
+    """A reader-version change (new liveDocs) while searches run on other threads: every answer is the oracle's
+    for one of the two versions -- never a mixture (the fold rewrites posting columns in place, so searches and
+    set_live_docs exclude each other per segment inside the library)."""
+    import threading
+
+    corpus = synth.build_corpus(120_000, [1, 3, 9, 40], n_segments=2, delete_fraction=0.02)
+    ix = Index(ctx, corpus)
+    try:
+        rng = np.random.Generator(np.random.PCG64(5))
+        v_a = [s.live_bits.copy() for s in corpus.segments]
+        v_b = []
+        for s in corpus.segments:
+            alive = np.unpackbits(s.live_bits.view(np.uint8), bitorder="little")[: s.max_doc].astype(bool) & (rng.random(s.max_doc) >= 0.2)
+            padded = np.zeros(((s.max_doc + 63) // 64) * 64, dtype=bool)
+            padded[: s.max_doc] = alive
+            v_b.append(np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1))
+        terms = [1, 9, 40]
+        q = api.BooleanQuery(tuple(api.TermQuery(0, t) for t in terms))
+        # the leaves switch one after the other, so a search may legally see any combination of versions per leaf
+        exp = []
+        for c0 in (v_a, v_b):
+            for c1 in (v_a, v_b):
+                d, s_, tot, gte = oracle.search_bm25(corpus, terms, 100, accept=[c0[0], c1[1]])
+                exp.append((d.tolist(), s_.view(np.uint32).tolist(), tot, gte))
+        stop = threading.Event()
+        errors = []
+
+        def flip():
+            i = 0
+            while not stop.is_set():
+                ver = v_b if i % 2 == 0 else v_a
+                for leaf, bits in zip(ix.leaves, ver):
+                    leaf.set_live_docs(bits)
+                i += 1
+
+        def search():
+            for _ in range(150):
+                got = ix.searcher.search(q, api.TopScoreDocCollectorManager(100))
+                rec = (got.docs.tolist(), got.scores.view(np.uint32).tolist(), got.total_hits, got.relation_gte)
+                if rec not in exp:
+                    errors.append(rec[2])
+
+        t_flip = threading.Thread(target=flip)
+        t_search = [threading.Thread(target=search) for _ in range(3)]
+        t_flip.start()
+        for t in t_search:
+            t.start()
+        for t in t_search:
+            t.join()
+        stop.set()
+        t_flip.join()
+        assert not errors, f"{len(errors)} searches saw a torn segment"
+        for leaf, bits in zip(ix.leaves, v_a):
+            leaf.set_live_docs(bits)
+        got = ix.searcher.search(q, api.TopScoreDocCollectorManager(100))
+        assert got.docs.tolist() == exp[0][0] and got.total_hits == exp[0][2]   # exp[0] = both leaves at version A
+    finally:
+        ix.close()
