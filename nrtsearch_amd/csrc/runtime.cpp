@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <cmath>
@@ -217,9 +218,19 @@ struct nrtgpu_seg {
   // searches hold this shared from planning until their kernels have finished; set_live_docs / set_mask take it
   // exclusively, so a reader-version change never rewrites columns or masks under a running scan
   mutable std::shared_mutex content_mu;
+  mutable std::atomic<int> content_writers{0};  // pending exclusive owners: new searches let them go first (no writer starvation)
   std::map<int32_t, std::vector<uint64_t>> masks;
   mutable std::mutex accept_mu;
   mutable std::map<std::pair<int32_t, int32_t>, uint64_t*> accept;
+};
+
+// Exclusive ownership of a segment's content (liveDocs, masks, the posting columns' liveness coding).
+struct SegWriteLock {
+  nrtgpu_seg* seg;
+  explicit SegWriteLock(nrtgpu_seg* s);
+  ~SegWriteLock();
+  SegWriteLock(const SegWriteLock&) = delete;
+  SegWriteLock& operator=(const SegWriteLock&) = delete;
 };
 
 // Shared locks on the content of every (distinct) segment of a call, taken in address order.
@@ -230,7 +241,10 @@ struct SegReadLocks {
       if (segs && segs[i]) held.push_back(segs[i]);
     std::sort(held.begin(), held.end());
     held.erase(std::unique(held.begin(), held.end()), held.end());
-    for (const nrtgpu_seg* s : held) s->content_mu.lock_shared();
+    for (const nrtgpu_seg* s : held) {
+      while (s->content_writers.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      s->content_mu.lock_shared();
+    }
   }
   ~SegReadLocks() {
     for (const nrtgpu_seg* s : held) s->content_mu.unlock_shared();
@@ -238,6 +252,15 @@ struct SegReadLocks {
   SegReadLocks(const SegReadLocks&) = delete;
   SegReadLocks& operator=(const SegReadLocks&) = delete;
 };
+
+SegWriteLock::SegWriteLock(nrtgpu_seg* s) : seg(s) {
+  seg->content_writers.fetch_add(1, std::memory_order_acq_rel);
+  seg->content_mu.lock();
+}
+SegWriteLock::~SegWriteLock() {
+  seg->content_mu.unlock();
+  seg->content_writers.fetch_sub(1, std::memory_order_acq_rel);
+}
 
 static const size_t kMaskPadBytes = 256;  // doc-set masks are readable one sub-tile (128 bytes) past max_doc
 
@@ -656,7 +679,7 @@ static int fold_live_docs(nrtgpu_seg* seg) {
 
 extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
-  std::unique_lock<std::shared_mutex> content(seg->content_mu);  // waits for the searches running over this segment
+  SegWriteLock content(seg);  // waits for the searches running over this segment; later ones wait for it
   HIP_TRY(hipSetDevice(seg->ctx->device));
   const int32_t need = (seg->max_doc + 63) / 64;
   drop_accept_sets(seg);
@@ -681,7 +704,7 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
 extern "C" int nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const uint64_t* bits, int32_t n_words) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
   if (mask_id <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "mask id must be > 0, got %d", mask_id);
-  std::unique_lock<std::shared_mutex> content(seg->content_mu);  // waits for the searches running over this segment
+  SegWriteLock content(seg);  // waits for the searches running over this segment; later ones wait for it
   HIP_TRY(hipSetDevice(seg->ctx->device));
   const int32_t need = (seg->max_doc + 63) / 64;
   drop_accept_sets(seg);
