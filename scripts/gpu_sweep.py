@@ -93,12 +93,17 @@ def main():
         L = max(1, st["scan_launches"])
         scan_ms = st["scan_ms"] / L
         bytes_l = st["scan_postings"] / L * 8
+        prof = ctx.scan_profile() if ((fl >> 8) & 15) == 7 else None
+        per_item = None
+        if prof:   # the counters are sums over every item of every launch since reset_stats (wave 0 of each workgroup)
+            n_it = max(1.0, float(st["scan_items"]))
+            per_item = {k: round(v / n_it, 2) for k, v in prof.items() if not k.endswith("finish_cycles")}
         log(json.dumps({"event": "variant", "target_items": ti, "flags": fl, "batch": B, "qps": round(args.steps * B / dt, 1),
                         "ms_per_step": round(dt / args.steps * 1e3, 3), "p50_ms": round(float(np.median(lat)) * 1e3, 3),
                         "scan_ms": round(scan_ms, 3), "merge_ms": round(st["merge_ms"] / L, 3),
                         "plan_ms": round(st["host_plan_ms"] / L, 3), "items": st["scan_items"] / L,
                         "GBps_scan": round(bytes_l / (scan_ms * 1e-3) / 1e9, 1) if scan_ms > 0 else None,
-                        "checksum": cs, "profile": ctx.scan_profile() if ((fl >> 8) & 15) == 7 else None}))
+                        "checksum": cs, "profile": prof, "profile_per_item": per_item}))
         for l in leaves:
             l.release()
         ctx.close()
