@@ -41,7 +41,7 @@ typedef const NRT_GLOBAL uint32_t* gu32_ptr;
 typedef const NRT_GLOBAL float* gf32_ptr;
 
 // Accumulators.  One 64-bit LDS slot per doc of a wave's sub-tile, in one of two exact representations
-// chosen per batch by the host (runtime.cpp: fixed_scale_of_term):
+// chosen per batch by the host (planner.cpp: fixed_scale_of_term):
 //   fp64  (FX = false): the double sum of the fp32 term scores, as the reference computes it
 //                       ("unmatched" marker: -0.0, which no sum of non-negative scores produces)
 //   fixed (FX = true):  the same sum as an integer multiple of 2^-fx_E: every term score is a positive
@@ -497,7 +497,7 @@ __device__ __forceinline__ uint32_t reserve_candidates(ScanSmem& s, uint32_t lan
 // sub-tile, i.e. to bit `lane` of the mask's 64-bit word j: the complement of that word IS the execution
 // mask of the store.  The 16 words arrive by scalar loads (two of 64 bytes); per word: three scalar
 // instructions and one LDS store.  `mask_tile` points at the sub-tile's 128 mask bytes (uniform; the
-// arrays are padded, runtime.cpp, so the last sub-tile of a segment may read past max_doc).
+// arrays are padded, segment.cpp, so the last sub-tile of a segment may read past max_doc).
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 template <int OFF>
 __device__ __forceinline__ void store_where_clear(uint64_t word, uint32_t addr, uint64_t value) {
@@ -1116,7 +1116,7 @@ void apply_live_kernel(const uint32_t* __restrict__ docids, uint32_t* __restrict
   }
 }
 
-// ---- launchers (called from runtime.cpp) ---------------------------------------------------------
+// ---- launchers (called from the host runtime) ---------------------------------------------------------
 void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fnorm, uint64_t n, const uint64_t* live) {
   if (n == 0) return;
   const uint64_t blocks = (n + 1023) / 1024;

@@ -1,0 +1,394 @@
+// planner.cpp -- one batch of queries -> the launch plan of the scan and merge kernels: term resolution per
+// (clause, leaf), score-table and fixed-point analysis, work items of equal cost.
+#include "runtime_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// plan building
+// ------------------------------------------------------------------------------------------------
+
+
+int nrtgpu::rt::validate_query(const nrtgpu_bm25_query& q, int qi) {
+  // LazyQueueTopScoreDocCollectorManager.java:90-98
+  if (q.k <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: numHits must be > 0; got %d", qi, q.k);
+  if (q.total_hits_threshold < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: totalHitsThreshold must be >= 0, got %d", qi, q.total_hits_threshold);
+  if (q.k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: numHits %d > %d", qi, q.k, NRTGPU_MAX_K);
+  if (q.n_terms <= 0 || !q.terms) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: no terms", qi);
+  if (q.n_terms > NRTGPU_MAX_TERMS) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d clauses > %d", qi, q.n_terms, NRTGPU_MAX_TERMS);
+  if (q.min_should_match < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: minimumNumberShouldMatch %d", qi, q.min_should_match);
+  if (q.n_caches <= 0 || !q.norm_cache) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: norm_cache missing", qi);
+  if (q.n_caches > kLdsCaches) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d scored fields > %d", qi, q.n_caches, kLdsCaches);
+  for (int t = 0; t < q.n_terms; ++t) {
+    if (q.terms[t].cache_slot < 0 || q.terms[t].cache_slot >= q.n_caches)
+      return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: cache_slot out of range", qi, t);
+    if (!(q.terms[t].weight >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: weight must be >= 0", qi, t);
+  }
+  if (!(q.min_competitive_score >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: min_competitive_score must be >= 0", qi);
+  if (q.filter_mask < 0 || q.must_not_mask < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: mask ids must be >= 0", qi);
+  return 0;
+}
+
+// Cost model for cutting a query into work items: postings streamed + a per-tile constant for the
+// accumulator sweep (in posting equivalents).
+static const int64_t kTileCostPostings = 48;
+
+struct QS { uint32_t term_begin, n_terms; int32_t seg; int64_t postings; };
+struct QTabs { uint32_t n; float weight[kTabTerms]; uint32_t cache[kTabTerms]; int32_t scale[kTabTerms]; int32_t fx_E; };
+static const int32_t kNoFixed = INT32_MIN;  // QTabs.fx_E: the query needs the fp64 accumulators
+
+// Fixed-point eligibility of one query term: every score the term can produce in these
+// segments must be a positive integer below 2^32 after scaling by 2^E_t.  Scores grow with freq and
+// shrink with the norm byte, so the smallest one is score(1, largest norm byte present) and the
+// weight bounds them from above.  Returns false when the range does not fit.
+static bool fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale) {
+  const float s_min = nrtgpu::hostmath::bm25_score(weight, 1.0f, cache256[max_norm & 255u]);
+  if (!(s_min > 0.0f) || !std::isnormal(s_min) || !std::isnormal(weight)) return false;
+  const int e_min = std::ilogb(s_min), e_w = std::ilogb(weight);
+  if (e_w - e_min > 7) return false;  // 24 mantissa bits + 8 binades of range fill the 32-bit table entry
+  *scale = 23 - e_min;
+  return *scale > -64 && *scale < 64;
+}
+struct PlanPiece {
+  std::vector<DTerm> terms;
+  std::vector<float> caches;
+  int64_t postings = 0, cost = 0;
+};
+
+// Pass 1 of the planner for queries [q_begin, q_end): one dictionary lookup per (clause, leaf); score
+// tables go to the clauses with the most postings; terms of a (query, leaf) sorted densest first.
+// Offsets (term_begin, cache offsets) are relative to the piece.
+static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const nrtgpu_bm25_query* queries, int q_begin,
+                            int q_end, PlanPiece& pc, std::vector<std::vector<QS>>& per_query,
+                            std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs) {
+  std::vector<int64_t> term_total;
+  std::vector<int32_t> tab_of_term, term_scale;
+  std::vector<const TermEntry*> found;
+  std::vector<const FieldData*> fld((size_t)n_segs, nullptr);
+  std::vector<const FieldData*> found_field;
+  int32_t fld_id = 0;
+  bool fld_valid = false;
+  size_t prev_cache_off = 0, prev_cache_len = 0;
+  for (int qi = q_begin; qi < q_end; ++qi) {
+    const nrtgpu_bm25_query& q = queries[qi];
+    // consecutive queries over the same fields carry identical normInverse tables: keep one copy
+    const size_t cache_len = (size_t)q.n_caches * 256;
+    if (prev_cache_len == cache_len && memcmp(pc.caches.data() + prev_cache_off, q.norm_cache, cache_len * sizeof(float)) == 0) {
+      cache_base[(size_t)qi] = (uint32_t)prev_cache_off;
+    } else {
+      prev_cache_off = pc.caches.size();
+      prev_cache_len = cache_len;
+      cache_base[(size_t)qi] = (uint32_t)prev_cache_off;
+      pc.caches.insert(pc.caches.end(), q.norm_cache, q.norm_cache + cache_len);
+    }
+    found.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
+    found_field.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
+    term_total.assign((size_t)q.n_terms, 0);
+    for (int t = 0; t < q.n_terms; ++t) {
+      if (!fld_valid || fld_id != q.terms[t].field_id) {  // per-leaf field lookup hoisted out of the clause loop
+        fld_id = q.terms[t].field_id;
+        fld_valid = true;
+        for (int si = 0; si < n_segs; ++si) {
+          auto fit = segs[si]->fields.find(fld_id);
+          fld[(size_t)si] = fit == segs[si]->fields.end() ? nullptr : &fit->second;
+        }
+      }
+      for (int si = 0; si < n_segs; ++si) {
+        const FieldData* f = fld[(size_t)si];
+        if (!f) continue;
+        const TermEntry* e = f->flat.find(q.terms[t].term_hash);
+        if (!e || e->count == 0) continue;
+        found[(size_t)t * n_segs + si] = e;
+        found_field[(size_t)t * n_segs + si] = f;
+        term_total[(size_t)t] += e->count;
+      }
+    }
+    // fixed-point analysis: per clause the scale of its scores, per query the common scale
+    term_scale.assign((size_t)q.n_terms, 0);
+    bool fx_ok = true;
+    int32_t fx_E = kNoFixed;
+    for (int t = 0; t < q.n_terms && fx_ok; ++t) {
+      if (term_total[(size_t)t] == 0) continue;  // matches nothing here
+      uint32_t max_norm = 0;
+      for (int si = 0; si < n_segs; ++si)
+        if (const FieldData* f = found_field[(size_t)t * n_segs + si]) max_norm = std::max(max_norm, f->max_norm);
+      int32_t sc = 0;
+      fx_ok = fixed_scale_of_term(q.terms[t].weight, q.norm_cache + (size_t)q.terms[t].cache_slot * 256, max_norm, &sc);
+      term_scale[(size_t)t] = sc;
+      if (fx_ok) fx_E = std::max(fx_E, sc);
+    }
+    for (int t = 0; t < q.n_terms && fx_ok; ++t)  // 32-bit entries shifted into the common scale, summed over
+      if (term_total[(size_t)t] != 0 && fx_E - term_scale[(size_t)t] > 15) fx_ok = false;  // <= 32 clauses: < 2^53
+    if (!fx_ok) fx_E = kNoFixed;
+    tab_of_term.assign((size_t)q.n_terms, -1);
+    QTabs& qt_ = qtabs[(size_t)qi];
+    qt_.n = 0;
+    qt_.fx_E = fx_E;
+    for (int r = 0; r < kTabTerms && r < q.n_terms; ++r) {
+      int best = -1;
+      for (int t = 0; t < q.n_terms; ++t)
+        if (tab_of_term[(size_t)t] < 0 && term_total[(size_t)t] > 0 && (best < 0 || term_total[(size_t)t] > term_total[(size_t)best])) best = t;
+      if (best < 0) break;
+      tab_of_term[(size_t)best] = (int32_t)qt_.n;
+      qt_.weight[qt_.n] = q.terms[best].weight;
+      qt_.cache[qt_.n] = (uint32_t)q.terms[best].cache_slot;
+      qt_.scale[qt_.n] = term_scale[(size_t)best];
+      qt_.n++;
+    }
+    per_query[(size_t)qi].reserve((size_t)n_segs);
+    for (int si = 0; si < n_segs; ++si) {
+      const nrtgpu_seg* seg = segs[si];
+      QS qs{(uint32_t)pc.terms.size(), 0, si, 0};
+      for (int t = 0; t < q.n_terms; ++t) {
+        const nrtgpu_term& qt = q.terms[t];
+        const TermEntry* ep = found[(size_t)t * n_segs + si];
+        if (!ep) continue;
+        const TermEntry& e = *ep;
+        const FieldData& f = *found_field[(size_t)t * n_segs + si];
+        const TermGroup& g = f.groups[e.group];
+        DTerm d{};
+        d.docids = g.d_docids;
+        d.fnorm = g.d_fnorm;
+        d.cell_off = g.d_cells + e.cell_start;
+        d.start = e.start;
+        d.count = e.count;
+        d.shift = e.shift;
+        d.weight = qt.weight;
+        d.cache_off = cache_base[(size_t)qi] + (uint32_t)qt.cache_slot * 256u;
+        d.cache_slot = (uint32_t)qt.cache_slot;
+        d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
+        d.fx_scale = term_scale[(size_t)t];
+        d.fx_shift = fx_ok ? (uint32_t)(fx_E - term_scale[(size_t)t]) : 0u;
+        pc.terms.push_back(d);
+        qs.n_terms++;
+        qs.postings += e.count;
+      }
+      if (qs.n_terms > 0) {
+        // densest clause first; stable insertion sort (a handful of clauses; std::stable_sort allocates per call)
+        DTerm* tb = pc.terms.data() + qs.term_begin;
+        for (uint32_t i = 1; i < qs.n_terms; ++i) {
+          const DTerm key = tb[i];
+          uint32_t j = i;
+          for (; j > 0 && tb[j - 1].count < key.count; --j) tb[j] = tb[j - 1];
+          tb[j] = key;
+        }
+        per_query[(size_t)qi].push_back(qs);
+        pc.postings += qs.postings;
+        pc.cost += qs.postings + (int64_t)seg->n_tiles * kTileCostPostings;
+      }
+    }
+  }
+}
+
+int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp) {
+  uint32_t kmax = 1;
+  for (int qi = 0; qi < n_queries; ++qi) {
+    if (int rc = validate_query(queries[qi], qi)) return rc;
+    kmax = std::max<uint32_t>(kmax, (uint32_t)queries[qi].k);
+  }
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+    if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);
+    if (segs[si]->ctx != ctx) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d belongs to another context", si);
+  }
+  hp.k_stride = round_up(kmax, 16);
+  hp.queries.resize((size_t)n_queries);
+  hp.q_k.resize((size_t)n_queries);
+  hp.theta_init.resize((size_t)n_queries);
+  for (int qi = 0; qi < n_queries; ++qi)  // lowest key with that score: a doc scoring exactly the bound still passes
+    hp.theta_init[(size_t)qi] = queries[qi].min_competitive_score > 0.0f ? pack_key(queries[qi].min_competitive_score, 0xFFFFFFFFu) : 0ull;
+
+  static const bool plan_trace = getenv("NRTGPU_PLAN_TRACE") != nullptr;  // debug aid: phase times on stderr
+  const double tp0 = plan_trace ? now_ms() : 0.0;
+  // pass 1: resolve terms per (query, segment), densest term first; remember posting counts.
+  // Queries are independent here, so the batch is cut into contiguous chunks resolved by
+  // cfg.host_threads planner threads and concatenated (offsets rebased) afterwards.
+  std::vector<std::vector<QS>> per_query((size_t)n_queries);
+  std::vector<uint32_t> cache_base((size_t)n_queries);
+  std::vector<QTabs> qtabs((size_t)n_queries);
+  int n_thr = ctx->cfg.host_threads > 0 ? ctx->cfg.host_threads : 4;
+  n_thr = std::max(1, std::min(n_thr, n_queries / 64));
+  std::vector<PlanPiece> pieces((size_t)n_thr);
+  auto chunk_begin = [&](int t) { return (int)((int64_t)n_queries * t / n_thr); };
+  auto work = [&](int t) {
+    resolve_queries(segs, n_segs, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t], per_query, cache_base, qtabs);
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  const double tp1 = plan_trace ? now_ms() : 0.0;
+  int64_t total_postings = 0, total_cost = 0;
+  {
+    size_t nt = 0, nc = 0;
+    for (const PlanPiece& pc : pieces) { nt += pc.terms.size(); nc += pc.caches.size(); }
+    hp.terms.reserve(nt);
+    hp.caches.reserve(nc);
+  }
+  for (int t = 0; t < n_thr; ++t) {
+    PlanPiece& pc = pieces[(size_t)t];
+    const uint32_t term_base = (uint32_t)hp.terms.size(), c_base = (uint32_t)hp.caches.size();
+    for (DTerm& d : pc.terms) d.cache_off += c_base;
+    hp.terms.insert(hp.terms.end(), pc.terms.begin(), pc.terms.end());
+    hp.caches.insert(hp.caches.end(), pc.caches.begin(), pc.caches.end());
+    for (int qi = chunk_begin(t); qi < chunk_begin(t + 1); ++qi) {
+      cache_base[(size_t)qi] += c_base;
+      for (QS& qs : per_query[(size_t)qi]) qs.term_begin += term_base;
+    }
+    total_postings += pc.postings;
+    total_cost += pc.cost;
+  }
+  hp.postings = total_postings;
+  hp.fixed_point = (ctx->cfg.flags & NRTGPU_FLAG_NO_FIXED_POINT) == 0;
+  for (int qi = 0; qi < n_queries && hp.fixed_point; ++qi)
+    if (!per_query[(size_t)qi].empty() && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
+  // minimumNumberShouldMatch > 1 (QueryNodeMapper.java:259-261): the clause count rides in the fixed-point
+  // accumulator, so the whole batch must be in fixed-point mode; otherwise the caller runs Lucene's WANDScorer
+  hp.clause_counting = false;
+  for (int qi = 0; qi < n_queries; ++qi)
+    if (queries[qi].min_should_match > 1) hp.clause_counting = true;
+  if (hp.clause_counting && !hp.fixed_point)
+    return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 needs the fixed-point accumulators (weights of a query in "
+                                        "this batch span too many binades, or NRTGPU_FLAG_NO_FIXED_POINT is set)");
+
+  const double tp2 = plan_trace ? now_ms() : 0.0;
+  // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
+  // may span several segments (like a LeafSlice) and a large segment may be cut by tile range.
+  // Measured on MI355X (one workgroup per CU): every extra item of a query costs a cold
+  // top-k start, so a query is cut only when it alone would take longer than its fair share of the
+  // batch on one CU.  target_items == 0 => one share per CU.
+  const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : (int64_t)std::max(ctx->n_cus, 1);
+  const int64_t min_item_cost = 1 << 17;
+  const int64_t per_item = std::max<int64_t>(min_item_cost, total_cost / std::max<int64_t>(1, target_items));
+  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; };
+  std::vector<Pending> pend;
+  std::vector<int64_t> q_costs((size_t)n_queries, 0), q_items((size_t)n_queries, 0);
+  int64_t n_live = 0, n_items_total = 0;
+  for (int qi = 0; qi < n_queries; ++qi) {
+    for (const QS& qs : per_query[(size_t)qi]) q_costs[(size_t)qi] += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
+    if (q_costs[(size_t)qi] == 0) continue;
+    ++n_live;
+    q_items[(size_t)qi] = std::max<int64_t>(1, (q_costs[(size_t)qi] + per_item / 2) / per_item);
+    n_items_total += q_items[(size_t)qi];
+  }
+  // A small batch is cut into EXACTLY one item per CU: rounding each query on its own gives a few items more
+  // than CUs, and near-equal items then run in two rounds with most CUs idle in the second (64 queries: 273
+  // items on 256 CUs).  Largest-remainder apportionment of the CUs over the queries by cost.
+  if (n_live > 0 && n_live * 2 <= target_items && n_items_total > target_items && total_cost >= target_items * min_item_cost) {
+    std::vector<std::pair<double, int>> frac;
+    int64_t given = 0;
+    for (int qi = 0; qi < n_queries; ++qi) {
+      if (q_costs[(size_t)qi] == 0) continue;
+      const double share = (double)q_costs[(size_t)qi] * (double)target_items / (double)total_cost;
+      q_items[(size_t)qi] = std::max<int64_t>(1, (int64_t)share);
+      given += q_items[(size_t)qi];
+      frac.emplace_back(share - std::floor(share), qi);
+    }
+    std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    for (size_t i = 0; i < frac.size() && given < target_items; ++i, ++given) q_items[(size_t)frac[i].second]++;
+  }
+  for (int qi = 0; qi < n_queries; ++qi) {
+    const int64_t q_cost = q_costs[(size_t)qi];
+    if (q_cost == 0) continue;
+    const int64_t n_it = q_items[(size_t)qi];
+    const double budget = (double)q_cost / (double)n_it;
+    Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
+    double filled = 0.0;
+    for (const QS& qs : per_query[(size_t)qi]) {
+      const nrtgpu_seg* seg = segs[qs.seg];
+      const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
+      const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
+      if (int rc = accept_set_of(seg, queries[qi].filter_mask, queries[qi].must_not_mask, &accept)) return rc;
+      uint32_t tb = 0;
+      while (tb < seg->n_tiles) {
+        double room = budget - filled;
+        uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tile_cost + 0.5));
+        take = std::min<uint32_t>(take, seg->n_tiles - tb);
+        DPart p{};
+        p.live_bits = accept;
+        if (accept) hp.masked = true;
+        p.term_begin = qs.term_begin;
+        p.n_terms = qs.n_terms;
+        p.tile_begin = tb;
+        p.tile_end = tb + take;
+        p.max_doc = (uint32_t)seg->max_doc;
+        p.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
+        p.tile_offset = cur.tiles;
+        hp.parts.push_back(p);
+        cur.n_parts++;
+        cur.tiles += take;
+        cur.cost += (int64_t)(take * tile_cost);
+        filled += take * tile_cost;
+        tb += take;
+        if (filled >= budget * 0.999) {  // item full: close it
+          pend.push_back(cur);
+          cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
+          filled = 0.0;
+        }
+      }
+    }
+    if (cur.n_parts > 0) {
+      // A short remainder (the tile rounding of the items before it) does not become an item of its own: it would
+      // finish without a single compaction, never publish its quantile, and with one peer silent the bound
+      // exchange between the query's items never forms (kernels.hip: peers_bound).  It joins the item before it.
+      if (!pend.empty() && pend.back().query == (uint32_t)qi && (double)cur.cost < 0.5 * budget &&
+          pend.back().part_begin + pend.back().n_parts == cur.part_begin) {
+        Pending& prev = pend.back();
+        for (uint32_t pi2 = 0; pi2 < cur.n_parts; ++pi2) hp.parts[cur.part_begin + pi2].tile_offset += prev.tiles;
+        prev.n_parts += cur.n_parts;
+        prev.tiles += cur.tiles;
+        prev.cost += cur.cost;
+      } else {
+        pend.push_back(cur);
+      }
+    }
+  }
+  // longest-processing-time-first launch order: the hardware dispatcher hands out workgroups in
+  // index order, so big items start first and small ones fill the tail
+  // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
+  std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.cost > b.cost; });
+  hp.items.resize(pend.size());
+  std::vector<std::vector<uint32_t>> lists((size_t)n_queries);
+  for (size_t i = 0; i < pend.size(); ++i) {
+    DItem it{};
+    it.query = pend[i].query;
+    it.part_begin = pend[i].part_begin;
+    it.n_parts = pend[i].n_parts;
+    it.cache_off = cache_base[pend[i].query];
+    it.n_caches = (uint32_t)queries[pend[i].query].n_caches;
+    const QTabs& qt_ = qtabs[pend[i].query];
+    it.n_tabs = qt_.n;
+    it.fx_E = qt_.fx_E;
+    for (uint32_t r = 0; r < qt_.n; ++r) {
+      it.tab_weight[r] = qt_.weight[r];
+      it.tab_cache[r] = qt_.cache[r];
+      it.tab_scale[r] = qt_.scale[r];
+    }
+    it.peer_slot = (uint32_t)lists[pend[i].query].size();  // rebased by the query's list offset below
+    hp.items[i] = it;
+    lists[pend[i].query].push_back((uint32_t)i);
+  }
+  hp.q_base.resize((size_t)n_queries);
+  hp.q_nlists.resize((size_t)n_queries);
+  for (int qi = 0; qi < n_queries; ++qi) {
+    const nrtgpu_bm25_query& q = queries[qi];
+    hp.q_base[(size_t)qi] = (uint32_t)hp.list_idx.size();
+    hp.q_nlists[(size_t)qi] = (uint32_t)lists[(size_t)qi].size();
+    hp.list_idx.insert(hp.list_idx.end(), lists[(size_t)qi].begin(), lists[(size_t)qi].end());
+    for (uint32_t ii : lists[(size_t)qi]) hp.items[ii].peer_slot += hp.q_base[(size_t)qi];
+    hp.q_k[(size_t)qi] = (uint32_t)q.k;
+    DQuery& dq = hp.queries[(size_t)qi];
+    dq.k = (uint32_t)q.k;
+    dq.has_after = q.has_after ? 1u : 0u;
+    dq.after_doc = q.after_doc;
+    dq.after_score = q.after_score;
+    dq.item_begin = hp.q_base[(size_t)qi];
+    dq.n_items = hp.q_nlists[(size_t)qi];
+    dq.min_should_match = (uint32_t)std::max(q.min_should_match, 0);
+  }
+  if (plan_trace)
+    fprintf(stderr, "[nrtgpu plan] %d queries: resolve %.3f ms (%d threads), concat %.3f, cut+items %.3f; %zu terms %zu parts %zu items\n",
+            n_queries, tp1 - tp0, n_thr, tp2 - tp1, now_ms() - tp2, hp.terms.size(), hp.parts.size(), hp.items.size());
+  return 0;
+}

@@ -1,0 +1,344 @@
+// runtime_internal.h -- shared declarations of the host runtime behind include/nrtgpu.h (not part of the ABI).
+//
+// The runtime is split by concern: runtime.cpp (errors, context, workspaces, statistics, exchange table, host
+// helpers), segment.cpp (the segment store: upload, seal, liveDocs, masks), planner.cpp (queries -> launch
+// plan), search.cpp (BM25 entry points, hybrid tail, request coalescing, merge), vectors.cpp (exact kNN,
+// vector rescoring).  Types the ABI names opaquely (nrtgpu_ctx, nrtgpu_seg) live in the global namespace;
+// everything else in nrtgpu::rt.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <climits>
+#include <cmath>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nrtgpu.h"
+#include "host_math.h"
+#include "plan.h"
+
+namespace nrtgpu {
+void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
+                      const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
+                      unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
+                      uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
+void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
+                       const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
+                       const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
+                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out);
+void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,
+                       uint32_t* fnorm, uint64_t n, uint32_t* overflow);
+void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fnorm, uint64_t n, const uint64_t* live);
+void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float* norm2);
+int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
+                     const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
+                     const float* qpanel, const float* qnorm2, int32_t n_q, int32_t sim, float boost,
+                     const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap);
+void launch_knn_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,
+                       const uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, unsigned long long* theta,
+                       uint32_t* overflow);
+void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnorm2, int32_t dim, const float* query,
+                            float qnorm2, int32_t sim, float boost, const int64_t* vec_row, const float* first_scores,
+                            int32_t n, double qw, double rw, float* out_scores);
+void launch_hybrid_rescore(hipStream_t st, uint32_t n_queries, const uint64_t* first_keys, const uint32_t* first_counts,
+                           uint32_t k_stride, const DVecSeg* segs, int32_t n_segs, int32_t dim, const float* qvecs,
+                           const float* qnorm2, int32_t sim, float boost, double qw, double rw, uint32_t window,
+                           uint64_t* out_keys, uint32_t* out_counts, uint32_t w_stride);
+}  // namespace nrtgpu
+
+namespace nrtgpu {
+namespace rt {
+
+// ---- errors (runtime.cpp) ----------------------------------------------------------------------
+extern thread_local std::string g_last_error;
+int fail(int code, const char* fmt, ...);
+double now_ms();
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(_e == hipErrorOutOfMemory ? NRTGPU_ERR_OOM : NRTGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                  hipGetErrorString(_e), __FILE__, __LINE__);                                      \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// growable device / pinned buffers
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// segment store
+// ------------------------------------------------------------------------------------------------
+struct TermEntry {
+  uint32_t group;      // which upload group holds the columns
+  uint64_t start;      // first posting in the group's columns
+  uint32_t count;
+  uint32_t shift;      // doc-range cell = tile >> shift
+  uint64_t cell_start; // first entry of the term's cell table inside the group's table buffer
+};
+
+struct TermGroup {
+  uint32_t* d_docids = nullptr;
+  uint32_t* d_freqs = nullptr;   // raw freq column, only between add_terms and seal (nullptr => freq == 1)
+  uint32_t* d_fnorm = nullptr;   // score-code column (same allocation as d_docids), filled at seal
+  bool folded = false;
+  uint32_t* d_cells = nullptr;   // concatenated per-term cell tables
+  bool has_freqs = false;
+  uint64_t n_postings = 0;
+};
+
+// Read-only open-addressing view of a field's term dictionary (built at seal): the planner does
+// one lookup per (query clause, leaf), ~50k per batch, so a probe should touch one cache line.
+struct FlatDict {
+  struct Cell { int64_t key; uint32_t idx; uint32_t used; };
+  std::vector<Cell> cells;
+  std::vector<TermEntry> entries;
+  uint32_t shift = 64;
+  static inline uint64_t mix(int64_t k) { return (uint64_t)k * 0x9E3779B97F4A7C15ull; }
+  void build(const std::unordered_map<int64_t, TermEntry>& d) {
+    size_t cap = 16;
+    uint32_t bits = 4;
+    while (cap < d.size() * 2 + 2) { cap <<= 1; ++bits; }
+    cells.assign(cap, Cell{0, 0, 0});
+    entries.clear();
+    entries.reserve(d.size());
+    shift = 64 - bits;
+    for (const auto& kv : d) {
+      size_t h = (size_t)(mix(kv.first) >> shift);
+      while (cells[h].used) h = (h + 1) & (cap - 1);
+      cells[h] = Cell{kv.first, (uint32_t)entries.size(), 1u};
+      entries.push_back(kv.second);
+    }
+  }
+  inline const TermEntry* find(int64_t key) const {
+    if (cells.empty()) return nullptr;
+    const size_t mask = cells.size() - 1;
+    size_t h = (size_t)(mix(key) >> shift);
+    for (;;) {
+      const Cell& c = cells[h];
+      if (!c.used) return nullptr;
+      if (c.key == key) return &entries[c.idx];
+      h = (h + 1) & mask;
+    }
+  }
+};
+
+struct FieldData {
+  uint8_t* d_norms = nullptr;    // nullptr => norms omitted
+  uint32_t max_norm = 1;         // largest norm byte of the field in this segment (longest doc); 1 when omitted
+  std::unordered_map<int64_t, TermEntry> dict;   // build-time (duplicate detection); searches use `flat`
+  FlatDict flat;
+  std::vector<TermGroup> groups;
+  float* d_vectors = nullptr;
+  float* d_vnorm2 = nullptr;            // |v|^2 per row (cosine / euclidean)
+  int32_t* d_ord_to_doc = nullptr;
+  std::vector<int32_t> h_ord_to_doc;     // host copy: docid -> row lookups of the rescore path
+  int32_t dim = 0, n_vec = 0;
+};
+
+}  // namespace rt
+}  // namespace nrtgpu
+
+using namespace nrtgpu;      // (internal header: every translation unit of the runtime wants both)
+using namespace nrtgpu::rt;
+
+struct nrtgpu_ctx;
+struct nrtgpu_seg {
+  nrtgpu_ctx* ctx = nullptr;
+  int32_t max_doc = 0;
+  uint32_t n_tiles = 0;
+  bool sealed = false;
+  std::map<int32_t, FieldData> fields;
+  uint64_t* d_live = nullptr;
+  int64_t device_bytes = 0;
+  // FILTER / MUST_NOT clauses as doc-set masks: host copies of the registered masks and of liveDocs,
+  // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use
+  std::vector<uint64_t> h_live;                      // empty = all live
+  bool live_folded = false;  // the posting columns carry the current liveDocs (apply_live_kernel): the scan needs no mask for them
+  // searches hold this shared from planning until their kernels have finished; set_live_docs / set_mask take it
+  // exclusively, so a reader-version change never rewrites columns or masks under a running scan
+  mutable std::shared_mutex content_mu;
+  mutable std::atomic<int> content_writers{0};  // pending exclusive owners: new searches let them go first (no writer starvation)
+  std::map<int32_t, std::vector<uint64_t>> masks;
+  mutable std::mutex accept_mu;
+  mutable std::map<std::pair<int32_t, int32_t>, uint64_t*> accept;
+};
+
+// Exclusive ownership of a segment's content (liveDocs, masks, the posting columns' liveness coding).
+struct SegWriteLock {
+  nrtgpu_seg* seg;
+  explicit SegWriteLock(nrtgpu_seg* s);
+  ~SegWriteLock();
+  SegWriteLock(const SegWriteLock&) = delete;
+  SegWriteLock& operator=(const SegWriteLock&) = delete;
+};
+
+// Shared locks on the content of every (distinct) segment of a call, taken in address order.
+struct SegReadLocks {
+  std::vector<const nrtgpu_seg*> held;
+  SegReadLocks(const nrtgpu_seg* const* segs, int32_t n) {
+    for (int32_t i = 0; i < n; ++i)
+      if (segs && segs[i]) held.push_back(segs[i]);
+    std::sort(held.begin(), held.end());
+    held.erase(std::unique(held.begin(), held.end()), held.end());
+    for (const nrtgpu_seg* s : held) {
+      while (s->content_writers.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      s->content_mu.lock_shared();
+    }
+  }
+  ~SegReadLocks() {
+    for (const nrtgpu_seg* s : held) s->content_mu.unlock_shared();
+  }
+  SegReadLocks(const SegReadLocks&) = delete;
+  SegReadLocks& operator=(const SegReadLocks&) = delete;
+};
+
+namespace nrtgpu {
+namespace rt {
+// ------------------------------------------------------------------------------------------------
+// per-call workspace
+// ------------------------------------------------------------------------------------------------
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  PinBuf h_plan;     // host staging of the plan blob
+  DevBuf d_plan;     // device copy
+  DevBuf d_work;     // theta + item outputs + merge outputs
+  DevBuf d_aux;      // hybrid tail: leaf table, query vectors, rescored windows
+  PinBuf h_aux;
+  PinBuf h_out;      // merged results on the host
+  bool busy = false;
+};
+
+}  // namespace rt
+}  // namespace nrtgpu
+
+struct nrtgpu_ctx {
+  nrtgpu_config cfg{};
+  int device = 0;
+  int n_cus = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::unique_ptr<Slot>> slots;
+  std::mutex gpu_mu;    // device execution of one batch at a time: a scan kernel wants the whole GPU,
+                        // overlapping two only stretches both (host-side planning/unpacking still overlap)
+  std::mutex stats_mu;
+  nrtgpu_stats stats{};
+  double prof[16] = {0};
+  // request coalescing (nrtgpu_search_bm25_coalesced)
+  std::mutex co_mu;
+  std::condition_variable co_cv;
+  std::vector<struct CoRequest*> co_pending;  // waiting for a leader
+  struct CoRequest* co_leader = nullptr;      // the caller lingering for / about to run the next batch
+  int co_inflight = 0;                        // coalesced batches executing right now
+  int co_inflight_queries = 0;                // ... and how many queries they hold
+  int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
+  int32_t co_linger_us = 150;
+  // cross-GPU bound exchange (nrtgpu_exchange_open)
+  void* xch_host = nullptr;                 // mmap of the shared table
+  unsigned long long* xch_dev = nullptr;    // the same memory as the GPU sees it
+  size_t xch_bytes = 0;
+  int32_t xch_world = 0, xch_rank = 0;
+};
+
+namespace nrtgpu {
+namespace rt {
+
+// layout helper: carve 256-byte aligned regions out of one blob
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+// ---- workspaces (runtime.cpp) ------------------------------------------------------------------
+int acquire_slot(nrtgpu_ctx* ctx, Slot** out);
+void release_slot(nrtgpu_ctx* ctx, Slot* s);
+
+// ---- segment store (segment.cpp) ---------------------------------------------------------------
+// The doc set a query's hits must lie in: liveDocs & FILTER mask & ~MUST_NOT mask, resident in HBM
+// ((0, 0): liveDocs itself, or nullptr once they are folded into the posting columns).
+int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out);
+
+// ---- planner (planner.cpp) ---------------------------------------------------------------------
+struct HostPlan {
+  std::vector<DQuery> queries;
+  std::vector<DItem> items;
+  std::vector<DPart> parts;
+  std::vector<DTerm> terms;
+  std::vector<float> caches;
+  std::vector<uint32_t> list_idx;   // per query: item indices (merge input lists)
+  std::vector<uint32_t> q_base, q_nlists, q_k;
+  std::vector<uint64_t> theta_init;  // per query: key below which nothing is collected (min_competitive_score)
+  uint32_t k_stride = 0;
+  int64_t postings = 0;             // postings in the scanned term ranges (algorithmic work)
+  bool fixed_point = false;         // every query of the batch passed the fixed-point range analysis
+  bool clause_counting = false;     // some query has minimumNumberShouldMatch > 1: count-carrying kernel variant
+  bool masked = false;              // some part reads a doc-set mask (liveDocs / FILTER / MUST_NOT)
+};
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+int validate_query(const nrtgpu_bm25_query& q, int qi);
+int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+               const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp);
+
+}  // namespace rt
+}  // namespace nrtgpu

@@ -1,0 +1,604 @@
+// search.cpp -- BM25 entry points of the C ABI: plan upload + scan + merge, the fused hybrid tail, request
+// coalescing, device-resident results for the multi-GPU exchange.
+#include "runtime_internal.h"
+
+
+struct DeviceRun {
+  // device pointers valid until the slot is reused
+  uint64_t* out_keys = nullptr;
+  uint32_t* out_counts = nullptr;
+  uint64_t* out_hits = nullptr;
+  uint64_t* prof = nullptr;   // instrumented variant: 8 counters per item
+  size_t n_items = 0;
+};
+
+// Enqueue plan upload + scan + merge on the slot's stream.  Merge output goes to (ext_keys,
+// ext_counts, ext_hits) when given (device-resident variant), else into the slot's scratch.
+// `gpu` (unlocked on entry) is taken only once the plan has reached the device: the upload of this
+// batch overlaps the kernels of the batch another host thread has in flight.
+static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
+                          uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
+                          std::unique_lock<std::mutex>& gpu, int64_t epoch = -1) {
+  const size_t n_items = hp.items.size();
+  Carver pc;
+  const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
+  const size_t o_items = pc.take(n_items * sizeof(DItem));
+  const size_t o_parts = pc.take(hp.parts.size() * sizeof(DPart));
+  const size_t o_terms = pc.take(hp.terms.size() * sizeof(DTerm));
+  const size_t o_caches = pc.take(hp.caches.size() * sizeof(float));
+  const size_t o_lidx = pc.take(hp.list_idx.size() * 4);
+  const size_t o_qbase = pc.take(hp.q_base.size() * 4);
+  const size_t o_qnl = pc.take(hp.q_nlists.size() * 4);
+  const size_t o_qk = pc.take(hp.q_k.size() * 4);
+  const size_t o_theta = pc.take(hp.theta_init.size() * 8);  // uploaded with the plan, then updated by the kernel
+  const size_t o_quant = pc.take(hp.list_idx.size() * 8);    // per item: published quantile bound (zeros)
+  const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
+  const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
+  const size_t plan_bytes = pc.off;
+  if (int rc = slot->h_plan.reserve(plan_bytes)) return rc;
+  if (int rc = slot->d_plan.reserve(plan_bytes)) return rc;
+  char* hb = (char*)slot->h_plan.p;
+  memcpy(hb + o_queries, hp.queries.data(), hp.queries.size() * sizeof(DQuery));
+  if (n_items) memcpy(hb + o_items, hp.items.data(), n_items * sizeof(DItem));
+  if (!hp.parts.empty()) memcpy(hb + o_parts, hp.parts.data(), hp.parts.size() * sizeof(DPart));
+  if (!hp.terms.empty()) memcpy(hb + o_terms, hp.terms.data(), hp.terms.size() * sizeof(DTerm));
+  memcpy(hb + o_caches, hp.caches.data(), hp.caches.size() * sizeof(float));
+  if (!hp.list_idx.empty()) memcpy(hb + o_lidx, hp.list_idx.data(), hp.list_idx.size() * 4);
+  memcpy(hb + o_qbase, hp.q_base.data(), hp.q_base.size() * 4);
+  memcpy(hb + o_qnl, hp.q_nlists.data(), hp.q_nlists.size() * 4);
+  memcpy(hb + o_qk, hp.q_k.data(), hp.q_k.size() * 4);
+  memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
+  memset(hb + o_quant, 0, hp.list_idx.size() * 8);
+  if (use_xch) {
+    DExchange x{};
+    const size_t stride = (size_t)ctx->cfg.max_batch;
+    x.slot = ctx->xch_dev + (size_t)(epoch % kExchangeSlots) * (size_t)ctx->xch_world * stride;
+    x.world = (uint32_t)ctx->xch_world;
+    x.rank = (uint32_t)ctx->xch_rank;
+    x.stride = (uint32_t)stride;
+    x.tag = (uint32_t)(epoch + 1);  // never 0
+    if (x.tag == 0) x.tag = 1;
+    memcpy(hb + o_xch, &x, sizeof(x));
+  }
+
+  Carver wc;
+  const size_t o_ikeys = wc.take(n_items * (size_t)hp.k_stride * 8);
+  const size_t o_icnt = wc.take(n_items * 4);
+  const size_t o_ihits = wc.take(n_items * 8);
+  const size_t o_okeys = wc.take((size_t)n_queries * k_stride_out * 8);
+  const size_t o_ocnt = wc.take((size_t)n_queries * 4);
+  const size_t o_ohits = wc.take((size_t)n_queries * 8);
+  // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
+  const int flag_variant = (ctx->cfg.flags >> 8) & 15;
+  const int ablation = hp.clause_counting ? 8 : ((hp.masked && flag_variant == 0 && !(ctx->cfg.flags & NRTGPU_FLAG_NO_MASK_VARIANT)) ? 9 : flag_variant);
+  const size_t o_prof = wc.take(ablation == 7 ? n_items * 128 : 0);
+  if (int rc = slot->d_work.reserve(wc.off)) return rc;
+  char* db = (char*)slot->d_plan.p;
+  char* wb = (char*)slot->d_work.p;
+
+  hipStream_t st = slot->stream;
+  HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  gpu.lock();
+  const bool timing = ctx->cfg.collect_timing != 0;
+  if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
+  launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
+                   (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
+                   (unsigned long long*)(db + o_theta), (unsigned long long*)(db + o_quant),
+                   use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
+                   (uint64_t*)(wb + o_ihits), hp.k_stride, ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr);
+  if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
+  uint64_t* okeys = ext_keys ? ext_keys : (uint64_t*)(wb + o_okeys);
+  uint32_t* ocnt = ext_counts ? ext_counts : (uint32_t*)(wb + o_ocnt);
+  uint64_t* ohits = ext_hits ? ext_hits : (uint64_t*)(wb + o_ohits);
+  launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)(wb + o_ikeys), (const uint32_t*)(wb + o_icnt),
+                    (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
+                    (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
+                    k_stride_out);
+  if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
+  HIP_TRY(hipGetLastError());
+  run->out_keys = okeys;
+  run->out_counts = ocnt;
+  run->out_hits = ohits;
+  run->prof = ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr;
+  run->n_items = n_items;
+  return 0;
+}
+
+static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, double plan_ms) {
+  float scan_ms = 0.f, merge_ms = 0.f;
+  if (ctx->cfg.collect_timing) {
+    (void)hipEventElapsedTime(&scan_ms, slot->ev0, slot->ev1);
+    (void)hipEventElapsedTime(&merge_ms, slot->ev1, slot->ev2);
+  }
+  std::lock_guard<std::mutex> lk(ctx->stats_mu);
+  ctx->stats.batches += 1;
+  ctx->stats.queries += n_queries;
+  ctx->stats.scan_launches += hp.items.empty() ? 0 : 1;
+  ctx->stats.fixed_point_launches += (!hp.items.empty() && hp.fixed_point) ? 1 : 0;
+  ctx->stats.scan_ms += scan_ms;
+  ctx->stats.merge_ms += merge_ms;
+  ctx->stats.scan_postings += hp.postings;
+  ctx->stats.scan_items += (int64_t)hp.items.size();
+  ctx->stats.host_plan_ms += plan_ms;
+}
+
+// relation: GREATER_THAN_OR_EQUAL_TO exactly where LazyQueueTopScoreDocCollector would have started
+// publishing a min competitive score: totalHits > max(threshold, numHits) and the queue is full
+// (LazyQueueTopScoreDocCollector.java:176-199, …Manager.java:102).
+static inline int32_t relation_gte(int64_t total_hits, int32_t n_hits, int32_t k, int32_t threshold) {
+  const int64_t thr = std::max<int64_t>(threshold, k);
+  return (total_hits > thr && n_hits == k) ? 1 : 0;
+}
+
+static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, const int32_t k, const int32_t threshold,
+                           nrtgpu_topdocs* out) {
+  const int32_t cap = out->capacity > 0 ? out->capacity : k;
+  const int32_t m = std::min<int32_t>((int32_t)n, cap);
+  // two plain loops (vectorisable): doc = ~low word, score = high word reinterpreted
+  if (int32_t* __restrict__ docs = out->docs)
+    for (int32_t i = 0; i < m; ++i) docs[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)keys[i]);
+  if (uint32_t* __restrict__ sc = (uint32_t*)out->scores)
+    for (int32_t i = 0; i < m; ++i) sc[i] = (uint32_t)(keys[i] >> 32);
+  out->n_hits = m;
+  out->total_hits = (int64_t)hits;
+  out->total_hits_is_lower_bound = relation_gte((int64_t)hits, (int32_t)n, k, threshold);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI: search
+// ------------------------------------------------------------------------------------------------
+extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                        nrtgpu_topdocs* out) {
+  if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
+  if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  HostPlan hp;
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  const double plan_ms = now_ms() - t0;
+
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  DeviceRun run;
+  const size_t kb = (size_t)n_queries * hp.k_stride * 8, cb = (size_t)n_queries * 4, hb = (size_t)n_queries * 8;
+  Carver oc;
+  const size_t o_k = oc.take(kb), o_c = oc.take(cb), o_h = oc.take(hb);
+  if (int rc = slot->h_out.reserve(oc.off)) return rc;
+  char* ho = (char*)slot->h_out.p;
+  {
+    std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
+    HIP_TRY(hipStreamSynchronize(slot->stream));  // kernels done: the next batch may have the device ...
+  }
+  // ... while this one's results travel to the host
+  HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
+  HIP_TRY(hipStreamSynchronize(slot->stream));
+  const uint64_t* keys = (const uint64_t*)(ho + o_k);
+  const uint32_t* cnts = (const uint32_t*)(ho + o_c);
+  const uint64_t* hits = (const uint64_t*)(ho + o_h);
+  for (int qi = 0; qi < n_queries; ++qi)
+    unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, &out[qi]);
+  if (run.prof && run.n_items) {
+    std::vector<uint64_t> hp_prof(run.n_items * 16);
+    HIP_TRY(hipMemcpy(hp_prof.data(), run.prof, hp_prof.size() * 8, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(ctx->stats_mu);
+    for (size_t i = 0; i < run.n_items; ++i)
+      for (int j = 0; j < 16; ++j) ctx->prof[j] += (double)hp_prof[i * 16 + j];
+  }
+  account(ctx, slot, hp, n_queries, plan_ms);
+  return NRTGPU_OK;
+}
+
+// Hybrid tail: BM25 recall -> exact-vector rescore -> window, one stream, no host round trip between
+// the stages (RescoreTask.java:47-50 -> QueryRescore.java:39-57 applied to the hits of
+// SearchHandler.java:1412-1413).  Same results as nrtgpu_search_bm25_batch followed per query by
+// nrtgpu_rescore_vectors.
+extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                          int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                          int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost,
+                                          double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out) {
+  if (!ctx || !queries || !out || !query_vectors || (n_segs > 0 && (!segs || !doc_bases)))
+    return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
+  if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
+  if (dim <= 0 || sim < 0 || sim > 3 || window <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad rescore arguments");
+  if (!(query_weight >= 0.0) || !(rescore_weight >= 0.0) || !(boost >= 0.0f))
+    return fail(NRTGPU_ERR_UNSUPPORTED, "hybrid tail: negative weights (combined scores must stay >= 0)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  HostPlan hp;
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  const double plan_ms = now_ms() - t0;
+  for (int si = 0; si < n_segs; ++si) {
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
+      return fail(NRTGPU_ERR_INVALID_ARG, "vector dimension mismatch");
+  }
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  hipStream_t st = slot->stream;
+  const uint32_t w_stride = round_up((uint32_t)std::min<int32_t>(window, NRTGPU_MAX_K), 16);
+  const size_t nq = (size_t)n_queries;
+  Carver ac;
+  const size_t o_segs = ac.take((size_t)std::max(n_segs, 1) * sizeof(DVecSeg)), o_qv = ac.take(nq * (size_t)dim * 4),
+               o_qn = ac.take(nq * 4);
+  const size_t in_bytes = ac.off;
+  const size_t o_wk = ac.take(nq * w_stride * 8), o_wc = ac.take(nq * 4);
+  if (int rc = slot->d_aux.reserve(ac.off)) return rc;
+  const size_t kb = nq * w_stride * 8, cb = nq * 4, hb = nq * 8;
+  Carver hc;
+  const size_t oh_in = hc.take(in_bytes), oh_k = hc.take(kb), oh_c = hc.take(cb), oh_fc = hc.take(cb), oh_h = hc.take(hb);
+  if (int rc = slot->h_aux.reserve(hc.off)) return rc;
+  char* ha = (char*)slot->h_aux.p;
+  char* da = (char*)slot->d_aux.p;
+  DVecSeg* hs = (DVecSeg*)(ha + oh_in + o_segs);
+  for (int si = 0; si < n_segs; ++si) {
+    DVecSeg v{};
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors) {
+      v.vecs = fit->second.d_vectors;
+      v.vnorm2 = fit->second.d_vnorm2;
+      v.ord_to_doc = fit->second.d_ord_to_doc;
+      v.n_vec = fit->second.n_vec;
+    }
+    v.doc_base = doc_bases[si];
+    v.max_doc = segs[si]->max_doc;
+    hs[si] = v;
+  }
+  memcpy(ha + oh_in + o_qv, query_vectors, nq * (size_t)dim * 4);
+  float* hqn = (float*)(ha + oh_in + o_qn);
+  for (size_t q = 0; q < nq; ++q) {  // |q|^2 in the order nrtgpu_rescore_vectors uses
+    const float* qv = query_vectors + q * (size_t)dim;
+    float qn = 0.f;
+    for (int d = 0; d < dim; ++d) {
+      volatile float p2 = qv[d] * qv[d];
+      qn = qn + p2;
+    }
+    hqn[q] = qn;
+  }
+  HIP_TRY(hipMemcpyAsync(da, ha + oh_in, in_bytes, hipMemcpyHostToDevice, st));
+  DeviceRun run;
+  {
+    std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
+    launch_hybrid_rescore(st, (uint32_t)n_queries, run.out_keys, run.out_counts, hp.k_stride, (const DVecSeg*)(da + o_segs), n_segs,
+                          dim, (const float*)(da + o_qv), (const float*)(da + o_qn), sim, boost, query_weight, rescore_weight,
+                          (uint32_t)window, (uint64_t*)(da + o_wk), (uint32_t*)(da + o_wc), w_stride);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  HIP_TRY(hipMemcpyAsync(ha + oh_k, da + o_wk, kb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ha + oh_c, da + o_wc, cb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ha + oh_fc, run.out_counts, cb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ha + oh_h, run.out_hits, hb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t* keys = (const uint64_t*)(ha + oh_k);
+  const uint32_t* cnts = (const uint32_t*)(ha + oh_c);
+  const uint32_t* first_cnts = (const uint32_t*)(ha + oh_fc);
+  const uint64_t* hits = (const uint64_t*)(ha + oh_h);
+  for (int qi = 0; qi < n_queries; ++qi) {
+    // QueryRescorer keeps the first pass's TotalHits; the window only trims the hits
+    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi], std::min<int32_t>(window, NRTGPU_MAX_K), queries[qi].total_hits_threshold, &out[qi]);
+    out[qi].total_hits_is_lower_bound = relation_gte((int64_t)hits[qi], (int32_t)first_cnts[qi], queries[qi].k, queries[qi].total_hits_threshold);
+  }
+  account(ctx, slot, hp, n_queries, plan_ms);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                  const nrtgpu_bm25_query* q, nrtgpu_topdocs* out) {
+  return nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, q, 1, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Request coalescing: concurrent single-query callers (the SEARCH pool's threads) are merged into
+// device batches leader/follower style -- no extra thread.  The first caller to find no lingering
+// leader becomes one: it waits co_linger_us (or until max_batch requests are pending), takes every
+// pending request that searches the same leaves, runs them as one batch and wakes their callers.
+// Later arrivals elect the next leader, so two batches are in flight and planning overlaps kernels.
+// ------------------------------------------------------------------------------------------------
+struct CoRequest {
+  const nrtgpu_seg* const* segs;
+  const int32_t* doc_bases;
+  int32_t n_segs;
+  const nrtgpu_bm25_query* q;
+  nrtgpu_topdocs* out;
+  int rc = 0;
+  bool done = false;   // results (or the error) are in place
+  bool lead = false;   // promoted: this caller lingers for and runs the next batch
+  std::string err;
+  // Every caller sleeps on its own condition variable AND its own mutex: a finished batch wakes hundreds of
+  // callers, and if they all had to re-acquire the coalescer's lock to leave their wait (and again to submit
+  // their next request) the lock handoffs alone would cost more than the batch's kernels.  done / lead are
+  // written under `m`; the lingering leader is the one waiter that uses `cv` with the coalescer's lock.
+  std::mutex m;
+  std::condition_variable cv;
+};
+
+static bool same_leaves(const CoRequest* a, const CoRequest* b) {
+  if (a->n_segs != b->n_segs) return false;
+  if (a->n_segs == 0) return true;
+  if (memcmp(a->segs, b->segs, (size_t)a->n_segs * sizeof(void*)) != 0) return false;
+  if ((a->doc_bases == nullptr) != (b->doc_bases == nullptr)) return false;
+  return !a->doc_bases || memcmp(a->doc_bases, b->doc_bases, (size_t)a->n_segs * 4) == 0;
+}
+
+extern "C" int nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us) {
+  if (!ctx || linger_us < 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad coalescing arguments");
+  std::lock_guard<std::mutex> lk(ctx->co_mu);
+  ctx->co_linger_us = linger_us;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                            int32_t n_segs, const nrtgpu_bm25_query* q, nrtgpu_topdocs* out) {
+  if (!ctx || !q || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_segs must be >= 0");
+  if (int rc = validate_query(*q, 0)) return rc;  // a bad request must not fail its batch mates
+  if (q->min_should_match > 1)  // whether it can run depends on the whole batch (fixed-point mode): use the batch call
+    return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 is not coalesced");
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+    if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);
+    if (segs[si]->ctx != ctx) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d belongs to another context", si);
+  }
+  CoRequest me{segs, doc_bases, n_segs, q, out};
+  std::vector<CoRequest*> batch;
+  {
+    std::unique_lock<std::mutex> lk(ctx->co_mu);
+    ctx->co_pending.push_back(&me);
+    if (ctx->co_leader) {  // follower: the lingering leader takes this request (or a later one does)
+      if ((int32_t)ctx->co_pending.size() >= ctx->cfg.max_batch) ctx->co_leader->cv.notify_one();
+      lk.unlock();
+      {
+        std::unique_lock<std::mutex> mine(me.m);
+        me.cv.wait(mine, [&] { return me.done || me.lead; });
+      }
+      if (me.done) {
+        if (me.rc != 0) g_last_error = me.err;
+        return me.rc;
+      }
+      lk.lock();  // promoted: continue as the leader
+    } else {
+      ctx->co_leader = &me;
+    }
+    // leader: linger for company, then leave when the device is idle.  While one batch is running a second one
+    // leaves only if it is big enough to be worth overlapping (planning and copies of one then hide behind the
+    // kernels of the other: >= kCoOverlapMin queries, or twice the running batch); a smaller one waits for the
+    // running batch's callers to come back and join it -- below a few hundred queries device time per query
+    // falls so steeply with the batch size that one cohort of C callers beats two alternating cohorts of C / 2
+    // even with the device idle between its batches (measured: 64 callers 18.2 k -> 23.9 k queries/s).  Never
+    // more than two in flight.  Woken by a full queue or a finishing batch.
+    constexpr int32_t kCoOverlapMin = 192;
+    // (a caller that was alone last time and is alone now does not linger: a single stream of requests pays
+    // no batching latency)
+    const bool alone = ctx->co_last_batch <= 1 && ctx->co_pending.size() == 1 && ctx->co_inflight == 0;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(alone ? 0 : ctx->co_linger_us);
+    for (;;) {
+      const int32_t waiting = (int32_t)ctx->co_pending.size();
+      if (waiting >= ctx->cfg.max_batch) break;
+      const bool late = std::chrono::steady_clock::now() >= deadline;
+      if (late && (ctx->co_inflight == 0 ||
+                   (ctx->co_inflight == 1 && (waiting >= 2 * ctx->co_inflight_queries || waiting >= kCoOverlapMin)))) break;
+      if (late) me.cv.wait(lk);
+      else me.cv.wait_until(lk, deadline);
+    }
+    // take my request and every pending one over the same leaves (up to max_batch).  A big cohort that finds the
+    // device idle is cut in two, so that from now on the host work of one half (planning, copies, waking its
+    // callers) hides behind the kernels of the other.
+    int32_t cap = ctx->cfg.max_batch;
+    if (ctx->co_inflight == 0 && (int32_t)ctx->co_pending.size() >= 2 * kCoOverlapMin && (int32_t)ctx->co_pending.size() < cap)
+      cap = ((int32_t)ctx->co_pending.size() + 1) / 2;
+    std::vector<CoRequest*> rest;
+    batch.push_back(&me);
+    for (CoRequest* r : ctx->co_pending) {
+      if (r == &me) continue;
+      if ((int32_t)batch.size() < cap && same_leaves(&me, r)) batch.push_back(r);
+      else rest.push_back(r);
+    }
+    ctx->co_pending.swap(rest);
+    ctx->co_leader = nullptr;
+    if (!ctx->co_pending.empty()) {  // hand the lead to the oldest request left behind
+      CoRequest* next = ctx->co_pending.front();
+      ctx->co_leader = next;
+      std::lock_guard<std::mutex> theirs(next->m);
+      next->lead = true;
+      next->cv.notify_one();
+    }
+    ctx->co_inflight++;
+    ctx->co_inflight_queries += (int)batch.size();
+    ctx->co_last_batch = (int)batch.size();
+  }
+  // run the batch outside the lock
+  std::vector<nrtgpu_bm25_query> qs(batch.size());
+  std::vector<nrtgpu_topdocs> outs(batch.size());
+  for (size_t i = 0; i < batch.size(); ++i) {
+    qs[i] = *batch[i]->q;
+    outs[i] = *batch[i]->out;
+  }
+  const int rc = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data());
+  const std::string err = rc ? g_last_error : std::string();
+  for (size_t i = 0; i < batch.size(); ++i) {
+    CoRequest* r = batch[i];
+    if (r == &me) {
+      if (rc == 0) *out = outs[i];
+      continue;
+    }
+    // (notified under the request's own lock: the woken caller cannot return -- and free its request -- before
+    // we are done with it, and it contends with nobody but us)
+    std::lock_guard<std::mutex> theirs(r->m);
+    if (rc == 0) *r->out = outs[i];
+    r->rc = rc;
+    if (rc != 0) r->err = err;
+    r->done = true;
+    r->cv.notify_one();
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->co_mu);
+    ctx->co_inflight--;
+    ctx->co_inflight_queries -= (int)batch.size();
+    if (ctx->co_leader) ctx->co_leader->cv.notify_one();  // a lingering leader may be waiting for the device
+  }
+  if (rc != 0) g_last_error = err;
+  return rc;
+}
+
+// Closed-loop load generator (diagnostics; SURVEY 8d's "C concurrent clients"): `clients` native threads each
+// issue one query at a time through nrtgpu_search_bm25_coalesced for duration_ms, cycling through `queries`.
+// out[0] = completed queries, out[1] = seconds, out[2] = p50 latency ms, out[3] = p99 latency ms.
+extern "C" int nrtgpu_bench_closed_loop(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                        int32_t clients, int32_t duration_ms, double* out4) {
+  if (!ctx || !queries || !out4 || n_queries <= 0 || clients <= 0 || duration_ms <= 0)
+    return fail(NRTGPU_ERR_INVALID_ARG, "bad closed-loop arguments");
+  std::vector<std::vector<float>> lat((size_t)clients);
+  std::vector<int> rcs((size_t)clients, 0);
+  std::vector<std::string> errs((size_t)clients);
+  const auto t_begin = std::chrono::steady_clock::now();
+  const auto t_stop = t_begin + std::chrono::milliseconds(duration_ms);
+  auto client = [&](int c) {
+    int32_t kmax = 1;
+    for (int i = 0; i < n_queries; ++i) kmax = std::max(kmax, queries[i].k);
+    std::vector<int32_t> docs((size_t)kmax);
+    std::vector<float> scores((size_t)kmax);
+    size_t i = (size_t)c * 7919u;
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (t0 >= t_stop) break;
+      nrtgpu_topdocs o{};
+      o.capacity = kmax;
+      o.docs = docs.data();
+      o.scores = scores.data();
+      const int rc = nrtgpu_search_bm25_coalesced(ctx, segs, doc_bases, n_segs, &queries[i % (size_t)n_queries], &o);
+      if (rc != 0) {
+        rcs[(size_t)c] = rc;
+        errs[(size_t)c] = g_last_error;
+        break;
+      }
+      lat[(size_t)c].push_back(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      ++i;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int c = 0; c < clients; ++c) pool.emplace_back(client, c);
+  for (auto& t : pool) t.join();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  for (int c = 0; c < clients; ++c)
+    if (rcs[(size_t)c] != 0) return fail(rcs[(size_t)c], "client %d: %s", c, errs[(size_t)c].c_str());
+  std::vector<float> all;
+  for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+  std::sort(all.begin(), all.end());
+  out4[0] = (double)all.size();
+  out4[1] = secs;
+  out4[2] = all.empty() ? 0.0 : all[all.size() / 2];
+  out4[3] = all.empty() ? 0.0 : all[(size_t)((double)all.size() * 0.99)];
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                               int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                               int32_t k_stride, void* d_keys, void* d_counts, void* d_hits) {
+  return nrtgpu_search_bm25_batch_device_epoch(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts,
+                                               d_hits, -1);
+}
+
+extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                                     int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
+                                                     int64_t epoch) {
+  if (!ctx || !queries || !d_keys || !d_counts || !d_hits || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
+  if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  HostPlan hp;
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  if (k_stride < (int32_t)hp.k_stride && k_stride < NRTGPU_MAX_K) {
+    for (int qi = 0; qi < n_queries; ++qi)
+      if (queries[qi].k > k_stride) return fail(NRTGPU_ERR_INVALID_ARG, "k_stride %d smaller than numHits %d", k_stride, queries[qi].k);
+  }
+  const double plan_ms = now_ms() - t0;
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  DeviceRun run;
+  {
+    std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
+                                (uint64_t*)d_hits, &run, gpu, epoch))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(slot->stream));
+  }
+  account(ctx, slot, hp, n_queries, plan_ms);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride,
+                                        const void* d_keys_in, const void* d_counts_in, const void* d_hits_in,
+                                        const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
+  if (!ctx || !d_keys_in || !d_counts_in || !d_hits_in || !ks || !total_hits_thresholds || !out)
+    return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_lists <= 0 || n_queries <= 0 || k_stride <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad sizes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int qi = 0; qi < n_queries; ++qi)
+    if (ks[qi] <= 0 || ks[qi] > NRTGPU_MAX_K || ks[qi] > k_stride) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: bad k %d", qi, ks[qi]);
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  // plan blob: list_idx (n_queries * n_lists), q_base, q_nlists, q_k
+  const size_t nq = (size_t)n_queries, nl = (size_t)n_lists;
+  Carver pc;
+  const size_t o_lidx = pc.take(nq * nl * 4), o_qbase = pc.take(nq * 4), o_qnl = pc.take(nq * 4), o_qk = pc.take(nq * 4);
+  if (int rc = slot->h_plan.reserve(pc.off)) return rc;
+  if (int rc = slot->d_plan.reserve(pc.off)) return rc;
+  char* hb = (char*)slot->h_plan.p;
+  uint32_t* lidx = (uint32_t*)(hb + o_lidx);
+  uint32_t* qbase = (uint32_t*)(hb + o_qbase);
+  uint32_t* qnl = (uint32_t*)(hb + o_qnl);
+  uint32_t* qk = (uint32_t*)(hb + o_qk);
+  for (size_t q = 0; q < nq; ++q) {
+    qbase[q] = (uint32_t)(q * nl);
+    qnl[q] = (uint32_t)nl;
+    qk[q] = (uint32_t)ks[q];
+    for (size_t l = 0; l < nl; ++l) lidx[q * nl + l] = (uint32_t)(l * nq + q);
+  }
+  Carver wc;
+  const size_t o_okeys = wc.take(nq * (size_t)k_stride * 8), o_ocnt = wc.take(nq * 4), o_ohits = wc.take(nq * 8);
+  if (int rc = slot->d_work.reserve(wc.off)) return rc;
+  if (int rc = slot->h_out.reserve(wc.off)) return rc;
+  char* db = (char*)slot->d_plan.p;
+  char* wb = (char*)slot->d_work.p;
+  char* ho = (char*)slot->h_out.p;
+  hipStream_t st = slot->stream;
+  HIP_TRY(hipMemcpyAsync(db, hb, pc.off, hipMemcpyHostToDevice, st));
+  launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)d_keys_in, (const uint32_t*)d_counts_in,
+                    (const uint64_t*)d_hits_in, (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
+                    (const uint32_t*)(db + o_qnl), (uint32_t)k_stride, (const uint32_t*)(db + o_qk),
+                    (uint64_t*)(wb + o_okeys), (uint32_t*)(wb + o_ocnt), (uint64_t*)(wb + o_ohits), (uint32_t)k_stride);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ho, wb, wc.off, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const uint64_t* keys = (const uint64_t*)(ho + o_okeys);
+  const uint32_t* cnts = (const uint32_t*)(ho + o_ocnt);
+  const uint64_t* hits = (const uint64_t*)(ho + o_ohits);
+  for (int qi = 0; qi < n_queries; ++qi)
+    unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], total_hits_thresholds[qi], &out[qi]);
+  return NRTGPU_OK;
+}
+

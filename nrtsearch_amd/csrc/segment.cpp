@@ -1,0 +1,346 @@
+// segment.cpp -- the segment store: a read-only columnar replica of one Lucene segment's scoring data in HBM
+// (upload, seal, liveDocs folded into the posting columns, doc-set masks and their combined accept sets).
+#include "runtime_internal.h"
+
+SegWriteLock::SegWriteLock(nrtgpu_seg* s) : seg(s) {
+  seg->content_writers.fetch_add(1, std::memory_order_acq_rel);
+  seg->content_mu.lock();
+}
+SegWriteLock::~SegWriteLock() {
+  seg->content_mu.unlock();
+  seg->content_writers.fetch_sub(1, std::memory_order_acq_rel);
+}
+
+static const size_t kMaskPadBytes = 256;  // doc-set masks are readable one sub-tile (128 bytes) past max_doc
+
+static void drop_accept_sets(nrtgpu_seg* seg) {
+  std::lock_guard<std::mutex> lk(seg->accept_mu);
+  for (auto& kv : seg->accept) {
+    (void)hipFree(kv.second);
+    seg->device_bytes -= (int64_t)((seg->max_doc + 63) / 64) * 8;
+  }
+  seg->accept.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ABI: segment lifecycle
+// ------------------------------------------------------------------------------------------------
+static int dev_alloc(nrtgpu_seg* seg, void** p, size_t bytes) {
+  HIP_TRY(hipMalloc(p, bytes));
+  seg->device_bytes += (int64_t)bytes;
+  return 0;
+}
+
+extern "C" int nrtgpu_segment_begin(nrtgpu_ctx* ctx, int32_t max_doc, int32_t /*device_hint*/, nrtgpu_seg** out) {
+  if (!ctx || !out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (max_doc <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "max_doc must be > 0, got %d", max_doc);
+  auto* seg = new nrtgpu_seg();
+  seg->ctx = ctx;
+  seg->max_doc = max_doc;
+  seg->n_tiles = (uint32_t)(((int64_t)max_doc + kTileDocs - 1) / kTileDocs);
+  *out = seg;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id, const uint8_t* norm_bytes) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return fail(NRTGPU_ERR_STATE, "segment already sealed");
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  FieldData& f = seg->fields[field_id];
+  if (f.d_norms) {
+    (void)hipFree(f.d_norms);
+    f.d_norms = nullptr;
+  }
+  if (!norm_bytes) return NRTGPU_OK;  // norms omitted: norm value 1 everywhere
+  void* p = nullptr;
+  if (int rc = dev_alloc(seg, &p, (size_t)seg->max_doc + 64)) return rc;
+  f.d_norms = (uint8_t*)p;
+  HIP_TRY(hipMemcpy(f.d_norms, norm_bytes, (size_t)seg->max_doc, hipMemcpyHostToDevice));
+  uint32_t mx = 0;
+  for (int32_t d = 0; d < seg->max_doc; ++d) mx = std::max<uint32_t>(mx, norm_bytes[d]);
+  f.max_norm = mx;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64_t n_terms, const int64_t* term_hash,
+                                        const int64_t* offsets, const int32_t* docids, const int32_t* freqs) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return fail(NRTGPU_ERR_STATE, "segment already sealed");
+  if (n_terms < 0 || (n_terms > 0 && (!term_hash || !offsets))) return fail(NRTGPU_ERR_INVALID_ARG, "bad term arrays");
+  if (n_terms == 0) return NRTGPU_OK;
+  const int64_t total = offsets[n_terms];
+  if (offsets[0] != 0 || total < 0) return fail(NRTGPU_ERR_INVALID_ARG, "offsets must start at 0 and be non-negative");
+  if (total > 0 && !docids) return fail(NRTGPU_ERR_INVALID_ARG, "docids is NULL");
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  FieldData& f = seg->fields[field_id];
+
+  // doc-range cell tables: per term, posting offset at each cell boundary (cell = 2^shift tiles).
+  // Dense terms get one cell per tile; sparse terms coarser cells so a table never exceeds ~1/8
+  // of the term's postings.
+  std::vector<uint32_t> cells;
+  std::vector<TermEntry> entries((size_t)n_terms);
+  for (int64_t t = 0; t < n_terms; ++t) {
+    const int64_t lo = offsets[t], hi = offsets[t + 1];
+    if (hi < lo || hi > total) return fail(NRTGPU_ERR_INVALID_ARG, "offsets not monotone at term %lld", (long long)t);
+    const int64_t cnt = hi - lo;
+    if (cnt > 0xFFFFFFFFll) return fail(NRTGPU_ERR_UNSUPPORTED, "term with more than 2^32 postings");
+    uint32_t shift = 0;
+    const uint64_t budget = std::max<int64_t>(1, cnt / 8);
+    while (((uint64_t)(seg->n_tiles - 1) >> shift) + 1 > budget && shift < 31) ++shift;
+    const uint32_t n_cells = (uint32_t)(((uint64_t)(seg->n_tiles - 1) >> shift) + 1);
+    TermEntry& e = entries[(size_t)t];
+    e.group = (uint32_t)f.groups.size();
+    e.start = (uint64_t)lo;
+    e.count = (uint32_t)cnt;
+    e.shift = shift;
+    e.cell_start = cells.size();
+    const int64_t cell_docs = (int64_t)kTileDocs << shift;  // a cell covers 2^shift sub-tiles
+    int64_t p = lo;
+    int32_t prev = -1;
+    for (uint32_t c = 0; c < n_cells; ++c) {
+      cells.push_back((uint32_t)(p - lo));
+      const int64_t bound = (int64_t)(c + 1) * cell_docs;  // first doc of the next cell
+      while (p < hi && (int64_t)docids[p] < bound) {
+        const int32_t d = docids[p];
+        if (d <= prev || d >= seg->max_doc)
+          return fail(NRTGPU_ERR_INVALID_ARG, "docids of term %lld not strictly ascending in [0,max_doc)", (long long)t);
+        prev = d;
+        ++p;
+      }
+    }
+    if (p != hi) return fail(NRTGPU_ERR_INVALID_ARG, "docids of term %lld exceed max_doc", (long long)t);
+    cells.push_back((uint32_t)cnt);
+  }
+  for (int64_t t = 0; t < n_terms; ++t)
+    if (f.dict.count(term_hash[t])) return fail(NRTGPU_ERR_INVALID_ARG, "term %lld added twice to field %d", (long long)term_hash[t], field_id);
+
+  TermGroup g;
+  g.n_postings = (uint64_t)total;
+  void* p = nullptr;
+  // one allocation per upload group: [docid column | code column], each padded to a multiple of
+  // 16 bytes plus 64 (16-byte group loads may run past the end); the kernel addresses the code column
+  // as docid column + a per-term constant
+  const size_t col_bytes = (((size_t)total * 4 + 15) & ~(size_t)15) + 64;
+  if (int rc = dev_alloc(seg, &p, 2 * col_bytes)) return rc;
+  g.d_docids = (uint32_t*)p;
+  g.d_fnorm = (uint32_t*)((char*)p + col_bytes);
+  HIP_TRY(hipMemset(p, 0, 2 * col_bytes));
+  if (total) HIP_TRY(hipMemcpy(g.d_docids, docids, (size_t)total * 4, hipMemcpyHostToDevice));
+  if (freqs) {
+    if (int rc = dev_alloc(seg, &p, col_bytes)) return rc;
+    g.d_freqs = (uint32_t*)p;
+    g.has_freqs = true;
+    HIP_TRY(hipMemset(g.d_freqs, 0, col_bytes));
+    if (total) HIP_TRY(hipMemcpy(g.d_freqs, freqs, (size_t)total * 4, hipMemcpyHostToDevice));
+  }
+  if (int rc = dev_alloc(seg, &p, cells.size() * 4 + 64)) return rc;
+  g.d_cells = (uint32_t*)p;
+  HIP_TRY(hipMemcpy(g.d_cells, cells.data(), cells.size() * 4, hipMemcpyHostToDevice));
+  f.groups.push_back(g);
+  for (int64_t t = 0; t < n_terms; ++t) f.dict.emplace(term_hash[t], entries[(size_t)t]);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int32_t dim, int32_t n,
+                                          const int32_t* ord_to_doc, const float* row_major) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return fail(NRTGPU_ERR_STATE, "segment already sealed");
+  if (dim <= 0 || n < 0 || (n > 0 && !row_major)) return fail(NRTGPU_ERR_INVALID_ARG, "bad vector arguments");
+  if (n > seg->max_doc) return fail(NRTGPU_ERR_INVALID_ARG, "more vectors (%d) than docs (%d)", n, seg->max_doc);
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  FieldData& f = seg->fields[field_id];
+  if (f.d_vectors) return fail(NRTGPU_ERR_STATE, "vectors of field %d already added", field_id);
+  f.dim = dim;
+  f.n_vec = n;
+  if (n == 0) return NRTGPU_OK;
+  void* p = nullptr;
+  if (int rc = dev_alloc(seg, &p, (size_t)n * dim * 4 + 256)) return rc;
+  f.d_vectors = (float*)p;
+  HIP_TRY(hipMemcpy(f.d_vectors, row_major, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+  if (int rc = dev_alloc(seg, &p, (size_t)n * 4 + 64)) return rc;
+  f.d_vnorm2 = (float*)p;
+  launch_knn_row_norms(nullptr, f.d_vectors, dim, n, f.d_vnorm2);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  if (ord_to_doc) {
+    for (int32_t i = 0; i < n; ++i)
+      if (ord_to_doc[i] < 0 || ord_to_doc[i] >= seg->max_doc || (i > 0 && ord_to_doc[i] <= ord_to_doc[i - 1]))
+        return fail(NRTGPU_ERR_INVALID_ARG, "ord_to_doc must be strictly ascending docids in [0,max_doc)");
+    if (int rc = dev_alloc(seg, &p, (size_t)n * 4)) return rc;
+    f.d_ord_to_doc = (int32_t*)p;
+    HIP_TRY(hipMemcpy(f.d_ord_to_doc, ord_to_doc, (size_t)n * 4, hipMemcpyHostToDevice));
+    f.h_ord_to_doc.assign(ord_to_doc, ord_to_doc + n);
+  }
+  return NRTGPU_OK;
+}
+
+static int fold_live_docs(nrtgpu_seg* seg);
+
+extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (seg->sealed) return NRTGPU_OK;
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  // fold every posting's field-norm byte into its freq word: fnorm = (freq << 8) | norm
+  uint32_t* d_overflow = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_overflow, 4));
+  HIP_TRY(hipMemset(d_overflow, 0, 4));
+  int rc = NRTGPU_OK;
+  for (auto& kv : seg->fields) {
+    FieldData& f = kv.second;
+    for (auto& g : f.groups) {
+      if (g.folded) continue;
+      launch_fold_norms(nullptr, g.d_docids, g.d_freqs, f.d_norms, g.d_fnorm, g.n_postings, d_overflow);
+      hipError_t e = hipGetLastError();
+      g.folded = true;
+      if (e != hipSuccess) {
+        rc = fail(NRTGPU_ERR_HIP, "fold_norms failed: %s", hipGetErrorString(e));
+        break;
+      }
+    }
+    if (rc) break;
+  }
+  uint32_t overflow = 0;
+  if (!rc) {
+    hipError_t e = hipMemcpy(&overflow, d_overflow, 4, hipMemcpyDeviceToHost);  // also syncs the null stream
+    if (e != hipSuccess) rc = fail(NRTGPU_ERR_HIP, "seal: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_overflow);
+  if (rc) return rc;
+  if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^22 does not fit the packed freq|norm column");
+  for (auto& kv : seg->fields) kv.second.flat.build(kv.second.dict);
+  for (auto& kv : seg->fields)
+    for (auto& g : kv.second.groups)
+      if (g.d_freqs) {  // raw freq column no longer needed
+        (void)hipFree(g.d_freqs);
+        g.d_freqs = nullptr;
+        seg->device_bytes -= (int64_t)((((size_t)g.n_postings * 4 + 15) & ~(size_t)15) + 64);
+      }
+  seg->sealed = true;
+  if (seg->d_live) return fold_live_docs(seg);  // liveDocs set before the seal
+  return NRTGPU_OK;
+}
+
+// Re-code the posting columns for the segment's current liveDocs (kernels.hip: apply_live_kernel).  One pass
+// over the segment's postings per reader version instead of a liveness test per matched doc per query.
+static int fold_live_docs(nrtgpu_seg* seg) {
+  seg->live_folded = false;
+  if (seg->ctx->cfg.flags & NRTGPU_FLAG_NO_LIVE_FOLD) return NRTGPU_OK;
+  if (!seg->sealed) return NRTGPU_OK;  // seal folds
+  for (auto& kv : seg->fields)
+    for (auto& g : kv.second.groups)
+      launch_apply_live(nullptr, g.d_docids, g.d_fnorm, g.n_postings, seg->d_live);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  seg->live_folded = seg->d_live != nullptr;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  SegWriteLock content(seg);  // waits for the searches running over this segment; later ones wait for it
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  const int32_t need = (seg->max_doc + 63) / 64;
+  drop_accept_sets(seg);
+  if (!bits) {
+    if (seg->d_live) (void)hipFree(seg->d_live);
+    seg->d_live = nullptr;
+    seg->h_live.clear();
+    return fold_live_docs(seg);
+  }
+  if (n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "live bits: %d words given, %d needed", n_words, need);
+  seg->h_live.assign(bits, bits + need);
+  if (!seg->d_live) {  // padded: the masked scan variant reads whole sub-tiles (128 bytes) of the mask
+    void* p = nullptr;
+    if (int rc = dev_alloc(seg, &p, (size_t)need * 8 + kMaskPadBytes)) return rc;
+    seg->d_live = (uint64_t*)p;
+    HIP_TRY(hipMemset((char*)p + (size_t)need * 8, 0, kMaskPadBytes));
+  }
+  HIP_TRY(hipMemcpy(seg->d_live, bits, (size_t)need * 8, hipMemcpyHostToDevice));
+  return fold_live_docs(seg);
+}
+
+extern "C" int nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const uint64_t* bits, int32_t n_words) {
+  if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
+  if (mask_id <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "mask id must be > 0, got %d", mask_id);
+  SegWriteLock content(seg);  // waits for the searches running over this segment; later ones wait for it
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  const int32_t need = (seg->max_doc + 63) / 64;
+  drop_accept_sets(seg);
+  if (!bits) {
+    seg->masks.erase(mask_id);
+    return NRTGPU_OK;
+  }
+  if (n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "mask %d: %d words given, %d needed", mask_id, n_words, need);
+  seg->masks[mask_id].assign(bits, bits + need);
+  return NRTGPU_OK;
+}
+
+// The doc set a query's hits must lie in: liveDocs & FILTER mask & ~MUST_NOT mask, resident in HBM.
+// (0, 0) is liveDocs itself.  Built and uploaded on first use, then shared by every query that names
+// the same pair (the role LRUQueryCache plays for Lucene's non-scoring clauses).
+int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out) {
+  if (filter_mask == 0 && must_not_mask == 0) {
+    *out = seg->live_folded ? nullptr : seg->d_live;
+    return 0;
+  }
+  std::lock_guard<std::mutex> lk(seg->accept_mu);
+  const auto key = std::make_pair(filter_mask, must_not_mask);
+  auto it = seg->accept.find(key);
+  if (it != seg->accept.end()) {
+    *out = it->second;
+    return 0;
+  }
+  const std::vector<uint64_t>* f = nullptr;
+  const std::vector<uint64_t>* mn = nullptr;
+  if (filter_mask) {
+    auto m = seg->masks.find(filter_mask);
+    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "filter mask %d is not resident on a segment", filter_mask);
+    f = &m->second;
+  }
+  if (must_not_mask) {
+    auto m = seg->masks.find(must_not_mask);
+    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "must_not mask %d is not resident on a segment", must_not_mask);
+    mn = &m->second;
+  }
+  const size_t need = (size_t)(seg->max_doc + 63) / 64;
+  std::vector<uint64_t> w(need + kMaskPadBytes / 8, 0ull);  // padded like liveDocs
+  for (size_t i = 0; i < need; ++i) {
+    uint64_t v = seg->h_live.empty() ? ~0ull : seg->h_live[i];
+    if (f) v &= (*f)[i];
+    if (mn) v &= ~(*mn)[i];
+    w[i] = v;
+  }
+  void* p = nullptr;
+  HIP_TRY(hipSetDevice(seg->ctx->device));
+  if (hipMalloc(&p, w.size() * 8) != hipSuccess) return fail(NRTGPU_ERR_OOM, "hipMalloc(%zu) for an accept set failed", w.size() * 8);
+  if (hipMemcpy(p, w.data(), w.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p);
+    return fail(NRTGPU_ERR_HIP, "upload of an accept set failed");
+  }
+  const_cast<nrtgpu_seg*>(seg)->device_bytes += (int64_t)need * 8;
+  seg->accept[key] = (uint64_t*)p;
+  *out = (uint64_t*)p;
+  return 0;
+}
+
+extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
+  if (!seg) return;
+  (void)hipSetDevice(seg->ctx->device);
+  drop_accept_sets(seg);
+  for (auto& kv : seg->fields) {
+    FieldData& f = kv.second;
+    if (f.d_norms) (void)hipFree(f.d_norms);
+    if (f.d_vectors) (void)hipFree(f.d_vectors);
+    if (f.d_vnorm2) (void)hipFree(f.d_vnorm2);
+    if (f.d_ord_to_doc) (void)hipFree(f.d_ord_to_doc);
+    for (auto& g : f.groups) {
+      if (g.d_docids) (void)hipFree(g.d_docids);
+      if (g.d_freqs) (void)hipFree(g.d_freqs);
+      if (g.d_cells) (void)hipFree(g.d_cells);
+    }
+  }
+  if (seg->d_live) (void)hipFree(seg->d_live);
+  delete seg;
+}
+
+extern "C" int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg) { return seg ? seg->device_bytes : 0; }

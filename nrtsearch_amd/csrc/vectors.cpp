@@ -1,0 +1,229 @@
+// vectors.cpp -- exact vector search (the knn request path and ExactVectorQuery) and the vector rescorer.
+#include "runtime_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// ABI: exact vector search / vector rescore
+// ------------------------------------------------------------------------------------------------
+static const uint32_t kKnnCap = 1u << 18;   // candidate keys per query and round (2 MiB)
+static const int kKnnMaxQ = 32;
+
+// Shared by the two vector entry points.  knn_request = false: ExactVectorQuery (every doc with a vector
+// matches, boost inside the score).  knn_request = true: the `knn` request path -- pre-filter mask, score
+// threshold on the unboosted score (MinThresholdQuery's MinScoreWrapper), boost applied afterwards,
+// totalHits = the docs returned.
+static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                    int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
+                    int32_t k, float boost, bool knn_request, int32_t filter_mask, float min_score, nrtgpu_topdocs* out) {
+  if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n_queries <= 0 || k <= 0 || dim <= 0 || sim < 0 || sim > 3) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
+  if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
+  if (dim % 16 != 0 || dim > 1280) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 1280)", dim);
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int si = 0; si < n_segs; ++si)
+    if (!segs[si]) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
+  SegReadLocks content(segs, n_segs);  // liveDocs / masks stay as they are until the kernels have finished
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si] || !segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
+      return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim, dim);
+  }
+  const uint32_t k_stride = round_up((uint32_t)k, 16);
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+  hipStream_t st = slot->stream;
+  Carver wc;
+  const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_th = wc.take(kKnnMaxQ * 8);
+  const size_t o_tk = wc.take((size_t)kKnnMaxQ * k_stride * 8), o_tc = wc.take(kKnnMaxQ * 4);
+  const size_t o_cc = wc.take(kKnnMaxQ * 4), o_ov = wc.take(64), o_cd = wc.take((size_t)kKnnMaxQ * kKnnCap * 8);
+  if (int rc = slot->d_work.reserve(wc.off)) return rc;
+  if (int rc = slot->h_out.reserve((size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4)) return rc;
+  char* wb = (char*)slot->d_work.p;
+  std::vector<float> qn(kKnnMaxQ);
+  for (int q0 = 0; q0 < n_queries; q0 += kKnnMaxQ) {
+    const int nq = std::min(kKnnMaxQ, n_queries - q0);
+    for (int q = 0; q < nq; ++q) {
+      float s2 = 0.f;  // squareMagnitude of the query, fp32
+      const float* qv = queries + (size_t)(q0 + q) * dim;
+      for (int d = 0; d < dim; ++d) {
+        volatile float p2 = qv[d] * qv[d];
+        s2 = s2 + p2;
+      }
+      qn[(size_t)q] = s2;
+    }
+    HIP_TRY(hipMemcpyAsync(wb + o_q, queries + (size_t)q0 * dim, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(wb + o_qn, qn.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(wb + o_th, 0, wc.off - o_th > 0 ? (o_cd - o_th) : 0, st));  // theta, topk, counters
+    if (knn_request && min_score > 0.0f) {  // start theta just below the lowest key of that score: score >= min_score passes
+      std::vector<uint64_t> th0((size_t)nq, pack_key(min_score, 0xFFFFFFFFu) - 1ull);
+      HIP_TRY(hipMemcpyAsync(wb + o_th, th0.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
+    }
+    int64_t total_vec = 0;
+    for (int si = 0; si < n_segs; ++si) {
+      const nrtgpu_seg* seg = segs[si];
+      auto fit = seg->fields.find(field_id);
+      if (fit == seg->fields.end() || !fit->second.d_vectors) continue;
+      const FieldData& f = fit->second;
+      total_vec += f.n_vec;
+      const uint64_t* accept = seg->d_live;  // (vectors are not re-coded for liveDocs: always the mask)
+      if (knn_request && filter_mask != 0)
+        if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
+      // rounds never exceed the candidate capacity, so a list cannot overflow; theta tightens between rounds
+      int64_t r = 0, round = 1 << 16;
+      while (r < f.n_vec) {
+        const int64_t re = std::min<int64_t>(f.n_vec, r + std::min<int64_t>(round, kKnnCap));
+        const uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
+        const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
+                                       doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
+                                       sim, knn_request ? 1.0f : boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
+                                       (uint32_t*)(wb + o_cc), kKnnCap);
+        if (e) return fail(NRTGPU_ERR_HIP, "knn_score launch: %s", hipGetErrorString((hipError_t)e));
+        launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), k_stride, (uint32_t)k,
+                          (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
+                          (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov));
+        r = re;
+        round = std::min<int64_t>(round * 4, kKnnCap);  // (unbounded growth overflowed after 24 rounds: > 6M rows hung)
+      }
+    }
+    HIP_TRY(hipGetLastError());
+    char* ho = (char*)slot->h_out.p;
+    HIP_TRY(hipMemcpyAsync(ho, wb + o_tk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ho + (size_t)kKnnMaxQ * k_stride * 8, wb + o_tc, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t* keys = (const uint64_t*)ho;
+    const uint32_t* cnts = (const uint32_t*)(ho + (size_t)kKnnMaxQ * k_stride * 8);
+    for (int q = 0; q < nq; ++q) {
+      nrtgpu_topdocs* o = &out[q0 + q];
+      const int32_t cap = o->capacity > 0 ? o->capacity : k;
+      const int32_t m = std::min<int32_t>((int32_t)cnts[q], cap);
+      for (int32_t i = 0; i < m; ++i) {
+        if (o->docs) o->docs[i] = (int32_t)key_doc(keys[(size_t)q * k_stride + i]);
+        if (o->scores) o->scores[i] = key_score(keys[(size_t)q * k_stride + i]);
+      }
+      o->n_hits = m;
+      o->total_hits = total_vec;   // every doc with a vector matches an exact vector query (deletes not subtracted)
+      o->total_hits_is_lower_bound = 0;
+      if (knn_request) {
+        o->total_hits = m;  // the rewritten knn query matches exactly the docs it returns
+        if (boost != 1.0f && o->scores) {
+          for (int32_t i = 0; i < m; ++i) o->scores[i] = o->scores[i] * boost;
+          // distinct scores can round to one product: restore (score desc, doc asc) among equals
+          if (o->docs)
+            for (int32_t i = 1; i < m; ++i)
+              for (int32_t j = i; j > 0 && o->scores[j - 1] == o->scores[j] && o->docs[j - 1] > o->docs[j]; --j) std::swap(o->docs[j - 1], o->docs[j]);
+        }
+      }
+    }
+  }
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
+                                int32_t k, float boost, nrtgpu_topdocs* out) {
+  return knn_impl(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, false, 0, 0.0f, out);
+}
+
+extern "C" int nrtgpu_knn_search(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                 int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
+                                 int32_t k, float boost, int32_t filter_mask, float min_score, nrtgpu_topdocs* out) {
+  if (filter_mask < 0 || !(min_score >= 0.0f) || !(boost > 0.0f))
+    return fail(NRTGPU_ERR_INVALID_ARG, "knn search: filter_mask >= 0, min_score >= 0 and boost > 0 expected");
+  return knn_impl(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, true, filter_mask, min_score, out);
+}
+
+extern "C" int nrtgpu_rescore_vectors(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                      int32_t field_id, int32_t sim, const float* query, int32_t dim, float boost,
+                                      const int32_t* docs, const float* first_scores, int32_t n, double query_weight,
+                                      double rescore_weight, int32_t window, nrtgpu_topdocs* out) {
+  if (!ctx || !query || !out || (n > 0 && (!docs || !first_scores)) || (n_segs > 0 && (!segs || !doc_bases)))
+    return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (n < 0 || dim <= 0 || sim < 0 || sim > 3 || window <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad rescore arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  float qn = 0.f;
+  for (int d = 0; d < dim; ++d) {
+    volatile float p2 = query[d] * query[d];
+    qn = qn + p2;
+  }
+  // hits -> (segment, vector row); per segment one gather kernel
+  std::vector<int> seg_of((size_t)n, -1);
+  std::vector<int64_t> row_of((size_t)n, -1);
+  for (int i = 0; i < n; ++i) {
+    for (int si = 0; si < n_segs; ++si) {
+      const int32_t local = docs[i] - doc_bases[si];
+      if (local < 0 || local >= segs[si]->max_doc) continue;
+      seg_of[(size_t)i] = si;
+      auto fit = segs[si]->fields.find(field_id);
+      if (fit == segs[si]->fields.end() || !fit->second.d_vectors) break;
+      const FieldData& f = fit->second;
+      if (f.dim != dim) return fail(NRTGPU_ERR_INVALID_ARG, "vector dimension mismatch");
+      if (f.h_ord_to_doc.empty()) {
+        if (local < f.n_vec) row_of[(size_t)i] = local;
+      } else {
+        auto it = std::lower_bound(f.h_ord_to_doc.begin(), f.h_ord_to_doc.end(), local);
+        if (it != f.h_ord_to_doc.end() && *it == local) row_of[(size_t)i] = it - f.h_ord_to_doc.begin();
+      }
+      break;
+    }
+    if (seg_of[(size_t)i] < 0) return fail(NRTGPU_ERR_INVALID_ARG, "hit %d (doc %d) is outside every segment", i, docs[i]);
+  }
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+  hipStream_t st = slot->stream;
+  Carver wc;
+  const size_t o_q = wc.take((size_t)dim * 4), o_rows = wc.take((size_t)n * 8 + 8), o_first = wc.take((size_t)n * 4 + 4),
+               o_out = wc.take((size_t)n * 4 + 4);
+  if (int rc = slot->d_work.reserve(wc.off)) return rc;
+  char* wb = (char*)slot->d_work.p;
+  std::vector<float> combined((size_t)n);
+  HIP_TRY(hipMemcpyAsync(wb + o_q, query, (size_t)dim * 4, hipMemcpyHostToDevice, st));
+  for (int si = 0; si < n_segs; ++si) {
+    std::vector<int> idx;
+    for (int i = 0; i < n; ++i)
+      if (seg_of[(size_t)i] == si) idx.push_back(i);
+    if (idx.empty()) continue;
+    auto fit = segs[si]->fields.find(field_id);
+    const FieldData* f = (fit != segs[si]->fields.end() && fit->second.d_vectors) ? &fit->second : nullptr;
+    std::vector<int64_t> rows(idx.size());
+    std::vector<float> first(idx.size()), res(idx.size());
+    for (size_t j = 0; j < idx.size(); ++j) {
+      rows[j] = row_of[(size_t)idx[j]];
+      first[j] = first_scores[idx[j]];
+    }
+    if (!f) {  // no vectors in this leaf: second pass matches nothing
+      for (size_t j = 0; j < idx.size(); ++j) combined[(size_t)idx[j]] = (float)(query_weight * (double)first[j]);
+      continue;
+    }
+    HIP_TRY(hipMemcpyAsync(wb + o_rows, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(wb + o_first, first.data(), first.size() * 4, hipMemcpyHostToDevice, st));
+    launch_rescore_vectors(st, f->d_vectors, f->d_vnorm2, dim, (const float*)(wb + o_q), qn, sim, boost,
+                           (const int64_t*)(wb + o_rows), (const float*)(wb + o_first), (int32_t)idx.size(), query_weight,
+                           rescore_weight, (float*)(wb + o_out));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(res.data(), wb + o_out, res.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t j = 0; j < idx.size(); ++j) combined[(size_t)idx[j]] = res[j];
+  }
+  // QueryRescorer: sort by (combined score desc, doc asc), keep the window
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    if (combined[(size_t)a] != combined[(size_t)b]) return combined[(size_t)a] > combined[(size_t)b];
+    return docs[a] < docs[b];
+  });
+  const int32_t cap = out->capacity > 0 ? out->capacity : window;
+  const int32_t m = std::min<int32_t>(std::min<int32_t>(n, window), cap);
+  for (int32_t i = 0; i < m; ++i) {
+    if (out->docs) out->docs[i] = docs[order[(size_t)i]];
+    if (out->scores) out->scores[i] = combined[(size_t)order[(size_t)i]];
+  }
+  out->n_hits = m;
+  out->total_hits = n;
+  out->total_hits_is_lower_bound = 0;
+  return NRTGPU_OK;
+}
