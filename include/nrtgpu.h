@@ -264,6 +264,10 @@ int  nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
  * Host-side restatements the Java shim would otherwise take from Lucene objects
  * (BM25Similarity.scorer(boost, collectionStats, termStats); SmallFloat; slices()).
  * --------------------------------------------------------------------------------------------- */
+/* The planner's rule for cutting a batch's queries into work items (one item runs on one CU), exposed for the
+ * tests: query_costs[q] = postings + 48 per 1024-doc sub-tile of the query (0: matches nothing), target_items =
+ * CUs; out_items[q] = number of items.  Needs no device. */
+int  nrtgpu_plan_item_counts(int32_t n_queries, const int64_t* query_costs, int32_t target_items, int64_t* out_items);
 int32_t nrtgpu_int_to_byte4(int32_t length);
 int32_t nrtgpu_byte4_to_int(int32_t norm_byte);
 float   nrtgpu_bm25_idf(int64_t doc_count, int64_t doc_freq);

@@ -201,5 +201,38 @@ inline std::vector<std::vector<int32_t>> slices_for_shards(const std::vector<Lea
   return out;
 }
 
+// How many work items each query of a batch is cut into (planner.cpp; exported as nrtgpu_plan_item_counts for
+// the tests).  cost[q] = the query's postings + a per-sub-tile constant; 0 = matches nothing (no item).
+// One item runs on one CU.  Default rule: a query is cut only when it alone exceeds the batch's fair share of
+// a CU (cost / per_item, rounded), items never cheaper than min_item_cost.  A small batch (at most half as many
+// queries as CUs) whose rounded counts overshoot the CUs is apportioned instead into EXACTLY target_items
+// items by largest remainder: near-equal items one more than the CUs would run in two rounds with most CUs
+// idle in the second.
+inline void plan_item_counts(const int64_t* cost, int32_t n, int64_t target_items, int64_t min_item_cost, int64_t* items) {
+  int64_t total = 0, n_live = 0, n_items = 0;
+  for (int32_t q = 0; q < n; ++q) total += cost[q];
+  const int64_t per_item = std::max<int64_t>(min_item_cost, total / std::max<int64_t>(1, target_items));
+  for (int32_t q = 0; q < n; ++q) {
+    items[q] = 0;
+    if (cost[q] <= 0) continue;
+    ++n_live;
+    items[q] = std::max<int64_t>(1, (cost[q] + per_item / 2) / per_item);
+    n_items += items[q];
+  }
+  if (n_live == 0 || n_live * 2 > target_items || n_items <= target_items || total < target_items * min_item_cost) return;
+  std::vector<std::pair<double, int32_t>> frac;
+  int64_t given = 0;
+  for (int32_t q = 0; q < n; ++q) {
+    if (cost[q] <= 0) continue;
+    const double share = (double)cost[q] * (double)target_items / (double)total;
+    items[q] = std::max<int64_t>(1, (int64_t)share);
+    given += items[q];
+    frac.emplace_back(share < 1.0 ? 0.0 : share - std::floor(share), q);  // (rounded up to one item already)
+  }
+  std::stable_sort(frac.begin(), frac.end(),
+                   [](const std::pair<double, int32_t>& a, const std::pair<double, int32_t>& b) { return a.first > b.first; });
+  for (size_t i = 0; i < frac.size() && given < target_items; ++i, ++given) items[frac[i].second]++;
+}
+
 }  // namespace hostmath
 }  // namespace nrtgpu

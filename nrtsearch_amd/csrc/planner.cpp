@@ -219,7 +219,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     for (auto& th : pool) th.join();
   }
   const double tp1 = plan_trace ? now_ms() : 0.0;
-  int64_t total_postings = 0, total_cost = 0;
+  int64_t total_postings = 0;
   {
     size_t nt = 0, nc = 0;
     for (const PlanPiece& pc : pieces) { nt += pc.terms.size(); nc += pc.caches.size(); }
@@ -237,7 +237,6 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       for (QS& qs : per_query[(size_t)qi]) qs.term_begin += term_base;
     }
     total_postings += pc.postings;
-    total_cost += pc.cost;
   }
   hp.postings = total_postings;
   hp.fixed_point = (ctx->cfg.flags & NRTGPU_FLAG_NO_FIXED_POINT) == 0;
@@ -260,34 +259,12 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // batch on one CU.  target_items == 0 => one share per CU.
   const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : (int64_t)std::max(ctx->n_cus, 1);
   const int64_t min_item_cost = 1 << 17;
-  const int64_t per_item = std::max<int64_t>(min_item_cost, total_cost / std::max<int64_t>(1, target_items));
   struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; };
   std::vector<Pending> pend;
   std::vector<int64_t> q_costs((size_t)n_queries, 0), q_items((size_t)n_queries, 0);
-  int64_t n_live = 0, n_items_total = 0;
-  for (int qi = 0; qi < n_queries; ++qi) {
+  for (int qi = 0; qi < n_queries; ++qi)
     for (const QS& qs : per_query[(size_t)qi]) q_costs[(size_t)qi] += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
-    if (q_costs[(size_t)qi] == 0) continue;
-    ++n_live;
-    q_items[(size_t)qi] = std::max<int64_t>(1, (q_costs[(size_t)qi] + per_item / 2) / per_item);
-    n_items_total += q_items[(size_t)qi];
-  }
-  // A small batch is cut into EXACTLY one item per CU: rounding each query on its own gives a few items more
-  // than CUs, and near-equal items then run in two rounds with most CUs idle in the second (64 queries: 273
-  // items on 256 CUs).  Largest-remainder apportionment of the CUs over the queries by cost.
-  if (n_live > 0 && n_live * 2 <= target_items && n_items_total > target_items && total_cost >= target_items * min_item_cost) {
-    std::vector<std::pair<double, int>> frac;
-    int64_t given = 0;
-    for (int qi = 0; qi < n_queries; ++qi) {
-      if (q_costs[(size_t)qi] == 0) continue;
-      const double share = (double)q_costs[(size_t)qi] * (double)target_items / (double)total_cost;
-      q_items[(size_t)qi] = std::max<int64_t>(1, (int64_t)share);
-      given += q_items[(size_t)qi];
-      frac.emplace_back(share - std::floor(share), qi);
-    }
-    std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
-    for (size_t i = 0; i < frac.size() && given < target_items; ++i, ++given) q_items[(size_t)frac[i].second]++;
-  }
+  hostmath::plan_item_counts(q_costs.data(), n_queries, target_items, min_item_cost, q_items.data());  // host_math.h
   for (int qi = 0; qi < n_queries; ++qi) {
     const int64_t q_cost = q_costs[(size_t)qi];
     if (q_cost == 0) continue;

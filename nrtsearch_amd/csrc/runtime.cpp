@@ -188,6 +188,13 @@ extern "C" float nrtgpu_bm25_idf(int64_t doc_count, int64_t doc_freq) { return h
 extern "C" float nrtgpu_bm25_avgdl(int64_t sttf, int64_t doc_count) { return hostmath::bm25_avgdl(sttf, doc_count); }
 extern "C" void nrtgpu_bm25_norm_cache(float avgdl, float k1, float b, float* out256) { hostmath::bm25_norm_cache(avgdl, k1, b, out256); }
 
+extern "C" int nrtgpu_plan_item_counts(int32_t n_queries, const int64_t* query_costs, int32_t target_items, int64_t* out_items) {
+  if (n_queries < 0 || (n_queries > 0 && (!query_costs || !out_items)) || target_items <= 0)
+    return fail(NRTGPU_ERR_INVALID_ARG, "bad plan_item_counts arguments");
+  hostmath::plan_item_counts(query_costs, n_queries, target_items, (int64_t)1 << 17, out_items);
+  return NRTGPU_OK;
+}
+
 extern "C" int32_t nrtgpu_slices(int32_t n_leaves, const int32_t* max_docs, const int32_t* num_docs, const int32_t* doc_bases,
                                  int32_t virtual_shards, int32_t slice_max_docs, int32_t slice_max_segments,
                                  int32_t* slice_of_leaf, int32_t* shard_of_leaf) {

@@ -176,3 +176,36 @@ def test_query_eligibility_mapping():
                 api.BooleanQuery(())):
         with pytest.raises(api.UnsupportedQuery):
             api._flatten(bad)
+
+
+def test_planner_item_counts():
+    """The planner's cut of a batch into work items (host logic; no device): per-query rounding for big batches,
+    exactly one item per CU for small ones."""
+    import ctypes as C
+    L = _lib.load()
+
+    def counts(costs, target=256):
+        c = np.asarray(costs, dtype=np.int64)
+        out = np.zeros(len(c), dtype=np.int64)
+        assert L.nrtgpu_plan_item_counts(len(c), c.ctypes.data, target, out.ctypes.data) == 0
+        return out
+
+    # a full batch: one item per query, only a query far above the fair share is split
+    big = counts([4_000_000] * 1023 + [40_000_000])
+    assert big[:1023].tolist() == [1] * 1023 and big[1023] == 2          # per item ~16 M: 40 M / 16 M = 2.5 -> rounds to 2
+    # 64 equal queries on 256 CUs: exactly 4 each (per-query rounding used to give a few more than 256)
+    eq = counts([4_500_000] * 64)
+    assert eq.tolist() == [4] * 64
+    # unequal small batch: exactly 256 items, proportional to cost, every live query gets one
+    rng = np.random.Generator(np.random.PCG64(1))
+    costs = rng.integers(500_000, 12_000_000, size=40)
+    it = counts(costs)
+    assert it.sum() == 256 and (it >= 1).all()
+    share = costs * 256 / costs.sum()
+    assert (np.abs(it - share) < 1.0 + 1e-9).all()
+    # queries that match nothing get no item; a cheap batch is not cut below the minimum item cost
+    assert counts([0, 3_000_000, 0]).tolist()[0] == 0
+    assert counts([200_000] * 8).tolist() == [2] * 8 or counts([200_000] * 8).sum() <= 16
+    tiny = counts([50_000] * 4)
+    assert tiny.tolist() == [1] * 4
+    assert L.nrtgpu_plan_item_counts(1, None, 256, None) != 0
