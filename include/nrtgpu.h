@@ -264,6 +264,12 @@ int  nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
  * Host-side restatements the Java shim would otherwise take from Lucene objects
  * (BM25Similarity.scorer(boost, collectionStats, termStats); SmallFloat; slices()).
  * --------------------------------------------------------------------------------------------- */
+/* The planner's fixed-point analysis of one clause, exposed for the tests: returns 1 and *out_scale = E when
+ * every score the clause can produce over docs whose norm byte is <= max_norm -- weight - weight / (1 + freq *
+ * norm_cache256[norm]), freq >= 1 -- is a positive integer below 2^32 after multiplication by 2^E (the
+ * accumulators then add integers: exact, ds_add_u64); 0 when the range does not fit (the batch runs in fp64);
+ * negative on bad arguments.  Needs no device. */
+int  nrtgpu_fixed_point_scale(float weight, const float* norm_cache256, int32_t max_norm, int32_t* out_scale);
 /* The planner's rule for cutting a batch's queries into work items (one item runs on one CU), exposed for the
  * tests: query_costs[q] = postings + 48 per 1024-doc sub-tile of the query (0: matches nothing), target_items =
  * CUs; out_items[q] = number of items.  Needs no device. */

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "nrtgpu_search_bm25_coalesced", "nrtgpu_set_coalescing", "nrtgpu_bench_closed_loop",
     "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_knn_search", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
-    "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_get_stats", "nrtgpu_reset_stats",
+    "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
     "nrtgpu_get_scan_profile",
 ]
 
@@ -132,6 +132,7 @@ def load() -> C.CDLL:
     L.nrtgpu_bm25_norm_cache.argtypes = [f32, f32, f32, vp]
     L.nrtgpu_bm25_norm_cache.restype = None
     L.nrtgpu_plan_item_counts.argtypes = [i32, vp, i32, vp]
+    L.nrtgpu_fixed_point_scale.argtypes = [f32, vp, i32, vp]
     L.nrtgpu_slices.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp]
     L.nrtgpu_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.nrtgpu_reset_stats.argtypes = [vp]

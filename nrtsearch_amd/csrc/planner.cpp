@@ -39,7 +39,7 @@ static const int32_t kNoFixed = INT32_MIN;  // QTabs.fx_E: the query needs the f
 // segments must be a positive integer below 2^32 after scaling by 2^E_t.  Scores grow with freq and
 // shrink with the norm byte, so the smallest one is score(1, largest norm byte present) and the
 // weight bounds them from above.  Returns false when the range does not fit.
-static bool fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale) {
+bool nrtgpu::rt::fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale) {
   const float s_min = nrtgpu::hostmath::bm25_score(weight, 1.0f, cache256[max_norm & 255u]);
   if (!(s_min > 0.0f) || !std::isnormal(s_min) || !std::isnormal(weight)) return false;
   const int e_min = std::ilogb(s_min), e_w = std::ilogb(weight);

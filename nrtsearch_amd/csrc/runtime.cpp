@@ -188,6 +188,11 @@ extern "C" float nrtgpu_bm25_idf(int64_t doc_count, int64_t doc_freq) { return h
 extern "C" float nrtgpu_bm25_avgdl(int64_t sttf, int64_t doc_count) { return hostmath::bm25_avgdl(sttf, doc_count); }
 extern "C" void nrtgpu_bm25_norm_cache(float avgdl, float k1, float b, float* out256) { hostmath::bm25_norm_cache(avgdl, k1, b, out256); }
 
+extern "C" int nrtgpu_fixed_point_scale(float weight, const float* norm_cache256, int32_t max_norm, int32_t* out_scale) {
+  if (!norm_cache256 || !out_scale || max_norm < 0 || max_norm > 255) return fail(NRTGPU_ERR_INVALID_ARG, "bad fixed_point_scale arguments");
+  return fixed_scale_of_term(weight, norm_cache256, (uint32_t)max_norm, out_scale) ? 1 : 0;
+}
+
 extern "C" int nrtgpu_plan_item_counts(int32_t n_queries, const int64_t* query_costs, int32_t target_items, int64_t* out_items) {
   if (n_queries < 0 || (n_queries > 0 && (!query_costs || !out_items)) || target_items <= 0)
     return fail(NRTGPU_ERR_INVALID_ARG, "bad plan_item_counts arguments");

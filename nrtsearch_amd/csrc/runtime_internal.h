@@ -337,6 +337,8 @@ struct HostPlan {
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 int validate_query(const nrtgpu_bm25_query& q, int qi);
+// fixed-point eligibility of one query term: the scale 2^E at which all its scores are integers < 2^32
+bool fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale);
 int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp);
 

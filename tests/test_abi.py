@@ -209,3 +209,37 @@ def test_planner_item_counts():
     tiny = counts([50_000] * 4)
     assert tiny.tolist() == [1] * 4
     assert L.nrtgpu_plan_item_counts(1, None, 256, None) != 0
+
+
+def test_fixed_point_scale_makes_every_score_an_integer():
+    """The exactness claim behind the fixed-point accumulators, checked on the host: at the scale the
+    planner picks, every BM25 score a clause can produce -- any freq >= 1, any norm byte up to the largest one
+    present -- is a positive integer below 2^32, so sums of up to 32 clauses shifted by <= 15 stay below 2^53."""
+    import ctypes as C
+    from oracle import oracle
+    L = _lib.load()
+    rng = np.random.Generator(np.random.PCG64(7))
+    freqs = np.concatenate([np.arange(1, 300), [1000, 65535, 2**22 - 1]]).astype(np.float32)
+    accepted = 0
+    for trial in range(60):
+        avgdl = np.float32(rng.choice([2.5, 17.0, 80.0, 400.0, 3000.0]))
+        cache = oracle.bm25_norm_cache(float(avgdl))
+        weight = np.float32(rng.choice([0.0488, 0.693, 2.3, 7.7, 13.1]) * rng.choice([1.0, 0.5, 3.25, 100.0]))
+        max_norm = int(rng.choice([1, 40, 90, 127, 180, 255]))
+        scale = C.c_int32(0)
+        ok = L.nrtgpu_fixed_point_scale(C.c_float(weight), cache.ctypes.data, max_norm, C.byref(scale))
+        assert ok in (0, 1)
+        norms = np.arange(0, max_norm + 1)
+        ninv = cache[norms][None, :]
+        f = freqs[:, None]
+        sc = (weight - weight / (np.float32(1.0) + f * ninv)).astype(np.float32)     # float32 ops, as BM25Similarity
+        assert sc.dtype == np.float32
+        if not ok:
+            # refused only for a reason: the range really does not fit 8 binades below the weight
+            s_min = float(sc[0, max_norm])
+            assert s_min <= 0 or np.floor(np.log2(float(weight))) - np.floor(np.log2(s_min)) > 7
+            continue
+        accepted += 1
+        scaled = sc.astype(np.float64) * 2.0 ** scale.value
+        assert (scaled == np.floor(scaled)).all() and (scaled >= 1).all() and (scaled < 2.0 ** 32).all()
+    assert accepted >= 20   # (norm byte 255 is a 2-billion-token field: those configurations are refused)
