@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--oracle-queries", type=int, default=6)
     ap.add_argument("--world", type=int, default=1, help="index only rank 0's docid range of a WORLD-GPU job")
+    ap.add_argument("--min-rank", type=int, default=0,
+                    help="replace every query term of Zipf rank < MIN_RANK by MIN_RANK + rank (sparse-only query set: "
+                         "isolates the per-sub-tile cost of the walk)")
     ap.add_argument("--variants", default="0:0:1024,0:1:1024,1024:0:1024,8192:0:1024,0:0:256,0:0:64,0:0:1",
                     help="comma list of target_items:flags:batch")
     args = ap.parse_args()
@@ -46,6 +49,8 @@ def main():
     w.n_docs = args.docs
     t0 = time.time()
     qr = synth.make_queries(args.queries, w.n_terms, w.max_rank)
+    if args.min_rank > 0:
+        qr = np.where(qr < args.min_rank, qr + args.min_rank, qr)
     corpus = workload.build_shard_corpus(w, qr, args.world, 0)
     ppq = workload.postings_per_query(corpus.doc_freq, qr)
     log(json.dumps({"event": "corpus", "docs": w.n_docs, "postings": corpus.total_postings, "build_s": round(time.time() - t0, 1),
