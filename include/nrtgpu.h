@@ -63,6 +63,8 @@ typedef struct {
 #define NRTGPU_FLAG_NO_FIXED_POINT 2  /* always accumulate in fp64 (A/B; results are identical either way) */
 #define NRTGPU_FLAG_NO_LIVE_FOLD 8     /* A/B: liveDocs stay a mask read by the scan instead of being folded into the posting columns */
 #define NRTGPU_FLAG_NO_MASK_VARIANT 4   /* A/B: docs outside liveDocs / a mask are checked one by one (general sweep) */
+#define NRTGPU_FLAG_NO_PRUNE 16        /* never take the MaxScore route: every query is scanned exhaustively and total_hits is
+                                        * always the exact count (the relation still follows totalHitsThreshold) */
 
 const char* nrtgpu_version(void);
 const char* nrtgpu_last_error(void);
@@ -160,7 +162,8 @@ typedef struct {
   int32_t  capacity;                   /* in : capacity of docs/scores (>= k) */
   int32_t* docs;                       /* out: global docids (doc_base + leaf doc) */
   float*   scores;                     /* out: (score desc, doc asc) */
-  int64_t  total_hits;                 /* out: exact number of live matching docs */
+  int64_t  total_hits;                 /* out: live matching docs: the exact number, or -- when the query ran with
+                                        * dynamic pruning (MaxScore route) -- a lower bound above totalHitsThreshold */
   int32_t  total_hits_is_lower_bound;  /* out: 1 == GREATER_THAN_OR_EQUAL_TO */
 } nrtgpu_topdocs;
 
@@ -301,6 +304,10 @@ typedef struct {
   double  merge_ms;
   double  host_plan_ms;       /* host time spent building launch plans */
   int64_t fixed_point_launches; /* scan launches that accumulated in exact fixed point (the others: fp64) */
+  int64_t maxscore_launches;  /* launches of the MaxScore (dynamic pruning) kernel */
+  double  maxscore_ms;        /* sum of their HIP-event durations (collect_timing) */
+  int64_t maxscore_postings;  /* postings of the term ranges of the queries on that route (what an exhaustive scan streams) */
+  int64_t maxscore_items;
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 /* Closed-loop load generator (C concurrent clients): `clients` native threads each issue one query at a
@@ -318,6 +325,10 @@ void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
  * through the postings), [10] rendezvous: keep cycles, [11] rendezvous: publish + append cycles, [12] sub-tiles with candidates,
  * [13] sub-tiles with a possibly competitive doc, [14] last wave's finish cycle, [15] first wave's */
 int  nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16);
+/* the same flag, items of the MaxScore route; sums over items since the last reset: [0] doc windows walked, [1] top-k
+ * compactions, [2] posting chunks (512 postings), [3] postings streamed, [4] postings whose bound reached theta,
+ * [5] docs evaluated, [6] lookups in later clauses, [7] candidates collected */
+int  nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out8);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,8 @@ NRTGPU_FLAG_NO_PREFETCH = 1
 NRTGPU_FLAG_NO_FIXED_POINT = 2
 NRTGPU_FLAG_NO_MASK_VARIANT = 4
 NRTGPU_FLAG_NO_LIVE_FOLD = 8
+NRTGPU_FLAG_NO_PRUNE = 16
+NRTGPU_FLAG_PROFILE = 7 << 8
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
 ABI_SYMBOLS = [
@@ -36,7 +38,7 @@ ABI_SYMBOLS = [
     "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_knn_search", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
-    "nrtgpu_get_scan_profile",
+    "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile",
 ]
 
 
@@ -67,7 +69,9 @@ class TopDocs(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("batches", C.c_int64), ("queries", C.c_int64), ("scan_launches", C.c_int64),
                 ("scan_ms", C.c_double), ("scan_postings", C.c_int64), ("scan_items", C.c_int64),
-                ("merge_ms", C.c_double), ("host_plan_ms", C.c_double), ("fixed_point_launches", C.c_int64)]
+                ("merge_ms", C.c_double), ("host_plan_ms", C.c_double), ("fixed_point_launches", C.c_int64),
+                ("maxscore_launches", C.c_int64), ("maxscore_ms", C.c_double), ("maxscore_postings", C.c_int64),
+                ("maxscore_items", C.c_int64)]
 
 
 class NrtGpuError(RuntimeError):
@@ -138,6 +142,7 @@ def load() -> C.CDLL:
     L.nrtgpu_reset_stats.argtypes = [vp]
     L.nrtgpu_reset_stats.restype = None
     L.nrtgpu_get_scan_profile.argtypes = [vp, vp]
+    L.nrtgpu_get_maxscore_profile.argtypes = [vp, vp]
     _lib = L
     return L
 

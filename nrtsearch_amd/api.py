@@ -174,6 +174,13 @@ class GpuContext:
                  "first_wave_finish_cycles"]
         return dict(zip(names, out.tolist()))
 
+    def maxscore_profile(self) -> dict:
+        out = np.zeros(8, dtype=np.float64)
+        _lib.check(_lib.load().nrtgpu_get_maxscore_profile(self._h, out.ctypes.data))
+        names = ["windows", "compactions", "chunks", "postings_streamed", "postings_surviving", "docs_evaluated", "lookups",
+                 "candidates"]
+        return dict(zip(names, out.tolist()))
+
     def reset_stats(self) -> None:
         _lib.load().nrtgpu_reset_stats(self._h)
 

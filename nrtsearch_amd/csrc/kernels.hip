@@ -29,70 +29,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "plan.h"
-#include "topk.hiph"
+#include "bm25_common.hiph"
 
 namespace nrtgpu {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define NRT_GLOBAL __attribute__((address_space(1)))
-typedef const NRT_GLOBAL u32x4* gvec_ptr;
-typedef const NRT_GLOBAL uint32_t* gu32_ptr;
-typedef const NRT_GLOBAL float* gf32_ptr;
-
-// Accumulators.  One 64-bit LDS slot per doc of a wave's sub-tile, in one of two exact representations
-// chosen per batch by the host (planner.cpp: fixed_scale_of_term):
-//   fp64  (FX = false): the double sum of the fp32 term scores, as the reference computes it
-//                       ("unmatched" marker: -0.0, which no sum of non-negative scores produces)
-//   fixed (FX = true):  the same sum as an integer multiple of 2^-fx_E: every term score is a positive
-//                       integer < 2^32 at its own scale and enters shifted left by DTerm.fx_shift; the sum
-//                       stays below 2^53, so converting it to double is exact and (float) rounds it exactly
-//                       like the reference's (float)(double sum).  Marker: 0.  ds_add_u64 costs half of
-//                       ds_add_f64 in the LDS pipe (profiles/: 10 vs 19 cycles per wave instruction).
-constexpr uint64_t kUnmatchedF64 = 0x8000000000000000ull;  // -0.0
-template <bool FX>
-__device__ __forceinline__ constexpr uint64_t acc_marker() { return FX ? 0ull : kUnmatchedF64; }
-
-// fp32 score of an accumulator value (the one rounding of the reference's (float) sum)
-template <bool FX>
-__device__ __forceinline__ float acc_score(uint64_t a, int fx_E) {
-  if (FX) return (float)ldexp((double)a, -fx_E);  // a < 2^53: exact conversion, exact scaling
-  return (float)__longlong_as_double((long long)a);
-}
-
-// "the fp32 score could reach theta's score" as ONE 64-bit compare against this value: signed compare
-// of the double's bits (non-negative doubles order like their bit patterns, the marker -0.0 is
-// INT64_MIN) / unsigned compare of the fixed-point sum (>= 1 keeps the marker 0 out).  The cut lies
-// at least half a float ulp below theta's score, so no doc whose sum rounds up to it is lost.
-template <bool FX>
-__device__ __forceinline__ uint64_t acc_threshold(uint64_t theta_key, int fx_E) {
-  const double th = (double)key_score(theta_key);
-  if (FX) {
-    const double cut = ldexp(th * (1.0 - 1.0 / 8388608.0), fx_E);  // one float ulp below, scaled
-    const uint64_t t = (uint64_t)cut;
-    return t > 1ull ? t : 1ull;
-  }
-  return (uint64_t)(__double_as_longlong(th) - (1ll << 28));
-}
-template <bool FX>
-__device__ __forceinline__ bool acc_reaches(uint64_t a, uint64_t thr) {
-  return (long long)a >= (long long)thr;  // fixed-point sums stay below 2^53: signed works for both, and keeps kAccDead out
-}
-// Masked variant (deletes / FILTER / MUST_NOT as a doc-set mask): the slot of a doc outside the mask is
-// poisoned before its sub-tile is scored -- a value that absorbs every add and is negative as int64
-// (fixed point: the top bit above any sum; fp64: -infinity) -- so such docs are neither hits nor
-// candidates, at a cost per sub-tile instead of per posting.  A hit is then a slot that is neither the
-// marker nor poisoned: one signed compare.
-template <bool FX>
-__device__ __forceinline__ constexpr uint64_t acc_dead() { return FX ? 0x8000000000000000ull : 0xFFF0000000000000ull; }
-template <bool FX>
-__device__ __forceinline__ bool acc_is_hit(uint64_t a) { return FX ? ((long long)a > 0ll) : ((long long)a >= 0ll); }
-
-// LDS byte addresses as plain 32-bit integers: the accumulator address of a posting is then ONE
-// shift-add from its docid, with no pointer arithmetic left for the LDS instruction.
-typedef __attribute__((address_space(3))) char* lds_char_ptr;
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_char_ptr)p; }
-__device__ __forceinline__ char* lds_ptr(uint32_t a) { return (char*)(lds_char_ptr)(uintptr_t)a; }
 
 // Work decomposition: a workgroup is kScanWaves AUTONOMOUS waves and owns one CU (all 160 KiB of LDS).
 // The sub-tiles (kTileDocs docs) of an item's parts form one sequence from which the waves help
@@ -127,45 +66,6 @@ struct ScanSmem {
 static_assert(sizeof(ScanSmem) <= 160 * 1024, "the scan workgroup owns one CU's 160 KiB LDS");
 
 constexpr int kSlots = kTileDocs / 64;  // accumulator slots per lane (dense sweep)
-
-// BM25Similarity SimScorer.score(freq, norm): weight - weight / (1f + freq * normInverse),
-// one IEEE rounding per operation (no contraction, correctly rounded division).
-__device__ __forceinline__ float bm25_score(float w, float freq, float ninv) {
-  const float prod = freq * ninv;
-  const float den = 1.0f + prod;
-  const float quo = w / den;
-  return w - quo;
-}
-// the value a posting adds: fp32 bits, or the score as an integer at the term's scale (exact: the host
-// chose the scale so that every score of the term is an integer below 2^32 after it)
-template <bool FX>
-__device__ __forceinline__ uint32_t score_value(float sc, int fx_scale) {
-  return FX ? (uint32_t)ldexpf(sc, fx_scale) : __float_as_uint(sc);
-}
-
-// (mask & a) | (~mask & b) in one instruction (the compiler expands the C expression to three)
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
-  return r;
-}
-
-// Inclusive prefix sum over lanes 0..31 with DPP row shifts (VALU only, no LDS-pipe traffic).
-__device__ __forceinline__ uint32_t scan32_dpp(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);  // row_shr:8
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1, 3
-  return x;
-}
-
-// Inclusive prefix sum over all 64 lanes (lane 63 ends up with the wave total).
-__device__ __forceinline__ uint32_t scan64_dpp(uint32_t x) {
-  x = scan32_dpp(x);
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2, 3
-  return x;
-}
 
 // Per-term view of one sub-tile, built by lane l for term l and published in the wave's LDS table.
 // The term's postings of the sub-tile are seen through a window of 16-byte groups (4 postings each):

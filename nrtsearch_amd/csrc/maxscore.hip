@@ -1,0 +1,623 @@
+// maxscore.hip -- the MaxScore route of the BM25 hot path on gfx950 (CDNA4, wave64): dynamic pruning on the device.
+//
+// What it replaces in the reference: the block-max / MaxScore skipping of lucene-core 10.4.0's
+// MaxScoreBulkScorer (pure-SHOULD disjunctions under ScoreMode.TOP_SCORES), driven by the collector's
+// Scorable.setMinCompetitiveScore calls
+// (/root/reference/src/main/java/org/apache/lucene/search/LazyQueueTopScoreDocCollector.java:168-171,176-199).
+// SURVEY.md 8a row a5.  Same contract as Lucene's: the top-k (docids, ranks, score bits) is exactly the
+// exhaustive one -- only docs that provably cannot enter it are skipped -- and totalHits becomes a lower bound
+// (relation GREATER_THAN_OR_EQUAL_TO), which is why the host takes this route only for queries whose hit count
+// certainly exceeds totalHitsThreshold (planner.cpp) and never in ScoreMode.COMPLETE.
+//
+// Algorithm (the MaxScore idea, organised for a GPU: no per-doc priority queue of clause iterators, no
+// per-sub-tile accumulators).  The clauses of a (query, segment) are ordered by weight, rarest first:
+// t_0 .. t_{n-1}, each with its exact maximum score ub_j in this segment under the query's statistics (from
+// the term's impact frontier, DTermAux) and the suffix sums S_j = ub_j + ... + ub_{n-1}.  A doc is evaluated at
+// the FIRST clause (in that order) that matches it:
+//   * clause t_i streams its postings (coalesced 32 B/lane column loads, score = one LDS table read);
+//   * a posting whose score s_i + S_{i+1} cannot reach theta is dropped: if the doc matched an earlier clause it
+//     was that clause's business, otherwise S_{i+1} bounds everything else it can get;
+//   * a surviving posting tests-and-sets its doc's bit in the wave's LDS window ("already evaluated": the doc
+//     matched an earlier clause and survived there); the winner looks the doc up in the later clauses
+//     t_{i+1} .. one by one -- a 16-byte membership + rank record per 64 docs for dense terms, the cell
+//     table + a short binary search for sparse ones -- re-checking running + S_j before each lookup, and ends
+//     with the doc's exact score (the same fixed-point integers the exhaustive scan adds: identical bits);
+//   * once S_i < theta the clauses t_i .. are non-essential: their postings are never streamed.
+// A doc dropped at clause i is never evaluated later: under a later clause m its bound s_m + S_{m+1} <= S_{i+1}
+// is below the theta it was dropped at, and theta only grows.  So every doc that can reach the final theta is
+// evaluated exactly once, with its complete score.
+//
+// Work decomposition: one work item (query x doc range) per workgroup of kMsWaves autonomous waves; a wave
+// takes windows of kMsWinDocs docs from an LDS counter and walks the clauses of its window on its own, so the
+// ordering argument above holds per wave with no barrier.  Competitive docs go to the workgroup's shared LDS
+// candidate buffer; when it overflows all waves meet, a bucket select (topk.hiph) keeps the k best and raises
+// theta -- the collector's pqTop / minCompetitiveScore.
+// Roofline: HBM.  Reported both ways: effective = 9 B x the postings of the query's terms, physical
+// = what the kernel fetches (a few percent of that).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bm25_common.hiph"
+
+namespace nrtgpu {
+
+constexpr int kMsWinWords = kMsWinDocs / 32;
+
+struct MsSmem {
+  uint64_t cand[kMsCandCap];               // competitive hits of the item (packed keys), unordered
+  uint32_t tab[kTabTerms][kTabEntries];    // fixed-point BM25 score of (freq, norm byte) for the item's densest terms
+  float    cache[kLdsCaches][256];         // BM25 normInverse tables of the query's fields (division path, bounds)
+  uint32_t seen[kMsWaves][kMsWinWords];    // per wave: docs of its window that have been evaluated
+  TopkScratch sc;
+  uint64_t theta;        // packed key of the k-th best hit seen so far (0 = none)
+  uint64_t thr;          // acc_threshold(theta): what running sums are compared with
+  uint32_t cnt;          // entries in cand
+  uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kMsCandCap
+  uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet
+  uint32_t next_win;     // next unassigned window of the item
+  uint32_t hits;         // docs evaluated
+  uint32_t pad;
+  uint64_t prof[8];
+};
+static_assert(sizeof(MsSmem) <= 160 * 1024, "the MaxScore workgroup owns one CU's 160 KiB LDS");
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
+// The value postings add for 8 score codes of ONE term (wave-uniform term): a table read, or -- for codes the
+// table cannot serve (freq > kTabMaxFreq / norm >= kTabNorms, sign bit set) and for terms without a table -- the
+// BM25 formula itself.  0 = posting of a deleted doc (apply_live_kernel) -- every live posting scores >= 1.
+__device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t (&c)[8], uint32_t need, uint32_t tab_slot,
+                                                float w, int fx_scale, uint32_t cache_slot, uint32_t (&val)[8]) {
+  const uint32_t tab = tab_slot < (uint32_t)kTabTerms ? tab_slot : 7u;
+  const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
+  uint32_t cor = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    val[j] = *(const uint32_t*)(tb + (c[j] & 0x1FFCu));
+    cor |= ((need >> j) & 1u) ? c[j] : 0u;
+  }
+  const bool special = need != 0u && ((cor >> 31) != 0u || tab == 7u);
+  if (__any(special)) {
+    const float* cache = &s.cache[cache_slot][0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t cj = c[j];
+      const bool esc = (cj >> 31) != 0u;
+      const uint32_t f = esc ? ((cj >> 8) & 0x3FFFFFu) : ((cj >> 9) & 15u);
+      const bool dead = esc ? ((cj >> 30) & 1u) != 0u : (cj >> 20) != 0u;
+      const uint32_t nb = esc ? (cj & 255u) : ((cj >> 2) & 127u);
+      if (((need >> j) & 1u) && (esc || tab == 7u))
+        val[j] = dead ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
+    }
+  }
+}
+
+// All waves: keep the k best candidates, raise theta.  Contains barriers.
+__device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem* sp, uint32_t k, int fx_E,
+                                        unsigned long long* theta_g) {
+  MsSmem& s = *(MsSmem*)sp;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t cnt_raw = s.cnt;
+  const uint32_t cnt0 = cnt_raw > (uint32_t)kMsCandCap ? s.cnt_valid : cnt_raw;  // failed reservations inflate cnt
+  __syncthreads();
+  if (cnt0 > k) {  // uniform
+    const uint64_t thr = topk_kth_union<kMsThreads>(s.cand, cnt0, k, &s.sc, [](auto&&) {});
+    const uint32_t kept = topk_keep_ge<kMsThreads, kMsCandCap>(s.cand, cnt0, thr, &s.sc);
+    if (tid == 0) {
+      s.cnt = kept;
+      if (thr > s.theta) {
+        s.theta = thr;
+        s.thr = acc_threshold<true>(thr, fx_E);
+      }
+      atomicMax(theta_g, (unsigned long long)thr);  // LazyMaxScoreAccumulator.accumulate analogue
+      s.prof[1] += 1;
+    }
+  } else if (tid == 0) {
+    s.cnt = cnt0;
+  }
+  __syncthreads();
+  if (tid == 0) s.rz_flag = 0;
+  __syncthreads();
+}
+
+// Meeting point of the workgroup's waves: returns false when nobody asked for a compaction (every wave is out
+// of work), else runs it.
+__device__ __forceinline__ bool ms_meet(MsSmem& s, uint32_t k, int fx_E, unsigned long long* theta_g) {
+  __syncthreads();
+  if (!__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+  ms_compact((__attribute__((address_space(3))) MsSmem*)&s, k, fx_E, theta_g);
+  return true;
+}
+
+// Reserve room for the wave's `mine`-per-lane candidates in the shared buffer: one DPP scan and ONE LDS atomic.
+// Returns whether they fit -- a WAVE-UNIFORM answer, computed from scalars: the caller's failure path contains
+// a workgroup barrier, so no lane may disagree (a lane past the wave's last candidate holds pos == end of the
+// reservation, which for an exactly filled buffer equals its capacity).  On failure rz_flag is raised; cnt only
+// grows between compactions, so exactly the first reservation that crosses the end has base <= kMsCandCap:
+// everything below its base is completely written -> cnt_valid.
+__device__ __forceinline__ bool ms_reserve(MsSmem& s, uint32_t lane, uint32_t mine, uint32_t& pos) {
+  const uint32_t incl = scan64_dpp(mine);
+  const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t wbase = 0;
+  if (lane == 0) {
+    wbase = atomicAdd(&s.cnt, wave_total);
+    if (wbase + wave_total > (uint32_t)kMsCandCap) {
+      if (wbase <= (uint32_t)kMsCandCap) s.cnt_valid = wbase;
+      __hip_atomic_store(&s.rz_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+  pos = wbase + incl - mine;
+  return wbase + wave_total <= (uint32_t)kMsCandCap;
+}
+
+// PROF: per-item event counters (nrtgpu_get_scan_profile): [0] windows, [1] compactions, [2] posting chunks,
+// [3] postings streamed, [4] postings surviving the bound, [5] docs evaluated, [6] lookups, [7] candidates.
+template <bool PROF>
+__global__ __launch_bounds__(kMsThreads)
+void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts, const DTerm* __restrict__ terms,
+                          const DQuery* __restrict__ queries,
+                          const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
+                          uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
+                          uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof) {
+  __shared__ MsSmem s;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  const DItem item = items[blockIdx.x];
+  const DQuery q = queries[item.query];
+  const uint32_t k = q.k;
+  const int fx_E = item.fx_E;
+  unsigned long long* const my_theta_g = theta_g + item.query;
+  const bool multi_item = q.n_items > 1;
+  const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
+
+  // ---- item prologue: normInverse tables, score tables
+  {
+    const uint32_t n_lds = min(item.n_caches, (uint32_t)kLdsCaches) * 256u;
+    for (uint32_t i = tid; i < n_lds; i += kMsThreads) (&s.cache[0][0])[i] = caches[item.cache_off + i];
+  }
+  if (tid == 0) {
+    const uint64_t theta0 = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s.theta = theta0;
+    s.thr = acc_threshold<true>(theta0, fx_E);
+    s.cnt = 0;
+    s.cnt_valid = 0;
+    s.rz_flag = 0;
+    s.next_win = (uint32_t)kMsWaves;
+    s.hits = 0;
+    for (int i = 0; i < 8; ++i) s.prof[i] = 0;
+  }
+  __syncthreads();
+  for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
+    const float w = items[blockIdx.x].tab_weight[slot];
+    const int scale = items[blockIdx.x].tab_scale[slot];
+    const float* cache = &s.cache[items[blockIdx.x].tab_cache[slot]][0];
+    for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kMsThreads)  // row 0: postings of deleted docs score 0
+      s.tab[slot][e] = e < (uint32_t)kTabNorms ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
+  }
+  __syncthreads();  // from here on the waves run on their own
+
+  uint32_t* const seen = &s.seen[wave][0];
+  uint32_t wave_hits = 0;
+  uint64_t pc_post = 0, pc_surv = 0, pc_look = 0, pc_cand = 0, pc_chunks = 0, pc_wins = 0;
+  uint32_t g = wave;      // my current window (flattened over the item's parts)
+  uint32_t pi = 0;        // its part ...
+  uint32_t win_base = 0;  // ... and the windows of the parts before that one
+  bool work = true;
+
+  while (work) {
+    // ---- the part that holds window g
+    DPart part;
+    uint32_t part_wins = 0;
+    for (;; ++pi) {
+      if (pi >= item.n_parts) break;
+      part = parts[item.part_begin + pi];
+      part_wins = (part.tile_end - part.tile_begin + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
+      if (g < win_base + part_wins) break;
+      win_base += part_wins;
+    }
+    if (pi >= item.n_parts) break;
+    const uint32_t n_terms = part.n_terms;
+    const DTerm* const part_terms = terms + part.term_begin;
+
+    // ---- per part: lane l looks after clause l: its exact maximum score in this segment, suffix sums
+    uint64_t my_ub = 0, my_suf = 0;
+    for (uint32_t t = 0; t < n_terms; ++t) {  // uniform
+      const DTerm T = part_terms[t];
+      const float* cache = &s.cache[T.cache_slot][0];
+      uint32_t v = 0;
+      if (lane < 12u) {  // (read through the pointer: a lane-indexed private copy would not stay in registers)
+        const uint32_t nb = T.aux->min_norm[lane];
+        if (nb != 0xFFu) v = score_value<true>(bm25_score(T.weight, (float)(int32_t)(lane + 1u), cache[nb]), T.fx_scale);
+      } else if (lane == 12u) {
+        const uint32_t mf = T.aux->esc_max_freq;
+        if (mf != 0u) v = score_value<true>(bm25_score(T.weight, (float)(int32_t)mf, cache[T.aux->esc_min_norm]), T.fx_scale);
+      }
+      v = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32(v), 63);
+      if (lane == t) my_ub = (uint64_t)v << T.fx_shift;
+    }
+    {
+      uint64_t run = 0;
+      for (int m = (int)n_terms - 1; m >= 0; --m) {
+        run += readlane_u64(my_ub, (uint32_t)m);
+        if (lane == (uint32_t)m) my_suf = run;
+      }
+    }
+    const DTerm mt = part_terms[min(lane, n_terms - 1u)];
+    const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
+    const uint32_t my_shift = mt.shift;
+
+    for (;;) {  // windows of this part
+      const uint32_t t0 = part.tile_begin + (g - win_base) * (uint32_t)kMsWinTiles;
+      const uint32_t t1 = min(t0 + (uint32_t)kMsWinTiles, part.tile_end);
+      const uint32_t doc_lo = t0 * (uint32_t)kTileDocs;
+      const uint32_t doc_span = min(t1 * (uint32_t)kTileDocs, part.max_doc) - doc_lo;
+      if (PROF) pc_wins += 1;
+      // theta of the query's other items (LazyMaxScoreAccumulator analogue), once per window
+      uint64_t theta_other = 0, thr_other = 0;
+      if (multi_item) {
+        theta_other = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thr_other = acc_threshold<true>(theta_other, fx_E);
+      }
+      // posting range of every clause in this window (cells may be coarser than the window: doc-range filter below)
+      uint32_t my_lo = 0, my_hi = 0;
+      if (lane < n_terms) {
+        my_lo = my_cells[t0 >> my_shift];
+        my_hi = my_cells[((t1 - 1u) >> my_shift) + 1u];
+      }
+      if (n_terms > 1u) {
+#pragma unroll
+        for (int j = 0; j < kMsWinWords / 64 / 4; ++j) *(u32x4*)&seen[(lane + 64u * (uint32_t)j) * 4u] = u32x4{0u, 0u, 0u, 0u};
+      }
+
+      for (uint32_t i = 0; i < n_terms; ++i) {  // clauses, rarest first
+        const uint64_t S_i = readlane_u64(my_suf, i);
+        const uint64_t U_after = S_i - readlane_u64(my_ub, i);
+        if (S_i < max(s.thr, thr_other)) break;  // this and the remaining clauses are non-essential here
+        const DTerm T = part_terms[i];
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)i);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)my_hi, (int)i);
+        if (hi <= lo) continue;
+        const uint64_t p_begin = T.start + lo, p_end = T.start + hi;
+        const uint64_t p_al = p_begin & ~3ull;  // 16-byte groups
+
+        for (uint64_t cbase = p_al; cbase < p_end; cbase += 512u) {  // chunks of 512 postings: 8 per lane
+          if (PROF) pc_chunks += 1;
+          const uint64_t mine0 = cbase + (uint64_t)lane * 8u;
+          uint32_t d[8], c[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[j] = c[j] = 0u;
+          if (mine0 < p_end) {  // (the columns are padded: a partly valid lane may read past the term)
+            const u32x4 d0 = __builtin_nontemporal_load((gvec_ptr)(T.docids + mine0));
+            const u32x4 d1 = __builtin_nontemporal_load((gvec_ptr)(T.docids + mine0) + 1);
+            const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(T.fnorm + mine0));
+            const u32x4 c1 = __builtin_nontemporal_load((gvec_ptr)(T.fnorm + mine0) + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              d[j] = d0[j]; d[4 + j] = d1[j];
+              c[j] = c0[j]; c[4 + j] = c1[j];
+            }
+          }
+          uint32_t vmask = 0;  // my postings inside the clause's range and the window
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint64_t p = mine0 + (uint64_t)j;
+            if (p >= p_begin && p < p_end && d[j] - doc_lo < doc_span) vmask |= 1u << j;
+          }
+          uint32_t val[8];
+          values_of_codes(s, c, vmask, T.tab_slot, T.weight, T.fx_scale, T.cache_slot, val);
+          // theta as of now (it only grows: a stale value costs work, never a result)
+          const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
+          uint64_t run[8];
+          uint32_t alive = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            run[j] = (uint64_t)val[j] << T.fx_shift;
+            if (((vmask >> j) & 1u) && val[j] != 0u && run[j] + U_after >= thr) alive |= 1u << j;
+          }
+          if (PROF) {
+            pc_post += (uint64_t)__popc(vmask);
+            pc_surv += (uint64_t)__popc(alive);
+          }
+          // first clause to reach the doc?  (test-and-set; lanes without a survivor OR a zero into a word of theirs)
+          if (n_terms > 1u && __any(alive != 0u)) {
+            uint32_t old[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const bool a = (alive >> j) & 1u;
+              const uint32_t w = a ? ((d[j] - doc_lo) >> 5) : lane;
+              old[j] = atomicOr(&seen[w], a ? (1u << (d[j] & 31u)) : 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if ((old[j] >> (d[j] & 31u)) & 1u) alive &= ~(1u << j);
+          }
+          {
+            uint32_t h = (uint32_t)__popc(alive);
+            h = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(h), 63);
+            wave_hits += h;
+            if (PROF) pc_look += 0;
+          }
+
+          // ---- the later clauses of the surviving docs, one clause at a time
+          for (uint32_t j2 = i + 1u; j2 < n_terms; ++j2) {
+            const uint64_t S_j = readlane_u64(my_suf, j2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (run[j] + S_j < thr) alive &= ~(1u << j);
+            if (!__any(alive != 0u)) break;
+            if (PROF) pc_look += (uint64_t)__popc(alive);
+            const DTerm T2 = part_terms[j2];
+            const void* const bits2 = T2.aux->bits;
+            uint32_t c2[8];
+            uint32_t present = 0;
+            if (bits2 != nullptr) {
+              // dense clause: one 16-byte record per 64 docs says whether the doc is there and where its posting is
+              const gvec_ptr recs = (gvec_ptr)bits2;
+              u32x4 r[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) r[j] = recs[((alive >> j) & 1u) ? (d[j] >> 6) : 0u];
+              uint32_t idx[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const uint32_t b = d[j] & 63u;
+                const uint32_t w0 = r[j][0], w1 = r[j][1];
+                const uint32_t word = b < 32u ? w0 : w1;
+                const bool there = ((alive >> j) & 1u) && ((word >> (b & 31u)) & 1u);
+                const uint32_t m0 = b < 32u ? (w0 & ((1u << b) - 1u)) : w0;
+                const uint32_t m1 = b < 32u ? 0u : (w1 & ((1u << (b - 32u)) - 1u));
+                idx[j] = there ? r[j][2] + (uint32_t)__popc(m0) + (uint32_t)__popc(m1) : 0u;
+                present |= (there ? 1u : 0u) << j;
+              }
+              const gu32_ptr codes = (gu32_ptr)(T2.fnorm + T2.start);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) c2[j] = codes[idx[j]];
+            } else {
+              // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
+              // lane advance in lockstep, so every step is one round of loads in flight instead of eight
+              const gu32_ptr cells2 = (gu32_ptr)T2.cell_off;
+              const gu32_ptr docs2 = (gu32_ptr)(T2.docids + T2.start);
+              const gu32_ptr codes2 = (gu32_ptr)(T2.fnorm + T2.start);
+              uint32_t a[8], b[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const uint32_t cell = ((alive >> j) & 1u) ? ((d[j] >> 10) >> T2.shift) : 0u;
+                a[j] = cells2[cell];
+                b[j] = cells2[cell + 1u];
+              }
+              uint32_t open = 0;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                if (!((alive >> j) & 1u)) b[j] = a[j];
+                open |= (a[j] < b[j] ? 1u : 0u) << j;
+              }
+              while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
+                uint32_t mid[8], v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  mid[j] = (a[j] + b[j]) >> 1;
+                  v[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                  if ((open >> j) & 1u) {
+                    if (v[j] < d[j]) a[j] = mid[j] + 1u;
+                    else b[j] = mid[j];
+                    if (v[j] == d[j]) {  // found: close the search on it
+                      a[j] = b[j] = mid[j];
+                      present |= 1u << j;
+                    }
+                    if (!(a[j] < b[j])) open &= ~(1u << j);
+                  }
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];
+            }
+            if (__any(present != 0u)) {
+              uint32_t v2[8];
+              values_of_codes(s, c2, present, T2.tab_slot, T2.weight, T2.fx_scale, T2.cache_slot, v2);
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if ((present >> j) & 1u) run[j] += (uint64_t)v2[j] << T2.fx_shift;
+            }
+          }
+
+          // ---- complete scores: the competitive ones go to the shared candidate buffer
+          uint32_t cmask = 0;
+          if (__any(alive != 0u)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (((alive >> j) & 1u) && run[j] >= thr) {
+                const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
+                if (key > theta && key < after_key) cmask |= 1u << j;
+              }
+          }
+          while (__any(cmask != 0u)) {
+            uint32_t pos = 0;
+            if (ms_reserve(s, lane, (uint32_t)__popc(cmask), pos)) {  // wave-uniform
+              if (PROF) pc_cand += (uint64_t)__popc(cmask);
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if ((cmask >> j) & 1u)
+                  s.cand[pos++] = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
+              break;
+            }
+            // no room: everybody meets, the k best stay, theta rises; then retry with what is still competitive
+            (void)ms_meet(s, k, fx_E, my_theta_g);
+            const uint64_t th2 = s.theta;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if ((cmask >> j) & 1u) {
+                const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
+                if (!(key > th2)) cmask &= ~(1u << j);
+              }
+          }
+          // somebody else asked for a compaction: join it between two chunks
+          if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) (void)ms_meet(s, k, fx_E, my_theta_g);
+        }
+      }
+
+      // ---- next window
+      uint32_t g_new = 0;
+      if (lane == 0) g_new = atomicAdd(&s.next_win, 1u);
+      g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
+      if (g >= win_base + part_wins) break;  // a later part (or past the item)
+    }
+  }
+  // ---- out of work: stay available for the others' compactions until everybody is done
+  while (ms_meet(s, k, fx_E, my_theta_g)) {
+  }
+
+  // ---- item epilogue
+  {
+    const uint32_t c = s.cnt;
+    __syncthreads();
+    if (c > k) {
+      uint64_t thr = 0;
+      const uint32_t m = topk_compact<kMsThreads, kMsCandCap>(s.cand, c, k, &s.sc, &thr);
+      if (tid == 0) s.cnt = m;
+    }
+  }
+  if (lane == 0 && wave_hits) atomicAdd(&s.hits, wave_hits);
+  if (PROF && lane == 0) {
+    atomicAdd((unsigned long long*)&s.prof[0], (unsigned long long)pc_wins);
+    atomicAdd((unsigned long long*)&s.prof[2], (unsigned long long)pc_chunks);
+  }
+  if (PROF) {
+    uint64_t v3 = pc_post, v4 = pc_surv, v6 = pc_look, v7 = pc_cand;
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) {
+      v3 += __shfl_xor(v3, dlt, 64);
+      v4 += __shfl_xor(v4, dlt, 64);
+      v6 += __shfl_xor(v6, dlt, 64);
+      v7 += __shfl_xor(v7, dlt, 64);
+    }
+    if (lane == 0) {
+      atomicAdd((unsigned long long*)&s.prof[3], (unsigned long long)v3);
+      atomicAdd((unsigned long long*)&s.prof[4], (unsigned long long)v4);
+      atomicAdd((unsigned long long*)&s.prof[6], (unsigned long long)v6);
+      atomicAdd((unsigned long long*)&s.prof[7], (unsigned long long)v7);
+    }
+  }
+  __syncthreads();
+  const uint32_t n = s.cnt;
+  uint64_t* out = item_keys + (size_t)blockIdx.x * k_stride;
+  for (uint32_t i = tid; i < n; i += kMsThreads) out[i] = s.cand[i];
+  if (tid == 0) {
+    item_counts[blockIdx.x] = n;
+    // anything skipped?  Only a theta can skip; with none the walk evaluated every live matching doc exactly once.
+    const bool pruned = s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+    item_hits[blockIdx.x] = (uint64_t)s.hits + (pruned ? kHitsPrunedUnit : 0ull);
+    if (PROF && item_prof) {
+      s.prof[5] = s.hits;
+      for (int i = 0; i < 8; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
+      for (int i = 8; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Seal-time kernels of the MaxScore route.
+//
+// term_frontier_kernel: per term its DTermAux record: the impact frontier (min_norm / esc_*) from the score codes
+// fold_norms_kernel wrote (before any liveDocs are folded in), and where its membership records are
+// (t_rec[t] = first record, ~0: none).  One workgroup per term.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
+                          const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_rec,
+                          const uint32_t* __restrict__ recs, DTermAux* __restrict__ out) {
+  __shared__ uint32_t mn[13];
+  __shared__ uint32_t mf;
+  const uint32_t t = blockIdx.x;
+  if (threadIdx.x < 13) mn[threadIdx.x] = 0xFFu;
+  if (threadIdx.x == 13) mf = 0u;
+  __syncthreads();
+  const uint64_t st = t_start[t];
+  const uint32_t n = t_count[t];
+  uint32_t lmn[13];
+  uint32_t lmf = 0;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) lmn[i] = 0xFFu;
+  for (uint32_t p = threadIdx.x; p < n; p += 256u) {
+    const uint32_t c = fnorm[st + p];
+    if (c >> 31) {
+      lmn[12] = min(lmn[12], c & 255u);
+      lmf = max(lmf, (c >> 8) & 0x3FFFFFu);
+    } else {
+      const uint32_t f = (c >> 9) & 15u, nb = (c >> 2) & 127u;
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+        if (f == (uint32_t)(i + 1)) lmn[i] = min(lmn[i], nb);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 13; ++i)
+    if (lmn[i] != 0xFFu) atomicMin(&mn[i], lmn[i]);
+  if (lmf) atomicMax(&mf, lmf);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DTermAux a;
+    a.bits = t_rec[t] == ~0ull ? nullptr : (const void*)(recs + t_rec[t] * 4u);
+    for (int i = 0; i < 12; ++i) a.min_norm[i] = (uint8_t)mn[i];
+    a.esc_min_norm = (uint8_t)mn[12];
+    a.pad[0] = a.pad[1] = a.pad[2] = 0;
+    a.esc_max_freq = mf;
+    a.pad2 = 0;
+    out[t] = a;
+  }
+}
+
+// term_bits_kernel: membership + rank records of the dense terms (DTermAux.bits).  Grid: (chunks, terms); the
+// records were zeroed.  Postings are ascending in docid, so the first posting of a 64-doc block is the one whose
+// predecessor lies in an earlier block: it records its index as the block's rank.
+__global__ __launch_bounds__(256)
+void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ t_start,
+                      const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_rec, uint32_t* __restrict__ recs) {
+  const uint32_t t = blockIdx.y;
+  if (t_rec[t] == ~0ull) return;  // sparse term: no records
+  const uint64_t st = t_start[t];
+  const uint32_t n = t_count[t];
+  uint32_t* const r = recs + t_rec[t] * 4u;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const uint32_t d = docids[st + p];
+    const uint32_t blk = d >> 6;
+    atomicOr(&r[(size_t)blk * 4u + ((d >> 5) & 1u)], 1u << (d & 31u));
+    if (p == 0u || (docids[st + p - 1u] >> 6) != blk) r[(size_t)blk * 4u + 2u] = p;
+  }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+void launch_bm25_maxscore(hipStream_t stream, bool profile, uint32_t n_items, const DItem* items, const DPart* parts,
+                          const DTerm* terms, const DQuery* queries, const float* caches,
+                          unsigned long long* theta_g, uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits,
+                          uint32_t k_stride, uint64_t* item_prof) {
+  if (n_items == 0) return;
+  if (profile)
+    hipLaunchKernelGGL((bm25_maxscore_kernel<true>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries,
+                       caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof);
+  else
+    hipLaunchKernelGGL((bm25_maxscore_kernel<false>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries,
+                       caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof);
+}
+
+void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
+                          const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out) {
+  if (n_terms == 0) return;
+  hipLaunchKernelGGL(term_frontier_kernel, dim3(n_terms), dim3(256), 0, stream, fnorm, t_start, t_count, t_rec, recs, out);
+}
+
+void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
+                      const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs) {
+  if (n_terms == 0) return;
+  uint32_t chunks = (max_count + 256u * 16u - 1u) / (256u * 16u);
+  chunks = chunks < 1u ? 1u : (chunks > 1024u ? 1024u : chunks);
+  hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n_terms), dim3(256), 0, stream, docids, t_start, t_count, t_rec, recs);
+}
+
+}  // namespace nrtgpu

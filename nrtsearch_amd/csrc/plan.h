@@ -34,6 +34,7 @@ constexpr int kTabEntries = (kTabMaxFreq + 1) * kTabNorms;  // row 0 (freq 0) un
 constexpr int kMaxK = 1024;
 constexpr int kMaxTerms = 32;
 
+struct DTermAux;
 // One query term inside one segment: where its posting columns live in HBM.
 struct alignas(16) DTerm {
   const uint32_t* docids;    // docid column (all terms of the upload group, concatenated)
@@ -41,16 +42,42 @@ struct alignas(16) DTerm {
                              // freq <= kTabMaxFreq and norm < kTabNorms, else 0x80000000 | freq << 8 | norm
   const uint32_t* cell_off;  // (n_cells + 1) posting offsets relative to `start`, one per doc-range cell
   uint64_t start;            // index of the term's first posting in the columns
-  uint32_t count;            // postings of the term in this segment (docFreq within the leaf)
+  const DTermAux* aux;       // seal-time facts of the term the MaxScore route uses (resident next to the columns)
   uint32_t shift;            // cell = tile >> shift (0 for dense terms: one cell per tile)
   float    weight;           // boost * idf
-  uint32_t cache_off;        // offset in floats of the term's 256-entry normInverse table
   uint32_t cache_slot;       // per-query normInverse table index (< kLdsCaches)
   uint32_t tab_slot;         // score table of this term in the item's LDS (< kTabTerms) or 0xFFFFFFFF
   int32_t  fx_scale;         // fixed-point batches: the term's scores are integers < 2^32 after * 2^fx_scale ...
   uint32_t fx_shift;         // ... and enter the query's common scale 2^-fx_E shifted left by fx_shift
 };
 static_assert(sizeof(DTerm) == 64, "DTerm layout");
+
+// What the MaxScore route (maxscore.hip) knows about a term besides its columns (one record per term of a segment,
+// written at seal): a doc -> posting map for lookups, and the term's impact frontier -- per freq the smallest norm byte it occurs
+// with -- from which the kernel takes the term's exact maximum score under the query's statistics (the role of
+// Lucene's competitive (freq, norm) impacts).
+struct alignas(16) DTermAux {
+  const void* bits;        // one 16-byte record per 64 docs: {doc bits 0-31, bits 32-63, postings of the term before the
+                           // block, 0}; nullptr for a sparse term (looked up through its cell table instead)
+  uint8_t  min_norm[12];   // postings a score table can serve (freq f = 1..12, norm byte < 128): smallest norm byte
+                           // seen with freq f at [f - 1]; 0xFF = no such posting
+  uint8_t  esc_min_norm;   // the other postings (freq > 12 or norm byte >= 128): smallest norm byte ...
+  uint8_t  pad[3];
+  uint32_t esc_max_freq;   // ... and largest freq among them; 0 = none
+  uint32_t pad2;
+};
+static_assert(sizeof(DTermAux) == 32, "DTermAux layout");
+
+// Workgroup shape of the MaxScore route: 16 autonomous waves; a wave owns a window of kMsWinTiles sub-tiles at a
+// time (its docs' "already evaluated" bits: kMsWinDocs / 8 bytes of LDS).
+constexpr int kMsWaves = 12;
+constexpr int kMsThreads = kMsWaves * 64;
+constexpr int kMsWinTiles = 32;
+constexpr int kMsWinDocs = kMsWinTiles * kTileDocs;
+constexpr int kMsCandCap = 3072;    // LDS candidate slots of the MaxScore route (>= kMaxK + 512: a wave's retry always fits)
+// item_hits of a MaxScore item: the docs it evaluated, plus kHitsPrunedUnit when it skipped anything (the count is
+// then a lower bound).  The merge kernel's plain sum keeps both: low 48 bits = docs, high 16 = pruned items.
+constexpr uint64_t kHitsPrunedUnit = 1ull << 48;
 
 // One part of a work item: a contiguous tile range of one segment (a LeafReaderContextPartition).
 struct alignas(16) DPart {

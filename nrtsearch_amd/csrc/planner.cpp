@@ -58,12 +58,14 @@ struct PlanPiece {
 // Offsets (term_begin, cache offsets) are relative to the piece.
 static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const nrtgpu_bm25_query* queries, int q_begin,
                             int q_end, PlanPiece& pc, std::vector<std::vector<QS>>& per_query,
-                            std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs) {
+                            std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, bool allow_prune,
+                            std::vector<int64_t>& q_lower) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
   std::vector<const TermEntry*> found;
   std::vector<const FieldData*> fld((size_t)n_segs, nullptr);
   std::vector<const FieldData*> found_field;
+  uint32_t counts[kMaxTerms];
   int32_t fld_id = 0;
   bool fld_valid = false;
   size_t prev_cache_off = 0, prev_cache_len = 0;
@@ -118,6 +120,27 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
     for (int t = 0; t < q.n_terms && fx_ok; ++t)  // 32-bit entries shifted into the common scale, summed over
       if (term_total[(size_t)t] != 0 && fx_E - term_scale[(size_t)t] > 15) fx_ok = false;  // <= 32 clauses: < 2^53
     if (!fx_ok) fx_E = kNoFixed;
+    // MaxScore route (maxscore.hip)?  Its hit count is a lower bound, so -- like Lucene, which starts skipping only
+    // once totalHits has passed the threshold (LazyQueueTopScoreDocCollector.java:176-199) -- it is taken only when
+    // more than max(totalHitsThreshold, numHits) live docs certainly match: some clause has that many postings left
+    // after discounting every deleted doc of its segments.  Needs the exact fixed-point sums, plain liveDocs
+    // (folded into the columns) and a plain disjunction.
+    int64_t lower = 0;
+    if (allow_prune && fx_ok && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
+        !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
+      bool plain = true;
+      for (int si = 0; si < n_segs && plain; ++si) plain = segs[si]->d_live == nullptr || segs[si]->live_folded;
+      if (plain) {
+        for (int t = 0; t < q.n_terms; ++t) {
+          int64_t certain = 0;
+          for (int si = 0; si < n_segs; ++si)
+            if (const TermEntry* e = found[(size_t)t * n_segs + si]) certain += std::max<int64_t>(0, (int64_t)e->count - segs[si]->n_deleted);
+          lower = std::max(lower, certain);
+        }
+        if (lower <= std::max<int64_t>(q.total_hits_threshold, q.k)) lower = 0;
+      }
+    }
+    q_lower[(size_t)qi] = lower;
     tab_of_term.assign((size_t)q.n_terms, -1);
     QTabs& qt_ = qtabs[(size_t)qi];
     qt_.n = 0;
@@ -149,26 +172,34 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
         d.fnorm = g.d_fnorm;
         d.cell_off = g.d_cells + e.cell_start;
         d.start = e.start;
-        d.count = e.count;
+        d.aux = g.d_aux + e.aux_idx;
         d.shift = e.shift;
         d.weight = qt.weight;
-        d.cache_off = cache_base[(size_t)qi] + (uint32_t)qt.cache_slot * 256u;
         d.cache_slot = (uint32_t)qt.cache_slot;
         d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
         d.fx_scale = term_scale[(size_t)t];
         d.fx_shift = fx_ok ? (uint32_t)(fx_E - term_scale[(size_t)t]) : 0u;
         pc.terms.push_back(d);
+        counts[qs.n_terms] = e.count;
         qs.n_terms++;
         qs.postings += e.count;
       }
       if (qs.n_terms > 0) {
-        // densest clause first; stable insertion sort (a handful of clauses; std::stable_sort allocates per call)
+        // exhaustive scan: densest clause first.  MaxScore route: heaviest (rarest) clause first, the order its
+        // bounds are taken in.  Stable insertion sort (a handful of clauses; std::stable_sort allocates per call)
         DTerm* tb = pc.terms.data() + qs.term_begin;
+        const bool by_weight = lower > 0;
         for (uint32_t i = 1; i < qs.n_terms; ++i) {
           const DTerm key = tb[i];
+          const uint32_t kc = counts[i];
           uint32_t j = i;
-          for (; j > 0 && tb[j - 1].count < key.count; --j) tb[j] = tb[j - 1];
+          for (; j > 0 && (by_weight ? (tb[j - 1].weight < key.weight || (tb[j - 1].weight == key.weight && counts[j - 1] > kc))
+                                     : counts[j - 1] < kc); --j) {
+            tb[j] = tb[j - 1];
+            counts[j] = counts[j - 1];
+          }
           tb[j] = key;
+          counts[j] = kc;
         }
         per_query[(size_t)qi].push_back(qs);
         pc.postings += qs.postings;
@@ -179,7 +210,7 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
 }
 
 int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp) {
+                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp, bool allow_prune) {
   uint32_t kmax = 1;
   for (int qi = 0; qi < n_queries; ++qi) {
     if (int rc = validate_query(queries[qi], qi)) return rc;
@@ -209,8 +240,14 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   n_thr = std::max(1, std::min(n_thr, n_queries / 64));
   std::vector<PlanPiece> pieces((size_t)n_thr);
   auto chunk_begin = [&](int t) { return (int)((int64_t)n_queries * t / n_thr); };
+  {
+    const int variant = (ctx->cfg.flags >> 8) & 15;  // (the timing ablations of the scan stay exhaustive; 7 = instrumented kernels)
+    allow_prune = allow_prune && (ctx->cfg.flags & NRTGPU_FLAG_NO_PRUNE) == 0 && (variant == 0 || variant == 7);
+  }
+  hp.q_lower.assign((size_t)n_queries, 0);
   auto work = [&](int t) {
-    resolve_queries(segs, n_segs, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t], per_query, cache_base, qtabs);
+    resolve_queries(segs, n_segs, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t], per_query, cache_base, qtabs,
+                    allow_prune, hp.q_lower);
   };
   {
     std::vector<std::thread> pool;
@@ -229,7 +266,6 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   for (int t = 0; t < n_thr; ++t) {
     PlanPiece& pc = pieces[(size_t)t];
     const uint32_t term_base = (uint32_t)hp.terms.size(), c_base = (uint32_t)hp.caches.size();
-    for (DTerm& d : pc.terms) d.cache_off += c_base;
     hp.terms.insert(hp.terms.end(), pc.terms.begin(), pc.terms.end());
     hp.caches.insert(hp.caches.end(), pc.caches.begin(), pc.caches.end());
     for (int qi = chunk_begin(t); qi < chunk_begin(t + 1); ++qi) {
@@ -242,6 +278,9 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   hp.fixed_point = (ctx->cfg.flags & NRTGPU_FLAG_NO_FIXED_POINT) == 0;
   for (int qi = 0; qi < n_queries && hp.fixed_point; ++qi)
     if (!per_query[(size_t)qi].empty() && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
+  for (int qi = 0; qi < n_queries; ++qi)
+    if (hp.q_lower[(size_t)qi] > 0)
+      for (const QS& qs : per_query[(size_t)qi]) hp.ms_postings += qs.postings;
   // minimumNumberShouldMatch > 1 (QueryNodeMapper.java:259-261): the clause count rides in the fixed-point
   // accumulator, so the whole batch must be in fixed-point mode; otherwise the caller runs Lucene's WANDScorer
   hp.clause_counting = false;
@@ -325,6 +364,10 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // index order, so big items start first and small ones fill the tail
   // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
   std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.cost > b.cost; });
+  // the items of the queries on the MaxScore route first: they run in a launch of their own
+  std::stable_partition(pend.begin(), pend.end(), [&](const Pending& a) { return hp.q_lower[a.query] > 0; });
+  hp.n_ms_items = 0;
+  for (const Pending& a : pend) hp.n_ms_items += hp.q_lower[a.query] > 0 ? 1u : 0u;
   hp.items.resize(pend.size());
   std::vector<std::vector<uint32_t>> lists((size_t)n_queries);
   for (size_t i = 0; i < pend.size(); ++i) {

@@ -87,6 +87,7 @@ extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
     HIP_TRY(hipEventCreate(&s->ev2));
+    HIP_TRY(hipEventCreate(&s->ev3));
     ctx->slots.push_back(std::move(s));
   }
   *out = ctx.release();
@@ -155,6 +156,7 @@ extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev2) (void)hipEventDestroy(s->ev2);
+    if (s->ev3) (void)hipEventDestroy(s->ev3);
     if (s->stream) (void)hipStreamDestroy(s->stream);
   }
   delete ctx;
@@ -171,11 +173,19 @@ extern "C" void nrtgpu_reset_stats(nrtgpu_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
   ctx->stats = nrtgpu_stats{};
   for (double& p : ctx->prof) p = 0;
+  for (double& p : ctx->ms_prof) p = 0;
 }
 extern "C" int nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16) {
   if (!ctx || !out16) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
   for (int i = 0; i < 16; ++i) out16[i] = ctx->prof[i];
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out8) {
+  if (!ctx || !out8) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->stats_mu);
+  for (int i = 0; i < 8; ++i) out8[i] = ctx->ms_prof[i];
   return NRTGPU_OK;
 }
 

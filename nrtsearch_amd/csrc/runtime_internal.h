@@ -39,6 +39,13 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int 
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
+void launch_bm25_maxscore(hipStream_t stream, bool profile, uint32_t n_items, const DItem* items, const DPart* parts,
+                          const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
+                          uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
+void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
+                          const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
+void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
+                      const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs);
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
@@ -130,6 +137,7 @@ struct TermEntry {
   uint32_t count;
   uint32_t shift;      // doc-range cell = tile >> shift
   uint64_t cell_start; // first entry of the term's cell table inside the group's table buffer
+  uint32_t aux_idx;    // the term's DTermAux record inside the group's d_aux (written at seal)
 };
 
 struct TermGroup {
@@ -138,6 +146,11 @@ struct TermGroup {
   uint32_t* d_fnorm = nullptr;   // score-code column (same allocation as d_docids), filled at seal
   bool folded = false;
   uint32_t* d_cells = nullptr;   // concatenated per-term cell tables
+  DTermAux* d_aux = nullptr;     // MaxScore route: one record per term of the group (impact frontier, membership records), seal
+  uint32_t* d_bits = nullptr;    // membership + rank records of the group's dense terms (16 B per 64 docs and term)
+  uint32_t n_terms = 0;
+  std::vector<uint64_t> h_start;  // per term of the group (add order): first posting, postings -- kept until the seal
+  std::vector<uint32_t> h_count;
   bool has_freqs = false;
   uint64_t n_postings = 0;
 };
@@ -205,6 +218,7 @@ struct nrtgpu_seg {
   bool sealed = false;
   std::map<int32_t, FieldData> fields;
   uint64_t* d_live = nullptr;
+  int32_t n_deleted = 0;         // docs cleared in liveDocs (host pop-count at set_live_docs)
   int64_t device_bytes = 0;
   // FILTER / MUST_NOT clauses as doc-set masks: host copies of the registered masks and of liveDocs,
   // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use
@@ -255,7 +269,7 @@ namespace rt {
 // ------------------------------------------------------------------------------------------------
 struct Slot {
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   PinBuf h_plan;     // host staging of the plan blob
   DevBuf d_plan;     // device copy
   DevBuf d_work;     // theta + item outputs + merge outputs
@@ -280,6 +294,7 @@ struct nrtgpu_ctx {
   std::mutex stats_mu;
   nrtgpu_stats stats{};
   double prof[16] = {0};
+  double ms_prof[16] = {0};   // the same for the items of the MaxScore route (nrtgpu_get_maxscore_profile)
   // request coalescing (nrtgpu_search_bm25_coalesced)
   std::mutex co_mu;
   std::condition_variable co_cv;
@@ -333,14 +348,19 @@ struct HostPlan {
   bool fixed_point = false;         // every query of the batch passed the fixed-point range analysis
   bool clause_counting = false;     // some query has minimumNumberShouldMatch > 1: count-carrying kernel variant
   bool masked = false;              // some part reads a doc-set mask (liveDocs / FILTER / MUST_NOT)
+  // MaxScore route (maxscore.hip): items [0, n_ms_items) run it, the others the exhaustive scan
+  uint32_t n_ms_items = 0;
+  std::vector<int64_t> q_lower;     // per query on that route: live docs certain to match (> totalHitsThreshold), else 0
+  int64_t ms_postings = 0;          // postings of the queries on that route (algorithmic work, as `postings`)
 };
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 int validate_query(const nrtgpu_bm25_query& q, int qi);
 // fixed-point eligibility of one query term: the scale 2^E at which all its scores are integers < 2^32
 bool fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale);
+// allow_prune: queries that qualify may take the MaxScore route (total_hits then a lower bound, relation GTE)
 int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-               const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp);
+               const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp, bool allow_prune = false);
 
 }  // namespace rt
 }  // namespace nrtgpu

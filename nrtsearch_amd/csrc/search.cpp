@@ -10,6 +10,7 @@ struct DeviceRun {
   uint64_t* out_hits = nullptr;
   uint64_t* prof = nullptr;   // instrumented variant: 8 counters per item
   size_t n_items = 0;
+  size_t n_ms_items = 0;
 };
 
 // Enqueue plan upload + scan + merge on the slot's stream.  Merge output goes to (ext_keys,
@@ -71,7 +72,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
   const int flag_variant = (ctx->cfg.flags >> 8) & 15;
   const int ablation = hp.clause_counting ? 8 : ((hp.masked && flag_variant == 0 && !(ctx->cfg.flags & NRTGPU_FLAG_NO_MASK_VARIANT)) ? 9 : flag_variant);
-  const size_t o_prof = wc.take(ablation == 7 ? n_items * 128 : 0);
+  const bool profile = flag_variant == 7;
+  const size_t o_prof = wc.take((ablation == 7 || profile) ? n_items * 128 : 0);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   char* db = (char*)slot->d_plan.p;
   char* wb = (char*)slot->d_work.p;
@@ -81,12 +83,21 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   HIP_TRY(hipStreamSynchronize(st));
   gpu.lock();
   const bool timing = ctx->cfg.collect_timing != 0;
+  // the queries on the MaxScore route (items [0, n_ms)), then the exhaustive scan of the others
+  const size_t n_ms = hp.n_ms_items;
+  if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
+  launch_bm25_maxscore(st, profile, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
+                       (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
+                       (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
+                       profile ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
-  launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)n_items, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
+  launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)(n_items - n_ms),
+                   (const DItem*)(db + o_items) + n_ms, (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
                    (unsigned long long*)(db + o_theta), (unsigned long long*)(db + o_quant),
-                   use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt),
-                   (uint64_t*)(wb + o_ihits), hp.k_stride, ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr);
+                   use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys) + n_ms * (size_t)hp.k_stride,
+                   (uint32_t*)(wb + o_icnt) + n_ms, (uint64_t*)(wb + o_ihits) + n_ms, hp.k_stride,
+                   ablation == 7 ? (uint64_t*)(wb + o_prof) + n_ms * 16 : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
   uint64_t* okeys = ext_keys ? ext_keys : (uint64_t*)(wb + o_okeys);
   uint32_t* ocnt = ext_counts ? ext_counts : (uint32_t*)(wb + o_ocnt);
@@ -100,26 +111,33 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   run->out_keys = okeys;
   run->out_counts = ocnt;
   run->out_hits = ohits;
-  run->prof = ablation == 7 ? (uint64_t*)(wb + o_prof) : nullptr;
+  run->prof = (ablation == 7 || profile) ? (uint64_t*)(wb + o_prof) : nullptr;
   run->n_items = n_items;
+  run->n_ms_items = n_ms;
   return 0;
 }
 
 static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, double plan_ms) {
-  float scan_ms = 0.f, merge_ms = 0.f;
+  float scan_ms = 0.f, merge_ms = 0.f, ms_ms = 0.f;
   if (ctx->cfg.collect_timing) {
+    (void)hipEventElapsedTime(&ms_ms, slot->ev3, slot->ev0);
     (void)hipEventElapsedTime(&scan_ms, slot->ev0, slot->ev1);
     (void)hipEventElapsedTime(&merge_ms, slot->ev1, slot->ev2);
   }
+  const size_t n_scan = hp.items.size() - hp.n_ms_items;
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
   ctx->stats.batches += 1;
   ctx->stats.queries += n_queries;
-  ctx->stats.scan_launches += hp.items.empty() ? 0 : 1;
-  ctx->stats.fixed_point_launches += (!hp.items.empty() && hp.fixed_point) ? 1 : 0;
-  ctx->stats.scan_ms += scan_ms;
+  ctx->stats.scan_launches += n_scan ? 1 : 0;
+  ctx->stats.fixed_point_launches += (n_scan && hp.fixed_point) ? 1 : 0;
+  ctx->stats.scan_ms += n_scan ? scan_ms : 0.f;
   ctx->stats.merge_ms += merge_ms;
-  ctx->stats.scan_postings += hp.postings;
-  ctx->stats.scan_items += (int64_t)hp.items.size();
+  ctx->stats.scan_postings += hp.postings - hp.ms_postings;
+  ctx->stats.scan_items += (int64_t)n_scan;
+  ctx->stats.maxscore_launches += hp.n_ms_items ? 1 : 0;
+  ctx->stats.maxscore_ms += hp.n_ms_items ? ms_ms : 0.f;
+  ctx->stats.maxscore_postings += hp.ms_postings;
+  ctx->stats.maxscore_items += (int64_t)hp.n_ms_items;
   ctx->stats.host_plan_ms += plan_ms;
 }
 
@@ -131,8 +149,13 @@ static inline int32_t relation_gte(int64_t total_hits, int32_t n_hits, int32_t k
   return (total_hits > thr && n_hits == k) ? 1 : 0;
 }
 
+// `hits` as the merge leaves it: low 48 bits = docs counted, high 16 = items of the query that skipped docs on the
+// MaxScore route (plan.h: kHitsPrunedUnit).  With none the count is exact and the relation follows from it; else the
+// count is a lower bound, reported together with `lower` -- the live docs the planner knew to match, more than the
+// threshold -- as GREATER_THAN_OR_EQUAL_TO, which is what the reference reports once its collectors have started
+// skipping (the value itself is an artefact of the traversal there as well, SURVEY 7 hard part 3).
 static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, const int32_t k, const int32_t threshold,
-                           nrtgpu_topdocs* out) {
+                           int64_t lower, nrtgpu_topdocs* out) {
   const int32_t cap = out->capacity > 0 ? out->capacity : k;
   const int32_t m = std::min<int32_t>((int32_t)n, cap);
   // two plain loops (vectorisable): doc = ~low word, score = high word reinterpreted
@@ -141,8 +164,14 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
   if (uint32_t* __restrict__ sc = (uint32_t*)out->scores)
     for (int32_t i = 0; i < m; ++i) sc[i] = (uint32_t)(keys[i] >> 32);
   out->n_hits = m;
-  out->total_hits = (int64_t)hits;
-  out->total_hits_is_lower_bound = relation_gte((int64_t)hits, (int32_t)n, k, threshold);
+  const int64_t counted = (int64_t)(hits & (kHitsPrunedUnit - 1));
+  if ((hits >> 48) != 0) {
+    out->total_hits = std::max(counted, lower);
+    out->total_hits_is_lower_bound = 1;
+  } else {
+    out->total_hits = counted;
+    out->total_hits_is_lower_bound = relation_gte(counted, (int32_t)n, k, threshold);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,7 +189,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
   SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
-  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, true)) return rc;
   const double plan_ms = now_ms() - t0;
 
   Slot* slot = nullptr;
@@ -186,13 +215,13 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   const uint32_t* cnts = (const uint32_t*)(ho + o_c);
   const uint64_t* hits = (const uint64_t*)(ho + o_h);
   for (int qi = 0; qi < n_queries; ++qi)
-    unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, &out[qi]);
+    unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, hp.q_lower[(size_t)qi], &out[qi]);
   if (run.prof && run.n_items) {
     std::vector<uint64_t> hp_prof(run.n_items * 16);
     HIP_TRY(hipMemcpy(hp_prof.data(), run.prof, hp_prof.size() * 8, hipMemcpyDeviceToHost));
     std::lock_guard<std::mutex> lk(ctx->stats_mu);
     for (size_t i = 0; i < run.n_items; ++i)
-      for (int j = 0; j < 16; ++j) ctx->prof[j] += (double)hp_prof[i * 16 + j];
+      for (int j = 0; j < 16; ++j) (i < run.n_ms_items ? ctx->ms_prof : ctx->prof)[j] += (double)hp_prof[i * 16 + j];
   }
   account(ctx, slot, hp, n_queries, plan_ms);
   return NRTGPU_OK;
@@ -219,7 +248,7 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
   SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
-  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, true)) return rc;
   const double plan_ms = now_ms() - t0;
   for (int si = 0; si < n_segs; ++si) {
     auto fit = segs[si]->fields.find(field_id);
@@ -291,8 +320,10 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   const uint64_t* hits = (const uint64_t*)(ha + oh_h);
   for (int qi = 0; qi < n_queries; ++qi) {
     // QueryRescorer keeps the first pass's TotalHits; the window only trims the hits
-    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi], std::min<int32_t>(window, NRTGPU_MAX_K), queries[qi].total_hits_threshold, &out[qi]);
-    out[qi].total_hits_is_lower_bound = relation_gte((int64_t)hits[qi], (int32_t)first_cnts[qi], queries[qi].k, queries[qi].total_hits_threshold);
+    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi], std::min<int32_t>(window, NRTGPU_MAX_K), queries[qi].total_hits_threshold,
+                   hp.q_lower[(size_t)qi], &out[qi]);
+    if ((hits[qi] >> 48) == 0)  // exact count: the relation is the first pass's (its queue, not the window)
+      out[qi].total_hits_is_lower_bound = relation_gte((int64_t)hits[qi], (int32_t)first_cnts[qi], queries[qi].k, queries[qi].total_hits_threshold);
   }
   account(ctx, slot, hp, n_queries, plan_ms);
   return NRTGPU_OK;
@@ -598,7 +629,7 @@ extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_
   const uint32_t* cnts = (const uint32_t*)(ho + o_ocnt);
   const uint64_t* hits = (const uint64_t*)(ho + o_ohits);
   for (int qi = 0; qi < n_queries; ++qi)
-    unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], total_hits_thresholds[qi], &out[qi]);
+    unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], total_hits_thresholds[qi], 0, &out[qi]);
   return NRTGPU_OK;
 }
 

@@ -94,6 +94,7 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
     e.count = (uint32_t)cnt;
     e.shift = shift;
     e.cell_start = cells.size();
+    e.aux_idx = (uint32_t)t;
     const int64_t cell_docs = (int64_t)kTileDocs << shift;  // a cell covers 2^shift sub-tiles
     int64_t p = lo;
     int32_t prev = -1;
@@ -116,6 +117,13 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
 
   TermGroup g;
   g.n_postings = (uint64_t)total;
+  g.n_terms = (uint32_t)n_terms;
+  g.h_start.resize((size_t)n_terms);
+  g.h_count.resize((size_t)n_terms);
+  for (int64_t t = 0; t < n_terms; ++t) {
+    g.h_start[(size_t)t] = (uint64_t)offsets[t];
+    g.h_count[(size_t)t] = (uint32_t)(offsets[t + 1] - offsets[t]);
+  }
   void* p = nullptr;
   // one allocation per upload group: [docid column | code column], each padded to a multiple of
   // 16 bytes plus 64 (16-byte group loads may run past the end); the kernel addresses the code column
@@ -176,6 +184,57 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
 
 static int fold_live_docs(nrtgpu_seg* seg);
 
+// What the MaxScore route needs per term besides the columns (plan.h: DTermAux), built on the device from the
+// sealed columns: the impact frontier of every term, and for terms dense enough that a doc-indexed structure is
+// affordable (at least one posting per kBitsDocsPerPosting docs: the records then take at most 4x the term's
+// posting bytes) one membership + rank record per 64 docs.  Sparser terms are looked up through their cell table.
+static const int64_t kBitsDocsPerPosting = 128;
+static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
+  if (g.d_aux || g.n_terms == 0) return NRTGPU_OK;
+  const size_t nt = g.n_terms;
+  const uint64_t n_blocks = ((uint64_t)seg->max_doc + 63) / 64 + 1;  // (+1: lookups of absent docs may read record 0 only, keep a pad)
+  std::vector<uint64_t> rec((size_t)nt, ~0ull);
+  uint64_t n_recs = 0;
+  uint32_t max_count = 0;
+  for (size_t t = 0; t < nt; ++t) {
+    if (g.h_count[t] > 0 && (int64_t)g.h_count[t] * kBitsDocsPerPosting >= (int64_t)seg->max_doc) {
+      rec[t] = n_recs;
+      n_recs += n_blocks;
+      max_count = std::max(max_count, g.h_count[t]);
+    }
+  }
+  void* p = nullptr;
+  if (int rc = dev_alloc(seg, &p, nt * sizeof(DTermAux))) return rc;
+  g.d_aux = (DTermAux*)p;
+  if (n_recs) {
+    if (int rc = dev_alloc(seg, &p, (size_t)n_recs * 16)) return rc;
+    g.d_bits = (uint32_t*)p;
+    HIP_TRY(hipMemset(g.d_bits, 0, (size_t)n_recs * 16));
+  }
+  uint64_t* d_start = nullptr;
+  uint64_t* d_rec = nullptr;
+  uint32_t* d_count = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_start, nt * 8));
+  HIP_TRY(hipMalloc((void**)&d_rec, nt * 8));
+  HIP_TRY(hipMalloc((void**)&d_count, nt * 4));
+  HIP_TRY(hipMemcpy(d_start, g.h_start.data(), nt * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_rec, rec.data(), nt * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_count, g.h_count.data(), nt * 4, hipMemcpyHostToDevice));
+  launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_rec, g.d_bits, (uint32_t)nt, g.d_aux);
+  if (n_recs) launch_term_bits(nullptr, g.d_docids, d_start, d_count, d_rec, (uint32_t)nt, max_count, g.d_bits);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipFree(d_start);
+  (void)hipFree(d_rec);
+  (void)hipFree(d_count);
+  if (e != hipSuccess) return fail(NRTGPU_ERR_HIP, "building the MaxScore term records failed: %s", hipGetErrorString(e));
+  g.h_start.clear();
+  g.h_start.shrink_to_fit();
+  g.h_count.clear();
+  g.h_count.shrink_to_fit();
+  return NRTGPU_OK;
+}
+
 extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
   if (seg->sealed) return NRTGPU_OK;
@@ -207,6 +266,9 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   (void)hipFree(d_overflow);
   if (rc) return rc;
   if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^22 does not fit the packed freq|norm column");
+  for (auto& kv : seg->fields)
+    for (auto& g : kv.second.groups)
+      if (int rc2 = build_term_aux(seg, g)) return rc2;
   for (auto& kv : seg->fields) kv.second.flat.build(kv.second.dict);
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
@@ -245,10 +307,20 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
     if (seg->d_live) (void)hipFree(seg->d_live);
     seg->d_live = nullptr;
     seg->h_live.clear();
+    seg->n_deleted = 0;
     return fold_live_docs(seg);
   }
   if (n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "live bits: %d words given, %d needed", n_words, need);
   seg->h_live.assign(bits, bits + need);
+  {
+    int64_t live = 0;
+    for (int32_t i = 0; i < need; ++i) {
+      uint64_t w = bits[i];
+      if (i == need - 1 && (seg->max_doc & 63)) w &= (1ull << (seg->max_doc & 63)) - 1ull;
+      live += __builtin_popcountll(w);
+    }
+    seg->n_deleted = (int32_t)((int64_t)seg->max_doc - live);
+  }
   if (!seg->d_live) {  // padded: the masked scan variant reads whole sub-tiles (128 bytes) of the mask
     void* p = nullptr;
     if (int rc = dev_alloc(seg, &p, (size_t)need * 8 + kMaskPadBytes)) return rc;
@@ -337,6 +409,8 @@ extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
       if (g.d_docids) (void)hipFree(g.d_docids);
       if (g.d_freqs) (void)hipFree(g.d_freqs);
       if (g.d_cells) (void)hipFree(g.d_cells);
+      if (g.d_aux) (void)hipFree(g.d_aux);
+      if (g.d_bits) (void)hipFree(g.d_bits);
     }
   }
   if (seg->d_live) (void)hipFree(seg->d_live);

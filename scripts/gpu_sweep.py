@@ -70,8 +70,9 @@ def main():
             bad = 0
             for qi in range(n):
                 d, s_, tot, gte = oracle.search_bm25(corpus, qr[qi].tolist(), w.k)
+                tot_ok = (w.k < got[qi].total_hits <= tot) if gte else got[qi].total_hits == tot   # pruned: a lower bound
                 ok = (got[qi].docs.tolist() == d.tolist() and got[qi].scores.view(np.uint32).tolist() == s_.view(np.uint32).tolist()
-                      and got[qi].total_hits == tot and got[qi].relation_gte == gte)
+                      and tot_ok and got[qi].relation_gte == gte)
                 bad += (not ok)
                 if not ok:
                     log(json.dumps({"event": "MISMATCH", "query": qi, "got_total": got[qi].total_hits, "exp_total": tot,
@@ -82,7 +83,7 @@ def main():
         pbs = [api.PreparedBatch(sr, queries[i * B:(i + 1) * B], [mgr] * B) for i in range(nb)]
         pbs[0].run()  # warm
         cs = checksum(pbs[0], B)
-        key = B
+        key = (B, bool(fl & 16))   # total_hits of a pruned search is a lower bound: its own checksum class
         if key in ref_sum and ref_sum[key] != cs:
             log(json.dumps({"event": "CHECKSUM_MISMATCH", "variant": v}))
         ref_sum.setdefault(key, cs)
@@ -95,15 +96,20 @@ def main():
             lat.append(time.perf_counter() - ts)
         dt = time.perf_counter() - t1
         st = ctx.stats()
-        L = max(1, st["scan_launches"])
-        scan_ms = st["scan_ms"] / L
-        bytes_l = st["scan_postings"] / L * 8
+        L = max(1, st["scan_launches"], st["maxscore_launches"])
+        scan_ms = (st["scan_ms"] + st["maxscore_ms"]) / L
+        bytes_l = (st["scan_postings"] + st["maxscore_postings"]) / L * 8
         prof = ctx.scan_profile() if ((fl >> 8) & 15) == 7 else None
         per_item = None
         if prof:   # the counters are sums over every item of every launch since reset_stats (wave 0 of each workgroup)
             n_it = max(1.0, float(st["scan_items"]))
             per_item = {k: round(v / n_it, 2) for k, v in prof.items() if not k.endswith("finish_cycles")}
-        log(json.dumps({"event": "variant", "target_items": ti, "flags": fl, "batch": B, "qps": round(args.steps * B / dt, 1),
+        ms_prof = ctx.maxscore_profile() if ((fl >> 8) & 15) == 7 and st["maxscore_items"] else None
+        if ms_prof:
+            nq_run = max(1, st["queries"])
+            ms_prof = {k: round(v / nq_run, 1) for k, v in ms_prof.items()}   # per query
+        log(json.dumps({"event": "variant", "maxscore_items": st["maxscore_items"] / L, "maxscore_ms": round(st["maxscore_ms"] / L, 3),
+                        "maxscore_profile_per_query": ms_prof, "target_items": ti, "flags": fl, "batch": B, "qps": round(args.steps * B / dt, 1),
                         "ms_per_step": round(dt / args.steps * 1e3, 3), "p50_ms": round(float(np.median(lat)) * 1e3, 3),
                         "scan_ms": round(scan_ms, 3), "merge_ms": round(st["merge_ms"] / L, 3),
                         "plan_ms": round(st["host_plan_ms"] / L, 3), "items": st["scan_items"] / L,

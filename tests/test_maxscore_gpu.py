@@ -1,0 +1,151 @@
+"""The MaxScore route (dynamic pruning on the device): its top-k -- docids, ranks, score bits --
+must be the exhaustive scan's and the oracle's; total_hits becomes a lower bound above the threshold with relation
+GREATER_THAN_OR_EQUAL_TO, exactly where the exhaustive count exceeds the threshold.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from nrtsearch_amd import _lib, api, synth
+
+pytestmark = pytest.mark.gpu
+INT_MAX = 2**31 - 1
+
+
+class Index:
+    def __init__(self, ctx, corpus):
+        self.corpus = corpus
+        self.leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+        self.searcher = api.GpuIndexSearcher(ctx, self.leaves, api.IndexStatistics.from_corpus(corpus))
+
+    def close(self):
+        for l in self.leaves:
+            l.release()
+
+
+def bq(terms, boosts=None):
+    cl = []
+    for i, t in enumerate(terms):
+        q = api.TermQuery(0, int(t))
+        if boosts is not None:
+            q = api.BoostQuery(q, float(boosts[i]))
+        cl.append(q)
+    return cl[0] if len(cl) == 1 else api.BooleanQuery(tuple(cl))
+
+
+def check(name, got: api.TopDocs, exp, k, thr):
+    """got: a search that may have pruned; exp: the oracle's exhaustive (docs, scores, total, gte)."""
+    edocs, escores, etotal, egte = exp
+    assert got.docs.tolist() == edocs.tolist(), f"{name}: docids/ranks differ"
+    assert got.scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist(), f"{name}: score bits differ"
+    assert got.relation_gte == egte, f"{name}: relation"
+    if egte:
+        assert max(thr, k) < got.total_hits <= etotal, f"{name}: lower bound {got.total_hits} not in ({max(thr, k)}, {etotal}]"
+    else:
+        assert got.total_hits == etotal, f"{name}: totalHits {got.total_hits} != {etotal}"
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    pruned = api.GpuContext(device_id=0, max_batch=1024)
+    plain = api.GpuContext(device_id=0, max_batch=1024, flags=_lib.NRTGPU_FLAG_NO_PRUNE)
+    yield pruned, plain
+    pruned.close()
+    plain.close()
+
+
+RANKS = [1, 2, 3, 5, 8, 13, 40, 100, 333, 1000, 5000, 9999]
+
+
+@pytest.fixture(scope="module")
+def mid(ctxs):
+    corpus = synth.build_corpus(300_000, RANKS, n_segments=4, delete_fraction=0.02)
+    a, b = Index(ctxs[0], corpus), Index(ctxs[1], corpus)
+    yield a, b
+    a.close()
+    b.close()
+
+
+SHAPES = [[1], [100], [5000], [1, 2], [1, 9999], [333, 1000], [5, 40, 1000], [1, 2, 3, 5, 8], [13, 40, 100, 333, 1000],
+          [1, 100, 1000, 5000, 9999], [2, 3, 5000], [1, 2, 3, 5, 8, 13, 40, 100, 333, 1000, 5000, 9999], [8, 8, 40],
+          [9999, 5000], [3, 13, 333, 9999]]
+
+
+def test_pruned_topk_equals_exhaustive_equals_oracle(ctxs, mid, oracle):
+    pruned, plain = mid
+    qs, mgrs, meta = [], [], []
+    for terms in SHAPES:
+        for k, thr in [(10, 1000), (100, 1000), (1000, 1000), (1, 0), (37, 50), (100, INT_MAX)]:
+            qs.append(bq(terms))
+            mgrs.append(api.TopScoreDocCollectorManager(k, total_hits_threshold=thr))
+            meta.append((terms, k, thr))
+    ctxs[0].reset_stats()
+    got = pruned.searcher.search_batch(qs, mgrs)
+    ref = plain.searcher.search_batch(qs, mgrs)
+    st = ctxs[0].stats()
+    assert st["maxscore_items"] > 0 and st["scan_items"] > 0, st   # both routes ran (INT_MAX / few-hit queries stay exhaustive)
+    assert ctxs[1].stats()["maxscore_items"] == 0
+    for (terms, k, thr), g, r in zip(meta, got, ref):
+        exp = oracle.search_bm25(pruned.corpus, terms, k, total_hits_threshold=thr)
+        name = f"{terms}_k{k}_thr{thr}"
+        check(name, g, exp, k, thr)
+        check(name + "_plain", r, exp, k, thr)
+        assert r.total_hits == exp[2]   # the exhaustive route always counts exactly
+
+
+def test_boosts_and_paging(ctxs, mid, oracle):
+    pruned, _ = mid
+    terms, boosts = [2, 40, 333, 5000], [0.5, 2.0, 1.0, 3.0]
+    k = 50
+    exp_all = oracle.search_bm25(pruned.corpus, terms, 200, boosts=boosts, total_hits_threshold=1000)
+    after = None
+    seen = []
+    for page in range(4):
+        mgr = api.TopScoreDocCollectorManager(k, after=after, total_hits_threshold=1000)
+        got = pruned.searcher.search(bq(terms, boosts), mgr)
+        lo = page * k
+        assert got.docs.tolist() == exp_all[0][lo: lo + k].tolist(), f"page {page}"
+        assert got.scores.view(np.uint32).tolist() == exp_all[1][lo: lo + k].view(np.uint32).tolist()
+        assert got.relation_gte
+        seen += got.docs.tolist()
+        after = api.ScoreDoc(int(got.docs[-1]), float(got.scores[-1]))
+    assert len(set(seen)) == 4 * k
+
+
+def test_route_is_taken_only_when_the_count_certainly_passes_the_threshold(ctxs, mid, oracle):
+    pruned, _ = mid
+    ctx = ctxs[0]
+    # rank 9999: ~30 postings in 300k docs -- never more than the threshold: exhaustive, exact count
+    ctx.reset_stats()
+    got = pruned.searcher.search(bq([9999, 5000]), api.TopScoreDocCollectorManager(10))
+    exp = oracle.search_bm25(pruned.corpus, [9999, 5000], 10, total_hits_threshold=1000)
+    assert ctx.stats()["maxscore_items"] == 0 and got.total_hits == exp[2] and not got.relation_gte
+    # ScoreMode.COMPLETE (threshold INT_MAX): exhaustive, exact count
+    ctx.reset_stats()
+    got = pruned.searcher.search(bq([1, 100]), api.TopScoreDocCollectorManager(10, total_hits_threshold=INT_MAX))
+    exp = oracle.search_bm25(pruned.corpus, [1, 100], 10, total_hits_threshold=INT_MAX)
+    assert ctx.stats()["maxscore_items"] == 0 and got.total_hits == exp[2] and not got.relation_gte
+    # a dense clause: certainly more than 1000 live matches
+    ctx.reset_stats()
+    got = pruned.searcher.search(bq([1, 100]), api.TopScoreDocCollectorManager(10))
+    assert ctx.stats()["maxscore_items"] > 0 and got.relation_gte and got.total_hits > 1000
+
+
+def test_larger_index_c3_shaped_queries(ctxs, oracle):
+    qr = synth.make_queries(96, 5, 10000)
+    corpus = synth.build_corpus(2_000_000, sorted(set(int(r) for r in qr.reshape(-1))), n_segments=6)
+    ix = Index(ctxs[0], corpus)
+    try:
+        k = 1000
+        ctxs[0].reset_stats()
+        got = ix.searcher.search_batch([bq(r) for r in qr], [api.TopScoreDocCollectorManager(k)] * len(qr))
+        assert ctxs[0].stats()["maxscore_items"] >= len(qr) - 2
+        for qi in range(len(qr)):
+            exp = oracle.search_bm25(corpus, qr[qi].tolist(), k, total_hits_threshold=1000)
+            check(f"c3_{qi}", got[qi], exp, k, 1000)
+        # one query at a time: the query is cut into many work items that share theta
+        for qi in range(0, 24):
+            one = ix.searcher.search(bq(qr[qi]), api.TopScoreDocCollectorManager(k))
+            assert one.docs.tolist() == got[qi].docs.tolist()
+            assert one.scores.view(np.uint32).tolist() == got[qi].scores.view(np.uint32).tolist()
+            assert one.relation_gte
+    finally:
+        ix.close()
