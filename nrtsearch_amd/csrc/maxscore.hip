@@ -43,11 +43,27 @@ namespace nrtgpu {
 
 constexpr int kMsWinWords = kMsWinDocs / 32;
 
+// What a lane needs to stream or look up one clause of the wave's current part / window (wave-private LDS table,
+// written by lane c for clause c): lanes of one instruction may work for different clauses.
+struct alignas(16) WClause {
+  uint64_t docids, fnorm;   // column bases
+  uint64_t begin, end;      // postings of the clause inside the window (absolute indices into the columns)
+  float    weight;
+  int32_t  fx_scale;
+  uint32_t flags;           // score table (0-2, 7 = none) | fx_shift << 4 | normInverse table << 8 | cell shift << 16
+  uint32_t pad;
+  uint64_t u_after;         // what the later clauses can add at most: S_{c+1}
+  uint64_t bits;            // membership + rank records, 0 = sparse clause
+  uint64_t cells, start;    // cell table, first posting of the term in the columns
+};
+static_assert(sizeof(WClause) == 80, "WClause layout");
+
 struct MsSmem {
   uint64_t cand[kMsCandCap];               // competitive hits of the item (packed keys), unordered
   uint32_t tab[kTabTerms][kTabEntries];    // fixed-point BM25 score of (freq, norm byte) for the item's densest terms
   float    cache[kLdsCaches][256];         // BM25 normInverse tables of the query's fields (division path, bounds)
   uint32_t seen[kMsWaves][kMsWinWords];    // per wave: docs of its window that have been evaluated
+  WClause  wc[kMsWaves][kMsMaxTerms];      // per wave: the clauses of its part / window
   TopkScratch sc;
   uint64_t theta;        // packed key of the k-th best hit seen so far (0 = none)
   uint64_t thr;          // acc_threshold(theta): what running sums are compared with
@@ -202,14 +218,15 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   __syncthreads();  // from here on the waves run on their own
 
   uint32_t* const seen = &s.seen[wave][0];
+  WClause* const wcl = &s.wc[wave][0];
+  const uint32_t wcl_addr = lds_addr(wcl);
   uint32_t wave_hits = 0;
   uint64_t pc_post = 0, pc_surv = 0, pc_look = 0, pc_cand = 0, pc_chunks = 0, pc_wins = 0;
   uint32_t g = wave;      // my current window (flattened over the item's parts)
   uint32_t pi = 0;        // its part ...
   uint32_t win_base = 0;  // ... and the windows of the parts before that one
-  bool work = true;
 
-  while (work) {
+  for (;;) {
     // ---- the part that holds window g
     DPart part;
     uint32_t part_wins = 0;
@@ -221,10 +238,11 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       win_base += part_wins;
     }
     if (pi >= item.n_parts) break;
-    const uint32_t n_terms = part.n_terms;
+    const uint32_t n_terms = part.n_terms;  // <= kMsMaxTerms (planner)
     const DTerm* const part_terms = terms + part.term_begin;
 
-    // ---- per part: lane l looks after clause l: its exact maximum score in this segment, suffix sums
+    // ---- per part: lane l looks after clause l: its exact maximum score in this segment, suffix sums, and the
+    //      clause's record in the wave's LDS table (what a lane needs to stream or look up clause l)
     uint64_t my_ub = 0, my_suf = 0;
     for (uint32_t t = 0; t < n_terms; ++t) {  // uniform
       const DTerm T = part_terms[t];
@@ -250,6 +268,21 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
     const uint32_t my_shift = mt.shift;
+    if (lane < n_terms) {
+      WClause w;
+      w.docids = (uint64_t)mt.docids;
+      w.fnorm = (uint64_t)mt.fnorm;
+      w.begin = w.end = 0;
+      w.weight = mt.weight;
+      w.fx_scale = mt.fx_scale;
+      w.flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
+      w.pad = 0;
+      w.u_after = my_suf - my_ub;
+      w.bits = (uint64_t)mt.aux->bits;
+      w.cells = (uint64_t)mt.cell_off;
+      w.start = mt.start;
+      wcl[lane] = w;
+    }
 
     for (;;) {  // windows of this part
       const uint32_t t0 = part.tile_begin + (g - win_base) * (uint32_t)kMsWinTiles;
@@ -257,6 +290,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       const uint32_t doc_lo = t0 * (uint32_t)kTileDocs;
       const uint32_t doc_span = min(t1 * (uint32_t)kTileDocs, part.max_doc) - doc_lo;
       if (PROF) pc_wins += 1;
+      // my next window: taken now, so that the counter's answer is there when this one is done
+      uint32_t g_new = 0;
+      if (lane == 0) g_new = atomicAdd(&s.next_win, 1u);
       // theta of the query's other items (LazyMaxScoreAccumulator analogue), once per window
       uint64_t theta_other = 0, thr_other = 0;
       if (multi_item) {
@@ -273,197 +309,260 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
 #pragma unroll
         for (int j = 0; j < kMsWinWords / 64 / 4; ++j) *(u32x4*)&seen[(lane + 64u * (uint32_t)j) * 4u] = u32x4{0u, 0u, 0u, 0u};
       }
-
-      for (uint32_t i = 0; i < n_terms; ++i) {  // clauses, rarest first
-        const uint64_t S_i = readlane_u64(my_suf, i);
-        const uint64_t U_after = S_i - readlane_u64(my_ub, i);
-        if (S_i < max(s.thr, thr_other)) break;  // this and the remaining clauses are non-essential here
-        const DTerm T = part_terms[i];
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)i);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)my_hi, (int)i);
-        if (hi <= lo) continue;
-        const uint64_t p_begin = T.start + lo, p_end = T.start + hi;
-        const uint64_t p_al = p_begin & ~3ull;  // 16-byte groups
-
-        for (uint64_t cbase = p_al; cbase < p_end; cbase += 512u) {  // chunks of 512 postings: 8 per lane
-          if (PROF) pc_chunks += 1;
-          const uint64_t mine0 = cbase + (uint64_t)lane * 8u;
-          uint32_t d[8], c[8];
+      // The essential clauses of the window -- S_c >= theta, a prefix of the order -- are streamed as ONE sequence of
+      // 8-posting groups (16-byte aligned in the columns): a lane takes one group, so sparse clauses share an
+      // instruction instead of taking one each.  Clause c's groups come before clause c + 1's.
+      uint32_t ng = 0;
+      {
+        const uint64_t thr_w = max(s.thr, thr_other);
+        const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
+        if (lane < n_terms) {
+          if (my_suf >= thr_w && pe > pb) ng = (uint32_t)((pe - (pb & ~3ull) + 7ull) >> 3);
+          *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)pe, (uint32_t)(pe >> 32)};
+        }
+      }
+      const uint32_t incl = scan32_dpp(ng);
+      uint32_t pre[kMsMaxTerms];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) d[j] = c[j] = 0u;
-          if (mine0 < p_end) {  // (the columns are padded: a partly valid lane may read past the term)
-            const u32x4 d0 = __builtin_nontemporal_load((gvec_ptr)(T.docids + mine0));
-            const u32x4 d1 = __builtin_nontemporal_load((gvec_ptr)(T.docids + mine0) + 1);
-            const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(T.fnorm + mine0));
-            const u32x4 c1 = __builtin_nontemporal_load((gvec_ptr)(T.fnorm + mine0) + 1);
+      for (int i = 0; i < kMsMaxTerms; ++i) pre[i] = (uint32_t)__builtin_amdgcn_readlane((int)incl, i);
+      const uint32_t n_groups = pre[kMsMaxTerms - 1];
+
+      for (uint32_t v0 = 0; v0 < n_groups; v0 += 64u) {  // 64 groups = up to 512 postings per instruction
+        const uint32_t v = v0 + lane;
+        const bool act = v < n_groups;
+        uint32_t c = 0, before = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              d[j] = d0[j]; d[4 + j] = d1[j];
-              c[j] = c0[j]; c[4 + j] = c1[j];
+        for (int i = 0; i < kMsMaxTerms - 1; ++i) {
+          c += (v >= pre[i]) ? 1u : 0u;
+          before = (v >= pre[i]) ? pre[i] : before;
+        }
+        const uint32_t c_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        // theta as of now (it only grows: a stale value costs work, never a result).  Has it passed what this
+        // instruction's first clause and everything after it can reach?  Then the rest of the window is non-essential.
+        const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
+        if (readlane_u64(my_suf, c_first) < thr) break;
+        if (PROF) pc_chunks += 1;
+        // what my clause is: column bases, posting range, score table, scale, what the later clauses can still add
+        const uint32_t rec = wcl_addr + c * (uint32_t)sizeof(WClause);
+        const u32x4 r0 = *(const u32x4*)lds_ptr(rec), r1 = *(const u32x4*)lds_ptr(rec + 16u), r2 = *(const u32x4*)lds_ptr(rec + 32u);
+        const uint64_t u_after = *(const uint64_t*)lds_ptr(rec + 48u);
+        const uint64_t col_d = ((uint64_t)r0[1] << 32) | r0[0], col_c = ((uint64_t)r0[3] << 32) | r0[2];
+        const uint64_t p_begin = ((uint64_t)r1[1] << 32) | r1[0], p_end = ((uint64_t)r1[3] << 32) | r1[2];
+        const uint32_t flags = r2[2];
+        const uint64_t mine0 = (p_begin & ~3ull) + (uint64_t)(v - before) * 8u;
+        uint32_t d[8], cd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = cd[j] = 0u;
+        if (act) {  // (the columns are padded: a partly valid group may read past the term)
+          const u32x4 d0 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u));
+          const u32x4 d1 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u) + 1);
+          const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u));
+          const u32x4 c1 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u) + 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            d[j] = d0[j]; d[4 + j] = d1[j];
+            cd[j] = c0[j]; cd[4 + j] = c1[j];
+          }
+        }
+        uint32_t vmask = 0;  // my postings inside the clause's range and the window
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint64_t p = mine0 + (uint64_t)j;
+          if (act && p >= p_begin && p < p_end && d[j] - doc_lo < doc_span) vmask |= 1u << j;
+        }
+        // the values my postings add: per-lane table (lanes of one instruction may belong to different clauses)
+        uint32_t val[8];
+        {
+          const uint32_t tab = flags & 7u;
+          const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
+          uint32_t cor = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            val[j] = *(const uint32_t*)(tb + (cd[j] & 0x1FFCu));
+            cor |= ((vmask >> j) & 1u) ? cd[j] : 0u;
+          }
+          const bool special = vmask != 0u && ((cor >> 31) != 0u || tab == 7u);
+          if (__any(special)) {  // long docs / high freqs / clauses without a score table
+            const float w = __uint_as_float(r2[0]);
+            const int fx_scale = (int)r2[1];
+            const float* cache = &s.cache[(flags >> 8) & 255u][0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const uint32_t cj = cd[j];
+              const bool esc = (cj >> 31) != 0u;
+              const uint32_t f = esc ? ((cj >> 8) & 0x3FFFFFu) : ((cj >> 9) & 15u);
+              const bool dead = esc ? ((cj >> 30) & 1u) != 0u : (cj >> 20) != 0u;
+              const uint32_t nb = esc ? (cj & 255u) : ((cj >> 2) & 127u);
+              if (((vmask >> j) & 1u) && (esc || tab == 7u))
+                val[j] = dead ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
             }
           }
-          uint32_t vmask = 0;  // my postings inside the clause's range and the window
+        }
+        uint64_t run[8];
+        uint32_t alive = 0;
+        {
+          const uint32_t sh = (flags >> 4) & 15u;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const uint64_t p = mine0 + (uint64_t)j;
-            if (p >= p_begin && p < p_end && d[j] - doc_lo < doc_span) vmask |= 1u << j;
+            run[j] = (uint64_t)val[j] << sh;
+            if (((vmask >> j) & 1u) && val[j] != 0u && run[j] + u_after >= thr) alive |= 1u << j;
           }
-          uint32_t val[8];
-          values_of_codes(s, c, vmask, T.tab_slot, T.weight, T.fx_scale, T.cache_slot, val);
-          // theta as of now (it only grows: a stale value costs work, never a result)
-          const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
-          uint64_t run[8];
-          uint32_t alive = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            run[j] = (uint64_t)val[j] << T.fx_shift;
-            if (((vmask >> j) & 1u) && val[j] != 0u && run[j] + U_after >= thr) alive |= 1u << j;
-          }
-          if (PROF) {
-            pc_post += (uint64_t)__popc(vmask);
-            pc_surv += (uint64_t)__popc(alive);
-          }
-          // first clause to reach the doc?  (test-and-set; lanes without a survivor OR a zero into a word of theirs)
-          if (n_terms > 1u && __any(alive != 0u)) {
+        }
+        if (PROF) {
+          pc_post += (uint64_t)__popc(vmask);
+          pc_surv += (uint64_t)__popc(alive);
+        }
+        // first clause to reach the doc?  Test-and-set, clause by clause in order: LDS executes a wave's operations
+        // in order, so of two postings of one doc in this instruction the earlier clause's wins.  (Lanes without a
+        // survivor OR a zero into a word of their own.)
+        const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)(min(n_groups - v0, 64u) - 1u));
+        if (n_terms > 1u && __any(alive != 0u)) {
+          for (uint32_t cc = c_first; cc <= c_last; ++cc) {
+            const uint32_t am = c == cc ? alive : 0u;
+            if (!__any(am != 0u)) continue;
             uint32_t old[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const bool a = (alive >> j) & 1u;
+              const bool a = (am >> j) & 1u;
               const uint32_t w = a ? ((d[j] - doc_lo) >> 5) : lane;
               old[j] = atomicOr(&seen[w], a ? (1u << (d[j] & 31u)) : 0u);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if ((old[j] >> (d[j] & 31u)) & 1u) alive &= ~(1u << j);
+              if (((am >> j) & 1u) && ((old[j] >> (d[j] & 31u)) & 1u)) alive &= ~(1u << j);
           }
-          {
-            uint32_t h = (uint32_t)__popc(alive);
-            h = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(h), 63);
-            wave_hits += h;
-            if (PROF) pc_look += 0;
-          }
-
-          // ---- the later clauses of the surviving docs, one clause at a time
-          for (uint32_t j2 = i + 1u; j2 < n_terms; ++j2) {
-            const uint64_t S_j = readlane_u64(my_suf, j2);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (run[j] + S_j < thr) alive &= ~(1u << j);
-            if (!__any(alive != 0u)) break;
-            if (PROF) pc_look += (uint64_t)__popc(alive);
-            const DTerm T2 = part_terms[j2];
-            const void* const bits2 = T2.aux->bits;
-            uint32_t c2[8];
-            uint32_t present = 0;
-            if (bits2 != nullptr) {
-              // dense clause: one 16-byte record per 64 docs says whether the doc is there and where its posting is
-              const gvec_ptr recs = (gvec_ptr)bits2;
-              u32x4 r[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) r[j] = recs[((alive >> j) & 1u) ? (d[j] >> 6) : 0u];
-              uint32_t idx[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const uint32_t b = d[j] & 63u;
-                const uint32_t w0 = r[j][0], w1 = r[j][1];
-                const uint32_t word = b < 32u ? w0 : w1;
-                const bool there = ((alive >> j) & 1u) && ((word >> (b & 31u)) & 1u);
-                const uint32_t m0 = b < 32u ? (w0 & ((1u << b) - 1u)) : w0;
-                const uint32_t m1 = b < 32u ? 0u : (w1 & ((1u << (b - 32u)) - 1u));
-                idx[j] = there ? r[j][2] + (uint32_t)__popc(m0) + (uint32_t)__popc(m1) : 0u;
-                present |= (there ? 1u : 0u) << j;
-              }
-              const gu32_ptr codes = (gu32_ptr)(T2.fnorm + T2.start);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) c2[j] = codes[idx[j]];
-            } else {
-              // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
-              // lane advance in lockstep, so every step is one round of loads in flight instead of eight
-              const gu32_ptr cells2 = (gu32_ptr)T2.cell_off;
-              const gu32_ptr docs2 = (gu32_ptr)(T2.docids + T2.start);
-              const gu32_ptr codes2 = (gu32_ptr)(T2.fnorm + T2.start);
-              uint32_t a[8], b[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const uint32_t cell = ((alive >> j) & 1u) ? ((d[j] >> 10) >> T2.shift) : 0u;
-                a[j] = cells2[cell];
-                b[j] = cells2[cell + 1u];
-              }
-              uint32_t open = 0;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                if (!((alive >> j) & 1u)) b[j] = a[j];
-                open |= (a[j] < b[j] ? 1u : 0u) << j;
-              }
-              while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
-                uint32_t mid[8], v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  mid[j] = (a[j] + b[j]) >> 1;
-                  v[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                  if ((open >> j) & 1u) {
-                    if (v[j] < d[j]) a[j] = mid[j] + 1u;
-                    else b[j] = mid[j];
-                    if (v[j] == d[j]) {  // found: close the search on it
-                      a[j] = b[j] = mid[j];
-                      present |= 1u << j;
-                    }
-                    if (!(a[j] < b[j])) open &= ~(1u << j);
-                  }
-              }
-#pragma unroll
-              for (int j = 0; j < 8; ++j) c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];
-            }
-            if (__any(present != 0u)) {
-              uint32_t v2[8];
-              values_of_codes(s, c2, present, T2.tab_slot, T2.weight, T2.fx_scale, T2.cache_slot, v2);
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if ((present >> j) & 1u) run[j] += (uint64_t)v2[j] << T2.fx_shift;
-            }
-          }
-
-          // ---- complete scores: the competitive ones go to the shared candidate buffer
-          uint32_t cmask = 0;
-          if (__any(alive != 0u)) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (((alive >> j) & 1u) && run[j] >= thr) {
-                const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
-                if (key > theta && key < after_key) cmask |= 1u << j;
-              }
-          }
-          while (__any(cmask != 0u)) {
-            uint32_t pos = 0;
-            if (ms_reserve(s, lane, (uint32_t)__popc(cmask), pos)) {  // wave-uniform
-              if (PROF) pc_cand += (uint64_t)__popc(cmask);
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                if ((cmask >> j) & 1u)
-                  s.cand[pos++] = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
-              break;
-            }
-            // no room: everybody meets, the k best stay, theta rises; then retry with what is still competitive
-            (void)ms_meet(s, k, fx_E, my_theta_g);
-            const uint64_t th2 = s.theta;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if ((cmask >> j) & 1u) {
-                const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
-                if (!(key > th2)) cmask &= ~(1u << j);
-              }
-          }
-          // somebody else asked for a compaction: join it between two chunks
-          if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) (void)ms_meet(s, k, fx_E, my_theta_g);
         }
+        {
+          uint32_t h = (uint32_t)__popc(alive);
+          h = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(h), 63);
+          wave_hits += h;
+        }
+
+        // ---- the later clauses of the surviving docs, one clause at a time (a lane of clause c takes part from c + 1 on)
+        for (uint32_t j2 = c_first + 1u; j2 < n_terms; ++j2) {
+          if (!__any(alive != 0u)) break;
+          const uint64_t S_j = readlane_u64(my_suf, j2);
+          uint32_t am = c < j2 ? alive : 0u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (((am >> j) & 1u) && run[j] + S_j < thr) {
+              alive &= ~(1u << j);
+              am &= ~(1u << j);
+            }
+          if (!__any(am != 0u)) continue;
+          if (PROF) pc_look += (uint64_t)__popc(am);
+          const WClause& w2 = wcl[j2];  // uniform reads
+          const uint64_t bits2 = w2.bits;
+          const uint32_t flags2 = w2.flags;
+          const gu32_ptr codes2 = (gu32_ptr)(w2.fnorm + w2.start * 4u);
+          uint32_t c2[8];
+          uint32_t present = 0;
+          if (bits2 != 0ull) {
+            // dense clause: one 16-byte record per 64 docs says whether the doc is there and where its posting is
+            const gvec_ptr recs = (gvec_ptr)bits2;
+            u32x4 r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 6) : 0u];
+            uint32_t idx[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const uint32_t bb = d[j] & 63u;
+              const uint32_t w0 = r[j][0], w1 = r[j][1];
+              const uint32_t word = bb < 32u ? w0 : w1;
+              const bool there = ((am >> j) & 1u) && ((word >> (bb & 31u)) & 1u);
+              const uint32_t m0 = bb < 32u ? (w0 & ((1u << bb) - 1u)) : w0;
+              const uint32_t m1 = bb < 32u ? 0u : (w1 & ((1u << (bb - 32u)) - 1u));
+              idx[j] = there ? r[j][2] + (uint32_t)__popc(m0) + (uint32_t)__popc(m1) : 0u;
+              present |= (there ? 1u : 0u) << j;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c2[j] = codes2[idx[j]];
+          } else {
+            // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
+            // lane advance in lockstep, so every step is one round of loads in flight instead of eight
+            const gu32_ptr cells2 = (gu32_ptr)w2.cells;
+            const gu32_ptr docs2 = (gu32_ptr)(w2.docids + w2.start * 4u);
+            const uint32_t cshift = flags2 >> 16;
+            uint32_t a[8], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const uint32_t cell = ((am >> j) & 1u) ? ((d[j] >> 10) >> cshift) : 0u;
+              a[j] = cells2[cell];
+              b[j] = cells2[cell + 1u];
+            }
+            uint32_t open = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (!((am >> j) & 1u)) b[j] = a[j];
+              open |= (a[j] < b[j] ? 1u : 0u) << j;
+            }
+            while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
+              uint32_t mid[8], vv[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                mid[j] = (a[j] + b[j]) >> 1;
+                vv[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if ((open >> j) & 1u) {
+                  if (vv[j] < d[j]) a[j] = mid[j] + 1u;
+                  else b[j] = mid[j];
+                  if (vv[j] == d[j]) {  // found: close the search on it
+                    a[j] = b[j] = mid[j];
+                    present |= 1u << j;
+                  }
+                  if (!(a[j] < b[j])) open &= ~(1u << j);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];
+          }
+          if (__any(present != 0u)) {
+            uint32_t v2[8];
+            values_of_codes(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, v2);
+            const uint32_t sh2 = (flags2 >> 4) & 15u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if ((present >> j) & 1u) run[j] += (uint64_t)v2[j] << sh2;
+          }
+        }
+
+        // ---- complete scores: the competitive ones go to the shared candidate buffer
+        uint32_t cmask = 0;
+        if (__any(alive != 0u)) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (((alive >> j) & 1u) && run[j] >= thr) {
+              const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
+              if (key > theta && key < after_key) cmask |= 1u << j;
+            }
+        }
+        while (__any(cmask != 0u)) {
+          uint32_t pos = 0;
+          if (ms_reserve(s, lane, (uint32_t)__popc(cmask), pos)) {  // wave-uniform
+            if (PROF) pc_cand += (uint64_t)__popc(cmask);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if ((cmask >> j) & 1u)
+                s.cand[pos++] = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
+            break;
+          }
+          // no room: everybody meets, the k best stay, theta rises; then retry with what is still competitive
+          (void)ms_meet(s, k, fx_E, my_theta_g);
+          const uint64_t th2 = s.theta;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if ((cmask >> j) & 1u) {
+              const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
+              if (!(key > th2)) cmask &= ~(1u << j);
+            }
+        }
+        // somebody else asked for a compaction: join it between two instructions
+        if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) (void)ms_meet(s, k, fx_E, my_theta_g);
       }
 
       // ---- next window
-      uint32_t g_new = 0;
-      if (lane == 0) g_new = atomicAdd(&s.next_win, 1u);
       g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
       if (g >= win_base + part_wins) break;  // a later part (or past the item)
     }

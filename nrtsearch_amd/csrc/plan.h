@@ -68,13 +68,17 @@ struct alignas(16) DTermAux {
 };
 static_assert(sizeof(DTermAux) == 32, "DTermAux layout");
 
-// Workgroup shape of the MaxScore route: 16 autonomous waves; a wave owns a window of kMsWinTiles sub-tiles at a
-// time (its docs' "already evaluated" bits: kMsWinDocs / 8 bytes of LDS).
+// Workgroup shape of the MaxScore route: 12 autonomous waves (168 VGPRs each); a wave owns a window of kMsWinTiles
+// sub-tiles at a time (its docs' "already evaluated" bits: kMsWinDocs / 8 bytes of LDS).
+#ifndef NRT_MS_WIN_TILES
+#define NRT_MS_WIN_TILES 64
+#endif
 constexpr int kMsWaves = 12;
 constexpr int kMsThreads = kMsWaves * 64;
-constexpr int kMsWinTiles = 32;
+constexpr int kMsWinTiles = NRT_MS_WIN_TILES;
 constexpr int kMsWinDocs = kMsWinTiles * kTileDocs;
-constexpr int kMsCandCap = 3072;    // LDS candidate slots of the MaxScore route (>= kMaxK + 512: a wave's retry always fits)
+constexpr int kMsMaxTerms = 8;      // clauses of a query on the MaxScore route (longer disjunctions are scanned exhaustively)
+constexpr int kMsCandCap = kMsWinTiles > 32 ? 2304 : 3072;  // LDS candidate slots (>= kMaxK + 512: a wave's retry always fits)
 // item_hits of a MaxScore item: the docs it evaluated, plus kHitsPrunedUnit when it skipped anything (the count is
 // then a lower bound).  The merge kernel's plain sum keeps both: low 48 bits = docs, high 16 = pruned items.
 constexpr uint64_t kHitsPrunedUnit = 1ull << 48;

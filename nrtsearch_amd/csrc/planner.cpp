@@ -126,7 +126,7 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
     // after discounting every deleted doc of its segments.  Needs the exact fixed-point sums, plain liveDocs
     // (folded into the columns) and a plain disjunction.
     int64_t lower = 0;
-    if (allow_prune && fx_ok && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
+    if (allow_prune && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
         !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
       bool plain = true;
       for (int si = 0; si < n_segs && plain; ++si) plain = segs[si]->d_live == nullptr || segs[si]->live_folded;

@@ -151,8 +151,8 @@ static inline int32_t relation_gte(int64_t total_hits, int32_t n_hits, int32_t k
 
 // `hits` as the merge leaves it: low 48 bits = docs counted, high 16 = items of the query that skipped docs on the
 // MaxScore route (plan.h: kHitsPrunedUnit).  With none the count is exact and the relation follows from it; else the
-// count is a lower bound, reported together with `lower` -- the live docs the planner knew to match, more than the
-// threshold -- as GREATER_THAN_OR_EQUAL_TO, which is what the reference reports once its collectors have started
+// count is a lower bound and what is reported is `lower` -- the live docs the planner knew to match, more than the
+// threshold, the same on every run -- as GREATER_THAN_OR_EQUAL_TO, which is what the reference reports once its collectors have started
 // skipping (the value itself is an artefact of the traversal there as well, SURVEY 7 hard part 3).
 static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, const int32_t k, const int32_t threshold,
                            int64_t lower, nrtgpu_topdocs* out) {
@@ -166,7 +166,7 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
   out->n_hits = m;
   const int64_t counted = (int64_t)(hits & (kHitsPrunedUnit - 1));
   if ((hits >> 48) != 0) {
-    out->total_hits = std::max(counted, lower);
+    out->total_hits = lower;  // (not max(counted, lower): how many docs were evaluated depends on the order theta grew in)
     out->total_hits_is_lower_bound = 1;
   } else {
     out->total_hits = counted;

@@ -122,7 +122,8 @@ def test_exchange_table_written_and_honoured():
                 n = int(cc[qi])
                 docs = (np.uint64(0xFFFFFFFF) - (kk[qi, :n] & np.uint64(0xFFFFFFFF))).astype(np.int32)
                 scores = (kk[qi, :n] >> np.uint64(32)).astype(np.uint32).view(np.float32)
-                assert hh[qi] == plain[qi].total_hits
+                # (the device-resident entry point counts exactly; the plain search may have pruned: a lower bound)
+                assert hh[qi] >= plain[qi].total_hits if plain[qi].relation_gte else hh[qi] == plain[qi].total_hits
                 if not tag_ok:
                     assert docs.tolist() == plain[qi].docs.tolist()
                     continue

@@ -37,7 +37,8 @@ def test_full_size_oracle_parity(c3, oracle):
         got = c3["res"][qi]
         assert got.docs.tolist() == docs.tolist()
         assert got.scores.view(np.uint32).tolist() == scores.view(np.uint32).tolist()
-        assert got.total_hits == total and got.relation_gte == gte
+        assert got.relation_gte == gte
+        assert (c3["w"].k < got.total_hits <= total) if gte else got.total_hits == total   # pruned: a lower bound
 
 
 def test_full_size_ordering_and_counts(c3):
@@ -61,7 +62,7 @@ def test_full_size_idempotent_and_chunking_invariant(c3):
         for other in (b, c):
             assert a.docs.tolist() == other.docs.tolist()
             assert a.scores.view(np.uint32).tolist() == other.scores.view(np.uint32).tolist()
-            assert a.total_hits == other.total_hits
+            assert a.relation_gte == other.relation_gte and (a.relation_gte or a.total_hits == other.total_hits)
     for l in leaves:
         l.release()
     c2.close()
@@ -78,4 +79,5 @@ def test_full_size_merge_of_segments_equals_whole(c3, oracle):
         docs, scores = oracle.topdocs_merge(c3["w"].k, [(r[qi].docs, r[qi].scores) for r in per_leaf])
         assert docs.tolist() == c3["res"][qi].docs.tolist()
         assert scores.view(np.uint32).tolist() == c3["res"][qi].scores.view(np.uint32).tolist()
-        assert sum(r[qi].total_hits for r in per_leaf) == c3["res"][qi].total_hits
+        whole = c3["res"][qi]   # (pruned searches report lower bounds: the sum of the leaves' is one as well, not the same one)
+        assert whole.relation_gte or sum(r[qi].total_hits for r in per_leaf) == whole.total_hits

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from nrtsearch_amd import api, synth
+from tests.test_parity_gpu import total_ok
 
 pytestmark = pytest.mark.gpu
 VEC_FIELD, DIM = 7, 64
@@ -69,7 +70,7 @@ def test_fused_tail_equals_two_calls(hybrid, oracle):
         second = float(oracle.vector_score(0, q, hybrid["vecs"][si][doc - bases[si]]))
         exp.append((float(oracle.rescore_combine(f, True, second, 1.0, 3.0)), doc))
     exp.sort(key=lambda t: (-t[0], t[1]))
-    assert got.total_hits == etotal and len(got.docs) == 50
+    assert 1000 < got.total_hits <= etotal and got.relation_gte and len(got.docs) == 50   # (pruned first pass: a lower bound)
     assert np.allclose(got.scores, [s for s, _ in exp[:50]], rtol=1e-5, atol=1e-6)
     assert len(set(got.docs.tolist()) & set(d for _, d in exp[:50])) >= 49
 
@@ -140,7 +141,7 @@ def test_concurrent_batch_calls_from_many_threads(hybrid, oracle):
                 for i, r in zip(order, res):
                     ed, es, et, eg = expected[i]
                     if (r.docs.tolist() != ed.tolist() or r.scores.view(np.uint32).tolist() != es.view(np.uint32).tolist()
-                            or r.total_hits != et or r.relation_gte != eg):
+                            or not total_ok(r, et, eg, 100, 1000)):
                         errors.append((tix, it, i))
         except Exception as e:  # noqa: BLE001
             errors.append((tix, repr(e)))
@@ -167,7 +168,7 @@ def test_coalesced_single_searches_from_many_threads(hybrid, oracle):
                 r = hybrid["sr"].search_coalesced(_bq(term_sets[i]), api.TopScoreDocCollectorManager(100))
                 ed, es, et, eg = expected[i]
                 if (r.docs.tolist() != ed.tolist() or r.scores.view(np.uint32).tolist() != es.view(np.uint32).tolist()
-                        or r.total_hits != et or r.relation_gte != eg):
+                        or not total_ok(r, et, eg, 100, 1000)):
                     errors.append((tix, it, i))
         except Exception as e:  # noqa: BLE001
             errors.append((tix, repr(e)))

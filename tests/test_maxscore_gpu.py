@@ -65,7 +65,7 @@ def mid(ctxs):
 
 
 SHAPES = [[1], [100], [5000], [1, 2], [1, 9999], [333, 1000], [5, 40, 1000], [1, 2, 3, 5, 8], [13, 40, 100, 333, 1000],
-          [1, 100, 1000, 5000, 9999], [2, 3, 5000], [1, 2, 3, 5, 8, 13, 40, 100, 333, 1000, 5000, 9999], [8, 8, 40],
+          [1, 100, 1000, 5000, 9999], [2, 3, 5000], [1, 2, 3, 5, 8, 13, 40, 100, 333, 1000, 5000, 9999], [2, 5, 13, 40, 100, 333, 1000, 9999], [8, 8, 40],
           [9999, 5000], [3, 13, 333, 9999]]
 
 
