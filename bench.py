@@ -45,8 +45,11 @@ def parse_args():
     ap.add_argument("--no-prefetch", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exchange", action="store_true",
-                    help="N>1: do not share score bounds between the GPUs' shards (A/B; results are identical)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N>1: share score bounds between the GPUs' shards (nrtgpu_exchange_open); the shards then run the "
+                         "exhaustive scan, which takes part in the exchange, instead of pruning on their own (A/B; results are identical)")
+    ap.add_argument("--no-prune", action="store_true",
+                    help="A/B: exhaustive scan only (NRTGPU_FLAG_NO_PRUNE): every posting of every query term is streamed")
     ap.add_argument("--debug-same-gpu", action="store_true",
                     help="debug: run an N-rank job with every rank on GPU 0 (gloo, collectives staged through the host)")
     ap.add_argument("--all-to-all", action="store_true",
@@ -169,7 +172,7 @@ def main():
     corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank)
     t_build = time.perf_counter() - t_build
 
-    flags = _lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0
+    flags = (_lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0) | (_lib.NRTGPU_FLAG_NO_PRUNE if args.no_prune else 0)
     # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
     # (the node's ranks share the host; 4 is the library's default and enough at one rank)
     planner_threads = max(1, min(4, usable_cpus() // max(1, world * max(1, args.host_threads))))
@@ -185,7 +188,7 @@ def main():
     k_stride = (w.k + 15) // 16 * 16
     use_dist = world > 1 or args.force_dist
     exchange_name = None
-    if world > 1 and not args.no_exchange:
+    if world > 1 and args.exchange:
         # cross-GPU bound exchange (include/nrtgpu.h): one shared-memory table per job, opened by every rank
         import uuid
         box = [f"/nrtgpu_bench_{uuid.uuid4().hex[:16]}" if rank == 0 else None]
@@ -308,19 +311,26 @@ def main():
     st = ctx.stats()
     n_q = args.steps * B
     qps = n_q / elapsed
-    # dominant kernel: bm25_scan_kernel.  achieved = algorithmic bytes per launch / avg launch time,
-    # measured with HIP events on the library's own stream (collect_timing).
-    launches = max(1, st["scan_launches"])
-    scan_ms = st["scan_ms"] / launches
-    bytes_per_launch = st["scan_postings"] / launches * BYTES_PER_POSTING
+    # Dominant kernel: whichever of the two scorers took more device time -- bm25_maxscore_kernel (dynamic pruning;
+    # the default for this workload) or bm25_scan_kernel (exhaustive).  achieved = algorithmic bytes per launch / avg
+    # launch time, measured with HIP events on the library's own stream (collect_timing).  Algorithmic bytes = 9 B x the
+    # postings of the launch's query terms (the exhaustive-scan figure also normalises a pruned run, whose
+    # "effective" rate may therefore exceed the peak; the physical rate = PMC traffic / launch time is reported beside it).
+    pruned = st["maxscore_ms"] > st["scan_ms"]
+    kernel = "bm25_maxscore_kernel" if pruned else "bm25_scan_kernel"
+    launches = max(1, st["maxscore_launches"] if pruned else st["scan_launches"])
+    scan_ms = (st["maxscore_ms"] if pruned else st["scan_ms"]) / launches
+    bytes_per_launch = (st["maxscore_postings"] if pruned else st["scan_postings"]) / launches * BYTES_PER_POSTING
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            rec = json.load(open(pmc))
-            if rec.get("workload") == args.workload and rec.get("batch") == B and world == 1 and shard_world == 1:
-                traffic = rec.get("hbm_bytes_per_launch")
+            recs = json.load(open(pmc))
+            for rec in (recs if isinstance(recs, list) else [recs]):
+                if (rec.get("workload") == args.workload and rec.get("batch") == B and rec.get("kernel") == kernel
+                        and world == 1 and shard_world == 1):
+                    traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -347,20 +357,25 @@ def main():
                         + (", score-bound exchange between shards" if exchange_name else "")
                         + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
-            "scan_items_per_step": st["scan_items"] / max(1, st["batches"]),
+            "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
+            "dynamic_pruning": not args.no_prune,
             "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
             "host_threads": n_thr,
             "corpus_build_s": round(t_build, 1),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "bm25_scan_kernel",
+            "bound": "hbm", "kernel": kernel,
+            "effective": pruned,   # pruned: algorithmic (exhaustive-scan) bytes over the time of a kernel that skips most of them
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "bytes_per_posting": BYTES_PER_POSTING,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "achieved_at_8B_per_posting": round(achieved * BYTES_PER_POSTING_FUSED / BYTES_PER_POSTING, 1),
             "frac_at_8B_per_posting": round(achieved * BYTES_PER_POSTING_FUSED / BYTES_PER_POSTING / HBM_PEAK_GBS, 4),
-            "accumulators": "fixed-point u64" if st.get("fixed_point_launches", 0) == st["scan_launches"] else "fp64",
+            "accumulators": "fixed-point u64" if (pruned or st.get("fixed_point_launches", 0) == st["scan_launches"]) else "fp64",
+            "physical_achieved": round(traffic / (scan_ms * 1e-3) / 1e9, 1) if (traffic and scan_ms > 0) else None,
+            "physical_frac": round(traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and scan_ms > 0) else None,
+            "other_scorer_ms_per_step": round((st["scan_ms"] if pruned else st["maxscore_ms"]) / max(1, st["batches"]), 4),
             "avg_launch_ms": round(scan_ms, 4),
             "merge_ms_per_step": round(st["merge_ms"] / max(1, st["batches"]), 4),
             "host_plan_ms_per_step": round(st["host_plan_ms"] / max(1, st["batches"]), 4),

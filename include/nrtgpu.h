@@ -186,7 +186,9 @@ int  nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us);
  *   d_keys  : n_queries * k_stride uint64 (device), key = (float_bits(score) << 32) | (0xFFFFFFFF - doc),
  *             sorted descending == (score desc, doc asc); unused tail slots are 0
  *   d_counts: n_queries uint32 (device) hits per query
- *   d_hits  : n_queries uint64 (device) exact total hits per query
+ *   d_hits  : n_queries uint64 (device) total hits per query: the exact count, or -- for a query that ran with dynamic
+ *             pruning -- (1 << 48) + a lower bound above totalHitsThreshold; sums of these over shards keep both
+ *             parts, and nrtgpu_merge_topk_device reports such a sum as GREATER_THAN_OR_EQUAL_TO
  * Returns after the work is enqueued AND complete on the library's stream (synchronous). */
 int  nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                      int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,

@@ -1016,6 +1016,18 @@ void apply_live_kernel(const uint32_t* __restrict__ docids, uint32_t* __restrict
   }
 }
 
+// Device-resident results (multi-GPU path): a query that ran on the MaxScore route reports the planner's certain
+// lower bound, tagged as such (plan.h: kHitsPrunedUnit), instead of the number of docs the kernel happened to evaluate.
+__global__ __launch_bounds__(256)
+void patch_hits_kernel(const uint64_t* __restrict__ lower, uint64_t* __restrict__ hits, uint32_t n) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n && lower[q] != 0ull) hits[q] = kHitsPrunedUnit + lower[q];
+}
+void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(patch_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, lower, hits, n);
+}
+
 // ---- launchers (called from the host runtime) ---------------------------------------------------------
 void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fnorm, uint64_t n, const uint64_t* live) {
   if (n == 0) return;

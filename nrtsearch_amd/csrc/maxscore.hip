@@ -42,12 +42,15 @@
 namespace nrtgpu {
 
 constexpr int kMsWinWords = kMsWinDocs / 32;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const NRT_GLOBAL u32x2* gvec2_ptr;
 
 // What a lane needs to stream or look up one clause of the wave's current part / window (wave-private LDS table,
 // written by lane c for clause c): lanes of one instruction may work for different clauses.
 struct alignas(16) WClause {
   uint64_t docids, fnorm;   // column bases
-  uint64_t begin, end;      // postings of the clause inside the window (absolute indices into the columns)
+  uint64_t begin;           // postings of the clause inside the window: first (absolute index into the columns) ...
+  uint32_t count, pad0;     // ... and how many
   float    weight;
   int32_t  fx_scale;
   uint32_t flags;           // score table (0-2, 7 = none) | fx_shift << 4 | normInverse table << 8 | cell shift << 16
@@ -272,7 +275,8 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       WClause w;
       w.docids = (uint64_t)mt.docids;
       w.fnorm = (uint64_t)mt.fnorm;
-      w.begin = w.end = 0;
+      w.begin = 0;
+      w.count = w.pad0 = 0;
       w.weight = mt.weight;
       w.fx_scale = mt.fx_scale;
       w.flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
@@ -318,7 +322,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
         if (lane < n_terms) {
           if (my_suf >= thr_w && pe > pb) ng = (uint32_t)((pe - (pb & ~3ull) + 7ull) >> 3);
-          *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)pe, (uint32_t)(pe >> 32)};
+          *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)(pe - pb), 0u};
         }
       }
       const uint32_t incl = scan32_dpp(ng);
@@ -347,9 +351,10 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         const u32x4 r0 = *(const u32x4*)lds_ptr(rec), r1 = *(const u32x4*)lds_ptr(rec + 16u), r2 = *(const u32x4*)lds_ptr(rec + 32u);
         const uint64_t u_after = *(const uint64_t*)lds_ptr(rec + 48u);
         const uint64_t col_d = ((uint64_t)r0[1] << 32) | r0[0], col_c = ((uint64_t)r0[3] << 32) | r0[2];
-        const uint64_t p_begin = ((uint64_t)r1[1] << 32) | r1[0], p_end = ((uint64_t)r1[3] << 32) | r1[2];
+        const uint64_t p_begin = ((uint64_t)r1[1] << 32) | r1[0];
         const uint32_t flags = r2[2];
-        const uint64_t mine0 = (p_begin & ~3ull) + (uint64_t)(v - before) * 8u;
+        const uint32_t q0 = (v - before) * 8u;  // my group's first posting, counted from the clause's 16-byte aligned begin
+        const uint64_t mine0 = (p_begin & ~3ull) + (uint64_t)q0;
         uint32_t d[8], cd[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] = cd[j] = 0u;
@@ -364,11 +369,12 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             cd[j] = c0[j]; cd[4 + j] = c1[j];
           }
         }
-        uint32_t vmask = 0;  // my postings inside the clause's range and the window
+        uint32_t vmask = 0;  // my postings inside the clause's range (one unsigned compare: positions before the range wrap) and the window
+        {
+          const uint32_t rel = q0 - ((uint32_t)p_begin & 3u), cnt = act ? r1[2] : 0u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint64_t p = mine0 + (uint64_t)j;
-          if (act && p >= p_begin && p < p_end && d[j] - doc_lo < doc_span) vmask |= 1u << j;
+          for (int j = 0; j < 8; ++j)
+            if (rel + (uint32_t)j < cnt && d[j] - doc_lo < doc_span) vmask |= 1u << j;
         }
         // the values my postings add: per-lane table (lanes of one instruction may belong to different clauses)
         uint32_t val[8];
@@ -401,10 +407,10 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         uint64_t run[8];
         uint32_t alive = 0;
         {
-          const uint32_t sh = (flags >> 4) & 15u;
+          const uint32_t mult = 1u << ((flags >> 4) & 15u);  // entry << shift as one 32 x 32 -> 64 multiply
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            run[j] = (uint64_t)val[j] << sh;
+            run[j] = (uint64_t)val[j] * (uint64_t)mult;
             if (((vmask >> j) & 1u) && val[j] != 0u && run[j] + u_after >= thr) alive |= 1u << j;
           }
         }
@@ -458,21 +464,18 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           uint32_t c2[8];
           uint32_t present = 0;
           if (bits2 != 0ull) {
-            // dense clause: one 16-byte record per 64 docs says whether the doc is there and where its posting is
-            const gvec_ptr recs = (gvec_ptr)bits2;
-            u32x4 r[8];
+            // dense clause: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether
+            // the doc is there and where its posting is
+            const gvec2_ptr recs = (gvec2_ptr)bits2;
+            u32x2 r[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 6) : 0u];
+            for (int j = 0; j < 8; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
             uint32_t idx[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const uint32_t bb = d[j] & 63u;
-              const uint32_t w0 = r[j][0], w1 = r[j][1];
-              const uint32_t word = bb < 32u ? w0 : w1;
-              const bool there = ((am >> j) & 1u) && ((word >> (bb & 31u)) & 1u);
-              const uint32_t m0 = bb < 32u ? (w0 & ((1u << bb) - 1u)) : w0;
-              const uint32_t m1 = bb < 32u ? 0u : (w1 & ((1u << (bb - 32u)) - 1u));
-              idx[j] = there ? r[j][2] + (uint32_t)__popc(m0) + (uint32_t)__popc(m1) : 0u;
+              const uint32_t bb = d[j] & 31u;
+              const bool there = ((am >> j) & 1u) && ((r[j][0] >> bb) & 1u);
+              idx[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
               present |= (there ? 1u : 0u) << j;
             }
 #pragma unroll
@@ -521,42 +524,46 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           if (__any(present != 0u)) {
             uint32_t v2[8];
             values_of_codes(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, v2);
-            const uint32_t sh2 = (flags2 >> 4) & 15u;
+            const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if ((present >> j) & 1u) run[j] += (uint64_t)v2[j] << sh2;
+            for (int j = 0; j < 8; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
           }
         }
 
-        // ---- complete scores: the competitive ones go to the shared candidate buffer
-        uint32_t cmask = 0;
-        if (__any(alive != 0u)) {
+        // ---- complete scores: the competitive ones go to the shared candidate buffer.  Rare once theta has
+        //      converged, so the key (a double conversion) is built only for sums that reach theta's score, one
+        //      posting per lane and round.
+        uint32_t maybe = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (((alive >> j) & 1u) && run[j] >= thr) {
-              const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
-              if (key > theta && key < after_key) cmask |= 1u << j;
+        for (int j = 0; j < 8; ++j)
+          if (((alive >> j) & 1u) && run[j] >= thr) maybe |= 1u << j;
+        uint64_t theta_now = theta;
+        while (__any(maybe != 0u)) {
+          const uint32_t low = maybe & (0u - maybe);  // my lowest pending posting
+          uint64_t rsel = run[0];
+          uint32_t dsel = d[0];
+#pragma unroll
+          for (int j = 1; j < 8; ++j)
+            if (low == (1u << j)) {
+              rsel = run[j];
+              dsel = d[j];
             }
-        }
-        while (__any(cmask != 0u)) {
+          const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
+          const bool want = low != 0u && key > theta_now && key < after_key;
           uint32_t pos = 0;
-          if (ms_reserve(s, lane, (uint32_t)__popc(cmask), pos)) {  // wave-uniform
-            if (PROF) pc_cand += (uint64_t)__popc(cmask);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if ((cmask >> j) & 1u)
-                s.cand[pos++] = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
-            break;
+          if (!__any(want)) {
+            maybe &= ~low;
+            continue;
           }
-          // no room: everybody meets, the k best stay, theta rises; then retry with what is still competitive
+          if (ms_reserve(s, lane, want ? 1u : 0u, pos)) {  // wave-uniform
+            if (want) s.cand[pos] = key;
+            if (PROF) pc_cand += want ? 1u : 0u;
+            maybe &= ~low;
+            continue;
+          }
+          // no room: everybody meets, the k best stay, theta rises; then the same postings again under the new theta
           (void)ms_meet(s, k, fx_E, my_theta_g);
-          const uint64_t th2 = s.theta;
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if ((cmask >> j) & 1u) {
-              const uint64_t key = pack_key(acc_score<true>(run[j], fx_E), (uint32_t)(part.doc_base + (int32_t)d[j]));
-              if (!(key > th2)) cmask &= ~(1u << j);
-            }
+          theta_now = max(theta_now, s.theta);
         }
         // somebody else asked for a compaction: join it between two instructions
         if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) (void)ms_meet(s, k, fx_E, my_theta_g);
@@ -661,7 +668,7 @@ void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __
   __syncthreads();
   if (threadIdx.x == 0) {
     DTermAux a;
-    a.bits = t_rec[t] == ~0ull ? nullptr : (const void*)(recs + t_rec[t] * 4u);
+    a.bits = t_rec[t] == ~0ull ? nullptr : (const void*)(recs + t_rec[t] * 2u);
     for (int i = 0; i < 12; ++i) a.min_norm[i] = (uint8_t)mn[i];
     a.esc_min_norm = (uint8_t)mn[12];
     a.pad[0] = a.pad[1] = a.pad[2] = 0;
@@ -671,9 +678,9 @@ void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __
   }
 }
 
-// term_bits_kernel: membership + rank records of the dense terms (DTermAux.bits).  Grid: (chunks, terms); the
-// records were zeroed.  Postings are ascending in docid, so the first posting of a 64-doc block is the one whose
-// predecessor lies in an earlier block: it records its index as the block's rank.
+// term_bits_kernel: membership + rank records of the dense terms (DTermAux.bits): per 32 docs {doc bits, postings of
+// the term before the block}.  Grid: (chunks, terms); the records were zeroed.  Postings are ascending in docid, so
+// the first posting of a block is the one whose predecessor lies in an earlier block: it records its index.
 __global__ __launch_bounds__(256)
 void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ t_start,
                       const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_rec, uint32_t* __restrict__ recs) {
@@ -681,13 +688,13 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
   if (t_rec[t] == ~0ull) return;  // sparse term: no records
   const uint64_t st = t_start[t];
   const uint32_t n = t_count[t];
-  uint32_t* const r = recs + t_rec[t] * 4u;
+  uint32_t* const r = recs + t_rec[t] * 2u;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
     const uint32_t d = docids[st + p];
-    const uint32_t blk = d >> 6;
-    atomicOr(&r[(size_t)blk * 4u + ((d >> 5) & 1u)], 1u << (d & 31u));
-    if (p == 0u || (docids[st + p - 1u] >> 6) != blk) r[(size_t)blk * 4u + 2u] = p;
+    const uint32_t blk = d >> 5;
+    atomicOr(&r[(size_t)blk * 2u], 1u << (d & 31u));
+    if (p == 0u || (docids[st + p - 1u] >> 5) != blk) r[(size_t)blk * 2u + 1u] = p;
   }
 }
 

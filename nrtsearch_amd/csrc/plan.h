@@ -57,8 +57,8 @@ static_assert(sizeof(DTerm) == 64, "DTerm layout");
 // with -- from which the kernel takes the term's exact maximum score under the query's statistics (the role of
 // Lucene's competitive (freq, norm) impacts).
 struct alignas(16) DTermAux {
-  const void* bits;        // one 16-byte record per 64 docs: {doc bits 0-31, bits 32-63, postings of the term before the
-                           // block, 0}; nullptr for a sparse term (looked up through its cell table instead)
+  const void* bits;        // one 8-byte record per 32 docs: {doc bits, postings of the term before the block}; nullptr
+                           // for a sparse term (looked up through its cell table instead)
   uint8_t  min_norm[12];   // postings a score table can serve (freq f = 1..12, norm byte < 128): smallest norm byte
                            // seen with freq f at [f - 1]; 0xFF = no such posting
   uint8_t  esc_min_norm;   // the other postings (freq > 12 or norm byte >= 128): smallest norm byte ...

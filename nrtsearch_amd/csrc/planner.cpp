@@ -58,7 +58,7 @@ struct PlanPiece {
 // Offsets (term_begin, cache offsets) are relative to the piece.
 static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const nrtgpu_bm25_query* queries, int q_begin,
                             int q_end, PlanPiece& pc, std::vector<std::vector<QS>>& per_query,
-                            std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, bool allow_prune,
+                            std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, int prune,
                             std::vector<int64_t>& q_lower) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
@@ -126,7 +126,7 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
     // after discounting every deleted doc of its segments.  Needs the exact fixed-point sums, plain liveDocs
     // (folded into the columns) and a plain disjunction.
     int64_t lower = 0;
-    if (allow_prune && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
+    if (prune != 0 && !(prune == 2 && q.has_after) && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
         !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
       bool plain = true;
       for (int si = 0; si < n_segs && plain; ++si) plain = segs[si]->d_live == nullptr || segs[si]->live_folded;
@@ -210,7 +210,7 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
 }
 
 int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp, bool allow_prune) {
+                      const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp, int prune) {
   uint32_t kmax = 1;
   for (int qi = 0; qi < n_queries; ++qi) {
     if (int rc = validate_query(queries[qi], qi)) return rc;
@@ -242,12 +242,12 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   auto chunk_begin = [&](int t) { return (int)((int64_t)n_queries * t / n_thr); };
   {
     const int variant = (ctx->cfg.flags >> 8) & 15;  // (the timing ablations of the scan stay exhaustive; 7 = instrumented kernels)
-    allow_prune = allow_prune && (ctx->cfg.flags & NRTGPU_FLAG_NO_PRUNE) == 0 && (variant == 0 || variant == 7);
+    if ((ctx->cfg.flags & NRTGPU_FLAG_NO_PRUNE) != 0 || !(variant == 0 || variant == 7)) prune = 0;
   }
   hp.q_lower.assign((size_t)n_queries, 0);
   auto work = [&](int t) {
     resolve_queries(segs, n_segs, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t], per_query, cache_base, qtabs,
-                    allow_prune, hp.q_lower);
+                    prune, hp.q_lower);
   };
   {
     std::vector<std::thread> pool;

@@ -46,6 +46,7 @@ void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint6
                           const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
                       const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs);
+void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits, uint32_t n);
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
@@ -358,9 +359,11 @@ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 int validate_query(const nrtgpu_bm25_query& q, int qi);
 // fixed-point eligibility of one query term: the scale 2^E at which all its scores are integers < 2^32
 bool fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale);
-// allow_prune: queries that qualify may take the MaxScore route (total_hits then a lower bound, relation GTE)
+// prune: 0 = every query is scanned exhaustively; 1 = queries that qualify take the MaxScore route (total_hits then a
+// lower bound, relation GTE); 2 = the same for device-resident results: no searchAfter there (a page may hold fewer
+// than numHits hits, and then the relation needs the exact count)
 int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-               const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp, bool allow_prune = false);
+               const nrtgpu_bm25_query* queries, int32_t n_queries, HostPlan& hp, int prune = 0);
 
 }  // namespace rt
 }  // namespace nrtgpu

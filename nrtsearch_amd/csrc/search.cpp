@@ -33,6 +33,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_qk = pc.take(hp.q_k.size() * 4);
   const size_t o_theta = pc.take(hp.theta_init.size() * 8);  // uploaded with the plan, then updated by the kernel
   const size_t o_quant = pc.take(hp.list_idx.size() * 8);    // per item: published quantile bound (zeros)
+  const size_t o_lower = pc.take(ext_hits ? hp.q_lower.size() * 8 : 0);  // device-resident results: certain lower bounds
   const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
   const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
   const size_t plan_bytes = pc.off;
@@ -50,6 +51,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_qk, hp.q_k.data(), hp.q_k.size() * 4);
   memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
   memset(hb + o_quant, 0, hp.list_idx.size() * 8);
+  if (ext_hits) memcpy(hb + o_lower, hp.q_lower.data(), hp.q_lower.size() * 8);
   if (use_xch) {
     DExchange x{};
     const size_t stride = (size_t)ctx->cfg.max_batch;
@@ -106,6 +108,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                     (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
                     (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
                     k_stride_out);
+  if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
   if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
   HIP_TRY(hipGetLastError());
   run->out_keys = okeys;
@@ -166,7 +169,9 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
   out->n_hits = m;
   const int64_t counted = (int64_t)(hits & (kHitsPrunedUnit - 1));
   if ((hits >> 48) != 0) {
-    out->total_hits = lower;  // (not max(counted, lower): how many docs were evaluated depends on the order theta grew in)
+    // (not max(counted, lower): how many docs were evaluated depends on the order theta grew in.  Merged per-GPU
+    // results carry their shards' bounds in `counted`: nrtgpu_search_bm25_batch_device)
+    out->total_hits = lower > 0 ? lower : counted;
     out->total_hits_is_lower_bound = 1;
   } else {
     out->total_hits = counted;
@@ -189,7 +194,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
   SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
-  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, true)) return rc;
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, 1)) return rc;
   const double plan_ms = now_ms() - t0;
 
   Slot* slot = nullptr;
@@ -248,7 +253,7 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
   SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
-  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, true)) return rc;
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, 1)) return rc;
   const double plan_ms = now_ms() - t0;
   for (int si = 0; si < n_segs; ++si) {
     auto fit = segs[si]->fields.find(field_id);
@@ -559,7 +564,8 @@ extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtg
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
   SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
-  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp)) return rc;
+  // (with a bound exchange open the shards run the exhaustive scan, which takes part in it; else they may prune)
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, (epoch >= 0 && ctx->xch_dev) ? 0 : 2)) return rc;
   if (k_stride < (int32_t)hp.k_stride && k_stride < NRTGPU_MAX_K) {
     for (int qi = 0; qi < n_queries; ++qi)
       if (queries[qi].k > k_stride) return fail(NRTGPU_ERR_INVALID_ARG, "k_stride %d smaller than numHits %d", k_stride, queries[qi].k);

@@ -187,12 +187,12 @@ static int fold_live_docs(nrtgpu_seg* seg);
 // What the MaxScore route needs per term besides the columns (plan.h: DTermAux), built on the device from the
 // sealed columns: the impact frontier of every term, and for terms dense enough that a doc-indexed structure is
 // affordable (at least one posting per kBitsDocsPerPosting docs: the records then take at most 4x the term's
-// posting bytes) one membership + rank record per 64 docs.  Sparser terms are looked up through their cell table.
+// posting bytes) one membership + rank record per 32 docs.  Sparser terms are looked up through their cell table.
 static const int64_t kBitsDocsPerPosting = 128;
 static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   if (g.d_aux || g.n_terms == 0) return NRTGPU_OK;
   const size_t nt = g.n_terms;
-  const uint64_t n_blocks = ((uint64_t)seg->max_doc + 63) / 64 + 1;  // (+1: lookups of absent docs may read record 0 only, keep a pad)
+  const uint64_t n_blocks = ((uint64_t)seg->max_doc + 31) / 32 + 1;  // 8-byte records, one per 32 docs (+1 pad)
   std::vector<uint64_t> rec((size_t)nt, ~0ull);
   uint64_t n_recs = 0;
   uint32_t max_count = 0;
@@ -207,9 +207,9 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   if (int rc = dev_alloc(seg, &p, nt * sizeof(DTermAux))) return rc;
   g.d_aux = (DTermAux*)p;
   if (n_recs) {
-    if (int rc = dev_alloc(seg, &p, (size_t)n_recs * 16)) return rc;
+    if (int rc = dev_alloc(seg, &p, (size_t)n_recs * 8)) return rc;
     g.d_bits = (uint32_t*)p;
-    HIP_TRY(hipMemset(g.d_bits, 0, (size_t)n_recs * 16));
+    HIP_TRY(hipMemset(g.d_bits, 0, (size_t)n_recs * 8));
   }
   uint64_t* d_start = nullptr;
   uint64_t* d_rec = nullptr;

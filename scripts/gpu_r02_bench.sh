@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round 2: official bench line (MaxScore route), the exhaustive A/B, the 8-GPU per-rank projection, rocprofv3 kernel
+# stats and FETCH_SIZE for the same command, then the whole GPU test suite.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOT=$(pwd); export TMPDIR=/tmp
+mkdir -p gpurun_out/r02
+echo "== bench.py (default) =="
+timeout 600 python bench.py 2>gpurun_out/r02/bench.err | tee gpurun_out/r02/bench_line.json | cut -c1-1800
+tail -2 gpurun_out/r02/bench.err
+echo "== bench.py --no-prune =="
+timeout 300 python bench.py --no-prune --no-cpu-baseline --steps 10 2>/dev/null | tee gpurun_out/r02/bench_line_no_prune.json | cut -c1-700
+echo "== per-rank share of an 8-GPU job (pruned / exhaustive) =="
+timeout 300 python bench.py --force-dist --emulate-world 8 --no-cpu-baseline --steps 20 2>/dev/null | tee gpurun_out/r02/bench_emulate8.json | cut -c1-500
+timeout 300 python bench.py --force-dist --emulate-world 8 --no-prune --no-cpu-baseline --steps 20 2>/dev/null | tee gpurun_out/r02/bench_emulate8_no_prune.json | cut -c1-500
+timeout 300 python bench.py --force-dist --emulate-world 2 --no-cpu-baseline --steps 20 2>/dev/null | tee gpurun_out/r02/bench_emulate2.json | cut -c1-500
+cd /tmp
+echo "== rocprofv3 --kernel-trace --stats =="
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r02 --output-format csv -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /tmp/prof_bench.log 2>&1
+tail -1 /tmp/prof_bench.log | cut -c1-300
+find /tmp/prof -name "*kernel_stats*" -exec cp {} $ROOT/gpurun_out/r02/r02_kernel_stats.csv \;
+head -6 $ROOT/gpurun_out/r02/r02_kernel_stats.csv | cut -c1-60,240-420
+echo "== rocprofv3 --pmc FETCH_SIZE =="
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d /tmp/pmcb -o b --output-format csv -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --host-threads 1 > /tmp/pmcb.log 2>&1
+tail -1 /tmp/pmcb.log | cut -c1-200
+f=$(find /tmp/pmcb -name "*counter_collection.csv" | head -1)
+python - "$f" $ROOT/gpurun_out/r02/pmc_traffic_maxscore.json <<'PY' | tee $ROOT/gpurun_out/r02/r02_pmc_fetch.txt
+import csv, sys, collections, json
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    agg[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in agg.items():
+    print(k, {c: (len(v), sum(v) / len(v)) for c, v in d.items()})
+    if 'bm25_maxscore' in k and 'FETCH_SIZE' in d:
+        v = d['FETCH_SIZE']
+        kb = sum(v) / len(v)
+        json.dump({"workload": "C3", "batch": 1024, "kernel": "bm25_maxscore_kernel", "launches": len(v),
+                   "FETCH_SIZE_KB_per_launch": kb, "hbm_bytes_per_launch": kb * 1024 * 2,
+                   "note": "FETCH_SIZE (KB) x 1024 x 2: gfx950 rocprofv3 reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM); "
+                           "this kernel mixes such reads (posting columns) with 8-byte / 4-byte gathers for which the factor is "
+                           "uncalibrated, so the figure is an upper estimate of the bytes fetched"}, open(sys.argv[2], "w"))
+PY
+cd $ROOT
+echo "== pytest -m gpu =="
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
