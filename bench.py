@@ -234,6 +234,7 @@ def main():
 
     last = {}
     lat = []
+    stage = {"scan_call_s": 0.0, "exchange_s": 0.0, "merge_call_s": 0.0, "steps": 0}   # multi-GPU path: where a step's time goes
 
     def run_steps(first, count, record):
         """`count` steps starting at batch index `first`.  The C ABI is thread-safe (one workspace + HIP
@@ -271,12 +272,15 @@ def main():
             keys, cnt, hits = bufs[b]
             batches[(first + i) % len(batches)].run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(),
                                                            epoch=(first + i) if exchange_name else -1)
+            if record:
+                stage["scan_call_s"] += time.perf_counter() - t_start[i]
             return b
 
         with ThreadPoolExecutor(max_workers=max(1, args.host_threads)) as ex:  # FIFO: steps start in order
             futs = [ex.submit(produce, i) for i in range(count)]
             for i in range(count):
                 b = futs[i].result()
+                te0 = time.perf_counter()
                 keys, cnt, hits = bufs[b]
                 exchange = all_to_all if split_reduce else all_gather
                 exchange(g_keys, keys) if world > 1 else g_keys.copy_(keys)
@@ -284,9 +288,13 @@ def main():
                 exchange(g_hits, hits) if world > 1 else g_hits.copy_(hits)
                 torch.cuda.current_stream().synchronize()   # only this stream: the next scan keeps running
                 free[b].release()
+                te1 = time.perf_counter()
                 merger.run(g_keys.data_ptr(), g_cnt.data_ptr(), g_hits.data_ptr())
                 if record:
                     lat.append(time.perf_counter() - t_start[i])
+                    stage["exchange_s"] += te1 - te0
+                    stage["merge_call_s"] += time.perf_counter() - te1
+                    stage["steps"] += 1
         last["td"] = merger
 
     def fence():
@@ -362,6 +370,8 @@ def main():
             "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
             "host_threads": n_thr,
             "corpus_build_s": round(t_build, 1),
+            "dist_stage_ms": ({k_: round(v / max(1, stage["steps"]) * 1e3, 3) for k_, v in stage.items() if k_ != "steps"}
+                              if use_dist else None),   # per step on this rank: scan call (per scan thread), exchange, merge call
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel,

@@ -1016,6 +1016,52 @@ void apply_live_kernel(const uint32_t* __restrict__ docids, uint32_t* __restrict
   }
 }
 
+// expand_terms_kernel: the compact plan -> the DTerm records of every (query, leaf).  One thread per (query, leaf):
+// the clauses the leaf holds, ordered densest first (exhaustive scan) or heaviest first, ties sparsest first (MaxScore
+// route), written at the offset the host reserved (out_begin; ~0 = the leaf holds none of the query's terms).  The
+// position of a clause is its rank among the leaf's clauses -- at most 32, so ranking by comparison needs no scratch.
+__global__ __launch_bounds__(256)
+void expand_terms_kernel(const DQExpand* __restrict__ qx, const DQTerm* __restrict__ qterms, const uint32_t* __restrict__ out_begin,
+                         uint32_t n_queries, uint32_t n_leaves, DTerm* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_queries * n_leaves) return;
+  const uint32_t ob = out_begin[i];
+  if (ob == 0xFFFFFFFFu) return;
+  const uint32_t q = i / n_leaves, leaf = i - q * n_leaves;
+  const DQExpand x = qx[q];
+  const DQTerm* const qt = qterms + x.term_begin;
+  for (uint32_t t = 0; t < x.n_terms; ++t) {
+    DTerm d = qt[t].table[leaf];
+    if (d.docids == nullptr) continue;
+    const uint32_t cnt = __float_as_uint(d.weight);
+    const float w = qt[t].weight;
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u < x.n_terms; ++u) {
+      if (u == t) continue;
+      const DTerm& o = qt[u].table[leaf];
+      if (o.docids == nullptr) continue;
+      const uint32_t oc = __float_as_uint(o.weight);
+      const float ow = qt[u].weight;
+      const bool before = x.by_weight ? (ow > w || (ow == w && (oc < cnt || (oc == cnt && u < t))))
+                                      : (oc > cnt || (oc == cnt && u < t));
+      rank += before ? 1u : 0u;
+    }
+    d.weight = w;
+    d.cache_slot = qt[t].cache_slot;
+    d.tab_slot = qt[t].tab_slot;
+    d.fx_scale = qt[t].fx_scale;
+    d.fx_shift = qt[t].fx_shift;
+    out[ob + rank] = d;
+  }
+}
+void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* qterms, const uint32_t* out_begin, uint32_t n_queries,
+                         uint32_t n_leaves, DTerm* out) {
+  const uint64_t n = (uint64_t)n_queries * n_leaves;
+  if (n == 0) return;
+  hipLaunchKernelGGL(expand_terms_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, qx, qterms, out_begin, n_queries,
+                     n_leaves, out);
+}
+
 // Device-resident results (multi-GPU path): a query that ran on the MaxScore route reports the planner's certain
 // lower bound, tagged as such (plan.h: kHitsPrunedUnit), instead of the number of docs the kernel happened to evaluate.
 __global__ __launch_bounds__(256)

@@ -52,6 +52,28 @@ struct alignas(16) DTerm {
 };
 static_assert(sizeof(DTerm) == 64, "DTerm layout");
 
+// The host uploads a COMPACT plan: per query clause one DQTerm naming the term's resident per-leaf table (the static
+// half of a DTerm for every leaf of the leaf set, written once per term: planner.cpp, LeafSetCache) plus the query's
+// side of it; expand_terms_kernel writes the DTerm records of every (query, leaf) the scorers read.  The host touches
+// one cache line per clause instead of one per (clause, leaf).
+struct alignas(16) DQTerm {
+  const DTerm* table;        // n_leaves entries; docids == nullptr: the leaf lacks the term; `weight` holds the posting count (bits)
+  float    weight;           // boost * idf
+  uint32_t cache_slot;
+  uint32_t tab_slot;
+  int32_t  fx_scale;
+  uint32_t fx_shift;
+  uint32_t pad;
+};
+static_assert(sizeof(DQTerm) == 32, "DQTerm layout");
+struct alignas(16) DQExpand {
+  uint32_t term_begin;       // the query's DQTerms
+  uint32_t n_terms;
+  uint32_t by_weight;        // order of a (query, leaf)'s DTerms: 1 = heaviest clause first (MaxScore route), 0 = densest first
+  uint32_t pad;
+};
+static_assert(sizeof(DQExpand) == 16, "DQExpand layout");
+
 // What the MaxScore route (maxscore.hip) knows about a term besides its columns (one record per term of a segment,
 // written at seal): a doc -> posting map for lookups, and the term's impact frontier -- per freq the smallest norm byte it occurs
 // with -- from which the kernel takes the term's exact maximum score under the query's statistics (the role of

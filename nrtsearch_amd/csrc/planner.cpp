@@ -48,27 +48,125 @@ bool nrtgpu::rt::fixed_scale_of_term(float weight, const float* cache256, uint32
   return *scale > -64 && *scale < 64;
 }
 struct PlanPiece {
-  std::vector<DTerm> terms;
+  std::vector<DQTerm> qterms;
   std::vector<float> caches;
+  std::vector<QS> qs;          // per (query, leaf) with at least one clause, in query order
+  uint32_t n_dterms = 0;
   int64_t postings = 0, cost = 0;
+  bool oom = false;
 };
 
-// Pass 1 of the planner for queries [q_begin, q_end): one dictionary lookup per (clause, leaf); score
+// ------------------------------------------------------------------------------------------------
+// planner caches
+// ------------------------------------------------------------------------------------------------
+std::shared_ptr<LeafSetCache> nrtgpu::rt::leaf_set_cache(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs) {
+  std::lock_guard<std::mutex> lk(ctx->lsc_mu);
+  for (size_t i = 0; i < ctx->leaf_sets.size(); ++i) {
+    const std::vector<uint64_t>& u = ctx->leaf_sets[i]->uids;
+    bool same = u.size() == (size_t)n_segs;
+    for (int32_t s = 0; same && s < n_segs; ++s) same = u[(size_t)s] == segs[s]->uid;
+    if (same && ctx->leaf_sets[i]->full()) {  // its arena has grown past the cap: start over (plans in flight keep the old one)
+      ctx->leaf_sets.erase(ctx->leaf_sets.begin() + (ptrdiff_t)i);
+      break;
+    }
+    if (same) {
+      if (i != 0) std::rotate(ctx->leaf_sets.begin(), ctx->leaf_sets.begin() + (ptrdiff_t)i, ctx->leaf_sets.begin() + (ptrdiff_t)i + 1);
+      return ctx->leaf_sets[0];
+    }
+  }
+  auto c = std::make_shared<LeafSetCache>();
+  c->device = ctx->device;
+  c->uids.resize((size_t)n_segs);
+  for (int32_t s = 0; s < n_segs; ++s) c->uids[(size_t)s] = segs[s]->uid;
+  ctx->leaf_sets.insert(ctx->leaf_sets.begin(), c);
+  if (ctx->leaf_sets.size() > 8) ctx->leaf_sets.pop_back();  // (a search still planning with it keeps its reference)
+  return c;
+}
+
+std::shared_ptr<const TermLeaves> LeafSetCache::get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash) {
+  const Key key{field, hash};
+  Stripe& st = stripes[KeyHash()(key) % (size_t)kStripes];
+  {
+    std::shared_lock<std::shared_mutex> rd(st.mu);
+    auto it = st.map.find(key);
+    if (it != st.map.end()) return it->second;
+  }
+  auto tl = std::make_shared<TermLeaves>();
+  std::vector<DTerm> leaf((size_t)n_segs, DTerm{});
+  tl->count.assign((size_t)n_segs, 0u);
+  for (int32_t si = 0; si < n_segs; ++si) {
+    auto fit = segs[si]->fields.find(field);
+    if (fit == segs[si]->fields.end()) continue;
+    const FieldData& f = fit->second;
+    const TermEntry* e = f.flat.find(hash);
+    if (!e || e->count == 0) continue;
+    const TermGroup& g = f.groups[e->group];
+    DTerm& d = leaf[(size_t)si];
+    d.docids = g.d_docids;
+    d.fnorm = g.d_fnorm;
+    d.cell_off = g.d_cells + e->cell_start;
+    d.start = e->start;
+    d.aux = g.d_aux + e->aux_idx;
+    d.shift = e->shift;
+    memcpy(&d.weight, &e->count, 4);  // the posting count rides in the weight slot (expand_terms_kernel orders by it)
+    tl->count[(size_t)si] = e->count;
+    tl->total += e->count;
+    tl->max_norm = std::max(tl->max_norm, f.max_norm);
+  }
+  if (tl->total > 0) {  // (a term no leaf holds needs no table: it never reaches the device)
+    DTerm* d_table = alloc_table((size_t)n_segs);
+    if (d_table == nullptr || hipMemcpy(d_table, leaf.data(), (size_t)n_segs * sizeof(DTerm), hipMemcpyHostToDevice) != hipSuccess) {
+      tl->total = -1;   // out of device memory: the caller fails the batch
+      return tl;
+    }
+    tl->d_table = d_table;
+  }
+  std::unique_lock<std::shared_mutex> wr(st.mu);
+  if (st.map.size() >= kMaxPerStripe) st.map.clear();   // (the tables stay resident until the cache itself goes)
+  auto ins = st.map.emplace(key, tl);
+  return ins.first->second;
+}
+
+DTerm* LeafSetCache::alloc_table(size_t n_leaves) {
+  const size_t bytes = (n_leaves * sizeof(DTerm) + 255) & ~(size_t)255;
+  std::lock_guard<std::mutex> lk(arena_mu);
+  if (bytes > kChunkBytes) return nullptr;
+  if (chunks.empty() || chunk_used + bytes > kChunkBytes) {
+    void* p = nullptr;
+    (void)hipSetDevice(device);
+    if (hipMalloc(&p, kChunkBytes) != hipSuccess) return nullptr;
+    chunks.push_back(p);
+    chunk_used = 0;
+  }
+  DTerm* r = (DTerm*)((char*)chunks.back() + chunk_used);
+  chunk_used += bytes;
+  return r;
+}
+
+LeafSetCache::~LeafSetCache() {
+  (void)hipSetDevice(device);
+  for (void* p : chunks) (void)hipFree(p);
+}
+
+// Pass 1 of the planner for queries [q_begin, q_end): one cache lookup per clause (LeafSetCache); score
 // tables go to the clauses with the most postings; terms of a (query, leaf) sorted densest first.
 // Offsets (term_begin, cache offsets) are relative to the piece.
-static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const nrtgpu_bm25_query* queries, int q_begin,
-                            int q_end, PlanPiece& pc, std::vector<std::vector<QS>>& per_query,
+static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, int32_t n_segs, const int32_t* n_deleted,
+                            const nrtgpu_bm25_query* queries, int q_begin, int q_end, PlanPiece& pc, uint32_t* q_qs_begin,
+                            uint32_t* q_qs_cnt, uint32_t* qs_begin, DQExpand* qexpand,
                             std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, int prune,
                             std::vector<int64_t>& q_lower) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
-  std::vector<const TermEntry*> found;
-  std::vector<const FieldData*> fld((size_t)n_segs, nullptr);
-  std::vector<const FieldData*> found_field;
-  uint32_t counts[kMaxTerms];
-  int32_t fld_id = 0;
-  bool fld_valid = false;
+  std::vector<std::shared_ptr<const TermLeaves>> ents;
+  bool any_deleted = false, plain = true;
+  for (int si = 0; si < n_segs; ++si) {
+    any_deleted = any_deleted || n_deleted[si] != 0;
+    plain = plain && (segs[si]->d_live == nullptr || segs[si]->live_folded);
+  }
   size_t prev_cache_off = 0, prev_cache_len = 0;
+  pc.qterms.reserve((size_t)(q_end - q_begin) * 6);
+  pc.qs.reserve((size_t)(q_end - q_begin) * (size_t)std::max(n_segs, 1));
   for (int qi = q_begin; qi < q_end; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
     // consecutive queries over the same fields carry identical normInverse tables: keep one copy
@@ -81,27 +179,12 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
       cache_base[(size_t)qi] = (uint32_t)prev_cache_off;
       pc.caches.insert(pc.caches.end(), q.norm_cache, q.norm_cache + cache_len);
     }
-    found.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
-    found_field.assign((size_t)q.n_terms * (size_t)n_segs, nullptr);
+    ents.resize((size_t)q.n_terms);
     term_total.assign((size_t)q.n_terms, 0);
     for (int t = 0; t < q.n_terms; ++t) {
-      if (!fld_valid || fld_id != q.terms[t].field_id) {  // per-leaf field lookup hoisted out of the clause loop
-        fld_id = q.terms[t].field_id;
-        fld_valid = true;
-        for (int si = 0; si < n_segs; ++si) {
-          auto fit = segs[si]->fields.find(fld_id);
-          fld[(size_t)si] = fit == segs[si]->fields.end() ? nullptr : &fit->second;
-        }
-      }
-      for (int si = 0; si < n_segs; ++si) {
-        const FieldData* f = fld[(size_t)si];
-        if (!f) continue;
-        const TermEntry* e = f->flat.find(q.terms[t].term_hash);
-        if (!e || e->count == 0) continue;
-        found[(size_t)t * n_segs + si] = e;
-        found_field[(size_t)t * n_segs + si] = f;
-        term_total[(size_t)t] += e->count;
-      }
+      ents[(size_t)t] = lsc.get(segs, n_segs, q.terms[t].field_id, q.terms[t].term_hash);
+      if (ents[(size_t)t]->total < 0) pc.oom = true;
+      term_total[(size_t)t] = std::max<int64_t>(ents[(size_t)t]->total, 0);
     }
     // fixed-point analysis: per clause the scale of its scores, per query the common scale
     term_scale.assign((size_t)q.n_terms, 0);
@@ -109,9 +192,7 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
     int32_t fx_E = kNoFixed;
     for (int t = 0; t < q.n_terms && fx_ok; ++t) {
       if (term_total[(size_t)t] == 0) continue;  // matches nothing here
-      uint32_t max_norm = 0;
-      for (int si = 0; si < n_segs; ++si)
-        if (const FieldData* f = found_field[(size_t)t * n_segs + si]) max_norm = std::max(max_norm, f->max_norm);
+      const uint32_t max_norm = ents[(size_t)t]->max_norm;
       int32_t sc = 0;
       fx_ok = fixed_scale_of_term(q.terms[t].weight, q.norm_cache + (size_t)q.terms[t].cache_slot * 256, max_norm, &sc);
       term_scale[(size_t)t] = sc;
@@ -128,13 +209,14 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
     int64_t lower = 0;
     if (prune != 0 && !(prune == 2 && q.has_after) && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
         !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
-      bool plain = true;
-      for (int si = 0; si < n_segs && plain; ++si) plain = segs[si]->d_live == nullptr || segs[si]->live_folded;
       if (plain) {
         for (int t = 0; t < q.n_terms; ++t) {
-          int64_t certain = 0;
-          for (int si = 0; si < n_segs; ++si)
-            if (const TermEntry* e = found[(size_t)t * n_segs + si]) certain += std::max<int64_t>(0, (int64_t)e->count - segs[si]->n_deleted);
+          int64_t certain = term_total[(size_t)t];
+          if (any_deleted) {
+            certain = 0;
+            const uint32_t* cnt = ents[(size_t)t]->count.data();
+            for (int si = 0; si < n_segs; ++si) certain += std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
+          }
           lower = std::max(lower, certain);
         }
         if (lower <= std::max<int64_t>(q.total_hits_threshold, q.k)) lower = 0;
@@ -156,56 +238,44 @@ static void resolve_queries(const nrtgpu_seg* const* segs, int32_t n_segs, const
       qt_.scale[qt_.n] = term_scale[(size_t)best];
       qt_.n++;
     }
-    per_query[(size_t)qi].reserve((size_t)n_segs);
-    for (int si = 0; si < n_segs; ++si) {
-      const nrtgpu_seg* seg = segs[si];
-      QS qs{(uint32_t)pc.terms.size(), 0, si, 0};
-      for (int t = 0; t < q.n_terms; ++t) {
-        const nrtgpu_term& qt = q.terms[t];
-        const TermEntry* ep = found[(size_t)t * n_segs + si];
-        if (!ep) continue;
-        const TermEntry& e = *ep;
-        const FieldData& f = *found_field[(size_t)t * n_segs + si];
-        const TermGroup& g = f.groups[e.group];
-        DTerm d{};
-        d.docids = g.d_docids;
-        d.fnorm = g.d_fnorm;
-        d.cell_off = g.d_cells + e.cell_start;
-        d.start = e.start;
-        d.aux = g.d_aux + e.aux_idx;
-        d.shift = e.shift;
-        d.weight = qt.weight;
-        d.cache_slot = (uint32_t)qt.cache_slot;
-        d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
-        d.fx_scale = term_scale[(size_t)t];
-        d.fx_shift = fx_ok ? (uint32_t)(fx_E - term_scale[(size_t)t]) : 0u;
-        pc.terms.push_back(d);
-        counts[qs.n_terms] = e.count;
-        qs.n_terms++;
-        qs.postings += e.count;
-      }
-      if (qs.n_terms > 0) {
-        // exhaustive scan: densest clause first.  MaxScore route: heaviest (rarest) clause first, the order its
-        // bounds are taken in.  Stable insertion sort (a handful of clauses; std::stable_sort allocates per call)
-        DTerm* tb = pc.terms.data() + qs.term_begin;
-        const bool by_weight = lower > 0;
-        for (uint32_t i = 1; i < qs.n_terms; ++i) {
-          const DTerm key = tb[i];
-          const uint32_t kc = counts[i];
-          uint32_t j = i;
-          for (; j > 0 && (by_weight ? (tb[j - 1].weight < key.weight || (tb[j - 1].weight == key.weight && counts[j - 1] > kc))
-                                     : counts[j - 1] < kc); --j) {
-            tb[j] = tb[j - 1];
-            counts[j] = counts[j - 1];
-          }
-          tb[j] = key;
-          counts[j] = kc;
-        }
-        per_query[(size_t)qi].push_back(qs);
-        pc.postings += qs.postings;
-        pc.cost += qs.postings + (int64_t)seg->n_tiles * kTileCostPostings;
-      }
+    // the compact plan of the query: one DQTerm per clause that matches anything, and per leaf how many of them it holds
+    DQExpand& qx = qexpand[(size_t)qi];
+    qx.term_begin = (uint32_t)pc.qterms.size();
+    qx.by_weight = lower > 0 ? 1u : 0u;
+    qx.pad = 0;
+    const uint32_t* cnt_of[kMaxTerms];
+    uint32_t n_live = 0;
+    for (int t = 0; t < q.n_terms; ++t) {
+      const TermLeaves& tl = *ents[(size_t)t];
+      if (tl.total <= 0) continue;
+      DQTerm d{};
+      d.table = tl.d_table;
+      d.weight = q.terms[t].weight;
+      d.cache_slot = (uint32_t)q.terms[t].cache_slot;
+      d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
+      d.fx_scale = term_scale[(size_t)t];
+      d.fx_shift = fx_ok ? (uint32_t)(fx_E - term_scale[(size_t)t]) : 0u;
+      pc.qterms.push_back(d);
+      cnt_of[n_live++] = tl.count.data();
     }
+    qx.n_terms = n_live;
+    q_qs_begin[qi] = (uint32_t)pc.qs.size();
+    for (int si = 0; si < n_segs; ++si) {
+      uint32_t n = 0;
+      int64_t postings = 0;
+      for (uint32_t t = 0; t < n_live; ++t) {
+        const uint32_t c = cnt_of[t][si];
+        n += c != 0u ? 1u : 0u;
+        postings += c;
+      }
+      qs_begin[(size_t)qi * (size_t)n_segs + (size_t)si] = n ? pc.n_dterms : 0xFFFFFFFFu;
+      if (n == 0) continue;
+      pc.qs.push_back(QS{pc.n_dterms, n, si, postings});
+      pc.n_dterms += n;
+      pc.postings += postings;
+      pc.cost += postings + (int64_t)segs[si]->n_tiles * kTileCostPostings;
+    }
+    q_qs_cnt[qi] = (uint32_t)pc.qs.size() - q_qs_begin[qi];
   }
 }
 
@@ -233,7 +303,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // pass 1: resolve terms per (query, segment), densest term first; remember posting counts.
   // Queries are independent here, so the batch is cut into contiguous chunks resolved by
   // cfg.host_threads planner threads and concatenated (offsets rebased) afterwards.
-  std::vector<std::vector<QS>> per_query((size_t)n_queries);
+  std::vector<uint32_t> q_qs_begin((size_t)n_queries), q_qs_cnt((size_t)n_queries);
   std::vector<uint32_t> cache_base((size_t)n_queries);
   std::vector<QTabs> qtabs((size_t)n_queries);
   int n_thr = ctx->cfg.host_threads > 0 ? ctx->cfg.host_threads : 4;
@@ -242,45 +312,60 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   auto chunk_begin = [&](int t) { return (int)((int64_t)n_queries * t / n_thr); };
   {
     const int variant = (ctx->cfg.flags >> 8) & 15;  // (the timing ablations of the scan stay exhaustive; 7 = instrumented kernels)
-    if ((ctx->cfg.flags & NRTGPU_FLAG_NO_PRUNE) != 0 || !(variant == 0 || variant == 7)) prune = 0;
+    // (the MaxScore route adds exact fixed-point integers: a context that asks for fp64 sums gets the exhaustive scan)
+    if ((ctx->cfg.flags & (NRTGPU_FLAG_NO_PRUNE | NRTGPU_FLAG_NO_FIXED_POINT)) != 0 || !(variant == 0 || variant == 7)) prune = 0;
   }
   hp.q_lower.assign((size_t)n_queries, 0);
+  hp.lsc = leaf_set_cache(ctx, segs, n_segs);
+  hp.n_leaves = (uint32_t)n_segs;
+  hp.qexpand.resize((size_t)n_queries);
+  hp.qs_begin.assign((size_t)n_queries * (size_t)std::max(n_segs, 1), 0xFFFFFFFFu);
+  std::vector<int32_t> n_deleted((size_t)std::max(n_segs, 1), 0);
+  for (int si = 0; si < n_segs; ++si) n_deleted[(size_t)si] = segs[si]->n_deleted;
   auto work = [&](int t) {
-    resolve_queries(segs, n_segs, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t], per_query, cache_base, qtabs,
-                    prune, hp.q_lower);
+    resolve_queries(*hp.lsc, segs, n_segs, n_deleted.data(), queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t],
+                    q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower);
   };
-  {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
-  }
+  ctx->pool->run(n_thr, work);
   const double tp1 = plan_trace ? now_ms() : 0.0;
+  // concatenate the pieces: offsets were relative to the piece
   int64_t total_postings = 0;
   {
     size_t nt = 0, nc = 0;
-    for (const PlanPiece& pc : pieces) { nt += pc.terms.size(); nc += pc.caches.size(); }
-    hp.terms.reserve(nt);
+    for (const PlanPiece& pc : pieces) { nt += pc.qterms.size(); nc += pc.caches.size(); }
+    hp.qterms.reserve(nt);
     hp.caches.reserve(nc);
   }
+  std::vector<int> piece_of((size_t)n_queries, 0);
   for (int t = 0; t < n_thr; ++t) {
     PlanPiece& pc = pieces[(size_t)t];
-    const uint32_t term_base = (uint32_t)hp.terms.size(), c_base = (uint32_t)hp.caches.size();
-    hp.terms.insert(hp.terms.end(), pc.terms.begin(), pc.terms.end());
+    if (pc.oom) return fail(NRTGPU_ERR_OOM, "out of device memory for the resident term tables");
+    const uint32_t qterm_base = (uint32_t)hp.qterms.size(), c_base = (uint32_t)hp.caches.size(), dterm_base = hp.n_dterms;
+    hp.qterms.insert(hp.qterms.end(), pc.qterms.begin(), pc.qterms.end());
     hp.caches.insert(hp.caches.end(), pc.caches.begin(), pc.caches.end());
+    for (QS& qs : pc.qs) qs.term_begin += dterm_base;
     for (int qi = chunk_begin(t); qi < chunk_begin(t + 1); ++qi) {
       cache_base[(size_t)qi] += c_base;
-      for (QS& qs : per_query[(size_t)qi]) qs.term_begin += term_base;
+      hp.qexpand[(size_t)qi].term_begin += qterm_base;
+      piece_of[(size_t)qi] = t;
+      if (dterm_base)
+        for (int si = 0; si < n_segs; ++si) {
+          uint32_t& b = hp.qs_begin[(size_t)qi * (size_t)n_segs + (size_t)si];
+          if (b != 0xFFFFFFFFu) b += dterm_base;
+        }
     }
+    hp.n_dterms += pc.n_dterms;
     total_postings += pc.postings;
   }
+  // the (query, leaf) pairs of query qi
+  auto qs_of = [&](int qi) { return pieces[(size_t)piece_of[(size_t)qi]].qs.data() + q_qs_begin[(size_t)qi]; };
   hp.postings = total_postings;
   hp.fixed_point = (ctx->cfg.flags & NRTGPU_FLAG_NO_FIXED_POINT) == 0;
   for (int qi = 0; qi < n_queries && hp.fixed_point; ++qi)
-    if (!per_query[(size_t)qi].empty() && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
+    if (q_qs_cnt[(size_t)qi] != 0 && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
   for (int qi = 0; qi < n_queries; ++qi)
     if (hp.q_lower[(size_t)qi] > 0)
-      for (const QS& qs : per_query[(size_t)qi]) hp.ms_postings += qs.postings;
+      for (uint32_t j = 0; j < q_qs_cnt[(size_t)qi]; ++j) hp.ms_postings += qs_of(qi)[j].postings;
   // minimumNumberShouldMatch > 1 (QueryNodeMapper.java:259-261): the clause count rides in the fixed-point
   // accumulator, so the whole batch must be in fixed-point mode; otherwise the caller runs Lucene's WANDScorer
   hp.clause_counting = false;
@@ -302,7 +387,10 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   std::vector<Pending> pend;
   std::vector<int64_t> q_costs((size_t)n_queries, 0), q_items((size_t)n_queries, 0);
   for (int qi = 0; qi < n_queries; ++qi)
-    for (const QS& qs : per_query[(size_t)qi]) q_costs[(size_t)qi] += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
+    for (uint32_t j = 0; j < q_qs_cnt[(size_t)qi]; ++j) {
+      const QS& qs = qs_of(qi)[j];
+      q_costs[(size_t)qi] += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
+    }
   hostmath::plan_item_counts(q_costs.data(), n_queries, target_items, min_item_cost, q_items.data());  // host_math.h
   for (int qi = 0; qi < n_queries; ++qi) {
     const int64_t q_cost = q_costs[(size_t)qi];
@@ -311,7 +399,8 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     const double budget = (double)q_cost / (double)n_it;
     Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
     double filled = 0.0;
-    for (const QS& qs : per_query[(size_t)qi]) {
+    for (uint32_t j = 0; j < q_qs_cnt[(size_t)qi]; ++j) {
+      const QS& qs = qs_of(qi)[j];
       const nrtgpu_seg* seg = segs[qs.seg];
       const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
       const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
@@ -409,6 +498,6 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   }
   if (plan_trace)
     fprintf(stderr, "[nrtgpu plan] %d queries: resolve %.3f ms (%d threads), concat %.3f, cut+items %.3f; %zu terms %zu parts %zu items\n",
-            n_queries, tp1 - tp0, n_thr, tp2 - tp1, now_ms() - tp2, hp.terms.size(), hp.parts.size(), hp.items.size());
+            n_queries, tp1 - tp0, n_thr, tp2 - tp1, now_ms() - tp2, (size_t)hp.n_dterms, hp.parts.size(), hp.items.size());
   return 0;
 }

@@ -57,6 +57,72 @@ void release_slot(nrtgpu_ctx* ctx, Slot* s) {
 // ------------------------------------------------------------------------------------------------
 // ABI: context
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// helper threads
+// ------------------------------------------------------------------------------------------------
+WorkPool::WorkPool(int helpers) {
+  for (int i = 0; i < helpers; ++i) threads_.emplace_back([this] { loop(); });
+}
+WorkPool::~WorkPool() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_.notify_all();
+  for (auto& t : threads_) t.join();
+}
+void WorkPool::loop() {
+  for (;;) {
+    std::shared_ptr<Job> job;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] {
+        if (stop_) return true;
+        for (auto& j : jobs_)
+          if (j->next.load(std::memory_order_relaxed) < j->n) return true;
+        return false;
+      });
+      if (stop_) return;
+      for (auto& j : jobs_)
+        if (j->next.load(std::memory_order_relaxed) < j->n) {
+          job = j;
+          break;
+        }
+    }
+    if (!job) continue;
+    for (;;) {
+      const int i = job->next.fetch_add(1, std::memory_order_acq_rel);
+      if (i >= job->n) break;
+      (*job->fn)(i);
+      job->done.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
+}
+void WorkPool::run(int n, const std::function<void(int)>& fn) {
+  if (n <= 0) return;
+  if (n == 1 || threads_.empty()) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  auto job = std::make_shared<Job>();
+  job->fn = &fn;
+  job->n = n;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    jobs_.push_back(job);
+  }
+  cv_.notify_all();
+  for (;;) {  // the caller works too
+    const int i = job->next.fetch_add(1, std::memory_order_acq_rel);
+    if (i >= n) break;
+    fn(i);
+    job->done.fetch_add(1, std::memory_order_acq_rel);
+  }
+  while (job->done.load(std::memory_order_acquire) < n) std::this_thread::yield();  // helpers finishing their last chunk
+  std::lock_guard<std::mutex> lk(mu_);
+  jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));
+}
+
 extern "C" const char* nrtgpu_version(void) { return "nrtgpu 0.1 (gfx950)"; }
 extern "C" const char* nrtgpu_last_error(void) { return g_last_error.c_str(); }
 
@@ -90,6 +156,7 @@ extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
     HIP_TRY(hipEventCreate(&s->ev3));
     ctx->slots.push_back(std::move(s));
   }
+  ctx->pool = std::make_unique<WorkPool>(std::max(0, (c.host_threads > 0 ? c.host_threads : 4) - 1));
   *out = ctx.release();
   return NRTGPU_OK;
 }

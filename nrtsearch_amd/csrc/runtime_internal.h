@@ -21,6 +21,7 @@
 #include <cmath>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -46,6 +47,8 @@ void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint6
                           const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
                       const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs);
+void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* qterms, const uint32_t* out_begin, uint32_t n_queries,
+                         uint32_t n_leaves, DTerm* out);
 void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits, uint32_t n);
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
@@ -214,6 +217,7 @@ using namespace nrtgpu::rt;
 struct nrtgpu_ctx;
 struct nrtgpu_seg {
   nrtgpu_ctx* ctx = nullptr;
+  uint64_t uid = 0;              // unique over the process (never reused, unlike the handle's address): keys the planner's caches
   int32_t max_doc = 0;
   uint32_t n_tiles = 0;
   bool sealed = false;
@@ -283,6 +287,37 @@ struct Slot {
 }  // namespace rt
 }  // namespace nrtgpu
 
+namespace nrtgpu {
+namespace rt {
+struct LeafSetCache;
+
+// The context's helper threads (cfg.host_threads - 1 of them, started at nrtgpu_create): run(n, fn) executes
+// fn(0) .. fn(n - 1) on the caller and whichever helpers are free, and returns when all are done.  Several
+// callers may run jobs at the same time (two batches in flight).  Replaces a std::thread per planner chunk per
+// batch: thread creation alone cost more than the work once term lookups came from the cache.
+class WorkPool {
+ public:
+  explicit WorkPool(int helpers);
+  ~WorkPool();
+  void run(int n, const std::function<void(int)>& fn);
+  int helpers() const { return (int)threads_.size(); }
+
+ private:
+  struct Job {
+    const std::function<void(int)>* fn;
+    int n;
+    std::atomic<int> next{0}, done{0};
+  };
+  void loop();
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::shared_ptr<Job>> jobs_;
+  bool stop_ = false;
+};
+}  // namespace rt
+}  // namespace nrtgpu
+
 struct nrtgpu_ctx {
   nrtgpu_config cfg{};
   int device = 0;
@@ -305,6 +340,10 @@ struct nrtgpu_ctx {
   int co_inflight_queries = 0;                // ... and how many queries they hold
   int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
   int32_t co_linger_us = 150;
+  std::unique_ptr<nrtgpu::rt::WorkPool> pool;   // helper threads of the host side (planning, unpacking results)
+  // planner caches, one per leaf set seen lately (most recent first)
+  std::mutex lsc_mu;
+  std::vector<std::shared_ptr<nrtgpu::rt::LeafSetCache>> leaf_sets;
   // cross-GPU bound exchange (nrtgpu_exchange_open)
   void* xch_host = nullptr;                 // mmap of the shared table
   unsigned long long* xch_dev = nullptr;    // the same memory as the GPU sees it
@@ -325,6 +364,49 @@ struct Carver {
   }
 };
 
+// ---- planner caches ----------------------------------------------------------------------------
+// One term over one leaf set, resolved once: the per-leaf dictionary lookups and the static half of every DTerm.
+// A batch of 1024 five-clause queries over 10 leaves otherwise pays 51 k dictionary probes; query terms repeat
+// across batches (and within them), the leaf set changes only when the searcher is refreshed.
+struct TermLeaves {
+  const DTerm* d_table = nullptr;  // resident copy of the per-leaf records (columns, cell table, aux record, posting count in
+                                   // `weight`; docids == nullptr: the leaf lacks the term) -- what DQTerm.table points at
+  std::vector<uint32_t> count;     // postings per leaf
+  int64_t total = 0;
+  uint32_t max_norm = 0;           // largest norm byte of the field over the leaves that hold the term
+};
+struct LeafSetCache {
+  std::vector<uint64_t> uids;    // the leaf set this cache belongs to (segment uids, in call order)
+  struct Key {
+    int32_t field;
+    int64_t hash;
+    bool operator==(const Key& o) const { return field == o.field && hash == o.hash; }
+  };
+  struct KeyHash {
+    size_t operator()(const Key& k) const { return (size_t)(((uint64_t)k.hash ^ ((uint64_t)(uint32_t)k.field << 40)) * 0x9E3779B97F4A7C15ull >> 7); }
+  };
+  static const int kStripes = 64;
+  static const size_t kMaxPerStripe = 8192;   // entries per stripe before it is dropped and refilled (bounds the memory)
+  struct Stripe {
+    std::shared_mutex mu;
+    std::unordered_map<Key, std::shared_ptr<const TermLeaves>, KeyHash> map;
+  };
+  Stripe stripes[kStripes];
+  // the terms' resident tables: carved out of 1 MiB device chunks that live as long as the cache (a plan in flight
+  // holds a reference to the cache)
+  int device = 0;
+  std::mutex arena_mu;
+  std::vector<void*> chunks;
+  size_t chunk_used = 0;
+  static const size_t kChunkBytes = 1 << 20;
+  static const size_t kMaxChunks = 256;       // then the context starts a fresh cache for the leaf set
+  bool full() { std::lock_guard<std::mutex> lk(arena_mu); return chunks.size() > kMaxChunks; }
+  DTerm* alloc_table(size_t n_leaves);
+  ~LeafSetCache();
+  std::shared_ptr<const TermLeaves> get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash);
+};
+std::shared_ptr<LeafSetCache> leaf_set_cache(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs);
+
 // ---- workspaces (runtime.cpp) ------------------------------------------------------------------
 int acquire_slot(nrtgpu_ctx* ctx, Slot** out);
 void release_slot(nrtgpu_ctx* ctx, Slot* s);
@@ -339,7 +421,12 @@ struct HostPlan {
   std::vector<DQuery> queries;
   std::vector<DItem> items;
   std::vector<DPart> parts;
-  std::vector<DTerm> terms;
+  std::vector<DQTerm> qterms;       // compact plan: per query clause (expand_terms_kernel writes the DTerms on the device)
+  std::vector<DQExpand> qexpand;    // per query
+  std::vector<uint32_t> qs_begin;   // per (query, leaf): first DTerm of the pair, ~0 = none
+  uint32_t n_dterms = 0;            // DTerm records the expansion writes
+  uint32_t n_leaves = 0;
+  std::shared_ptr<LeafSetCache> lsc;  // keeps the terms' resident tables alive until the call is over
   std::vector<float> caches;
   std::vector<uint32_t> list_idx;   // per query: item indices (merge input lists)
   std::vector<uint32_t> q_base, q_nlists, q_k;

@@ -25,7 +25,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
   const size_t o_items = pc.take(n_items * sizeof(DItem));
   const size_t o_parts = pc.take(hp.parts.size() * sizeof(DPart));
-  const size_t o_terms = pc.take(hp.terms.size() * sizeof(DTerm));
+  const size_t o_qterms = pc.take(hp.qterms.size() * sizeof(DQTerm));
+  const size_t o_qexp = pc.take(hp.qexpand.size() * sizeof(DQExpand));
+  const size_t o_qsb = pc.take(hp.qs_begin.size() * 4);
   const size_t o_caches = pc.take(hp.caches.size() * sizeof(float));
   const size_t o_lidx = pc.take(hp.list_idx.size() * 4);
   const size_t o_qbase = pc.take(hp.q_base.size() * 4);
@@ -43,7 +45,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_queries, hp.queries.data(), hp.queries.size() * sizeof(DQuery));
   if (n_items) memcpy(hb + o_items, hp.items.data(), n_items * sizeof(DItem));
   if (!hp.parts.empty()) memcpy(hb + o_parts, hp.parts.data(), hp.parts.size() * sizeof(DPart));
-  if (!hp.terms.empty()) memcpy(hb + o_terms, hp.terms.data(), hp.terms.size() * sizeof(DTerm));
+  if (!hp.qterms.empty()) memcpy(hb + o_qterms, hp.qterms.data(), hp.qterms.size() * sizeof(DQTerm));
+  memcpy(hb + o_qexp, hp.qexpand.data(), hp.qexpand.size() * sizeof(DQExpand));
+  if (!hp.qs_begin.empty()) memcpy(hb + o_qsb, hp.qs_begin.data(), hp.qs_begin.size() * 4);
   memcpy(hb + o_caches, hp.caches.data(), hp.caches.size() * sizeof(float));
   if (!hp.list_idx.empty()) memcpy(hb + o_lidx, hp.list_idx.data(), hp.list_idx.size() * 4);
   memcpy(hb + o_qbase, hp.q_base.data(), hp.q_base.size() * 4);
@@ -71,6 +75,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_okeys = wc.take((size_t)n_queries * k_stride_out * 8);
   const size_t o_ocnt = wc.take((size_t)n_queries * 4);
   const size_t o_ohits = wc.take((size_t)n_queries * 8);
+  const size_t o_terms = wc.take((size_t)hp.n_dterms * sizeof(DTerm));  // written by expand_terms_kernel
   // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
   const int flag_variant = (ctx->cfg.flags >> 8) & 15;
   const int ablation = hp.clause_counting ? 8 : ((hp.masked && flag_variant == 0 && !(ctx->cfg.flags & NRTGPU_FLAG_NO_MASK_VARIANT)) ? 9 : flag_variant);
@@ -87,14 +92,17 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const bool timing = ctx->cfg.collect_timing != 0;
   // the queries on the MaxScore route (items [0, n_ms)), then the exhaustive scan of the others
   const size_t n_ms = hp.n_ms_items;
+  // the compact plan -> the DTerm records of every (query, leaf), on the device
+  launch_expand_terms(st, (const DQExpand*)(db + o_qexp), (const DQTerm*)(db + o_qterms), (const uint32_t*)(db + o_qsb),
+                      (uint32_t)n_queries, hp.n_leaves, (DTerm*)(wb + o_terms));
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
-  launch_bm25_maxscore(st, profile, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
+  launch_bm25_maxscore(st, profile, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                        (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
                        (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
                        profile ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)(n_items - n_ms),
-                   (const DItem*)(db + o_items) + n_ms, (const DPart*)(db + o_parts), (const DTerm*)(db + o_terms),
+                   (const DItem*)(db + o_items) + n_ms, (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
                    (unsigned long long*)(db + o_theta), (unsigned long long*)(db + o_quant),
                    use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys) + n_ms * (size_t)hp.k_stride,
@@ -206,21 +214,34 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   const size_t o_k = oc.take(kb), o_c = oc.take(cb), o_h = oc.take(hb);
   if (int rc = slot->h_out.reserve(oc.off)) return rc;
   char* ho = (char*)slot->h_out.p;
+  static const bool call_trace = getenv("NRTGPU_PLAN_TRACE") != nullptr;  // debug aid: phase times on stderr
+  const double tc0 = call_trace ? now_ms() : 0.0;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
     HIP_TRY(hipStreamSynchronize(slot->stream));  // kernels done: the next batch may have the device ...
   }
+  const double tc1 = call_trace ? now_ms() : 0.0;
   // ... while this one's results travel to the host
   HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
   HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
   HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
   HIP_TRY(hipStreamSynchronize(slot->stream));
+  const double tc2 = call_trace ? now_ms() : 0.0;
   const uint64_t* keys = (const uint64_t*)(ho + o_k);
   const uint32_t* cnts = (const uint32_t*)(ho + o_c);
   const uint64_t* hits = (const uint64_t*)(ho + o_h);
-  for (int qi = 0; qi < n_queries; ++qi)
-    unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, hp.q_lower[(size_t)qi], &out[qi]);
+  {
+    const int n_chunks = n_queries >= 256 ? std::min(8, ctx->pool->helpers() + 1) : 1;   // ~8 KB of docs + scores per query
+    ctx->pool->run(n_chunks, [&](int c) {
+      const int q0 = (int)((int64_t)n_queries * c / n_chunks), q1 = (int)((int64_t)n_queries * (c + 1) / n_chunks);
+      for (int qi = q0; qi < q1; ++qi)
+        unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, hp.q_lower[(size_t)qi], &out[qi]);
+    });
+  }
+  if (call_trace)
+    fprintf(stderr, "[nrtgpu call] %d queries: plan %.3f ms, upload + kernels %.3f, results to host %.3f, unpack %.3f\n", n_queries, plan_ms,
+            tc1 - tc0, tc2 - tc1, now_ms() - tc2);
   if (run.prof && run.n_items) {
     std::vector<uint64_t> hp_prof(run.n_items * 16);
     HIP_TRY(hipMemcpy(hp_prof.data(), run.prof, hp_prof.size() * 8, hipMemcpyDeviceToHost));
@@ -634,8 +655,14 @@ extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_
   const uint64_t* keys = (const uint64_t*)(ho + o_okeys);
   const uint32_t* cnts = (const uint32_t*)(ho + o_ocnt);
   const uint64_t* hits = (const uint64_t*)(ho + o_ohits);
-  for (int qi = 0; qi < n_queries; ++qi)
-    unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], total_hits_thresholds[qi], 0, &out[qi]);
+  {
+    const int n_chunks = n_queries >= 256 ? std::min(8, ctx->pool->helpers() + 1) : 1;
+    ctx->pool->run(n_chunks, [&](int c) {
+      const int q0 = (int)((int64_t)n_queries * c / n_chunks), q1 = (int)((int64_t)n_queries * (c + 1) / n_chunks);
+      for (int qi = q0; qi < q1; ++qi)
+        unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], total_hits_thresholds[qi], 0, &out[qi]);
+    });
+  }
   return NRTGPU_OK;
 }
 

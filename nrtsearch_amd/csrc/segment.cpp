@@ -34,8 +34,10 @@ static int dev_alloc(nrtgpu_seg* seg, void** p, size_t bytes) {
 extern "C" int nrtgpu_segment_begin(nrtgpu_ctx* ctx, int32_t max_doc, int32_t /*device_hint*/, nrtgpu_seg** out) {
   if (!ctx || !out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (max_doc <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "max_doc must be > 0, got %d", max_doc);
+  static std::atomic<uint64_t> next_uid{1};
   auto* seg = new nrtgpu_seg();
   seg->ctx = ctx;
+  seg->uid = next_uid.fetch_add(1, std::memory_order_relaxed);
   seg->max_doc = max_doc;
   seg->n_tiles = (uint32_t)(((int64_t)max_doc + kTileDocs - 1) / kTileDocs);
   *out = seg;

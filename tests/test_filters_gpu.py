@@ -286,7 +286,8 @@ def test_live_docs_change_while_searching(ctx):
             for _ in range(150):
                 got = ix.searcher.search(q, api.TopScoreDocCollectorManager(100))
                 rec = (got.docs.tolist(), got.scores.view(np.uint32).tolist(), got.total_hits, got.relation_gte)
-                if rec not in exp:
+                # (a pruned search reports a lower bound above the threshold where the relation is GTE)
+                if not any(rec[:2] == e[:2] and rec[3] == e[3] and (rec[2] == e[2] or (e[3] and 1000 < rec[2] <= e[2])) for e in exp):
                     errors.append(rec[2])
 
         t_flip = threading.Thread(target=flip)
@@ -302,6 +303,7 @@ def test_live_docs_change_while_searching(ctx):
         for leaf, bits in zip(ix.leaves, v_a):
             leaf.set_live_docs(bits)
         got = ix.searcher.search(q, api.TopScoreDocCollectorManager(100))
-        assert got.docs.tolist() == exp[0][0] and got.total_hits == exp[0][2]   # exp[0] = both leaves at version A
+        assert got.docs.tolist() == exp[0][0] and got.relation_gte == exp[0][3]   # exp[0] = both leaves at version A
+        assert (1000 < got.total_hits <= exp[0][2]) if exp[0][3] else got.total_hits == exp[0][2]
     finally:
         ix.close()

@@ -305,7 +305,7 @@ def test_fixed_point_and_fp64_accumulators_agree(mid, oracle):
     # (like the reference's double sum); both must give the oracle's bits
     cases = [([1, 5, 100, 5000], None), ([2, 3, 13, 40, 333], [1.0, 0.5, 3.0, 2.0, 1.5]), ([9999], None)]
     for flags, want_fixed in [(0, True), (_lib.NRTGPU_FLAG_NO_FIXED_POINT, False)]:
-        c2 = api.GpuContext(0, 64, flags=flags)
+        c2 = api.GpuContext(0, 64, flags=flags | _lib.NRTGPU_FLAG_NO_PRUNE)   # (this test is about the exhaustive scan's accumulators)
         leaves = [api.GpuSegment.from_data(c2, s) for s in mid.corpus.segments]
         sr = api.GpuIndexSearcher(c2, leaves, api.IndexStatistics.from_corpus(mid.corpus))
         for terms, boosts in cases:
