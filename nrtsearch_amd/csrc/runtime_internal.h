@@ -206,6 +206,14 @@ struct FieldData {
   int32_t* d_ord_to_doc = nullptr;
   std::vector<int32_t> h_ord_to_doc;     // host copy: docid -> row lookups of the rescore path
   int32_t dim = 0, n_vec = 0;
+  // rows whose doc is live under the segment's current liveDocs (what an exact vector query matches), counted on first
+  // use per liveDocs version
+  mutable std::atomic<int64_t> live_vec{-1};
+  mutable std::atomic<uint64_t> live_vec_version{0};
+  FieldData() = default;
+  FieldData(const FieldData& o)
+      : d_norms(o.d_norms), max_norm(o.max_norm), dict(o.dict), flat(o.flat), groups(o.groups), d_vectors(o.d_vectors),
+        d_vnorm2(o.d_vnorm2), d_ord_to_doc(o.d_ord_to_doc), h_ord_to_doc(o.h_ord_to_doc), dim(o.dim), n_vec(o.n_vec) {}
 };
 
 }  // namespace rt
@@ -224,6 +232,7 @@ struct nrtgpu_seg {
   std::map<int32_t, FieldData> fields;
   uint64_t* d_live = nullptr;
   int32_t n_deleted = 0;         // docs cleared in liveDocs (host pop-count at set_live_docs)
+  uint64_t live_version = 1;     // bumped by every set_live_docs
   int64_t device_bytes = 0;
   // FILTER / MUST_NOT clauses as doc-set masks: host copies of the registered masks and of liveDocs,
   // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use
@@ -415,6 +424,8 @@ void release_slot(nrtgpu_ctx* ctx, Slot* s);
 // The doc set a query's hits must lie in: liveDocs & FILTER mask & ~MUST_NOT mask, resident in HBM
 // ((0, 0): liveDocs itself, or nullptr once they are folded into the posting columns).
 int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out);
+// vectors of the field whose doc is live (the hits of an exact vector query over the segment)
+int64_t live_vector_count(const nrtgpu_seg* seg, const FieldData& f);
 
 // ---- planner (planner.cpp) ---------------------------------------------------------------------
 struct HostPlan {

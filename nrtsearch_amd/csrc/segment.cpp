@@ -305,6 +305,7 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
   HIP_TRY(hipSetDevice(seg->ctx->device));
   const int32_t need = (seg->max_doc + 63) / 64;
   drop_accept_sets(seg);
+  seg->live_version++;
   if (!bits) {
     if (seg->d_live) (void)hipFree(seg->d_live);
     seg->d_live = nullptr;
@@ -395,6 +396,26 @@ int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_
   seg->accept[key] = (uint64_t*)p;
   *out = (uint64_t*)p;
   return 0;
+}
+
+int64_t nrtgpu::rt::live_vector_count(const nrtgpu_seg* seg, const FieldData& f) {
+  if (seg->h_live.empty()) return f.n_vec;
+  if (f.live_vec_version.load(std::memory_order_acquire) == seg->live_version) {
+    const int64_t c = f.live_vec.load(std::memory_order_acquire);
+    if (c >= 0) return c;
+  }
+  int64_t n = 0;
+  const uint64_t* live = seg->h_live.data();
+  if (f.h_ord_to_doc.empty()) {  // row == docid
+    const int32_t full = f.n_vec / 64;
+    for (int32_t i = 0; i < full; ++i) n += __builtin_popcountll(live[i]);
+    if (f.n_vec & 63) n += __builtin_popcountll(live[full] & ((1ull << (f.n_vec & 63)) - 1ull));
+  } else {
+    for (int32_t d : f.h_ord_to_doc) n += (live[d >> 6] >> (d & 63)) & 1ull;
+  }
+  f.live_vec.store(n, std::memory_order_release);
+  f.live_vec_version.store(seg->live_version, std::memory_order_release);
+  return n;
 }
 
 extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {

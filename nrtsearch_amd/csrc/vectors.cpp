@@ -67,7 +67,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       auto fit = seg->fields.find(field_id);
       if (fit == seg->fields.end() || !fit->second.d_vectors) continue;
       const FieldData& f = fit->second;
-      total_vec += f.n_vec;
+      total_vec += live_vector_count(seg, f);   // (deleted docs are masked inside the kernel and are no hits)
       const uint64_t* accept = seg->d_live;  // (vectors are not re-coded for liveDocs: always the mask)
       if (knn_request && filter_mask != 0)
         if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
@@ -104,7 +104,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         if (o->scores) o->scores[i] = key_score(keys[(size_t)q * k_stride + i]);
       }
       o->n_hits = m;
-      o->total_hits = total_vec;   // every doc with a vector matches an exact vector query (deletes not subtracted)
+      o->total_hits = total_vec;   // every live doc with a vector matches an exact vector query
       o->total_hits_is_lower_bound = 0;
       if (knn_request) {
         o->total_hits = m;  // the rewritten knn query matches exactly the docs it returns

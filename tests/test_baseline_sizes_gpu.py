@@ -1,0 +1,170 @@
+"""Parity at BASELINE.json's configuration sizes, run by the driver (`-m gpu`): C3 (10M docs, 5-term disjunction,
+top-1000; 256 queries, plain and with 1 % deletes), C2 (1M docs, 2-term, top-100; 256 queries), a C4-shaped exact kNN
+(2M x 768 fp32 cosine, top-100) against an fp64 reference with a real rank assertion, and the C5-shaped hybrid
+(5M docs, BM25 recall-1000 -> 768-d cosine rescore -> top-100; 32 queries).  BM25: docids, ranks and score bits
+bit-exact against the CPU oracle's EXHAUSTIVE scorer (one C call, OpenMP over queries).  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from nrtsearch_amd import _lib, api, synth, workload
+
+pytestmark = pytest.mark.gpu
+N_Q = 256
+
+
+def _cpus():
+    return max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+
+
+def _check_batch(got, exp, k, thr=1000):
+    docs, scores, n, total, gte, _ = exp
+    bad = []
+    for qi, g in enumerate(got):
+        m = int(n[qi])
+        ok = (g.docs.tolist() == docs[qi, :m].tolist() and g.scores.view(np.uint32).tolist() == scores[qi, :m].view(np.uint32).tolist()
+              and g.relation_gte == bool(gte[qi])
+              and ((max(thr, k) < g.total_hits <= int(total[qi])) if gte[qi] else g.total_hits == int(total[qi])))
+        if not ok:
+            bad.append(qi)
+    assert not bad, f"{len(bad)} of {len(got)} queries differ from the oracle: {bad[:8]}"
+
+
+def _vectors(rng, n, dim):
+    """n x dim fp32, uniform in [-1, 1) (the generator's fastest path: these tests move gigabytes)."""
+    v = rng.random((n, dim), dtype=np.float32)
+    v *= 2.0
+    v -= 1.0
+    return v
+
+
+def _deletes(corpus, fraction, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for s in corpus.segments:
+        alive = rng.random(s.max_doc) >= fraction
+        padded = np.zeros(((s.max_doc + 63) // 64) * 64, dtype=bool)
+        padded[: s.max_doc] = alive
+        s.live_bits = np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+
+
+@pytest.mark.parametrize("wname", ["C3", "C2"])
+def test_bm25_full_size_against_the_exhaustive_oracle(oracle, wname):
+    w = getattr(workload, wname)
+    qr = synth.make_queries(N_Q, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr)
+    ctx = api.GpuContext(0, max_batch=N_Q)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    try:
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        queries = workload.boolean_queries(qr)
+        mgr = api.TopScoreDocCollectorManager(w.k)
+        sample = [q.tolist() for q in qr]
+        # plain index
+        ctx.reset_stats()
+        got = sr.search_batch(queries, [mgr] * N_Q)
+        assert ctx.stats()["maxscore_items"] >= N_Q - 8       # the default route for this workload: dynamic pruning
+        exp = oracle.PreparedBatch(corpus, sample, w.k).run(False, _cpus())
+        _check_batch(got, exp, w.k)
+        # 1 % deletes (liveDocs folded into the posting columns)
+        _deletes(corpus, 0.01, 99)
+        for leaf, seg in zip(leaves, corpus.segments):
+            leaf.set_live_docs(seg.live_bits)
+        got = sr.search_batch(queries, [mgr] * N_Q)
+        exp = oracle.PreparedBatch(corpus, sample, w.k).run(False, _cpus())
+        _check_batch(got, exp, w.k)
+        # ScoreMode.COMPLETE: exhaustive route, exact counts
+        mgr_c = api.TopScoreDocCollectorManager(w.k, total_hits_threshold=2**31 - 1)
+        got = sr.search_batch(queries[:64], [mgr_c] * 64)
+        exp = oracle.PreparedBatch(corpus, sample[:64], w.k, total_hits_threshold=2**31 - 1).run(False, _cpus())
+        _check_batch(got, exp, w.k, thr=2**31 - 1)
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()
+
+
+def test_knn_c4_shape_against_fp64(oracle):
+    n, dim, k, nq = 2_000_000, 768, 100, 40
+    rng = np.random.default_rng(777)
+    n_seg = 4
+    per = n // n_seg
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves, host = [], []
+    try:
+        for si in range(n_seg):
+            v = _vectors(rng, per, dim)
+            host.append(v)
+            leaf = api.GpuSegment(ctx, per, si * per)
+            leaf.add_vectors(0, v)
+            leaf.seal()
+            leaves.append(leaf)
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics())
+        queries = np.random.default_rng(778).standard_normal((nq, dim)).astype(np.float32)
+        got = sr.knn_exact(0, "cosine", queries, k)
+        for qi in (0, 19, 39):
+            q = queries[qi].astype(np.float64)
+            sc = np.empty(n, dtype=np.float64)
+            for si, v in enumerate(host):   # fp64 reference, a chunk at a time
+                for a in range(0, per, 250_000):
+                    blk = v[a: a + 250_000].astype(np.float64)
+                    cos = (blk @ q) / (np.linalg.norm(blk, axis=1) * np.linalg.norm(q))
+                    sc[si * per + a: si * per + a + len(blk)] = np.maximum((1.0 + cos) / 2.0, 0.0)
+            order = np.lexsort((np.arange(n), -sc))[:k]
+            gd, gs = got[qi].docs, got[qi].scores
+            assert got[qi].total_hits == n and len(gd) == k and len(set(gd.tolist())) == k
+            assert np.allclose(gs, sc[order], rtol=2e-5, atol=2e-6)
+            for r in range(k):   # a docid that differs at its rank must be a near-tie of the reference's doc there
+                if gd[r] != order[r]:
+                    assert abs(sc[gd[r]] - sc[order[r]]) <= 2e-5 * sc[order[r]] + 2e-6, f"query {qi} rank {r}"
+            assert len(set(gd.tolist()) & set(order.tolist())) >= k - 2
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()
+
+
+def test_hybrid_c5_shape(oracle):
+    n_docs, dim, nq, recall, window = 5_000_000, 768, 32, 1000, 100
+    w = workload.Workload("C5-shaped: 5M docs, recall-1000 -> rescore top-100", n_docs, 5, recall, nq, 4)
+    qr = synth.make_queries(nq, 5, 10000)
+    corpus = workload.build_shard_corpus(w, qr)
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves, host = [], []
+    rng = np.random.default_rng(7)
+    try:
+        for seg in corpus.segments:
+            v = _vectors(rng, seg.max_doc, dim)
+            host.append(v)
+            leaf = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
+            leaf.add_field_norms(0, seg.norms)
+            leaf.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+            leaf.add_vectors(7, v)
+            leaf.seal()
+            leaves.append(leaf)
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        queries = workload.boolean_queries(qr)
+        mgr = api.TopScoreDocCollectorManager(recall)
+        qv = np.random.default_rng(8).standard_normal((nq, dim)).astype(np.float32)
+        fused = sr.search_hybrid_batch(queries, [mgr] * nq, 7, "cosine", qv, window, 1.0, 2.0)
+        first = oracle.PreparedBatch(corpus, [q.tolist() for q in qr], recall).run(False, _cpus())
+        bases = [s.doc_base for s in corpus.segments]
+        for qi in range(nq):
+            docs, scores = first[0][qi, : first[2][qi]], first[1][qi, : first[2][qi]]
+            exp = []
+            for doc, f in zip(docs.tolist(), scores.tolist()):   # QueryRescore.combine over the oracle's first pass
+                si = max(i for i, b in enumerate(bases) if b <= doc)
+                second = float(oracle.vector_score(0, qv[qi], host[si][doc - bases[si]]))
+                exp.append((float(oracle.rescore_combine(f, True, second, 1.0, 2.0)), doc))
+            exp.sort(key=lambda t: (-t[0], t[1]))
+            got = fused[qi]
+            assert len(got.docs) == window and got.relation_gte
+            assert np.allclose(got.scores, [s for s, _ in exp[:window]], rtol=1e-5, atol=1e-6)
+            ref = dict((d, s) for s, d in exp)
+            for r, d in enumerate(got.docs.tolist()):   # every returned doc was recalled; off-rank only among near-ties
+                assert d in ref
+                assert abs(ref[d] - exp[r][0]) <= 1e-5 * abs(exp[r][0]) + 1e-6
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()
