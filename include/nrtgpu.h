@@ -164,8 +164,19 @@ typedef struct {
   float*   scores;                     /* out: (score desc, doc asc) */
   int64_t  total_hits;                 /* out: live matching docs: the exact number, or -- when the query ran with
                                         * dynamic pruning (MaxScore route) -- a lower bound above totalHitsThreshold */
-  int32_t  total_hits_is_lower_bound;  /* out: 1 == GREATER_THAN_OR_EQUAL_TO */
+  int32_t  total_hits_is_lower_bound;  /* out: 1 == GREATER_THAN_OR_EQUAL_TO: some slice of the searcher (nrtgpu_set_slicing)
+                                        * collected more than max(totalHitsThreshold, numHits) hits and numHits hits were returned */
 } nrtgpu_topdocs;
+
+/* Slicing of the searcher this context serves (MyIndexSearcher.SlicingParams: the index live settings sliceMaxDocs,
+ * sliceMaxSegments, virtualShards; src/main/java/com/yelp/nrtsearch/server/search/MyIndexSearcher.java:79-208).  The
+ * reference runs one collector per slice and merges: TotalHits.relation is GREATER_THAN_OR_EQUAL_TO iff SOME SLICE
+ * collected more than max(totalHitsThreshold, numHits) hits (LazyQueueTopScoreDocCollector.java:176-199 per slice,
+ * LazyQueueTopScoreDocCollectorManager.java:137-144) -- 1500 hits spread over ten slices are EQUAL_TO 1500.  The
+ * library derives the same slices from the leaves of each call (maxDoc, live docs, docBase) and reports the relation
+ * by that rule; dynamic pruning is used only where some slice certainly passes the threshold.  Defaults: 250000, 5, 1.
+ * slice_max_docs == 0: the whole search counts as one slice. */
+int  nrtgpu_set_slicing(nrtgpu_ctx* ctx, int32_t slice_max_docs, int32_t slice_max_segments, int32_t virtual_shards);
 
 int  nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                         const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);
@@ -211,7 +222,9 @@ int  nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* co
 
 /* TopDocs.merge of n_lists per-GPU results laid out as the all-gather leaves them:
  * d_keys_in[list][query][k_stride], d_counts_in[list][query], d_hits_in[list][query] (device).
- * Writes host-side topdocs (docs/scores/total_hits/relation) for each query. */
+ * Writes host-side topdocs (docs/scores/total_hits/relation) for each query.  total_hits = the sum of the lists' counts;
+ * the relation is GREATER_THAN_OR_EQUAL_TO iff some list's count carries the tag (a slice of that shard passed the
+ * threshold, or the shard pruned) and numHits hits are returned.  total_hits_thresholds is kept for the signature. */
 int  nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride,
                               const void* d_keys_in, const void* d_counts_in, const void* d_hits_in,
                               const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out);

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_knn_search", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
-    "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile",
+    "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile", "nrtgpu_set_slicing",
 ]
 
 
@@ -143,6 +143,7 @@ def load() -> C.CDLL:
     L.nrtgpu_reset_stats.restype = None
     L.nrtgpu_get_scan_profile.argtypes = [vp, vp]
     L.nrtgpu_get_maxscore_profile.argtypes = [vp, vp]
+    L.nrtgpu_set_slicing.argtypes = [vp, i32, i32, i32]
     _lib = L
     return L
 

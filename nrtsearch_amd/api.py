@@ -152,6 +152,10 @@ class GpuContext:
         self._h = h
         self.max_batch = max_batch
 
+    def set_slicing(self, slice_max_docs: int = 250_000, slice_max_segments: int = 5, virtual_shards: int = 1) -> None:
+        """MyIndexSearcher.SlicingParams of the searcher this context serves (TotalHits.relation is decided per slice)."""
+        _lib.check(_lib.load().nrtgpu_set_slicing(self._h, int(slice_max_docs), int(slice_max_segments), int(virtual_shards)))
+
     def exchange_open(self, shm_name: str, world: int, rank: int) -> None:
         """Cross-GPU bound exchange (include/nrtgpu.h); synchronise the ranks once before the first search."""
         _lib.check(_lib.load().nrtgpu_exchange_open(self._h, shm_name.encode(), int(world), int(rank)))

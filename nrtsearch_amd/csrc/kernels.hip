@@ -1062,6 +1062,44 @@ void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* q
                      n_leaves, out);
 }
 
+// slice_relation_kernel: TotalHits.relation by the reference's rule -- GREATER_THAN_OR_EQUAL_TO iff some slice's
+// collector saw more than max(totalHitsThreshold, numHits) hits.  One thread per query sums its items' exact hit
+// counts per slice (an item never spans slices when the relation can depend on it: planner.cpp) and tags the merged
+// count with kHitsPrunedUnit, the same tag the MaxScore route's items carry through the merge's sum.
+__global__ __launch_bounds__(256)
+void slice_relation_kernel(const uint64_t* __restrict__ item_hits, const uint32_t* __restrict__ item_slice,
+                           const uint32_t* __restrict__ list_idx, const uint32_t* __restrict__ q_base,
+                           const uint32_t* __restrict__ q_nlists, const uint32_t* __restrict__ q_floor,
+                           uint64_t* __restrict__ out_hits, uint32_t n) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  if ((out_hits[q] >> 48) != 0ull) return;  // already tagged (pruned items)
+  const uint32_t base = q_base[q], nl = q_nlists[q];
+  const uint64_t floor_ = q_floor[q];
+  bool gte = false;
+  for (uint32_t i = 0; i < nl && !gte; ++i) {
+    const uint32_t it = list_idx[base + i];
+    const uint32_t sl = item_slice[it];
+    if (sl == 0xFFFFFFFFu) continue;
+    bool first = true;   // sum a slice once: at its first item
+    for (uint32_t j = 0; j < i; ++j) first = first && item_slice[list_idx[base + j]] != sl;
+    if (!first) continue;
+    uint64_t sum = 0;
+    for (uint32_t j = i; j < nl; ++j) {
+      const uint32_t jt = list_idx[base + j];
+      if (item_slice[jt] == sl) sum += item_hits[jt] & (kHitsPrunedUnit - 1ull);
+    }
+    gte = sum > floor_;
+  }
+  if (gte) out_hits[q] += kHitsPrunedUnit;
+}
+void launch_slice_relation(hipStream_t stream, const uint64_t* item_hits, const uint32_t* item_slice, const uint32_t* list_idx,
+                           const uint32_t* q_base, const uint32_t* q_nlists, const uint32_t* q_floor, uint64_t* out_hits, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(slice_relation_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, item_hits, item_slice, list_idx, q_base,
+                     q_nlists, q_floor, out_hits, n);
+}
+
 // Device-resident results (multi-GPU path): a query that ran on the MaxScore route reports the planner's certain
 // lower bound, tagged as such (plan.h: kHitsPrunedUnit), instead of the number of docs the kernel happened to evaluate.
 __global__ __launch_bounds__(256)

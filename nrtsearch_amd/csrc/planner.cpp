@@ -152,13 +152,14 @@ LeafSetCache::~LeafSetCache() {
 // tables go to the clauses with the most postings; terms of a (query, leaf) sorted densest first.
 // Offsets (term_begin, cache offsets) are relative to the piece.
 static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, int32_t n_segs, const int32_t* n_deleted,
-                            const nrtgpu_bm25_query* queries, int q_begin, int q_end, PlanPiece& pc, uint32_t* q_qs_begin,
+                            const int32_t* slice_of_leaf, int32_t n_slices, const nrtgpu_bm25_query* queries, int q_begin, int q_end, PlanPiece& pc, uint32_t* q_qs_begin,
                             uint32_t* q_qs_cnt, uint32_t* qs_begin, DQExpand* qexpand,
                             std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, int prune,
                             std::vector<int64_t>& q_lower) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
   std::vector<std::shared_ptr<const TermLeaves>> ents;
+  std::vector<int64_t> slice_sum((size_t)std::max(n_slices, 1));
   bool any_deleted = false, plain = true;
   for (int si = 0; si < n_segs; ++si) {
     any_deleted = any_deleted || n_deleted[si] != 0;
@@ -210,16 +211,31 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     if (prune != 0 && !(prune == 2 && q.has_after) && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
         !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
       if (plain) {
+        // the reference counts per slice (one collector each): some slice must certainly pass the threshold
+        const int64_t floor_ = std::max<int64_t>(q.total_hits_threshold, q.k);
+        int64_t best_slice = 0;
         for (int t = 0; t < q.n_terms; ++t) {
-          int64_t certain = term_total[(size_t)t];
-          if (any_deleted) {
-            certain = 0;
-            const uint32_t* cnt = ents[(size_t)t]->count.data();
-            for (int si = 0; si < n_segs; ++si) certain += std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
+          const uint32_t* cnt = ents[(size_t)t]->count.data();
+          int64_t certain = 0;
+          if (n_slices <= 1) {
+            certain = term_total[(size_t)t];
+            if (any_deleted) {
+              certain = 0;
+              for (int si = 0; si < n_segs; ++si) certain += std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
+            }
+            best_slice = std::max(best_slice, certain);
+          } else {
+            std::fill(slice_sum.begin(), slice_sum.end(), 0);
+            for (int si = 0; si < n_segs; ++si) {
+              const int64_t c = std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
+              slice_sum[(size_t)slice_of_leaf[si]] += c;
+              certain += c;
+            }
+            for (int sl = 0; sl < n_slices; ++sl) best_slice = std::max(best_slice, slice_sum[(size_t)sl]);
           }
-          lower = std::max(lower, certain);
+          lower = std::max(lower, certain);   // what is reported: certain matches of the whole search
         }
-        if (lower <= std::max<int64_t>(q.total_hits_threshold, q.k)) lower = 0;
+        if (best_slice <= floor_) lower = 0;
       }
     }
     q_lower[(size_t)qi] = lower;
@@ -322,8 +338,26 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   hp.qs_begin.assign((size_t)n_queries * (size_t)std::max(n_segs, 1), 0xFFFFFFFFu);
   std::vector<int32_t> n_deleted((size_t)std::max(n_segs, 1), 0);
   for (int si = 0; si < n_segs; ++si) n_deleted[(size_t)si] = segs[si]->n_deleted;
+  // the searcher's slices over these leaves (MyIndexSearcher.slices / slicesForShards): relation and route depend on them
+  std::vector<int32_t> slice_of_leaf((size_t)std::max(n_segs, 1), 0);
+  int32_t n_slices = 1;
+  if (ctx->slice_max_docs.load() > 0 && n_segs > 0) {
+    std::vector<hostmath::LeafInfo> all((size_t)n_segs);
+    int32_t base = 0;
+    for (int32_t i = 0; i < n_segs; ++i) {
+      all[(size_t)i] = {i, segs[i]->max_doc, segs[i]->max_doc - segs[i]->n_deleted, doc_bases ? doc_bases[i] : base};
+      base += segs[i]->max_doc;
+    }
+    const int32_t vs = ctx->virtual_shards.load();
+    const std::vector<std::vector<int32_t>> sl = vs > 1
+        ? hostmath::slices_for_shards(all, vs, ctx->slice_max_docs.load(), ctx->slice_max_segments.load(), nullptr)
+        : hostmath::slices(all, ctx->slice_max_docs.load(), ctx->slice_max_segments.load(), all);
+    n_slices = (int32_t)std::max<size_t>(sl.size(), 1);
+    for (size_t s_ = 0; s_ < sl.size(); ++s_)
+      for (int32_t li : sl[s_]) slice_of_leaf[(size_t)li] = (int32_t)s_;
+  }
   auto work = [&](int t) {
-    resolve_queries(*hp.lsc, segs, n_segs, n_deleted.data(), queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t],
+    resolve_queries(*hp.lsc, segs, n_segs, n_deleted.data(), slice_of_leaf.data(), n_slices, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t],
                     q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower);
   };
   ctx->pool->run(n_thr, work);
@@ -383,7 +417,9 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // batch on one CU.  target_items == 0 => one share per CU.
   const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : (int64_t)std::max(ctx->n_cus, 1);
   const int64_t min_item_cost = 1 << 17;
-  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; };
+  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; uint32_t slice; };
+  const uint32_t kAnySlice = 0xFFFFFFFFu;
+  std::vector<QS> by_slice;
   std::vector<Pending> pend;
   std::vector<int64_t> q_costs((size_t)n_queries, 0), q_items((size_t)n_queries, 0);
   for (int qi = 0; qi < n_queries; ++qi)
@@ -397,11 +433,30 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     if (q_cost == 0) continue;
     const int64_t n_it = q_items[(size_t)qi];
     const double budget = (double)q_cost / (double)n_it;
-    Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
+    // The relation of an exhaustively scanned query with a finite threshold is decided per slice (slice_relation_kernel):
+    // its items then never span two slices.  COMPLETE mode never reports GTE and the MaxScore route tags its own items.
+    const bool per_slice = n_slices > 1 && hp.q_lower[(size_t)qi] == 0 && queries[qi].total_hits_threshold != INT32_MAX;
+    const QS* qsv = qs_of(qi);
+    const uint32_t n_qs = q_qs_cnt[(size_t)qi];
+    if (per_slice) {
+      by_slice.assign(qsv, qsv + n_qs);
+      std::stable_sort(by_slice.begin(), by_slice.end(), [&](const QS& a, const QS& b) { return slice_of_leaf[(size_t)a.seg] < slice_of_leaf[(size_t)b.seg]; });
+      qsv = by_slice.data();
+    }
+    auto slice_of = [&](const QS& qs) { return n_slices > 1 && hp.q_lower[(size_t)qi] == 0 ? (uint32_t)slice_of_leaf[(size_t)qs.seg]
+                                                                                         : (n_slices > 1 ? kAnySlice : 0u); };
+    Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0, n_qs ? slice_of(qsv[0]) : 0u};
     double filled = 0.0;
-    for (uint32_t j = 0; j < q_qs_cnt[(size_t)qi]; ++j) {
-      const QS& qs = qs_of(qi)[j];
+    for (uint32_t j = 0; j < n_qs; ++j) {
+      const QS& qs = qsv[j];
       const nrtgpu_seg* seg = segs[qs.seg];
+      if (per_slice && cur.n_parts > 0 && slice_of(qs) != cur.slice) {  // slice boundary: close the item
+        pend.push_back(cur);
+        cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0, slice_of(qs)};
+        filled = 0.0;
+      }
+      if (cur.n_parts == 0) cur.slice = slice_of(qs);
+      else if (!per_slice && slice_of(qs) != cur.slice) cur.slice = kAnySlice;
       const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
       const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
       if (int rc = accept_set_of(seg, queries[qi].filter_mask, queries[qi].must_not_mask, &accept)) return rc;
@@ -428,7 +483,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
         tb += take;
         if (filled >= budget * 0.999) {  // item full: close it
           pend.push_back(cur);
-          cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0};
+          cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0, slice_of(qs)};
           filled = 0.0;
         }
       }
@@ -438,12 +493,13 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       // finish without a single compaction, never publish its quantile, and with one peer silent the bound
       // exchange between the query's items never forms (kernels.hip: peers_bound).  It joins the item before it.
       if (!pend.empty() && pend.back().query == (uint32_t)qi && (double)cur.cost < 0.5 * budget &&
-          pend.back().part_begin + pend.back().n_parts == cur.part_begin) {
+          pend.back().part_begin + pend.back().n_parts == cur.part_begin && (!per_slice || pend.back().slice == cur.slice)) {
         Pending& prev = pend.back();
         for (uint32_t pi2 = 0; pi2 < cur.n_parts; ++pi2) hp.parts[cur.part_begin + pi2].tile_offset += prev.tiles;
         prev.n_parts += cur.n_parts;
         prev.tiles += cur.tiles;
         prev.cost += cur.cost;
+        if (prev.slice != cur.slice) prev.slice = kAnySlice;
       } else {
         pend.push_back(cur);
       }
@@ -458,6 +514,12 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   hp.n_ms_items = 0;
   for (const Pending& a : pend) hp.n_ms_items += hp.q_lower[a.query] > 0 ? 1u : 0u;
   hp.items.resize(pend.size());
+  hp.item_slice.resize(pend.size());
+  for (size_t i = 0; i < pend.size(); ++i) hp.item_slice[i] = hp.q_lower[pend[i].query] > 0 ? kAnySlice : pend[i].slice;
+  hp.q_gte_floor.resize((size_t)n_queries);
+  for (int qi = 0; qi < n_queries; ++qi)   // COMPLETE mode: nothing exceeds it
+    hp.q_gte_floor[(size_t)qi] = queries[qi].total_hits_threshold == INT32_MAX ? 0xFFFFFFFFu
+                                                                               : (uint32_t)std::max(queries[qi].total_hits_threshold, queries[qi].k);
   std::vector<std::vector<uint32_t>> lists((size_t)n_queries);
   for (size_t i = 0; i < pend.size(); ++i) {
     DItem it{};

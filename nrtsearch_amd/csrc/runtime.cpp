@@ -229,6 +229,14 @@ extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
   delete ctx;
 }
 
+extern "C" int nrtgpu_set_slicing(nrtgpu_ctx* ctx, int32_t slice_max_docs, int32_t slice_max_segments, int32_t virtual_shards) {
+  if (!ctx || slice_max_docs < 0 || slice_max_segments <= 0 || virtual_shards <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad slicing parameters");
+  ctx->slice_max_docs = slice_max_docs;
+  ctx->slice_max_segments = slice_max_segments;
+  ctx->virtual_shards = virtual_shards;
+  return NRTGPU_OK;
+}
+
 extern "C" int nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out) {
   if (!ctx || !out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   std::lock_guard<std::mutex> lk(ctx->stats_mu);

@@ -49,6 +49,8 @@ void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t
                       const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs);
 void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* qterms, const uint32_t* out_begin, uint32_t n_queries,
                          uint32_t n_leaves, DTerm* out);
+void launch_slice_relation(hipStream_t stream, const uint64_t* item_hits, const uint32_t* item_slice, const uint32_t* list_idx,
+                           const uint32_t* q_base, const uint32_t* q_nlists, const uint32_t* q_floor, uint64_t* out_hits, uint32_t n);
 void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits, uint32_t n);
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
@@ -349,6 +351,8 @@ struct nrtgpu_ctx {
   int co_inflight_queries = 0;                // ... and how many queries they hold
   int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
   int32_t co_linger_us = 150;
+  // MyIndexSearcher.SlicingParams of the searcher this context serves (nrtgpu_set_slicing)
+  std::atomic<int32_t> slice_max_docs{250000}, slice_max_segments{5}, virtual_shards{1};
   std::unique_ptr<nrtgpu::rt::WorkPool> pool;   // helper threads of the host side (planning, unpacking results)
   // planner caches, one per leaf set seen lately (most recent first)
   std::mutex lsc_mu;
@@ -450,6 +454,8 @@ struct HostPlan {
   // MaxScore route (maxscore.hip): items [0, n_ms_items) run it, the others the exhaustive scan
   uint32_t n_ms_items = 0;
   std::vector<int64_t> q_lower;     // per query on that route: live docs certain to match (> totalHitsThreshold), else 0
+  std::vector<uint32_t> item_slice; // per item: the slice (MyIndexSearcher.slices) its parts belong to; ~0: several (no relation from it)
+  std::vector<uint32_t> q_gte_floor;  // per query: max(totalHitsThreshold, numHits), what a slice's hits must exceed for GTE
   int64_t ms_postings = 0;          // postings of the queries on that route (algorithmic work, as `postings`)
 };
 

@@ -36,6 +36,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_theta = pc.take(hp.theta_init.size() * 8);  // uploaded with the plan, then updated by the kernel
   const size_t o_quant = pc.take(hp.list_idx.size() * 8);    // per item: published quantile bound (zeros)
   const size_t o_lower = pc.take(ext_hits ? hp.q_lower.size() * 8 : 0);  // device-resident results: certain lower bounds
+  const size_t o_islice = pc.take(hp.item_slice.size() * 4);
+  const size_t o_floor = pc.take(hp.q_gte_floor.size() * 4);
   const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
   const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
   const size_t plan_bytes = pc.off;
@@ -56,6 +58,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
   memset(hb + o_quant, 0, hp.list_idx.size() * 8);
   if (ext_hits) memcpy(hb + o_lower, hp.q_lower.data(), hp.q_lower.size() * 8);
+  if (!hp.item_slice.empty()) memcpy(hb + o_islice, hp.item_slice.data(), hp.item_slice.size() * 4);
+  memcpy(hb + o_floor, hp.q_gte_floor.data(), hp.q_gte_floor.size() * 4);
   if (use_xch) {
     DExchange x{};
     const size_t stride = (size_t)ctx->cfg.max_batch;
@@ -116,6 +120,10 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                     (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
                     (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
                     k_stride_out);
+  // TotalHits.relation by the reference's per-slice rule, tagged into the merged counts
+  launch_slice_relation(st, (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_islice), (const uint32_t*)(db + o_lidx),
+                        (const uint32_t*)(db + o_qbase), (const uint32_t*)(db + o_qnl), (const uint32_t*)(db + o_floor), ohits,
+                        (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
   if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
   HIP_TRY(hipGetLastError());
@@ -152,21 +160,16 @@ static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_q
   ctx->stats.host_plan_ms += plan_ms;
 }
 
-// relation: GREATER_THAN_OR_EQUAL_TO exactly where LazyQueueTopScoreDocCollector would have started
-// publishing a min competitive score: totalHits > max(threshold, numHits) and the queue is full
-// (LazyQueueTopScoreDocCollector.java:176-199, …Manager.java:102).
-static inline int32_t relation_gte(int64_t total_hits, int32_t n_hits, int32_t k, int32_t threshold) {
-  const int64_t thr = std::max<int64_t>(threshold, k);
-  return (total_hits > thr && n_hits == k) ? 1 : 0;
-}
-
-// `hits` as the merge leaves it: low 48 bits = docs counted, high 16 = items of the query that skipped docs on the
-// MaxScore route (plan.h: kHitsPrunedUnit).  With none the count is exact and the relation follows from it; else the
-// count is a lower bound and what is reported is `lower` -- the live docs the planner knew to match, more than the
-// threshold, the same on every run -- as GREATER_THAN_OR_EQUAL_TO, which is what the reference reports once its collectors have started
-// skipping (the value itself is an artefact of the traversal there as well, SURVEY 7 hard part 3).
-static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, const int32_t k, const int32_t threshold,
-                           int64_t lower, nrtgpu_topdocs* out) {
+// `hits` as the device leaves it: low 48 bits = a count, high 16 != 0 = the relation is GREATER_THAN_OR_EQUAL_TO
+// (plan.h: kHitsPrunedUnit) -- some slice of the searcher collected more than max(totalHitsThreshold, numHits) hits,
+// where one reference collector starts publishing a min competitive score (LazyQueueTopScoreDocCollector.java:176-199;
+// slices: MyIndexSearcher.java:163-208; reduce: LazyQueueTopScoreDocCollectorManager.java:137-144).  The tag comes from
+// slice_relation_kernel (exhaustive scan: the count is exact) or from the MaxScore route's items (the count is a lower
+// bound; what is reported then is `lower` -- the live docs the planner knew to match, the same on every run: the
+// reference's own value there is an artefact of its traversal, SURVEY 7 hard part 3).  Either way the queue must be
+// full: a page of a searchAfter walk that returns fewer than numHits hits is EQUAL_TO.
+static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, const int32_t k, int64_t lower, uint32_t n_first,
+                           nrtgpu_topdocs* out) {
   const int32_t cap = out->capacity > 0 ? out->capacity : k;
   const int32_t m = std::min<int32_t>((int32_t)n, cap);
   // two plain loops (vectorisable): doc = ~low word, score = high word reinterpreted
@@ -176,15 +179,12 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
     for (int32_t i = 0; i < m; ++i) sc[i] = (uint32_t)(keys[i] >> 32);
   out->n_hits = m;
   const int64_t counted = (int64_t)(hits & (kHitsPrunedUnit - 1));
-  if ((hits >> 48) != 0) {
-    // (not max(counted, lower): how many docs were evaluated depends on the order theta grew in.  Merged per-GPU
-    // results carry their shards' bounds in `counted`: nrtgpu_search_bm25_batch_device)
-    out->total_hits = lower > 0 ? lower : counted;
-    out->total_hits_is_lower_bound = 1;
-  } else {
-    out->total_hits = counted;
-    out->total_hits_is_lower_bound = relation_gte(counted, (int32_t)n, k, threshold);
-  }
+  // (lower > 0: the query took the MaxScore route, i.e. the planner KNEW some slice passes the threshold, whether
+  // or not the kernel then skipped anything.  Merged per-GPU results carry their shards' bounds in `counted`:
+  // nrtgpu_search_bm25_batch_device)
+  const bool gte = ((hits >> 48) != 0 || lower > 0) && n_first == (uint32_t)k;
+  out->total_hits = (gte && lower > 0) ? lower : counted;
+  out->total_hits_is_lower_bound = gte ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,7 +236,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     ctx->pool->run(n_chunks, [&](int c) {
       const int q0 = (int)((int64_t)n_queries * c / n_chunks), q1 = (int)((int64_t)n_queries * (c + 1) / n_chunks);
       for (int qi = q0; qi < q1; ++qi)
-        unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, queries[qi].total_hits_threshold, hp.q_lower[(size_t)qi], &out[qi]);
+        unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, hp.q_lower[(size_t)qi], cnts[qi], &out[qi]);
     });
   }
   if (call_trace)
@@ -346,10 +346,8 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   const uint64_t* hits = (const uint64_t*)(ha + oh_h);
   for (int qi = 0; qi < n_queries; ++qi) {
     // QueryRescorer keeps the first pass's TotalHits; the window only trims the hits
-    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi], std::min<int32_t>(window, NRTGPU_MAX_K), queries[qi].total_hits_threshold,
-                   hp.q_lower[(size_t)qi], &out[qi]);
-    if ((hits[qi] >> 48) == 0)  // exact count: the relation is the first pass's (its queue, not the window)
-      out[qi].total_hits_is_lower_bound = relation_gte((int64_t)hits[qi], (int32_t)first_cnts[qi], queries[qi].k, queries[qi].total_hits_threshold);
+    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi], std::min<int32_t>(window, NRTGPU_MAX_K), hp.q_lower[(size_t)qi],
+                   first_cnts[qi] == (uint32_t)queries[qi].k ? (uint32_t)std::min<int32_t>(window, NRTGPU_MAX_K) : 0xFFFFFFFFu, &out[qi]);
   }
   account(ctx, slot, hp, n_queries, plan_ms);
   return NRTGPU_OK;
@@ -660,7 +658,7 @@ extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_
     ctx->pool->run(n_chunks, [&](int c) {
       const int q0 = (int)((int64_t)n_queries * c / n_chunks), q1 = (int)((int64_t)n_queries * (c + 1) / n_chunks);
       for (int qi = q0; qi < q1; ++qi)
-        unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], total_hits_thresholds[qi], 0, &out[qi]);
+        unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], 0, cnts[qi], &out[qi]);
     });
   }
   return NRTGPU_OK;

@@ -183,7 +183,44 @@ def topdocs_merge(top_n: int, lists: Sequence[Tuple[np.ndarray, np.ndarray]]):
     return od[:n].copy(), os_[:n].copy()
 
 
-# ---- whole-index search (single collector over all leaves == one Lucene slice) -----------------
+# ---- slices ----------------------------------------------------------------------------------------
+DEFAULT_SLICING = (250_000, 5)   # the reference's sliceMaxDocs / sliceMaxSegments defaults
+
+
+def leaf_slices(max_docs: Sequence[int], doc_bases: Sequence[int], slice_max_docs: int = 250_000,
+                slice_max_segments: int = 5) -> List[List[int]]:
+    """MyIndexSearcher.slices(leaves, sliceMaxDocs, sliceMaxSegments)
+    (/root/reference/src/main/java/com/yelp/nrtsearch/server/search/MyIndexSearcher.java:163-208): leaves sorted by
+    maxDoc descending (stable); a leaf above sliceMaxDocs is a slice of its own; the others are packed into the
+    current group until it holds sliceMaxSegments leaves or more than sliceMaxDocs docs; each slice's leaves in
+    docBase order.  Returns lists of leaf indices."""
+    order = sorted(range(len(max_docs)), key=lambda i: -int(max_docs[i]))
+    groups: List[List[int]] = []
+    cur, doc_sum = None, 0
+    for i in order:
+        if max_docs[i] > slice_max_docs:
+            groups.append([i])
+            continue
+        if cur is None:
+            groups.append([i])
+            cur = len(groups) - 1
+        else:
+            groups[cur].append(i)
+        doc_sum += int(max_docs[i])
+        if len(groups[cur]) >= slice_max_segments or doc_sum > slice_max_docs:
+            cur, doc_sum = None, 0
+    for g in groups:
+        g.sort(key=lambda i: int(doc_bases[i]))
+    return groups
+
+
+def corpus_slices(corpus, slicing=DEFAULT_SLICING) -> List[List[int]]:
+    if slicing is None:
+        return [list(range(len(corpus.segments)))]
+    return leaf_slices([s.max_doc for s in corpus.segments], [s.doc_base for s in corpus.segments], slicing[0], slicing[1])
+
+
+# ---- whole-index search: one collector per slice, TopDocs.merge (LazyQueueTopScoreDocCollectorManager.java:137-144) ---
 def bm25_query_stats(corpus, term_ids: Sequence[int], boosts: Optional[Sequence[float]] = None,
                      k1: float = 1.2, b: float = 0.75):
     """Index-global CollectionStatistics/TermStatistics -> (weights float32[n], cache float32[256])."""
@@ -216,15 +253,25 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
                 after: Optional[Tuple[int, float]] = None, total_hits_threshold: int = 1000,
                 segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False,
                 maxscore: bool = False, stats: Optional[dict] = None,
-                accept: Optional[Sequence[Optional[np.ndarray]]] = None, min_should_match: int = 0):
-    """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr))
-    executed as ONE slice (one collector visiting the leaves in docBase order).
+                accept: Optional[Sequence[Optional[np.ndarray]]] = None, min_should_match: int = 0,
+                slicing=DEFAULT_SLICING):
+    """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr)): one
+    collector per slice of the searcher (corpus_slices; each visits its leaves in docBase order), reduced like
+    LazyQueueTopScoreDocCollectorManager.reduce: TopDocs.merge of the slices' hits, totalHits summed, relation
+    GREATER_THAN_OR_EQUAL_TO if any slice's is.  `segments` (an explicit leaf list) or slicing=None: ONE collector.
     maxscore=True runs the dynamically pruned scorer (same top-k, totalHits a lower bound);
     stats["postings_scored"] then accumulates the postings it touched.
     accept[si] (uint64 words) replaces leaf si's liveDocs as the acceptDocs handed to the bulk scorer:
     liveDocs & FILTER doc set & ~MUST_NOT doc set -- what BooleanWeight's conjunction of a FILTER clause
     with the SHOULD disjunction (minimumNumberShouldMatch = 1) and its ReqExclScorer let through; such
     clauses add nothing to the score."""
+    if segments is None and slicing is not None:
+        groups = corpus_slices(corpus, slicing)
+        if len(groups) > 1:
+            parts = [search_bm25(corpus, term_ids, k, boosts, after, total_hits_threshold, g, omit_norms, omit_freqs, maxscore,
+                                 stats, accept, min_should_match, None) for g in groups]
+            docs, scores = topdocs_merge(k, [(p[0], p[1]) for p in parts])
+            return docs, scores, int(sum(p[2] for p in parts)), bool(any(p[3] for p in parts))
     weights, cache = bm25_query_stats(corpus, term_ids, boosts)
     col = Collector(k, after, total_hits_threshold)
     seg_ids = range(len(corpus.segments)) if segments is None else segments
@@ -277,15 +324,20 @@ class PreparedBatch:
     """Queries resolved to per-leaf clause arrays once (Weight creation + impacts, untimed), so that
     run() is a single C call: n_queries searches over n_threads OpenMP threads."""
 
-    def __init__(self, corpus, queries: Sequence[Sequence[int]], k: int, total_hits_threshold: int = 1000):
-        self.k, self.thr, self.nq = int(k), int(total_hits_threshold), len(queries)
+    def __init__(self, corpus, queries: Sequence[Sequence[int]], k: int, total_hits_threshold: int = 1000, slicing=None):
+        """slicing=None: one collector per query over all leaves (the timed CPU baseline); else one collector per
+        (query, slice) and run() reduces them per query like the reference's CollectorManager."""
+        self.k, self.thr, self.n_user = int(k), int(total_hits_threshold), len(queries)
         self._keep = []
         leaves = []
         offsets = [0]
-        for term_ids in queries:
+        groups = corpus_slices(corpus, slicing)
+        self._groups_per_query = len(groups)
+        for term_ids, group in [(t, g) for t in queries for g in groups]:
             weights, cache = bm25_query_stats(corpus, term_ids)
             self._keep.append(cache)
-            for si, seg in enumerate(corpus.segments):
+            for si in group:
+                seg = corpus.segments[si]
                 arr = (_Term * max(len(term_ids), 1))()
                 bms = []
                 n_present = 0
@@ -314,6 +366,7 @@ class PreparedBatch:
         self._corpus = corpus
         self._leaves = (_Leaf * max(len(leaves), 1))(*leaves)
         self._offsets = np.asarray(offsets, dtype=np.int64)
+        self.nq = self.n_user * self._groups_per_query
 
     def run(self, maxscore: bool, n_threads: int):
         docs = np.zeros((self.nq, self.k), np.int32)
@@ -325,4 +378,15 @@ class PreparedBatch:
         lib().nrt_oracle_search_batch(self.nq, self._offsets.ctypes.data, C.byref(self._leaves), self.k, self.thr,
                                       int(maxscore), int(n_threads), docs.ctypes.data, scores.ctypes.data,
                                       n.ctypes.data, total.ctypes.data, gte.ctypes.data, C.byref(scored))
-        return docs, scores, n, total, gte, int(scored.value)
+        g = self._groups_per_query
+        if g == 1:
+            return docs, scores, n, total, gte, int(scored.value)
+        md = np.zeros((self.n_user, self.k), np.int32)
+        ms = np.zeros((self.n_user, self.k), np.float32)
+        mn = np.zeros(self.n_user, np.int32)
+        for q in range(self.n_user):   # CollectorManager.reduce: TopDocs.merge, totals summed, GTE if any slice's is
+            d_, s_ = topdocs_merge(self.k, [(docs[q * g + j, : n[q * g + j]], scores[q * g + j, : n[q * g + j]]) for j in range(g)])
+            mn[q] = len(d_)
+            md[q, : len(d_)] = d_
+            ms[q, : len(d_)] = s_
+        return (md, ms, mn, total.reshape(self.n_user, g).sum(axis=1), gte.reshape(self.n_user, g).max(axis=1), int(scored.value))

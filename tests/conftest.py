@@ -16,6 +16,16 @@ def has_gpu() -> bool:
     return os.path.exists("/dev/kfd") and os.path.exists("/dev/dri")
 
 
+if has_gpu():
+    # Tests that hand torch tensors to the library (the multi-GPU exchange) need torch's bundled HIP runtime to be the
+    # one in the process: import it before anything loads libnrtgpu.so (as bench.py does), whatever order the test
+    # files run in.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as o

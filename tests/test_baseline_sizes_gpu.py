@@ -64,14 +64,14 @@ def test_bm25_full_size_against_the_exhaustive_oracle(oracle, wname):
         ctx.reset_stats()
         got = sr.search_batch(queries, [mgr] * N_Q)
         assert ctx.stats()["maxscore_items"] >= N_Q - 8       # the default route for this workload: dynamic pruning
-        exp = oracle.PreparedBatch(corpus, sample, w.k).run(False, _cpus())
+        exp = oracle.PreparedBatch(corpus, sample, w.k, slicing=oracle.DEFAULT_SLICING).run(False, _cpus())
         _check_batch(got, exp, w.k)
         # 1 % deletes (liveDocs folded into the posting columns)
         _deletes(corpus, 0.01, 99)
         for leaf, seg in zip(leaves, corpus.segments):
             leaf.set_live_docs(seg.live_bits)
         got = sr.search_batch(queries, [mgr] * N_Q)
-        exp = oracle.PreparedBatch(corpus, sample, w.k).run(False, _cpus())
+        exp = oracle.PreparedBatch(corpus, sample, w.k, slicing=oracle.DEFAULT_SLICING).run(False, _cpus())
         _check_batch(got, exp, w.k)
         # ScoreMode.COMPLETE: exhaustive route, exact counts
         mgr_c = api.TopScoreDocCollectorManager(w.k, total_hits_threshold=2**31 - 1)
@@ -147,7 +147,7 @@ def test_hybrid_c5_shape(oracle):
         mgr = api.TopScoreDocCollectorManager(recall)
         qv = np.random.default_rng(8).standard_normal((nq, dim)).astype(np.float32)
         fused = sr.search_hybrid_batch(queries, [mgr] * nq, 7, "cosine", qv, window, 1.0, 2.0)
-        first = oracle.PreparedBatch(corpus, [q.tolist() for q in qr], recall).run(False, _cpus())
+        first = oracle.PreparedBatch(corpus, [q.tolist() for q in qr], recall, slicing=oracle.DEFAULT_SLICING).run(False, _cpus())
         bases = [s.doc_base for s in corpus.segments]
         for qi in range(nq):
             docs, scores = first[0][qi, : first[2][qi]], first[1][qi, : first[2][qi]]

@@ -149,3 +149,31 @@ def test_larger_index_c3_shaped_queries(ctxs, oracle):
             assert one.relation_gte
     finally:
         ix.close()
+
+
+def test_relation_is_decided_per_slice(ctxs, oracle):
+    """The reference runs one collector per slice (MyIndexSearcher.slices) and reduces: the relation is
+    GREATER_THAN_OR_EQUAL_TO iff SOME SLICE collected more than max(threshold, numHits) hits -- a query whose hits are
+    spread thinly over many slices is EQUAL_TO with its exact count, however many hits it has in total."""
+    ranks = [3, 30, 100, 300, 1000, 3000]
+    corpus = synth.build_corpus(400_000, ranks, n_segments=8, delete_fraction=0.01)
+    slicing = (30_000, 2)          # many small slices (the live settings sliceMaxDocs / sliceMaxSegments)
+    groups = oracle.corpus_slices(corpus, slicing)
+    assert len(groups) >= 5
+    ctx = ctxs[0]
+    ctx.set_slicing(*slicing)
+    ix = Index(ctx, corpus)
+    try:
+        seen = set()
+        for terms in ([100], [300], [1000], [3000], [300, 1000], [100, 3000], [3, 1000], [30], [30, 300, 3000]):
+            for k, thr in ((10, 1000), (100, 200), (10, 50), (500, 1000), (10, 2**31 - 1)):
+                got = ix.searcher.search(bq(terms), api.TopScoreDocCollectorManager(k, total_hits_threshold=thr))
+                exp = oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, slicing=slicing)
+                whole = oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, slicing=None)
+                check(f"{terms}_k{k}_thr{thr}", got, exp, k, thr)
+                seen.add((exp[3], whole[3]))
+        assert (False, True) in seen   # some query is EQUAL_TO per slice although its total passes the threshold
+        assert (True, True) in seen and (False, False) in seen
+    finally:
+        ix.close()
+        ctx.set_slicing()
