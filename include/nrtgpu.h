@@ -180,6 +180,12 @@ int  nrtgpu_set_slicing(nrtgpu_ctx* ctx, int32_t slice_max_docs, int32_t slice_m
 
 int  nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                         const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);
+/* The eligibility test alone (the predicate a GpuIndexSearcher applies to the rewritten query before it
+ * chooses between this library and super.search): NRTGPU_OK if nrtgpu_search_bm25 would run `q` over these leaves,
+ * else the status it would return (NRTGPU_ERR_UNSUPPORTED: too many clauses / fields, numHits > NRTGPU_MAX_K, a mask
+ * that is not resident on a leaf, minimumNumberShouldMatch > 1 without the fixed-point range, ...) with the reason
+ * in nrtgpu_last_error().  No device work. */
+int  nrtgpu_query_supported(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, const nrtgpu_bm25_query* q);
 /* n_queries independent searches over the same leaves in one device pass */
 int  nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                               const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out);
@@ -325,14 +331,10 @@ typedef struct {
   int64_t maxscore_items;
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
-/* Closed-loop load generator (C concurrent clients): `clients` native threads each issue one query at a
- * time through nrtgpu_search_bm25_coalesced for duration_ms, cycling through `queries`.
- * out4 = {completed queries, elapsed seconds, p50 latency ms, p99 latency ms}. */
-int  nrtgpu_bench_closed_loop(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-                              const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t clients, int32_t duration_ms,
-                              double* out4);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
-#define NRTGPU_FLAG_PROFILE (7 << 8)  /* instrumented scan kernel: per-item phase cycle and event counters of wave 0 (nrtgpu_get_scan_profile) */
+#define NRTGPU_FLAG_PROFILE (7 << 8)  /* instrumented kernels (same results): per-item phase cycle and event counters
+                                       * (nrtgpu_get_scan_profile, nrtgpu_get_maxscore_profile).  Bits 8-11 hold no other
+                                       * value in the product library: nrtgpu_create rejects them */
 /* sums over all items since the last reset, instrumented kernel only (wave 0 of each workgroup;
  * cycles = shader clock): [0] prologue cycles, [1] cycles waiting at the rendezvous barrier,
  * [2] rendezvous cycles incl. that wait, [3] walk cycles, [4] epilogue cycles, [5] rendezvous,

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "nrtgpu_segment_set_mask", "nrtgpu_segment_release", "nrtgpu_segment_device_bytes",
     "nrtgpu_search_bm25", "nrtgpu_search_bm25_batch", "nrtgpu_search_bm25_batch_device",
     "nrtgpu_search_bm25_batch_device_epoch", "nrtgpu_exchange_open", "nrtgpu_exchange_close",
-    "nrtgpu_search_bm25_coalesced", "nrtgpu_set_coalescing", "nrtgpu_bench_closed_loop",
+    "nrtgpu_search_bm25_coalesced", "nrtgpu_set_coalescing", "nrtgpu_query_supported",
     "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_knn_search", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
@@ -116,7 +116,9 @@ def load() -> C.CDLL:
     L.nrtgpu_search_bm25_batch_device_epoch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, vp, vp, vp, i64]
     L.nrtgpu_search_bm25_coalesced.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), C.POINTER(TopDocs)]
     L.nrtgpu_set_coalescing.argtypes = [vp, i32]
-    L.nrtgpu_bench_closed_loop.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, i32, vp]
+    if hasattr(L, "nrtgpu_bench_closed_loop"):   # development build only (include/nrtgpu_dev.h)
+        L.nrtgpu_bench_closed_loop.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, i32, vp]
+    L.nrtgpu_query_supported.argtypes = [vp, vp, i32, C.POINTER(Bm25Query)]
     L.nrtgpu_exchange_open.argtypes = [vp, C.c_char_p, i32, i32]
     L.nrtgpu_exchange_close.argtypes = [vp]
     L.nrtgpu_exchange_close.restype = None

@@ -401,6 +401,17 @@ class GpuIndexSearcher:
     def search(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
         return self.search_batch([query], [manager])[0]
 
+    def supported(self, query: Query, manager: TopScoreDocCollectorManager) -> bool:
+        """The eligibility predicate alone (nrtgpu_query_supported): would the device route take this query?"""
+        m = self._marshal([query], [manager])
+        rc = _lib.load().nrtgpu_query_supported(self.ctx._h, self._segs, len(self.leaves), m.queries)
+        if rc == _lib.NRTGPU_OK:
+            return True
+        if rc == _lib.NRTGPU_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc)
+        return False
+
     def search_coalesced(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
         """Blocking single search meant to be called from many threads at once: the library merges
         concurrent callers into device batches (nrtgpu_search_bm25_coalesced)."""

@@ -23,6 +23,16 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+DEV_OUT = os.path.join(HERE, "libnrtgpu_dev.so")
+DEV_SOURCES = ["devtools.cpp"]   # measurement helpers outside the product ABI (include/nrtgpu_dev.h)
+
+
+def build_dev(verbose: bool = False) -> str:
+    """The development build: the product sources + devtools.cpp with -DNRTGPU_DEV (closed-loop load generator, timing
+    ablations of the scan).  NRTGPU_LIB_PATH=<this file> makes nrtsearch_amd._lib load it."""
+    return build(force=True, verbose=verbose, extra=["-DNRTGPU_DEV"] + [os.path.join(CSRC, s) for s in DEV_SOURCES], out=DEV_OUT)
+
+
 def build(force: bool = False, verbose: bool = False, extra=(), out: str = OUT) -> str:
     """extra: additional hipcc flags (e.g. -DNRT_SCAN_WAVES=16 -DNRT_TILE_DOCS=768 for an A/B build
     written to `out`; NRTGPU_LIB_PATH makes nrtsearch_amd._lib load it)."""
@@ -37,4 +47,4 @@ def build(force: bool = False, verbose: bool = False, extra=(), out: str = OUT) 
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build_dev(verbose=True) if "--dev" in sys.argv else build(force="--force" in sys.argv, verbose=True))

@@ -1135,11 +1135,13 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int 
   if (ablation == 9) { NRT_LAUNCH_FX(true, 9); return; }  // some part carries a doc-set mask (deletes / FILTER / MUST_NOT)  // minimumNumberShouldMatch > 1 somewhere in the batch (fixed point only)
   if (!pipelined) { NRT_LAUNCH_FX(false, 0); return; }
   switch (ablation) {
-    case 1: NRT_LAUNCH(false, true, 1); break;  // 1-4: timing ablations of the fp64 kernel (wrong results)
+#ifdef NRTGPU_DEV  // timing ablations (wrong results): development build only, nrtgpu_create rejects the flag values otherwise
+    case 1: NRT_LAUNCH(false, true, 1); break;  // 1-4: of the fp64 kernel
     case 2: NRT_LAUNCH(false, true, 2); break;
     case 3: NRT_LAUNCH(false, true, 3); break;
     case 4: NRT_LAUNCH(false, true, 4); break;
     case 6: NRT_LAUNCH(false, true, 6); break;  // no candidate handling in sparse sub-tiles
+#endif
     case 7: NRT_LAUNCH_FX(true, 7); break;
     default: NRT_LAUNCH_FX(true, 0); break;
   }

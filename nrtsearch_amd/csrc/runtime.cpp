@@ -132,6 +132,13 @@ extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
   nrtgpu_config c{};
   if (cfg) c = *cfg;
   if (c.max_batch <= 0) c.max_batch = 1024;
+#ifndef NRTGPU_DEV
+  {
+    const int variant = (c.flags >> 8) & 15;  // 7 = instrumented kernels; the rest are timing ablations with wrong results
+    if (variant != 0 && variant != 7)
+      return fail(NRTGPU_ERR_INVALID_ARG, "flags: kernel variant %d exists only in the development build (-DNRTGPU_DEV)", variant);
+  }
+#endif
   int n_dev = 0;
   hipError_t e = hipGetDeviceCount(&n_dev);
   if (e != hipSuccess || n_dev <= 0)

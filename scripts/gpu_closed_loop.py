@@ -11,6 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
+from nrtsearch_amd import build as _build  # noqa: E402
+
+# the load generator lives in the development build only (include/nrtgpu_dev.h), not in the product library
+os.environ["NRTGPU_LIB_PATH"] = _build.DEV_OUT if os.path.exists(_build.DEV_OUT) else _build.build_dev()
 from nrtsearch_amd import _lib, api, synth, workload  # noqa: E402
 
 

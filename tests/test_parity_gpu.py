@@ -423,3 +423,15 @@ def test_live_docs_update_after_seal(ctx, oracle):
     assert top not in got2.docs.tolist() and exp2[2] == exp[2] - 1
     assert_same("live1", got2, exp2, 20, INT_MAX)
     ix.close()
+
+
+def test_query_supported_is_the_planners_predicate(mid):
+    ok = api.TopScoreDocCollectorManager(100)
+    assert mid.searcher.supported(bq([1, 100, 5000]), ok)
+    assert mid.searcher.supported(bq([424242]), ok)                                   # a term no leaf holds: runs, matches nothing
+    assert not mid.searcher.supported(bq([1, 5]), api.TopScoreDocCollectorManager(5000))            # numHits > NRTGPU_MAX_K
+    assert not mid.searcher.supported(bq(list(range(1, 40))), ok)                     # more clauses than NRTGPU_MAX_TERMS
+    q = api.BooleanQuery(tuple(api.TermQuery(0, t) for t in (1, 100)), 0, (api.MaskFilter(9999),), ())
+    assert not mid.searcher.supported(q, ok)                                          # FILTER mask not resident
+    with pytest.raises(_lib.NrtGpuError):
+        mid.searcher.supported(bq([1]), api.TopScoreDocCollectorManager(0))           # invalid argument, not "unsupported"
