@@ -117,6 +117,51 @@ def cpu_baseline(corpus, query_ranks, k, n_queries):
                       f"exhaustive scorer on the first {n_ex}: {dt_ex:.2f}s"}
 
 
+def lucene_baseline(w, searcher, queries, mgr, n_queries):
+    """The reference's own CPU path, when this box can run it: probe `java` / `javac` and lucene-core
+    (LUCENE_JARS=<classpath>, or jars under /opt/lucene); if present dump the same corpus + queries
+    (scripts/dump_corpus.py), compile and run bench/lucene/LuceneBaseline.java at 1 and all host threads, and diff its
+    docids / score bits against the device's answers.  Returns a dict for cpu_baseline["lucene"]."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    java, javac = shutil.which("java"), shutil.which("javac")
+    jars = os.environ.get("LUCENE_JARS") or ":".join(sorted(glob.glob("/opt/lucene/*.jar")))
+    if not java or not javac or not jars:
+        return {"available": False, "reason": "no JDK on this box" if not (java and javac) else "no lucene-core jar (LUCENE_JARS)"}
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import dump_corpus
+
+    import numpy as np
+
+    tmp = tempfile.mkdtemp(prefix="lucene_baseline_")
+    try:
+        dump_corpus.dump(w, os.path.join(tmp, "dump"), n_queries)
+        subprocess.check_call([javac, "-cp", jars, os.path.join(ROOT, "bench", "lucene", "LuceneBaseline.java"), "-d", os.path.join(tmp, "cls")])
+        out = {}
+        for threads in (usable_cpus(), 1):
+            res = os.path.join(tmp, f"out_{threads}.json")
+            subprocess.check_call([java, "-Xmx32g", "-cp", os.path.join(tmp, "cls") + ":" + jars, "LuceneBaseline", os.path.join(tmp, "dump"),
+                                   os.path.join(tmp, "index"), str(threads), res, str(n_queries)])
+            r = json.load(open(res))
+            out[f"threads_{threads}"] = {k_: r[k_] for k_ in ("queries_per_s", "p50_ms", "p99_ms", "threads")}
+            out.update(lucene=r["lucene"], java=r["java"], index_build_s=r["index_build_s"], segments=r["segments"])
+        got = searcher.search_batch(queries[:n_queries], [mgr] * n_queries)
+        same_docs = same_bits = same_rel = 0
+        for g, e in zip(got, r["results"]):
+            same_docs += g.docs.tolist() == e["docs"]
+            same_bits += g.scores.view(np.uint32).tolist() == [b & 0xFFFFFFFF for b in e["score_bits"]]
+            same_rel += bool(g.relation_gte) == bool(e["gte"])
+        out.update(available=True, queries=n_queries, docids_identical=same_docs, score_bits_identical=same_bits, relation_identical=same_rel)
+        return out
+    except Exception as e:   # noqa: BLE001 -- a reported baseline must never take the bench line down
+        return {"available": False, "reason": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -394,6 +439,15 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
         out["cpu_baseline"] = cpu_baseline(corpus, qranks, w.k, args.cpu_queries)
+        luc = lucene_baseline(w, searcher, queries, mgr, min(256, n_distinct))
+        out["cpu_baseline"]["lucene"] = luc
+        if luc.get("available"):   # the reference itself ran here: it is the baseline, the C port stays beside it
+            cb = out["cpu_baseline"]
+            cb["port_value"] = cb["value"]
+            cb["value"] = luc[f"threads_{cb['cores']}"]["queries_per_s"]
+            cb["kind"] = "reference"
+            cb["sample"] = (f"first {luc['queries']} queries through JVM Lucene {luc['lucene']} (bench/lucene/LuceneBaseline.java), "
+                            f"{cb['cores']} threads; C port on the same box: {cb['port_value']} queries/s")
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
