@@ -1,0 +1,157 @@
+package com.yelp.nrtsearch.gpu;
+
+import static java.lang.foreign.ValueLayout.*;
+
+import java.io.IOException;
+import java.lang.foreign.Arena;
+import java.lang.foreign.MemorySegment;
+import java.util.*;
+import java.util.concurrent.ConcurrentHashMap;
+import org.apache.lucene.index.*;
+import org.apache.lucene.search.DocIdSetIterator;
+import org.apache.lucene.util.Bits;
+import org.apache.lucene.util.BytesRef;
+
+/**
+ * One resident replica (nrtgpu_seg) per segment core, keyed like the reference keys its own per-segment caches
+ * (IndexReader.CacheKey + addClosedListener, cf. field/TextBaseFieldDef.java:335-371).  Filled through Lucene's public
+ * reader APIs -- TermsEnum / PostingsEnum (the per-leaf iteration idiom of query/MatchPhrasePrefixQuery.java:241-270),
+ * getNormValues, getFloatVectorValues -- so nothing depends on Lucene104PostingsFormat internals.  Called from
+ * GpuIndexSearcher's factory hook at refresh / warm time (index/ShardState.java:506-527), never on the query path.
+ * NOT COMPILED here (no JDK).
+ */
+final class GpuSegmentStore {
+  record Resident(MemorySegment seg, long liveDocsVersion) {}
+
+  private final MemorySegment ctx;
+  private final Map<IndexReader.CacheKey, Resident> resident = new ConcurrentHashMap<>();
+  private final Map<String, Integer> fieldIds = new ConcurrentHashMap<>();
+
+  GpuSegmentStore(MemorySegment ctx) { this.ctx = ctx; }
+
+  int fieldId(String field) { return fieldIds.computeIfAbsent(field, f -> fieldIds.size() + 1); }
+
+  /** Injective 64-bit id of (term bytes): must be the same at upload and at query time. */
+  static long termHash(BytesRef term) {
+    long h = 0xcbf29ce484222325L;                       // FNV-1a 64; the shim may keep a dictionary instead if it wants a proof
+    for (int i = 0; i < term.length; i++) h = (h ^ (term.bytes[term.offset + i] & 0xff)) * 0x100000001b3L;
+    return h;
+  }
+
+  /** Segments of `reader` that are not resident yet are uploaded; liveDocs of the others are refreshed when they changed. */
+  void sync(DirectoryReader reader, Collection<String> textFields, Collection<String> vectorFields) throws IOException {
+    for (LeafReaderContext lc : reader.leaves()) {
+      LeafReader leaf = lc.reader();
+      IndexReader.CacheHelper core = leaf.getCoreCacheHelper();
+      if (core == null) continue;                       // not cacheable: this leaf stays on the CPU path
+      Resident r = resident.get(core.getKey());
+      if (r == null) {
+        MemorySegment seg = upload(leaf, textFields, vectorFields);
+        r = new Resident(seg, -1);
+        resident.put(core.getKey(), r);
+        core.addClosedListener(key -> {                 // segment merged away / reader closed
+          Resident gone = resident.remove(key);
+          if (gone != null) try { NrtGpu.RELEASE.invokeExact(gone.seg()); } catch (Throwable ignored) { }
+        });
+      }
+      long version = leaf.getReaderCacheHelper() == null ? 0 : System.identityHashCode(leaf.getReaderCacheHelper().getKey());
+      if (version != r.liveDocsVersion()) {
+        setLiveDocs(r.seg(), leaf.getLiveDocs(), leaf.maxDoc());
+        resident.put(core.getKey(), new Resident(r.seg(), version));
+      }
+    }
+  }
+
+  MemorySegment segmentOf(LeafReaderContext lc) {
+    IndexReader.CacheHelper core = lc.reader().getCoreCacheHelper();
+    Resident r = core == null ? null : resident.get(core.getKey());
+    return r == null ? null : r.seg();
+  }
+
+  private MemorySegment upload(LeafReader leaf, Collection<String> textFields, Collection<String> vectorFields) throws IOException {
+    try (Arena a = Arena.ofConfined()) {
+      MemorySegment out = a.allocate(ADDRESS);
+      NrtGpu.check((int) NrtGpu.SEG_BEGIN.invokeExact(ctx, leaf.maxDoc(), 0, out));
+      MemorySegment seg = out.get(ADDRESS, 0);
+      for (String field : textFields) {
+        Terms terms = leaf.terms(field);
+        if (terms == null) continue;
+        int fid = fieldId(field);
+        NumericDocValues norms = leaf.getNormValues(field);
+        if (norms != null) {                            // norms omitted (ATOM fields, AtomFieldDef.java:123-126): NULL => 1
+          MemorySegment nb = a.allocate(leaf.maxDoc());
+          for (int d = norms.nextDoc(); d != DocIdSetIterator.NO_MORE_DOCS; d = norms.nextDoc()) nb.set(JAVA_BYTE, d, (byte) norms.longValue());
+          NrtGpu.check((int) NrtGpu.ADD_NORMS.invokeExact(seg, fid, nb));
+        } else {
+          NrtGpu.check((int) NrtGpu.ADD_NORMS.invokeExact(seg, fid, MemorySegment.NULL));
+        }
+        // postings column-major, in groups of ~64 M postings per add_terms call (bounded staging memory)
+        final long groupCap = 1L << 26;
+        List<Long> hashes = new ArrayList<>();
+        List<Long> offs = new ArrayList<>(List.of(0L));
+        MemorySegment docs = a.allocate(groupCap * 4), freqs = a.allocate(groupCap * 4);
+        long n = 0;
+        TermsEnum te = terms.iterator();
+        PostingsEnum pe = null;
+        boolean hasFreqs = terms.hasFreqs();
+        for (BytesRef t = te.next(); t != null; t = te.next()) {
+          if (n + te.docFreq() > groupCap) { flushTerms(a, seg, fid, hashes, offs, docs, hasFreqs ? freqs : MemorySegment.NULL); n = 0; }
+          pe = te.postings(pe, hasFreqs ? PostingsEnum.FREQS : PostingsEnum.NONE);
+          for (int d = pe.nextDoc(); d != DocIdSetIterator.NO_MORE_DOCS; d = pe.nextDoc(), n++) {
+            docs.setAtIndex(JAVA_INT, n, d);
+            if (hasFreqs) freqs.setAtIndex(JAVA_INT, n, pe.freq());
+          }
+          hashes.add(termHash(t));
+          offs.add(n);
+        }
+        flushTerms(a, seg, fid, hashes, offs, docs, hasFreqs ? freqs : MemorySegment.NULL);
+      }
+      for (String field : vectorFields) {
+        FloatVectorValues vv = leaf.getFloatVectorValues(field);   // API use: VectorFieldDefTest.java:2301-2315
+        if (vv == null || vv.size() == 0) continue;
+        int dim = vv.dimension(), n = vv.size();
+        MemorySegment rows = a.allocate((long) n * dim * 4), ord2doc = a.allocate((long) n * 4);
+        KnnVectorValues.DocIndexIterator it = vv.iterator();
+        for (int d = it.nextDoc(); d != DocIdSetIterator.NO_MORE_DOCS; d = it.nextDoc()) {
+          int ord = it.index();
+          ord2doc.setAtIndex(JAVA_INT, ord, d);
+          MemorySegment.copy(vv.vectorValue(ord), 0, rows, JAVA_FLOAT, (long) ord * dim * 4, dim);
+        }
+        NrtGpu.check((int) NrtGpu.ADD_VECTORS.invokeExact(seg, fieldId(field), dim, n, n == leaf.maxDoc() ? MemorySegment.NULL : ord2doc, rows));
+      }
+      NrtGpu.check((int) NrtGpu.SEAL.invokeExact(seg));
+      return seg;
+    } catch (IOException | RuntimeException e) {
+      throw e;
+    } catch (Throwable t) {
+      throw new IOException(t);
+    }
+  }
+
+  private static void flushTerms(Arena a, MemorySegment seg, int fid, List<Long> hashes, List<Long> offs, MemorySegment docs,
+      MemorySegment freqs) throws Throwable {
+    if (hashes.isEmpty()) return;
+    MemorySegment h = a.allocate((long) hashes.size() * 8), o = a.allocate((long) offs.size() * 8);
+    for (int i = 0; i < hashes.size(); i++) h.setAtIndex(JAVA_LONG, i, hashes.get(i));
+    for (int i = 0; i < offs.size(); i++) o.setAtIndex(JAVA_LONG, i, offs.get(i));
+    NrtGpu.check((int) NrtGpu.ADD_TERMS.invokeExact(seg, fid, (long) hashes.size(), h, o, docs, freqs));
+    hashes.clear();
+    offs.clear();
+    offs.add(0L);
+  }
+
+  private static void setLiveDocs(MemorySegment seg, Bits live, int maxDoc) throws IOException {
+    try (Arena a = Arena.ofConfined()) {
+      if (live == null) { NrtGpu.check((int) NrtGpu.SET_LIVE.invokeExact(seg, MemorySegment.NULL, 0)); return; }
+      int words = (maxDoc + 63) >>> 6;
+      MemorySegment bits = a.allocate((long) words * 8);
+      for (int d = 0; d < maxDoc; d++)
+        if (live.get(d)) bits.setAtIndex(JAVA_LONG, d >>> 6, bits.getAtIndex(JAVA_LONG, d >>> 6) | (1L << (d & 63)));
+      NrtGpu.check((int) NrtGpu.SET_LIVE.invokeExact(seg, bits, words));
+    } catch (IOException | RuntimeException e) {
+      throw e;
+    } catch (Throwable t) {
+      throw new IOException(t);
+    }
+  }
+}
