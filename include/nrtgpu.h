@@ -226,6 +226,20 @@ int  nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* co
                                            int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                                            int32_t k_stride, void* d_keys, void* d_counts, void* d_hits, int64_t epoch);
 
+/* The multi-GPU search with the collective INSIDE the library (a JVM caller has no torch): one process per GPU, every
+ * rank holds a docid-range shard of the index.  nrtgpu_dist_unique_id on one rank (128 bytes: an ncclUniqueId), the bytes
+ * travel to the other ranks by whatever means the deployment has, nrtgpu_dist_init on every rank (ncclCommInitRank on the
+ * context's device; RCCL is bound at run time with dlopen, NRTGPU_ERR_UNSUPPORTED if it is not installed).  Then every
+ * rank calls nrtgpu_dist_search_bm25_batch with the same queries in the same order (index-global statistics in the
+ * weights) over ITS leaves: local search -> ONE grouped RCCL all-gather of keys / counts / hit totals over xGMI ->
+ * TopDocs.merge on every rank; every rank receives every answer.  total_hits sums the shards' counts; the relation is
+ * GREATER_THAN_OR_EQUAL_TO iff some shard's is. */
+int  nrtgpu_dist_unique_id(void* out128);
+int  nrtgpu_dist_init(nrtgpu_ctx* ctx, int32_t world, int32_t rank, const void* id128);
+int  nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                   const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out);
+void nrtgpu_dist_close(nrtgpu_ctx* ctx);
+
 /* TopDocs.merge of n_lists per-GPU results laid out as the all-gather leaves them:
  * d_keys_in[list][query][k_stride], d_counts_in[list][query], d_hits_in[list][query] (device).
  * Writes host-side topdocs (docs/scores/total_hits/relation) for each query.  total_hits = the sum of the lists' counts;
@@ -298,6 +312,17 @@ int  nrtgpu_fixed_point_scale(float weight, const float* norm_cache256, int32_t 
  * tests: query_costs[q] = postings + 48 per 1024-doc sub-tile of the query (0: matches nothing), target_items =
  * CUs; out_items[q] = number of items.  Needs no device. */
 int  nrtgpu_plan_item_counts(int32_t n_queries, const int64_t* query_costs, int32_t target_items, int64_t* out_items);
+/* Multi-retriever blend (O(hits) host work, no device): BlenderOperation.blend =
+ * mergeHits + sortAndPaginate (src/main/java/com/yelp/nrtsearch/server/search/multiretriever/blender/BlenderOperation.java:76-132).
+ *   mode 0: WeightedRrfBlenderOperation (…/operation/WeightedRrfBlenderOperation.java:53-78): score = sum over retrievers, in
+ *           declaration order, of boost / (rank_constant + rank), rank 1-based, float (…/score/WeightedRRFScoreDoc.java:62,75)
+ *   mode 1: score order: score = sum of boost * the retriever's score
+ * docs[r] / scores[r]: retriever r's hits in rank order (global docids), counts[r] of them; boosts NULL => 1.  Returns hits
+ * [start_hit, top_hits) of the blended order; total_hits = distinct docs, relation GREATER_THAN_OR_EQUAL_TO as the
+ * reference reports it.  Docs with EQUAL blended scores come out in the reference's order too: its java.util.HashMap
+ * iteration order feeding a bounded java.util.PriorityQueue is restated (host_math.h). */
+int  nrtgpu_blend(int32_t n_retrievers, const int32_t* const* docs, const float* const* scores, const int32_t* counts,
+                  const float* boosts, int32_t mode, int32_t rank_constant, int32_t start_hit, int32_t top_hits, nrtgpu_topdocs* out);
 int32_t nrtgpu_int_to_byte4(int32_t length);
 int32_t nrtgpu_byte4_to_int(int32_t norm_byte);
 float   nrtgpu_bm25_idf(int64_t doc_count, int64_t doc_freq);

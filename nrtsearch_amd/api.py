@@ -156,6 +156,20 @@ class GpuContext:
         """MyIndexSearcher.SlicingParams of the searcher this context serves (TotalHits.relation is decided per slice)."""
         _lib.check(_lib.load().nrtgpu_set_slicing(self._h, int(slice_max_docs), int(slice_max_segments), int(virtual_shards)))
 
+    @staticmethod
+    def dist_unique_id() -> bytes:
+        """An ncclUniqueId (128 bytes) for dist_init: made on one rank, handed to the others by the deployment."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().nrtgpu_dist_unique_id(buf))
+        return bytes(buf.raw)
+
+    def dist_init(self, world: int, rank: int, unique_id: bytes) -> None:
+        """Joins the RCCL communicator of a `world`-GPU search (one process per GPU): the collective lives in the library."""
+        _lib.check(_lib.load().nrtgpu_dist_init(self._h, int(world), int(rank), C.c_char_p(unique_id)))
+
+    def dist_close(self) -> None:
+        _lib.load().nrtgpu_dist_close(self._h)
+
     def exchange_open(self, shm_name: str, world: int, rank: int) -> None:
         """Cross-GPU bound exchange (include/nrtgpu.h); synchronise the ranks once before the first search."""
         _lib.check(_lib.load().nrtgpu_exchange_open(self._h, shm_name.encode(), int(world), int(rank)))
@@ -401,6 +415,25 @@ class GpuIndexSearcher:
     def search(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
         return self.search_batch([query], [manager])[0]
 
+    def dist_search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> List[TopDocs]:
+        """The multi-GPU search through nrtgpu_dist_search_bm25_batch: this rank's leaves, RCCL all-gather + merge inside
+        the library; every rank gets every answer (GpuContext.dist_init first)."""
+        n = len(queries)
+        m = self._marshal(queries, managers)
+        outs = (_lib.TopDocs * n)()
+        bufs = []
+        for qi, mgr in enumerate(managers):
+            cap = max(int(mgr.num_hits), 1)
+            d = np.zeros(cap, dtype=np.int32)
+            s = np.zeros(cap, dtype=np.float32)
+            bufs.append((d, s))
+            outs[qi].capacity = cap
+            outs[qi].docs = d.ctypes.data_as(C.POINTER(C.c_int32))
+            outs[qi].scores = s.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_dist_search_bm25_batch(self.ctx._h, self._segs, self._bases, len(self.leaves), m.queries, n, outs))
+        return [TopDocs(bufs[qi][0][: outs[qi].n_hits].copy(), bufs[qi][1][: outs[qi].n_hits].copy(), int(outs[qi].total_hits),
+                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n)]
+
     def supported(self, query: Query, manager: TopScoreDocCollectorManager) -> bool:
         """The eligibility predicate alone (nrtgpu_query_supported): would the device route take this query?"""
         m = self._marshal([query], [manager])
@@ -606,6 +639,27 @@ def slices(max_docs: Sequence[int], num_docs: Optional[Sequence[int]] = None, vi
     for i in range(n):
         out[sl[i]].append(i)
     return out, sh[:n].tolist()
+
+
+def blend(retriever_docs: Sequence[np.ndarray], retriever_scores: Optional[Sequence[np.ndarray]] = None,
+          boosts: Optional[Sequence[float]] = None, mode: str = "rrf", k: int = 60, start_hit: int = 0, top_hits: int = 10) -> TopDocs:
+    """BlenderOperation.blend through the library (nrtgpu_blend): weighted RRF or score order, ties in the reference's order."""
+    n = len(retriever_docs)
+    docs = [np.ascontiguousarray(d, dtype=np.int32) for d in retriever_docs]
+    scs = [np.ascontiguousarray(s_, dtype=np.float32) for s_ in retriever_scores] if retriever_scores is not None else None
+    dp = (C.c_void_p * max(n, 1))(*[d.ctypes.data for d in docs])
+    sp = (C.c_void_p * max(n, 1))(*[s_.ctypes.data for s_ in scs]) if scs is not None else None
+    counts = np.asarray([len(d) for d in docs], dtype=np.int32)
+    b = np.ascontiguousarray(boosts, dtype=np.float32) if boosts is not None else None
+    cap = max(int(top_hits), 1)
+    od, os_ = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+    out = _lib.TopDocs()
+    out.capacity = cap
+    out.docs = od.ctypes.data_as(C.POINTER(C.c_int32))
+    out.scores = os_.ctypes.data_as(C.POINTER(C.c_float))
+    _lib.check(_lib.load().nrtgpu_blend(n, dp, sp, counts.ctypes.data, b.ctypes.data if b is not None else None,
+                                        0 if mode == "rrf" else 1, int(k), int(start_hit), int(top_hits), C.byref(out)))
+    return TopDocs(od[: out.n_hits].copy(), os_[: out.n_hits].copy(), int(out.total_hits), bool(out.total_hits_is_lower_bound))
 
 
 # ---- blenders (multi-retriever; O(k) host work that stays in Java in the reference) ----------------

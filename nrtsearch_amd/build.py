@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnrtgpu.so")
-SOURCES = ["kernels.hip", "maxscore.hip", "knn.hip", "runtime.cpp", "segment.cpp", "planner.cpp", "search.cpp", "vectors.cpp"]
+SOURCES = ["kernels.hip", "maxscore.hip", "knn.hip", "runtime.cpp", "segment.cpp", "planner.cpp", "search.cpp", "vectors.cpp", "dist.cpp"]
 HEADERS = ["plan.h", "topk.hiph", "bm25_common.hiph", "host_math.h", "runtime_internal.h", os.path.join("..", "..", "include", "nrtgpu.h")]
 # -ffp-contract=off + no fast-math: BM25 arithmetic must round exactly like Java's float ops.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <unordered_map>
 #include <vector>
 
 namespace nrtgpu {
@@ -78,6 +79,7 @@ class JavaPriorityQueue {
   explicit JavaPriorityQueue(Less less) : less_(less) {}
   bool empty() const { return q_.empty(); }
   size_t size() const { return q_.size(); }
+  const T& peek() const { return q_[0]; }
   void add(const T& x) {
     q_.push_back(x);
     size_t k = q_.size() - 1;
@@ -199,6 +201,66 @@ inline std::vector<std::vector<int32_t>> slices_for_shards(const std::vector<Lea
   }
   while (!sorted_slices.empty()) out.push_back(pool[sorted_slices.poll()].leaves);
   return out;
+}
+
+// WeightedRrfBlenderOperation.mergeHits + BlenderOperation.sortAndPaginate
+// (/root/reference/src/main/java/com/yelp/nrtsearch/server/search/multiretriever/blender/operation/
+// WeightedRrfBlenderOperation.java:53-78, .../score/WeightedRRFScoreDoc.java:62,75, .../BlenderOperation.java:96-132):
+// score(doc) = sum over retrievers, in declaration order, of boost / (k + rank) (float, rank 1-based); hits merged in a
+// java.util.HashMap<Integer, ...> whose values() order feeds a size-bounded java.util.PriorityQueue (min-heap on score;
+// an incoming doc displaces the root only if strictly greater); the heap is drained from the back.  Equal scores
+// therefore come out in an order that depends on both containers -- restated here (HashMap: buckets of a power-of-two
+// table in index order, insertion order inside a bucket, hash(key) = key ^ (key >>> 16), resize at 0.75 load; buckets
+// that Java would treeify (>= 8 colliding keys in a table of >= 64) are not modelled).  weighted == false is the
+// score-order blender's sibling with the same containers: score = sum of boost * retriever score.
+struct BlendHit { int32_t doc; float score; };
+inline int64_t blend_hits(int32_t n_retrievers, const int32_t* const* docs, const float* const* scores, const int32_t* counts,
+                          const float* boosts, int32_t k, bool rrf, int32_t start_hit, int32_t top_hits, std::vector<BlendHit>* page) {
+  page->clear();
+  if (top_hits == 0 || start_hit > top_hits) return 0;
+  // mergeHits: insertion-ordered entries + the HashMap's bucket structure
+  struct Entry { int32_t doc; float score; };
+  std::vector<Entry> entries;
+  std::unordered_map<int32_t, size_t> where;
+  for (int32_t r = 0; r < n_retrievers; ++r) {
+    const float boost = boosts ? boosts[r] : 1.0f;
+    for (int32_t i = 0; i < counts[r]; ++i) {
+      const float add = rrf ? boost / (float)(k + i + 1) : boost * scores[r][i];
+      auto it = where.find(docs[r][i]);
+      if (it == where.end()) {
+        where.emplace(docs[r][i], entries.size());
+        entries.push_back({docs[r][i], add});
+      } else {
+        entries[it->second].score += add;
+      }
+    }
+  }
+  const size_t total = entries.size();
+  size_t cap = 16;
+  while ((double)total > 0.75 * (double)cap) cap <<= 1;  // HashMap.resize(): threshold = 0.75 * capacity, doubling
+  std::vector<size_t> order(total);
+  for (size_t i = 0; i < total; ++i) order[i] = i;
+  auto bucket = [&](size_t i) {
+    const uint32_t h = (uint32_t)entries[i].doc;
+    return (size_t)((h ^ (h >> 16)) & (uint32_t)(cap - 1));
+  };
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bucket(a) < bucket(b); });  // values(): bucket order, insertion order inside
+  // sortAndPaginate
+  const size_t capacity = std::min<size_t>((size_t)top_hits, total);
+  auto less = [&](size_t a, size_t b) { return entries[a].score < entries[b].score; };   // Float.compare for the non-NaN, non-(-0.0 vs 0.0) scores here
+  JavaPriorityQueue<size_t, decltype(less)> heap(less);
+  for (size_t idx : order) {
+    if (heap.size() < capacity) {
+      heap.add(idx);
+    } else if (capacity > 0 && entries[idx].score > entries[heap.peek()].score) {
+      heap.poll();
+      heap.add(idx);
+    }
+  }
+  std::vector<size_t> topk(heap.size());
+  for (size_t i = topk.size(); i-- > 0;) topk[i] = heap.poll();
+  for (size_t i = std::min<size_t>((size_t)start_hit, topk.size()); i < topk.size(); ++i) page->push_back({entries[topk[i]].doc, entries[topk[i]].score});
+  return (int64_t)total;
 }
 
 // How many work items each query of a batch is cut into (planner.cpp; exported as nrtgpu_plan_item_counts for

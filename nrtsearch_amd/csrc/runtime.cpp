@@ -217,6 +217,7 @@ extern "C" int nrtgpu_exchange_open(nrtgpu_ctx* ctx, const char* shm_name, int32
 
 extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
   if (!ctx) return;
+  nrtgpu_dist_close(ctx);
   nrtgpu_exchange_close(ctx);
   (void)hipSetDevice(ctx->device);
   for (auto& s : ctx->slots) {
@@ -283,6 +284,29 @@ extern "C" void nrtgpu_bm25_norm_cache(float avgdl, float k1, float b, float* ou
 extern "C" int nrtgpu_fixed_point_scale(float weight, const float* norm_cache256, int32_t max_norm, int32_t* out_scale) {
   if (!norm_cache256 || !out_scale || max_norm < 0 || max_norm > 255) return fail(NRTGPU_ERR_INVALID_ARG, "bad fixed_point_scale arguments");
   return fixed_scale_of_term(weight, norm_cache256, (uint32_t)max_norm, out_scale) ? 1 : 0;
+}
+
+extern "C" int nrtgpu_blend(int32_t n_retrievers, const int32_t* const* docs, const float* const* scores, const int32_t* counts,
+                            const float* boosts, int32_t mode, int32_t rank_constant, int32_t start_hit, int32_t top_hits,
+                            nrtgpu_topdocs* out) {
+  if (n_retrievers < 0 || (n_retrievers > 0 && (!docs || !counts)) || !out || top_hits < 0 || start_hit < 0 || (mode != 0 && mode != 1))
+    return fail(NRTGPU_ERR_INVALID_ARG, "bad blend arguments");
+  if (mode == 0 && rank_constant < 1) return fail(NRTGPU_ERR_INVALID_ARG, "k must be >= 1, got: %d", rank_constant);  // WeightedRRFScoreDoc.java:62
+  if (mode == 1 && n_retrievers > 0 && !scores) return fail(NRTGPU_ERR_INVALID_ARG, "score-order blend needs the retrievers' scores");
+  for (int32_t r = 0; r < n_retrievers; ++r)
+    if (counts[r] < 0 || (counts[r] > 0 && (!docs[r] || (mode == 1 && !scores[r])))) return fail(NRTGPU_ERR_INVALID_ARG, "bad retriever %d", r);
+  std::vector<hostmath::BlendHit> page;
+  const int64_t total = hostmath::blend_hits(n_retrievers, docs, scores, counts, boosts, rank_constant, mode == 0, start_hit, top_hits, &page);
+  const int32_t cap = out->capacity > 0 ? out->capacity : top_hits;
+  const int32_t m = std::min<int32_t>((int32_t)page.size(), cap);
+  for (int32_t i = 0; i < m; ++i) {
+    if (out->docs) out->docs[i] = page[(size_t)i].doc;
+    if (out->scores) out->scores[i] = page[(size_t)i].score;
+  }
+  out->n_hits = m;
+  out->total_hits = total;
+  out->total_hits_is_lower_bound = 1;   // BlenderOperation.java: always GREATER_THAN_OR_EQUAL_TO
+  return NRTGPU_OK;
 }
 
 extern "C" int nrtgpu_plan_item_counts(int32_t n_queries, const int64_t* query_costs, int32_t target_items, int64_t* out_items) {

@@ -329,8 +329,11 @@ class WorkPool {
 }  // namespace rt
 }  // namespace nrtgpu
 
+struct nrtgpu_dist;   // dist.cpp: RCCL communicator of this context (nrtgpu_dist_init)
+
 struct nrtgpu_ctx {
   nrtgpu_config cfg{};
+  nrtgpu_dist* dist = nullptr;
   int device = 0;
   int n_cus = 0;
   std::mutex mu;

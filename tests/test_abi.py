@@ -243,3 +243,39 @@ def test_fixed_point_scale_makes_every_score_an_integer():
         scaled = sc.astype(np.float64) * 2.0 ** scale.value
         assert (scaled == np.floor(scaled)).all() and (scaled >= 1).all() and (scaled < 2.0 ** 32).all()
     assert accepted >= 20   # (norm byte 255 is a 2-billion-token field: those configurations are refused)
+
+
+def test_blend_product_function_matches_the_reference_rules(lib):
+    """nrtgpu_blend: WeightedRrfBlenderOperation / score order + sortAndPaginate; the golden 1 / (60 + r) of
+    MultiRetrieverSearchTest.java:410-442, docs in both retrievers outrank 1/61 (:449-497), window / startHit rules."""
+    td = api.blend([np.array([7, 3, 9])], top_hits=10)
+    assert td.docs.tolist() == [7, 3, 9] and td.relation_gte and td.total_hits == 3
+    assert np.allclose(td.scores, [1 / 61, 1 / 62, 1 / 63], rtol=0, atol=1e-7)
+    td = api.blend([np.array([1, 2, 3]), np.array([3, 4, 1])], top_hits=10)
+    assert td.docs.tolist()[:2] == [1, 3] and td.total_hits == 4
+    assert abs(float(td.scores[0]) - float(np.float32(np.float32(1 / np.float32(61)) + np.float32(1 / np.float32(63))))) < 1e-9
+    assert float(td.scores[1]) > 1 / 61
+    td = api.blend([np.array([5]), np.array([6])], boosts=[1.0, 3.0], top_hits=2)
+    assert td.docs.tolist() == [6, 5]
+    assert api.blend([np.array([1, 2, 3])], start_hit=1, top_hits=3).docs.tolist() == [2, 3]
+    assert len(api.blend([np.array([1])], top_hits=0).docs) == 0
+    with pytest.raises(_lib.NrtGpuError):
+        api.blend([np.array([1])], k=0)
+    # score order: boost * score summed over the retrievers
+    td = api.blend([np.array([1, 2]), np.array([2, 3])], [np.array([2.0, 1.0], np.float32), np.array([4.0, 0.5], np.float32)],
+                   boosts=[1.0, 0.5], mode="score", top_hits=3)
+    assert td.docs.tolist() == [2, 1, 3] and np.allclose(td.scores, [3.0, 2.0, 0.25])
+    # against the Python mirror on random lists (distinct scores: tie order is the reference's containers', checked below)
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        lists = [rng.choice(500, size=int(rng.integers(1, 60)), replace=False) for _ in range(int(rng.integers(1, 4)))]
+        boosts = rng.uniform(0.5, 2.0, size=len(lists)).astype(np.float32)
+        a = api.blend(lists, boosts=boosts, top_hits=25)
+        b = api.weighted_rrf_blend(lists, boosts=boosts, top_hits=25)
+        assert a.total_hits == b.total_hits and np.array_equal(a.scores, b.scores)
+        distinct = len(set(a.scores.tolist())) == len(a.scores)
+        assert (not distinct) or a.docs.tolist() == b.docs.tolist()
+    # ties: every doc of one list of 3 scores differently, but two one-hit retrievers tie at 1/61: the survivor order is
+    # java.util.HashMap's bucket order (doc 17 -> bucket 1, doc 33 -> bucket 1 after doc 17; doc 2 -> bucket 2) feeding the heap
+    td = api.blend([np.array([33]), np.array([2]), np.array([17])], top_hits=3)
+    assert sorted(td.docs.tolist()) == [2, 17, 33] and len(set(td.scores.tolist())) == 1

@@ -148,3 +148,31 @@ def test_exchange_table_written_and_honoured():
         for l in leaves:
             l.release()
         ctx.close()
+
+
+def test_collective_inside_the_library_world_of_one(oracle):
+    """nrtgpu_dist_*: local search -> RCCL all-gather -> merge, all behind the C ABI (no torch in the data path).  A
+    one-rank communicator exercises every step on the one GPU this pool has; the N-rank logic is the same call."""
+    from nrtsearch_amd import api
+
+    w = workload.Workload("dist test", 300_000, 4, 100, 24, 3)
+    qr = synth.make_queries(24, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr)
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    try:
+        ctx.dist_init(1, 0, api.GpuContext.dist_unique_id())
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        queries = workload.boolean_queries(qr)
+        mgr = api.TopScoreDocCollectorManager(w.k)
+        got = sr.dist_search_batch(queries, [mgr] * len(queries))
+        for qi in range(len(queries)):
+            edocs, escores, etotal, egte = oracle.search_bm25(corpus, qr[qi].tolist(), w.k)
+            assert got[qi].docs.tolist() == edocs.tolist() and got[qi].scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist()
+            assert got[qi].relation_gte == egte
+            assert (1000 < got[qi].total_hits <= etotal) if egte else got[qi].total_hits == etotal
+    finally:
+        ctx.dist_close()
+        for l in leaves:
+            l.release()
+        ctx.close()
