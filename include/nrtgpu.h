@@ -260,7 +260,10 @@ int  nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_querie
  *   queries: n_queries * dim fp32, row-major (already normalised by the caller where the field asks
  *        for it, VectorFieldDef.java:564-573)
  * Scores are fp32 sums in MFMA order: equal to Lucene within 1e-5 relative (Lucene's own order
- * depends on the JVM's vector width); docids ranked by (score desc, doc asc).
+ * depends on the JVM's vector width); docids ranked by (score desc, doc asc).  l2_norm: the squared distance is taken
+ * as |q|^2 + |v|^2 - 2 q.v (one pass over the rows for every query of the batch), whose rounding error is
+ * ~1e-7 * (|q|^2 + |v|^2): for near-duplicate vectors of large norm that exceeds 1e-5 of a tiny distance -- the
+ * tolerance claim holds for the score 1 / (1 + d^2) (absolute 1e-4, tests/test_vectors_gpu.py), not for d^2 itself.
  * --------------------------------------------------------------------------------------------- */
 int  nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                       int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k,

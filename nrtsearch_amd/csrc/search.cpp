@@ -328,7 +328,10 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   DeviceRun run;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
-    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) {
+      (void)hipStreamSynchronize(st);   // the upload of the query vectors reads the slot's pinned buffer: not in flight when the slot is released
+      return rc;
+    }
     launch_hybrid_rescore(st, (uint32_t)n_queries, run.out_keys, run.out_counts, hp.k_stride, (const DVecSeg*)(da + o_segs), n_segs,
                           dim, (const float*)(da + o_qv), (const float*)(da + o_qn), sim, boost, query_weight, rescore_weight,
                           (uint32_t)window, (uint64_t*)(da + o_wk), (uint32_t*)(da + o_wc), w_stride);
@@ -495,20 +498,32 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     qs[i] = *batch[i]->q;
     outs[i] = *batch[i]->out;
   }
-  const int rc = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data());
-  const std::string err = rc ? g_last_error : std::string();
+  int rc = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data());
+  std::string err = rc ? g_last_error : std::string();
+  // A request the planner rejects (a mask that is not resident on a leaf, a clause shape outside the fixed-point range ...)
+  // must not fail its batch mates: the batch is re-run member by member and only the offender gets the error.
+  std::vector<int> rcs(batch.size(), rc);
+  std::vector<std::string> errs(batch.size(), err);
+  if (rc != 0 && batch.size() > 1) {
+    for (size_t i = 0; i < batch.size(); ++i) {
+      rcs[i] = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, &qs[i], 1, &outs[i]);
+      errs[i] = rcs[i] ? g_last_error : std::string();
+    }
+    rc = rcs[0];   // batch[0] is this caller
+    err = errs[0];
+  }
   for (size_t i = 0; i < batch.size(); ++i) {
     CoRequest* r = batch[i];
     if (r == &me) {
-      if (rc == 0) *out = outs[i];
+      if (rcs[i] == 0) *out = outs[i];
       continue;
     }
     // (notified under the request's own lock: the woken caller cannot return -- and free its request -- before
     // we are done with it, and it contends with nobody but us)
     std::lock_guard<std::mutex> theirs(r->m);
-    if (rc == 0) *r->out = outs[i];
-    r->rc = rc;
-    if (rc != 0) r->err = err;
+    if (rcs[i] == 0) *r->out = outs[i];
+    r->rc = rcs[i];
+    if (rcs[i] != 0) r->err = errs[i];
     r->done = true;
     r->cv.notify_one();
   }

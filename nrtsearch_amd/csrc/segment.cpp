@@ -11,6 +11,7 @@ SegWriteLock::~SegWriteLock() {
   seg->content_writers.fetch_sub(1, std::memory_order_acq_rel);
 }
 
+static const size_t kMaxAcceptSets = 64;   // combined accept sets (liveDocs & filter & ~must_not) resident per segment
 static const size_t kMaskPadBytes = 256;  // doc-set masks are readable one sub-tile (128 bytes) past max_doc
 
 static void drop_accept_sets(nrtgpu_seg* seg) {
@@ -365,6 +366,11 @@ int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_
     *out = it->second;
     return 0;
   }
+  // Bounded like the reference's LRUQueryCache -- but an entry may be in use by a search in flight, so the bound refuses
+  // rather than evicts: further (filter, must_not) combinations of this leaf run on the caller's own path until liveDocs
+  // or a mask change (which drops every set).
+  if (seg->accept.size() >= kMaxAcceptSets)
+    return fail(NRTGPU_ERR_UNSUPPORTED, "%zu combined doc sets are resident on a segment already", seg->accept.size());
   const std::vector<uint64_t>* f = nullptr;
   const std::vector<uint64_t>* mn = nullptr;
   if (filter_mask) {
