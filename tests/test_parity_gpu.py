@@ -431,7 +431,7 @@ def test_query_supported_is_the_planners_predicate(mid):
     assert mid.searcher.supported(bq([424242]), ok)                                   # a term no leaf holds: runs, matches nothing
     assert not mid.searcher.supported(bq([1, 5]), api.TopScoreDocCollectorManager(5000))            # numHits > NRTGPU_MAX_K
     assert not mid.searcher.supported(bq(list(range(1, 40))), ok)                     # more clauses than NRTGPU_MAX_TERMS
-    q = api.BooleanQuery(tuple(api.TermQuery(0, t) for t in (1, 100)), 0, (api.MaskFilter(9999),), ())
+    q = api.BooleanQuery(tuple(api.TermQuery(0, t) for t in (1, 100)), 1, (api.MaskFilter(9999),), ())
     assert not mid.searcher.supported(q, ok)                                          # FILTER mask not resident
     with pytest.raises(_lib.NrtGpuError):
         mid.searcher.supported(bq([1]), api.TopScoreDocCollectorManager(0))           # invalid argument, not "unsupported"
