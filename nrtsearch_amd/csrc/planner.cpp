@@ -74,7 +74,9 @@ std::shared_ptr<LeafSetCache> nrtgpu::rt::leaf_set_cache(nrtgpu_ctx* ctx, const 
       return ctx->leaf_sets[0];
     }
   }
+  static std::atomic<uint64_t> next_id{1};
   auto c = std::make_shared<LeafSetCache>();
+  c->id = next_id.fetch_add(1, std::memory_order_relaxed);
   c->device = ctx->device;
   c->uids.resize((size_t)n_segs);
   for (int32_t s = 0; s < n_segs; ++s) c->uids[(size_t)s] = segs[s]->uid;
@@ -83,13 +85,32 @@ std::shared_ptr<LeafSetCache> nrtgpu::rt::leaf_set_cache(nrtgpu_ctx* ctx, const 
   return c;
 }
 
-std::shared_ptr<const TermLeaves> LeafSetCache::get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash) {
+size_t LeafSetCache::entries() {
+  size_t n = 0;
+  for (Stripe& st : stripes) {
+    std::shared_lock<std::shared_mutex> rd(st.mu);
+    n += st.map.size();
+  }
+  return n;
+}
+
+const TermLeaves* LeafSetCache::get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash) {
+  // the calling thread's front cache: direct-mapped, tagged with the cache object's id
+  struct Front { uint64_t owner; int64_t hash; int32_t field; const TermLeaves* tl; };
+  static const size_t kFront = 8192;
+  thread_local std::vector<Front> front(kFront, Front{0, 0, 0, nullptr});
   const Key key{field, hash};
-  Stripe& st = stripes[KeyHash()(key) % (size_t)kStripes];
+  const size_t kh = KeyHash()(key);
+  Front& f = front[(kh >> 6) & (kFront - 1)];
+  if (f.owner == id && f.hash == hash && f.field == field) return f.tl;
+  Stripe& st = stripes[kh % (size_t)kStripes];
   {
     std::shared_lock<std::shared_mutex> rd(st.mu);
     auto it = st.map.find(key);
-    if (it != st.map.end()) return it->second;
+    if (it != st.map.end()) {
+      f = Front{id, hash, field, it->second.get()};
+      return f.tl;
+    }
   }
   auto tl = std::make_shared<TermLeaves>();
   std::vector<DTerm> leaf((size_t)n_segs, DTerm{});
@@ -116,15 +137,15 @@ std::shared_ptr<const TermLeaves> LeafSetCache::get(const nrtgpu_seg* const* seg
   if (tl->total > 0) {  // (a term no leaf holds needs no table: it never reaches the device)
     DTerm* d_table = alloc_table((size_t)n_segs);
     if (d_table == nullptr || hipMemcpy(d_table, leaf.data(), (size_t)n_segs * sizeof(DTerm), hipMemcpyHostToDevice) != hipSuccess) {
-      tl->total = -1;   // out of device memory: the caller fails the batch
-      return tl;
+      tl->total = -1;   // out of device memory: the caller fails the batch (the entry is kept: later batches fail alike
+    } else {            // until the cache is replaced)
+      tl->d_table = d_table;
     }
-    tl->d_table = d_table;
   }
   std::unique_lock<std::shared_mutex> wr(st.mu);
-  if (st.map.size() >= kMaxPerStripe) st.map.clear();   // (the tables stay resident until the cache itself goes)
-  auto ins = st.map.emplace(key, tl);
-  return ins.first->second;
+  auto ins = st.map.emplace(key, tl);   // (a racing thread may have inserted the term meanwhile: its entry stays)
+  f = Front{id, hash, field, ins.first->second.get()};
+  return f.tl;
 }
 
 DTerm* LeafSetCache::alloc_table(size_t n_leaves) {
@@ -158,7 +179,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
                             std::vector<int64_t>& q_lower) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
-  std::vector<std::shared_ptr<const TermLeaves>> ents;
+  std::vector<const TermLeaves*> ents;
   std::vector<int64_t> slice_sum((size_t)std::max(n_slices, 1));
   bool any_deleted = false, plain = true;
   for (int si = 0; si < n_segs; ++si) {
@@ -419,7 +440,6 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   const int64_t min_item_cost = 1 << 17;
   struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; uint32_t slice; };
   const uint32_t kAnySlice = 0xFFFFFFFFu;
-  std::vector<QS> by_slice;
   std::vector<Pending> pend;
   std::vector<int64_t> q_costs((size_t)n_queries, 0), q_items((size_t)n_queries, 0);
   for (int qi = 0; qi < n_queries; ++qi)
@@ -428,81 +448,109 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       q_costs[(size_t)qi] += qs.postings + (int64_t)segs[qs.seg]->n_tiles * kTileCostPostings;
     }
   hostmath::plan_item_counts(q_costs.data(), n_queries, target_items, min_item_cost, q_items.data());  // host_math.h
-  for (int qi = 0; qi < n_queries; ++qi) {
-    const int64_t q_cost = q_costs[(size_t)qi];
-    if (q_cost == 0) continue;
-    const int64_t n_it = q_items[(size_t)qi];
-    const double budget = (double)q_cost / (double)n_it;
-    // The relation of an exhaustively scanned query with a finite threshold is decided per slice (slice_relation_kernel):
-    // its items then never span two slices.  COMPLETE mode never reports GTE and the MaxScore route tags its own items.
-    const bool per_slice = n_slices > 1 && hp.q_lower[(size_t)qi] == 0 && queries[qi].total_hits_threshold != INT32_MAX;
-    const QS* qsv = qs_of(qi);
-    const uint32_t n_qs = q_qs_cnt[(size_t)qi];
-    if (per_slice) {
-      by_slice.assign(qsv, qsv + n_qs);
-      std::stable_sort(by_slice.begin(), by_slice.end(), [&](const QS& a, const QS& b) { return slice_of_leaf[(size_t)a.seg] < slice_of_leaf[(size_t)b.seg]; });
-      qsv = by_slice.data();
-    }
-    auto slice_of = [&](const QS& qs) { return n_slices > 1 && hp.q_lower[(size_t)qi] == 0 ? (uint32_t)slice_of_leaf[(size_t)qs.seg]
-                                                                                         : (n_slices > 1 ? kAnySlice : 0u); };
-    Pending cur{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0, n_qs ? slice_of(qsv[0]) : 0u};
-    double filled = 0.0;
-    for (uint32_t j = 0; j < n_qs; ++j) {
-      const QS& qs = qsv[j];
-      const nrtgpu_seg* seg = segs[qs.seg];
-      if (per_slice && cur.n_parts > 0 && slice_of(qs) != cur.slice) {  // slice boundary: close the item
-        pend.push_back(cur);
-        cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0, slice_of(qs)};
-        filled = 0.0;
+  // One contiguous range of queries per worker, each into its own part / item vectors; concatenated in range order
+  // below, so the plan is the one a single thread would have produced.
+  struct CutPiece { std::vector<DPart> parts; std::vector<Pending> pend; bool masked = false; int rc = 0; };
+  std::vector<CutPiece> cuts((size_t)n_thr);
+  auto cut_work = [&](int t) {
+    const int q0 = chunk_begin(t), q1 = chunk_begin(t + 1);
+    std::vector<DPart>& parts = cuts[(size_t)t].parts;
+    std::vector<Pending>& pend = cuts[(size_t)t].pend;
+    bool& masked = cuts[(size_t)t].masked;
+    int& cut_rc = cuts[(size_t)t].rc;
+    std::vector<QS> by_slice;
+    parts.reserve((size_t)(q1 - q0) * (size_t)std::max(n_segs, 1));
+    pend.reserve((size_t)(q1 - q0) * 2);
+    for (int qi = q0; qi < q1; ++qi) {
+      const int64_t q_cost = q_costs[(size_t)qi];
+      if (q_cost == 0) continue;
+      const int64_t n_it = q_items[(size_t)qi];
+      const double budget = (double)q_cost / (double)n_it;
+      // The relation of an exhaustively scanned query with a finite threshold is decided per slice (slice_relation_kernel):
+      // its items then never span two slices.  COMPLETE mode never reports GTE and the MaxScore route tags its own items.
+      const bool per_slice = n_slices > 1 && hp.q_lower[(size_t)qi] == 0 && queries[qi].total_hits_threshold != INT32_MAX;
+      const QS* qsv = qs_of(qi);
+      const uint32_t n_qs = q_qs_cnt[(size_t)qi];
+      if (per_slice) {
+        by_slice.assign(qsv, qsv + n_qs);
+        std::stable_sort(by_slice.begin(), by_slice.end(), [&](const QS& a, const QS& b) { return slice_of_leaf[(size_t)a.seg] < slice_of_leaf[(size_t)b.seg]; });
+        qsv = by_slice.data();
       }
-      if (cur.n_parts == 0) cur.slice = slice_of(qs);
-      else if (!per_slice && slice_of(qs) != cur.slice) cur.slice = kAnySlice;
-      const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
-      const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
-      if (int rc = accept_set_of(seg, queries[qi].filter_mask, queries[qi].must_not_mask, &accept)) return rc;
-      uint32_t tb = 0;
-      while (tb < seg->n_tiles) {
-        double room = budget - filled;
-        uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tile_cost + 0.5));
-        take = std::min<uint32_t>(take, seg->n_tiles - tb);
-        DPart p{};
-        p.live_bits = accept;
-        if (accept) hp.masked = true;
-        p.term_begin = qs.term_begin;
-        p.n_terms = qs.n_terms;
-        p.tile_begin = tb;
-        p.tile_end = tb + take;
-        p.max_doc = (uint32_t)seg->max_doc;
-        p.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
-        p.tile_offset = cur.tiles;
-        hp.parts.push_back(p);
-        cur.n_parts++;
-        cur.tiles += take;
-        cur.cost += (int64_t)(take * tile_cost);
-        filled += take * tile_cost;
-        tb += take;
-        if (filled >= budget * 0.999) {  // item full: close it
+      auto slice_of = [&](const QS& qs) { return n_slices > 1 && hp.q_lower[(size_t)qi] == 0 ? (uint32_t)slice_of_leaf[(size_t)qs.seg]
+                                                                                           : (n_slices > 1 ? kAnySlice : 0u); };
+      Pending cur{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, n_qs ? slice_of(qsv[0]) : 0u};
+      double filled = 0.0;
+      for (uint32_t j = 0; j < n_qs; ++j) {
+        const QS& qs = qsv[j];
+        const nrtgpu_seg* seg = segs[qs.seg];
+        if (per_slice && cur.n_parts > 0 && slice_of(qs) != cur.slice) {  // slice boundary: close the item
           pend.push_back(cur);
-          cur = Pending{0, (uint32_t)qi, (uint32_t)hp.parts.size(), 0, 0, slice_of(qs)};
+          cur = Pending{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, slice_of(qs)};
           filled = 0.0;
+        }
+        if (cur.n_parts == 0) cur.slice = slice_of(qs);
+        else if (!per_slice && slice_of(qs) != cur.slice) cur.slice = kAnySlice;
+        const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
+        const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
+        if (int rc = accept_set_of(seg, queries[qi].filter_mask, queries[qi].must_not_mask, &accept)) { cut_rc = rc; return; }
+        uint32_t tb = 0;
+        while (tb < seg->n_tiles) {
+          double room = budget - filled;
+          uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tile_cost + 0.5));
+          take = std::min<uint32_t>(take, seg->n_tiles - tb);
+          DPart p{};
+          p.live_bits = accept;
+          if (accept) masked = true;
+          p.term_begin = qs.term_begin;
+          p.n_terms = qs.n_terms;
+          p.tile_begin = tb;
+          p.tile_end = tb + take;
+          p.max_doc = (uint32_t)seg->max_doc;
+          p.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
+          p.tile_offset = cur.tiles;
+          parts.push_back(p);
+          cur.n_parts++;
+          cur.tiles += take;
+          cur.cost += (int64_t)(take * tile_cost);
+          filled += take * tile_cost;
+          tb += take;
+          if (filled >= budget * 0.999) {  // item full: close it
+            pend.push_back(cur);
+            cur = Pending{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, slice_of(qs)};
+            filled = 0.0;
+          }
+        }
+      }
+      if (cur.n_parts > 0) {
+        // A short remainder (the tile rounding of the items before it) does not become an item of its own: it would
+        // finish without a single compaction, never publish its quantile, and with one peer silent the bound
+        // exchange between the query's items never forms (kernels.hip: peers_bound).  It joins the item before it.
+        if (!pend.empty() && pend.back().query == (uint32_t)qi && (double)cur.cost < 0.5 * budget &&
+            pend.back().part_begin + pend.back().n_parts == cur.part_begin && (!per_slice || pend.back().slice == cur.slice)) {
+          Pending& prev = pend.back();
+          for (uint32_t pi2 = 0; pi2 < cur.n_parts; ++pi2) parts[cur.part_begin + pi2].tile_offset += prev.tiles;
+          prev.n_parts += cur.n_parts;
+          prev.tiles += cur.tiles;
+          prev.cost += cur.cost;
+          if (prev.slice != cur.slice) prev.slice = kAnySlice;
+        } else {
+          pend.push_back(cur);
         }
       }
     }
-    if (cur.n_parts > 0) {
-      // A short remainder (the tile rounding of the items before it) does not become an item of its own: it would
-      // finish without a single compaction, never publish its quantile, and with one peer silent the bound
-      // exchange between the query's items never forms (kernels.hip: peers_bound).  It joins the item before it.
-      if (!pend.empty() && pend.back().query == (uint32_t)qi && (double)cur.cost < 0.5 * budget &&
-          pend.back().part_begin + pend.back().n_parts == cur.part_begin && (!per_slice || pend.back().slice == cur.slice)) {
-        Pending& prev = pend.back();
-        for (uint32_t pi2 = 0; pi2 < cur.n_parts; ++pi2) hp.parts[cur.part_begin + pi2].tile_offset += prev.tiles;
-        prev.n_parts += cur.n_parts;
-        prev.tiles += cur.tiles;
-        prev.cost += cur.cost;
-        if (prev.slice != cur.slice) prev.slice = kAnySlice;
-      } else {
-        pend.push_back(cur);
-      }
+  };
+  ctx->pool->run(n_thr, cut_work);
+  {
+    size_t np = 0, ni = 0;
+    for (const CutPiece& c : cuts) { np += c.parts.size(); ni += c.pend.size(); }
+    hp.parts.reserve(hp.parts.size() + np);
+    pend.reserve(ni);
+    for (CutPiece& c : cuts) {
+      if (c.rc) return c.rc;
+      const uint32_t base = (uint32_t)hp.parts.size();
+      hp.parts.insert(hp.parts.end(), c.parts.begin(), c.parts.end());
+      for (Pending& a : c.pend) { a.part_begin += base; pend.push_back(a); }
+      if (c.masked) hp.masked = true;
     }
   }
   // longest-processing-time-first launch order: the hardware dispatcher hands out workgroups in
@@ -520,7 +568,16 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   for (int qi = 0; qi < n_queries; ++qi)   // COMPLETE mode: nothing exceeds it
     hp.q_gte_floor[(size_t)qi] = queries[qi].total_hits_threshold == INT32_MAX ? 0xFFFFFFFFu
                                                                                : (uint32_t)std::max(queries[qi].total_hits_threshold, queries[qi].k);
-  std::vector<std::vector<uint32_t>> lists((size_t)n_queries);
+  // the items of a query, in launch order: counting sort by query (q_base = first slot of the query's list)
+  hp.q_base.assign((size_t)n_queries, 0);
+  hp.q_nlists.assign((size_t)n_queries, 0);
+  for (const Pending& a : pend) hp.q_nlists[a.query]++;
+  {
+    uint32_t run = 0;
+    for (int qi = 0; qi < n_queries; ++qi) { hp.q_base[(size_t)qi] = run; run += hp.q_nlists[(size_t)qi]; }
+  }
+  hp.list_idx.assign(pend.size(), 0);
+  std::vector<uint32_t> q_fill((size_t)n_queries, 0);
   for (size_t i = 0; i < pend.size(); ++i) {
     DItem it{};
     it.query = pend[i].query;
@@ -536,18 +593,12 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       it.tab_cache[r] = qt_.cache[r];
       it.tab_scale[r] = qt_.scale[r];
     }
-    it.peer_slot = (uint32_t)lists[pend[i].query].size();  // rebased by the query's list offset below
+    it.peer_slot = hp.q_base[pend[i].query] + q_fill[pend[i].query]++;
     hp.items[i] = it;
-    lists[pend[i].query].push_back((uint32_t)i);
+    hp.list_idx[it.peer_slot] = (uint32_t)i;
   }
-  hp.q_base.resize((size_t)n_queries);
-  hp.q_nlists.resize((size_t)n_queries);
   for (int qi = 0; qi < n_queries; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
-    hp.q_base[(size_t)qi] = (uint32_t)hp.list_idx.size();
-    hp.q_nlists[(size_t)qi] = (uint32_t)lists[(size_t)qi].size();
-    hp.list_idx.insert(hp.list_idx.end(), lists[(size_t)qi].begin(), lists[(size_t)qi].end());
-    for (uint32_t ii : lists[(size_t)qi]) hp.items[ii].peer_slot += hp.q_base[(size_t)qi];
     hp.q_k[(size_t)qi] = (uint32_t)q.k;
     DQuery& dq = hp.queries[(size_t)qi];
     dq.k = (uint32_t)q.k;

@@ -402,7 +402,7 @@ struct LeafSetCache {
     size_t operator()(const Key& k) const { return (size_t)(((uint64_t)k.hash ^ ((uint64_t)(uint32_t)k.field << 40)) * 0x9E3779B97F4A7C15ull >> 7); }
   };
   static const int kStripes = 64;
-  static const size_t kMaxPerStripe = 8192;   // entries per stripe before it is dropped and refilled (bounds the memory)
+  static const size_t kMaxEntries = 1 << 20;  // then the context starts a fresh cache for the leaf set (bounds the memory)
   struct Stripe {
     std::shared_mutex mu;
     std::unordered_map<Key, std::shared_ptr<const TermLeaves>, KeyHash> map;
@@ -416,10 +416,22 @@ struct LeafSetCache {
   size_t chunk_used = 0;
   static const size_t kChunkBytes = 1 << 20;
   static const size_t kMaxChunks = 256;       // then the context starts a fresh cache for the leaf set
-  bool full() { std::lock_guard<std::mutex> lk(arena_mu); return chunks.size() > kMaxChunks; }
+  bool full() {
+    {
+      std::lock_guard<std::mutex> lk(arena_mu);
+      if (chunks.size() > kMaxChunks) return true;
+    }
+    return entries() > kMaxEntries;
+  }
   DTerm* alloc_table(size_t n_leaves);
   ~LeafSetCache();
-  std::shared_ptr<const TermLeaves> get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash);
+  // Entries are never freed while the cache lives (a full cache is replaced as a whole, leaf_set_cache()), so a raw
+  // pointer stays valid for as long as the caller holds the cache -- which lets every planner thread keep a private
+  // front cache and take no lock and no reference count on a hit (four threads bouncing the stripes' lock words cost
+  // more than the lookups themselves).
+  uint64_t id = 0;   // unique per cache object: tags the threads' front-cache entries
+  const TermLeaves* get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash);
+  size_t entries();
 };
 std::shared_ptr<LeafSetCache> leaf_set_cache(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs);
 
