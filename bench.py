@@ -39,7 +39,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024, help="queries per step")
     ap.add_argument("--host-threads", type=int, default=2,
                     help="N=1 only: host threads submitting steps (plan building of step i+1 overlaps the kernels of step i)")
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "SMOKE"])
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "SMOKE"],
+                    help="C3 (default, the headline), C2, or C4 = exact kNN over --docs (default 10M) x 768 fp32 rows, "
+                         "cosine, top-100, --knn-queries per step (1 GPU)")
+    ap.add_argument("--knn-queries", type=int, default=32, help="C4: queries per step (one panel = up to 32 queries)")
     ap.add_argument("--docs", type=int, default=0, help="override the number of docs (debug)")
     ap.add_argument("--target-items", type=int, default=0)
     ap.add_argument("--no-prefetch", action="store_true")
@@ -59,6 +62,9 @@ def parse_args():
                     help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="debug, 1 GPU: index only rank 0's docid range of an N-GPU job (per-rank step time at --gpus N)")
+    ap.add_argument("--torch-collective", action="store_true",
+                    help="N>1: exchange with torch.distributed's all-gather instead of the library's own RCCL stage "
+                         "(nrtgpu_dist_allgather_merge, the default; falls back to torch by itself if RCCL cannot be bound)")
     return ap.parse_args()
 
 
@@ -82,6 +88,25 @@ def usable_cpus():
         except (OSError, ValueError):
             pass
     return n
+
+
+def stdout_to_stderr(fn):
+    """Runs fn() with file descriptor 1 pointing at stderr: RCCL prints a version banner on stdout when a communicator is
+    created (through C stdio, so it would land AFTER the JSON line at exit); the bench's stdout carries the JSON line only."""
+    import ctypes
+
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return fn()
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def cpu_baseline(corpus, query_ranks, k, n_queries):
@@ -162,8 +187,108 @@ def lucene_baseline(w, searcher, queries, mgr, n_queries):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 is exact fp32
+
+
+def run_c4(args):
+    """BASELINE.json config 4 at one GPU: N x 768 fp32 rows resident in HBM, exact (brute-force) cosine kNN top-100 --
+    what KnnFloatVectorQuery / ExactVectorQuery compute, answered by nrtgpu_knn_exact.  A step = one call with
+    --knn-queries queries (every <= 64 of them stream the rows once).  Roofline: HBM (N * dim * 4 bytes per pass), with the
+    fp32 MFMA fraction beside it (at 64 queries per pass the matrix rate needed is as large as the HBM rate allows)."""
+    import numpy as np
+    import torch
+
+    from nrtsearch_amd import api, build
+
+    build.build()
+    torch.cuda.set_device(0)
+    n, dim, k, Q = (args.docs or 10_000_000), 768, 100, max(1, args.knn_queries)
+    seg_rows = 2_500_000
+    ctx = api.GpuContext(device_id=0, max_batch=64, collect_timing=True)
+    t_build = time.perf_counter()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(777)
+    leaves, base, first_seg = [], 0, None
+    while base < n:
+        rows = min(seg_rows, n - base)
+        host = torch.randn((rows, dim), generator=gen, device="cuda", dtype=torch.float32).cpu().numpy()
+        g = api.GpuSegment(ctx, rows, base)
+        g.add_vectors(0, host)
+        g.seal()
+        leaves.append(g)
+        if first_seg is None:
+            first_seg = host[: min(rows, 1_000_000)].copy()
+        del host
+        base += rows
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics())
+    t_build = time.perf_counter() - t_build
+    qrng = np.random.Generator(np.random.PCG64(778))
+    panels = [qrng.standard_normal((Q, dim), dtype=np.float32) for _ in range(4)]
+    lat = []
+    for i in range(args.warmup):
+        sr.knn_exact(0, "cosine", panels[i % len(panels)], k)
+    ctx.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        last = sr.knn_exact(0, "cosine", panels[(args.warmup + i) % len(panels)], k)
+        lat.append(time.perf_counter() - ts)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    n_panels = max(1, st["knn_panels"])
+    score_ms = st["knn_score_ms"] / n_panels                    # knn_score_kernel launches of one panel (HIP events, its stream)
+    bytes_per_panel = st["knn_rows"] / n_panels * dim * 4        # every row once per panel
+    q_per_panel = Q / max(1, (Q + 63) // 64)   # queries per pass over the rows (two 32-query panels on paired workgroups)
+    achieved = bytes_per_panel / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+    tflops = 2.0 * (st["knn_rows"] / n_panels) * dim * q_per_panel / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
+    out = {
+        "metric": "queries/sec, exact kNN 10M x 768 fp32 cosine top-100" if n == 10_000_000 else f"queries/sec, exact kNN {n} x 768 fp32 cosine top-100",
+        "value": round(args.steps * Q / elapsed, 2), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(statistics.median(lat) * 1e3, 4),
+        "max_latency_ms": round(max(lat) * 1e3, 4), "slowest_step": int(np.argmax(lat)),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C4: {n} x {dim} fp32 rows, brute-force cosine top-{k}", "n_docs": n, "dim": dim, "k": k,
+                   "queries_per_step": Q, "segments_per_gpu": len(leaves), "corpus_build_s": round(t_build, 1)},
+        "roofline": {"bound": "hbm", "kernel": "knn_score_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(bytes_per_panel),
+                     "launch": "the knn_score_kernel launches of one pass over the rows (<= 64 queries; a few rounds, theta tightens in between)",
+                     "score_launches_per_panel": round(st["knn_score_launches"] / n_panels, 2),
+                     "avg_launch_ms": round(score_ms, 4),
+                     "mfma_tflops": round(tflops, 2), "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                     "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None},
+    }
+    if not args.no_cpu_baseline:
+        # the C restatement of ExactVectorQuery + collector on the host cores, bounded sample: first rows of segment 0
+        from oracle import oracle
+
+        oracle.build()
+        cores = usable_cpus()
+        nq_cpu = min(Q, 8)
+        t1 = time.perf_counter()
+        docs, scores, cnt = oracle.knn_exact(0, panels[(args.warmup + args.steps - 1) % len(panels)][:nq_cpu], first_seg, k, n_threads=cores)
+        dt = time.perf_counter() - t1
+        # the sample doubles as a check of the device's answer: both top-k lists restricted to the sample's rows
+        ok = True
+        if n <= len(first_seg):
+            for qi in range(nq_cpu):
+                ok = ok and np.allclose(last[qi].scores, scores[qi], rtol=1e-5, atol=1e-6)
+        out["cpu_baseline"] = {"value": round(nq_cpu * (n / len(first_seg)) ** -1 / dt, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+                               "rows_per_s": round(nq_cpu * len(first_seg) / dt, 1),
+                               "sample": f"{nq_cpu} queries x the first {len(first_seg)} rows (oracle/nrt_oracle.c nrt_oracle_knn_exact, scalar fp32 "
+                                         f"left to right, C + OpenMP, {cores} threads, {dt:.2f}s); value = queries/s extrapolated to {n} rows",
+                               "agrees_with_device": bool(ok) if n <= len(first_seg) else None}
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
 def main():
     args = parse_args()
+    if args.workload == "C4":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+            sys.exit("--workload C4 is a one-GPU line (the headline workload C3 is the multi-GPU one)")
+        return run_c4(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -183,7 +308,11 @@ def main():
         if args.debug_same_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            def _init():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()   # the communicator is created here at the latest
+
+            stdout_to_stderr(_init)
 
     def all_gather(dst, src):
         if args.debug_same_gpu:   # gloo: stage through the host
@@ -245,6 +374,7 @@ def main():
             print(f"[rank {rank}] bound exchange unavailable: {e}", file=sys.stderr, flush=True)
         dist.barrier()
     NB = 3  # device result buffers in flight between the scan threads and the exchange thread
+    lib_collective = False
     if use_dist:
         bufs = [(torch.zeros((B, k_stride), dtype=torch.int64, device="cuda"),
                  torch.zeros((B,), dtype=torch.int32, device="cuda"),
@@ -273,6 +403,23 @@ def main():
         g_hits = torch.zeros((rows,), dtype=torch.int64, device="cuda")
         mq = B // world if split_reduce else B
         merger = api.PreparedMerge(ctx, world, mq, k_stride, [w.k] * mq, [api.TOTAL_HITS_THRESHOLD] * mq)
+        # The exchange stage through the C ABI (what a JVM caller has): the library's own RCCL communicator, one grouped
+        # all-gather + merge per batch.  Every rank must take the same path: agree on it once.
+        if not (args.torch_collective or args.debug_same_gpu or split_reduce):
+            ok = 1
+            try:
+                box = [api.GpuContext.dist_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                stdout_to_stderr(lambda: ctx.dist_init(world, rank, box[0]))
+            except Exception as e:   # noqa: BLE001
+                print(f"[rank {rank}] library collective unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
+                ok = 0
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            lib_collective = bool(ok)
 
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -327,6 +474,14 @@ def main():
                 b = futs[i].result()
                 te0 = time.perf_counter()
                 keys, cnt, hits = bufs[b]
+                if lib_collective:
+                    merger.run_dist(keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())   # all-gather + merge, synchronous
+                    free[b].release()
+                    if record:
+                        lat.append(time.perf_counter() - t_start[i])
+                        stage["exchange_s"] += time.perf_counter() - te0
+                        stage["steps"] += 1
+                    continue
                 exchange = all_to_all if split_reduce else all_gather
                 exchange(g_keys, keys) if world > 1 else g_keys.copy_(keys)
                 exchange(g_cnt, cnt) if world > 1 else g_cnt.copy_(cnt)
@@ -407,6 +562,7 @@ def main():
             "segments_per_gpu": len(corpus.segments),
             "sharding": "contiguous docid ranges, 1 process per GPU" + ((", RCCL all-to-all of per-GPU top-k, each rank merges its slice of the batch" if split_reduce else
                                                                            ", RCCL all-gather of per-GPU top-k + merge on every rank") if use_dist else "")
+                        + ((" (collective inside the library: nrtgpu_dist_allgather_merge)" if lib_collective else " (collective: torch.distributed)") if use_dist else "")
                         + (", score-bound exchange between shards" if exchange_name else "")
                         + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
@@ -452,6 +608,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
+    os.dup2(2, 1)   # whatever the runtimes still print at teardown (C stdio) goes to stderr: stdout stays the one JSON line
     if world > 1:
         dist.barrier()
         if exchange_name:

@@ -238,6 +238,11 @@ int  nrtgpu_dist_unique_id(void* out128);
 int  nrtgpu_dist_init(nrtgpu_ctx* ctx, int32_t world, int32_t rank, const void* id128);
 int  nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                    const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out);
+/* The exchange stage on its own, for callers that pipeline (host threads run nrtgpu_search_bm25_batch_device[_epoch] ahead,
+ * one thread issues the exchanges in batch order -- the same order on every rank): this rank's device-resident shard
+ * results (keys n_queries x k_stride, counts, hit totals) -> grouped all-gather -> TopDocs.merge into `out`. */
+int  nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
+                                 const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out);
 void nrtgpu_dist_close(nrtgpu_ctx* ctx);
 
 /* TopDocs.merge of n_lists per-GPU results laid out as the all-gather leaves them:
@@ -357,6 +362,10 @@ typedef struct {
   double  maxscore_ms;        /* sum of their HIP-event durations (collect_timing) */
   int64_t maxscore_postings;  /* postings of the term ranges of the queries on that route (what an exhaustive scan streams) */
   int64_t maxscore_items;
+  int64_t knn_panels;         /* exact vector searches: query panels (<= 32 queries) scored against every row */
+  int64_t knn_score_launches; /* knn_score_kernel launches (a panel takes a few rounds, theta tightens in between) */
+  double  knn_score_ms;       /* sum of their HIP-event durations (collect_timing) */
+  int64_t knn_rows;           /* sum over panels of the rows scored */
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);

@@ -608,6 +608,13 @@ class PreparedMerge:
             self.ctx._h, self.n_lists, self.n, self.k_stride, C.c_void_p(d_keys), C.c_void_p(d_counts),
             C.c_void_p(d_hits), self._ks.ctypes.data, self._thr.ctypes.data, self._outs))
 
+    def run_dist(self, d_keys: int, d_counts: int, d_hits: int) -> None:
+        """This rank's device-resident shard results -> RCCL all-gather inside the library -> merge
+        (nrtgpu_dist_allgather_merge; GpuContext.dist_init first; n_lists must equal the world size)."""
+        _lib.check(_lib.load().nrtgpu_dist_allgather_merge(
+            self.ctx._h, self.n, self.k_stride, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits),
+            self._ks.ctypes.data, self._thr.ctypes.data, self._outs))
+
     def topdocs(self, qi: int) -> TopDocs:
         o = self._outs[qi]
         return TopDocs(self.docs[qi, : o.n_hits].copy(), self.scores[qi, : o.n_hits].copy(), int(o.total_hits),

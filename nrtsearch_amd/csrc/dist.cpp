@@ -102,13 +102,43 @@ extern "C" void nrtgpu_dist_close(nrtgpu_ctx* ctx) {
   delete d;
 }
 
+// The exchange stage alone: this rank's device-resident shard results (what nrtgpu_search_bm25_batch_device[_epoch] left
+// in HBM: keys n_queries x k_stride, counts, hit totals) -> ONE grouped all-gather over xGMI -> TopDocs.merge on this
+// rank.  A caller that pipelines (scan threads ahead of the exchange) issues these in batch order on every rank.
+extern "C" int nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys,
+                                           const void* d_counts, const void* d_hits, const int32_t* ks,
+                                           const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
+  if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
+  if (!d_keys || !d_counts || !d_hits || !ks || !total_hits_thresholds || !out || n_queries <= 0 || k_stride <= 0 || k_stride % 16 != 0)
+    return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
+  Rccl* r = rccl();
+  nrtgpu_dist* d = ctx->dist;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t nq = (size_t)n_queries, kb = nq * (size_t)k_stride * 8, hb = nq * 8, cb = nq * 4;
+  const size_t W = (size_t)d->world;
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (int rc = d->gathered.reserve((kb + hb + ((cb + 7) & ~(size_t)7)) * W)) return rc;
+  // gathered[array][rank][query]: the layout nrtgpu_merge_topk_device reads
+  char* gb = (char*)d->gathered.p;
+  char* g_keys = gb;
+  char* g_hits = gb + W * kb;
+  char* g_cnt = gb + W * (kb + hb);
+  if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
+  int rc1 = r->all_gather(d_keys, g_keys, kb / 8, kNcclInt64, d->comm, d->stream);
+  int rc2 = r->all_gather(d_hits, g_hits, hb / 8, kNcclInt64, d->comm, d->stream);
+  int rc3 = r->all_gather(d_counts, g_cnt, cb / 4, kNcclInt32, d->comm, d->stream);
+  if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
+  if (rc1 || rc2 || rc3) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : rc3));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return nrtgpu_merge_topk_device(ctx, d->world, n_queries, k_stride, g_keys, g_cnt, g_hits, ks, total_hits_thresholds, out);
+}
+
 // Every rank calls this with the same queries in the same order (index-global statistics in the weights) over ITS
 // leaves; every rank receives every answer.
 extern "C" int nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                              const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out) {
   if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
   if (!queries || !out || n_queries <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
-  Rccl* r = rccl();
   nrtgpu_dist* d = ctx->dist;
   HIP_TRY(hipSetDevice(ctx->device));
   int32_t kmax = 1;
@@ -116,30 +146,19 @@ extern "C" int nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* 
   const int32_t k_stride = (int32_t)round_up((uint32_t)std::min(kmax, NRTGPU_MAX_K), 16);
   const size_t nq = (size_t)n_queries, kb = nq * (size_t)k_stride * 8, hb = nq * 8, cb = nq * 4;
   const size_t o_k = 0, o_h = kb, o_c = kb + hb, block = kb + hb + ((cb + 7) & ~(size_t)7);
-  std::lock_guard<std::mutex> lk(d->mu);
-  if (int rc = d->local.reserve(block)) return rc;
-  if (int rc = d->gathered.reserve(block * (size_t)d->world)) return rc;
-  char* lb = (char*)d->local.p;
-  char* gb = (char*)d->gathered.p;
+  char* lb = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (int rc = d->local.reserve(block)) return rc;
+    lb = (char*)d->local.p;
+  }
   // 1. this rank's shard: top-k per query stays in HBM (synchronous: complete when it returns)
   if (int rc = nrtgpu_search_bm25_batch_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lb + o_k, lb + o_c, lb + o_h)) return rc;
-  // 2. all-gather over xGMI: keys, hit totals, counts -- gathered[array][rank][query], the layout nrtgpu_merge_topk_device reads
-  const size_t W = (size_t)d->world;
-  char* g_keys = gb;
-  char* g_hits = gb + W * kb;
-  char* g_cnt = gb + W * (kb + hb);
-  if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
-  int rc1 = r->all_gather(lb + o_k, g_keys, kb / 8, kNcclInt64, d->comm, d->stream);
-  int rc2 = r->all_gather(lb + o_h, g_hits, hb / 8, kNcclInt64, d->comm, d->stream);
-  int rc3 = r->all_gather(lb + o_c, g_cnt, cb / 4, kNcclInt32, d->comm, d->stream);
-  if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
-  if (rc1 || rc2 || rc3) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : rc3));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  // 3. TopDocs.merge of the shards' lists on this rank
+  // 2 + 3. all-gather over xGMI, TopDocs.merge of the shards' lists on this rank
   std::vector<int32_t> ks(nq), thr(nq);
   for (size_t q = 0; q < nq; ++q) {
     ks[q] = queries[q].k;
     thr[q] = queries[q].total_hits_threshold;
   }
-  return nrtgpu_merge_topk_device(ctx, d->world, n_queries, k_stride, g_keys, g_cnt, g_hits, ks.data(), thr.data(), out);
+  return nrtgpu_dist_allgather_merge(ctx, n_queries, k_stride, lb + o_k, lb + o_c, lb + o_h, ks.data(), thr.data(), out);
 }

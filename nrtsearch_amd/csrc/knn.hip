@@ -58,8 +58,8 @@ __device__ __forceinline__ float knn_map_score(int sim, float dot, float nq, flo
   return s * boost;
 }
 
-// Scores docs [row_begin, row_end) of one segment against <= 32 queries; hits with key > theta[q]
-// are appended to query q's candidate list.  dim must be a multiple of 16.
+// Scores docs [row_begin, row_end) of one segment against <= 64 queries (panels of <= 32, see below); hits with
+// key > theta[q] are appended to query q's candidate list.  dim must be a multiple of 16.
 //   qpanel : n_q * dim floats (row-major), qnorm2 : n_q floats
 //   cand   : n_q lists of `cap` keys, cand_cnt : n_q counters (may exceed cap => overflow, host redoes)
 // Tiling: v_mfma_f32_16x16x4_f32, C[16 docs x 16 queries] per instruction, two query panels.  A operand:
@@ -76,6 +76,21 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* qs = (f32x4*)smem;  // [dim/16][2][64] float4: chunk c, panel p, lane (j, kk) -> q[j + 16p][16c + 4kk .. +4]
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // 33 .. 64 queries: two panels of <= 32.  Workgroups b and b + 8 (the same XCD under round-robin dispatch, so the
+  // same L2, and the Infinity Cache behind it) stream the SAME rows at the same pace, one panel each: the rows come
+  // from HBM once.  The grid is a multiple of 16 then.
+  uint32_t slice = blockIdx.x, n_slices = gridDim.x;
+  if (n_q > 32) {
+    const uint32_t b = blockIdx.x, panel = (b >> 3) & 1u;
+    slice = (b & 7u) + 8u * (b >> 4);
+    n_slices = gridDim.x >> 1;
+    qpanel += (size_t)panel * 32u * (size_t)dim;
+    qnorm2 += panel * 32u;
+    theta += panel * 32u;
+    cand += (size_t)panel * 32u * (size_t)cap;
+    cand_cnt += panel * 32u;
+    n_q = panel ? n_q - 32 : 32;
+  }
   const uint32_t j = lane & 15u, kk = lane >> 4;
   const int32_t chunks = dim >> 4;
   for (int32_t i = (int32_t)tid; i < chunks * 128; i += kKnnThreads) {
@@ -101,8 +116,8 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
   }
 
   const int64_t rows_per_block = (int64_t)(kKnnThreads / 64) * 16;
-  for (int64_t r0 = row_begin + (int64_t)blockIdx.x * rows_per_block + (int64_t)wave * 16; r0 < row_end;
-       r0 += (int64_t)gridDim.x * rows_per_block) {
+  for (int64_t r0 = row_begin + (int64_t)slice * rows_per_block + (int64_t)wave * 16; r0 < row_end;
+       r0 += (int64_t)n_slices * rows_per_block) {
     const int64_t row = min(r0 + (int64_t)j, row_end - 1);  // clamped: loads are unconditional
     const f32x4* vp = (const f32x4*)(vecs + row * dim) + kk;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -162,7 +177,9 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
                 // candidate and owns slot (row - row_begin) -- no counter traffic at all
                 const uint64_t pos = (uint64_t)(drow - row_begin);
                 if (pos < cap) cand[(size_t)q * cap + pos] = key;
-                if (drow == row_end - 1) cand_cnt[q] = (uint32_t)min<int64_t>(row_end - row_begin, (int64_t)cap);
+                // (a round longer than the list while theta is still unknown -- too few live rows so far -- reports
+                // its length: the select kernel flags the overflow and the host repeats the panel in bounded rounds)
+                if (drow == row_end - 1) cand_cnt[q] = (uint32_t)min<int64_t>(row_end - row_begin, (int64_t)0xFFFFFFFFll);
               } else if (key > th[p]) {
                 const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
                 if (pos < cap) cand[(size_t)q * cap + pos] = key;

@@ -232,6 +232,7 @@ extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev2) (void)hipEventDestroy(s->ev2);
     if (s->ev3) (void)hipEventDestroy(s->ev3);
+    for (hipEvent_t e : s->round_ev) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
   }
   delete ctx;

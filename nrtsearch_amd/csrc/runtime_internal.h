@@ -292,6 +292,7 @@ struct Slot {
   DevBuf d_aux;      // hybrid tail: leaf table, query vectors, rescored windows
   PinBuf h_aux;
   PinBuf h_out;      // merged results on the host
+  std::vector<hipEvent_t> round_ev;   // collect_timing: start / stop of every knn_score launch of a panel
   bool busy = false;
 };
 
@@ -423,7 +424,7 @@ struct LeafSetCache {
     }
     return entries() > kMaxEntries;
   }
-  DTerm* alloc_table(size_t n_leaves);
+  void* alloc_tables(size_t stride, size_t want, size_t* got);
   ~LeafSetCache();
   // Entries are never freed while the cache lives (a full cache is replaced as a whole, leaf_set_cache()), so a raw
   // pointer stays valid for as long as the caller holds the cache -- which lets every planner thread keep a private
@@ -431,6 +432,7 @@ struct LeafSetCache {
   // more than the lookups themselves).
   uint64_t id = 0;   // unique per cache object: tags the threads' front-cache entries
   const TermLeaves* get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash);
+  void get_many(const nrtgpu_seg* const* segs, int32_t n_segs, const Key* keys, size_t n, const TermLeaves** out);
   size_t entries();
 };
 std::shared_ptr<LeafSetCache> leaf_set_cache(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs);

@@ -5,7 +5,7 @@
 // ABI: exact vector search / vector rescore
 // ------------------------------------------------------------------------------------------------
 static const uint32_t kKnnCap = 1u << 18;   // candidate keys per query and round (2 MiB)
-static const int kKnnMaxQ = 32;
+static const int kKnnMaxQ = 64;   // queries per pass over the rows: two panels of 32 on paired workgroups (knn.hip)
 
 // Shared by the two vector entry points.  knn_request = false: ExactVectorQuery (every doc with a vector
 // matches, boost inside the score).  knn_request = true: the `knn` request path -- pre-filter mask, score
@@ -34,15 +34,21 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
   std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
   hipStream_t st = slot->stream;
+  const bool timing = ctx->cfg.collect_timing != 0;
   Carver wc;
   const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_th = wc.take(kKnnMaxQ * 8);
   const size_t o_tk = wc.take((size_t)kKnnMaxQ * k_stride * 8), o_tc = wc.take(kKnnMaxQ * 4);
   const size_t o_cc = wc.take(kKnnMaxQ * 4), o_ov = wc.take(64), o_cd = wc.take((size_t)kKnnMaxQ * kKnnCap * 8);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
-  if (int rc = slot->h_out.reserve((size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4)) return rc;
+  if (int rc = slot->h_out.reserve((size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4 + 64)) return rc;
   char* wb = (char*)slot->d_work.p;
   std::vector<float> qn(kKnnMaxQ);
-  for (int q0 = 0; q0 < n_queries; q0 += kKnnMaxQ) {
+  // Rows are scored in rounds with a selection in between (theta tightens from round to round).  The first round of
+  // a panel gives every row a slot of the candidate list; later rounds only append rows that beat theta, so they can
+  // be long: with rows in no particular order a round that multiplies the rows seen by 16 appends about
+  // k * ln 16 candidates.  Rows ordered by rising similarity could overflow the list (every row beats theta): the
+  // select kernel flags that and the panel is redone with rounds no longer than the list (`safe`).
+  for (int q0 = 0, safe = 0; q0 < n_queries; q0 += safe ? 0 : kKnnMaxQ) {
     const int nq = std::min(kKnnMaxQ, n_queries - q0);
     for (int q = 0; q < nq; ++q) {
       float s2 = 0.f;  // squareMagnitude of the query, fp32
@@ -61,7 +67,8 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       HIP_TRY(hipMemcpyAsync(wb + o_th, th0.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
     }
-    int64_t total_vec = 0;
+    int64_t total_vec = 0, seen = 0, round = 1 << 16;
+    size_t n_ev = 0;
     for (int si = 0; si < n_segs; ++si) {
       const nrtgpu_seg* seg = segs[si];
       auto fit = seg->fields.find(field_id);
@@ -72,27 +79,63 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       if (knn_request && filter_mask != 0)
         if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
       // rounds never exceed the candidate capacity, so a list cannot overflow; theta tightens between rounds
-      int64_t r = 0, round = 1 << 16;
+      int64_t r = 0;
+      if (seen == 0) round = 1 << 16;
       while (r < f.n_vec) {
-        const int64_t re = std::min<int64_t>(f.n_vec, r + std::min<int64_t>(round, kKnnCap));
-        const uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
+        const int64_t rb = r;
+        const int64_t re = std::min<int64_t>(f.n_vec, r + ((safe || seen == 0) ? std::min<int64_t>(round, kKnnCap) : round));
+        uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
+        if (nq > 32) blocks = std::max(16u, std::min((uint32_t)std::max(ctx->n_cus, 16), 2u * blocks) / 16u * 16u);   // paired workgroups
+        if (timing) {
+          while (slot->round_ev.size() < n_ev + 2) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            slot->round_ev.push_back(ev);
+          }
+          HIP_TRY(hipEventRecord(slot->round_ev[n_ev], st));
+        }
         const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
                                        doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
                                        sim, knn_request ? 1.0f : boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
                                        (uint32_t*)(wb + o_cc), kKnnCap);
         if (e) return fail(NRTGPU_ERR_HIP, "knn_score launch: %s", hipGetErrorString((hipError_t)e));
+        if (timing) {
+          HIP_TRY(hipEventRecord(slot->round_ev[n_ev + 1], st));
+          n_ev += 2;
+        }
         launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), k_stride, (uint32_t)k,
                           (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
                           (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov));
         r = re;
-        round = std::min<int64_t>(round * 4, kKnnCap);  // (unbounded growth overflowed after 24 rounds: > 6M rows hung)
+        seen += re - rb;
+        round = safe ? std::min<int64_t>(round * 4, kKnnCap) : std::min<int64_t>(seen * 15, (int64_t)1 << 40);
       }
     }
     HIP_TRY(hipGetLastError());
     char* ho = (char*)slot->h_out.p;
     HIP_TRY(hipMemcpyAsync(ho, wb + o_tk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ho + (size_t)kKnnMaxQ * k_stride * 8, wb + o_tc, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ho + (size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4, wb + o_ov, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (*(const uint32_t*)(ho + (size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4) != 0u) {
+      if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
+      safe = 1;   // same panel again, bounded rounds
+      continue;
+    }
+    safe = 0;
+    {
+      double ms = 0.0;
+      for (size_t i = 0; i + 1 < n_ev; i += 2) {
+        float one = 0.f;
+        (void)hipEventElapsedTime(&one, slot->round_ev[i], slot->round_ev[i + 1]);
+        ms += (double)one;
+      }
+      std::lock_guard<std::mutex> lk(ctx->stats_mu);
+      ctx->stats.knn_panels += 1;
+      ctx->stats.knn_score_launches += (int64_t)(n_ev / 2);
+      ctx->stats.knn_score_ms += ms;
+      ctx->stats.knn_rows += seen;
+    }
     const uint64_t* keys = (const uint64_t*)ho;
     const uint32_t* cnts = (const uint32_t*)(ho + (size_t)kKnnMaxQ * k_stride * 8);
     for (int q = 0; q < nq; ++q) {

@@ -550,6 +550,75 @@ float nrt_oracle_vector_score(int32_t sim, const float* q, const float* v, int32
   return dot + 1.0f;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Exact vector search: ExactVectorQuery scores EVERY doc that has a vector
+ * (src/main/java/com/yelp/nrtsearch/server/query/vector/ExactVectorQuery.java:137-173, VectorValuesScorer.score() =
+ * similarity.compare(query, vector) * boost) into a top-k collector (score descending, ties by docid ascending: the
+ * order TopScoreDocCollector + TopDocs.merge produce).  n_q queries x n rows (row r is doc doc_base + r; live == NULL
+ * or bit r of live set = the row's doc is live).  Queries spread over OpenMP threads, rows of one query scored in
+ * order (the order does not matter to the result: the comparison is total).
+ * out_docs / out_scores: n_q x k, out_n: hits per query.
+ * ------------------------------------------------------------------------------------------ */
+void nrt_oracle_knn_exact(int32_t sim, const float* queries, int32_t n_q, const float* vecs, int64_t n, int32_t dim,
+                          const uint64_t* live, int32_t doc_base, float boost, int32_t k, int32_t n_threads,
+                          int32_t* out_docs, float* out_scores, int32_t* out_n) {
+  if (n_threads < 1) n_threads = 1;
+  /* rows are cut into blocks so that one query also scales over the threads; per (query, block) a sorted top-k, merged after */
+  const int64_t block = 1 << 16;
+  const int64_t n_blocks = (n + block - 1) / block;
+  const int64_t n_tasks = (int64_t)n_q * (n_blocks > 0 ? n_blocks : 1);
+  float* bs = (float*)malloc((size_t)n_tasks * (size_t)k * sizeof(float));
+  int32_t* bd = (int32_t*)malloc((size_t)n_tasks * (size_t)k * sizeof(int32_t));
+  int32_t* bn = (int32_t*)calloc((size_t)n_tasks, sizeof(int32_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+  for (int64_t t = 0; t < n_tasks; ++t) {
+    const int32_t q = (int32_t)(t / (n_blocks > 0 ? n_blocks : 1));
+    const int64_t b = t % (n_blocks > 0 ? n_blocks : 1);
+    float* s = bs + (size_t)t * (size_t)k;
+    int32_t* d = bd + (size_t)t * (size_t)k;
+    int32_t m = 0;
+    const int64_t r1 = (b + 1) * block < n ? (b + 1) * block : n;
+    for (int64_t r = b * block; r < r1; ++r) {
+      if (live && !((live[r >> 6] >> (r & 63)) & 1ull)) continue;
+      const float sc = nrt_oracle_vector_score(sim, queries + (size_t)q * (size_t)dim, vecs + (size_t)r * (size_t)dim, dim) * boost;
+      if (m == k && !(sc > s[k - 1])) continue; /* rows come in docid order: an equal score loses to the earlier doc */
+      int32_t i = m < k ? m : k - 1;
+      while (i > 0 && s[i - 1] < sc) {
+        s[i] = s[i - 1];
+        d[i] = d[i - 1];
+        --i;
+      }
+      s[i] = sc;
+      d[i] = doc_base + (int32_t)r;
+      if (m < k) ++m;
+    }
+    bn[t] = m;
+  }
+  for (int32_t q = 0; q < n_q; ++q) { /* k-way merge of the blocks' lists (blocks in docid order: ties keep it) */
+    int32_t* pos = (int32_t*)calloc((size_t)(n_blocks > 0 ? n_blocks : 1), sizeof(int32_t));
+    int32_t m = 0;
+    while (m < k) {
+      int64_t best = -1;
+      for (int64_t b = 0; b < n_blocks; ++b) {
+        const int64_t t = (int64_t)q * n_blocks + b;
+        if (pos[b] >= bn[t]) continue;
+        if (best < 0 || bs[(size_t)t * (size_t)k + (size_t)pos[b]] > bs[(size_t)((int64_t)q * n_blocks + best) * (size_t)k + (size_t)pos[best]]) best = b;
+      }
+      if (best < 0) break;
+      const int64_t t = (int64_t)q * n_blocks + best;
+      out_scores[(size_t)q * (size_t)k + (size_t)m] = bs[(size_t)t * (size_t)k + (size_t)pos[best]];
+      out_docs[(size_t)q * (size_t)k + (size_t)m] = bd[(size_t)t * (size_t)k + (size_t)pos[best]];
+      ++pos[best];
+      ++m;
+    }
+    out_n[q] = m;
+    free(pos);
+  }
+  free(bs);
+  free(bd);
+  free(bn);
+}
+
 /* QueryRescore.combine, src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-45 */
 float nrt_oracle_rescore_combine(float first_pass, int32_t matched, float second_pass,
                                  double query_weight, double rescore_weight) {

@@ -120,6 +120,10 @@ int32_t nrt_oracle_topdocs_merge(int32_t top_n, int32_t n_lists, const int32_t* 
 /* ---- exact vector scoring (ExactVectorQuery.java:137-173 + VectorSimilarityFunction) ----
  * sim: 0 cosine, 1 dot_product, 2 l2_norm (euclidean), 3 max_inner_product. */
 float nrt_oracle_vector_score(int32_t sim, const float* q, const float* v, int32_t dim);
+/* ExactVectorQuery over one matrix of rows + the top-k collector behind it (ExactVectorQuery.java:137-173) */
+void nrt_oracle_knn_exact(int32_t sim, const float* queries, int32_t n_q, const float* vecs, int64_t n, int32_t dim,
+                          const uint64_t* live, int32_t doc_base, float boost, int32_t k, int32_t n_threads,
+                          int32_t* out_docs, float* out_scores, int32_t* out_n);
 
 /* QueryRescorer.combine as overridden by QueryRescore.java:40-45:
  * (float)(queryWeight * firstPass + rescoreWeight * secondPass), double arithmetic. */

@@ -93,6 +93,9 @@ def lib():
         L.nrt_oracle_topdocs_merge.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.nrt_oracle_vector_score.restype = C.c_float
         L.nrt_oracle_vector_score.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.nrt_oracle_knn_exact.restype = None
+        L.nrt_oracle_knn_exact.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                           C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.nrt_oracle_rescore_combine.restype = C.c_float
         L.nrt_oracle_rescore_combine.argtypes = [C.c_float, C.c_int32, C.c_float, C.c_double, C.c_double]
         _lib = L
@@ -130,6 +133,23 @@ def vector_score(sim: int, q: np.ndarray, v: np.ndarray) -> np.float32:
     q = np.ascontiguousarray(q, dtype=np.float32)
     v = np.ascontiguousarray(v, dtype=np.float32)
     return np.float32(lib().nrt_oracle_vector_score(int(sim), q.ctypes.data, v.ctypes.data, int(q.shape[0])))
+
+
+def knn_exact(sim: int, queries: np.ndarray, vecs: np.ndarray, k: int, live_words: Optional[np.ndarray] = None,
+              doc_base: int = 0, boost: float = 1.0, n_threads: int = 1):
+    """ExactVectorQuery + top-k collector over one matrix of rows (row r = doc doc_base + r).
+    -> (docs [n_q, k] int32, scores [n_q, k] float32, n [n_q])."""
+    queries = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    n_q, dim = queries.shape
+    docs = np.zeros((n_q, k), dtype=np.int32)
+    scores = np.zeros((n_q, k), dtype=np.float32)
+    cnt = np.zeros(n_q, dtype=np.int32)
+    lw = None if live_words is None else np.ascontiguousarray(live_words, dtype=np.uint64)
+    lib().nrt_oracle_knn_exact(int(sim), queries.ctypes.data, n_q, vecs.ctypes.data, int(vecs.shape[0]), int(dim),
+                               None if lw is None else lw.ctypes.data, int(doc_base), C.c_float(boost), int(k), int(n_threads),
+                               docs.ctypes.data, scores.ctypes.data, cnt.ctypes.data)
+    return docs, scores, cnt
 
 
 def rescore_combine(first: float, matched: bool, second: float, qw: float, rw: float) -> np.float32:

@@ -196,6 +196,41 @@ def test_vector_score_maps(oracle):
     assert oracle.vector_score(3, q, 2 * q) == f32(3.0)          # mip: dot=2 -> 3
 
 
+def test_knn_exact_is_score_every_row_then_sort(oracle):
+    """nrt_oracle_knn_exact (the C4 CPU baseline / checker) == vector_score of every live row, sorted by
+    (score desc, docid asc) -- ExactVectorQuery.java:137-173 behind a top-k collector; ties lose to the earlier doc."""
+    rng = np.random.default_rng(5)
+    n, dim, k = 150_000, 16, 37
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    vecs[1000] = vecs[10]            # an exact tie: doc 10 must rank before doc 1000
+    vecs[140_000] = vecs[10]
+    q = np.vstack([vecs[10] * 2.0, rng.standard_normal(dim)]).astype(np.float32)
+    live = np.ones(((n + 63) // 64) * 64, dtype=bool)
+    live[[3, 70_000]] = False
+    words = np.packbits(live.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+    for sim in range(4):
+        docs, scores, cnt = oracle.knn_exact(sim, q, vecs, k, live_words=words, doc_base=7, boost=1.5, n_threads=3)
+        for qi in range(2):
+            # (a python loop over 150k rows is too slow: score the rows the oracle returned plus a random sample and
+            # check the order properties)
+            assert cnt[qi] == k
+            got = [(float(scores[qi, i]), int(docs[qi, i])) for i in range(k)]
+            assert got == sorted(got, key=lambda t: (-t[0], t[1]))
+            for sc, d in got[:5]:
+                assert live[d - 7]
+                assert np.float32(oracle.vector_score(sim, q[qi], vecs[d - 7]) * np.float32(1.5)) == np.float32(sc)
+            sample = rng.choice(n, size=300, replace=False)
+            worst = got[-1]
+            for r in sample.tolist():
+                if not live[r] or (r + 7) in set(docs[qi].tolist()):
+                    continue
+                sc = float(np.float32(oracle.vector_score(sim, q[qi], vecs[r]) * np.float32(1.5)))
+                assert (sc, -(r + 7)) < (worst[0], -worst[1]) or sc < worst[0]
+        if sim in (0, 1, 3):   # the planted ties of query 0 (cosine of identical directions / equal dots)
+            top = docs[0].tolist()
+            assert top.index(17) < top.index(1007) < top.index(140_007)
+
+
 def test_segment_search_matches_bruteforce(oracle):
     from nrtsearch_amd import synth
 

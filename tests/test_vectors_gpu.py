@@ -185,6 +185,63 @@ def test_knn_segment_with_more_than_24_rounds(ctx):
     g.release()
 
 
+def test_knn_rows_ordered_by_rising_similarity(ctx):
+    """Long rounds assume rows in no particular order; here EVERY row beats the running theta (dot product grows with the
+    row), so a long round overflows the candidate list: the library must notice and redo the panel in bounded rounds."""
+    n, dim, k = 700_000, 16, 100
+    t = (np.arange(n, dtype=np.float64) + 1.0) / (n + 1.0)
+    vecs = np.zeros((n, dim), dtype=np.float32)
+    vecs[:, 0] = t
+    vecs[:, 1] = np.sqrt(1.0 - t * t)
+    g = api.GpuSegment(ctx, n, 0)
+    g.add_vectors(0, vecs)
+    g.seal()
+    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+    q = np.zeros((2, dim), dtype=np.float32)
+    q[0, 0] = 1.0            # dot = t: rising
+    q[1, 1] = 1.0            # dot = sqrt(1 - t^2): falling (nothing after the first round is competitive)
+    got = sr.knn_exact(0, "dot_product", q, k)
+    for qi in range(2):
+        dots = vecs.astype(np.float64) @ q[qi].astype(np.float64)
+        scores = np.maximum((1.0 + dots) / 2.0, 0.0)
+        order = np.lexsort((np.arange(n), -scores))[:k]
+        assert np.allclose(got[qi].scores, scores[order].astype(np.float32), rtol=1e-5, atol=1e-6)
+        # fp32 scores of neighbouring rows tie; the docs must come from the reference's near-tie set
+        lo = scores[order[-1]] * (1 - 1e-5) - 1e-6
+        assert all(scores[d] >= lo for d in got[qi].docs.tolist())
+        assert len(set(got[qi].docs.tolist())) == k
+        assert got[qi].total_hits == n
+    g.release()
+
+
+def test_knn_theta_unknown_after_the_first_round(ctx):
+    """Fewer than k live rows among the first 65536: theta is still unknown when the long rounds start, every row keeps its
+    own slot and a round longer than the list must be caught (not silently truncated)."""
+    rng = np.random.default_rng(21)
+    n, dim, k = 500_000, 16, 64
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    live = np.ones(n, dtype=bool)
+    live[:70_000] = False
+    live[5:45] = True          # 40 live rows < k in the first round
+    g = api.GpuSegment(ctx, n, 0)
+    g.add_vectors(0, vecs)
+    g.seal()
+    padded = np.zeros(((n + 63) // 64) * 64, dtype=bool)
+    padded[:n] = live
+    g.set_live_docs(np.packbits(padded.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1))
+    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+    q = rng.standard_normal((1, dim)).astype(np.float32)
+    got = sr.knn_exact(0, "max_inner_product", q, k)[0]
+    dots = vecs.astype(np.float64) @ q[0].astype(np.float64)
+    scores = np.where(dots < 0, 1.0 / (1.0 - dots), dots + 1.0)
+    scores[~live] = -1.0
+    order = np.lexsort((np.arange(n), -scores))[:k]
+    assert np.allclose(got.scores, scores[order].astype(np.float32), rtol=1e-5, atol=1e-6)
+    assert len(set(got.docs.tolist()) & set(order.tolist())) >= k - 1
+    assert got.total_hits == int(live.sum())
+    g.release()
+
+
 def test_knn_unsupported_dimension_falls_back(ctx):
     g = api.GpuSegment(ctx, 10, 0)
     g.add_vectors(0, np.ones((10, 3), np.float32))   # d = 3 as in VectorFieldDefTest: not a multiple of 8
