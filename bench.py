@@ -62,6 +62,7 @@ def parse_args():
                     help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="debug, 1 GPU: index only rank 0's docid range of an N-GPU job (per-rank step time at --gpus N)")
+    ap.add_argument("--debug-k", type=int, default=0, help="debug: numHits override (what a shard costs at a smaller k)")
     ap.add_argument("--torch-collective", action="store_true",
                     help="N>1: exchange with torch.distributed's all-gather instead of the library's own RCCL stage "
                          "(nrtgpu_dist_allgather_merge, the default; falls back to torch by itself if RCCL cannot be bound)")
@@ -338,6 +339,8 @@ def main():
     w = {"C2": workload.C2, "C3": workload.C3, "SMOKE": workload.SMOKE}[args.workload]
     if args.docs:
         w.n_docs = args.docs
+    if args.debug_k:
+        w.k = args.debug_k
     B = args.batch
     n_distinct = max(B, (w.n_queries // B) * B)
     qranks = synth.make_queries(n_distinct, w.n_terms, w.max_rank)
