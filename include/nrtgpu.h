@@ -154,7 +154,14 @@ typedef struct {
                                     * or "+(should clauses) #filter" -- either way a hit matches >= 1 scoring
                                     * clause and the filter adds nothing to the score */
   int32_t must_not_mask;           /* 0 = none; else hits must NOT lie in this mask (MUST_NOT clause) */
-  int32_t reserved;
+  int32_t disjunction_max;         /* 0: BooleanQuery of SHOULD clauses, a doc scores the sum of its matching clauses.
+                                    * 1: DisjunctionMaxQuery over the same term clauses with tieBreakerMultiplier 0
+                                    * (src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:350-358; the
+                                    * reference's own test uses 0, src/test/java/com/yelp/nrtsearch/server/grpc/
+                                    * QueryTest.java:541-583): a doc scores its BEST matching clause.  Exhaustive route,
+                                    * fixed-point accumulators for the whole batch (else NRTGPU_ERR_UNSUPPORTED),
+                                    * min_should_match <= 1; a tie breaker > 0 or disjuncts that are not term queries
+                                    * stay on the caller's path; not accepted by nrtgpu_search_bm25_coalesced */
 } nrtgpu_bm25_query;
 
 typedef struct {

@@ -18,7 +18,8 @@ import org.apache.lucene.search.similarities.Similarity;
 
 /**
  * The eligibility predicate of SURVEY 8b, Java half: recognise the shapes the native planner takes -- a (boosted)
- * TermQuery or a BooleanQuery of SHOULD (boosted) TermQuery clauses (built at query/QueryNodeMapper.java:257-283,360-395),
+ * TermQuery, a BooleanQuery of SHOULD (boosted) TermQuery clauses (built at query/QueryNodeMapper.java:257-283,360-395) or a
+ * DisjunctionMaxQuery over such term queries with tie breaker 0 (QueryNodeMapper.java:350-358),
  * collected by a plain RelevanceCollector (search/collectors/RelevanceCollector.java:42-69) -- and marshal them into a
  * nrtgpu_bm25_query.  Whatever remains (clause counts, fields, fixed-point range, resident masks ...) is decided by the
  * library itself (nrtgpu_query_supported / NRTGPU_ERR_UNSUPPORTED), so this class carries no limits of its own.
@@ -37,9 +38,21 @@ final class GpuEligibility {
     }
   }
 
-  /** Flattens the rewritten query; null = not a shape the device takes. */
-  static List<Clause> clauses(Query q, int[] minShouldMatch) {
+  /** Flattens the rewritten query; null = not a shape the device takes.  shape[0] = minimumNumberShouldMatch,
+   *  shape[1] = 1 for a DisjunctionMaxQuery (best clause instead of the sum). */
+  static List<Clause> clauses(Query q, int[] shape) {
+    int[] minShouldMatch = shape;
     List<Clause> out = new ArrayList<>();
+    if (q instanceof DisjunctionMaxQuery dm) {                         // QueryNodeMapper.java:350-358
+      if (dm.getTieBreakerMultiplier() != 0f) return null;            // the device keeps the best clause only
+      for (Query d : dm.getDisjuncts()) {
+        Clause cl = term(d, 1f);
+        if (cl == null) return null;                                  // disjuncts that are not (boosted) term queries
+        out.add(cl);
+      }
+      shape[1] = 1;
+      return out.isEmpty() ? null : out;
+    }
     if (q instanceof BooleanQuery bq) {
       for (BooleanClause c : bq.clauses()) {
         if (c.occur() != BooleanClause.Occur.SHOULD) return null;     // FILTER / MUST_NOT as masks: GpuMaskCache (not in this sketch)
@@ -72,8 +85,8 @@ final class GpuEligibility {
     return rc;
   }
 
-  static Plan marshal(Arena a, IndexSearcher searcher, GpuSegmentStore store, List<Clause> clauses, int msm, int k,
-      int totalHitsThreshold, ScoreDoc after) throws IOException {
+  static Plan marshal(Arena a, IndexSearcher searcher, GpuSegmentStore store, List<Clause> clauses, int msm, int disjunctionMax,
+      int k, int totalHitsThreshold, ScoreDoc after) throws IOException {
     Similarity sim = searcher.getSimilarity();
     if (!(sim instanceof BM25Similarity)) return null;                // IndexSimilarity.java:51-63: default similarity only
     List<String> fields = new ArrayList<>();
@@ -109,6 +122,7 @@ final class GpuEligibility {
     q.set(JAVA_INT, 44, after != null ? after.doc : 0);
     q.set(JAVA_FLOAT, 48, after != null ? after.score : 0f);
     q.set(JAVA_INT, 52, msm);
+    q.set(JAVA_INT, 68, disjunctionMax);
     MemorySegment docs = a.allocate(JAVA_INT, k), scores = a.allocate(JAVA_FLOAT, k), out = a.allocate(NrtGpu.TOPDOCS);
     out.set(JAVA_INT, 4, k);
     out.set(ADDRESS, 8, docs);

@@ -37,7 +37,7 @@ public class GpuIndexSearcher extends MyIndexSearcher {
   public <C extends Collector, T> T search(Query query, CollectorManager<C, T> manager) throws IOException {
     RelevanceCollector rc = GpuEligibility.relevance(manager);
     if (rc == null) return super.search(query, manager);
-    int[] msm = {0};
+    int[] msm = {0, 0};   // minimumNumberShouldMatch, DisjunctionMaxQuery?
     List<GpuEligibility.Clause> clauses = GpuEligibility.clauses(rewrite(query), msm);
     if (clauses == null) return super.search(query, manager);
     List<LeafReaderContext> leaves = getIndexReader().leaves();
@@ -49,7 +49,7 @@ public class GpuIndexSearcher extends MyIndexSearcher {
         segs.setAtIndex(ADDRESS, i, s);
         bases.setAtIndex(JAVA_INT, i, leaves.get(i).docBase);
       }
-      GpuEligibility.Plan plan = GpuEligibility.marshal(a, this, store, clauses, msm[0], rc.getNumHitsToCollect(),
+      GpuEligibility.Plan plan = GpuEligibility.marshal(a, this, store, clauses, msm[0], msm[1], rc.getNumHitsToCollect(),
           rc.getTotalHitsThreshold(), rc.getSearchAfter());
       if (plan == null) return super.search(query, manager);
       int status = (int) NrtGpu.SEARCH1.invokeExact(ctx, segs, bases, leaves.size(), plan.query(), plan.out());   // blocks; batched inside

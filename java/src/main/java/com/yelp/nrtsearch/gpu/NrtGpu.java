@@ -35,7 +35,7 @@ final class NrtGpu {
           JAVA_INT.withName("n_caches"), MemoryLayout.paddingLayout(4), ADDRESS.withName("norm_cache"), JAVA_INT.withName("k"),
           JAVA_INT.withName("total_hits_threshold"), JAVA_INT.withName("has_after"), JAVA_INT.withName("after_doc"),
           JAVA_FLOAT.withName("after_score"), JAVA_INT.withName("min_should_match"), JAVA_FLOAT.withName("min_competitive_score"),
-          JAVA_INT.withName("filter_mask"), JAVA_INT.withName("must_not_mask"), JAVA_INT.withName("reserved"));
+          JAVA_INT.withName("filter_mask"), JAVA_INT.withName("must_not_mask"), JAVA_INT.withName("disjunction_max"));
   // nrtgpu_topdocs, 40 bytes
   static final StructLayout TOPDOCS =
       MemoryLayout.structLayout(JAVA_INT.withName("n_hits"), JAVA_INT.withName("capacity"), ADDRESS.withName("docs"),

@@ -59,7 +59,7 @@ class Bm25Query(C.Structure):
                 ("norm_cache", C.POINTER(C.c_float)), ("k", C.c_int32), ("total_hits_threshold", C.c_int32),
                 ("has_after", C.c_int32), ("after_doc", C.c_int32), ("after_score", C.c_float),
                 ("min_should_match", C.c_int32), ("min_competitive_score", C.c_float), ("filter_mask", C.c_int32),
-                ("must_not_mask", C.c_int32), ("reserved", C.c_int32)]
+                ("must_not_mask", C.c_int32), ("disjunction_max", C.c_int32)]
 
 
 class TopDocs(C.Structure):

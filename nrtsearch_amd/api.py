@@ -64,7 +64,16 @@ class BooleanQuery:
     must: Tuple[Union[TermQuery, BoostQuery], ...] = ()   # MatchQuery with operator MUST (QueryNodeMapper.java:369-373)
 
 
-Query = Union[TermQuery, BoostQuery, BooleanQuery]
+@dataclasses.dataclass(frozen=True)
+class DisjunctionMaxQuery:
+    """DisjunctionMaxQuery over (boosted) term queries (S/query/QueryNodeMapper.java:350-358): a doc scores its best
+    disjunct plus tie_breaker_multiplier x the others.  The device route takes tie_breaker_multiplier == 0."""
+
+    disjuncts: Tuple[Union[TermQuery, BoostQuery], ...] = ()
+    tie_breaker_multiplier: float = 0.0
+
+
+Query = Union[TermQuery, BoostQuery, BooleanQuery, DisjunctionMaxQuery]
 
 
 class UnsupportedQuery(Exception):
@@ -296,9 +305,14 @@ def _unsupported(msg: str):
     raise UnsupportedQuery(msg)
 
 
-def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int]:
+def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int, int]:
     """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost)], msm,
-    filter mask id, must_not mask id (0 = none)."""
+    filter mask id, must_not mask id (0 = none), disjunction_max (1: best clause instead of the sum)."""
+    r = _flatten_sum(query)
+    return r if len(r) == 5 else (*r, 0)
+
+
+def _flatten_sum(query: Query):
     def one(q) -> Tuple[int, int, float]:
         if isinstance(q, TermQuery):
             return (q.field, q.term, 1.0)
@@ -306,6 +320,23 @@ def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int]
             return (q.query.field, q.query.term, float(q.boost))
         raise UnsupportedQuery(f"clause {q!r} is not a (boosted) TermQuery")
 
+    def dismax(q: DisjunctionMaxQuery):
+        if q.tie_breaker_multiplier != 0.0:
+            raise UnsupportedQuery("DisjunctionMaxQuery with a tie breaker")
+        if not q.disjuncts:
+            raise UnsupportedQuery("empty DisjunctionMaxQuery")
+        return [one(c) for c in q.disjuncts]
+
+    if isinstance(query, DisjunctionMaxQuery):
+        return dismax(query), 0, 0, 0, 1
+    if isinstance(query, BooleanQuery) and len(query.must) == 1 and isinstance(query.must[0], DisjunctionMaxQuery):
+        # "+dismax #filter -must_not": one scoring clause, the masks add nothing to the score
+        if query.should or len(query.filter) > 1 or len(query.must_not) > 1:
+            raise UnsupportedQuery("a DisjunctionMaxQuery next to SHOULD clauses / several masks")
+        if any(not isinstance(c, MaskFilter) or c.mask_id <= 0 for c in query.filter + query.must_not):
+            raise UnsupportedQuery("FILTER / MUST_NOT clauses must be resident masks")
+        return (dismax(query.must[0]), 0, query.filter[0].mask_id if query.filter else 0,
+                query.must_not[0].mask_id if query.must_not else 0, 1)
     if isinstance(query, BooleanQuery):
         if query.must:
             # a conjunction of term clauses matches the docs all of them match and sums all their scores
@@ -359,7 +390,7 @@ class GpuIndexSearcher:
     def _marshal(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> _Marshalled:
         m = _Marshalled(len(queries))
         for qi, (query, mgr) in enumerate(zip(queries, managers)):
-            clauses, msm, filter_mask, must_not_mask = _flatten(query)
+            clauses, msm, filter_mask, must_not_mask, dis_max = _flatten(query)
             fields: List[int] = []
             terms = (_lib.Term * len(clauses))()
             for ti, (field, term, boost) in enumerate(clauses):
@@ -387,6 +418,7 @@ class GpuIndexSearcher:
             q.min_competitive_score = float(mgr.min_competitive_score)
             q.filter_mask = int(filter_mask)
             q.must_not_mask = int(must_not_mask)
+            q.disjunction_max = int(dis_max)
         return m
 
     def search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> List[TopDocs]:

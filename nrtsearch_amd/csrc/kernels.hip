@@ -214,10 +214,17 @@ __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr
 // score widened to double, or ds_add_u64 of the term's fixed-point integer shifted into the query's scale.
 // cnt_hi != 0 (minimumNumberShouldMatch variant, FX only): every valid posting (its entry is a positive
 // integer; redirected ones add 0) also adds one to the clause count kept above the score sum.
+// use_max (query-shapes variant, FX only; wave-uniform): DisjunctionMaxQuery with tie breaker 0 -- the doc keeps its best
+// clause's entry instead of the sum (ds_max_u64; the unmatched marker 0 and the redirected zeros behave as under add).
 template <bool FX>
 __device__ __forceinline__ void group_commit_add(const uint32_t (&off)[8], const uint32_t (&val)[8], uint32_t fx_shift,
-                                                 uint32_t cnt_hi = 0) {
+                                                 uint32_t cnt_hi = 0, bool use_max = false) {
   const uint32_t fx_mult = 1u << fx_shift;  // entry << shift as one 32 x 32 -> 64 multiply (no 64-bit operand to set up)
+  if (FX && use_max) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicMax((unsigned long long*)lds_ptr(off[j]), (unsigned long long)val[j] * (unsigned long long)fx_mult);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (FX) {
@@ -515,6 +522,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   const uint32_t cnt_hi = (kMsm && msm > 1u) ? (1u << (kMsmCountShift - 32)) : 0u;
   const uint64_t hit_floor = cnt_hi ? (uint64_t)msm << kMsmCountShift : 1ull;
   const uint32_t score_hi_mask = cnt_hi ? (1u << (kMsmCountShift - 32)) - 1u : 0xFFFFFFFFu;
+  const bool use_max = kMsm && q.combine_max != 0u;  // DisjunctionMaxQuery: best clause instead of the sum
 
   uint64_t t_start = 0, t_walk = 0;
   if (ABL == 7) t_start = __builtin_readcyclecounter();
@@ -665,7 +673,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
             Group a;
             group_locate_load(s, wave, n_terms, vb + lane, cur_groups, pre, a);
             group_prepare<FX, ABL>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
-            if (vb + lane < cur_groups) group_commit_add<FX>(off2, val2, a.meta >> 28, cnt_hi);
+            if (vb + lane < cur_groups) group_commit_add<FX>(off2, val2, a.meta >> 28, cnt_hi, use_max);
           }
         }
         group_prepare<FX, ABL>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, val);
@@ -693,9 +701,9 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = a2[j] = acc_marker<FX>();
       if (cur_groups != 0) {
-        if (act && ABL != 2 && ABL != 4) group_commit_add<FX>(off, val, sh, cnt_hi);
+        if (act && ABL != 2 && ABL != 4) group_commit_add<FX>(off, val, sh, cnt_hi, use_max);
         if (sparse && ABL != 2 && ABL != 3) {
-          if (act2) group_commit_add<FX>(off2, val2, sh2, cnt_hi);
+          if (act2) group_commit_add<FX>(off2, val2, sh2, cnt_hi, use_max);
           if (act) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = atomicExch((unsigned long long*)lds_ptr(off[j]), (unsigned long long)acc_marker<FX>());

@@ -145,7 +145,7 @@ struct alignas(16) DQuery {
   uint32_t item_begin;     // items of this query are [item_begin, item_begin + n_items)
   uint32_t n_items;
   uint32_t min_should_match;  // > 1: only docs matched by that many clauses are hits (count-carrying kernel variant)
-  uint32_t pad1;
+  uint32_t combine_max;       // 1: DisjunctionMaxQuery (tie breaker 0): a doc scores its best clause, not the sum (same variant)
 };
 static_assert(sizeof(DQuery) == 32, "DQuery layout");
 // minimumNumberShouldMatch > 1: the fixed-point accumulator carries the number of matching clauses above

@@ -15,6 +15,9 @@ int nrtgpu::rt::validate_query(const nrtgpu_bm25_query& q, int qi) {
   if (q.n_terms <= 0 || !q.terms) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: no terms", qi);
   if (q.n_terms > NRTGPU_MAX_TERMS) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d clauses > %d", qi, q.n_terms, NRTGPU_MAX_TERMS);
   if (q.min_should_match < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: minimumNumberShouldMatch %d", qi, q.min_should_match);
+  if (q.disjunction_max != 0 && q.disjunction_max != 1) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: disjunction_max must be 0 or 1", qi);
+  if (q.disjunction_max == 1 && q.min_should_match > 1)
+    return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: a DisjunctionMaxQuery has no minimumNumberShouldMatch", qi);
   if (q.n_caches <= 0 || !q.norm_cache) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: norm_cache missing", qi);
   if (q.n_caches > kLdsCaches) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d scored fields > %d", qi, q.n_caches, kLdsCaches);
   for (int t = 0; t < q.n_terms; ++t) {
@@ -307,7 +310,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     // after discounting every deleted doc of its segments.  Needs the exact fixed-point sums, plain liveDocs
     // (folded into the columns) and a plain disjunction.
     int64_t lower = 0;
-    if (prune != 0 && !(prune == 2 && q.has_after) && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.filter_mask == 0 && q.must_not_mask == 0 &&
+    if (prune != 0 && !(prune == 2 && q.has_after) && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.disjunction_max == 0 && q.filter_mask == 0 && q.must_not_mask == 0 &&
         !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
       if (plain) {
         // the reference counts per slice (one collector each): some slice must certainly pass the threshold
@@ -503,10 +506,10 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // accumulator, so the whole batch must be in fixed-point mode; otherwise the caller runs Lucene's WANDScorer
   hp.clause_counting = false;
   for (int qi = 0; qi < n_queries; ++qi)
-    if (queries[qi].min_should_match > 1) hp.clause_counting = true;
+    if (queries[qi].min_should_match > 1 || queries[qi].disjunction_max == 1) hp.clause_counting = true;   // (the query-shapes variant)
   if (hp.clause_counting && !hp.fixed_point)
-    return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 needs the fixed-point accumulators (weights of a query in "
-                                        "this batch span too many binades, or NRTGPU_FLAG_NO_FIXED_POINT is set)");
+    return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 / DisjunctionMaxQuery need the fixed-point accumulators (weights of "
+                                        "a query in this batch span too many binades, or NRTGPU_FLAG_NO_FIXED_POINT is set)");
 
   const double tp2 = plan_trace ? now_ms() : 0.0;
   // pass 2: cut every query's leaves (in docBase order) into items of roughly equal cost.  An item
@@ -686,6 +689,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     dq.item_begin = hp.q_base[(size_t)qi];
     dq.n_items = hp.q_nlists[(size_t)qi];
     dq.min_should_match = (uint32_t)std::max(q.min_should_match, 0);
+    dq.combine_max = q.disjunction_max == 1 ? 1u : 0u;
   }
   if (plan_trace)
     fprintf(stderr, "[nrtgpu plan] %d queries: resolve %.3f ms (%d threads), concat %.3f, cut+items %.3f; %zu terms %zu parts %zu items\n",

@@ -419,6 +419,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
   if (int rc = validate_query(*q, 0)) return rc;  // a bad request must not fail its batch mates
   if (q->min_should_match > 1)  // whether it can run depends on the whole batch (fixed-point mode): use the batch call
     return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 is not coalesced");
+  if (q->disjunction_max != 0) return fail(NRTGPU_ERR_UNSUPPORTED, "a DisjunctionMaxQuery is not coalesced");
   for (int si = 0; si < n_segs; ++si) {
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
     if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);

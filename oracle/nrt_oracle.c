@@ -289,6 +289,62 @@ void nrt_oracle_search_segment_msm(int32_t max_doc, int32_t doc_base, const uint
   free(cursor);
 }
 
+/* DisjunctionMaxQuery over term clauses (src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:350-358
+ * builds org.apache.lucene.search.DisjunctionMaxQuery(disjuncts, tieBreakerMultiplier)).  lucene-core 10.4.0's
+ * DisjunctionMaxScorer.score() [Lucene-recall, SURVEY A]: over the matching sub-scorers keep scoreMax (float) and
+ * otherScoreSum (double: every sub score that is not the max), return (float)(scoreMax + otherScoreSum * tieBreaker).
+ * With tieBreaker == 0 -- the only value the device route takes, and the one the reference's own test uses
+ * (src/test/java/com/yelp/nrtsearch/server/grpc/QueryTest.java:541-583) -- the score is the best clause's score and no
+ * order of the sub-scorers matters; with a tie breaker the sub-scorers are visited here in clause order (Lucene visits
+ * its DisiPriorityQueue's order: the double sum may differ in the last bit). */
+void nrt_oracle_search_segment_dismax(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                                      int32_t n_terms, const nrt_oracle_term* terms, float tie_breaker,
+                                      nrt_oracle_collector* collector) {
+  float smax[ORACLE_WINDOW];
+  double other[ORACLE_WINDOW];
+  uint8_t matched[ORACLE_WINDOW];
+  int64_t* cursor = (int64_t*)calloc((size_t)(n_terms > 0 ? n_terms : 1), sizeof(int64_t));
+  nrt_oracle_collector_set_leaf(collector, doc_base);
+  for (int32_t base = 0; base < max_doc; base += ORACLE_WINDOW) {
+    int32_t end = base + ORACLE_WINDOW;
+    if (end > max_doc) end = max_doc;
+    int any = 0;
+    for (int t = 0; t < n_terms; ++t) {
+      const nrt_oracle_term* tm = &terms[t];
+      int64_t p = cursor[t];
+      if (p < tm->n && tm->docids[p] < end) {
+        if (!any) {
+          memset(smax, 0, sizeof(float) * (size_t)(end - base));
+          memset(other, 0, sizeof(double) * (size_t)(end - base));
+          memset(matched, 0, (size_t)(end - base));
+          any = 1;
+        }
+        for (; p < tm->n && tm->docids[p] < end; ++p) {
+          int32_t d = tm->docids[p];
+          float freq = tm->freqs ? (float)tm->freqs[p] : 1.0f;
+          uint8_t norm = tm->norms ? tm->norms[d] : (uint8_t)1;
+          float s = nrt_oracle_bm25_score(tm->weight, freq, tm->cache[norm]);
+          if (s >= smax[d - base]) {
+            other[d - base] += (double)smax[d - base];
+            smax[d - base] = s;
+          } else {
+            other[d - base] += (double)s;
+          }
+          matched[d - base] = 1;
+        }
+        cursor[t] = p;
+      }
+    }
+    if (!any) continue;
+    for (int32_t d = base; d < end; ++d) {
+      if (!matched[d - base]) continue;
+      if (live_bits && !((live_bits[d >> 6] >> (d & 63)) & 1ULL)) continue;
+      nrt_oracle_collector_collect(collector, d, (float)((double)smax[d - base] + other[d - base] * (double)tie_breaker));
+    }
+  }
+  free(cursor);
+}
+
 /* ------------------------------------------------------------------------------------------
  * The same disjunction with dynamic pruning: the algorithm family of Lucene's
  * MaxScoreBulkScorer (lucene-core 10.4.0; chosen for a top-level pure-SHOULD BooleanQuery under

@@ -80,6 +80,9 @@ def lib():
         L.nrt_oracle_search_segment_msm.restype = None
         L.nrt_oracle_search_segment_msm.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                                     C.c_void_p]
+        L.nrt_oracle_search_segment_dismax.restype = None
+        L.nrt_oracle_search_segment_dismax.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
+                                                       C.c_void_p]
         L.nrt_oracle_block_max.restype = None
         L.nrt_oracle_block_max.argtypes = [C.c_void_p, C.c_void_p]
         L.nrt_oracle_search_segment_maxscore.restype = None
@@ -274,7 +277,7 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
                 segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False,
                 maxscore: bool = False, stats: Optional[dict] = None,
                 accept: Optional[Sequence[Optional[np.ndarray]]] = None, min_should_match: int = 0,
-                slicing=DEFAULT_SLICING):
+                slicing=DEFAULT_SLICING, dismax: Optional[float] = None):
     """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr)): one
     collector per slice of the searcher (corpus_slices; each visits its leaves in docBase order), reduced like
     LazyQueueTopScoreDocCollectorManager.reduce: TopDocs.merge of the slices' hits, totalHits summed, relation
@@ -284,12 +287,13 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
     accept[si] (uint64 words) replaces leaf si's liveDocs as the acceptDocs handed to the bulk scorer:
     liveDocs & FILTER doc set & ~MUST_NOT doc set -- what BooleanWeight's conjunction of a FILTER clause
     with the SHOULD disjunction (minimumNumberShouldMatch = 1) and its ReqExclScorer let through; such
-    clauses add nothing to the score."""
+    clauses add nothing to the score.
+    dismax = tie breaker: the clauses are the disjuncts of a DisjunctionMaxQuery instead (best clause + tie x the others)."""
     if segments is None and slicing is not None:
         groups = corpus_slices(corpus, slicing)
         if len(groups) > 1:
             parts = [search_bm25(corpus, term_ids, k, boosts, after, total_hits_threshold, g, omit_norms, omit_freqs, maxscore,
-                                 stats, accept, min_should_match, None) for g in groups]
+                                 stats, accept, min_should_match, None, dismax) for g in groups]
             docs, scores = topdocs_merge(k, [(p[0], p[1]) for p in parts])
             return docs, scores, int(sum(p[2] for p in parts)), bool(any(p[3] for p in parts))
     weights, cache = bm25_query_stats(corpus, term_ids, boosts)
@@ -328,6 +332,8 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
             ptrs = (C.c_void_p * max(n_present, 1))(*[b.ctypes.data for b in bms])
             lib().nrt_oracle_search_segment_maxscore(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr),
                                                      C.byref(ptrs), col._h, C.byref(scored))
+        elif dismax is not None:
+            lib().nrt_oracle_search_segment_dismax(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr), C.c_float(dismax), col._h)
         elif min_should_match > 1:
             lib().nrt_oracle_search_segment_msm(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr),
                                                 int(min_should_match), col._h)

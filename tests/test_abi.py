@@ -161,18 +161,25 @@ def test_query_eligibility_mapping():
     """Host logic only: which rewritten queries the mirror sends to the device and how."""
     from nrtsearch_amd import api
     t = [api.TermQuery(0, i) for i in (3, 5, 8)]
-    assert api._flatten(t[0]) == ([(0, 3, 1.0)], 0, 0, 0)
-    assert api._flatten(api.BoostQuery(t[1], 2.0)) == ([(0, 5, 2.0)], 0, 0, 0)
-    assert api._flatten(api.BooleanQuery(tuple(t), 2)) == ([(0, 3, 1.0), (0, 5, 1.0), (0, 8, 1.0)], 2, 0, 0)
-    assert api._flatten(api.BooleanQuery(tuple(t), 1, (api.MaskFilter(4),), (api.MaskFilter(9),)))[2:] == (4, 9)
+    assert api._flatten(t[0]) == ([(0, 3, 1.0)], 0, 0, 0, 0)
+    assert api._flatten(api.BoostQuery(t[1], 2.0)) == ([(0, 5, 2.0)], 0, 0, 0, 0)
+    assert api._flatten(api.BooleanQuery(tuple(t), 2)) == ([(0, 3, 1.0), (0, 5, 1.0), (0, 8, 1.0)], 2, 0, 0, 0)
+    assert api._flatten(api.BooleanQuery(tuple(t), 1, (api.MaskFilter(4),), (api.MaskFilter(9),)))[2:] == (4, 9, 0)
     # a pure-MUST conjunction of terms is the disjunction that needs every clause
     assert api._flatten(api.BooleanQuery(must=tuple(t)))[1] == 3
-    assert api._flatten(api.BooleanQuery(must=tuple(t), filter=(api.MaskFilter(2),)))[1:] == (3, 2, 0)
+    assert api._flatten(api.BooleanQuery(must=tuple(t), filter=(api.MaskFilter(2),)))[1:] == (3, 2, 0, 0)
+    # DisjunctionMaxQuery over (boosted) term queries, tie breaker 0 (QueryNodeMapper.java:350-358): best clause, not the sum
+    dm = api.DisjunctionMaxQuery((t[0], api.BoostQuery(t[2], 3.0)))
+    assert api._flatten(dm) == ([(0, 3, 1.0), (0, 8, 3.0)], 0, 0, 0, 1)
+    assert api._flatten(api.BooleanQuery(must=(dm,), filter=(api.MaskFilter(6),)))[1:] == (0, 6, 0, 1)
     import pytest
     for bad in (api.BooleanQuery(tuple(t), 0, (api.MaskFilter(4),)),              # FILTER + optional SHOULD: score-0 hits
                 api.BooleanQuery(tuple(t[:1]), must=tuple(t[1:])),                 # MUST and SHOULD mixed
                 api.BooleanQuery((api.BooleanQuery(tuple(t)),)),                    # nested clause
                 api.BooleanQuery(tuple(t), 1, (api.MaskFilter(1), api.MaskFilter(2))),
+                api.DisjunctionMaxQuery(tuple(t), 0.3),                             # tie breaker: the caller's path
+                api.DisjunctionMaxQuery((api.BooleanQuery(tuple(t)),)),             # disjunct that is not a term query
+                api.BooleanQuery(tuple(t[:1]), must=(api.DisjunctionMaxQuery(tuple(t)),)),
                 api.BooleanQuery(())):
         with pytest.raises(api.UnsupportedQuery):
             api._flatten(bad)

@@ -150,6 +150,59 @@ def test_minimum_should_match(ctx, deletes):
         ix.close()
 
 
+@pytest.mark.parametrize("deletes", [0.0, 0.03])
+def test_disjunction_max_query(ctx, deletes):
+    """DisjunctionMaxQuery over (boosted) term queries with tie breaker 0 (QueryNodeMapper.java:350-358; the reference's
+    test: QueryTest.java:541-583): the doc's best clause instead of the sum -- docids, ranks, score bits == oracle."""
+    ranks = [1, 2, 3, 6, 15, 50, 400, 3000]
+    corpus = synth.build_corpus(260_000, ranks, n_segments=3, delete_fraction=deletes)
+    ix = Index(ctx, corpus)
+    try:
+        terms = [1, 3, 15, 400, 3000]
+        dq = api.DisjunctionMaxQuery(tuple(api.TermQuery(0, t) for t in terms))
+        for k, thr in ((10, 1000), (1000, 1000), (100, 2**31 - 1), (1000, 10)):
+            got = ix.searcher.search(dq, api.TopScoreDocCollectorManager(k, None, thr))
+            assert_same(f"dismax_{k}_{thr}_{deletes}", got, oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, dismax=0.0), k, thr)
+        # it is not the sum: the plain disjunction ranks differently
+        plain = ix.searcher.search(api.BooleanQuery(dq.disjuncts), api.TopScoreDocCollectorManager(100))
+        dm = ix.searcher.search(dq, api.TopScoreDocCollectorManager(100))
+        assert dm.scores[0] < plain.scores[0]
+        # boosted disjuncts (the usual multi-field shape: one clause dominates), a repeated term, paging
+        boosts = [0.5, 3.0, 1.0, 2.0, 4.0]
+        bdq = api.DisjunctionMaxQuery(tuple(api.BoostQuery(api.TermQuery(0, t), b) for t, b in zip(terms, boosts)))
+        first = ix.searcher.search(bdq, api.TopScoreDocCollectorManager(60))
+        assert_same("dismax_boost_p1", first, oracle.search_bm25(corpus, terms, 60, boosts=boosts, dismax=0.0), 60, 1000)
+        after = api.ScoreDoc(int(first.docs[-1]), float(first.scores[-1]))
+        second = ix.searcher.search(bdq, api.TopScoreDocCollectorManager(60, after))
+        assert_same("dismax_boost_p2", second, oracle.search_bm25(corpus, terms, 60, boosts=boosts, dismax=0.0, after=(after.doc, after.score)), 60, 1000)
+        dup = [2, 2, 50]
+        got = ix.searcher.search(api.DisjunctionMaxQuery(tuple(api.TermQuery(0, t) for t in dup)), api.TopScoreDocCollectorManager(50))
+        assert_same("dismax_dup", got, oracle.search_bm25(corpus, dup, 50, dismax=0.0), 50, 1000)
+        # one batch: dismax, plain sum, clause counting, dismax behind a FILTER mask, a single term
+        masks = [random_mask(s.max_doc, 0.35, 500 + i) for i, s in enumerate(corpus.segments)]
+        for leaf, m in zip(ix.leaves, masks):
+            leaf.set_mask(5, m)
+        should = dq.disjuncts
+        qs = [dq, api.BooleanQuery(should), api.BooleanQuery(should, 3), api.BooleanQuery(must=(dq,), filter=(api.MaskFilter(5),)),
+              api.DisjunctionMaxQuery((api.TermQuery(0, 50),))]
+        res = ix.searcher.search_batch(qs, [api.TopScoreDocCollectorManager(300)] * 5)
+        acc = [accept_of(s, masks[i], None) for i, s in enumerate(corpus.segments)]
+        assert_same("dismax_batch0", res[0], oracle.search_bm25(corpus, terms, 300, dismax=0.0), 300, 1000)
+        assert_same("dismax_batch1", res[1], oracle.search_bm25(corpus, terms, 300), 300, 1000)
+        assert_same("dismax_batch2", res[2], oracle.search_bm25(corpus, terms, 300, min_should_match=3), 300, 1000)
+        assert_same("dismax_batch3", res[3], oracle.search_bm25(corpus, terms, 300, dismax=0.0, accept=acc), 300, 1000)
+        assert_same("dismax_batch4", res[4], oracle.search_bm25(corpus, [50], 300), 300, 1000)
+        assert ix.searcher.supported(dq, api.TopScoreDocCollectorManager(10))
+        # what stays on the caller's path
+        with pytest.raises(api.UnsupportedQuery):
+            ix.searcher.search(api.DisjunctionMaxQuery(should, 0.1), api.TopScoreDocCollectorManager(10))
+        with pytest.raises(_lib.NrtGpuError) as e:   # depends on the whole batch (fixed-point mode): not coalesced
+            ix.searcher.search_coalesced(dq, api.TopScoreDocCollectorManager(10))
+        assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
+    finally:
+        ix.close()
+
+
 def test_minimum_should_match_full_tiles(ctx):
     """Dense terms over many sub-tiles and several items per query (k-th best shared between items)."""
     ranks = [1, 2, 3, 4, 5]

@@ -260,6 +260,41 @@ def test_segment_search_matches_bruteforce(oracle):
     assert scores.tolist() == [s for s, _ in allhits[:50]]
 
 
+def test_dismax_matches_bruteforce(oracle):
+    """DisjunctionMaxQuery over term clauses (QueryNodeMapper.java:350-358): the oracle against a numpy restatement of
+    DisjunctionMaxScorer.score() -- best clause (float) + tie breaker x the double sum of the others, one cast."""
+    from nrtsearch_amd import synth
+
+    corpus = synth.build_corpus(25000, [1, 3, 9, 50, 350], n_segments=3, delete_fraction=0.04)
+    terms, boosts = [1, 9, 350, 9], [1.0, 2.5, 0.5, 1.0]      # (a repeated term is two disjuncts)
+    w, cache = oracle.bm25_query_stats(corpus, terms, boosts)
+    for tie in (0.0, 0.25):
+        hits = []
+        for seg in corpus.segments:
+            best = np.zeros(seg.max_doc, np.float32)
+            other = np.zeros(seg.max_doc, np.float64)
+            m = np.zeros(seg.max_doc, bool)
+            for wi, t in zip(w, terms):
+                d, f = seg.postings(t)
+                sc = (wi - wi / (f32(1.0) + f.astype(np.float32) * cache[seg.norms[d]])).astype(np.float32)
+                ge = sc >= best[d]
+                other[d] += np.where(ge, best[d], sc).astype(np.float64)
+                best[d] = np.where(ge, sc, best[d])
+                m[d] = True
+            live = np.unpackbits(seg.live_bits.view(np.uint8), bitorder="little")[: seg.max_doc].astype(bool)
+            for i in np.nonzero(m & live)[0]:
+                hits.append((float(f32(np.float64(best[i]) + other[i] * np.float64(f32(tie)))), int(i) + seg.doc_base))
+        hits.sort(key=lambda t: (-t[0], t[1]))
+        docs, scores, total, gte = oracle.search_bm25(corpus, terms, 40, boosts=boosts, total_hits_threshold=2**31 - 1, dismax=tie)
+        assert total == len(hits) and not gte
+        assert docs.tolist() == [d for _, d in hits[:40]]
+        assert scores.tolist() == [s for s, _ in hits[:40]]
+    # tie breaker 0: the score IS the best clause's score, never above a single clause's maximum
+    docs, scores, _, _ = oracle.search_bm25(corpus, terms, 5, boosts=boosts, dismax=0.0)
+    plain = oracle.search_bm25(corpus, terms, 5, boosts=boosts)
+    assert scores[0] <= plain[1][0]
+
+
 def test_query_shapes_match_bruteforce(oracle):
     """minimumNumberShouldMatch, FILTER / MUST_NOT doc sets, searchAfter and repeated clauses of the oracle
     against an independent numpy restatement (float32 term scores, float64 sums, one cast, HitQueue order)."""
