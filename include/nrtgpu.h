@@ -63,6 +63,12 @@ typedef struct {
 #define NRTGPU_FLAG_NO_FIXED_POINT 2  /* always accumulate in fp64 (A/B; results are identical either way) */
 #define NRTGPU_FLAG_NO_LIVE_FOLD 8     /* A/B: liveDocs stay a mask read by the scan instead of being folded into the posting columns */
 #define NRTGPU_FLAG_NO_MASK_VARIANT 4   /* A/B: docs outside liveDocs / a mask are checked one by one (general sweep) */
+#define NRTGPU_FLAG_PACKED_POSTINGS 32  /* compressed postings: every segment of this context keeps ONE 32-bit word per
+                                        * posting in HBM (20-bit doc offset inside its 2^20-doc super-window | 12-bit score code) instead of
+                                        * a docid and a code column: half the posting bytes, same results bit for bit.  liveDocs are then not
+                                        * folded into the postings (the scorers test the mask).  Postings the 12-bit code cannot name (freq > 12
+                                        * or norm byte >= 128) go through a per-upload-group exception list (4 B each).  A separately
+                                        * reported configuration (its own roofline denominator). */
 #define NRTGPU_FLAG_NO_PRUNE 16        /* never take the MaxScore route: every query is scanned exhaustively and total_hits is
                                         * always the exact count (the relation still follows totalHitsThreshold) */
 

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import os
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -155,6 +156,9 @@ class GpuContext:
     def __init__(self, device_id: int = 0, max_batch: int = 1024, target_items: int = 0,
                  collect_timing: bool = False, flags: int = 0, host_threads: int = 0):
         L = _lib.load()
+        if os.environ.get("NRTGPU_PACKED_POSTINGS", "") not in ("", "0"):   # run anything (the whole test suite) on the packed layout
+            flags |= _lib.NRTGPU_FLAG_PACKED_POSTINGS
+        self.flags = flags
         cfg = _lib.Config(device_id, max_batch, target_items, int(collect_timing), flags, host_threads)
         h = C.c_void_p()
         _lib.check(L.nrtgpu_create(C.byref(cfg), C.byref(h)))

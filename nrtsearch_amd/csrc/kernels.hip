@@ -94,7 +94,9 @@ __device__ __forceinline__ uint32_t subtile_build(ScanSmem& s, uint32_t wave, ui
   if (lane < (uint32_t)kMaxTerms) {
     s.w_incl[wave][lane] = incl;
     s.w_before[wave][lane] = incl - np;
-    u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16, end | (first << 22) | (my_flags << 24)};
+    // my_delta16 == 0xFFFFFFFF: packed postings -- the slot holds the window's first group as a posting index instead
+    u32x4 rec = {(uint32_t)addr_d, (uint32_t)(addr_d >> 32), my_delta16 == 0xFFFFFFFFu ? (uint32_t)(gs << 2) : my_delta16,
+                 end | (first << 22) | (my_flags << 24)};
     *(u32x4*)&s.w_rec[wave][lane][0] = rec;
   }
   // the prefixes of the first 8 terms as wave-uniform scalars: locating a pair needs no LDS round trip
@@ -109,10 +111,12 @@ struct Group {
   uint32_t p;     // pair index inside the term's window of this sub-tile
   uint32_t meta;  // the term's meta
   uint32_t term;  // term index inside the part (division path only)
+  uint32_t pidx;  // packed postings: index of the pair's first posting in its column (exception lookups)
 };
 
 // Locate flattened pair v of the sub-tile (clamped so the loads are always legal) through the wave's
 // LDS table and load its column words (2 x 16 B per column).  No control flow around the loads.
+template <bool PACKED>
 __device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wave, uint32_t n_terms, uint32_t v,
                                                   uint32_t total, const uint32_t (&pre)[8], Group& gr) {
   const uint32_t vc = min(v, max(total, 1u) - 1u);
@@ -130,10 +134,13 @@ __device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wa
   gr.p = p;
   gr.meta = rec[3];
   gr.term = t;
+  gr.pidx = PACKED ? rec[2] + p * 8u : 0u;  // (packed: rec[2] is the window's first group as a posting index, not the column distance)
   gr.d4[0] = __builtin_nontemporal_load((gvec_ptr)ad);
   gr.d4[1] = __builtin_nontemporal_load((gvec_ptr)ad + 1);
-  gr.c4[0] = __builtin_nontemporal_load((gvec_ptr)ac);
-  gr.c4[1] = __builtin_nontemporal_load((gvec_ptr)ac + 1);
+  if (!PACKED) {  // (packed postings: the 8 words of the pair ARE d4 -- doc offset and code in one)
+    gr.c4[0] = __builtin_nontemporal_load((gvec_ptr)ac);
+    gr.c4[1] = __builtin_nontemporal_load((gvec_ptr)ac + 1);
+  }
 }
 
 // Scoring a pair of groups happens in two steps so that the registers holding the loaded column
@@ -146,7 +153,7 @@ __device__ __forceinline__ void group_locate_load(const ScanSmem& s, uint32_t wa
 // "unmatched" marker forever, so neither the adds nor the collecting swaps need per-posting control
 // flow (a conditionally executed returning LDS op makes the compiler wait for each result at the end
 // of its branch) and a dummy never looks like a matched doc.
-template <bool FX, int ABL>
+template <bool FX, int ABL, bool PACKED>
 __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr, bool valid, uint32_t acc_addr, uint32_t base,
                                               uint32_t tile_len, uint32_t dummy_addr, const DTerm* __restrict__ part_terms,
                                               uint32_t (&off)[8], uint32_t (&val)[8]) {
@@ -159,9 +166,15 @@ __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr
   uint32_t vmask = valid ? (hm & ~lm) : 0u;
   const uint32_t tab = (meta >> 24) & 7u;
   // LDS address of the doc's accumulator in the wave's sub-tile: acc + (doc - base) * 8 in one op
-  const uint32_t abase = acc_addr - base * 8u;
+  // (packed postings: the word's upper 20 bits are the doc's offset inside the sub-tile's 2^20-doc super-window)
+  const uint32_t abase = acc_addr - (PACKED ? (base & kPackDocMask) : base) * 8u;
+  uint32_t cw[8];  // the postings' score codes as table byte offsets; sign bit: escape
 #pragma unroll
-  for (int j = 0; j < 8; ++j) off[j] = (gr.d4[j >> 2][j & 3] << 3) + abase;
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t w = gr.d4[j >> 2][j & 3];
+    off[j] = ((PACKED ? (w >> kPackCodeBits) : w) << 3) + abase;
+    cw[j] = PACKED ? (w & kPackCodeMask) << 2 : gr.c4[j >> 2][j & 3];
+  }
   if (__any((meta >> 27) & 1u)) {
     // sparse terms share one posting range between several sub-tiles (coarse cells): doc-range filter
     // (unsigned: docs below the sub-tile wrap to huge values)
@@ -172,25 +185,34 @@ __device__ __forceinline__ void group_prepare(const ScanSmem& s, const Group& gr
   // postings the score table cannot serve: freq > kTabMaxFreq / norm >= kTabNorms (sign bit of the
   // code) or a term without a table.  Rare: one OR-reduction decides whether anybody in the wave
   // needs the division at all.
-  uint32_t cor = gr.c4[0][0] | gr.c4[0][1] | gr.c4[0][2];
-  cor |= gr.c4[0][3] | gr.c4[1][0];
-  cor |= gr.c4[1][1] | gr.c4[1][2];
-  cor |= gr.c4[1][3];
-  const bool special = vmask != 0u && ((cor >> 31) != 0u || tab == 7u);
+  bool any_esc;
+  if (PACKED) {  // escape codes are the ones past the table's last entry
+    const uint32_t mx = max(max(max(cw[0], cw[1]), max(cw[2], cw[3])), max(max(cw[4], cw[5]), max(cw[6], cw[7])));
+    any_esc = mx >= (kPackEscBase << 2);
+  } else {
+    uint32_t cor = cw[0] | cw[1] | cw[2];
+    cor |= cw[3] | cw[4];
+    cor |= cw[5] | cw[6];
+    cor |= cw[7];
+    any_esc = (cor >> 31) != 0u;
+  }
+  const bool special = vmask != 0u && (any_esc || tab == 7u);
   const char* tb = (const char*)&s.tab[0][0] + (tab == 7u ? 0u : tab) * (uint32_t)(kTabEntries * 4);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (ABL == 1) val[j] = (gr.c4[j >> 2][j & 3] & 0x1FFCu) | 0x3F000000u;  // timing ablation: no table read
-    else val[j] = *(const uint32_t*)(tb + (gr.c4[j >> 2][j & 3] & 0x1FFCu));  // masked: idle lanes stay in LDS
+    if (ABL == 1) val[j] = (cw[j] & 0x1FFCu) | 0x3F000000u;  // timing ablation: no table read
+    else val[j] = *(const uint32_t*)(tb + (cw[j] & 0x1FFCu));  // masked: idle lanes stay in LDS
   }
   if (__any(special)) {
     // long docs / high freqs / terms without a score table (a few lanes)
     const float w = part_terms[gr.term].weight;
     const int fx_scale = part_terms[gr.term].fx_scale;
     const float* cache = &s.cache[part_terms[gr.term].cache_slot][0];
+    const gu32_ptr esc_list = (gu32_ptr)part_terms[gr.term].fnorm;  // packed postings: the group's exception list
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t c = gr.c4[j >> 2][j & 3];
+      uint32_t c = cw[j];
+      if (PACKED && c >= (kPackEscBase << 2)) c = ((vmask >> j) & 1u) ? packed_escape_word(esc_list, gr.pidx + (uint32_t)j, c >> 2) : 0x80000100u;
       const bool esc = (c >> 31) != 0u;
       const uint32_t f = esc ? ((c >> 8) & 0x3FFFFFu) : ((c >> 9) & 15u);
       const bool dead = esc ? ((c >> 30) & 1u) != 0u : (c >> 20) != 0u;  // posting of a deleted doc (apply_live_kernel)
@@ -491,7 +513,7 @@ __device__ __forceinline__ bool collect_swapped(ScanSmem& s, uint32_t acc_addr, 
 // 0 = the scan; 8 = clause counting (minimumNumberShouldMatch > 1, fixed point only); 9 = doc-set masks
 // (FILTER / MUST_NOT, liveDocs that are not folded into the postings); 7 = instrumented (event counters
 // per item); 1-4, 6 = timing ablations (wrong results).
-template <bool FX, bool PIPE, int ABL>
+template <bool FX, bool PIPE, int ABL, bool PACKED>
 __global__ __launch_bounds__(kScanThreads, kScanWaves / 4)
 void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts,
                       const DTerm* __restrict__ terms, const DQuery* __restrict__ queries,
@@ -617,7 +639,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     // lane l looks after term min(l, n_terms - 1) of this part (registers)
     const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     const uint64_t my_docids = (uint64_t)mt.docids, my_lo = mt.start;
-    const uint32_t my_delta16 = (uint32_t)(((uint64_t)mt.fnorm - (uint64_t)mt.docids) >> 4);  // same allocation
+    const uint32_t my_delta16 = PACKED ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)mt.fnorm - (uint64_t)mt.docids) >> 4);  // same allocation
     const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
     const uint32_t my_shift = mt.shift;
     const uint32_t my_flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | ((mt.shift != 0 ? 1u : 0u) << 3) |
@@ -638,7 +660,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       nhi = my_cells[c1 + 1];
     }
     Group pf;
-    group_locate_load(s, wave, n_terms, lane, total_groups, pre, pf);
+    group_locate_load<PACKED>(s, wave, n_terms, lane, total_groups, pre, pf);
     // theta of the query's other items (LazyMaxScoreAccumulator analogue): read one sub-tile ahead of its
     // use -- it is only a filter, a stale value costs a few extra candidates, never a result
     uint64_t theta_other = 0, theta_other_next = 0;
@@ -664,19 +686,19 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         if (sparse) {
           if (second) {
             Group a;
-            group_locate_load(s, wave, n_terms, 64u + lane, cur_groups, pre, a);
-            group_prepare<FX, ABL>(s, a, 64u + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
+            group_locate_load<PACKED>(s, wave, n_terms, 64u + lane, cur_groups, pre, a);
+            group_prepare<FX, ABL, PACKED>(s, a, 64u + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
             sh2 = a.meta >> 28;
           }
         } else {
           for (uint32_t vb = 64u; vb < cur_groups; vb += 64u) {  // dense sub-tile: pairs beyond the first 64 (wave-uniform trip count)
             Group a;
-            group_locate_load(s, wave, n_terms, vb + lane, cur_groups, pre, a);
-            group_prepare<FX, ABL>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
+            group_locate_load<PACKED>(s, wave, n_terms, vb + lane, cur_groups, pre, a);
+            group_prepare<FX, ABL, PACKED>(s, a, vb + lane < cur_groups, acc_addr, base, tile_len, dummy_addr, part_terms, off2, val2);
             if (vb + lane < cur_groups) group_commit_add<FX>(off2, val2, a.meta >> 28, cnt_hi, use_max);
           }
         }
-        group_prepare<FX, ABL>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, val);
+        group_prepare<FX, ABL, PACKED>(s, pf, act, acc_addr, base, tile_len, dummy_addr, part_terms, off, val);
         sh = pf.meta >> 28;
       }
 
@@ -716,7 +738,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       }
 
       // ---- (2b) the next sub-tile's first posting pairs: in flight while this one is collected
-      group_locate_load(s, wave, n_terms, lane, total_groups, pre, pf);
+      group_locate_load<PACKED>(s, wave, n_terms, lane, total_groups, pre, pf);
       if (!PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A/B: no overlap of the column loads
 
       if (cur_groups != 0) {
@@ -1024,6 +1046,65 @@ void apply_live_kernel(const uint32_t* __restrict__ docids, uint32_t* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Seal time, NRTGPU_FLAG_PACKED_POSTINGS: (docid, 32-bit score code) -> ONE word per posting (plan.h: kPack*).
+// pack_count_kernel: one workgroup per block of 2048 postings counts the block's exceptions (escape words: freq >
+// kTabMaxFreq or norm >= kTabNorms); the host turns the counts into the directory (exclusive prefix).
+// pack_write_kernel: the same blocks write the packed words; exceptions are numbered in posting order (directory entry +
+// rank inside the block: wave ballots + an LDS prefix over the four waves x eight rounds) and their escape words
+// stored at that number.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void pack_count_kernel(const uint32_t* __restrict__ fnorm, uint64_t n, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  const uint64_t p0 = (uint64_t)blockIdx.x << kPackEscBlockShift;
+  uint32_t mine = 0;
+  for (uint32_t i = threadIdx.x; i < (1u << kPackEscBlockShift); i += 256u) {
+    const uint64_t p = p0 + i;
+    if (p < n && (fnorm[p] >> 31) != 0u) ++mine;
+  }
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256)
+void pack_write_kernel(const uint32_t* __restrict__ docids, const uint32_t* __restrict__ fnorm, uint64_t n,
+                       const uint32_t* __restrict__ dir, uint32_t* __restrict__ exceptions, uint32_t* __restrict__ packed) {
+  __shared__ uint32_t wave_cnt[8][4];  // [round][wave]: exceptions of that wave's 64 postings
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint64_t p0 = (uint64_t)blockIdx.x << kPackEscBlockShift;
+  uint32_t c[8];
+  unsigned long long ball[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {  // posting (r, wave, lane) = p0 + r * 256 + wave * 64 + lane: posting order = (r, wave, lane) order
+    const uint64_t p = p0 + (uint64_t)r * 256u + threadIdx.x;
+    c[r] = p < n ? fnorm[p] : 0u;
+    ball[r] = __builtin_amdgcn_ballot_w64((c[r] >> 31) != 0u);
+    if (lane == 0) wave_cnt[r][wave] = (uint32_t)__popcll(ball[r]);
+  }
+  __syncthreads();
+  const uint32_t e_block = dir[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint64_t p = p0 + (uint64_t)r * 256u + threadIdx.x;
+    if (p >= n) continue;
+    uint32_t code = c[r] >> 2;
+    if ((c[r] >> 31) != 0u) {
+      uint32_t before = 0;
+      for (int rr = 0; rr < 8; ++rr)
+        for (int ww = 0; ww < 4; ++ww)
+          if (rr < r || (rr == r && (uint32_t)ww < wave)) before += wave_cnt[rr][ww];
+      const uint32_t e = e_block + before + (uint32_t)__popcll(ball[r] & ((1ull << lane) - 1ull));
+      exceptions[e] = c[r];
+      code = kPackEscBase + (e & kPackEscLowMask);
+    }
+    packed[p] = ((docids[p] & kPackDocMask) << kPackCodeBits) | code;
+  }
+}
+
 // expand_terms_kernel: the compact plan -> the DTerm records of every (query, leaf).  One thread per (query, leaf):
 // the clauses the leaf holds, ordered densest first (exhaustive scan) or heaviest first, ties sparsest first (MaxScore
 // route), written at the offset the host reserved (out_begin; ~0 = the leaf holds none of the query's terms).  The
@@ -1121,40 +1202,55 @@ void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits
 }
 
 // ---- launchers (called from the host runtime) ---------------------------------------------------------
+void launch_pack_count(hipStream_t stream, const uint32_t* fnorm, uint64_t n, uint32_t n_blocks, uint32_t* counts) {
+  if (n_blocks == 0) return;
+  hipLaunchKernelGGL(pack_count_kernel, dim3(n_blocks), dim3(256), 0, stream, fnorm, n, counts);
+}
+void launch_pack_write(hipStream_t stream, const uint32_t* docids, const uint32_t* fnorm, uint64_t n, uint32_t n_blocks,
+                       const uint32_t* dir, uint32_t* exceptions, uint32_t* packed) {
+  if (n_blocks == 0) return;
+  hipLaunchKernelGGL(pack_write_kernel, dim3(n_blocks), dim3(256), 0, stream, docids, fnorm, n, dir, exceptions, packed);
+}
 void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fnorm, uint64_t n, const uint64_t* live) {
   if (n == 0) return;
   const uint64_t blocks = (n + 1023) / 1024;
   hipLaunchKernelGGL(apply_live_kernel, dim3((uint32_t)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, docids, fnorm, n, live);
 }
-void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
+void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool packed, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof) {
   if (n_items == 0) return;
-#define NRT_LAUNCH(F, P, A)                                                                                  \
-  hipLaunchKernelGGL((bm25_scan_kernel<F, P, A>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
+#define NRT_LAUNCH_K(F, P, A, K)                                                                                  \
+  hipLaunchKernelGGL((bm25_scan_kernel<F, P, A, K>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
                      caches, theta_g, quant_g, xch, item_keys, item_counts, item_hits, k_stride, item_prof)
+#define NRT_LAUNCH(F, P, A)                 \
+  do {                                      \
+    if (packed) NRT_LAUNCH_K(F, P, A, true);  \
+    else NRT_LAUNCH_K(F, P, A, false);      \
+  } while (0)
 #define NRT_LAUNCH_FX(P, A)            \
   do {                                 \
     if (fixed_point) NRT_LAUNCH(true, P, A); \
     else NRT_LAUNCH(false, P, A);      \
   } while (0)
-  if (ablation == 8) { NRT_LAUNCH(true, true, 8); return; }
-  if (ablation == 9) { NRT_LAUNCH_FX(true, 9); return; }  // some part carries a doc-set mask (deletes / FILTER / MUST_NOT)  // minimumNumberShouldMatch > 1 somewhere in the batch (fixed point only)
+  if (ablation == 8) { NRT_LAUNCH(true, true, 8); return; }  // minimumNumberShouldMatch > 1 / DisjunctionMaxQuery somewhere in the batch (fixed point only)
+  if (ablation == 9) { NRT_LAUNCH_FX(true, 9); return; }     // some part carries a doc-set mask (deletes / FILTER / MUST_NOT)
   if (!pipelined) { NRT_LAUNCH_FX(false, 0); return; }
   switch (ablation) {
 #ifdef NRTGPU_DEV  // timing ablations (wrong results): development build only, nrtgpu_create rejects the flag values otherwise
-    case 1: NRT_LAUNCH(false, true, 1); break;  // 1-4: of the fp64 kernel
-    case 2: NRT_LAUNCH(false, true, 2); break;
-    case 3: NRT_LAUNCH(false, true, 3); break;
-    case 4: NRT_LAUNCH(false, true, 4); break;
-    case 6: NRT_LAUNCH(false, true, 6); break;  // no candidate handling in sparse sub-tiles
+    case 1: NRT_LAUNCH_K(false, true, 1, false); break;  // 1-4: of the fp64 kernel
+    case 2: NRT_LAUNCH_K(false, true, 2, false); break;
+    case 3: NRT_LAUNCH_K(false, true, 3, false); break;
+    case 4: NRT_LAUNCH_K(false, true, 4, false); break;
+    case 6: NRT_LAUNCH_K(false, true, 6, false); break;  // no candidate handling in sparse sub-tiles
 #endif
     case 7: NRT_LAUNCH_FX(true, 7); break;
     default: NRT_LAUNCH_FX(true, 0); break;
   }
 #undef NRT_LAUNCH_FX
 #undef NRT_LAUNCH
+#undef NRT_LAUNCH_K
 }
 
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,

@@ -89,22 +89,28 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
 // The value postings add for 8 score codes of ONE term (wave-uniform term): a table read, or -- for codes the
 // table cannot serve (freq > kTabMaxFreq / norm >= kTabNorms, sign bit set) and for terms without a table -- the
 // BM25 formula itself.  0 = posting of a deleted doc (apply_live_kernel) -- every live posting scores >= 1.
+// PACKED: c[j] = the packed word's 12-bit code << 2 (codes from kPackEscBase on: exceptions, looked up in the group's
+// exception list by the posting's index pidx[j] in its column).
+template <bool PACKED>
 __device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t (&c)[8], uint32_t need, uint32_t tab_slot,
-                                                float w, int fx_scale, uint32_t cache_slot, uint32_t (&val)[8]) {
+                                                float w, int fx_scale, uint32_t cache_slot, uint64_t esc_list,
+                                                const uint32_t (&pidx)[8], uint32_t (&val)[8]) {
   const uint32_t tab = tab_slot < (uint32_t)kTabTerms ? tab_slot : 7u;
   const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
   uint32_t cor = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     val[j] = *(const uint32_t*)(tb + (c[j] & 0x1FFCu));
-    cor |= ((need >> j) & 1u) ? c[j] : 0u;
+    const uint32_t cn = ((need >> j) & 1u) ? c[j] : 0u;
+    cor = PACKED ? max(cor, cn) : (cor | cn);
   }
-  const bool special = need != 0u && ((cor >> 31) != 0u || tab == 7u);
+  const bool special = need != 0u && ((PACKED ? cor >= (kPackEscBase << 2) : (cor >> 31) != 0u) || tab == 7u);
   if (__any(special)) {
     const float* cache = &s.cache[cache_slot][0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t cj = c[j];
+      uint32_t cj = c[j];
+      if (PACKED && cj >= (kPackEscBase << 2)) cj = ((need >> j) & 1u) ? packed_escape_word((gu32_ptr)esc_list, pidx[j], cj >> 2) : 0x80000100u;
       const bool esc = (cj >> 31) != 0u;
       const uint32_t f = esc ? ((cj >> 8) & 0x3FFFFFu) : ((cj >> 9) & 15u);
       const bool dead = esc ? ((cj >> 30) & 1u) != 0u : (cj >> 20) != 0u;
@@ -176,7 +182,9 @@ __device__ __forceinline__ bool ms_reserve(MsSmem& s, uint32_t lane, uint32_t mi
 
 // PROF: per-item event counters (nrtgpu_get_scan_profile): [0] windows, [1] compactions, [2] posting chunks,
 // [3] postings streamed, [4] postings surviving the bound, [5] docs evaluated, [6] lookups, [7] candidates.
-template <bool PROF>
+// PACKED: the segments keep one 32-bit word per posting (plan.h: kPack*); liveDocs are then a mask (part.live_bits)
+// tested when a doc's score is complete.
+template <bool PROF, bool PACKED>
 __global__ __launch_bounds__(kMsThreads)
 void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts, const DTerm* __restrict__ terms,
                           const DQuery* __restrict__ queries,
@@ -236,7 +244,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     for (;; ++pi) {
       if (pi >= item.n_parts) break;
       part = parts[item.part_begin + pi];
-      part_wins = (part.tile_end - part.tile_begin + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
+      // windows start on kMsWinTiles boundaries of the SEGMENT (the first one of a part may be short): a window never
+      // spans two 2^20-doc super-windows, which is what packed doc offsets are relative to
+      part_wins = (part.tile_end - (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
       if (g < win_base + part_wins) break;
       win_base += part_wins;
     }
@@ -289,8 +299,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     }
 
     for (;;) {  // windows of this part
-      const uint32_t t0 = part.tile_begin + (g - win_base) * (uint32_t)kMsWinTiles;
-      const uint32_t t1 = min(t0 + (uint32_t)kMsWinTiles, part.tile_end);
+      const uint32_t ta = (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (g - win_base) * (uint32_t)kMsWinTiles;
+      const uint32_t t0 = max(ta, part.tile_begin);
+      const uint32_t t1 = min(ta + (uint32_t)kMsWinTiles, part.tile_end);
       const uint32_t doc_lo = t0 * (uint32_t)kTileDocs;
       const uint32_t doc_span = min(t1 * (uint32_t)kTileDocs, part.max_doc) - doc_lo;
       if (PROF) pc_wins += 1;
@@ -361,12 +372,21 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         if (act) {  // (the columns are padded: a partly valid group may read past the term)
           const u32x4 d0 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u));
           const u32x4 d1 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u) + 1);
-          const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u));
-          const u32x4 c1 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u) + 1);
+          if (PACKED) {  // one word per posting: doc offset inside the window's super-window | code
+            const uint32_t sw = doc_lo & ~kPackDocMask;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            d[j] = d0[j]; d[4 + j] = d1[j];
-            cd[j] = c0[j]; cd[4 + j] = c1[j];
+            for (int j = 0; j < 4; ++j) {
+              d[j] = (d0[j] >> kPackCodeBits) | sw; d[4 + j] = (d1[j] >> kPackCodeBits) | sw;
+              cd[j] = (d0[j] & kPackCodeMask) << 2; cd[4 + j] = (d1[j] & kPackCodeMask) << 2;
+            }
+          } else {
+            const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u));
+            const u32x4 c1 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u) + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              d[j] = d0[j]; d[4 + j] = d1[j];
+              cd[j] = c0[j]; cd[4 + j] = c1[j];
+            }
           }
         }
         uint32_t vmask = 0;  // my postings inside the clause's range (one unsigned compare: positions before the range wrap) and the window
@@ -385,16 +405,19 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             val[j] = *(const uint32_t*)(tb + (cd[j] & 0x1FFCu));
-            cor |= ((vmask >> j) & 1u) ? cd[j] : 0u;
+            const uint32_t cn = ((vmask >> j) & 1u) ? cd[j] : 0u;
+            cor = PACKED ? max(cor, cn) : (cor | cn);
           }
-          const bool special = vmask != 0u && ((cor >> 31) != 0u || tab == 7u);
+          const bool special = vmask != 0u && ((PACKED ? cor >= (kPackEscBase << 2) : (cor >> 31) != 0u) || tab == 7u);
           if (__any(special)) {  // long docs / high freqs / clauses without a score table
             const float w = __uint_as_float(r2[0]);
             const int fx_scale = (int)r2[1];
             const float* cache = &s.cache[(flags >> 8) & 255u][0];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const uint32_t cj = cd[j];
+              uint32_t cj = cd[j];
+              if (PACKED && cj >= (kPackEscBase << 2))   // (col_c: the group's exception list; mine0 + j: the posting's index in its column)
+                cj = ((vmask >> j) & 1u) ? packed_escape_word((gu32_ptr)col_c, (uint32_t)mine0 + (uint32_t)j, cj >> 2) : 0x80000100u;
               const bool esc = (cj >> 31) != 0u;
               const uint32_t f = esc ? ((cj >> 8) & 0x3FFFFFu) : ((cj >> 9) & 15u);
               const bool dead = esc ? ((cj >> 30) & 1u) != 0u : (cj >> 20) != 0u;
@@ -460,8 +483,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           const WClause& w2 = wcl[j2];  // uniform reads
           const uint64_t bits2 = w2.bits;
           const uint32_t flags2 = w2.flags;
-          const gu32_ptr codes2 = (gu32_ptr)(w2.fnorm + w2.start * 4u);
+          const gu32_ptr codes2 = (gu32_ptr)((PACKED ? w2.docids : w2.fnorm) + w2.start * 4u);  // packed: the code rides in the posting's word
           uint32_t c2[8];
+          uint32_t pi2[8];  // packed postings: the looked-up postings' indices in their column (exception lookups)
           uint32_t present = 0;
           if (bits2 != 0ull) {
             // dense clause: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether
@@ -479,7 +503,10 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
               present |= (there ? 1u : 0u) << j;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c2[j] = codes2[idx[j]];
+            for (int j = 0; j < 8; ++j) {
+              c2[j] = codes2[idx[j]];
+              pi2[j] = (uint32_t)w2.start + idx[j];
+            }
           } else {
             // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
             // lane advance in lockstep, so every step is one round of loads in flight instead of eight
@@ -509,9 +536,11 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
 #pragma unroll
               for (int j = 0; j < 8; ++j)
                 if ((open >> j) & 1u) {
-                  if (vv[j] < d[j]) a[j] = mid[j] + 1u;
+                  // (packed: doc offsets inside the cell's super-window -- the doc's own, a cell never spans two)
+                  const uint32_t dv = PACKED ? vv[j] >> kPackCodeBits : vv[j], dd = PACKED ? d[j] & kPackDocMask : d[j];
+                  if (dv < dd) a[j] = mid[j] + 1u;
                   else b[j] = mid[j];
-                  if (vv[j] == d[j]) {  // found: close the search on it
+                  if (dv == dd) {  // found: close the search on it
                     a[j] = b[j] = mid[j];
                     present |= 1u << j;
                   }
@@ -519,11 +548,18 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];
+            for (int j = 0; j < 8; ++j) {
+              c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];
+              pi2[j] = (uint32_t)w2.start + a[j];
+            }
           }
           if (__any(present != 0u)) {
             uint32_t v2[8];
-            values_of_codes(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, v2);
+            if (PACKED) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) c2[j] = (c2[j] & kPackCodeMask) << 2;
+            }
+            values_of_codes<PACKED>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
             const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
 #pragma unroll
             for (int j = 0; j < 8; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
@@ -549,7 +585,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
               dsel = d[j];
             }
           const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
-          const bool want = low != 0u && key > theta_now && key < after_key;
+          bool want = low != 0u && key > theta_now && key < after_key;
+          if (PACKED && part.live_bits != nullptr && want)   // deletes are not folded into packed postings: a deleted doc is no hit
+            want = (((const NRT_GLOBAL uint64_t*)part.live_bits)[dsel >> 6] >> (dsel & 63u)) & 1ull;
           uint32_t pos = 0;
           if (!__any(want)) {
             maybe &= ~low;
@@ -699,17 +737,22 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-void launch_bm25_maxscore(hipStream_t stream, bool profile, uint32_t n_items, const DItem* items, const DPart* parts,
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, uint32_t n_items, const DItem* items, const DPart* parts,
                           const DTerm* terms, const DQuery* queries, const float* caches,
                           unsigned long long* theta_g, uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits,
                           uint32_t k_stride, uint64_t* item_prof) {
   if (n_items == 0) return;
-  if (profile)
-    hipLaunchKernelGGL((bm25_maxscore_kernel<true>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries,
-                       caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof);
-  else
-    hipLaunchKernelGGL((bm25_maxscore_kernel<false>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries,
-                       caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof);
+#define NRT_MS_LAUNCH(P, K)                                                                                                      \
+  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
+                     caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof)
+  if (profile) {
+    if (packed) NRT_MS_LAUNCH(true, true);
+    else NRT_MS_LAUNCH(true, false);
+  } else {
+    if (packed) NRT_MS_LAUNCH(false, true);
+    else NRT_MS_LAUNCH(false, false);
+  }
+#undef NRT_MS_LAUNCH
 }
 
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,

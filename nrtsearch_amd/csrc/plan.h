@@ -33,13 +33,37 @@ constexpr int kTabNorms = 128;
 constexpr int kTabEntries = (kTabMaxFreq + 1) * kTabNorms;  // row 0 (freq 0) unused
 constexpr int kMaxK = 1024;
 constexpr int kMaxTerms = 32;
+// Packed postings (NRTGPU_FLAG_PACKED_POSTINGS): ONE 32-bit word per posting instead of the docid and
+// code columns -- the doc's offset inside its 2^20-doc super-window (bits 12-31; the super-window is known from the
+// posting's cell: cell shifts are capped so that a cell never spans two) | a 12-bit score code:
+//   code <  kPackEscBase : (freq << 7) | norm byte (freq <= kTabMaxFreq, norm < kTabNorms): table byte offset = code << 2
+//   code >= kPackEscBase : an EXCEPTION (freq > kTabMaxFreq or norm >= kTabNorms): the low 11 bits of its number e in
+//                          the upload group's exception list (exceptions numbered in posting order).  The list's
+//                          directory holds, per block of 2^kPackEscBlockShift = 2048 postings, the number of
+//                          exceptions before the block (e0): e = e0 + ((low bits - e0) & 2047) -- unique, a block
+//                          holds at most 2048.  exceptions[e] is the 32-bit escape word 0x80000000 | freq << 8 | norm
+//                          of the unpacked layout.  Memory: 4 B per exception + 4 B per 2048 postings.
+// The list (DTerm.fnorm of a packed term): u32 header[4] = {n_blocks, n_exceptions, 0, 0}, u32 dir[n_blocks + 1],
+// u32 exceptions[n_exceptions].
+// liveDocs are NOT folded into packed postings (no spare bit): deletes stay a mask the scorers test.
+constexpr uint32_t kPackDocBits = 20;
+constexpr uint32_t kPackCodeBits = 12;
+constexpr uint32_t kPackCodeMask = (1u << kPackCodeBits) - 1u;
+constexpr uint32_t kPackDocMask = (1u << kPackDocBits) - 1u;
+constexpr uint32_t kPackEscBase = (uint32_t)kTabEntries;                    // 1664
+constexpr uint32_t kPackEscBlockShift = 11;
+constexpr uint32_t kPackEscLowMask = (1u << kPackEscBlockShift) - 1u;
+static_assert(kPackEscBase + kPackEscLowMask < (1u << kPackCodeBits), "exception codes must fit the 12-bit code");
+constexpr uint32_t kPackMaxCellShift = kPackDocBits - 10;                   // cell = tile >> shift with 1024-doc tiles: <= 2^20 docs
+static_assert(kTileDocs == 1024 || kPackMaxCellShift > 0, "packed postings assume 1024-doc sub-tiles");
 
 struct DTermAux;
 // One query term inside one segment: where its posting columns live in HBM.
 struct alignas(16) DTerm {
   const uint32_t* docids;    // docid column (all terms of the upload group, concatenated)
   const uint32_t* fnorm;     // score-code column: byte offset ((freq << 7 | norm) << 2) into a score table when
-                             // freq <= kTabMaxFreq and norm < kTabNorms, else 0x80000000 | freq << 8 | norm
+                             // freq <= kTabMaxFreq and norm < kTabNorms, else 0x80000000 | freq << 8 | norm.
+                             // Packed postings: `docids` is the packed column and this is the group's exception list
   const uint32_t* cell_off;  // (n_cells + 1) posting offsets relative to `start`, one per doc-range cell
   uint64_t start;            // index of the term's first posting in the columns
   const DTermAux* aux;       // seal-time facts of the term the MaxScore route uses (resident next to the columns)

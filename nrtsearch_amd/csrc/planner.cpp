@@ -256,7 +256,8 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
   bool any_deleted = false, plain = true;
   for (int si = 0; si < n_segs; ++si) {
     any_deleted = any_deleted || n_deleted[si] != 0;
-    plain = plain && (segs[si]->d_live == nullptr || segs[si]->live_folded);
+    // (packed postings never fold liveDocs: the MaxScore kernel tests the mask when a doc's score is complete)
+    plain = plain && (segs[si]->d_live == nullptr || segs[si]->live_folded || (segs[si]->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0);
   }
   size_t prev_cache_off = 0, prev_cache_len = 0;
   pc.qterms.reserve((size_t)(q_end - q_begin) * 6);

@@ -36,11 +36,11 @@
 #include "plan.h"
 
 namespace nrtgpu {
-void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, int ablation, uint32_t n_items, const DItem* items,
+void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool packed, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
-void launch_bm25_maxscore(hipStream_t stream, bool profile, uint32_t n_items, const DItem* items, const DPart* parts,
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, uint32_t n_items, const DItem* items, const DPart* parts,
                           const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                           uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
@@ -58,6 +58,9 @@ void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* i
                        uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out);
 void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,
                        uint32_t* fnorm, uint64_t n, uint32_t* overflow);
+void launch_pack_count(hipStream_t stream, const uint32_t* fnorm, uint64_t n, uint32_t n_blocks, uint32_t* counts);
+void launch_pack_write(hipStream_t stream, const uint32_t* docids, const uint32_t* fnorm, uint64_t n, uint32_t n_blocks,
+                       const uint32_t* dir, uint32_t* exceptions, uint32_t* packed);
 void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fnorm, uint64_t n, const uint64_t* live);
 void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float* norm2);
 int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
@@ -151,6 +154,8 @@ struct TermGroup {
   uint32_t* d_freqs = nullptr;   // raw freq column, only between add_terms and seal (nullptr => freq == 1)
   uint32_t* d_fnorm = nullptr;   // score-code column (same allocation as d_docids), filled at seal
   bool folded = false;
+  bool packed = false;           // NRTGPU_FLAG_PACKED_POSTINGS, after the seal: d_docids = packed column, d_fnorm = d_dict
+  uint32_t* d_dict = nullptr;    // packed postings: the group's exception list (header, directory, escape words)
   uint32_t* d_cells = nullptr;   // concatenated per-term cell tables
   DTermAux* d_aux = nullptr;     // MaxScore route: one record per term of the group (impact frontier, membership records), seal
   uint32_t* d_bits = nullptr;    // membership + rank records of the group's dense terms (16 B per 64 docs and term)

@@ -100,12 +100,12 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_expand_terms(st, (const DQExpand*)(db + o_qexp), (const DQTerm*)(db + o_qterms), (const uint32_t*)(db + o_qsb),
                       (uint32_t)n_queries, hp.n_leaves, (DTerm*)(wb + o_terms));
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
-  launch_bm25_maxscore(st, profile, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
+  launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                        (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
                        (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
                        profile ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
-  launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, ablation, (uint32_t)(n_items - n_ms),
+  launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, ablation, (uint32_t)(n_items - n_ms),
                    (const DItem*)(db + o_items) + n_ms, (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
                    (unsigned long long*)(db + o_theta), (unsigned long long*)(db + o_quant),

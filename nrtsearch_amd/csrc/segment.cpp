@@ -89,7 +89,9 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
     if (cnt > 0xFFFFFFFFll) return fail(NRTGPU_ERR_UNSUPPORTED, "term with more than 2^32 postings");
     uint32_t shift = 0;
     const uint64_t budget = std::max<int64_t>(1, cnt / 8);
-    while (((uint64_t)(seg->n_tiles - 1) >> shift) + 1 > budget && shift < 31) ++shift;
+    // (packed postings: a cell must not span two 2^20-doc super-windows -- a posting's doc offset is relative to its cell's)
+    const uint32_t max_shift = (seg->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) ? kPackMaxCellShift : 31u;
+    while (((uint64_t)(seg->n_tiles - 1) >> shift) + 1 > budget && shift < max_shift) ++shift;
     const uint32_t n_cells = (uint32_t)(((uint64_t)(seg->n_tiles - 1) >> shift) + 1);
     TermEntry& e = entries[(size_t)t];
     e.group = (uint32_t)f.groups.size();
@@ -238,6 +240,58 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   return NRTGPU_OK;
 }
 
+// NRTGPU_FLAG_PACKED_POSTINGS: the group's docid and code columns become ONE column of 32-bit words plus the group's
+// exception list (plan.h: kPack*); the two columns are freed.  From here on g.d_docids is the packed column and
+// g.d_fnorm the list (what DTerm.docids / DTerm.fnorm then mean to the kernels).
+static int pack_group(nrtgpu_seg* seg, TermGroup& g) {
+  if (g.packed) return NRTGPU_OK;
+  const uint64_t n = g.n_postings;
+  if (n >= (1ull << 32)) return fail(NRTGPU_ERR_UNSUPPORTED, "packed postings: an upload group of 2^32 postings or more");
+  const uint32_t n_blocks = (uint32_t)((n + (1ull << kPackEscBlockShift) - 1) >> kPackEscBlockShift);
+  // exceptions per block of 2048 postings -> directory (exclusive prefix)
+  std::vector<uint32_t> dir((size_t)n_blocks + 1, 0u);
+  if (n_blocks) {
+    uint32_t* d_counts = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_counts, (size_t)n_blocks * 4));
+    launch_pack_count(nullptr, g.d_fnorm, n, n_blocks, d_counts);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(dir.data() + 1, d_counts, (size_t)n_blocks * 4, hipMemcpyDeviceToHost);   // (syncs the null stream)
+    (void)hipFree(d_counts);
+    if (e != hipSuccess) return fail(NRTGPU_ERR_HIP, "packing the postings failed: %s", hipGetErrorString(e));
+  }
+  uint64_t run = 0;
+  for (uint32_t b = 0; b < n_blocks; ++b) {
+    const uint32_t c = dir[(size_t)b + 1];
+    dir[(size_t)b + 1] = 0;
+    dir[(size_t)b] = (uint32_t)run;
+    run += c;
+  }
+  dir[(size_t)n_blocks] = (uint32_t)run;
+  const uint32_t n_exc = (uint32_t)run;
+  const size_t list_words = 4 + (size_t)n_blocks + 1 + (size_t)n_exc;
+  const size_t col_bytes = (((size_t)n * 4 + 15) & ~(size_t)15) + 64;
+  void* p = nullptr;
+  if (int rc = dev_alloc(seg, &p, list_words * 4 + 64)) return rc;
+  uint32_t* d_list = (uint32_t*)p;
+  if (int rc = dev_alloc(seg, &p, col_bytes)) return rc;
+  uint32_t* d_packed = (uint32_t*)p;
+  const uint32_t header[4] = {n_blocks, n_exc, 0u, 0u};
+  HIP_TRY(hipMemset(d_packed, 0, col_bytes));
+  HIP_TRY(hipMemset(d_list, 0, list_words * 4 + 64));
+  HIP_TRY(hipMemcpy(d_list, header, sizeof(header), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_list + 4, dir.data(), dir.size() * 4, hipMemcpyHostToDevice));
+  launch_pack_write(nullptr, g.d_docids, g.d_fnorm, n, n_blocks, d_list + 4, d_list + 4 + n_blocks + 1, d_packed);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  (void)hipFree(g.d_docids);   // [docid column | code column]: one allocation
+  seg->device_bytes -= (int64_t)(2 * col_bytes);
+  g.d_docids = d_packed;
+  g.d_fnorm = d_list;
+  g.d_dict = d_list;
+  g.packed = true;
+  return NRTGPU_OK;
+}
+
 extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
   if (seg->sealed) return NRTGPU_OK;
@@ -272,6 +326,10 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
       if (int rc2 = build_term_aux(seg, g)) return rc2;
+  if (seg->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS)   // (the seal-time builders above read the two-column form)
+    for (auto& kv : seg->fields)
+      for (auto& g : kv.second.groups)
+        if (int rc2 = pack_group(seg, g)) return rc2;
   for (auto& kv : seg->fields) kv.second.flat.build(kv.second.dict);
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
@@ -289,7 +347,7 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
 // over the segment's postings per reader version instead of a liveness test per matched doc per query.
 static int fold_live_docs(nrtgpu_seg* seg) {
   seg->live_folded = false;
-  if (seg->ctx->cfg.flags & NRTGPU_FLAG_NO_LIVE_FOLD) return NRTGPU_OK;
+  if (seg->ctx->cfg.flags & (NRTGPU_FLAG_NO_LIVE_FOLD | NRTGPU_FLAG_PACKED_POSTINGS)) return NRTGPU_OK;   // (a packed word has no spare bit)
   if (!seg->sealed) return NRTGPU_OK;  // seal folds
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
@@ -436,6 +494,7 @@ extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
     if (f.d_ord_to_doc) (void)hipFree(f.d_ord_to_doc);
     for (auto& g : f.groups) {
       if (g.d_docids) (void)hipFree(g.d_docids);
+      if (g.d_dict) (void)hipFree(g.d_dict);
       if (g.d_freqs) (void)hipFree(g.d_freqs);
       if (g.d_cells) (void)hipFree(g.d_cells);
       if (g.d_aux) (void)hipFree(g.d_aux);

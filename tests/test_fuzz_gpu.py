@@ -1,6 +1,6 @@
 """Seeded differential fuzz of the query shapes against the oracle: random corpora (segment counts, deletes,
 ragged sizes), random clause sets (1..10 terms, boosts, repeats), numHits, thresholds, paging, masks,
-minimumNumberShouldMatch, min competitive scores -- mixed inside batches so that every kernel variant and the
+minimumNumberShouldMatch, DisjunctionMaxQuery, min competitive scores -- mixed inside batches so that every kernel variant and the
 batch-level switches between them are exercised together.  Bit-exact like every BM25 test.
 NRT_FUZZ_ROUNDS scales the number of corpora (default 6)."""
 import os
@@ -51,7 +51,13 @@ def test_fuzz_query_shapes(round_):
                 if f and msm == 0:
                     msm = 1
                 clauses = tuple(api.BoostQuery(api.TermQuery(0, t), b) if b != 1.0 else api.TermQuery(0, t) for t, b in zip(terms, boosts))
-                if nt == 1 and not f and not mn and msm == 0:
+                dismax = allow_msm and msm <= 1 and rng.random() < 0.25   # (same kernel variant as the clause counts: fixed point only)
+                if dismax:
+                    dq = api.DisjunctionMaxQuery(clauses)
+                    q = dq if not (f or mn) else api.BooleanQuery(must=(dq,), filter=(api.MaskFilter(f),) if f else (),
+                                                                  must_not=(api.MaskFilter(mn),) if mn else ())
+                    msm = 0
+                elif nt == 1 and not f and not mn and msm == 0:
                     q = clauses[0]
                 else:
                     q = api.BooleanQuery(clauses, msm, (api.MaskFilter(f),) if f else (), (api.MaskFilter(mn),) if mn else ())
@@ -59,7 +65,7 @@ def test_fuzz_query_shapes(round_):
                 if f or mn:
                     acc = [accept_of(s, masks[f][i] if f else None, masks[mn][i] if mn else None) for i, s in enumerate(corpus.segments)]
                 after = None
-                okw = dict(boosts=boosts, total_hits_threshold=thr, accept=acc, min_should_match=msm)
+                okw = dict(boosts=boosts, total_hits_threshold=thr, accept=acc, min_should_match=msm, dismax=0.0 if dismax else None)
                 if rng.random() < 0.25:
                     first = oracle.search_bm25(corpus, terms, k, **okw)
                     if len(first[0]):
