@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--exchange", action="store_true",
                     help="N>1: share score bounds between the GPUs' shards (nrtgpu_exchange_open); the shards then run the "
                          "exhaustive scan, which takes part in the exchange, instead of pruning on their own (A/B; results are identical)")
+    ap.add_argument("--packed", action="store_true",
+                    help="compressed postings (NRTGPU_FLAG_PACKED_POSTINGS): one 32-bit word per posting in HBM.  A separately "
+                         "reported configuration: the roofline's algorithmic bytes are then 4 per posting, not 9")
     ap.add_argument("--no-prune", action="store_true",
                     help="A/B: exhaustive scan only (NRTGPU_FLAG_NO_PRUNE): every posting of every query term is streamed")
     ap.add_argument("--debug-same-gpu", action="store_true",
@@ -349,7 +352,8 @@ def main():
     corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank)
     t_build = time.perf_counter() - t_build
 
-    flags = (_lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0) | (_lib.NRTGPU_FLAG_NO_PRUNE if args.no_prune else 0)
+    flags = ((_lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0) | (_lib.NRTGPU_FLAG_NO_PRUNE if args.no_prune else 0)
+             | (_lib.NRTGPU_FLAG_PACKED_POSTINGS if args.packed else 0))
     # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
     # (the node's ranks share the host; 4 is the library's default and enough at one rank)
     planner_threads = max(1, min(4, usable_cpus() // max(1, world * max(1, args.host_threads))))
@@ -531,7 +535,9 @@ def main():
     kernel = "bm25_maxscore_kernel" if pruned else "bm25_scan_kernel"
     launches = max(1, st["maxscore_launches"] if pruned else st["scan_launches"])
     scan_ms = (st["maxscore_ms"] if pruned else st["scan_ms"]) / launches
-    bytes_per_launch = (st["maxscore_postings"] if pruned else st["scan_postings"]) / launches * BYTES_PER_POSTING
+    bpp = 4 if args.packed else BYTES_PER_POSTING               # packed: the one word IS the posting (norm and freq inside its code)
+    bpp_fused = 4 if args.packed else BYTES_PER_POSTING_FUSED
+    bytes_per_launch = (st["maxscore_postings"] if pruned else st["scan_postings"]) / launches * bpp
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -540,12 +546,12 @@ def main():
             recs = json.load(open(pmc))
             for rec in (recs if isinstance(recs, list) else [recs]):
                 if (rec.get("workload") == args.workload and rec.get("batch") == B and rec.get("kernel") == kernel
-                        and world == 1 and shard_world == 1):
+                        and bool(rec.get("packed", False)) == bool(args.packed) and world == 1 and shard_world == 1):
                     traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
-        "metric": "queries/sec, 10M-doc 5-term BM25 top-1000" if args.workload == "C3" else f"queries/sec, {w.name}",
+        "metric": ("queries/sec, 10M-doc 5-term BM25 top-1000" if args.workload == "C3" else f"queries/sec, {w.name}") + (" (packed postings)" if args.packed else ""),
         "value": round(qps, 1),
         "unit": "queries/s",
         "n_gpus": world,
@@ -559,7 +565,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": w.name,
+            "workload": w.name + (" [packed postings: 4 B per posting in HBM]" if args.packed else ""),
+            "device_bytes_per_gpu": int(sum(l.device_bytes for l in leaves)),
             "n_docs": w.n_docs, "terms_per_query": w.n_terms, "k": w.k, "batch_queries": B,
             "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
             "segments_per_gpu": len(corpus.segments),
@@ -582,10 +589,10 @@ def main():
             "effective": pruned,   # pruned: algorithmic (exhaustive-scan) bytes over the time of a kernel that skips most of them
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "bytes_per_posting": BYTES_PER_POSTING,
+            "bytes_per_posting": bpp,
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
-            "achieved_at_8B_per_posting": round(achieved * BYTES_PER_POSTING_FUSED / BYTES_PER_POSTING, 1),
-            "frac_at_8B_per_posting": round(achieved * BYTES_PER_POSTING_FUSED / BYTES_PER_POSTING / HBM_PEAK_GBS, 4),
+            "achieved_at_8B_per_posting": round(achieved * bpp_fused / bpp, 1),    # (packed: 4 B either way)
+            "frac_at_8B_per_posting": round(achieved * bpp_fused / bpp / HBM_PEAK_GBS, 4),
             "accumulators": "fixed-point u64" if (pruned or st.get("fixed_point_launches", 0) == st["scan_launches"]) else "fp64",
             "physical_achieved": round(traffic / (scan_ms * 1e-3) / 1e9, 1) if (traffic and scan_ms > 0) else None,
             "physical_frac": round(traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and scan_ms > 0) else None,
