@@ -346,8 +346,10 @@ __device__ __forceinline__ void rendezvous_compact(ScanSmem& s, uint64_t* acc, b
       if (n_shares > 1u && q2_hi != 0u) atomicMax(peers + my_peer, ((unsigned long long)q2_hi << 32) | 1ull);
       s.prof[6] += 1;
     }
-    if (n_shares > 1u && tid < 64u) {  // wave 0 (uniform inside it): what the search's slices know together
-      uint64_t pb = peers_bound(peers, n_peers, lane, others_only ? my_peer : ~0u);  // this GPU's items
+    if ((n_shares > 1u || xch) && tid < 64u) {  // wave 0 (uniform inside it): what the search's slices know together
+      // (one share = an unsplit query on two GPUs: the share is the item's own k-th best -- k of this rank's docs reach it)
+      uint64_t pb = n_shares > 1u ? peers_bound(peers, n_peers, lane, others_only ? my_peer : ~0u)  // this GPU's items
+                                  : (thr & 0xFFFFFFFF00000000ull);
       if (xch) pb = exchange_bound(*xch, query, pb, lane);  // publish it, bound myself by the other GPUs' entries
       if (tid == 0 && pb > s.theta) {
         s.theta = pb;
