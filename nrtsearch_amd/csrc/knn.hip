@@ -58,6 +58,74 @@ __device__ __forceinline__ float knn_map_score(int sim, float dot, float nq, flo
   return s * boost;
 }
 
+// The dot products of one 16-row tile with the workgroup's query panel(s): acc0 / acc1 = C tiles of panel 0 / 1.
+// vp: the lane's row chunk pointer (row j, 16-byte piece kk of every 64-byte chunk), qs: the panel in LDS in operand
+// order.  kKnnDepth row chunks are in flight per lane; the body of the main loop has no control flow, so the LDS operand
+// reads of the next chunks are scheduled under the MFMAs of the current one (with a branch per chunk the compiler issued
+// them right before their use: every chunk waited for the LDS).
+template <bool TWO>
+__device__ __forceinline__ void knn_tile_dots(const f32x4* __restrict__ vp, const f32x4* qs, int32_t chunks, uint32_t lane,
+                                              f32x4& acc0, f32x4& acc1) {
+  f32x4 abuf[kKnnDepth];
+#pragma unroll
+  for (int i = 0; i < kKnnDepth; ++i) abuf[i] = vp[4 * min(i, chunks - 1)];
+  int32_t c0 = 0;
+  // the panel's operands of the NEXT chunk are read from LDS before the current chunk's MFMAs are issued (b0n / b1n)
+  f32x4 b0n = qs[(int32_t)lane], b1n = b0n;
+  if (TWO) b1n = qs[64 + (int32_t)lane];
+  for (; c0 + kKnnDepth <= chunks; c0 += kKnnDepth) {
+#pragma unroll
+    for (int i = 0; i < kKnnDepth; ++i) {
+      const int32_t c = c0 + i;
+      const f32x4 a = abuf[i];
+      abuf[i] = vp[4 * min(c + kKnnDepth, chunks - 1)];
+      const f32x4 b0 = b0n, b1 = b1n;
+      const int32_t cn = min(c + 1, chunks - 1);
+      b0n = qs[cn * 128 + (int32_t)lane];
+      if (TWO) b1n = qs[cn * 128 + 64 + (int32_t)lane];
+      __builtin_amdgcn_sched_barrier(0);  // the reads stay ahead of the MFMAs: their LDS latency hides under 8 matrix instructions
+      if (TWO) {  // two independent accumulation chains, interleaved (pinned: left alone the scheduler runs one chain after the other)
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1[0], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1[1], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b1[2], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b1[3], acc1, 0, 0, 0);
+      } else {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
+      }
+    }
+  }
+  // the last chunks of a dimension that is no multiple of 16 * kKnnDepth (their rows are in abuf already)
+#pragma unroll
+  for (int i = 0; i < kKnnDepth; ++i) {
+    const int32_t c = c0 + i;
+    if (c < chunks) {  // wave-uniform
+      const f32x4 a = abuf[i];
+      const f32x4 b0 = qs[c * 128 + (int32_t)lane];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
+      if (TWO) {
+        const f32x4 b1 = qs[c * 128 + 64 + (int32_t)lane];
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1[0], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1[1], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b1[2], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b1[3], acc1, 0, 0, 0);
+      }
+    }
+  }
+}
+
 // Scores docs [row_begin, row_end) of one segment against <= 64 queries (panels of <= 32, see below); hits with
 // key > theta[q] are appended to query q's candidate list.  dim must be a multiple of 16.
 //   qpanel : n_q * dim floats (row-major), qnorm2 : n_q floats
@@ -121,36 +189,8 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
     const int64_t row = min(r0 + (int64_t)j, row_end - 1);  // clamped: loads are unconditional
     const f32x4* vp = (const f32x4*)(vecs + row * dim) + kk;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 abuf[kKnnDepth];
-#pragma unroll
-    for (int i = 0; i < kKnnDepth; ++i) abuf[i] = vp[4 * min(i, chunks - 1)];
-    for (int32_t c0 = 0; c0 < chunks; c0 += kKnnDepth) {
-#pragma unroll
-      for (int i = 0; i < kKnnDepth; ++i) {
-        const int32_t c = c0 + i;
-        const f32x4 a = abuf[i];
-        abuf[i] = vp[4 * min(c + kKnnDepth, chunks - 1)];
-        if (c < chunks) {  // wave-uniform
-          const f32x4 b0 = qs[c * 128 + (int32_t)lane];
-          if (two_panels) {  // two independent accumulation chains, interleaved
-            const f32x4 b1 = qs[c * 128 + 64 + (int32_t)lane];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1[0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b1[2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b1[3], acc1, 0, 0, 0);
-          } else {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
-          }
-        }
-      }
-    }
+    if (two_panels) knn_tile_dots<true>(vp, qs, chunks, lane, acc0, acc1);   // (wave-uniform; each variant's chunk loop is branch-free)
+    else knn_tile_dots<false>(vp, qs, chunks, lane, acc0, acc1);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int32_t q = (int32_t)j + 16 * p;
