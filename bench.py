@@ -382,6 +382,7 @@ def main():
         dist.barrier()
     NB = 3  # device result buffers in flight between the scan threads and the exchange thread
     lib_collective = False
+    lib_collective_hung = False   # its setup thread never came back: leave through os._exit at the end
     if use_dist:
         bufs = [(torch.zeros((B, k_stride), dtype=torch.int64, device="cuda"),
                  torch.zeros((B,), dtype=torch.int32, device="cuda"),
@@ -418,7 +419,28 @@ def main():
                 box = [api.GpuContext.dist_unique_id() if rank == 0 else None]
                 if world > 1:
                     dist.broadcast_object_list(box, src=0)
-                stdout_to_stderr(lambda: ctx.dist_init(world, rank, box[0]))
+                # communicator + one exchange of the real shape, under a watchdog: a setup that never returns must cost
+                # this run the library path, not the measurement (the ranks then agree on torch.distributed below)
+                import threading as _th
+
+                probe_err = []
+
+                def _probe():
+                    try:
+                        stdout_to_stderr(lambda: ctx.dist_init(world, rank, box[0]))
+                        keys0, cnt0, hits0 = bufs[0]
+                        merger.run_dist(keys0.data_ptr(), cnt0.data_ptr(), hits0.data_ptr())   # (zero counts: merges nothing)
+                    except Exception as e_:   # noqa: BLE001
+                        probe_err.append(e_)
+
+                th = _th.Thread(target=_probe, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("NRTGPU_BENCH_COLLECTIVE_TIMEOUT", "180")))
+                if th.is_alive():
+                    lib_collective_hung = True
+                    raise RuntimeError("setup did not finish in time")
+                if probe_err:
+                    raise probe_err[0]
             except Exception as e:   # noqa: BLE001
                 print(f"[rank {rank}] library collective unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
                 ok = 0
@@ -619,6 +641,10 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     os.dup2(2, 1)   # whatever the runtimes still print at teardown (C stdio) goes to stderr: stdout stays the one JSON line
+    if lib_collective_hung:   # a thread is stuck inside the collective library: no orderly teardown
+        if world > 1:
+            dist.barrier()
+        os._exit(0)
     if world > 1:
         dist.barrier()
         if exchange_name:
