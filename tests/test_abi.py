@@ -286,3 +286,31 @@ def test_blend_product_function_matches_the_reference_rules(lib):
     # java.util.HashMap's bucket order (doc 17 -> bucket 1, doc 33 -> bucket 1 after doc 17; doc 2 -> bucket 2) feeding the heap
     td = api.blend([np.array([33]), np.array([2]), np.array([17])], top_hits=3)
     assert sorted(td.docs.tolist()) == [2, 17, 33] and len(set(td.scores.tolist())) == 1
+
+
+def test_packed_posting_word_arithmetic():
+    """Host restatement of the packed-postings word (plan.h: kPack*; no device): the exception number of a posting is
+    rebuilt from the 11 bits its word carries and the directory entry of its 2048-posting block, whatever the density of
+    exceptions; doc offsets are relative to the 2^20-doc super-window a cell (shift <= 10) never leaves."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    ESC_BASE, LOW, BLOCK = 1664, 2047, 2048
+    for density in (0.0005, 0.2, 1.0):
+        n = 50_000
+        is_exc = rng.random(n) < density
+        e_of = np.cumsum(is_exc) - 1                                  # exceptions numbered in posting order
+        code = np.where(is_exc, ESC_BASE + (e_of & LOW), 7)          # what pack_write_kernel stores
+        assert code.max() < 4096
+        counts = np.add.reduceat(is_exc.astype(np.int64), np.arange(0, n, BLOCK))
+        directory = np.concatenate([[0], np.cumsum(counts)])          # exclusive prefix per block (+ total)
+        p = np.nonzero(is_exc)[0]
+        e0 = directory[p // BLOCK]
+        rebuilt = e0 + (((code[p] - ESC_BASE) - e0) & LOW)            # packed_escape_word
+        assert np.array_equal(rebuilt, e_of[p])
+    # doc offset: 20 bits inside the super-window; every cell of a packed segment lies inside one
+    for shift in range(0, 11):
+        for cell in (0, 1, 5, 1023):
+            first_tile, last_tile = cell << shift, ((cell + 1) << shift) - 1
+            assert (first_tile * 1024) >> 20 == (last_tile * 1024 + 1023) >> 20
+    doc = np.array([0, 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 77, 2_600_000 - 1])
+    word = ((doc & ((1 << 20) - 1)) << 12) | 5
+    assert np.array_equal((word >> 12) | (doc & ~((1 << 20) - 1)), doc) and word.max() < 2**32
