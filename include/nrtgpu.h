@@ -107,6 +107,14 @@ int  nrtgpu_segment_seal(nrtgpu_seg* seg);
  * the searches running over this segment and later ones wait for it (they see the new liveDocs; one
  * liveDocs version per segment handle at a time). */
 int  nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bits, int32_t n_words);
+/* A new reader version of a sealed segment (what a refresh produces when only liveDocs changed): a handle that SHARES
+ * the segment's postings, norms and vectors (nothing is copied or re-uploaded) and carries its own liveDocs (bits as
+ * above; NULL = all live) and its own doc-set masks.  Searches over `seg` keep seeing `seg`'s liveDocs -- the
+ * point-in-time view an IndexSearcher has in Lucene -- and nobody waits for anybody.  The shared data is freed with the
+ * last handle (nrtgpu_segment_release on each).  While a segment has several handles its deletes are tested as a mask
+ * instead of being folded into the postings, and -- as in Lucene, where a segment's deletes only accumulate -- a handle's
+ * liveDocs may not bring back a doc that the shared postings already carry as deleted (NRTGPU_ERR_UNSUPPORTED). */
+int  nrtgpu_segment_fork(nrtgpu_seg* seg, const uint64_t* live_bits, int32_t n_words, nrtgpu_seg** out);
 /* Non-scoring clauses as doc-set masks (FILTER / MUST_NOT of the BooleanQuery built at
  * src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:257-283).  The shim materialises the
  * clause's per-leaf DocIdSet (what LRUQueryCache caches) as 64-bit words, bit d set = doc d matches,

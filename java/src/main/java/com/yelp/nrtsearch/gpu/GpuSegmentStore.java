@@ -24,7 +24,8 @@ final class GpuSegmentStore {
   record Resident(MemorySegment seg, long liveDocsVersion) {}
 
   private final MemorySegment ctx;
-  private final Map<IndexReader.CacheKey, Resident> resident = new ConcurrentHashMap<>();
+  private final Map<IndexReader.CacheKey, Resident> resident = new ConcurrentHashMap<>();      // by segment core
+  private final Map<IndexReader.CacheKey, MemorySegment> versions = new ConcurrentHashMap<>();  // by leaf reader version: forks
   private final Map<String, Integer> fieldIds = new ConcurrentHashMap<>();
 
   GpuSegmentStore(MemorySegment ctx) { this.ctx = ctx; }
@@ -38,7 +39,12 @@ final class GpuSegmentStore {
     return h;
   }
 
-  /** Segments of `reader` that are not resident yet are uploaded; liveDocs of the others are refreshed when they changed. */
+  /**
+   * Segments of `reader` that are not resident yet are uploaded (keyed by the segment CORE: postings, norms and vectors
+   * are immutable).  A leaf reader with deletes gets its own handle per READER version: nrtgpu_segment_fork shares the
+   * core's data and carries that version's liveDocs, so a search holding an older IndexSearcher keeps its point-in-time
+   * view and a refresh never waits for running searches.  Forks go away with their reader, the data with the core.
+   */
   void sync(DirectoryReader reader, Collection<String> textFields, Collection<String> vectorFields) throws IOException {
     for (LeafReaderContext lc : reader.leaves()) {
       LeafReader leaf = lc.reader();
@@ -49,23 +55,50 @@ final class GpuSegmentStore {
         MemorySegment seg = upload(leaf, textFields, vectorFields);
         r = new Resident(seg, -1);
         resident.put(core.getKey(), r);
-        core.addClosedListener(key -> {                 // segment merged away / reader closed
+        core.addClosedListener(key -> {                 // segment merged away / last reader closed
           Resident gone = resident.remove(key);
           if (gone != null) try { NrtGpu.RELEASE.invokeExact(gone.seg()); } catch (Throwable ignored) { }
         });
       }
-      long version = leaf.getReaderCacheHelper() == null ? 0 : System.identityHashCode(leaf.getReaderCacheHelper().getKey());
-      if (version != r.liveDocsVersion()) {
-        setLiveDocs(r.seg(), leaf.getLiveDocs(), leaf.maxDoc());
-        resident.put(core.getKey(), new Resident(r.seg(), version));
+      IndexReader.CacheHelper version = leaf.getReaderCacheHelper();
+      if (leaf.getLiveDocs() != null && version != null && !versions.containsKey(version.getKey())) {
+        MemorySegment fork = fork(r.seg(), leaf.getLiveDocs(), leaf.maxDoc());
+        versions.put(version.getKey(), fork);
+        version.addClosedListener(key -> {              // this reader version is gone
+          MemorySegment gone = versions.remove(key);
+          if (gone != null) try { NrtGpu.RELEASE.invokeExact(gone); } catch (Throwable ignored) { }
+        });
       }
     }
   }
 
+  /** The handle a search over this leaf READER uses: its version's fork when it has deletes, else the core's handle. */
   MemorySegment segmentOf(LeafReaderContext lc) {
-    IndexReader.CacheHelper core = lc.reader().getCoreCacheHelper();
+    LeafReader leaf = lc.reader();
+    IndexReader.CacheHelper version = leaf.getReaderCacheHelper();
+    if (leaf.getLiveDocs() != null) {
+      MemorySegment fork = version == null ? null : versions.get(version.getKey());
+      return fork;                                      // (null: a version the store has not seen -- CPU path)
+    }
+    IndexReader.CacheHelper core = leaf.getCoreCacheHelper();
     Resident r = core == null ? null : resident.get(core.getKey());
     return r == null ? null : r.seg();
+  }
+
+  private static MemorySegment fork(MemorySegment seg, Bits live, int maxDoc) throws IOException {
+    try (Arena a = Arena.ofConfined()) {
+      int words = (maxDoc + 63) >>> 6;
+      MemorySegment bits = a.allocate((long) words * 8);
+      for (int d = 0; d < maxDoc; d++)
+        if (live.get(d)) bits.setAtIndex(JAVA_LONG, d >>> 6, bits.getAtIndex(JAVA_LONG, d >>> 6) | (1L << (d & 63)));
+      MemorySegment out = a.allocate(ADDRESS);
+      NrtGpu.check((int) NrtGpu.FORK.invokeExact(seg, bits, words, out));
+      return out.get(ADDRESS, 0);
+    } catch (IOException | RuntimeException e) {
+      throw e;
+    } catch (Throwable t) {
+      throw new IOException(t);
+    }
   }
 
   private MemorySegment upload(LeafReader leaf, Collection<String> textFields, Collection<String> vectorFields) throws IOException {

@@ -58,6 +58,7 @@ final class NrtGpu {
       h("nrtgpu_segment_add_vectors", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
   static final MethodHandle SEAL = h("nrtgpu_segment_seal", FunctionDescriptor.of(JAVA_INT, ADDRESS));
   static final MethodHandle SET_LIVE = h("nrtgpu_segment_set_live_docs", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT));
+  static final MethodHandle FORK = h("nrtgpu_segment_fork", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
   static final MethodHandle SET_MASK = h("nrtgpu_segment_set_mask", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT));
   static final MethodHandle RELEASE = h("nrtgpu_segment_release", FunctionDescriptor.ofVoid(ADDRESS));
   static final MethodHandle SUPPORTED = h("nrtgpu_query_supported", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));

@@ -286,6 +286,19 @@ class GpuSegment:
         bits = np.ascontiguousarray(bits, dtype=np.uint64)
         _lib.check(_lib.load().nrtgpu_segment_set_live_docs(self._h, bits.ctypes.data, len(bits)))
 
+    def fork(self, live_bits: Optional[np.ndarray]) -> "GpuSegment":
+        """A new reader version of this sealed segment: shares its data, carries its own liveDocs (nrtgpu_segment_fork)."""
+        g = GpuSegment.__new__(GpuSegment)
+        g.ctx, g.max_doc, g.doc_base = self.ctx, self.max_doc, self.doc_base
+        h = C.c_void_p()
+        if live_bits is None:
+            _lib.check(_lib.load().nrtgpu_segment_fork(self._h, None, 0, C.byref(h)))
+        else:
+            live_bits = np.ascontiguousarray(live_bits, dtype=np.uint64)
+            _lib.check(_lib.load().nrtgpu_segment_fork(self._h, live_bits.ctypes.data, len(live_bits), C.byref(h)))
+        g._h = h
+        return g
+
     def set_mask(self, mask_id: int, bits: Optional[np.ndarray]) -> None:
         """Doc set of a non-scoring clause (uint64 words, bit d = doc d matches); None drops it."""
         if bits is None:

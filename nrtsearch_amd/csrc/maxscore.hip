@@ -182,8 +182,8 @@ __device__ __forceinline__ bool ms_reserve(MsSmem& s, uint32_t lane, uint32_t mi
 
 // PROF: per-item event counters (nrtgpu_get_scan_profile): [0] windows, [1] compactions, [2] posting chunks,
 // [3] postings streamed, [4] postings surviving the bound, [5] docs evaluated, [6] lookups, [7] candidates.
-// PACKED: the segments keep one 32-bit word per posting (plan.h: kPack*); liveDocs are then a mask (part.live_bits)
-// tested when a doc's score is complete.
+// PACKED: the segments keep one 32-bit word per posting (plan.h: kPack*).  liveDocs that are not folded into the
+// postings (part.live_bits != nullptr) are tested when a doc's score is complete.
 template <bool PROF, bool PACKED>
 __global__ __launch_bounds__(kMsThreads)
 void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts, const DTerm* __restrict__ terms,
@@ -587,7 +587,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             }
           const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
           bool want = low != 0u && key > theta_now && key < after_key;
-          if (PACKED && part.live_bits != nullptr && want)   // deletes are not folded into packed postings: a deleted doc is no hit
+          if (part.live_bits != nullptr && want)   // liveDocs that are not folded into the postings (packed layout, forked reader versions): a deleted doc is no hit
             want = (((const NRT_GLOBAL uint64_t*)part.live_bits)[dsel >> 6] >> (dsel & 63u)) & 1ull;
           uint32_t pos = 0;
           if (!__any(want)) {

@@ -253,11 +253,11 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
   std::vector<int32_t> tab_of_term, term_scale;
   std::vector<const TermLeaves*> ents;
   std::vector<int64_t> slice_sum((size_t)std::max(n_slices, 1));
-  bool any_deleted = false, plain = true;
+  bool any_deleted = false;
   for (int si = 0; si < n_segs; ++si) {
     any_deleted = any_deleted || n_deleted[si] != 0;
-    // (packed postings never fold liveDocs: the MaxScore kernel tests the mask when a doc's score is complete)
-    plain = plain && (segs[si]->d_live == nullptr || segs[si]->live_folded || (segs[si]->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0);
+    // (liveDocs that are not folded into the postings -- packed layout, forked reader versions, NRTGPU_FLAG_NO_LIVE_FOLD --
+    //  are a mask the MaxScore kernel tests when a doc's score is complete: no obstacle to the route)
   }
   size_t prev_cache_off = 0, prev_cache_len = 0;
   pc.qterms.reserve((size_t)(q_end - q_begin) * 6);
@@ -308,12 +308,12 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     // MaxScore route (maxscore.hip)?  Its hit count is a lower bound, so -- like Lucene, which starts skipping only
     // once totalHits has passed the threshold (LazyQueueTopScoreDocCollector.java:176-199) -- it is taken only when
     // more than max(totalHitsThreshold, numHits) live docs certainly match: some clause has that many postings left
-    // after discounting every deleted doc of its segments.  Needs the exact fixed-point sums, plain liveDocs
-    // (folded into the columns) and a plain disjunction.
+    // after discounting every deleted doc of its segments.  Needs the exact fixed-point sums and a plain disjunction
+    // (liveDocs are folded into the postings or tested as a mask by the kernel).
     int64_t lower = 0;
     if (prune != 0 && !(prune == 2 && q.has_after) && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.disjunction_max == 0 && q.filter_mask == 0 && q.must_not_mask == 0 &&
         !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
-      if (plain) {
+      {
         // the reference counts per slice (one collector each): some slice must certainly pass the threshold
         const int64_t floor_ = std::max<int64_t>(q.total_hits_threshold, q.k);
         int64_t best_slice = 0;

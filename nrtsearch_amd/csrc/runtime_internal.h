@@ -230,16 +230,31 @@ using namespace nrtgpu;      // (internal header: every translation unit of the 
 using namespace nrtgpu::rt;
 
 struct nrtgpu_ctx;
+// The immutable part of a segment -- posting columns, norms, vectors, the seal-time structures -- shared by the handles
+// of its reader versions (nrtgpu_segment_fork): freed with the last of them.
+struct SegCore {
+  int device = 0;
+  std::map<int32_t, FieldData> fields;
+  // the liveDocs folded into the posting columns (apply_live_kernel), if any: once a core is shared nobody folds again,
+  // and every handle's liveDocs must be a subset of these (Lucene's deletes only accumulate)
+  std::vector<uint64_t> folded_live;
+  bool folded = false;
+  ~SegCore();
+};
 struct nrtgpu_seg {
   nrtgpu_ctx* ctx = nullptr;
-  uint64_t uid = 0;              // unique over the process (never reused, unlike the handle's address): keys the planner's caches
+  uint64_t uid = 0;              // unique over the process (never reused, unlike the handle's address): keys the planner's caches;
+                                 // the forks of a segment share it (and with it the resident term tables)
   int32_t max_doc = 0;
   uint32_t n_tiles = 0;
   bool sealed = false;
-  std::map<int32_t, FieldData> fields;
+  std::shared_ptr<SegCore> core;
+  std::map<int32_t, FieldData>& fields;   // == core->fields
+  nrtgpu_seg() : core(std::make_shared<SegCore>()), fields(core->fields) {}
+  explicit nrtgpu_seg(std::shared_ptr<SegCore> c) : core(std::move(c)), fields(core->fields) {}
   uint64_t* d_live = nullptr;
   int32_t n_deleted = 0;         // docs cleared in liveDocs (host pop-count at set_live_docs)
-  uint64_t live_version = 1;     // bumped by every set_live_docs
+  uint64_t live_version = 1;     // a fresh process-wide number at every set_live_docs / fork (keys per-liveDocs caches in the shared core)
   int64_t device_bytes = 0;
   // FILTER / MUST_NOT clauses as doc-set masks: host copies of the registered masks and of liveDocs,
   // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use

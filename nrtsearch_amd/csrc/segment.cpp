@@ -38,6 +38,7 @@ extern "C" int nrtgpu_segment_begin(nrtgpu_ctx* ctx, int32_t max_doc, int32_t /*
   static std::atomic<uint64_t> next_uid{1};
   auto* seg = new nrtgpu_seg();
   seg->ctx = ctx;
+  seg->core->device = ctx->device;
   seg->uid = next_uid.fetch_add(1, std::memory_order_relaxed);
   seg->max_doc = max_doc;
   seg->n_tiles = (uint32_t)(((int64_t)max_doc + kTileDocs - 1) / kTileDocs);
@@ -349,12 +350,15 @@ static int fold_live_docs(nrtgpu_seg* seg) {
   seg->live_folded = false;
   if (seg->ctx->cfg.flags & (NRTGPU_FLAG_NO_LIVE_FOLD | NRTGPU_FLAG_PACKED_POSTINGS)) return NRTGPU_OK;   // (a packed word has no spare bit)
   if (!seg->sealed) return NRTGPU_OK;  // seal folds
+  if (seg->core.use_count() > 1) return NRTGPU_OK;  // the columns belong to several reader versions: this one's deletes stay a mask
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
       launch_apply_live(nullptr, g.d_docids, g.d_fnorm, g.n_postings, seg->d_live);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   seg->live_folded = seg->d_live != nullptr;
+  seg->core->folded = seg->live_folded;
+  seg->core->folded_live = seg->live_folded ? seg->h_live : std::vector<uint64_t>();
   return NRTGPU_OK;
 }
 
@@ -363,8 +367,21 @@ extern "C" int nrtgpu_segment_set_live_docs(nrtgpu_seg* seg, const uint64_t* bit
   SegWriteLock content(seg);  // waits for the searches running over this segment; later ones wait for it
   HIP_TRY(hipSetDevice(seg->ctx->device));
   const int32_t need = (seg->max_doc + 63) / 64;
+  if (bits && n_words < need) return fail(NRTGPU_ERR_INVALID_ARG, "live bits: %d words given, %d needed", n_words, need);
+  if (seg->core.use_count() > 1 && seg->core->folded) {
+    // the shared posting columns carry another reader version's deletes: this version may only have MORE of them
+    for (int32_t i = 0; i < need; ++i) {
+      const uint64_t want = bits ? bits[i] : ~0ull;
+      uint64_t extra = want & ~seg->core->folded_live[(size_t)i];
+      if (i == need - 1 && (seg->max_doc & 63)) extra &= (1ull << (seg->max_doc & 63)) - 1ull;
+      if (extra)
+        return fail(NRTGPU_ERR_UNSUPPORTED, "liveDocs of a forked segment may only lose docs (doc %d is deleted in the shared columns)",
+                    i * 64 + __builtin_ctzll(extra));
+    }
+  }
+  static std::atomic<uint64_t> next_live_version{2};
   drop_accept_sets(seg);
-  seg->live_version++;
+  seg->live_version = next_live_version.fetch_add(1, std::memory_order_relaxed);
   if (!bits) {
     if (seg->d_live) (void)hipFree(seg->d_live);
     seg->d_live = nullptr;
@@ -482,11 +499,9 @@ int64_t nrtgpu::rt::live_vector_count(const nrtgpu_seg* seg, const FieldData& f)
   return n;
 }
 
-extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
-  if (!seg) return;
-  (void)hipSetDevice(seg->ctx->device);
-  drop_accept_sets(seg);
-  for (auto& kv : seg->fields) {
+SegCore::~SegCore() {
+  (void)hipSetDevice(device);
+  for (auto& kv : fields) {
     FieldData& f = kv.second;
     if (f.d_norms) (void)hipFree(f.d_norms);
     if (f.d_vectors) (void)hipFree(f.d_vectors);
@@ -501,8 +516,33 @@ extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
       if (g.d_bits) (void)hipFree(g.d_bits);
     }
   }
+}
+
+extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
+  if (!seg) return;
+  (void)hipSetDevice(seg->ctx->device);
+  drop_accept_sets(seg);
   if (seg->d_live) (void)hipFree(seg->d_live);
-  delete seg;
+  delete seg;   // (the shared core -- columns, norms, vectors -- goes with its last handle)
+}
+
+// A new reader version of a sealed segment: same immutable data (shared, not copied), its own liveDocs / masks.  Searches
+// over the previous handle keep seeing the previous liveDocs -- the point-in-time view an IndexSearcher has in Lucene.
+extern "C" int nrtgpu_segment_fork(nrtgpu_seg* seg, const uint64_t* live_bits, int32_t n_words, nrtgpu_seg** out) {
+  if (!seg || !out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (!seg->sealed) return fail(NRTGPU_ERR_STATE, "segment is not sealed");
+  auto* f = new nrtgpu_seg(seg->core);
+  f->ctx = seg->ctx;
+  f->uid = seg->uid;
+  f->max_doc = seg->max_doc;
+  f->n_tiles = seg->n_tiles;
+  f->sealed = true;
+  if (int rc = nrtgpu_segment_set_live_docs(f, live_bits, n_words)) {
+    nrtgpu_segment_release(f);
+    return rc;
+  }
+  *out = f;
+  return NRTGPU_OK;
 }
 
 extern "C" int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg) { return seg ? seg->device_bytes : 0; }

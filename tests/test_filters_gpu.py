@@ -360,3 +360,50 @@ def test_live_docs_change_while_searching(ctx):
         assert (1000 < got.total_hits <= exp[0][2]) if exp[0][3] else got.total_hits == exp[0][2]
     finally:
         ix.close()
+
+
+def test_forked_reader_versions_are_point_in_time(ctx):
+    """nrtgpu_segment_fork: a refresh that only changed liveDocs gets new handles that SHARE the postings; searches over
+    the previous handles keep the previous liveDocs (Lucene's point-in-time IndexSearcher) while the new ones see the new
+    deletes -- both bit-exact against the oracle, on the MaxScore route and on the exhaustive scan."""
+    import copy
+
+    ranks = [1, 2, 3, 9, 40, 300, 2500]
+    v1 = synth.build_corpus(400_000, ranks, n_segments=3, delete_fraction=0.01)     # reader version 1: 1 % deleted
+    v2 = copy.deepcopy(v1)                                                           # version 2: more deletes on top
+    rng = np.random.Generator(np.random.PCG64(77))
+    for seg in v2.segments:
+        more = rng.random(seg.max_doc) < 0.05
+        words = seg.live_bits.copy()
+        idx = np.nonzero(more)[0]
+        np.bitwise_and.at(words, idx // 64, ~(np.uint64(1) << (idx % 64).astype(np.uint64)))
+        seg.live_bits = words
+    ix1 = Index(ctx, v1)
+    forks = [leaf.fork(seg.live_bits) for leaf, seg in zip(ix1.leaves, v2.segments)]
+    sr2 = api.GpuIndexSearcher(ctx, forks, api.IndexStatistics.from_corpus(v2))
+    try:
+        assert sum(f.device_bytes for f in forks) < 0.05 * sum(l.device_bytes for l in ix1.leaves)   # only the bit sets are new
+        for terms in ([1, 3, 40, 300, 2500], [2, 9], [2500]):
+            for k, thr in ((1000, 1000), (50, 2**31 - 1)):
+                mgr = api.TopScoreDocCollectorManager(k, None, thr)
+                assert_same(f"fork_v1_{terms[0]}_{k}", ix1.searcher.search(bq_(terms), mgr), oracle.search_bm25(v1, terms, k, total_hits_threshold=thr), k, thr)
+                assert_same(f"fork_v2_{terms[0]}_{k}", sr2.search(bq_(terms), mgr), oracle.search_bm25(v2, terms, k, total_hits_threshold=thr), k, thr)
+        # a version may not resurrect a doc the shared postings already carry as deleted
+        all_live = np.full(len(v1.segments[0].live_bits), np.uint64(0xFFFFFFFFFFFFFFFF))
+        with pytest.raises(_lib.NrtGpuError) as e:
+            ix1.leaves[0].fork(all_live)
+        assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
+        # the old reader closes: the forks keep the data alive
+        ix1.close()
+        got = sr2.search(bq_([1, 3, 40, 300, 2500]), api.TopScoreDocCollectorManager(100))
+        assert_same("fork_after_release", got, oracle.search_bm25(v2, [1, 3, 40, 300, 2500], 100), 100, 1000)
+    finally:
+        for f in forks:
+            f.release()
+        ix1.close()
+
+
+def bq_(terms):
+    from tests.test_parity_gpu import bq
+
+    return bq(terms)
