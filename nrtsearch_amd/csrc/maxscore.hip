@@ -587,8 +587,11 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             }
           const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
           bool want = low != 0u && key > theta_now && key < after_key;
-          if (part.live_bits != nullptr && want)   // liveDocs that are not folded into the postings (packed layout, forked reader versions): a deleted doc is no hit
-            want = (((const NRT_GLOBAL uint64_t*)part.live_bits)[dsel >> 6] >> (dsel & 63u)) & 1ull;
+          if (part.live_bits != nullptr) {   // (uniform) liveDocs that are not folded into the postings -- packed layout, forked
+            // reader versions: a deleted doc is no hit.  32-bit words: one dword gather per competitive doc
+            const uint32_t lw = ((const NRT_GLOBAL uint32_t*)part.live_bits)[want ? (dsel >> 5) : 0u];
+            want = want && ((lw >> (dsel & 31u)) & 1u) != 0u;
+          }
           uint32_t pos = 0;
           if (!__any(want)) {
             maybe &= ~low;
