@@ -52,7 +52,11 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       GpuEligibility.Plan plan = GpuEligibility.marshal(a, this, store, clauses, msm[0], msm[1], rc.getNumHitsToCollect(),
           rc.getTotalHitsThreshold(), rc.getSearchAfter());
       if (plan == null) return super.search(query, manager);
-      int status = (int) NrtGpu.SEARCH1.invokeExact(ctx, segs, bases, leaves.size(), plan.query(), plan.out());   // blocks; batched inside
+      int status;
+      if (msm[0] > 1 || msm[1] != 0)   // clause counts / best-clause scores depend on the whole batch's accumulator mode: a batch of one
+        status = (int) NrtGpu.SEARCH_BATCH.invokeExact(ctx, segs, bases, leaves.size(), plan.query(), 1, plan.out());
+      else
+        status = (int) NrtGpu.SEARCH1.invokeExact(ctx, segs, bases, leaves.size(), plan.query(), plan.out());   // blocks; batched inside
       if (status == NrtGpu.ERR_UNSUPPORTED) return super.search(query, manager);
       NrtGpu.check(status);
       return (T) new SearcherResult(plan.toTopDocs(), Map.of());       // search/SearcherResult.java:31-34
