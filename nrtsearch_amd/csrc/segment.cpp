@@ -274,16 +274,28 @@ static int pack_group(nrtgpu_seg* seg, TermGroup& g) {
   void* p = nullptr;
   if (int rc = dev_alloc(seg, &p, list_words * 4 + 64)) return rc;
   uint32_t* d_list = (uint32_t*)p;
-  if (int rc = dev_alloc(seg, &p, col_bytes)) return rc;
+  if (int rc = dev_alloc(seg, &p, col_bytes)) {
+    (void)hipFree(d_list);
+    seg->device_bytes -= (int64_t)(list_words * 4 + 64);
+    return rc;
+  }
   uint32_t* d_packed = (uint32_t*)p;
   const uint32_t header[4] = {n_blocks, n_exc, 0u, 0u};
-  HIP_TRY(hipMemset(d_packed, 0, col_bytes));
-  HIP_TRY(hipMemset(d_list, 0, list_words * 4 + 64));
-  HIP_TRY(hipMemcpy(d_list, header, sizeof(header), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_list + 4, dir.data(), dir.size() * 4, hipMemcpyHostToDevice));
-  launch_pack_write(nullptr, g.d_docids, g.d_fnorm, n, n_blocks, d_list + 4, d_list + 4 + n_blocks + 1, d_packed);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
+  hipError_t e = hipMemset(d_packed, 0, col_bytes);
+  if (e == hipSuccess) e = hipMemset(d_list, 0, list_words * 4 + 64);
+  if (e == hipSuccess) e = hipMemcpy(d_list, header, sizeof(header), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_list + 4, dir.data(), dir.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_pack_write(nullptr, g.d_docids, g.d_fnorm, n, n_blocks, d_list + 4, d_list + 4 + n_blocks + 1, d_packed);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {  // the two-column form stays in place (and is freed with the segment)
+    (void)hipFree(d_packed);
+    (void)hipFree(d_list);
+    seg->device_bytes -= (int64_t)(col_bytes + list_words * 4 + 64);
+    return fail(NRTGPU_ERR_HIP, "packing the postings failed: %s", hipGetErrorString(e));
+  }
   (void)hipFree(g.d_docids);   // [docid column | code column]: one allocation
   seg->device_bytes -= (int64_t)(2 * col_bytes);
   g.d_docids = d_packed;
