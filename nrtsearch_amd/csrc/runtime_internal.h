@@ -306,6 +306,7 @@ namespace rt {
 struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipEvent_t ev_turn = nullptr;   // recorded behind this call's whole-GPU kernels (nrtgpu_ctx::last_turn)
   PinBuf h_plan;     // host staging of the plan blob
   DevBuf d_plan;     // device copy
   DevBuf d_work;     // theta + item outputs + merge outputs
@@ -360,6 +361,7 @@ struct nrtgpu_ctx {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<std::unique_ptr<Slot>> slots;
+  hipEvent_t last_turn = nullptr;   // (under gpu_mu) recorded behind the whole-GPU kernels enqueued last: the next ones wait for it ON THE DEVICE
   std::mutex gpu_mu;    // device execution of one batch at a time: a scan kernel wants the whole GPU,
                         // overlapping two only stretches both (host-side planning/unpacking still overlap)
   std::mutex stats_mu;

@@ -15,8 +15,12 @@ struct DeviceRun {
 
 // Enqueue plan upload + scan + merge on the slot's stream.  Merge output goes to (ext_keys,
 // ext_counts, ext_hits) when given (device-resident variant), else into the slot's scratch.
-// `gpu` (unlocked on entry) is taken only once the plan has reached the device: the upload of this
-// batch overlaps the kernels of the batch another host thread has in flight.
+// Everything is enqueued at once on the slot's stream and nothing waits on the host.  The kernels that want the whole
+// GPU (the two scorers) take turns ON THE DEVICE: under `gpu` (unlocked on entry and on return) the stream is made to
+// wait for the event recorded behind the previous batch's scorers, then this batch's are enqueued and their event
+// recorded behind their merge.  The plan upload and its expansion run ahead of that wait: they overlap the scorers of the
+// batch before instead of sitting between the two (before: lock -> launch -> host sync -> unlock, a host round trip plus
+// upload and expansion between any two scorer launches).
 static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
                           uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
                           std::unique_lock<std::mutex>& gpu, int64_t epoch = -1) {
@@ -91,14 +95,14 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
 
   hipStream_t st = slot->stream;
   HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  gpu.lock();
   const bool timing = ctx->cfg.collect_timing != 0;
   // the queries on the MaxScore route (items [0, n_ms)), then the exhaustive scan of the others
   const size_t n_ms = hp.n_ms_items;
   // the compact plan -> the DTerm records of every (query, leaf), on the device
   launch_expand_terms(st, (const DQExpand*)(db + o_qexp), (const DQTerm*)(db + o_qterms), (const uint32_t*)(db + o_qsb),
                       (uint32_t)n_queries, hp.n_leaves, (DTerm*)(wb + o_terms));
+  gpu.lock();
+  if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
   launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                        (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
@@ -126,6 +130,11 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                         (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
   if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
+  // (the merge belongs to the turn: behind the next batch's scorers it would wait for a free CU until they drain, and this
+  //  batch's caller with it)
+  HIP_TRY(hipEventRecord(slot->ev_turn, st));
+  ctx->last_turn = slot->ev_turn;
+  gpu.unlock();
   HIP_TRY(hipGetLastError());
   run->out_keys = okeys;
   run->out_counts = ocnt;
@@ -219,10 +228,9 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
-    HIP_TRY(hipStreamSynchronize(slot->stream));  // kernels done: the next batch may have the device ...
   }
+  HIP_TRY(hipStreamSynchronize(slot->stream));
   const double tc1 = call_trace ? now_ms() : 0.0;
-  // ... while this one's results travel to the host
   HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
   HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
   HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));

@@ -34,6 +34,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
   std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
   hipStream_t st = slot->stream;
+  if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));   // behind the scorers enqueued last (search.cpp: enqueue_search)
   const bool timing = ctx->cfg.collect_timing != 0;
   Carver wc;
   const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_th = wc.take(kKnnMaxQ * 8);
@@ -217,6 +218,7 @@ extern "C" int nrtgpu_rescore_vectors(nrtgpu_ctx* ctx, const nrtgpu_seg* const* 
   acquire_slot(ctx, &slot);
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
   std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+  if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(slot->stream, ctx->last_turn, 0));
   hipStream_t st = slot->stream;
   Carver wc;
   const size_t o_q = wc.take((size_t)dim * 4), o_rows = wc.take((size_t)n * 8 + 8), o_first = wc.take((size_t)n * 4 + 4),
