@@ -200,6 +200,8 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   const int fx_E = item.fx_E;
   unsigned long long* const my_theta_g = theta_g + item.query;
   const bool multi_item = q.n_items > 1;
+  // EXACT (planner: a small query whose count matters): no bound ever skips anything -- theta only filters the candidates
+  const bool exact = (item.flags & 1u) != 0u;
   const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
 
   // ---- item prologue: normInverse tables, score tables
@@ -329,7 +331,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       // instruction instead of taking one each.  Clause c's groups come before clause c + 1's.
       uint32_t ng = 0;
       {
-        const uint64_t thr_w = max(s.thr, thr_other);
+        const uint64_t thr_w = exact ? 0ull : max(s.thr, thr_other);
         const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
         if (lane < n_terms) {
           if (my_suf >= thr_w && pe > pb) ng = (uint32_t)((pe - (pb & ~3ull) + 7ull) >> 3);
@@ -355,7 +357,8 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         // theta as of now (it only grows: a stale value costs work, never a result).  Has it passed what this
         // instruction's first clause and everything after it can reach?  Then the rest of the window is non-essential.
         const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
-        if (readlane_u64(my_suf, c_first) < thr) break;
+        const uint64_t thr_p = exact ? 0ull : thr;   // what the bounds are compared with
+        if (readlane_u64(my_suf, c_first) < thr_p) break;
         if (PROF) pc_chunks += 1;
         // what my clause is: column bases, posting range, score table, scale, what the later clauses can still add
         const uint32_t rec = wcl_addr + c * (uint32_t)sizeof(WClause);
@@ -434,7 +437,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             run[j] = (uint64_t)val[j] * (uint64_t)mult;
-            if (((vmask >> j) & 1u) && val[j] != 0u && run[j] + u_after >= thr) alive |= 1u << j;
+            if (((vmask >> j) & 1u) && val[j] != 0u && run[j] + u_after >= thr_p) alive |= 1u << j;
           }
         }
         if (PROF) {
@@ -474,7 +477,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           uint32_t am = c < j2 ? alive : 0u;
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (((am >> j) & 1u) && run[j] + S_j < thr) {
+            if (((am >> j) & 1u) && run[j] + S_j < thr_p) {
               alive &= ~(1u << j);
               am &= ~(1u << j);
             }
@@ -658,7 +661,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   if (tid == 0) {
     item_counts[blockIdx.x] = n;
     // anything skipped?  Only a theta can skip; with none the walk evaluated every live matching doc exactly once.
-    const bool pruned = s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+    const bool pruned = !exact && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
     item_hits[blockIdx.x] = (uint64_t)s.hits + (pruned ? kHitsPrunedUnit : 0ull);
     if (PROF && item_prof) {
       s.prof[5] = s.hits;

@@ -124,6 +124,11 @@ constexpr int kMsThreads = kMsWaves * 64;
 constexpr int kMsWinTiles = NRT_MS_WIN_TILES;
 constexpr int kMsWinDocs = kMsWinTiles * kTileDocs;
 constexpr int kMsMaxTerms = 8;      // clauses of a query on the MaxScore route (longer disjunctions are scanned exhaustively)
+// A query whose hit count is not certain to pass the threshold (or that wants the exact count: ScoreMode.COMPLETE) may still
+// run in the MaxScore kernel when it is SMALL (<= this many postings over all clauses and leaves): in EXACT mode the kernel
+// skips nothing, so every matching doc is evaluated once and counted -- the exhaustive scan's answer, without walking every
+// 1024-doc sub-tile of the shard for a handful of postings.
+constexpr int64_t kMsExactMaxPostings = 1 << 18;
 constexpr int kMsCandCap = kMsWinTiles > 32 ? 2304 : 3072;  // LDS candidate slots (>= kMaxK + 512: a wave's retry always fits)
 // item_hits of a MaxScore item: the docs it evaluated, plus kHitsPrunedUnit when it skipped anything (the count is
 // then a lower bound).  The merge kernel's plain sum keeps both: low 48 bits = docs, high 16 = pruned items.
@@ -157,7 +162,7 @@ struct alignas(16) DItem {
   int32_t  tab_scale[kTabTerms];  // fixed-point batches: fx_scale of each score table's term
   int32_t  fx_E;                  // fixed-point batches: accumulators hold score * 2^fx_E
   uint32_t peer_slot;             // this item's slot among the query's items [DQuery.item_begin, + n_items)
-  uint32_t pad1;
+  uint32_t flags;                 // bit 0 (MaxScore kernel): EXACT -- nothing is skipped, every matching live doc is evaluated and counted
 };
 static_assert(sizeof(DItem) == 96, "DItem layout");
 

@@ -248,14 +248,15 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
                             const int32_t* slice_of_leaf, int32_t n_slices, const nrtgpu_bm25_query* queries, int q_begin, int q_end, PlanPiece& pc, uint32_t* q_qs_begin,
                             uint32_t* q_qs_cnt, uint32_t* qs_begin, DQExpand* qexpand,
                             std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, int prune,
-                            std::vector<int64_t>& q_lower) {
+                            std::vector<int64_t>& q_lower, std::vector<uint8_t>& q_exact) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
   std::vector<const TermLeaves*> ents;
   std::vector<int64_t> slice_sum((size_t)std::max(n_slices, 1));
-  bool any_deleted = false;
+  bool any_deleted = false, folded = true;   // folded: every leaf's deletes (if any) are coded into its posting columns
   for (int si = 0; si < n_segs; ++si) {
     any_deleted = any_deleted || n_deleted[si] != 0;
+    folded = folded && (segs[si]->d_live == nullptr || segs[si]->live_folded);
     // (liveDocs that are not folded into the postings -- packed layout, forked reader versions, NRTGPU_FLAG_NO_LIVE_FOLD --
     //  are a mask the MaxScore kernel tests when a doc's score is complete: no obstacle to the route)
   }
@@ -342,6 +343,18 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
       }
     }
     q_lower[(size_t)qi] = lower;
+    // Not certain to pass the threshold (or the exact count is wanted: COMPLETE), but SMALL: the MaxScore kernel in EXACT mode
+    // -- nothing skipped, every matching doc evaluated and counted -- answers like the exhaustive scan without walking every
+    // sub-tile of the shard for a handful of postings.  (Deletes must be folded into the postings: the count is taken
+    // before a mask would be consulted.)
+    bool exact = false;
+    if (lower == 0 && prune != 0 && !(prune == 2 && q.has_after) && fx_ok && folded && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 &&
+        q.disjunction_max == 0 && q.filter_mask == 0 && q.must_not_mask == 0 && !(q.min_competitive_score > 0.0f)) {
+      int64_t all = 0;
+      for (int t = 0; t < q.n_terms; ++t) all += term_total[(size_t)t];
+      exact = all > 0 && all <= kMsExactMaxPostings;
+    }
+    q_exact[(size_t)qi] = exact ? 1 : 0;
     tab_of_term.assign((size_t)q.n_terms, -1);
     QTabs& qt_ = qtabs[(size_t)qi];
     qt_.n = 0;
@@ -360,7 +373,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     // the compact plan of the query: one DQTerm per clause that matches anything, and per leaf how many of them it holds
     DQExpand& qx = qexpand[(size_t)qi];
     qx.term_begin = (uint32_t)pc.qterms.size();
-    qx.by_weight = lower > 0 ? 1u : 0u;
+    qx.by_weight = (lower > 0 || exact) ? 1u : 0u;
     qx.pad = 0;
     const uint32_t* cnt_of[kMaxTerms];
     uint32_t n_live = 0;
@@ -435,6 +448,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     if ((ctx->cfg.flags & (NRTGPU_FLAG_NO_PRUNE | NRTGPU_FLAG_NO_FIXED_POINT)) != 0 || !(variant == 0 || variant == 7)) prune = 0;
   }
   hp.q_lower.assign((size_t)n_queries, 0);
+  hp.q_exact.assign((size_t)n_queries, 0);
   hp.lsc = leaf_set_cache(ctx, segs, n_segs);
   hp.n_leaves = (uint32_t)n_segs;
   hp.qexpand.resize((size_t)n_queries);
@@ -461,7 +475,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   }
   auto work = [&](int t) {
     resolve_queries(*hp.lsc, segs, n_segs, n_deleted.data(), slice_of_leaf.data(), n_slices, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t],
-                    q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower);
+                    q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower, hp.q_exact);
   };
   ctx->pool->run(n_thr, work);
   const double tp1 = plan_trace ? now_ms() : 0.0;
@@ -501,7 +515,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   for (int qi = 0; qi < n_queries && hp.fixed_point; ++qi)
     if (q_qs_cnt[(size_t)qi] != 0 && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
   for (int qi = 0; qi < n_queries; ++qi)
-    if (hp.q_lower[(size_t)qi] > 0)
+    if (hp.q_lower[(size_t)qi] > 0 || hp.q_exact[(size_t)qi])
       for (uint32_t j = 0; j < q_qs_cnt[(size_t)qi]; ++j) hp.ms_postings += qs_of(qi)[j].postings;
   // minimumNumberShouldMatch > 1 (QueryNodeMapper.java:259-261): the clause count rides in the fixed-point
   // accumulator, so the whole batch must be in fixed-point mode; otherwise the caller runs Lucene's WANDScorer
@@ -640,9 +654,10 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
   std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.cost > b.cost; });
   // the items of the queries on the MaxScore route first: they run in a launch of their own
-  std::stable_partition(pend.begin(), pend.end(), [&](const Pending& a) { return hp.q_lower[a.query] > 0; });
+  auto on_ms_kernel = [&](uint32_t q_) { return hp.q_lower[q_] > 0 || hp.q_exact[q_] != 0; };
+  std::stable_partition(pend.begin(), pend.end(), [&](const Pending& a) { return on_ms_kernel(a.query); });
   hp.n_ms_items = 0;
-  for (const Pending& a : pend) hp.n_ms_items += hp.q_lower[a.query] > 0 ? 1u : 0u;
+  for (const Pending& a : pend) hp.n_ms_items += on_ms_kernel(a.query) ? 1u : 0u;
   hp.items.resize(pend.size());
   hp.item_slice.resize(pend.size());
   for (size_t i = 0; i < pend.size(); ++i) hp.item_slice[i] = hp.q_lower[pend[i].query] > 0 ? kAnySlice : pend[i].slice;
@@ -676,6 +691,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       it.tab_scale[r] = qt_.scale[r];
     }
     it.peer_slot = hp.q_base[pend[i].query] + q_fill[pend[i].query]++;
+    it.flags = hp.q_exact[pend[i].query] ? 1u : 0u;
     hp.items[i] = it;
     hp.list_idx[it.peer_slot] = (uint32_t)i;
   }

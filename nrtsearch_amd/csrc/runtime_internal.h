@@ -493,6 +493,7 @@ struct HostPlan {
   // MaxScore route (maxscore.hip): items [0, n_ms_items) run it, the others the exhaustive scan
   uint32_t n_ms_items = 0;
   std::vector<int64_t> q_lower;     // per query on that route: live docs certain to match (> totalHitsThreshold), else 0
+  std::vector<uint8_t> q_exact;     // per query: runs in the MaxScore kernel in EXACT mode (small; counted like an exhaustive scan)
   std::vector<uint32_t> item_slice; // per item: the slice (MyIndexSearcher.slices) its parts belong to; ~0: several (no relation from it)
   std::vector<uint32_t> q_gte_floor;  // per query: max(totalHitsThreshold, numHits), what a slice's hits must exceed for GTE
   int64_t ms_postings = 0;          // postings of the queries on that route (algorithmic work, as `postings`)

@@ -113,20 +113,42 @@ def test_boosts_and_paging(ctxs, mid, oracle):
 def test_route_is_taken_only_when_the_count_certainly_passes_the_threshold(ctxs, mid, oracle):
     pruned, _ = mid
     ctx = ctxs[0]
-    # rank 9999: ~30 postings in 300k docs -- never more than the threshold: exhaustive, exact count
+    # rank 9999: ~30 postings in 300k docs -- never more than the threshold: nothing may be skipped, the count is exact.
+    # A query this small runs in the MaxScore kernel in EXACT mode (no bound skips anything) instead of an exhaustive scan
     ctx.reset_stats()
     got = pruned.searcher.search(bq([9999, 5000]), api.TopScoreDocCollectorManager(10))
     exp = oracle.search_bm25(pruned.corpus, [9999, 5000], 10, total_hits_threshold=1000)
-    assert ctx.stats()["maxscore_items"] == 0 and got.total_hits == exp[2] and not got.relation_gte
-    # ScoreMode.COMPLETE (threshold INT_MAX): exhaustive, exact count
+    st = ctx.stats()
+    folds = not (ctx.flags & _lib.NRTGPU_FLAG_PACKED_POSTINGS)   # (EXACT mode counts before a liveDocs mask would be consulted: it needs
+    assert (st["maxscore_items"] > 0 and st["scan_items"] == 0) or not folds   # the deletes folded into the postings; packed postings never fold)
+    check("exact_small", got, exp, 10, 1000)
+    assert got.total_hits == exp[2] and not got.relation_gte
+    # ScoreMode.COMPLETE (threshold INT_MAX) on a small query: the same, with a dense-ish clause (153 k postings)
     ctx.reset_stats()
     got = pruned.searcher.search(bq([1, 100]), api.TopScoreDocCollectorManager(10, total_hits_threshold=INT_MAX))
     exp = oracle.search_bm25(pruned.corpus, [1, 100], 10, total_hits_threshold=INT_MAX)
+    st = ctx.stats()
+    assert (st["maxscore_items"] > 0 and st["scan_items"] == 0) or not folds
+    check("exact_complete", got, exp, 10, INT_MAX)
+    assert got.total_hits == exp[2] and not got.relation_gte
+    # ScoreMode.COMPLETE on a big query (> 2^18 postings): exhaustive scan, exact count
+    ctx.reset_stats()
+    got = pruned.searcher.search(bq([1, 2, 3]), api.TopScoreDocCollectorManager(10, total_hits_threshold=INT_MAX))
+    exp = oracle.search_bm25(pruned.corpus, [1, 2, 3], 10, total_hits_threshold=INT_MAX)
     assert ctx.stats()["maxscore_items"] == 0 and got.total_hits == exp[2] and not got.relation_gte
-    # a dense clause: certainly more than 1000 live matches
+    # a dense clause: certainly more than 1000 live matches -- pruned, a lower bound is reported
     ctx.reset_stats()
     got = pruned.searcher.search(bq([1, 100]), api.TopScoreDocCollectorManager(10))
     assert ctx.stats()["maxscore_items"] > 0 and got.relation_gte and got.total_hits > 1000
+    # exact mode over many numHits / thresholds / paging, against the oracle and the exhaustive context
+    for terms in ([9999], [5000, 9999], [333, 1000, 5000], [100, 333], [1000, 1000, 9999]):
+        for k, thr in ((1, 1000), (10, 10), (1000, 1000), (1000, INT_MAX), (64, 0)):
+            got = pruned.searcher.search(bq(terms), api.TopScoreDocCollectorManager(k, None, thr))
+            check(f"exact_{terms[0]}_{len(terms)}_{k}_{thr}", got, oracle.search_bm25(pruned.corpus, terms, k, total_hits_threshold=thr), k, thr)
+    first = pruned.searcher.search(bq([333, 1000, 5000]), api.TopScoreDocCollectorManager(20, None, INT_MAX))
+    after = api.ScoreDoc(int(first.docs[-1]), float(first.scores[-1]))
+    second = pruned.searcher.search(bq([333, 1000, 5000]), api.TopScoreDocCollectorManager(20, after, INT_MAX))
+    check("exact_page2", second, oracle.search_bm25(pruned.corpus, [333, 1000, 5000], 20, total_hits_threshold=INT_MAX, after=(after.doc, after.score)), 20, INT_MAX)
 
 
 def test_larger_index_c3_shaped_queries(ctxs, oracle):
