@@ -259,19 +259,34 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     // ---- per part: lane l looks after clause l: its exact maximum score in this segment, suffix sums, and the
     //      clause's record in the wave's LDS table (what a lane needs to stream or look up clause l)
     uint64_t my_ub = 0, my_suf = 0;
-    for (uint32_t t = 0; t < n_terms; ++t) {  // uniform
-      const DTerm T = part_terms[t];
-      const float* cache = &s.cache[T.cache_slot][0];
-      uint32_t v = 0;
-      if (lane < 12u) {  // (read through the pointer: a lane-indexed private copy would not stay in registers)
-        const uint32_t nb = T.aux->min_norm[lane];
-        if (nb != 0xFFu) v = score_value<true>(bm25_score(T.weight, (float)(int32_t)(lane + 1u), cache[nb]), T.fx_scale);
-      } else if (lane == 12u) {
-        const uint32_t mf = T.aux->esc_max_freq;
-        if (mf != 0u) v = score_value<true>(bm25_score(T.weight, (float)(int32_t)mf, cache[T.aux->esc_min_norm]), T.fx_scale);
+    const DTerm mt = part_terms[min(lane, n_terms - 1u)];
+    {
+      // 16 lanes per clause, four clauses per pass: lane (g, i) evaluates frontier entry i of clause 4 * pass + g -- two
+      // dependent loads per PASS (the clause's record, then its frontier byte) instead of two per clause
+      uint32_t ub_raw = 0;
+      for (uint32_t pass = 0; pass * 4u < n_terms; ++pass) {  // uniform
+        const uint32_t tt = pass * 4u + (lane >> 4), i = lane & 15u;
+        const DTerm* Tp = part_terms + min(tt, n_terms - 1u);
+        const DTermAux* ax = Tp->aux;
+        const float w = Tp->weight;
+        const int scale = Tp->fx_scale;
+        const float* cache = &s.cache[Tp->cache_slot][0];
+        uint32_t v = 0;
+        if (tt < n_terms) {
+          if (i < 12u) {
+            const uint32_t nb = ax->min_norm[i];
+            if (nb != 0xFFu) v = score_value<true>(bm25_score(w, (float)(int32_t)(i + 1u), cache[nb]), scale);
+          } else if (i == 12u) {
+            const uint32_t mf = ax->esc_max_freq;
+            if (mf != 0u) v = score_value<true>(bm25_score(w, (float)(int32_t)mf, cache[ax->esc_min_norm]), scale);
+          }
+        }
+#pragma unroll
+        for (int dlt = 8; dlt > 0; dlt >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, dlt, 64));  // maximum of each 16-lane group
+        const uint32_t got = (uint32_t)__shfl((int)v, (int)((lane & 3u) * 16u), 64);            // lane L = clause L: group L & 3 of pass L >> 2
+        if ((lane >> 2) == pass) ub_raw = got;
       }
-      v = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32(v), 63);
-      if (lane == t) my_ub = (uint64_t)v << T.fx_shift;
+      if (lane < n_terms) my_ub = (uint64_t)ub_raw << mt.fx_shift;
     }
     {
       uint64_t run = 0;
@@ -280,7 +295,6 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         if (lane == (uint32_t)m) my_suf = run;
       }
     }
-    const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
     const uint32_t my_shift = mt.shift;
     if (lane < n_terms) {
