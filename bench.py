@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--packed", action="store_true",
                     help="compressed postings (NRTGPU_FLAG_PACKED_POSTINGS): one 32-bit word per posting in HBM.  A separately "
                          "reported configuration: the roofline's algorithmic bytes are then 4 per posting, not 9")
+    ap.add_argument("--blocking-wait", action="store_true", help="NRTGPU_FLAG_BLOCKING_WAIT also at one rank (default: only for N > 1)")
     ap.add_argument("--no-prune", action="store_true",
                     help="A/B: exhaustive scan only (NRTGPU_FLAG_NO_PRUNE): every posting of every query term is streamed")
     ap.add_argument("--debug-same-gpu", action="store_true",
@@ -353,7 +354,10 @@ def main():
     t_build = time.perf_counter() - t_build
 
     flags = ((_lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0) | (_lib.NRTGPU_FLAG_NO_PRUNE if args.no_prune else 0)
-             | (_lib.NRTGPU_FLAG_PACKED_POSTINGS if args.packed else 0))
+             | (_lib.NRTGPU_FLAG_PACKED_POSTINGS if args.packed else 0)
+             # several ranks share this host's CPUs: their callers sleep on their results instead of spinning (the box grants
+             # 16 CPUs; 8 ranks x (2 scan threads + the exchange thread) spinning would want 24)
+             | (_lib.NRTGPU_FLAG_BLOCKING_WAIT if (shard_world > 1 or args.blocking_wait) else 0))
     # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
     # (the node's ranks share the host; 4 is the library's default and enough at one rank)
     planner_threads = max(1, min(4, usable_cpus() // max(1, world * max(1, args.host_threads))))
@@ -536,10 +540,14 @@ def main():
     ctx.reset_stats()
     fence()
     n_thr = max(1, args.host_threads)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(elapsed, 1e-9)   # CPUs this rank kept busy
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.debug_same_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -601,7 +609,7 @@ def main():
             "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
             "dynamic_pruning": not args.no_prune,
             "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
-            "host_threads": n_thr,
+            "host_threads": n_thr, "host_cpus_busy": round(host_cpu_busy, 2),
             "corpus_build_s": round(t_build, 1),
             "dist_stage_ms": ({k_: round(v / max(1, stage["steps"]) * 1e3, 3) for k_, v in stage.items() if k_ != "steps"}
                               if use_dist else None),   # per step on this rank: scan call (per scan thread), exchange, merge call

@@ -69,6 +69,9 @@ typedef struct {
                                         * folded into the postings (the scorers test the mask).  Postings the 12-bit code cannot name (freq > 12
                                         * or norm byte >= 128) go through a per-upload-group exception list (4 B each).  A separately
                                         * reported configuration (its own roofline denominator). */
+#define NRTGPU_FLAG_BLOCKING_WAIT 64    /* callers sleep until their results are there instead of spinning on the stream: for deployments
+                                        * where several processes (one per GPU) with several calls in flight each share the host's CPUs.
+                                        * Costs a wake-up (tens of microseconds) per call */
 #define NRTGPU_FLAG_NO_PRUNE 16        /* never take the MaxScore route: every query is scanned exhaustively and total_hits is
                                         * always the exact count (the relation still follows totalHitsThreshold) */
 

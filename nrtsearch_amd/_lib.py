@@ -25,6 +25,7 @@ NRTGPU_FLAG_NO_MASK_VARIANT = 4
 NRTGPU_FLAG_NO_LIVE_FOLD = 8
 NRTGPU_FLAG_NO_PRUNE = 16
 NRTGPU_FLAG_PACKED_POSTINGS = 32
+NRTGPU_FLAG_BLOCKING_WAIT = 64
 NRTGPU_FLAG_PROFILE = 7 << 8
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)

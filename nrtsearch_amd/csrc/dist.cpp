@@ -57,6 +57,7 @@ struct nrtgpu_dist {
   NcclComm comm = nullptr;
   int32_t world = 0, rank = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev_wait = nullptr;   // NRTGPU_FLAG_BLOCKING_WAIT
   DevBuf local, gathered;   // [keys | hits | counts] of this rank / of every rank
   std::mutex mu;            // one collective at a time per communicator
 };
@@ -84,6 +85,7 @@ extern "C" int nrtgpu_dist_init(nrtgpu_ctx* ctx, int32_t world, int32_t rank, co
   memcpy(&id, id128, sizeof(id));
   if (int rc = r->comm_init_rank(&d->comm, world, id, rank)) return nccl_fail("ncclCommInitRank", rc);
   HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&d->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
   ctx->dist = d.release();
   return NRTGPU_OK;
 }
@@ -97,6 +99,7 @@ extern "C" void nrtgpu_dist_close(nrtgpu_ctx* ctx) {
   if (Rccl* r = rccl())
     if (d->comm) (void)r->comm_destroy(d->comm);
   if (d->stream) (void)hipStreamDestroy(d->stream);
+  if (d->ev_wait) (void)hipEventDestroy(d->ev_wait);
   d->local.release();
   d->gathered.release();
   delete d;
@@ -129,7 +132,7 @@ extern "C" int nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, i
   int rc3 = r->all_gather(d_counts, g_cnt, cb / 4, kNcclInt32, d->comm, d->stream);
   if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
   if (rc1 || rc2 || rc3) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : rc3));
-  HIP_TRY(hipStreamSynchronize(d->stream));
+  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, d->stream, d->ev_wait));
   return nrtgpu_merge_topk_device(ctx, d->world, n_queries, k_stride, g_keys, g_cnt, g_hits, ks, total_hits_thresholds, out);
 }
 

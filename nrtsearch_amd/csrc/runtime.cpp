@@ -162,6 +162,7 @@ extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
     HIP_TRY(hipEventCreate(&s->ev2));
     HIP_TRY(hipEventCreate(&s->ev3));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_turn, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
     ctx->slots.push_back(std::move(s));
   }
   ctx->pool = std::make_unique<WorkPool>(std::max(0, (c.host_threads > 0 ? c.host_threads : 4) - 1));
@@ -234,6 +235,7 @@ extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
     if (s->ev2) (void)hipEventDestroy(s->ev2);
     if (s->ev3) (void)hipEventDestroy(s->ev3);
     if (s->ev_turn) (void)hipEventDestroy(s->ev_turn);
+    if (s->ev_wait) (void)hipEventDestroy(s->ev_wait);
     for (hipEvent_t e : s->round_ev) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
   }

@@ -307,6 +307,7 @@ struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   hipEvent_t ev_turn = nullptr;   // recorded behind this call's whole-GPU kernels (nrtgpu_ctx::last_turn)
+  hipEvent_t ev_wait = nullptr;   // hipEventBlockingSync: what a caller sleeps on under NRTGPU_FLAG_BLOCKING_WAIT
   PinBuf h_plan;     // host staging of the plan blob
   DevBuf d_plan;     // device copy
   DevBuf d_work;     // theta + item outputs + merge outputs
@@ -316,6 +317,15 @@ struct Slot {
   std::vector<hipEvent_t> round_ev;   // collect_timing: start / stop of every knn_score launch of a panel
   bool busy = false;
 };
+
+// The caller's wait for its stream: a spin inside hipStreamSynchronize by default (lowest latency; it keeps a CPU busy), a
+// sleep on a blocking event under NRTGPU_FLAG_BLOCKING_WAIT (several ranks sharing the host's CPUs: one process per GPU
+// with a few calls in flight each would otherwise spin on more CPUs than the box has).
+inline hipError_t wait_for_stream(bool blocking, hipStream_t st, hipEvent_t blocking_event) {
+  if (!blocking) return hipStreamSynchronize(st);
+  const hipError_t e = hipEventRecord(blocking_event, st);
+  return e != hipSuccess ? e : hipEventSynchronize(blocking_event);
+}
 
 }  // namespace rt
 }  // namespace nrtgpu

@@ -229,12 +229,12 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
   }
-  HIP_TRY(hipStreamSynchronize(slot->stream));
+  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
   const double tc1 = call_trace ? now_ms() : 0.0;
   HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
   HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
   HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
-  HIP_TRY(hipStreamSynchronize(slot->stream));
+  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
   const double tc2 = call_trace ? now_ms() : 0.0;
   const uint64_t* keys = (const uint64_t*)(ho + o_k);
   const uint32_t* cnts = (const uint32_t*)(ho + o_c);
@@ -344,13 +344,13 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
                           dim, (const float*)(da + o_qv), (const float*)(da + o_qn), sim, boost, query_weight, rescore_weight,
                           (uint32_t)window, (uint64_t*)(da + o_wk), (uint32_t*)(da + o_wc), w_stride);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, st, slot->ev_wait));
   }
   HIP_TRY(hipMemcpyAsync(ha + oh_k, da + o_wk, kb, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(ha + oh_c, da + o_wc, cb, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(ha + oh_fc, run.out_counts, cb, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(ha + oh_h, run.out_hits, hb, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, st, slot->ev_wait));
   const uint64_t* keys = (const uint64_t*)(ha + oh_k);
   const uint32_t* cnts = (const uint32_t*)(ha + oh_c);
   const uint32_t* first_cnts = (const uint32_t*)(ha + oh_fc);
@@ -582,7 +582,7 @@ extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtg
     if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
                                 (uint64_t*)d_hits, &run, gpu, epoch))
       return rc;
-    HIP_TRY(hipStreamSynchronize(slot->stream));
+    HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
   }
   account(ctx, slot, hp, n_queries, plan_ms);
   return NRTGPU_OK;
@@ -632,7 +632,7 @@ extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_
                     (uint64_t*)(wb + o_okeys), (uint32_t*)(wb + o_ocnt), (uint64_t*)(wb + o_ohits), (uint32_t)k_stride);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ho, wb, wc.off, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, st, slot->ev_wait));
   const uint64_t* keys = (const uint64_t*)(ho + o_okeys);
   const uint32_t* cnts = (const uint32_t*)(ho + o_ocnt);
   const uint64_t* hits = (const uint64_t*)(ho + o_ohits);
