@@ -311,7 +311,7 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.debug_same_gpu:
-            dist.init_process_group("gloo")
+            stdout_to_stderr(lambda: (dist.init_process_group("gloo"), dist.barrier()))   # (gloo announces its connections on stdout)
         else:
             def _init():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
