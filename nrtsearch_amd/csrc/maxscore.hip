@@ -560,14 +560,14 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
                   if (dv == dd) {  // found: close the search on it
                     a[j] = b[j] = mid[j];
                     present |= 1u << j;
-                    if (PACKED) c2[j] = vv[j];  // the posting's word carries its code: no second gather
                   }
                   if (!(a[j] < b[j])) open &= ~(1u << j);
                 }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              if (!PACKED) c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];
+              c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];   // (packed: the posting's word again -- keeping the probe's word alive
+                                                                    //  through the search loop cost more than this gather)
               pi2[j] = (uint32_t)w2.start + a[j];
             }
           }
