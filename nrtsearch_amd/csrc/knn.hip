@@ -66,6 +66,7 @@ __device__ __forceinline__ float knn_map_score(int sim, float dot, float nq, flo
 template <bool TWO>
 __device__ __forceinline__ void knn_tile_dots(const f32x4* __restrict__ vp, const f32x4* qs, int32_t chunks, uint32_t lane,
                                               f32x4& acc0, f32x4& acc1) {
+  constexpr int32_t kStride = TWO ? 128 : 64;   // float4s per chunk in LDS: one or two 16-query panels x 64 lanes
   f32x4 abuf[kKnnDepth];
 #pragma unroll
   for (int i = 0; i < kKnnDepth; ++i) abuf[i] = vp[4 * min(i, chunks - 1)];
@@ -81,8 +82,8 @@ __device__ __forceinline__ void knn_tile_dots(const f32x4* __restrict__ vp, cons
       abuf[i] = vp[4 * min(c + kKnnDepth, chunks - 1)];
       const f32x4 b0 = b0n, b1 = b1n;
       const int32_t cn = min(c + 1, chunks - 1);
-      b0n = qs[cn * 128 + (int32_t)lane];
-      if (TWO) b1n = qs[cn * 128 + 64 + (int32_t)lane];
+      b0n = qs[cn * kStride + (int32_t)lane];
+      if (TWO) b1n = qs[cn * kStride + 64 + (int32_t)lane];
       __builtin_amdgcn_sched_barrier(0);  // the reads stay ahead of the MFMAs: their LDS latency hides under 8 matrix instructions
       if (TWO) {  // two independent accumulation chains, interleaved (pinned: left alone the scheduler runs one chain after the other)
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
@@ -110,13 +111,13 @@ __device__ __forceinline__ void knn_tile_dots(const f32x4* __restrict__ vp, cons
     const int32_t c = c0 + i;
     if (c < chunks) {  // wave-uniform
       const f32x4 a = abuf[i];
-      const f32x4 b0 = qs[c * 128 + (int32_t)lane];
+      const f32x4 b0 = qs[c * kStride + (int32_t)lane];
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0[0], acc0, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0[1], acc0, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0[2], acc0, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0[3], acc0, 0, 0, 0);
       if (TWO) {
-        const f32x4 b1 = qs[c * 128 + 64 + (int32_t)lane];
+        const f32x4 b1 = qs[c * kStride + 64 + (int32_t)lane];
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1[0], acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1[1], acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b1[2], acc1, 0, 0, 0);
@@ -161,15 +162,16 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
   }
   const uint32_t j = lane & 15u, kk = lane >> 4;
   const int32_t chunks = dim >> 4;
-  for (int32_t i = (int32_t)tid; i < chunks * 128; i += kKnnThreads) {
-    const int32_t c = i >> 7, p = (i >> 6) & 1, l = i & 63;
+  const bool two_panels = n_q > 16;  // uniform.  <= 16 queries: one panel in LDS (half the bytes: dimensions up to 2048 fit)
+  const int32_t pshift = two_panels ? 7 : 6;
+  for (int32_t i = (int32_t)tid; i < (chunks << pshift); i += kKnnThreads) {
+    const int32_t c = i >> pshift, p = two_panels ? (i >> 6) & 1 : 0, l = i & 63;
     const int32_t q = (l & 15) + 16 * p;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (q < n_q) v = *(const f32x4*)(qpanel + (int64_t)q * dim + 16 * c + 4 * (l >> 4));
     qs[i] = v;
   }
   __syncthreads();
-  const bool two_panels = n_q > 16;  // uniform
   // D layout (per panel): query col = lane & 15 (+ 16p), doc row in tile = 4 * (lane >> 4) + reg
   float nq[2], th_lo[2];
   unsigned long long th[2];
@@ -404,13 +406,13 @@ void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_
   if (n == 0) return;
   hipLaunchKernelGGL(knn_row_norms_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, vecs, dim, n, norm2);
 }
-size_t knn_score_lds_bytes(int32_t dim) { return (size_t)(dim >> 4) * 128 * 16; }
+size_t knn_score_lds_bytes(int32_t dim, int32_t n_q) { return (size_t)(dim >> 4) * (((n_q > 32 ? 32 : n_q) > 16) ? 128 : 64) * 16; }
 int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
                      const float* qpanel, const float* qnorm2, int32_t n_q, int32_t sim, float boost,
                      const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap) {
   if (row_end <= row_begin) return 0;
-  const size_t lds = knn_score_lds_bytes(dim);
+  const size_t lds = knn_score_lds_bytes(dim, n_q);
   hipError_t e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(knn_score_kernel, dim3(blocks), dim3(kKnnThreads), lds, st, vecs, vnorm2, ord_to_doc, live_bits, dim,

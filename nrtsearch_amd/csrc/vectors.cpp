@@ -17,7 +17,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || k <= 0 || dim <= 0 || sim < 0 || sim > 3) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
-  if (dim % 16 != 0 || dim > 1280) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 1280)", dim);
+  if (dim % 16 != 0 || dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 2048)", dim);
   HIP_TRY(hipSetDevice(ctx->device));
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
@@ -49,8 +49,10 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   // be long: with rows in no particular order a round that multiplies the rows seen by 16 appends about
   // k * ln 16 candidates.  Rows ordered by rising similarity could overflow the list (every row beats theta): the
   // select kernel flags that and the panel is redone with rounds no longer than the list (`safe`).
-  for (int q0 = 0, safe = 0; q0 < n_queries; q0 += safe ? 0 : kKnnMaxQ) {
-    const int nq = std::min(kKnnMaxQ, n_queries - q0);
+  // 160 KB of LDS hold two 16-query panels up to 1280 dimensions; beyond that one panel (16 queries per pass) up to 2048
+  const int pass_q = dim > 1280 ? 16 : kKnnMaxQ;
+  for (int q0 = 0, safe = 0; q0 < n_queries; q0 += safe ? 0 : pass_q) {
+    const int nq = std::min(pass_q, n_queries - q0);
     for (int q = 0; q < nq; ++q) {
       float s2 = 0.f;  // squareMagnitude of the query, fp32
       const float* qv = queries + (size_t)(q0 + q) * dim;

@@ -242,6 +242,37 @@ def test_knn_theta_unknown_after_the_first_round(ctx):
     g.release()
 
 
+def test_knn_large_dimensions_one_panel(ctx):
+    """d = 1536 and 2048 (above 1280 the query panel is one 16-query MFMA panel per pass: LDS): 20 queries = two passes,
+    against fp64 numpy; d = 2064 is refused."""
+    rng = np.random.default_rng(31)
+    for dim in (1536, 2048):
+        n = 30_000
+        vecs = rng.standard_normal((n, dim)).astype(np.float32)
+        g = api.GpuSegment(ctx, n, 0)
+        g.add_vectors(0, vecs)
+        g.seal()
+        sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+        qs = rng.standard_normal((20, dim)).astype(np.float32)
+        got = sr.knn_exact(0, "cosine", qs, 50)
+        vn = np.linalg.norm(vecs.astype(np.float64), axis=1)
+        for qi in (0, 15, 16, 19):
+            q = qs[qi].astype(np.float64)
+            sc = np.maximum((1.0 + (vecs.astype(np.float64) @ q) / (vn * np.linalg.norm(q))) / 2.0, 0.0)
+            order = np.lexsort((np.arange(n), -sc))[:50]
+            assert np.allclose(got[qi].scores, sc[order], rtol=2e-5, atol=2e-6)
+            assert len(set(got[qi].docs.tolist()) & set(order.tolist())) >= 49
+            assert got[qi].total_hits == n
+        g.release()
+    g = api.GpuSegment(ctx, 8, 0)
+    g.add_vectors(0, np.ones((8, 2064), np.float32))
+    g.seal()
+    with pytest.raises(api.NrtGpuError) as e:
+        api.GpuIndexSearcher(ctx, [g], api.IndexStatistics()).knn_exact(0, "cosine", np.ones((1, 2064), np.float32), 5)
+    assert e.value.code == -4
+    g.release()
+
+
 def test_knn_unsupported_dimension_falls_back(ctx):
     g = api.GpuSegment(ctx, 10, 0)
     g.add_vectors(0, np.ones((10, 3), np.float32))   # d = 3 as in VectorFieldDefTest: not a multiple of 8
