@@ -21,9 +21,9 @@ constexpr int kScanWaves = NRT_SCAN_WAVES;      // autonomous wave64 per workgro
 constexpr int kScanThreads = kScanWaves * 64;
 static_assert(kScanWaves % 4 == 0 && kTileDocs % 64 == 0 && kTileDocs / 64 <= 16, "scan workgroup shape");
 static_assert(kScanWaves * kTileDocs * 8 <= 96 * 1024, "accumulators exceed their LDS share");
-constexpr int kCandCap = (kScanWaves == 12) ? 2176 : 1920;  // scan: LDS candidate slots (what the LDS budget leaves: 17 / 15 KiB)
+constexpr int kCandCap = (kScanWaves == 12) ? 1920 : 1664;  // scan: LDS candidate slots (what the LDS budget leaves next to four normInverse tables: 15 / 13 KiB; 2176 / 1920 with two tables measured the same)
 constexpr int kMergeCap = 2048;     // merge: candidate slots = kMaxK + kScanThreads
-constexpr int kLdsCaches = 2;       // normInverse tables kept in LDS per item (one per field)
+constexpr int kLdsCaches = 4;       // normInverse tables kept in LDS per item (one per field)
 // Score tables: for the kTabTerms densest terms of a query the BM25 score of every
 // (freq <= kTabMaxFreq, norm byte < kTabNorms) pair is computed once per item into LDS, so scoring a
 // posting is one LDS read.  Other (freq, norm) pairs / terms take the division path.

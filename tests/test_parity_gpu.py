@@ -335,9 +335,9 @@ def test_wide_score_range_falls_back_to_fp64(mid, oracle):
     c2.close()
 
 
-def test_two_fields_parity_three_fields_fall_back(ctx, oracle):
-    # two scored fields: both normInverse tables live in LDS; a third field is beyond the device
-    # fast path (NRTGPU_ERR_UNSUPPORTED -> the caller runs Lucene)
+def test_four_fields_parity_five_fields_fall_back(ctx, oracle):
+    # up to four scored fields (multi-field match, DisjunctionMax over fields): their normInverse tables live in LDS; a
+    # fifth field is beyond the device fast path (NRTGPU_ERR_UNSUPPORTED -> the caller runs Lucene)
     import ctypes as C
 
     from oracle import oracle as o
@@ -346,7 +346,7 @@ def test_two_fields_parity_three_fields_fall_back(ctx, oracle):
     seg = corpus.segments[0]
     g = api.GpuSegment(ctx, seg.max_doc, 0)
     stats = api.IndexStatistics()
-    for field in range(3):
+    for field in range(5):
         g.add_field_norms(field, seg.norms)
         g.add_terms(field, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
         stats.fields[field] = api.CollectionStatistics(corpus.doc_count, corpus.sum_total_term_freq * (field + 1))
@@ -354,27 +354,35 @@ def test_two_fields_parity_three_fields_fall_back(ctx, oracle):
             stats.doc_freq[(field, t)] = df
     g.seal()
     sr = api.GpuIndexSearcher(ctx, [g], stats)
-    clauses = [(0, 1), (1, 4), (1, 20), (0, 20)]
-    q = api.BooleanQuery(tuple(api.TermQuery(f, t) for f, t in clauses))
-    got = sr.search(q, api.TopScoreDocCollectorManager(100, None, INT_MAX))
-    col = o.Collector(100, None, INT_MAX)
-    arr = (o._Term * len(clauses))()
-    keep = []
-    for i, (field, t) in enumerate(clauses):
-        d, f = seg.postings(t)
-        d = np.ascontiguousarray(d)
-        f = np.ascontiguousarray(f)
-        cs = stats.fields[field]
-        cache = o.bm25_norm_cache(float(o.bm25_avgdl(cs.sum_total_term_freq, cs.doc_count)))
-        keep += [d, f, cache]
-        arr[i].docids, arr[i].freqs, arr[i].n = d.ctypes.data, f.ctypes.data, len(d)
-        arr[i].weight = float(o.bm25_idf(cs.doc_count, corpus.doc_freq[t]))
-        arr[i].norms, arr[i].cache = seg.norms.ctypes.data, cache.ctypes.data
-    o.lib().nrt_oracle_search_segment(seg.max_doc, 0, None, len(clauses), C.byref(arr), col._h)
-    assert_same("fields2", got, col.topdocs(), 100, INT_MAX)
-    q3 = api.BooleanQuery((api.TermQuery(0, 1), api.TermQuery(1, 4), api.TermQuery(2, 20)))
+
+    def reference(clauses, dismax):
+        col = o.Collector(100, None, INT_MAX)
+        arr = (o._Term * len(clauses))()
+        keep = []
+        for i, (field, t) in enumerate(clauses):
+            d, f = seg.postings(t)
+            d = np.ascontiguousarray(d)
+            f = np.ascontiguousarray(f)
+            cs = stats.fields[field]
+            cache = o.bm25_norm_cache(float(o.bm25_avgdl(cs.sum_total_term_freq, cs.doc_count)))
+            keep += [d, f, cache]
+            arr[i].docids, arr[i].freqs, arr[i].n = d.ctypes.data, f.ctypes.data, len(d)
+            arr[i].weight = float(o.bm25_idf(cs.doc_count, corpus.doc_freq[t]))
+            arr[i].norms, arr[i].cache = seg.norms.ctypes.data, cache.ctypes.data
+        if dismax:
+            o.lib().nrt_oracle_search_segment_dismax(seg.max_doc, 0, None, len(clauses), C.byref(arr), C.c_float(0.0), col._h)
+        else:
+            o.lib().nrt_oracle_search_segment(seg.max_doc, 0, None, len(clauses), C.byref(arr), col._h)
+        return col.topdocs()
+
+    for clauses in ([(0, 1), (1, 4), (1, 20), (0, 20)], [(0, 4), (1, 4), (2, 4), (3, 4)], [(3, 1), (2, 20), (0, 4), (1, 1), (3, 20)]):
+        q = api.BooleanQuery(tuple(api.TermQuery(f, t) for f, t in clauses))
+        assert_same(f"fields_sum_{len(clauses)}", sr.search(q, api.TopScoreDocCollectorManager(100, None, INT_MAX)), reference(clauses, False), 100, INT_MAX)
+        dq = api.DisjunctionMaxQuery(tuple(api.TermQuery(f, t) for f, t in clauses))      # the multi-field "best field" shape
+        assert_same(f"fields_max_{len(clauses)}", sr.search(dq, api.TopScoreDocCollectorManager(100, None, INT_MAX)), reference(clauses, True), 100, INT_MAX)
+    q5 = api.BooleanQuery(tuple(api.TermQuery(f, 4) for f in range(5)))
     with pytest.raises(api.NrtGpuError) as e:
-        sr.search(q3, api.TopScoreDocCollectorManager(100))
+        sr.search(q5, api.TopScoreDocCollectorManager(100))
     assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
     g.release()
 
