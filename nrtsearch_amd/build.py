@@ -12,14 +12,14 @@ SOURCES = ["kernels.hip", "maxscore.hip", "knn.hip", "runtime.cpp", "segment.cpp
 HEADERS = ["plan.h", "topk.hiph", "bm25_common.hiph", "host_math.h", "runtime_internal.h", os.path.join("..", "..", "include", "nrtgpu.h")]
 # -ffp-contract=off + no fast-math: BM25 arithmetic must round exactly like Java's float ops.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-parallel-jobs=8", "-x", "hip"]   # (the translation units compile side by side: 50 s -> 23 s)
 
 
-def _stale() -> bool:
-    if not os.path.exists(OUT):
+def _stale(out: str = OUT, more=()) -> bool:
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(out)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + list(more)] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -30,6 +30,8 @@ DEV_SOURCES = ["devtools.cpp"]   # measurement helpers outside the product ABI (
 def build_dev(verbose: bool = False) -> str:
     """The development build: the product sources + devtools.cpp with -DNRTGPU_DEV (closed-loop load generator, timing
     ablations of the scan).  NRTGPU_LIB_PATH=<this file> makes nrtsearch_amd._lib load it."""
+    if not _stale(DEV_OUT, DEV_SOURCES + [os.path.join("..", "..", "include", "nrtgpu_dev.h")]):
+        return DEV_OUT
     return build(force=True, verbose=verbose, extra=["-DNRTGPU_DEV"] + [os.path.join(CSRC, s) for s in DEV_SOURCES], out=DEV_OUT)
 
 
