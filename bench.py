@@ -66,6 +66,10 @@ def parse_args():
                     help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="debug, 1 GPU: index only rank 0's docid range of an N-GPU job (per-rank step time at --gpus N)")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's shard (the last rank holds the small segments)")
+    ap.add_argument("--shard-layout", default="index", choices=["index", "per_shard"],
+                    help="N>1: a rank owns the pieces of the index's segments inside its docid range (default), or -- rounds 1-2 -- "
+                         "its range cut into a full set of tiered segments of its own")
     ap.add_argument("--debug-k", type=int, default=0, help="debug: numHits override (what a shard costs at a smaller k)")
     ap.add_argument("--torch-collective", action="store_true",
                     help="N>1: exchange with torch.distributed's all-gather instead of the library's own RCCL stage "
@@ -298,8 +302,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # launched as plain `python bench.py --gpus N`: start the ranks ourselves, exactly as the driver would
+            # (one process per GPU over RCCL, rendezvous on 127.0.0.1), and hand their output and exit code through
+            import socket
+            import subprocess
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.call(cmd))
         args.gpus = world
 
     import torch  # first: its bundled HIP runtime must be the one libnrtgpu.so binds to
@@ -349,8 +363,8 @@ def main():
     n_distinct = max(B, (w.n_queries // B) * B)
     qranks = synth.make_queries(n_distinct, w.n_terms, w.max_rank)
     t_build = time.perf_counter()
-    shard_world, shard_rank = (args.emulate_world, 0) if (args.emulate_world > 1 and world == 1) else (world, rank)
-    corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank)
+    shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if (args.emulate_world > 1 and world == 1) else (world, rank)
+    corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank, layout=args.shard_layout)
     t_build = time.perf_counter() - t_build
 
     flags = ((_lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0) | (_lib.NRTGPU_FLAG_NO_PRUNE if args.no_prune else 0)
@@ -604,7 +618,7 @@ def main():
                                                                            ", RCCL all-gather of per-GPU top-k + merge on every rank") if use_dist else "")
                         + ((" (collective inside the library: nrtgpu_dist_allgather_merge)" if lib_collective else " (collective: torch.distributed)") if use_dist else "")
                         + (", score-bound exchange between shards" if exchange_name else "")
-                        + (f" [emulating rank 0 of {shard_world}]" if shard_world != world else ""),
+                        + (f" [emulating rank {shard_rank} of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
             "dynamic_pruning": not args.no_prune,

@@ -56,7 +56,8 @@ struct ScanSmem {
   uint64_t thr;          // acc_threshold(theta): what the walk compares accumulators with
   uint32_t cnt;          // valid entries in cand
   uint32_t tile_cand;    // rendezvous: competitive hits still parked in the accumulators
-  uint32_t hits;         // live matching docs of this item
+  uint32_t slot_hits[kSliceSlots];   // live matching docs of this item, per searcher slice it touches (plan.h: DPart.slice)
+  uint32_t slot_slice[kSliceSlots];  // which slice a slot stands for
   uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet at the rendezvous
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kCandCap
   uint32_t next_tile;    // next unassigned sub-tile of the item (flattened over its parts)
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(kScanThreads, kScanWaves / 4)
 void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts,
                       const DTerm* __restrict__ terms, const DQuery* __restrict__ queries,
                       const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
-                      unsigned long long* __restrict__ quant_g, const DExchange* __restrict__ xch,
+                      unsigned long long* __restrict__ quant_g, const DExchange* __restrict__ xch, uint32_t* __restrict__ slice_sum,
                       uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
                       uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof) {
   __shared__ ScanSmem s;
@@ -564,7 +565,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     s.thr = acc_threshold<FX>(theta0, fx_E);
     s.cnt = 0;
     s.tile_cand = 0;
-    s.hits = 0;
+    for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
     s.rz_flag = 0;
     s.cnt_valid = 0;
     s.next_tile = 3u * (uint32_t)kScanWaves;  // every wave starts with three sub-tiles
@@ -596,7 +597,8 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     if (tid == 0) s.prof[0] += t_walk - t_start;
   }
   uint32_t my_hits = 0;    // per-lane count (general sweep)
-  uint32_t wave_hits = 0;  // wave-uniform count, added once by lane 0
+  uint32_t wave_hits = 0;  // wave-uniform count, added by lane 0 when the wave moves on to a part of another slice (and at the end)
+  uint32_t cur_slot = 0;   // the slot (searcher slice) of the part the wave is in
   // The sub-tiles of the item's parts form one sequence g = 0, 1, ... (part.tile_offset + tile index in the
   // part).  Waves take them DYNAMICALLY from a shared counter: the hardware favours the oldest waves,
   // with a static split the youngest ones finish ~20% later while the others idle.  A wave always holds
@@ -619,6 +621,17 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       if (g_cur < part.tile_offset + (part.tile_end - part.tile_begin)) break;
     }
     if (pi >= item.n_parts) break;  // this wave is out of sub-tiles
+    {  // hits are counted per searcher slice: a part of another slice closes my count of the previous one
+      const uint32_t p_slot = part.slice >> 24;
+      if (p_slot != cur_slot) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) my_hits += __shfl_xor(my_hits, d, 64);
+        if (lane == 0 && (my_hits + wave_hits)) atomicAdd(&s.slot_hits[cur_slot], my_hits + wave_hits);
+        my_hits = wave_hits = 0;
+        cur_slot = p_slot;
+      }
+      if (lane == 0) s.slot_slice[p_slot] = part.slice & 0xFFFFFFu;
+    }
     const uint32_t g0 = part.tile_offset, gn = g0 + (part.tile_end - part.tile_begin);
     // tile index inside the segment of a flattened index of this part: g - g0 + tile_begin
     const uint32_t tile_bias = part.tile_begin - g0;
@@ -901,14 +914,21 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) my_hits += __shfl_xor(my_hits, d, 64);
-  if (lane == 0 && (my_hits + wave_hits)) atomicAdd(&s.hits, my_hits + wave_hits);
+  if (lane == 0 && (my_hits + wave_hits)) atomicAdd(&s.slot_hits[cur_slot], my_hits + wave_hits);
   __syncthreads();
   const uint32_t n = s.cnt;
   uint64_t* out = item_keys + (size_t)blockIdx.x * k_stride;
   for (uint32_t i = tid; i < n; i += kScanThreads) out[i] = s.cand[i];
   if (tid == 0) {
     item_counts[blockIdx.x] = n;
-    item_hits[blockIdx.x] = s.hits;
+    // the item's hits (exact: the scan skips nothing), per slice into the query's sums (slice_relation_kernel) and in total
+    uint32_t hits = 0;
+    for (int i = 0; i < kSliceSlots; ++i) {
+      const uint32_t h = s.slot_hits[i];
+      hits += h;
+      if (h != 0u && q.gte_floor != 0xFFFFFFFFu) atomicAdd(&slice_sum[q.slice_base + s.slot_slice[i]], h);
+    }
+    item_hits[blockIdx.x] = hits;
     if (ABL == 7 && item_prof) {
       s.prof[4] += __builtin_readcyclecounter() - t_epi;  // epilogue
       for (int i = 0; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
@@ -1154,49 +1174,38 @@ void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* q
 }
 
 // slice_relation_kernel: TotalHits.relation by the reference's rule -- GREATER_THAN_OR_EQUAL_TO iff some slice's
-// collector saw more than max(totalHitsThreshold, numHits) hits.  One thread per query sums its items' exact hit
-// counts per slice (an item never spans slices when the relation can depend on it: planner.cpp) and tags the merged
-// count with kHitsPrunedUnit, the same tag the MaxScore route's items carry through the merge's sum.
+// collector saw more than max(totalHitsThreshold, numHits) hits (one collector per slice, MyIndexSearcher.java:163-208;
+// LazyQueueTopScoreDocCollector.java:176-199; reduce: LazyQueueTopScoreDocCollectorManager.java:137-144).  The scorers' items
+// have added their per-slice counts into slice_sum (exact for every item that skipped nothing; an item that did skip has
+// tagged its own count -- it only starts once a slice of its own has passed the floor); one thread per query tags the
+// merged count with kHitsPrunedUnit, the same tag such items carry through the merge's sum.
 __global__ __launch_bounds__(256)
-void slice_relation_kernel(const uint64_t* __restrict__ item_hits, const uint32_t* __restrict__ item_slice,
-                           const uint32_t* __restrict__ list_idx, const uint32_t* __restrict__ q_base,
-                           const uint32_t* __restrict__ q_nlists, const uint32_t* __restrict__ q_floor,
+void slice_relation_kernel(const uint32_t* __restrict__ slice_sum, const DQuery* __restrict__ queries, uint32_t n_slices,
                            uint64_t* __restrict__ out_hits, uint32_t n) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   if ((out_hits[q] >> 48) != 0ull) return;  // already tagged (pruned items)
-  const uint32_t base = q_base[q], nl = q_nlists[q];
-  const uint64_t floor_ = q_floor[q];
+  const uint32_t floor_ = queries[q].gte_floor;
+  if (floor_ == 0xFFFFFFFFu) return;        // ScoreMode.COMPLETE: the count is the count
+  const uint32_t* sums = slice_sum + queries[q].slice_base;
   bool gte = false;
-  for (uint32_t i = 0; i < nl && !gte; ++i) {
-    const uint32_t it = list_idx[base + i];
-    const uint32_t sl = item_slice[it];
-    if (sl == 0xFFFFFFFFu) continue;
-    bool first = true;   // sum a slice once: at its first item
-    for (uint32_t j = 0; j < i; ++j) first = first && item_slice[list_idx[base + j]] != sl;
-    if (!first) continue;
-    uint64_t sum = 0;
-    for (uint32_t j = i; j < nl; ++j) {
-      const uint32_t jt = list_idx[base + j];
-      if (item_slice[jt] == sl) sum += item_hits[jt] & (kHitsPrunedUnit - 1ull);
-    }
-    gte = sum > floor_;
-  }
+  for (uint32_t i = 0; i < n_slices; ++i) gte = gte || sums[i] > floor_;
   if (gte) out_hits[q] += kHitsPrunedUnit;
 }
-void launch_slice_relation(hipStream_t stream, const uint64_t* item_hits, const uint32_t* item_slice, const uint32_t* list_idx,
-                           const uint32_t* q_base, const uint32_t* q_nlists, const uint32_t* q_floor, uint64_t* out_hits, uint32_t n) {
+void launch_slice_relation(hipStream_t stream, const uint32_t* slice_sum, const DQuery* queries, uint32_t n_slices, uint64_t* out_hits,
+                           uint32_t n) {
   if (n == 0) return;
-  hipLaunchKernelGGL(slice_relation_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, item_hits, item_slice, list_idx, q_base,
-                     q_nlists, q_floor, out_hits, n);
+  hipLaunchKernelGGL(slice_relation_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, slice_sum, queries, n_slices, out_hits, n);
 }
 
-// Device-resident results (multi-GPU path): a query that ran on the MaxScore route reports the planner's certain
-// lower bound, tagged as such (plan.h: kHitsPrunedUnit), instead of the number of docs the kernel happened to evaluate.
+// Device-resident results (multi-GPU path): a query whose kernel SKIPPED work (its count carries the tag, plan.h:
+// kHitsPrunedUnit) and for which the planner knew a certain lower bound reports that bound instead of the number of docs
+// the kernel happened to evaluate -- the same value on every run.  A count without the tag is exact (nothing was
+// skipped: e.g. the last page of a searchAfter walk) and stays.
 __global__ __launch_bounds__(256)
 void patch_hits_kernel(const uint64_t* __restrict__ lower, uint64_t* __restrict__ hits, uint32_t n) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n && lower[q] != 0ull) hits[q] = kHitsPrunedUnit + lower[q];
+  if (q < n && lower[q] != 0ull && (hits[q] >> 48) != 0ull) hits[q] = kHitsPrunedUnit + lower[q];
 }
 void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits, uint32_t n) {
   if (n == 0) return;
@@ -1220,12 +1229,12 @@ void launch_apply_live(hipStream_t stream, const uint32_t* docids, uint32_t* fno
 }
 void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool packed, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                      unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
+                      unsigned long long* quant_g, const DExchange* xch, uint32_t* slice_sum, uint64_t* item_keys, uint32_t* item_counts,
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof) {
   if (n_items == 0) return;
 #define NRT_LAUNCH_K(F, P, A, K)                                                                                  \
   hipLaunchKernelGGL((bm25_scan_kernel<F, P, A, K>), dim3(n_items), dim3(kScanThreads), 0, stream, items, parts, terms, queries, \
-                     caches, theta_g, quant_g, xch, item_keys, item_counts, item_hits, k_stride, item_prof)
+                     caches, theta_g, quant_g, xch, slice_sum, item_keys, item_counts, item_hits, k_stride, item_prof)
 #define NRT_LAUNCH(F, P, A)                 \
   do {                                      \
     if (packed) NRT_LAUNCH_K(F, P, A, true);  \

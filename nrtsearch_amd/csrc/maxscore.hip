@@ -74,8 +74,9 @@ struct MsSmem {
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kMsCandCap
   uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet
   uint32_t next_win;     // next unassigned window of the item
-  uint32_t hits;         // docs evaluated
-  uint32_t pad;
+  uint32_t prune_on;     // bounds may skip work (kMsModeCount: raised once a slice's count has passed the query's gte_floor)
+  uint32_t slot_hits[kSliceSlots];   // live matching docs evaluated, per searcher slice the item touches (plan.h: DPart.slice)
+  uint32_t slot_slice[kSliceSlots];  // which slice a slot stands for
   uint64_t prof[8];
 };
 static_assert(sizeof(MsSmem) <= 160 * 1024, "the MaxScore workgroup owns one CU's 160 KiB LDS");
@@ -184,11 +185,20 @@ __device__ __forceinline__ bool ms_reserve(MsSmem& s, uint32_t lane, uint32_t mi
 // [3] postings streamed, [4] postings surviving the bound, [5] docs evaluated, [6] lookups, [7] candidates.
 // PACKED: the segments keep one 32-bit word per posting (plan.h: kPack*).  liveDocs that are not folded into the
 // postings (part.live_bits != nullptr) are tested when a doc's score is complete.
-template <bool PROF, bool PACKED>
+// SHAPES: the batch holds queries with a doc-set mask next to their scoring clauses (FILTER / MUST_NOT,
+// QueryNodeMapper.java:257-283), minimumNumberShouldMatch > 1 (:259-261) or a DisjunctionMaxQuery (:350-358, tie breaker 0):
+//   * mask: a doc outside part.live_bits (liveDocs & filter & ~must_not) is no hit -- tested when its score is complete;
+//   * minimumNumberShouldMatch: the clauses that matched a doc are counted next to its sum (4 bits per posting slot); a doc
+//     with fewer is no hit.  The MaxScore argument is untouched: a doc that matches non-essential clauses only cannot be
+//     competitive however many of them it matches;
+//   * DisjunctionMaxQuery: a doc scores its BEST clause -- `max` where the sum has `+`, and the clauses after c can lift a
+//     doc to max(ub_c+1 ..) instead of their sum.
+template <bool PROF, bool PACKED, bool SHAPES>
 __global__ __launch_bounds__(kMsThreads)
 void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts, const DTerm* __restrict__ terms,
                           const DQuery* __restrict__ queries,
                           const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
+                          uint32_t* __restrict__ slice_sum, uint32_t* __restrict__ q_prune,
                           uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
                           uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof) {
   __shared__ MsSmem s;
@@ -200,8 +210,13 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   const int fx_E = item.fx_E;
   unsigned long long* const my_theta_g = theta_g + item.query;
   const bool multi_item = q.n_items > 1;
-  // EXACT (planner: a small query whose count matters): no bound ever skips anything -- theta only filters the candidates
-  const bool exact = (item.flags & 1u) != 0u;
+  // When may bounds skip work (plan.h: kMsMode*)?  Exact: never.  Count: once a slice has collected more than gte_floor hits --
+  // until then every live matching doc is evaluated and counted, as the reference's collector does before it first
+  // publishes a min competitive score.  theta filters the candidates in every mode.
+  const uint32_t mode = item.flags & 3u;
+  const uint32_t msm = SHAPES ? q.min_should_match : 0u;   // (> 1: clause counting)
+  const bool use_max = SHAPES && q.combine_max != 0u;       // DisjunctionMaxQuery
+  unsigned int* const my_prune_g = q_prune + item.query;    // set by the first item of the query whose slice passed the floor
   const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
 
   // ---- item prologue: normInverse tables, score tables
@@ -217,7 +232,8 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     s.cnt_valid = 0;
     s.rz_flag = 0;
     s.next_win = (uint32_t)kMsWaves;
-    s.hits = 0;
+    s.prune_on = mode == kMsModePrune ? 1u : 0u;
+    for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
     for (int i = 0; i < 8; ++i) s.prof[i] = 0;
   }
   __syncthreads();
@@ -233,7 +249,8 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   uint32_t* const seen = &s.seen[wave][0];
   WClause* const wcl = &s.wc[wave][0];
   const uint32_t wcl_addr = lds_addr(wcl);
-  uint32_t wave_hits = 0;
+  uint32_t wave_hits = 0;    // hits of my current slot not yet added to s.slot_hits
+  uint32_t cur_slot = 0;
   uint64_t pc_post = 0, pc_surv = 0, pc_look = 0, pc_cand = 0, pc_chunks = 0, pc_wins = 0;
   uint32_t g = wave;      // my current window (flattened over the item's parts)
   uint32_t pi = 0;        // its part ...
@@ -253,6 +270,15 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       win_base += part_wins;
     }
     if (pi >= item.n_parts) break;
+    {  // hits are counted per searcher slice: a part of another slice closes my count of the previous one
+      const uint32_t p_slot = part.slice >> 24;
+      if (p_slot != cur_slot && wave_hits != 0u) {
+        if (lane == 0) atomicAdd(&s.slot_hits[cur_slot], wave_hits);
+        wave_hits = 0;
+      }
+      cur_slot = p_slot;
+      if (lane == 0) s.slot_slice[p_slot] = part.slice & 0xFFFFFFu;
+    }
     const uint32_t n_terms = part.n_terms;  // <= kMsMaxTerms (planner)
     const DTerm* const part_terms = terms + part.term_begin;
 
@@ -288,10 +314,13 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       }
       if (lane < n_terms) my_ub = (uint64_t)ub_raw << mt.fx_shift;
     }
+    uint64_t my_after = 0;   // what the clauses after mine can add (sum) / lift a doc to (DisjunctionMaxQuery): S_{lane+1}
     {
       uint64_t run = 0;
       for (int m = (int)n_terms - 1; m >= 0; --m) {
-        run += readlane_u64(my_ub, (uint32_t)m);
+        const uint64_t ub = readlane_u64(my_ub, (uint32_t)m);
+        if (lane == (uint32_t)m) my_after = run;
+        run = use_max ? max(run, ub) : run + ub;
         if (lane == (uint32_t)m) my_suf = run;
       }
     }
@@ -307,7 +336,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       w.fx_scale = mt.fx_scale;
       w.flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
       w.pad = 0;
-      w.u_after = my_suf - my_ub;
+      w.u_after = my_after;
       w.bits = (uint64_t)mt.aux->bits;
       w.cells = (uint64_t)mt.cell_off;
       w.start = mt.start;
@@ -329,6 +358,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       if (multi_item) {
         theta_other = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         thr_other = acc_threshold<true>(theta_other, fx_E);
+        // (another item's slice has passed the floor: the relation is decided, this item may skip as well)
+        if (mode == kMsModeCount && lane == 0 && __hip_atomic_load(my_prune_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+          __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       // posting range of every clause in this window (cells may be coarser than the window: doc-range filter below)
       uint32_t my_lo = 0, my_hi = 0;
@@ -345,7 +377,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       // instruction instead of taking one each.  Clause c's groups come before clause c + 1's.
       uint32_t ng = 0;
       {
-        const uint64_t thr_w = exact ? 0ull : max(s.thr, thr_other);
+        const uint64_t thr_w = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? max(s.thr, thr_other) : 0ull;
         const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
         if (lane < n_terms) {
           if (my_suf >= thr_w && pe > pb) ng = (uint32_t)((pe - (pb & ~3ull) + 7ull) >> 3);
@@ -371,7 +403,8 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         // theta as of now (it only grows: a stale value costs work, never a result).  Has it passed what this
         // instruction's first clause and everything after it can reach?  Then the rest of the window is non-essential.
         const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
-        const uint64_t thr_p = exact ? 0ull : thr;   // what the bounds are compared with
+        const bool pruning = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;   // (uniform)
+        const uint64_t thr_p = pruning ? thr : 0ull;   // what the bounds are compared with
         if (readlane_u64(my_suf, c_first) < thr_p) break;
         if (PROF) pc_chunks += 1;
         // what my clause is: column bases, posting range, score table, scale, what the later clauses can still add
@@ -451,7 +484,8 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             run[j] = (uint64_t)val[j] * (uint64_t)mult;
-            if (((vmask >> j) & 1u) && val[j] != 0u && run[j] + u_after >= thr_p) alive |= 1u << j;
+            const uint64_t reach = use_max ? max(run[j], u_after) : run[j] + u_after;
+            if (((vmask >> j) & 1u) && val[j] != 0u && reach >= thr_p) alive |= 1u << j;
           }
         }
         if (PROF) {
@@ -478,11 +512,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
               if (((am >> j) & 1u) && ((old[j] >> (d[j] & 31u)) & 1u)) alive &= ~(1u << j);
           }
         }
-        {
-          uint32_t h = (uint32_t)__popc(alive);
-          h = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(h), 63);
-          wave_hits += h;
-        }
+        uint32_t ccnt = 0x11111111u;   // SHAPES, minimumNumberShouldMatch: clauses that matched the doc, 4 bits per posting slot
 
         // ---- the later clauses of the surviving docs, one clause at a time (a lane of clause c takes part from c + 1 on)
         for (uint32_t j2 = c_first + 1u; j2 < n_terms; ++j2) {
@@ -491,7 +521,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           uint32_t am = c < j2 ? alive : 0u;
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (((am >> j) & 1u) && run[j] + S_j < thr_p) {
+            if (((am >> j) & 1u) && (use_max ? max(run[j], S_j) : run[j] + S_j) < thr_p) {
               alive &= ~(1u << j);
               am &= ~(1u << j);
             }
@@ -579,8 +609,20 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             }
             values_of_codes<PACKED>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
             const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
+            if (use_max) {   // (uniform)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
+              for (int j = 0; j < 8; ++j) run[j] = max(run[j], (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
+            }
+            if (SHAPES && msm > 1u) {   // (uniform) bit j of `present` -> nibble j
+              uint32_t x = present;
+              x = (x | (x << 12)) & 0x000F000Fu;
+              x = (x | (x << 6)) & 0x03030303u;
+              x = (x | (x << 3)) & 0x11111111u;
+              ccnt += x;
+            }
           }
         }
 
@@ -591,6 +633,41 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (((alive >> j) & 1u) && run[j] >= thr) maybe |= 1u << j;
+        // ---- hits.  While nothing is being skipped every live matching doc reaches this point exactly once: the count is
+        //      exact.  Once bounds skip it is a lower bound, and only the docs that reach theta's score are looked at.
+        //      A hit lies inside the part's doc set (liveDocs that are not folded into the postings -- packed layout, forked
+        //      reader versions -- and FILTER / MUST_NOT masks: one dword gather per doc) and matches enough clauses.
+        {
+          uint32_t pool = pruning ? maybe : alive;
+          if (SHAPES && msm > 1u) {   // (uniform)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (((ccnt >> (4 * j)) & 15u) < msm) pool &= ~(1u << j);
+          }
+          if (part.live_bits != nullptr && __any(pool != 0u)) {   // (uniform)
+            uint32_t lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lw[j] = ((const NRT_GLOBAL uint32_t*)part.live_bits)[((pool >> j) & 1u) ? (d[j] >> 5) : 0u];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (!((lw[j] >> (d[j] & 31u)) & 1u)) pool &= ~(1u << j);
+          }
+          maybe &= pool;
+          uint32_t h = (uint32_t)__popc(pool);
+          h = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(h), 63);
+          if (mode == kMsModeCount && !pruning) {
+            // counting towards the floor: into the slot at once, so that the item notices when a slice has passed it
+            if (lane == 0 && h != 0u) {
+              const uint32_t tot = atomicAdd(&s.slot_hits[cur_slot], h) + h;
+              if (tot > q.gte_floor) {
+                __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (multi_item) __hip_atomic_store(my_prune_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          } else {
+            wave_hits += h;
+          }
+        }
         uint64_t theta_now = theta;
         while (__any(maybe != 0u)) {
           const uint32_t low = maybe & (0u - maybe);  // my lowest pending posting
@@ -603,12 +680,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
               dsel = d[j];
             }
           const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
-          bool want = low != 0u && key > theta_now && key < after_key;
-          if (part.live_bits != nullptr) {   // (uniform) liveDocs that are not folded into the postings -- packed layout, forked
-            // reader versions: a deleted doc is no hit.  32-bit words: one dword gather per competitive doc
-            const uint32_t lw = ((const NRT_GLOBAL uint32_t*)part.live_bits)[want ? (dsel >> 5) : 0u];
-            want = want && ((lw >> (dsel & 31u)) & 1u) != 0u;
-          }
+          const bool want = low != 0u && key > theta_now && key < after_key;
           uint32_t pos = 0;
           if (!__any(want)) {
             maybe &= ~low;
@@ -647,7 +719,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       if (tid == 0) s.cnt = m;
     }
   }
-  if (lane == 0 && wave_hits) atomicAdd(&s.hits, wave_hits);
+  if (lane == 0 && wave_hits) atomicAdd(&s.slot_hits[cur_slot], wave_hits);
   if (PROF && lane == 0) {
     atomicAdd((unsigned long long*)&s.prof[0], (unsigned long long)pc_wins);
     atomicAdd((unsigned long long*)&s.prof[2], (unsigned long long)pc_chunks);
@@ -674,11 +746,19 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   for (uint32_t i = tid; i < n; i += kMsThreads) out[i] = s.cand[i];
   if (tid == 0) {
     item_counts[blockIdx.x] = n;
-    // anything skipped?  Only a theta can skip; with none the walk evaluated every live matching doc exactly once.
-    const bool pruned = !exact && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
-    item_hits[blockIdx.x] = (uint64_t)s.hits + (pruned ? kHitsPrunedUnit : 0ull);
+    // the item's hits, per slice into the query's sums (slice_relation_kernel) and in total
+    uint32_t hits = 0;
+    for (int i = 0; i < kSliceSlots; ++i) {
+      const uint32_t h = s.slot_hits[i];
+      hits += h;
+      if (h != 0u && q.gte_floor != 0xFFFFFFFFu) atomicAdd(&slice_sum[q.slice_base + s.slot_slice[i]], h);
+    }
+    // anything skipped?  Only a theta can skip, and only once the item may prune; with none the walk evaluated every live
+    // matching doc exactly once.
+    const bool pruned = s.prune_on != 0u && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
+    item_hits[blockIdx.x] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
     if (PROF && item_prof) {
-      s.prof[5] = s.hits;
+      s.prof[5] = hits;
       for (int i = 0; i < 8; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
       for (int i = 8; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = 0;
     }
@@ -758,21 +838,27 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, uint32_t n_items, const DItem* items, const DPart* parts,
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, uint32_t n_items, const DItem* items, const DPart* parts,
                           const DTerm* terms, const DQuery* queries, const float* caches,
-                          unsigned long long* theta_g, uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits,
-                          uint32_t k_stride, uint64_t* item_prof) {
+                          unsigned long long* theta_g, uint32_t* slice_sum, uint32_t* q_prune, uint64_t* item_keys, uint32_t* item_counts,
+                          uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof) {
   if (n_items == 0) return;
-#define NRT_MS_LAUNCH(P, K)                                                                                                      \
-  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
-                     caches, theta_g, item_keys, item_counts, item_hits, k_stride, item_prof)
+#define NRT_MS_LAUNCH(P, K, S)                                                                                                      \
+  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
+                     caches, theta_g, slice_sum, q_prune, item_keys, item_counts, item_hits, k_stride, item_prof)
+#define NRT_MS_LAUNCH_S(P, K)          \
+  do {                                 \
+    if (shapes) NRT_MS_LAUNCH(P, K, true); \
+    else NRT_MS_LAUNCH(P, K, false);   \
+  } while (0)
   if (profile) {
-    if (packed) NRT_MS_LAUNCH(true, true);
-    else NRT_MS_LAUNCH(true, false);
+    if (packed) NRT_MS_LAUNCH_S(true, true);
+    else NRT_MS_LAUNCH_S(true, false);
   } else {
-    if (packed) NRT_MS_LAUNCH(false, true);
-    else NRT_MS_LAUNCH(false, false);
+    if (packed) NRT_MS_LAUNCH_S(false, true);
+    else NRT_MS_LAUNCH_S(false, false);
   }
+#undef NRT_MS_LAUNCH_S
 #undef NRT_MS_LAUNCH
 }
 

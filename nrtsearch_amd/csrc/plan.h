@@ -143,7 +143,9 @@ struct alignas(16) DPart {
   uint32_t max_doc;
   int32_t  doc_base;
   uint32_t tile_offset;       // sub-tiles of the item's earlier parts: the item's sub-tiles form one sequence
-  uint32_t pad1;
+  uint32_t slice;             // bits 0-23: the searcher slice (MyIndexSearcher.slices) the part's leaf belongs to, an index into the
+                              // query's per-slice hit sums (DQuery.slice_base); bits 24-31: the slice's slot among the item's
+                              // slices (< kSliceSlots): the item counts its hits per slot
 };
 static_assert(sizeof(DPart) == 48, "DPart layout");
 
@@ -162,7 +164,7 @@ struct alignas(16) DItem {
   int32_t  tab_scale[kTabTerms];  // fixed-point batches: fx_scale of each score table's term
   int32_t  fx_E;                  // fixed-point batches: accumulators hold score * 2^fx_E
   uint32_t peer_slot;             // this item's slot among the query's items [DQuery.item_begin, + n_items)
-  uint32_t flags;                 // bit 0 (MaxScore kernel): EXACT -- nothing is skipped, every matching live doc is evaluated and counted
+  uint32_t flags;                 // MaxScore kernel, bits 0-1: when bounds may skip work (kMsMode*)
 };
 static_assert(sizeof(DItem) == 96, "DItem layout");
 
@@ -175,8 +177,24 @@ struct alignas(16) DQuery {
   uint32_t n_items;
   uint32_t min_should_match;  // > 1: only docs matched by that many clauses are hits (count-carrying kernel variant)
   uint32_t combine_max;       // 1: DisjunctionMaxQuery (tie breaker 0): a doc scores its best clause, not the sum (same variant)
+  uint32_t gte_floor;         // max(totalHitsThreshold, numHits): a slice that collects more hits makes the relation
+                              // GREATER_THAN_OR_EQUAL_TO (LazyQueueTopScoreDocCollector.java:176-199); ~0: never (ScoreMode.COMPLETE)
+  uint32_t slice_base;        // the query's per-slice hit sums: slice_sum[slice_base + slice]
+  uint32_t pad[2];
 };
-static_assert(sizeof(DQuery) == 32, "DQuery layout");
+static_assert(sizeof(DQuery) == 48, "DQuery layout");
+// Hit counting (both scorers): an item counts the live matching docs of each searcher slice it touches (at most kSliceSlots
+// of them: the planner cuts items there) in LDS and adds them to the query's per-slice sums at its end; slice_relation_kernel
+// then applies the reference's rule -- one collector per slice, MyIndexSearcher.java:163-208 -- to the sums.
+constexpr int kSliceSlots = 8;
+// MaxScore kernel, DItem.flags bits 0-1: when may bounds skip work?
+//   kMsModePrune : from the start (the planner KNOWS some slice passes max(totalHitsThreshold, numHits): what is reported is
+//                  its certain lower bound)
+//   kMsModeExact : never (ScoreMode.COMPLETE on a small query): every live matching doc is evaluated and counted
+//   kMsModeCount : like Lucene's collector (LazyQueueTopScoreDocCollector.java:176-199: no min competitive score before
+//                  totalHits has passed the threshold) -- exact counting until some slice's count passes gte_floor, from
+//                  then on bounds skip and the count is a lower bound (relation GREATER_THAN_OR_EQUAL_TO)
+constexpr uint32_t kMsModePrune = 0, kMsModeExact = 1, kMsModeCount = 2;
 // minimumNumberShouldMatch > 1: the fixed-point accumulator carries the number of matching clauses above
 // the score sum (sum < 2^52: 32 clauses x 2^32 x 2^15)
 constexpr int kMsmCountShift = 56;

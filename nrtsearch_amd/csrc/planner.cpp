@@ -248,18 +248,15 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
                             const int32_t* slice_of_leaf, int32_t n_slices, const nrtgpu_bm25_query* queries, int q_begin, int q_end, PlanPiece& pc, uint32_t* q_qs_begin,
                             uint32_t* q_qs_cnt, uint32_t* qs_begin, DQExpand* qexpand,
                             std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, int prune,
-                            std::vector<int64_t>& q_lower, std::vector<uint8_t>& q_exact) {
+                            std::vector<int64_t>& q_lower, std::vector<uint8_t>& q_route) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
   std::vector<const TermLeaves*> ents;
   std::vector<int64_t> slice_sum((size_t)std::max(n_slices, 1));
-  bool any_deleted = false, folded = true;   // folded: every leaf's deletes (if any) are coded into its posting columns
-  for (int si = 0; si < n_segs; ++si) {
-    any_deleted = any_deleted || n_deleted[si] != 0;
-    folded = folded && (segs[si]->d_live == nullptr || segs[si]->live_folded);
-    // (liveDocs that are not folded into the postings -- packed layout, forked reader versions, NRTGPU_FLAG_NO_LIVE_FOLD --
-    //  are a mask the MaxScore kernel tests when a doc's score is complete: no obstacle to the route)
-  }
+  bool any_deleted = false;
+  for (int si = 0; si < n_segs; ++si) any_deleted = any_deleted || n_deleted[si] != 0;
+  // (liveDocs that are not folded into the postings -- packed layout, forked reader versions, NRTGPU_FLAG_NO_LIVE_FOLD --
+  //  are a mask the MaxScore kernel tests when a doc's score is complete: no obstacle to the route)
   size_t prev_cache_off = 0, prev_cache_len = 0;
   pc.qterms.reserve((size_t)(q_end - q_begin) * 6);
   pc.qs.reserve((size_t)(q_end - q_begin) * (size_t)std::max(n_segs, 1));
@@ -306,55 +303,58 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     for (int t = 0; t < q.n_terms && fx_ok; ++t)  // 32-bit entries shifted into the common scale, summed over
       if (term_total[(size_t)t] != 0 && fx_E - term_scale[(size_t)t] > 15) fx_ok = false;  // <= 32 clauses: < 2^53
     if (!fx_ok) fx_E = kNoFixed;
-    // MaxScore route (maxscore.hip)?  Its hit count is a lower bound, so -- like Lucene, which starts skipping only
-    // once totalHits has passed the threshold (LazyQueueTopScoreDocCollector.java:176-199) -- it is taken only when
-    // more than max(totalHitsThreshold, numHits) live docs certainly match: some clause has that many postings left
-    // after discounting every deleted doc of its segments.  Needs the exact fixed-point sums and a plain disjunction
-    // (liveDocs are folded into the postings or tested as a mask by the kernel).
+    // MaxScore route (maxscore.hip)?  Any disjunction of up to kMsMaxTerms clauses with the exact fixed-point sums -- plain,
+    // with a FILTER / MUST_NOT doc set, with minimumNumberShouldMatch, or a DisjunctionMaxQuery -- unless a bound from
+    // outside (min_competitive_score) makes the count's meaning the caller's business.  The mode says when bounds may skip
+    // (plan.h: kMsMode*): like Lucene, which starts skipping only once a collector's totalHits has passed the threshold
+    // (LazyQueueTopScoreDocCollector.java:176-199).
+    //   * the planner KNOWS that some slice passes max(totalHitsThreshold, numHits) -- some clause has that many postings
+    //     left in it after discounting every deleted doc of the slice's leaves, and nothing else narrows the hits: skipping
+    //     from the start, the certain lower bound is what is reported;
+    //   * it cannot know (few postings, a mask, a clause count): the kernel counts exactly until a slice passes;
+    //   * ScoreMode.COMPLETE: nothing may ever be skipped -- worth it only for a small query, for which the exhaustive scan
+    //     would walk every sub-tile of the shard for a handful of postings.
     int64_t lower = 0;
-    if (prune != 0 && !(prune == 2 && q.has_after) && fx_ok && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 && q.disjunction_max == 0 && q.filter_mask == 0 && q.must_not_mask == 0 &&
-        !(q.min_competitive_score > 0.0f) && q.total_hits_threshold != INT32_MAX) {
-      {
-        // the reference counts per slice (one collector each): some slice must certainly pass the threshold
-        const int64_t floor_ = std::max<int64_t>(q.total_hits_threshold, q.k);
-        int64_t best_slice = 0;
-        for (int t = 0; t < q.n_terms; ++t) {
-          const uint32_t* cnt = ents[(size_t)t]->count.data();
-          int64_t certain = 0;
-          if (n_slices <= 1) {
-            certain = term_total[(size_t)t];
-            if (any_deleted) {
-              certain = 0;
-              for (int si = 0; si < n_segs; ++si) certain += std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
+    uint8_t route = kRouteScan;
+    if (prune != 0 && fx_ok && q.n_terms <= kMsMaxTerms && !(q.min_competitive_score > 0.0f)) {
+      const bool shaped = q.min_should_match > 1 || q.filter_mask != 0 || q.must_not_mask != 0;
+      if (q.total_hits_threshold == INT32_MAX) {
+        int64_t all = 0;
+        for (int t = 0; t < q.n_terms; ++t) all += term_total[(size_t)t];
+        if (all > 0 && all <= kMsExactMaxPostings) route = kRouteMs + (uint8_t)kMsModeExact;
+      } else {
+        if (!shaped) {
+          // the reference counts per slice (one collector each): some slice must certainly pass the threshold
+          const int64_t floor_ = std::max<int64_t>(q.total_hits_threshold, q.k);
+          int64_t best_slice = 0;
+          for (int t = 0; t < q.n_terms; ++t) {
+            const uint32_t* cnt = ents[(size_t)t]->count.data();
+            int64_t certain = 0;
+            if (n_slices <= 1) {
+              certain = term_total[(size_t)t];
+              if (any_deleted) {
+                certain = 0;
+                for (int si = 0; si < n_segs; ++si) certain += std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
+              }
+              best_slice = std::max(best_slice, certain);
+            } else {
+              std::fill(slice_sum.begin(), slice_sum.end(), 0);
+              for (int si = 0; si < n_segs; ++si) {
+                const int64_t c = std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
+                slice_sum[(size_t)slice_of_leaf[si]] += c;
+                certain += c;
+              }
+              for (int sl = 0; sl < n_slices; ++sl) best_slice = std::max(best_slice, slice_sum[(size_t)sl]);
             }
-            best_slice = std::max(best_slice, certain);
-          } else {
-            std::fill(slice_sum.begin(), slice_sum.end(), 0);
-            for (int si = 0; si < n_segs; ++si) {
-              const int64_t c = std::max<int64_t>(0, (int64_t)cnt[si] - n_deleted[si]);
-              slice_sum[(size_t)slice_of_leaf[si]] += c;
-              certain += c;
-            }
-            for (int sl = 0; sl < n_slices; ++sl) best_slice = std::max(best_slice, slice_sum[(size_t)sl]);
+            lower = std::max(lower, certain);   // what is reported: certain matches of the whole search
           }
-          lower = std::max(lower, certain);   // what is reported: certain matches of the whole search
+          if (best_slice <= floor_) lower = 0;
         }
-        if (best_slice <= floor_) lower = 0;
+        route = kRouteMs + (uint8_t)(lower > 0 ? kMsModePrune : kMsModeCount);
       }
     }
     q_lower[(size_t)qi] = lower;
-    // Not certain to pass the threshold (or the exact count is wanted: COMPLETE), but SMALL: the MaxScore kernel in EXACT mode
-    // -- nothing skipped, every matching doc evaluated and counted -- answers like the exhaustive scan without walking every
-    // sub-tile of the shard for a handful of postings.  (Deletes must be folded into the postings: the count is taken
-    // before a mask would be consulted.)
-    bool exact = false;
-    if (lower == 0 && prune != 0 && !(prune == 2 && q.has_after) && fx_ok && folded && q.n_terms <= kMsMaxTerms && q.min_should_match <= 1 &&
-        q.disjunction_max == 0 && q.filter_mask == 0 && q.must_not_mask == 0 && !(q.min_competitive_score > 0.0f)) {
-      int64_t all = 0;
-      for (int t = 0; t < q.n_terms; ++t) all += term_total[(size_t)t];
-      exact = all > 0 && all <= kMsExactMaxPostings;
-    }
-    q_exact[(size_t)qi] = exact ? 1 : 0;
+    q_route[(size_t)qi] = route;
     tab_of_term.assign((size_t)q.n_terms, -1);
     QTabs& qt_ = qtabs[(size_t)qi];
     qt_.n = 0;
@@ -373,7 +373,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     // the compact plan of the query: one DQTerm per clause that matches anything, and per leaf how many of them it holds
     DQExpand& qx = qexpand[(size_t)qi];
     qx.term_begin = (uint32_t)pc.qterms.size();
-    qx.by_weight = (lower > 0 || exact) ? 1u : 0u;
+    qx.by_weight = route != kRouteScan ? 1u : 0u;
     qx.pad = 0;
     const uint32_t* cnt_of[kMaxTerms];
     uint32_t n_live = 0;
@@ -448,7 +448,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     if ((ctx->cfg.flags & (NRTGPU_FLAG_NO_PRUNE | NRTGPU_FLAG_NO_FIXED_POINT)) != 0 || !(variant == 0 || variant == 7)) prune = 0;
   }
   hp.q_lower.assign((size_t)n_queries, 0);
-  hp.q_exact.assign((size_t)n_queries, 0);
+  hp.q_route.assign((size_t)n_queries, kRouteScan);
   hp.lsc = leaf_set_cache(ctx, segs, n_segs);
   hp.n_leaves = (uint32_t)n_segs;
   hp.qexpand.resize((size_t)n_queries);
@@ -475,7 +475,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   }
   auto work = [&](int t) {
     resolve_queries(*hp.lsc, segs, n_segs, n_deleted.data(), slice_of_leaf.data(), n_slices, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t],
-                    q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower, hp.q_exact);
+                    q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower, hp.q_route);
   };
   ctx->pool->run(n_thr, work);
   const double tp1 = plan_trace ? now_ms() : 0.0;
@@ -511,17 +511,24 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // the (query, leaf) pairs of query qi
   auto qs_of = [&](int qi) { return pieces[(size_t)piece_of[(size_t)qi]].qs.data() + q_qs_begin[(size_t)qi]; };
   hp.postings = total_postings;
+  auto on_ms_kernel = [&](uint32_t q_) { return hp.q_route[q_] != kRouteScan; };
+  // (the accumulator form is a property of the exhaustive scan's launch; the MaxScore route only takes fixed-point queries)
   hp.fixed_point = (ctx->cfg.flags & NRTGPU_FLAG_NO_FIXED_POINT) == 0;
   for (int qi = 0; qi < n_queries && hp.fixed_point; ++qi)
-    if (q_qs_cnt[(size_t)qi] != 0 && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
+    if (!on_ms_kernel((uint32_t)qi) && q_qs_cnt[(size_t)qi] != 0 && qtabs[(size_t)qi].fx_E == kNoFixed) hp.fixed_point = false;
   for (int qi = 0; qi < n_queries; ++qi)
-    if (hp.q_lower[(size_t)qi] > 0 || hp.q_exact[(size_t)qi])
+    if (on_ms_kernel((uint32_t)qi))
       for (uint32_t j = 0; j < q_qs_cnt[(size_t)qi]; ++j) hp.ms_postings += qs_of(qi)[j].postings;
-  // minimumNumberShouldMatch > 1 (QueryNodeMapper.java:259-261): the clause count rides in the fixed-point
-  // accumulator, so the whole batch must be in fixed-point mode; otherwise the caller runs Lucene's WANDScorer
+  // Exhaustive scan, minimumNumberShouldMatch > 1 (QueryNodeMapper.java:259-261) / DisjunctionMaxQuery: the clause count rides
+  // in the fixed-point accumulator, so the scan's whole launch must be in fixed-point mode; otherwise the caller runs Lucene
   hp.clause_counting = false;
-  for (int qi = 0; qi < n_queries; ++qi)
-    if (queries[qi].min_should_match > 1 || queries[qi].disjunction_max == 1) hp.clause_counting = true;   // (the query-shapes variant)
+  hp.ms_shapes = false;
+  for (int qi = 0; qi < n_queries; ++qi) {
+    const nrtgpu_bm25_query& q = queries[qi];
+    if (q.min_should_match > 1 || q.disjunction_max == 1) (on_ms_kernel((uint32_t)qi) ? hp.ms_shapes : hp.clause_counting) = true;
+    if ((q.filter_mask != 0 || q.must_not_mask != 0) && on_ms_kernel((uint32_t)qi)) hp.ms_shapes = true;
+  }
+  hp.n_slices = (uint32_t)n_slices;
   if (hp.clause_counting && !hp.fixed_point)
     return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 / DisjunctionMaxQuery need the fixed-point accumulators (weights of "
                                         "a query in this batch span too many binades, or NRTGPU_FLAG_NO_FIXED_POINT is set)");
@@ -534,8 +541,9 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // batch on one CU.  target_items == 0 => one share per CU.
   const int64_t target_items = ctx->cfg.target_items > 0 ? ctx->cfg.target_items : (int64_t)std::max(ctx->n_cus, 1);
   const int64_t min_item_cost = 1 << 17;
-  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; uint32_t slice; };
-  const uint32_t kAnySlice = 0xFFFFFFFFu;
+  // An item counts its hits per searcher slice (plan.h: kSliceSlots): at most that many distinct slices per item; the
+  // (query, leaf) pairs of a query are visited slice by slice so that a slice's parts are neighbours.
+  struct Pending { int64_t cost; uint32_t query; uint32_t part_begin, n_parts; uint32_t tiles; int32_t first_slice, last_slice; uint32_t n_slices; };
   std::vector<Pending> pend;
   std::vector<int64_t> q_costs((size_t)n_queries, 0), q_items((size_t)n_queries, 0);
   for (int qi = 0; qi < n_queries; ++qi)
@@ -562,30 +570,26 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       if (q_cost == 0) continue;
       const int64_t n_it = q_items[(size_t)qi];
       const double budget = (double)q_cost / (double)n_it;
-      // The relation of an exhaustively scanned query with a finite threshold is decided per slice (slice_relation_kernel):
-      // its items then never span two slices.  COMPLETE mode never reports GTE and the MaxScore route tags its own items.
-      const bool per_slice = n_slices > 1 && hp.q_lower[(size_t)qi] == 0 && queries[qi].total_hits_threshold != INT32_MAX;
       const QS* qsv = qs_of(qi);
       const uint32_t n_qs = q_qs_cnt[(size_t)qi];
-      if (per_slice) {
+      if (n_slices > 1) {
         by_slice.assign(qsv, qsv + n_qs);
         std::stable_sort(by_slice.begin(), by_slice.end(), [&](const QS& a, const QS& b) { return slice_of_leaf[(size_t)a.seg] < slice_of_leaf[(size_t)b.seg]; });
         qsv = by_slice.data();
       }
-      auto slice_of = [&](const QS& qs) { return n_slices > 1 && hp.q_lower[(size_t)qi] == 0 ? (uint32_t)slice_of_leaf[(size_t)qs.seg]
-                                                                                           : (n_slices > 1 ? kAnySlice : 0u); };
-      Pending cur{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, n_qs ? slice_of(qsv[0]) : 0u};
+      const bool scan_route = hp.q_route[(size_t)qi] == kRouteScan;
+      Pending cur{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, -1, -1, 0};
       double filled = 0.0;
+      auto close_item = [&]() {
+        pend.push_back(cur);
+        cur = Pending{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, -1, -1, 0};
+        filled = 0.0;
+      };
       for (uint32_t j = 0; j < n_qs; ++j) {
         const QS& qs = qsv[j];
         const nrtgpu_seg* seg = segs[qs.seg];
-        if (per_slice && cur.n_parts > 0 && slice_of(qs) != cur.slice) {  // slice boundary: close the item
-          pend.push_back(cur);
-          cur = Pending{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, slice_of(qs)};
-          filled = 0.0;
-        }
-        if (cur.n_parts == 0) cur.slice = slice_of(qs);
-        else if (!per_slice && slice_of(qs) != cur.slice) cur.slice = kAnySlice;
+        const int32_t sl = slice_of_leaf[(size_t)qs.seg];
+        if (cur.n_parts > 0 && sl != cur.last_slice && cur.n_slices == (uint32_t)kSliceSlots) close_item();  // no slot left for another slice
         const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
         const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
         if (int rc = accept_set_of(seg, queries[qi].filter_mask, queries[qi].must_not_mask, &accept)) { cut_rc = rc; return; }
@@ -594,9 +598,11 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
           double room = budget - filled;
           uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tile_cost + 0.5));
           take = std::min<uint32_t>(take, seg->n_tiles - tb);
+          if (cur.n_parts == 0) cur.first_slice = sl;
+          if (sl != cur.last_slice) { cur.n_slices++; cur.last_slice = sl; }
           DPart p{};
           p.live_bits = accept;
-          if (accept) masked = true;
+          if (accept && scan_route) masked = true;
           p.term_begin = qs.term_begin;
           p.n_terms = qs.n_terms;
           p.tile_begin = tb;
@@ -604,17 +610,14 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
           p.max_doc = (uint32_t)seg->max_doc;
           p.doc_base = doc_bases ? doc_bases[qs.seg] : 0;
           p.tile_offset = cur.tiles;
+          p.slice = (uint32_t)sl;   // (the slot is assigned once the items are final, below)
           parts.push_back(p);
           cur.n_parts++;
           cur.tiles += take;
           cur.cost += (int64_t)(take * tile_cost);
           filled += take * tile_cost;
           tb += take;
-          if (filled >= budget * 0.999) {  // item full: close it
-            pend.push_back(cur);
-            cur = Pending{0, (uint32_t)qi, (uint32_t)parts.size(), 0, 0, slice_of(qs)};
-            filled = 0.0;
-          }
+          if (filled >= budget * 0.999) close_item();  // item full
         }
       }
       if (cur.n_parts > 0) {
@@ -622,16 +625,27 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
         // finish without a single compaction, never publish its quantile, and with one peer silent the bound
         // exchange between the query's items never forms (kernels.hip: peers_bound).  It joins the item before it.
         if (!pend.empty() && pend.back().query == (uint32_t)qi && (double)cur.cost < 0.5 * budget &&
-            pend.back().part_begin + pend.back().n_parts == cur.part_begin && (!per_slice || pend.back().slice == cur.slice)) {
+            pend.back().part_begin + pend.back().n_parts == cur.part_begin &&
+            pend.back().n_slices + cur.n_slices - (pend.back().last_slice == cur.first_slice ? 1u : 0u) <= (uint32_t)kSliceSlots) {
           Pending& prev = pend.back();
           for (uint32_t pi2 = 0; pi2 < cur.n_parts; ++pi2) parts[cur.part_begin + pi2].tile_offset += prev.tiles;
+          prev.n_slices += cur.n_slices - (prev.last_slice == cur.first_slice ? 1u : 0u);
+          prev.last_slice = cur.last_slice;
           prev.n_parts += cur.n_parts;
           prev.tiles += cur.tiles;
           prev.cost += cur.cost;
-          if (prev.slice != cur.slice) prev.slice = kAnySlice;
         } else {
           pend.push_back(cur);
         }
+      }
+    }
+    // the slot of every part: the running number of its slice among the item's slices (a slice's parts are neighbours)
+    for (const Pending& a : pend) {
+      uint32_t slot = 0;
+      for (uint32_t pi2 = 0; pi2 < a.n_parts; ++pi2) {
+        DPart& p = parts[a.part_begin + pi2];
+        if (pi2 > 0 && p.slice != (parts[a.part_begin + pi2 - 1].slice & 0xFFFFFFu)) ++slot;
+        p.slice |= slot << 24;
       }
     }
   };
@@ -654,17 +668,10 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
   std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.cost > b.cost; });
   // the items of the queries on the MaxScore route first: they run in a launch of their own
-  auto on_ms_kernel = [&](uint32_t q_) { return hp.q_lower[q_] > 0 || hp.q_exact[q_] != 0; };
   std::stable_partition(pend.begin(), pend.end(), [&](const Pending& a) { return on_ms_kernel(a.query); });
   hp.n_ms_items = 0;
   for (const Pending& a : pend) hp.n_ms_items += on_ms_kernel(a.query) ? 1u : 0u;
   hp.items.resize(pend.size());
-  hp.item_slice.resize(pend.size());
-  for (size_t i = 0; i < pend.size(); ++i) hp.item_slice[i] = hp.q_lower[pend[i].query] > 0 ? kAnySlice : pend[i].slice;
-  hp.q_gte_floor.resize((size_t)n_queries);
-  for (int qi = 0; qi < n_queries; ++qi)   // COMPLETE mode: nothing exceeds it
-    hp.q_gte_floor[(size_t)qi] = queries[qi].total_hits_threshold == INT32_MAX ? 0xFFFFFFFFu
-                                                                               : (uint32_t)std::max(queries[qi].total_hits_threshold, queries[qi].k);
   // the items of a query, in launch order: counting sort by query (q_base = first slot of the query's list)
   hp.q_base.assign((size_t)n_queries, 0);
   hp.q_nlists.assign((size_t)n_queries, 0);
@@ -691,7 +698,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       it.tab_scale[r] = qt_.scale[r];
     }
     it.peer_slot = hp.q_base[pend[i].query] + q_fill[pend[i].query]++;
-    it.flags = hp.q_exact[pend[i].query] ? 1u : 0u;
+    it.flags = on_ms_kernel(pend[i].query) ? (uint32_t)(hp.q_route[pend[i].query] - kRouteMs) : 0u;
     hp.items[i] = it;
     hp.list_idx[it.peer_slot] = (uint32_t)i;
   }
@@ -707,6 +714,10 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     dq.n_items = hp.q_nlists[(size_t)qi];
     dq.min_should_match = (uint32_t)std::max(q.min_should_match, 0);
     dq.combine_max = q.disjunction_max == 1 ? 1u : 0u;
+    // what a slice's hits must exceed for GREATER_THAN_OR_EQUAL_TO; COMPLETE mode: nothing does
+    dq.gte_floor = q.total_hits_threshold == INT32_MAX ? 0xFFFFFFFFu : (uint32_t)std::max(q.total_hits_threshold, q.k);
+    dq.slice_base = (uint32_t)qi * hp.n_slices;
+    dq.pad[0] = dq.pad[1] = 0;
   }
   if (plan_trace)
     fprintf(stderr, "[nrtgpu plan] %d queries: resolve %.3f ms (%d threads), concat %.3f, cut+items %.3f; %zu terms %zu parts %zu items\n",

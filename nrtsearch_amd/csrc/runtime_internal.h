@@ -38,19 +38,20 @@
 namespace nrtgpu {
 void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool packed, int ablation, uint32_t n_items, const DItem* items,
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                      unsigned long long* quant_g, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
+                      unsigned long long* quant_g, const DExchange* xch, uint32_t* slice_sum, uint64_t* item_keys, uint32_t* item_counts,
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
-void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, uint32_t n_items, const DItem* items, const DPart* parts,
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, uint32_t n_items, const DItem* items, const DPart* parts,
                           const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                          uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
+                          uint32_t* slice_sum, uint32_t* q_prune, uint64_t* item_keys, uint32_t* item_counts, uint64_t* item_hits,
+                          uint32_t k_stride, uint64_t* item_prof);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
                           const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
                       const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs);
 void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* qterms, const uint32_t* out_begin, uint32_t n_queries,
                          uint32_t n_leaves, DTerm* out);
-void launch_slice_relation(hipStream_t stream, const uint64_t* item_hits, const uint32_t* item_slice, const uint32_t* list_idx,
-                           const uint32_t* q_base, const uint32_t* q_nlists, const uint32_t* q_floor, uint64_t* out_hits, uint32_t n);
+void launch_slice_relation(hipStream_t stream, const uint32_t* slice_sum, const DQuery* queries, uint32_t n_slices, uint64_t* out_hits,
+                           uint32_t n);
 void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits, uint32_t n);
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
@@ -498,17 +499,18 @@ struct HostPlan {
   uint32_t k_stride = 0;
   int64_t postings = 0;             // postings in the scanned term ranges (algorithmic work)
   bool fixed_point = false;         // every query of the batch passed the fixed-point range analysis
-  bool clause_counting = false;     // some query has minimumNumberShouldMatch > 1: count-carrying kernel variant
-  bool masked = false;              // some part reads a doc-set mask (liveDocs / FILTER / MUST_NOT)
+  bool clause_counting = false;     // exhaustive scan: some query has minimumNumberShouldMatch > 1 / is a DisjunctionMaxQuery: count-carrying variant
+  bool masked = false;              // exhaustive scan: some part reads a doc-set mask (liveDocs / FILTER / MUST_NOT)
+  bool ms_shapes = false;           // MaxScore route: some query has a FILTER / MUST_NOT mask, minimumNumberShouldMatch > 1 or is a DisjunctionMaxQuery
+  uint32_t n_slices = 1;            // searcher slices over the call's leaves (MyIndexSearcher.slices): per query that many hit sums
   // MaxScore route (maxscore.hip): items [0, n_ms_items) run it, the others the exhaustive scan
   uint32_t n_ms_items = 0;
-  std::vector<int64_t> q_lower;     // per query on that route: live docs certain to match (> totalHitsThreshold), else 0
-  std::vector<uint8_t> q_exact;     // per query: runs in the MaxScore kernel in EXACT mode (small; counted like an exhaustive scan)
-  std::vector<uint32_t> item_slice; // per item: the slice (MyIndexSearcher.slices) its parts belong to; ~0: several (no relation from it)
-  std::vector<uint32_t> q_gte_floor;  // per query: max(totalHitsThreshold, numHits), what a slice's hits must exceed for GTE
+  std::vector<int64_t> q_lower;     // per query on that route in kMsModePrune: live docs certain to match (> totalHitsThreshold), else 0
+  std::vector<uint8_t> q_route;     // per query: kRouteScan (exhaustive scan) or kRouteMs + its kMsMode* (plan.h)
   int64_t ms_postings = 0;          // postings of the queries on that route (algorithmic work, as `postings`)
 };
 
+const uint8_t kRouteScan = 0, kRouteMs = 1;   // HostPlan.q_route: kRouteMs + kMsMode*
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 int validate_query(const nrtgpu_bm25_query& q, int qi);
 // fixed-point eligibility of one query term: the scale 2^E at which all its scores are integers < 2^32

@@ -40,8 +40,6 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_theta = pc.take(hp.theta_init.size() * 8);  // uploaded with the plan, then updated by the kernel
   const size_t o_quant = pc.take(hp.list_idx.size() * 8);    // per item: published quantile bound (zeros)
   const size_t o_lower = pc.take(ext_hits ? hp.q_lower.size() * 8 : 0);  // device-resident results: certain lower bounds
-  const size_t o_islice = pc.take(hp.item_slice.size() * 4);
-  const size_t o_floor = pc.take(hp.q_gte_floor.size() * 4);
   const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
   const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
   const size_t plan_bytes = pc.off;
@@ -62,8 +60,6 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
   memset(hb + o_quant, 0, hp.list_idx.size() * 8);
   if (ext_hits) memcpy(hb + o_lower, hp.q_lower.data(), hp.q_lower.size() * 8);
-  if (!hp.item_slice.empty()) memcpy(hb + o_islice, hp.item_slice.data(), hp.item_slice.size() * 4);
-  memcpy(hb + o_floor, hp.q_gte_floor.data(), hp.q_gte_floor.size() * 4);
   if (use_xch) {
     DExchange x{};
     const size_t stride = (size_t)ctx->cfg.max_batch;
@@ -84,6 +80,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_ocnt = wc.take((size_t)n_queries * 4);
   const size_t o_ohits = wc.take((size_t)n_queries * 8);
   const size_t o_terms = wc.take((size_t)hp.n_dterms * sizeof(DTerm));  // written by expand_terms_kernel
+  // per (query, searcher slice) the hits its items counted, per query "some item's slice has passed the floor": zeroed per call
+  const size_t o_ssum = wc.take((size_t)n_queries * hp.n_slices * 4), o_qprune = wc.take((size_t)n_queries * 4);
+  const size_t zero_bytes = wc.off - o_ssum;
   // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
   const int flag_variant = (ctx->cfg.flags >> 8) & 15;
   const int ablation = hp.clause_counting ? 8 : ((hp.masked && flag_variant == 0 && !(ctx->cfg.flags & NRTGPU_FLAG_NO_MASK_VARIANT)) ? 9 : flag_variant);
@@ -95,6 +94,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
 
   hipStream_t st = slot->stream;
   HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(wb + o_ssum, 0, zero_bytes, st));
   const bool timing = ctx->cfg.collect_timing != 0;
   // the queries on the MaxScore route (items [0, n_ms)), then the exhaustive scan of the others
   const size_t n_ms = hp.n_ms_items;
@@ -104,16 +104,16 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   gpu.lock();
   if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
-  launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
+  launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, hp.ms_shapes, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                        (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
-                       (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
+                       (uint32_t*)(wb + o_ssum), (uint32_t*)(wb + o_qprune), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
                        profile ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, ablation, (uint32_t)(n_items - n_ms),
                    (const DItem*)(db + o_items) + n_ms, (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                    (const DQuery*)(db + o_queries), (const float*)(db + o_caches),
                    (unsigned long long*)(db + o_theta), (unsigned long long*)(db + o_quant),
-                   use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys) + n_ms * (size_t)hp.k_stride,
+                   use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint32_t*)(wb + o_ssum), (uint64_t*)(wb + o_ikeys) + n_ms * (size_t)hp.k_stride,
                    (uint32_t*)(wb + o_icnt) + n_ms, (uint64_t*)(wb + o_ihits) + n_ms, hp.k_stride,
                    ablation == 7 ? (uint64_t*)(wb + o_prof) + n_ms * 16 : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
@@ -125,9 +125,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                     (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
                     k_stride_out);
   // TotalHits.relation by the reference's per-slice rule, tagged into the merged counts
-  launch_slice_relation(st, (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_islice), (const uint32_t*)(db + o_lidx),
-                        (const uint32_t*)(db + o_qbase), (const uint32_t*)(db + o_qnl), (const uint32_t*)(db + o_floor), ohits,
-                        (uint32_t)n_queries);
+  launch_slice_relation(st, (const uint32_t*)(wb + o_ssum), (const DQuery*)(db + o_queries), hp.n_slices, ohits, (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
   if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
   // (the merge belongs to the turn: behind the next batch's scorers it would wait for a free CU until they drain, and this
@@ -425,9 +423,9 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
   if (!ctx || !q || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_segs must be >= 0");
   if (int rc = validate_query(*q, 0)) return rc;  // a bad request must not fail its batch mates
-  if (q->min_should_match > 1)  // whether it can run depends on the whole batch (fixed-point mode): use the batch call
-    return fail(NRTGPU_ERR_UNSUPPORTED, "minimumNumberShouldMatch > 1 is not coalesced");
-  if (q->disjunction_max != 0) return fail(NRTGPU_ERR_UNSUPPORTED, "a DisjunctionMaxQuery is not coalesced");
+  // (minimumNumberShouldMatch > 1 / DisjunctionMaxQuery: on the MaxScore route they run next to anything; where one of them needs
+  //  the exhaustive scan's count-carrying variant and a batch mate forces fp64 sums, the batch fails as a whole and is re-run
+  //  member by member below: only the offender sees NRTGPU_ERR_UNSUPPORTED)
   for (int si = 0; si < n_segs; ++si) {
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
     if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);

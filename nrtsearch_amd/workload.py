@@ -39,13 +39,45 @@ def shard_range(n_docs: int, world: int, rank: int):
     return lo, hi
 
 
-def build_shard_corpus(w: Workload, queries: np.ndarray, world: int = 1, rank: int = 0, seed: int = 1234):
+def shard_leaves(w: Workload, world: int, rank: int, layout: str = "index"):
+    """The leaves of `rank`'s shard as (lo, hi, sizes): its docid range and the sizes of its leaves, in docid order.
+    layout "index" (default): the INDEX has `segments_per_shard` tiered segments (what one GPU holds at world 1) and a rank
+    owns the pieces of them that fall into its docid range -- large segments are cut by docid range like a
+    LeafReaderContextPartition, so most ranks of an 8-GPU job hold one piece of a big segment and the last one the small
+    segments.  layout "per_shard" (rounds 1-2): every rank's range is cut into `segments_per_shard` tiered segments of its own."""
+    lo, hi = shard_range(w.n_docs, world, rank)
+    if world > 1 and layout == "index":
+        # a range boundary that falls next to a segment boundary (within 1 % of a shard) is moved onto it: no slivers
+        edges = np.cumsum(synth.tiered_segment_sizes(w.n_docs, w.segments_per_shard))[:-1]
+        per = shard_range(w.n_docs, world, 0)[1]
+
+        def snap(x):
+            if 0 < x < w.n_docs and len(edges):
+                e = int(edges[np.argmin(np.abs(edges - x))])
+                if abs(e - x) <= per // 100:
+                    return e
+            return x
+
+        lo, hi = snap(lo), snap(hi)
+    if hi <= lo:
+        return lo, hi, []
+    if world <= 1 or layout == "per_shard":
+        return lo, hi, synth.tiered_segment_sizes(hi - lo, w.segments_per_shard)
+    sizes, base = [], 0
+    for g in synth.tiered_segment_sizes(w.n_docs, w.segments_per_shard):
+        a, b = max(base, lo), min(base + g, hi)
+        if b > a:
+            sizes.append(b - a)
+        base += g
+    return lo, hi, sizes
+
+
+def build_shard_corpus(w: Workload, queries: np.ndarray, world: int = 1, rank: int = 0, seed: int = 1234, layout: str = "index"):
     """Corpus restricted to this rank's docid range, with index-global statistics."""
     ranks = sorted(set(int(r) for r in queries.reshape(-1)))
     lens = synth.doc_lengths(w.n_docs, seed)
     norms_all = synth.int_to_byte4(lens)
-    lo, hi = shard_range(w.n_docs, world, rank)
-    sizes = synth.tiered_segment_sizes(hi - lo, w.segments_per_shard) if hi > lo else []
+    lo, hi, sizes = shard_leaves(w, world, rank, layout)
     bases = np.concatenate([[lo], lo + np.cumsum(sizes)]).astype(np.int64)
     per_docs: List[List[np.ndarray]] = [[] for _ in sizes]
     per_freqs: List[List[np.ndarray]] = [[] for _ in sizes]
