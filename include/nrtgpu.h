@@ -405,8 +405,11 @@ void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
 int  nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16);
 /* the same flag, items of the MaxScore route; sums over items since the last reset: [0] doc windows walked, [1] top-k
  * compactions, [2] posting chunks (512 postings), [3] postings streamed, [4] postings whose bound reached theta,
- * [5] docs evaluated, [6] lookups in later clauses, [7] candidates collected */
-int  nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out8);
+ * [5] docs evaluated, [6] lookups in later clauses, [7] candidates collected; shader-clock cycles: [8] item prologue,
+ * [9] whole item, [10] waves in meetings (waiting + compaction), [11] waves out of windows waiting for the item's end,
+ * [12] waves in part prologues, [13] waves walking windows, [14] the item's last wave running out of windows, [15] item
+ * epilogue ([10]-[13]: summed over the item's 12 waves) */
+int  nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out16);
 
 #ifdef __cplusplus
 }

@@ -206,10 +206,11 @@ class GpuContext:
         return dict(zip(names, out.tolist()))
 
     def maxscore_profile(self) -> dict:
-        out = np.zeros(8, dtype=np.float64)
+        out = np.zeros(16, dtype=np.float64)
         _lib.check(_lib.load().nrtgpu_get_maxscore_profile(self._h, out.ctypes.data))
         names = ["windows", "compactions", "chunks", "postings_streamed", "postings_surviving", "docs_evaluated", "lookups",
-                 "candidates"]
+                 "candidates", "prologue_cycles", "item_cycles", "waves_meeting_cycles", "waves_idle_cycles", "waves_part_prologue_cycles",
+                 "waves_walk_cycles", "last_wave_out_cycles", "epilogue_cycles"]
         return dict(zip(names, out.tolist()))
 
     def reset_stats(self) -> None:

@@ -77,7 +77,7 @@ struct MsSmem {
   uint32_t prune_on;     // bounds may skip work (kMsModeCount: raised once a slice's count has passed the query's gte_floor)
   uint32_t slot_hits[kSliceSlots];   // live matching docs evaluated, per searcher slice the item touches (plan.h: DPart.slice)
   uint32_t slot_slice[kSliceSlots];  // which slice a slot stands for
-  uint64_t prof[8];
+  uint64_t prof[16];
 };
 static_assert(sizeof(MsSmem) <= 160 * 1024, "the MaxScore workgroup owns one CU's 160 KiB LDS");
 
@@ -181,8 +181,12 @@ __device__ __forceinline__ bool ms_reserve(MsSmem& s, uint32_t lane, uint32_t mi
   return wbase + wave_total <= (uint32_t)kMsCandCap;
 }
 
-// PROF: per-item event counters (nrtgpu_get_scan_profile): [0] windows, [1] compactions, [2] posting chunks,
-// [3] postings streamed, [4] postings surviving the bound, [5] docs evaluated, [6] lookups, [7] candidates.
+// PROF: per-item event counters (nrtgpu_get_maxscore_profile): [0] windows, [1] compactions, [2] posting chunks,
+// [3] postings streamed, [4] postings surviving the bound, [5] docs evaluated, [6] lookups, [7] candidates; shader-clock
+// cycles: [8] item prologue (tables), [9] the whole item, [10] sum over waves of the cycles spent in meetings (waiting +
+// compaction), [11] sum over waves of the cycles between running out of windows and the item's end, [12] sum over waves of
+// part prologues (clause maxima), [13] sum over waves of the window walk (stream + lookups + candidates), [14] the last
+// wave's cycle of running out of windows, [15] item epilogue.
 // PACKED: the segments keep one 32-bit word per posting (plan.h: kPack*).  liveDocs that are not folded into the
 // postings (part.live_bits != nullptr) are tested when a doc's score is complete.
 // SHAPES: the batch holds queries with a doc-set mask next to their scoring clauses (FILTER / MUST_NOT,
@@ -234,8 +238,10 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     s.next_win = (uint32_t)kMsWaves;
     s.prune_on = mode == kMsModePrune ? 1u : 0u;
     for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
-    for (int i = 0; i < 8; ++i) s.prof[i] = 0;
+    for (int i = 0; i < 16; ++i) s.prof[i] = 0;
   }
+  const uint64_t t_item0 = PROF ? __builtin_readcyclecounter() : 0ull;
+  uint64_t tc_meet = 0, tc_part = 0, tc_walk = 0;
   __syncthreads();
   for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
     const float w = items[blockIdx.x].tab_weight[slot];
@@ -245,6 +251,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       s.tab[slot][e] = e < (uint32_t)kTabNorms ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
   }
   __syncthreads();  // from here on the waves run on their own
+  if (PROF && tid == 0) s.prof[8] = __builtin_readcyclecounter() - t_item0;
 
   uint32_t* const seen = &s.seen[wave][0];
   WClause* const wcl = &s.wc[wave][0];
@@ -285,6 +292,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     // ---- per part: lane l looks after clause l: its exact maximum score in this segment, suffix sums, and the
     //      clause's record in the wave's LDS table (what a lane needs to stream or look up clause l)
     uint64_t my_ub = 0, my_suf = 0;
+    const uint64_t t_part0 = PROF ? __builtin_readcyclecounter() : 0ull;
     const DTerm mt = part_terms[min(lane, n_terms - 1u)];
     {
       // 16 lanes per clause, four clauses per pass: lane (g, i) evaluates frontier entry i of clause 4 * pass + g -- two
@@ -342,8 +350,10 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       w.start = mt.start;
       wcl[lane] = w;
     }
+    if (PROF) tc_part += __builtin_readcyclecounter() - t_part0;
 
     for (;;) {  // windows of this part
+      const uint64_t t_win0 = PROF ? __builtin_readcyclecounter() : 0ull;
       const uint32_t ta = (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (g - win_base) * (uint32_t)kMsWinTiles;
       const uint32_t t0 = max(ta, part.tile_begin);
       const uint32_t t1 = min(ta + (uint32_t)kMsWinTiles, part.tile_end);
@@ -380,7 +390,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         const uint64_t thr_w = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? max(s.thr, thr_other) : 0ull;
         const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
         if (lane < n_terms) {
-          if (my_suf >= thr_w && pe > pb) ng = (uint32_t)((pe - (pb & ~3ull) + 7ull) >> 3);
+          // (minimumNumberShouldMatch: a doc is evaluated at the first clause that holds it, so one first met at clause c matches
+          //  at most n_terms - c clauses: the last msm - 1 clauses cannot start a hit and are never streamed)
+          if (my_suf >= thr_w && pe > pb && (!SHAPES || msm <= 1u || lane + msm <= n_terms)) ng = (uint32_t)((pe - (pb & ~3ull) + 7ull) >> 3);
           *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)(pe - pb), 0u};
         }
       }
@@ -525,6 +537,15 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
               alive &= ~(1u << j);
               am &= ~(1u << j);
             }
+          if (SHAPES && msm > 1u) {   // (uniform) too few clauses left to reach minimumNumberShouldMatch: no hit, whatever it scores
+            const uint32_t left = n_terms - j2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (((am >> j) & 1u) && ((ccnt >> (4 * j)) & 15u) + left < msm) {
+                alive &= ~(1u << j);
+                am &= ~(1u << j);
+              }
+          }
           if (!__any(am != 0u)) continue;
           if (PROF) pc_look += (uint64_t)__popc(am);
           const WClause& w2 = wcl[j2];  // uniform reads
@@ -693,20 +714,36 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             continue;
           }
           // no room: everybody meets, the k best stay, theta rises; then the same postings again under the new theta
+          const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
           (void)ms_meet(s, k, fx_E, my_theta_g);
+          if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
           theta_now = max(theta_now, s.theta);
         }
         // somebody else asked for a compaction: join it between two instructions
-        if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) (void)ms_meet(s, k, fx_E, my_theta_g);
+        if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
+          (void)ms_meet(s, k, fx_E, my_theta_g);
+          if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
+        }
       }
 
       // ---- next window
+      if (PROF) tc_walk += __builtin_readcyclecounter() - t_win0;
       g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
       if (g >= win_base + part_wins) break;  // a later part (or past the item)
     }
   }
   // ---- out of work: stay available for the others' compactions until everybody is done
+  const uint64_t t_idle0 = PROF ? __builtin_readcyclecounter() : 0ull;
   while (ms_meet(s, k, fx_E, my_theta_g)) {
+  }
+  const uint64_t t_epi0 = PROF ? __builtin_readcyclecounter() : 0ull;
+  if (PROF && lane == 0) {
+    atomicAdd((unsigned long long*)&s.prof[10], (unsigned long long)tc_meet);
+    atomicAdd((unsigned long long*)&s.prof[11], (unsigned long long)(t_epi0 - t_idle0));
+    atomicAdd((unsigned long long*)&s.prof[12], (unsigned long long)tc_part);
+    atomicAdd((unsigned long long*)&s.prof[13], (unsigned long long)(tc_walk - tc_meet));
+    atomicMax((unsigned long long*)&s.prof[14], (unsigned long long)(t_idle0 - t_item0));
   }
 
   // ---- item epilogue
@@ -759,8 +796,10 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     item_hits[blockIdx.x] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
     if (PROF && item_prof) {
       s.prof[5] = hits;
-      for (int i = 0; i < 8; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
-      for (int i = 8; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = 0;
+      const uint64_t t_end = __builtin_readcyclecounter();
+      s.prof[9] = t_end - t_item0;
+      s.prof[15] = t_end - t_epi0;
+      for (int i = 0; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
     }
   }
 }

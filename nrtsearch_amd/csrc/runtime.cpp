@@ -270,10 +270,10 @@ extern "C" int nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16) {
   return NRTGPU_OK;
 }
 
-extern "C" int nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out8) {
-  if (!ctx || !out8) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+extern "C" int nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out16) {
+  if (!ctx || !out16) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
-  for (int i = 0; i < 8; ++i) out8[i] = ctx->ms_prof[i];
+  for (int i = 0; i < 16; ++i) out16[i] = ctx->ms_prof[i];
   return NRTGPU_OK;
 }
 
