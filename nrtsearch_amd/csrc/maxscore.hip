@@ -42,6 +42,7 @@
 namespace nrtgpu {
 
 constexpr int kMsWinWords = kMsWinDocs / 32;
+constexpr int kSl = kMsSlots;   // postings a lane holds per instruction
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const NRT_GLOBAL u32x2* gvec2_ptr;
 
@@ -81,6 +82,12 @@ struct MsSmem {
 };
 static_assert(sizeof(MsSmem) <= 160 * 1024, "the MaxScore workgroup owns one CU's 160 KiB LDS");
 
+// a value every lane holds, moved into scalar registers (the compiler cannot know that an LDS read is uniform)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
@@ -92,15 +99,15 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l) {
 // BM25 formula itself.  0 = posting of a deleted doc (apply_live_kernel) -- every live posting scores >= 1.
 // PACKED: c[j] = the packed word's 12-bit code << 2 (codes from kPackEscBase on: exceptions, looked up in the group's
 // exception list by the posting's index pidx[j] in its column).
-template <bool PACKED>
-__device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t (&c)[8], uint32_t need, uint32_t tab_slot,
+template <bool PACKED, int NS>
+__device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t (&c)[NS], uint32_t need, uint32_t tab_slot,
                                                 float w, int fx_scale, uint32_t cache_slot, uint64_t esc_list,
-                                                const uint32_t (&pidx)[8], uint32_t (&val)[8]) {
+                                                const uint32_t (&pidx)[NS], uint32_t (&val)[NS]) {
   const uint32_t tab = tab_slot < (uint32_t)kTabTerms ? tab_slot : 7u;
   const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
   uint32_t cor = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < NS; ++j) {
     val[j] = *(const uint32_t*)(tb + (c[j] & 0x1FFCu));
     const uint32_t cn = ((need >> j) & 1u) ? c[j] : 0u;
     cor = PACKED ? max(cor, cn) : (cor | cn);
@@ -109,7 +116,7 @@ __device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t 
   if (__any(special)) {
     const float* cache = &s.cache[cache_slot][0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NS; ++j) {
       uint32_t cj = c[j];
       if (PACKED && cj >= (kPackEscBase << 2)) cj = ((need >> j) & 1u) ? packed_escape_word((gu32_ptr)esc_list, pidx[j], cj >> 2) : 0x80000100u;
       const bool esc = (cj >> 31) != 0u;
@@ -120,6 +127,38 @@ __device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t 
         val[j] = dead ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
     }
   }
+}
+
+// The docs a wave still follows -- at most 63, spread over the posting slots of its lanes (bit j of `alive`) -- dealt out one
+// per lane: the i-th of them (lane order, then slot order) goes to lane i, with its running sum and `c | clause count << 4`.
+// ds_permute_b32 is a PUSH (every lane names the lane its value goes to; a lane nobody names reads 0), so each slot takes one
+// push per register and the receiver ORs what arrives; a slot without a doc pushes to lane 63, which holds no doc.
+// Measured (round 3, profiles/r03_kernel_shapes.log): the collapse is correct (the whole parity suite passes with it) but
+// does not pay -- 3.00 vs 2.89 ms per 1024 C3 queries: the survivors of an instruction rarely fit one row before its last
+// lookup round, and the extra code costs registers.  A build-time option (-DNRT_MS_COLLAPSE=1), off by default.
+#ifndef NRT_MS_COLLAPSE
+#define NRT_MS_COLLAPSE 0
+#endif
+constexpr bool kMsCollapse = NRT_MS_COLLAPSE != 0;
+template <int NS>
+__device__ __forceinline__ void collapse_to_rows(const uint32_t (&d)[NS], const uint64_t (&run)[NS], uint32_t alive, uint32_t c,
+                                                 uint32_t ccnt, uint32_t& d1, uint64_t& run1, uint32_t& meta1) {
+  const uint32_t mine = (uint32_t)__popc(alive);
+  uint32_t p = scan64_dpp(mine) - mine;   // the lane my first doc goes to
+  uint32_t od = 0, olo = 0, ohi = 0, om = 0;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const bool a = (alive >> j) & 1u;
+    const int addr = (int)((a ? p : 63u) << 2);
+    p += a ? 1u : 0u;
+    od |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)d[j]);
+    olo |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)run[j]);
+    ohi |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)(run[j] >> 32));
+    om |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(c | (((ccnt >> (4 * j)) & 15u) << 4)));
+  }
+  d1 = od;
+  run1 = ((uint64_t)ohi << 32) | (uint64_t)olo;
+  meta1 = om;
 }
 
 // All waves: keep the k best candidates, raise theta.  Contains barriers.
@@ -259,6 +298,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   uint32_t wave_hits = 0;    // hits of my current slot not yet added to s.slot_hits
   uint32_t cur_slot = 0;
   uint64_t pc_post = 0, pc_surv = 0, pc_look = 0, pc_cand = 0, pc_chunks = 0, pc_wins = 0;
+#ifdef NRT_MS_COUNT_ROUNDS   // experiment build: event counts instead of four of the cycle counters
+  uint64_t pc_dense = 0, pc_sparse = 0, pc_steps = 0, pc_tas = 0, pc_crounds = 0;
+#endif
   uint32_t g = wave;      // my current window (flattened over the item's parts)
   uint32_t pi = 0;        // its part ...
   uint32_t win_base = 0;  // ... and the windows of the parts before that one
@@ -392,7 +434,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         if (lane < n_terms) {
           // (minimumNumberShouldMatch: a doc is evaluated at the first clause that holds it, so one first met at clause c matches
           //  at most n_terms - c clauses: the last msm - 1 clauses cannot start a hit and are never streamed)
-          if (my_suf >= thr_w && pe > pb && (!SHAPES || msm <= 1u || lane + msm <= n_terms)) ng = (uint32_t)((pe - (pb & ~3ull) + 7ull) >> 3);
+          if (my_suf >= thr_w && pe > pb && (!SHAPES || msm <= 1u || lane + msm <= n_terms)) ng = (uint32_t)((pe - (pb & ~3ull) + (uint64_t)(kSl - 1)) / (uint64_t)kSl);
           *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)(pe - pb), 0u};
         }
       }
@@ -426,28 +468,36 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         const uint64_t col_d = ((uint64_t)r0[1] << 32) | r0[0], col_c = ((uint64_t)r0[3] << 32) | r0[2];
         const uint64_t p_begin = ((uint64_t)r1[1] << 32) | r1[0];
         const uint32_t flags = r2[2];
-        const uint32_t q0 = (v - before) * 8u;  // my group's first posting, counted from the clause's 16-byte aligned begin
+        const uint32_t q0 = (v - before) * (uint32_t)kSl;  // my group's first posting, counted from the clause's 16-byte aligned begin
         const uint64_t mine0 = (p_begin & ~3ull) + (uint64_t)q0;
-        uint32_t d[8], cd[8];
+        uint32_t d[kSl], cd[kSl];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = cd[j] = 0u;
+        for (int j = 0; j < kSl; ++j) d[j] = cd[j] = 0u;
         if (act) {  // (the columns are padded: a partly valid group may read past the term)
           const u32x4 d0 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u));
-          const u32x4 d1 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u) + 1);
+          const u32x4 d1 = kSl > 4 ? __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u) + 1) : d0;
           if (PACKED) {  // one word per posting: doc offset inside the window's super-window | code
             const uint32_t sw = doc_lo & ~kPackDocMask;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              d[j] = (d0[j] >> kPackCodeBits) | sw; d[4 + j] = (d1[j] >> kPackCodeBits) | sw;
-              cd[j] = (d0[j] & kPackCodeMask) << 2; cd[4 + j] = (d1[j] & kPackCodeMask) << 2;
+              d[j] = (d0[j] >> kPackCodeBits) | sw;
+              cd[j] = (d0[j] & kPackCodeMask) << 2;
+              if (kSl > 4) {
+                d[(4 + j) % kSl] = (d1[j] >> kPackCodeBits) | sw;
+                cd[(4 + j) % kSl] = (d1[j] & kPackCodeMask) << 2;
+              }
             }
           } else {
             const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u));
-            const u32x4 c1 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u) + 1);
+            const u32x4 c1 = kSl > 4 ? __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u) + 1) : c0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              d[j] = d0[j]; d[4 + j] = d1[j];
-              cd[j] = c0[j]; cd[4 + j] = c1[j];
+              d[j] = d0[j];
+              cd[j] = c0[j];
+              if (kSl > 4) {
+                d[(4 + j) % kSl] = d1[j];
+                cd[(4 + j) % kSl] = c1[j];
+              }
             }
           }
         }
@@ -455,17 +505,17 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         {
           const uint32_t rel = q0 - ((uint32_t)p_begin & 3u), cnt = act ? r1[2] : 0u;
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
+          for (int j = 0; j < kSl; ++j)
             if (rel + (uint32_t)j < cnt && d[j] - doc_lo < doc_span) vmask |= 1u << j;
         }
         // the values my postings add: per-lane table (lanes of one instruction may belong to different clauses)
-        uint32_t val[8];
+        uint32_t val[kSl];
         {
           const uint32_t tab = flags & 7u;
           const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
           uint32_t cor = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < kSl; ++j) {
             val[j] = *(const uint32_t*)(tb + (cd[j] & 0x1FFCu));
             const uint32_t cn = ((vmask >> j) & 1u) ? cd[j] : 0u;
             cor = PACKED ? max(cor, cn) : (cor | cn);
@@ -476,7 +526,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             const int fx_scale = (int)r2[1];
             const float* cache = &s.cache[(flags >> 8) & 255u][0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kSl; ++j) {
               uint32_t cj = cd[j];
               if (PACKED && cj >= (kPackEscBase << 2))   // (col_c: the group's exception list; mine0 + j: the posting's index in its column)
                 cj = ((vmask >> j) & 1u) ? packed_escape_word((gu32_ptr)col_c, (uint32_t)mine0 + (uint32_t)j, cj >> 2) : 0x80000100u;
@@ -489,15 +539,30 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             }
           }
         }
-        uint64_t run[8];
+        uint64_t run[kSl];
         uint32_t alive = 0;
         {
           const uint32_t mult = 1u << ((flags >> 4) & 15u);  // entry << shift as one 32 x 32 -> 64 multiply
+          // "entry * mult + u_after >= thr_p" (DisjunctionMaxQuery: max instead of +) as ONE 32-bit compare per posting: the
+          // smallest entry that passes, computed once per lane (>= 1: a posting of a deleted doc scores 0 and never passes)
+          uint32_t need_v = 1u;
+          if (u_after < thr_p) {
+            const uint64_t gap = use_max ? thr_p : thr_p - u_after;
+            const uint64_t nv = (gap + (uint64_t)(mult - 1u)) >> ((flags >> 4) & 15u);
+            need_v = nv > 0xFFFFFFFFull ? 0xFFFFFFFFu : max((uint32_t)nv, 1u);
+            // (an entry of 2^32 - 1 that still falls short: the exact test below is the rare fallback)
+          }
+          uint32_t pass = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < kSl; ++j) {
             run[j] = (uint64_t)val[j] * (uint64_t)mult;
-            const uint64_t reach = use_max ? max(run[j], u_after) : run[j] + u_after;
-            if (((vmask >> j) & 1u) && val[j] != 0u && reach >= thr_p) alive |= 1u << j;
+            pass |= val[j] >= need_v ? (1u << j) : 0u;
+          }
+          alive = vmask & pass;
+          if (need_v == 0xFFFFFFFFu) {   // (per lane, practically never)
+#pragma unroll
+            for (int j = 0; j < kSl; ++j)
+              if ((use_max ? max(run[j], u_after) : run[j] + u_after) < thr_p) alive &= ~(1u << j);
           }
         }
         if (PROF) {
@@ -512,97 +577,217 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           for (uint32_t cc = c_first; cc <= c_last; ++cc) {
             const uint32_t am = c == cc ? alive : 0u;
             if (!__any(am != 0u)) continue;
-            uint32_t old[8];
+#ifdef NRT_MS_COUNT_ROUNDS
+            if (PROF) pc_tas += 1;
+#endif
+            uint32_t old[kSl];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kSl; ++j) {
               const bool a = (am >> j) & 1u;
               const uint32_t w = a ? ((d[j] - doc_lo) >> 5) : lane;
               old[j] = atomicOr(&seen[w], a ? (1u << (d[j] & 31u)) : 0u);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < kSl; ++j)
               if (((am >> j) & 1u) && ((old[j] >> (d[j] & 31u)) & 1u)) alive &= ~(1u << j);
           }
         }
         uint32_t ccnt = 0x11111111u;   // SHAPES, minimumNumberShouldMatch: clauses that matched the doc, 4 bits per posting slot
+
+        // ---- One doc per lane: what is left of an instruction once few of its docs survive (collapse_to_rows).  The same
+        //      steps as the rounds below -- bound, lookup, sum, then hits and candidates -- on scalars, at an eighth of the
+        //      vector instructions per round.
+        auto finish_rows = [&](uint32_t d1, uint64_t run1, bool live1, uint32_t c1, uint32_t cnt1, uint32_t j2_begin) {
+          for (uint32_t j2 = j2_begin; j2 < n_terms; ++j2) {
+            if (!__any(live1)) break;
+            const uint64_t S_j = readlane_u64(my_suf, j2);
+            bool am = live1 && c1 < j2;
+            if (am && (use_max ? max(run1, S_j) : run1 + S_j) < thr_p) live1 = am = false;
+            if (SHAPES && msm > 1u && am && cnt1 + (n_terms - j2) < msm) live1 = am = false;
+            if (!__any(am)) continue;
+            if (PROF) pc_look += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(am));
+            const WClause& w2 = wcl[j2];  // uniform reads
+            const uint64_t bits2 = w2.bits;
+            const uint32_t flags2 = w2.flags;
+            const gu32_ptr codes2 = (gu32_ptr)((PACKED ? w2.docids : w2.fnorm) + w2.start * 4u);
+            bool present = false;
+            uint32_t at = 0;   // the doc's posting in the clause (index relative to the clause's first)
+            if (bits2 != 0ull) {
+              const u32x2 r = ((gvec2_ptr)bits2)[am ? (d1 >> 5) : 0u];
+              const uint32_t bb = d1 & 31u;
+              present = am && ((r[0] >> bb) & 1u);
+              at = present ? r[1] + (uint32_t)__popc(r[0] & ((1u << bb) - 1u)) : 0u;
+            } else {
+              const gu32_ptr cells2 = (gu32_ptr)w2.cells;
+              const gu32_ptr docs2 = (gu32_ptr)(w2.docids + w2.start * 4u);
+              const uint32_t cell = am ? ((d1 >> 10) >> (flags2 >> 16)) : 0u;
+              uint32_t a = cells2[cell], b = cells2[cell + 1u];
+              if (!am) b = a;
+              bool open = a < b;
+              while (__any(open)) {
+                const uint32_t mid = (a + b) >> 1;
+                const uint32_t vv = docs2[open ? mid : 0u];
+                if (open) {
+                  const uint32_t dv = PACKED ? vv >> kPackCodeBits : vv, dd = PACKED ? d1 & kPackDocMask : d1;
+                  if (dv < dd) a = mid + 1u;
+                  else b = mid;
+                  if (dv == dd) {
+                    a = b = mid;
+                    present = true;
+                  }
+                  open = a < b;
+                }
+              }
+              at = present ? a : 0u;
+            }
+            if (__any(present)) {
+              uint32_t c2[1] = {codes2[at]}, pi2[1] = {(uint32_t)w2.start + at}, v2[1];
+              if (PACKED) c2[0] = (c2[0] & kPackCodeMask) << 2;
+              values_of_codes<PACKED, 1>(s, c2, present ? 1u : 0u, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
+              const uint64_t add = (uint64_t)(present ? v2[0] : 0u) * (uint64_t)(1u << ((flags2 >> 4) & 15u));
+              run1 = use_max ? max(run1, add) : run1 + add;
+              cnt1 += present ? 1u : 0u;
+            }
+          }
+          bool maybe = live1 && run1 >= thr;
+          {
+            bool pool = pruning ? maybe : live1;
+            if (SHAPES && msm > 1u && cnt1 < msm) pool = false;
+            if (part.live_bits != nullptr && __any(pool)) {   // (uniform)
+              const uint32_t lw = ((const NRT_GLOBAL uint32_t*)part.live_bits)[pool ? (d1 >> 5) : 0u];
+              pool = pool && ((lw >> (d1 & 31u)) & 1u) != 0u;
+            }
+            maybe = maybe && pool;
+            const uint32_t h = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pool));
+            if (mode == kMsModeCount && !pruning) {
+              if (lane == 0 && h != 0u) {
+                const uint32_t tot = atomicAdd(&s.slot_hits[cur_slot], h) + h;
+                if (tot > q.gte_floor) {
+                  __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  if (multi_item) __hip_atomic_store(my_prune_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
+            } else {
+              wave_hits += h;
+            }
+          }
+          uint64_t theta_now = theta;
+          while (__any(maybe)) {
+            const uint64_t key = pack_key(acc_score<true>(run1, fx_E), (uint32_t)(part.doc_base + (int32_t)d1));
+            const bool want = maybe && key > theta_now && key < after_key;
+            uint32_t pos = 0;
+            if (!__any(want)) break;
+            if (ms_reserve(s, lane, want ? 1u : 0u, pos)) {  // wave-uniform
+              if (want) s.cand[pos] = key;
+              if (PROF) pc_cand += want ? 1u : 0u;
+              break;
+            }
+            const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
+            (void)ms_meet(s, k, fx_E, my_theta_g);
+            if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
+            theta_now = max(theta_now, s.theta);
+          }
+        };
+        bool collapsed = false;
 
         // ---- the later clauses of the surviving docs, one clause at a time (a lane of clause c takes part from c + 1 on)
         for (uint32_t j2 = c_first + 1u; j2 < n_terms; ++j2) {
           if (!__any(alive != 0u)) break;
           const uint64_t S_j = readlane_u64(my_suf, j2);
           uint32_t am = c < j2 ? alive : 0u;
+          {
+            // "sum + S_j < thr_p" (DisjunctionMaxQuery: max(sum, S_j)) against a UNIFORM value: sum < thr_p - S_j -- one 64-bit
+            // compare per doc, no add; nothing is dropped while S_j alone reaches thr_p
+            const uint64_t short_of = S_j < thr_p ? (use_max ? thr_p : thr_p - S_j) : 0ull;
+            uint32_t kill = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (((am >> j) & 1u) && (use_max ? max(run[j], S_j) : run[j] + S_j) < thr_p) {
-              alive &= ~(1u << j);
-              am &= ~(1u << j);
+            for (int j = 0; j < kSl; ++j) kill |= run[j] < short_of ? (1u << j) : 0u;
+            if (SHAPES && msm > 1u) {   // (uniform) too few clauses left to reach minimumNumberShouldMatch: no hit, whatever it scores
+              const uint32_t left = n_terms - j2;
+#pragma unroll
+              for (int j = 0; j < kSl; ++j) kill |= ((ccnt >> (4 * j)) & 15u) + left < msm ? (1u << j) : 0u;
             }
-          if (SHAPES && msm > 1u) {   // (uniform) too few clauses left to reach minimumNumberShouldMatch: no hit, whatever it scores
-            const uint32_t left = n_terms - j2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (((am >> j) & 1u) && ((ccnt >> (4 * j)) & 15u) + left < msm) {
-                alive &= ~(1u << j);
-                am &= ~(1u << j);
-              }
+            kill &= am;
+            alive &= ~kill;
+            am &= ~kill;
           }
           if (!__any(am != 0u)) continue;
+          if (kMsCollapse) {
+            // few docs of the instruction left: dealt out one per lane, the rest of the instruction runs on rows
+            const uint32_t n_left = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp((uint32_t)__popc(alive)), 63);
+            if (n_left <= 63u) {
+              uint32_t d1, meta1;
+              uint64_t run1;
+              collapse_to_rows<kSl>(d, run, alive, c, ccnt, d1, run1, meta1);
+              finish_rows(d1, run1, lane < n_left, meta1 & 15u, meta1 >> 4, j2);
+              collapsed = true;
+              break;
+            }
+          }
           if (PROF) pc_look += (uint64_t)__popc(am);
-          const WClause& w2 = wcl[j2];  // uniform reads
-          const uint64_t bits2 = w2.bits;
-          const uint32_t flags2 = w2.flags;
-          const gu32_ptr codes2 = (gu32_ptr)((PACKED ? w2.docids : w2.fnorm) + w2.start * 4u);  // packed: the code rides in the posting's word
-          uint32_t c2[8];
-          uint32_t pi2[8];  // packed postings: the looked-up postings' indices in their column (exception lookups)
+          const WClause& w2 = wcl[j2];  // uniform reads; the pointers as scalars: a gather is then base + 32-bit lane offset
+          const uint64_t bits2 = uniform_u64(w2.bits);
+          const uint32_t flags2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w2.flags);
+          const uint64_t start2 = uniform_u64(w2.start);
+          const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + start2 * 4u);  // packed: the code rides in the posting's word
+          uint32_t c2[kSl];
+          uint32_t pi2[kSl];  // packed postings: the looked-up postings' indices in their column (exception lookups)
           uint32_t present = 0;
+#ifdef NRT_MS_COUNT_ROUNDS
+          if (PROF) { if (bits2 != 0ull) pc_dense += 1; else pc_sparse += 1; }
+#endif
           if (bits2 != 0ull) {
             // dense clause: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether
             // the doc is there and where its posting is
             const gvec2_ptr recs = (gvec2_ptr)bits2;
-            u32x2 r[8];
+            u32x2 r[kSl];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
-            uint32_t idx[8];
+            for (int j = 0; j < kSl; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
+            __builtin_amdgcn_sched_barrier(0);   // every record load is issued before the first one is waited for
+            uint32_t idx[kSl];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kSl; ++j) {
               const uint32_t bb = d[j] & 31u;
               const bool there = ((am >> j) & 1u) && ((r[j][0] >> bb) & 1u);
               idx[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
               present |= (there ? 1u : 0u) << j;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              c2[j] = codes2[idx[j]];
-              pi2[j] = (uint32_t)w2.start + idx[j];
-            }
+            for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
+            __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
+#pragma unroll
+            for (int j = 0; j < kSl; ++j) pi2[j] = (uint32_t)start2 + idx[j];
           } else {
             // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
             // lane advance in lockstep, so every step is one round of loads in flight instead of eight
-            const gu32_ptr cells2 = (gu32_ptr)w2.cells;
-            const gu32_ptr docs2 = (gu32_ptr)(w2.docids + w2.start * 4u);
+            const gu32_ptr cells2 = (gu32_ptr)uniform_u64(w2.cells);
+            const gu32_ptr docs2 = (gu32_ptr)(uniform_u64(w2.docids) + start2 * 4u);
             const uint32_t cshift = flags2 >> 16;
-            uint32_t a[8], b[8];
+            uint32_t a[kSl], b[kSl];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kSl; ++j) {
               const uint32_t cell = ((am >> j) & 1u) ? ((d[j] >> 10) >> cshift) : 0u;
               a[j] = cells2[cell];
               b[j] = cells2[cell + 1u];
             }
             uint32_t open = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kSl; ++j) {
               if (!((am >> j) & 1u)) b[j] = a[j];
               open |= (a[j] < b[j] ? 1u : 0u) << j;
             }
             while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
-              uint32_t mid[8], vv[8];
+#ifdef NRT_MS_COUNT_ROUNDS
+              if (PROF) pc_steps += 1;
+#endif
+              uint32_t mid[kSl], vv[kSl];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
+              for (int j = 0; j < kSl; ++j) {
                 mid[j] = (a[j] + b[j]) >> 1;
                 vv[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
               }
 #pragma unroll
-              for (int j = 0; j < 8; ++j)
+              for (int j = 0; j < kSl; ++j)
                 if ((open >> j) & 1u) {
                   // (packed: doc offsets inside the cell's super-window -- the doc's own, a cell never spans two)
                   const uint32_t dv = PACKED ? vv[j] >> kPackCodeBits : vv[j], dd = PACKED ? d[j] & kPackDocMask : d[j];
@@ -616,26 +801,26 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kSl; ++j) {
               c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];   // (packed: the posting's word again -- keeping the probe's word alive
                                                                     //  through the search loop cost more than this gather)
-              pi2[j] = (uint32_t)w2.start + a[j];
+              pi2[j] = (uint32_t)start2 + a[j];
             }
           }
           if (__any(present != 0u)) {
-            uint32_t v2[8];
+            uint32_t v2[kSl];
             if (PACKED) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) c2[j] = (c2[j] & kPackCodeMask) << 2;
+              for (int j = 0; j < kSl; ++j) c2[j] = (c2[j] & kPackCodeMask) << 2;
             }
-            values_of_codes<PACKED>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
+            values_of_codes<PACKED, kSl>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
             const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
             if (use_max) {   // (uniform)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) run[j] = max(run[j], (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2);
+              for (int j = 0; j < kSl; ++j) run[j] = max(run[j], (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2);
             } else {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
+              for (int j = 0; j < kSl; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
             }
             if (SHAPES && msm > 1u) {   // (uniform) bit j of `present` -> nibble j
               uint32_t x = present;
@@ -647,12 +832,13 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           }
         }
 
+        if (!collapsed) {
         // ---- complete scores: the competitive ones go to the shared candidate buffer.  Rare once theta has
         //      converged, so the key (a double conversion) is built only for sums that reach theta's score, one
         //      posting per lane and round.
         uint32_t maybe = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < kSl; ++j)
           if (((alive >> j) & 1u) && run[j] >= thr) maybe |= 1u << j;
         // ---- hits.  While nothing is being skipped every live matching doc reaches this point exactly once: the count is
         //      exact.  Once bounds skip it is a lower bound, and only the docs that reach theta's score are looked at.
@@ -662,15 +848,15 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           uint32_t pool = pruning ? maybe : alive;
           if (SHAPES && msm > 1u) {   // (uniform)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < kSl; ++j)
               if (((ccnt >> (4 * j)) & 15u) < msm) pool &= ~(1u << j);
           }
           if (part.live_bits != nullptr && __any(pool != 0u)) {   // (uniform)
-            uint32_t lw[8];
+            uint32_t lw[kSl];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) lw[j] = ((const NRT_GLOBAL uint32_t*)part.live_bits)[((pool >> j) & 1u) ? (d[j] >> 5) : 0u];
+            for (int j = 0; j < kSl; ++j) lw[j] = ((const NRT_GLOBAL uint32_t*)part.live_bits)[((pool >> j) & 1u) ? (d[j] >> 5) : 0u];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < kSl; ++j)
               if (!((lw[j] >> (d[j] & 31u)) & 1u)) pool &= ~(1u << j);
           }
           maybe &= pool;
@@ -691,11 +877,14 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         }
         uint64_t theta_now = theta;
         while (__any(maybe != 0u)) {
+#ifdef NRT_MS_COUNT_ROUNDS
+          if (PROF) pc_crounds += 1;
+#endif
           const uint32_t low = maybe & (0u - maybe);  // my lowest pending posting
           uint64_t rsel = run[0];
           uint32_t dsel = d[0];
 #pragma unroll
-          for (int j = 1; j < 8; ++j)
+          for (int j = 1; j < kSl; ++j)
             if (low == (1u << j)) {
               rsel = run[j];
               dsel = d[j];
@@ -719,6 +908,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
           theta_now = max(theta_now, s.theta);
         }
+        }  // (!collapsed)
         // somebody else asked for a compaction: join it between two instructions
         if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
           const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
@@ -744,6 +934,13 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     atomicAdd((unsigned long long*)&s.prof[12], (unsigned long long)tc_part);
     atomicAdd((unsigned long long*)&s.prof[13], (unsigned long long)(tc_walk - tc_meet));
     atomicMax((unsigned long long*)&s.prof[14], (unsigned long long)(t_idle0 - t_item0));
+#ifdef NRT_MS_COUNT_ROUNDS
+    atomicAdd((unsigned long long*)&s.prof[11], (unsigned long long)pc_tas - (unsigned long long)(t_epi0 - t_idle0));
+    atomicAdd((unsigned long long*)&s.prof[12], (unsigned long long)pc_dense - (unsigned long long)tc_part);
+    atomicAdd((unsigned long long*)&s.prof[10], (unsigned long long)pc_sparse - (unsigned long long)tc_meet);
+    atomicAdd((unsigned long long*)&s.prof[13], (unsigned long long)pc_steps - (unsigned long long)(tc_walk - tc_meet));
+    atomicAdd((unsigned long long*)&s.prof[8], (unsigned long long)pc_crounds);
+#endif
   }
 
   // ---- item epilogue

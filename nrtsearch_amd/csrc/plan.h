@@ -119,8 +119,17 @@ static_assert(sizeof(DTermAux) == 32, "DTermAux layout");
 #ifndef NRT_MS_WIN_TILES
 #define NRT_MS_WIN_TILES 64
 #endif
-constexpr int kMsWaves = 12;
+#ifndef NRT_MS_WAVES
+#define NRT_MS_WAVES 12
+#endif
+#ifndef NRT_MS_SLOTS
+#define NRT_MS_SLOTS 8
+#endif
+constexpr int kMsWaves = NRT_MS_WAVES;
+constexpr int kMsSlots = NRT_MS_SLOTS;   // postings per lane and instruction: 8 (two 16-byte loads per column) or 4
+static_assert(kMsSlots == 4 || kMsSlots == 8, "MaxScore kernel: 4 or 8 postings per lane");
 constexpr int kMsThreads = kMsWaves * 64;
+static_assert(kMsThreads <= 1024, "a workgroup holds at most 16 waves");
 constexpr int kMsWinTiles = NRT_MS_WIN_TILES;
 constexpr int kMsWinDocs = kMsWinTiles * kTileDocs;
 constexpr int kMsMaxTerms = 8;      // clauses of a query on the MaxScore route (longer disjunctions are scanned exhaustively)
@@ -129,7 +138,11 @@ constexpr int kMsMaxTerms = 8;      // clauses of a query on the MaxScore route 
 // skips nothing, so every matching doc is evaluated once and counted -- the exhaustive scan's answer, without walking every
 // 1024-doc sub-tile of the shard for a handful of postings.
 constexpr int64_t kMsExactMaxPostings = 1 << 18;
-constexpr int kMsCandCap = kMsWinTiles > 32 ? 2304 : 3072;  // LDS candidate slots (>= kMaxK + 512: a wave's retry always fits)
+#ifndef NRT_MS_CAND_CAP
+#define NRT_MS_CAND_CAP (NRT_MS_WIN_TILES > 32 ? 2304 : 3072)
+#endif
+constexpr int kMsCandCap = NRT_MS_CAND_CAP;  // LDS candidate slots (>= kMaxK + 512: a wave's retry always fits)
+static_assert(kMsCandCap >= kMaxK + 512, "candidate buffer too small");
 // item_hits of a MaxScore item: the docs it evaluated, plus kHitsPrunedUnit when it skipped anything (the count is
 // then a lower bound).  The merge kernel's plain sum keeps both: low 48 bits = docs, high 16 = pruned items.
 constexpr uint64_t kHitsPrunedUnit = 1ull << 48;
