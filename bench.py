@@ -34,8 +34,8 @@ BYTES_PER_POSTING_FUSED = 8
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="queries per step")
     ap.add_argument("--host-threads", type=int, default=2,
                     help="N=1 only: host threads submitting steps (plan building of step i+1 overlaps the kernels of step i)")
@@ -60,8 +60,17 @@ def parse_args():
     ap.add_argument("--debug-same-gpu", action="store_true",
                     help="debug: run an N-rank job with every rank on GPU 0 (gloo, collectives staged through the host)")
     ap.add_argument("--all-to-all", action="store_true",
-                    help="N>1: split the reduce between the ranks (all-to-all, each rank merges its slice of the batch) "
-                         "instead of the north star's all-gather + merge on every rank")
+                    help="with --torch-collective: torch.distributed's all_to_all_single instead of its all-gather")
+    ap.add_argument("--exchange-mode", default="alltoall", choices=["alltoall", "allgather"],
+                    help="N>1, the library's exchange stage (nrtgpu_dist_exchange_merge): alltoall (default) = every rank receives the "
+                         "other ranks' lists for ITS slice of the batch, merges and delivers only those (1/N of the bytes per xGMI link, "
+                         "of the merge and of the host-side unpacking); allgather = BASELINE.json's north-star form: every rank merges "
+                         "every query and holds every answer")
+    ap.add_argument("--planner-threads", type=int, default=0, help="planner threads per in-flight call (0 = what the box's CPUs allow)")
+    ap.add_argument("--closed-loop", default="64,512",
+                    help="N=1, C3: after the batch line, closed loop with that many concurrent callers, one query per call through "
+                         "nrtgpu_search_bm25_coalesced (comma list; empty = skip): qps / p50 / p99 per caller count")
+    ap.add_argument("--closed-loop-ms", type=int, default=2500)
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -97,6 +106,25 @@ def usable_cpus():
         except (OSError, ValueError):
             pass
     return n
+
+
+def thread_cpu_seconds():
+    """utime + stime of every thread of this process, by tid (Linux): {tid: (comm, seconds)}."""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{tid}/stat") as f:
+                    st = f.read()
+                comm = st[st.index("(") + 1: st.rindex(")")]
+                fields = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (comm, (int(fields[11]) + int(fields[12])) / tck)
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        pass
+    return out
 
 
 def stdout_to_stderr(fn):
@@ -196,6 +224,66 @@ def lucene_baseline(w, searcher, queries, mgr, n_queries):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def roofline_record(kernel, pruned, avg_launch_ms, algorithmic_bytes_per_launch, bytes_per_posting, bytes_per_posting_streamed, traffic,
+                    traffic_note=None):
+    """The `roofline` object of the BM25 bench line from measured numbers (pure: tests/test_bench_contract.py checks its arithmetic).
+    achieved / frac: for the exhaustive scan the ALGORITHMIC rate (9 B per posting of the query's terms / launch time).
+    The pruned kernel skips most of those bytes by design, so its algorithmic rate is an EFFECTIVE figure (may exceed the peak):
+    it moves to effective_*, and achieved / frac are the PHYSICAL rate -- HBM bytes of the PMC profile / launch time."""
+    t = avg_launch_ms * 1e-3
+    algo = algorithmic_bytes_per_launch / t / 1e9 if t > 0 else 0.0
+    phys = traffic / t / 1e9 if (traffic and t > 0) else None
+    main = phys if (pruned and phys is not None) else algo
+    return {
+        "bound": "hbm", "kernel": kernel, "effective": bool(pruned),
+        "achieved": round(main, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(main / HBM_PEAK_GBS, 4),
+        "achieved_is": "physical (PMC traffic / launch time)" if (pruned and phys is not None) else "algorithmic bytes / launch time",
+        "effective_achieved": round(algo, 1) if pruned else None,
+        "effective_frac": round(algo / HBM_PEAK_GBS, 4) if pruned else None,
+        "bytes_per_posting": bytes_per_posting,
+        "algorithmic_bytes_per_launch": int(algorithmic_bytes_per_launch),
+        "achieved_at_8B_per_posting": round(algo * bytes_per_posting_streamed / bytes_per_posting, 1),
+        "frac_at_8B_per_posting": round(algo * bytes_per_posting_streamed / bytes_per_posting / HBM_PEAK_GBS, 4),
+        "physical_achieved": round(phys, 1) if phys is not None else None,
+        "physical_frac": round(phys / HBM_PEAK_GBS, 4) if phys is not None else None,
+        "avg_launch_ms": round(avg_launch_ms, 4),
+        "traffic": traffic,
+        "traffic_source": (("static profile: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE of this command, collected in a run of "
+                            "its own; " + str(traffic_note) + ")") if traffic else None),
+    }
+
+
+def closed_loop(ctx, searcher, queries, mgr, callers, duration_ms):
+    """SURVEY 8d's metric shape: C concurrent callers, each with ONE query in flight through nrtgpu_search_bm25_coalesced (the library
+    merges them into device batches).  The callers are native threads of bench/loadgen (host-only tooling that knows nothing but
+    include/nrtgpu.h): Python threads would measure the GIL.  -> {C: {qps, p50_ms, p99_ms, mean_batch}}"""
+    import ctypes as C
+
+    import numpy as np
+
+    from nrtsearch_amd import _lib, build
+
+    lg = C.CDLL(build.build_loadgen())
+    lg.loadgen_closed_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p]
+    L = _lib.load()
+    fn = C.cast(L.nrtgpu_search_bm25_coalesced, C.c_void_p)
+    m = searcher._marshal(queries, [mgr] * len(queries))
+    out = {}
+    for c in callers:
+        res = np.zeros(4, dtype=np.float64)
+        ctx.reset_stats()
+        rc = lg.loadgen_closed_loop(fn, ctx._h, searcher._segs, searcher._bases, len(searcher.leaves), m.queries, len(queries), int(c),
+                                    int(duration_ms), res.ctypes.data)
+        if rc != 0:
+            out[str(c)] = {"error": int(rc)}
+            continue
+        st = ctx.stats()
+        out[str(c)] = {"qps": round(res[0] / res[1], 1), "p50_ms": round(res[2], 3), "p99_ms": round(res[3], 3),
+                       "mean_batch": round(st["queries"] / max(1, st["batches"]), 1)}
+    return out
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 is exact fp32
 
 
@@ -210,18 +298,41 @@ def run_c4(args):
     from nrtsearch_amd import api, build
 
     build.build()
-    torch.cuda.set_device(0)
-    n, dim, k, Q = (args.docs or 10_000_000), 768, 100, max(1, args.knn_queries)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    n_all, dim, k, Q = (args.docs or 10_000_000), 768, 100, max(1, args.knn_queries)
+    # N > 1 (BASELINE config 4, 1 -> 8 GPUs): the rows are partitioned like the docid shards -- rank r holds rows
+    # [r * n / N, (r + 1) * n / N) -- every rank scores its rows for every query, the per-rank top-k lists are exchanged and merged
+    # inside the library (nrtgpu_dist_knn_exact).  --emulate-world N on one GPU: rank --emulate-rank's share, no exchange.
+    shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if (args.emulate_world > 1 and world == 1) else (world, rank)
+    row_lo = n_all * shard_rank // shard_world
+    n = n_all * (shard_rank + 1) // shard_world - row_lo
     seg_rows = 2_500_000
-    ctx = api.GpuContext(device_id=0, max_batch=64, collect_timing=True)
+    ctx = api.GpuContext(device_id=local_rank, max_batch=64, collect_timing=True)
+    mode = api.EXCHANGE_ALLTOALL if args.exchange_mode == "alltoall" else api.EXCHANGE_ALLGATHER
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+        def _init():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            box = [api.GpuContext.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.dist_init(world, rank, box[0])
+
+        stdout_to_stderr(_init)
     t_build = time.perf_counter()
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(777)
+    gen.manual_seed(777 + shard_rank)
     leaves, base, first_seg = [], 0, None
     while base < n:
         rows = min(seg_rows, n - base)
         host = torch.randn((rows, dim), generator=gen, device="cuda", dtype=torch.float32).cpu().numpy()
-        g = api.GpuSegment(ctx, rows, base)
+        g = api.GpuSegment(ctx, rows, row_lo + base)
         g.add_vectors(0, host)
         g.seal()
         leaves.append(g)
@@ -234,17 +345,31 @@ def run_c4(args):
     qrng = np.random.Generator(np.random.PCG64(778))
     panels = [qrng.standard_normal((Q, dim), dtype=np.float32) for _ in range(4)]
     lat = []
+
+    def one(panel):
+        return sr.dist_knn_exact(0, "cosine", panel, k, mode=mode) if world > 1 else sr.knn_exact(0, "cosine", panel, k)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for i in range(args.warmup):
-        sr.knn_exact(0, "cosine", panels[i % len(panels)], k)
+        one(panels[i % len(panels)])
     ctx.reset_stats()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ts = time.perf_counter()
-        last = sr.knn_exact(0, "cosine", panels[(args.warmup + i) % len(panels)], k)
+        last = one(panels[(args.warmup + i) % len(panels)])
         lat.append(time.perf_counter() - ts)
-    torch.cuda.synchronize()
+    fence()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     st = ctx.stats()
     n_panels = max(1, st["knn_panels"])
     score_ms = st["knn_score_ms"] / n_panels                    # knn_score_kernel launches of one panel (HIP events, its stream)
@@ -253,13 +378,16 @@ def run_c4(args):
     achieved = bytes_per_panel / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
     tflops = 2.0 * (st["knn_rows"] / n_panels) * dim * q_per_panel / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
     out = {
-        "metric": "queries/sec, exact kNN 10M x 768 fp32 cosine top-100" if n == 10_000_000 else f"queries/sec, exact kNN {n} x 768 fp32 cosine top-100",
-        "value": round(args.steps * Q / elapsed, 2), "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "metric": "queries/sec, exact kNN 10M x 768 fp32 cosine top-100" if n_all == 10_000_000 else f"queries/sec, exact kNN {n_all} x 768 fp32 cosine top-100",
+        "value": round(args.steps * Q / elapsed, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(statistics.median(lat) * 1e3, 4),
         "max_latency_ms": round(max(lat) * 1e3, 4), "slowest_step": int(np.argmax(lat)),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C4: {n} x {dim} fp32 rows, brute-force cosine top-{k}", "n_docs": n, "dim": dim, "k": k,
-                   "queries_per_step": Q, "segments_per_gpu": len(leaves), "corpus_build_s": round(t_build, 1)},
+        "config": {"workload": f"C4: {n_all} x {dim} fp32 rows, brute-force cosine top-{k}", "n_docs": n_all, "rows_per_gpu": n, "dim": dim, "k": k,
+                   "queries_per_step": Q, "segments_per_gpu": len(leaves), "corpus_build_s": round(t_build, 1),
+                   "sharding": ("rows partitioned by docid range, 1 process per GPU, per-rank top-k exchanged inside the library "
+                                f"(nrtgpu_dist_knn_exact, {'all-to-all' if mode == api.EXCHANGE_ALLTOALL else 'all-gather'})" if world > 1 else
+                                (f"[emulating rank {shard_rank} of {shard_world}: its rows, no exchange]" if shard_world > 1 else "one GPU"))},
         "roofline": {"bound": "hbm", "kernel": "knn_score_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(bytes_per_panel),
                      "launch": "the knn_score_kernel launches of one pass over the rows (<= 64 queries; a few rounds, theta tightens in between)",
@@ -268,7 +396,7 @@ def run_c4(args):
                      "mfma_tflops": round(tflops, 2), "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                      "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
         # the C restatement of ExactVectorQuery + collector on the host cores, bounded sample: first rows of segment 0
         from oracle import oracle
 
@@ -278,26 +406,35 @@ def run_c4(args):
         t1 = time.perf_counter()
         docs, scores, cnt = oracle.knn_exact(0, panels[(args.warmup + args.steps - 1) % len(panels)][:nq_cpu], first_seg, k, n_threads=cores)
         dt = time.perf_counter() - t1
-        # the sample doubles as a check of the device's answer: both top-k lists restricted to the sample's rows
-        ok = True
-        if n <= len(first_seg):
-            for qi in range(nq_cpu):
-                ok = ok and np.allclose(last[qi].scores, scores[qi], rtol=1e-5, atol=1e-6)
+        # The sample doubles as a check of the device's answer: a row of the sample that made the device's top-k over ALL rows is
+        # certainly among the k best of the sample -- so it must be in the oracle's list, with the same score (1e-5 relative: the
+        # summation orders differ); and the sample's best row that the device ranks at all must come in the oracle's order.
+        ok, checked = True, 0
+        for qi in range(nq_cpu):
+            dev = {int(d_): float(s_) for d_, s_ in zip(last[qi].docs, last[qi].scores) if int(d_) < len(first_seg)}
+            cpu = {int(d_): float(s_) for d_, s_ in zip(docs[qi][: cnt[qi]], scores[qi][: cnt[qi]])}
+            for d_, s_ in dev.items():
+                checked += 1
+                ok = ok and d_ in cpu and abs(cpu[d_] - s_) <= 1e-5 * max(abs(s_), 1e-30) + 1e-7
+            order = [d_ for d_ in docs[qi][: cnt[qi]].tolist() if d_ in dev]
+            ok = ok and order == [int(d_) for d_ in last[qi].docs if int(d_) in dev]
         out["cpu_baseline"] = {"value": round(nq_cpu * (n / len(first_seg)) ** -1 / dt, 3), "unit": "queries/s", "cores": cores, "kind": "port",
                                "rows_per_s": round(nq_cpu * len(first_seg) / dt, 1),
                                "sample": f"{nq_cpu} queries x the first {len(first_seg)} rows (oracle/nrt_oracle.c nrt_oracle_knn_exact, scalar fp32 "
                                          f"left to right, C + OpenMP, {cores} threads, {dt:.2f}s); value = queries/s extrapolated to {n} rows",
-                               "agrees_with_device": bool(ok) if n <= len(first_seg) else None}
-    print(json.dumps(out), flush=True)
+                               "agrees_with_device": bool(ok) and checked > 0, "device_hits_checked": checked}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
+    if world > 1:
+        dist.barrier()
+        ctx.dist_close()
+        dist.destroy_process_group()
     ctx.close()
 
 
 def main():
     args = parse_args()
-    if args.workload == "C4":
-        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
-            sys.exit("--workload C4 is a one-GPU line (the headline workload C3 is the multi-GPU one)")
-        return run_c4(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -315,6 +452,8 @@ def main():
                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
             sys.exit(subprocess.call(cmd))
         args.gpus = world
+    if args.workload == "C4":
+        return run_c4(args)
 
     import torch  # first: its bundled HIP runtime must be the one libnrtgpu.so binds to
     import torch.distributed as dist
@@ -374,7 +513,7 @@ def main():
              | (_lib.NRTGPU_FLAG_BLOCKING_WAIT if (shard_world > 1 or args.blocking_wait) else 0))
     # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
     # (the node's ranks share the host; 4 is the library's default and enough at one rank)
-    planner_threads = max(1, min(4, usable_cpus() // max(1, world * max(1, args.host_threads))))
+    planner_threads = args.planner_threads or max(1, min(4, usable_cpus() // max(1, max(world, shard_world) * max(1, args.host_threads))))
     ctx = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True, flags=flags,
                          host_threads=planner_threads)
     leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
@@ -387,6 +526,8 @@ def main():
     k_stride = (w.k + 15) // 16 * 16
     use_dist = world > 1 or args.force_dist
     exchange_name = None
+    emu_exchange = False
+    lib_mode = api.EXCHANGE_ALLGATHER
     if world > 1 and args.exchange:
         # cross-GPU bound exchange (include/nrtgpu.h): one shared-memory table per job, opened by every rank
         import uuid
@@ -410,7 +551,7 @@ def main():
         # instead: rank r receives every rank's lists for ITS B / world queries (rows [j * B/world, (j + 1) * B/world)
         # came from rank j) and merges only those -- 1/world of the bytes and of the merge work; the exchange stage
         # is overlapped with the scans either way, so this changes latency, not throughput.
-        split_reduce = (B % world == 0) and args.all_to_all
+        split_reduce = (B % world == 0) and args.all_to_all and args.torch_collective
         if split_reduce and world > 1:   # probe the collective once; every rank must take the same path
             ok = 1
             try:
@@ -428,10 +569,24 @@ def main():
         g_cnt = torch.zeros((rows,), dtype=torch.int32, device="cuda")
         g_hits = torch.zeros((rows,), dtype=torch.int64, device="cuda")
         mq = B // world if split_reduce else B
+        shard_exchange_world = shard_world if shard_world != world else world   # (emulation: the slice a rank of that job would own)
         merger = api.PreparedMerge(ctx, world, mq, k_stride, [w.k] * mq, [api.TOTAL_HITS_THRESHOLD] * mq)
         # The exchange stage through the C ABI (what a JVM caller has): the library's own RCCL communicator, one grouped
         # all-gather + merge per batch.  Every rank must take the same path: agree on it once.
-        if not (args.torch_collective or args.debug_same_gpu or split_reduce):
+        lib_mode = api.EXCHANGE_ALLTOALL if (args.exchange_mode == "alltoall" and B % world == 0) else api.EXCHANGE_ALLGATHER
+        # One GPU playing rank r of an N-GPU job (--emulate-world): the exchange stage does the work THAT rank would do -- the
+        # merge of N lists for its slice of the batch (all-to-all) or for every query (all-gather), the result copy and the
+        # unpacking -- with the other ranks' lists stood in for by copies of its own (the xGMI transfer itself, ~1 MB per link and
+        # batch in the all-to-all form, is not in it).
+        emu_exchange = world == 1 and shard_world > 1 and not args.torch_collective and B % shard_world == 0
+        if emu_exchange:
+            W_e = shard_world
+            mq_e = B // W_e if lib_mode == api.EXCHANGE_ALLTOALL else B
+            e_keys = torch.zeros((W_e, mq_e, k_stride), dtype=torch.int64, device="cuda")
+            e_cnt = torch.zeros((W_e, mq_e), dtype=torch.int32, device="cuda")
+            e_hits = torch.zeros((W_e, mq_e), dtype=torch.int64, device="cuda")
+            merger = api.PreparedMerge(ctx, W_e, mq_e, k_stride, [w.k] * mq_e, [api.TOTAL_HITS_THRESHOLD] * mq_e)
+        if not (args.torch_collective or args.debug_same_gpu or split_reduce or emu_exchange):
             ok = 1
             try:
                 box = [api.GpuContext.dist_unique_id() if rank == 0 else None]
@@ -447,7 +602,7 @@ def main():
                     try:
                         stdout_to_stderr(lambda: ctx.dist_init(world, rank, box[0]))
                         keys0, cnt0, hits0 = bufs[0]
-                        merger.run_dist(keys0.data_ptr(), cnt0.data_ptr(), hits0.data_ptr())   # (zero counts: merges nothing)
+                        merger.run_dist(keys0.data_ptr(), cnt0.data_ptr(), hits0.data_ptr(), lib_mode)   # (zero counts: merges nothing)
                     except Exception as e_:   # noqa: BLE001
                         probe_err.append(e_)
 
@@ -521,8 +676,22 @@ def main():
                 b = futs[i].result()
                 te0 = time.perf_counter()
                 keys, cnt, hits = bufs[b]
+                if emu_exchange:
+                    e_keys.copy_(keys[:mq_e].unsqueeze(0).expand(W_e, mq_e, k_stride))
+                    e_cnt.copy_(cnt[:mq_e].unsqueeze(0).expand(W_e, mq_e))
+                    e_hits.copy_(hits[:mq_e].unsqueeze(0).expand(W_e, mq_e))
+                    torch.cuda.current_stream().synchronize()
+                    free[b].release()
+                    te1 = time.perf_counter()
+                    merger.run(e_keys.data_ptr(), e_cnt.data_ptr(), e_hits.data_ptr())
+                    if record:
+                        lat.append(time.perf_counter() - t_start[i])
+                        stage["exchange_s"] += te1 - te0
+                        stage["merge_call_s"] += time.perf_counter() - te1
+                        stage["steps"] += 1
+                    continue
                 if lib_collective:
-                    merger.run_dist(keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())   # all-gather + merge, synchronous
+                    merger.run_dist(keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), lib_mode)   # exchange + merge, synchronous
                     free[b].release()
                     if record:
                         lat.append(time.perf_counter() - t_start[i])
@@ -556,11 +725,20 @@ def main():
     n_thr = max(1, args.host_threads)
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    tc0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    tc1 = thread_cpu_seconds()
+    # CPUs kept busy by kind of thread: this process's main thread (N > 1: the exchange stage), the library's helper threads
+    # (planning, unpacking), everything else (the threads submitting steps, the runtimes' own)
+    by_kind = {}
+    for tid, (comm, sec) in tc1.items():
+        kind = "main" if tid == os.getpid() else ("library helpers" if comm.startswith("nrtgpu-helper") else "submitting + runtime threads")
+        by_kind[kind] = by_kind.get(kind, 0.0) + sec - tc0.get(tid, (comm, 0.0))[1]
+    cpu_by_kind = {k_: round(v / max(elapsed, 1e-9), 2) for k_, v in by_kind.items()}
     host_cpu_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(elapsed, 1e-9)   # CPUs this rank kept busy
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.debug_same_gpu else "cuda")
@@ -584,6 +762,7 @@ def main():
     bytes_per_launch = (st["maxscore_postings"] if pruned else st["scan_postings"]) / launches * bpp
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
+    traffic_note = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
@@ -592,6 +771,7 @@ def main():
                 if (rec.get("workload") == args.workload and rec.get("batch") == B and rec.get("kernel") == kernel
                         and bool(rec.get("packed", False)) == bool(args.packed) and world == 1 and shard_world == 1):
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_note = rec.get("note")
         except Exception:
             traffic = None
     out = {
@@ -615,38 +795,35 @@ def main():
             "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
             "segments_per_gpu": len(corpus.segments),
             "sharding": "contiguous docid ranges, 1 process per GPU" + ((", RCCL all-to-all of per-GPU top-k, each rank merges its slice of the batch" if split_reduce else
-                                                                           ", RCCL all-gather of per-GPU top-k + merge on every rank") if use_dist else "")
-                        + ((" (collective inside the library: nrtgpu_dist_allgather_merge)" if lib_collective else " (collective: torch.distributed)") if use_dist else "")
+                                                                           (", RCCL all-to-all of per-GPU top-k, each rank merges and delivers its slice of the batch" if (lib_collective and lib_mode == api.EXCHANGE_ALLTOALL)
+                                                                            else ", RCCL all-gather of per-GPU top-k + merge on every rank")) if use_dist else "")
+                        + (f" (exchange stage emulated: merge of {shard_world} lists for {'this rank' + chr(39) + 's slice of the batch' if lib_mode == api.EXCHANGE_ALLTOALL else 'every query'})" if (use_dist and emu_exchange) else "")
+                        + ((f" (collective inside the library: nrtgpu_dist_exchange_merge, {'all-to-all' if lib_mode == api.EXCHANGE_ALLTOALL else 'all-gather'})"
+                            if lib_collective else ("" if emu_exchange else " (collective: torch.distributed)")) if use_dist else "")
                         + (", score-bound exchange between shards" if exchange_name else "")
                         + (f" [emulating rank {shard_rank} of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
             "dynamic_pruning": not args.no_prune,
             "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
-            "host_threads": n_thr, "host_cpus_busy": round(host_cpu_busy, 2),
+            "host_threads": n_thr, "host_cpus_busy": round(host_cpu_busy, 2), "host_cpus_busy_by_thread_kind": cpu_by_kind,
             "corpus_build_s": round(t_build, 1),
             "dist_stage_ms": ({k_: round(v / max(1, stage["steps"]) * 1e3, 3) for k_, v in stage.items() if k_ != "steps"}
                               if use_dist else None),   # per step on this rank: scan call (per scan thread), exchange, merge call
         },
-        "roofline": {
-            "bound": "hbm", "kernel": kernel,
-            "effective": pruned,   # pruned: algorithmic (exhaustive-scan) bytes over the time of a kernel that skips most of them
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "bytes_per_posting": bpp,
-            "algorithmic_bytes_per_launch": int(bytes_per_launch),
-            "achieved_at_8B_per_posting": round(achieved * bpp_fused / bpp, 1),    # (packed: 4 B either way)
-            "frac_at_8B_per_posting": round(achieved * bpp_fused / bpp / HBM_PEAK_GBS, 4),
-            "accumulators": "fixed-point u64" if (pruned or st.get("fixed_point_launches", 0) == st["scan_launches"]) else "fp64",
-            "physical_achieved": round(traffic / (scan_ms * 1e-3) / 1e9, 1) if (traffic and scan_ms > 0) else None,
-            "physical_frac": round(traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and scan_ms > 0) else None,
-            "other_scorer_ms_per_step": round((st["scan_ms"] if pruned else st["maxscore_ms"]) / max(1, st["batches"]), 4),
-            "avg_launch_ms": round(scan_ms, 4),
-            "merge_ms_per_step": round(st["merge_ms"] / max(1, st["batches"]), 4),
-            "host_plan_ms_per_step": round(st["host_plan_ms"] / max(1, st["batches"]), 4),
-            "traffic": traffic,
-        },
+        "roofline": roofline_record(kernel, pruned, scan_ms, bytes_per_launch, bpp, bpp_fused, traffic, traffic_note),
     }
+    out["roofline"].update({
+        "accumulators": "fixed-point u64" if (pruned or st.get("fixed_point_launches", 0) == st["scan_launches"]) else "fp64",
+        "other_scorer_ms_per_step": round((st["scan_ms"] if pruned else st["maxscore_ms"]) / max(1, st["batches"]), 4),
+        "merge_ms_per_step": round(st["merge_ms"] / max(1, st["batches"]), 4),
+        "host_plan_ms_per_step": round(st["host_plan_ms"] / max(1, st["batches"]), 4),
+    })
+    if rank == 0 and world == 1 and not use_dist and args.closed_loop and args.workload in ("C3", "C2"):
+        # queries/s AND latency (BASELINE.json's metric): the closed loop of SURVEY 8d, same index, same query set
+        callers = [int(x) for x in args.closed_loop.split(",") if x.strip()]
+        out["closed_loop"] = closed_loop(ctx, searcher, queries, mgr, callers, args.closed_loop_ms)
+        out["closed_loop"]["entry"] = "nrtgpu_search_bm25_coalesced, one query per call, native caller threads (bench/loadgen)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:
         out["cpu_baseline"] = cpu_baseline(corpus, qranks, w.k, args.cpu_queries)
         luc = lucene_baseline(w, searcher, queries, mgr, min(256, n_distinct))

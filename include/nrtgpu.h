@@ -267,6 +267,29 @@ int  nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* seg
  * results (keys n_queries x k_stride, counts, hit totals) -> grouped all-gather -> TopDocs.merge into `out`. */
 int  nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
                                  const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out);
+/* Who receives which answer.  ALLGATHER (BASELINE.json's north star, and what the two calls above do): every rank merges every
+ * query and holds every answer.  ALLTOALL: rank r receives every rank's lists for ITS slice of the batch -- queries
+ * [r * n / world, (r + 1) * n / world) -- and merges only those: 1 / world of the bytes on every xGMI link (point-to-point
+ * links: what an all-to-all wants), of the merge and of the host-side unpacking; the rank that owns a query answers its caller.
+ * `out` always has n_queries entries, indexed like the batch; entries of queries this rank does not own come back with
+ * n_hits = 0, total_hits = -1.  A batch the ranks cannot share evenly (n_queries % world != 0), or an RCCL without
+ * ncclSend / ncclRecv, is gathered whole: nrtgpu_dist_owned_range says what a call will deliver. */
+#define NRTGPU_EXCHANGE_ALLGATHER 0
+#define NRTGPU_EXCHANGE_ALLTOALL 1
+int  nrtgpu_dist_owned_range(nrtgpu_ctx* ctx, int32_t n_queries, int32_t mode, int32_t* first_query, int32_t* n_owned);
+int  nrtgpu_dist_search_bm25_batch_mode(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                        const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t mode, nrtgpu_topdocs* out);
+int  nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
+                                const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, int32_t mode,
+                                nrtgpu_topdocs* out);
+/* Exact vector search over a row-partitioned field (BASELINE config 4: 10M x 768 over 1..8 GPUs): every rank scores the rows of
+ * ITS leaves (nrtgpu_knn_exact on its shard, results kept in HBM), the per-rank top-k lists are exchanged and merged like the
+ * BM25 ones -- NrtKnnFloatVectorQuery's per-leaf merge (src/main/java/com/yelp/nrtsearch/server/query/vector/
+ * NrtKnnFloatVectorQuery.java:60-64; request glue: search/KnnUtils.java:47-66) taken across GPUs.  Every rank passes the same
+ * queries; total_hits = the live vectors of all shards. */
+int  nrtgpu_dist_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs, int32_t field_id,
+                           int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k, float boost, int32_t mode,
+                           nrtgpu_topdocs* out /* n_queries */);
 void nrtgpu_dist_close(nrtgpu_ctx* ctx);
 
 /* TopDocs.merge of n_lists per-GPU results laid out as the all-gather leaves them:

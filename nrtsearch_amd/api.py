@@ -33,6 +33,9 @@ TOTAL_HITS_THRESHOLD = 1000  # S/search/SearchRequestProcessor.java:102
 
 
 # ---- queries (only the shapes eligible for the device route) ------------------------
+EXCHANGE_ALLGATHER, EXCHANGE_ALLTOALL = 0, 1   # nrtgpu.h: NRTGPU_EXCHANGE_*
+
+
 @dataclasses.dataclass(frozen=True)
 class TermQuery:
     field: int
@@ -465,9 +468,11 @@ class GpuIndexSearcher:
     def search(self, query: Query, manager: TopScoreDocCollectorManager) -> TopDocs:
         return self.search_batch([query], [manager])[0]
 
-    def dist_search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> List[TopDocs]:
-        """The multi-GPU search through nrtgpu_dist_search_bm25_batch: this rank's leaves, RCCL all-gather + merge inside
-        the library; every rank gets every answer (GpuContext.dist_init first)."""
+    def dist_search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager],
+                          mode: int = EXCHANGE_ALLGATHER) -> List[Optional[TopDocs]]:
+        """The multi-GPU search through nrtgpu_dist_search_bm25_batch_mode: this rank's leaves, RCCL exchange + merge inside
+        the library (GpuContext.dist_init first).  EXCHANGE_ALLGATHER: every rank gets every answer; EXCHANGE_ALLTOALL: this
+        rank gets the answers of its slice of the batch, None for the others."""
         n = len(queries)
         m = self._marshal(queries, managers)
         outs = (_lib.TopDocs * n)()
@@ -480,9 +485,33 @@ class GpuIndexSearcher:
             outs[qi].capacity = cap
             outs[qi].docs = d.ctypes.data_as(C.POINTER(C.c_int32))
             outs[qi].scores = s.ctypes.data_as(C.POINTER(C.c_float))
-        _lib.check(_lib.load().nrtgpu_dist_search_bm25_batch(self.ctx._h, self._segs, self._bases, len(self.leaves), m.queries, n, outs))
-        return [TopDocs(bufs[qi][0][: outs[qi].n_hits].copy(), bufs[qi][1][: outs[qi].n_hits].copy(), int(outs[qi].total_hits),
+        _lib.check(_lib.load().nrtgpu_dist_search_bm25_batch_mode(self.ctx._h, self._segs, self._bases, len(self.leaves), m.queries, n,
+                                                                  int(mode), outs))
+        return [None if outs[qi].total_hits < 0 else
+                TopDocs(bufs[qi][0][: outs[qi].n_hits].copy(), bufs[qi][1][: outs[qi].n_hits].copy(), int(outs[qi].total_hits),
                         bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n)]
+
+    def dist_knn_exact(self, field: int, similarity: str, queries: np.ndarray, k: int, boost: float = 1.0,
+                       mode: int = EXCHANGE_ALLGATHER) -> List[Optional[TopDocs]]:
+        """Exact vector search over a row-partitioned field (nrtgpu_dist_knn_exact): this rank's leaves, exchange + merge
+        inside the library; every rank passes the same queries."""
+        queries = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        if similarity == "normalized_cosine":
+            queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True).astype(np.float32), dtype=np.float32)
+        nq, dim = queries.shape
+        outs = (_lib.TopDocs * nq)()
+        docs = np.zeros((nq, k), dtype=np.int32)
+        scores = np.zeros((nq, k), dtype=np.float32)
+        for qi in range(nq):
+            outs[qi].capacity = k
+            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_dist_knn_exact(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
+                                                     self.SIMILARITY[similarity], queries.ctypes.data, nq, dim, int(k),
+                                                     C.c_float(boost), int(mode), outs))
+        return [None if outs[qi].total_hits < 0 else
+                TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
+                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
 
     def supported(self, query: Query, manager: TopScoreDocCollectorManager) -> bool:
         """The eligibility predicate alone (nrtgpu_query_supported): would the device route take this query?"""
@@ -658,12 +687,16 @@ class PreparedMerge:
             self.ctx._h, self.n_lists, self.n, self.k_stride, C.c_void_p(d_keys), C.c_void_p(d_counts),
             C.c_void_p(d_hits), self._ks.ctypes.data, self._thr.ctypes.data, self._outs))
 
-    def run_dist(self, d_keys: int, d_counts: int, d_hits: int) -> None:
-        """This rank's device-resident shard results -> RCCL all-gather inside the library -> merge
-        (nrtgpu_dist_allgather_merge; GpuContext.dist_init first; n_lists must equal the world size)."""
-        _lib.check(_lib.load().nrtgpu_dist_allgather_merge(
+    def run_dist(self, d_keys: int, d_counts: int, d_hits: int, mode: int = EXCHANGE_ALLGATHER) -> None:
+        """This rank's device-resident shard results -> RCCL exchange inside the library -> merge
+        (nrtgpu_dist_exchange_merge; GpuContext.dist_init first; n_lists must equal the world size).  EXCHANGE_ALLTOALL:
+        only this rank's slice of the batch is merged and delivered (owned(qi))."""
+        _lib.check(_lib.load().nrtgpu_dist_exchange_merge(
             self.ctx._h, self.n, self.k_stride, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits),
-            self._ks.ctypes.data, self._thr.ctypes.data, self._outs))
+            self._ks.ctypes.data, self._thr.ctypes.data, int(mode), self._outs))
+
+    def owned(self, qi: int) -> bool:
+        return self._outs[qi].total_hits >= 0
 
     def topdocs(self, qi: int) -> TopDocs:
         o = self._outs[qi]

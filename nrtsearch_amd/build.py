@@ -48,5 +48,18 @@ def build(force: bool = False, verbose: bool = False, extra=(), out: str = OUT) 
     return out
 
 
+LOADGEN_SRC = os.path.join(HERE, "..", "bench", "loadgen", "loadgen.cpp")
+LOADGEN_OUT = os.path.join(HERE, "..", "bench", "loadgen", "libloadgen.so")
+
+
+def build_loadgen() -> str:
+    """bench.py's closed-loop load generator: a host-only helper that knows nothing but include/nrtgpu.h (not part of the product)."""
+    src, out = os.path.abspath(LOADGEN_SRC), os.path.abspath(LOADGEN_OUT)
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "nrtgpu.h"))):
+        return out
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", out])
+    return out
+
+
 if __name__ == "__main__":
     print(build_dev(verbose=True) if "--dev" in sys.argv else build(force="--force" in sys.argv, verbose=True))

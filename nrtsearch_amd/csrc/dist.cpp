@@ -13,6 +13,8 @@ typedef void* NcclComm;
 typedef int (*GetUniqueIdFn)(NcclUniqueId*);
 typedef int (*CommInitRankFn)(NcclComm*, int, NcclUniqueId, int);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, NcclComm, hipStream_t);
+typedef int (*SendFn)(const void*, size_t, int, int, NcclComm, hipStream_t);
+typedef int (*RecvFn)(void*, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*CommDestroyFn)(NcclComm);
 typedef int (*GroupFn)(void);
 typedef const char* (*ErrStrFn)(int);
@@ -23,6 +25,8 @@ struct Rccl {
   GetUniqueIdFn get_unique_id = nullptr;
   CommInitRankFn comm_init_rank = nullptr;
   AllGatherFn all_gather = nullptr;
+  SendFn send = nullptr;   // (point-to-point: the all-to-all form of the exchange; absent in very old builds -> all-gather only)
+  RecvFn recv = nullptr;
   CommDestroyFn comm_destroy = nullptr;
   GroupFn group_start = nullptr, group_end = nullptr;
   ErrStrFn err_str = nullptr;
@@ -40,6 +44,8 @@ Rccl* rccl() {
     r.get_unique_id = (GetUniqueIdFn)dlsym(r.lib, "ncclGetUniqueId");
     r.comm_init_rank = (CommInitRankFn)dlsym(r.lib, "ncclCommInitRank");
     r.all_gather = (AllGatherFn)dlsym(r.lib, "ncclAllGather");
+    r.send = (SendFn)dlsym(r.lib, "ncclSend");
+    r.recv = (RecvFn)dlsym(r.lib, "ncclRecv");
     r.comm_destroy = (CommDestroyFn)dlsym(r.lib, "ncclCommDestroy");
     r.group_start = (GroupFn)dlsym(r.lib, "ncclGroupStart");
     r.group_end = (GroupFn)dlsym(r.lib, "ncclGroupEnd");
@@ -59,7 +65,8 @@ struct nrtgpu_dist {
   hipStream_t stream = nullptr;
   hipEvent_t ev_wait = nullptr;   // NRTGPU_FLAG_BLOCKING_WAIT
   DevBuf local, gathered;   // [keys | hits | counts] of this rank / of every rank
-  std::mutex mu;            // one collective at a time per communicator
+  std::mutex mu;            // one collective (one user of `gathered`) at a time per communicator
+  std::mutex call_mu;       // one whole search call (one user of `local`) at a time: taken before `mu`
 };
 
 extern "C" int nrtgpu_dist_unique_id(void* out128) {
@@ -84,8 +91,13 @@ extern "C" int nrtgpu_dist_init(nrtgpu_ctx* ctx, int32_t world, int32_t rank, co
   NcclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   if (int rc = r->comm_init_rank(&d->comm, world, id, rank)) return nccl_fail("ncclCommInitRank", rc);
-  HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&d->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
+  hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_wait, hipEventBlockingSync | hipEventDisableTiming);
+  if (e != hipSuccess) {   // (the communicator must not outlive a failed init)
+    (void)r->comm_destroy(d->comm);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    return fail(NRTGPU_ERR_HIP, "nrtgpu_dist_init: %s", hipGetErrorString(e));
+  }
   ctx->dist = d.release();
   return NRTGPU_OK;
 }
@@ -105,41 +117,142 @@ extern "C" void nrtgpu_dist_close(nrtgpu_ctx* ctx) {
   delete d;
 }
 
-// The exchange stage alone: this rank's device-resident shard results (what nrtgpu_search_bm25_batch_device[_epoch] left
-// in HBM: keys n_queries x k_stride, counts, hit totals) -> ONE grouped all-gather over xGMI -> TopDocs.merge on this
-// rank.  A caller that pipelines (scan threads ahead of the exchange) issues these in batch order on every rank.
-extern "C" int nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys,
-                                           const void* d_counts, const void* d_hits, const int32_t* ks,
-                                           const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
+// ------------------------------------------------------------------------------------------------
+// The exchange stage: this rank's device-resident shard results (keys n_queries x k_stride, counts, hit totals: what
+// nrtgpu_search_bm25_batch_device[_epoch] or the vector search left in HBM) -> the other ranks -> TopDocs.merge.
+//   mode NRTGPU_EXCHANGE_ALLGATHER : ONE grouped RCCL all-gather; every rank merges every query and holds every answer
+//                                    (BASELINE.json's north star)
+//   mode NRTGPU_EXCHANGE_ALLTOALL  : grouped ncclSend / ncclRecv -- rank r receives every rank's lists for ITS slice of the
+//                                    batch, queries [r * n / W, (r + 1) * n / W), and merges only those: 1 / W of the bytes on
+//                                    every link (xGMI is point-to-point: exactly what an all-to-all wants), 1 / W of the merge
+//                                    and of the host-side unpacking.  The rank that owns a query answers its caller.
+// Gathered layout [array][list][query]: what nrtgpu_merge_topk_device reads.
+// ------------------------------------------------------------------------------------------------
+struct Gathered {
+  char* keys = nullptr;
+  char* cnt = nullptr;
+  char* hits = nullptr;
+  int32_t first_q = 0, n_q = 0;   // the queries this rank merges
+};
+
+static void owned_range(int32_t world, int32_t rank, int32_t n_queries, int32_t mode, int32_t* first, int32_t* count) {
+  if (mode == NRTGPU_EXCHANGE_ALLTOALL && world > 0 && n_queries % world == 0) {
+    *count = n_queries / world;
+    *first = rank * *count;
+  } else {   // (a batch the ranks cannot share evenly is gathered whole)
+    *first = 0;
+    *count = n_queries;
+  }
+}
+
+extern "C" int nrtgpu_dist_owned_range(nrtgpu_ctx* ctx, int32_t n_queries, int32_t mode, int32_t* first_query, int32_t* n_owned) {
+  if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
+  if (!first_query || !n_owned || n_queries <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
+  const bool p2p = rccl() && rccl()->send && rccl()->recv;
+  owned_range(ctx->dist->world, ctx->dist->rank, n_queries, (mode == NRTGPU_EXCHANGE_ALLTOALL && p2p) ? mode : NRTGPU_EXCHANGE_ALLGATHER, first_query,
+              n_owned);
+  return NRTGPU_OK;
+}
+
+// (d->mu held by the caller)
+static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
+                          const void* d_hits, int32_t mode, Gathered* g) {
+  Rccl* r = rccl();
+  const size_t W = (size_t)d->world;
+  if (mode == NRTGPU_EXCHANGE_ALLTOALL && !(r->send && r->recv)) mode = NRTGPU_EXCHANGE_ALLGATHER;
+  owned_range(d->world, d->rank, n_queries, mode, &g->first_q, &g->n_q);
+  const bool sliced = g->n_q != n_queries;
+  const size_t nq = (size_t)g->n_q, kb = nq * (size_t)k_stride * 8, hb = nq * 8, cb = nq * 4;
+  if (int rc = d->gathered.reserve((kb + hb + ((cb + 7) & ~(size_t)7)) * W)) return rc;
+  char* gb = (char*)d->gathered.p;
+  g->keys = gb;
+  g->hits = gb + W * kb;
+  g->cnt = gb + W * (kb + hb);
+  if (!sliced) {
+    if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
+    int rc1 = r->all_gather(d_keys, g->keys, kb / 8, kNcclInt64, d->comm, d->stream);
+    int rc2 = r->all_gather(d_hits, g->hits, hb / 8, kNcclInt64, d->comm, d->stream);
+    int rc3 = r->all_gather(d_counts, g->cnt, cb / 4, kNcclInt32, d->comm, d->stream);
+    if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
+    if (rc1 || rc2 || rc3) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : rc3));
+  } else {
+    // my lists for peer p's slice go to p; p's lists for my slice arrive as list p.  My own slice: a device copy.
+    const char* lk = (const char*)d_keys;
+    const char* lh = (const char*)d_hits;
+    const char* lc = (const char*)d_counts;
+    int bad = 0;
+    if (W > 1) {
+      if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
+      for (int p = 0; p < d->world; ++p) {
+        if (p == d->rank) continue;
+        bad |= r->send(lk + (size_t)p * kb, kb / 8, kNcclInt64, p, d->comm, d->stream);
+        bad |= r->recv(g->keys + (size_t)p * kb, kb / 8, kNcclInt64, p, d->comm, d->stream);
+        bad |= r->send(lh + (size_t)p * hb, hb / 8, kNcclInt64, p, d->comm, d->stream);
+        bad |= r->recv(g->hits + (size_t)p * hb, hb / 8, kNcclInt64, p, d->comm, d->stream);
+        bad |= r->send(lc + (size_t)p * cb, cb / 4, kNcclInt32, p, d->comm, d->stream);
+        bad |= r->recv(g->cnt + (size_t)p * cb, cb / 4, kNcclInt32, p, d->comm, d->stream);
+      }
+      if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
+      if (bad) return nccl_fail("ncclSend / ncclRecv", bad);
+    }
+    const size_t me = (size_t)d->rank;
+    HIP_TRY(hipMemcpyAsync(g->keys + me * kb, lk + me * kb, kb, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(g->hits + me * hb, lh + me * hb, hb, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(g->cnt + me * cb, lc + me * cb, cb, hipMemcpyDeviceToDevice, d->stream));
+  }
+  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, d->stream, d->ev_wait));
+  return NRTGPU_OK;
+}
+
+// `out` has n_queries entries (indexed like the batch); the entries of the queries this rank does not own (all-to-all) are
+// marked n_hits = 0, total_hits = -1.
+static void mark_not_owned(nrtgpu_topdocs* out, int32_t n_queries, const Gathered& g) {
+  for (int32_t qi = 0; qi < n_queries; ++qi)
+    if (qi < g.first_q || qi >= g.first_q + g.n_q) {
+      out[qi].n_hits = 0;
+      out[qi].total_hits = -1;
+      out[qi].total_hits_is_lower_bound = 0;
+    }
+}
+
+extern "C" int nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
+                                          const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, int32_t mode,
+                                          nrtgpu_topdocs* out) {
   if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
   if (!d_keys || !d_counts || !d_hits || !ks || !total_hits_thresholds || !out || n_queries <= 0 || k_stride <= 0 || k_stride % 16 != 0)
     return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
-  Rccl* r = rccl();
+  if (mode != NRTGPU_EXCHANGE_ALLGATHER && mode != NRTGPU_EXCHANGE_ALLTOALL) return fail(NRTGPU_ERR_INVALID_ARG, "unknown exchange mode %d", mode);
   nrtgpu_dist* d = ctx->dist;
   HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lk(d->mu);   // one collective (and one user of the gathered buffer) at a time per communicator
+  Gathered g;
+  if (int rc = exchange_lists(ctx, d, n_queries, k_stride, d_keys, d_counts, d_hits, mode, &g)) return rc;
+  mark_not_owned(out, n_queries, g);
+  return nrtgpu_merge_topk_device(ctx, d->world, g.n_q, k_stride, g.keys, g.cnt, g.hits, ks + g.first_q, total_hits_thresholds + g.first_q,
+                                  out + g.first_q);
+}
+
+extern "C" int nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys,
+                                           const void* d_counts, const void* d_hits, const int32_t* ks,
+                                           const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
+  return nrtgpu_dist_exchange_merge(ctx, n_queries, k_stride, d_keys, d_counts, d_hits, ks, total_hits_thresholds, NRTGPU_EXCHANGE_ALLGATHER, out);
+}
+
+// This rank's buffer for a whole call: [keys | hits | counts] of n_queries queries.  Calls on one communicator are serialised
+// (`call_mu`): the buffer belongs to the call from the local search to the end of the exchange.
+static int local_lists(nrtgpu_dist* d, int32_t n_queries, int32_t k_stride, char** keys, char** hits, char** cnts) {
   const size_t nq = (size_t)n_queries, kb = nq * (size_t)k_stride * 8, hb = nq * 8, cb = nq * 4;
-  const size_t W = (size_t)d->world;
-  std::lock_guard<std::mutex> lk(d->mu);
-  if (int rc = d->gathered.reserve((kb + hb + ((cb + 7) & ~(size_t)7)) * W)) return rc;
-  // gathered[array][rank][query]: the layout nrtgpu_merge_topk_device reads
-  char* gb = (char*)d->gathered.p;
-  char* g_keys = gb;
-  char* g_hits = gb + W * kb;
-  char* g_cnt = gb + W * (kb + hb);
-  if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
-  int rc1 = r->all_gather(d_keys, g_keys, kb / 8, kNcclInt64, d->comm, d->stream);
-  int rc2 = r->all_gather(d_hits, g_hits, hb / 8, kNcclInt64, d->comm, d->stream);
-  int rc3 = r->all_gather(d_counts, g_cnt, cb / 4, kNcclInt32, d->comm, d->stream);
-  if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
-  if (rc1 || rc2 || rc3) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : rc3));
-  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, d->stream, d->ev_wait));
-  return nrtgpu_merge_topk_device(ctx, d->world, n_queries, k_stride, g_keys, g_cnt, g_hits, ks, total_hits_thresholds, out);
+  if (int rc = d->local.reserve(kb + hb + ((cb + 7) & ~(size_t)7))) return rc;
+  *keys = (char*)d->local.p;
+  *hits = *keys + kb;
+  *cnts = *hits + hb;
+  return NRTGPU_OK;
 }
 
 // Every rank calls this with the same queries in the same order (index-global statistics in the weights) over ITS
-// leaves; every rank receives every answer.
-extern "C" int nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
-                                             const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out) {
+// leaves.  mode: who receives which answer (above).
+extern "C" int nrtgpu_dist_search_bm25_batch_mode(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                                  const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t mode, nrtgpu_topdocs* out) {
   if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
   if (!queries || !out || n_queries <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
   nrtgpu_dist* d = ctx->dist;
@@ -147,21 +260,42 @@ extern "C" int nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* 
   int32_t kmax = 1;
   for (int qi = 0; qi < n_queries; ++qi) kmax = std::max(kmax, queries[qi].k);
   const int32_t k_stride = (int32_t)round_up((uint32_t)std::min(kmax, NRTGPU_MAX_K), 16);
-  const size_t nq = (size_t)n_queries, kb = nq * (size_t)k_stride * 8, hb = nq * 8, cb = nq * 4;
-  const size_t o_k = 0, o_h = kb, o_c = kb + hb, block = kb + hb + ((cb + 7) & ~(size_t)7);
-  char* lb = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(d->mu);
-    if (int rc = d->local.reserve(block)) return rc;
-    lb = (char*)d->local.p;
-  }
+  std::lock_guard<std::mutex> call(d->call_mu);   // the local buffer is this call's until its exchange is over
+  char *lk = nullptr, *lh = nullptr, *lc = nullptr;
+  if (int rc = local_lists(d, n_queries, k_stride, &lk, &lh, &lc)) return rc;
   // 1. this rank's shard: top-k per query stays in HBM (synchronous: complete when it returns)
-  if (int rc = nrtgpu_search_bm25_batch_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lb + o_k, lb + o_c, lb + o_h)) return rc;
-  // 2 + 3. all-gather over xGMI, TopDocs.merge of the shards' lists on this rank
-  std::vector<int32_t> ks(nq), thr(nq);
-  for (size_t q = 0; q < nq; ++q) {
-    ks[q] = queries[q].k;
-    thr[q] = queries[q].total_hits_threshold;
+  if (int rc = nrtgpu_search_bm25_batch_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lk, lc, lh)) return rc;
+  // 2 + 3. the exchange over xGMI, TopDocs.merge of the shards' lists
+  std::vector<int32_t> ks((size_t)n_queries), thr((size_t)n_queries);
+  for (int32_t q = 0; q < n_queries; ++q) {
+    ks[(size_t)q] = queries[q].k;
+    thr[(size_t)q] = queries[q].total_hits_threshold;
   }
-  return nrtgpu_dist_allgather_merge(ctx, n_queries, k_stride, lb + o_k, lb + o_c, lb + o_h, ks.data(), thr.data(), out);
+  return nrtgpu_dist_exchange_merge(ctx, n_queries, k_stride, lk, lc, lh, ks.data(), thr.data(), mode, out);
+}
+
+extern "C" int nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                             const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out) {
+  return nrtgpu_dist_search_bm25_batch_mode(ctx, segs, doc_bases, n_segs, queries, n_queries, NRTGPU_EXCHANGE_ALLGATHER, out);
+}
+
+// Exact vector search over a row-partitioned field (BASELINE config 4): every rank scores ITS rows (the leaves of its docid
+// range), the per-rank top-k lists are exchanged like the BM25 ones and merged -- NrtKnnFloatVectorQuery's per-leaf merge
+// (src/main/java/com/yelp/nrtsearch/server/query/vector/NrtKnnFloatVectorQuery.java:60-64; the per-request glue:
+// search/KnnUtils.java:47-66) taken across GPUs.  total_hits = the live vectors of all shards.
+extern "C" int nrtgpu_dist_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs, int32_t field_id,
+                                     int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k, float boost, int32_t mode,
+                                     nrtgpu_topdocs* out) {
+  if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
+  if (!queries || !out || n_queries <= 0 || k <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
+  if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
+  nrtgpu_dist* d = ctx->dist;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int32_t k_stride = (int32_t)round_up((uint32_t)k, 16);
+  std::lock_guard<std::mutex> call(d->call_mu);
+  char *lk = nullptr, *lh = nullptr, *lc = nullptr;
+  if (int rc = local_lists(d, n_queries, k_stride, &lk, &lh, &lc)) return rc;
+  if (int rc = knn_exact_device(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, k_stride, lk, lc, lh)) return rc;
+  std::vector<int32_t> ks((size_t)n_queries, k), thr((size_t)n_queries, INT32_MAX);
+  return nrtgpu_dist_exchange_merge(ctx, n_queries, k_stride, lk, lc, lh, ks.data(), thr.data(), mode, out);
 }

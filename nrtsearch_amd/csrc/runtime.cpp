@@ -61,7 +61,11 @@ void release_slot(nrtgpu_ctx* ctx, Slot* s) {
 // helper threads
 // ------------------------------------------------------------------------------------------------
 WorkPool::WorkPool(int helpers) {
-  for (int i = 0; i < helpers; ++i) threads_.emplace_back([this] { loop(); });
+  for (int i = 0; i < helpers; ++i)
+    threads_.emplace_back([this] {
+      (void)pthread_setname_np(pthread_self(), "nrtgpu-helper");   // (shows up in /proc/<pid>/task/<tid>/comm: who burns the CPUs)
+      loop();
+    });
 }
 WorkPool::~WorkPool() {
   {

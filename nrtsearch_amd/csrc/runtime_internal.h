@@ -481,6 +481,12 @@ int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_m
 // vectors of the field whose doc is live (the hits of an exact vector query over the segment)
 int64_t live_vector_count(const nrtgpu_seg* seg, const FieldData& f);
 
+// ---- vectors (vectors.cpp) ---------------------------------------------------------------------
+// nrtgpu_knn_exact with device-resident results (per query k_stride sorted keys, count, live-vector total): the multi-GPU path
+int knn_exact_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs, int32_t field_id,
+                     int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k, float boost, int32_t k_stride,
+                     void* d_keys, void* d_counts, void* d_hits);
+
 // ---- planner (planner.cpp) ---------------------------------------------------------------------
 struct HostPlan {
   std::vector<DQuery> queries;

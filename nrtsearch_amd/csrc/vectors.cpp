@@ -13,8 +13,11 @@ static const int kKnnMaxQ = 64;   // queries per pass over the rows: two panels 
 // totalHits = the docs returned.
 static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                     int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
-                    int32_t k, float boost, bool knn_request, int32_t filter_mask, float min_score, nrtgpu_topdocs* out) {
-  if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+                    int32_t k, float boost, bool knn_request, int32_t filter_mask, float min_score, nrtgpu_topdocs* out,
+                    char* ext_keys = nullptr, char* ext_cnts = nullptr, char* ext_hits = nullptr) {
+  // ext_*: device-resident results instead of `out` (the multi-GPU path): per query k_stride sorted keys, its count, and the live
+  // vectors of these leaves as the hit total -- the layout the exchange stage takes
+  if (!ctx || !queries || (!out && !ext_keys) || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || k <= 0 || dim <= 0 || sim < 0 || sim > 3) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
   if (dim % 16 != 0 || dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 2048)", dim);
@@ -139,6 +142,14 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       ctx->stats.knn_score_ms += ms;
       ctx->stats.knn_rows += seen;
     }
+    if (ext_keys) {   // stays in HBM: what nrtgpu_dist_knn_exact exchanges
+      std::vector<uint64_t> tv((size_t)nq, (uint64_t)total_vec);
+      HIP_TRY(hipMemcpyAsync(ext_keys + (size_t)q0 * k_stride * 8, wb + o_tk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ext_cnts + (size_t)q0 * 4, wb + o_tc, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ext_hits + (size_t)q0 * 8, tv.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));   // (tv is a stack vector; the workspace is reused by the next panel)
+      continue;
+    }
     const uint64_t* keys = (const uint64_t*)ho;
     const uint32_t* cnts = (const uint32_t*)(ho + (size_t)kKnnMaxQ * k_stride * 8);
     for (int q = 0; q < nq; ++q) {
@@ -165,6 +176,15 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     }
   }
   return NRTGPU_OK;
+}
+
+int nrtgpu::rt::knn_exact_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs, int32_t field_id,
+                                 int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k, float boost, int32_t k_stride,
+                                 void* d_keys, void* d_counts, void* d_hits) {
+  if (!d_keys || !d_counts || !d_hits) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (k_stride != (int32_t)round_up((uint32_t)k, 16)) return fail(NRTGPU_ERR_INVALID_ARG, "k_stride must be numHits rounded up to 16");
+  return knn_impl(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, false, 0, 0.0f, nullptr, (char*)d_keys,
+                  (char*)d_counts, (char*)d_hits);
 }
 
 extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,

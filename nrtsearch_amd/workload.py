@@ -26,7 +26,7 @@ class Workload:
 
 
 C2 = Workload("C2: 1M docs, Zipf terms, 2-term BooleanQuery BM25 top-100", 1_000_000, 2, 100, 4096, 6)
-C3 = Workload("C3: 10M docs, 5-term disjunction BM25 top-1000", 10_000_000, 5, 1000, 4096, 10)
+C3 = Workload("C3: 10M docs, 5-term disjunction BM25 top-1000", 10_000_000, 5, 1000, 10240, 10)   # 10 000 queries, ten 1024-query batches
 SMOKE = Workload("smoke: 200k docs, 3-term disjunction top-100", 200_000, 3, 100, 8, 3, max_rank=2000)
 
 

@@ -1,11 +1,44 @@
-"""The bench line's contract, checked on the committed line of the round (no GPU): the keys the driver and the judge read,
-and the arithmetic between them (queries/s vs ms per step, roofline fraction vs achieved / peak, algorithmic bytes vs
-the per-posting figure of SURVEY 8d)."""
+"""The bench line's contract, checked on CODE (no GPU): bench.roofline_record builds the `roofline` object from measured
+numbers -- its arithmetic (fraction = achieved / peak; algorithmic bytes = the per-posting figure of SURVEY 8d; a pruned
+kernel's algorithmic rate is reported as an EFFECTIVE figure and its fraction is the physical one) is asserted on synthetic
+inputs.  The committed line of the round is checked for the keys the driver and the judge read."""
 import glob
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_roofline_record_exhaustive_scan_is_an_algorithmic_bandwidth_fraction():
+    # 4.05 G postings x 9 B in 10.1 ms
+    r = bench.roofline_record("bm25_scan_kernel", False, 10.1, 4.05e9 * 9, 9, 8, 31.4e9, "x2 wide reads")
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["effective"] is False
+    assert abs(r["achieved"] - 4.05e9 * 9 / 10.1e-3 / 1e9) < 0.1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["effective_frac"] is None and r["effective_achieved"] is None
+    assert abs(r["frac_at_8B_per_posting"] - r["frac"] * 8 / 9) < 1e-3
+    assert abs(r["physical_achieved"] - 31.4e9 / 10.1e-3 / 1e9) < 0.1 and r["traffic"] == 31.4e9
+    assert "static profile" in r["traffic_source"]
+
+
+def test_roofline_record_pruned_kernel_reports_the_physical_fraction():
+    r = bench.roofline_record("bm25_maxscore_kernel", True, 2.9, 4.05e9 * 9, 9, 8, 7.0e9, "counted + streamed bytes")
+    assert r["effective"] is True
+    # frac / achieved: what the kernel physically fetched; the effective (algorithmic) rate beside it may exceed the peak
+    assert abs(r["achieved"] - 7.0e9 / 2.9e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4 and r["frac"] < 1.0
+    assert abs(r["effective_achieved"] - 4.05e9 * 9 / 2.9e-3 / 1e9) < 0.1 and r["effective_frac"] > 1.0
+    assert r["achieved_is"].startswith("physical")
+    # without a PMC profile there is no physical figure: the algorithmic one stays, flagged effective
+    r2 = bench.roofline_record("bm25_maxscore_kernel", True, 2.9, 4.05e9 * 9, 9, 8, None)
+    assert r2["traffic"] is None and r2["physical_frac"] is None and r2["traffic_source"] is None
+    assert abs(r2["frac"] - r2["effective_frac"]) < 1e-9 and r2["achieved_is"].startswith("algorithmic")
+
+
+def test_usable_cpus_is_positive():
+    assert bench.usable_cpus() >= 1
 
 
 def _line(path):
@@ -29,19 +62,9 @@ def test_committed_bench_line_has_the_contract_keys():
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # achieved = algorithmic bytes per launch / average launch time (HIP events), 9 B per posting
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * r["achieved"]
     assert r["bytes_per_posting"] == 9
     assert r["avg_launch_ms"] <= d["ms_per_step"]          # the kernel fits inside the step
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
-
-
-def test_packed_line_reports_its_own_denominator():
-    path = os.path.join(ROOT, "profiles", "r02_bench_c3_packed.json")
-    if not os.path.exists(path):
-        return
-    d = _line(path)
-    assert "packed" in d["metric"] and d["roofline"]["bytes_per_posting"] == 4

@@ -57,6 +57,25 @@ def _worker(rank: int, world: int, port: int, ret):
             ed, es, etotal, _ = oracle.search_bm25(full, qr[qi].tolist(), k, total_hits_threshold=2**31 - 1)
             ok &= md.tolist() == ed.tolist() and ms.view(np.uint32).tolist() == es.view(np.uint32).tolist()
             ok &= int(a_hits[:, j].sum()) == etotal
+        # Row-partitioned exact vector search (BASELINE config 4; nrtgpu_dist_knn_exact): every rank scores its rows for every
+        # query, the per-rank top-k lists are all-gathered and merged -- the whole matrix's answer
+        rng = np.random.Generator(np.random.PCG64(5))
+        n_rows, dim, kk = 4000, 32, 20
+        mat = rng.standard_normal((n_rows, dim), dtype=np.float32)
+        qv = rng.standard_normal((4, dim), dtype=np.float32)
+        lo, hi = n_rows * rank // world, n_rows * (rank + 1) // world
+        d_, s_, c_ = oracle.knn_exact(0, qv, mat[lo:hi], kk, doc_base=lo)
+        vkeys = np.zeros((len(qv), 32), dtype=np.int64)
+        for qi in range(len(qv)):
+            vkeys[qi] = nd.pack_keys(d_[qi, : c_[qi]], s_[qi, : c_[qi]], 32)
+        gk, gc, gh = nd.all_gather_topk(torch.from_numpy(vkeys), torch.from_numpy(c_.astype(np.int32)),
+                                        torch.from_numpy(np.full(len(qv), hi - lo, dtype=np.int64)))
+        wd, ws, wc = oracle.knn_exact(0, qv, mat, kk)
+        for qi in range(len(qv)):
+            lists = [nd.unpack_keys(gk[r, qi].numpy(), int(gc[r, qi])) for r in range(world)]
+            md, ms = oracle.topdocs_merge(kk, lists)
+            ok &= md.tolist() == wd[qi, : wc[qi]].tolist() and ms.view(np.uint32).tolist() == ws[qi, : wc[qi]].view(np.uint32).tolist()
+            ok &= int(gh[:, qi].sum()) == n_rows
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -89,6 +108,34 @@ def test_shard_ranges_cover_the_index():
             for (a, b), (c, d) in zip(ranges, ranges[1:]):
                 assert b == c and a <= b
             assert all(a % 1024 == 0 for a, b in ranges if b > a)   # non-empty ranges start on a sub-tile boundary
+
+
+def test_shard_leaves_tile_the_index():
+    """layout "index": a rank owns the pieces of the INDEX's segments inside its docid range; the ranks' leaves tile the index and
+    a boundary next to a segment boundary snaps onto it (no slivers)."""
+    sys.path.insert(0, ROOT)
+    import dataclasses
+
+    from nrtsearch_amd import synth, workload
+
+    for n_docs in (10_000_000, 3_000_000, 1_234_567):
+        w = dataclasses.replace(workload.C3, n_docs=n_docs)
+        whole = synth.tiered_segment_sizes(n_docs, w.segments_per_shard)
+        for world in (1, 2, 4, 8):
+            pos = 0
+            pieces = []
+            for r in range(world):
+                lo, hi, sizes = workload.shard_leaves(w, world, r)
+                assert lo == pos and sum(sizes) == hi - lo
+                pos = hi
+                pieces += sizes
+            assert pos == n_docs
+            if world == 1:
+                assert pieces == whole
+            # cutting never merges segments: the pieces refine the index's segments
+            edges = set(np.cumsum(whole).tolist())
+            assert edges <= set(np.cumsum(pieces).tolist())
+            assert min(pieces) > n_docs // world // 100 or min(pieces) in whole   # no slivers besides the index's own small segments
 
 
 def test_key_packing_roundtrip_and_order():

@@ -176,3 +176,51 @@ def test_collective_inside_the_library_world_of_one(oracle):
         for l in leaves:
             l.release()
         ctx.close()
+
+
+def test_exchange_modes_and_vector_search_world_of_one(oracle):
+    """The all-to-all form of the exchange (rank r merges and delivers its slice of the batch) and the row-partitioned exact
+    vector search (nrtgpu_dist_knn_exact), through a one-rank communicator: the slice is the whole batch, the other ranks'
+    lists are none -- every step of the N-rank call runs, on the one GPU this pool has."""
+    from nrtsearch_amd import api
+
+    w = workload.Workload("dist test", 200_000, 3, 50, 16, 2)
+    qr = synth.make_queries(16, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr)
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves = []
+    rng = np.random.Generator(np.random.PCG64(11))
+    dim = 64
+    mats = []
+    for s in corpus.segments:
+        g = api.GpuSegment(ctx, s.max_doc, s.doc_base)
+        g.add_field_norms(0, s.norms)
+        g.add_terms(0, s.term_ids, s.offsets, s.docids, s.freqs)
+        m = rng.standard_normal((s.max_doc, dim), dtype=np.float32)
+        g.add_vectors(5, m)
+        g.seal()
+        mats.append(m)
+        leaves.append(g)
+    try:
+        ctx.dist_init(1, 0, api.GpuContext.dist_unique_id())
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        queries = workload.boolean_queries(qr)
+        mgr = api.TopScoreDocCollectorManager(w.k)
+        for mode in (api.EXCHANGE_ALLGATHER, api.EXCHANGE_ALLTOALL):
+            got = sr.dist_search_batch(queries, [mgr] * len(queries), mode=mode)
+            assert all(g is not None for g in got)          # a world of one owns every query
+            for qi in range(len(queries)):
+                edocs, escores, etotal, egte = oracle.search_bm25(corpus, qr[qi].tolist(), w.k)
+                assert got[qi].docs.tolist() == edocs.tolist() and got[qi].scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist()
+                assert got[qi].relation_gte == egte
+            qv = rng.standard_normal((5, dim), dtype=np.float32)
+            local = sr.knn_exact(5, "cosine", qv, 20)
+            dist_ = sr.dist_knn_exact(5, "cosine", qv, 20, mode=mode)
+            for a, b in zip(local, dist_):
+                assert a.docs.tolist() == b.docs.tolist() and a.scores.view(np.uint32).tolist() == b.scores.view(np.uint32).tolist()
+                assert a.total_hits == b.total_hits == sum(len(m) for m in mats) and not b.relation_gte
+    finally:
+        ctx.dist_close()
+        for l in leaves:
+            l.release()
+        ctx.close()
