@@ -66,6 +66,9 @@ def parse_args():
                          "other ranks' lists for ITS slice of the batch, merges and delivers only those (1/N of the bytes per xGMI link, "
                          "of the merge and of the host-side unpacking); allgather = BASELINE.json's north-star form: every rank merges "
                          "every query and holds every answer")
+    ap.add_argument("--sync-submit", action="store_true",
+                    help="N>1: --host-threads threads each block in nrtgpu_search_bm25_batch_device_epoch (rounds 1-2) instead of ONE thread "
+                         "submitting with nrtgpu_search_bm25_batch_device_begin and the exchange thread waiting (nrtgpu_pending_wait)")
     ap.add_argument("--planner-threads", type=int, default=0, help="planner threads per in-flight call (0 = what the box's CPUs allow)")
     ap.add_argument("--closed-loop", default="64,512",
                     help="N=1, C3: after the batch line, closed loop with that many concurrent callers, one query per call through "
@@ -435,6 +438,10 @@ def run_c4(args):
 
 def main():
     args = parse_args()
+    if os.environ.get("NRTGPU_BENCH_WATCHDOG"):   # debug aid: every thread's Python stack on stderr after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["NRTGPU_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -513,7 +520,9 @@ def main():
              | (_lib.NRTGPU_FLAG_BLOCKING_WAIT if (shard_world > 1 or args.blocking_wait) else 0))
     # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
     # (the node's ranks share the host; 4 is the library's default and enough at one rank)
-    planner_threads = args.planner_threads or max(1, min(4, usable_cpus() // max(1, max(world, shard_world) * max(1, args.host_threads))))
+    # (a rank of an N-GPU job has ONE submitting thread unless --sync-submit)
+    submitters = max(1, args.host_threads) if (args.sync_submit or not (world > 1 or args.force_dist)) else 1
+    planner_threads = args.planner_threads or max(1, min(4, usable_cpus() // max(1, max(world, shard_world) * submitters)))
     ctx = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True, flags=flags,
                          host_threads=planner_threads)
     leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
@@ -585,6 +594,7 @@ def main():
             e_keys = torch.zeros((W_e, mq_e, k_stride), dtype=torch.int64, device="cuda")
             e_cnt = torch.zeros((W_e, mq_e), dtype=torch.int32, device="cuda")
             e_hits = torch.zeros((W_e, mq_e), dtype=torch.int64, device="cuda")
+            e_tag = (torch.arange(W_e, dtype=torch.int64, device="cuda") << 27).view(W_e, 1, 1)
             merger = api.PreparedMerge(ctx, W_e, mq_e, k_stride, [w.k] * mq_e, [api.TOTAL_HITS_THRESHOLD] * mq_e)
         if not (args.torch_collective or args.debug_same_gpu or split_reduce or emu_exchange):
             ok = 1
@@ -628,7 +638,7 @@ def main():
 
     last = {}
     lat = []
-    stage = {"scan_call_s": 0.0, "exchange_s": 0.0, "merge_call_s": 0.0, "steps": 0}   # multi-GPU path: where a step's time goes
+    stage = {"scan_call_s": 0.0, "wait_s": 0.0, "exchange_s": 0.0, "merge_call_s": 0.0, "steps": 0}   # multi-GPU path: where a step's time goes
 
     def run_steps(first, count, record):
         """`count` steps starting at batch index `first`.  The C ABI is thread-safe (one workspace + HIP
@@ -659,25 +669,38 @@ def main():
         free = [threading.Semaphore(1) for _ in range(NB)]
         t_start = [0.0] * count
 
+        pending = [None] * count
+
         def produce(i):
             b = i % NB
             free[b].acquire()          # the exchange thread has gathered this buffer's previous contents
             t_start[i] = time.perf_counter()
             keys, cnt, hits = bufs[b]
-            batches[(first + i) % len(batches)].run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(),
-                                                           epoch=(first + i) if exchange_name else -1)
+            pb = batches[(first + i) % len(batches)]
+            if args.sync_submit:
+                pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=(first + i) if exchange_name else -1)
+            else:   # plan + enqueue only: the exchange thread waits for the results
+                pending[i] = pb.begin_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=(first + i) if exchange_name else -1)
             if record:
                 stage["scan_call_s"] += time.perf_counter() - t_start[i]
             return b
 
-        with ThreadPoolExecutor(max_workers=max(1, args.host_threads)) as ex:  # FIFO: steps start in order
+        with ThreadPoolExecutor(max_workers=max(1, args.host_threads) if args.sync_submit else 1) as ex:  # FIFO: steps start in order
             futs = [ex.submit(produce, i) for i in range(count)]
             for i in range(count):
                 b = futs[i].result()
+                if pending[i] is not None:
+                    tw0 = time.perf_counter()
+                    api.PreparedBatch.wait_device(pending[i])
+                    if record:
+                        stage["wait_s"] += time.perf_counter() - tw0
                 te0 = time.perf_counter()
                 keys, cnt, hits = bufs[b]
                 if emu_exchange:
-                    e_keys.copy_(keys[:mq_e].unsqueeze(0).expand(W_e, mq_e, k_stride))
+                    # (a key is (score bits << 32) | ~docid and docids are unique across the shards of a real job: the stand-in
+                    #  lists get distinct docids -- list l flips bits 27-29 of the docid word with l -- so the merge sees N disjoint
+                    #  lists of the same shape and order; the selection kernels assume unique keys)
+                    torch.bitwise_xor(keys[:mq_e].unsqueeze(0), e_tag, out=e_keys)
                     e_cnt.copy_(cnt[:mq_e].unsqueeze(0).expand(W_e, mq_e))
                     e_hits.copy_(hits[:mq_e].unsqueeze(0).expand(W_e, mq_e))
                     torch.cuda.current_stream().synchronize()

@@ -39,7 +39,9 @@ typedef enum {
   NRTGPU_ERR_HIP = -2,         /* device / runtime failure -> IOException -> gRPC INTERNAL */
   NRTGPU_ERR_OOM = -3,
   NRTGPU_ERR_UNSUPPORTED = -4, /* shape not handled on device: caller falls back to Lucene */
-  NRTGPU_ERR_STATE = -5        /* lifecycle misuse (e.g. search on an unsealed segment) */
+  NRTGPU_ERR_STATE = -5,       /* lifecycle misuse (e.g. search on an unsealed segment) */
+  NRTGPU_ERR_TIMEOUT = -6      /* the calling thread's deadline passed before the work was launched (nrtgpu_set_thread_deadline_ns):
+                                * gRPC DEADLINE_EXCEEDED / SearchResponse.hitTimeout */
 } nrtgpu_status;
 
 typedef struct nrtgpu_ctx nrtgpu_ctx;
@@ -234,6 +236,19 @@ int  nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us);
 int  nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                      int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                                      int32_t k_stride, void* d_keys, void* d_counts, void* d_hits);
+/* The same in two halves, for callers that pipeline: _begin plans the batch, enqueues its kernels on one of the library's streams
+ * and returns at once (the plan, the workspace and shared locks on the segments' content stay with the pending handle);
+ * nrtgpu_pending_wait blocks until the results are complete in d_keys / d_counts / d_hits and releases everything.  ONE
+ * submitting thread then keeps the device fed -- the plan of batch i + 1 is built while the kernels of batch i run -- and
+ * nobody spins on a stream in between (a rank of a multi-GPU job: ~1 CPU instead of one per call in flight).  At most 4
+ * batches in flight per context (a fifth _begin waits for a workspace); every handle must be waited for exactly once.
+ * epoch: as nrtgpu_search_bm25_batch_device_epoch below (-1: no bound exchange). */
+typedef struct nrtgpu_pending nrtgpu_pending;
+int  nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                           int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                           int32_t k_stride, void* d_keys, void* d_counts, void* d_hits, int64_t epoch,
+                                           nrtgpu_pending** out);
+int  nrtgpu_pending_wait(nrtgpu_pending* pending);
 /* Cross-GPU bound exchange (the LazyMaxScoreAccumulator idea across processes, SURVEY 8e "optional cross-GPU
  * theta sharing").  When one search is sharded over `world` GPUs, every shard alone would converge on the
  * k-th best of ITS docs.  With an exchange open, each shard publishes a score that at least
@@ -391,6 +406,34 @@ void    nrtgpu_bm25_norm_cache(float avgdl, float k1, float b, float* out256);
 int32_t nrtgpu_slices(int32_t n_leaves, const int32_t* max_docs, const int32_t* num_docs, const int32_t* doc_bases,
                       int32_t virtual_shards, int32_t slice_max_docs, int32_t slice_max_segments,
                       int32_t* slice_of_leaf, int32_t* shard_of_leaf);
+
+/* ---------------------------------------------------------------------------------------------
+ * Deadlines and per-call diagnostics.
+ * The reference checks the request's deadline between the phases of a search (src/main/java/com/yelp/nrtsearch/server/
+ * handler/SearchHandler.java:158,194,263,277 -> grpc/DeadlineUtils.java:48-58) and bounds collection with timeoutSec
+ * (search/SearchCutoffWrapper.java:149-159).  Here: the request thread states its deadline once -- absolute CLOCK_MONOTONIC
+ * nanoseconds, 0 = none (the default) -- and every search / vector call it makes afterwards checks it on entry, again after
+ * planning (i.e. after waiting for a workspace and for the device) and, in the vector search, between the passes over the
+ * rows: past the deadline the call returns NRTGPU_ERR_TIMEOUT without launching (more) work.  A request waiting in
+ * nrtgpu_search_bm25_coalesced carries its own thread's deadline: the batch leaves without it once it has expired.  Kernels
+ * that are already launched run to completion (a batch is a few milliseconds); their results are returned as valid.
+ * nrtgpu_last_diagnostics: what the calling thread's last completed search call cost -- the numbers behind
+ * SearchResponse.Diagnostics.firstPassSearchTimeMs (SearchHandler.java:261) and a profile's per-phase times.
+ * --------------------------------------------------------------------------------------------- */
+void nrtgpu_set_thread_deadline_ns(int64_t deadline_ns);
+int64_t nrtgpu_monotonic_ns(void);   /* the clock deadlines are on */
+typedef struct {
+  double  total_ms;        /* entry to return of the call (a coalesced request: of the batch it travelled in) */
+  double  plan_ms;         /* host: queries -> launch plan */
+  double  queue_ms;        /* waiting for a workspace and for the device (other batches' kernels) */
+  double  device_ms;       /* scorer + merge kernels, HIP events; 0 unless nrtgpu_config.collect_timing */
+  int64_t postings;        /* postings of the call's query terms (what an exhaustive scan streams) */
+  int32_t queries;         /* queries of the batch */
+  int32_t items_maxscore;  /* work items on the dynamic-pruning route */
+  int32_t items_scan;      /* work items on the exhaustive route */
+  int32_t reserved;
+} nrtgpu_diagnostics;
+int  nrtgpu_last_diagnostics(nrtgpu_diagnostics* out);
 
 /* ---------------------------------------------------------------------------------------------
  * Diagnostics (maps onto SearchResponse.Diagnostics / profile fields).

@@ -16,6 +16,7 @@ NRTGPU_ERR_HIP = -2
 NRTGPU_ERR_OOM = -3
 NRTGPU_ERR_UNSUPPORTED = -4
 NRTGPU_ERR_STATE = -5
+NRTGPU_ERR_TIMEOUT = -6
 NRTGPU_MAX_K = 1024
 NRTGPU_MAX_TERMS = 32
 NRTGPU_TILE_DOCS = 1024
@@ -42,7 +43,7 @@ ABI_SYMBOLS = [
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
     "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile", "nrtgpu_set_slicing",
     "nrtgpu_blend", "nrtgpu_dist_unique_id", "nrtgpu_dist_init", "nrtgpu_dist_search_bm25_batch", "nrtgpu_dist_allgather_merge", "nrtgpu_segment_fork",
-    "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_knn_exact",
+    "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_knn_exact",
 ]
 
 
@@ -68,6 +69,12 @@ class TopDocs(C.Structure):
     _fields_ = [("n_hits", C.c_int32), ("capacity", C.c_int32), ("docs", C.POINTER(C.c_int32)),
                 ("scores", C.POINTER(C.c_float)), ("total_hits", C.c_int64),
                 ("total_hits_is_lower_bound", C.c_int32)]
+
+
+class Diagnostics(C.Structure):   # nrtgpu_diagnostics
+    _fields_ = [("total_ms", C.c_double), ("plan_ms", C.c_double), ("queue_ms", C.c_double), ("device_ms", C.c_double),
+                ("postings", C.c_int64), ("queries", C.c_int32), ("items_maxscore", C.c_int32), ("items_scan", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -157,6 +164,13 @@ def load() -> C.CDLL:
     L.nrtgpu_dist_search_bm25_batch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_allgather_merge.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, C.POINTER(TopDocs)]
     L.nrtgpu_segment_fork.argtypes = [vp, vp, i32, C.POINTER(vp)]
+    L.nrtgpu_search_bm25_batch_device_begin.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, vp, vp, vp, C.c_int64, vp]
+    L.nrtgpu_pending_wait.argtypes = [vp]
+    L.nrtgpu_set_thread_deadline_ns.argtypes = [C.c_int64]
+    L.nrtgpu_set_thread_deadline_ns.restype = None
+    L.nrtgpu_monotonic_ns.argtypes = []
+    L.nrtgpu_monotonic_ns.restype = C.c_int64
+    L.nrtgpu_last_diagnostics.argtypes = [vp]
     L.nrtgpu_dist_owned_range.argtypes = [vp, i32, i32, vp, vp]
     L.nrtgpu_dist_search_bm25_batch_mode.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_exchange_merge.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(TopDocs)]

@@ -216,6 +216,19 @@ class GpuContext:
                  "waves_walk_cycles", "last_wave_out_cycles", "epilogue_cycles"]
         return dict(zip(names, out.tolist()))
 
+    @staticmethod
+    def set_thread_deadline(seconds_from_now: Optional[float]) -> None:
+        """The calling thread's deadline for the search calls it makes from now on (nrtgpu_set_thread_deadline_ns): None = no deadline."""
+        L = _lib.load()
+        L.nrtgpu_set_thread_deadline_ns(0 if seconds_from_now is None else int(L.nrtgpu_monotonic_ns() + seconds_from_now * 1e9))
+
+    @staticmethod
+    def last_diagnostics() -> dict:
+        """What the calling thread's last completed search call cost (nrtgpu_last_diagnostics)."""
+        d = _lib.Diagnostics()
+        _lib.check(_lib.load().nrtgpu_last_diagnostics(C.byref(d)))
+        return {n: getattr(d, n) for n, _ in _lib.Diagnostics._fields_ if n != "reserved"}
+
     def reset_stats(self) -> None:
         _lib.load().nrtgpu_reset_stats(self._h)
 
@@ -656,6 +669,20 @@ class PreparedBatch:
         _lib.check(_lib.load().nrtgpu_search_bm25_batch_device_epoch(
             s.ctx._h, s._segs, s._bases, len(s.leaves), self._m.queries, self.n, int(k_stride),
             C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits), int(epoch)))
+
+    def begin_device(self, k_stride: int, d_keys: int, d_counts: int, d_hits: int, epoch: int = -1) -> int:
+        """run_device in two halves (nrtgpu_search_bm25_batch_device_begin): plans and enqueues, returns a pending handle at
+        once; wait_device(handle) blocks until the results are complete in HBM."""
+        s = self.searcher
+        h = C.c_void_p()
+        _lib.check(_lib.load().nrtgpu_search_bm25_batch_device_begin(
+            s.ctx._h, s._segs, s._bases, len(s.leaves), self._m.queries, self.n, int(k_stride),
+            C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits), int(epoch), C.byref(h)))
+        return h.value
+
+    @staticmethod
+    def wait_device(handle: int) -> None:
+        _lib.check(_lib.load().nrtgpu_pending_wait(C.c_void_p(handle)))
 
     def topdocs(self, qi: int) -> TopDocs:
         o = self._outs[qi]

@@ -1054,13 +1054,13 @@ void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __
 }
 
 // term_bits_kernel: membership + rank records of the dense terms (DTermAux.bits): per 32 docs {doc bits, postings of
-// the term before the block}.  Grid: (chunks, terms); the records were zeroed.  Postings are ascending in docid, so
+// the term before the block}.  Grid: (chunks, dense terms); the records were zeroed.  Postings are ascending in docid, so
 // the first posting of a block is the one whose predecessor lies in an earlier block: it records its index.
 __global__ __launch_bounds__(256)
 void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ t_start,
-                      const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_rec, uint32_t* __restrict__ recs) {
-  const uint32_t t = blockIdx.y;
-  if (t_rec[t] == ~0ull) return;  // sparse term: no records
+                      const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_rec, const uint32_t* __restrict__ dense,
+                      uint32_t* __restrict__ recs) {
+  const uint32_t t = dense[blockIdx.y];   // grid.y runs over the dense terms of the group
   const uint64_t st = t_start[t];
   const uint32_t n = t_count[t];
   uint32_t* const r = recs + t_rec[t] * 2u;
@@ -1105,11 +1105,11 @@ void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint6
 }
 
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
-                      const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs) {
-  if (n_terms == 0) return;
+                      const uint64_t* t_rec, const uint32_t* dense, uint32_t n_dense, uint32_t max_count, uint32_t* recs) {
+  if (n_dense == 0) return;
   uint32_t chunks = (max_count + 256u * 16u - 1u) / (256u * 16u);
   chunks = chunks < 1u ? 1u : (chunks > 1024u ? 1024u : chunks);
-  hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n_terms), dim3(256), 0, stream, docids, t_start, t_count, t_rec, recs);
+  hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n_dense), dim3(256), 0, stream, docids, t_start, t_count, t_rec, dense, recs);
 }
 
 }  // namespace nrtgpu

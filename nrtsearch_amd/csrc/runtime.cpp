@@ -12,6 +12,13 @@ namespace rt {
 // errors
 // ------------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
+thread_local int64_t g_deadline_ns = 0;
+thread_local nrtgpu_diagnostics g_diag{};
+int64_t monotonic_ns() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (int64_t)ts.tv_sec * 1000000000ll + (int64_t)ts.tv_nsec;
+}
 
 int fail(int code, const char* fmt, ...) {
   char buf[1024];
@@ -129,6 +136,13 @@ void WorkPool::run(int n, const std::function<void(int)>& fn) {
 
 extern "C" const char* nrtgpu_version(void) { return "nrtgpu 0.1 (gfx950)"; }
 extern "C" const char* nrtgpu_last_error(void) { return g_last_error.c_str(); }
+extern "C" void nrtgpu_set_thread_deadline_ns(int64_t deadline_ns) { g_deadline_ns = deadline_ns; }
+extern "C" int64_t nrtgpu_monotonic_ns(void) { return monotonic_ns(); }
+extern "C" int nrtgpu_last_diagnostics(nrtgpu_diagnostics* out) {
+  if (!out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  *out = g_diag;
+  return NRTGPU_OK;
+}
 
 extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
   if (!out) return fail(NRTGPU_ERR_INVALID_ARG, "out is NULL");

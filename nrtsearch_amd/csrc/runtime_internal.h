@@ -47,7 +47,7 @@ void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool sh
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
                           const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
-                      const uint64_t* t_rec, uint32_t n_terms, uint32_t max_count, uint32_t* recs);
+                      const uint64_t* t_rec, const uint32_t* dense, uint32_t n_dense, uint32_t max_count, uint32_t* recs);
 void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* qterms, const uint32_t* out_begin, uint32_t n_queries,
                          uint32_t n_leaves, DTerm* out);
 void launch_slice_relation(hipStream_t stream, const uint32_t* slice_sum, const DQuery* queries, uint32_t n_slices, uint64_t* out_hits,
@@ -85,6 +85,14 @@ namespace rt {
 
 // ---- errors (runtime.cpp) ----------------------------------------------------------------------
 extern thread_local std::string g_last_error;
+extern thread_local int64_t g_deadline_ns;           // nrtgpu_set_thread_deadline_ns: 0 = none
+extern thread_local nrtgpu_diagnostics g_diag;       // nrtgpu_last_diagnostics
+int64_t monotonic_ns();
+inline bool deadline_passed(int64_t deadline_ns) { return deadline_ns != 0 && monotonic_ns() >= deadline_ns; }
+#define NRT_CHECK_DEADLINE(what)                                                                             \
+  do {                                                                                                       \
+    if (deadline_passed(g_deadline_ns)) return fail(NRTGPU_ERR_TIMEOUT, "deadline passed %s", what);        \
+  } while (0)
 int fail(int code, const char* fmt, ...);
 double now_ms();
 

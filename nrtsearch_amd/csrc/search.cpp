@@ -143,7 +143,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   return 0;
 }
 
-static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, double plan_ms) {
+static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, double plan_ms, double t_entry_ms = 0.0,
+                    double queue_ms = 0.0) {
   float scan_ms = 0.f, merge_ms = 0.f, ms_ms = 0.f;
   if (ctx->cfg.collect_timing) {
     (void)hipEventElapsedTime(&ms_ms, slot->ev3, slot->ev0);
@@ -151,6 +152,18 @@ static void account(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_q
     (void)hipEventElapsedTime(&merge_ms, slot->ev1, slot->ev2);
   }
   const size_t n_scan = hp.items.size() - hp.n_ms_items;
+  {   // what this call cost, for the calling thread (nrtgpu_last_diagnostics)
+    nrtgpu_diagnostics d{};
+    d.total_ms = t_entry_ms > 0.0 ? now_ms() - t_entry_ms : 0.0;
+    d.plan_ms = plan_ms;
+    d.queue_ms = queue_ms;
+    d.device_ms = (double)(hp.n_ms_items ? ms_ms : 0.f) + (double)(n_scan ? scan_ms : 0.f) + (double)merge_ms;
+    d.postings = hp.postings;
+    d.queries = n_queries;
+    d.items_maxscore = (int32_t)hp.n_ms_items;
+    d.items_scan = (int32_t)n_scan;
+    g_diag = d;
+  }
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
   ctx->stats.batches += 1;
   ctx->stats.queries += n_queries;
@@ -203,6 +216,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
   if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
+  NRT_CHECK_DEADLINE("before the search was planned");
   HIP_TRY(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   HostPlan hp;
@@ -215,6 +229,8 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   Slot* slot = nullptr;
   acquire_slot(ctx, &slot);
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  const double queue_ms = now_ms() - t0 - plan_ms;
+  NRT_CHECK_DEADLINE("while the search waited for a workspace");   // (nothing has been launched)
   DeviceRun run;
   const size_t kb = (size_t)n_queries * hp.k_stride * 8, cb = (size_t)n_queries * 4, hb = (size_t)n_queries * 8;
   Carver oc;
@@ -255,7 +271,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     for (size_t i = 0; i < run.n_items; ++i)
       for (int j = 0; j < 16; ++j) (i < run.n_ms_items ? ctx->ms_prof : ctx->prof)[j] += (double)hp_prof[i * 16 + j];
   }
-  account(ctx, slot, hp, n_queries, plan_ms);
+  account(ctx, slot, hp, n_queries, plan_ms, t0, queue_ms);
   return NRTGPU_OK;
 }
 
@@ -274,6 +290,7 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   if (dim <= 0 || sim < 0 || sim > 3 || window <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad rescore arguments");
   if (!(query_weight >= 0.0) || !(rescore_weight >= 0.0) || !(boost >= 0.0f))
     return fail(NRTGPU_ERR_UNSUPPORTED, "hybrid tail: negative weights (combined scores must stay >= 0)");
+  NRT_CHECK_DEADLINE("before the search was planned");
   HIP_TRY(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   HostPlan hp;
@@ -391,6 +408,8 @@ struct CoRequest {
   int32_t n_segs;
   const nrtgpu_bm25_query* q;
   nrtgpu_topdocs* out;
+  int64_t deadline_ns = 0;        // the calling thread's (nrtgpu_set_thread_deadline_ns)
+  nrtgpu_diagnostics diag{};      // of the batch the request travelled in
   int rc = 0;
   bool done = false;   // results (or the error) are in place
   bool lead = false;   // promoted: this caller lingers for and runs the next batch
@@ -431,7 +450,9 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     if (!segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d is not sealed", si);
     if (segs[si]->ctx != ctx) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d belongs to another context", si);
   }
+  NRT_CHECK_DEADLINE("before the request was queued");
   CoRequest me{segs, doc_bases, n_segs, q, out};
+  me.deadline_ns = g_deadline_ns;
   std::vector<CoRequest*> batch;
   {
     std::unique_lock<std::mutex> lk(ctx->co_mu);
@@ -445,6 +466,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
       }
       if (me.done) {
         if (me.rc != 0) g_last_error = me.err;
+        else g_diag = me.diag;
         return me.rc;
       }
       lk.lock();  // promoted: continue as the leader
@@ -478,12 +500,20 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     int32_t cap = ctx->cfg.max_batch;
     if (ctx->co_inflight == 0 && (int32_t)ctx->co_pending.size() >= 2 * kCoOverlapMin && (int32_t)ctx->co_pending.size() < cap)
       cap = ((int32_t)ctx->co_pending.size() + 1) / 2;
-    std::vector<CoRequest*> rest;
+    std::vector<CoRequest*> rest, expired;
     batch.push_back(&me);
     for (CoRequest* r : ctx->co_pending) {
       if (r == &me) continue;
-      if ((int32_t)batch.size() < cap && same_leaves(&me, r)) batch.push_back(r);
+      if (deadline_passed(r->deadline_ns)) expired.push_back(r);   // waited too long: leaves without being searched
+      else if ((int32_t)batch.size() < cap && same_leaves(&me, r)) batch.push_back(r);
       else rest.push_back(r);
+    }
+    for (CoRequest* r : expired) {
+      std::lock_guard<std::mutex> theirs(r->m);
+      r->rc = NRTGPU_ERR_TIMEOUT;
+      r->err = "deadline passed while the request waited for a batch";
+      r->done = true;
+      r->cv.notify_one();
     }
     ctx->co_pending.swap(rest);
     ctx->co_leader = nullptr;
@@ -505,8 +535,16 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     qs[i] = *batch[i]->q;
     outs[i] = *batch[i]->out;
   }
+  // (a batch of several requests is not failed for the leader's deadline: its mates have not expired -- they were checked when the
+  //  batch was formed -- and a batch is a few milliseconds.  A lone request keeps its deadline.)
+  struct DeadlineScope {
+    int64_t saved;
+    explicit DeadlineScope(bool clear) : saved(g_deadline_ns) { if (clear) g_deadline_ns = 0; }
+    ~DeadlineScope() { g_deadline_ns = saved; }
+  } deadline_scope(batch.size() > 1);
   int rc = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data());
   std::string err = rc ? g_last_error : std::string();
+  const nrtgpu_diagnostics batch_diag = g_diag;
   // A request the planner rejects (a mask that is not resident on a leaf, a clause shape outside the fixed-point range ...)
   // must not fail its batch mates: the batch is re-run member by member and only the offender gets the error.
   std::vector<int> rcs(batch.size(), rc);
@@ -529,6 +567,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     // we are done with it, and it contends with nobody but us)
     std::lock_guard<std::mutex> theirs(r->m);
     if (rcs[i] == 0) *r->out = outs[i];
+    r->diag = batch_diag;
     r->rc = rcs[i];
     if (rcs[i] != 0) r->err = errs[i];
     r->done = true;
@@ -551,39 +590,76 @@ extern "C" int nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg
                                                d_hits, -1);
 }
 
-extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+// A device-resident search in flight (nrtgpu_search_bm25_batch_device_begin): what must outlive the enqueue -- the plan (its
+// resident term tables), the workspace, the shared locks on the segments' content -- until nrtgpu_pending_wait.
+struct nrtgpu_pending {
+  nrtgpu_ctx* ctx = nullptr;
+  Slot* slot = nullptr;
+  HostPlan hp;
+  std::unique_ptr<SegReadLocks> content;
+  int32_t n_queries = 0;
+  double plan_ms = 0.0;
+};
+
+extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                                      int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
-                                                     int64_t epoch) {
-  if (!ctx || !queries || !d_keys || !d_counts || !d_hits || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+                                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits, int64_t epoch,
+                                                     nrtgpu_pending** out) {
+  if (!ctx || !queries || !d_keys || !d_counts || !d_hits || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  *out = nullptr;
+  NRT_CHECK_DEADLINE("before the search was planned");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
   if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
   HIP_TRY(hipSetDevice(ctx->device));
   const double t0 = now_ms();
-  HostPlan hp;
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
-  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
+  auto p = std::make_unique<nrtgpu_pending>();
+  p->ctx = ctx;
+  p->n_queries = n_queries;
+  p->content = std::make_unique<SegReadLocks>(segs, n_segs);  // until this call's kernels have finished (nrtgpu_pending_wait)
   // (with a bound exchange open the shards run the exhaustive scan, which takes part in it; else they may prune)
-  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, (epoch >= 0 && ctx->xch_dev) ? 0 : 2)) return rc;
-  if (k_stride < (int32_t)hp.k_stride && k_stride < NRTGPU_MAX_K) {
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, p->hp, (epoch >= 0 && ctx->xch_dev) ? 0 : 2)) return rc;
+  if (k_stride < (int32_t)p->hp.k_stride && k_stride < NRTGPU_MAX_K) {
     for (int qi = 0; qi < n_queries; ++qi)
       if (queries[qi].k > k_stride) return fail(NRTGPU_ERR_INVALID_ARG, "k_stride %d smaller than numHits %d", k_stride, queries[qi].k);
   }
-  const double plan_ms = now_ms() - t0;
-  Slot* slot = nullptr;
-  acquire_slot(ctx, &slot);
-  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  p->plan_ms = now_ms() - t0;
+  acquire_slot(ctx, &p->slot);
   DeviceRun run;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
-    if (int rc = enqueue_search(ctx, slot, hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
-                                (uint64_t*)d_hits, &run, gpu, epoch))
+    if (int rc = enqueue_search(ctx, p->slot, p->hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
+                                (uint64_t*)d_hits, &run, gpu, epoch)) {
+      (void)hipStreamSynchronize(p->slot->stream);   // whatever was enqueued reads the slot's buffers
+      release_slot(ctx, p->slot);
       return rc;
-    HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
+    }
   }
-  account(ctx, slot, hp, n_queries, plan_ms);
+  *out = p.release();
   return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_pending_wait(nrtgpu_pending* pending) {
+  if (!pending) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  std::unique_ptr<nrtgpu_pending> p(pending);
+  nrtgpu_ctx* ctx = p->ctx;
+  (void)hipSetDevice(ctx->device);
+  const hipError_t e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
+  if (e == hipSuccess) account(ctx, p->slot, p->hp, p->n_queries, p->plan_ms);   // (fills the WAITING thread's diagnostics)
+  release_slot(ctx, p->slot);
+  if (e != hipSuccess) return fail(NRTGPU_ERR_HIP, "device-resident search failed: %s", hipGetErrorString(e));
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                                     int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
+                                                     int64_t epoch) {
+  nrtgpu_pending* p = nullptr;
+  if (int rc = nrtgpu_search_bm25_batch_device_begin(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts, d_hits, epoch, &p))
+    return rc;
+  return nrtgpu_pending_wait(p);
 }
 
 extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride,

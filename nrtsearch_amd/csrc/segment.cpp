@@ -118,8 +118,16 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
     if (p != hi) return fail(NRTGPU_ERR_INVALID_ARG, "docids of term %lld exceed max_doc", (long long)t);
     cells.push_back((uint32_t)cnt);
   }
-  for (int64_t t = 0; t < n_terms; ++t)
-    if (f.dict.count(term_hash[t])) return fail(NRTGPU_ERR_INVALID_ARG, "term %lld added twice to field %d", (long long)term_hash[t], field_id);
+  {
+    // A term id names ONE posting list of the field: two terms under one id -- in this call or across calls (e.g. a 64-bit hash
+    // of the term bytes that collides) -- would silently alias.  Refused, so that the caller keeps the leaf on its own path.
+    std::unordered_map<int64_t, int64_t> seen_here;
+    seen_here.reserve((size_t)n_terms * 2);
+    for (int64_t t = 0; t < n_terms; ++t) {
+      if (f.dict.count(term_hash[t]) || !seen_here.emplace(term_hash[t], t).second)
+        return fail(NRTGPU_ERR_INVALID_ARG, "term id %lld added twice to field %d (term ids must be unique per field)", (long long)term_hash[t], field_id);
+    }
+  }
 
   TermGroup g;
   g.n_postings = (uint64_t)total;
@@ -227,9 +235,23 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   HIP_TRY(hipMemcpy(d_rec, rec.data(), nt * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_count, g.h_count.data(), nt * 4, hipMemcpyHostToDevice));
   launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_rec, g.d_bits, (uint32_t)nt, g.d_aux);
-  if (n_recs) launch_term_bits(nullptr, g.d_docids, d_start, d_count, d_rec, (uint32_t)nt, max_count, g.d_bits);
   hipError_t e = hipGetLastError();
+  uint32_t* d_dense = nullptr;
+  if (e == hipSuccess && n_recs) {
+    // the record kernel runs over the DENSE terms only (a field's dictionary holds 10^5 - 10^6 terms, a few hundred of them dense)
+    std::vector<uint32_t> dense;
+    for (size_t t = 0; t < nt; ++t)
+      if (rec[t] != ~0ull) dense.push_back((uint32_t)t);
+    e = hipMalloc((void**)&d_dense, dense.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_dense, dense.data(), dense.size() * 4, hipMemcpyHostToDevice);
+    for (size_t i = 0; e == hipSuccess && i < dense.size(); i += 32768) {   // (grid.y stays far below 65535)
+      launch_term_bits(nullptr, g.d_docids, d_start, d_count, d_rec, d_dense + i, (uint32_t)std::min<size_t>(32768, dense.size() - i), max_count,
+                       g.d_bits);
+      e = hipGetLastError();
+    }
+  }
   if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (d_dense) (void)hipFree(d_dense);
   (void)hipFree(d_start);
   (void)hipFree(d_rec);
   (void)hipFree(d_count);

@@ -21,6 +21,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   if (n_queries <= 0 || k <= 0 || dim <= 0 || sim < 0 || sim > 3) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
   if (dim % 16 != 0 || dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 2048)", dim);
+  NRT_CHECK_DEADLINE("before the vector search started");
   HIP_TRY(hipSetDevice(ctx->device));
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
@@ -56,6 +57,10 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   const int pass_q = dim > 1280 ? 16 : kKnnMaxQ;
   for (int q0 = 0, safe = 0; q0 < n_queries; q0 += safe ? 0 : pass_q) {
     const int nq = std::min(pass_q, n_queries - q0);
+    if (deadline_passed(g_deadline_ns)) {   // between two passes over the rows: nothing of the next one has been launched
+      (void)hipStreamSynchronize(st);
+      return fail(NRTGPU_ERR_TIMEOUT, "deadline passed between two passes over the rows (%d of %d queries answered)", q0, n_queries);
+    }
     for (int q = 0; q < nq; ++q) {
       float s2 = 0.f;  // squareMagnitude of the query, fp32
       const float* qv = queries + (size_t)(q0 + q) * dim;

@@ -54,6 +54,29 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.Bm25Query) == 72
     assert C.sizeof(_lib.TopDocs) == 40
     assert C.sizeof(_lib.Stats) == 136
+    assert C.sizeof(_lib.Diagnostics) == 56
+
+
+def test_deadline_clock_and_thread_local_state_need_no_device(lib):
+    """nrtgpu_monotonic_ns / nrtgpu_set_thread_deadline_ns / nrtgpu_last_diagnostics are host state of the calling thread."""
+    import threading
+
+    t0 = lib.nrtgpu_monotonic_ns()
+    assert lib.nrtgpu_monotonic_ns() >= t0 > 0
+    lib.nrtgpu_set_thread_deadline_ns(t0 - 1)          # an expired deadline on THIS thread ...
+    seen = []
+
+    def other():                                        # ... is nobody else's
+        d = _lib.Diagnostics()
+        assert lib.nrtgpu_last_diagnostics(C.byref(d)) == 0
+        seen.append((d.queries, d.total_ms))
+
+    th = threading.Thread(target=other)
+    th.start()
+    th.join()
+    assert seen == [(0, 0.0)]
+    lib.nrtgpu_set_thread_deadline_ns(0)
+    assert lib.nrtgpu_last_diagnostics(None) == _lib.NRTGPU_ERR_INVALID_ARG
 
 
 def test_host_smallfloat_matches_oracle(lib, oracle):

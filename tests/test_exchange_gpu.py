@@ -224,3 +224,45 @@ def test_exchange_modes_and_vector_search_world_of_one(oracle):
         for l in leaves:
             l.release()
         ctx.close()
+
+
+def test_device_resident_search_in_two_halves(oracle):
+    """nrtgpu_search_bm25_batch_device_begin + nrtgpu_pending_wait == the synchronous call: same keys / counts / hit totals in
+    HBM, several batches in flight from one submitting thread."""
+    import torch
+
+    from nrtsearch_amd import api
+
+    w = workload.Workload("begin-wait test", 250_000, 4, 100, 48, 3)
+    qr = synth.make_queries(48, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr)
+    ctx = api.GpuContext(0, max_batch=16)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    try:
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        queries = workload.boolean_queries(qr)
+        mgr = api.TopScoreDocCollectorManager(w.k)
+        k_stride = 112
+        pbs = [api.PreparedBatch(sr, queries[i: i + 16], [mgr] * 16) for i in range(0, 48, 16)]
+        bufs = [(torch.zeros((16, k_stride), dtype=torch.int64, device="cuda"), torch.zeros((16,), dtype=torch.int32, device="cuda"),
+                 torch.zeros((16,), dtype=torch.int64, device="cuda")) for _ in range(6)]
+        for b, pb in enumerate(pbs):   # the synchronous call
+            pb.run_device(k_stride, *(t.data_ptr() for t in bufs[b]))
+        handles = [pb.begin_device(k_stride, *(t.data_ptr() for t in bufs[3 + b])) for b, pb in enumerate(pbs)]   # three in flight
+        for h in handles:
+            api.PreparedBatch.wait_device(h)
+        torch.cuda.synchronize()
+        for b in range(3):
+            for x, y in zip(bufs[b], bufs[3 + b]):
+                assert torch.equal(x, y)
+            keys = bufs[3 + b][0].cpu().numpy().view(np.uint64)
+            cnt = bufs[3 + b][1].cpu().numpy()
+            for j in range(16):
+                qi = b * 16 + j
+                edocs, escores, _, _ = oracle.search_bm25(corpus, qr[qi].tolist(), w.k)
+                docs = (0xFFFFFFFF - (keys[j, : cnt[j]] & np.uint64(0xFFFFFFFF))).astype(np.int64)
+                assert docs.tolist() == edocs.tolist()
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()

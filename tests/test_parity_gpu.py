@@ -443,3 +443,31 @@ def test_query_supported_is_the_planners_predicate(mid):
     assert not mid.searcher.supported(q, ok)                                          # FILTER mask not resident
     with pytest.raises(_lib.NrtGpuError):
         mid.searcher.supported(bq([1]), api.TopScoreDocCollectorManager(0))           # invalid argument, not "unsupported"
+
+
+def test_deadline_and_diagnostics(mid, oracle):
+    """A request thread states its deadline (gRPC Context / timeoutSec in the reference: SearchHandler.java:158-277,
+    SearchCutoffWrapper.java:149-159); past it, calls return NRTGPU_ERR_TIMEOUT without launching work.  Every completed call
+    leaves its cost for SearchResponse.Diagnostics."""
+    terms = [1, 5, 100, 5000]
+    mgr = api.TopScoreDocCollectorManager(50)
+    try:
+        api.GpuContext.set_thread_deadline(-0.001)      # already expired
+        for call in (lambda: mid.searcher.search(bq(terms), mgr), lambda: mid.searcher.search_coalesced(bq(terms), mgr),
+                     lambda: mid.searcher.search_batch([bq(terms)] * 3, [mgr] * 3)):
+            with pytest.raises(_lib.NrtGpuError) as e:
+                call()
+            assert e.value.code == _lib.NRTGPU_ERR_TIMEOUT
+        api.GpuContext.set_thread_deadline(30.0)        # far away: the answers are the oracle's
+        got = mid.searcher.search(bq(terms), mgr)
+        assert_same("deadline_far", got, oracle.search_bm25(mid.corpus, terms, 50), 50, 1000)
+        d = api.GpuContext.last_diagnostics()
+        assert d["queries"] == 1 and d["postings"] > 0 and d["items_maxscore"] + d["items_scan"] >= 1
+        assert d["total_ms"] >= d["plan_ms"] > 0.0 and d["queue_ms"] >= 0.0
+        got = mid.searcher.search_coalesced(bq(terms), mgr)
+        assert_same("deadline_far_coalesced", got, oracle.search_bm25(mid.corpus, terms, 50), 50, 1000)
+        assert api.GpuContext.last_diagnostics()["queries"] >= 1
+    finally:
+        api.GpuContext.set_thread_deadline(None)
+    got = mid.searcher.search(bq(terms), mgr)           # no deadline again
+    assert_same("deadline_none", got, oracle.search_bm25(mid.corpus, terms, 50), 50, 1000)
