@@ -3,6 +3,8 @@ package com.yelp.nrtsearch.gpu;
 import static java.lang.foreign.ValueLayout.*;
 
 import com.yelp.nrtsearch.server.search.SearchCollectorManager;
+import com.yelp.nrtsearch.server.search.SearchCutoffWrapper;
+import com.yelp.nrtsearch.server.search.SearchStatsWrapper;
 import com.yelp.nrtsearch.server.search.collectors.DocCollector;
 import com.yelp.nrtsearch.server.search.collectors.RelevanceCollector;
 import java.io.IOException;
@@ -18,7 +20,8 @@ import org.apache.lucene.search.similarities.Similarity;
 
 /**
  * The eligibility predicate of SURVEY 8b, Java half: recognise the shapes the native planner takes -- a (boosted)
- * TermQuery, a BooleanQuery of SHOULD (boosted) TermQuery clauses (built at query/QueryNodeMapper.java:257-283,360-395) or a
+ * TermQuery, a BooleanQuery of SHOULD (boosted) TermQuery clauses with at most one FILTER and one MUST_NOT clause next to them
+ * (built at query/QueryNodeMapper.java:257-283,360-395; the non-scoring clauses become resident doc-set masks: GpuMaskCache) or a
  * DisjunctionMaxQuery over such term queries with tie breaker 0 (QueryNodeMapper.java:350-358),
  * collected by a plain RelevanceCollector (search/collectors/RelevanceCollector.java:42-69) -- and marshal them into a
  * nrtgpu_bm25_query.  Whatever remains (clause counts, fields, fixed-point range, resident masks ...) is decided by the
@@ -27,6 +30,12 @@ import org.apache.lucene.search.similarities.Similarity;
  */
 final class GpuEligibility {
   record Clause(Term term, float boost) {}
+
+  /** The flattened query: scoring clauses, minimumNumberShouldMatch, DisjunctionMaxQuery?, and the non-scoring clauses (null = none). */
+  record Shape(List<Clause> clauses, int minShouldMatch, int disjunctionMax, Query filter, Query mustNot) {}
+
+  /** The collector behind the manager handed to search(), and the request's timeoutSec (0 = none). */
+  record Eligible(RelevanceCollector collector, double timeoutSec) {}
 
   record Plan(MemorySegment query, MemorySegment out, MemorySegment docs, MemorySegment scores, int k) {
     TopDocs toTopDocs() {
@@ -38,10 +47,8 @@ final class GpuEligibility {
     }
   }
 
-  /** Flattens the rewritten query; null = not a shape the device takes.  shape[0] = minimumNumberShouldMatch,
-   *  shape[1] = 1 for a DisjunctionMaxQuery (best clause instead of the sum). */
-  static List<Clause> clauses(Query q, int[] shape) {
-    int[] minShouldMatch = shape;
+  /** Flattens the rewritten query; null = not a shape the device takes. */
+  static Shape shape(Query q) {
     List<Clause> out = new ArrayList<>();
     if (q instanceof DisjunctionMaxQuery dm) {                         // QueryNodeMapper.java:350-358
       if (dm.getTieBreakerMultiplier() != 0f) return null;            // the device keeps the best clause only
@@ -50,23 +57,39 @@ final class GpuEligibility {
         if (cl == null) return null;                                  // disjuncts that are not (boosted) term queries
         out.add(cl);
       }
-      shape[1] = 1;
-      return out.isEmpty() ? null : out;
+      return out.isEmpty() ? null : new Shape(out, 0, 1, null, null);
     }
     if (q instanceof BooleanQuery bq) {
+      Query filter = null, mustNot = null;
+      int must = 0;
       for (BooleanClause c : bq.clauses()) {
-        if (c.occur() != BooleanClause.Occur.SHOULD) return null;     // FILTER / MUST_NOT as masks: GpuMaskCache (not in this sketch)
-        Clause cl = term(c.query(), 1f);
-        if (cl == null) return null;
-        out.add(cl);
+        switch (c.occur()) {
+          case SHOULD, MUST -> {                                       // MUST term clauses: every one required (MatchQuery operator MUST)
+            Clause cl = term(c.query(), 1f);
+            if (cl == null) return null;
+            out.add(cl);
+            if (c.occur() == BooleanClause.Occur.MUST) must++;
+          }
+          case FILTER -> {                                             // one resident mask per kind; more: the caller's path
+            if (filter != null) return null;
+            filter = c.query();
+          }
+          case MUST_NOT -> {
+            if (mustNot != null) return null;
+            mustNot = c.query();
+          }
+        }
       }
-      minShouldMatch[0] = bq.getMinimumNumberShouldMatch();
-      return out.isEmpty() ? null : out;
+      if (out.isEmpty()) return null;                                 // filter-only queries score 0 for every match: Lucene's business
+      if (must != 0 && must != out.size()) return null;               // mixed MUST / SHOULD: a nested shape
+      int msm = must != 0 ? out.size() : bq.getMinimumNumberShouldMatch();
+      if (filter != null && must == 0 && msm == 0) return null;       // SHOULD clauses next to a FILTER are optional: filter-only docs match with score 0
+      return new Shape(out, msm, 0, filter, mustNot);
     }
     Clause cl = term(q, 1f);
     if (cl == null) return null;
     out.add(cl);
-    return out;
+    return new Shape(out, 0, 0, null, null);
   }
 
   private static Clause term(Query q, float boost) {
@@ -75,18 +98,36 @@ final class GpuEligibility {
     return null;
   }
 
-  /** The unwrapped doc collector must be a plain RelevanceCollector: no sort, no additional collectors, no terminateAfter. */
-  static RelevanceCollector relevance(CollectorManager<?, ?> manager) {
+  /**
+   * What SearchHandler hands to search() is DocCollector.getWrappedManager() (search/collectors/DocCollector.java:120-125,
+   * :197-220): a SearchCollectorManager, possibly inside a SearchStatsWrapper (profile), a SearchCutoffWrapper (timeoutSec) and
+   * a TerminateAfterWrapper.  The unwrapped doc collector must be a plain RelevanceCollector: no sort, no additional collectors
+   * (facets ...), no terminateAfter (its early termination counts collected docs: the reference's business).  getWrapped() /
+   * getAdditionalCollectors(): java/patches/nrtsearch-gpu-hook.diff.
+   */
+  static Eligible relevance(CollectorManager<?, ?> manager) {
     Object m = manager;
-    while (m instanceof com.yelp.nrtsearch.server.search.collectors.additional.WrappedCollectorManager<?, ?> w) m = w.getWrapped();
+    double timeoutSec = 0.0;
+    for (;;) {
+      if (m instanceof SearchStatsWrapper<?> stats) {
+        m = stats.getWrapped();
+      } else if (m instanceof SearchCutoffWrapper<?> cutoff) {
+        timeoutSec = cutoff.getTimeoutSec();
+        m = cutoff.getWrapped();
+      } else {
+        break;
+      }
+    }
     if (!(m instanceof SearchCollectorManager scm)) return null;
     DocCollector dc = scm.getDocCollector();
     if (!(dc instanceof RelevanceCollector rc) || !scm.getAdditionalCollectors().isEmpty()) return null;
-    return rc;
+    return new Eligible(rc, timeoutSec);
   }
 
-  static Plan marshal(Arena a, IndexSearcher searcher, GpuSegmentStore store, List<Clause> clauses, int msm, int disjunctionMax,
+  static Plan marshal(Arena a, IndexSearcher searcher, GpuSegmentStore store, Shape shape, int filterMask, int mustNotMask,
       int k, int totalHitsThreshold, ScoreDoc after) throws IOException {
+    List<Clause> clauses = shape.clauses();
+    int msm = shape.minShouldMatch(), disjunctionMax = shape.disjunctionMax();
     Similarity sim = searcher.getSimilarity();
     if (!(sim instanceof BM25Similarity)) return null;                // IndexSimilarity.java:51-63: default similarity only
     List<String> fields = new ArrayList<>();
@@ -122,6 +163,8 @@ final class GpuEligibility {
     q.set(JAVA_INT, 44, after != null ? after.doc : 0);
     q.set(JAVA_FLOAT, 48, after != null ? after.score : 0f);
     q.set(JAVA_INT, 52, msm);
+    q.set(JAVA_INT, 60, filterMask);
+    q.set(JAVA_INT, 64, mustNotMask);
     q.set(JAVA_INT, 68, disjunctionMax);
     MemorySegment docs = a.allocate(JAVA_INT, k), scores = a.allocate(JAVA_FLOAT, k), out = a.allocate(NrtGpu.TOPDOCS);
     out.set(JAVA_INT, 4, k);

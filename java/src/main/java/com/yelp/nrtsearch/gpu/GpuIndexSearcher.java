@@ -16,30 +16,46 @@ import org.apache.lucene.index.LeafReaderContext;
 import org.apache.lucene.search.*;
 
 /**
- * Seam B2 (SURVEY 8b): the searcher nrtsearch installs in ShardSearcherFactory.newSearcher
- * (index/ShardState.java:506-527, :792-803).  search(Query, CollectorManager) -- the single entry of the hot path
- * (handler/SearchHandler.java:1412-1413, :556) -- goes to the device when the rewritten query and the collector are
- * eligible and every leaf is resident; anything else is super.search, i.e. the untouched Lucene path.
- * NOT COMPILED here (no JDK).
+ * Seam B2 (SURVEY 8b): the searcher ShardSearcherFactory.newSearcher builds when the plugin has installed its
+ * MyIndexSearcher.SearcherHook (java/patches/nrtsearch-gpu-hook.diff; index/ShardState.java:506-527).
+ * search(Query, CollectorManager) -- the single entry of the hot path (handler/SearchHandler.java:1412-1413, :556) -- goes
+ * to the device when the rewritten query and the collector are eligible and every leaf is resident; anything else is
+ * super.search, i.e. the untouched Lucene path.
+ * NOT COMPILED in this repository's image (no JDK); tests/test_java_shim_signatures.py checks every nrtsearch type, constructor
+ * and method used here against the reference sources plus the patch.
  */
 public class GpuIndexSearcher extends MyIndexSearcher {
   private final MemorySegment ctx;
   private final GpuSegmentStore store;
+  private final GpuMaskCache masks;
+  private static final ThreadLocal<double[]> LAST_DIAGNOSTICS = new ThreadLocal<>();
 
-  public GpuIndexSearcher(IndexReader reader, Executor executor, SlicingParams slicing, MemorySegment ctx, GpuSegmentStore store) {
-    super(reader, executor, slicing);
+  /** MyIndexSearcher reads its slicing params from a static under a lock: construction goes through its factory. */
+  public static GpuIndexSearcher create(IndexReader reader, Executor executor, MyIndexSearcher.SlicingParams slicing, MemorySegment ctx,
+      GpuSegmentStore store, GpuMaskCache masks) {
+    return MyIndexSearcher.create(reader, executor, slicing, (r, e) -> new GpuIndexSearcher(r, e, ctx, store, masks));
+  }
+
+  protected GpuIndexSearcher(IndexReader reader, Executor executor, MemorySegment ctx, GpuSegmentStore store, GpuMaskCache masks) {
+    super(reader, executor);
     this.ctx = ctx;
     this.store = store;
+    this.masks = masks;
+  }
+
+  /** {total_ms, plan_ms, queue_ms, device_ms, postings} of the calling thread's last device search (SearchResponse.Diagnostics). */
+  public static double[] lastDiagnostics() {
+    return LAST_DIAGNOSTICS.get();
   }
 
   @Override
   @SuppressWarnings("unchecked")
   public <C extends Collector, T> T search(Query query, CollectorManager<C, T> manager) throws IOException {
-    RelevanceCollector rc = GpuEligibility.relevance(manager);
-    if (rc == null) return super.search(query, manager);
-    int[] msm = {0, 0};   // minimumNumberShouldMatch, DisjunctionMaxQuery?
-    List<GpuEligibility.Clause> clauses = GpuEligibility.clauses(rewrite(query), msm);
-    if (clauses == null) return super.search(query, manager);
+    GpuEligibility.Eligible el = GpuEligibility.relevance(manager);
+    if (el == null) return super.search(query, manager);
+    RelevanceCollector rc = el.collector();
+    GpuEligibility.Shape shape = GpuEligibility.shape(rewrite(query));
+    if (shape == null) return super.search(query, manager);
     List<LeafReaderContext> leaves = getIndexReader().leaves();
     try (Arena a = Arena.ofConfined()) {
       MemorySegment segs = a.allocate(ADDRESS, leaves.size()), bases = a.allocate(JAVA_INT, leaves.size());
@@ -49,16 +65,30 @@ public class GpuIndexSearcher extends MyIndexSearcher {
         segs.setAtIndex(ADDRESS, i, s);
         bases.setAtIndex(JAVA_INT, i, leaves.get(i).docBase);
       }
-      GpuEligibility.Plan plan = GpuEligibility.marshal(a, this, store, clauses, msm[0], msm[1], rc.getNumHitsToCollect(),
+      // FILTER / MUST_NOT clauses next to the scoring ones: resident doc-set masks (nrtgpu_segment_set_mask)
+      int filterMask = shape.filter() == null ? 0 : masks.maskOf(this, store, leaves, shape.filter());
+      int mustNotMask = shape.mustNot() == null ? 0 : masks.maskOf(this, store, leaves, shape.mustNot());
+      if (filterMask < 0 || mustNotMask < 0) return super.search(query, manager);
+      GpuEligibility.Plan plan = GpuEligibility.marshal(a, this, store, shape, filterMask, mustNotMask, rc.getNumHitsToCollect(),
           rc.getTotalHitsThreshold(), rc.getSearchAfter());
       if (plan == null) return super.search(query, manager);
+      // timeoutSec of the request (DocCollector's SearchCutoffWrapper) -> the thread's deadline inside the library
+      long deadline = el.timeoutSec() > 0.0 ? (long) NrtGpu.MONOTONIC_NS.invokeExact() + (long) (el.timeoutSec() * 1e9) : 0L;
       int status;
-      if (msm[0] > 1 || msm[1] != 0)   // clause counts / best-clause scores depend on the whole batch's accumulator mode: a batch of one
-        status = (int) NrtGpu.SEARCH_BATCH.invokeExact(ctx, segs, bases, leaves.size(), plan.query(), 1, plan.out());
-      else
+      try {
+        NrtGpu.SET_DEADLINE.invokeExact(deadline);
         status = (int) NrtGpu.SEARCH1.invokeExact(ctx, segs, bases, leaves.size(), plan.query(), plan.out());   // blocks; batched inside
-      if (status == NrtGpu.ERR_UNSUPPORTED) return super.search(query, manager);
+      } finally {
+        NrtGpu.SET_DEADLINE.invokeExact(0L);
+      }
+      // not a shape / size the device takes, or out of time before anything was launched: the reference's own path decides
+      // (its SearchCutoffWrapper reports the timeout the reference's way)
+      if (status == NrtGpu.ERR_UNSUPPORTED || status == NrtGpu.ERR_TIMEOUT) return super.search(query, manager);
       NrtGpu.check(status);
+      MemorySegment d = a.allocate(NrtGpu.DIAGNOSTICS);
+      if ((int) NrtGpu.LAST_DIAGNOSTICS.invokeExact(d) == NrtGpu.OK)
+        LAST_DIAGNOSTICS.set(new double[] {d.get(JAVA_DOUBLE, 0), d.get(JAVA_DOUBLE, 8), d.get(JAVA_DOUBLE, 16), d.get(JAVA_DOUBLE, 24),
+            (double) d.get(JAVA_LONG, 32)});
       return (T) new SearcherResult(plan.toTopDocs(), Map.of());       // search/SearcherResult.java:31-34
     } catch (IOException | RuntimeException e) {
       throw e;

@@ -32,9 +32,11 @@ final class GpuSegmentStore {
 
   int fieldId(String field) { return fieldIds.computeIfAbsent(field, f -> fieldIds.size() + 1); }
 
-  /** Injective 64-bit id of (term bytes): must be the same at upload and at query time. */
+  /** 64-bit id of (term bytes): the same at upload and at query time.  FNV-1a 64 is not injective: should two terms of one
+   *  field ever collide, nrtgpu_segment_add_terms refuses the second (term ids must be unique per field) and sync() leaves that
+   *  segment on the CPU path instead of letting the two posting lists alias. */
   static long termHash(BytesRef term) {
-    long h = 0xcbf29ce484222325L;                       // FNV-1a 64; the shim may keep a dictionary instead if it wants a proof
+    long h = 0xcbf29ce484222325L;
     for (int i = 0; i < term.length; i++) h = (h ^ (term.bytes[term.offset + i] & 0xff)) * 0x100000001b3L;
     return h;
   }
@@ -52,7 +54,12 @@ final class GpuSegmentStore {
       if (core == null) continue;                       // not cacheable: this leaf stays on the CPU path
       Resident r = resident.get(core.getKey());
       if (r == null) {
-        MemorySegment seg = upload(leaf, textFields, vectorFields);
+        MemorySegment seg;
+        try {
+          seg = upload(leaf, textFields, vectorFields);
+        } catch (IllegalArgumentException collision) {   // NRTGPU_ERR_INVALID_ARG: a term id added twice
+          continue;                                       // this segment is searched by Lucene (segmentOf -> null)
+        }
         r = new Resident(seg, -1);
         resident.put(core.getKey(), r);
         core.addClosedListener(key -> {                 // segment merged away / last reader closed

@@ -8,13 +8,13 @@ import java.lang.invoke.MethodHandle;
 
 /**
  * FFM binding of include/nrtgpu.h (x86-64 SysV).  No logic: one downcall handle per ABI function the plugin uses and the
- * three struct layouts, whose sizes tests/test_abi.py pins on the library side (nrtgpu_term 24 B, nrtgpu_bm25_query 72 B,
- * nrtgpu_topdocs 40 B).  NOT COMPILED in the image this repository is developed in (no JDK).
+ * struct layouts, whose sizes tests/test_abi.py pins on the library side (nrtgpu_term 24 B, nrtgpu_bm25_query 72 B,
+ * nrtgpu_topdocs 40 B, nrtgpu_diagnostics 56 B).  NOT COMPILED in the image this repository is developed in (no JDK).
  */
 final class NrtGpu {
   private NrtGpu() {}
 
-  static final int OK = 0, ERR_INVALID_ARG = -1, ERR_HIP = -2, ERR_OOM = -3, ERR_UNSUPPORTED = -4, ERR_STATE = -5;
+  static final int OK = 0, ERR_INVALID_ARG = -1, ERR_HIP = -2, ERR_OOM = -3, ERR_UNSUPPORTED = -4, ERR_STATE = -5, ERR_TIMEOUT = -6;
   static final int MAX_K = 1024, MAX_TERMS = 32;
 
   private static final Linker L = Linker.nativeLinker();
@@ -45,6 +45,17 @@ final class NrtGpu {
   static final StructLayout CONFIG =
       MemoryLayout.structLayout(JAVA_INT.withName("device_id"), JAVA_INT.withName("max_batch"), JAVA_INT.withName("target_items"),
           JAVA_INT.withName("collect_timing"), JAVA_INT.withName("flags"), JAVA_INT.withName("host_threads"));
+
+  // nrtgpu_diagnostics, 56 bytes
+  static final StructLayout DIAGNOSTICS =
+      MemoryLayout.structLayout(JAVA_DOUBLE.withName("total_ms"), JAVA_DOUBLE.withName("plan_ms"), JAVA_DOUBLE.withName("queue_ms"),
+          JAVA_DOUBLE.withName("device_ms"), JAVA_LONG.withName("postings"), JAVA_INT.withName("queries"),
+          JAVA_INT.withName("items_maxscore"), JAVA_INT.withName("items_scan"), JAVA_INT.withName("reserved"));
+
+  /** The request thread's deadline (absolute, on nrtgpu_monotonic_ns' clock; 0 = none) and what its last call cost. */
+  static final MethodHandle SET_DEADLINE = h("nrtgpu_set_thread_deadline_ns", FunctionDescriptor.ofVoid(JAVA_LONG));
+  static final MethodHandle MONOTONIC_NS = h("nrtgpu_monotonic_ns", FunctionDescriptor.of(JAVA_LONG));
+  static final MethodHandle LAST_DIAGNOSTICS = h("nrtgpu_last_diagnostics", FunctionDescriptor.of(JAVA_INT, ADDRESS));
 
   static final MethodHandle CREATE = h("nrtgpu_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
   static final MethodHandle DESTROY = h("nrtgpu_destroy", FunctionDescriptor.ofVoid(ADDRESS));
