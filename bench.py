@@ -74,6 +74,7 @@ def parse_args():
                     help="N=1, C3: after the batch line, closed loop with that many concurrent callers, one query per call through "
                          "nrtgpu_search_bm25_coalesced (comma list; empty = skip): qps / p50 / p99 per caller count")
     ap.add_argument("--closed-loop-ms", type=int, default=2500)
+    ap.add_argument("--no-verify", action="store_true", help="C4: skip the fp64 check of the device's answer over all rows")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -332,9 +333,32 @@ def run_c4(args):
     gen = torch.Generator(device="cuda")
     gen.manual_seed(777 + shard_rank)
     leaves, base, first_seg = [], 0, None
+    # Parity at the BASELINE size, in this run: for three queries of the last timed panel the cosine score map of EVERY row is taken
+    # in fp64 (torch on the device, chunk by chunk while the rows are generated) and the 100 best kept -- what the device's answer
+    # is compared with below ("verify").  One GPU only (a rank of a job sees its rows only).
+    qrng = np.random.Generator(np.random.PCG64(778))
+    panels = [qrng.standard_normal((Q, dim), dtype=np.float32) for _ in range(4)]
+    verify_q = sorted(set([0, Q // 2, Q - 1])) if (world == 1 and shard_world == 1 and not args.no_verify) else []
+    last_panel = panels[(args.warmup + args.steps - 1) % len(panels)]
+    vq64 = torch.from_numpy(last_panel[verify_q].astype(np.float64)).cuda() if verify_q else None
+    v_best = None    # (scores fp64 [nq, <=2k], docs int64)
     while base < n:
         rows = min(seg_rows, n - base)
-        host = torch.randn((rows, dim), generator=gen, device="cuda", dtype=torch.float32).cpu().numpy()
+        dev_rows = torch.randn((rows, dim), generator=gen, device="cuda", dtype=torch.float32)
+        if verify_q:
+            cand_s, cand_d = [], []
+            for a0 in range(0, rows, 500_000):
+                blk = dev_rows[a0: a0 + 500_000].to(torch.float64)
+                cos = (blk @ vq64.T) / (blk.norm(dim=1, keepdim=True) * vq64.norm(dim=1).unsqueeze(0))
+                sc64 = torch.clamp((1.0 + cos) / 2.0, min=0.0).T            # VectorSimilarityFunction.COSINE's score map
+                top = torch.topk(sc64, k=min(2 * k, sc64.shape[1]), dim=1)
+                cand_s.append(top.values)
+                cand_d.append(top.indices + (row_lo + base + a0))
+            cs, cd = torch.cat(cand_s + ([v_best[0]] if v_best else []), dim=1), torch.cat(cand_d + ([v_best[1]] if v_best else []), dim=1)
+            keep = torch.topk(cs, k=min(2 * k, cs.shape[1]), dim=1)
+            v_best = (keep.values, torch.gather(cd, 1, keep.indices))
+        host = dev_rows.cpu().numpy()
+        del dev_rows
         g = api.GpuSegment(ctx, rows, row_lo + base)
         g.add_vectors(0, host)
         g.seal()
@@ -345,8 +369,6 @@ def run_c4(args):
         base += rows
     sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics())
     t_build = time.perf_counter() - t_build
-    qrng = np.random.Generator(np.random.PCG64(778))
-    panels = [qrng.standard_normal((Q, dim), dtype=np.float32) for _ in range(4)]
     lat = []
 
     def one(panel):
@@ -399,6 +421,23 @@ def run_c4(args):
                      "mfma_tflops": round(tflops, 2), "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
                      "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None},
     }
+    if verify_q and v_best is not None:
+        # the device's top-k of the last timed panel against the fp64 ranking over all rows: scores within 2e-5 relative, a docid
+        # that differs at its rank must be a near-tie of the fp64 doc there (the fp32 sums differ in their last bits)
+        vs, vd = v_best[0].cpu().numpy(), v_best[1].cpu().numpy()
+        ok, off_rank = True, 0
+        for j, qi in enumerate(verify_q):
+            order = np.lexsort((vd[j], -vs[j]))[:k]
+            ref_d, ref_s = vd[j][order], vs[j][order]
+            gd, gs = last[qi].docs, last[qi].scores
+            ok = ok and len(gd) == k and last[qi].total_hits == n and np.allclose(gs, ref_s, rtol=2e-5, atol=2e-6)
+            score_of = {int(d_): float(s_) for d_, s_ in zip(vd[j], vs[j])}
+            for r in range(min(k, len(gd))):
+                if gd[r] != ref_d[r]:
+                    off_rank += 1
+                    ok = ok and int(gd[r]) in score_of and abs(score_of[int(gd[r])] - ref_s[r]) <= 2e-5 * ref_s[r] + 2e-6
+        out["verify"] = {"agrees_with_fp64": bool(ok), "queries": len(verify_q), "rows": n, "docids_off_rank_among_near_ties": off_rank,
+                         "what": "device top-100 vs fp64 cosine score map over every row (torch, on the device), last timed panel"}
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         # the C restatement of ExactVectorQuery + collector on the host cores, bounded sample: first rows of segment 0
         from oracle import oracle

@@ -305,6 +305,15 @@ int  nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_st
 int  nrtgpu_dist_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs, int32_t field_id,
                            int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k, float boost, int32_t mode,
                            nrtgpu_topdocs* out /* n_queries */);
+/* The hybrid (BASELINE config 5: BM25 recall + vector rescore over 1..8 GPUs) on docid-range shards.  Every rank passes the same
+ * queries and query vectors and ITS leaves: BM25 recall on every shard -> ONE all-gather + merge on every rank (the GLOBAL first
+ * pass: a doc of a shard's list that did not make the merged list must not be rescored) -> every rank rescores ITS docs of the
+ * merged lists against its resident vectors -> the rescored windows are exchanged (`mode`) and merged.  Same answers as
+ * nrtgpu_search_hybrid_batch over the whole index; total_hits / relation are the first pass's. */
+int  nrtgpu_dist_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                     const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t field_id, int32_t sim,
+                                     const float* query_vectors, int32_t dim, float boost, double query_weight, double rescore_weight,
+                                     int32_t window, int32_t mode, nrtgpu_topdocs* out /* n_queries, capacity >= window */);
 void nrtgpu_dist_close(nrtgpu_ctx* ctx);
 
 /* TopDocs.merge of n_lists per-GPU results laid out as the all-gather leaves them:

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
     "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile", "nrtgpu_set_slicing",
     "nrtgpu_blend", "nrtgpu_dist_unique_id", "nrtgpu_dist_init", "nrtgpu_dist_search_bm25_batch", "nrtgpu_dist_allgather_merge", "nrtgpu_segment_fork",
-    "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_knn_exact",
+    "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_knn_exact", "nrtgpu_dist_search_hybrid_batch",
 ]
 
 
@@ -175,6 +175,8 @@ def load() -> C.CDLL:
     L.nrtgpu_dist_search_bm25_batch_mode.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_exchange_merge.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_knn_exact.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, C.c_float, i32, C.POINTER(TopDocs)]
+    L.nrtgpu_dist_search_hybrid_batch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, i32, vp, i32, C.c_float, C.c_double, C.c_double,
+                                                  i32, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_close.argtypes = [vp]
     L.nrtgpu_dist_close.restype = None
     _lib = L

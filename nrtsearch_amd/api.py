@@ -639,6 +639,31 @@ class GpuIndexSearcher:
                         bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n)]
 
 
+    def dist_search_hybrid_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager], field: int,
+                                 similarity: str, query_vectors: np.ndarray, window: int, query_weight: float = 1.0,
+                                 rescore_weight: float = 1.0, boost: float = 1.0, mode: int = EXCHANGE_ALLGATHER) -> List[Optional[TopDocs]]:
+        """The hybrid over docid-range shards (nrtgpu_dist_search_hybrid_batch): this rank's leaves; every rank passes the same
+        queries and query vectors."""
+        n = len(queries)
+        qv = np.ascontiguousarray(np.atleast_2d(query_vectors), dtype=np.float32)
+        if qv.shape[0] != n:
+            raise ValueError("one query vector per query")
+        m = self._marshal(queries, managers)
+        outs = (_lib.TopDocs * n)()
+        docs = np.zeros((n, max(window, 1)), dtype=np.int32)
+        scores = np.zeros((n, max(window, 1)), dtype=np.float32)
+        for qi in range(n):
+            outs[qi].capacity = window
+            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_dist_search_hybrid_batch(
+            self.ctx._h, self._segs, self._bases, len(self.leaves), m.queries, n, int(field), self.SIMILARITY[similarity],
+            qv.ctypes.data, qv.shape[1], C.c_float(boost), float(query_weight), float(rescore_weight), int(window), int(mode), outs))
+        return [None if outs[qi].total_hits < 0 else
+                TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
+                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n)]
+
+
 # ---- pre-marshalled batches (bench / serving loop: no Python work inside the timed region) --------
 class PreparedBatch:
     """A batch of queries marshalled once; `run()` is a single C-ABI call."""

@@ -65,6 +65,7 @@ struct nrtgpu_dist {
   hipStream_t stream = nullptr;
   hipEvent_t ev_wait = nullptr;   // NRTGPU_FLAG_BLOCKING_WAIT
   DevBuf local, gathered;   // [keys | hits | counts] of this rank / of every rank
+  DevBuf stage;             // hybrid: the merged first pass and this rank's rescored windows
   std::mutex mu;            // one collective (one user of `gathered`) at a time per communicator
   std::mutex call_mu;       // one whole search call (one user of `local`) at a time: taken before `mu`
 };
@@ -114,6 +115,7 @@ extern "C" void nrtgpu_dist_close(nrtgpu_ctx* ctx) {
   if (d->ev_wait) (void)hipEventDestroy(d->ev_wait);
   d->local.release();
   d->gathered.release();
+  d->stage.release();
   delete d;
 }
 
@@ -298,4 +300,74 @@ extern "C" int nrtgpu_dist_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* s
   if (int rc = knn_exact_device(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, k_stride, lk, lc, lh)) return rc;
   std::vector<int32_t> ks((size_t)n_queries, k), thr((size_t)n_queries, INT32_MAX);
   return nrtgpu_dist_exchange_merge(ctx, n_queries, k_stride, lk, lc, lh, ks.data(), thr.data(), mode, out);
+}
+
+// The hybrid (BASELINE config 5) over docid-range shards: BM25 recall on every shard -> ONE all-gather + merge on every rank
+// (the GLOBAL first pass: a doc that made its shard's list but not the merged one must not be rescored) -> every rank rescores
+// ITS docs of the merged lists against its resident vectors -> the rescored windows are exchanged (mode) and merged.  Same
+// answers as nrtgpu_search_hybrid_batch over the whole index; TotalHits are the first pass's (QueryRescorer keeps them).
+// Reference: multi-retriever / rescorer chain of SearchHandler.java:556 -> RescoreTask.java:47-50 -> QueryRescore.java:39-57.
+extern "C" int nrtgpu_dist_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                               const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t field_id, int32_t sim,
+                                               const float* query_vectors, int32_t dim, float boost, double query_weight,
+                                               double rescore_weight, int32_t window, int32_t mode, nrtgpu_topdocs* out) {
+  if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
+  if (!queries || !out || !query_vectors || n_queries <= 0 || (n_segs > 0 && (!segs || !doc_bases))) return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
+  if (dim <= 0 || sim < 0 || sim > 3 || window <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad rescore arguments");
+  if (!(query_weight >= 0.0) || !(rescore_weight >= 0.0) || !(boost >= 0.0f))
+    return fail(NRTGPU_ERR_UNSUPPORTED, "hybrid tail: negative weights (combined scores must stay >= 0)");
+  nrtgpu_dist* d = ctx->dist;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int32_t kmax = 1;
+  for (int qi = 0; qi < n_queries; ++qi) kmax = std::max(kmax, queries[qi].k);
+  const int32_t k_stride = (int32_t)round_up((uint32_t)std::min(kmax, NRTGPU_MAX_K), 16);
+  const int32_t win = std::min<int32_t>(window, NRTGPU_MAX_K);
+  const uint32_t w_stride = round_up((uint32_t)win, 16);
+  const size_t nq = (size_t)n_queries;
+  std::lock_guard<std::mutex> call(d->call_mu);
+  char *lk = nullptr, *lh = nullptr, *lc = nullptr;
+  if (int rc = local_lists(d, n_queries, k_stride, &lk, &lh, &lc)) return rc;
+  // 1. the first pass on this shard
+  if (int rc = nrtgpu_search_bm25_batch_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lk, lc, lh)) return rc;
+  std::vector<int32_t> ks(nq), thr(nq), wins(nq, win);
+  for (size_t q = 0; q < nq; ++q) {
+    ks[q] = queries[q].k;
+    thr[q] = queries[q].total_hits_threshold;
+  }
+  // merged first pass [keys | hits | counts], this rank's windows [keys | hits | counts]
+  const size_t kb = nq * (size_t)k_stride * 8, wb = nq * (size_t)w_stride * 8, hb = nq * 8, cb = (nq * 4 + 7) & ~(size_t)7, qb = cb;
+  if (int rc = d->stage.reserve(kb + hb + cb + wb + hb + cb + qb)) return rc;
+  char* mk = (char*)d->stage.p;
+  char* mh = mk + kb;
+  char* mc = mh + hb;
+  char* wk = mc + cb;
+  char* wh = wk + wb;
+  char* wc = wh + hb;
+  char* qk = wc + cb;   // numHits per query, for hybrid_hits_kernel
+  Slot* slot = nullptr;
+  acquire_slot(ctx, &slot);
+  struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
+  {
+    std::lock_guard<std::mutex> lk_(d->mu);
+    // 2. the global first pass: every rank needs every merged list (its docs may be anywhere in it)
+    Gathered g;
+    if (int rc = exchange_lists(ctx, d, n_queries, k_stride, lk, lc, lh, NRTGPU_EXCHANGE_ALLGATHER, &g)) return rc;
+    if (int rc = merge_lists_on_device(ctx, slot, d->world, n_queries, k_stride, g.keys, g.cnt, g.hits, ks.data(), mk, mc, mh)) return rc;
+    HIP_TRY(hipStreamSynchronize(slot->stream));   // (`gathered` is free again)
+  }
+  // 3. this rank's docs of the merged lists, rescored; rank 0 carries the first pass's hit totals
+  SegReadLocks content(segs, n_segs);
+  if (int rc = hybrid_tail_on_device(ctx, slot, segs, doc_bases, n_segs, field_id, sim, query_vectors, dim, boost, query_weight, rescore_weight,
+                                     win, n_queries, mk, mc, k_stride, d->world > 1 ? 1 : 0, wk, wc, w_stride))
+    return rc;
+  {
+    std::vector<uint32_t> hk(nq);
+    for (size_t q = 0; q < nq; ++q) hk[q] = (uint32_t)ks[q];
+    HIP_TRY(hipMemcpyAsync(qk, hk.data(), nq * 4, hipMemcpyHostToDevice, slot->stream));
+    launch_hybrid_hits(slot->stream, (const uint64_t*)mh, (const uint32_t*)mc, (const uint32_t*)qk, d->rank == 0 ? 1 : 0, (uint64_t*)wh, (uint32_t)n_queries);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(slot->stream));   // (hk is a stack vector; the windows must be complete before the exchange reads them)
+  }
+  // 4. the windows: exchanged and merged like any per-rank top-k
+  return nrtgpu_dist_exchange_merge(ctx, n_queries, (int32_t)w_stride, wk, wc, wh, wins.data(), thr.data(), mode, out);
 }

@@ -344,8 +344,13 @@ void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32
                            uint32_t k_stride, const DVecSeg* __restrict__ segs, int32_t n_segs, int32_t dim,
                            const float* __restrict__ qvecs, const float* __restrict__ qnorm2, int32_t sim, float boost,
                            double qw, double rw, uint32_t window, uint64_t* __restrict__ out_keys,
-                           uint32_t* __restrict__ out_counts, uint32_t w_stride) {
+                           uint32_t* __restrict__ out_counts, uint32_t w_stride, int32_t drop_foreign) {
+  // drop_foreign (multi-GPU: the list is the MERGED first pass of all shards): a hit whose doc lies in none of these leaves
+  // belongs to another rank -- that rank rescores it; here it is dropped (key 0 sorts last and is not counted)
   __shared__ uint64_t cand[1024];
+  __shared__ uint32_t n_foreign;
+  if (threadIdx.x == 0) n_foreign = 0;
+  __syncthreads();
   const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n = min(first_counts[q], 1024u);
   const float* qv = qvecs + (size_t)q * dim;
@@ -357,10 +362,12 @@ void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32
     int64_t row = -1;
     const float* v = nullptr;
     float nv = 0.f;
+    bool mine = false;
     for (int32_t si = 0; si < n_segs; ++si) {  // wave-uniform
       const DVecSeg sg = segs[si];
       const int64_t local = (int64_t)gdoc - (int64_t)sg.doc_base;
       if (local < 0 || local >= (int64_t)sg.max_doc) continue;
+      mine = true;
       if (sg.vecs) {
         if (!sg.ord_to_doc) {
           if (local < (int64_t)sg.n_vec) row = local;
@@ -389,14 +396,16 @@ void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32
     }
     if (lane == 0) {
       const double comb = row >= 0 ? qw * (double)first + rw * (double)second : qw * (double)first;
-      cand[i] = pack_key((float)comb, gdoc);
+      const bool foreign = drop_foreign != 0 && !mine;
+      cand[i] = foreign ? 0ull : pack_key((float)comb, gdoc);
+      if (foreign) atomicAdd(&n_foreign, 1u);
     }
   }
   uint32_t n2 = 1;
   while (n2 < n) n2 <<= 1;
   for (uint32_t i = n + tid; i < n2; i += (uint32_t)kHybridThreads) cand[i] = 0;
   bitonic_sort_desc<kHybridThreads>(cand, n2);  // starts with a barrier
-  const uint32_t m = min(n, window);
+  const uint32_t m = min(n - n_foreign, window);
   for (uint32_t i = tid; i < w_stride; i += (uint32_t)kHybridThreads) out_keys[(size_t)q * w_stride + i] = i < m ? cand[i] : 0;
   if (tid == 0) out_counts[q] = m;
 }
@@ -435,10 +444,29 @@ void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnor
 void launch_hybrid_rescore(hipStream_t st, uint32_t n_queries, const uint64_t* first_keys, const uint32_t* first_counts,
                            uint32_t k_stride, const DVecSeg* segs, int32_t n_segs, int32_t dim, const float* qvecs,
                            const float* qnorm2, int32_t sim, float boost, double qw, double rw, uint32_t window,
-                           uint64_t* out_keys, uint32_t* out_counts, uint32_t w_stride) {
+                           uint64_t* out_keys, uint32_t* out_counts, uint32_t w_stride, int32_t drop_foreign) {
   if (n_queries == 0) return;
   hipLaunchKernelGGL(hybrid_rescore_kernel, dim3(n_queries), dim3(kHybridThreads), 0, st, first_keys, first_counts, k_stride,
-                     segs, n_segs, dim, qvecs, qnorm2, sim, boost, qw, rw, window, out_keys, out_counts, w_stride);
+                     segs, n_segs, dim, qvecs, qnorm2, sim, boost, qw, rw, window, out_keys, out_counts, w_stride, drop_foreign);
+}
+
+// Multi-GPU hybrid: the hit totals a rank's rescored window carries into the second exchange.  The first pass's total (and
+// its relation tag, plan.h: kHitsPrunedUnit) is the MERGED one, the same on every rank: rank 0 carries it, the others 0, so
+// the merge's sum is that total.  GREATER_THAN_OR_EQUAL_TO needs the first pass's queue full (numHits hits): else the tag is
+// dropped here, as unpack_topdocs does for one GPU.
+__global__ __launch_bounds__(256)
+void hybrid_hits_kernel(const uint64_t* __restrict__ first_hits, const uint32_t* __restrict__ first_counts,
+                        const uint32_t* __restrict__ q_k, int32_t carries, uint64_t* __restrict__ out_hits, uint32_t n) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  uint64_t h = first_hits[q];
+  if (first_counts[q] < q_k[q]) h &= kHitsPrunedUnit - 1ull;
+  out_hits[q] = carries ? h : 0ull;
+}
+void launch_hybrid_hits(hipStream_t st, const uint64_t* first_hits, const uint32_t* first_counts, const uint32_t* q_k, int32_t carries,
+                        uint64_t* out_hits, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(hybrid_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, st, first_hits, first_counts, q_k, carries, out_hits, n);
 }
 
 }  // namespace nrtgpu

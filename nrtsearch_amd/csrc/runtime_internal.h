@@ -77,7 +77,9 @@ void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnor
 void launch_hybrid_rescore(hipStream_t st, uint32_t n_queries, const uint64_t* first_keys, const uint32_t* first_counts,
                            uint32_t k_stride, const DVecSeg* segs, int32_t n_segs, int32_t dim, const float* qvecs,
                            const float* qnorm2, int32_t sim, float boost, double qw, double rw, uint32_t window,
-                           uint64_t* out_keys, uint32_t* out_counts, uint32_t w_stride);
+                           uint64_t* out_keys, uint32_t* out_counts, uint32_t w_stride, int32_t drop_foreign = 0);
+void launch_hybrid_hits(hipStream_t st, const uint64_t* first_hits, const uint32_t* first_counts, const uint32_t* q_k, int32_t carries,
+                        uint64_t* out_hits, uint32_t n);
 }  // namespace nrtgpu
 
 namespace nrtgpu {
@@ -494,6 +496,18 @@ int64_t live_vector_count(const nrtgpu_seg* seg, const FieldData& f);
 int knn_exact_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs, int32_t field_id,
                      int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k, float boost, int32_t k_stride,
                      void* d_keys, void* d_counts, void* d_hits);
+
+// ---- search (search.cpp): pieces of the hybrid path the multi-GPU entry reuses -------------------
+// TopDocs.merge of n_lists gathered lists per query (layout [list][query]) into DEVICE arrays (keys n_queries x k_stride, counts,
+// hit totals), enqueued on `slot`'s stream; the caller synchronises.
+int merge_lists_on_device(nrtgpu_ctx* ctx, Slot* slot, int32_t n_lists, int32_t n_queries, int32_t k_stride, const void* g_keys,
+                          const void* g_counts, const void* g_hits, const int32_t* ks, void* d_keys, void* d_counts, void* d_hits);
+// The vector rescorer over device-resident first-pass lists (hybrid_rescore_kernel), enqueued on `slot`'s stream: uploads the leaf
+// table and the query vectors into the slot's aux buffers; windows -> d_win_keys (n_queries x w_stride), d_win_counts.
+int hybrid_tail_on_device(nrtgpu_ctx* ctx, Slot* slot, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                          int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost, double qw, double rw,
+                          int32_t window, int32_t n_queries, const void* d_first_keys, const void* d_first_counts, int32_t k_stride,
+                          int32_t drop_foreign, void* d_win_keys, void* d_win_counts, uint32_t w_stride);
 
 // ---- planner (planner.cpp) ---------------------------------------------------------------------
 struct HostPlan {

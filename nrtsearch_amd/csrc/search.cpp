@@ -379,6 +379,78 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   return NRTGPU_OK;
 }
 
+int nrtgpu::rt::hybrid_tail_on_device(nrtgpu_ctx* ctx, Slot* slot, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                      int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost, double qw, double rw,
+                                      int32_t window, int32_t n_queries, const void* d_first_keys, const void* d_first_counts,
+                                      int32_t k_stride, int32_t drop_foreign, void* d_win_keys, void* d_win_counts, uint32_t w_stride) {
+  const size_t nq = (size_t)n_queries;
+  Carver ac;
+  const size_t o_segs = ac.take((size_t)std::max(n_segs, 1) * sizeof(DVecSeg)), o_qv = ac.take(nq * (size_t)dim * 4), o_qn = ac.take(nq * 4);
+  if (int rc = slot->d_aux.reserve(ac.off)) return rc;
+  if (int rc = slot->h_aux.reserve(ac.off)) return rc;
+  char* ha = (char*)slot->h_aux.p;
+  char* da = (char*)slot->d_aux.p;
+  DVecSeg* hs = (DVecSeg*)(ha + o_segs);
+  for (int si = 0; si < n_segs; ++si) {
+    DVecSeg v{};
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors) {
+      if (fit->second.dim != dim) return fail(NRTGPU_ERR_INVALID_ARG, "vector dimension mismatch");
+      v.vecs = fit->second.d_vectors;
+      v.vnorm2 = fit->second.d_vnorm2;
+      v.ord_to_doc = fit->second.d_ord_to_doc;
+      v.n_vec = fit->second.n_vec;
+    }
+    v.doc_base = doc_bases[si];
+    v.max_doc = segs[si]->max_doc;
+    hs[si] = v;
+  }
+  memcpy(ha + o_qv, query_vectors, nq * (size_t)dim * 4);
+  float* hqn = (float*)(ha + o_qn);
+  for (size_t q = 0; q < nq; ++q) {  // |q|^2 in the order nrtgpu_rescore_vectors uses
+    const float* qv = query_vectors + q * (size_t)dim;
+    float qn = 0.f;
+    for (int d = 0; d < dim; ++d) {
+      volatile float p2 = qv[d] * qv[d];
+      qn = qn + p2;
+    }
+    hqn[q] = qn;
+  }
+  HIP_TRY(hipMemcpyAsync(da, ha, ac.off, hipMemcpyHostToDevice, slot->stream));
+  launch_hybrid_rescore(slot->stream, (uint32_t)n_queries, (const uint64_t*)d_first_keys, (const uint32_t*)d_first_counts, (uint32_t)k_stride,
+                        (const DVecSeg*)(da + o_segs), n_segs, dim, (const float*)(da + o_qv), (const float*)(da + o_qn), sim, boost, qw, rw,
+                        (uint32_t)window, (uint64_t*)d_win_keys, (uint32_t*)d_win_counts, w_stride, drop_foreign);
+  HIP_TRY(hipGetLastError());
+  return NRTGPU_OK;
+}
+
+int nrtgpu::rt::merge_lists_on_device(nrtgpu_ctx* ctx, Slot* slot, int32_t n_lists, int32_t n_queries, int32_t k_stride, const void* g_keys,
+                                      const void* g_counts, const void* g_hits, const int32_t* ks, void* d_keys, void* d_counts, void* d_hits) {
+  const size_t nq = (size_t)n_queries, nl = (size_t)n_lists;
+  Carver pc;
+  const size_t o_lidx = pc.take(nq * nl * 4), o_qbase = pc.take(nq * 4), o_qnl = pc.take(nq * 4), o_qk = pc.take(nq * 4);
+  if (int rc = slot->h_plan.reserve(pc.off)) return rc;
+  if (int rc = slot->d_plan.reserve(pc.off)) return rc;
+  char* hb = (char*)slot->h_plan.p;
+  uint32_t* lidx = (uint32_t*)(hb + o_lidx);
+  uint32_t* qbase = (uint32_t*)(hb + o_qbase);
+  uint32_t* qnl = (uint32_t*)(hb + o_qnl);
+  uint32_t* qk = (uint32_t*)(hb + o_qk);
+  for (size_t q = 0; q < nq; ++q) {
+    qbase[q] = (uint32_t)(q * nl);
+    qnl[q] = (uint32_t)nl;
+    qk[q] = (uint32_t)ks[q];
+    for (size_t l = 0; l < nl; ++l) lidx[q * nl + l] = (uint32_t)(l * nq + q);
+  }
+  char* db = (char*)slot->d_plan.p;
+  HIP_TRY(hipMemcpyAsync(db, hb, pc.off, hipMemcpyHostToDevice, slot->stream));
+  launch_merge_topk(slot->stream, (uint32_t)n_queries, (const uint64_t*)g_keys, (const uint32_t*)g_counts, (const uint64_t*)g_hits,
+                    (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase), (const uint32_t*)(db + o_qnl), (uint32_t)k_stride,
+                    (const uint32_t*)(db + o_qk), (uint64_t*)d_keys, (uint32_t*)d_counts, (uint64_t*)d_hits, (uint32_t)k_stride);
+  HIP_TRY(hipGetLastError());
+  return NRTGPU_OK;
+}
+
 extern "C" int nrtgpu_query_supported(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, const nrtgpu_bm25_query* q) {
   if (!ctx || !q || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_segs must be >= 0");

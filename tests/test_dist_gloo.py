@@ -76,6 +76,37 @@ def _worker(rank: int, world: int, port: int, ret):
             md, ms = oracle.topdocs_merge(kk, lists)
             ok &= md.tolist() == wd[qi, : wc[qi]].tolist() and ms.view(np.uint32).tolist() == ws[qi, : wc[qi]].view(np.uint32).tolist()
             ok &= int(gh[:, qi].sum()) == n_rows
+        # The hybrid over shards (BASELINE config 5; nrtgpu_dist_search_hybrid_batch): shard first passes -> all-gather + merge
+        # (the GLOBAL first pass) -> every rank rescores ITS docs of the merged list -> the windows are gathered and merged.
+        # Must equal: the global first pass rescored by one process.
+        vec = np.random.Generator(np.random.PCG64(9)).standard_normal((w.n_docs, 16), dtype=np.float32)
+        hq = np.random.Generator(np.random.PCG64(10)).standard_normal((w.n_queries, 16), dtype=np.float32)
+        lo_d, hi_d = workload.shard_range(w.n_docs, world, rank)
+        window, qw, rw = 10, 1.0, 3.0
+
+        def rescored(docs_, scores_, qi, only_mine):
+            rows = [(float(oracle.rescore_combine(float(s0), True, float(oracle.vector_score(0, hq[qi], vec[d0])), qw, rw)), int(d0))
+                    for d0, s0 in zip(docs_, scores_) if (not only_mine or lo_d <= d0 < hi_d)]
+            rows.sort(key=lambda r: (-r[0], r[1]))
+            rows = rows[:window]
+            return np.array([r[1] for r in rows], dtype=np.int32), np.array([r[0] for r in rows], dtype=np.float32)
+
+        wkeys = np.zeros((w.n_queries, 16), dtype=np.int64)
+        wcnt = np.zeros(w.n_queries, dtype=np.int32)
+        merged_first = []
+        for qi in range(w.n_queries):
+            lists = [nd.unpack_keys(g_keys[r, qi].numpy(), int(g_cnt[r, qi])) for r in range(world)]
+            md, ms = oracle.topdocs_merge(k, lists)                      # every rank holds the merged first pass
+            merged_first.append((md, ms))
+            wd, ws = rescored(md, ms, qi, True)
+            wkeys[qi] = nd.pack_keys(wd, ws, 16)
+            wcnt[qi] = len(wd)
+        hk, hc, _ = nd.all_gather_topk(torch.from_numpy(wkeys), torch.from_numpy(wcnt), torch.from_numpy(np.zeros(w.n_queries, dtype=np.int64)))
+        for qi in range(w.n_queries):
+            lists = [nd.unpack_keys(hk[r, qi].numpy(), int(hc[r, qi])) for r in range(world)]
+            fd, fs = oracle.topdocs_merge(window, lists)
+            ed, es = rescored(merged_first[qi][0], merged_first[qi][1], qi, False)
+            ok &= fd.tolist() == ed.tolist() and fs.view(np.uint32).tolist() == es.view(np.uint32).tolist()
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

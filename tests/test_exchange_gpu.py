@@ -219,6 +219,13 @@ def test_exchange_modes_and_vector_search_world_of_one(oracle):
             for a, b in zip(local, dist_):
                 assert a.docs.tolist() == b.docs.tolist() and a.scores.view(np.uint32).tolist() == b.scores.view(np.uint32).tolist()
                 assert a.total_hits == b.total_hits == sum(len(m) for m in mats) and not b.relation_gte
+            # the hybrid over shards (config 5): first pass -> all-gather + merge -> this rank's docs rescored -> windows exchanged
+            hq = rng.standard_normal((len(queries), dim), dtype=np.float32)
+            one = sr.search_hybrid_batch(queries, [mgr] * len(queries), 5, "cosine", hq, 20, 1.0, 2.0)
+            many = sr.dist_search_hybrid_batch(queries, [mgr] * len(queries), 5, "cosine", hq, 20, 1.0, 2.0, mode=mode)
+            for a, b in zip(one, many):
+                assert a.docs.tolist() == b.docs.tolist() and a.scores.view(np.uint32).tolist() == b.scores.view(np.uint32).tolist()
+                assert a.total_hits == b.total_hits and a.relation_gte == b.relation_gte
     finally:
         ctx.dist_close()
         for l in leaves:

@@ -199,3 +199,42 @@ def test_relation_is_decided_per_slice(ctxs, oracle):
     finally:
         ix.close()
         ctx.set_slicing()
+
+
+def test_search_after_under_slicing_pins_the_documented_divergence(ctxs, oracle):
+    """searchAfter under many slices.  The reference's collector turns GREATER_THAN_OR_EQUAL_TO only once ITS SLICE's queue is
+    full (LazyQueueTopScoreDocCollector.java:112-120,176-199: hits of earlier pages do not enter the queue); the library asks
+    for the MERGED page to be full (numHits hits returned) and some slice's count above the threshold.  Docids, ranks, score
+    bits and -- wherever the relation agrees -- totalHits are the oracle's on every page; where the two rules differ it can only
+    be this way round: oracle EQUAL_TO, library GREATER_THAN_OR_EQUAL_TO, on a full page."""
+    ranks = [3, 30, 100, 300, 1000]
+    corpus = synth.build_corpus(300_000, ranks, n_segments=8, delete_fraction=0.01)
+    slicing = (20_000, 2)
+    ctx = ctxs[0]
+    ctx.set_slicing(*slicing)
+    ix = Index(ctx, corpus)
+    try:
+        agree = differ = 0
+        for terms, k, thr in (([30, 300], 40, 60), ([100, 1000], 25, 30), ([3, 300], 200, 1000), ([300], 30, 20)):
+            after = None
+            for page in range(8):
+                mgr = api.TopScoreDocCollectorManager(k, after=after, total_hits_threshold=thr)
+                got = ix.searcher.search(bq(terms), mgr)
+                edocs, escores, etotal, egte = oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, slicing=slicing,
+                                                                  after=(after.doc, after.score) if after else None)
+                assert got.docs.tolist() == edocs.tolist(), f"{terms} page {page}: docids"
+                assert got.scores.view(np.uint32).tolist() == escores.view(np.uint32).tolist(), f"{terms} page {page}: scores"
+                if got.relation_gte == egte:
+                    agree += 1
+                    assert (max(thr, k) < got.total_hits <= etotal) if egte else got.total_hits == etotal
+                else:
+                    differ += 1
+                    assert got.relation_gte and not egte and len(got.docs) == k, f"{terms} page {page}: the rules may only differ this way round"
+                    assert max(thr, k) < got.total_hits <= etotal
+                if len(got.docs) < k:
+                    break
+                after = api.ScoreDoc(int(got.docs[-1]), float(got.scores[-1]))
+        assert agree > 0
+    finally:
+        ix.close()
+        ctx.set_slicing()
