@@ -66,6 +66,11 @@ extern "C" int nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id,
   return NRTGPU_OK;
 }
 
+// A sparse term's cell table holds one posting offset per 2^shift sub-tiles; a lookup (maxscore.hip) binary-searches the docids
+// of ONE cell, so the table is sized for about kCellPostings postings per cell (it then takes 4 / kCellPostings bytes per posting:
+// "table <= 1/4 of the term's postings").
+static const int kCellPostings = 4;   // (8 -> 4: -2 % kernel time for +1.4 % segment bytes at C3; 2: -2.6 % for +3.6 %, profiles/r03_kernel_shapes.log)
+
 extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64_t n_terms, const int64_t* term_hash,
                                         const int64_t* offsets, const int32_t* docids, const int32_t* freqs) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
@@ -89,7 +94,12 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
     const int64_t cnt = hi - lo;
     if (cnt > 0xFFFFFFFFll) return fail(NRTGPU_ERR_UNSUPPORTED, "term with more than 2^32 postings");
     uint32_t shift = 0;
-    const uint64_t budget = std::max<int64_t>(1, cnt / 8);
+    static const int64_t budget_div = [] {   // (experiment knob: postings per cell aimed for; default below)
+      const char* e = getenv("NRTGPU_CELL_POSTINGS");
+      const int64_t v = e ? atoll(e) : 0;
+      return v >= 1 && v <= 64 ? v : (int64_t)kCellPostings;
+    }();
+    const uint64_t budget = std::max<int64_t>(1, cnt / budget_div);
     // (packed postings: a cell must not span two 2^20-doc super-windows -- a posting's doc offset is relative to its cell's)
     const uint32_t max_shift = (seg->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) ? kPackMaxCellShift : 31u;
     while (((uint64_t)(seg->n_tiles - 1) >> shift) + 1 > budget && shift < max_shift) ++shift;
