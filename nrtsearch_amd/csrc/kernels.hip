@@ -275,26 +275,6 @@ __device__ __forceinline__ uint64_t peers_bound(const unsigned long long* peers,
   return inv == 0xFFFFFFFFu ? 0ull : (uint64_t)(~inv) << 32;
 }
 
-// The same between the shards of one search on different GPUs (plan.h: DExchange).  Every rank publishes
-// a score that at least ceil(k / (world - 1)) of its docs reach, so the entries of ANY world - 1 ranks
-// cover k docs: a rank bounds itself by the smallest entry of the OTHER ranks and does not have to wait
-// for its own first compaction.  `local` (what this rank's items know together about that quantile) is
-// stored into the rank's own entry; any published value is valid, so a plain store suffices.
-__device__ __forceinline__ uint64_t exchange_bound(const DExchange& x, uint32_t query, uint64_t local, uint32_t lane) {
-  if (local != 0ull && lane == 0)
-    __hip_atomic_store(x.slot + (size_t)x.rank * x.stride + query, ((unsigned long long)x.tag << 32) | (local >> 32),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  uint32_t inv = 0;
-  for (uint32_t r = lane; r < x.world; r += 64u) {
-    if (r == x.rank) continue;
-    const unsigned long long e = __hip_atomic_load(x.slot + (size_t)r * x.stride + query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint32_t hi = (uint32_t)(e >> 32) == x.tag ? (uint32_t)e : 0u;  // another epoch's entry: silent
-    inv = max(inv, ~hi);
-  }
-  inv = (uint32_t)__builtin_amdgcn_readlane((int)wave_max_u32(inv), 63);
-  return inv == 0xFFFFFFFFu ? 0ull : (uint64_t)(~inv) << 32;
-}
-
 // Workgroup-wide rendezvous body: keep the k best of (candidate buffer UNION the candidates a wave
 // still has parked in its sub-tile), publish theta.  Every thread calls it.  A wave whose reservation
 // failed (`parked`) has reset every non-competitive slot of its sub-tile, so its parked candidates are

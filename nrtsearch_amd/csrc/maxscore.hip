@@ -162,15 +162,20 @@ __device__ __forceinline__ void collapse_to_rows(const uint32_t (&d)[NS], const 
 }
 
 // All waves: keep the k best candidates, raise theta.  Contains barriers.
+// xch (multi-GPU, nrtgpu_exchange_open): the item also publishes a score that ceil(k / (world - 1)) of ITS docs reach -- for free
+// from the selection's histogram -- and bounds itself by the smallest entry of the OTHER ranks (bm25_common.hiph:
+// exchange_bound): nothing below it can enter the merged top-k.
 __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem* sp, uint32_t k, int fx_E,
-                                        unsigned long long* theta_g) {
+                                        unsigned long long* theta_g, const DExchange* xch, uint32_t query) {
   MsSmem& s = *(MsSmem*)sp;
   const uint32_t tid = threadIdx.x;
   const uint32_t cnt_raw = s.cnt;
   const uint32_t cnt0 = cnt_raw > (uint32_t)kMsCandCap ? s.cnt_valid : cnt_raw;  // failed reservations inflate cnt
   __syncthreads();
   if (cnt0 > k) {  // uniform
-    const uint64_t thr = topk_kth_union<kMsThreads>(s.cand, cnt0, k, &s.sc, [](auto&&) {});
+    const uint32_t k2 = (xch && xch->world > 1u) ? (k + xch->world - 2u) / (xch->world - 1u) : 0u;
+    const uint64_t thr = topk_kth_union<kMsThreads>(s.cand, cnt0, k, &s.sc, [](auto&&) {}, k2);
+    const uint32_t q2_hi = s.sc.q2_hi;  // (stable until the next selection)
     const uint32_t kept = topk_keep_ge<kMsThreads, kMsCandCap>(s.cand, cnt0, thr, &s.sc);
     if (tid == 0) {
       s.cnt = kept;
@@ -180,6 +185,14 @@ __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem
       }
       atomicMax(theta_g, (unsigned long long)thr);  // LazyMaxScoreAccumulator.accumulate analogue
       s.prof[1] += 1;
+    }
+    if (xch && tid < 64u) {   // wave 0: publish my quantile, bound myself by the other ranks' entries
+      const uint64_t pb = exchange_bound(*xch, query, q2_hi != 0u ? (uint64_t)q2_hi << 32 : 0ull, tid);
+      if (tid == 0 && pb > s.theta) {
+        s.theta = pb;
+        s.thr = acc_threshold<true>(pb, fx_E);
+        atomicMax(theta_g, (unsigned long long)pb);   // (the query's other items on this GPU get it through theta_g)
+      }
     }
   } else if (tid == 0) {
     s.cnt = cnt0;
@@ -191,10 +204,11 @@ __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem
 
 // Meeting point of the workgroup's waves: returns false when nobody asked for a compaction (every wave is out
 // of work), else runs it.
-__device__ __forceinline__ bool ms_meet(MsSmem& s, uint32_t k, int fx_E, unsigned long long* theta_g) {
+__device__ __forceinline__ bool ms_meet(MsSmem& s, uint32_t k, int fx_E, unsigned long long* theta_g, const DExchange* xch = nullptr,
+                                        uint32_t query = 0) {
   __syncthreads();
   if (!__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
-  ms_compact((__attribute__((address_space(3))) MsSmem*)&s, k, fx_E, theta_g);
+  ms_compact((__attribute__((address_space(3))) MsSmem*)&s, k, fx_E, theta_g, xch, query);
   return true;
 }
 
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(kMsThreads)
 void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts, const DTerm* __restrict__ terms,
                           const DQuery* __restrict__ queries,
                           const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
-                          uint32_t* __restrict__ slice_sum, uint32_t* __restrict__ q_prune,
+                          uint32_t* __restrict__ slice_sum, uint32_t* __restrict__ q_prune, const DExchange* __restrict__ xch,
                           uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
                           uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof) {
   __shared__ MsSmem s;
@@ -282,6 +296,13 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   const uint64_t t_item0 = PROF ? __builtin_readcyclecounter() : 0ull;
   uint64_t tc_meet = 0, tc_part = 0, tc_walk = 0;
   __syncthreads();
+  if (xch && tid < 64u) {   // wave 0: what the other GPUs' shards have published for this query so far (nothing of mine yet)
+    const uint64_t pb = exchange_bound(*xch, item.query, 0ull, tid);
+    if (tid == 0 && pb > s.theta) {
+      s.theta = pb;
+      s.thr = acc_threshold<true>(pb, fx_E);
+    }
+  }
   for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
     const float w = items[blockIdx.x].tab_weight[slot];
     const int scale = items[blockIdx.x].tab_scale[slot];
@@ -683,7 +704,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
               break;
             }
             const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
-            (void)ms_meet(s, k, fx_E, my_theta_g);
+            (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
             if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
             theta_now = max(theta_now, s.theta);
           }
@@ -904,7 +925,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
           }
           // no room: everybody meets, the k best stay, theta rises; then the same postings again under the new theta
           const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
-          (void)ms_meet(s, k, fx_E, my_theta_g);
+          (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
           if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
           theta_now = max(theta_now, s.theta);
         }
@@ -912,7 +933,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         // somebody else asked for a compaction: join it between two instructions
         if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
           const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
-          (void)ms_meet(s, k, fx_E, my_theta_g);
+          (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
           if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
         }
       }
@@ -925,7 +946,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   }
   // ---- out of work: stay available for the others' compactions until everybody is done
   const uint64_t t_idle0 = PROF ? __builtin_readcyclecounter() : 0ull;
-  while (ms_meet(s, k, fx_E, my_theta_g)) {
+  while (ms_meet(s, k, fx_E, my_theta_g, xch, item.query)) {
   }
   const uint64_t t_epi0 = PROF ? __builtin_readcyclecounter() : 0ull;
   if (PROF && lane == 0) {
@@ -1076,12 +1097,12 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
 // ---- launchers ---------------------------------------------------------------------------------------
 void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, uint32_t n_items, const DItem* items, const DPart* parts,
                           const DTerm* terms, const DQuery* queries, const float* caches,
-                          unsigned long long* theta_g, uint32_t* slice_sum, uint32_t* q_prune, uint64_t* item_keys, uint32_t* item_counts,
-                          uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof) {
+                          unsigned long long* theta_g, uint32_t* slice_sum, uint32_t* q_prune, const DExchange* xch, uint64_t* item_keys,
+                          uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof) {
   if (n_items == 0) return;
 #define NRT_MS_LAUNCH(P, K, S)                                                                                                      \
   hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
-                     caches, theta_g, slice_sum, q_prune, item_keys, item_counts, item_hits, k_stride, item_prof)
+                     caches, theta_g, slice_sum, q_prune, xch, item_keys, item_counts, item_hits, k_stride, item_prof)
 #define NRT_MS_LAUNCH_S(P, K)          \
   do {                                 \
     if (shapes) NRT_MS_LAUNCH(P, K, true); \

@@ -106,7 +106,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
   launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, hp.ms_shapes, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                        (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
-                       (uint32_t*)(wb + o_ssum), (uint32_t*)(wb + o_qprune), (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
+                       (uint32_t*)(wb + o_ssum), (uint32_t*)(wb + o_qprune), use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
                        profile ? (uint64_t*)(wb + o_prof) : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, ablation, (uint32_t)(n_items - n_ms),
@@ -690,8 +690,8 @@ extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtg
   p->ctx = ctx;
   p->n_queries = n_queries;
   p->content = std::make_unique<SegReadLocks>(segs, n_segs);  // until this call's kernels have finished (nrtgpu_pending_wait)
-  // (with a bound exchange open the shards run the exhaustive scan, which takes part in it; else they may prune)
-  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, p->hp, (epoch >= 0 && ctx->xch_dev) ? 0 : 2)) return rc;
+  // (both scorers take part in a bound exchange that is open: nrtgpu_exchange_open)
+  if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, p->hp, 2)) return rc;
   if (k_stride < (int32_t)p->hp.k_stride && k_stride < NRTGPU_MAX_K) {
     for (int qi = 0; qi < n_queries; ++qi)
       if (queries[qi].k > k_stride) return fail(NRTGPU_ERR_INVALID_ARG, "k_stride %d smaller than numHits %d", k_stride, queries[qi].k);

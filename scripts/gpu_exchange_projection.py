@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--queries", type=int, default=1024)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=6)
     a = ap.parse_args()
     w, W, n_q = workload.C3, a.world, a.queries
     qr = synth.make_queries(n_q, w.n_terms, w.max_rank)
@@ -56,8 +56,8 @@ def main():
         ctx.reset_stats()
         for i in range(a.steps):
             pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=(epoch0 + 1 + i) if epoch0 >= 0 else -1)
-        st = ctx.stats()
-        return st["scan_ms"] / st["scan_launches"]
+        st = ctx.stats()   # (both scorers take part in the exchange: the batch's device time per step)
+        return (st["scan_ms"] + st["maxscore_ms"]) / max(1, st["batches"])
 
     plain = timed(-1)
     name = f"/nrtgpu_proj_{uuid.uuid4().hex[:12]}"
@@ -73,7 +73,7 @@ def main():
     del table
     ctx.exchange_close()
     os.unlink("/dev/shm" + name)
-    print(json.dumps({"world": W, "scan_ms_rank0_shard": round(plain, 3), "scan_ms_with_peers_published": round(exch, 3)}))
+    print(json.dumps({"world": W, "scorer_ms_rank0_shard": round(plain, 3), "scorer_ms_with_peers_published": round(exch, 3)}))
 
 
 if __name__ == "__main__":
