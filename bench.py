@@ -48,9 +48,14 @@ def parse_args():
     ap.add_argument("--no-prefetch", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", action="store_true",
-                    help="N>1: share score bounds between the GPUs' shards (nrtgpu_exchange_open); the shards then run the "
-                         "exhaustive scan, which takes part in the exchange, instead of pruning on their own (A/B; results are identical)")
+    ap.add_argument("--no-exchange", action="store_true",
+                    help="N>1: do not share score bounds between the GPUs' shards (nrtgpu_exchange_open, on by default: a shard "
+                         "stops collecting below the score that k docs of the OTHER shards already reach; results are identical)")
+    ap.add_argument("--exchange", action="store_true", help="(accepted for older scripts: the exchange is the default at N>1)")
+    ap.add_argument("--emulate-peers", default="none", choices=["none", "final"],
+                    help="with --emulate-world: open the bound exchange for that job and play the other ranks' rows: none = they "
+                         "never publish (the shard prunes on its own, the pessimistic end), final = each publishes from the start "
+                         "what it would hold after its own scan (the optimistic end; a real job lies between the two)")
     ap.add_argument("--packed", action="store_true",
                     help="compressed postings (NRTGPU_FLAG_PACKED_POSTINGS): one 32-bit word per posting in HBM.  A separately "
                          "reported configuration: the roofline's algorithmic bytes are then 4 per posting, not 9")
@@ -576,7 +581,8 @@ def main():
     exchange_name = None
     emu_exchange = False
     lib_mode = api.EXCHANGE_ALLGATHER
-    if world > 1 and args.exchange:
+    peer_words = None   # --emulate-peers final: [batch] -> (shard_world, B) uint32 score bits the other ranks would publish
+    if world > 1 and not args.no_exchange:
         # cross-GPU bound exchange (include/nrtgpu.h): one shared-memory table per job, opened by every rank
         import uuid
         box = [f"/nrtgpu_bench_{uuid.uuid4().hex[:16]}" if rank == 0 else None]
@@ -587,6 +593,36 @@ def main():
         except Exception as e:   # a rank without the table only misses the pruning; results do not depend on it
             print(f"[rank {rank}] bound exchange unavailable: {e}", file=sys.stderr, flush=True)
         dist.barrier()
+    elif world == 1 and shard_world > 1 and args.emulate_peers != "none":
+        import uuid
+        k2 = -(-w.k // (shard_world - 1))
+        peer_words = [np.zeros((shard_world, B), dtype=np.uint64) for _ in batches]
+        for r in range(shard_world):
+            if r == shard_rank:
+                continue
+            c_r = workload.build_shard_corpus(w, qranks, shard_world, r, layout=args.shard_layout)
+            ctx_r = api.GpuContext(device_id=local_rank, max_batch=B, flags=flags, host_threads=planner_threads)
+            leaves_r = [api.GpuSegment.from_data(ctx_r, s) for s in c_r.segments]
+            sr_r = api.GpuIndexSearcher(ctx_r, leaves_r, api.IndexStatistics.from_corpus(c_r))
+            for bi in range(len(batches)):
+                res = sr_r.search_batch(queries[bi * B: (bi + 1) * B], [mgr] * B)
+                sc = np.array([float(t.scores[k2 - 1]) if len(t.scores) >= k2 else 0.0 for t in res], dtype=np.float32)
+                peer_words[bi][r] = sc.view(np.uint32).astype(np.uint64)
+            for l in leaves_r:
+                l.release()
+            ctx_r.close()
+            del c_r
+        exchange_name = f"/nrtgpu_bench_{uuid.uuid4().hex[:16]}"
+        ctx.exchange_open(exchange_name, shard_world, shard_rank)
+        peer_table = np.memmap("/dev/shm" + exchange_name, dtype=np.uint64, mode="r+", shape=(8, shard_world, B))
+        peer_rows = [r for r in range(shard_world) if r != shard_rank]
+
+    def play_peers(epoch):
+        """The other ranks' rows of the exchange table for this epoch (slot epoch % 8, tag epoch + 1), written before the
+        step is submitted; at most NB steps are in flight, so the slot's previous epoch is long finished."""
+        if peer_words is not None:
+            words = peer_words[epoch % len(batches)]
+            peer_table[epoch % 8, peer_rows, :] = (np.uint64(epoch + 1) << np.uint64(32)) | words[peer_rows]
     NB = 3  # device result buffers in flight between the scan threads and the exchange thread
     lib_collective = False
     lib_collective_hung = False   # its setup thread never came back: leave through os._exit at the end
@@ -716,6 +752,7 @@ def main():
             t_start[i] = time.perf_counter()
             keys, cnt, hits = bufs[b]
             pb = batches[(first + i) % len(batches)]
+            play_peers(first + i)
             if args.sync_submit:
                 pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=(first + i) if exchange_name else -1)
             else:   # plan + enqueue only: the exchange thread waits for the results
@@ -863,6 +900,7 @@ def main():
                         + ((f" (collective inside the library: nrtgpu_dist_exchange_merge, {'all-to-all' if lib_mode == api.EXCHANGE_ALLTOALL else 'all-gather'})"
                             if lib_collective else ("" if emu_exchange else " (collective: torch.distributed)")) if use_dist else "")
                         + (", score-bound exchange between shards" if exchange_name else "")
+                        + (f" (the other ranks' rows played by this process: --emulate-peers {args.emulate_peers})" if peer_words is not None else "")
                         + (f" [emulating rank {shard_rank} of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
@@ -906,6 +944,9 @@ def main():
         if world > 1:
             dist.barrier()
         os._exit(0)
+    if world == 1 and exchange_name:
+        ctx.exchange_close()
+        os.unlink("/dev/shm" + exchange_name)
     if world > 1:
         dist.barrier()
         if exchange_name:

@@ -465,6 +465,7 @@ typedef struct {
   int64_t knn_score_launches; /* knn_score_kernel launches (a panel takes a few rounds, theta tightens in between) */
   double  knn_score_ms;       /* sum of their HIP-event durations (collect_timing) */
   int64_t knn_rows;           /* sum over panels of the rows scored */
+  int64_t knn_second_passes;  /* panels that needed a second pass over the rows: a query's nominations did not certify its answer */
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);

@@ -83,7 +83,7 @@ class Stats(C.Structure):
                 ("merge_ms", C.c_double), ("host_plan_ms", C.c_double), ("fixed_point_launches", C.c_int64),
                 ("maxscore_launches", C.c_int64), ("maxscore_ms", C.c_double), ("maxscore_postings", C.c_int64),
                 ("maxscore_items", C.c_int64), ("knn_panels", C.c_int64), ("knn_score_launches", C.c_int64),
-                ("knn_score_ms", C.c_double), ("knn_rows", C.c_int64)]
+                ("knn_score_ms", C.c_double), ("knn_rows", C.c_int64), ("knn_second_passes", C.c_int64)]
 
 
 class NrtGpuError(RuntimeError):

@@ -42,6 +42,15 @@ __global__ __launch_bounds__(256) void knn_row_norms_kernel(const float* __restr
   if (lane == 0) norm2[row] = s;
 }
 
+// *out = max(*out, max_i norm2[i]) as float bits (squared norms are >= 0: their bits order like the values).
+__global__ __launch_bounds__(256) void knn_norm_max_kernel(const float* __restrict__ norm2, int64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(norm2[i])));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
+}
+
 __device__ __forceinline__ float knn_map_score(int sim, float dot, float nq, float nv, float boost) {
   float s;
   if (sim == 0) {  // COSINE: max((1 + cos) / 2, 0), cos = (float)(dot / sqrt((double)nq * nv))
@@ -56,6 +65,91 @@ __device__ __forceinline__ float knn_map_score(int sim, float dot, float nq, flo
     s = dot < 0.0f ? 1.0f / (1.0f - dot) : dot + 1.0f;
   }
   return s * boost;
+}
+
+// The similarity in the ORACLE's order (oracle/nrt_oracle.c nrt_oracle_vector_score: scalar, left to right, every product
+// and every sum rounded to fp32; the build has -ffp-contract=off), one lane per (query, row): what the exact vector search
+// returns.  The matrix-core pass above it only nominates rows; a result is the bits this function gives.
+//   q: the query (LDS or global), v: the row, nq: the query's |q|^2 summed in the same order (host).
+// (U 16-byte pieces of the row are requested before the first is used: a lane walks its own row, nothing is coalesced, and
+//  the walk is latency bound -- 256 bytes per lane in flight instead of 64 took the rescoring of 150 nominations x 32 queries
+//  at 768 dimensions from 0.6 ms to <see DESIGN 4.5>.)
+template <int SIM, int U>
+__device__ __forceinline__ void knn_seq_block(const f32x4* __restrict__ vp, const f32x4* qp, int32_t c0, float& a, float& b) {
+  f32x4 x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) x[u] = vp[c0 + u];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const f32x4 y = qp[c0 + u];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (SIM == 2) {
+        const float d = y[e] - x[u][e];
+        const float sq = d * d;
+        a = a + sq;
+      } else {
+        const float p = y[e] * x[u][e];
+        a = a + p;
+        if (SIM == 0) {
+          const float vv = x[u][e] * x[u][e];
+          b = b + vv;
+        }
+      }
+    }
+  }
+}
+template <int SIM>
+__device__ __forceinline__ void knn_seq_sums(const float* q, const float* __restrict__ v, int32_t dim, float& a, float& b) {
+  const f32x4* vp = (const f32x4*)v;
+  const f32x4* qp = (const f32x4*)q;
+  const int32_t n4 = dim >> 2;   // dim % 16 == 0: whole groups of four 16-byte pieces
+  int32_t c0 = 0;
+  for (; c0 + 16 <= n4; c0 += 16) knn_seq_block<SIM, 16>(vp, qp, c0, a, b);
+  for (; c0 < n4; c0 += 4) knn_seq_block<SIM, 4>(vp, qp, c0, a, b);
+}
+__device__ __forceinline__ float knn_score_seq(int sim, const float* q, const float* __restrict__ v, int32_t dim, float nq, float boost) {
+  float a = 0.f, b = 0.f;
+  if (sim == 2) {   // squareDistance
+    knn_seq_sums<2>(q, v, dim, a, b);
+    return (1.0f / (1.0f + a)) * boost;
+  }
+  if (sim == 0) {   // cosine: dot and |v|^2 in one sweep, each its own chain
+    knn_seq_sums<0>(q, v, dim, a, b);
+    const float c = (float)((double)a / sqrt((double)nq * (double)b));
+    return fmaxf((1.0f + c) / 2.0f, 0.0f) * boost;   // (a NaN cosine -- a zero vector -- scores 0, as the oracle's `s > 0 ? s : 0`)
+  }
+  knn_seq_sums<1>(q, v, dim, a, b);
+  float s;
+  if (sim == 1) s = fmaxf((1.0f + a) / 2.0f, 0.0f);
+  else s = a < 0.0f ? 1.0f / (1.0f - a) : a + 1.0f;
+  return s * boost;
+}
+
+// global docid -> its vector row (nullptr: the doc has no vector for the field, or lies in none of these leaves).
+__device__ __forceinline__ const float* knn_row_of_doc(const DVecSeg* __restrict__ segs, int32_t n_segs, int32_t dim, uint32_t gdoc,
+                                                       bool* in_these_leaves) {
+  *in_these_leaves = false;
+  for (int32_t si = 0; si < n_segs; ++si) {
+    const DVecSeg sg = segs[si];
+    const int64_t local = (int64_t)gdoc - (int64_t)sg.doc_base;
+    if (local < 0 || local >= (int64_t)sg.max_doc) continue;
+    *in_these_leaves = true;
+    if (!sg.vecs) return nullptr;
+    int64_t row = -1;
+    if (!sg.ord_to_doc) {
+      if (local < (int64_t)sg.n_vec) row = local;
+    } else {  // lower_bound over the leaf's ascending ord -> doc map
+      int32_t lo = 0, hi = sg.n_vec;
+      while (lo < hi) {
+        const int32_t mid = lo + ((hi - lo) >> 1);
+        if (sg.ord_to_doc[mid] < (int32_t)local) lo = mid + 1; else hi = mid;
+      }
+      if (lo < sg.n_vec && sg.ord_to_doc[lo] == (int32_t)local) row = lo;
+    }
+    return row >= 0 ? sg.vecs + row * dim : nullptr;
+  }
+  return nullptr;
 }
 
 // The dot products of one 16-row tile with the workgroup's query panel(s): acc0 / acc1 = C tiles of panel 0 / 1.
@@ -236,6 +330,26 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
 
 // Per query: top-k of (running top-k  UNION  the round's candidate list) -> running top-k (sorted),
 // theta[q] = k-th key once k hits are known.  One workgroup per query.
+//
+// REFINE: the candidates are NOMINATIONS (keys carrying the matrix-core estimate of the score); each is rescored in the
+// oracle's order (knn_score_seq) before it competes, so the running top-k holds result bits.  Two uses (vectors.cpp):
+//   certify = 1: the candidates are the sorted top-k_int of the estimates, the running list starts empty.  A row outside that
+//     list has an estimate <= the list's last one, m, hence a result <= knn_result_upper(m) (plan.h; DESIGN §4.5: the
+//     worst-case rounding bound of two length-dim fp32 sums), so the top-k of the rescored list IS the answer when its k-th
+//     score lies above that or the list held every row; cert[q] says which.  If not, theta[q] becomes the lowest key a row
+//     of the answer can carry as an estimate (k-th rescored score - E) and the host runs the second use:
+//   certify = 0: a pass over the rows with theta fixed; every nomination is rescored and merged (theta is left alone).
+struct KnnRefine {
+  const DVecSeg* segs;
+  const float* qpanel;      // the panel's queries, row-major
+  const float* qnorm2;
+  const float* ebound;      // per query: e_abs of knn_result_upper / knn_estimate_lower (plan.h)
+  uint32_t* cert;
+  int32_t n_segs, dim, sim, certify;
+  float boost, erel, min_score;
+  uint32_t k_int;
+};
+
 struct KnnSelSmem {
   uint64_t cand[kMergeCap];
   TopkScratch sc;
@@ -244,16 +358,20 @@ struct KnnSelSmem {
   uint32_t pad;
 };
 
+template <bool REFINE>
 __global__ __launch_bounds__(kScanThreads)
 void knn_select_kernel(uint64_t* __restrict__ topk, uint32_t* __restrict__ topk_cnt, uint32_t k_stride, uint32_t k,
                        const uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt, uint32_t cap,
-                       unsigned long long* __restrict__ theta, uint32_t* __restrict__ overflow) {
+                       unsigned long long* __restrict__ theta, uint32_t* __restrict__ overflow, KnnRefine rf) {
   __shared__ KnnSelSmem s;
+  __shared__ __attribute__((aligned(16))) float qv[REFINE ? 2048 : 4];
   const uint32_t tid = threadIdx.x, q = blockIdx.x;
   if (tid == 0) {
     s.theta = 0;
     s.cnt = 0;
   }
+  if (REFINE)
+    for (int32_t i = (int32_t)tid; i < rf.dim; i += kScanThreads) qv[i] = rf.qpanel[(size_t)q * rf.dim + i];
   __syncthreads();
   const uint32_t n_prev = topk_cnt[q];
   const uint32_t n_raw = cand_cnt[q];
@@ -264,7 +382,17 @@ void knn_select_kernel(uint64_t* __restrict__ topk, uint32_t* __restrict__ topk_
     const uint32_t c = pass == 0 ? n_prev : n_cand;
     for (uint32_t off = 0; off < c; off += kScanThreads) {
       const uint32_t i = off + tid;
-      const uint64_t key = (i < c) ? src[i] : 0;
+      uint64_t key = (i < c) ? src[i] : 0;
+      if (REFINE && pass == 1 && key != 0ull) {   // nomination -> result bits
+        const uint32_t gdoc = 0xFFFFFFFFu - (uint32_t)key;
+        bool mine;
+        const float* v = knn_row_of_doc(rf.segs, rf.n_segs, rf.dim, gdoc, &mine);
+        key = 0ull;
+        if (v) {
+          const float sc = knn_score_seq(rf.sim, qv, v, rf.dim, rf.qnorm2[q], rf.boost);
+          if (!(rf.min_score > 0.0f) || sc >= rf.min_score) key = pack_key(sc, gdoc);
+        }
+      }
       const bool want = (i < c) && (key > s.theta);
       topk_append(s.cand, &s.cnt, want, key);
       __syncthreads();
@@ -302,8 +430,45 @@ void knn_select_kernel(uint64_t* __restrict__ topk, uint32_t* __restrict__ topk_
   if (tid == 0) {
     topk_cnt[q] = n;
     cand_cnt[q] = 0;
-    if (n == k) theta[q] = s.cand[k - 1];
+    if (!REFINE) {
+      if (n == k) theta[q] = s.cand[k - 1];
+    } else if (rf.certify) {
+      // the nominations: sorted, at most k_int of them; a full list may have left rows outside, none with an estimate above m
+      const bool full = n_raw >= rf.k_int;
+      const double m = full ? (double)key_score(cand[(size_t)q * cap + rf.k_int - 1]) : 0.0;
+      const double e_abs = (double)rf.ebound[q], e_rel = (double)rf.erel, b = (double)rf.boost;
+      const bool ok = !full || (n == k && (double)key_score(s.cand[k - 1]) > knn_result_upper(rf.sim, m, e_abs, e_rel, b));
+      rf.cert[q] = ok ? 1u : 0u;
+      unsigned long long th = ~0ull;   // certified: the second pass nominates nothing for this query
+      if (!ok) {
+        // a row of the answer scores >= the k-th rescored score (or >= min_score while fewer than k are known): the lowest key
+        // its estimate can carry
+        const double base = n == k ? (double)key_score(s.cand[k - 1]) : (double)rf.min_score * b;
+        const float lo = (float)knn_estimate_lower(rf.sim, base, e_abs, e_rel, b);
+        th = lo > 0.0f ? pack_key(lo, 0xFFFFFFFFu) - 1ull : 0ull;
+      }
+      theta[q] = th;
+    }
   }
+}
+
+// One wave, one (query, row): the similarity with the lanes striding the dimensions (coalesced row reads) and a butterfly
+// sum.  EUCLIDEAN sums (q - v)^2 directly: |q|^2 + |v|^2 - 2 q.v cancels for near-duplicates and large norms.
+__device__ __forceinline__ float knn_wave_score(int sim, const float* __restrict__ v, const float* __restrict__ q, int32_t dim,
+                                                uint32_t lane, float nq, float nv, float boost) {
+  float acc = 0.f;
+  if (sim == 2) {
+    for (int32_t k = (int32_t)lane; k < dim; k += 64) {
+      const float d = q[k] - v[k];
+      acc += d * d;
+    }
+  } else {
+    for (int32_t k = (int32_t)lane; k < dim; k += 64) acc += v[k] * q[k];
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (sim == 2) return (1.0f / (1.0f + acc)) * boost;
+  return knn_map_score(sim, acc, nq, nv, boost);
 }
 
 // Rescore: one wave per candidate doc: exact similarity of the query vector with the doc's vector
@@ -320,12 +485,7 @@ void rescore_vectors_kernel(const float* __restrict__ vecs, const float* __restr
   const int64_t row = vec_row[i];
   float second = 0.f;
   if (row >= 0) {
-    const float* v = vecs + row * dim;
-    float dot = 0.f;
-    for (int32_t k = (int32_t)lane; k < dim; k += 64) dot += v[k] * query[k];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) dot += __shfl_xor(dot, d, 64);
-    second = knn_map_score(sim, dot, qnorm2, vnorm2[row], boost);
+    second = knn_wave_score(sim, vecs + row * dim, query, dim, lane, qnorm2, vnorm2[row], boost);
   }
   if (lane == 0) {
     const double comb = row >= 0 ? qw * (double)first_scores[i] + rw * (double)second : qw * (double)first_scores[i];
@@ -387,13 +547,7 @@ void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32
       break;
     }
     float second = 0.f;
-    if (row >= 0) {
-      float dot = 0.f;
-      for (int32_t k = (int32_t)lane; k < dim; k += 64) dot += v[k] * qv[k];
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) dot += __shfl_xor(dot, d, 64);
-      second = knn_map_score(sim, dot, nq, nv, boost);
-    }
+    if (row >= 0) second = knn_wave_score(sim, v, qv, dim, lane, nq, nv, boost);
     if (lane == 0) {
       const double comb = row >= 0 ? qw * (double)first + rw * (double)second : qw * (double)first;
       const bool foreign = drop_foreign != 0 && !mine;
@@ -415,6 +569,10 @@ void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_
   if (n == 0) return;
   hipLaunchKernelGGL(knn_row_norms_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, st, vecs, dim, n, norm2);
 }
+void launch_knn_norm_max(hipStream_t st, const float* norm2, int64_t n, uint32_t* out_bits) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(knn_norm_max_kernel, dim3((uint32_t)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, norm2, n, out_bits);
+}
 size_t knn_score_lds_bytes(int32_t dim, int32_t n_q) { return (size_t)(dim >> 4) * (((n_q > 32 ? 32 : n_q) > 16) ? 128 : 64) * 16; }
 int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
@@ -431,8 +589,20 @@ int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const f
 void launch_knn_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,
                        const uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, unsigned long long* theta,
                        uint32_t* overflow) {
-  hipLaunchKernelGGL(knn_select_kernel, dim3(n_q), dim3(kScanThreads), 0, st, topk, topk_cnt, k_stride, k, cand, cand_cnt,
-                     cap, theta, overflow);
+  hipLaunchKernelGGL(knn_select_kernel<false>, dim3(n_q), dim3(kScanThreads), 0, st, topk, topk_cnt, k_stride, k, cand, cand_cnt,
+                     cap, theta, overflow, KnnRefine{});
+}
+void launch_knn_refine_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,
+                              const uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, unsigned long long* theta, uint32_t* overflow,
+                              const DVecSeg* segs, int32_t n_segs, int32_t dim, int32_t sim, const float* qpanel, const float* qnorm2,
+                              float boost, const float* ebound, float erel, float min_score, uint32_t k_int, int32_t certify,
+                              uint32_t* cert) {
+  KnnRefine rf{};
+  rf.segs = segs; rf.qpanel = qpanel; rf.qnorm2 = qnorm2; rf.ebound = ebound; rf.cert = cert;
+  rf.n_segs = n_segs; rf.dim = dim; rf.sim = sim; rf.certify = certify;
+  rf.boost = boost; rf.erel = erel; rf.min_score = min_score; rf.k_int = k_int;
+  hipLaunchKernelGGL(knn_select_kernel<true>, dim3(n_q), dim3(kScanThreads), 0, st, topk, topk_cnt, k_stride, k, cand, cand_cnt,
+                     cap, theta, overflow, rf);
 }
 void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnorm2, int32_t dim, const float* query,
                             float qnorm2, int32_t sim, float boost, const int64_t* vec_row, const float* first_scores,

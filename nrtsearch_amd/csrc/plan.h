@@ -234,6 +234,30 @@ struct DVecSeg {
 };
 static_assert(sizeof(DVecSeg) == 40, "DVecSeg layout");
 
+// Exact vector search: the matrix-core ESTIMATE of a score against the RESULT (the same similarity summed in the oracle's
+// order).  e_abs bounds |estimate - result| -- for EUCLIDEAN of the squared distance (the score 1 / (1 + d2) flattens with d2: a
+// bound in score units would be useless for far rows), else of the score with the boost applied; e_rel covers the roundings of
+// the map to a score.  DESIGN 4.5.
+//   knn_result_upper: no row whose estimate is <= m has a result above this.
+//   knn_estimate_lower: every row whose result is >= s has an estimate of at least this.
+__host__ __device__ inline double knn_result_upper(int sim, double m, double e_abs, double e_rel, double boost) {
+  if (sim == 2) {
+    if (!(m > 0.0)) return 0.0;
+    const double d2 = boost / m - 1.0;
+    const double lo = d2 - (e_abs + e_rel * (1.0 + d2));
+    return boost / (1.0 + (lo > 0.0 ? lo : 0.0)) * (1.0 + 1e-6);
+  }
+  return (m + e_abs + e_rel * (m < 0.0 ? -m : m)) * (1.0 + 1e-6);
+}
+__host__ __device__ inline double knn_estimate_lower(int sim, double s, double e_abs, double e_rel, double boost) {
+  if (sim == 2) {
+    if (!(s > 0.0)) return 0.0;
+    const double d2 = boost / s - 1.0;
+    return boost / (1.0 + (d2 > 0.0 ? d2 : 0.0) + e_abs + e_rel * (1.0 + d2)) * (1.0 - 1e-6);
+  }
+  return (s - (e_abs + e_rel * (s < 0.0 ? -s : s))) * (1.0 - 1e-6);
+}
+
 __host__ __device__ inline uint64_t pack_key(float score, uint32_t global_doc) {
   union { float f; uint32_t u; } c;
   c.f = score;

@@ -71,6 +71,12 @@ int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const f
 void launch_knn_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,
                        const uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, unsigned long long* theta,
                        uint32_t* overflow);
+void launch_knn_refine_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,
+                              const uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, unsigned long long* theta, uint32_t* overflow,
+                              const DVecSeg* segs, int32_t n_segs, int32_t dim, int32_t sim, const float* qpanel, const float* qnorm2,
+                              float boost, const float* ebound, float erel, float min_score, uint32_t k_int, int32_t certify,
+                              uint32_t* cert);
+void launch_knn_norm_max(hipStream_t st, const float* norm2, int64_t n, uint32_t* out_bits);
 void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnorm2, int32_t dim, const float* query,
                             float qnorm2, int32_t sim, float boost, const int64_t* vec_row, const float* first_scores,
                             int32_t n, double qw, double rw, float* out_scores);
@@ -224,6 +230,7 @@ struct FieldData {
   int32_t* d_ord_to_doc = nullptr;
   std::vector<int32_t> h_ord_to_doc;     // host copy: docid -> row lookups of the rescore path
   int32_t dim = 0, n_vec = 0;
+  float vnorm2_max = 0.f;                // largest |v|^2 of the rows
   // rows whose doc is live under the segment's current liveDocs (what an exact vector query matches), counted on first
   // use per liveDocs version
   mutable std::atomic<int64_t> live_vec{-1};
@@ -231,7 +238,8 @@ struct FieldData {
   FieldData() = default;
   FieldData(const FieldData& o)
       : d_norms(o.d_norms), max_norm(o.max_norm), dict(o.dict), flat(o.flat), groups(o.groups), d_vectors(o.d_vectors),
-        d_vnorm2(o.d_vnorm2), d_ord_to_doc(o.d_ord_to_doc), h_ord_to_doc(o.h_ord_to_doc), dim(o.dim), n_vec(o.n_vec) {}
+        d_vnorm2(o.d_vnorm2), d_ord_to_doc(o.d_ord_to_doc), h_ord_to_doc(o.h_ord_to_doc), dim(o.dim), n_vec(o.n_vec),
+        vnorm2_max(o.vnorm2_max) {}
 };
 
 }  // namespace rt

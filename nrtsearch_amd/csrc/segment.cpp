@@ -192,8 +192,13 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
   if (int rc = dev_alloc(seg, &p, (size_t)n * 4 + 64)) return rc;
   f.d_vnorm2 = (float*)p;
   launch_knn_row_norms(nullptr, f.d_vectors, dim, n, f.d_vnorm2);
+  // the largest |v|^2 of the field in this segment: the rounding bound the exact search certifies its answer with (vectors.cpp)
+  uint32_t* d_max = (uint32_t*)(f.d_vnorm2 + n);   // (the allocation's spare tail)
+  HIP_TRY(hipMemsetAsync(d_max, 0, 4, nullptr));
+  launch_knn_norm_max(nullptr, f.d_vnorm2, n, d_max);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&f.vnorm2_max, d_max, 4, hipMemcpyDeviceToHost));
   if (ord_to_doc) {
     for (int32_t i = 0; i < n; ++i)
       if (ord_to_doc[i] < 0 || ord_to_doc[i] >= seg->max_doc || (i > 0 && ord_to_doc[i] <= ord_to_doc[i - 1]))

@@ -33,6 +33,11 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim, dim);
   }
   const uint32_t k_stride = round_up((uint32_t)k, 16);
+  // The matrix-core pass NOMINATES: it keeps the k_int best rows by its estimate of the score (an fp32 fma chain in the
+  // MFMA's order, |q|^2 + |v|^2 - 2 q.v for EUCLIDEAN).  The answer is the top k of the nominations rescored in the
+  // oracle's order (knn_score_seq), certified against the rows left outside (knn.hip: knn_select_kernel<true>).
+  const uint32_t k_int = std::min<uint32_t>((uint32_t)NRTGPU_MAX_K, (uint32_t)k + std::max<uint32_t>(32u, (uint32_t)k / 2u));
+  const uint32_t ki_stride = round_up(k_int, 16);
   Slot* slot = nullptr;
   acquire_slot(ctx, &slot);
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
@@ -41,13 +46,52 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));   // behind the scorers enqueued last (search.cpp: enqueue_search)
   const bool timing = ctx->cfg.collect_timing != 0;
   Carver wc;
-  const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_th = wc.take(kKnnMaxQ * 8);
-  const size_t o_tk = wc.take((size_t)kKnnMaxQ * k_stride * 8), o_tc = wc.take(kKnnMaxQ * 4);
-  const size_t o_cc = wc.take(kKnnMaxQ * 4), o_ov = wc.take(64), o_cd = wc.take((size_t)kKnnMaxQ * kKnnCap * 8);
+  const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_eb = wc.take(kKnnMaxQ * 4);
+  const size_t o_segs = wc.take((size_t)std::max(n_segs, 1) * sizeof(DVecSeg));
+  const size_t o_th = wc.take(kKnnMaxQ * 8);
+  const size_t o_tk = wc.take((size_t)kKnnMaxQ * ki_stride * 8), o_tc = wc.take(kKnnMaxQ * 4);
+  const size_t o_cc = wc.take(kKnnMaxQ * 4), o_xk = wc.take((size_t)kKnnMaxQ * k_stride * 8);
+  const size_t o_xc = wc.take(kKnnMaxQ * 4), o_cert = wc.take(kKnnMaxQ * 4), o_ov = wc.take(64);   // (fetched in one copy)
+  const size_t o_cd = wc.take((size_t)kKnnMaxQ * kKnnCap * 8);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
-  if (int rc = slot->h_out.reserve((size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4 + 64)) return rc;
+  const size_t oh_cnt = (size_t)kKnnMaxQ * k_stride * 8, oh_cert = oh_cnt + (o_cert - o_xc), oh_ov = oh_cnt + (o_ov - o_xc);
+  if (int rc = slot->h_out.reserve(oh_ov + 64)) return rc;
   char* wb = (char*)slot->d_work.p;
-  std::vector<float> qn(kKnnMaxQ);
+  char* ho = (char*)slot->h_out.p;
+  std::vector<float> qn(kKnnMaxQ), eb(kKnnMaxQ);
+  // the leaves' vector matrices, for docid -> row on the device (the rescoring reads rows by docid)
+  std::vector<DVecSeg> hsegs((size_t)std::max(n_segs, 1));
+  double nv_max = 0.0;
+  for (int si = 0; si < n_segs; ++si) {
+    DVecSeg v{};
+    v.doc_base = doc_bases ? doc_bases[si] : 0;
+    v.max_doc = segs[si]->max_doc;
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors) {
+      v.vecs = fit->second.d_vectors;
+      v.vnorm2 = fit->second.d_vnorm2;
+      v.ord_to_doc = fit->second.d_ord_to_doc;
+      v.n_vec = fit->second.n_vec;
+      nv_max = std::max(nv_max, (double)fit->second.vnorm2_max);
+    }
+    hsegs[(size_t)si] = v;
+  }
+  HIP_TRY(hipMemcpyAsync(wb + o_segs, hsegs.data(), hsegs.size() * sizeof(DVecSeg), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));   // (hsegs is a stack vector)
+  // |estimate - result| <= E: both are fp32 evaluations of the same length-dim sums, each within gamma = dim * 2^-24 (relative
+  // to the sum of the terms' magnitudes) of the real value whatever the order; the maps to a score have slope <= 1 and add a
+  // few roundings (erel).  DESIGN §4.5 derives the constants.
+  const double u_fp32 = std::ldexp(1.0, -24), gam = (double)(dim + 4) * u_fp32;
+  const float score_boost = knn_request ? 1.0f : boost;
+  const float erel = (float)(8.0 * u_fp32);
+  auto bound_of = [&](double nq) {   // e_abs of plan.h's knn_result_upper / knn_estimate_lower
+    double e = 0.0;
+    if (sim == 0) e = 2.0 * gam * (double)score_boost;
+    else if (sim == 1) e = 1.1 * gam * std::sqrt(nq * nv_max) * (double)score_boost;
+    else if (sim == 2) e = 4.5 * gam * (nq + nv_max);   // squared-distance units, no boost
+    else e = 2.2 * gam * std::sqrt(nq * nv_max) * (double)score_boost;
+    return std::nextafter((float)((e + 4.0 * u_fp32) * (1.0 + 1e-6)), INFINITY);
+  };
   // Rows are scored in rounds with a selection in between (theta tightens from round to round).  The first round of
   // a panel gives every row a slot of the candidate list; later rounds only append rows that beat theta, so they can
   // be long: with rows in no particular order a round that multiplies the rows seen by 16 appends about
@@ -55,7 +99,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   // select kernel flags that and the panel is redone with rounds no longer than the list (`safe`).
   // 160 KB of LDS hold two 16-query panels up to 1280 dimensions; beyond that one panel (16 queries per pass) up to 2048
   const int pass_q = dim > 1280 ? 16 : kKnnMaxQ;
-  for (int q0 = 0, safe = 0; q0 < n_queries; q0 += safe ? 0 : pass_q) {
+  for (int q0 = 0; q0 < n_queries; q0 += pass_q) {
     const int nq = std::min(pass_q, n_queries - q0);
     if (deadline_passed(g_deadline_ns)) {   // between two passes over the rows: nothing of the next one has been launched
       (void)hipStreamSynchronize(st);
@@ -69,71 +113,116 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         s2 = s2 + p2;
       }
       qn[(size_t)q] = s2;
+      eb[(size_t)q] = bound_of((double)s2);
     }
     HIP_TRY(hipMemcpyAsync(wb + o_q, queries + (size_t)q0 * dim, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(wb + o_qn, qn.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(wb + o_th, 0, wc.off - o_th > 0 ? (o_cd - o_th) : 0, st));  // theta, topk, counters
-    if (knn_request && min_score > 0.0f) {  // start theta just below the lowest key of that score: score >= min_score passes
-      std::vector<uint64_t> th0((size_t)nq, pack_key(min_score, 0xFFFFFFFFu) - 1ull);
-      HIP_TRY(hipMemcpyAsync(wb + o_th, th0.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
-    }
-    int64_t total_vec = 0, seen = 0, round = 1 << 16;
+    HIP_TRY(hipMemcpyAsync(wb + o_eb, eb.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    int64_t total_vec = 0, rows_scored = 0;
     size_t n_ev = 0;
-    for (int si = 0; si < n_segs; ++si) {
-      const nrtgpu_seg* seg = segs[si];
-      auto fit = seg->fields.find(field_id);
-      if (fit == seg->fields.end() || !fit->second.d_vectors) continue;
-      const FieldData& f = fit->second;
-      total_vec += live_vector_count(seg, f);   // (deleted docs are masked inside the kernel and are no hits)
-      const uint64_t* accept = seg->d_live;  // (vectors are not re-coded for liveDocs: always the mask)
-      if (knn_request && filter_mask != 0)
-        if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
-      // rounds never exceed the candidate capacity, so a list cannot overflow; theta tightens between rounds
-      int64_t r = 0;
-      if (seen == 0) round = 1 << 16;
-      while (r < f.n_vec) {
-        const int64_t rb = r;
-        const int64_t re = std::min<int64_t>(f.n_vec, r + ((safe || seen == 0) ? std::min<int64_t>(round, kKnnCap) : round));
-        uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
-        if (nq > 32) blocks = std::max(16u, std::min((uint32_t)std::max(ctx->n_cus, 16), 2u * blocks) / 16u * 16u);   // paired workgroups
-        if (timing) {
-          while (slot->round_ev.size() < n_ev + 2) {
-            hipEvent_t ev = nullptr;
-            HIP_TRY(hipEventCreate(&ev));
-            slot->round_ev.push_back(ev);
+    // One pass over the rows of every leaf.  nominate: the estimates' running top-k_int, theta tightening (knn_select_kernel
+    // <false>); else theta stays what the certification left and every nomination is rescored into the answer (<true>).
+    auto rows_pass = [&](bool nominate, int safe) -> int {
+      int64_t seen = 0, round = 1 << 16;
+      total_vec = 0;
+      for (int si = 0; si < n_segs; ++si) {
+        const nrtgpu_seg* seg = segs[si];
+        auto fit = seg->fields.find(field_id);
+        if (fit == seg->fields.end() || !fit->second.d_vectors) continue;
+        const FieldData& f = fit->second;
+        total_vec += live_vector_count(seg, f);   // (deleted docs are masked inside the kernel and are no hits)
+        const uint64_t* accept = seg->d_live;  // (vectors are not re-coded for liveDocs: always the mask)
+        if (knn_request && filter_mask != 0)
+          if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
+        // rounds never exceed the candidate capacity, so a list cannot overflow; theta tightens between rounds
+        int64_t r = 0;
+        if (seen == 0) round = 1 << 16;
+        while (r < f.n_vec) {
+          const int64_t rb = r;
+          int64_t len = (safe || (nominate && seen == 0)) ? std::min<int64_t>(round, kKnnCap) : round;
+          if (!nominate && !safe) len = f.n_vec;   // theta is fixed and tight: the whole leaf at once
+          const int64_t re = std::min<int64_t>(f.n_vec, r + len);
+          uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
+          if (nq > 32) blocks = std::max(16u, std::min((uint32_t)std::max(ctx->n_cus, 16), 2u * blocks) / 16u * 16u);   // paired workgroups
+          if (timing) {
+            while (slot->round_ev.size() < n_ev + 2) {
+              hipEvent_t ev = nullptr;
+              HIP_TRY(hipEventCreate(&ev));
+              slot->round_ev.push_back(ev);
+            }
+            HIP_TRY(hipEventRecord(slot->round_ev[n_ev], st));
           }
-          HIP_TRY(hipEventRecord(slot->round_ev[n_ev], st));
+          const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
+                                         doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
+                                         sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
+                                         (uint32_t*)(wb + o_cc), kKnnCap);
+          if (e) return fail(NRTGPU_ERR_HIP, "knn_score launch: %s", hipGetErrorString((hipError_t)e));
+          if (timing) {
+            HIP_TRY(hipEventRecord(slot->round_ev[n_ev + 1], st));
+            n_ev += 2;
+          }
+          if (nominate)
+            launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, k_int,
+                              (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
+                              (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov));
+          else
+            launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
+                                     (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
+                                     (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim,
+                                     sim, (const float*)(wb + o_q), (const float*)(wb + o_qn), score_boost, (const float*)(wb + o_eb), erel,
+                                     knn_request ? min_score : 0.0f, k_int, 0, (uint32_t*)(wb + o_cert));
+          r = re;
+          seen += re - rb;
+          round = safe ? std::min<int64_t>(round * 4, kKnnCap) : std::min<int64_t>(seen * 15, (int64_t)1 << 40);
         }
-        const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
-                                       doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
-                                       sim, knn_request ? 1.0f : boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
-                                       (uint32_t*)(wb + o_cc), kKnnCap);
-        if (e) return fail(NRTGPU_ERR_HIP, "knn_score launch: %s", hipGetErrorString((hipError_t)e));
-        if (timing) {
-          HIP_TRY(hipEventRecord(slot->round_ev[n_ev + 1], st));
-          n_ev += 2;
-        }
-        launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), k_stride, (uint32_t)k,
-                          (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
-                          (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov));
-        r = re;
-        seen += re - rb;
-        round = safe ? std::min<int64_t>(round * 4, kKnnCap) : std::min<int64_t>(seen * 15, (int64_t)1 << 40);
       }
-    }
-    HIP_TRY(hipGetLastError());
-    char* ho = (char*)slot->h_out.p;
-    HIP_TRY(hipMemcpyAsync(ho, wb + o_tk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(ho + (size_t)kKnnMaxQ * k_stride * 8, wb + o_tc, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(ho + (size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4, wb + o_ov, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (*(const uint32_t*)(ho + (size_t)kKnnMaxQ * k_stride * 8 + kKnnMaxQ * 4) != 0u) {
+      rows_scored += seen;
+      return NRTGPU_OK;
+    };
+    auto fetch = [&]() -> int {   // the answer so far + the flags
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(ho, wb + o_xk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ho + oh_cnt, wb + o_xc, o_ov + 4 - o_xc, hipMemcpyDeviceToHost, st));   // counts, flags, overflow: one copy
+      HIP_TRY(hipStreamSynchronize(st));
+      return NRTGPU_OK;
+    };
+    // 1. nominate, rescore the nominations, certify
+    for (int safe = 0;; ++safe) {
+      HIP_TRY(hipMemsetAsync(wb + o_th, 0, o_cd - o_th, st));  // theta, lists, counters
+      if (knn_request && min_score > 0.0f) {  // start theta below the lowest key whose RESULT can still reach min_score
+        std::vector<uint64_t> th0((size_t)nq);
+        for (int q = 0; q < nq; ++q) {
+          const float lo = (float)knn_estimate_lower(sim, (double)min_score, (double)eb[(size_t)q], (double)erel, 1.0);
+          th0[(size_t)q] = lo > 0.0f ? pack_key(lo, 0xFFFFFFFFu) - 1ull : 0ull;
+        }
+        HIP_TRY(hipMemcpyAsync(wb + o_th, th0.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
+      }
+      if (int rc = rows_pass(true, safe)) return rc;
+      launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
+                               (const uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, (unsigned long long*)(wb + o_th),
+                               (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim, sim, (const float*)(wb + o_q),
+                               (const float*)(wb + o_qn), score_boost, (const float*)(wb + o_eb), erel, knn_request ? min_score : 0.0f,
+                               k_int, 1, (uint32_t*)(wb + o_cert));
+      if (int rc = fetch()) return rc;
+      if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
       if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
-      safe = 1;   // same panel again, bounded rounds
-      continue;
     }
-    safe = 0;
+    // 2. queries whose answer the nominations do not certify (rows outside the list within the rounding bound of the k-th
+    //    result: near-duplicates, or k at the list's capacity): a second pass nominates every row whose estimate is within
+    //    the bound of the k-th rescored score, and rescores all of them
+    int uncertified = 0;
+    for (int q = 0; q < nq; ++q) uncertified += ((const uint32_t*)(ho + oh_cert))[q] == 0u;
+    for (int safe = 0; uncertified; ++safe) {
+      for (int q = 0; q < nq; ++q)   // their answers start over (a nomination found again must not be counted twice)
+        if (((const uint32_t*)(ho + oh_cert))[q] == 0u) HIP_TRY(hipMemsetAsync(wb + o_xc + (size_t)q * 4, 0, 4, st));
+      HIP_TRY(hipMemsetAsync(wb + o_cc, 0, kKnnMaxQ * 4, st));
+      HIP_TRY(hipMemsetAsync(wb + o_ov, 0, 4, st));
+      if (int rc = rows_pass(false, safe)) return rc;
+      if (int rc = fetch()) return rc;   // (the second pass leaves the flags as they are)
+      if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
+      if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
+    }
     {
       double ms = 0.0;
       for (size_t i = 0; i + 1 < n_ev; i += 2) {
@@ -145,18 +234,19 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       ctx->stats.knn_panels += 1;
       ctx->stats.knn_score_launches += (int64_t)(n_ev / 2);
       ctx->stats.knn_score_ms += ms;
-      ctx->stats.knn_rows += seen;
+      ctx->stats.knn_rows += rows_scored;
+      ctx->stats.knn_second_passes += uncertified ? 1 : 0;
     }
     if (ext_keys) {   // stays in HBM: what nrtgpu_dist_knn_exact exchanges
       std::vector<uint64_t> tv((size_t)nq, (uint64_t)total_vec);
-      HIP_TRY(hipMemcpyAsync(ext_keys + (size_t)q0 * k_stride * 8, wb + o_tk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(ext_cnts + (size_t)q0 * 4, wb + o_tc, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ext_keys + (size_t)q0 * k_stride * 8, wb + o_xk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ext_cnts + (size_t)q0 * 4, wb + o_xc, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipMemcpyAsync(ext_hits + (size_t)q0 * 8, tv.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));   // (tv is a stack vector; the workspace is reused by the next panel)
       continue;
     }
     const uint64_t* keys = (const uint64_t*)ho;
-    const uint32_t* cnts = (const uint32_t*)(ho + (size_t)kKnnMaxQ * k_stride * 8);
+    const uint32_t* cnts = (const uint32_t*)(ho + oh_cnt);
     for (int q = 0; q < nq; ++q) {
       nrtgpu_topdocs* o = &out[q0 + q];
       const int32_t cap = o->capacity > 0 ? o->capacity : k;

@@ -118,6 +118,16 @@ def test_knn_c4_shape_against_fp64(oracle):
                 if gd[r] != order[r]:
                     assert abs(sc[gd[r]] - sc[order[r]]) <= 2e-5 * sc[order[r]] + 2e-6, f"query {qi} rank {r}"
             assert len(set(gd.tolist()) & set(order.tolist())) >= k - 2
+        # and the oracle itself (scalar fp32, its order of summation), leaf by leaf, on two queries: bit for bit
+        for qi in (0, 39):
+            hits = []
+            for si, v in enumerate(host):
+                d_, s_, c_ = oracle.knn_exact(0, queries[[qi]], v, k, doc_base=si * per, n_threads=_cpus())
+                hits += list(zip((-s_[0][: c_[0]].astype(np.float64)).tolist(), d_[0][: c_[0]].tolist(), s_[0][: c_[0]].tolist()))
+            hits.sort()
+            assert got[qi].docs.tolist() == [d for _, d, _ in hits[:k]]
+            assert got[qi].scores.view(np.uint32).tolist() == np.array([s for _, _, s in hits[:k]], np.float32).view(np.uint32).tolist()
+        assert ctx.stats()["knn_second_passes"] == 0
     finally:
         for l in leaves:
             l.release()
