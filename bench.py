@@ -79,6 +79,10 @@ def parse_args():
                     help="N=1, C3: after the batch line, closed loop with that many concurrent callers, one query per call through "
                          "nrtgpu_search_bm25_coalesced (comma list; empty = skip): qps / p50 / p99 per caller count")
     ap.add_argument("--closed-loop-ms", type=int, default=2500)
+    ap.add_argument("--no-sketch", action="store_true",
+                    help="C4 A/B: NRTGPU_FLAG_NO_VECTOR_SKETCH -- no fp16 copy of the rows, the exact search nominates from the fp32 rows "
+                         "(twice the bytes per pass); the answers are the same bits")
+    ap.add_argument("--c4-callers", action="store_true", help="C4, one GPU: --host-threads callers take the steps in turn (A/B)")
     ap.add_argument("--no-verify", action="store_true", help="C4: skip the fp64 check of the device's answer over all rows")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the multi-GPU path (device-resident top-k -> exchange -> merge) even at world size 1")
@@ -319,7 +323,9 @@ def run_c4(args):
     row_lo = n_all * shard_rank // shard_world
     n = n_all * (shard_rank + 1) // shard_world - row_lo
     seg_rows = 2_500_000
-    ctx = api.GpuContext(device_id=local_rank, max_batch=64, collect_timing=True)
+    from nrtsearch_amd import _lib
+    ctx = api.GpuContext(device_id=local_rank, max_batch=64, collect_timing=True,
+                         flags=_lib.NRTGPU_FLAG_NO_VECTOR_SKETCH if args.no_sketch else 0)
     mode = api.EXCHANGE_ALLTOALL if args.exchange_mode == "alltoall" else api.EXCHANGE_ALLGATHER
     if world > 1:
         import torch.distributed as dist
@@ -389,11 +395,34 @@ def run_c4(args):
         one(panels[i % len(panels)])
     ctx.reset_stats()
     fence()
+    # One caller by default: a step is one call, its latency the call's.  --c4-callers: --host-threads callers take the steps in
+    # turn (the library runs one call's kernels at a time; a caller's staging and unpacking overlap the other's kernels) --
+    # measured: no gain in throughput (the gap between two calls is ~0.1 ms of 3.6), twice the latency.
+    n_thr = max(1, args.host_threads) if (world == 1 and args.c4_callers) else 1
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ts = time.perf_counter()
-        last = one(panels[(args.warmup + i) % len(panels)])
-        lat.append(time.perf_counter() - ts)
+    if n_thr == 1:
+        for i in range(args.steps):
+            ts = time.perf_counter()
+            last = one(panels[(args.warmup + i) % len(panels)])
+            lat.append(time.perf_counter() - ts)
+    else:
+        import threading
+        results = {}
+
+        def caller(tix):
+            for i in range(tix, args.steps, n_thr):
+                ts = time.perf_counter()
+                r = one(panels[(args.warmup + i) % len(panels)])
+                lat.append(time.perf_counter() - ts)
+                if i == args.steps - 1:
+                    results["last"] = r
+
+        threads = [threading.Thread(target=caller, args=(t,)) for t in range(n_thr)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        last = results["last"]
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -405,7 +434,14 @@ def run_c4(args):
     score_ms = st["knn_score_ms"] / n_panels                    # knn_score_kernel launches of one panel (HIP events, its stream)
     bytes_per_panel = st["knn_rows"] / n_panels * dim * 4        # every row once per panel
     q_per_panel = Q / max(1, (Q + 63) // 64)   # queries per pass over the rows (two 32-query panels on paired workgroups)
-    achieved = bytes_per_panel / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+    # The pass over the rows nominates from the fp16 sketch when the segment keeps one (2 bytes per element, matrix-core operand
+    # order): the kernel then READS half of SURVEY 8d's algorithmic bytes.  As for the pruned BM25 kernel the roofline fraction is the
+    # PHYSICAL one (bytes the kernel streams / launch time) and the algorithmic figure stands beside it as effective_*.
+    sketched = st["knn_sketch_launches"] > 0 and st["knn_sketch_launches"] == st["knn_score_launches"]
+    steps16 = ((dim + 31) // 32 + 3) // 4 * 4
+    phys_bytes_per_panel = st["knn_rows"] / n_panels * (steps16 * 64 if sketched else dim * 4)
+    effective = bytes_per_panel / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+    achieved = phys_bytes_per_panel / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
     tflops = 2.0 * (st["knn_rows"] / n_panels) * dim * q_per_panel / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
     out = {
         "metric": "queries/sec, exact kNN 10M x 768 fp32 cosine top-100" if n_all == 10_000_000 else f"queries/sec, exact kNN {n_all} x 768 fp32 cosine top-100",
@@ -414,17 +450,24 @@ def run_c4(args):
         "max_latency_ms": round(max(lat) * 1e3, 4), "slowest_step": int(np.argmax(lat)),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C4: {n_all} x {dim} fp32 rows, brute-force cosine top-{k}", "n_docs": n_all, "rows_per_gpu": n, "dim": dim, "k": k,
-                   "queries_per_step": Q, "segments_per_gpu": len(leaves), "corpus_build_s": round(t_build, 1),
+                   "queries_per_step": Q, "host_threads": n_thr, "segments_per_gpu": len(leaves), "corpus_build_s": round(t_build, 1),
                    "sharding": ("rows partitioned by docid range, 1 process per GPU, per-rank top-k exchanged inside the library "
                                 f"(nrtgpu_dist_knn_exact, {'all-to-all' if mode == api.EXCHANGE_ALLTOALL else 'all-gather'})" if world > 1 else
                                 (f"[emulating rank {shard_rank} of {shard_world}: its rows, no exchange]" if shard_world > 1 else "one GPU"))},
-        "roofline": {"bound": "hbm", "kernel": "knn_score_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(bytes_per_panel),
-                     "launch": "the knn_score_kernel launches of one pass over the rows (<= 64 queries; a few rounds, theta tightens in between)",
+        "roofline": {"bound": "hbm", "kernel": "knn_sketch_kernel" if sketched else "knn_score_kernel", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "achieved_is": ("physical: the fp16 sketch's bytes (2 per element) / launch time" if sketched
+                                     else "algorithmic bytes (fp32 rows) / launch time"),
+                     "effective": bool(sketched),
+                     "effective_achieved": round(effective, 1) if sketched else None,
+                     "effective_frac": round(effective / HBM_PEAK_GBS, 4) if sketched else None,
+                     "algorithmic_bytes_per_launch": int(bytes_per_panel), "streamed_bytes_per_launch": int(phys_bytes_per_panel),
+                     "launch": "the nomination kernel's launches of one pass over the rows (<= 64 queries; a few rounds, theta tightens in between)",
                      "score_launches_per_panel": round(st["knn_score_launches"] / n_panels, 2),
+                     "second_passes": int(st["knn_second_passes"]),
                      "avg_launch_ms": round(score_ms, 4),
-                     "mfma_tflops": round(tflops, 2), "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                     "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None},
+                     "mfma_tflops": round(tflops, 2) if not sketched else None, "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS if not sketched else None,
+                     "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4) if not sketched else None, "traffic": None},
     }
     if verify_q and v_best is not None:
         # the device's top-k of the last timed panel against the fp64 ranking over all rows: scores within 2e-5 relative, a docid

@@ -74,6 +74,9 @@ typedef struct {
 #define NRTGPU_FLAG_BLOCKING_WAIT 64    /* callers sleep until their results are there instead of spinning on the stream: for deployments
                                         * where several processes (one per GPU) with several calls in flight each share the host's CPUs.
                                         * Costs a wake-up (tens of microseconds) per call */
+#define NRTGPU_FLAG_NO_VECTOR_SKETCH 128 /* vector fields keep no fp16 copy of their rows (+50 % of the fp32 matrix): the exact search then
+                                         * nominates from the fp32 rows (2x the bytes per pass, 32 queries per pass instead of 64).
+                                         * Results are the same bits either way */
 #define NRTGPU_FLAG_NO_PRUNE 16        /* never take the MaxScore route: every query is scanned exhaustively and total_hits is
                                         * always the exact count (the relation still follows totalHitsThreshold) */
 
@@ -466,6 +469,7 @@ typedef struct {
   double  knn_score_ms;       /* sum of their HIP-event durations (collect_timing) */
   int64_t knn_rows;           /* sum over panels of the rows scored */
   int64_t knn_second_passes;  /* panels that needed a second pass over the rows: a query's nominations did not certify its answer */
+  int64_t knn_sketch_launches; /* of knn_score_launches: passes that nominated from the fp16 sketch (half the bytes per row) */
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);

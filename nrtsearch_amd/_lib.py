@@ -27,6 +27,7 @@ NRTGPU_FLAG_NO_LIVE_FOLD = 8
 NRTGPU_FLAG_NO_PRUNE = 16
 NRTGPU_FLAG_PACKED_POSTINGS = 32
 NRTGPU_FLAG_BLOCKING_WAIT = 64
+NRTGPU_FLAG_NO_VECTOR_SKETCH = 128
 NRTGPU_FLAG_PROFILE = 7 << 8
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
@@ -83,7 +84,7 @@ class Stats(C.Structure):
                 ("merge_ms", C.c_double), ("host_plan_ms", C.c_double), ("fixed_point_launches", C.c_int64),
                 ("maxscore_launches", C.c_int64), ("maxscore_ms", C.c_double), ("maxscore_postings", C.c_int64),
                 ("maxscore_items", C.c_int64), ("knn_panels", C.c_int64), ("knn_score_launches", C.c_int64),
-                ("knn_score_ms", C.c_double), ("knn_rows", C.c_int64), ("knn_second_passes", C.c_int64)]
+                ("knn_score_ms", C.c_double), ("knn_rows", C.c_int64), ("knn_second_passes", C.c_int64), ("knn_sketch_launches", C.c_int64)]
 
 
 class NrtGpuError(RuntimeError):

@@ -235,7 +235,9 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
                       int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
                       const float* __restrict__ qpanel, const float* __restrict__ qnorm2, int32_t n_q, int32_t sim,
                       float boost, const unsigned long long* __restrict__ theta, uint64_t* __restrict__ cand,
-                      uint32_t* __restrict__ cand_cnt, uint32_t cap) {
+                      uint32_t* __restrict__ cand_cnt, uint32_t cap, int32_t append_only) {
+  // append_only: this launch is not followed by a selection (the host defers it once theta is tight): a query whose theta is
+  // still unknown appends its live rows like everybody else instead of taking per-row slots a later launch would overwrite
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* qs = (f32x4*)smem;  // [dim/16][2][64] float4: chunk c, panel p, lane (j, kk) -> q[j + 16p][16c + 4kk .. +4]
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -308,7 +310,7 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
               if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
               uint64_t key = 0;  // 0 = "nothing": never above a theta
               if (live) key = pack_key(knn_map_score(sim, dot, nq[p], nv, boost), (uint32_t)(doc_base + ldoc));
-              if (th[p] == 0ull) {
+              if (th[p] == 0ull && !append_only) {
                 // no theta yet (the query's first round, never longer than the list): every row is a
                 // candidate and owns slot (row - row_begin) -- no counter traffic at all
                 const uint64_t pos = (uint64_t)(drow - row_begin);
@@ -324,6 +326,263 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
           }
         }
       }
+    }
+  }
+}
+
+// ---- the fp16 sketch: nomination at half the bytes ---------------------------------------------------------------------
+// The answer's bits come from knn_score_seq over the fp32 rows; what the pass over ALL rows has to do is nominate, and a
+// nomination only needs an estimate with a KNOWN error (knn_select_kernel<true> certifies against it).  So next to the fp32
+// matrix a segment keeps the rows rounded to fp16 (scaled by a power of two so the largest |element| sits at 2^14), laid out in
+// the order the matrix cores take them: tile t = rows 16t .. 16t+15, step s = dimensions 32s .. 32s+31, lane l supplies row
+// (l & 15), dimensions 8 (l >> 4) .. +7 -- one v_mfma_f32_16x16x32_f16 A operand per lane, 1 KiB per (tile, step), the tiles of a
+// row range contiguous.  A wave streams a contiguous run of tiles with kKnnDepth 16-byte pieces in flight per lane: perfectly
+// coalesced, N * dim * 2 bytes per pass, and up to 64 queries (4 panels of 16, fp16 in LDS) ride on one pass because the fp16
+// matrix rate is 16x the fp32 one.  |estimate - result| <= 2^-10 |q||v| (+ fp32 accumulation + flushed tiny elements): vectors.cpp.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// max |element| of the matrix as float bits (atomicMax on uints: magnitudes order like their bits)
+__global__ __launch_bounds__(256) void knn_absmax_kernel(const float* __restrict__ vecs, int64_t n_elems, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * 256)
+    m = max(m, __float_as_uint(fabsf(vecs[i])));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
+}
+// *out = min over rows with a non-zero norm (bits; 0xFFFFFFFF when there is none)
+__global__ __launch_bounds__(256) void knn_norm_min_kernel(const float* __restrict__ norm2, int64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0xFFFFFFFFu;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t b = __float_as_uint(fabsf(norm2[i]));
+    if (b) m = min(m, b);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  if ((threadIdx.x & 63u) == 0) atomicMin(out, m);
+}
+// one thread per 16-byte piece of the sketch
+__global__ __launch_bounds__(256) void knn_sketch_build_kernel(const float* __restrict__ vecs, int32_t dim, int64_t n, int32_t steps,
+                                                              float scale, f16x8* __restrict__ sketch) {
+  const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tiles = (n + 15) >> 4;
+  if (piece >= tiles * steps * 64) return;
+  const int32_t l = (int32_t)(piece & 63);
+  const int64_t ts = piece >> 6;
+  const int32_t s = (int32_t)(ts % steps);
+  const int64_t row = (ts / steps) * 16 + (l & 15);
+  const int32_t k0 = 32 * s + 8 * (l >> 4);
+  f16x8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int32_t k = k0 + e;
+    const float x = (row < n && k < dim) ? vecs[row * dim + k] * scale : 0.0f;
+    h[e] = (_Float16)x;   // round to nearest even; |x| <= 2^14
+  }
+  sketch[piece] = h;
+}
+
+// The ring of row pieces is driven by hand: the requests are inline asm (the compiler's waitcnt insertion does not see them),
+// and before slot i is consumed the wave waits until at most D - 1 requests are outstanding -- exactly the ones issued after slot
+// i's.  Left to the compiler the loop either drained the ring at every group of D pieces (vmcnt(0) at the loop header) or copied
+// the ring's registers at the top of the group, which needs the same wait.  The wait carries the slot as an in/out operand so
+// that the matrix instruction reading it cannot be scheduled above the wait.
+template <int OFF>
+__device__ __forceinline__ void sk_request(f16x8& dst, const f16x8* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void sk_wait(f16x8& slot) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(slot) : "n"(N) : "memory");
+}
+template <int P, int D, int I>
+__device__ __forceinline__ void sk_step(f16x8 (&abuf)[D], f32x4 (&acc)[P], const f16x8* qs_step, const f16x8* nxt_lo, const f16x8* nxt_hi) {
+  sk_wait<D - 1>(abuf[I]);
+#pragma unroll
+  for (int p = 0; p < P; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[I], qs_step[(I * P + p) * 64], acc[p], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // into the registers the matrix instructions above have just read: no copy, D - 1 requests stay in flight
+  if (I < 4) sk_request<(I & 3) * 1024>(abuf[I], nxt_lo);
+  else sk_request<(I & 3) * 1024>(abuf[I], nxt_hi);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Nominations from the sketch: the fp32 kernel's contract (candidate lists, theta, first-round slots), rows [row_begin, row_end)
+// with row_begin a multiple of 16.  P = panels of 16 queries (1 .. 4); D = pieces in flight per lane, `steps` (the sketch's,
+// padded: a multiple of 4) is a multiple of D so that the ring of row pieces is indexed statically and the epilogue stands once
+// per tile.  qscale[q]: the power of two the query was multiplied by before rounding to fp16, inv_rows_scale: 1 / the rows' scale;
+// acc / (qscale * rows' scale) is the dot product in the vectors' own units (powers of two: exact).
+template <int P, int D>
+__global__ __launch_bounds__(kKnnThreads, 1)
+void knn_sketch_kernel(const f16x8* __restrict__ sketch, int32_t steps, const float* __restrict__ vnorm2,
+                       const int32_t* __restrict__ ord_to_doc, const uint64_t* __restrict__ live_bits, int32_t dim,
+                       int64_t row_begin, int64_t row_end, int32_t doc_base, const float* __restrict__ qpanel,
+                       const float* __restrict__ qnorm2, const float* __restrict__ qscale, float inv_rows_scale,
+                       int32_t n_q, int32_t sim, float boost, const unsigned long long* __restrict__ theta,
+                       uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt, uint32_t cap, int32_t append_only,
+                       uint32_t qcap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f16x8* qs = (f16x8*)smem;  // [steps][P][64]: step s, panel p, lane l -> q[(l & 15) + 16p][32s + 8(l >> 4) .. +7] * qscale
+  // Behind the panel: the workgroup's queue of nominations (qcap entries: score bits << 32 | row - row_begin << 6 | query).
+  // A row that passes is pushed HERE (an LDS atomic: lgkmcnt) and the queue is written out once, when the workgroup has streamed
+  // its rows: a global atomic with a return value in the tile epilogue is the newest vector-memory operation of the wave, and
+  // waiting for it waits for every request of the ring before it -- with one passing row per tile (the round after the first
+  // selection) the ring ran dry at every tile and the launch at 3.2 TB/s instead of 5.2.
+  uint32_t* const q_n = (uint32_t*)(smem + (size_t)steps * P * 1024);
+  uint64_t* const q_e = (uint64_t*)(smem + (size_t)steps * P * 1024 + 16);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) *q_n = 0u;
+  for (int32_t i = (int32_t)tid; i < steps * P * 64; i += kKnnThreads) {
+    const int32_t l = i & 63, p = (i >> 6) % P, sidx = (i >> 6) / P;
+    const int32_t q = (l & 15) + 16 * p, k0 = 32 * sidx + 8 * (l >> 4);
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int32_t k = k0 + e;
+      h[e] = (_Float16)((q < n_q && k < dim) ? qpanel[(int64_t)q * dim + k] * qscale[q] : 0.0f);
+    }
+    qs[i] = h;
+  }
+  __syncthreads();
+  const uint32_t j = lane & 15u, kk = lane >> 4;
+  float nq[P], th_hi[P], dsc[P];
+  unsigned long long th[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int32_t q = (int32_t)j + 16 * p;
+    nq[p] = q < n_q ? qnorm2[q] : 0.f;
+    dsc[p] = q < n_q ? inv_rows_scale / qscale[q] : 0.f;   // powers of two: exact
+    th[p] = q < n_q ? theta[q] : ~0ull;
+    // a key above theta carries a score >= theta's (equal scores: the docid decides): rows strictly below are rejected on the
+    // score alone (theta = ~0, "nothing passes", is a NaN score: every compare with it is false)
+    const uint32_t tsb = __float_as_uint(key_score(th[p]));
+    th_hi[p] = tsb ? __uint_as_float(tsb - 1u) : -1.0f;   // (a theta of score 0: ties among zero scores are the docid's business)
+  }
+  // a contiguous run of tiles per wave: one sequential stream of 1 KiB pieces
+  const int64_t t_first = row_begin >> 4, n_tiles = ((row_end + 15) >> 4) - t_first;
+  const int64_t n_waves = (int64_t)gridDim.x * (kKnnThreads / 64), w = (int64_t)blockIdx.x * (kKnnThreads / 64) + wave;
+  const int64_t t0 = t_first + n_tiles * w / n_waves, t1 = t_first + n_tiles * (w + 1) / n_waves;
+  if (t0 < t1) {   // (a wave without tiles still meets the others at the queue's barrier)
+  // the run as groups of D pieces (a tile is steps / D whole groups): `cur` walks the groups, the ring slot of piece i of a group
+  // is i, and the piece D ahead -- the same slot of the NEXT group -- is requested the moment slot i has been consumed (pinned
+  // with sched_barrier: left alone the compiler collects the group's eight requests at its end, and the wave's memory pipeline
+  // runs dry once per group)
+  const f16x8* cur = sketch + (t0 * steps) * 64 + lane;
+  const f16x8* const last_group = cur + ((t1 - t0) * steps - D) * 64;
+  f16x8 abuf[D];
+  sk_request<0>(abuf[0], cur);
+  sk_request<1024>(abuf[1], cur);
+  sk_request<2048>(abuf[2], cur);
+  sk_request<3072>(abuf[3], cur);
+  if (D == 8) {
+    sk_request<0>(abuf[D - 4], cur + 256);
+    sk_request<1024>(abuf[D - 3], cur + 256);
+    sk_request<2048>(abuf[D - 2], cur + 256);
+    sk_request<3072>(abuf[D - 1], cur + 256);
+  }
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    // |v|^2 of the tile's 16 rows: the tile is the same for the whole wave, so they come through the SCALAR cache (s_load,
+    // counted by lgkmcnt, not by the ring's vmcnt)
+    const uint32_t t_lo = __builtin_amdgcn_readfirstlane((uint32_t)(tile & 0xFFFFFFFFll));
+    const uint32_t t_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tile >> 32));
+    const int64_t u_r0 = (int64_t)(((uint64_t)t_hi << 32) | t_lo) << 4;
+    float nvt[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) nvt[c] = vnorm2[u_r0 + c];   // (the norms' allocation is padded: reads past row n - 1 stay inside it)
+    f32x4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int32_t s0 = 0; s0 < steps; s0 += D) {
+      const f16x8* nxt = cur < last_group ? cur + D * 64 : cur;   // (past the run's end: its last group again, never used)
+      const f16x8* nxt_hi = nxt + 256;
+      const f16x8* qg = qs + (size_t)s0 * P * 64 + lane;
+      sk_step<P, D, 0>(abuf, acc, qg, nxt, nxt_hi);
+      sk_step<P, D, 1>(abuf, acc, qg, nxt, nxt_hi);
+      sk_step<P, D, 2>(abuf, acc, qg, nxt, nxt_hi);
+      sk_step<P, D, 3>(abuf, acc, qg, nxt, nxt_hi);
+      if (D == 8) {
+        sk_step<P, D, D - 4>(abuf, acc, qg, nxt, nxt_hi);
+        sk_step<P, D, D - 3>(abuf, acc, qg, nxt, nxt_hi);
+        sk_step<P, D, D - 2>(abuf, acc, qg, nxt, nxt_hi);
+        sk_step<P, D, D - 1>(abuf, acc, qg, nxt, nxt_hi);
+      }
+      cur = nxt;
+    }
+    float nv4[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+      nv4[reg] = kk == 0 ? nvt[reg] : kk == 1 ? nvt[4 + reg] : kk == 2 ? nvt[8 + reg] : nvt[12 + reg];
+    // D layout: query col = lane & 15 (+ 16p), row in tile = 4 * (lane >> 4) + reg
+    const int64_t r0 = tile << 4;
+    float rn4[4];
+    if (sim == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) rn4[reg] = __builtin_amdgcn_rsqf(nv4[reg]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int32_t q = (int32_t)j + 16 * p;
+      if (q < n_q) {
+        const float inv_nq = nq[p] > 0.f ? __builtin_amdgcn_rsqf(nq[p]) : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int64_t drow = r0 + 4 * (int32_t)kk + reg;
+          if (drow >= row_begin && drow < row_end) {
+            const float dot = acc[p][reg] * dsc[p];
+            const float nv = nv4[reg];
+            float est;
+            if (sim == 0) est = fmaxf((1.0f + dot * inv_nq * rn4[reg]) * 0.5f, 0.0f);
+            else if (sim == 1) est = fmaxf((1.0f + dot) * 0.5f, 0.0f);
+            else if (sim == 2) est = __builtin_amdgcn_rcpf(1.0f + fmaxf(nq[p] + nv - 2.0f * dot, 0.0f));
+            else est = dot < 0.0f ? __builtin_amdgcn_rcpf(1.0f - dot) : dot + 1.0f;
+            // this estimate IS the nomination's score (hardware rsq / rcp, a few fp32 roundings: the bound's e_rel covers them):
+            // nothing in double, nothing but compares until a row passes
+            const float sc = est * boost;
+            if (sc > th_hi[p] || th[p] == 0ull) {
+              const bool slot_round = th[p] == 0ull && !append_only;   // no theta yet: the row owns slot (row - row_begin), see knn_score_kernel
+              uint32_t qi = 0xFFFFFFFFu;
+              if (!slot_round) qi = atomicAdd(q_n, 1u);
+              if (qi < qcap) {
+                q_e[qi] = ((uint64_t)__float_as_uint(sc) << 32) | ((uint64_t)(drow - row_begin) << 6) | (uint64_t)q;
+              } else {   // the first round's slots, or a full queue: straight to the list
+                const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
+                bool live = true;
+                if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+                uint64_t key = 0;  // 0 = "nothing": never above a theta
+                if (live) key = pack_key(sc, (uint32_t)(doc_base + ldoc));
+                if (slot_round) {
+                  const uint64_t pos = (uint64_t)(drow - row_begin);
+                  if (pos < cap) cand[(size_t)q * cap + pos] = key;
+                  if (drow == row_end - 1) cand_cnt[q] = (uint32_t)min<int64_t>(row_end - row_begin, (int64_t)0xFFFFFFFFll);
+                } else if (key > th[p]) {
+                  const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
+                  if (pos < cap) cand[(size_t)q * cap + pos] = key;
+                }
+                // (its loads and stores are complete here as far as the compiler's bookkeeping goes: with vector memory events
+                // pending at the next tile's loop it waits vmcnt(0) in front of it -- the ring with them)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last requests (never used) land before the registers are reused
+  }
+  __syncthreads();
+  const uint32_t n_queued = min(*q_n, qcap);
+  for (uint32_t i = tid; i < n_queued; i += kKnnThreads) {
+    const uint64_t e = q_e[i];
+    const uint32_t q = (uint32_t)(e & 63ull);
+    const int64_t drow = row_begin + (int64_t)((e >> 6) & 0x3FFFFFFull);
+    const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
+    bool live = true;
+    if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+    const uint64_t key = pack_key(__uint_as_float((uint32_t)(e >> 32)), (uint32_t)(doc_base + ldoc));
+    if (live && key > theta[q]) {
+      const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
+      if (pos < cap) cand[(size_t)q * cap + pos] = key;
     }
   }
 }
@@ -577,13 +836,59 @@ size_t knn_score_lds_bytes(int32_t dim, int32_t n_q) { return (size_t)(dim >> 4)
 int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
                      const float* qpanel, const float* qnorm2, int32_t n_q, int32_t sim, float boost,
-                     const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap) {
+                     const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only) {
   if (row_end <= row_begin) return 0;
   const size_t lds = knn_score_lds_bytes(dim, n_q);
   hipError_t e = hipFuncSetAttribute((const void*)knn_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(knn_score_kernel, dim3(blocks), dim3(kKnnThreads), lds, st, vecs, vnorm2, ord_to_doc, live_bits, dim,
-                     row_begin, row_end, doc_base, qpanel, qnorm2, n_q, sim, boost, theta, cand, cand_cnt, cap);
+                     row_begin, row_end, doc_base, qpanel, qnorm2, n_q, sim, boost, theta, cand, cand_cnt, cap, append_only);
+  return 0;
+}
+int32_t knn_sketch_steps(int32_t dim) { return (((dim + 31) >> 5) + 3) & ~3; }   // 32 dimensions per step, whole groups of 4 steps (zero padded)
+size_t knn_sketch_bytes(int32_t dim, int64_t n) { return (size_t)((n + 15) >> 4) * (size_t)knn_sketch_steps(dim) * 1024; }
+void launch_knn_absmax(hipStream_t st, const float* vecs, int64_t n_elems, uint32_t* out_bits) {
+  if (n_elems == 0) return;
+  hipLaunchKernelGGL(knn_absmax_kernel, dim3((uint32_t)std::min<int64_t>((n_elems + 255) / 256, 4096)), dim3(256), 0, st, vecs, n_elems, out_bits);
+}
+void launch_knn_norm_min(hipStream_t st, const float* norm2, int64_t n, uint32_t* out_bits) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(knn_norm_min_kernel, dim3((uint32_t)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, norm2, n, out_bits);
+}
+void launch_knn_sketch_build(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float scale, void* sketch) {
+  if (n == 0) return;
+  const int32_t steps = knn_sketch_steps(dim);
+  const int64_t pieces = ((n + 15) >> 4) * steps * 64;
+  hipLaunchKernelGGL(knn_sketch_build_kernel, dim3((uint32_t)((pieces + 255) / 256)), dim3(256), 0, st, vecs, dim, n, steps, scale, (f16x8*)sketch);
+}
+size_t knn_sketch_lds_bytes(int32_t dim, int32_t n_q) { return (size_t)knn_sketch_steps(dim) * (size_t)((n_q + 15) >> 4) * 1024; }
+int launch_knn_sketch(hipStream_t st, uint32_t blocks, const void* sketch, const float* vnorm2, const int32_t* ord_to_doc,
+                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
+                      const float* qpanel, const float* qnorm2, const float* qscale, float inv_rows_scale, int32_t n_q, int32_t sim,
+                      float boost, const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only) {
+  if (row_end <= row_begin) return 0;
+  const int32_t steps = knn_sketch_steps(dim), panels = (n_q + 15) >> 4;
+  const size_t panel_bytes = knn_sketch_lds_bytes(dim, n_q);
+  if (panel_bytes + 16 + 256 * 8 > 160 * 1024) return (int)hipErrorInvalidValue;   // (vectors.cpp only comes here when it fits)
+  const uint32_t qcap = (uint32_t)std::min<size_t>(4096, (160 * 1024 - panel_bytes - 16) / 8);   // the nomination queue behind the panel
+  const size_t lds = panel_bytes + 16 + (size_t)qcap * 8;
+#define NRT_SKETCH_LAUNCH(PANELS, DEPTH)                                                                                            \
+  {                                                                                                                                 \
+    hipError_t e = hipFuncSetAttribute((const void*)knn_sketch_kernel<PANELS, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                       (int)lds);                                                                                   \
+    if (e != hipSuccess) return (int)e;                                                                                             \
+    hipLaunchKernelGGL((knn_sketch_kernel<PANELS, DEPTH>), dim3(blocks), dim3(kKnnThreads), lds, st, (const f16x8*)sketch, steps,   \
+                       vnorm2, ord_to_doc, live_bits, dim, row_begin, row_end, doc_base, qpanel, qnorm2, qscale, inv_rows_scale, n_q, \
+                       sim, boost, theta, cand, cand_cnt, cap, append_only, qcap);                                                  \
+  }
+#define NRT_SKETCH_PANELS(PANELS) \
+  if (steps % 8 == 0) NRT_SKETCH_LAUNCH(PANELS, 8) else NRT_SKETCH_LAUNCH(PANELS, 4)
+  if (panels <= 1) { NRT_SKETCH_PANELS(1) }
+  else if (panels == 2) { NRT_SKETCH_PANELS(2) }
+  else if (panels == 3) { NRT_SKETCH_PANELS(3) }
+  else { NRT_SKETCH_PANELS(4) }
+#undef NRT_SKETCH_PANELS
+#undef NRT_SKETCH_LAUNCH
   return 0;
 }
 void launch_knn_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,

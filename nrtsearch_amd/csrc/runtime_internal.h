@@ -67,7 +67,7 @@ void launch_knn_row_norms(hipStream_t st, const float* vecs, int32_t dim, int64_
 int launch_knn_score(hipStream_t st, uint32_t blocks, const float* vecs, const float* vnorm2, const int32_t* ord_to_doc,
                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
                      const float* qpanel, const float* qnorm2, int32_t n_q, int32_t sim, float boost,
-                     const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap);
+                     const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only = 0);
 void launch_knn_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint32_t* topk_cnt, uint32_t k_stride, uint32_t k,
                        const uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, unsigned long long* theta,
                        uint32_t* overflow);
@@ -77,6 +77,15 @@ void launch_knn_refine_select(hipStream_t st, uint32_t n_q, uint64_t* topk, uint
                               float boost, const float* ebound, float erel, float min_score, uint32_t k_int, int32_t certify,
                               uint32_t* cert);
 void launch_knn_norm_max(hipStream_t st, const float* norm2, int64_t n, uint32_t* out_bits);
+void launch_knn_norm_min(hipStream_t st, const float* norm2, int64_t n, uint32_t* out_bits);
+void launch_knn_absmax(hipStream_t st, const float* vecs, int64_t n_elems, uint32_t* out_bits);
+size_t knn_sketch_bytes(int32_t dim, int64_t n);
+size_t knn_sketch_lds_bytes(int32_t dim, int32_t n_q);
+void launch_knn_sketch_build(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float scale, void* sketch);
+int launch_knn_sketch(hipStream_t st, uint32_t blocks, const void* sketch, const float* vnorm2, const int32_t* ord_to_doc,
+                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
+                      const float* qpanel, const float* qnorm2, const float* qscale, float inv_rows_scale, int32_t n_q, int32_t sim,
+                      float boost, const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only = 0);
 void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnorm2, int32_t dim, const float* query,
                             float qnorm2, int32_t sim, float boost, const int64_t* vec_row, const float* first_scores,
                             int32_t n, double qw, double rw, float* out_scores);
@@ -231,6 +240,9 @@ struct FieldData {
   std::vector<int32_t> h_ord_to_doc;     // host copy: docid -> row lookups of the rescore path
   int32_t dim = 0, n_vec = 0;
   float vnorm2_max = 0.f;                // largest |v|^2 of the rows
+  void* d_sketch = nullptr;              // the rows in fp16, matrix-core operand order (knn.hip); nullptr: none kept
+  float sketch_scale = 1.f;              // the power of two the rows were multiplied by before rounding
+  float absmax = 0.f, vnorm2_min = 0.f;  // largest |element|, smallest non-zero |v|^2 (the sketch's error bound)
   // rows whose doc is live under the segment's current liveDocs (what an exact vector query matches), counted on first
   // use per liveDocs version
   mutable std::atomic<int64_t> live_vec{-1};
@@ -239,7 +251,7 @@ struct FieldData {
   FieldData(const FieldData& o)
       : d_norms(o.d_norms), max_norm(o.max_norm), dict(o.dict), flat(o.flat), groups(o.groups), d_vectors(o.d_vectors),
         d_vnorm2(o.d_vnorm2), d_ord_to_doc(o.d_ord_to_doc), h_ord_to_doc(o.h_ord_to_doc), dim(o.dim), n_vec(o.n_vec),
-        vnorm2_max(o.vnorm2_max) {}
+        vnorm2_max(o.vnorm2_max), d_sketch(o.d_sketch), sketch_scale(o.sketch_scale), absmax(o.absmax), vnorm2_min(o.vnorm2_min) {}
 };
 
 }  // namespace rt
@@ -395,6 +407,7 @@ struct nrtgpu_ctx {
                         // overlapping two only stretches both (host-side planning/unpacking still overlap)
   std::mutex stats_mu;
   nrtgpu_stats stats{};
+  std::atomic<int> knn_sketch_skip[4] = {};   // per similarity: panels that go straight to the fp32 rows (the sketch did not certify lately)
   double prof[16] = {0};
   double ms_prof[16] = {0};   // the same for the items of the MaxScore route (nrtgpu_get_maxscore_profile)
   // request coalescing (nrtgpu_search_bm25_coalesced)

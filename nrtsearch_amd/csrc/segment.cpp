@@ -199,6 +199,28 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(&f.vnorm2_max, d_max, 4, hipMemcpyDeviceToHost));
+  if (!(seg->ctx->cfg.flags & NRTGPU_FLAG_NO_VECTOR_SKETCH)) {
+    // the fp16 sketch the exact search nominates from (knn.hip): the rows scaled by a power of two that puts the largest
+    // |element| at 2^14 at most, rounded to fp16, in matrix-core operand order; and what its error bound needs besides
+    uint32_t stats[2] = {0u, 0xFFFFFFFFu};   // max |element|, min non-zero |v|^2 (float bits)
+    HIP_TRY(hipMemcpy(d_max + 1, stats, 8, hipMemcpyHostToDevice));
+    launch_knn_absmax(nullptr, f.d_vectors, (int64_t)n * dim, d_max + 1);
+    launch_knn_norm_min(nullptr, f.d_vnorm2, n, d_max + 2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(stats, d_max + 1, 8, hipMemcpyDeviceToHost));
+    memcpy(&f.absmax, &stats[0], 4);
+    if (stats[1] != 0xFFFFFFFFu) memcpy(&f.vnorm2_min, &stats[1], 4);
+    if (std::isfinite(f.absmax) && std::isfinite(f.vnorm2_max)) {   // (rows with inf / NaN: the fp32 pass only)
+      int e = 0;
+      (void)std::frexp(f.absmax, &e);   // absmax < 2^e
+      f.sketch_scale = f.absmax > 0.f ? std::ldexp(1.0f, 14 - e) : 1.0f;
+      if (int rc = dev_alloc(seg, &p, knn_sketch_bytes(dim, n) + 256)) return rc;
+      f.d_sketch = p;
+      launch_knn_sketch_build(nullptr, f.d_vectors, dim, n, f.sketch_scale, f.d_sketch);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+    }
+  }
   if (ord_to_doc) {
     for (int32_t i = 0; i < n; ++i)
       if (ord_to_doc[i] < 0 || ord_to_doc[i] >= seg->max_doc || (i > 0 && ord_to_doc[i] <= ord_to_doc[i - 1]))
@@ -555,6 +577,7 @@ SegCore::~SegCore() {
     if (f.d_norms) (void)hipFree(f.d_norms);
     if (f.d_vectors) (void)hipFree(f.d_vectors);
     if (f.d_vnorm2) (void)hipFree(f.d_vnorm2);
+    if (f.d_sketch) (void)hipFree(f.d_sketch);
     if (f.d_ord_to_doc) (void)hipFree(f.d_ord_to_doc);
     for (auto& g : f.groups) {
       if (g.d_docids) (void)hipFree(g.d_docids);

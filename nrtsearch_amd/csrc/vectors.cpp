@@ -41,12 +41,14 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   Slot* slot = nullptr;
   acquire_slot(ctx, &slot);
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
-  std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+  // the whole-GPU kernels of one call at a time (gpu_mu, taken when the first panel's inputs are staged: the staging and its
+  // copy overlap the kernels of the call before)
+  std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
   hipStream_t st = slot->stream;
-  if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));   // behind the scorers enqueued last (search.cpp: enqueue_search)
   const bool timing = ctx->cfg.collect_timing != 0;
   Carver wc;
   const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_eb = wc.take(kKnnMaxQ * 4);
+  const size_t o_eb16 = wc.take(kKnnMaxQ * 4), o_qs = wc.take(kKnnMaxQ * 4);
   const size_t o_segs = wc.take((size_t)std::max(n_segs, 1) * sizeof(DVecSeg));
   const size_t o_th = wc.take(kKnnMaxQ * 8);
   const size_t o_tk = wc.take((size_t)kKnnMaxQ * ki_stride * 8), o_tc = wc.take(kKnnMaxQ * 4);
@@ -56,12 +58,16 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   const size_t oh_cnt = (size_t)kKnnMaxQ * k_stride * 8, oh_cert = oh_cnt + (o_cert - o_xc), oh_ov = oh_cnt + (o_ov - o_xc);
   if (int rc = slot->h_out.reserve(oh_ov + 64)) return rc;
+  // the panel's inputs are staged in pinned memory laid out like the workspace's head [o_q, o_th): two copies per panel, no sync
+  if (int rc = slot->h_aux.reserve(o_th)) return rc;
   char* wb = (char*)slot->d_work.p;
   char* ho = (char*)slot->h_out.p;
-  std::vector<float> qn(kKnnMaxQ), eb(kKnnMaxQ);
+  char* hs = (char*)slot->h_aux.p;
+  float *qn = (float*)(hs + o_qn), *eb = (float*)(hs + o_eb), *eb16 = (float*)(hs + o_eb16), *qsc = (float*)(hs + o_qs);
   // the leaves' vector matrices, for docid -> row on the device (the rescoring reads rows by docid)
-  std::vector<DVecSeg> hsegs((size_t)std::max(n_segs, 1));
-  double nv_max = 0.0;
+  DVecSeg* hsegs = (DVecSeg*)(hs + o_segs);
+  double nv_max = 0.0, nv_min = INFINITY, rows_unit = 0.0;   // rows_unit: the largest 1 / scale of the leaves' sketches
+  bool all_sketched = true, any_vectors = false;
   for (int si = 0; si < n_segs; ++si) {
     DVecSeg v{};
     v.doc_base = doc_bases ? doc_bases[si] : 0;
@@ -73,17 +79,21 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       v.ord_to_doc = fit->second.d_ord_to_doc;
       v.n_vec = fit->second.n_vec;
       nv_max = std::max(nv_max, (double)fit->second.vnorm2_max);
+      if (fit->second.n_vec > 0) {
+        if (!fit->second.d_sketch) all_sketched = false;
+        any_vectors = true;
+        if (fit->second.vnorm2_min > 0.f) nv_min = std::min(nv_min, (double)fit->second.vnorm2_min);
+        rows_unit = std::max(rows_unit, 1.0 / (double)fit->second.sketch_scale);
+      }
     }
     hsegs[(size_t)si] = v;
   }
-  HIP_TRY(hipMemcpyAsync(wb + o_segs, hsegs.data(), hsegs.size() * sizeof(DVecSeg), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));   // (hsegs is a stack vector)
   // |estimate - result| <= E: both are fp32 evaluations of the same length-dim sums, each within gamma = dim * 2^-24 (relative
   // to the sum of the terms' magnitudes) of the real value whatever the order; the maps to a score have slope <= 1 and add a
   // few roundings (erel).  DESIGN §4.5 derives the constants.
   const double u_fp32 = std::ldexp(1.0, -24), gam = (double)(dim + 4) * u_fp32;
   const float score_boost = knn_request ? 1.0f : boost;
-  const float erel = (float)(8.0 * u_fp32);
+  const float erel = (float)(32.0 * u_fp32);
   auto bound_of = [&](double nq) {   // e_abs of plan.h's knn_result_upper / knn_estimate_lower
     double e = 0.0;
     if (sim == 0) e = 2.0 * gam * (double)score_boost;
@@ -91,6 +101,27 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     else if (sim == 2) e = 4.5 * gam * (nq + nv_max);   // squared-distance units, no boost
     else e = 2.2 * gam * std::sqrt(nq * nv_max) * (double)score_boost;
     return std::nextafter((float)((e + 4.0 * u_fp32) * (1.0 + 1e-6)), INFINITY);
+  };
+  // The fp16 sketch (knn.hip): rows and queries rounded to 11 significant bits (relative 2^-11 each), products exact in fp32,
+  // fp32 accumulation; elements that fall under fp16's normal range (2^-14 after scaling: 2^-28 of the largest) may be flushed.
+  //   |dot16 - q.v| <= (2^-10 + 2^-22 + gamma) sum |q_i v_i|  +  |q|_1 * 2^-14 / rows' scale  +  |v|_1 * 2^-14 / query's scale
+  // with sum |q_i v_i| <= |q||v| and |v|_1 <= sqrt(dim) |v|.  Cosine divides by the row's own |v|: the first term's |v| cancels,
+  // the flush terms need the smallest non-zero |v| of the leaves.  On top: the fp32 bound above (the estimate's norms are fp32).
+  // (the query panel in fp16 and at least a small nomination queue behind it must fit the CU's 160 KB of LDS)
+  const bool sketch_ok = all_sketched && any_vectors && std::isfinite(nv_max) &&
+                         knn_sketch_lds_bytes(dim, std::min(n_queries, dim > 1280 ? 16 : kKnnMaxQ)) + 16 + 256 * 8 <= 160 * 1024;
+  auto bound16_of = [&](double nq, double q_l1, double q_unit, double e32) {
+    const double e16 = std::ldexp(1.0, -10) + std::ldexp(1.0, -22) + gam;
+    const double flush = q_l1 * std::ldexp(1.0, -14) * rows_unit + std::sqrt((double)dim * nv_max) * std::ldexp(1.0, -14) * q_unit;
+    const double e_dot = 1.01 * (e16 * std::sqrt(nq * nv_max) + flush);
+    double e = 0.0;
+    if (sim == 0) e = 0.5 * 1.01 * (e16 + (nq > 0.0 && std::isfinite(nv_min) ? flush / std::sqrt(nq * nv_min) : 0.0)) * (double)score_boost;
+    else if (sim == 1) e = 0.5 * e_dot * (double)score_boost;
+    else if (sim == 2) e = 2.0 * e_dot;
+    else e = e_dot * (double)score_boost;
+    // (+ 32 u: the kernel maps the dot product to a score with hardware rsq / rcp and a handful of fp32 roundings, scores <= 1;
+    //  MAXIMUM_INNER_PRODUCT's unbounded scores take theirs from e_rel)
+    return std::nextafter((float)((e + e32 + 32.0 * u_fp32 * (sim == 2 ? 4.0 : (double)score_boost)) * (1.0 + 1e-6)), INFINITY);
   };
   // Rows are scored in rounds with a selection in between (theta tightens from round to round).  The first round of
   // a panel gives every row a slot of the candidate list; later rounds only append rows that beat theta, so they can
@@ -105,6 +136,12 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       (void)hipStreamSynchronize(st);
       return fail(NRTGPU_ERR_TIMEOUT, "deadline passed between two passes over the rows (%d of %d queries answered)", q0, n_queries);
     }
+    // nominate from the sketch unless it failed to certify lately for this similarity (then: a few panels straight from fp32)
+    bool panel_sketch = sketch_ok;
+    if (panel_sketch && ctx->knn_sketch_skip[sim].load(std::memory_order_relaxed) > 0) {
+      ctx->knn_sketch_skip[sim].fetch_sub(1, std::memory_order_relaxed);
+      panel_sketch = false;
+    }
     for (int q = 0; q < nq; ++q) {
       float s2 = 0.f;  // squareMagnitude of the query, fp32
       const float* qv = queries + (size_t)(q0 + q) * dim;
@@ -114,16 +151,38 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       }
       qn[(size_t)q] = s2;
       eb[(size_t)q] = bound_of((double)s2);
+      float q_max = 0.f;
+      double q_l1 = 0.0;
+      for (int d = 0; d < dim; ++d) {
+        q_max = std::max(q_max, std::fabs(qv[d]));
+        q_l1 += std::fabs((double)qv[d]);
+      }
+      int e2 = 0;
+      (void)std::frexp(q_max, &e2);   // q_max < 2^e2: the scaled query's largest |element| is below 2^14
+      qsc[(size_t)q] = (q_max > 0.f && std::isfinite(q_max)) ? std::ldexp(1.0f, 14 - e2) : 1.0f;
+      eb16[(size_t)q] = bound16_of((double)s2, q_l1, 1.0 / (double)qsc[(size_t)q], (double)eb[(size_t)q]);
+      if (!std::isfinite(q_max) || !std::isfinite(eb16[(size_t)q])) panel_sketch = false;
     }
-    HIP_TRY(hipMemcpyAsync(wb + o_q, queries + (size_t)q0 * dim, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(wb + o_qn, qn.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(wb + o_eb, eb.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    memcpy(hs + o_q, queries + (size_t)q0 * dim, (size_t)nq * dim * 4);
+    HIP_TRY(hipMemcpyAsync(wb + o_q, hs + o_q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(wb + o_qn, hs + o_qn, o_th - o_qn, hipMemcpyHostToDevice, st));   // |q|^2, bounds, scales, leaf table
+    if (!gpu.owns_lock()) {
+      gpu.lock();
+      if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));   // behind the scorers enqueued last (search.cpp: enqueue_search)
+    }
     int64_t total_vec = 0, rows_scored = 0;
     size_t n_ev = 0;
     // One pass over the rows of every leaf.  nominate: the estimates' running top-k_int, theta tightening (knn_select_kernel
     // <false>); else theta stays what the certification left and every nomination is rescored into the answer (<true>).
-    auto rows_pass = [&](bool nominate, int safe) -> int {
+    int64_t sketch_launches = 0;
+    auto rows_pass = [&](bool nominate, int safe, bool sketch) -> int {
       int64_t seen = 0, round = 1 << 16;
+      // Nominating, theta tightens fast: after two selections (>= 1M rows seen) a later launch appends about k ln(rows / rows
+      // seen) keys per query, so the remaining launches run back to back (append_only) and ONE selection closes the pass.  A
+      // theta still unknown then (hardly any live row) makes those launches append every live row: the list overflows, the
+      // flag is raised and the panel is redone in bounded rounds with a selection after each.
+      int selections = 0;
+      bool pending = false;
       total_vec = 0;
       for (int si = 0; si < n_segs; ++si) {
         const nrtgpu_seg* seg = segs[si];
@@ -141,9 +200,10 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
           const int64_t rb = r;
           int64_t len = (safe || (nominate && seen == 0)) ? std::min<int64_t>(round, kKnnCap) : round;
           if (!nominate && !safe) len = f.n_vec;   // theta is fixed and tight: the whole leaf at once
-          const int64_t re = std::min<int64_t>(f.n_vec, r + len);
+          len = std::min<int64_t>(len, (int64_t)1 << 26);   // (the sketch kernel's queue entries carry row - round start in 26 bits)
+          const int64_t re = std::min<int64_t>(f.n_vec, (r + len + 15) & ~(int64_t)15);   // rounds begin on tile boundaries (16 rows)
           uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
-          if (nq > 32) blocks = std::max(16u, std::min((uint32_t)std::max(ctx->n_cus, 16), 2u * blocks) / 16u * 16u);   // paired workgroups
+          if (nq > 32 && !sketch) blocks = std::max(16u, std::min((uint32_t)std::max(ctx->n_cus, 16), 2u * blocks) / 16u * 16u);   // paired workgroups
           if (timing) {
             while (slot->round_ev.size() < n_ev + 2) {
               hipEvent_t ev = nullptr;
@@ -152,20 +212,30 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
             }
             HIP_TRY(hipEventRecord(slot->round_ev[n_ev], st));
           }
-          const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
-                                         doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
-                                         sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
-                                         (uint32_t*)(wb + o_cc), kKnnCap);
+          const bool defer = nominate && !safe && selections >= 2;
+          const int e = sketch
+              ? launch_knn_sketch(st, blocks, f.d_sketch, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re, doc_bases ? doc_bases[si] : 0,
+                                  (const float*)(wb + o_q), (const float*)(wb + o_qn), (const float*)(wb + o_qs), 1.0f / f.sketch_scale, nq,
+                                  sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
+                                  (uint32_t*)(wb + o_cc), kKnnCap, defer ? 1 : 0)
+              : launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
+                                 doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
+                                 sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
+                                 (uint32_t*)(wb + o_cc), kKnnCap, defer ? 1 : 0);
           if (e) return fail(NRTGPU_ERR_HIP, "knn_score launch: %s", hipGetErrorString((hipError_t)e));
+          sketch_launches += sketch ? 1 : 0;
           if (timing) {
             HIP_TRY(hipEventRecord(slot->round_ev[n_ev + 1], st));
             n_ev += 2;
           }
-          if (nominate)
+          if (defer) {
+            pending = true;
+          } else if (nominate) {
             launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, k_int,
                               (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
                               (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov));
-          else
+            ++selections;
+          } else
             launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
                                      (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
                                      (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim,
@@ -176,6 +246,10 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
           round = safe ? std::min<int64_t>(round * 4, kKnnCap) : std::min<int64_t>(seen * 15, (int64_t)1 << 40);
         }
       }
+      if (pending)
+        launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, k_int,
+                          (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
+                          (unsigned long long*)(wb + o_th), (uint32_t*)(wb + o_ov));
       rows_scored += seen;
       return NRTGPU_OK;
     };
@@ -192,18 +266,18 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       if (knn_request && min_score > 0.0f) {  // start theta below the lowest key whose RESULT can still reach min_score
         std::vector<uint64_t> th0((size_t)nq);
         for (int q = 0; q < nq; ++q) {
-          const float lo = (float)knn_estimate_lower(sim, (double)min_score, (double)eb[(size_t)q], (double)erel, 1.0);
+          const float lo = (float)knn_estimate_lower(sim, (double)min_score, (double)(panel_sketch ? eb16 : eb)[(size_t)q], (double)erel, 1.0);
           th0[(size_t)q] = lo > 0.0f ? pack_key(lo, 0xFFFFFFFFu) - 1ull : 0ull;
         }
         HIP_TRY(hipMemcpyAsync(wb + o_th, th0.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
       }
-      if (int rc = rows_pass(true, safe)) return rc;
+      if (int rc = rows_pass(true, safe, panel_sketch)) return rc;
       launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
                                (const uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, (unsigned long long*)(wb + o_th),
                                (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim, sim, (const float*)(wb + o_q),
-                               (const float*)(wb + o_qn), score_boost, (const float*)(wb + o_eb), erel, knn_request ? min_score : 0.0f,
-                               k_int, 1, (uint32_t*)(wb + o_cert));
+                               (const float*)(wb + o_qn), score_boost, (const float*)(wb + (panel_sketch ? o_eb16 : o_eb)), erel,
+                               knn_request ? min_score : 0.0f, k_int, 1, (uint32_t*)(wb + o_cert));
       if (int rc = fetch()) return rc;
       if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
       if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
@@ -213,12 +287,29 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     //    the bound of the k-th rescored score, and rescores all of them
     int uncertified = 0;
     for (int q = 0; q < nq; ++q) uncertified += ((const uint32_t*)(ho + oh_cert))[q] == 0u;
+    std::vector<uint64_t> th2;
+    if (uncertified) {
+      // the second pass nominates from the fp32 rows (the tight bound): a row of the answer scores >= the k-th rescored score
+      // known so far (or >= min_score while fewer than k are known); certified queries nominate nothing (theta = ~0)
+      th2.assign((size_t)nq, ~0ull);
+      const uint64_t* xk = (const uint64_t*)ho;
+      const uint32_t* xc = (const uint32_t*)(ho + oh_cnt);
+      for (int q = 0; q < nq; ++q) {
+        if (((const uint32_t*)(ho + oh_cert))[q] != 0u) continue;
+        const double base = xc[q] >= (uint32_t)k ? (double)key_score(xk[(size_t)q * k_stride + (size_t)k - 1])
+                                                 : (knn_request ? (double)min_score : 0.0);
+        const float lo = (float)knn_estimate_lower(sim, base, (double)eb[(size_t)q], (double)erel, (double)score_boost);
+        th2[(size_t)q] = lo > 0.0f ? pack_key(lo, 0xFFFFFFFFu) - 1ull : 0ull;
+      }
+      if (panel_sketch) ctx->knn_sketch_skip[sim].store(16, std::memory_order_relaxed);
+    }
     for (int safe = 0; uncertified; ++safe) {
+      HIP_TRY(hipMemcpyAsync(wb + o_th, th2.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
       for (int q = 0; q < nq; ++q)   // their answers start over (a nomination found again must not be counted twice)
         if (((const uint32_t*)(ho + oh_cert))[q] == 0u) HIP_TRY(hipMemsetAsync(wb + o_xc + (size_t)q * 4, 0, 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_cc, 0, kKnnMaxQ * 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_ov, 0, 4, st));
-      if (int rc = rows_pass(false, safe)) return rc;
+      if (int rc = rows_pass(false, safe, false)) return rc;
       if (int rc = fetch()) return rc;   // (the second pass leaves the flags as they are)
       if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
       if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
@@ -236,6 +327,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       ctx->stats.knn_score_ms += ms;
       ctx->stats.knn_rows += rows_scored;
       ctx->stats.knn_second_passes += uncertified ? 1 : 0;
+      ctx->stats.knn_sketch_launches += sketch_launches;
     }
     if (ext_keys) {   // stays in HBM: what nrtgpu_dist_knn_exact exchanges
       std::vector<uint64_t> tv((size_t)nq, (uint64_t)total_vec);

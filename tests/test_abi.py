@@ -53,7 +53,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.Term) == 24
     assert C.sizeof(_lib.Bm25Query) == 72
     assert C.sizeof(_lib.TopDocs) == 40
-    assert C.sizeof(_lib.Stats) == 144
+    assert C.sizeof(_lib.Stats) == 152
     assert C.sizeof(_lib.Diagnostics) == 56
 
 

@@ -116,6 +116,40 @@ def test_knn_768d_many_queries_and_rounds(ctx, oracle):
     g.release()
 
 
+def test_knn_sketch_and_fp32_nominations_give_the_same_bits(oracle):
+    """The pass over all rows nominates from the fp16 sketch (half the bytes) unless the context keeps none
+    (NRTGPU_FLAG_NO_VECTOR_SKETCH); the answer is the rescored, certified one either way: identical bits, and the oracle's.
+    Dimensions that are no multiple of 32 / 128 (zero-padded steps), 1 - 4 query panels, deletes, sparse ordinals."""
+    from nrtsearch_amd import _lib
+    rng = np.random.default_rng(2024)
+    for dim, n_q, k in ((48, 3, 7), (96, 17, 30), (384, 33, 64), (768, 64, 100)):
+        segs = make_segments(rng, [5000, 2600], dim, sparse_ords=True, deletes=True)
+        queries = rng.standard_normal((n_q, dim)).astype(np.float32)
+        answers = []
+        for flags in (0, _lib.NRTGPU_FLAG_NO_VECTOR_SKETCH):
+            c = api.GpuContext(device_id=0, max_batch=64, flags=flags)
+            leaves = upload(c, segs)
+            sr = api.GpuIndexSearcher(c, leaves, api.IndexStatistics())
+            per_sim = {}
+            for sim_name in ("cosine", "l2_norm", "max_inner_product"):
+                c.reset_stats()
+                per_sim[sim_name] = sr.knn_exact(3, sim_name, queries, k)
+                st = c.stats()
+                assert (st["knn_sketch_launches"] > 0) == (flags == 0), (dim, sim_name, st)
+                assert st["knn_second_passes"] == 0
+            answers.append(per_sim)
+            for g in leaves:
+                g.release()
+            c.close()
+        for sim_name, sim in (("cosine", 0), ("l2_norm", 2), ("max_inner_product", 3)):
+            for qi in range(n_q):
+                a, b = answers[0][sim_name][qi], answers[1][sim_name][qi]
+                assert a.docs.tolist() == b.docs.tolist() and a.scores.view(np.uint32).tolist() == b.scores.view(np.uint32).tolist()
+            for qi in (0, n_q - 1):
+                exp, total, _ = brute_force(oracle, sim, queries[qi], [(b_, v, o, l) for b_, v, o, l, _ in segs], k)
+                check_hits(answers[0][sim_name][qi], exp)
+
+
 def test_knn_euclidean_near_duplicates_and_large_norms(ctx, oracle):
     """|q|^2 + |v|^2 - 2 q.v cancels when rows sit close to the query and far from the origin: norms ~ 1e4, distances ~ 1e-2,
     so the matrix-core estimate of |q - v|^2 is all rounding.  The answer must still be the oracle's, bit for bit: the
