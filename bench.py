@@ -399,6 +399,9 @@ def run_c4(args):
     # turn (the library runs one call's kernels at a time; a caller's staging and unpacking overlap the other's kernels) --
     # measured: no gain in throughput (the gap between two calls is ~0.1 ms of 3.6), twice the latency.
     n_thr = max(1, args.host_threads) if (world == 1 and args.c4_callers) else 1
+    import gc
+    gc.collect()
+    gc.disable()   # the interpreter's cycle collector is not what is measured: one full collection (40-55 ms with torch loaded) otherwise lands in some step
     t0 = time.perf_counter()
     if n_thr == 1:
         for i in range(args.steps):
@@ -425,6 +428,7 @@ def run_c4(args):
         last = results["last"]
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -448,6 +452,8 @@ def run_c4(args):
         "value": round(args.steps * Q / elapsed, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(statistics.median(lat) * 1e3, 4),
         "max_latency_ms": round(max(lat) * 1e3, 4), "slowest_step": int(np.argmax(lat)),
+        # steps that took more than twice the median (step index, ms): a stall on the host or the device shows up here, not in p50
+        "latency_outliers": [(int(i_), round(l_ * 1e3, 3)) for i_, l_ in enumerate(lat) if l_ > 2.0 * statistics.median(lat)][:16],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C4: {n_all} x {dim} fp32 rows, brute-force cosine top-{k}", "n_docs": n_all, "rows_per_gpu": n, "dim": dim, "k": k,
                    "queries_per_step": Q, "host_threads": n_thr, "segments_per_gpu": len(leaves), "corpus_build_s": round(t_build, 1),
@@ -863,6 +869,9 @@ def main():
 
     run_steps(0, args.warmup, False)
     ctx.reset_stats()
+    import gc
+    gc.collect()
+    gc.disable()   # (as in run_c4: the interpreter's cycle collector is not what is measured)
     fence()
     n_thr = max(1, args.host_threads)
     import resource
@@ -872,6 +881,7 @@ def main():
     run_steps(args.warmup, args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     tc1 = thread_cpu_seconds()
     # CPUs kept busy by kind of thread: this process's main thread (N > 1: the exchange stage), the library's helper threads
