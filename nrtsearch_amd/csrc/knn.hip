@@ -7,13 +7,15 @@
 //   /root/reference/src/main/java/com/yelp/nrtsearch/server/rescore/QueryRescore.java:40-57.
 // Similarity -> score mapping: VectorFieldDef.java:77-88 / docs/field_types/vector.rst:26-35.
 //
-// knn_score_kernel: C[16 docs x 16 queries] tiles on the matrix cores with the exact-fp32 MFMA
-// (v_mfma_f32_16x16x4_f32: an fp32 fma chain, no reduced precision), two query panels.  The query
-// panel (<= 32 queries x dim) sits in LDS in MFMA-operand order; vector rows stream from HBM once per
-// batch of <= 32 queries (roofline: HBM, N * dim * 4 bytes per batch; the fp32 matrix rate equals the
-// HBM rate at 32 queries and is twice it at <= 16).
-// Float summation order differs from Lucene's (which itself depends on the JVM's SIMD width), so
-// scores carry a tolerance (tests: 1e-5 relative), docids/ranks are compared modulo that.
+// Who computes what: a pass over ALL rows only NOMINATES -- it keeps, per query, the k + max(32, k / 2) rows
+// with the best ESTIMATE of the score: knn_sketch_kernel over the fp16 sketch of the rows (2 bytes per element, <= 64 queries per
+// pass, HBM roofline: N * dim * 2 bytes), or knn_score_kernel over the fp32 rows (v_mfma_f32_16x16x4_f32, <= 32 queries per
+// workgroup, N * dim * 4 bytes; segments without a sketch, second passes).  knn_select_kernel<true> then RESCORES every nomination in
+// the oracle's order of summation (knn_score_seq: scalar, left to right, every op rounded to fp32) and CERTIFIES the answer against
+// the rows left outside with a worst-case rounding bound of the estimate; what it cannot certify goes through a second pass.
+// The answer is the oracle's docids and score bits for all four similarities (tests/test_vectors_gpu.py compares with ==).
+// The vector RESCORER (rescore_vectors_kernel, hybrid_rescore_kernel: one wave per hit, lanes striding the dimensions) keeps a
+// tolerance of 1e-5 relative against the oracle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
