@@ -403,6 +403,7 @@ struct nrtgpu_ctx {
   std::condition_variable cv;
   std::vector<std::unique_ptr<Slot>> slots;
   hipEvent_t last_turn = nullptr;   // (under gpu_mu) recorded behind the whole-GPU kernels enqueued last: the next ones wait for it ON THE DEVICE
+  hipEvent_t last_knn_turn = nullptr;   // (under gpu_mu) the same behind the exact vector search's stage enqueued last (vectors.cpp)
   std::mutex gpu_mu;    // device execution of one batch at a time: a scan kernel wants the whole GPU,
                         // overlapping two only stretches both (host-side planning/unpacking still overlap)
   std::mutex stats_mu;

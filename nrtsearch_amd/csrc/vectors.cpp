@@ -41,10 +41,24 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   Slot* slot = nullptr;
   acquire_slot(ctx, &slot);
   struct Guard { nrtgpu_ctx* c; Slot* s; ~Guard() { release_slot(c, s); } } guard{ctx, slot};
-  // the whole-GPU kernels of one call at a time (gpu_mu, taken when the first panel's inputs are staged: the staging and its
-  // copy overlap the kernels of the call before)
-  std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+  // Ordering on the device (search.cpp: enqueue_search has the BM25 side): a stage of this call -- nomination launches,
+  // selections, rescoring -- starts behind the BM25 scorers enqueued last (they want every CU's LDS) and they start behind it;
+  // but two vector searches do NOT queue behind each other: the nomination kernel streams, its workgroups are handed out as
+  // CUs come free, so a second call's launches fill the tail of this call's and run under its small selection / rescoring
+  // kernels (34 KB of LDS beside a nomination workgroup's 112).  Measured with two callers at 10 M x 768: 32 queries per call
+  // 3.21 -> 2.90 ms per step, 64: 3.61 -> 3.20.  The host lock is held for the two event operations only.
   hipStream_t st = slot->stream;
+  auto take_turn = [&]() -> int {
+    std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+    if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
+    return NRTGPU_OK;
+  };
+  auto end_turn = [&]() -> int {
+    std::lock_guard<std::mutex> gpu(ctx->gpu_mu);
+    HIP_TRY(hipEventRecord(slot->ev_turn, st));
+    ctx->last_knn_turn = slot->ev_turn;
+    return NRTGPU_OK;
+  };
   const bool timing = ctx->cfg.collect_timing != 0;
   Carver wc;
   const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_eb = wc.take(kKnnMaxQ * 4);
@@ -166,17 +180,16 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     memcpy(hs + o_q, queries + (size_t)q0 * dim, (size_t)nq * dim * 4);
     HIP_TRY(hipMemcpyAsync(wb + o_q, hs + o_q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(wb + o_qn, hs + o_qn, o_th - o_qn, hipMemcpyHostToDevice, st));   // |q|^2, bounds, scales, leaf table
-    if (!gpu.owns_lock()) {
-      gpu.lock();
-      if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));   // behind the scorers enqueued last (search.cpp: enqueue_search)
-    }
+    if (int rc = take_turn()) return rc;   // (the staging above and its copies are not part of the turn)
     int64_t total_vec = 0, rows_scored = 0;
     size_t n_ev = 0;
     // One pass over the rows of every leaf.  nominate: the estimates' running top-k_int, theta tightening (knn_select_kernel
     // <false>); else theta stays what the certification left and every nomination is rescored into the answer (<true>).
     int64_t sketch_launches = 0;
     auto rows_pass = [&](bool nominate, int safe, bool sketch) -> int {
-      int64_t seen = 0, round = 1 << 16;
+      // (rows of the first round: every row takes a slot of the list and the first selection scans them all)
+      static const int64_t kFirstRound = []() { const char* e = getenv("NRTGPU_KNN_FIRST_ROUND"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1024 && v <= (1 << 18) ? (v & ~15L) : (1 << 16)); }();
+      int64_t seen = 0, round = kFirstRound;
       // Nominating, theta tightens fast: after two selections (>= 1M rows seen) a later launch appends about k ln(rows / rows
       // seen) keys per query, so the remaining launches run back to back (append_only) and ONE selection closes the pass.  A
       // theta still unknown then (hardly any live row) makes those launches append every live row: the list overflows, the
@@ -195,7 +208,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
           if (int rc = accept_set_of(seg, filter_mask, 0, &accept)) return rc;
         // rounds never exceed the candidate capacity, so a list cannot overflow; theta tightens between rounds
         int64_t r = 0;
-        if (seen == 0) round = 1 << 16;
+        if (seen == 0) round = kFirstRound;
         while (r < f.n_vec) {
           const int64_t rb = r;
           int64_t len = (safe || (nominate && seen == 0)) ? std::min<int64_t>(round, kKnnCap) : round;
@@ -262,6 +275,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     };
     // 1. nominate, rescore the nominations, certify
     for (int safe = 0;; ++safe) {
+      if (int rc = take_turn()) return rc;
       HIP_TRY(hipMemsetAsync(wb + o_th, 0, o_cd - o_th, st));  // theta, lists, counters
       if (knn_request && min_score > 0.0f) {  // start theta below the lowest key whose RESULT can still reach min_score
         std::vector<uint64_t> th0((size_t)nq);
@@ -278,6 +292,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
                                (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim, sim, (const float*)(wb + o_q),
                                (const float*)(wb + o_qn), score_boost, (const float*)(wb + (panel_sketch ? o_eb16 : o_eb)), erel,
                                knn_request ? min_score : 0.0f, k_int, 1, (uint32_t*)(wb + o_cert));
+      if (int rc = end_turn()) return rc;
       if (int rc = fetch()) return rc;
       if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
       if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
@@ -304,12 +319,14 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       if (panel_sketch) ctx->knn_sketch_skip[sim].store(16, std::memory_order_relaxed);
     }
     for (int safe = 0; uncertified; ++safe) {
+      if (int rc = take_turn()) return rc;
       HIP_TRY(hipMemcpyAsync(wb + o_th, th2.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
       for (int q = 0; q < nq; ++q)   // their answers start over (a nomination found again must not be counted twice)
         if (((const uint32_t*)(ho + oh_cert))[q] == 0u) HIP_TRY(hipMemsetAsync(wb + o_xc + (size_t)q * 4, 0, 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_cc, 0, kKnnMaxQ * 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_ov, 0, 4, st));
       if (int rc = rows_pass(false, safe, false)) return rc;
+      if (int rc = end_turn()) return rc;
       if (int rc = fetch()) return rc;   // (the second pass leaves the flags as they are)
       if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
       if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");

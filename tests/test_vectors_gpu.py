@@ -406,3 +406,41 @@ def test_knn_search_prefilter_and_threshold(ctx, oracle):
         sr.knn_search(3, "cosine", queries[0], 10, filter=api.MaskFilter(77))   # mask not resident
     for g in leaves:
         g.release()
+
+
+def test_knn_concurrent_callers_take_turns(ctx, oracle):
+    """Several threads in nrtgpu_knn_exact at once (each call has its own workspace and stream; their kernels take turns on the
+    device, the staging and the result handling of one overlap the kernels of another): every call returns what it returns alone."""
+    import threading
+    rng = np.random.default_rng(4242)
+    dim, n = 128, 60_000
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    g = api.GpuSegment(ctx, n, 0)
+    g.add_vectors(0, vecs)
+    g.seal()
+    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+    panels = [rng.standard_normal((nq, dim)).astype(np.float32) for nq in (1, 20, 64, 7)]
+    sims = ["cosine", "l2_norm", "max_inner_product", "dot_product"]
+    alone = [sr.knn_exact(0, sims[i], panels[i], 25) for i in range(4)]
+    results, errors = {}, []
+
+    def caller(i):
+        try:
+            for rep in range(6):
+                results[(i, rep)] = sr.knn_exact(0, sims[i], panels[i], 25)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=caller, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (i, rep), got in results.items():
+        for a, b in zip(alone[i], got):
+            assert a.docs.tolist() == b.docs.tolist() and a.scores.view(np.uint32).tolist() == b.scores.view(np.uint32).tolist(), (i, rep)
+    odocs, oscores, _ = oracle.knn_exact(2, panels[1][:2], vecs, 25, n_threads=4)
+    for qi in range(2):
+        assert alone[1][qi].docs.tolist() == odocs[qi].tolist()
+    g.release()
