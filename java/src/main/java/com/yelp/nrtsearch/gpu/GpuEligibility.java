@@ -2,6 +2,7 @@ package com.yelp.nrtsearch.gpu;
 
 import static java.lang.foreign.ValueLayout.*;
 
+import com.yelp.nrtsearch.server.query.vector.ExactVectorQuery;
 import com.yelp.nrtsearch.server.search.SearchCollectorManager;
 import com.yelp.nrtsearch.server.search.SearchCutoffWrapper;
 import com.yelp.nrtsearch.server.search.SearchStatsWrapper;
@@ -45,6 +46,20 @@ final class GpuEligibility {
       TotalHits.Relation rel = out.get(JAVA_INT, 32) != 0 ? TotalHits.Relation.GREATER_THAN_OR_EQUAL_TO : TotalHits.Relation.EQUAL_TO;
       return new TopDocs(new TotalHits(out.get(JAVA_LONG, 24), rel), hits);
     }
+  }
+
+  /** A (boosted) ExactFloatVectorQuery (query/vector/ExactVectorQuery.java:179-196): field, query vector, boost. */
+  record VectorShape(String field, float[] vector, float boost) {}
+
+  /** null = not an exact float vector query. */
+  static VectorShape vectorShape(Query q) {
+    float boost = 1f;
+    while (q instanceof BoostQuery b) {
+      boost *= b.getBoost();
+      q = b.getQuery();
+    }
+    if (q instanceof ExactVectorQuery.ExactFloatVectorQuery evq) return new VectorShape(evq.getField(), evq.getQueryVector(), boost);
+    return null;
   }
 
   /** Flattens the rewritten query; null = not a shape the device takes. */

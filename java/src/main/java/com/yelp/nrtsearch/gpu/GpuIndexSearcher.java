@@ -43,6 +43,56 @@ public class GpuIndexSearcher extends MyIndexSearcher {
     this.masks = masks;
   }
 
+  /**
+   * ExactFloatVectorQuery (query/vector/ExactVectorQuery.java:137-173: every doc with a vector is scored by
+   * VectorSimilarityFunction.compare(query, vector) * boost) answered by nrtgpu_knn_exact: the k best docs with the scalar
+   * left-to-right fp32 similarity of each (DESIGN 4.3).  null = the caller's path (a leaf not resident, a field without
+   * float vectors, a dimension the device does not take).
+   */
+  private TopDocs exactVectorSearch(GpuEligibility.VectorShape vs, int k) throws IOException {
+    List<LeafReaderContext> leaves = getIndexReader().leaves();
+    int sim = -1;
+    for (LeafReaderContext leaf : leaves) {
+      org.apache.lucene.index.FieldInfo fi = leaf.reader().getFieldInfos().fieldInfo(vs.field());
+      if (fi == null || fi.getVectorDimension() == 0) continue;         // a leaf without the field: nothing to score there
+      if (fi.getVectorEncoding() != org.apache.lucene.index.VectorEncoding.FLOAT32 || fi.getVectorDimension() != vs.vector().length) return null;
+      sim = switch (fi.getVectorSimilarityFunction()) {                 // field/VectorFieldDef.java:77-88
+        case COSINE -> 0;
+        case DOT_PRODUCT -> 1;
+        case EUCLIDEAN -> 2;
+        case MAXIMUM_INNER_PRODUCT -> 3;
+      };
+    }
+    if (sim < 0 || k > NrtGpu.MAX_K) return null;
+    try (Arena a = Arena.ofConfined()) {
+      MemorySegment segs = a.allocate(ADDRESS, leaves.size()), bases = a.allocate(JAVA_INT, leaves.size());
+      for (int i = 0; i < leaves.size(); i++) {
+        MemorySegment s = store.segmentOf(leaves.get(i));
+        if (s == null) return null;
+        segs.setAtIndex(ADDRESS, i, s);
+        bases.setAtIndex(JAVA_INT, i, leaves.get(i).docBase);
+      }
+      MemorySegment q = a.allocate(JAVA_FLOAT, vs.vector().length);
+      MemorySegment.copy(vs.vector(), 0, q, JAVA_FLOAT, 0, vs.vector().length);
+      MemorySegment docs = a.allocate(JAVA_INT, k), scores = a.allocate(JAVA_FLOAT, k), out = a.allocate(NrtGpu.TOPDOCS);
+      out.set(JAVA_INT, 4, k);
+      out.set(ADDRESS, 8, docs);
+      out.set(ADDRESS, 16, scores);
+      int status = (int) NrtGpu.KNN_EXACT.invokeExact(ctx, segs, bases, leaves.size(), store.fieldId(vs.field()), sim, q, 1,
+          vs.vector().length, k, vs.boost(), out);
+      if (status == NrtGpu.ERR_UNSUPPORTED || status == NrtGpu.ERR_TIMEOUT) return null;
+      NrtGpu.check(status);
+      int n = out.get(JAVA_INT, 0);
+      ScoreDoc[] hits = new ScoreDoc[n];
+      for (int i = 0; i < n; i++) hits[i] = new ScoreDoc(docs.getAtIndex(JAVA_INT, i), scores.getAtIndex(JAVA_FLOAT, i));
+      return new TopDocs(new TotalHits(out.get(JAVA_LONG, 24), TotalHits.Relation.EQUAL_TO), hits);   // every live doc with a vector matches
+    } catch (IOException | RuntimeException e) {
+      throw e;
+    } catch (Throwable t) {
+      throw new IOException(t);
+    }
+  }
+
   /** {total_ms, plan_ms, queue_ms, device_ms, postings} of the calling thread's last device search (SearchResponse.Diagnostics). */
   public static double[] lastDiagnostics() {
     return LAST_DIAGNOSTICS.get();
@@ -54,7 +104,13 @@ public class GpuIndexSearcher extends MyIndexSearcher {
     GpuEligibility.Eligible el = GpuEligibility.relevance(manager);
     if (el == null) return super.search(query, manager);
     RelevanceCollector rc = el.collector();
-    GpuEligibility.Shape shape = GpuEligibility.shape(rewrite(query));
+    Query rewritten = rewrite(query);
+    GpuEligibility.VectorShape vs = GpuEligibility.vectorShape(rewritten);
+    if (vs != null) {
+      TopDocs top = rc.getSearchAfter() == null ? exactVectorSearch(vs, rc.getNumHitsToCollect()) : null;   // (no paging on this route)
+      return top == null ? super.search(query, manager) : (T) new SearcherResult(top, Map.of());
+    }
+    GpuEligibility.Shape shape = GpuEligibility.shape(rewritten);
     if (shape == null) return super.search(query, manager);
     List<LeafReaderContext> leaves = getIndexReader().leaves();
     try (Arena a = Arena.ofConfined()) {

@@ -246,3 +246,15 @@ def test_the_round_two_mistakes_are_what_this_test_catches():
     rcp = RefClass("com.yelp.nrtsearch.server.search.collectors.RelevanceCollector", patch_additions())
     assert 0 in rcp.arities("getTotalHitsThreshold") and 0 in rcp.arities("getSearchAfter")
     assert 0 in RefClass("com.yelp.nrtsearch.server.search.collectors.DocCollector", {}).arities("getNumHitsToCollect")
+
+
+def test_exact_vector_query_accessors():
+    """GpuEligibility.vectorShape reads the field and the query vector of an ExactFloatVectorQuery: getField() is the reference's,
+    getQueryVector() comes with the patch (the vector is a private field of the nested class)."""
+    plain = RefClass("com.yelp.nrtsearch.server.query.vector.ExactVectorQuery", {})
+    assert 0 in plain.arities("getField") and not plain.arities("getQueryVector")
+    assert re.search(r"class\s+ExactFloatVectorQuery\s+extends\s+ExactVectorQuery", plain.text)
+    patched = RefClass("com.yelp.nrtsearch.server.query.vector.ExactVectorQuery", patch_additions())
+    assert 0 in patched.arities("getQueryVector")
+    shim = open(os.path.join(SHIM, "GpuEligibility.java")).read()
+    assert "evq.getField()" in shim and "evq.getQueryVector()" in shim
