@@ -74,7 +74,7 @@ typedef struct {
 #define NRTGPU_FLAG_BLOCKING_WAIT 64    /* callers sleep until their results are there instead of spinning on the stream: for deployments
                                         * where several processes (one per GPU) with several calls in flight each share the host's CPUs.
                                         * Costs a wake-up (tens of microseconds) per call */
-#define NRTGPU_FLAG_NO_VECTOR_SKETCH 128 /* vector fields keep no fp16 copy of their rows (+50 % of the fp32 matrix): the exact search then
+#define NRTGPU_FLAG_NO_VECTOR_SKETCH 128 /* vector fields keep no fp16 copy of their rows (+50 % of the fp32 matrix, built by a field's first exact search): the exact search then
                                          * nominates from the fp32 rows (2x the bytes per pass, 32 queries per pass instead of 64).
                                          * Results are the same bits either way */
 #define NRTGPU_FLAG_NO_PRUNE 16        /* never take the MaxScore route: every query is scanned exhaustively and total_hits is

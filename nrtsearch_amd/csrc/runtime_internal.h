@@ -240,7 +240,8 @@ struct FieldData {
   std::vector<int32_t> h_ord_to_doc;     // host copy: docid -> row lookups of the rescore path
   int32_t dim = 0, n_vec = 0;
   float vnorm2_max = 0.f;                // largest |v|^2 of the rows
-  void* d_sketch = nullptr;              // the rows in fp16, matrix-core operand order (knn.hip); nullptr: none kept
+  void* d_sketch = nullptr;              // the rows in fp16, matrix-core operand order (knn.hip); nullptr: none (yet)
+  int sketch_state = -1;                 // 0: to be built by the first exact search over the field (segment.cpp: ensure_vector_sketch), 1: built, -1: never
   float sketch_scale = 1.f;              // the power of two the rows were multiplied by before rounding
   float absmax = 0.f, vnorm2_min = 0.f;  // largest |element|, smallest non-zero |v|^2 (the sketch's error bound)
   // rows whose doc is live under the segment's current liveDocs (what an exact vector query matches), counted on first
@@ -251,7 +252,8 @@ struct FieldData {
   FieldData(const FieldData& o)
       : d_norms(o.d_norms), max_norm(o.max_norm), dict(o.dict), flat(o.flat), groups(o.groups), d_vectors(o.d_vectors),
         d_vnorm2(o.d_vnorm2), d_ord_to_doc(o.d_ord_to_doc), h_ord_to_doc(o.h_ord_to_doc), dim(o.dim), n_vec(o.n_vec),
-        vnorm2_max(o.vnorm2_max), d_sketch(o.d_sketch), sketch_scale(o.sketch_scale), absmax(o.absmax), vnorm2_min(o.vnorm2_min) {}
+        vnorm2_max(o.vnorm2_max), d_sketch(o.d_sketch), sketch_state(o.sketch_state), sketch_scale(o.sketch_scale), absmax(o.absmax),
+        vnorm2_min(o.vnorm2_min) {}
 };
 
 }  // namespace rt
@@ -270,6 +272,7 @@ struct SegCore {
   // and every handle's liveDocs must be a subset of these (Lucene's deletes only accumulate)
   std::vector<uint64_t> folded_live;
   bool folded = false;
+  std::mutex sketch_mu;   // the lazy build of a vector field's sketch
   ~SegCore();
 };
 struct nrtgpu_seg {
@@ -512,6 +515,7 @@ void release_slot(nrtgpu_ctx* ctx, Slot* s);
 int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out);
 // vectors of the field whose doc is live (the hits of an exact vector query over the segment)
 int64_t live_vector_count(const nrtgpu_seg* seg, const FieldData& f);
+int ensure_vector_sketch(const nrtgpu_seg* seg, int32_t field_id);
 
 // ---- vectors (vectors.cpp) ---------------------------------------------------------------------
 // nrtgpu_knn_exact with device-resident results (per query k_stride sorted keys, count, live-vector total): the multi-GPU path

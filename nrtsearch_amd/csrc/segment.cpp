@@ -199,10 +199,11 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(&f.vnorm2_max, d_max, 4, hipMemcpyDeviceToHost));
-  if (!(seg->ctx->cfg.flags & NRTGPU_FLAG_NO_VECTOR_SKETCH)) {
-    // the fp16 sketch the exact search nominates from (knn.hip): the rows scaled by a power of two that puts the largest
-    // |element| at 2^14 at most, rounded to fp16, in matrix-core operand order; and what its error bound needs besides
-    uint32_t stats[2] = {0u, 0xFFFFFFFFu};   // max |element|, min non-zero |v|^2 (float bits)
+  {
+    // what the exact search's error bounds need besides (vectors.cpp): max |element|, min non-zero |v|^2 (float bits).  The
+    // fp16 sketch itself is built by the first exact search over the field (ensure_vector_sketch below): a field that is only
+    // ever used to RESCORE hits never pays its +50 % of HBM
+    uint32_t stats[2] = {0u, 0xFFFFFFFFu};
     HIP_TRY(hipMemcpy(d_max + 1, stats, 8, hipMemcpyHostToDevice));
     launch_knn_absmax(nullptr, f.d_vectors, (int64_t)n * dim, d_max + 1);
     launch_knn_norm_min(nullptr, f.d_vnorm2, n, d_max + 2);
@@ -210,16 +211,8 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
     HIP_TRY(hipMemcpy(stats, d_max + 1, 8, hipMemcpyDeviceToHost));
     memcpy(&f.absmax, &stats[0], 4);
     if (stats[1] != 0xFFFFFFFFu) memcpy(&f.vnorm2_min, &stats[1], 4);
-    if (std::isfinite(f.absmax) && std::isfinite(f.vnorm2_max)) {   // (rows with inf / NaN: the fp32 pass only)
-      int e = 0;
-      (void)std::frexp(f.absmax, &e);   // absmax < 2^e
-      f.sketch_scale = f.absmax > 0.f ? std::ldexp(1.0f, 14 - e) : 1.0f;
-      if (int rc = dev_alloc(seg, &p, knn_sketch_bytes(dim, n) + 256)) return rc;
-      f.d_sketch = p;
-      launch_knn_sketch_build(nullptr, f.d_vectors, dim, n, f.sketch_scale, f.d_sketch);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipDeviceSynchronize());
-    }
+    // (rows with inf / NaN, or a context that declines the sketch: the fp32 pass only)
+    f.sketch_state = ((seg->ctx->cfg.flags & NRTGPU_FLAG_NO_VECTOR_SKETCH) || !std::isfinite(f.absmax) || !std::isfinite(f.vnorm2_max)) ? -1 : 0;
   }
   if (ord_to_doc) {
     for (int32_t i = 0; i < n; ++i)
@@ -568,6 +561,35 @@ int64_t nrtgpu::rt::live_vector_count(const nrtgpu_seg* seg, const FieldData& f)
   f.live_vec.store(n, std::memory_order_release);
   f.live_vec_version.store(seg->live_version, std::memory_order_release);
   return n;
+}
+
+// The fp16 sketch of a field's rows (knn.hip): the rows scaled by a power of two that puts the largest |element| at 2^14 at
+// most, rounded to fp16, in matrix-core operand order.  Built on first use, once per segment core (its forks share it); a
+// segment that cannot have one (declined, inf / NaN rows, no HBM left) is searched from its fp32 rows.
+int nrtgpu::rt::ensure_vector_sketch(const nrtgpu_seg* seg, int32_t field_id) {
+  auto fit = seg->fields.find(field_id);
+  if (fit == seg->fields.end() || !fit->second.d_vectors || fit->second.n_vec == 0) return NRTGPU_OK;
+  FieldData& f = fit->second;
+  std::lock_guard<std::mutex> lk(seg->core->sketch_mu);
+  if (f.sketch_state != 0) return NRTGPU_OK;   // built already, or never
+  HIP_TRY(hipSetDevice(seg->core->device));
+  void* p = nullptr;
+  const size_t bytes = knn_sketch_bytes(f.dim, f.n_vec) + 256;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    f.sketch_state = -1;
+    return NRTGPU_OK;
+  }
+  int e = 0;
+  (void)std::frexp(f.absmax, &e);   // absmax < 2^e
+  f.sketch_scale = f.absmax > 0.f ? std::ldexp(1.0f, 14 - e) : 1.0f;
+  launch_knn_sketch_build(nullptr, f.d_vectors, f.dim, f.n_vec, f.sketch_scale, p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  f.d_sketch = p;
+  f.sketch_state = 1;
+  const_cast<nrtgpu_seg*>(seg)->device_bytes += (int64_t)bytes;
+  return NRTGPU_OK;
 }
 
 SegCore::~SegCore() {

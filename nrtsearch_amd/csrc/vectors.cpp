@@ -32,6 +32,8 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
       return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim, dim);
   }
+  for (int si = 0; si < n_segs; ++si)   // the fp16 sketches this search nominates from: built on a field's first exact search
+    if (int rc = ensure_vector_sketch(segs[si], field_id)) return rc;
   const uint32_t k_stride = round_up((uint32_t)k, 16);
   // The matrix-core pass NOMINATES: it keeps the k_int best rows by its estimate of the score (an fp32 fma chain in the
   // MFMA's order, |q|^2 + |v|^2 - 2 q.v for EUCLIDEAN).  The answer is the top k of the nominations rescored in the

@@ -444,3 +444,32 @@ def test_knn_concurrent_callers_take_turns(ctx, oracle):
     for qi in range(2):
         assert alone[1][qi].docs.tolist() == odocs[qi].tolist()
     g.release()
+
+
+def test_sketch_is_built_by_the_first_exact_search_only(oracle):
+    """The fp16 sketch (+50 % of the fp32 matrix) is paid by fields that are searched exactly, on their first search: uploading
+    and RESCORING leave the segment's footprint alone; a context that declines the sketch never builds it."""
+    from nrtsearch_amd import _lib
+    rng = np.random.default_rng(88)
+    n, dim = 10_000, 96            # 3 steps of 32 dimensions, padded to 4: 16 rows x 4 KiB per tile
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    for flags in (0, _lib.NRTGPU_FLAG_NO_VECTOR_SKETCH):
+        c = api.GpuContext(device_id=0, max_batch=8, flags=flags)
+        g = api.GpuSegment(c, n, 0)
+        g.add_vectors(0, vecs)
+        g.seal()
+        sr = api.GpuIndexSearcher(c, [g], api.IndexStatistics())
+        b0 = g.device_bytes
+        hits = api.TopDocs(np.arange(50, dtype=np.int32), np.ones(50, dtype=np.float32), 50, False)
+        sr.rescore_vectors(hits, 0, "cosine", q, window=10, query_weight=1.0, rescore_weight=1.0)
+        assert g.device_bytes == b0
+        got = sr.knn_exact(0, "cosine", q[None, :], 5)[0]
+        grown = g.device_bytes - b0
+        assert grown == (0 if flags else ((n + 15) // 16) * 4 * 1024 + 256), (flags, grown)
+        sr.knn_exact(0, "l2_norm", q[None, :], 5)
+        assert g.device_bytes - b0 == grown           # once
+        odocs, oscores, _ = oracle.knn_exact(0, q[None, :], vecs, 5)
+        assert got.docs.tolist() == odocs[0].tolist() and got.scores.view(np.uint32).tolist() == oscores[0].view(np.uint32).tolist()
+        g.release()
+        c.close()
