@@ -475,6 +475,26 @@ def run_c4(args):
                      "mfma_tflops": round(tflops, 2) if not sketched else None, "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS if not sketched else None,
                      "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4) if not sketched else None, "traffic": None},
     }
+    if rank == 0 and world == 1 and shard_world == 1 and args.closed_loop:
+        # queries/s AND latency under concurrent clients: C native caller threads, ONE query per call through
+        # nrtgpu_knn_exact_coalesced -- the library merges them into panels of up to 64 that share a pass over the rows
+        import ctypes as C
+
+        lg = C.CDLL(build.build_loadgen())
+        lg.loadgen_closed_loop_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        fn = C.cast(_lib.load().nrtgpu_knn_exact_coalesced, C.c_void_p)
+        qset = np.ascontiguousarray(np.concatenate(panels, axis=0)[:256], dtype=np.float32)
+        out["closed_loop"] = {"entry": "nrtgpu_knn_exact_coalesced, one query per call, native caller threads (bench/loadgen)"}
+        for c in [int(x) for x in args.closed_loop.split(",") if x.strip()]:
+            res = np.zeros(4, dtype=np.float64)
+            ctx.reset_stats()
+            rc = lg.loadgen_closed_loop_knn(fn, ctx._h, sr._segs, sr._bases, len(sr.leaves), 0, 0, qset.ctypes.data, len(qset), dim, k, c,
+                                            int(args.closed_loop_ms), res.ctypes.data)
+            st_c = ctx.stats()
+            out["closed_loop"][str(c)] = ({"error": int(rc)} if rc != 0 else
+                                          {"qps": round(res[0] / res[1], 1), "p50_ms": round(res[2], 3), "p99_ms": round(res[3], 3),
+                                           "mean_panel": round(res[0] / max(1, st_c["knn_panels"]), 1)})
     if verify_q and v_best is not None:
         # the device's top-k of the last timed panel against the fp64 ranking over all rows: scores within 2e-5 relative, a docid
         # that differs at its rank must be a near-tie of the fp64 doc there (the fp32 sums differ in their last bits)

@@ -348,6 +348,16 @@ int  nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
                       int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k,
                       float boost, nrtgpu_topdocs* out /* n_queries */);
 
+/* What a request thread calls with ONE exact vector query (ExactFloatVectorQuery, query/vector/ExactVectorQuery.java:179-196):
+ * blocks; concurrent callers over the same leaves, field, similarity and boost are merged into panels of up to 64 queries that
+ * share one pass over the rows (a pass costs the same for 1 query as for 64).  Leader / follower, no extra thread: a caller that
+ * finds the device free runs at once with whatever is waiting (a lone caller pays no batching latency); while a panel runs,
+ * arrivals accumulate and leave together when it finishes, or as a second panel in flight once 64 are waiting.  A panel is
+ * searched with the largest k of its members; each gets the first k of its own.  Results, errors and deadlines
+ * (NRTGPU_ERR_TIMEOUT for a request that expired while waiting) as nrtgpu_knn_exact with n_queries = 1. */
+int  nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                int32_t field_id, int32_t similarity, const float* query, int32_t dim, int32_t k, float boost,
+                                nrtgpu_topdocs* out);
 /* The `knn` request path (KnnQuery -> NrtKnnFloatVectorQuery, src/main/java/com/yelp/nrtsearch/server/field/
  * VectorFieldDef.java:564-594, executed at search/KnnUtils.java:56) answered exactly: the k nearest docs among
  * those the pre-filter accepts (filter_mask: a resident mask, 0 = none; liveDocs always apply), optionally only

@@ -45,11 +45,11 @@ public class GpuIndexSearcher extends MyIndexSearcher {
 
   /**
    * ExactFloatVectorQuery (query/vector/ExactVectorQuery.java:137-173: every doc with a vector is scored by
-   * VectorSimilarityFunction.compare(query, vector) * boost) answered by nrtgpu_knn_exact: the k best docs with the scalar
+   * VectorSimilarityFunction.compare(query, vector) * boost) answered by nrtgpu_knn_exact_coalesced: the k best docs with the scalar
    * left-to-right fp32 similarity of each (DESIGN 4.3).  null = the caller's path (a leaf not resident, a field without
    * float vectors, a dimension the device does not take).
    */
-  private TopDocs exactVectorSearch(GpuEligibility.VectorShape vs, int k) throws IOException {
+  private TopDocs exactVectorSearch(GpuEligibility.VectorShape vs, int k, double timeoutSec) throws IOException {
     List<LeafReaderContext> leaves = getIndexReader().leaves();
     int sim = -1;
     for (LeafReaderContext leaf : leaves) {
@@ -78,8 +78,15 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       out.set(JAVA_INT, 4, k);
       out.set(ADDRESS, 8, docs);
       out.set(ADDRESS, 16, scores);
-      int status = (int) NrtGpu.KNN_EXACT.invokeExact(ctx, segs, bases, leaves.size(), store.fieldId(vs.field()), sim, q, 1,
-          vs.vector().length, k, vs.boost(), out);
+      long deadline = timeoutSec > 0.0 ? (long) NrtGpu.MONOTONIC_NS.invokeExact() + (long) (timeoutSec * 1e9) : 0L;
+      int status;
+      try {
+        NrtGpu.SET_DEADLINE.invokeExact(deadline);
+        status = (int) NrtGpu.KNN_EXACT1.invokeExact(ctx, segs, bases, leaves.size(), store.fieldId(vs.field()), sim, q,
+            vs.vector().length, k, vs.boost(), out);                       // blocks; merged with concurrent callers inside
+      } finally {
+        NrtGpu.SET_DEADLINE.invokeExact(0L);
+      }
       if (status == NrtGpu.ERR_UNSUPPORTED || status == NrtGpu.ERR_TIMEOUT) return null;
       NrtGpu.check(status);
       int n = out.get(JAVA_INT, 0);
@@ -107,7 +114,7 @@ public class GpuIndexSearcher extends MyIndexSearcher {
     Query rewritten = rewrite(query);
     GpuEligibility.VectorShape vs = GpuEligibility.vectorShape(rewritten);
     if (vs != null) {
-      TopDocs top = rc.getSearchAfter() == null ? exactVectorSearch(vs, rc.getNumHitsToCollect()) : null;   // (no paging on this route)
+      TopDocs top = rc.getSearchAfter() == null ? exactVectorSearch(vs, rc.getNumHitsToCollect(), el.timeoutSec()) : null;   // (no paging on this route)
       return top == null ? super.search(query, manager) : (T) new SearcherResult(top, Map.of());
     }
     GpuEligibility.Shape shape = GpuEligibility.shape(rewritten);

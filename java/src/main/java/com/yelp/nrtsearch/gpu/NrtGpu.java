@@ -78,9 +78,12 @@ final class NrtGpu {
       h("nrtgpu_search_bm25_coalesced", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS));
   static final MethodHandle SEARCH_BATCH =
       h("nrtgpu_search_bm25_batch", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
-  /** ExactVectorQuery: every doc with a vector scored, the k best (the oracle-order fp32 similarity of each hit). */
-  static final MethodHandle KNN_EXACT = h("nrtgpu_knn_exact", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
-      JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, ADDRESS));
+  /**
+   * ExactVectorQuery: every doc with a vector scored, the k best (the oracle-order fp32 similarity of each hit).  One query per
+   * call, blocks; concurrent request threads are merged into panels of up to 64 queries that share a pass over the rows.
+   */
+  static final MethodHandle KNN_EXACT1 = h("nrtgpu_knn_exact_coalesced", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
+      JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_FLOAT, ADDRESS));
   static final MethodHandle KNN_SEARCH = h("nrtgpu_knn_search", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
       JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_INT, JAVA_FLOAT, ADDRESS));
   static final MethodHandle RESCORE = h("nrtgpu_rescore_vectors", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "nrtgpu_search_bm25", "nrtgpu_search_bm25_batch", "nrtgpu_search_bm25_batch_device",
     "nrtgpu_search_bm25_batch_device_epoch", "nrtgpu_exchange_open", "nrtgpu_exchange_close",
     "nrtgpu_search_bm25_coalesced", "nrtgpu_set_coalescing", "nrtgpu_query_supported",
-    "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_knn_search", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
+    "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_knn_exact_coalesced", "nrtgpu_knn_search", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
     "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile", "nrtgpu_set_slicing",
@@ -137,6 +137,8 @@ def load() -> C.CDLL:
     L.nrtgpu_exchange_close.restype = None
     L.nrtgpu_merge_topk_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, C.POINTER(TopDocs)]
     L.nrtgpu_knn_exact.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, f32, C.POINTER(TopDocs)]
+    L.nrtgpu_knn_exact_coalesced.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, f32, C.POINTER(TopDocs)]
+    L.nrtgpu_knn_exact_coalesced.restype = i32
     L.nrtgpu_knn_search.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, f32, i32, f32, C.POINTER(TopDocs)]
     L.nrtgpu_rescore_vectors.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, f32, vp, vp, i32, C.c_double, C.c_double, i32,
                                          C.POINTER(TopDocs)]

@@ -575,6 +575,23 @@ class GpuIndexSearcher:
         return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
                         bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
 
+    def knn_exact_coalesced(self, field: int, similarity: str, query: np.ndarray, k: int, boost: float = 1.0) -> TopDocs:
+        """What a request thread calls with ONE exact vector query: concurrent callers are merged into panels of up to 64 queries
+        that share a pass over the rows (nrtgpu_knn_exact_coalesced)."""
+        query = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if similarity == "normalized_cosine":
+            query = np.ascontiguousarray(query / np.linalg.norm(query).astype(np.float32), dtype=np.float32)
+        out = _lib.TopDocs()
+        docs = np.zeros(k, dtype=np.int32)
+        scores = np.zeros(k, dtype=np.float32)
+        out.capacity = k
+        out.docs = docs.ctypes.data_as(C.POINTER(C.c_int32))
+        out.scores = scores.ctypes.data_as(C.POINTER(C.c_float))
+        _lib.check(_lib.load().nrtgpu_knn_exact_coalesced(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
+                                                          self.SIMILARITY[similarity], query.ctypes.data, int(query.shape[0]), int(k),
+                                                          C.c_float(boost), C.byref(out)))
+        return TopDocs(docs[: out.n_hits].copy(), scores[: out.n_hits].copy(), int(out.total_hits), bool(out.total_hits_is_lower_bound))
+
     def knn_search(self, field: int, similarity: str, queries: np.ndarray, k: int, boost: float = 1.0,
                    filter: Optional[MaskFilter] = None, min_score: float = 0.0) -> List[TopDocs]:
         """The `knn` request path (KnnQuery with filter and similarity threshold) answered by exact search."""

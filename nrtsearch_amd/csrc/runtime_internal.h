@@ -423,6 +423,11 @@ struct nrtgpu_ctx {
   int co_inflight_queries = 0;                // ... and how many queries they hold
   int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
   int32_t co_linger_us = 150;
+  // the same for exact vector searches (nrtgpu_knn_exact_coalesced, vectors.cpp)
+  std::mutex kco_mu;
+  std::vector<struct KnnCoRequest*> kco_pending;
+  struct KnnCoRequest* kco_leader = nullptr;   // the caller that will run the next panel
+  int kco_inflight = 0;                        // panels executing right now (at most two)
   // MyIndexSearcher.SlicingParams of the searcher this context serves (nrtgpu_set_slicing)
   std::atomic<int32_t> slice_max_docs{250000}, slice_max_segments{5}, virtual_shards{1};
   std::unique_ptr<nrtgpu::rt::WorkPool> pool;   // helper threads of the host side (planning, unpacking results)

@@ -399,6 +399,141 @@ extern "C" int nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, 
   return knn_impl(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, false, 0, 0.0f, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Request coalescing for exact vector searches (cf. search.cpp: nrtgpu_search_bm25_coalesced)
+// ------------------------------------------------------------------------------------------------
+struct KnnCoRequest {
+  const nrtgpu_seg* const* segs;
+  const int32_t* doc_bases;
+  int32_t n_segs, field_id, sim, dim, k;
+  float boost;
+  const float* query;
+  nrtgpu_topdocs* out;
+  int64_t deadline_ns = 0;
+  int rc = 0;
+  bool done = false, lead = false;
+  std::string err;
+  std::mutex m;   // (every caller sleeps on its own mutex + condition variable: no convoy on the coalescer's lock)
+  std::condition_variable cv;
+};
+
+static bool knn_co_compatible(const KnnCoRequest* a, const KnnCoRequest* b) {
+  if (a->n_segs != b->n_segs || a->field_id != b->field_id || a->sim != b->sim || a->dim != b->dim || a->boost != b->boost) return false;
+  if (a->n_segs && memcmp(a->segs, b->segs, (size_t)a->n_segs * sizeof(void*)) != 0) return false;
+  if ((a->doc_bases == nullptr) != (b->doc_bases == nullptr)) return false;
+  return !a->doc_bases || memcmp(a->doc_bases, b->doc_bases, (size_t)a->n_segs * 4) == 0;
+}
+
+extern "C" int nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                          int32_t field_id, int32_t sim, const float* query, int32_t dim, int32_t k, float boost,
+                                          nrtgpu_topdocs* out) {
+  if (!ctx || !query || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  // (what would fail the panel must fail this request alone)
+  if (k <= 0 || dim <= 0 || sim < 0 || sim > 3 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
+  if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
+  if (dim % 16 != 0 || dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 2048)", dim);
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si] || !segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
+      return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim, dim);
+  }
+  NRT_CHECK_DEADLINE("before the request was queued");
+  KnnCoRequest me{segs, doc_bases, n_segs, field_id, sim, dim, k, boost, query, out};
+  me.deadline_ns = g_deadline_ns;
+  std::vector<KnnCoRequest*> batch;
+  {
+    std::unique_lock<std::mutex> lk(ctx->kco_mu);
+    ctx->kco_pending.push_back(&me);
+    if (ctx->kco_leader) {   // follower: the leader (or a later one) takes this request
+      if (ctx->kco_pending.size() >= (size_t)kKnnMaxQ) ctx->kco_leader->cv.notify_one();
+      lk.unlock();
+      {
+        std::unique_lock<std::mutex> mine(me.m);
+        me.cv.wait(mine, [&] { return me.done || me.lead; });
+      }
+      if (me.done) {
+        if (me.rc != 0) g_last_error = me.err;
+        return me.rc;
+      }
+      lk.lock();   // promoted: continue as the leader
+    } else {
+      ctx->kco_leader = &me;
+    }
+    // leader: leave at once when the device is free; else when the running panel finishes, or -- as a second panel in flight,
+    // whose launches fill the tails of the first one's -- as soon as a whole panel is waiting
+    while (!(ctx->kco_inflight == 0 || (ctx->kco_inflight == 1 && ctx->kco_pending.size() >= (size_t)kKnnMaxQ))) me.cv.wait(lk);
+    std::vector<KnnCoRequest*> rest, expired;
+    batch.push_back(&me);
+    for (KnnCoRequest* r : ctx->kco_pending) {
+      if (r == &me) continue;
+      if (deadline_passed(r->deadline_ns)) expired.push_back(r);
+      else if (batch.size() < (size_t)kKnnMaxQ && knn_co_compatible(&me, r)) batch.push_back(r);
+      else rest.push_back(r);
+    }
+    for (KnnCoRequest* r : expired) {
+      std::lock_guard<std::mutex> theirs(r->m);
+      r->rc = NRTGPU_ERR_TIMEOUT;
+      r->err = "deadline passed while the request waited for a panel";
+      r->done = true;
+      r->cv.notify_one();
+    }
+    ctx->kco_pending.swap(rest);
+    ctx->kco_leader = nullptr;
+    if (!ctx->kco_pending.empty()) {   // hand the lead to the oldest request left behind
+      KnnCoRequest* next = ctx->kco_pending.front();
+      ctx->kco_leader = next;
+      std::lock_guard<std::mutex> theirs(next->m);
+      next->lead = true;
+      next->cv.notify_one();
+    }
+    ctx->kco_inflight++;
+  }
+  // the panel, outside the lock: the members' queries side by side, the largest k; every member's buffers take its own k
+  int32_t kmax = 0;
+  for (KnnCoRequest* r : batch) kmax = std::max(kmax, r->k);
+  std::vector<float> qs(batch.size() * (size_t)dim);
+  std::vector<nrtgpu_topdocs> outs(batch.size());
+  for (size_t i = 0; i < batch.size(); ++i) {
+    memcpy(qs.data() + i * (size_t)dim, batch[i]->query, (size_t)dim * 4);
+    outs[i] = *batch[i]->out;
+    const int32_t cap = outs[i].capacity > 0 ? outs[i].capacity : batch[i]->k;
+    outs[i].capacity = std::min(cap, batch[i]->k);
+  }
+  int rc;
+  {
+    // (a panel of several requests does not run under its leader's deadline: its mates have not expired)
+    struct DeadlineScope {
+      int64_t saved;
+      explicit DeadlineScope(bool clear) : saved(g_deadline_ns) { if (clear) g_deadline_ns = 0; }
+      ~DeadlineScope() { g_deadline_ns = saved; }
+    } deadline_scope(batch.size() > 1);
+    rc = knn_impl(ctx, segs, doc_bases, n_segs, field_id, sim, qs.data(), (int32_t)batch.size(), dim, kmax, boost, false, 0, 0.0f, outs.data());
+  }
+  const std::string err = rc ? g_last_error : std::string();
+  for (size_t i = 0; i < batch.size(); ++i) {
+    KnnCoRequest* r = batch[i];
+    if (rc == 0) {
+      const int32_t cap = r->out->capacity;
+      *r->out = outs[i];
+      r->out->capacity = cap;
+    }
+    if (r == &me) continue;
+    std::lock_guard<std::mutex> theirs(r->m);   // (the woken caller cannot return -- and free its request -- before we are done with it)
+    r->rc = rc;
+    if (rc != 0) r->err = err;
+    r->done = true;
+    r->cv.notify_one();
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->kco_mu);
+    ctx->kco_inflight--;
+    if (ctx->kco_leader) ctx->kco_leader->cv.notify_one();   // a leader may be waiting for the device
+  }
+  if (rc != 0) g_last_error = err;
+  return rc;
+}
+
 extern "C" int nrtgpu_knn_search(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                  int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
                                  int32_t k, float boost, int32_t filter_mask, float min_score, nrtgpu_topdocs* out) {

@@ -473,3 +473,53 @@ def test_sketch_is_built_by_the_first_exact_search_only(oracle):
         assert got.docs.tolist() == odocs[0].tolist() and got.scores.view(np.uint32).tolist() == oscores[0].view(np.uint32).tolist()
         g.release()
         c.close()
+
+
+def test_knn_coalesced_callers_share_passes(oracle):
+    """nrtgpu_knn_exact_coalesced: what a request thread calls with ONE query.  48 concurrent callers with their own queries and
+    their own k (two similarities: requests that cannot share a panel) get exactly what nrtgpu_knn_exact gives each of them alone,
+    from fewer passes over the rows than there were calls; a lone caller runs at once."""
+    import threading
+    rng = np.random.default_rng(515)
+    dim, n = 64, 40_000
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    c = api.GpuContext(device_id=0, max_batch=64)
+    g = api.GpuSegment(c, n, 0)
+    g.add_vectors(0, vecs)
+    g.seal()
+    sr = api.GpuIndexSearcher(c, [g], api.IndexStatistics())
+    n_callers, reps = 48, 5
+    queries = rng.standard_normal((n_callers, dim)).astype(np.float32)
+    ks = [int(x) for x in rng.choice([1, 10, 37, 100], size=n_callers)]
+    sims = ["cosine" if i % 3 else "l2_norm" for i in range(n_callers)]
+    alone = [sr.knn_exact(0, sims[i], queries[i][None, :], ks[i])[0] for i in range(n_callers)]
+    lone = sr.knn_exact_coalesced(0, "cosine", queries[1], ks[1])
+    assert lone.docs.tolist() == alone[1].docs.tolist() and lone.scores.view(np.uint32).tolist() == alone[1].scores.view(np.uint32).tolist()
+    c.reset_stats()
+    results, errors = {}, []
+    gate = threading.Barrier(n_callers)
+
+    def caller(i):
+        try:
+            gate.wait()
+            for rep in range(reps):
+                results[(i, rep)] = sr.knn_exact_coalesced(0, sims[i], queries[i], ks[i])
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=caller, args=(i,)) for i in range(n_callers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (i, rep), got in results.items():
+        assert got.docs.tolist() == alone[i].docs.tolist(), (i, rep)
+        assert got.scores.view(np.uint32).tolist() == alone[i].scores.view(np.uint32).tolist(), (i, rep)
+        assert got.total_hits == n
+    assert c.stats()["knn_panels"] < n_callers * reps // 3      # merged: far fewer passes than calls
+    with pytest.raises(api.NrtGpuError) as e:
+        sr.knn_exact_coalesced(0, "cosine", np.ones(24, np.float32), 5)      # dimension the device does not take: this request alone
+    assert e.value.code in (-1, -4)
+    g.release()
+    c.close()
