@@ -384,6 +384,24 @@ __global__ __launch_bounds__(256) void knn_sketch_build_kernel(const float* __re
   sketch[piece] = h;
 }
 
+// The query panel in the sketch kernel's B-operand order, once per panel (every launch of the pass and each of its 256 workgroups
+// then copies it into LDS with 16-byte loads instead of converting it again from the fp32 panel with scalar ones):
+//   out[(s * P + p) * 64 + l] = q[(l & 15) + 16p][32s + 8(l >> 4) .. +7] * qscale, rounded to fp16.
+__global__ __launch_bounds__(256) void knn_panel_fp16_kernel(const float* __restrict__ qpanel, const float* __restrict__ qscale, int32_t dim,
+                                                            int32_t steps, int32_t P, int32_t n_q, f16x8* __restrict__ out) {
+  const int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= steps * P * 64) return;
+  const int32_t l = i & 63, p = (i >> 6) % P, sidx = (i >> 6) / P;
+  const int32_t q = (l & 15) + 16 * p, k0 = 32 * sidx + 8 * (l >> 4);
+  f16x8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int32_t k = k0 + e;
+    h[e] = (_Float16)((q < n_q && k < dim) ? qpanel[(int64_t)q * dim + k] * qscale[q] : 0.0f);
+  }
+  out[i] = h;
+}
+
 // The ring of row pieces is driven by hand: the requests are inline asm (the compiler's waitcnt insertion does not see them),
 // and before slot i is consumed the wave waits until at most D - 1 requests are outstanding -- exactly the ones issued after slot
 // i's.  Left to the compiler the loop either drained the ring at every group of D pieces (vmcnt(0) at the loop header) or copied
@@ -418,7 +436,7 @@ template <int P, int D>
 __global__ __launch_bounds__(kKnnThreads, 1)
 void knn_sketch_kernel(const f16x8* __restrict__ sketch, int32_t steps, const float* __restrict__ vnorm2,
                        const int32_t* __restrict__ ord_to_doc, const uint64_t* __restrict__ live_bits, int32_t dim,
-                       int64_t row_begin, int64_t row_end, int32_t doc_base, const float* __restrict__ qpanel,
+                       int64_t row_begin, int64_t row_end, int32_t doc_base, const f16x8* __restrict__ panel16,
                        const float* __restrict__ qnorm2, const float* __restrict__ qscale, float inv_rows_scale,
                        int32_t n_q, int32_t sim, float boost, const unsigned long long* __restrict__ theta,
                        uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt, uint32_t cap, int32_t append_only,
@@ -434,17 +452,7 @@ void knn_sketch_kernel(const f16x8* __restrict__ sketch, int32_t steps, const fl
   uint64_t* const q_e = (uint64_t*)(smem + (size_t)steps * P * 1024 + 16);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) *q_n = 0u;
-  for (int32_t i = (int32_t)tid; i < steps * P * 64; i += kKnnThreads) {
-    const int32_t l = i & 63, p = (i >> 6) % P, sidx = (i >> 6) / P;
-    const int32_t q = (l & 15) + 16 * p, k0 = 32 * sidx + 8 * (l >> 4);
-    f16x8 h;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int32_t k = k0 + e;
-      h[e] = (_Float16)((q < n_q && k < dim) ? qpanel[(int64_t)q * dim + k] * qscale[q] : 0.0f);
-    }
-    qs[i] = h;
-  }
+  for (int32_t i = (int32_t)tid; i < steps * P * 64; i += kKnnThreads) qs[i] = panel16[i];   // (knn_panel_fp16_kernel's layout)
   __syncthreads();
   const uint32_t j = lane & 15u, kk = lane >> 4;
   float nq[P], th_hi[P], dsc[P];
@@ -863,10 +871,15 @@ void launch_knn_sketch_build(hipStream_t st, const float* vecs, int32_t dim, int
   const int64_t pieces = ((n + 15) >> 4) * steps * 64;
   hipLaunchKernelGGL(knn_sketch_build_kernel, dim3((uint32_t)((pieces + 255) / 256)), dim3(256), 0, st, vecs, dim, n, steps, scale, (f16x8*)sketch);
 }
+void launch_knn_panel_fp16(hipStream_t st, const float* qpanel, const float* qscale, int32_t dim, int32_t n_q, void* panel16) {
+  const int32_t steps = knn_sketch_steps(dim), panels = (n_q + 15) >> 4, pieces = steps * panels * 64;
+  hipLaunchKernelGGL(knn_panel_fp16_kernel, dim3((uint32_t)((pieces + 255) / 256)), dim3(256), 0, st, qpanel, qscale, dim, steps, panels, n_q,
+                     (f16x8*)panel16);
+}
 size_t knn_sketch_lds_bytes(int32_t dim, int32_t n_q) { return (size_t)knn_sketch_steps(dim) * (size_t)((n_q + 15) >> 4) * 1024; }
 int launch_knn_sketch(hipStream_t st, uint32_t blocks, const void* sketch, const float* vnorm2, const int32_t* ord_to_doc,
                       const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
-                      const float* qpanel, const float* qnorm2, const float* qscale, float inv_rows_scale, int32_t n_q, int32_t sim,
+                      const void* panel16, const float* qnorm2, const float* qscale, float inv_rows_scale, int32_t n_q, int32_t sim,
                       float boost, const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only) {
   if (row_end <= row_begin) return 0;
   const int32_t steps = knn_sketch_steps(dim), panels = (n_q + 15) >> 4;
@@ -880,7 +893,8 @@ int launch_knn_sketch(hipStream_t st, uint32_t blocks, const void* sketch, const
                                        (int)lds);                                                                                   \
     if (e != hipSuccess) return (int)e;                                                                                             \
     hipLaunchKernelGGL((knn_sketch_kernel<PANELS, DEPTH>), dim3(blocks), dim3(kKnnThreads), lds, st, (const f16x8*)sketch, steps,   \
-                       vnorm2, ord_to_doc, live_bits, dim, row_begin, row_end, doc_base, qpanel, qnorm2, qscale, inv_rows_scale, n_q, \
+                       vnorm2, ord_to_doc, live_bits, dim, row_begin, row_end, doc_base, (const f16x8*)panel16, qnorm2, qscale,       \
+                       inv_rows_scale, n_q,                                                                                        \
                        sim, boost, theta, cand, cand_cnt, cap, append_only, qcap);                                                  \
   }
 #define NRT_SKETCH_PANELS(PANELS) \

@@ -70,6 +70,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   const size_t o_tk = wc.take((size_t)kKnnMaxQ * ki_stride * 8), o_tc = wc.take(kKnnMaxQ * 4);
   const size_t o_cc = wc.take(kKnnMaxQ * 4), o_xk = wc.take((size_t)kKnnMaxQ * k_stride * 8);
   const size_t o_xc = wc.take(kKnnMaxQ * 4), o_cert = wc.take(kKnnMaxQ * 4), o_ov = wc.take(64);   // (fetched in one copy)
+  const size_t o_p16 = wc.take(160 * 1024);   // the panel in fp16, the sketch kernel's operand order (knn_panel_fp16_kernel)
   const size_t o_cd = wc.take((size_t)kKnnMaxQ * kKnnCap * 8);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   const size_t oh_cnt = (size_t)kKnnMaxQ * k_stride * 8, oh_cert = oh_cnt + (o_cert - o_xc), oh_ov = oh_cnt + (o_ov - o_xc);
@@ -230,7 +231,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
           const bool defer = nominate && !safe && selections >= 2;
           const int e = sketch
               ? launch_knn_sketch(st, blocks, f.d_sketch, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re, doc_bases ? doc_bases[si] : 0,
-                                  (const float*)(wb + o_q), (const float*)(wb + o_qn), (const float*)(wb + o_qs), 1.0f / f.sketch_scale, nq,
+                                  (const void*)(wb + o_p16), (const float*)(wb + o_qn), (const float*)(wb + o_qs), 1.0f / f.sketch_scale, nq,
                                   sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
                                   (uint32_t*)(wb + o_cc), kKnnCap, defer ? 1 : 0)
               : launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
@@ -288,6 +289,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         HIP_TRY(hipMemcpyAsync(wb + o_th, th0.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
       }
+      if (panel_sketch) launch_knn_panel_fp16(st, (const float*)(wb + o_q), (const float*)(wb + o_qs), dim, nq, wb + o_p16);
       if (int rc = rows_pass(true, safe, panel_sketch)) return rc;
       launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
                                (const uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, (unsigned long long*)(wb + o_th),
