@@ -121,14 +121,15 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   };
   // The fp16 sketch (knn.hip): rows and queries rounded to 11 significant bits (relative 2^-11 each), products exact in fp32,
   // fp32 accumulation; elements that fall under fp16's normal range (2^-14 after scaling: 2^-28 of the largest) may be flushed.
-  //   |dot16 - q.v| <= (2^-10 + 2^-22 + gamma) sum |q_i v_i|  +  |q|_1 * 2^-14 / rows' scale  +  |v|_1 * 2^-14 / query's scale
+  //   |dot16 - q.v| <= (2^-10 + 2^-22 + 4 gamma) sum |q_i v_i|  +  |q|_1 * 2^-14 / rows' scale  +  |v|_1 * 2^-14 / query's scale
   // with sum |q_i v_i| <= |q||v| and |v|_1 <= sqrt(dim) |v|.  Cosine divides by the row's own |v|: the first term's |v| cancels,
   // the flush terms need the smallest non-zero |v| of the leaves.  On top: the fp32 bound above (the estimate's norms are fp32).
   // (the query panel in fp16 and at least a small nomination queue behind it must fit the CU's 160 KB of LDS)
   const bool sketch_ok = all_sketched && any_vectors && std::isfinite(nv_max) &&
                          knn_sketch_lds_bytes(dim, std::min(n_queries, dim > 1280 ? 16 : kKnnMaxQ)) + 16 + 256 * 8 <= 160 * 1024;
   auto bound16_of = [&](double nq, double q_l1, double q_unit, double e32) {
-    const double e16 = std::ldexp(1.0, -10) + std::ldexp(1.0, -22) + gam;
+    // (4 gamma for the accumulation: the matrix cores' internal summation tree is not specified to round to nearest at every node)
+    const double e16 = std::ldexp(1.0, -10) + std::ldexp(1.0, -22) + 4.0 * gam;
     const double flush = q_l1 * std::ldexp(1.0, -14) * rows_unit + std::sqrt((double)dim * nv_max) * std::ldexp(1.0, -14) * q_unit;
     const double e_dot = 1.01 * (e16 * std::sqrt(nq * nv_max) + flush);
     double e = 0.0;
