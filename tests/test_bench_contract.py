@@ -68,3 +68,33 @@ def test_committed_bench_line_has_the_contract_keys():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_committed_c4_line_keeps_the_contract_and_its_roofline_arithmetic():
+    """The exact-kNN line (bench.py --workload C4): the contract keys; throughput = queries per step / step time; the roofline
+    fraction is the PHYSICAL one (the fp16 sketch's bytes the nomination kernel streams), the algorithmic fp32 bytes of SURVEY 8d
+    stand beside it as effective_*; the answer was verified against fp64 over every row and against the CPU port."""
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_c4_q32.json")))
+    assert lines
+    d = _line(lines[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    c, r = d["config"], d["roofline"]
+    assert d["dtype"] == "f32" and d["unit"] == "queries/s" and "workload" in c and "model" not in c
+    assert abs(d["value"] - c["queries_per_step"] / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if r["kernel"] == "knn_sketch_kernel":
+        rows, dim = c["rows_per_gpu"], c["dim"]
+        steps16 = ((dim + 31) // 32 + 3) // 4 * 4
+        assert r["effective"] is True and r["streamed_bytes_per_launch"] == rows * steps16 * 64
+        assert r["algorithmic_bytes_per_launch"] == rows * dim * 4
+        assert abs(r["achieved"] - r["streamed_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+        assert abs(r["effective_achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+        assert r["frac"] < 1.0 < r["effective_frac"]
+    assert d["verify"]["agrees_with_fp64"] is True and d["verify"]["rows"] == c["rows_per_gpu"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["agrees_with_device"] is True and cb["value"] > 0
+    cl = d.get("closed_loop")
+    if cl:
+        assert "nrtgpu_knn_exact_coalesced" in cl["entry"] and cl["64"]["qps"] > 10 * cl["1"]["qps"] / 2
