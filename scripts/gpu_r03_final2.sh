@@ -14,20 +14,21 @@ timeout 150 python bench.py 2>$O/bench.err | tee $O/bench_line.json | show c3
 timeout 60 python bench.py --no-cpu-baseline --closed-loop "" --no-prune --steps 60 2>/dev/null | tee $O/bench_line_no_prune.json | show c3_noprune
 timeout 60 python bench.py --no-cpu-baseline --closed-loop "" --packed 2>/dev/null | tee $O/bench_c3_packed.json | show c3_packed
 timeout 60 python bench.py --no-cpu-baseline --closed-loop "" --workload C2 2>/dev/null | tee $O/bench_c2.json | show c2
-timeout 200 python bench.py --workload C4 --knn-queries 32 --steps 40 --warmup 3 2>$O/bench_c4.err | tee $O/bench_c4_q32.json | show c4_q32
+timeout 300 python bench.py --workload C4 --knn-queries 32 --steps 40 --warmup 3 --closed-loop "1,8,64,512" 2>$O/bench_c4.err | tee $O/bench_c4_q32.json | show c4_q32
 for q in 1 64; do
-  timeout 200 python bench.py --workload C4 --knn-queries $q --steps 40 --warmup 3 --no-cpu-baseline 2>/dev/null | tee $O/bench_c4_q$q.json | show c4_q$q
+  timeout 200 python bench.py --workload C4 --knn-queries $q --steps $([ $q = 1 ] && echo 120 || echo 40) --warmup 3 --no-cpu-baseline --closed-loop "" 2>/dev/null | tee $O/bench_c4_q$q.json | show c4_q$q
 done
-timeout 200 python bench.py --workload C4 --knn-queries 32 --steps 20 --warmup 3 --no-cpu-baseline --no-sketch 2>/dev/null | tee $O/bench_c4_q32_no_sketch.json | show c4_q32_fp32
+timeout 200 python bench.py --workload C4 --knn-queries 32 --steps 20 --warmup 3 --no-cpu-baseline --closed-loop "" --no-sketch 2>/dev/null | tee $O/bench_c4_q32_no_sketch.json | show c4_q32_fp32
 timeout 100 python bench.py --workload C4 --emulate-world 8 --knn-queries 32 --steps 40 --warmup 3 --no-cpu-baseline --no-verify 2>/dev/null | tee $O/bench_c4_emulate8.json | show c4_emu8
+for q in 1 32 64; do timeout 200 python bench.py --workload C4 --knn-queries $q --steps 40 --warmup 4 --no-cpu-baseline --no-verify --closed-loop "" --c4-callers 2>/dev/null | tee $O/bench_c4_q${q}_two_callers.json | show c4_q${q}_two; done
 cd /tmp
 rm -rf /tmp/prof; timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r03 --output-format csv -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --warmup 2 --steps 20 > /tmp/prof_bench.log 2>&1
 find /tmp/prof -name "*kernel_stats*" -exec cp {} $O/r03_kernel_stats.csv \;
 head -4 $O/r03_kernel_stats.csv | cut -c1-60,200-420
-rm -rf /tmp/prof4; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof4 -o c4 --output-format csv -- python $ROOT/bench.py --workload C4 --knn-queries 32 --steps 10 --warmup 2 --no-cpu-baseline --no-verify > /tmp/prof_c4.log 2>&1
+rm -rf /tmp/prof4; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof4 -o c4 --output-format csv -- python $ROOT/bench.py --workload C4 --knn-queries 32 --steps 10 --warmup 2 --no-cpu-baseline --no-verify --closed-loop "" > /tmp/prof_c4.log 2>&1
 find /tmp/prof4 -name "*kernel_stats*" -exec cp {} $O/r03_c4_kernel_stats.csv \;
 grep "knn_" $O/r03_c4_kernel_stats.csv | cut -c1-50,150-330
-rm -rf /tmp/pmc4; timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d /tmp/pmc4 -o p --output-format csv -- python $ROOT/bench.py --workload C4 --knn-queries 32 --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /tmp/pmc4.log 2>&1
+rm -rf /tmp/pmc4; timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d /tmp/pmc4 -o p --output-format csv -- python $ROOT/bench.py --workload C4 --knn-queries 32 --steps 3 --warmup 1 --no-cpu-baseline --no-verify --closed-loop "" > /tmp/pmc4.log 2>&1
 f=$(find /tmp/pmc4 -name "*counter_collection.csv" | head -1)
 [ -n "$f" ] && python - "$f" <<'PY' | tee $O/r03_c4_pmc.txt
 import csv, sys, collections
