@@ -418,3 +418,67 @@ def bq_(terms):
     from tests.test_parity_gpu import bq
 
     return bq(terms)
+
+
+def test_segments_are_uploaded_and_sealed_while_searches_run(ctx):
+    """NRT churn (index/ShardState.java:506-527: a refresh builds the next searcher while the current one serves): a new
+    segment is uploaded and sealed on one thread -- norms, postings, the seal-time passes -- while other threads keep searching
+    the leaves that are already resident.  Those searches keep returning the oracle's answer for THEIR leaf set; the searcher
+    built afterwards over all leaves returns the oracle's answer for the whole index.  (Uploads run on the legacy stream, the
+    searches on non-blocking streams of their own: neither waits for the other on the device.)"""
+    import threading
+
+    corpus = synth.build_corpus(240_000, [1, 2, 7, 30, 200], n_segments=4, delete_fraction=0.01)
+    old_segs, new_segs = corpus.segments[:2], corpus.segments[2:]
+    old_leaves = [api.GpuSegment.from_data(ctx, s) for s in old_segs]
+    stats = api.IndexStatistics.from_corpus(corpus)       # index-global statistics, as the reference computes them
+    old_searcher = api.GpuIndexSearcher(ctx, old_leaves, stats)
+    terms = [2, 7, 200]
+    q = api.BooleanQuery(tuple(api.TermQuery(0, t) for t in terms))
+    first = old_searcher.search(q, api.TopScoreDocCollectorManager(50))
+    errors, new_leaves, stop = [], [], threading.Event()
+
+    def search():
+        while not stop.is_set():
+            got = old_searcher.search(q, api.TopScoreDocCollectorManager(50))
+            if got.docs.tolist() != first.docs.tolist() or got.scores.view(np.uint32).tolist() != first.scores.view(np.uint32).tolist():
+                errors.append("a search over the resident leaves changed its answer during an upload")
+                return
+
+    def upload():
+        try:
+            for rep in range(3):            # the same two segments three times over: as many seal-time passes under the searches
+                built = [api.GpuSegment.from_data(ctx, s) for s in new_segs]
+                if rep < 2:
+                    for g in built:
+                        g.release()
+                else:
+                    new_leaves.extend(built)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    searchers = [threading.Thread(target=search) for _ in range(3)]
+    up = threading.Thread(target=upload)
+    for t in searchers:
+        t.start()
+    up.start()
+    up.join()
+    stop.set()
+    for t in searchers:
+        t.join()
+    try:
+        assert not errors, errors
+        assert len(new_leaves) == len(new_segs)
+        whole = api.GpuIndexSearcher(ctx, old_leaves + new_leaves, stats)
+        got = whole.search(q, api.TopScoreDocCollectorManager(50))
+        d, s_, tot, gte = oracle.search_bm25(corpus, terms, 50)
+        assert got.docs.tolist() == d.tolist() and got.scores.view(np.uint32).tolist() == s_.view(np.uint32).tolist()
+        assert got.relation_gte == gte and ((1000 < got.total_hits <= tot) if gte else got.total_hits == tot)
+        # and the leaves searched during the upload gave the whole index's answer restricted to them (same statistics): the
+        # whole-index top-50's docs that lie in those leaves are the first so many of their own top-50
+        old_limit = old_segs[-1].doc_base + old_segs[-1].max_doc
+        restricted = [(doc, bits) for doc, bits in zip(d.tolist(), s_.view(np.uint32).tolist()) if doc < old_limit]
+        assert restricted == list(zip(first.docs.tolist(), first.scores.view(np.uint32).tolist()))[: len(restricted)]
+    finally:
+        for g in old_leaves + new_leaves:
+            g.release()
