@@ -82,6 +82,7 @@ def parse_args():
     ap.add_argument("--no-sketch", action="store_true",
                     help="C4 A/B: NRTGPU_FLAG_NO_VECTOR_SKETCH -- no fp16 copy of the rows, the exact search nominates from the fp32 rows "
                          "(twice the bytes per pass); the answers are the same bits")
+    ap.add_argument("--c4-seg-rows", type=int, default=2_500_000, help="C4: rows per segment (default 2.5 M: 4 segments of the 10 M)")
     ap.add_argument("--c4-callers", action="store_true", help="C4, one GPU: --host-threads callers take the steps in turn (A/B)")
     ap.add_argument("--no-verify", action="store_true", help="C4: skip the fp64 check of the device's answer over all rows")
     ap.add_argument("--force-dist", action="store_true",
@@ -322,7 +323,7 @@ def run_c4(args):
     shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if (args.emulate_world > 1 and world == 1) else (world, rank)
     row_lo = n_all * shard_rank // shard_world
     n = n_all * (shard_rank + 1) // shard_world - row_lo
-    seg_rows = 2_500_000
+    seg_rows = max(16, args.c4_seg_rows)
     from nrtsearch_amd import _lib
     ctx = api.GpuContext(device_id=local_rank, max_batch=64, collect_timing=True,
                          flags=_lib.NRTGPU_FLAG_NO_VECTOR_SKETCH if args.no_sketch else 0)

@@ -427,23 +427,38 @@ __device__ __forceinline__ void sk_step(f16x8 (&abuf)[D], f32x4 (&acc)[P], const
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// Nominations from the sketch: the fp32 kernel's contract (candidate lists, theta, first-round slots), rows [row_begin, row_end)
-// with row_begin a multiple of 16.  P = panels of 16 queries (1 .. 4); D = pieces in flight per lane, `steps` (the sketch's,
-// padded: a multiple of 4) is a multiple of D so that the ring of row pieces is indexed statically and the epilogue stands once
-// per tile.  qscale[q]: the power of two the query was multiplied by before rounding to fp16, inv_rows_scale: 1 / the rows' scale;
-// acc / (qscale * rows' scale) is the dot product in the vectors' own units (powers of two: exact).
+// Nominations from the sketch: the fp32 kernel's contract (candidate lists, theta, first-round slots) over the global tiles
+// [tile_begin, tile_end) of the search's leaves (plan.h: DKnnLeaf) -- ONE launch walks every leaf.  P = panels of 16 queries
+// (1 .. 4); D = pieces in flight per lane, `steps` (the sketch's, padded: a multiple of 4) is a multiple of D so that the ring of
+// row pieces is indexed statically and the epilogue stands once per tile.  qscale[q]: the power of two the query was multiplied by
+// before rounding to fp16; acc / (qscale * rows' scale) is the dot product in the vectors' own units (powers of two: exact).
+// Rows are addressed by their PADDED position: (tile - tile_begin) * 16 + row in tile (a leaf's last tile may hold fewer than 16
+// rows): a first-round slot, the row field of a queue entry.
+// a value every lane holds, moved into scalar registers (the compiler cannot know that the wave's leaf is uniform)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+__device__ __forceinline__ int32_t knn_leaf_of_tile(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, int64_t tile) {
+  int32_t lo = 0, hi = n_leaves;   // the last leaf whose tile_begin <= tile
+  while (hi - lo > 1) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (leaves[mid].tile_begin <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 template <int P, int D>
 __global__ __launch_bounds__(kKnnThreads, 1)
-void knn_sketch_kernel(const f16x8* __restrict__ sketch, int32_t steps, const float* __restrict__ vnorm2,
-                       const int32_t* __restrict__ ord_to_doc, const uint64_t* __restrict__ live_bits, int32_t dim,
-                       int64_t row_begin, int64_t row_end, int32_t doc_base, const f16x8* __restrict__ panel16,
-                       const float* __restrict__ qnorm2, const float* __restrict__ qscale, float inv_rows_scale,
+void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, int32_t steps, int64_t tile_begin, int64_t tile_end,
+                       const f16x8* __restrict__ panel16, const float* __restrict__ qnorm2, const float* __restrict__ qscale,
                        int32_t n_q, int32_t sim, float boost, const unsigned long long* __restrict__ theta,
                        uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt, uint32_t cap, int32_t append_only,
                        uint32_t qcap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16x8* qs = (f16x8*)smem;  // [steps][P][64]: step s, panel p, lane l -> q[(l & 15) + 16p][32s + 8(l >> 4) .. +7] * qscale
-  // Behind the panel: the workgroup's queue of nominations (qcap entries: score bits << 32 | row - row_begin << 6 | query).
+  // Behind the panel: the workgroup's queue of nominations (qcap entries: score bits << 32 | padded row << 6 | query).
   // A row that passes is pushed HERE (an LDS atomic: lgkmcnt) and the queue is written out once, when the workgroup has streamed
   // its rows: a global atomic with a return value in the tile epilogue is the newest vector-memory operation of the wave, and
   // waiting for it waits for every request of the ring before it -- with one passing row per tile (the round after the first
@@ -461,109 +476,127 @@ void knn_sketch_kernel(const f16x8* __restrict__ sketch, int32_t steps, const fl
   for (int p = 0; p < P; ++p) {
     const int32_t q = (int32_t)j + 16 * p;
     nq[p] = q < n_q ? qnorm2[q] : 0.f;
-    dsc[p] = q < n_q ? inv_rows_scale / qscale[q] : 0.f;   // powers of two: exact
+    dsc[p] = q < n_q ? 1.0f / qscale[q] : 0.f;   // a power of two: exact
     th[p] = q < n_q ? theta[q] : ~0ull;
     // a key above theta carries a score >= theta's (equal scores: the docid decides): rows strictly below are rejected on the
     // score alone (theta = ~0, "nothing passes", is a NaN score: every compare with it is false)
     const uint32_t tsb = __float_as_uint(key_score(th[p]));
     th_hi[p] = tsb ? __uint_as_float(tsb - 1u) : -1.0f;   // (a theta of score 0: ties among zero scores are the docid's business)
   }
-  // a contiguous run of tiles per wave: one sequential stream of 1 KiB pieces
-  const int64_t t_first = row_begin >> 4, n_tiles = ((row_end + 15) >> 4) - t_first;
+  const int64_t padded_rows = (tile_end - tile_begin) << 4;   // of this launch
+  // a contiguous run of tiles per wave: one sequential stream of 1 KiB pieces per leaf it crosses
+  const int64_t n_tiles = tile_end - tile_begin;
   const int64_t n_waves = (int64_t)gridDim.x * (kKnnThreads / 64), w = (int64_t)blockIdx.x * (kKnnThreads / 64) + wave;
-  const int64_t t0 = t_first + n_tiles * w / n_waves, t1 = t_first + n_tiles * (w + 1) / n_waves;
-  if (t0 < t1) {   // (a wave without tiles still meets the others at the queue's barrier)
-  // the run as groups of D pieces (a tile is steps / D whole groups): `cur` walks the groups, the ring slot of piece i of a group
-  // is i, and the piece D ahead -- the same slot of the NEXT group -- is requested the moment slot i has been consumed (pinned
-  // with sched_barrier: left alone the compiler collects the group's eight requests at its end, and the wave's memory pipeline
-  // runs dry once per group)
-  const f16x8* cur = sketch + (t0 * steps) * 64 + lane;
-  const f16x8* const last_group = cur + ((t1 - t0) * steps - D) * 64;
-  f16x8 abuf[D];
-  sk_request<0>(abuf[0], cur);
-  sk_request<1024>(abuf[1], cur);
-  sk_request<2048>(abuf[2], cur);
-  sk_request<3072>(abuf[3], cur);
-  if (D == 8) {
-    sk_request<0>(abuf[D - 4], cur + 256);
-    sk_request<1024>(abuf[D - 3], cur + 256);
-    sk_request<2048>(abuf[D - 2], cur + 256);
-    sk_request<3072>(abuf[D - 1], cur + 256);
-  }
-  for (int64_t tile = t0; tile < t1; ++tile) {
-    // |v|^2 of the tile's 16 rows: the tile is the same for the whole wave, so they come through the SCALAR cache (s_load,
-    // counted by lgkmcnt, not by the ring's vmcnt)
-    const uint32_t t_lo = __builtin_amdgcn_readfirstlane((uint32_t)(tile & 0xFFFFFFFFll));
-    const uint32_t t_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tile >> 32));
-    const int64_t u_r0 = (int64_t)(((uint64_t)t_hi << 32) | t_lo) << 4;
-    float nvt[16];
+  int64_t t_run = tile_begin + n_tiles * w / n_waves;
+  const int64_t t_run_end = tile_begin + n_tiles * (w + 1) / n_waves;
+  int32_t li = t_run < t_run_end ? knn_leaf_of_tile(leaves, n_leaves, t_run) : 0;
+  while (t_run < t_run_end) {   // (a wave without tiles still meets the others at the queue's barrier)
+    // the leaf, as scalars: its pointers feed scalar loads and the ring's base
+    const DKnnLeaf& lf = leaves[li];
+    const uint64_t u_sketch = uniform_u64((uint64_t)lf.sketch), u_norms = uniform_u64((uint64_t)lf.vnorm2);
+    const uint64_t u_o2d = uniform_u64((uint64_t)lf.ord_to_doc), u_accept = uniform_u64((uint64_t)lf.accept);
+    const int64_t leaf_t0 = (int64_t)uniform_u64((uint64_t)lf.tile_begin);
+    const int32_t leaf_rows = __builtin_amdgcn_readfirstlane(lf.n_rows), doc_base = __builtin_amdgcn_readfirstlane(lf.doc_base);
+    const float leaf_inv = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lf.inv_rows_scale)));
+    const int32_t* const ord_to_doc = (const int32_t*)u_o2d;
+    const uint64_t* const live_bits = (const uint64_t*)u_accept;
+    const float* const vnorm2 = (const float*)u_norms;
+    const int64_t t0 = t_run - leaf_t0, t1 = min(t_run_end, leaf_t0 + (((int64_t)leaf_rows + 15) >> 4)) - leaf_t0;   // local tiles
+    // the run as groups of D pieces (a tile is steps / D whole groups): `cur` walks the groups, the ring slot of piece i of a
+    // group is i, and the piece D ahead -- the same slot of the NEXT group -- is requested the moment slot i has been consumed
+    const f16x8* cur = (const f16x8*)u_sketch + (t0 * steps) * 64 + lane;
+    const f16x8* const last_group = cur + ((t1 - t0) * steps - D) * 64;
+    f16x8 abuf[D];
+    sk_request<0>(abuf[0], cur);
+    sk_request<1024>(abuf[1], cur);
+    sk_request<2048>(abuf[2], cur);
+    sk_request<3072>(abuf[3], cur);
+    if (D == 8) {
+      sk_request<0>(abuf[D - 4], cur + 256);
+      sk_request<1024>(abuf[D - 3], cur + 256);
+      sk_request<2048>(abuf[D - 2], cur + 256);
+      sk_request<3072>(abuf[D - 1], cur + 256);
+    }
+    for (int64_t tile = t0; tile < t1; ++tile) {
+      // |v|^2 of the tile's 16 rows: the tile is the same for the whole wave, so they come through the SCALAR cache (s_load,
+      // counted by lgkmcnt, not by the ring's vmcnt)
+      const uint32_t t_lo = __builtin_amdgcn_readfirstlane((uint32_t)(tile & 0xFFFFFFFFll));
+      const uint32_t t_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tile >> 32));
+      const int64_t u_r0 = (int64_t)(((uint64_t)t_hi << 32) | t_lo) << 4;
+      float nvt[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) nvt[c] = vnorm2[u_r0 + c];   // (the norms' allocation is padded: reads past row n - 1 stay inside it)
-    f32x4 acc[P];
+      for (int c = 0; c < 16; ++c) nvt[c] = vnorm2[u_r0 + c];   // (the norms' allocation is padded: reads past row n - 1 stay inside it)
+      f32x4 acc[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int32_t s0 = 0; s0 < steps; s0 += D) {
-      const f16x8* nxt = cur < last_group ? cur + D * 64 : cur;   // (past the run's end: its last group again, never used)
-      const f16x8* nxt_hi = nxt + 256;
-      const f16x8* qg = qs + (size_t)s0 * P * 64 + lane;
-      sk_step<P, D, 0>(abuf, acc, qg, nxt, nxt_hi);
-      sk_step<P, D, 1>(abuf, acc, qg, nxt, nxt_hi);
-      sk_step<P, D, 2>(abuf, acc, qg, nxt, nxt_hi);
-      sk_step<P, D, 3>(abuf, acc, qg, nxt, nxt_hi);
-      if (D == 8) {
-        sk_step<P, D, D - 4>(abuf, acc, qg, nxt, nxt_hi);
-        sk_step<P, D, D - 3>(abuf, acc, qg, nxt, nxt_hi);
-        sk_step<P, D, D - 2>(abuf, acc, qg, nxt, nxt_hi);
-        sk_step<P, D, D - 1>(abuf, acc, qg, nxt, nxt_hi);
+      for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int32_t s0 = 0; s0 < steps; s0 += D) {
+        const f16x8* nxt = cur < last_group ? cur + D * 64 : cur;   // (past the run's end: its last group again, never used)
+        const f16x8* nxt_hi = nxt + 256;
+        const f16x8* qg = qs + (size_t)s0 * P * 64 + lane;
+        sk_step<P, D, 0>(abuf, acc, qg, nxt, nxt_hi);
+        sk_step<P, D, 1>(abuf, acc, qg, nxt, nxt_hi);
+        sk_step<P, D, 2>(abuf, acc, qg, nxt, nxt_hi);
+        sk_step<P, D, 3>(abuf, acc, qg, nxt, nxt_hi);
+        if (D == 8) {
+          sk_step<P, D, D - 4>(abuf, acc, qg, nxt, nxt_hi);
+          sk_step<P, D, D - 3>(abuf, acc, qg, nxt, nxt_hi);
+          sk_step<P, D, D - 2>(abuf, acc, qg, nxt, nxt_hi);
+          sk_step<P, D, D - 1>(abuf, acc, qg, nxt, nxt_hi);
+        }
+        cur = nxt;
       }
-      cur = nxt;
-    }
-    float nv4[4];
+      float nv4[4];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg)
-      nv4[reg] = kk == 0 ? nvt[reg] : kk == 1 ? nvt[4 + reg] : kk == 2 ? nvt[8 + reg] : nvt[12 + reg];
-    // D layout: query col = lane & 15 (+ 16p), row in tile = 4 * (lane >> 4) + reg
-    const int64_t r0 = tile << 4;
-    float rn4[4];
-    if (sim == 0) {
+      for (int reg = 0; reg < 4; ++reg)
+        nv4[reg] = kk == 0 ? nvt[reg] : kk == 1 ? nvt[4 + reg] : kk == 2 ? nvt[8 + reg] : nvt[12 + reg];
+      // D layout: query col = lane & 15 (+ 16p), row in tile = 4 * (lane >> 4) + reg
+      const int64_t r0 = tile << 4;                                   // the tile's first row in its leaf
+      const int64_t g0 = (leaf_t0 + tile - tile_begin) << 4;          // ... and its padded position in this launch
+      float rn4[4];
+      if (sim == 0) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) rn4[reg] = __builtin_amdgcn_rsqf(nv4[reg]);
-    }
+        for (int reg = 0; reg < 4; ++reg) rn4[reg] = __builtin_amdgcn_rsqf(nv4[reg]);
+      }
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int32_t q = (int32_t)j + 16 * p;
-      if (q < n_q) {
-        const float inv_nq = nq[p] > 0.f ? __builtin_amdgcn_rsqf(nq[p]) : 0.f;
+      for (int p = 0; p < P; ++p) {
+        const int32_t q = (int32_t)j + 16 * p;
+        if (q < n_q) {
+          const float inv_nq = nq[p] > 0.f ? __builtin_amdgcn_rsqf(nq[p]) : 0.f;
+          const bool slot_round = th[p] == 0ull && !append_only;   // no theta yet: every padded row owns a slot, see knn_score_kernel
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int64_t drow = r0 + 4 * (int32_t)kk + reg;
-          if (drow >= row_begin && drow < row_end) {
-            const float dot = acc[p][reg] * dsc[p];
-            const float nv = nv4[reg];
-            float est;
-            if (sim == 0) est = fmaxf((1.0f + dot * inv_nq * rn4[reg]) * 0.5f, 0.0f);
-            else if (sim == 1) est = fmaxf((1.0f + dot) * 0.5f, 0.0f);
-            else if (sim == 2) est = __builtin_amdgcn_rcpf(1.0f + fmaxf(nq[p] + nv - 2.0f * dot, 0.0f));
-            else est = dot < 0.0f ? __builtin_amdgcn_rcpf(1.0f - dot) : dot + 1.0f;
-            // this estimate IS the nomination's score (hardware rsq / rcp, a few fp32 roundings: the bound's e_rel covers them):
-            // nothing in double, nothing but compares until a row passes
-            const float sc = est * boost;
-            if (sc > th_hi[p] || th[p] == 0ull) {
-              const bool slot_round = th[p] == 0ull && !append_only;   // no theta yet: the row owns slot (row - row_begin), see knn_score_kernel
+          for (int reg = 0; reg < 4; ++reg) {
+            const int64_t drow = r0 + 4 * (int32_t)kk + reg;
+            const int64_t gpos = g0 + 4 * (int32_t)kk + reg;
+            const bool valid = drow < (int64_t)leaf_rows;
+            float sc = 0.f;
+            if (valid) {
+              const float dot = acc[p][reg] * dsc[p] * leaf_inv;
+              const float nv = nv4[reg];
+              float est;
+              if (sim == 0) est = fmaxf((1.0f + dot * inv_nq * rn4[reg]) * 0.5f, 0.0f);
+              else if (sim == 1) est = fmaxf((1.0f + dot) * 0.5f, 0.0f);
+              else if (sim == 2) est = __builtin_amdgcn_rcpf(1.0f + fmaxf(nq[p] + nv - 2.0f * dot, 0.0f));
+              else est = dot < 0.0f ? __builtin_amdgcn_rcpf(1.0f - dot) : dot + 1.0f;
+              // this estimate IS the nomination's score (hardware rsq / rcp, a few fp32 roundings: the bound's e_rel covers
+              // them): nothing in double, nothing but compares until a row passes
+              sc = est * boost;
+            }
+            if (slot_round || (valid && sc > th_hi[p])) {
               uint32_t qi = 0xFFFFFFFFu;
               if (!slot_round) qi = atomicAdd(q_n, 1u);
               if (qi < qcap) {
-                q_e[qi] = ((uint64_t)__float_as_uint(sc) << 32) | ((uint64_t)(drow - row_begin) << 6) | (uint64_t)q;
-              } else {   // the first round's slots, or a full queue: straight to the list
-                const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
-                bool live = true;
-                if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+                q_e[qi] = ((uint64_t)__float_as_uint(sc) << 32) | ((uint64_t)gpos << 6) | (uint64_t)q;
+              } else {   // the first round's slots (a padding row's holds "nothing"), or a full queue: straight to the list
                 uint64_t key = 0;  // 0 = "nothing": never above a theta
-                if (live) key = pack_key(sc, (uint32_t)(doc_base + ldoc));
+                if (valid) {
+                  const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
+                  bool live = true;
+                  if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+                  if (live) key = pack_key(sc, (uint32_t)(doc_base + ldoc));
+                }
                 if (slot_round) {
-                  const uint64_t pos = (uint64_t)(drow - row_begin);
-                  if (pos < cap) cand[(size_t)q * cap + pos] = key;
-                  if (drow == row_end - 1) cand_cnt[q] = (uint32_t)min<int64_t>(row_end - row_begin, (int64_t)0xFFFFFFFFll);
+                  if ((uint64_t)gpos < (uint64_t)cap) cand[(size_t)q * cap + (size_t)gpos] = key;
+                  if (gpos == padded_rows - 1) cand_cnt[q] = (uint32_t)min<int64_t>(padded_rows, (int64_t)0xFFFFFFFFll);
                 } else if (key > th[p]) {
                   const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
                   if (pos < cap) cand[(size_t)q * cap + pos] = key;
@@ -577,19 +610,23 @@ void knn_sketch_kernel(const f16x8* __restrict__ sketch, int32_t steps, const fl
         }
       }
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last requests (never used) land before the registers are reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last requests (never used) land before the registers are reused
+    t_run = leaf_t0 + t1;
+    ++li;
   }
   __syncthreads();
   const uint32_t n_queued = min(*q_n, qcap);
   for (uint32_t i = tid; i < n_queued; i += kKnnThreads) {
     const uint64_t e = q_e[i];
     const uint32_t q = (uint32_t)(e & 63ull);
-    const int64_t drow = row_begin + (int64_t)((e >> 6) & 0x3FFFFFFull);
-    const int32_t ldoc = ord_to_doc ? ord_to_doc[drow] : (int32_t)drow;
+    const int64_t gpos = (int64_t)((e >> 6) & 0x3FFFFFFull);
+    const int64_t tile = tile_begin + (gpos >> 4);
+    const DKnnLeaf lf = leaves[knn_leaf_of_tile(leaves, n_leaves, tile)];
+    const int64_t drow = ((tile - lf.tile_begin) << 4) + (gpos & 15);
+    const int32_t ldoc = lf.ord_to_doc ? lf.ord_to_doc[drow] : (int32_t)drow;
     bool live = true;
-    if (live_bits) live = (live_bits[ldoc >> 6] >> (ldoc & 63)) & 1ull;
-    const uint64_t key = pack_key(__uint_as_float((uint32_t)(e >> 32)), (uint32_t)(doc_base + ldoc));
+    if (lf.accept) live = (lf.accept[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+    const uint64_t key = pack_key(__uint_as_float((uint32_t)(e >> 32)), (uint32_t)(lf.doc_base + ldoc));
     if (live && key > theta[q]) {
       const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
       if (pos < cap) cand[(size_t)q * cap + pos] = key;
@@ -877,11 +914,10 @@ void launch_knn_panel_fp16(hipStream_t st, const float* qpanel, const float* qsc
                      (f16x8*)panel16);
 }
 size_t knn_sketch_lds_bytes(int32_t dim, int32_t n_q) { return (size_t)knn_sketch_steps(dim) * (size_t)((n_q + 15) >> 4) * 1024; }
-int launch_knn_sketch(hipStream_t st, uint32_t blocks, const void* sketch, const float* vnorm2, const int32_t* ord_to_doc,
-                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
-                      const void* panel16, const float* qnorm2, const float* qscale, float inv_rows_scale, int32_t n_q, int32_t sim,
+int launch_knn_sketch(hipStream_t st, uint32_t blocks, const DKnnLeaf* leaves, int32_t n_leaves, int32_t dim, int64_t tile_begin,
+                      int64_t tile_end, const void* panel16, const float* qnorm2, const float* qscale, int32_t n_q, int32_t sim,
                       float boost, const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only) {
-  if (row_end <= row_begin) return 0;
+  if (tile_end <= tile_begin || n_leaves <= 0) return 0;
   const int32_t steps = knn_sketch_steps(dim), panels = (n_q + 15) >> 4;
   const size_t panel_bytes = knn_sketch_lds_bytes(dim, n_q);
   if (panel_bytes + 16 + 256 * 8 > 160 * 1024) return (int)hipErrorInvalidValue;   // (vectors.cpp only comes here when it fits)
@@ -892,10 +928,9 @@ int launch_knn_sketch(hipStream_t st, uint32_t blocks, const void* sketch, const
     hipError_t e = hipFuncSetAttribute((const void*)knn_sketch_kernel<PANELS, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                        (int)lds);                                                                                   \
     if (e != hipSuccess) return (int)e;                                                                                             \
-    hipLaunchKernelGGL((knn_sketch_kernel<PANELS, DEPTH>), dim3(blocks), dim3(kKnnThreads), lds, st, (const f16x8*)sketch, steps,   \
-                       vnorm2, ord_to_doc, live_bits, dim, row_begin, row_end, doc_base, (const f16x8*)panel16, qnorm2, qscale,       \
-                       inv_rows_scale, n_q,                                                                                        \
-                       sim, boost, theta, cand, cand_cnt, cap, append_only, qcap);                                                  \
+    hipLaunchKernelGGL((knn_sketch_kernel<PANELS, DEPTH>), dim3(blocks), dim3(kKnnThreads), lds, st, leaves, n_leaves, steps,       \
+                       tile_begin, tile_end, (const f16x8*)panel16, qnorm2, qscale, n_q, sim, boost, theta, cand, cand_cnt, cap,    \
+                       append_only, qcap);                                                                                          \
   }
 #define NRT_SKETCH_PANELS(PANELS) \
   if (steps % 8 == 0) NRT_SKETCH_LAUNCH(PANELS, 8) else NRT_SKETCH_LAUNCH(PANELS, 4)

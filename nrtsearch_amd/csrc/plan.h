@@ -234,6 +234,21 @@ struct DVecSeg {
 };
 static_assert(sizeof(DVecSeg) == 40, "DVecSeg layout");
 
+// A leaf as the sketch kernel sees it (knn.hip: knn_sketch_kernel walks ALL leaves of a search in one launch: an NRT index is
+// dozens of segments, and a launch per leaf cost 17 % of a pass at 40 leaves, 84 % at 160).  The leaves' tiles of 16 rows are
+// numbered through: leaf i holds tiles [tile_begin, tile_begin + ceil(n_rows / 16)).
+struct alignas(16) DKnnLeaf {
+  const void* sketch;          // the leaf's fp16 sketch (tile 0 first)
+  const float* vnorm2;         // |v|^2 per row (allocation padded by 64 B: a tile's 16 norms are read whole)
+  const int32_t* ord_to_doc;   // nullptr: row == docid
+  const uint64_t* accept;      // liveDocs (& filter) bits of the leaf; nullptr: every doc
+  int64_t tile_begin;
+  int32_t n_rows, doc_base;
+  float inv_rows_scale;        // 1 / the power of two the rows were multiplied by
+  int32_t pad[3];
+};
+static_assert(sizeof(DKnnLeaf) == 64, "DKnnLeaf layout");
+
 // Exact vector search: the matrix-core ESTIMATE of a score against the RESULT (the same similarity summed in the oracle's
 // order).  e_abs bounds |estimate - result| -- for EUCLIDEAN of the squared distance (the score 1 / (1 + d2) flattens with d2: a
 // bound in score units would be useless for far rows), else of the score with the boost applied; e_rel covers the roundings of

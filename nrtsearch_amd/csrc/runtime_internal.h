@@ -83,9 +83,8 @@ size_t knn_sketch_bytes(int32_t dim, int64_t n);
 size_t knn_sketch_lds_bytes(int32_t dim, int32_t n_q);
 void launch_knn_panel_fp16(hipStream_t st, const float* qpanel, const float* qscale, int32_t dim, int32_t n_q, void* panel16);
 void launch_knn_sketch_build(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float scale, void* sketch);
-int launch_knn_sketch(hipStream_t st, uint32_t blocks, const void* sketch, const float* vnorm2, const int32_t* ord_to_doc,
-                      const uint64_t* live_bits, int32_t dim, int64_t row_begin, int64_t row_end, int32_t doc_base,
-                      const void* panel16, const float* qnorm2, const float* qscale, float inv_rows_scale, int32_t n_q, int32_t sim,
+int launch_knn_sketch(hipStream_t st, uint32_t blocks, const DKnnLeaf* leaves, int32_t n_leaves, int32_t dim, int64_t tile_begin,
+                      int64_t tile_end, const void* panel16, const float* qnorm2, const float* qscale, int32_t n_q, int32_t sim,
                       float boost, const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only = 0);
 void launch_rescore_vectors(hipStream_t st, const float* vecs, const float* vnorm2, int32_t dim, const float* query,
                             float qnorm2, int32_t sim, float boost, const int64_t* vec_row, const float* first_scores,

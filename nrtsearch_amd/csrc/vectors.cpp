@@ -66,6 +66,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   const size_t o_q = wc.take((size_t)kKnnMaxQ * dim * 4), o_qn = wc.take(kKnnMaxQ * 4), o_eb = wc.take(kKnnMaxQ * 4);
   const size_t o_eb16 = wc.take(kKnnMaxQ * 4), o_qs = wc.take(kKnnMaxQ * 4);
   const size_t o_segs = wc.take((size_t)std::max(n_segs, 1) * sizeof(DVecSeg));
+  const size_t o_leaves = wc.take((size_t)std::max(n_segs, 1) * sizeof(DKnnLeaf));   // the sketch kernel's leaf table (plan.h)
   const size_t o_th = wc.take(kKnnMaxQ * 8);
   const size_t o_tk = wc.take((size_t)kKnnMaxQ * ki_stride * 8), o_tc = wc.take(kKnnMaxQ * 4);
   const size_t o_cc = wc.take(kKnnMaxQ * 4), o_xk = wc.take((size_t)kKnnMaxQ * k_stride * 8);
@@ -104,6 +105,31 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       }
     }
     hsegs[(size_t)si] = v;
+  }
+  // the sketch kernel's view of the same leaves: ONE launch walks them all (tiles of 16 rows numbered through the leaves)
+  DKnnLeaf* hleaves = (DKnnLeaf*)(hs + o_leaves);
+  int32_t n_kleaves = 0;
+  int64_t total_tiles = 0, total_rows = 0, live_vectors = 0;
+  for (int si = 0; si < n_segs; ++si) {
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit == segs[si]->fields.end() || !fit->second.d_vectors || fit->second.n_vec == 0) continue;
+    const FieldData& f = fit->second;
+    live_vectors += live_vector_count(segs[si], f);   // (deleted docs are masked inside the kernel and are no hits)
+    const uint64_t* accept = segs[si]->d_live;        // (vectors are not re-coded for liveDocs: always the mask)
+    if (knn_request && filter_mask != 0)
+      if (int rc = accept_set_of(segs[si], filter_mask, 0, &accept)) return rc;
+    DKnnLeaf l{};
+    l.sketch = f.d_sketch;
+    l.vnorm2 = f.d_vnorm2;
+    l.ord_to_doc = f.d_ord_to_doc;
+    l.accept = accept;
+    l.tile_begin = total_tiles;
+    l.n_rows = f.n_vec;
+    l.doc_base = doc_bases ? doc_bases[si] : 0;
+    l.inv_rows_scale = 1.0f / f.sketch_scale;
+    hleaves[n_kleaves++] = l;
+    total_tiles += ((int64_t)f.n_vec + 15) >> 4;
+    total_rows += f.n_vec;
   }
   // |estimate - result| <= E: both are fp32 evaluations of the same length-dim sums, each within gamma = dim * 2^-24 (relative
   // to the sum of the terms' magnitudes) of the real value whatever the order; the maps to a score have slope <= 1 and add a
@@ -189,10 +215,10 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     size_t n_ev = 0;
     // One pass over the rows of every leaf.  nominate: the estimates' running top-k_int, theta tightening (knn_select_kernel
     // <false>); else theta stays what the certification left and every nomination is rescored into the answer (<true>).
+    // (rows of the first round: every row takes a slot of the list and the first selection scans them all)
+    static const int64_t kFirstRound = []() { const char* e = getenv("NRTGPU_KNN_FIRST_ROUND"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1024 && v <= (1 << 18) ? (v & ~15L) : (1 << 16)); }();
     int64_t sketch_launches = 0;
-    auto rows_pass = [&](bool nominate, int safe, bool sketch) -> int {
-      // (rows of the first round: every row takes a slot of the list and the first selection scans them all)
-      static const int64_t kFirstRound = []() { const char* e = getenv("NRTGPU_KNN_FIRST_ROUND"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1024 && v <= (1 << 18) ? (v & ~15L) : (1 << 16)); }();
+    auto rows_pass = [&](bool nominate, int safe) -> int {   // (the fp32 rows: a launch per leaf and round)
       int64_t seen = 0, round = kFirstRound;
       // Nominating, theta tightens fast: after two selections (>= 1M rows seen) a later launch appends about k ln(rows / rows
       // seen) keys per query, so the remaining launches run back to back (append_only) and ONE selection closes the pass.  A
@@ -217,10 +243,9 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
           const int64_t rb = r;
           int64_t len = (safe || (nominate && seen == 0)) ? std::min<int64_t>(round, kKnnCap) : round;
           if (!nominate && !safe) len = f.n_vec;   // theta is fixed and tight: the whole leaf at once
-          len = std::min<int64_t>(len, (int64_t)1 << 26);   // (the sketch kernel's queue entries carry row - round start in 26 bits)
           const int64_t re = std::min<int64_t>(f.n_vec, (r + len + 15) & ~(int64_t)15);   // rounds begin on tile boundaries (16 rows)
           uint32_t blocks = (uint32_t)std::min<int64_t>((re - r + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));  // 256 rows per workgroup step
-          if (nq > 32 && !sketch) blocks = std::max(16u, std::min((uint32_t)std::max(ctx->n_cus, 16), 2u * blocks) / 16u * 16u);   // paired workgroups
+          if (nq > 32) blocks = std::max(16u, std::min((uint32_t)std::max(ctx->n_cus, 16), 2u * blocks) / 16u * 16u);   // paired workgroups
           if (timing) {
             while (slot->round_ev.size() < n_ev + 2) {
               hipEvent_t ev = nullptr;
@@ -230,17 +255,11 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
             HIP_TRY(hipEventRecord(slot->round_ev[n_ev], st));
           }
           const bool defer = nominate && !safe && selections >= 2;
-          const int e = sketch
-              ? launch_knn_sketch(st, blocks, f.d_sketch, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re, doc_bases ? doc_bases[si] : 0,
-                                  (const void*)(wb + o_p16), (const float*)(wb + o_qn), (const float*)(wb + o_qs), 1.0f / f.sketch_scale, nq,
-                                  sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
-                                  (uint32_t*)(wb + o_cc), kKnnCap, defer ? 1 : 0)
-              : launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
-                                 doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
-                                 sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
-                                 (uint32_t*)(wb + o_cc), kKnnCap, defer ? 1 : 0);
+          const int e = launch_knn_score(st, blocks, f.d_vectors, f.d_vnorm2, f.d_ord_to_doc, accept, dim, r, re,
+                                         doc_bases ? doc_bases[si] : 0, (const float*)(wb + o_q), (const float*)(wb + o_qn), nq,
+                                         sim, score_boost, (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd),
+                                         (uint32_t*)(wb + o_cc), kKnnCap, defer ? 1 : 0);
           if (e) return fail(NRTGPU_ERR_HIP, "knn_score launch: %s", hipGetErrorString((hipError_t)e));
-          sketch_launches += sketch ? 1 : 0;
           if (timing) {
             HIP_TRY(hipEventRecord(slot->round_ev[n_ev + 1], st));
             n_ev += 2;
@@ -270,6 +289,55 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       rows_scored += seen;
       return NRTGPU_OK;
     };
+    // The same from the fp16 sketch: a round is a range of the leaves' tiles, ONE launch whatever the number of leaves it crosses.
+    auto sketch_pass = [&](int safe) -> int {
+      int64_t seen = 0, round = kFirstRound >> 4;   // in tiles of 16 rows
+      int selections = 0;
+      bool pending = false;
+      total_vec = live_vectors;
+      for (int64_t t = 0; t < total_tiles;) {
+        int64_t len = (safe || seen == 0) ? std::min<int64_t>(round, kKnnCap >> 4) : round;
+        len = std::min<int64_t>(len, (int64_t)1 << 22);   // (a queue entry carries the padded row inside the launch in 26 bits)
+        const int64_t te = std::min<int64_t>(total_tiles, t + len);
+        const uint32_t blocks = (uint32_t)std::min<int64_t>(((te - t) * 16 + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));
+        if (timing) {
+          while (slot->round_ev.size() < n_ev + 2) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            slot->round_ev.push_back(ev);
+          }
+          HIP_TRY(hipEventRecord(slot->round_ev[n_ev], st));
+        }
+        const bool defer = !safe && selections >= 2;
+        const int e = launch_knn_sketch(st, blocks, (const DKnnLeaf*)(wb + o_leaves), n_kleaves, dim, t, te, (const void*)(wb + o_p16),
+                                        (const float*)(wb + o_qn), (const float*)(wb + o_qs), nq, sim, score_boost,
+                                        (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
+                                        defer ? 1 : 0);
+        if (e) return fail(NRTGPU_ERR_HIP, "knn_sketch launch: %s", hipGetErrorString((hipError_t)e));
+        ++sketch_launches;
+        if (timing) {
+          HIP_TRY(hipEventRecord(slot->round_ev[n_ev + 1], st));
+          n_ev += 2;
+        }
+        if (defer) {
+          pending = true;
+        } else {
+          launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, k_int,
+                            (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap, (unsigned long long*)(wb + o_th),
+                            (uint32_t*)(wb + o_ov));
+          ++selections;
+        }
+        seen += te - t;
+        t = te;
+        round = safe ? std::min<int64_t>(round * 4, kKnnCap >> 4) : std::min<int64_t>(seen * 15, (int64_t)1 << 36);
+      }
+      if (pending)
+        launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, k_int,
+                          (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap, (unsigned long long*)(wb + o_th),
+                          (uint32_t*)(wb + o_ov));
+      rows_scored += total_rows;
+      return NRTGPU_OK;
+    };
     auto fetch = [&]() -> int {   // the answer so far + the flags
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(ho, wb + o_xk, (size_t)nq * k_stride * 8, hipMemcpyDeviceToHost, st));
@@ -291,7 +359,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
       }
       if (panel_sketch) launch_knn_panel_fp16(st, (const float*)(wb + o_q), (const float*)(wb + o_qs), dim, nq, wb + o_p16);
-      if (int rc = rows_pass(true, safe, panel_sketch)) return rc;
+      if (int rc = panel_sketch ? sketch_pass(safe) : rows_pass(true, safe)) return rc;
       launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
                                (const uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, (unsigned long long*)(wb + o_th),
                                (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim, sim, (const float*)(wb + o_q),
@@ -330,7 +398,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         if (((const uint32_t*)(ho + oh_cert))[q] == 0u) HIP_TRY(hipMemsetAsync(wb + o_xc + (size_t)q * 4, 0, 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_cc, 0, kKnnMaxQ * 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_ov, 0, 4, st));
-      if (int rc = rows_pass(false, safe, false)) return rc;
+      if (int rc = rows_pass(false, safe)) return rc;
       if (int rc = end_turn()) return rc;
       if (int rc = fetch()) return rc;   // (the second pass leaves the flags as they are)
       if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
