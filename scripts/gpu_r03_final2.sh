@@ -38,7 +38,7 @@ for r in rows:
     agg[r['Kernel_Name'][:40]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     if 'knn_sketch_kernel' in k or 'knn_select' in k:
-        print(k, {c: (len(v), round(sum(v), 1)) for c, v in d.items()}, '(launches, SUM over launches; 4 passes of 6 launches: FETCH_SIZE in KB)')
+        print(k, {c: (len(v), round(sum(v), 1)) for c, v in d.items()}, '(launches, SUM over launches; 4 passes of 3 launches: FETCH_SIZE in KB)')
 PY
 cd $ROOT
 echo "== done ($(( $(date +%s) - T0 )) s) =="
