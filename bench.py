@@ -90,9 +90,11 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="debug, 1 GPU: index only rank 0's docid range of an N-GPU job (per-rank step time at --gpus N)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's shard (the last rank holds the small segments)")
-    ap.add_argument("--shard-layout", default="index", choices=["index", "per_shard"],
-                    help="N>1: a rank owns the pieces of the index's segments inside its docid range (default), or -- rounds 1-2 -- "
-                         "its range cut into a full set of tiered segments of its own")
+    ap.add_argument("--shard-layout", default="index", choices=["index", "per_shard", "balanced"],
+                    help="N>1: a rank owns the pieces of the index's segments inside its docid range (default); per_shard (rounds 1-2): "
+                         "its range cut into a full set of tiered segments of its own; balanced: the index's small segments are dealt "
+                         "out to the ranks and each rank is filled up from the big segments' docid space -- every rank holds 2-3 leaves "
+                         "instead of the last rank holding all the small ones")
     ap.add_argument("--debug-k", type=int, default=0, help="debug: numHits override (what a shard costs at a smaller k)")
     ap.add_argument("--torch-collective", action="store_true",
                     help="N>1: exchange with torch.distributed's all-gather instead of the library's own RCCL stage "

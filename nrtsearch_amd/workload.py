@@ -72,22 +72,63 @@ def shard_leaves(w: Workload, world: int, rank: int, layout: str = "index"):
     return lo, hi, sizes
 
 
+def shard_pieces(w: Workload, world: int, rank: int, layout: str = "index"):
+    """The leaves of `rank`'s shard as a list of (doc_base, size), in docid order.  "index" / "per_shard": shard_leaves (one
+    contiguous docid range per rank).  "balanced": the index's small segments (under half a shard) are dealt out to the ranks one by
+    one, largest first, and every rank is then filled up to its share from the docid space of the big segments (cut at 1024-doc
+    boundaries, like a LeafReaderContextPartition): every rank holds the same number of docs in one or two big pieces plus one or
+    two small segments, instead of the last rank holding all the small ones (whose per-leaf planning made it the slowest)."""
+    if world <= 1 or layout != "balanced":
+        lo, hi, sizes = shard_leaves(w, world, rank, layout)
+        out, base = [], lo
+        for g in sizes:
+            out.append((int(base), int(g)))
+            base += g
+        return out
+    sizes = synth.tiered_segment_sizes(w.n_docs, w.segments_per_shard)
+    bases = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+    share = -(-w.n_docs // world)
+    small = sorted([(int(g), int(b)) for g, b in zip(sizes, bases) if g < share // 2], reverse=True)
+    big = [(int(b), int(g)) for g, b in zip(sizes, bases) if g >= share // 2]
+    pieces = [[] for _ in range(world)]
+    load = [0] * world
+    for i, (g, b) in enumerate(small):       # round robin in size order: the loads stay within one small segment of each other
+        r = i % world
+        pieces[r].append((b, g))
+        load[r] += g
+    bi, off = 0, 0                           # the big segments' docid space, handed out rank by rank
+    for r in range(world):
+        need = share - load[r] if r < world - 1 else 1 << 62
+        while need > 0 and bi < len(big):
+            b, g = big[bi]
+            take = min(g - off, -(-need // 1024) * 1024)   # a cut inside a segment falls on a 1024-doc boundary
+            pieces[r].append((b + off, take))
+            load[r] += take
+            need -= take
+            off += take
+            if off == g:
+                bi, off = bi + 1, 0
+    return sorted(pieces[rank])
+
+
 def build_shard_corpus(w: Workload, queries: np.ndarray, world: int = 1, rank: int = 0, seed: int = 1234, layout: str = "index"):
-    """Corpus restricted to this rank's docid range, with index-global statistics."""
+    """Corpus restricted to this rank's leaves, with index-global statistics."""
     ranks = sorted(set(int(r) for r in queries.reshape(-1)))
     lens = synth.doc_lengths(w.n_docs, seed)
     norms_all = synth.int_to_byte4(lens)
-    lo, hi, sizes = shard_leaves(w, world, rank, layout)
-    bases = np.concatenate([[lo], lo + np.cumsum(sizes)]).astype(np.int64)
+    pieces = shard_pieces(w, world, rank, layout)
+    sizes = [g for _, g in pieces]
+    bases = np.asarray([b for b, _ in pieces], dtype=np.int64)
+    ends = bases + np.asarray(sizes, dtype=np.int64)
     per_docs: List[List[np.ndarray]] = [[] for _ in sizes]
     per_freqs: List[List[np.ndarray]] = [[] for _ in sizes]
     doc_freq = {}
     for r in ranks:
         d, f = synth.term_postings(w.n_docs, r, seed)
         doc_freq[r] = int(len(d))
-        cuts = np.searchsorted(d, bases)
+        lo_cut, hi_cut = np.searchsorted(d, bases), np.searchsorted(d, ends)
         for s in range(len(sizes)):
-            a, b = int(cuts[s]), int(cuts[s + 1])
+            a, b = int(lo_cut[s]), int(hi_cut[s])
             per_docs[s].append((d[a:b] - bases[s]).astype(np.int32))
             per_freqs[s].append(f[a:b])
     segments = []

@@ -169,6 +169,43 @@ def test_shard_leaves_tile_the_index():
             assert min(pieces) > n_docs // world // 100 or min(pieces) in whole   # no slivers besides the index's own small segments
 
 
+def test_balanced_shard_layout_tiles_the_index_and_spreads_the_small_segments():
+    """layout "balanced": the ranks' leaves partition the index's docid space, refine its segments (a cut falls on a 1024-doc
+    boundary inside a segment), every rank holds about the same number of docs and at most a handful of leaves -- no rank is left
+    with all the small segments; the corpus builder follows it (a rank's leaves need not be one contiguous docid range)."""
+    sys.path.insert(0, ROOT)
+    import dataclasses
+
+    from nrtsearch_amd import synth, workload
+
+    for n_docs in (10_000_000, 3_000_000, 1_234_567):
+        w = dataclasses.replace(workload.C3, n_docs=n_docs)
+        whole = synth.tiered_segment_sizes(n_docs, w.segments_per_shard)
+        seg_edges = np.concatenate([[0], np.cumsum(whole)])
+        for world in (2, 3, 4, 8):
+            per_rank = [workload.shard_pieces(w, world, r, "balanced") for r in range(world)]
+            pos = 0
+            for b, g in sorted(sum(per_rank, [])):
+                assert b == pos and g > 0
+                seg = int(np.searchsorted(seg_edges, b, side="right")) - 1
+                assert b + g <= seg_edges[seg + 1]                       # a piece lies inside one segment of the index
+                assert (b - seg_edges[seg]) % 1024 == 0                   # and starts on a sub-tile boundary of it
+                pos += g
+            assert pos == n_docs
+            loads = [sum(g for _, g in p) for p in per_rank]
+            assert max(loads) - min(loads) <= max(whole[2:]) if world <= 3 else max(loads) - min(loads) <= n_docs // world // 20
+            assert max(len(p) for p in per_rank) <= -(-len(whole) // world) + 3
+    w = dataclasses.replace(workload.SMOKE, n_docs=60_000)
+    qr = synth.make_queries(4, 3, 500)
+    docs = 0
+    for r in range(4):
+        c = workload.build_shard_corpus(w, qr, 4, r, layout="balanced")
+        assert [s.doc_base for s in c.segments] == sorted(s.doc_base for s in c.segments)
+        assert [(s.doc_base, s.max_doc) for s in c.segments] == workload.shard_pieces(w, 4, r, "balanced")
+        docs += sum(s.max_doc for s in c.segments)
+    assert docs == w.n_docs
+
+
 def test_key_packing_roundtrip_and_order():
     sys.path.insert(0, ROOT)
     from nrtsearch_amd import dist as nd
