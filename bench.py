@@ -303,6 +303,35 @@ def closed_loop(ctx, searcher, queries, mgr, callers, duration_ms):
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 is exact fp32
 
 
+def knn_roofline_record(rows_per_pass, dim, queries_per_pass, score_ms, sketched, score_launches_per_pass, second_passes):
+    """The `roofline` object of the exact-kNN line from measured numbers (pure: tests/test_bench_contract.py checks its arithmetic).
+    A pass over the rows that nominates from the fp16 sketch STREAMS 2 bytes per element (steps of 32 dimensions padded to whole
+    groups of four), half of SURVEY 8d's algorithmic fp32 bytes: `frac` is then the PHYSICAL fraction and the algorithmic rate
+    stands beside it as effective_* (it may exceed the peak); from the fp32 rows the two coincide and the fp32 matrix-pipe
+    fraction is reported as well."""
+    t = score_ms * 1e-3
+    algorithmic = rows_per_pass * dim * 4
+    steps16 = ((dim + 31) // 32 + 3) // 4 * 4
+    streamed = rows_per_pass * (steps16 * 64 if sketched else dim * 4)
+    effective = algorithmic / t / 1e9 if t > 0 else 0.0
+    achieved = streamed / t / 1e9 if t > 0 else 0.0
+    tflops = 2.0 * rows_per_pass * dim * queries_per_pass / t / 1e12 if t > 0 else 0.0
+    return {"bound": "hbm", "kernel": "knn_sketch_kernel" if sketched else "knn_score_kernel", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "achieved_is": ("physical: the fp16 sketch's bytes (2 per element) / launch time" if sketched
+                            else "algorithmic bytes (fp32 rows) / launch time"),
+            "effective": bool(sketched),
+            "effective_achieved": round(effective, 1) if sketched else None,
+            "effective_frac": round(effective / HBM_PEAK_GBS, 4) if sketched else None,
+            "algorithmic_bytes_per_launch": int(algorithmic), "streamed_bytes_per_launch": int(streamed),
+            "launch": "the nomination kernel's launches of one pass over the rows (<= 64 queries; a few rounds, theta tightens in between)",
+            "score_launches_per_panel": round(score_launches_per_pass, 2),
+            "second_passes": int(second_passes),
+            "avg_launch_ms": round(score_ms, 4),
+            "mfma_tflops": round(tflops, 2) if not sketched else None, "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS if not sketched else None,
+            "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4) if not sketched else None, "traffic": None}
+
+
 def run_c4(args):
     """BASELINE.json config 4 at one GPU: N x 768 fp32 rows resident in HBM, exact (brute-force) cosine kNN top-100 --
     what KnnFloatVectorQuery / ExactVectorQuery compute, answered by nrtgpu_knn_exact.  A step = one call with
@@ -439,17 +468,11 @@ def run_c4(args):
     st = ctx.stats()
     n_panels = max(1, st["knn_panels"])
     score_ms = st["knn_score_ms"] / n_panels                    # knn_score_kernel launches of one panel (HIP events, its stream)
-    bytes_per_panel = st["knn_rows"] / n_panels * dim * 4        # every row once per panel
     q_per_panel = Q / max(1, (Q + 63) // 64)   # queries per pass over the rows (two 32-query panels on paired workgroups)
     # The pass over the rows nominates from the fp16 sketch when the segment keeps one (2 bytes per element, matrix-core operand
     # order): the kernel then READS half of SURVEY 8d's algorithmic bytes.  As for the pruned BM25 kernel the roofline fraction is the
     # PHYSICAL one (bytes the kernel streams / launch time) and the algorithmic figure stands beside it as effective_*.
     sketched = st["knn_sketch_launches"] > 0 and st["knn_sketch_launches"] == st["knn_score_launches"]
-    steps16 = ((dim + 31) // 32 + 3) // 4 * 4
-    phys_bytes_per_panel = st["knn_rows"] / n_panels * (steps16 * 64 if sketched else dim * 4)
-    effective = bytes_per_panel / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-    achieved = phys_bytes_per_panel / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-    tflops = 2.0 * (st["knn_rows"] / n_panels) * dim * q_per_panel / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
     out = {
         "metric": "queries/sec, exact kNN 10M x 768 fp32 cosine top-100" if n_all == 10_000_000 else f"queries/sec, exact kNN {n_all} x 768 fp32 cosine top-100",
         "value": round(args.steps * Q / elapsed, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -463,20 +486,8 @@ def run_c4(args):
                    "sharding": ("rows partitioned by docid range, 1 process per GPU, per-rank top-k exchanged inside the library "
                                 f"(nrtgpu_dist_knn_exact, {'all-to-all' if mode == api.EXCHANGE_ALLTOALL else 'all-gather'})" if world > 1 else
                                 (f"[emulating rank {shard_rank} of {shard_world}: its rows, no exchange]" if shard_world > 1 else "one GPU"))},
-        "roofline": {"bound": "hbm", "kernel": "knn_sketch_kernel" if sketched else "knn_score_kernel", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "achieved_is": ("physical: the fp16 sketch's bytes (2 per element) / launch time" if sketched
-                                     else "algorithmic bytes (fp32 rows) / launch time"),
-                     "effective": bool(sketched),
-                     "effective_achieved": round(effective, 1) if sketched else None,
-                     "effective_frac": round(effective / HBM_PEAK_GBS, 4) if sketched else None,
-                     "algorithmic_bytes_per_launch": int(bytes_per_panel), "streamed_bytes_per_launch": int(phys_bytes_per_panel),
-                     "launch": "the nomination kernel's launches of one pass over the rows (<= 64 queries; a few rounds, theta tightens in between)",
-                     "score_launches_per_panel": round(st["knn_score_launches"] / n_panels, 2),
-                     "second_passes": int(st["knn_second_passes"]),
-                     "avg_launch_ms": round(score_ms, 4),
-                     "mfma_tflops": round(tflops, 2) if not sketched else None, "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS if not sketched else None,
-                     "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4) if not sketched else None, "traffic": None},
+        "roofline": knn_roofline_record(st["knn_rows"] / n_panels, dim, q_per_panel, score_ms, sketched, st["knn_score_launches"] / n_panels,
+                                        st["knn_second_passes"]),
     }
     if rank == 0 and world == 1 and shard_world == 1 and args.closed_loop:
         # queries/s AND latency under concurrent clients: C native caller threads, ONE query per call through

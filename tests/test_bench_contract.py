@@ -98,3 +98,23 @@ def test_committed_c4_line_keeps_the_contract_and_its_roofline_arithmetic():
     cl = d.get("closed_loop")
     if cl:
         assert "nrtgpu_knn_exact_coalesced" in cl["entry"] and cl["64"]["qps"] > 10 * cl["1"]["qps"] / 2
+
+
+def test_knn_roofline_record_arithmetic():
+    """bench.knn_roofline_record on synthetic numbers: from the fp16 sketch the fraction is physical (2 bytes per element, steps of 32
+    dimensions padded to groups of four) with the fp32 bytes beside it as effective; from the fp32 rows they coincide and the matrix
+    fraction is reported."""
+    r = bench.knn_roofline_record(10_000_000, 768, 32, 2.7, True, 3.0, 0)
+    assert r["kernel"] == "knn_sketch_kernel" and r["effective"] is True
+    assert r["streamed_bytes_per_launch"] == 10_000_000 * 24 * 64 == 10_000_000 * 768 * 2
+    assert r["algorithmic_bytes_per_launch"] == 10_000_000 * 768 * 4
+    assert abs(r["achieved"] - 15.36e9 / 2.7e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
+    assert abs(r["effective_frac"] - 2 * r["frac"]) < 1e-3 and r["mfma_frac"] is None and r["second_passes"] == 0
+    # 96 dimensions: 3 steps of 32, padded to 4 -> 256 bytes per row streamed, 384 algorithmic
+    r = bench.knn_roofline_record(1000, 96, 1, 1.0, True, 3.0, 1)
+    assert r["streamed_bytes_per_launch"] == 1000 * 256 and r["algorithmic_bytes_per_launch"] == 1000 * 384 and r["second_passes"] == 1
+    r = bench.knn_roofline_record(10_000_000, 768, 32, 6.0, False, 6.0, 0)
+    assert r["kernel"] == "knn_score_kernel" and r["effective"] is False and r["effective_frac"] is None
+    assert r["streamed_bytes_per_launch"] == r["algorithmic_bytes_per_launch"] == 10_000_000 * 768 * 4
+    assert abs(r["mfma_tflops"] - 2 * 10_000_000 * 768 * 32 / 6e-3 / 1e12) < 0.01
+    assert abs(r["mfma_frac"] - r["mfma_tflops"] / 157.3) < 1e-3
