@@ -74,6 +74,9 @@ def parse_args():
     ap.add_argument("--sync-submit", action="store_true",
                     help="N>1: --host-threads threads each block in nrtgpu_search_bm25_batch_device_epoch (rounds 1-2) instead of ONE thread "
                          "submitting with nrtgpu_search_bm25_batch_device_begin and the exchange thread waiting (nrtgpu_pending_wait)")
+    ap.add_argument("--submitters", type=int, default=0,
+                    help="N>1 (begin / wait submission): threads that plan and enqueue steps side by side (0 = 2 when the host has >= 6 CPUs "
+                         "per rank, else 1): a rank whose planning takes longer than its kernel is bound by ONE submitting thread")
     ap.add_argument("--planner-threads", type=int, default=0, help="planner threads per in-flight call (0 = what the box's CPUs allow)")
     ap.add_argument("--closed-loop", default="64,512",
                     help="N=1, C3: after the batch line, closed loop with that many concurrent callers, one query per call through "
@@ -648,7 +651,11 @@ def main():
     # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
     # (the node's ranks share the host; 4 is the library's default and enough at one rank)
     # (a rank of an N-GPU job has ONE submitting thread unless --sync-submit)
-    submitters = max(1, args.host_threads) if (args.sync_submit or not (world > 1 or args.force_dist)) else 1
+    if args.sync_submit or not (world > 1 or args.force_dist):
+        submitters = max(1, args.host_threads)
+    else:   # begin / wait: one submitting thread per rank, two where the host can afford them
+        submitters = args.submitters if args.submitters > 0 else (2 if usable_cpus() >= 6 * max(world, shard_world) else 1)
+        submitters = max(1, min(submitters, 2))   # (three result buffers are in flight: at most two steps being planned)
     planner_threads = args.planner_threads or max(1, min(4, usable_cpus() // max(1, max(world, shard_world) * submitters)))
     ctx = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True, flags=flags,
                          host_threads=planner_threads)
@@ -844,7 +851,7 @@ def main():
                 stage["scan_call_s"] += time.perf_counter() - t_start[i]
             return b
 
-        with ThreadPoolExecutor(max_workers=max(1, args.host_threads) if args.sync_submit else 1) as ex:  # FIFO: steps start in order
+        with ThreadPoolExecutor(max_workers=max(1, args.host_threads) if args.sync_submit else submitters) as ex:  # FIFO: steps start in order
             futs = [ex.submit(produce, i) for i in range(count)]
             for i in range(count):
                 b = futs[i].result()
