@@ -290,13 +290,14 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
       return NRTGPU_OK;
     };
     // The same from the fp16 sketch: a round is a range of the leaves' tiles, ONE launch whatever the number of leaves it crosses.
-    auto sketch_pass = [&](int safe) -> int {
+    auto sketch_pass = [&](int safe, bool nominate) -> int {   // nominate = false: theta is fixed, every nomination is rescored into the answer
       int64_t seen = 0, round = kFirstRound >> 4;   // in tiles of 16 rows
       int selections = 0;
       bool pending = false;
       total_vec = live_vectors;
       for (int64_t t = 0; t < total_tiles;) {
-        int64_t len = (safe || seen == 0) ? std::min<int64_t>(round, kKnnCap >> 4) : round;
+        int64_t len = (safe || (nominate && seen == 0)) ? std::min<int64_t>(round, kKnnCap >> 4) : round;
+        if (!nominate && !safe) len = total_tiles;   // theta is fixed and tight: everything at once
         len = std::min<int64_t>(len, (int64_t)1 << 22);   // (a queue entry carries the padded row inside the launch in 26 bits)
         const int64_t te = std::min<int64_t>(total_tiles, t + len);
         const uint32_t blocks = (uint32_t)std::min<int64_t>(((te - t) * 16 + 255) / 256, (int64_t)std::max(ctx->n_cus, 1));
@@ -308,7 +309,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
           }
           HIP_TRY(hipEventRecord(slot->round_ev[n_ev], st));
         }
-        const bool defer = !safe && selections >= 2;
+        const bool defer = nominate && !safe && selections >= 2;
         const int e = launch_knn_sketch(st, blocks, (const DKnnLeaf*)(wb + o_leaves), n_kleaves, dim, t, te, (const void*)(wb + o_p16),
                                         (const float*)(wb + o_qn), (const float*)(wb + o_qs), nq, sim, score_boost,
                                         (const unsigned long long*)(wb + o_th), (uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap,
@@ -321,11 +322,17 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         }
         if (defer) {
           pending = true;
-        } else {
+        } else if (nominate) {
           launch_knn_select(st, (uint32_t)nq, (uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, k_int,
                             (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap, (unsigned long long*)(wb + o_th),
                             (uint32_t*)(wb + o_ov));
           ++selections;
+        } else {
+          launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
+                                   (const uint64_t*)(wb + o_cd), (uint32_t*)(wb + o_cc), kKnnCap, (unsigned long long*)(wb + o_th),
+                                   (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim, sim, (const float*)(wb + o_q),
+                                   (const float*)(wb + o_qn), score_boost, (const float*)(wb + o_eb16), erel,
+                                   knn_request ? min_score : 0.0f, k_int, 0, (uint32_t*)(wb + o_cert));
         }
         seen += te - t;
         t = te;
@@ -359,7 +366,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         HIP_TRY(hipStreamSynchronize(st));  // th0 is a stack vector
       }
       if (panel_sketch) launch_knn_panel_fp16(st, (const float*)(wb + o_q), (const float*)(wb + o_qs), dim, nq, wb + o_p16);
-      if (int rc = panel_sketch ? sketch_pass(safe) : rows_pass(true, safe)) return rc;
+      if (int rc = panel_sketch ? sketch_pass(safe, true) : rows_pass(true, safe)) return rc;
       launch_knn_refine_select(st, (uint32_t)nq, (uint64_t*)(wb + o_xk), (uint32_t*)(wb + o_xc), k_stride, (uint32_t)k,
                                (const uint64_t*)(wb + o_tk), (uint32_t*)(wb + o_tc), ki_stride, (unsigned long long*)(wb + o_th),
                                (uint32_t*)(wb + o_ov), (const DVecSeg*)(wb + o_segs), n_segs, dim, sim, (const float*)(wb + o_q),
@@ -375,10 +382,13 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     //    the bound of the k-th rescored score, and rescores all of them
     int uncertified = 0;
     for (int q = 0; q < nq; ++q) uncertified += ((const uint32_t*)(ho + oh_cert))[q] == 0u;
-    std::vector<uint64_t> th2;
-    if (uncertified) {
-      // the second pass nominates from the fp32 rows (the tight bound): a row of the answer scores >= the k-th rescored score
-      // known so far (or >= min_score while fewer than k are known); certified queries nominate nothing (theta = ~0)
+    // Where: first the sketch again (half the bytes; its bound is wider, so more rows are nominated -- all of them are rescored,
+    // which costs nothing much while they are thousands); if that overflows a list -- the bound reaches down to rows by the
+    // hundred thousand: large norms against small distances -- the fp32 rows with their tight bound, and the next panels of this
+    // similarity go there directly.
+    auto second_theta = [&](const float* bound, std::vector<uint64_t>& th2) {
+      // a row of the answer scores >= the k-th rescored score known so far (or >= min_score while fewer than k are known): the
+      // lowest key its estimate can carry; certified queries nominate nothing (theta = ~0)
       th2.assign((size_t)nq, ~0ull);
       const uint64_t* xk = (const uint64_t*)ho;
       const uint32_t* xc = (const uint32_t*)(ho + oh_cnt);
@@ -386,23 +396,46 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
         if (((const uint32_t*)(ho + oh_cert))[q] != 0u) continue;
         const double base = xc[q] >= (uint32_t)k ? (double)key_score(xk[(size_t)q * k_stride + (size_t)k - 1])
                                                  : (knn_request ? (double)min_score : 0.0);
-        const float lo = (float)knn_estimate_lower(sim, base, (double)eb[(size_t)q], (double)erel, (double)score_boost);
+        const float lo = (float)knn_estimate_lower(sim, base, (double)bound[(size_t)q], (double)erel, (double)score_boost);
         th2[(size_t)q] = lo > 0.0f ? pack_key(lo, 0xFFFFFFFFu) - 1ull : 0ull;
       }
-      if (panel_sketch) ctx->knn_sketch_skip[sim].store(16, std::memory_order_relaxed);
-    }
-    for (int safe = 0; uncertified; ++safe) {
+    };
+    auto second_pass = [&](bool from_sketch, int safe, const std::vector<uint64_t>& th2) -> int {
       if (int rc = take_turn()) return rc;
       HIP_TRY(hipMemcpyAsync(wb + o_th, th2.data(), (size_t)nq * 8, hipMemcpyHostToDevice, st));
       for (int q = 0; q < nq; ++q)   // their answers start over (a nomination found again must not be counted twice)
         if (((const uint32_t*)(ho + oh_cert))[q] == 0u) HIP_TRY(hipMemsetAsync(wb + o_xc + (size_t)q * 4, 0, 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_cc, 0, kKnnMaxQ * 4, st));
       HIP_TRY(hipMemsetAsync(wb + o_ov, 0, 4, st));
-      if (int rc = rows_pass(false, safe)) return rc;
+      if (int rc = from_sketch ? sketch_pass(safe, false) : rows_pass(false, safe)) return rc;
       if (int rc = end_turn()) return rc;
-      if (int rc = fetch()) return rc;   // (the second pass leaves the flags as they are)
-      if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
-      if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
+      return fetch();   // (the second pass leaves the flags as they are)
+    };
+    if (uncertified) {
+      std::vector<uint64_t> th2;
+      bool done = false;
+      if (panel_sketch) {
+        const std::vector<uint32_t> cert0((const uint32_t*)(ho + oh_cert), (const uint32_t*)(ho + oh_cert) + nq);
+        const std::vector<uint64_t> xk0((const uint64_t*)ho, (const uint64_t*)ho + (size_t)nq * k_stride);
+        const std::vector<uint32_t> xc0((const uint32_t*)(ho + oh_cnt), (const uint32_t*)(ho + oh_cnt) + nq);
+        second_theta(eb16, th2);
+        if (int rc = second_pass(true, 0, th2)) return rc;
+        done = *(const uint32_t*)(ho + oh_ov) == 0u;
+        if (!done) {   // back to what the first stage left (the flags are untouched on the device; the host's copies are restored)
+          memcpy(ho, xk0.data(), xk0.size() * 8);
+          memcpy(ho + oh_cnt, xc0.data(), xc0.size() * 4);
+          memcpy(ho + oh_cert, cert0.data(), cert0.size() * 4);
+          ctx->knn_sketch_skip[sim].store(16, std::memory_order_relaxed);
+        }
+      }
+      if (!done) {
+        second_theta(eb, th2);
+        for (int safe = 0;; ++safe) {
+          if (int rc = second_pass(false, safe, th2)) return rc;
+          if (*(const uint32_t*)(ho + oh_ov) == 0u) break;
+          if (safe) return fail(NRTGPU_ERR_HIP, "knn: candidate list overflow in a bounded round");
+        }
+      }
     }
     {
       double ms = 0.0;

@@ -177,9 +177,11 @@ def test_knn_euclidean_near_duplicates_and_large_norms(ctx, oracle):
     g.release()
 
 
-def test_knn_more_equal_rows_than_nominations(ctx, oracle):
+def test_knn_more_equal_rows_than_nominations(oracle):
     """3000 copies of one row, all of them the best match: the nominations (k + max(32, k / 2) rows) cannot certify the answer,
-    the second pass sees every copy, and ties go to the lowest docids as in the oracle.  All four similarities, two leaves."""
+    the second pass sees every copy, and ties go to the lowest docids as in the oracle.  All four similarities, two leaves.
+    The second pass runs from the sketch as well (the fp32 rows are only read when its wider bound overflows a list)."""
+    ctx = api.GpuContext(device_id=0, max_batch=64, collect_timing=True)    # (timing on: the launches are counted by kind)
     rng = np.random.default_rng(7)
     dim, k = 32, 40
     base_rows = rng.standard_normal((5000, dim)).astype(np.float32)
@@ -204,9 +206,12 @@ def test_knn_more_equal_rows_than_nominations(ctx, oracle):
         odocs, oscores, _ = oracle.knn_exact(sim, q[None, :], rows, k, boost=2.0)
         assert got.docs.tolist() == odocs[0].tolist() == where[:k].tolist()
         assert got.scores.view(np.uint32).tolist() == oscores[0].view(np.uint32).tolist()
-        assert ctx.stats()["knn_second_passes"] == 1
+        st = ctx.stats()
+        assert st["knn_second_passes"] == 1
+        assert st["knn_score_launches"] == st["knn_sketch_launches"] == 2   # one nomination launch, one second pass: both from the sketch
         for g in leaves:
             g.release()
+    ctx.close()
 
 
 def test_vector_rescore_matches_queryrescore(ctx, oracle):
