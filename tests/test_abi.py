@@ -337,3 +337,36 @@ def test_packed_posting_word_arithmetic():
     doc = np.array([0, 1, (1 << 20) - 1, 1 << 20, (1 << 20) + 77, 2_600_000 - 1])
     word = ((doc & ((1 << 20) - 1)) << 12) | 5
     assert np.array_equal((word >> 12) | (doc & ~((1 << 20) - 1)), doc) and word.max() < 2**32
+
+
+def test_ctypes_bindings_have_the_arity_the_header_declares(lib):
+    """Every entry point the ctypes binding gives argument types for takes exactly as many arguments as include/nrtgpu.h declares
+    (a binding that lags the header would push garbage through the C ABI), and the Java binding's downcall descriptors agree with
+    the same header where they name the same symbol."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "nrtgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|void|int64_t|const char\*|double)\s+\*?\s*(nrtgpu_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    assert len(protos) > 40
+    checked = 0
+    for name, n_args in protos.items():
+        fn = getattr(lib, name, None)
+        if fn is None or fn.argtypes is None:
+            continue
+        assert len(fn.argtypes) == n_args, f"{name}: the binding passes {len(fn.argtypes)} arguments, the header declares {n_args}"
+        checked += 1
+    assert checked > 30
+    # java/.../NrtGpu.java: h("<symbol>", FunctionDescriptor.of(RET, args...)) / ofVoid(args...)
+    jtext = open(os.path.join(root, "java", "src", "main", "java", "com", "yelp", "nrtsearch", "gpu", "NrtGpu.java")).read()
+    jchecked = 0
+    for m in re.finditer(r'h\("(nrtgpu_\w+)",\s*FunctionDescriptor\.(of|ofVoid)\(([^;]*?)\)\);', jtext, flags=re.S):
+        name, kind, args = m.group(1), m.group(2), [a for a in m.group(3).split(",") if a.strip()]
+        n = len(args) - (1 if kind == "of" else 0)
+        assert name in protos, f"NrtGpu.java binds {name}, which include/nrtgpu.h does not declare"
+        assert n == protos[name], f"NrtGpu.java: {name} takes {n} arguments, the header declares {protos[name]}"
+        jchecked += 1
+    assert jchecked >= 20
