@@ -339,34 +339,69 @@ def test_packed_posting_word_arithmetic():
     assert np.array_equal((word >> 12) | (doc & ~((1 << 20) - 1)), doc) and word.max() < 2**32
 
 
-def test_ctypes_bindings_have_the_arity_the_header_declares(lib):
-    """Every entry point the ctypes binding gives argument types for takes exactly as many arguments as include/nrtgpu.h declares
-    (a binding that lags the header would push garbage through the C ABI), and the Java binding's downcall descriptors agree with
-    the same header where they name the same symbol."""
+def _header_prototypes():
+    """include/nrtgpu.h -> {symbol: (return kind, [argument kinds])}, kinds: "ptr", "i32", "i64", "f32", "f64", "void"."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, "include", "nrtgpu.h")).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+    def kind(decl):
+        decl = decl.strip()
+        if "*" in decl or "[" in decl:
+            return "ptr"
+        base = re.sub(r"\b(const|unsigned)\b", "", decl).split()
+        t = base[0] if base else ""
+        return {"int32_t": "i32", "int": "i32", "uint32_t": "i32", "int64_t": "i64", "uint64_t": "i64", "float": "f32", "double": "f64",
+                "void": "void"}[t]
+
     protos = {}
-    for m in re.finditer(r"\b(?:int|void|int64_t|const char\*|double)\s+\*?\s*(nrtgpu_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
-        args = m.group(2).strip()
-        protos[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    for m in re.finditer(r"(?:^|\n)\s*((?:const\s+)?[\w]+(?:\s*\*)?)\s+(\*?)\s*(nrtgpu_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret = kind(m.group(1) + m.group(2) + " x")
+        args = m.group(4).strip()
+        kinds = [] if args in ("", "void") else [kind(a) for a in args.split(",") if a.strip()]
+        protos[m.group(3)] = (ret, kinds)
+    return protos
+
+
+def test_ctypes_and_java_bindings_pass_what_the_header_declares(lib):
+    """Every entry point the ctypes binding gives argument types for, and every downcall handle of java/.../NrtGpu.java, takes the
+    arguments include/nrtgpu.h declares -- count AND kind (pointer, 32 / 64-bit integer, float, double): a binding that lags the
+    header pushes garbage through the C ABI without any error."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    protos = _header_prototypes()
     assert len(protos) > 40
+
+    def ckind(t):
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_int: "i32", C.c_uint32: "i32", C.c_int64: "i64", C.c_uint64: "i64", C.c_float: "f32",
+                C.c_double: "f64"}[t]
+
     checked = 0
-    for name, n_args in protos.items():
+    for name, (ret, kinds) in protos.items():
         fn = getattr(lib, name, None)
         if fn is None or fn.argtypes is None:
             continue
-        assert len(fn.argtypes) == n_args, f"{name}: the binding passes {len(fn.argtypes)} arguments, the header declares {n_args}"
+        got = [ckind(t) for t in fn.argtypes]
+        assert got == kinds, f"{name}: the ctypes binding passes {got}, the header declares {kinds}"
         checked += 1
     assert checked > 30
     # java/.../NrtGpu.java: h("<symbol>", FunctionDescriptor.of(RET, args...)) / ofVoid(args...)
     jtext = open(os.path.join(root, "java", "src", "main", "java", "com", "yelp", "nrtsearch", "gpu", "NrtGpu.java")).read()
+    jkind = {"ADDRESS": "ptr", "JAVA_INT": "i32", "JAVA_LONG": "i64", "JAVA_FLOAT": "f32", "JAVA_DOUBLE": "f64"}
     jchecked = 0
     for m in re.finditer(r'h\("(nrtgpu_\w+)",\s*FunctionDescriptor\.(of|ofVoid)\(([^;]*?)\)\);', jtext, flags=re.S):
-        name, kind, args = m.group(1), m.group(2), [a for a in m.group(3).split(",") if a.strip()]
-        n = len(args) - (1 if kind == "of" else 0)
+        name, form, args = m.group(1), m.group(2), [a.strip() for a in m.group(3).split(",") if a.strip()]
         assert name in protos, f"NrtGpu.java binds {name}, which include/nrtgpu.h does not declare"
-        assert n == protos[name], f"NrtGpu.java: {name} takes {n} arguments, the header declares {protos[name]}"
+        ret, kinds = protos[name]
+        if form == "of":
+            assert jkind[args[0]] == ret, f"NrtGpu.java: {name} returns {args[0]}, the header says {ret}"
+            args = args[1:]
+        else:
+            assert ret == "void", f"NrtGpu.java: {name} is bound as void, the header says {ret}"
+        assert [jkind[a] for a in args] == kinds, f"NrtGpu.java: {name} passes {args}, the header declares {kinds}"
         jchecked += 1
     assert jchecked >= 20
