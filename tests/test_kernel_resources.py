@@ -1,0 +1,92 @@
+"""What the compiler made of the kernels, checked where they are built (no GPU): registers, scratch and spills of every kernel in
+nrtsearch_amd/libnrtgpu.so, read from the gfx950 code objects (scripts/kernel_resources.py; profiles/rNN_kernel_resources.txt is
+its table).  The hot kernels sit on register edges by design (168 VGPRs = 3 waves per SIMD of a 768-thread
+workgroup; §4.4: 128 = the 16 waves of the sketch kernel's workgroup): a source or compiler change that pushes one over its edge
+shows up as scratch traffic and a lost wave long before a benchmark is read."""
+import fnmatch
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "nrtsearch_amd", "libnrtgpu.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# scratch bytes a kernel may use: nothing, except where the table of profiles/ already shows it and DESIGN names it
+KNOWN_SCRATCH = {
+    "bm25_maxscore_kernel<true, true, *>": 48,        # instrumented (NRTGPU_FLAG_PROFILE_ITEMS) over packed postings: measurement only
+    "bm25_scan_kernel<*, true, 7, false>": 16,        # instrumented scan: measurement only
+    "bm25_scan_kernel<true, true, 8, false>": 16,     # clause counting on the exhaustive route (COMPLETE mode): 2 VGPRs, outside the loop
+    "knn_sketch_kernel<4, 8>": 36,                    # 49-64 queries at a multiple of 256 dims: epilogue values
+}
+VGPR_EDGE = {"bm25_maxscore_kernel<*>": 168, "bm25_scan_kernel<*>": 168, "knn_sketch_kernel<*>": 128, "knn_score_kernel": 128,
+             "knn_select_kernel<*>": 168, "merge_topk_kernel": 168}
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-readelf")) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("the built library or the LLVM binutils are not here")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = mod.kernels_of(LIB)
+    assert len(rows) >= 50, "the code objects of the library were not found"
+    return {r["name"]: r for r in rows}
+
+
+def _allowed(name, table, default):
+    for pat, v in table.items():
+        if fnmatch.fnmatchcase(name, pat):
+            return v
+    return default
+
+
+def test_every_kernel_is_named_and_the_routes_are_all_there(kernels):
+    for must in ("bm25_maxscore_kernel<false, false, false>", "bm25_maxscore_kernel<false, true, true>", "bm25_scan_kernel<true, true, 0, false>",
+                 "bm25_scan_kernel<true, true, 9, true>", "knn_sketch_kernel<1, 4>", "knn_sketch_kernel<4, 8>", "knn_select_kernel<true>",
+                 "knn_score_kernel", "merge_topk_kernel", "hybrid_rescore_kernel", "knn_sketch_build_kernel", "knn_panel_fp16_kernel"):
+        assert must in kernels, f"{must} is not in the library (or its name was not understood): {sorted(kernels)[:5]} ..."
+
+
+def test_no_kernel_uses_scratch_it_is_not_known_to_use(kernels):
+    bad = []
+    for name, r in kernels.items():
+        allowed = _allowed(name, KNOWN_SCRATCH, 0)
+        if r["scratch"] > allowed:
+            bad.append(f"{name}: {r['scratch']} B of scratch, {r['vgpr_spills']} VGPRs spilled (allowed {allowed})")
+        if allowed == 0:
+            assert r["vgpr_spills"] == 0, f"{name} spills {r['vgpr_spills']} VGPRs"
+    assert not bad, "\n".join(bad)
+
+
+def test_hot_kernels_keep_their_occupancy(kernels):
+    """The workgroup shapes fix the register budget: 12 waves per CU = 3 per SIMD for the BM25 kernels (512 / 3 -> 168 VGPRs),
+    16 waves = 4 per SIMD for the sketch kernel (128).  More registers than that and the workgroup does not launch at all
+    (__launch_bounds__ would have failed the build); the point here is that nothing drifted BELOW the designed occupancy either."""
+    for name, r in kernels.items():
+        edge = _allowed(name, VGPR_EDGE, None)
+        if edge is None:
+            continue
+        assert r["vgpr"] + r["agpr"] <= edge, f"{name}: {r['vgpr']} + {r['agpr']} registers, designed for {edge}"
+    # the default BM25 route and the exact-kNN pass at up to 48 queries: not one byte of scratch
+    for name in ("bm25_maxscore_kernel<false, false, false>", "bm25_maxscore_kernel<false, true, false>", "bm25_maxscore_kernel<false, false, true>",
+                 "bm25_scan_kernel<true, true, 0, false>", "knn_sketch_kernel<1, 8>", "knn_sketch_kernel<2, 8>", "knn_sketch_kernel<3, 8>",
+                 "knn_select_kernel<true>"):
+        assert kernels[name]["scratch"] == 0 and kernels[name]["vgpr_spills"] == 0, name
+
+
+def test_the_committed_table_is_the_built_library(kernels):
+    """profiles/r03_kernel_resources.txt is this build's table (re-run scripts/kernel_resources.py after a kernel change)."""
+    path = os.path.join(ROOT, "profiles", "r03_kernel_resources.txt")
+    seen = {}
+    for line in open(path):
+        if line.startswith("#") or not line.strip():
+            continue
+        # name (may hold spaces inside <...>), then 9 numeric / a-b columns
+        parts = line.rstrip("\n").rsplit(None, 9)
+        seen[parts[0].strip()] = (int(parts[1]), int(parts[5]))
+    assert set(seen) == set(kernels), sorted(set(seen) ^ set(kernels))
+    for name, (vgpr, scratch) in seen.items():
+        assert (vgpr, scratch) == (kernels[name]["vgpr"], kernels[name]["scratch"]), f"{name}: table {vgpr, scratch}, library {kernels[name]['vgpr'], kernels[name]['scratch']}"
