@@ -500,7 +500,12 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
     const float leaf_inv = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lf.inv_rows_scale)));
     const int32_t* const ord_to_doc = (const int32_t*)u_o2d;
     const uint64_t* const live_bits = (const uint64_t*)u_accept;
+#ifdef NRT_KNN_SCALAR_NORMS   // A/B build (build.py extra=[...]): profiles/r03_knn_sketch_isa_note.txt -- the constant address space makes
+    typedef const float __attribute__((address_space(4))) cfloat_k;   // the tile's norms scalar loads again; the default until a GPU run says so:
+    cfloat_k* const vnorm2 = (cfloat_k*)u_norms;
+#else
     const float* const vnorm2 = (const float*)u_norms;
+#endif
     const int64_t t0 = t_run - leaf_t0, t1 = min(t_run_end, leaf_t0 + (((int64_t)leaf_rows + 15) >> 4)) - leaf_t0;   // local tiles
     // the run as groups of D pieces (a tile is steps / D whole groups): `cur` walks the groups, the ring slot of piece i of a
     // group is i, and the piece D ahead -- the same slot of the NEXT group -- is requested the moment slot i has been consumed

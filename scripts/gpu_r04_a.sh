@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round 4, FIRST call (prepared at the end of round 3, when the GPU minutes were spent): the sketch kernel with the tile norms back
+# in the scalar cache (profiles/r03_knn_sketch_isa_note.txt; knn.hip: -DNRT_KNN_SCALAR_NORMS).  The A/B library is built ON THE BOX
+# (same image, same hipcc) next to the shipped one; NRTGPU_LIB_PATH selects it.
+#   1. the vector parity tests + the kNN fuzz against the A/B library (bit-exact or it does not go in);
+#   2. C4 at 1 / 32 / 64 queries and the 1/8 share with both libraries, same box, interleaved;
+#   3. kernel trace of both (the sketch kernel's average launch).
+# -> gpurun_out/r04/a.  If 1 is green and 2 is not slower: make the cast the only code path (drop the macro), rebuild, re-run
+# scripts/kernel_resources.py > profiles/r04_kernel_resources.txt and drop `knn_sketch_kernel<4, 8>` from
+# tests/test_kernel_resources.py: KNOWN_SCRATCH.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOT=$(pwd); export TMPDIR=/tmp
+O=$ROOT/gpurun_out/r04/a; mkdir -p $O
+export NRTGPU_BENCH_WATCHDOG=110
+T0=$(date +%s)
+AB=/tmp/libnrtgpu_scalar_norms.so
+timeout 300 python - <<'PY' 2>&1 | tail -2
+from nrtsearch_amd import build
+print(build.build(force=True, extra=["-DNRT_KNN_SCALAR_NORMS"], out="/tmp/libnrtgpu_scalar_norms.so"))
+PY
+[ -f $AB ] || { echo "A/B build failed"; exit 1; }
+python scripts/kernel_resources.py $AB | grep "sketch_kernel" | tee $O/ab_kernel_resources.txt
+echo "== parity on the A/B library ($(( $(date +%s) - T0 )) s)"
+NRTGPU_LIB_PATH=$AB NRT_KNN_FUZZ_ROUNDS=64 timeout 600 python -m pytest tests/test_vectors_gpu.py tests/test_fuzz_gpu.py::test_fuzz_exact_vector_search tests/test_baseline_sizes_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider > $O/pytest_ab.log 2>&1
+echo "pytest (A/B) rc=$?"; grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr" $O/pytest_ab.log | tail -6 | cut -c1-300
+NRTGPU_LIB_PATH=$AB timeout 120 python __graft_entry__.py smoke 2>&1 | tail -1
+show() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(sys.argv[1], d['value'], d['ms_per_step'], r['kernel'], r['avg_launch_ms'], r['frac'])" "$1" 2>/dev/null || echo "$1 FAILED"; }
+echo "== C4, shipped vs A/B, interleaved ($(( $(date +%s) - T0 )) s)"
+for rep in 1 2; do
+  for q in 1 32 64; do
+    st=$([ $q = 1 ] && echo 120 || echo 40)
+    timeout 200 python bench.py --workload C4 --knn-queries $q --steps $st --warmup 3 --no-cpu-baseline --no-verify --closed-loop "" 2>/dev/null | tee $O/c4_q${q}_shipped_$rep.json | show "q$q shipped"
+    NRTGPU_LIB_PATH=$AB timeout 200 python bench.py --workload C4 --knn-queries $q --steps $st --warmup 3 --no-cpu-baseline --no-verify --closed-loop "" 2>/dev/null | tee $O/c4_q${q}_ab_$rep.json | show "q$q a/b"
+  done
+done
+timeout 100 python bench.py --workload C4 --emulate-world 8 --knn-queries 32 --steps 40 --warmup 3 --no-cpu-baseline --no-verify 2>/dev/null | tee $O/c4_emu8_shipped.json | show "emu8 shipped"
+NRTGPU_LIB_PATH=$AB timeout 100 python bench.py --workload C4 --emulate-world 8 --knn-queries 32 --steps 40 --warmup 3 --no-cpu-baseline --no-verify 2>/dev/null | tee $O/c4_emu8_ab.json | show "emu8 a/b"
+echo "== kernel traces ($(( $(date +%s) - T0 )) s)"
+cd /tmp
+for v in shipped ab; do
+  rm -rf /tmp/prof_$v
+  [ $v = ab ] && export NRTGPU_LIB_PATH=$AB || unset NRTGPU_LIB_PATH
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o c4 --output-format csv -- python $ROOT/bench.py --workload C4 --knn-queries 64 --steps 10 --warmup 2 --no-cpu-baseline --no-verify --closed-loop "" > /tmp/prof_$v.log 2>&1
+  find /tmp/prof_$v -name "*kernel_stats*" -exec cp {} $O/c4_q64_kernel_stats_$v.csv \;
+  echo "$v:"; grep "knn_" $O/c4_q64_kernel_stats_$v.csv | cut -c1-50,150-330
+done
+unset NRTGPU_LIB_PATH
+cd $ROOT
+echo "== done ($(( $(date +%s) - T0 )) s) =="
