@@ -1130,7 +1130,10 @@ void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t
   if (n_dense == 0) return;
   uint32_t chunks = (max_count + 256u * 16u - 1u) / (256u * 16u);
   chunks = chunks < 1u ? 1u : (chunks > 1024u ? 1024u : chunks);
-  hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n_dense), dim3(256), 0, stream, docids, t_start, t_count, t_rec, dense, recs);
+  for (uint32_t off = 0; off < n_dense; off += 65535u) {   // (gridDim.y holds 65535 at most)
+    const uint32_t n = n_dense - off < 65535u ? n_dense - off : 65535u;
+    hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, t_start, t_count, t_rec, dense + off, recs);
+  }
 }
 
 }  // namespace nrtgpu
