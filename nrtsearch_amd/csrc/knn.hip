@@ -491,7 +491,7 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
   const int64_t t_run_end = tile_begin + n_tiles * (w + 1) / n_waves;
   int32_t li = t_run < t_run_end ? knn_leaf_of_tile(leaves, n_leaves, t_run) : 0;
   while (t_run < t_run_end) {   // (a wave without tiles still meets the others at the queue's barrier)
-    // the leaf, as scalars: its pointers feed scalar loads and the ring's base
+    // the leaf, as scalars: its pointers feed the ring's base and uniform loads
     const DKnnLeaf& lf = leaves[li];
     const uint64_t u_sketch = uniform_u64((uint64_t)lf.sketch), u_norms = uniform_u64((uint64_t)lf.vnorm2);
     const uint64_t u_o2d = uniform_u64((uint64_t)lf.ord_to_doc), u_accept = uniform_u64((uint64_t)lf.accept);
@@ -500,8 +500,12 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
     const float leaf_inv = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lf.inv_rows_scale)));
     const int32_t* const ord_to_doc = (const int32_t*)u_o2d;
     const uint64_t* const live_bits = (const uint64_t*)u_accept;
-#ifdef NRT_KNN_SCALAR_NORMS   // A/B build (build.py extra=[...]): profiles/r03_knn_sketch_isa_note.txt -- the constant address space makes
-    typedef const float __attribute__((address_space(4))) cfloat_k;   // the tile's norms scalar loads again; the default until a GPU run says so:
+    // The norms' pointer.  Rebuilt from the leaf record it is a GENERIC pointer to the compiler, which then loads a tile's norms
+    // with flat VECTOR loads (vmcnt) and drains the ring at the tile's first use of one -- what the build does today.  In the
+    // constant address space the same loads are scalar (s_load, lgkmcnt) as they were before the leaf table: compiled and read,
+    // not yet run (profiles/r03_knn_sketch_isa_note.txt; build.py extra=["-DNRT_KNN_SCALAR_NORMS"], scripts/gpu_r04_a.sh).
+#ifdef NRT_KNN_SCALAR_NORMS
+    typedef const float __attribute__((address_space(4))) cfloat_k;
     cfloat_k* const vnorm2 = (cfloat_k*)u_norms;
 #else
     const float* const vnorm2 = (const float*)u_norms;
@@ -523,8 +527,8 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
       sk_request<3072>(abuf[D - 1], cur + 256);
     }
     for (int64_t tile = t0; tile < t1; ++tile) {
-      // |v|^2 of the tile's 16 rows: the tile is the same for the whole wave, so they come through the SCALAR cache (s_load,
-      // counted by lgkmcnt, not by the ring's vmcnt)
+      // |v|^2 of the tile's 16 rows: the tile is the same for the whole wave, so they are meant to come through the SCALAR
+      // cache (s_load, counted by lgkmcnt, not by the ring's vmcnt) -- see the note at `vnorm2` above
       const uint32_t t_lo = __builtin_amdgcn_readfirstlane((uint32_t)(tile & 0xFFFFFFFFll));
       const uint32_t t_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tile >> 32));
       const int64_t u_r0 = (int64_t)(((uint64_t)t_hi << 32) | t_lo) << 4;
