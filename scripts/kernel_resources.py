@@ -79,6 +79,32 @@ def waves_per_simd(vgpr, agpr, lds, wg_size):
     return by_regs
 
 
+def disassembly_of(lib, only=None):
+    """{short kernel name: [instruction lines]} of the gfx950 code objects in `lib` (`only`: a substring the MANGLED name must hold)."""
+    out, mangled = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(lib))
+        shutil.copy(lib, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(tmp, f)], text=True, capture_output=True, check=True).stdout
+            cur = None
+            for line in dis.split("\n"):
+                mm = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+                if mm:
+                    cur = mm.group(1) if (only is None or only in mm.group(1)) else None
+                    if cur:
+                        mangled[cur] = []
+                elif cur and line.startswith("\t"):
+                    mangled[cur].append(line.strip().split("//")[0].strip())
+    names = list(mangled)
+    for m, d in zip(names, demangle(names)):
+        out[short(d)] = mangled[m]
+    return out
+
+
 def kernels_of(lib):
     """[{name, vgpr, agpr, sgpr, lds, scratch, vgpr_spills, sgpr_spills, wg_size, waves}] for every kernel in `lib`."""
     import yaml
