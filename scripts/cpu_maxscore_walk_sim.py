@@ -21,6 +21,7 @@ WIN = 64 * 1024
 WAVES = 12
 CAP = 2304
 INSTR = 512
+BLOCK_SHIFTS = [int(x) for x in os.environ.get("BLOCK_SHIFTS", "").split(",") if x]   # e.g. 16,13,10,7
 
 
 class Item:
@@ -64,9 +65,11 @@ def window_instructions(D, lo_hi, clauses):
     return [(cl[i: i + INSTR], ix[i: i + INSTR]) for i in range(0, len(cl), INSTR)]
 
 
-def run_walk(it, D, Sc, dense, S, N, stream, mark_only=()):
+def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None):
     """One sweep over all windows.  stream: clauses that may be streamed (when essential); mark_only: clauses whose postings only set
-    the seen bits (already handled by an earlier sweep)."""
+    the seen bits (already handled by an earlier sweep).  blk = (shift, Sblk): bounds per block of 2^shift docs -- Sblk[j][b] = what
+    the clauses j.. can add at most to a doc of block b (their largest scores INSIDE the block) -- instead of the corpus-wide S[j]
+    in the per-posting bound and before each lookup (which clauses are streamed is still decided by S)."""
     n_terms = len(D)
     n_win = (N + WIN - 1) // WIN
     next_win = [0]
@@ -102,7 +105,7 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=()):
                 continue
             it.n["postings"] += len(docs)
             s = Sc[c][idx]
-            alive = s + S[c + 1] >= theta
+            alive = s + (S[c + 1] if blk is None else blk[1][c + 1][docs >> blk[0]]) >= theta
             docs, s = docs[alive], s[alive]
             it.n["survivors"] += len(docs)
             rel = docs - ws["w0"]
@@ -112,7 +115,7 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=()):
             it.n["docs"] += len(docs)
             live = np.ones(len(docs), dtype=bool)
             for j in range(c + 1, n_terms):
-                live &= run + S[j] >= theta
+                live &= run + (S[j] if blk is None else blk[1][j][docs >> blk[0]]) >= theta
                 if not live.any():
                     break
                 it.n["lookups"] += int(live.sum())
@@ -178,6 +181,17 @@ def main():
         if S[2] >= b.theta:                                        # something beyond the two rarest clauses is still essential
             run_walk(b, D, Sc, dense, S, N, stream=list(range(2, len(D))), mark_only=(0, 1))
         res["two sweeps"] = b
+        # bounds per block of docs for the clauses after the first (Lucene's block-max idea on doc ranges): how many fewer docs?
+        for shift in BLOCK_SHIFTS:
+            nb = (N >> shift) + 1
+            suf = [np.zeros(nb) for _ in range(len(D) + 1)]
+            for j in range(len(D) - 1, -1, -1):
+                bm = np.zeros(nb)
+                np.maximum.at(bm, D[j] >> shift, Sc[j])
+                suf[j] = suf[j + 1] + bm
+            bk = Item(k)
+            run_walk(bk, D, Sc, dense, S, N, stream=list(range(len(D))), blk=(shift, suf))
+            res[f"block bounds 2^{shift}"] = bk
         # calibration against profiles/r02_seed_experiment.log (kernel time with theta seeded at f x the final k-th score:
         # f = 1: -22 %, 0.9: -11 %, 0.7: -3 %): the kernel's order started from such a seed
         acc = np.zeros(N, dtype=np.float64)
