@@ -19,7 +19,8 @@ from nrtsearch_amd import _lib, synth, workload   # noqa: E402
 
 WIN = 64 * 1024
 WAVES = 12
-CAP = 2304
+CAP = int(os.environ.get("CAND_CAP", "2304"))     # the workgroup's candidate buffer (keys); a compaction keeps the k best
+ONLY_KERNEL_ORDER = os.environ.get("ONLY_KERNEL_ORDER", "") != ""
 INSTR = 512
 BLOCK_SHIFTS = [int(x) for x in os.environ.get("BLOCK_SHIFTS", "").split(",") if x]   # e.g. 16,13,10,7
 
@@ -175,6 +176,12 @@ def main():
         a = Item(k)
         run_walk(a, D, Sc, dense, S, N, stream=list(range(len(D))))
         res["kernel order"] = a
+        if ONLY_KERNEL_ORDER:
+            print(f"q{qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}", flush=True)
+            t = tot.setdefault("kernel order", {})
+            for kk, v in a.n.items():
+                t[kk] = t.get(kk, 0) + v
+            continue
         b = Item(k)
         run_walk(b, D, Sc, dense, S, N, stream=[0, 1])
         theta_1 = b.theta
@@ -217,6 +224,8 @@ def main():
     # A linear reading of the seed experiment: time ~ F groups + a postings + b docs + c lookups, non-negative weights fitted to
     # the three measured ratios; what it says about the two sweeps (an indication: 3 equations, 4 unknowns -> least norm)
     try:
+        if ONLY_KERNEL_ORDER:
+            raise RuntimeError("kernel order only")
         from scipy.optimize import nnls
         keys = ("groups", "postings", "docs", "lookups")
         base = np.array([tot["kernel order"][kk] for kk in keys], dtype=np.float64)
