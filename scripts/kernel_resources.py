@@ -18,8 +18,13 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def demangle(names):
-    out = subprocess.run(["c++filt"], input="\n".join(names), text=True, capture_output=True, check=True).stdout
-    return out.split("\n")[: len(names)]
+    if not names:
+        return []
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(names), text=True, capture_output=True, check=True).stdout
+        return out.split("\n")[: len(names)]
+    except (OSError, subprocess.CalledProcessError):   # no binutils here: short() falls back to by_hand() for mangled names
+        return list(names)
 
 
 def by_hand(mangled):
