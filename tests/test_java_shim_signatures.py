@@ -258,3 +258,24 @@ def test_exact_vector_query_accessors():
     assert 0 in patched.arities("getQueryVector")
     shim = open(os.path.join(SHIM, "GpuEligibility.java")).read()
     assert "evq.getField()" in shim and "evq.getQueryVector()" in shim
+
+
+def test_java_sources_are_lexically_whole():
+    """No JDK here: the least a file can promise is that its braces, parentheses and brackets pair up outside comments and
+    literals, that it declares the package of its directory and a top-level type named like the file."""
+    files = sorted(glob.glob(os.path.join(ROOT, "java", "src", "main", "java", "**", "*.java"), recursive=True)
+                   + glob.glob(os.path.join(ROOT, "bench", "lucene", "*.java")))
+    assert len(files) >= 9
+    for f in files:
+        src = open(f).read()
+        s = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        s = re.sub(r"//[^\n]*", "", s)
+        s = re.sub(r'"(\\.|[^"\\])*"', '""', s)
+        s = re.sub(r"'(\\.|[^'\\])'", "''", s)
+        for a, b in ("{}", "()", "[]"):
+            assert s.count(a) == s.count(b), f"{os.path.relpath(f, ROOT)}: {s.count(a)} '{a}' against {s.count(b)} '{b}'"
+        name = os.path.splitext(os.path.basename(f))[0]
+        assert re.search(r"\b(class|interface|record|enum)\s+" + name + r"\b", s), f"{os.path.relpath(f, ROOT)}: no top-level type {name}"
+        if os.sep + "java" + os.sep + "src" + os.sep in f:
+            pkg = os.path.relpath(os.path.dirname(f), os.path.join(ROOT, "java", "src", "main", "java")).replace(os.sep, ".")
+            assert re.search(r"^\s*package\s+" + re.escape(pkg) + r"\s*;", s, flags=re.M), f"{os.path.relpath(f, ROOT)}: package {pkg} expected"
