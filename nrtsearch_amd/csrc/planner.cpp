@@ -248,7 +248,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
                             const int32_t* slice_of_leaf, int32_t n_slices, const nrtgpu_bm25_query* queries, int q_begin, int q_end, PlanPiece& pc, uint32_t* q_qs_begin,
                             uint32_t* q_qs_cnt, uint32_t* qs_begin, DQExpand* qexpand,
                             std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, int prune,
-                            std::vector<int64_t>& q_lower, std::vector<uint8_t>& q_route) {
+                            std::vector<int64_t>& q_lower, std::vector<uint8_t>& q_route, std::vector<int64_t>& q_ms_key) {
   std::vector<int64_t> term_total;
   std::vector<int32_t> tab_of_term, term_scale;
   std::vector<const TermLeaves*> ents;
@@ -355,6 +355,21 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     }
     q_lower[(size_t)qi] = lower;
     q_route[(size_t)qi] = route;
+    {
+      // What a MaxScore item costs follows the docs it EVALUATES, not the postings of its clauses: the dense clauses of a query
+      // are non-essential almost from the start and never streamed.  Over 156 C3 queries the walk model's cost correlates +0.26
+      // with all postings and +0.84 with the postings of the two heaviest clauses (scripts/cpu_launch_order_sim.py): the key
+      // build_plan orders that route's items by when NRTGPU_MS_LPT is set (waits for its GPU run).
+      int64_t p0 = 0, p1 = 0;
+      float w0 = -1.0f, w1 = -1.0f;
+      for (int t = 0; t < q.n_terms; ++t) {
+        if (term_total[(size_t)t] == 0) continue;
+        const float wt = q.terms[t].weight;
+        if (wt > w0) { w1 = w0; p1 = p0; w0 = wt; p0 = term_total[(size_t)t]; }
+        else if (wt > w1) { w1 = wt; p1 = term_total[(size_t)t]; }
+      }
+      q_ms_key[(size_t)qi] = p0 + p1;
+    }
     tab_of_term.assign((size_t)q.n_terms, -1);
     QTabs& qt_ = qtabs[(size_t)qi];
     qt_.n = 0;
@@ -449,6 +464,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   }
   hp.q_lower.assign((size_t)n_queries, 0);
   hp.q_route.assign((size_t)n_queries, kRouteScan);
+  std::vector<int64_t> q_ms_key((size_t)n_queries, 0);   // (resolve_queries: launch-order key of the query's MaxScore items)
   hp.lsc = leaf_set_cache(ctx, segs, n_segs);
   hp.n_leaves = (uint32_t)n_segs;
   hp.qexpand.resize((size_t)n_queries);
@@ -475,7 +491,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   }
   auto work = [&](int t) {
     resolve_queries(*hp.lsc, segs, n_segs, n_deleted.data(), slice_of_leaf.data(), n_slices, queries, chunk_begin(t), chunk_begin(t + 1), pieces[(size_t)t],
-                    q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower, hp.q_route);
+                    q_qs_begin.data(), q_qs_cnt.data(), hp.qs_begin.data(), hp.qexpand.data(), cache_base, qtabs, prune, hp.q_lower, hp.q_route, q_ms_key);
   };
   ctx->pool->run(n_thr, work);
   const double tp1 = plan_trace ? now_ms() : 0.0;
@@ -666,6 +682,14 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // longest-processing-time-first launch order: the hardware dispatcher hands out workgroups in
   // index order, so big items start first and small ones fill the tail
   // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
+  {
+    // (off unless asked for: the order the round's measurements were taken with stays the default until this one has had its run)
+    static const bool ms_lpt = getenv("NRTGPU_MS_LPT") != nullptr && atoi(getenv("NRTGPU_MS_LPT")) != 0;
+    if (ms_lpt)
+      for (Pending& a : pend)
+        if (on_ms_kernel(a.query) && q_costs[(size_t)a.query] > 0)   // an item's share of its query's key
+          a.cost = 1 + (int64_t)((double)q_ms_key[(size_t)a.query] * ((double)a.cost / (double)q_costs[(size_t)a.query]));
+  }
   std::stable_sort(pend.begin(), pend.end(), [](const Pending& a, const Pending& b) { return a.cost > b.cost; });
   // the items of the queries on the MaxScore route first: they run in a launch of their own
   std::stable_partition(pend.begin(), pend.end(), [&](const Pending& a) { return on_ms_kernel(a.query); });

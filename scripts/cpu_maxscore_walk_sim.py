@@ -8,7 +8,7 @@ test-and-set per doc, S_j re-checked before each lookup, S of an instruction's f
 simplifications: one segment per item, a clause's bound = its largest score in the corpus, scores in fp64, ties ignored, the 12
 waves advance one instruction per tick.  (a)'s counts are to be held against profiles/r03_kernel_shapes.log -- per query 590
 instruction groups, 262 k postings streamed, 166 k docs evaluated, 248 k lookups -- before (b)'s are believed.
-    python scripts/cpu_maxscore_walk_sim.py [n_queries=8]"""
+    python scripts/cpu_maxscore_walk_sim.py [n_queries=8] [first_query=0]     (ONLY_KERNEL_ORDER=1: the kernel's order alone)"""
 import os
 import sys
 
@@ -144,9 +144,10 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None):
 
 def main():
     nq = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0         # queries [first, first + nq) of the bench's query set
     w = workload.C3
     N, k = w.n_docs, w.k
-    qr = synth.make_queries(nq, w.n_terms, w.max_rank)
+    qr = synth.make_queries(first + nq, w.n_terms, w.max_rank)[first:]
     lens = synth.doc_lengths(N)
     norms = synth.int_to_byte4(lens)
     avgdl = np.float32(int(lens.astype(np.int64).sum()) / N)
@@ -177,7 +178,7 @@ def main():
         run_walk(a, D, Sc, dense, S, N, stream=list(range(len(D))))
         res["kernel order"] = a
         if ONLY_KERNEL_ORDER:
-            print(f"q{qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}", flush=True)
+            print(f"q{first + qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}", flush=True)
             t = tot.setdefault("kernel order", {})
             for kk, v in a.n.items():
                 t[kk] = t.get(kk, 0) + v
@@ -211,7 +212,7 @@ def main():
             sd.theta = f * theta_final * (1 - 1e-12)
             run_walk(sd, D, Sc, dense, S, N, stream=list(range(len(D))))
             res[f"seed {f:.1f} x"] = sd
-        print(f"q{qi} df {[len(d) for d in D]} P {P}", flush=True)
+        print(f"q{first + qi} df {[len(d) for d in D]} P {P}", flush=True)
         for name, it in res.items():
             extra = f" theta after sweep 1: {theta_1:.3f}" if name == "two sweeps" else ""
             print(f"   {name:13s} theta {it.theta:.3f} {it.n}{extra}", flush=True)
