@@ -82,6 +82,34 @@ def main():
     print("makespan of 1024 items on 256 CUs / balanced load (20 draws: mean, min-max):")
     for name, v in res.items():
         print(f"  {np.mean(v):.3f}  ({min(v):.3f}-{max(v):.3f})  longest-first by {name}")
+    # Cutting the heavy queries: the walk model prices a query cut into two items over halves of its doc range, each warming
+    # up its own theta (the pessimistic end), at 0.53-0.58 of the whole per half (SPLIT_ITEMS=2 on the four heaviest queries).
+    # Rule: the key (two heaviest clauses) predicts the cost by a straight line; a query predicted above T x the mean goes in
+    # n = ceil(prediction / T) items of (1 / n) x 1.14 of its cost each; order: longest-first by the predicted item cost.
+    key = keys["postings of the 2 rarest clauses"]
+    A = np.stack([key, np.ones(len(key))], axis=1)
+    coef, *_ = np.linalg.lstsq(A, cost, rcond=None)
+    pred = A @ coef
+    print(f"the key as a predictor: cost ~ {coef[0] * key.mean():.2f} x key / mean key + {coef[1]:.2f}; relative error of the prediction, p50 / p90: "
+          f"{np.median(np.abs(pred - cost) / cost):.2f} / {np.percentile(np.abs(pred - cost) / cost, 90):.2f}")
+    print("with heavy queries cut (balanced load = the UNCUT batch's: the cuts' overhead counts against them):")
+    for T in (4.0, 3.0, 2.5, 2.0, 1.5):
+        out, n_items = [], []
+        rng = np.random.default_rng(7)
+        for trial in range(20):
+            pick = rng.integers(0, len(rows), 1024)
+            c, pr = cost[pick], pred[pick]
+            balanced = c.sum() / 256
+            ic, ip = [], []
+            for ci, pi in zip(c, pr):
+                n = max(1, int(np.ceil(pi / T)))
+                f = 1.0 if n == 1 else 1.14 / n
+                ic += [ci * f] * n
+                ip += [pi / n] * n
+            ic, ip = np.array(ic), np.array(ip)
+            out.append(makespan(ic, np.argsort(-ip, kind="stable")) / balanced)
+            n_items.append(len(ic))
+        print(f"  {np.mean(out):.3f}  ({min(out):.3f}-{max(out):.3f})  cut above {T} x the mean: {np.mean(n_items):.0f} items")
 
 
 main()

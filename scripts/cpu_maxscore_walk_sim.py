@@ -21,6 +21,7 @@ WIN = 64 * 1024
 WAVES = 12
 CAP = int(os.environ.get("CAND_CAP", "2304"))     # the workgroup's candidate buffer (keys); a compaction keeps the k best
 ONLY_KERNEL_ORDER = os.environ.get("ONLY_KERNEL_ORDER", "") != ""
+SPLIT_ITEMS = int(os.environ.get("SPLIT_ITEMS", "0"))   # > 1: also the query cut into that many items over equal doc ranges
 INSTR = 512
 BLOCK_SHIFTS = [int(x) for x in os.environ.get("BLOCK_SHIFTS", "").split(",") if x]   # e.g. 16,13,10,7
 
@@ -66,7 +67,7 @@ def window_instructions(D, lo_hi, clauses):
     return [(cl[i: i + INSTR], ix[i: i + INSTR]) for i in range(0, len(cl), INSTR)]
 
 
-def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None):
+def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None, win_range=None):
     """One sweep over all windows.  stream: clauses that may be streamed (when essential); mark_only: clauses whose postings only set
     the seen bits (already handled by an earlier sweep).  blk = (shift, Sblk): bounds per block of 2^shift docs -- Sblk[j][b] = what
     the clauses j.. can add at most to a doc of block b (their largest scores INSIDE the block) -- instead of the corpus-wide S[j]
@@ -74,6 +75,8 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None):
     n_terms = len(D)
     n_win = (N + WIN - 1) // WIN
     next_win = [0]
+    if win_range is not None:                                     # an item over a part of the doc range: windows [g0, g1)
+        next_win[0], n_win = win_range[0], min(win_range[1], n_win)
     waves = [None] * WAVES
 
     def open_window(g):
@@ -177,6 +180,16 @@ def main():
         a = Item(k)
         run_walk(a, D, Sc, dense, S, N, stream=list(range(len(D))))
         res["kernel order"] = a
+        if SPLIT_ITEMS > 1:   # the query as several items over equal doc ranges, each with a theta of its own (the pessimistic end:
+            #                   the kernel's items of a query read each other's theta once per window)
+            n_win = (N + WIN - 1) // WIN
+            parts = []
+            for pi in range(SPLIT_ITEMS):
+                sp = Item(k)
+                run_walk(sp, D, Sc, dense, S, N, stream=list(range(len(D))), win_range=(n_win * pi // SPLIT_ITEMS, n_win * (pi + 1) // SPLIT_ITEMS))
+                parts.append(sp.n)
+            print(f"q{first + qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}   split {SPLIT_ITEMS}: {parts}", flush=True)
+            continue
         if ONLY_KERNEL_ORDER:
             print(f"q{first + qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}", flush=True)
             t = tot.setdefault("kernel order", {})
