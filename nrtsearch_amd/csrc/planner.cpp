@@ -359,7 +359,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
       // What a MaxScore item costs follows the docs it EVALUATES, not the postings of its clauses: the dense clauses of a query
       // are non-essential almost from the start and never streamed.  Over 156 C3 queries the walk model's cost correlates +0.26
       // with all postings and +0.84 with the postings of the two heaviest clauses (scripts/cpu_launch_order_sim.py): the key
-      // build_plan orders that route's items by when NRTGPU_MS_LPT is set (waits for its GPU run).
+      // build_plan orders that route's items by.
       int64_t p0 = 0, p1 = 0;
       float w0 = -1.0f, w1 = -1.0f;
       for (int t = 0; t < q.n_terms; ++t) {
@@ -683,8 +683,10 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // index order, so big items start first and small ones fill the tail
   // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
   {
-    // (off unless asked for: the order the round's measurements were taken with stays the default until this one has had its run)
-    static const bool ms_lpt = getenv("NRTGPU_MS_LPT") != nullptr && atoi(getenv("NRTGPU_MS_LPT")) != 0;
+    // The MaxScore items' longest-first key: the postings of the query's two heaviest clauses (resolve_queries) instead of all
+    // its postings.  Results do not depend on the launch order (an item's output slot is assigned after the sort);
+    // NRTGPU_MS_LPT=0 restores the order round 3's profiles were measured with.
+    static const bool ms_lpt = getenv("NRTGPU_MS_LPT") == nullptr || atoi(getenv("NRTGPU_MS_LPT")) != 0;
     if (ms_lpt)
       for (Pending& a : pend)
         if (on_ms_kernel(a.query) && q_costs[(size_t)a.query] > 0)   // an item's share of its query's key
@@ -742,6 +744,20 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     dq.gte_floor = q.total_hits_threshold == INT32_MAX ? 0xFFFFFFFFu : (uint32_t)std::max(q.total_hits_threshold, q.k);
     dq.slice_base = (uint32_t)qi * hp.n_slices;
     dq.pad[0] = dq.pad[1] = 0;
+  }
+  if (plan_trace) {   // the items as a SET (order-free) and in launch order: two plans of one batch under different launch orders agree on the first
+    uint64_t h_set = 0, h_order = 0;
+    for (size_t i = 0; i < hp.items.size(); ++i) {
+      const DItem& it = hp.items[i];
+      uint64_t h = ((uint64_t)it.query << 40) ^ ((uint64_t)it.part_begin << 12) ^ (uint64_t)it.n_parts ^ ((uint64_t)it.flags << 60);
+      h *= 0x9E3779B97F4A7C15ull;
+      h ^= h >> 29;
+      h_set += h;
+      h_order = (h_order ^ h) * 0x100000001B3ull;
+    }
+    fprintf(stderr, "[nrtgpu plan] items as a set %016llx, in launch order %016llx; first items' queries:", (unsigned long long)h_set, (unsigned long long)h_order);
+    for (size_t i = 0; i < hp.items.size() && i < 8; ++i) fprintf(stderr, " %u", hp.items[i].query);
+    fprintf(stderr, "\n");
   }
   if (plan_trace)
     fprintf(stderr, "[nrtgpu plan] %d queries: resolve %.3f ms (%d threads), concat %.3f, cut+items %.3f; %zu terms %zu parts %zu items\n",

@@ -5,7 +5,8 @@
 #   1. the vector parity tests + the kNN fuzz against the A/B library (bit-exact or it does not go in);
 #   2. C4 at 1 / 32 / 64 queries and the 1/8 share with both libraries, same box, interleaved;
 #   3. kernel trace of both (the sketch kernel's average launch).
-#   4. the MaxScore items' launch order (NRTGPU_MS_LPT=1): parity suites under it, C3 / 1-of-8 / C2 bench lines A/B.
+#   4. the MaxScore items' launch order (the default two-clause key against NRTGPU_MS_LPT=0, round 3's measured order): parity suites
+#      under the old order once more, C3 / 1-of-8 / C2 bench lines A/B.
 # -> gpurun_out/r04/a.  If 1 is green and 2 is not slower: make the cast the only code path (drop the macro), rebuild, re-run
 # scripts/kernel_resources.py > profiles/r04_kernel_resources.txt and drop `knn_sketch_kernel<4, 8>` from
 # tests/test_kernel_resources.py: KNOWN_SCRATCH.
@@ -36,17 +37,17 @@ for rep in 1 2; do
 done
 timeout 100 python bench.py --workload C4 --emulate-world 8 --knn-queries 32 --steps 40 --warmup 3 --no-cpu-baseline --no-verify 2>/dev/null | tee $O/c4_emu8_shipped.json | show "emu8 shipped"
 NRTGPU_LIB_PATH=$AB timeout 100 python bench.py --workload C4 --emulate-world 8 --knn-queries 32 --steps 40 --warmup 3 --no-cpu-baseline --no-verify 2>/dev/null | tee $O/c4_emu8_ab.json | show "emu8 a/b"
-echo "== launch order of the MaxScore items: NRTGPU_MS_LPT=1 (planner.cpp; scripts/cpu_launch_order_sim.py predicts 1.56 -> 1.33 x the balanced load) ($(( $(date +%s) - T0 )) s)"
-NRTGPU_MS_LPT=1 timeout 600 python -m pytest tests/test_maxscore_gpu.py tests/test_parity_gpu.py tests/test_filters_gpu.py tests/test_fuzz_gpu.py tests/test_baseline_sizes_gpu.py tests/test_exchange_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider > $O/pytest_ms_lpt.log 2>&1
-echo "pytest (NRTGPU_MS_LPT=1) rc=$?"; grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr" $O/pytest_ms_lpt.log | tail -4 | cut -c1-300
+echo "== launch order of the MaxScore items: the default (two heaviest clauses) against NRTGPU_MS_LPT=0 (all postings: round 3's measured order); scripts/cpu_launch_order_sim.py predicts 1.56 -> 1.33 x the balanced load ($(( $(date +%s) - T0 )) s)"
+NRTGPU_MS_LPT=0 timeout 600 python -m pytest tests/test_maxscore_gpu.py tests/test_parity_gpu.py tests/test_filters_gpu.py tests/test_fuzz_gpu.py tests/test_baseline_sizes_gpu.py tests/test_exchange_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider > $O/pytest_ms_lpt.log 2>&1
+echo "pytest (NRTGPU_MS_LPT=0; the default order runs in the round's own suite) rc=$?"; grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr" $O/pytest_ms_lpt.log | tail -4 | cut -c1-300
 for rep in 1 2; do
-  timeout 100 python bench.py --no-cpu-baseline --closed-loop "" 2>/dev/null | tee $O/c3_default_$rep.json | show "c3 default order"
-  NRTGPU_MS_LPT=1 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" 2>/dev/null | tee $O/c3_ms_lpt_$rep.json | show "c3 NRTGPU_MS_LPT=1"
+  timeout 100 python bench.py --no-cpu-baseline --closed-loop "" 2>/dev/null | tee $O/c3_default_$rep.json | show "c3 default (two-clause key)"
+  NRTGPU_MS_LPT=0 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" 2>/dev/null | tee $O/c3_ms_lpt0_$rep.json | show "c3 NRTGPU_MS_LPT=0 (round 3 order)"
 done
-timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --force-dist --emulate-world 8 --emulate-peers final 2>/dev/null | tee $O/emu8_default.json | show "emu8 default order"
-NRTGPU_MS_LPT=1 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --force-dist --emulate-world 8 --emulate-peers final 2>/dev/null | tee $O/emu8_ms_lpt.json | show "emu8 NRTGPU_MS_LPT=1"
-timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --workload C2 2>/dev/null | tee $O/c2_default.json | show "c2 default order"
-NRTGPU_MS_LPT=1 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --workload C2 2>/dev/null | tee $O/c2_ms_lpt.json | show "c2 NRTGPU_MS_LPT=1"
+timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --force-dist --emulate-world 8 --emulate-peers final 2>/dev/null | tee $O/emu8_default.json | show "emu8 default (two-clause key)"
+NRTGPU_MS_LPT=0 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --force-dist --emulate-world 8 --emulate-peers final 2>/dev/null | tee $O/emu8_ms_lpt0.json | show "emu8 NRTGPU_MS_LPT=0"
+timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --workload C2 2>/dev/null | tee $O/c2_default.json | show "c2 default (two-clause key)"
+NRTGPU_MS_LPT=0 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --workload C2 2>/dev/null | tee $O/c2_ms_lpt0.json | show "c2 NRTGPU_MS_LPT=0"
 echo "== kernel traces ($(( $(date +%s) - T0 )) s)"
 cd /tmp
 for v in shipped ab; do

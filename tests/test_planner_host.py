@@ -1,0 +1,52 @@
+"""The HOST side of the library on a box without a GPU: segment upload bookkeeping, the planner and the result unpacking run
+against tests/mockhip (a stand-in HIP runtime whose kernels do nothing -- test infrastructure, see its header), in a
+subprocess with the stand-in preloaded.  What is checked is the PLAN (NRTGPU_PLAN_TRACE): results under the stand-in are empty.
+
+The launch order of the MaxScore route's items (planner.cpp): longest-first by the postings of the query's
+two heaviest clauses.  The order must not change WHAT is launched -- the same items, as a set, under either key -- and the
+heaviest queries by that key must lead."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "nrtsearch_amd", "libnrtgpu.so")
+
+
+@pytest.fixture(scope="module")
+def mockhip(tmp_path_factory):
+    if not (shutil.which("gcc") and os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h") and os.path.exists(LIB)):
+        pytest.skip("gcc, the HIP headers or the built library are not here")
+    out = str(tmp_path_factory.mktemp("mockhip") / "libmockhip.so")
+    subprocess.run(["gcc", "-O1", "-w", "-fPIC", "-shared", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "mockhip", "mockhip.c"), "-o", out],
+                   check=True)
+    return out
+
+
+def plan_of(mockhip, **env):
+    e = dict(os.environ, LD_PRELOAD=mockhip, NRTGPU_PLAN_TRACE="1", **env)
+    e.pop("NRTGPU_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "plan_batch.py")], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "done" in r.stdout, r.stderr[-2000:]
+    plans = [(m.group(1), m.group(2), [int(x) for x in m.group(3).split()])
+             for m in re.finditer(r"items as a set ([0-9a-f]+), in launch order ([0-9a-f]+); first items' queries:([ 0-9]*)", r.stderr)]
+    counts = [int(m.group(1)) for m in re.finditer(r"(\d+) parts (\d+) items", r.stderr)]
+    keys = [np.array([int(x) for x in line.split()[1:]]) for line in r.stdout.split("\n") if line.startswith("KEYS")]
+    return plans, keys, counts
+
+
+def test_host_runtime_plans_a_batch_without_a_gpu_and_the_launch_order_is_only_an_order(mockhip):
+    new, keys, counts = plan_of(mockhip)                       # the default: longest-first by the two heaviest clauses' postings
+    old, _, _ = plan_of(mockhip, NRTGPU_MS_LPT="0")            # round 3's measured order: by all postings
+    assert len(new) == len(old) == 2 and len(keys) == 2
+    for (set_new, order_new, first_new), (set_old, order_old, first_old), k in zip(new, old, keys):
+        assert set_new == set_old, "the launch order changed WHAT is launched"
+        assert order_new != order_old and first_new != first_old
+        rank = (-k).argsort(kind="stable").argsort()           # 0 = the query with the most postings in its two heaviest clauses
+        assert all(rank[q] < len(k) // 10 for q in first_new), f"leading items' queries {first_new} rank {[int(rank[q]) for q in first_new]} by the key"
+        assert not all(rank[q] < len(k) // 10 for q in first_old)
