@@ -102,7 +102,11 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_expand_terms(st, (const DQExpand*)(db + o_qexp), (const DQTerm*)(db + o_qterms), (const uint32_t*)(db + o_qsb),
                       (uint32_t)n_queries, hp.n_leaves, (DTerm*)(wb + o_terms));
   gpu.lock();
-  if (ctx->last_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
+  // (experiment, off unless NRTGPU_OVERLAP_SCORERS=1: no turn between consecutive calls' scorers -- nothing but the turn itself
+  //  orders them: workspaces are per slot, term tables reach the device before they become visible -- so that the next batch's
+  //  items fill the tail of this one's launch; needs its GPU run: the merge then queues behind foreign items)
+  static const bool overlap_scorers = getenv("NRTGPU_OVERLAP_SCORERS") != nullptr && atoi(getenv("NRTGPU_OVERLAP_SCORERS")) != 0;
+  if (ctx->last_turn && !overlap_scorers) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
   if (ctx->last_knn_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_knn_turn, 0));   // (vector searches do not queue behind each other, the scorers queue behind them)
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
   launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, hp.ms_shapes, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
