@@ -46,6 +46,7 @@ for rep in 1 2; do
 done
 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --force-dist --emulate-world 8 --emulate-peers final 2>/dev/null | tee $O/emu8_default.json | show "emu8 default (two-clause key)"
 NRTGPU_MS_LPT=0 timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --force-dist --emulate-world 8 --emulate-peers final 2>/dev/null | tee $O/emu8_ms_lpt0.json | show "emu8 NRTGPU_MS_LPT=0"
+for ti in 512 2048; do timeout 100 python bench.py --no-cpu-baseline --closed-loop "" --target-items $ti 2>/dev/null | tee $O/c3_target_items_$ti.json | show "c3 --target-items $ti (queries cut by all postings: smaller items, more cold starts)"; done
 NRTGPU_OVERLAP_SCORERS=1 timeout 100 python bench.py --no-cpu-baseline --closed-loop "64,512" 2>/dev/null | tee $O/c3_overlap_scorers.json | show "c3 NRTGPU_OVERLAP_SCORERS=1"
 python -c "import json; d=json.loads(open('$O/c3_overlap_scorers.json').read().strip().splitlines()[-1]); print('   closed loop:', d.get('closed_loop'), 'p50', d.get('p50_latency_ms'))" 2>/dev/null
 NRTGPU_OVERLAP_SCORERS=1 timeout 300 python -m pytest tests/test_parity_gpu.py tests/test_maxscore_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider 2>&1 | tail -2
