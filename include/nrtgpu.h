@@ -226,6 +226,13 @@ int  nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, co
 int  nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                   const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);
 int  nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us);
+/* TEST HOOKS for the two coalescers (this one and nrtgpu_knn_exact_coalesced).  hold != 0: no leader leaves with less than a
+ * full batch (max_batch queries) / panel (64 queries) until the hold is released -- a test queues a known set of callers behind
+ * it, waits until nrtgpu_debug_coalescer_pending (which: 0 = BM25, 1 = exact vector search) reports all of them, releases,
+ * and may then assert the batches formed BY CONSTRUCTION (what a batch is must not depend on the host's speed).  Not for
+ * production callers: a held coalescer parks every request. */
+int  nrtgpu_debug_hold_coalescers(nrtgpu_ctx* ctx, int32_t hold);
+int  nrtgpu_debug_coalescer_pending(nrtgpu_ctx* ctx, int32_t which);
 
 /* Device-resident variant for the multi-GPU path (one process per GPU): results stay
  * in HBM as packed keys so the caller can RCCL all-gather them without a host round trip.

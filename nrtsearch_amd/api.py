@@ -232,6 +232,14 @@ class GpuContext:
     def reset_stats(self) -> None:
         _lib.load().nrtgpu_reset_stats(self._h)
 
+    def debug_hold_coalescers(self, hold: bool) -> None:
+        """Test hook (nrtgpu_debug_hold_coalescers): while held, coalescer leaders leave only with a full batch / panel."""
+        _lib.check(_lib.load().nrtgpu_debug_hold_coalescers(self._h, 1 if hold else 0))
+
+    def debug_coalescer_pending(self, which: int) -> int:
+        """Requests parked in a coalescer: 0 = nrtgpu_search_bm25_coalesced, 1 = nrtgpu_knn_exact_coalesced."""
+        return int(_lib.load().nrtgpu_debug_coalescer_pending(self._h, int(which)))
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             _lib.load().nrtgpu_destroy(self._h)

@@ -423,6 +423,7 @@ struct nrtgpu_ctx {
   int co_inflight_queries = 0;                // ... and how many queries they hold
   int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
   int32_t co_linger_us = 150;
+  std::atomic<int> co_hold{0};                          // nrtgpu_debug_hold_coalescers: no leader (of either coalescer) leaves with less than a full batch / panel
   // the same for exact vector searches (nrtgpu_knn_exact_coalesced, vectors.cpp)
   std::mutex kco_mu;
   std::vector<struct KnnCoRequest*> kco_pending;
@@ -582,3 +583,7 @@ int build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* do
 
 }  // namespace rt
 }  // namespace nrtgpu
+
+// test hook halves that live in vectors.cpp (nrtgpu_debug_hold_coalescers / nrtgpu_debug_coalescer_pending, search.cpp)
+void nrtgpu_debug_knn_coalescer_wake(nrtgpu_ctx* ctx);
+int nrtgpu_debug_knn_coalescer_pending(nrtgpu_ctx* ctx);

@@ -514,6 +514,27 @@ extern "C" int nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us) {
   return NRTGPU_OK;
 }
 
+// Test hook (include/nrtgpu.h): while held, a coalescer's leader leaves only with a full batch / panel, so a test can queue a
+// known set of callers and assert what batches they form by construction instead of by the host's speed.
+extern "C" int nrtgpu_debug_hold_coalescers(nrtgpu_ctx* ctx, int32_t hold) {
+  if (!ctx) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  {
+    std::lock_guard<std::mutex> lk(ctx->co_mu);
+    ctx->co_hold = hold != 0 ? 1 : 0;   // (atomic: the kNN coalescer reads it under its own lock)
+    if (!hold && ctx->co_leader) ctx->co_leader->cv.notify_one();
+  }
+  nrtgpu_debug_knn_coalescer_wake(ctx);
+  return NRTGPU_OK;
+}
+extern "C" int nrtgpu_debug_coalescer_pending(nrtgpu_ctx* ctx, int32_t which) {
+  if (!ctx) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  if (which == 0) {
+    std::lock_guard<std::mutex> lk(ctx->co_mu);
+    return (int)ctx->co_pending.size();
+  }
+  return nrtgpu_debug_knn_coalescer_pending(ctx);
+}
+
 extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                             int32_t n_segs, const nrtgpu_bm25_query* q, nrtgpu_topdocs* out) {
   if (!ctx || !q || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
@@ -566,7 +587,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
       const int32_t waiting = (int32_t)ctx->co_pending.size();
       if (waiting >= ctx->cfg.max_batch) break;
       const bool late = std::chrono::steady_clock::now() >= deadline;
-      if (late && (ctx->co_inflight == 0 ||
+      if (late && !ctx->co_hold && (ctx->co_inflight == 0 ||
                    (ctx->co_inflight == 1 && (waiting >= 2 * ctx->co_inflight_queries || waiting >= kCoOverlapMin)))) break;
       if (late) me.cv.wait(lk);
       else me.cv.wait_until(lk, deadline);

@@ -528,6 +528,15 @@ static bool knn_co_compatible(const KnnCoRequest* a, const KnnCoRequest* b) {
   return !a->doc_bases || memcmp(a->doc_bases, b->doc_bases, (size_t)a->n_segs * 4) == 0;
 }
 
+void nrtgpu_debug_knn_coalescer_wake(nrtgpu_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(ctx->kco_mu);
+  if (ctx->kco_leader) ctx->kco_leader->cv.notify_one();
+}
+int nrtgpu_debug_knn_coalescer_pending(nrtgpu_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(ctx->kco_mu);
+  return (int)ctx->kco_pending.size();
+}
+
 extern "C" int nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                           int32_t field_id, int32_t sim, const float* query, int32_t dim, int32_t k, float boost,
                                           nrtgpu_topdocs* out) {
@@ -566,7 +575,9 @@ extern "C" int nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* con
     }
     // leader: leave at once when the device is free; else when the running panel finishes, or -- as a second panel in flight,
     // whose launches fill the tails of the first one's -- as soon as a whole panel is waiting
-    while (!(ctx->kco_inflight == 0 || (ctx->kco_inflight == 1 && ctx->kco_pending.size() >= (size_t)kKnnMaxQ))) me.cv.wait(lk);
+    // (NO linger: a caller that finds the device free runs alone -- company comes from the callers that arrive while a panel is
+    //  running.  co_hold: the test hook of nrtgpu_debug_hold_coalescers.)
+    while (!((ctx->kco_inflight == 0 && !ctx->co_hold) || ((ctx->kco_inflight == 1 || ctx->co_hold) && ctx->kco_pending.size() >= (size_t)kKnnMaxQ))) me.cv.wait(lk);
     std::vector<KnnCoRequest*> rest, expired;
     batch.push_back(&me);
     for (KnnCoRequest* r : ctx->kco_pending) {
