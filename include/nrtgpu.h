@@ -507,6 +507,12 @@ int  nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16);
  * [12] waves in part prologues, [13] waves walking windows, [14] the item's last wave running out of windows, [15] item
  * epilogue ([10]-[13]: summed over the item's 12 waves) */
 int  nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out16);
+/* the same flag: WHEN the workgroups of the last MaxScore launch ran.  Per output slot four words -- {start, end} on the device's
+ * 100 MHz wall clock, the item the workgroup worked on, the doc windows it walked; a slot nobody used is all zeros.  The first
+ * *n_items slots are the items' own workgroups; slots beyond the call's items (MaxScore + scan) are HELPERS: workgroups that got
+ * a CU when the items ran out and shared the windows of an unfinished item.  Returns the number of slots (<= cap_slots
+ * are written); the makespan of the launch against its balanced load is max(end) - min(start) vs sum(end - start) / CUs. */
+int64_t nrtgpu_get_maxscore_item_walls(nrtgpu_ctx* ctx, uint64_t* out, int64_t cap_slots, int64_t* n_items);
 
 #ifdef __cplusplus
 }

@@ -232,6 +232,17 @@ class GpuContext:
     def reset_stats(self) -> None:
         _lib.load().nrtgpu_reset_stats(self._h)
 
+    def maxscore_item_walls(self):
+        """(walls[n_slots, 4] = start, end (100 MHz ticks), item, windows; n_items) of the last instrumented MaxScore launch
+        (nrtgpu_get_maxscore_item_walls): rows >= the call's items are helper workgroups."""
+        L = _lib.load()
+        n_items = C.c_int64(0)
+        n = int(L.nrtgpu_get_maxscore_item_walls(self._h, None, 0, C.byref(n_items)))
+        out = np.zeros((max(n, 0), 4), dtype=np.uint64)
+        if n > 0:
+            L.nrtgpu_get_maxscore_item_walls(self._h, out.ctypes.data, n, C.byref(n_items))
+        return out, int(n_items.value)
+
     def debug_hold_coalescers(self, hold: bool) -> None:
         """Test hook (nrtgpu_debug_hold_coalescers): while held, coalescer leaders leave only with a full batch / panel."""
         _lib.check(_lib.load().nrtgpu_debug_hold_coalescers(self._h, 1 if hold else 0))

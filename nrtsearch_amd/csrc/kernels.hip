@@ -946,7 +946,8 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
                        const uint32_t* __restrict__ q_base, const uint32_t* __restrict__ q_nlists, uint32_t k_stride_in,
                        const uint32_t* __restrict__ q_k, uint64_t* __restrict__ out_keys,
                        uint32_t* __restrict__ out_counts, uint64_t* __restrict__ out_hits,
-                       uint32_t k_stride_out) {
+                       uint32_t k_stride_out, const uint32_t* __restrict__ help_head, const uint32_t* __restrict__ help_next,
+                       uint32_t help_slot_base) {
   __shared__ MergeSmem s;
   const uint32_t tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
@@ -963,8 +964,18 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
   for (uint32_t l = tid; l < nl; l += kScanThreads) h += in_hits[list_idx[base + l]];
   if (h) atomicAdd(&s.hits, h);
 
-  for (uint32_t l = 0; l < nl; ++l) {
-    const uint32_t rec = list_idx[base + l];
+  // the query's lists: its items' records, then the slots of the helpers that joined them (maxscore.hip, plan.h: DHelp --
+  // a linked list per query, slot = help_slot_base + helper number)
+  uint32_t hnext = help_head ? help_head[q] : 0u;
+  for (uint32_t l = 0; l < nl || hnext != 0u; ++l) {
+    uint32_t rec;
+    if (l < nl) {
+      rec = list_idx[base + l];
+    } else {
+      rec = help_slot_base + hnext - 1u;
+      hnext = help_next[hnext - 1u];
+      if (tid == 0) atomicAdd(&s.hits, (unsigned long long)in_hits[rec]);
+    }
     const uint32_t c = min(in_counts[rec], k_stride_in);
     const uint64_t* src = in_keys + (size_t)rec * k_stride_in;
     for (uint32_t off = 0; off < c; off += kScanThreads) {
@@ -1247,10 +1258,12 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
-                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out) {
+                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_head,
+                       const uint32_t* help_next, uint32_t help_slot_base) {
   if (n_queries == 0) return;
   hipLaunchKernelGGL(merge_topk_kernel, dim3(n_queries), dim3(kScanThreads), 0, stream, in_keys, in_counts, in_hits,
-                     list_idx, q_base, q_nlists, k_stride_in, q_k, out_keys, out_counts, out_hits, k_stride_out);
+                     list_idx, q_base, q_nlists, k_stride_in, q_k, out_keys, out_counts, out_hits, k_stride_out, help_head, help_next,
+                     help_slot_base);
 }
 
 void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,

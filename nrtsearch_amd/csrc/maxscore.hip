@@ -74,7 +74,7 @@ struct MsSmem {
   uint32_t cnt;          // entries in cand
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kMsCandCap
   uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet
-  uint32_t next_win;     // next unassigned window of the item
+  uint64_t pick;         // a helper's choice: float bits of the expected time left << 32 | item + 1
   uint32_t prune_on;     // bounds may skip work (kMsModeCount: raised once a slice's count has passed the query's gte_floor)
   uint32_t slot_hits[kSliceSlots];   // live matching docs evaluated, per searcher slice the item touches (plan.h: DPart.slice)
   uint32_t slot_slice[kSliceSlots];  // which slice a slot stands for
@@ -257,16 +257,55 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
                           const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
                           uint32_t* __restrict__ slice_sum, uint32_t* __restrict__ q_prune, const DExchange* __restrict__ xch,
                           uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
-                          uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof) {
+                          uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof, const DHelp* __restrict__ hpp) {
   __shared__ MsSmem s;
+  const DHelp& hp = *hpp;   // (resident next to the plan: its fields are scalar loads where they are used, not kernel arguments held in registers)
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  const DItem item = items[blockIdx.x];
+  // ---- which item?  The first n_own workgroups own one each.  The workgroups behind them are HELPERS (plan.h: DHelp): they get
+  //      a CU when the items have run out, and join the unfinished item with the most time left -- its windows come from a
+  //      counter in global memory, so owner and helpers simply share them.  Expected time left = the time the item has run so
+  //      far x unassigned windows / windows handed out, divided among the helpers already there.  Nothing worth joining: the
+  //      helper says so (help_off) and every later one leaves at once.
+  const bool helper = blockIdx.x >= hp.n_own;
+  uint32_t my_item = blockIdx.x;
+  if (helper) {
+    if (tid == 0) s.pick = __hip_atomic_load(hp.help_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? ~0ull : 0ull;
+    __syncthreads();
+    if (s.pick == ~0ull) return;   // (uniform)
+    const uint64_t now = wall_clock64();
+    for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
+      const uint32_t fl = items[i].flags;
+      if ((fl & 3u) != kMsModePrune) continue;   // (counting items decide per workgroup when bounds may skip: not shared)
+      const uint32_t nw = fl >> 8;
+      const uint32_t taken = (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (taken + hp.min_rem > nw) continue;
+      const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t0 == 0ull || now <= t0) continue;     // its owner has not started yet
+      const uint32_t hc = __hip_atomic_load(hp.help_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float left = (float)(now - t0) * (float)(nw - taken) / ((float)(taken - (uint32_t)kMsWaves + 1u) * (float)(1u + hc));
+      atomicMax((unsigned long long*)&s.pick, ((unsigned long long)__float_as_uint(left) << 32) | (unsigned long long)(i + 1u));
+    }
+    __syncthreads();
+    const uint64_t pick = s.pick;
+    if ((uint32_t)pick == 0u) {   // (uniform)
+      if (tid == 0) __hip_atomic_store(hp.help_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    my_item = (uint32_t)pick - 1u;
+    if (tid == 0) atomicAdd(hp.help_cnt + my_item, 1u);
+  }
+  const uint32_t out_slot = helper ? hp.slot_base + (blockIdx.x - hp.n_own) : blockIdx.x;
+  NRT_GLOBAL uint32_t* const win_next_g = (NRT_GLOBAL uint32_t*)(hp.win_next + my_item);   // (a global address: no flat instruction in the window loop)
+  // a helper wave's first window (an owner's waves start with windows 0 .. kMsWaves - 1): asked for now, read behind the tables
+  uint32_t first_win = 0;
+  if (helper && lane == 0) first_win = __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const DItem item = items[my_item];
   const DQuery q = queries[item.query];
   const uint32_t k = q.k;
   const int fx_E = item.fx_E;
   unsigned long long* const my_theta_g = theta_g + item.query;
-  const bool multi_item = q.n_items > 1;
+  const bool multi_item = q.n_items > 1 || hp.n_help != 0u;   // (theta_g is how owner and helpers share theta as well)
   // When may bounds skip work (plan.h: kMsMode*)?  Exact: never.  Count: once a slice has collected more than gte_floor hits --
   // until then every live matching doc is evaluated and counted, as the reference's collector does before it first
   // publishes a min competitive score.  theta filters the candidates in every mode.
@@ -288,12 +327,13 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     s.cnt = 0;
     s.cnt_valid = 0;
     s.rz_flag = 0;
-    s.next_win = (uint32_t)kMsWaves;
+    if (!helper && hp.n_help != 0u) __hip_atomic_store(hp.item_t0 + my_item, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s.prune_on = mode == kMsModePrune ? 1u : 0u;
     for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
     for (int i = 0; i < 16; ++i) s.prof[i] = 0;
   }
   const uint64_t t_item0 = PROF ? __builtin_readcyclecounter() : 0ull;
+  const uint64_t wall0 = PROF ? wall_clock64() : 0ull;
   uint64_t tc_meet = 0, tc_part = 0, tc_walk = 0;
   __syncthreads();
   if (xch && tid < 64u) {   // wave 0: what the other GPUs' shards have published for this query so far (nothing of mine yet)
@@ -304,9 +344,9 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     }
   }
   for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
-    const float w = items[blockIdx.x].tab_weight[slot];
-    const int scale = items[blockIdx.x].tab_scale[slot];
-    const float* cache = &s.cache[items[blockIdx.x].tab_cache[slot]][0];
+    const float w = items[my_item].tab_weight[slot];
+    const int scale = items[my_item].tab_scale[slot];
+    const float* cache = &s.cache[items[my_item].tab_cache[slot]][0];
     for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kMsThreads)  // row 0: postings of deleted docs score 0
       s.tab[slot][e] = e < (uint32_t)kTabNorms ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
   }
@@ -322,7 +362,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
 #ifdef NRT_MS_COUNT_ROUNDS   // experiment build: event counts instead of four of the cycle counters
   uint64_t pc_dense = 0, pc_sparse = 0, pc_steps = 0, pc_tas = 0, pc_crounds = 0;
 #endif
-  uint32_t g = wave;      // my current window (flattened over the item's parts)
+  uint32_t g = helper ? (uint32_t)kMsWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)first_win) : wave;   // my current window (flattened over the item's parts)
   uint32_t pi = 0;        // its part ...
   uint32_t win_base = 0;  // ... and the windows of the parts before that one
 
@@ -425,7 +465,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       if (PROF) pc_wins += 1;
       // my next window: taken now, so that the counter's answer is there when this one is done
       uint32_t g_new = 0;
-      if (lane == 0) g_new = atomicAdd(&s.next_win, 1u);
+      if (lane == 0) g_new = (uint32_t)kMsWaves + __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (global: shared with the item's helpers)
       // theta of the query's other items (LazyMaxScoreAccumulator analogue), once per window
       uint64_t theta_other = 0, thr_other = 0;
       if (multi_item) {
@@ -997,10 +1037,14 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   }
   __syncthreads();
   const uint32_t n = s.cnt;
-  uint64_t* out = item_keys + (size_t)blockIdx.x * k_stride;
+  uint64_t* out = item_keys + (size_t)out_slot * k_stride;
   for (uint32_t i = tid; i < n; i += kMsThreads) out[i] = s.cand[i];
   if (tid == 0) {
-    item_counts[blockIdx.x] = n;
+    item_counts[out_slot] = n;
+    if (helper) {   // my slot joins the query's list (merge_topk_kernel walks it behind the items' slots)
+      const uint32_t h = blockIdx.x - hp.n_own;
+      hp.help_next[h] = atomicExch(hp.help_head + item.query, h + 1u);
+    }
     // the item's hits, per slice into the query's sums (slice_relation_kernel) and in total
     uint32_t hits = 0;
     for (int i = 0; i < kSliceSlots; ++i) {
@@ -1011,13 +1055,19 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     // anything skipped?  Only a theta can skip, and only once the item may prune; with none the walk evaluated every live
     // matching doc exactly once.
     const bool pruned = s.prune_on != 0u && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
-    item_hits[blockIdx.x] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
+    item_hits[out_slot] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
     if (PROF && item_prof) {
       s.prof[5] = hits;
       const uint64_t t_end = __builtin_readcyclecounter();
       s.prof[9] = t_end - t_item0;
       s.prof[15] = t_end - t_epi0;
-      for (int i = 0; i < 16; ++i) item_prof[(size_t)blockIdx.x * 16 + i] = s.prof[i];
+      for (int i = 0; i < 16; ++i) item_prof[(size_t)out_slot * 16 + i] = s.prof[i];
+      if (hp.walls) {
+        hp.walls[(size_t)out_slot * 4 + 0] = wall0;
+        hp.walls[(size_t)out_slot * 4 + 1] = wall_clock64();
+        hp.walls[(size_t)out_slot * 4 + 2] = my_item;
+        hp.walls[(size_t)out_slot * 4 + 3] = s.prof[0];
+      }
     }
   }
 }
@@ -1098,11 +1148,12 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
 void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, uint32_t n_items, const DItem* items, const DPart* parts,
                           const DTerm* terms, const DQuery* queries, const float* caches,
                           unsigned long long* theta_g, uint32_t* slice_sum, uint32_t* q_prune, const DExchange* xch, uint64_t* item_keys,
-                          uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof) {
+                          uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof, const DHelp& help, const DHelp* help_d) {
   if (n_items == 0) return;
+  // (help: the host's copy of *help_d, the record the kernel reads; help.n_own == n_items; the helper workgroups are launched BEHIND the items: the dispatcher hands workgroups out in index order)
 #define NRT_MS_LAUNCH(P, K, S)                                                                                                      \
-  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(n_items), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
-                     caches, theta_g, slice_sum, q_prune, xch, item_keys, item_counts, item_hits, k_stride, item_prof)
+  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(n_items + help.n_help), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
+                     caches, theta_g, slice_sum, q_prune, xch, item_keys, item_counts, item_hits, k_stride, item_prof, help_d)
 #define NRT_MS_LAUNCH_S(P, K)          \
   do {                                 \
     if (shapes) NRT_MS_LAUNCH(P, K, true); \

@@ -177,7 +177,8 @@ struct alignas(16) DItem {
   int32_t  tab_scale[kTabTerms];  // fixed-point batches: fx_scale of each score table's term
   int32_t  fx_E;                  // fixed-point batches: accumulators hold score * 2^fx_E
   uint32_t peer_slot;             // this item's slot among the query's items [DQuery.item_begin, + n_items)
-  uint32_t flags;                 // MaxScore kernel, bits 0-1: when bounds may skip work (kMsMode*)
+  uint32_t flags;                 // MaxScore kernel, bits 0-1: when bounds may skip work (kMsMode*); bits 8-31: the item's doc windows
+                                  // (kMsWinDocs docs each, summed over its parts): what helpers share with the owner
 };
 static_assert(sizeof(DItem) == 96, "DItem layout");
 
@@ -211,6 +212,26 @@ constexpr uint32_t kMsModePrune = 0, kMsModeExact = 1, kMsModeCount = 2;
 // minimumNumberShouldMatch > 1: the fixed-point accumulator carries the number of matching clauses above
 // the score sum (sum < 2^52: 32 clauses x 2^32 x 2^15)
 constexpr int kMsmCountShift = 56;
+
+// Helping (maxscore.hip): the windows of an item are handed out by a counter in GLOBAL memory, so a workgroup other than the
+// item's own -- a HELPER, launched behind the items and dispatched when a CU runs out of them -- can take windows of the
+// heaviest unfinished item: the tail of a launch (1024 items of very different cost on 256 CUs, one workgroup per CU) is
+// shared instead of waited for.  A helper has its own score tables, candidate list and output slot (slot_base + its number),
+// starts from the theta the query's items have published (theta_g) and links its slot into the query's list for the merge.
+struct DHelp {
+  uint32_t* win_next;            // [n_own]   windows handed out beyond the owner's first kMsWaves (zeroed per launch)
+  uint32_t* help_cnt;            // [n_own]   helpers that joined the item
+  unsigned long long* item_t0;   // [n_own]   wall clock (100 MHz) at which the item's owner started; 0: not yet
+  uint32_t* help_head;           // [queries] the query's helper slots: number of the first + 1, 0 = none
+  uint32_t* help_next;           // [n_help]  ... and the next one
+  uint32_t* help_off;            // [1]       a helper found nothing left worth joining: the later ones leave at once
+  uint32_t n_own, n_help;        // items of the launch, helper workgroups behind them
+  uint32_t slot_base;            // output slot (item_keys / item_counts / item_hits) of helper 0
+  uint32_t min_rem;              // an item with fewer unassigned windows is not joined
+  unsigned long long* walls;     // instrumented kernel only, else nullptr: per output slot {start, end} on the 100 MHz wall clock and
+                                 // {item, windows walked} -- when every workgroup of the launch ran, on one time base
+                                 // (nrtgpu_get_maxscore_item_walls: the makespan against the balanced load)
+};
 
 // Cross-GPU bound exchange of one batch (nrtgpu_exchange_open): entry (rank r, query q) of the batch's
 // slot holds (tag << 32) | score word that at least ceil(k / world) docs of rank r's shard reach.

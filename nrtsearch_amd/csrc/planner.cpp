@@ -725,6 +725,16 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     }
     it.peer_slot = hp.q_base[pend[i].query] + q_fill[pend[i].query]++;
     it.flags = on_ms_kernel(pend[i].query) ? (uint32_t)(hp.q_route[pend[i].query] - kRouteMs) : 0u;
+    if (on_ms_kernel(pend[i].query)) {
+      // its doc windows (maxscore.hip: windows start on kMsWinTiles boundaries of the segment, a part's first one may be short):
+      // what the owner's waves and the item's helpers hand out from one counter (plan.h: DHelp)
+      uint32_t wins = 0;
+      for (uint32_t pi2 = 0; pi2 < it.n_parts; ++pi2) {
+        const DPart& p = hp.parts[it.part_begin + pi2];
+        wins += (p.tile_end - (p.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
+      }
+      it.flags |= std::min(wins, 0xFFFFFFu) << 8;
+    }
     hp.items[i] = it;
     hp.list_idx[it.peer_slot] = (uint32_t)i;
   }

@@ -43,7 +43,7 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
 void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, uint32_t n_items, const DItem* items, const DPart* parts,
                           const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                           uint32_t* slice_sum, uint32_t* q_prune, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
-                          uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
+                          uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof, const DHelp& help, const DHelp* help_d);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
                           const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
@@ -56,7 +56,8 @@ void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
-                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out);
+                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_head = nullptr,
+                       const uint32_t* help_next = nullptr, uint32_t help_slot_base = 0);
 void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,
                        uint32_t* fnorm, uint64_t n, uint32_t* overflow);
 void launch_pack_count(hipStream_t stream, const uint32_t* fnorm, uint64_t n, uint32_t n_blocks, uint32_t* counts);
@@ -413,6 +414,8 @@ struct nrtgpu_ctx {
   nrtgpu_stats stats{};
   std::atomic<int> knn_sketch_skip[4] = {};   // per similarity: panels that go straight to the fp32 rows (the sketch did not certify lately)
   double prof[16] = {0};
+  std::vector<uint64_t> last_walls;   // NRTGPU_FLAG_PROFILE: {start, end, item, windows} per output slot of the last MaxScore launch
+  int64_t last_walls_items = 0;       // ... whose first this-many slots are the items' owners (helpers behind the scan's slots)
   double ms_prof[16] = {0};   // the same for the items of the MaxScore route (nrtgpu_get_maxscore_profile)
   // request coalescing (nrtgpu_search_bm25_coalesced)
   std::mutex co_mu;

@@ -10,6 +10,8 @@ struct DeviceRun {
   uint64_t* out_hits = nullptr;
   uint64_t* prof = nullptr;   // instrumented variant: 8 counters per item
   size_t n_items = 0;
+  size_t n_slots = 0;      // items + the MaxScore route's helper slots behind them
+  uint64_t* walls = nullptr;   // instrumented variant: per slot {start, end, item, windows} (plan.h: DHelp.walls)
   size_t n_ms_items = 0;
 };
 
@@ -42,6 +44,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_lower = pc.take(ext_hits ? hp.q_lower.size() * 8 : 0);  // device-resident results: certain lower bounds
   const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
   const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
+  const size_t o_help = pc.take(sizeof(DHelp));   // filled in below, once the workspace is carved
   const size_t plan_bytes = pc.off;
   if (int rc = slot->h_plan.reserve(plan_bytes)) return rc;
   if (int rc = slot->d_plan.reserve(plan_bytes)) return rc;
@@ -72,25 +75,50 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     memcpy(hb + o_xch, &x, sizeof(x));
   }
 
+  // MaxScore route: helper workgroups behind the items (plan.h: DHelp; maxscore.hip) -- each with an output slot of its own
+  // behind the items' slots.  NRTGPU_MS_HELPERS: how many (default 4 per CU; 0: none), NRTGPU_MS_HELP_MIN: an item with fewer
+  // unassigned windows is not joined.
+  static const int env_helpers = getenv("NRTGPU_MS_HELPERS") ? atoi(getenv("NRTGPU_MS_HELPERS")) : -1;
+  static const int env_help_min = getenv("NRTGPU_MS_HELP_MIN") ? atoi(getenv("NRTGPU_MS_HELP_MIN")) : 16;
+  const size_t n_help = hp.n_ms_items == 0 ? 0 : (size_t)(env_helpers >= 0 ? env_helpers : 4 * std::max(ctx->n_cus, 1));
+  const size_t n_slots = n_items + n_help;
   Carver wc;
-  const size_t o_ikeys = wc.take(n_items * (size_t)hp.k_stride * 8);
-  const size_t o_icnt = wc.take(n_items * 4);
-  const size_t o_ihits = wc.take(n_items * 8);
+  const size_t o_ikeys = wc.take(n_slots * (size_t)hp.k_stride * 8);
+  const size_t o_icnt = wc.take(n_slots * 4);
+  const size_t o_ihits = wc.take(n_slots * 8);
   const size_t o_okeys = wc.take((size_t)n_queries * k_stride_out * 8);
   const size_t o_ocnt = wc.take((size_t)n_queries * 4);
   const size_t o_ohits = wc.take((size_t)n_queries * 8);
   const size_t o_terms = wc.take((size_t)hp.n_dterms * sizeof(DTerm));  // written by expand_terms_kernel
   // per (query, searcher slice) the hits its items counted, per query "some item's slice has passed the floor": zeroed per call
   const size_t o_ssum = wc.take((size_t)n_queries * hp.n_slices * 4), o_qprune = wc.take((size_t)n_queries * 4);
+  // the helpers' state (zeroed per call as well): per MaxScore item the window counter, the helpers that joined, the owner's
+  // start time; per query the head of its helper-slot list; the "nothing left to help" flag
+  const size_t o_hwin = wc.take(hp.n_ms_items * 4), o_hcnt = wc.take(hp.n_ms_items * 4), o_ht0 = wc.take(hp.n_ms_items * 8);
+  const size_t o_hhead = wc.take((size_t)n_queries * 4), o_hnext = wc.take(n_help * 4), o_hoff = wc.take(4);
   const size_t zero_bytes = wc.off - o_ssum;
   // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
   const int flag_variant = (ctx->cfg.flags >> 8) & 15;
   const int ablation = hp.clause_counting ? 8 : ((hp.masked && flag_variant == 0 && !(ctx->cfg.flags & NRTGPU_FLAG_NO_MASK_VARIANT)) ? 9 : flag_variant);
   const bool profile = flag_variant == 7;
-  const size_t o_prof = wc.take((ablation == 7 || profile) ? n_items * 128 : 0);
+  const size_t o_prof = wc.take((ablation == 7 || profile) ? n_slots * 128 : 0);
+  const size_t o_walls = wc.take(profile ? n_slots * 32 : 0);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   char* db = (char*)slot->d_plan.p;
   char* wb = (char*)slot->d_work.p;
+  DHelp help{};
+  help.win_next = (uint32_t*)(wb + o_hwin);
+  help.help_cnt = (uint32_t*)(wb + o_hcnt);
+  help.item_t0 = (unsigned long long*)(wb + o_ht0);
+  help.help_head = (uint32_t*)(wb + o_hhead);
+  help.help_next = (uint32_t*)(wb + o_hnext);
+  help.help_off = (uint32_t*)(wb + o_hoff);
+  help.n_own = (uint32_t)hp.n_ms_items;
+  help.n_help = (uint32_t)n_help;
+  help.slot_base = (uint32_t)n_items;
+  help.min_rem = (uint32_t)std::max(env_help_min, 1);
+  help.walls = profile ? (unsigned long long*)(wb + o_walls) : nullptr;
+  memcpy(hb + o_help, &help, sizeof(help));   // (the kernel reads the record from the plan: maxscore.hip)
 
   hipStream_t st = slot->stream;
   HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
@@ -109,10 +137,12 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   if (ctx->last_turn && !overlap_scorers) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
   if (ctx->last_knn_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_knn_turn, 0));   // (vector searches do not queue behind each other, the scorers queue behind them)
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
+  if (profile && n_help) HIP_TRY(hipMemsetAsync(wb + o_prof + n_items * 128, 0, n_help * 128, st));   // (a helper that leaves at once writes nothing)
+  if (profile) HIP_TRY(hipMemsetAsync(wb + o_walls, 0, n_slots * 32, st));
   launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, hp.ms_shapes, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                        (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
                        (uint32_t*)(wb + o_ssum), (uint32_t*)(wb + o_qprune), use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
-                       profile ? (uint64_t*)(wb + o_prof) : nullptr);
+                       profile ? (uint64_t*)(wb + o_prof) : nullptr, help, (const DHelp*)(db + o_help));
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, ablation, (uint32_t)(n_items - n_ms),
                    (const DItem*)(db + o_items) + n_ms, (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
@@ -128,7 +158,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)(wb + o_ikeys), (const uint32_t*)(wb + o_icnt),
                     (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
                     (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
-                    k_stride_out);
+                    k_stride_out, n_help ? help.help_head : nullptr, help.help_next, help.slot_base);
   // TotalHits.relation by the reference's per-slice rule, tagged into the merged counts
   launch_slice_relation(st, (const uint32_t*)(wb + o_ssum), (const DQuery*)(db + o_queries), hp.n_slices, ohits, (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
@@ -144,6 +174,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   run->out_hits = ohits;
   run->prof = (ablation == 7 || profile) ? (uint64_t*)(wb + o_prof) : nullptr;
   run->n_items = n_items;
+  run->n_slots = n_slots;
+  run->walls = profile ? (uint64_t*)(wb + o_walls) : nullptr;
   run->n_ms_items = n_ms;
   return 0;
 }
@@ -270,11 +302,17 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     fprintf(stderr, "[nrtgpu call] %d queries: plan %.3f ms, upload + kernels %.3f, results to host %.3f, unpack %.3f\n", n_queries, plan_ms,
             tc1 - tc0, tc2 - tc1, now_ms() - tc2);
   if (run.prof && run.n_items) {
-    std::vector<uint64_t> hp_prof(run.n_items * 16);
+    std::vector<uint64_t> hp_prof(run.n_slots * 16);
     HIP_TRY(hipMemcpy(hp_prof.data(), run.prof, hp_prof.size() * 8, hipMemcpyDeviceToHost));
     std::lock_guard<std::mutex> lk(ctx->stats_mu);
-    for (size_t i = 0; i < run.n_items; ++i)
-      for (int j = 0; j < 16; ++j) (i < run.n_ms_items ? ctx->ms_prof : ctx->prof)[j] += (double)hp_prof[i * 16 + j];
+    for (size_t i = 0; i < run.n_slots; ++i)   // (slots behind the items: helpers of the MaxScore route)
+      for (int j = 0; j < 16; ++j) ((i < run.n_ms_items || i >= run.n_items) ? ctx->ms_prof : ctx->prof)[j] += (double)hp_prof[i * 16 + j];
+    if (run.walls) {   // the last instrumented launch's workgroups in time (nrtgpu_get_maxscore_item_walls)
+      std::vector<uint64_t> w(run.n_slots * 4);
+      (void)hipMemcpy(w.data(), run.walls, w.size() * 8, hipMemcpyDeviceToHost);
+      ctx->last_walls.swap(w);
+      ctx->last_walls_items = (int64_t)run.n_ms_items;
+    }
   }
   account(ctx, slot, hp, n_queries, plan_ms, t0, queue_ms);
   return NRTGPU_OK;
