@@ -74,7 +74,7 @@ struct MsSmem {
   uint32_t cnt;          // entries in cand
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kMsCandCap
   uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet
-  uint64_t pick;         // a helper's choice: float bits of the expected time left << 32 | item + 1
+  uint64_t pick;         // a helper's choice: float bits of its key (expected time left / an exponential variate) << 32 | item + 1
   uint32_t prune_on;     // bounds may skip work (kMsModeCount: raised once a slice's count has passed the query's gte_floor)
   uint32_t slot_hits[kSliceSlots];   // live matching docs evaluated, per searcher slice the item touches (plan.h: DPart.slice)
   uint32_t slot_slice[kSliceSlots];  // which slice a slot stands for
@@ -279,12 +279,19 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
       if ((fl & 3u) != kMsModePrune) continue;   // (counting items decide per workgroup when bounds may skip: not shared)
       const uint32_t nw = fl >> 8;
       const uint32_t taken = (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (taken + hp.min_rem > nw) continue;
+      if (taken + (hp.min_rem & 0xFFFFu) > nw) continue;
       const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t0 == 0ull || now <= t0) continue;     // its owner has not started yet
       const uint32_t hc = __hip_atomic_load(hp.help_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float left = (float)(now - t0) * (float)(nw - taken) / ((float)(taken - (uint32_t)kMsWaves + 1u) * (float)(1u + hc));
-      atomicMax((unsigned long long*)&s.pick, ((unsigned long long)__float_as_uint(left) << 32) | (unsigned long long)(i + 1u));
+      // Helpers come in herds (an item that ends frees its owner and all its helpers at once), and herd members cannot see each
+      // other's choices: each picks item i with PROBABILITY proportional to left_i -- the largest left_i / -ln(u_i), u_i uniform
+      // and its own -- so a herd spreads over the unfinished items in proportion to the time they have left.
+      uint32_t hsh = (blockIdx.x * 0x9E3779B9u) ^ (i * 0x85EBCA6Bu) ^ (uint32_t)now;
+      hsh ^= hsh >> 16; hsh *= 0x7FEB352Du; hsh ^= hsh >> 15; hsh *= 0x846CA68Bu; hsh ^= hsh >> 16;
+      const float u = ((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float key = (hp.min_rem >> 16) != 0u ? left : left / -__logf(u);   // (bit 16: A/B -- everybody takes the largest left_i)
+      atomicMax((unsigned long long*)&s.pick, ((unsigned long long)__float_as_uint(key) << 32) | (unsigned long long)(i + 1u));
     }
     __syncthreads();
     const uint64_t pick = s.pick;

@@ -227,7 +227,7 @@ struct DHelp {
   uint32_t* help_off;            // [1]       a helper found nothing left worth joining: the later ones leave at once
   uint32_t n_own, n_help;        // items of the launch, helper workgroups behind them
   uint32_t slot_base;            // output slot (item_keys / item_counts / item_hits) of helper 0
-  uint32_t min_rem;              // an item with fewer unassigned windows is not joined
+  uint32_t min_rem;              // bits 0-15: an item with fewer unassigned windows is not joined; bit 16: A/B, greedy choice
   unsigned long long* walls;     // instrumented kernel only, else nullptr: per output slot {start, end} on the 100 MHz wall clock and
                                  // {item, windows walked} -- when every workgroup of the launch ran, on one time base
                                  // (nrtgpu_get_maxscore_item_walls: the makespan against the balanced load)

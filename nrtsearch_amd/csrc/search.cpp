@@ -116,7 +116,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   help.n_own = (uint32_t)hp.n_ms_items;
   help.n_help = (uint32_t)n_help;
   help.slot_base = (uint32_t)n_items;
-  help.min_rem = (uint32_t)std::max(env_help_min, 1);
+  static const bool env_help_greedy = getenv("NRTGPU_MS_HELP_GREEDY") != nullptr && atoi(getenv("NRTGPU_MS_HELP_GREEDY")) != 0;
+  help.min_rem = (uint32_t)std::min(std::max(env_help_min, 1), 0xFFFF) | (env_help_greedy ? 1u << 16 : 0u);
   help.walls = profile ? (unsigned long long*)(wb + o_walls) : nullptr;
   memcpy(hb + o_help, &help, sizeof(help));   // (the kernel reads the record from the plan: maxscore.hip)
 
