@@ -14,7 +14,7 @@ T0=$(date +%s)
 el() { echo "== $1 ($(( $(date +%s) - T0 )) s)"; }
 show() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(sys.argv[1], d['value'], d['ms_per_step'], r['kernel'], r['avg_launch_ms'], r['frac'])" "$1" 2>/dev/null || echo "$1 FAILED"; }
 el "suite"
-timeout 900 python -m pytest tests -m gpu -q -x --tb=short -p no:cacheprovider > $O/pytest_suite.log 2>&1
+timeout 420 python -m pytest tests -m gpu -q --maxfail=6 --tb=short -p no:cacheprovider > $O/pytest_suite.log 2>&1
 echo "pytest rc=$?"; grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr" $O/pytest_suite.log | tail -8 | cut -c1-300
 timeout 120 python __graft_entry__.py smoke 2>&1 | tail -1
 el "parity soak"
@@ -24,19 +24,19 @@ NRTGPU_MS_HELPERS=0 timeout 200 python scripts/gpu_makespan.py 2>/dev/null | tee
 timeout 200 python scripts/gpu_makespan.py 2>/dev/null | tee $O/makespan_default.log | cut -c1-900
 NRTGPU_MS_HELP_GREEDY=1 timeout 200 python scripts/gpu_makespan.py 2>/dev/null | tee $O/makespan_greedy.log | cut -c1-900
 el "bench A/B"
-B="timeout 100 python bench.py --no-cpu-baseline --closed-loop ''"
+bc3() { env "$@" timeout 100 python bench.py --no-cpu-baseline --closed-loop ''; }   # bc3 [VAR=value ...]
 for rep in 1 2; do
-  eval $B 2>/dev/null | tee $O/c3_default_$rep.json | show "c3 default"
-  NRTGPU_MS_HELPERS=0 eval $B 2>/dev/null | tee $O/c3_helpers0_$rep.json | show "c3 HELPERS=0"
+  bc3 2>/dev/null | tee $O/c3_default_$rep.json | show "c3 default"
+  bc3 NRTGPU_MS_HELPERS=0 2>/dev/null | tee $O/c3_helpers0_$rep.json | show "c3 HELPERS=0"
 done
-NRTGPU_MS_LPT=0 eval $B 2>/dev/null | tee $O/c3_lpt0.json | show "c3 LPT=0"
-NRTGPU_MS_LPT=0 NRTGPU_MS_HELPERS=0 eval $B 2>/dev/null | tee $O/c3_lpt0_helpers0.json | show "c3 LPT=0 HELPERS=0 (round 3)"
-NRTGPU_MS_HELP_MIN=6 eval $B 2>/dev/null | tee $O/c3_min6.json | show "c3 HELP_MIN=6"
-NRTGPU_MS_HELP_MIN=40 eval $B 2>/dev/null | tee $O/c3_min40.json | show "c3 HELP_MIN=40"
-NRTGPU_MS_HELP_GREEDY=1 eval $B 2>/dev/null | tee $O/c3_greedy.json | show "c3 HELP_GREEDY=1"
-NRTGPU_MS_HELPERS=256 eval $B 2>/dev/null | tee $O/c3_h256.json | show "c3 HELPERS=256"
-NRTGPU_MS_HELPERS=4096 eval $B 2>/dev/null | tee $O/c3_h4096.json | show "c3 HELPERS=4096"
-NRTGPU_OVERLAP_SCORERS=1 eval $B 2>/dev/null | tee $O/c3_overlap.json | show "c3 OVERLAP_SCORERS=1"
+bc3 NRTGPU_MS_LPT=0 2>/dev/null | tee $O/c3_lpt0.json | show "c3 LPT=0"
+bc3 NRTGPU_MS_LPT=0 NRTGPU_MS_HELPERS=0 2>/dev/null | tee $O/c3_lpt0_helpers0.json | show "c3 LPT=0 HELPERS=0 (round 3)"
+bc3 NRTGPU_MS_HELP_MIN=6 2>/dev/null | tee $O/c3_min6.json | show "c3 HELP_MIN=6"
+bc3 NRTGPU_MS_HELP_MIN=40 2>/dev/null | tee $O/c3_min40.json | show "c3 HELP_MIN=40"
+bc3 NRTGPU_MS_HELP_GREEDY=1 2>/dev/null | tee $O/c3_greedy.json | show "c3 HELP_GREEDY=1"
+bc3 NRTGPU_MS_HELPERS=256 2>/dev/null | tee $O/c3_h256.json | show "c3 HELPERS=256"
+bc3 NRTGPU_MS_HELPERS=4096 2>/dev/null | tee $O/c3_h4096.json | show "c3 HELPERS=4096"
+bc3 NRTGPU_OVERLAP_SCORERS=1 2>/dev/null | tee $O/c3_overlap.json | show "c3 OVERLAP_SCORERS=1"
 for rep in 1 2 3; do timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --closed-loop '' 2>/dev/null | tee $O/c3_steps20_$rep.json | show "c3 --steps 20"; done
 timeout 100 python bench.py --no-cpu-baseline --closed-loop '' --workload C2 2>/dev/null | tee $O/c2_default.json | show "c2 default"
 NRTGPU_MS_HELPERS=0 timeout 100 python bench.py --no-cpu-baseline --closed-loop '' --workload C2 2>/dev/null | tee $O/c2_helpers0.json | show "c2 HELPERS=0"
