@@ -40,11 +40,11 @@ final class GpuEligibility {
 
   record Plan(MemorySegment query, MemorySegment out, MemorySegment docs, MemorySegment scores, int k) {
     TopDocs toTopDocs() {
-      int n = out.get(JAVA_INT, 0);
+      int n = out.get(JAVA_INT, NrtGpuLayouts.TOPDOCS_N_HITS);
       ScoreDoc[] hits = new ScoreDoc[n];
       for (int i = 0; i < n; i++) hits[i] = new ScoreDoc(docs.getAtIndex(JAVA_INT, i), scores.getAtIndex(JAVA_FLOAT, i));
-      TotalHits.Relation rel = out.get(JAVA_INT, 32) != 0 ? TotalHits.Relation.GREATER_THAN_OR_EQUAL_TO : TotalHits.Relation.EQUAL_TO;
-      return new TopDocs(new TotalHits(out.get(JAVA_LONG, 24), rel), hits);
+      TotalHits.Relation rel = out.get(JAVA_INT, NrtGpuLayouts.TOPDOCS_TOTAL_HITS_IS_LOWER_BOUND) != 0 ? TotalHits.Relation.GREATER_THAN_OR_EQUAL_TO : TotalHits.Relation.EQUAL_TO;
+      return new TopDocs(new TotalHits(out.get(JAVA_LONG, NrtGpuLayouts.TOPDOCS_TOTAL_HITS), rel), hits);
     }
   }
 
@@ -155,10 +155,10 @@ final class GpuEligibility {
       float idf = ts.docFreq() == 0 || cs == null ? 0f
           : (float) Math.log(1 + (cs.docCount() - ts.docFreq() + 0.5D) / (ts.docFreq() + 0.5D));   // BM25Similarity.idf
       MemorySegment t = terms.asSlice(i * NrtGpu.TERM.byteSize(), NrtGpu.TERM.byteSize());
-      t.set(JAVA_INT, 0, store.fieldId(c.term().field()));
-      t.set(JAVA_INT, 4, fields.indexOf(c.term().field()));
-      t.set(JAVA_LONG, 8, GpuSegmentStore.termHash(c.term().bytes()));
-      t.set(JAVA_FLOAT, 16, c.boost() * idf);
+      t.set(JAVA_INT, NrtGpuLayouts.TERM_FIELD_ID, store.fieldId(c.term().field()));
+      t.set(JAVA_INT, NrtGpuLayouts.TERM_CACHE_SLOT, fields.indexOf(c.term().field()));
+      t.set(JAVA_LONG, NrtGpuLayouts.TERM_TERM_HASH, GpuSegmentStore.termHash(c.term().bytes()));
+      t.set(JAVA_FLOAT, NrtGpuLayouts.TERM_WEIGHT, c.boost() * idf);
     }
     MemorySegment cache = a.allocate(JAVA_FLOAT, fields.size() * 256L);
     for (int f = 0; f < fields.size(); f++) {
@@ -168,23 +168,23 @@ final class GpuEligibility {
         cache.setAtIndex(JAVA_FLOAT, f * 256L + i, 1f / (1.2f * ((1f - 0.75f) + 0.75f * org.apache.lucene.util.SmallFloat.byte4ToInt((byte) i) / avgdl)));
     }
     MemorySegment q = a.allocate(NrtGpu.QUERY);
-    q.set(JAVA_INT, 0, clauses.size());
-    q.set(ADDRESS, 8, terms);
-    q.set(JAVA_INT, 16, fields.size());
-    q.set(ADDRESS, 24, cache);
-    q.set(JAVA_INT, 32, k);
-    q.set(JAVA_INT, 36, totalHitsThreshold);
-    q.set(JAVA_INT, 40, after != null ? 1 : 0);
-    q.set(JAVA_INT, 44, after != null ? after.doc : 0);
-    q.set(JAVA_FLOAT, 48, after != null ? after.score : 0f);
-    q.set(JAVA_INT, 52, msm);
-    q.set(JAVA_INT, 60, filterMask);
-    q.set(JAVA_INT, 64, mustNotMask);
-    q.set(JAVA_INT, 68, disjunctionMax);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_N_TERMS, clauses.size());
+    q.set(ADDRESS, NrtGpuLayouts.QUERY_TERMS, terms);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_N_CACHES, fields.size());
+    q.set(ADDRESS, NrtGpuLayouts.QUERY_NORM_CACHE, cache);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_K, k);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_TOTAL_HITS_THRESHOLD, totalHitsThreshold);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_HAS_AFTER, after != null ? 1 : 0);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_AFTER_DOC, after != null ? after.doc : 0);
+    q.set(JAVA_FLOAT, NrtGpuLayouts.QUERY_AFTER_SCORE, after != null ? after.score : 0f);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_MIN_SHOULD_MATCH, msm);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_FILTER_MASK, filterMask);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_MUST_NOT_MASK, mustNotMask);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_DISJUNCTION_MAX, disjunctionMax);
     MemorySegment docs = a.allocate(JAVA_INT, k), scores = a.allocate(JAVA_FLOAT, k), out = a.allocate(NrtGpu.TOPDOCS);
-    out.set(JAVA_INT, 4, k);
-    out.set(ADDRESS, 8, docs);
-    out.set(ADDRESS, 16, scores);
+    out.set(JAVA_INT, NrtGpuLayouts.TOPDOCS_CAPACITY, k);
+    out.set(ADDRESS, NrtGpuLayouts.TOPDOCS_DOCS, docs);
+    out.set(ADDRESS, NrtGpuLayouts.TOPDOCS_SCORES, scores);
     return new Plan(q, out, docs, scores, k);
   }
 }

@@ -75,9 +75,9 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       MemorySegment q = a.allocate(JAVA_FLOAT, vs.vector().length);
       MemorySegment.copy(vs.vector(), 0, q, JAVA_FLOAT, 0, vs.vector().length);
       MemorySegment docs = a.allocate(JAVA_INT, k), scores = a.allocate(JAVA_FLOAT, k), out = a.allocate(NrtGpu.TOPDOCS);
-      out.set(JAVA_INT, 4, k);
-      out.set(ADDRESS, 8, docs);
-      out.set(ADDRESS, 16, scores);
+      out.set(JAVA_INT, NrtGpuLayouts.TOPDOCS_CAPACITY, k);
+      out.set(ADDRESS, NrtGpuLayouts.TOPDOCS_DOCS, docs);
+      out.set(ADDRESS, NrtGpuLayouts.TOPDOCS_SCORES, scores);
       long deadline = timeoutSec > 0.0 ? (long) NrtGpu.MONOTONIC_NS.invokeExact() + (long) (timeoutSec * 1e9) : 0L;
       int status;
       try {
@@ -89,10 +89,10 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       }
       if (status == NrtGpu.ERR_UNSUPPORTED || status == NrtGpu.ERR_TIMEOUT) return null;
       NrtGpu.check(status);
-      int n = out.get(JAVA_INT, 0);
+      int n = out.get(JAVA_INT, NrtGpuLayouts.TOPDOCS_N_HITS);
       ScoreDoc[] hits = new ScoreDoc[n];
       for (int i = 0; i < n; i++) hits[i] = new ScoreDoc(docs.getAtIndex(JAVA_INT, i), scores.getAtIndex(JAVA_FLOAT, i));
-      return new TopDocs(new TotalHits(out.get(JAVA_LONG, 24), TotalHits.Relation.EQUAL_TO), hits);   // every live doc with a vector matches
+      return new TopDocs(new TotalHits(out.get(JAVA_LONG, NrtGpuLayouts.TOPDOCS_TOTAL_HITS), TotalHits.Relation.EQUAL_TO), hits);   // every live doc with a vector matches
     } catch (IOException | RuntimeException e) {
       throw e;
     } catch (Throwable t) {
@@ -150,8 +150,9 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       NrtGpu.check(status);
       MemorySegment d = a.allocate(NrtGpu.DIAGNOSTICS);
       if ((int) NrtGpu.LAST_DIAGNOSTICS.invokeExact(d) == NrtGpu.OK)
-        LAST_DIAGNOSTICS.set(new double[] {d.get(JAVA_DOUBLE, 0), d.get(JAVA_DOUBLE, 8), d.get(JAVA_DOUBLE, 16), d.get(JAVA_DOUBLE, 24),
-            (double) d.get(JAVA_LONG, 32)});
+        LAST_DIAGNOSTICS.set(new double[] {d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_TOTAL_MS), d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_PLAN_MS),
+            d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_QUEUE_MS), d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_DEVICE_MS),
+            (double) d.get(JAVA_LONG, NrtGpuLayouts.DIAGNOSTICS_POSTINGS)});
       return (T) new SearcherResult(plan.toTopDocs(), Map.of());       // search/SearcherResult.java:31-34
     } catch (IOException | RuntimeException e) {
       throw e;

@@ -26,8 +26,8 @@ public class GpuPlugin extends Plugin {
   public GpuPlugin(NrtsearchConfig config) throws Exception {
     try (Arena a = Arena.ofConfined()) {
       MemorySegment cfg = a.allocate(NrtGpu.CONFIG);
-      cfg.set(JAVA_INT, 0, Integer.getInteger("nrtgpu.device", 0));
-      cfg.set(JAVA_INT, 4, 1024);     // max_batch
+      cfg.set(JAVA_INT, NrtGpuLayouts.CONFIG_DEVICE_ID, Integer.getInteger("nrtgpu.device", 0));
+      cfg.set(JAVA_INT, NrtGpuLayouts.CONFIG_MAX_BATCH, 1024);     // max_batch
       MemorySegment out = a.allocate(ADDRESS);
       try {
         NrtGpu.check((int) NrtGpu.CREATE.invokeExact(cfg, out));       // fails loudly without a gfx950 device: no CPU fallback inside
@@ -40,6 +40,7 @@ public class GpuPlugin extends Plugin {
     }
     store = new GpuSegmentStore(ctx);
     masks = new GpuMaskCache(Integer.getInteger("nrtgpu.maskCache", 64));
+    store.attach(masks);   // handles are freed through the cache: it forgets them first (GpuMaskCache.releaseHandle)
     java.util.List<String> text = java.util.Arrays.asList(System.getProperty("nrtgpu.textFields", "").split(","));
     java.util.List<String> vectors = java.util.Arrays.asList(System.getProperty("nrtgpu.vectorFields", "").split(","));
     MyIndexSearcher.setSearcherHook((reader, previousReader, executor, slicing) -> {

@@ -21,14 +21,32 @@ import org.apache.lucene.util.BytesRef;
  * NOT COMPILED here (no JDK).
  */
 final class GpuSegmentStore {
-  record Resident(MemorySegment seg, long liveDocsVersion) {}
+  /** A native handle and its generation: `uid` is never reused, the handle's ADDRESS may be (the allocator recycles it), so
+   *  whoever remembers handles across a release (GpuMaskCache) keys them by uid. */
+  record Handle(MemorySegment seg, long uid) {}
 
   private final MemorySegment ctx;
-  private final Map<IndexReader.CacheKey, Resident> resident = new ConcurrentHashMap<>();      // by segment core
-  private final Map<IndexReader.CacheKey, MemorySegment> versions = new ConcurrentHashMap<>();  // by leaf reader version: forks
+  private final Map<IndexReader.CacheKey, Handle> resident = new ConcurrentHashMap<>();   // by segment core
+  private final Map<IndexReader.CacheKey, Handle> versions = new ConcurrentHashMap<>();   // by leaf reader version: forks
   private final Map<String, Integer> fieldIds = new ConcurrentHashMap<>();
+  private final java.util.concurrent.atomic.AtomicLong nextUid = new java.util.concurrent.atomic.AtomicLong(1);
+  private volatile GpuMaskCache masks;    // told about every release BEFORE the handle is freed (GpuPlugin wires it)
 
   GpuSegmentStore(MemorySegment ctx) { this.ctx = ctx; }
+
+  void attach(GpuMaskCache maskCache) { this.masks = maskCache; }
+
+  /** nrtgpu_segment_release, after everybody who remembers the handle has forgotten it -- under the mask cache's lock, so that
+   *  an eviction (which calls nrtgpu_segment_set_mask on the handles it remembers) never meets a freed one.  Searches still in
+   *  flight over the handle are the library's business: the last of them frees it (include/nrtgpu.h). */
+  private void release(Handle h) {
+    GpuMaskCache m = masks;
+    if (m != null) {
+      m.releaseHandle(h);
+    } else {
+      try { NrtGpu.RELEASE.invokeExact(h.seg()); } catch (Throwable ignored) { }
+    }
+  }
 
   int fieldId(String field) { return fieldIds.computeIfAbsent(field, f -> fieldIds.size() + 1); }
 
@@ -52,7 +70,7 @@ final class GpuSegmentStore {
       LeafReader leaf = lc.reader();
       IndexReader.CacheHelper core = leaf.getCoreCacheHelper();
       if (core == null) continue;                       // not cacheable: this leaf stays on the CPU path
-      Resident r = resident.get(core.getKey());
+      Handle r = resident.get(core.getKey());
       if (r == null) {
         MemorySegment seg;
         try {
@@ -60,36 +78,38 @@ final class GpuSegmentStore {
         } catch (IllegalArgumentException collision) {   // NRTGPU_ERR_INVALID_ARG: a term id added twice
           continue;                                       // this segment is searched by Lucene (segmentOf -> null)
         }
-        r = new Resident(seg, -1);
+        r = new Handle(seg, nextUid.getAndIncrement());
         resident.put(core.getKey(), r);
         core.addClosedListener(key -> {                 // segment merged away / last reader closed
-          Resident gone = resident.remove(key);
-          if (gone != null) try { NrtGpu.RELEASE.invokeExact(gone.seg()); } catch (Throwable ignored) { }
+          Handle gone = resident.remove(key);            // (out of the map first: nobody finds it any more)
+          if (gone != null) release(gone);
         });
       }
       IndexReader.CacheHelper version = leaf.getReaderCacheHelper();
       if (leaf.getLiveDocs() != null && version != null && !versions.containsKey(version.getKey())) {
-        MemorySegment fork = fork(r.seg(), leaf.getLiveDocs(), leaf.maxDoc());
+        Handle fork = new Handle(fork(r.seg(), leaf.getLiveDocs(), leaf.maxDoc()), nextUid.getAndIncrement());
         versions.put(version.getKey(), fork);
         version.addClosedListener(key -> {              // this reader version is gone
-          MemorySegment gone = versions.remove(key);
-          if (gone != null) try { NrtGpu.RELEASE.invokeExact(gone); } catch (Throwable ignored) { }
+          Handle gone = versions.remove(key);
+          if (gone != null) release(gone);
         });
       }
     }
   }
 
   /** The handle a search over this leaf READER uses: its version's fork when it has deletes, else the core's handle. */
-  MemorySegment segmentOf(LeafReaderContext lc) {
+  Handle handleOf(LeafReaderContext lc) {
     LeafReader leaf = lc.reader();
     IndexReader.CacheHelper version = leaf.getReaderCacheHelper();
-    if (leaf.getLiveDocs() != null) {
-      MemorySegment fork = version == null ? null : versions.get(version.getKey());
-      return fork;                                      // (null: a version the store has not seen -- CPU path)
-    }
+    if (leaf.getLiveDocs() != null)
+      return version == null ? null : versions.get(version.getKey());   // (null: a version the store has not seen -- CPU path)
     IndexReader.CacheHelper core = leaf.getCoreCacheHelper();
-    Resident r = core == null ? null : resident.get(core.getKey());
-    return r == null ? null : r.seg();
+    return core == null ? null : resident.get(core.getKey());
+  }
+
+  MemorySegment segmentOf(LeafReaderContext lc) {
+    Handle h = handleOf(lc);
+    return h == null ? null : h.seg();
   }
 
   private static MemorySegment fork(MemorySegment seg, Bits live, int maxDoc) throws IOException {

@@ -46,12 +46,12 @@ final class GpuVectorRescorer implements RescoreOperation {
       for (int i = 0; i < n; i++) { docs.setAtIndex(JAVA_INT, i, hits.scoreDocs[i].doc); first.setAtIndex(JAVA_FLOAT, i, hits.scoreDocs[i].score); }
       MemorySegment.copy(queryVector, 0, q, JAVA_FLOAT, 0, queryVector.length);
       MemorySegment od = a.allocate(JAVA_INT, window), os = a.allocate(JAVA_FLOAT, window), out = a.allocate(NrtGpu.TOPDOCS);
-      out.set(JAVA_INT, 4, window);
-      out.set(ADDRESS, 8, od);
-      out.set(ADDRESS, 16, os);
+      out.set(JAVA_INT, NrtGpuLayouts.TOPDOCS_CAPACITY, window);
+      out.set(ADDRESS, NrtGpuLayouts.TOPDOCS_DOCS, od);
+      out.set(ADDRESS, NrtGpuLayouts.TOPDOCS_SCORES, os);
       NrtGpu.check((int) NrtGpu.RESCORE.invokeExact(ctx, segs, bases, leaves.size(), store.fieldId(field), sim, q, queryVector.length, 1.0f,
           docs, first, n, queryWeight, rescoreWeight, window, out));
-      int m = out.get(JAVA_INT, 0);
+      int m = out.get(JAVA_INT, NrtGpuLayouts.TOPDOCS_N_HITS);
       ScoreDoc[] res = new ScoreDoc[m];
       for (int i = 0; i < m; i++) res[i] = new ScoreDoc(od.getAtIndex(JAVA_INT, i), os.getAtIndex(JAVA_FLOAT, i));
       return new TopDocs(hits.totalHits, res);                            // QueryRescorer keeps the first pass's TotalHits

@@ -8,8 +8,9 @@ import java.lang.invoke.MethodHandle;
 
 /**
  * FFM binding of include/nrtgpu.h (x86-64 SysV).  No logic: one downcall handle per ABI function the plugin uses and the
- * struct layouts, whose sizes tests/test_abi.py pins on the library side (nrtgpu_term 24 B, nrtgpu_bm25_query 72 B,
- * nrtgpu_topdocs 40 B, nrtgpu_diagnostics 56 B).  NOT COMPILED in the image this repository is developed in (no JDK).
+ * struct layouts.  Field OFFSETS are never typed by hand: the shim's accessors go through {@link NrtGpuLayouts}, generated from
+ * the header by scripts/gen_java_layouts.py (gcc's offsetof), and tests/test_java_layouts.py checks these StructLayouts member by
+ * member against the same numbers.  NOT COMPILED in the image this repository is developed in (no JDK).
  */
 final class NrtGpu {
   private NrtGpu() {}

@@ -500,16 +500,14 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
     const float leaf_inv = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lf.inv_rows_scale)));
     const int32_t* const ord_to_doc = (const int32_t*)u_o2d;
     const uint64_t* const live_bits = (const uint64_t*)u_accept;
-    // The norms' pointer.  Rebuilt from the leaf record it is a GENERIC pointer to the compiler, which then loads a tile's norms
-    // with flat VECTOR loads (vmcnt) and drains the ring at the tile's first use of one -- what the build does today.  In the
-    // constant address space the same loads are scalar (s_load, lgkmcnt) as they were before the leaf table: compiled and read,
-    // not yet run (profiles/r03_knn_sketch_isa_note.txt; build.py extra=["-DNRT_KNN_SCALAR_NORMS"], scripts/gpu_r04_a.sh).
-#ifdef NRT_KNN_SCALAR_NORMS
+    // The norms' pointer.  Rebuilt from the leaf record it would be a GENERIC pointer to the compiler, which then loads a tile's
+    // norms with flat VECTOR loads (vmcnt) and drains the ring at the tile's first use of one (round 3's build:
+    // profiles/r03_knn_sketch_isa_note.txt).  In the constant address space the same loads are scalar (s_load, lgkmcnt), as they
+    // were before the leaf table.  Round 4, same box, interleaved (profiles/r04_knn_scalar_norms_ab.log): the vector tests, 64 fuzz
+    // rounds and the BASELINE-size tests bit-exact; kernel 2.66 -> 2.60 ms at 32 queries, 2.85 -> 2.82 at 64; no scratch in any
+    // instantiation (<4, 8> had 36 B).
     typedef const float __attribute__((address_space(4))) cfloat_k;
     cfloat_k* const vnorm2 = (cfloat_k*)u_norms;
-#else
-    const float* const vnorm2 = (const float*)u_norms;
-#endif
     const int64_t t0 = t_run - leaf_t0, t1 = min(t_run_end, leaf_t0 + (((int64_t)leaf_rows + 15) >> 4)) - leaf_t0;   // local tiles
     // the run as groups of D pieces (a tile is steps / D whole groups): `cur` walks the groups, the ring slot of piece i of a
     // group is i, and the piece D ahead -- the same slot of the NEXT group -- is requested the moment slot i has been consumed

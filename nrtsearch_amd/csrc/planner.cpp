@@ -683,10 +683,12 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // index order, so big items start first and small ones fill the tail
   // (cf. slices ordered largest first, MyIndexSearcher.java:154-158)
   {
-    // The MaxScore items' longest-first key: the postings of the query's two heaviest clauses (resolve_queries) instead of all
-    // its postings.  Results do not depend on the launch order (an item's output slot is assigned after the sort);
-    // NRTGPU_MS_LPT=0 restores the order round 3's profiles were measured with.
-    static const bool ms_lpt = getenv("NRTGPU_MS_LPT") == nullptr || atoi(getenv("NRTGPU_MS_LPT")) != 0;
+    // The MaxScore items' longest-first key.  Round 3 closed with "the postings of the query's two heaviest clauses" as the
+    // default on a CPU model's word (makespan 1.56 -> 1.33 x the balanced load) and no measurement.  Measured in round 4, same box,
+    // interleaved (profiles/r04_helpers_v1_ab.log): the two-clause key is SLOWER than all postings -- 3.00 vs 2.85 ms per 1024 C3
+    // queries without helper workgroups, 2.62 vs 2.51 with them.  The default is all postings again; NRTGPU_MS_LPT=1 keeps the
+    // two-clause key for A/B.  Results do not depend on the launch order (an item's output slot is assigned after the sort).
+    static const bool ms_lpt = getenv("NRTGPU_MS_LPT") != nullptr && atoi(getenv("NRTGPU_MS_LPT")) != 0;
     if (ms_lpt)
       for (Pending& a : pend)
         if (on_ms_kernel(a.query) && q_costs[(size_t)a.query] > 0)   // an item's share of its query's key

@@ -274,6 +274,7 @@ struct SegCore {
   std::vector<uint64_t> folded_live;
   bool folded = false;
   std::mutex sketch_mu;   // the lazy build of a vector field's sketch
+  std::atomic<int64_t> shared_extra_bytes{0};   // device memory added to the core after the seal (the sketches): counted for every handle
   ~SegCore();
 };
 struct nrtgpu_seg {
@@ -295,10 +296,23 @@ struct nrtgpu_seg {
   // and the combined accept sets (live & filter & ~must_not) the scan reads, built on first use
   std::vector<uint64_t> h_live;                      // empty = all live
   bool live_folded = false;  // the posting columns carry the current liveDocs (apply_live_kernel): the scan needs no mask for them
-  // searches hold this shared from planning until their kernels have finished; set_live_docs / set_mask take it
-  // exclusively, so a reader-version change never rewrites columns or masks under a running scan
-  mutable std::shared_mutex content_mu;
-  mutable std::atomic<int> content_writers{0};  // pending exclusive owners: new searches let them go first (no writer starvation)
+  // The content lock.  Searches hold it SHARED from planning until their kernels have finished; set_live_docs / set_mask
+  // take it exclusively, so a reader-version change never rewrites columns or masks under a running scan.  Not a
+  // std::shared_mutex: a search begun on one thread may be waited for on another (nrtgpu_search_bm25_batch_device_begin /
+  // nrtgpu_pending_wait -- unlocking a std::shared_mutex from a thread that does not hold it is undefined), and
+  // nrtgpu_segment_release under running searches must not free what they read (ShardState.java:506-527 closes readers
+  // while SEARCH-pool threads run): the handle is then freed by the LAST search that lets go of it.
+  mutable std::mutex content_m;
+  mutable std::condition_variable content_cv;
+  mutable int content_readers = 0;          // searches in flight over this handle
+  mutable int content_writers_waiting = 0;  // pending exclusive owners: new searches let them go first (no writer starvation) ...
+  mutable int content_bypass = 0;           // ... except up to kContentBypass searches per waiting writer while others are still in
+                                            // flight: a pipeline that begins search i + 1 before it waits for search i must not
+                                            // deadlock against a writer that waits for search i
+  mutable bool content_writing = false;
+  mutable bool content_released = false;    // nrtgpu_segment_release came while searches were in flight: the last one frees
+  void content_lock_shared() const;
+  void content_unlock_shared() const;       // may free the handle (content_released)
   std::map<int32_t, std::vector<uint64_t>> masks;
   mutable std::mutex accept_mu;
   mutable std::map<std::pair<int32_t, int32_t>, uint64_t*> accept;
@@ -321,13 +335,10 @@ struct SegReadLocks {
       if (segs && segs[i]) held.push_back(segs[i]);
     std::sort(held.begin(), held.end());
     held.erase(std::unique(held.begin(), held.end()), held.end());
-    for (const nrtgpu_seg* s : held) {
-      while (s->content_writers.load(std::memory_order_acquire) > 0) std::this_thread::yield();
-      s->content_mu.lock_shared();
-    }
+    for (const nrtgpu_seg* s : held) s->content_lock_shared();
   }
-  ~SegReadLocks() {
-    for (const nrtgpu_seg* s : held) s->content_mu.unlock_shared();
+  ~SegReadLocks() {   // (any thread: nrtgpu_pending_wait may run on another one than the begin)
+    for (const nrtgpu_seg* s : held) s->content_unlock_shared();
   }
   SegReadLocks(const SegReadLocks&) = delete;
   SegReadLocks& operator=(const SegReadLocks&) = delete;

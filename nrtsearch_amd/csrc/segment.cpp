@@ -2,13 +2,56 @@
 // (upload, seal, liveDocs folded into the posting columns, doc-set masks and their combined accept sets).
 #include "runtime_internal.h"
 
+static void destroy_segment(nrtgpu_seg* seg);
+constexpr int kContentBypass = 16;   // searches that may still start over a handle per waiting writer while others are in flight
+
 SegWriteLock::SegWriteLock(nrtgpu_seg* s) : seg(s) {
-  seg->content_writers.fetch_add(1, std::memory_order_acq_rel);
-  seg->content_mu.lock();
+  std::unique_lock<std::mutex> lk(seg->content_m);
+  seg->content_writers_waiting++;
+  seg->content_cv.wait(lk, [&] { return seg->content_readers == 0 && !seg->content_writing; });
+  seg->content_writers_waiting--;
+  seg->content_bypass = 0;
+  seg->content_writing = true;
 }
 SegWriteLock::~SegWriteLock() {
-  seg->content_mu.unlock();
-  seg->content_writers.fetch_sub(1, std::memory_order_acq_rel);
+  bool free_now = false;
+  {
+    std::lock_guard<std::mutex> lk(seg->content_m);
+    seg->content_writing = false;
+    free_now = seg->content_released && seg->content_readers == 0;   // released while this writer held it
+  }
+  if (free_now) {
+    destroy_segment(seg);
+    return;
+  }
+  seg->content_cv.notify_all();
+}
+void nrtgpu_seg::content_lock_shared() const {
+  std::unique_lock<std::mutex> lk(content_m);
+  for (;;) {
+    if (!content_writing && content_writers_waiting == 0) break;
+    // a writer waits for the searches in flight.  The caller may be the thread that must still wait for one of THEM (begin i + 1
+    // before wait i): let a bounded number through instead of parking it behind the writer
+    if (!content_writing && content_readers > 0 && content_bypass < kContentBypass) {
+      content_bypass++;
+      break;
+    }
+    content_cv.wait(lk);
+  }
+  content_readers++;
+}
+void nrtgpu_seg::content_unlock_shared() const {
+  bool last_of_released = false;
+  {
+    std::lock_guard<std::mutex> lk(content_m);
+    content_readers--;
+    last_of_released = content_readers == 0 && content_released && !content_writing;
+  }
+  if (last_of_released) {
+    destroy_segment(const_cast<nrtgpu_seg*>(this));   // nrtgpu_segment_release came while this search ran
+    return;
+  }
+  content_cv.notify_all();
 }
 
 static const size_t kMaxAcceptSets = 64;   // combined accept sets (liveDocs & filter & ~must_not) resident per segment
@@ -584,11 +627,16 @@ int nrtgpu::rt::ensure_vector_sketch(const nrtgpu_seg* seg, int32_t field_id) {
   (void)std::frexp(f.absmax, &e);   // absmax < 2^e
   f.sketch_scale = f.absmax > 0.f ? std::ldexp(1.0f, 14 - e) : 1.0f;
   launch_knn_sketch_build(nullptr, f.d_vectors, f.dim, f.n_vec, f.sketch_scale, p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(nullptr));
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+  if (he != hipSuccess) {   // no sketch for this field, ever (the fp32 pass serves it): nothing leaks, nobody retries
+    (void)hipFree(p);
+    f.sketch_state = -1;
+    return fail(NRTGPU_ERR_HIP, "vector sketch build: %s", hipGetErrorString(he));
+  }
   f.d_sketch = p;
   f.sketch_state = 1;
-  const_cast<nrtgpu_seg*>(seg)->device_bytes += (int64_t)bytes;
+  seg->core->shared_extra_bytes.fetch_add((int64_t)bytes, std::memory_order_relaxed);   // (the core's, not the handle's that happened to trigger it)
   return NRTGPU_OK;
 }
 
@@ -612,12 +660,26 @@ SegCore::~SegCore() {
   }
 }
 
-extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
-  if (!seg) return;
+static void destroy_segment(nrtgpu_seg* seg) {
   (void)hipSetDevice(seg->ctx->device);
   drop_accept_sets(seg);
   if (seg->d_live) (void)hipFree(seg->d_live);
   delete seg;   // (the shared core -- columns, norms, vectors -- goes with its last handle)
+}
+
+// Safe under running searches (the reference closes readers while SEARCH-pool threads run: ShardState.java:506-527; close
+// listeners: TextBaseFieldDef.java:335-371): the searches in flight over the handle keep what they read, and the last of
+// them frees it.  The caller must not START a search with the handle after this call.
+extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
+  if (!seg) return;
+  {
+    std::lock_guard<std::mutex> lk(seg->content_m);
+    if (seg->content_readers > 0 || seg->content_writing) {
+      seg->content_released = true;
+      return;
+    }
+  }
+  destroy_segment(seg);
 }
 
 // A new reader version of a sealed segment: same immutable data (shared, not copied), its own liveDocs / masks.  Searches
@@ -639,4 +701,6 @@ extern "C" int nrtgpu_segment_fork(nrtgpu_seg* seg, const uint64_t* live_bits, i
   return NRTGPU_OK;
 }
 
-extern "C" int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg) { return seg ? seg->device_bytes : 0; }
+extern "C" int64_t nrtgpu_segment_device_bytes(const nrtgpu_seg* seg) {
+  return seg ? seg->device_bytes + seg->core->shared_extra_bytes.load(std::memory_order_relaxed) : 0;
+}
