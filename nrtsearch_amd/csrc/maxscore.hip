@@ -75,6 +75,7 @@ struct MsSmem {
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kMsCandCap
   uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet
   uint64_t pick;         // a helper's choice: float bits of its key (expected time left / an exponential variate) << 32 | item + 1
+  uint32_t role[4];      // the workgroup's first decision (start the next item / help one): scratch values every thread reads
   uint32_t prune_on;     // bounds may skip work (kMsModeCount: raised once a slice's count has passed the query's gte_floor)
   uint32_t slot_hits[kSliceSlots];   // live matching docs evaluated, per searcher slice the item touches (plan.h: DPart.slice)
   uint32_t slot_slice[kSliceSlots];  // which slice a slot stands for
@@ -262,47 +263,107 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   const DHelp& hp = *hpp;   // (resident next to the plan: its fields are scalar loads where they are used, not kernel arguments held in registers)
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  // ---- which item?  The first n_own workgroups own one each.  The workgroups behind them are HELPERS (plan.h: DHelp): they get
-  //      a CU when the items have run out, and join the unfinished item with the most time left -- its windows come from a
-  //      counter in global memory, so owner and helpers simply share them.  Expected time left = the time the item has run so
-  //      far x unassigned windows / windows handed out, divided among the helpers already there.  Nothing worth joining: the
-  //      helper says so (help_off) and every later one leaves at once.
-  const bool helper = blockIdx.x >= hp.n_own;
-  uint32_t my_item = blockIdx.x;
-  if (helper) {
-    if (tid == 0) s.pick = __hip_atomic_load(hp.help_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? ~0ull : 0ull;
-    __syncthreads();
-    if (s.pick == ~0ull) return;   // (uniform)
-    const uint64_t now = wall_clock64();
-    for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
-      const uint32_t fl = items[i].flags;
-      if ((fl & 3u) != kMsModePrune) continue;   // (counting items decide per workgroup when bounds may skip: not shared)
-      const uint32_t nw = fl >> 8;
-      const uint32_t taken = (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (taken + (hp.min_rem & 0xFFFFu) > nw) continue;
-      const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t0 == 0ull || now <= t0) continue;     // its owner has not started yet
-      const uint32_t hc = __hip_atomic_load(hp.help_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float left = (float)(now - t0) * (float)(nw - taken) / ((float)(taken - (uint32_t)kMsWaves + 1u) * (float)(1u + hc));
-      // Helpers come in herds (an item that ends frees its owner and all its helpers at once), and herd members cannot see each
-      // other's choices: each picks item i with PROBABILITY proportional to left_i -- the largest left_i / -ln(u_i), u_i uniform
-      // and its own -- so a herd spreads over the unfinished items in proportion to the time they have left.
-      uint32_t hsh = (blockIdx.x * 0x9E3779B9u) ^ (i * 0x85EBCA6Bu) ^ (uint32_t)now;
-      hsh ^= hsh >> 16; hsh *= 0x7FEB352Du; hsh ^= hsh >> 15; hsh *= 0x846CA68Bu; hsh ^= hsh >> 16;
-      const float u = ((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const float key = (hp.min_rem >> 16) != 0u ? left : left / -__logf(u);   // (bit 16: A/B -- everybody takes the largest left_i)
-      atomicMax((unsigned long long*)&s.pick, ((unsigned long long)__float_as_uint(key) << 32) | (unsigned long long)(i + 1u));
+  // ---- what does this workgroup do?  The launch has n_own + n_help workgroups and a QUEUE of n_own items in launch order
+  //      (plan.h: DHelp.item_next).  A workgroup that gets a CU either starts the next item or HELPS one that is running: a
+  //      running item's windows come from a counter in global memory, so its owner and any number of helpers simply share them.
+  //        * While items are queued, it helps only an item on the launch's CRITICAL PATH: one whose expected time left -- the
+  //          time it has run so far x unassigned windows / windows handed out, divided among the helpers already there --
+  //          exceeds what is left of the whole launch (elapsed x windows not handed out / windows handed out over ALL items,
+  //          x alpha).  That item would end after everything else; a CU is better spent on it than on starting one more item.
+  //        * Once the queue is empty, it helps any item with min_rem windows left (the tail), or leaves.
+  //      At most n_help workgroups help (they reserve an output slot each), so at least n_own start items: the queue drains.
+  //      Helpers come in herds (an item that ends frees its owner and its helpers at once) whose members cannot see each
+  //      other's choices: each picks item i with PROBABILITY proportional to left_i -- the largest left_i / -ln(u_i), u_i
+  //      uniform and its own -- so a herd spreads over the candidates in proportion to the time they have left.
+  bool helper = false;
+  uint32_t my_item = 0, out_slot = 0;
+  {
+    const uint32_t min_rem = hp.min_rem & 0xFFFFu;
+    const bool greedy = ((hp.min_rem >> 16) & 1u) != 0u;
+    for (int attempt = 0; attempt < 2; ++attempt) {   // (the second: the queue ran dry between the look and the pop)
+      if (tid == 0) {
+        s.pick = 0ull;
+        s.role[0] = __hip_atomic_load(hp.item_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.role[1] = __hip_atomic_load(hp.help_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.role[2] = 0u;   // windows handed out, all items
+        s.role[3] = __hip_atomic_load(hp.help_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      const uint32_t q_next = s.role[0];
+      const bool queue_empty = attempt == 1 || q_next >= hp.n_own;
+      const bool slots_left = s.role[1] < hp.n_help;
+      if (queue_empty && (!slots_left || s.role[3] != 0u)) return;   // (uniform) nothing to start, nothing to help
+      // worth a look?  Not while the first items have hardly begun (nothing is known about anybody's pace yet)
+      const bool look = slots_left && (queue_empty || (hp.alpha16 != 0u && q_next >= hp.n_cus + hp.n_cus / 4u));
+      if (look) {
+        const uint64_t now = wall_clock64();
+        float t_rem = 0.f;   // what is left of the launch (queue not empty: the bar an item's own time left must pass)
+        if (!queue_empty) {
+          uint32_t mine = 0;
+          for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
+            const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t0 == 0ull) continue;
+            mine += min(items[i].flags >> 8, (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          }
+          mine = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(mine), 63);
+          if (lane == 0 && mine != 0u) atomicAdd(&s.role[2], mine);
+          __syncthreads();
+          const uint32_t handed = s.role[2];
+          const uint64_t ts = __hip_atomic_load(hp.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t_rem = (handed == 0u || ts == 0ull || now <= ts) ? 3.0e38f
+                  : (float)(now - ts) * (float)(hp.total_wins > handed ? hp.total_wins - handed : 0u) / (float)handed * ((float)hp.alpha16 * (1.0f / 16.0f));
+        }
+        for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
+          const uint32_t fl = items[i].flags;
+          if ((fl & 3u) != kMsModePrune) continue;   // (counting items decide per workgroup when bounds may skip: not shared)
+          const uint32_t nw = fl >> 8;
+          const uint32_t taken = (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (taken + min_rem > nw) continue;
+          const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (t0 == 0ull || now <= t0) continue;     // its owner has not started yet
+          const uint32_t hc = __hip_atomic_load(hp.help_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float left = (float)(now - t0) * (float)(nw - taken) / ((float)(taken - (uint32_t)kMsWaves + 1u) * (float)(1u + hc));
+          if (!queue_empty && !(left > t_rem)) continue;
+          uint32_t hsh = (blockIdx.x * 0x9E3779B9u) ^ (i * 0x85EBCA6Bu) ^ (uint32_t)now;
+          hsh ^= hsh >> 16; hsh *= 0x7FEB352Du; hsh ^= hsh >> 15; hsh *= 0x846CA68Bu; hsh ^= hsh >> 16;
+          const float u = ((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f);
+          const float key = greedy ? left : left / -__logf(u);   // (greedy: A/B -- everybody takes the largest left_i)
+          atomicMax((unsigned long long*)&s.pick, ((unsigned long long)__float_as_uint(key) << 32) | (unsigned long long)(i + 1u));
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const uint64_t pick = s.pick;
+        uint32_t r_item = 0xFFFFFFFFu, r_slot = 0xFFFFFFFFu;
+        if ((uint32_t)pick != 0u) {
+          const uint32_t slot = atomicAdd(hp.help_used, 1u);
+          if (slot < hp.n_help) {
+            r_slot = slot;
+            r_item = (uint32_t)pick - 1u;
+            atomicAdd(hp.help_cnt + r_item, 1u);
+          }
+        } else if (queue_empty && look) {
+          __hip_atomic_store(hp.help_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (it stays that way: nothing starts any more)
+        }
+        if (r_slot == 0xFFFFFFFFu && !queue_empty) {
+          const uint32_t it = atomicAdd(hp.item_next, 1u);
+          if (it < hp.n_own) r_item = it;
+        }
+        s.role[0] = r_item;
+        s.role[1] = r_slot;
+      }
+      __syncthreads();
+      const uint32_t r_item = s.role[0], r_slot = s.role[1];
+      __syncthreads();   // (s.role is rewritten by the next attempt)
+      if (r_item != 0xFFFFFFFFu) {
+        my_item = r_item;
+        helper = r_slot != 0xFFFFFFFFu;
+        out_slot = helper ? hp.slot_base + r_slot : r_item;
+        break;
+      }
+      if (queue_empty) return;   // (uniform)
     }
-    __syncthreads();
-    const uint64_t pick = s.pick;
-    if ((uint32_t)pick == 0u) {   // (uniform)
-      if (tid == 0) __hip_atomic_store(hp.help_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    my_item = (uint32_t)pick - 1u;
-    if (tid == 0) atomicAdd(hp.help_cnt + my_item, 1u);
   }
-  const uint32_t out_slot = helper ? hp.slot_base + (blockIdx.x - hp.n_own) : blockIdx.x;
   NRT_GLOBAL uint32_t* const win_next_g = (NRT_GLOBAL uint32_t*)(hp.win_next + my_item);   // (a global address: no flat instruction in the window loop)
   // a helper wave's first window (an owner's waves start with windows 0 .. kMsWaves - 1): asked for now, read behind the tables
   uint32_t first_win = 0;
@@ -334,7 +395,11 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     s.cnt = 0;
     s.cnt_valid = 0;
     s.rz_flag = 0;
-    if (!helper && hp.n_help != 0u) __hip_atomic_store(hp.item_t0 + my_item, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!helper) {   // when this item began; the launch's first item: when the launch began
+      const unsigned long long now0 = (unsigned long long)wall_clock64();
+      __hip_atomic_store(hp.item_t0 + my_item, now0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (my_item == 0u) __hip_atomic_store(hp.t_start, now0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     s.prune_on = mode == kMsModePrune ? 1u : 0u;
     for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
     for (int i = 0; i < 16; ++i) s.prof[i] = 0;
@@ -1049,7 +1114,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   if (tid == 0) {
     item_counts[out_slot] = n;
     if (helper) {   // my slot joins the query's list (merge_topk_kernel walks it behind the items' slots)
-      const uint32_t h = blockIdx.x - hp.n_own;
+      const uint32_t h = out_slot - hp.slot_base;
       hp.help_next[h] = atomicExch(hp.help_head + item.query, h + 1u);
     }
     // the item's hits, per slice into the query's sums (slice_relation_kernel) and in total

@@ -214,10 +214,12 @@ constexpr uint32_t kMsModePrune = 0, kMsModeExact = 1, kMsModeCount = 2;
 constexpr int kMsmCountShift = 56;
 
 // Helping (maxscore.hip): the windows of an item are handed out by a counter in GLOBAL memory, so a workgroup other than the
-// item's own -- a HELPER, launched behind the items and dispatched when a CU runs out of them -- can take windows of the
-// heaviest unfinished item: the tail of a launch (1024 items of very different cost on 256 CUs, one workgroup per CU) is
-// shared instead of waited for.  A helper has its own score tables, candidate list and output slot (slot_base + its number),
-// starts from the theta the query's items have published (theta_g) and links its slot into the query's list for the merge.
+// item's own -- a HELPER -- can take windows of an item that is running.  The launch has n_own + n_help workgroups; the items
+// themselves are a queue in launch order (item_next).  A workgroup that gets a CU starts the next item, or helps: an item on
+// the launch's critical path while the queue still holds items, any unfinished item once it is empty -- the tail of a launch
+// (1024 items of very different cost on 256 CUs, one workgroup per CU) is shared instead of waited for.  A helper has its own
+// score tables, candidate list and output slot (slot_base + its number), starts from the theta the query's items have
+// published (theta_g) and links its slot into the query's list for the merge.
 struct DHelp {
   uint32_t* win_next;            // [n_own]   windows handed out beyond the owner's first kMsWaves (zeroed per launch)
   uint32_t* help_cnt;            // [n_own]   helpers that joined the item
@@ -225,9 +227,15 @@ struct DHelp {
   uint32_t* help_head;           // [queries] the query's helper slots: number of the first + 1, 0 = none
   uint32_t* help_next;           // [n_help]  ... and the next one
   uint32_t* help_off;            // [1]       a helper found nothing left worth joining: the later ones leave at once
-  uint32_t n_own, n_help;        // items of the launch, helper workgroups behind them
+  uint32_t* item_next;           // [1]       the next item of the launch order to be started
+  uint32_t* help_used;           // [1]       helper slots handed out
+  unsigned long long* t_start;   // [1]       wall clock at which item 0 started
+  uint32_t n_own, n_help;        // items of the launch, workgroups launched beyond them
   uint32_t slot_base;            // output slot (item_keys / item_counts / item_hits) of helper 0
   uint32_t min_rem;              // bits 0-15: an item with fewer unassigned windows is not joined; bit 16: A/B, greedy choice
+  uint32_t total_wins;           // windows of all items (the launch's progress = windows handed out / this)
+  uint32_t alpha16;              // critical path: help while items are queued when an item's time left > alpha16 / 16 x the launch's; 0: never
+  uint32_t n_cus, pad;
   unsigned long long* walls;     // instrumented kernel only, else nullptr: per output slot {start, end} on the 100 MHz wall clock and
                                  // {item, windows walked} -- when every workgroup of the launch ran, on one time base
                                  // (nrtgpu_get_maxscore_item_walls: the makespan against the balanced load)

@@ -96,6 +96,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   // start time; per query the head of its helper-slot list; the "nothing left to help" flag
   const size_t o_hwin = wc.take(hp.n_ms_items * 4), o_hcnt = wc.take(hp.n_ms_items * 4), o_ht0 = wc.take(hp.n_ms_items * 8);
   const size_t o_hhead = wc.take((size_t)n_queries * 4), o_hnext = wc.take(n_help * 4), o_hoff = wc.take(4);
+  const size_t o_hqueue = wc.take(4), o_hused = wc.take(4), o_hstart = wc.take(8);
   const size_t zero_bytes = wc.off - o_ssum;
   // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
   const int flag_variant = (ctx->cfg.flags >> 8) & 15;
@@ -113,6 +114,19 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   help.help_head = (uint32_t*)(wb + o_hhead);
   help.help_next = (uint32_t*)(wb + o_hnext);
   help.help_off = (uint32_t*)(wb + o_hoff);
+  help.item_next = (uint32_t*)(wb + o_hqueue);
+  help.help_used = (uint32_t*)(wb + o_hused);
+  help.t_start = (unsigned long long*)(wb + o_hstart);
+  {
+    // NRTGPU_MS_HELP_ALPHA (x 16; default 16 = 1.0; 0: helpers only once the queue is empty): while items are queued a workgroup
+    // helps an item whose expected time left exceeds alpha x what is left of the launch
+    static const int env_help_alpha = getenv("NRTGPU_MS_HELP_ALPHA") ? atoi(getenv("NRTGPU_MS_HELP_ALPHA")) : 16;
+    uint64_t wins = 0;
+    for (size_t i = 0; i < hp.n_ms_items; ++i) wins += hp.items[i].flags >> 8;
+    help.total_wins = (uint32_t)std::min<uint64_t>(wins, 0xFFFFFFFFull);
+    help.alpha16 = (uint32_t)std::max(env_help_alpha, 0);
+    help.n_cus = (uint32_t)std::max(ctx->n_cus, 1);
+  }
   help.n_own = (uint32_t)hp.n_ms_items;
   help.n_help = (uint32_t)n_help;
   help.slot_base = (uint32_t)n_items;
