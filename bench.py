@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--docs", type=int, default=0, help="override the number of docs (debug)")
     ap.add_argument("--target-items", type=int, default=0)
     ap.add_argument("--no-prefetch", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=8192, help="queries timed on the CPU oracle (0 = skip): ~10 s of CPU work on 16 cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true",
                     help="N>1: do not share score bounds between the GPUs' shards (nrtgpu_exchange_open, on by default: a shard "
@@ -78,10 +78,13 @@ def parse_args():
                     help="N>1 (begin / wait submission): threads that plan and enqueue steps side by side (0 = 2 when the host has >= 6 CPUs "
                          "per rank, else 1): a rank whose planning takes longer than its kernel is bound by ONE submitting thread")
     ap.add_argument("--planner-threads", type=int, default=0, help="planner threads per in-flight call (0 = what the box's CPUs allow)")
-    ap.add_argument("--closed-loop", default="64,512",
+    ap.add_argument("--closed-loop", default="1,8,64,512",
                     help="N=1, C3: after the batch line, closed loop with that many concurrent callers, one query per call through "
                          "nrtgpu_search_bm25_coalesced (comma list; empty = skip): qps / p50 / p99 per caller count")
-    ap.add_argument("--closed-loop-ms", type=int, default=2500)
+    ap.add_argument("--closed-loop-ms", type=int, default=1500)
+    ap.add_argument("--exhaustive-steps", type=int, default=8,
+                    help="C3 / C2, one GPU: steps of the EXHAUSTIVE route (every posting streamed) timed after the main run for "
+                         "roofline.exhaustive (0 = skip)")
     ap.add_argument("--no-sketch", action="store_true",
                     help="C4 A/B: NRTGPU_FLAG_NO_VECTOR_SKETCH -- no fp16 copy of the rows, the exact search nominates from the fp32 rows "
                          "(twice the bytes per pass); the answers are the same bits")
@@ -954,8 +957,12 @@ def main():
     bpp_fused = 4 if args.packed else BYTES_PER_POSTING_FUSED
     bytes_per_launch = (st["maxscore_postings"] if pruned else st["scan_postings"]) / launches * bpp
     achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel: a PMC profile of THIS build (rocprofv3 --pmc needs a run of its own, so the number is a
+    # committed record) -- a record of another build's kernels says nothing about these: traffic stays null then
     traffic = None
     traffic_note = None
+    lib_id = build.build_id(_lib.LIB_PATH)
+    traffic_refused = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
@@ -963,8 +970,12 @@ def main():
             for rec in (recs if isinstance(recs, list) else [recs]):
                 if (rec.get("workload") == args.workload and rec.get("batch") == B and rec.get("kernel") == kernel
                         and bool(rec.get("packed", False)) == bool(args.packed) and world == 1 and shard_world == 1):
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_note = rec.get("note")
+                    if rec.get("build_id") is not None and rec.get("build_id") == lib_id:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_note = rec.get("note")
+                    else:
+                        traffic_refused = (f"profiles/pmc_traffic.json holds a record for this workload taken from build {rec.get('build_id')}; "
+                                           f"the loaded library is build {lib_id}: not reused")
         except Exception:
             traffic = None
     out = {
@@ -976,6 +987,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "p50_latency_ms": round(statistics.median(lat) * 1e3, 4),
+        "p99_latency_ms": round(float(np.percentile(np.asarray(lat), 99)) * 1e3, 4),   # (of `steps` batch calls: the slowest one at --steps 20)
+        "latency_samples": len(lat),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -1008,11 +1021,44 @@ def main():
         "roofline": roofline_record(kernel, pruned, scan_ms, bytes_per_launch, bpp, bpp_fused, traffic, traffic_note),
     }
     out["roofline"].update({
+        "build_id": lib_id,   # sha256 over the gfx950 machine code of the loaded library (nrtsearch_amd/build.py: build_id)
+        "traffic_refused": traffic_refused if traffic is None else None,
         "accumulators": "fixed-point u64" if (pruned or st.get("fixed_point_launches", 0) == st["scan_launches"]) else "fp64",
         "other_scorer_ms_per_step": round((st["scan_ms"] if pruned else st["maxscore_ms"]) / max(1, st["batches"]), 4),
         "merge_ms_per_step": round(st["merge_ms"] / max(1, st["batches"]), 4),
         "host_plan_ms_per_step": round(st["host_plan_ms"] / max(1, st["batches"]), 4),
     })
+    if rank == 0 and world == 1 and not use_dist and not args.no_prune and args.exhaustive_steps > 0 and args.workload in ("C3", "C2"):
+        # The north star's ">= 40 % of the HBM-read roofline on the postings scan": the EXHAUSTIVE route over the same batches
+        # (NRTGPU_FLAG_NO_PRUNE: every posting of every query term is streamed, nothing skipped), timed here in the same run --
+        # algorithmic bytes (9 B per posting) / the scan kernel's average launch (HIP events on the library's stream).
+        ctx_x = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True,
+                               flags=flags | _lib.NRTGPU_FLAG_NO_PRUNE, host_threads=planner_threads)
+        leaves_x = [api.GpuSegment.from_data(ctx_x, s) for s in corpus.segments]
+        sr_x = api.GpuIndexSearcher(ctx_x, leaves_x, api.IndexStatistics.from_corpus(corpus))
+        bx = [api.PreparedBatch(sr_x, queries[i: i + B], [mgr] * B) for i in range(0, min(n_distinct, 4 * B), B)]
+        for i in range(2):
+            bx[i % len(bx)].run()
+        ctx_x.reset_stats()
+        tx0 = time.perf_counter()
+        for i in range(args.exhaustive_steps):
+            bx[i % len(bx)].run()
+        tx = time.perf_counter() - tx0
+        sx = ctx_x.stats()
+        lx = max(1, sx["scan_launches"])
+        x_ms = sx["scan_ms"] / lx
+        x_bytes = sx["scan_postings"] / lx * bpp
+        x_rate = x_bytes / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
+        out["roofline"]["exhaustive"] = {
+            "kernel": "bm25_scan_kernel", "steps": args.exhaustive_steps, "avg_launch_ms": round(x_ms, 4),
+            "algorithmic_bytes_per_launch": int(x_bytes), "achieved": round(x_rate, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": round(x_rate / HBM_PEAK_GBS, 4), "queries_per_s": round(args.exhaustive_steps * B / tx, 1),
+            "note": "every posting of the queries' terms streamed (NRTGPU_FLAG_NO_PRUNE), same index and batches, same run; achieved = "
+                    "9 B x postings / the kernel's average launch",
+        }
+        for l in leaves_x:
+            l.release()
+        ctx_x.close()
     if rank == 0 and world == 1 and not use_dist and args.closed_loop and args.workload in ("C3", "C2"):
         # queries/s AND latency (BASELINE.json's metric): the closed loop of SURVEY 8d, same index, same query set
         callers = [int(x) for x in args.closed_loop.split(",") if x.strip()]

@@ -365,6 +365,13 @@ int  nrtgpu_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int3
 int  nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                 int32_t field_id, int32_t similarity, const float* query, int32_t dim, int32_t k, float boost,
                                 nrtgpu_topdocs* out);
+/* TotalHits.relation of an exact vector query as the reference reports it.  The count is exact either way (the scorer ignores
+ * min competitive scores: every live doc with a vector is collected), but the reference's collector still flips its relation to
+ * GREATER_THAN_OR_EQUAL_TO once a slice has collected more than max(totalHitsThreshold, numHits) hits with a full queue
+ * (LazyQueueTopScoreDocCollector.java:176-199, one collector per slice: MyIndexSearcher.java:163-208).  Host only: the live
+ * vectors of every leaf are known from upload and liveDocs.  Returns 1 = GREATER_THAN_OR_EQUAL_TO, 0 = EQUAL_TO, < 0 = error. */
+int  nrtgpu_knn_exact_relation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                               int32_t field_id, int32_t k, int32_t total_hits_threshold);
 /* The `knn` request path (KnnQuery -> NrtKnnFloatVectorQuery, src/main/java/com/yelp/nrtsearch/server/field/
  * VectorFieldDef.java:564-594, executed at search/KnnUtils.java:56) answered exactly: the k nearest docs among
  * those the pre-filter accepts (filter_mask: a resident mask, 0 = none; liveDocs always apply), optionally only
@@ -507,11 +514,12 @@ int  nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16);
  * [12] waves in part prologues, [13] waves walking windows, [14] the item's last wave running out of windows, [15] item
  * epilogue ([10]-[13]: summed over the item's 12 waves) */
 int  nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out16);
-/* the same flag: WHEN the workgroups of the last MaxScore launch ran.  Per output slot four words -- {start, end} on the device's
- * 100 MHz wall clock, the item the workgroup worked on, the doc windows it walked; a slot nobody used is all zeros.  The first
- * *n_items slots are the items' own workgroups; slots beyond the call's items (MaxScore + scan) are HELPERS: workgroups that got
- * a CU when the items ran out and shared the windows of an unfinished item.  Returns the number of slots (<= cap_slots
- * are written); the makespan of the launch against its balanced load is max(end) - min(start) vs sum(end - start) / CUs. */
+/* the same flag: WHEN the pieces of the last MaxScore launch ran.  Per output slot eight words -- {start, end} on the device's
+ * 100 MHz wall clock, the item worked on, the doc windows walked, when the workgroup's round began (persistent workgroups choose
+ * work round after round), the CU (XCC << 8 | SE, SH, CU), the round, the workgroup; a slot nobody used is all zeros.  The first
+ * *n_items slots are the items' owners; slots beyond the call's items (MaxScore + scan) are HELPERS: workgroups that shared the
+ * windows of an item someone else owns.  Returns the number of slots (<= cap_slots are written); the makespan of the
+ * launch against its balanced load is max(end) - min(start) vs sum(end - start) / CUs. */
 int64_t nrtgpu_get_maxscore_item_walls(nrtgpu_ctx* ctx, uint64_t* out, int64_t cap_slots, int64_t* n_items);
 
 #ifdef __cplusplus

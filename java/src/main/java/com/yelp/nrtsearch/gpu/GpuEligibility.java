@@ -35,8 +35,9 @@ final class GpuEligibility {
   /** The flattened query: scoring clauses, minimumNumberShouldMatch, DisjunctionMaxQuery?, and the non-scoring clauses (null = none). */
   record Shape(List<Clause> clauses, int minShouldMatch, int disjunctionMax, Query filter, Query mustNot) {}
 
-  /** The collector behind the manager handed to search(), and the request's timeoutSec (0 = none). */
-  record Eligible(RelevanceCollector collector, double timeoutSec) {}
+  /** The collector behind the manager handed to search(), the request's timeoutSec (0 = none) and the wrapper that enforces it
+   *  on the reference's path (null = none): a timeout on the device route is reported THROUGH it (GpuIndexSearcher.timedOut). */
+  record Eligible(RelevanceCollector collector, double timeoutSec, SearchCutoffWrapper<?> cutoff) {}
 
   record Plan(MemorySegment query, MemorySegment out, MemorySegment docs, MemorySegment scores, int k) {
     TopDocs toTopDocs() {
@@ -117,17 +118,20 @@ final class GpuEligibility {
    * What SearchHandler hands to search() is DocCollector.getWrappedManager() (search/collectors/DocCollector.java:120-125,
    * :197-220): a SearchCollectorManager, possibly inside a SearchStatsWrapper (profile), a SearchCutoffWrapper (timeoutSec) and
    * a TerminateAfterWrapper.  The unwrapped doc collector must be a plain RelevanceCollector: no sort, no additional collectors
-   * (facets ...), no terminateAfter (its early termination counts collected docs: the reference's business).  getWrapped() /
-   * getAdditionalCollectors(): java/patches/nrtsearch-gpu-hook.diff.
+   * (facets ...), no terminateAfter (its early termination counts collected docs: the reference's business).  getWrapped() is
+   * the reference's own (SearchCutoffWrapper.java:132, SearchStatsWrapper.java:90); getAdditionalCollectors() and
+   * SearchCutoffWrapper.timedOutBeforeCollection() come with java/patches/nrtsearch-gpu-hook.diff.
    */
   static Eligible relevance(CollectorManager<?, ?> manager) {
     Object m = manager;
     double timeoutSec = 0.0;
+    SearchCutoffWrapper<?> cutoffWrapper = null;
     for (;;) {
       if (m instanceof SearchStatsWrapper<?> stats) {
         m = stats.getWrapped();
       } else if (m instanceof SearchCutoffWrapper<?> cutoff) {
         timeoutSec = cutoff.getTimeoutSec();
+        cutoffWrapper = cutoff;
         m = cutoff.getWrapped();
       } else {
         break;
@@ -136,7 +140,7 @@ final class GpuEligibility {
     if (!(m instanceof SearchCollectorManager scm)) return null;
     DocCollector dc = scm.getDocCollector();
     if (!(dc instanceof RelevanceCollector rc) || !scm.getAdditionalCollectors().isEmpty()) return null;
-    return new Eligible(rc, timeoutSec);
+    return new Eligible(rc, timeoutSec, cutoffWrapper);
   }
 
   static Plan marshal(Arena a, IndexSearcher searcher, GpuSegmentStore store, Shape shape, int filterMask, int mustNotMask,

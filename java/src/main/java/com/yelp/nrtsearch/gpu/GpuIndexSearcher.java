@@ -49,7 +49,7 @@ public class GpuIndexSearcher extends MyIndexSearcher {
    * left-to-right fp32 similarity of each (DESIGN 4.3).  null = the caller's path (a leaf not resident, a field without
    * float vectors, a dimension the device does not take).
    */
-  private TopDocs exactVectorSearch(GpuEligibility.VectorShape vs, int k, double timeoutSec) throws IOException {
+  private TopDocs exactVectorSearch(GpuEligibility.VectorShape vs, int k, int totalHitsThreshold, double timeoutSec) throws IOException {
     List<LeafReaderContext> leaves = getIndexReader().leaves();
     int sim = -1;
     for (LeafReaderContext leaf : leaves) {
@@ -87,17 +87,39 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       } finally {
         NrtGpu.SET_DEADLINE.invokeExact(0L);
       }
-      if (status == NrtGpu.ERR_UNSUPPORTED || status == NrtGpu.ERR_TIMEOUT) return null;
+      if (status == NrtGpu.ERR_TIMEOUT) return TIMED_OUT;               // the request's budget is spent: no second run on the CPU path
+      if (status == NrtGpu.ERR_UNSUPPORTED) return null;
       NrtGpu.check(status);
+      // the count is exact (every live doc with a vector is collected), the RELATION is the reference collector's: it flips to
+      // GREATER_THAN_OR_EQUAL_TO once a slice has collected more than max(totalHitsThreshold, numHits) hits with a full queue,
+      // although this query's scorer ignores min competitive scores (LazyQueueTopScoreDocCollector.java:176-199)
+      int gte = (int) NrtGpu.KNN_RELATION.invokeExact(ctx, segs, bases, leaves.size(), store.fieldId(vs.field()), k, totalHitsThreshold);
+      if (gte < 0) NrtGpu.check(gte);
       int n = out.get(JAVA_INT, NrtGpuLayouts.TOPDOCS_N_HITS);
       ScoreDoc[] hits = new ScoreDoc[n];
       for (int i = 0; i < n; i++) hits[i] = new ScoreDoc(docs.getAtIndex(JAVA_INT, i), scores.getAtIndex(JAVA_FLOAT, i));
-      return new TopDocs(new TotalHits(out.get(JAVA_LONG, NrtGpuLayouts.TOPDOCS_TOTAL_HITS), TotalHits.Relation.EQUAL_TO), hits);   // every live doc with a vector matches
+      return new TopDocs(new TotalHits(out.get(JAVA_LONG, NrtGpuLayouts.TOPDOCS_TOTAL_HITS),   // every live doc with a vector matches
+          gte != 0 && n == k ? TotalHits.Relation.GREATER_THAN_OR_EQUAL_TO : TotalHits.Relation.EQUAL_TO), hits);
     } catch (IOException | RuntimeException e) {
       throw e;
     } catch (Throwable t) {
       throw new IOException(t);
     }
+  }
+
+  private static final TopDocs TIMED_OUT = new TopDocs(new TotalHits(0, TotalHits.Relation.EQUAL_TO), new ScoreDoc[0]);
+
+  /**
+   * NRTGPU_ERR_TIMEOUT: the request spent its timeoutSec waiting for the device -- nothing was launched for it, so there are no
+   * partial results.  Reported the reference's way, NOT by running the query again on the CPU path under a fresh budget (a
+   * timed-out request would then take up to twice its timeoutSec, under exactly the overload that made it time out): what
+   * SearchCutoffWrapper makes of a timeout at the first segment boundary -- CollectionTimeoutException when partial results are
+   * not allowed, else the timeout action runs and the (empty) result stands (SearchCutoffWrapper.java:117-131, 160-172;
+   * timedOutBeforeCollection(): java/patches/nrtsearch-gpu-hook.diff).
+   */
+  private static SearcherResult timedOut(GpuEligibility.Eligible el) {
+    if (el.cutoff() != null) el.cutoff().timedOutBeforeCollection();
+    return new SearcherResult(new TopDocs(new TotalHits(0, TotalHits.Relation.EQUAL_TO), new ScoreDoc[0]), Map.of());
   }
 
   /** {total_ms, plan_ms, queue_ms, device_ms, postings} of the calling thread's last device search (SearchResponse.Diagnostics). */
@@ -114,7 +136,9 @@ public class GpuIndexSearcher extends MyIndexSearcher {
     Query rewritten = rewrite(query);
     GpuEligibility.VectorShape vs = GpuEligibility.vectorShape(rewritten);
     if (vs != null) {
-      TopDocs top = rc.getSearchAfter() == null ? exactVectorSearch(vs, rc.getNumHitsToCollect(), el.timeoutSec()) : null;   // (no paging on this route)
+      TopDocs top = rc.getSearchAfter() == null
+          ? exactVectorSearch(vs, rc.getNumHitsToCollect(), rc.getTotalHitsThreshold(), el.timeoutSec()) : null;   // (no paging on this route)
+      if (top == TIMED_OUT) return (T) timedOut(el);
       return top == null ? super.search(query, manager) : (T) new SearcherResult(top, Map.of());
     }
     GpuEligibility.Shape shape = GpuEligibility.shape(rewritten);
@@ -144,9 +168,8 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       } finally {
         NrtGpu.SET_DEADLINE.invokeExact(0L);
       }
-      // not a shape / size the device takes, or out of time before anything was launched: the reference's own path decides
-      // (its SearchCutoffWrapper reports the timeout the reference's way)
-      if (status == NrtGpu.ERR_UNSUPPORTED || status == NrtGpu.ERR_TIMEOUT) return super.search(query, manager);
+      if (status == NrtGpu.ERR_TIMEOUT) return (T) timedOut(el);       // out of time before anything was launched
+      if (status == NrtGpu.ERR_UNSUPPORTED) return super.search(query, manager);   // not a shape / size the device takes
       NrtGpu.check(status);
       MemorySegment d = a.allocate(NrtGpu.DIAGNOSTICS);
       if ((int) NrtGpu.LAST_DIAGNOSTICS.invokeExact(d) == NrtGpu.OK)

@@ -85,6 +85,9 @@ final class NrtGpu {
    */
   static final MethodHandle KNN_EXACT1 = h("nrtgpu_knn_exact_coalesced", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
       JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_FLOAT, ADDRESS));
+  /** TotalHits.relation of an exact vector query by the reference's per-slice rule (host only): 1 = GREATER_THAN_OR_EQUAL_TO. */
+  static final MethodHandle KNN_RELATION = h("nrtgpu_knn_exact_relation", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
+      JAVA_INT, JAVA_INT, JAVA_INT));
   static final MethodHandle KNN_SEARCH = h("nrtgpu_knn_search", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
       JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_INT, JAVA_FLOAT, ADDRESS));
   static final MethodHandle RESCORE = h("nrtgpu_rescore_vectors", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,

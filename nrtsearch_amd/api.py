@@ -233,12 +233,12 @@ class GpuContext:
         _lib.load().nrtgpu_reset_stats(self._h)
 
     def maxscore_item_walls(self):
-        """(walls[n_slots, 4] = start, end (100 MHz ticks), item, windows; n_items) of the last instrumented MaxScore launch
-        (nrtgpu_get_maxscore_item_walls): rows >= the call's items are helper workgroups."""
+        """(walls[n_slots, 8] = start, end (100 MHz ticks), item, windows, round begin, CU, round, workgroup; n_items) of the last
+        instrumented MaxScore launch (nrtgpu_get_maxscore_item_walls): rows >= the call's items are helper sessions."""
         L = _lib.load()
         n_items = C.c_int64(0)
         n = int(L.nrtgpu_get_maxscore_item_walls(self._h, None, 0, C.byref(n_items)))
-        out = np.zeros((max(n, 0), 4), dtype=np.uint64)
+        out = np.zeros((max(n, 0), 8), dtype=np.uint64)
         if n > 0:
             L.nrtgpu_get_maxscore_item_walls(self._h, out.ctypes.data, n, C.byref(n_items))
         return out, int(n_items.value)
@@ -610,6 +610,14 @@ class GpuIndexSearcher:
                                                           self.SIMILARITY[similarity], query.ctypes.data, int(query.shape[0]), int(k),
                                                           C.c_float(boost), C.byref(out)))
         return TopDocs(docs[: out.n_hits].copy(), scores[: out.n_hits].copy(), int(out.total_hits), bool(out.total_hits_is_lower_bound))
+
+    def knn_exact_relation(self, field: int, k: int, total_hits_threshold: int = TOTAL_HITS_THRESHOLD) -> bool:
+        """TotalHits.relation of an exact vector query over these leaves by the reference's per-slice rule: True = GREATER_THAN_OR_EQUAL_TO
+        (nrtgpu_knn_exact_relation; host only)."""
+        rc = _lib.load().nrtgpu_knn_exact_relation(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field), int(k), int(total_hits_threshold))
+        if rc < 0:
+            _lib.check(rc)
+        return bool(rc)
 
     def knn_search(self, field: int, similarity: str, queries: np.ndarray, k: int, boost: float = 1.0,
                    filter: Optional[MaskFilter] = None, min_score: float = 0.0) -> List[TopDocs]:

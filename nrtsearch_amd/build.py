@@ -48,6 +48,49 @@ def build(force: bool = False, verbose: bool = False, extra=(), out: str = OUT) 
     return out
 
 
+_BUILD_ID_CACHE = {}
+
+
+def build_id(path: str = OUT):
+    """Identity of the DEVICE code in a built library: sha256 (first 16 hex digits) over the `.text` sections of its gfx950
+    code objects (llvm-objdump --offloading unbundles them; the bundle itself is not reproducible -- it embeds temporary
+    file names -- but the machine code is).  A measurement can then name the kernels it was taken from: bench.py stamps
+    `roofline.build_id`, profiles/pmc_traffic.json records carry the id of the build they profiled, and bench.py refuses to
+    reuse their traffic for another one.  Host-side edits do not change it; any kernel edit does.  None when the LLVM
+    binutils are not there."""
+    import hashlib
+    import shutil
+    import tempfile
+
+    key = (os.path.abspath(path), os.path.getmtime(path))
+    if key in _BUILD_ID_CACHE:
+        return _BUILD_ID_CACHE[key]
+    llvm = os.environ.get("NRTGPU_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    objdump, objcopy = os.path.join(llvm, "llvm-objdump"), os.path.join(llvm, "llvm-objcopy")
+    out = None
+    if os.path.exists(objdump) and os.path.exists(objcopy):
+        tmp = tempfile.mkdtemp(prefix="nrtgpu_id_")
+        try:
+            local = os.path.join(tmp, "lib.so")
+            shutil.copy(path, local)
+            subprocess.run([objdump, "--offloading", local], cwd=tmp, check=True, capture_output=True)
+            digests = []
+            for f in sorted(os.listdir(tmp)):
+                if "gfx950" not in f:
+                    continue
+                text = os.path.join(tmp, f + ".text")
+                subprocess.run([objcopy, "-O", "binary", "--only-section=.text", os.path.join(tmp, f), text], check=True, capture_output=True)
+                digests.append(hashlib.sha256(open(text, "rb").read()).hexdigest())
+            if digests:
+                out = hashlib.sha256("".join(sorted(digests)).encode()).hexdigest()[:16]
+        except (OSError, subprocess.CalledProcessError):
+            out = None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    _BUILD_ID_CACHE[key] = out
+    return out
+
+
 LOADGEN_SRC = os.path.join(HERE, "..", "bench", "loadgen", "loadgen.cpp")
 LOADGEN_OUT = os.path.join(HERE, "..", "bench", "loadgen", "libloadgen.so")
 

@@ -275,524 +275,734 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   //      Helpers come in herds (an item that ends frees its owner and its helpers at once) whose members cannot see each
   //      other's choices: each picks item i with PROBABILITY proportional to left_i -- the largest left_i / -ln(u_i), u_i
   //      uniform and its own -- so a herd spreads over the candidates in proportion to the time they have left.
-  bool helper = false;
-  uint32_t my_item = 0, out_slot = 0;
-  {
-    const uint32_t min_rem = hp.min_rem & 0xFFFFu;
-    const bool greedy = ((hp.min_rem >> 16) & 1u) != 0u;
-    for (int attempt = 0; attempt < 2; ++attempt) {   // (the second: the queue ran dry between the look and the pop)
-      if (tid == 0) {
-        s.pick = 0ull;
-        s.role[0] = __hip_atomic_load(hp.item_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s.role[1] = __hip_atomic_load(hp.help_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s.role[2] = 0u;   // windows handed out, all items
-        s.role[3] = __hip_atomic_load(hp.help_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      const uint32_t q_next = s.role[0];
-      const bool queue_empty = attempt == 1 || q_next >= hp.n_own;
-      const bool slots_left = s.role[1] < hp.n_help;
-      if (queue_empty && (!slots_left || s.role[3] != 0u)) return;   // (uniform) nothing to start, nothing to help
-      // worth a look?  Not while the first items have hardly begun (nothing is known about anybody's pace yet)
-      const bool look = slots_left && (queue_empty || (hp.alpha16 != 0u && q_next >= hp.n_cus + hp.n_cus / 4u));
-      if (look) {
-        const uint64_t now = wall_clock64();
-        float t_rem = 0.f;   // what is left of the launch (queue not empty: the bar an item's own time left must pass)
-        if (!queue_empty) {
-          uint32_t mine = 0;
+  // A workgroup is PERSISTENT (hp.persistent; the launch then has one workgroup per CU): having finished what it chose to do it
+  // chooses again -- start the next item of the queue, or help -- until there is nothing left.  A workgroup that owns a whole CU
+  // (160 KB of LDS) is not replaced the moment it ends: measured with one workgroup per item, ~9 % of the CUs sat between two
+  // workgroups at any time while items were still queued (profiles/r04_makespan_*.log: 215-235 of 256 running).
+  for (uint32_t round = 0;; ++round) {
+    const uint64_t wall_entry = PROF ? wall_clock64() : 0ull;
+    bool helper = false;
+    uint32_t my_item = 0, out_slot = 0;
+    {
+      const uint32_t min_rem = hp.min_rem & 0xFFFFu;
+      const bool greedy = ((hp.min_rem >> 16) & 1u) != 0u;
+      for (int attempt = 0; attempt < 2; ++attempt) {   // (the second: the queue ran dry between the look and the pop)
+        if (tid == 0) {
+          s.pick = 0ull;
+          s.role[0] = __hip_atomic_load(hp.item_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s.role[1] = __hip_atomic_load(hp.help_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s.role[2] = 0u;   // windows handed out, all items
+          s.role[3] = __hip_atomic_load(hp.help_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const uint32_t q_next = s.role[0];
+        const bool queue_empty = attempt == 1 || q_next >= hp.n_own;
+        const bool slots_left = s.role[1] < hp.n_help;
+        if (queue_empty && (!slots_left || s.role[3] != 0u)) return;   // (uniform) nothing to start, nothing to help
+        // worth a look?  Not while the first items have hardly begun (nothing is known about anybody's pace yet)
+        const bool look = slots_left && (queue_empty || (hp.alpha16 != 0u && q_next >= hp.n_cus + hp.n_cus / 4u));
+        if (look) {
+          const uint64_t now = wall_clock64();
+          float t_rem = 0.f;   // what is left of the launch (queue not empty: the bar an item's own time left must pass)
+          if (!queue_empty) {
+            uint32_t mine = 0;
+            for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
+              const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (t0 == 0ull) continue;
+              mine += min(items[i].flags >> 8, (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            mine = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(mine), 63);
+            if (lane == 0 && mine != 0u) atomicAdd(&s.role[2], mine);
+            __syncthreads();
+            const uint32_t handed = s.role[2];
+            const uint64_t ts = __hip_atomic_load(hp.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t_rem = (handed == 0u || ts == 0ull || now <= ts) ? 3.0e38f
+                    : (float)(now - ts) * (float)(hp.total_wins > handed ? hp.total_wins - handed : 0u) / (float)handed * ((float)hp.alpha16 * (1.0f / 16.0f));
+          }
           for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
+            const uint32_t fl = items[i].flags;
+            if ((fl & 3u) != kMsModePrune) continue;   // (counting items decide per workgroup when bounds may skip: not shared)
+            const uint32_t nw = fl >> 8;
+            const uint32_t taken = (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (taken + min_rem > nw) continue;
             const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t0 == 0ull) continue;
-            mine += min(items[i].flags >> 8, (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (t0 == 0ull || now <= t0) continue;     // its owner has not started yet
+            const uint32_t hc = __hip_atomic_load(hp.help_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float left = (float)(now - t0) * (float)(nw - taken) / ((float)(taken - (uint32_t)kMsWaves + 1u) * (float)(1u + hc));
+            if (!queue_empty && !(left > t_rem)) continue;
+            uint32_t hsh = ((blockIdx.x + round * gridDim.x) * 0x9E3779B9u) ^ (i * 0x85EBCA6Bu) ^ (uint32_t)now;
+            hsh ^= hsh >> 16; hsh *= 0x7FEB352Du; hsh ^= hsh >> 15; hsh *= 0x846CA68Bu; hsh ^= hsh >> 16;
+            const float u = ((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float key = greedy ? left : left / -__logf(u);   // (greedy: A/B -- everybody takes the largest left_i)
+            atomicMax((unsigned long long*)&s.pick, ((unsigned long long)__float_as_uint(key) << 32) | (unsigned long long)(i + 1u));
           }
-          mine = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(mine), 63);
-          if (lane == 0 && mine != 0u) atomicAdd(&s.role[2], mine);
-          __syncthreads();
-          const uint32_t handed = s.role[2];
-          const uint64_t ts = __hip_atomic_load(hp.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          t_rem = (handed == 0u || ts == 0ull || now <= ts) ? 3.0e38f
-                  : (float)(now - ts) * (float)(hp.total_wins > handed ? hp.total_wins - handed : 0u) / (float)handed * ((float)hp.alpha16 * (1.0f / 16.0f));
         }
-        for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
-          const uint32_t fl = items[i].flags;
-          if ((fl & 3u) != kMsModePrune) continue;   // (counting items decide per workgroup when bounds may skip: not shared)
-          const uint32_t nw = fl >> 8;
-          const uint32_t taken = (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (taken + min_rem > nw) continue;
-          const uint64_t t0 = __hip_atomic_load(hp.item_t0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (t0 == 0ull || now <= t0) continue;     // its owner has not started yet
-          const uint32_t hc = __hip_atomic_load(hp.help_cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const float left = (float)(now - t0) * (float)(nw - taken) / ((float)(taken - (uint32_t)kMsWaves + 1u) * (float)(1u + hc));
-          if (!queue_empty && !(left > t_rem)) continue;
-          uint32_t hsh = (blockIdx.x * 0x9E3779B9u) ^ (i * 0x85EBCA6Bu) ^ (uint32_t)now;
-          hsh ^= hsh >> 16; hsh *= 0x7FEB352Du; hsh ^= hsh >> 15; hsh *= 0x846CA68Bu; hsh ^= hsh >> 16;
-          const float u = ((float)(hsh >> 8) + 0.5f) * (1.0f / 16777216.0f);
-          const float key = greedy ? left : left / -__logf(u);   // (greedy: A/B -- everybody takes the largest left_i)
-          atomicMax((unsigned long long*)&s.pick, ((unsigned long long)__float_as_uint(key) << 32) | (unsigned long long)(i + 1u));
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const uint64_t pick = s.pick;
-        uint32_t r_item = 0xFFFFFFFFu, r_slot = 0xFFFFFFFFu;
-        if ((uint32_t)pick != 0u) {
-          const uint32_t slot = atomicAdd(hp.help_used, 1u);
-          if (slot < hp.n_help) {
-            r_slot = slot;
-            r_item = (uint32_t)pick - 1u;
-            atomicAdd(hp.help_cnt + r_item, 1u);
+        __syncthreads();
+        if (tid == 0) {
+          const uint64_t pick = s.pick;
+          uint32_t r_item = 0xFFFFFFFFu, r_slot = 0xFFFFFFFFu;
+          if ((uint32_t)pick != 0u) {
+            const uint32_t slot = atomicAdd(hp.help_used, 1u);
+            if (slot < hp.n_help) {
+              r_slot = slot;
+              r_item = (uint32_t)pick - 1u;
+              atomicAdd(hp.help_cnt + r_item, 1u);
+            }
+          } else if (queue_empty && look) {
+            __hip_atomic_store(hp.help_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (it stays that way: nothing starts any more)
           }
-        } else if (queue_empty && look) {
-          __hip_atomic_store(hp.help_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (it stays that way: nothing starts any more)
+          if (r_slot == 0xFFFFFFFFu && !queue_empty) {
+            const uint32_t it = atomicAdd(hp.item_next, 1u);
+            if (it < hp.n_own) r_item = it;
+          }
+          s.role[0] = r_item;
+          s.role[1] = r_slot;
         }
-        if (r_slot == 0xFFFFFFFFu && !queue_empty) {
-          const uint32_t it = atomicAdd(hp.item_next, 1u);
-          if (it < hp.n_own) r_item = it;
+        __syncthreads();
+        const uint32_t r_item = s.role[0], r_slot = s.role[1];
+        __syncthreads();   // (s.role is rewritten by the next attempt)
+        if (r_item != 0xFFFFFFFFu) {
+          my_item = r_item;
+          helper = r_slot != 0xFFFFFFFFu;
+          out_slot = helper ? hp.slot_base + r_slot : r_item;
+          break;
         }
-        s.role[0] = r_item;
-        s.role[1] = r_slot;
+        if (queue_empty) return;   // (uniform)
       }
-      __syncthreads();
-      const uint32_t r_item = s.role[0], r_slot = s.role[1];
-      __syncthreads();   // (s.role is rewritten by the next attempt)
-      if (r_item != 0xFFFFFFFFu) {
-        my_item = r_item;
-        helper = r_slot != 0xFFFFFFFFu;
-        out_slot = helper ? hp.slot_base + r_slot : r_item;
-        break;
+    }
+    NRT_GLOBAL uint32_t* const win_next_g = (NRT_GLOBAL uint32_t*)(hp.win_next + my_item);   // (a global address: no flat instruction in the window loop)
+    // a helper wave's first window (an owner's waves start with windows 0 .. kMsWaves - 1): asked for now, read behind the tables
+    uint32_t first_win = 0;
+    if (helper && lane == 0) first_win = __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const DItem item = items[my_item];
+    const DQuery q = queries[item.query];
+    const uint32_t k = q.k;
+    const int fx_E = item.fx_E;
+    unsigned long long* const my_theta_g = theta_g + item.query;
+    const bool multi_item = q.n_items > 1 || hp.n_help != 0u;   // (theta_g is how owner and helpers share theta as well)
+    // When may bounds skip work (plan.h: kMsMode*)?  Exact: never.  Count: once a slice has collected more than gte_floor hits --
+    // until then every live matching doc is evaluated and counted, as the reference's collector does before it first
+    // publishes a min competitive score.  theta filters the candidates in every mode.
+    const uint32_t mode = item.flags & 3u;
+    const uint32_t msm = SHAPES ? q.min_should_match : 0u;   // (> 1: clause counting)
+    const bool use_max = SHAPES && q.combine_max != 0u;       // DisjunctionMaxQuery
+    unsigned int* const my_prune_g = q_prune + item.query;    // set by the first item of the query whose slice passed the floor
+    const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
+
+    // ---- item prologue: normInverse tables, score tables
+    {
+      const uint32_t n_lds = min(item.n_caches, (uint32_t)kLdsCaches) * 256u;
+      for (uint32_t i = tid; i < n_lds; i += kMsThreads) (&s.cache[0][0])[i] = caches[item.cache_off + i];
+    }
+    if (tid == 0) {
+      const uint64_t theta0 = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s.theta = theta0;
+      s.thr = acc_threshold<true>(theta0, fx_E);
+      s.cnt = 0;
+      s.cnt_valid = 0;
+      s.rz_flag = 0;
+      if (!helper) {   // when this item began; the launch's first item: when the launch began
+        const unsigned long long now0 = (unsigned long long)wall_clock64();
+        __hip_atomic_store(hp.item_t0 + my_item, now0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (my_item == 0u) __hip_atomic_store(hp.t_start, now0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (queue_empty) return;   // (uniform)
+      s.prune_on = mode == kMsModePrune ? 1u : 0u;
+      for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
+      for (int i = 0; i < 16; ++i) s.prof[i] = 0;
     }
-  }
-  NRT_GLOBAL uint32_t* const win_next_g = (NRT_GLOBAL uint32_t*)(hp.win_next + my_item);   // (a global address: no flat instruction in the window loop)
-  // a helper wave's first window (an owner's waves start with windows 0 .. kMsWaves - 1): asked for now, read behind the tables
-  uint32_t first_win = 0;
-  if (helper && lane == 0) first_win = __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const DItem item = items[my_item];
-  const DQuery q = queries[item.query];
-  const uint32_t k = q.k;
-  const int fx_E = item.fx_E;
-  unsigned long long* const my_theta_g = theta_g + item.query;
-  const bool multi_item = q.n_items > 1 || hp.n_help != 0u;   // (theta_g is how owner and helpers share theta as well)
-  // When may bounds skip work (plan.h: kMsMode*)?  Exact: never.  Count: once a slice has collected more than gte_floor hits --
-  // until then every live matching doc is evaluated and counted, as the reference's collector does before it first
-  // publishes a min competitive score.  theta filters the candidates in every mode.
-  const uint32_t mode = item.flags & 3u;
-  const uint32_t msm = SHAPES ? q.min_should_match : 0u;   // (> 1: clause counting)
-  const bool use_max = SHAPES && q.combine_max != 0u;       // DisjunctionMaxQuery
-  unsigned int* const my_prune_g = q_prune + item.query;    // set by the first item of the query whose slice passed the floor
-  const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
-
-  // ---- item prologue: normInverse tables, score tables
-  {
-    const uint32_t n_lds = min(item.n_caches, (uint32_t)kLdsCaches) * 256u;
-    for (uint32_t i = tid; i < n_lds; i += kMsThreads) (&s.cache[0][0])[i] = caches[item.cache_off + i];
-  }
-  if (tid == 0) {
-    const uint64_t theta0 = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s.theta = theta0;
-    s.thr = acc_threshold<true>(theta0, fx_E);
-    s.cnt = 0;
-    s.cnt_valid = 0;
-    s.rz_flag = 0;
-    if (!helper) {   // when this item began; the launch's first item: when the launch began
-      const unsigned long long now0 = (unsigned long long)wall_clock64();
-      __hip_atomic_store(hp.item_t0 + my_item, now0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (my_item == 0u) __hip_atomic_store(hp.t_start, now0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t_item0 = PROF ? __builtin_readcyclecounter() : 0ull;
+    const uint64_t wall0 = PROF ? wall_clock64() : 0ull;
+    uint64_t tc_meet = 0, tc_part = 0, tc_walk = 0;
+    __syncthreads();
+    if (xch && tid < 64u) {   // wave 0: what the other GPUs' shards have published for this query so far (nothing of mine yet)
+      const uint64_t pb = exchange_bound(*xch, item.query, 0ull, tid);
+      if (tid == 0 && pb > s.theta) {
+        s.theta = pb;
+        s.thr = acc_threshold<true>(pb, fx_E);
+      }
     }
-    s.prune_on = mode == kMsModePrune ? 1u : 0u;
-    for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
-    for (int i = 0; i < 16; ++i) s.prof[i] = 0;
-  }
-  const uint64_t t_item0 = PROF ? __builtin_readcyclecounter() : 0ull;
-  const uint64_t wall0 = PROF ? wall_clock64() : 0ull;
-  uint64_t tc_meet = 0, tc_part = 0, tc_walk = 0;
-  __syncthreads();
-  if (xch && tid < 64u) {   // wave 0: what the other GPUs' shards have published for this query so far (nothing of mine yet)
-    const uint64_t pb = exchange_bound(*xch, item.query, 0ull, tid);
-    if (tid == 0 && pb > s.theta) {
-      s.theta = pb;
-      s.thr = acc_threshold<true>(pb, fx_E);
+    for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
+      const float w = items[my_item].tab_weight[slot];
+      const int scale = items[my_item].tab_scale[slot];
+      const float* cache = &s.cache[items[my_item].tab_cache[slot]][0];
+      for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kMsThreads)  // row 0: postings of deleted docs score 0
+        s.tab[slot][e] = e < (uint32_t)kTabNorms ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
     }
-  }
-  for (uint32_t slot = 0; slot < item.n_tabs; ++slot) {
-    const float w = items[my_item].tab_weight[slot];
-    const int scale = items[my_item].tab_scale[slot];
-    const float* cache = &s.cache[items[my_item].tab_cache[slot]][0];
-    for (uint32_t e = tid; e < (uint32_t)kTabEntries; e += kMsThreads)  // row 0: postings of deleted docs score 0
-      s.tab[slot][e] = e < (uint32_t)kTabNorms ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
-  }
-  __syncthreads();  // from here on the waves run on their own
-  if (PROF && tid == 0) s.prof[8] = __builtin_readcyclecounter() - t_item0;
+    __syncthreads();  // from here on the waves run on their own
+    if (PROF && tid == 0) s.prof[8] = __builtin_readcyclecounter() - t_item0;
 
-  uint32_t* const seen = &s.seen[wave][0];
-  WClause* const wcl = &s.wc[wave][0];
-  const uint32_t wcl_addr = lds_addr(wcl);
-  uint32_t wave_hits = 0;    // hits of my current slot not yet added to s.slot_hits
-  uint32_t cur_slot = 0;
-  uint64_t pc_post = 0, pc_surv = 0, pc_look = 0, pc_cand = 0, pc_chunks = 0, pc_wins = 0;
-#ifdef NRT_MS_COUNT_ROUNDS   // experiment build: event counts instead of four of the cycle counters
-  uint64_t pc_dense = 0, pc_sparse = 0, pc_steps = 0, pc_tas = 0, pc_crounds = 0;
-#endif
-  uint32_t g = helper ? (uint32_t)kMsWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)first_win) : wave;   // my current window (flattened over the item's parts)
-  uint32_t pi = 0;        // its part ...
-  uint32_t win_base = 0;  // ... and the windows of the parts before that one
+    uint32_t* const seen = &s.seen[wave][0];
+    WClause* const wcl = &s.wc[wave][0];
+    const uint32_t wcl_addr = lds_addr(wcl);
+    uint32_t wave_hits = 0;    // hits of my current slot not yet added to s.slot_hits
+    uint32_t cur_slot = 0;
+    uint64_t pc_post = 0, pc_surv = 0, pc_look = 0, pc_cand = 0, pc_chunks = 0, pc_wins = 0;
+  #ifdef NRT_MS_COUNT_ROUNDS   // experiment build: event counts instead of four of the cycle counters
+    uint64_t pc_dense = 0, pc_sparse = 0, pc_steps = 0, pc_tas = 0, pc_crounds = 0;
+  #endif
+    uint32_t g = helper ? (uint32_t)kMsWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)first_win) : wave;   // my current window (flattened over the item's parts)
+    uint32_t pi = 0;        // its part ...
+    uint32_t win_base = 0;  // ... and the windows of the parts before that one
 
-  for (;;) {
-    // ---- the part that holds window g
-    DPart part;
-    uint32_t part_wins = 0;
-    for (;; ++pi) {
+    for (;;) {
+      // ---- the part that holds window g
+      DPart part;
+      uint32_t part_wins = 0;
+      for (;; ++pi) {
+        if (pi >= item.n_parts) break;
+        part = parts[item.part_begin + pi];
+        // windows start on kMsWinTiles boundaries of the SEGMENT (the first one of a part may be short): a window never
+        // spans two 2^20-doc super-windows, which is what packed doc offsets are relative to
+        part_wins = (part.tile_end - (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
+        if (g < win_base + part_wins) break;
+        win_base += part_wins;
+      }
       if (pi >= item.n_parts) break;
-      part = parts[item.part_begin + pi];
-      // windows start on kMsWinTiles boundaries of the SEGMENT (the first one of a part may be short): a window never
-      // spans two 2^20-doc super-windows, which is what packed doc offsets are relative to
-      part_wins = (part.tile_end - (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
-      if (g < win_base + part_wins) break;
-      win_base += part_wins;
-    }
-    if (pi >= item.n_parts) break;
-    {  // hits are counted per searcher slice: a part of another slice closes my count of the previous one
-      const uint32_t p_slot = part.slice >> 24;
-      if (p_slot != cur_slot && wave_hits != 0u) {
-        if (lane == 0) atomicAdd(&s.slot_hits[cur_slot], wave_hits);
-        wave_hits = 0;
-      }
-      cur_slot = p_slot;
-      if (lane == 0) s.slot_slice[p_slot] = part.slice & 0xFFFFFFu;
-    }
-    const uint32_t n_terms = part.n_terms;  // <= kMsMaxTerms (planner)
-    const DTerm* const part_terms = terms + part.term_begin;
-
-    // ---- per part: lane l looks after clause l: its exact maximum score in this segment, suffix sums, and the
-    //      clause's record in the wave's LDS table (what a lane needs to stream or look up clause l)
-    uint64_t my_ub = 0, my_suf = 0;
-    const uint64_t t_part0 = PROF ? __builtin_readcyclecounter() : 0ull;
-    const DTerm mt = part_terms[min(lane, n_terms - 1u)];
-    {
-      // 16 lanes per clause, four clauses per pass: lane (g, i) evaluates frontier entry i of clause 4 * pass + g -- two
-      // dependent loads per PASS (the clause's record, then its frontier byte) instead of two per clause
-      uint32_t ub_raw = 0;
-      for (uint32_t pass = 0; pass * 4u < n_terms; ++pass) {  // uniform
-        const uint32_t tt = pass * 4u + (lane >> 4), i = lane & 15u;
-        const DTerm* Tp = part_terms + min(tt, n_terms - 1u);
-        const DTermAux* ax = Tp->aux;
-        const float w = Tp->weight;
-        const int scale = Tp->fx_scale;
-        const float* cache = &s.cache[Tp->cache_slot][0];
-        uint32_t v = 0;
-        if (tt < n_terms) {
-          if (i < 12u) {
-            const uint32_t nb = ax->min_norm[i];
-            if (nb != 0xFFu) v = score_value<true>(bm25_score(w, (float)(int32_t)(i + 1u), cache[nb]), scale);
-          } else if (i == 12u) {
-            const uint32_t mf = ax->esc_max_freq;
-            if (mf != 0u) v = score_value<true>(bm25_score(w, (float)(int32_t)mf, cache[ax->esc_min_norm]), scale);
-          }
+      {  // hits are counted per searcher slice: a part of another slice closes my count of the previous one
+        const uint32_t p_slot = part.slice >> 24;
+        if (p_slot != cur_slot && wave_hits != 0u) {
+          if (lane == 0) atomicAdd(&s.slot_hits[cur_slot], wave_hits);
+          wave_hits = 0;
         }
-#pragma unroll
-        for (int dlt = 8; dlt > 0; dlt >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, dlt, 64));  // maximum of each 16-lane group
-        const uint32_t got = (uint32_t)__shfl((int)v, (int)((lane & 3u) * 16u), 64);            // lane L = clause L: group L & 3 of pass L >> 2
-        if ((lane >> 2) == pass) ub_raw = got;
+        cur_slot = p_slot;
+        if (lane == 0) s.slot_slice[p_slot] = part.slice & 0xFFFFFFu;
       }
-      if (lane < n_terms) my_ub = (uint64_t)ub_raw << mt.fx_shift;
-    }
-    uint64_t my_after = 0;   // what the clauses after mine can add (sum) / lift a doc to (DisjunctionMaxQuery): S_{lane+1}
-    {
-      uint64_t run = 0;
-      for (int m = (int)n_terms - 1; m >= 0; --m) {
-        const uint64_t ub = readlane_u64(my_ub, (uint32_t)m);
-        if (lane == (uint32_t)m) my_after = run;
-        run = use_max ? max(run, ub) : run + ub;
-        if (lane == (uint32_t)m) my_suf = run;
-      }
-    }
-    const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
-    const uint32_t my_shift = mt.shift;
-    if (lane < n_terms) {
-      WClause w;
-      w.docids = (uint64_t)mt.docids;
-      w.fnorm = (uint64_t)mt.fnorm;
-      w.begin = 0;
-      w.count = w.pad0 = 0;
-      w.weight = mt.weight;
-      w.fx_scale = mt.fx_scale;
-      w.flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
-      w.pad = 0;
-      w.u_after = my_after;
-      w.bits = (uint64_t)mt.aux->bits;
-      w.cells = (uint64_t)mt.cell_off;
-      w.start = mt.start;
-      wcl[lane] = w;
-    }
-    if (PROF) tc_part += __builtin_readcyclecounter() - t_part0;
+      const uint32_t n_terms = part.n_terms;  // <= kMsMaxTerms (planner)
+      const DTerm* const part_terms = terms + part.term_begin;
 
-    for (;;) {  // windows of this part
-      const uint64_t t_win0 = PROF ? __builtin_readcyclecounter() : 0ull;
-      const uint32_t ta = (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (g - win_base) * (uint32_t)kMsWinTiles;
-      const uint32_t t0 = max(ta, part.tile_begin);
-      const uint32_t t1 = min(ta + (uint32_t)kMsWinTiles, part.tile_end);
-      const uint32_t doc_lo = t0 * (uint32_t)kTileDocs;
-      const uint32_t doc_span = min(t1 * (uint32_t)kTileDocs, part.max_doc) - doc_lo;
-      if (PROF) pc_wins += 1;
-      // my next window: taken now, so that the counter's answer is there when this one is done
-      uint32_t g_new = 0;
-      if (lane == 0) g_new = (uint32_t)kMsWaves + __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (global: shared with the item's helpers)
-      // theta of the query's other items (LazyMaxScoreAccumulator analogue), once per window
-      uint64_t theta_other = 0, thr_other = 0;
-      if (multi_item) {
-        theta_other = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        thr_other = acc_threshold<true>(theta_other, fx_E);
-        // (another item's slice has passed the floor: the relation is decided, this item may skip as well)
-        if (mode == kMsModeCount && lane == 0 && __hip_atomic_load(my_prune_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-          __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      // posting range of every clause in this window (cells may be coarser than the window: doc-range filter below)
-      uint32_t my_lo = 0, my_hi = 0;
-      if (lane < n_terms) {
-        my_lo = my_cells[t0 >> my_shift];
-        my_hi = my_cells[((t1 - 1u) >> my_shift) + 1u];
-      }
-      if (n_terms > 1u) {
-#pragma unroll
-        for (int j = 0; j < kMsWinWords / 64 / 4; ++j) *(u32x4*)&seen[(lane + 64u * (uint32_t)j) * 4u] = u32x4{0u, 0u, 0u, 0u};
-      }
-      // The essential clauses of the window -- S_c >= theta, a prefix of the order -- are streamed as ONE sequence of
-      // 8-posting groups (16-byte aligned in the columns): a lane takes one group, so sparse clauses share an
-      // instruction instead of taking one each.  Clause c's groups come before clause c + 1's.
-      uint32_t ng = 0;
+      // ---- per part: lane l looks after clause l: its exact maximum score in this segment, suffix sums, and the
+      //      clause's record in the wave's LDS table (what a lane needs to stream or look up clause l)
+      uint64_t my_ub = 0, my_suf = 0;
+      const uint64_t t_part0 = PROF ? __builtin_readcyclecounter() : 0ull;
+      const DTerm mt = part_terms[min(lane, n_terms - 1u)];
       {
-        const uint64_t thr_w = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? max(s.thr, thr_other) : 0ull;
-        const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
-        if (lane < n_terms) {
-          // (minimumNumberShouldMatch: a doc is evaluated at the first clause that holds it, so one first met at clause c matches
-          //  at most n_terms - c clauses: the last msm - 1 clauses cannot start a hit and are never streamed)
-          if (my_suf >= thr_w && pe > pb && (!SHAPES || msm <= 1u || lane + msm <= n_terms)) ng = (uint32_t)((pe - (pb & ~3ull) + (uint64_t)(kSl - 1)) / (uint64_t)kSl);
-          *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)(pe - pb), 0u};
+        // 16 lanes per clause, four clauses per pass: lane (g, i) evaluates frontier entry i of clause 4 * pass + g -- two
+        // dependent loads per PASS (the clause's record, then its frontier byte) instead of two per clause
+        uint32_t ub_raw = 0;
+        for (uint32_t pass = 0; pass * 4u < n_terms; ++pass) {  // uniform
+          const uint32_t tt = pass * 4u + (lane >> 4), i = lane & 15u;
+          const DTerm* Tp = part_terms + min(tt, n_terms - 1u);
+          const DTermAux* ax = Tp->aux;
+          const float w = Tp->weight;
+          const int scale = Tp->fx_scale;
+          const float* cache = &s.cache[Tp->cache_slot][0];
+          uint32_t v = 0;
+          if (tt < n_terms) {
+            if (i < 12u) {
+              const uint32_t nb = ax->min_norm[i];
+              if (nb != 0xFFu) v = score_value<true>(bm25_score(w, (float)(int32_t)(i + 1u), cache[nb]), scale);
+            } else if (i == 12u) {
+              const uint32_t mf = ax->esc_max_freq;
+              if (mf != 0u) v = score_value<true>(bm25_score(w, (float)(int32_t)mf, cache[ax->esc_min_norm]), scale);
+            }
+          }
+  #pragma unroll
+          for (int dlt = 8; dlt > 0; dlt >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, dlt, 64));  // maximum of each 16-lane group
+          const uint32_t got = (uint32_t)__shfl((int)v, (int)((lane & 3u) * 16u), 64);            // lane L = clause L: group L & 3 of pass L >> 2
+          if ((lane >> 2) == pass) ub_raw = got;
+        }
+        if (lane < n_terms) my_ub = (uint64_t)ub_raw << mt.fx_shift;
+      }
+      uint64_t my_after = 0;   // what the clauses after mine can add (sum) / lift a doc to (DisjunctionMaxQuery): S_{lane+1}
+      {
+        uint64_t run = 0;
+        for (int m = (int)n_terms - 1; m >= 0; --m) {
+          const uint64_t ub = readlane_u64(my_ub, (uint32_t)m);
+          if (lane == (uint32_t)m) my_after = run;
+          run = use_max ? max(run, ub) : run + ub;
+          if (lane == (uint32_t)m) my_suf = run;
         }
       }
-      const uint32_t incl = scan32_dpp(ng);
-      uint32_t pre[kMsMaxTerms];
-#pragma unroll
-      for (int i = 0; i < kMsMaxTerms; ++i) pre[i] = (uint32_t)__builtin_amdgcn_readlane((int)incl, i);
-      const uint32_t n_groups = pre[kMsMaxTerms - 1];
+      const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
+      const uint32_t my_shift = mt.shift;
+      if (lane < n_terms) {
+        WClause w;
+        w.docids = (uint64_t)mt.docids;
+        w.fnorm = (uint64_t)mt.fnorm;
+        w.begin = 0;
+        w.count = w.pad0 = 0;
+        w.weight = mt.weight;
+        w.fx_scale = mt.fx_scale;
+        w.flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
+        w.pad = 0;
+        w.u_after = my_after;
+        w.bits = (uint64_t)mt.aux->bits;
+        w.cells = (uint64_t)mt.cell_off;
+        w.start = mt.start;
+        wcl[lane] = w;
+      }
+      if (PROF) tc_part += __builtin_readcyclecounter() - t_part0;
 
-      for (uint32_t v0 = 0; v0 < n_groups; v0 += 64u) {  // 64 groups = up to 512 postings per instruction
-        const uint32_t v = v0 + lane;
-        const bool act = v < n_groups;
-        uint32_t c = 0, before = 0;
-#pragma unroll
-        for (int i = 0; i < kMsMaxTerms - 1; ++i) {
-          c += (v >= pre[i]) ? 1u : 0u;
-          before = (v >= pre[i]) ? pre[i] : before;
+      for (;;) {  // windows of this part
+        const uint64_t t_win0 = PROF ? __builtin_readcyclecounter() : 0ull;
+        const uint32_t ta = (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (g - win_base) * (uint32_t)kMsWinTiles;
+        const uint32_t t0 = max(ta, part.tile_begin);
+        const uint32_t t1 = min(ta + (uint32_t)kMsWinTiles, part.tile_end);
+        const uint32_t doc_lo = t0 * (uint32_t)kTileDocs;
+        const uint32_t doc_span = min(t1 * (uint32_t)kTileDocs, part.max_doc) - doc_lo;
+        if (PROF) pc_wins += 1;
+        // my next window: taken now, so that the counter's answer is there when this one is done
+        uint32_t g_new = 0;
+        if (lane == 0) g_new = (uint32_t)kMsWaves + __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (global: shared with the item's helpers)
+        // theta of the query's other items (LazyMaxScoreAccumulator analogue), once per window
+        uint64_t theta_other = 0, thr_other = 0;
+        if (multi_item) {
+          theta_other = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          thr_other = acc_threshold<true>(theta_other, fx_E);
+          // (another item's slice has passed the floor: the relation is decided, this item may skip as well)
+          if (mode == kMsModeCount && lane == 0 && __hip_atomic_load(my_prune_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        const uint32_t c_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-        // theta as of now (it only grows: a stale value costs work, never a result).  Has it passed what this
-        // instruction's first clause and everything after it can reach?  Then the rest of the window is non-essential.
-        const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
-        const bool pruning = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;   // (uniform)
-        const uint64_t thr_p = pruning ? thr : 0ull;   // what the bounds are compared with
-        if (readlane_u64(my_suf, c_first) < thr_p) break;
-        if (PROF) pc_chunks += 1;
-        // what my clause is: column bases, posting range, score table, scale, what the later clauses can still add
-        const uint32_t rec = wcl_addr + c * (uint32_t)sizeof(WClause);
-        const u32x4 r0 = *(const u32x4*)lds_ptr(rec), r1 = *(const u32x4*)lds_ptr(rec + 16u), r2 = *(const u32x4*)lds_ptr(rec + 32u);
-        const uint64_t u_after = *(const uint64_t*)lds_ptr(rec + 48u);
-        const uint64_t col_d = ((uint64_t)r0[1] << 32) | r0[0], col_c = ((uint64_t)r0[3] << 32) | r0[2];
-        const uint64_t p_begin = ((uint64_t)r1[1] << 32) | r1[0];
-        const uint32_t flags = r2[2];
-        const uint32_t q0 = (v - before) * (uint32_t)kSl;  // my group's first posting, counted from the clause's 16-byte aligned begin
-        const uint64_t mine0 = (p_begin & ~3ull) + (uint64_t)q0;
-        uint32_t d[kSl], cd[kSl];
-#pragma unroll
-        for (int j = 0; j < kSl; ++j) d[j] = cd[j] = 0u;
-        if (act) {  // (the columns are padded: a partly valid group may read past the term)
-          const u32x4 d0 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u));
-          const u32x4 d1 = kSl > 4 ? __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u) + 1) : d0;
-          if (PACKED) {  // one word per posting: doc offset inside the window's super-window | code
-            const uint32_t sw = doc_lo & ~kPackDocMask;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              d[j] = (d0[j] >> kPackCodeBits) | sw;
-              cd[j] = (d0[j] & kPackCodeMask) << 2;
-              if (kSl > 4) {
-                d[(4 + j) % kSl] = (d1[j] >> kPackCodeBits) | sw;
-                cd[(4 + j) % kSl] = (d1[j] & kPackCodeMask) << 2;
-              }
-            }
-          } else {
-            const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u));
-            const u32x4 c1 = kSl > 4 ? __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u) + 1) : c0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              d[j] = d0[j];
-              cd[j] = c0[j];
-              if (kSl > 4) {
-                d[(4 + j) % kSl] = d1[j];
-                cd[(4 + j) % kSl] = c1[j];
-              }
-            }
-          }
+        // posting range of every clause in this window (cells may be coarser than the window: doc-range filter below)
+        uint32_t my_lo = 0, my_hi = 0;
+        if (lane < n_terms) {
+          my_lo = my_cells[t0 >> my_shift];
+          my_hi = my_cells[((t1 - 1u) >> my_shift) + 1u];
         }
-        uint32_t vmask = 0;  // my postings inside the clause's range (one unsigned compare: positions before the range wrap) and the window
+        if (n_terms > 1u) {
+  #pragma unroll
+          for (int j = 0; j < kMsWinWords / 64 / 4; ++j) *(u32x4*)&seen[(lane + 64u * (uint32_t)j) * 4u] = u32x4{0u, 0u, 0u, 0u};
+        }
+        // The essential clauses of the window -- S_c >= theta, a prefix of the order -- are streamed as ONE sequence of
+        // 8-posting groups (16-byte aligned in the columns): a lane takes one group, so sparse clauses share an
+        // instruction instead of taking one each.  Clause c's groups come before clause c + 1's.
+        uint32_t ng = 0;
         {
-          const uint32_t rel = q0 - ((uint32_t)p_begin & 3u), cnt = act ? r1[2] : 0u;
-#pragma unroll
-          for (int j = 0; j < kSl; ++j)
-            if (rel + (uint32_t)j < cnt && d[j] - doc_lo < doc_span) vmask |= 1u << j;
-        }
-        // the values my postings add: per-lane table (lanes of one instruction may belong to different clauses)
-        uint32_t val[kSl];
-        {
-          const uint32_t tab = flags & 7u;
-          const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
-          uint32_t cor = 0;
-#pragma unroll
-          for (int j = 0; j < kSl; ++j) {
-            val[j] = *(const uint32_t*)(tb + (cd[j] & 0x1FFCu));
-            const uint32_t cn = ((vmask >> j) & 1u) ? cd[j] : 0u;
-            cor = PACKED ? max(cor, cn) : (cor | cn);
-          }
-          const bool special = vmask != 0u && ((PACKED ? cor >= (kPackEscBase << 2) : (cor >> 31) != 0u) || tab == 7u);
-          if (__any(special)) {  // long docs / high freqs / clauses without a score table
-            const float w = __uint_as_float(r2[0]);
-            const int fx_scale = (int)r2[1];
-            const float* cache = &s.cache[(flags >> 8) & 255u][0];
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) {
-              uint32_t cj = cd[j];
-              if (PACKED && cj >= (kPackEscBase << 2))   // (col_c: the group's exception list; mine0 + j: the posting's index in its column)
-                cj = ((vmask >> j) & 1u) ? packed_escape_word((gu32_ptr)col_c, (uint32_t)mine0 + (uint32_t)j, cj >> 2) : 0x80000100u;
-              const bool esc = (cj >> 31) != 0u;
-              const uint32_t f = esc ? ((cj >> 8) & 0x3FFFFFu) : ((cj >> 9) & 15u);
-              const bool dead = esc ? ((cj >> 30) & 1u) != 0u : (cj >> 20) != 0u;
-              const uint32_t nb = esc ? (cj & 255u) : ((cj >> 2) & 127u);
-              if (((vmask >> j) & 1u) && (esc || tab == 7u))
-                val[j] = dead ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
-            }
+          const uint64_t thr_w = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? max(s.thr, thr_other) : 0ull;
+          const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
+          if (lane < n_terms) {
+            // (minimumNumberShouldMatch: a doc is evaluated at the first clause that holds it, so one first met at clause c matches
+            //  at most n_terms - c clauses: the last msm - 1 clauses cannot start a hit and are never streamed)
+            if (my_suf >= thr_w && pe > pb && (!SHAPES || msm <= 1u || lane + msm <= n_terms)) ng = (uint32_t)((pe - (pb & ~3ull) + (uint64_t)(kSl - 1)) / (uint64_t)kSl);
+            *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)(pe - pb), 0u};
           }
         }
-        uint64_t run[kSl];
-        uint32_t alive = 0;
-        {
-          const uint32_t mult = 1u << ((flags >> 4) & 15u);  // entry << shift as one 32 x 32 -> 64 multiply
-          // "entry * mult + u_after >= thr_p" (DisjunctionMaxQuery: max instead of +) as ONE 32-bit compare per posting: the
-          // smallest entry that passes, computed once per lane (>= 1: a posting of a deleted doc scores 0 and never passes)
-          uint32_t need_v = 1u;
-          if (u_after < thr_p) {
-            const uint64_t gap = use_max ? thr_p : thr_p - u_after;
-            const uint64_t nv = (gap + (uint64_t)(mult - 1u)) >> ((flags >> 4) & 15u);
-            need_v = nv > 0xFFFFFFFFull ? 0xFFFFFFFFu : max((uint32_t)nv, 1u);
-            // (an entry of 2^32 - 1 that still falls short: the exact test below is the rare fallback)
-          }
-          uint32_t pass = 0;
-#pragma unroll
-          for (int j = 0; j < kSl; ++j) {
-            run[j] = (uint64_t)val[j] * (uint64_t)mult;
-            pass |= val[j] >= need_v ? (1u << j) : 0u;
-          }
-          alive = vmask & pass;
-          if (need_v == 0xFFFFFFFFu) {   // (per lane, practically never)
-#pragma unroll
-            for (int j = 0; j < kSl; ++j)
-              if ((use_max ? max(run[j], u_after) : run[j] + u_after) < thr_p) alive &= ~(1u << j);
-          }
-        }
-        if (PROF) {
-          pc_post += (uint64_t)__popc(vmask);
-          pc_surv += (uint64_t)__popc(alive);
-        }
-        // first clause to reach the doc?  Test-and-set, clause by clause in order: LDS executes a wave's operations
-        // in order, so of two postings of one doc in this instruction the earlier clause's wins.  (Lanes without a
-        // survivor OR a zero into a word of their own.)
-        const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)(min(n_groups - v0, 64u) - 1u));
-        if (n_terms > 1u && __any(alive != 0u)) {
-          for (uint32_t cc = c_first; cc <= c_last; ++cc) {
-            const uint32_t am = c == cc ? alive : 0u;
-            if (!__any(am != 0u)) continue;
-#ifdef NRT_MS_COUNT_ROUNDS
-            if (PROF) pc_tas += 1;
-#endif
-            uint32_t old[kSl];
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) {
-              const bool a = (am >> j) & 1u;
-              const uint32_t w = a ? ((d[j] - doc_lo) >> 5) : lane;
-              old[j] = atomicOr(&seen[w], a ? (1u << (d[j] & 31u)) : 0u);
-            }
-#pragma unroll
-            for (int j = 0; j < kSl; ++j)
-              if (((am >> j) & 1u) && ((old[j] >> (d[j] & 31u)) & 1u)) alive &= ~(1u << j);
-          }
-        }
-        uint32_t ccnt = 0x11111111u;   // SHAPES, minimumNumberShouldMatch: clauses that matched the doc, 4 bits per posting slot
+        const uint32_t incl = scan32_dpp(ng);
+        uint32_t pre[kMsMaxTerms];
+  #pragma unroll
+        for (int i = 0; i < kMsMaxTerms; ++i) pre[i] = (uint32_t)__builtin_amdgcn_readlane((int)incl, i);
+        const uint32_t n_groups = pre[kMsMaxTerms - 1];
 
-        // ---- One doc per lane: what is left of an instruction once few of its docs survive (collapse_to_rows).  The same
-        //      steps as the rounds below -- bound, lookup, sum, then hits and candidates -- on scalars, at an eighth of the
-        //      vector instructions per round.
-        auto finish_rows = [&](uint32_t d1, uint64_t run1, bool live1, uint32_t c1, uint32_t cnt1, uint32_t j2_begin) {
-          for (uint32_t j2 = j2_begin; j2 < n_terms; ++j2) {
-            if (!__any(live1)) break;
-            const uint64_t S_j = readlane_u64(my_suf, j2);
-            bool am = live1 && c1 < j2;
-            if (am && (use_max ? max(run1, S_j) : run1 + S_j) < thr_p) live1 = am = false;
-            if (SHAPES && msm > 1u && am && cnt1 + (n_terms - j2) < msm) live1 = am = false;
-            if (!__any(am)) continue;
-            if (PROF) pc_look += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(am));
-            const WClause& w2 = wcl[j2];  // uniform reads
-            const uint64_t bits2 = w2.bits;
-            const uint32_t flags2 = w2.flags;
-            const gu32_ptr codes2 = (gu32_ptr)((PACKED ? w2.docids : w2.fnorm) + w2.start * 4u);
-            bool present = false;
-            uint32_t at = 0;   // the doc's posting in the clause (index relative to the clause's first)
-            if (bits2 != 0ull) {
-              const u32x2 r = ((gvec2_ptr)bits2)[am ? (d1 >> 5) : 0u];
-              const uint32_t bb = d1 & 31u;
-              present = am && ((r[0] >> bb) & 1u);
-              at = present ? r[1] + (uint32_t)__popc(r[0] & ((1u << bb) - 1u)) : 0u;
-            } else {
-              const gu32_ptr cells2 = (gu32_ptr)w2.cells;
-              const gu32_ptr docs2 = (gu32_ptr)(w2.docids + w2.start * 4u);
-              const uint32_t cell = am ? ((d1 >> 10) >> (flags2 >> 16)) : 0u;
-              uint32_t a = cells2[cell], b = cells2[cell + 1u];
-              if (!am) b = a;
-              bool open = a < b;
-              while (__any(open)) {
-                const uint32_t mid = (a + b) >> 1;
-                const uint32_t vv = docs2[open ? mid : 0u];
-                if (open) {
-                  const uint32_t dv = PACKED ? vv >> kPackCodeBits : vv, dd = PACKED ? d1 & kPackDocMask : d1;
-                  if (dv < dd) a = mid + 1u;
-                  else b = mid;
-                  if (dv == dd) {
-                    a = b = mid;
-                    present = true;
-                  }
-                  open = a < b;
+        for (uint32_t v0 = 0; v0 < n_groups; v0 += 64u) {  // 64 groups = up to 512 postings per instruction
+          const uint32_t v = v0 + lane;
+          const bool act = v < n_groups;
+          uint32_t c = 0, before = 0;
+  #pragma unroll
+          for (int i = 0; i < kMsMaxTerms - 1; ++i) {
+            c += (v >= pre[i]) ? 1u : 0u;
+            before = (v >= pre[i]) ? pre[i] : before;
+          }
+          const uint32_t c_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+          // theta as of now (it only grows: a stale value costs work, never a result).  Has it passed what this
+          // instruction's first clause and everything after it can reach?  Then the rest of the window is non-essential.
+          const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
+          const bool pruning = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;   // (uniform)
+          const uint64_t thr_p = pruning ? thr : 0ull;   // what the bounds are compared with
+          if (readlane_u64(my_suf, c_first) < thr_p) break;
+          if (PROF) pc_chunks += 1;
+          // what my clause is: column bases, posting range, score table, scale, what the later clauses can still add
+          const uint32_t rec = wcl_addr + c * (uint32_t)sizeof(WClause);
+          const u32x4 r0 = *(const u32x4*)lds_ptr(rec), r1 = *(const u32x4*)lds_ptr(rec + 16u), r2 = *(const u32x4*)lds_ptr(rec + 32u);
+          const uint64_t u_after = *(const uint64_t*)lds_ptr(rec + 48u);
+          const uint64_t col_d = ((uint64_t)r0[1] << 32) | r0[0], col_c = ((uint64_t)r0[3] << 32) | r0[2];
+          const uint64_t p_begin = ((uint64_t)r1[1] << 32) | r1[0];
+          const uint32_t flags = r2[2];
+          const uint32_t q0 = (v - before) * (uint32_t)kSl;  // my group's first posting, counted from the clause's 16-byte aligned begin
+          const uint64_t mine0 = (p_begin & ~3ull) + (uint64_t)q0;
+          uint32_t d[kSl], cd[kSl];
+  #pragma unroll
+          for (int j = 0; j < kSl; ++j) d[j] = cd[j] = 0u;
+          if (act) {  // (the columns are padded: a partly valid group may read past the term)
+            const u32x4 d0 = __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u));
+            const u32x4 d1 = kSl > 4 ? __builtin_nontemporal_load((gvec_ptr)(col_d + mine0 * 4u) + 1) : d0;
+            if (PACKED) {  // one word per posting: doc offset inside the window's super-window | code
+              const uint32_t sw = doc_lo & ~kPackDocMask;
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                d[j] = (d0[j] >> kPackCodeBits) | sw;
+                cd[j] = (d0[j] & kPackCodeMask) << 2;
+                if (kSl > 4) {
+                  d[(4 + j) % kSl] = (d1[j] >> kPackCodeBits) | sw;
+                  cd[(4 + j) % kSl] = (d1[j] & kPackCodeMask) << 2;
                 }
               }
-              at = present ? a : 0u;
-            }
-            if (__any(present)) {
-              uint32_t c2[1] = {codes2[at]}, pi2[1] = {(uint32_t)w2.start + at}, v2[1];
-              if (PACKED) c2[0] = (c2[0] & kPackCodeMask) << 2;
-              values_of_codes<PACKED, 1>(s, c2, present ? 1u : 0u, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
-              const uint64_t add = (uint64_t)(present ? v2[0] : 0u) * (uint64_t)(1u << ((flags2 >> 4) & 15u));
-              run1 = use_max ? max(run1, add) : run1 + add;
-              cnt1 += present ? 1u : 0u;
+            } else {
+              const u32x4 c0 = __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u));
+              const u32x4 c1 = kSl > 4 ? __builtin_nontemporal_load((gvec_ptr)(col_c + mine0 * 4u) + 1) : c0;
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                d[j] = d0[j];
+                cd[j] = c0[j];
+                if (kSl > 4) {
+                  d[(4 + j) % kSl] = d1[j];
+                  cd[(4 + j) % kSl] = c1[j];
+                }
+              }
             }
           }
-          bool maybe = live1 && run1 >= thr;
+          uint32_t vmask = 0;  // my postings inside the clause's range (one unsigned compare: positions before the range wrap) and the window
           {
-            bool pool = pruning ? maybe : live1;
-            if (SHAPES && msm > 1u && cnt1 < msm) pool = false;
-            if (part.live_bits != nullptr && __any(pool)) {   // (uniform)
-              const uint32_t lw = ((const NRT_GLOBAL uint32_t*)part.live_bits)[pool ? (d1 >> 5) : 0u];
-              pool = pool && ((lw >> (d1 & 31u)) & 1u) != 0u;
+            const uint32_t rel = q0 - ((uint32_t)p_begin & 3u), cnt = act ? r1[2] : 0u;
+  #pragma unroll
+            for (int j = 0; j < kSl; ++j)
+              if (rel + (uint32_t)j < cnt && d[j] - doc_lo < doc_span) vmask |= 1u << j;
+          }
+          // the values my postings add: per-lane table (lanes of one instruction may belong to different clauses)
+          uint32_t val[kSl];
+          {
+            const uint32_t tab = flags & 7u;
+            const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
+            uint32_t cor = 0;
+  #pragma unroll
+            for (int j = 0; j < kSl; ++j) {
+              val[j] = *(const uint32_t*)(tb + (cd[j] & 0x1FFCu));
+              const uint32_t cn = ((vmask >> j) & 1u) ? cd[j] : 0u;
+              cor = PACKED ? max(cor, cn) : (cor | cn);
             }
-            maybe = maybe && pool;
-            const uint32_t h = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pool));
+            const bool special = vmask != 0u && ((PACKED ? cor >= (kPackEscBase << 2) : (cor >> 31) != 0u) || tab == 7u);
+            if (__any(special)) {  // long docs / high freqs / clauses without a score table
+              const float w = __uint_as_float(r2[0]);
+              const int fx_scale = (int)r2[1];
+              const float* cache = &s.cache[(flags >> 8) & 255u][0];
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) {
+                uint32_t cj = cd[j];
+                if (PACKED && cj >= (kPackEscBase << 2))   // (col_c: the group's exception list; mine0 + j: the posting's index in its column)
+                  cj = ((vmask >> j) & 1u) ? packed_escape_word((gu32_ptr)col_c, (uint32_t)mine0 + (uint32_t)j, cj >> 2) : 0x80000100u;
+                const bool esc = (cj >> 31) != 0u;
+                const uint32_t f = esc ? ((cj >> 8) & 0x3FFFFFu) : ((cj >> 9) & 15u);
+                const bool dead = esc ? ((cj >> 30) & 1u) != 0u : (cj >> 20) != 0u;
+                const uint32_t nb = esc ? (cj & 255u) : ((cj >> 2) & 127u);
+                if (((vmask >> j) & 1u) && (esc || tab == 7u))
+                  val[j] = dead ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
+              }
+            }
+          }
+          uint64_t run[kSl];
+          uint32_t alive = 0;
+          {
+            const uint32_t mult = 1u << ((flags >> 4) & 15u);  // entry << shift as one 32 x 32 -> 64 multiply
+            // "entry * mult + u_after >= thr_p" (DisjunctionMaxQuery: max instead of +) as ONE 32-bit compare per posting: the
+            // smallest entry that passes, computed once per lane (>= 1: a posting of a deleted doc scores 0 and never passes)
+            uint32_t need_v = 1u;
+            if (u_after < thr_p) {
+              const uint64_t gap = use_max ? thr_p : thr_p - u_after;
+              const uint64_t nv = (gap + (uint64_t)(mult - 1u)) >> ((flags >> 4) & 15u);
+              need_v = nv > 0xFFFFFFFFull ? 0xFFFFFFFFu : max((uint32_t)nv, 1u);
+              // (an entry of 2^32 - 1 that still falls short: the exact test below is the rare fallback)
+            }
+            uint32_t pass = 0;
+  #pragma unroll
+            for (int j = 0; j < kSl; ++j) {
+              run[j] = (uint64_t)val[j] * (uint64_t)mult;
+              pass |= val[j] >= need_v ? (1u << j) : 0u;
+            }
+            alive = vmask & pass;
+            if (need_v == 0xFFFFFFFFu) {   // (per lane, practically never)
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j)
+                if ((use_max ? max(run[j], u_after) : run[j] + u_after) < thr_p) alive &= ~(1u << j);
+            }
+          }
+          if (PROF) {
+            pc_post += (uint64_t)__popc(vmask);
+            pc_surv += (uint64_t)__popc(alive);
+          }
+          // first clause to reach the doc?  Test-and-set, clause by clause in order: LDS executes a wave's operations
+          // in order, so of two postings of one doc in this instruction the earlier clause's wins.  (Lanes without a
+          // survivor OR a zero into a word of their own.)
+          const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)(min(n_groups - v0, 64u) - 1u));
+          if (n_terms > 1u && __any(alive != 0u)) {
+            for (uint32_t cc = c_first; cc <= c_last; ++cc) {
+              const uint32_t am = c == cc ? alive : 0u;
+              if (!__any(am != 0u)) continue;
+  #ifdef NRT_MS_COUNT_ROUNDS
+              if (PROF) pc_tas += 1;
+  #endif
+              uint32_t old[kSl];
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) {
+                const bool a = (am >> j) & 1u;
+                const uint32_t w = a ? ((d[j] - doc_lo) >> 5) : lane;
+                old[j] = atomicOr(&seen[w], a ? (1u << (d[j] & 31u)) : 0u);
+              }
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j)
+                if (((am >> j) & 1u) && ((old[j] >> (d[j] & 31u)) & 1u)) alive &= ~(1u << j);
+            }
+          }
+          uint32_t ccnt = 0x11111111u;   // SHAPES, minimumNumberShouldMatch: clauses that matched the doc, 4 bits per posting slot
+
+          // ---- One doc per lane: what is left of an instruction once few of its docs survive (collapse_to_rows).  The same
+          //      steps as the rounds below -- bound, lookup, sum, then hits and candidates -- on scalars, at an eighth of the
+          //      vector instructions per round.
+          auto finish_rows = [&](uint32_t d1, uint64_t run1, bool live1, uint32_t c1, uint32_t cnt1, uint32_t j2_begin) {
+            for (uint32_t j2 = j2_begin; j2 < n_terms; ++j2) {
+              if (!__any(live1)) break;
+              const uint64_t S_j = readlane_u64(my_suf, j2);
+              bool am = live1 && c1 < j2;
+              if (am && (use_max ? max(run1, S_j) : run1 + S_j) < thr_p) live1 = am = false;
+              if (SHAPES && msm > 1u && am && cnt1 + (n_terms - j2) < msm) live1 = am = false;
+              if (!__any(am)) continue;
+              if (PROF) pc_look += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(am));
+              const WClause& w2 = wcl[j2];  // uniform reads
+              const uint64_t bits2 = w2.bits;
+              const uint32_t flags2 = w2.flags;
+              const gu32_ptr codes2 = (gu32_ptr)((PACKED ? w2.docids : w2.fnorm) + w2.start * 4u);
+              bool present = false;
+              uint32_t at = 0;   // the doc's posting in the clause (index relative to the clause's first)
+              if (bits2 != 0ull) {
+                const u32x2 r = ((gvec2_ptr)bits2)[am ? (d1 >> 5) : 0u];
+                const uint32_t bb = d1 & 31u;
+                present = am && ((r[0] >> bb) & 1u);
+                at = present ? r[1] + (uint32_t)__popc(r[0] & ((1u << bb) - 1u)) : 0u;
+              } else {
+                const gu32_ptr cells2 = (gu32_ptr)w2.cells;
+                const gu32_ptr docs2 = (gu32_ptr)(w2.docids + w2.start * 4u);
+                const uint32_t cell = am ? ((d1 >> 10) >> (flags2 >> 16)) : 0u;
+                uint32_t a = cells2[cell], b = cells2[cell + 1u];
+                if (!am) b = a;
+                bool open = a < b;
+                while (__any(open)) {
+                  const uint32_t mid = (a + b) >> 1;
+                  const uint32_t vv = docs2[open ? mid : 0u];
+                  if (open) {
+                    const uint32_t dv = PACKED ? vv >> kPackCodeBits : vv, dd = PACKED ? d1 & kPackDocMask : d1;
+                    if (dv < dd) a = mid + 1u;
+                    else b = mid;
+                    if (dv == dd) {
+                      a = b = mid;
+                      present = true;
+                    }
+                    open = a < b;
+                  }
+                }
+                at = present ? a : 0u;
+              }
+              if (__any(present)) {
+                uint32_t c2[1] = {codes2[at]}, pi2[1] = {(uint32_t)w2.start + at}, v2[1];
+                if (PACKED) c2[0] = (c2[0] & kPackCodeMask) << 2;
+                values_of_codes<PACKED, 1>(s, c2, present ? 1u : 0u, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
+                const uint64_t add = (uint64_t)(present ? v2[0] : 0u) * (uint64_t)(1u << ((flags2 >> 4) & 15u));
+                run1 = use_max ? max(run1, add) : run1 + add;
+                cnt1 += present ? 1u : 0u;
+              }
+            }
+            bool maybe = live1 && run1 >= thr;
+            {
+              bool pool = pruning ? maybe : live1;
+              if (SHAPES && msm > 1u && cnt1 < msm) pool = false;
+              if (part.live_bits != nullptr && __any(pool)) {   // (uniform)
+                const uint32_t lw = ((const NRT_GLOBAL uint32_t*)part.live_bits)[pool ? (d1 >> 5) : 0u];
+                pool = pool && ((lw >> (d1 & 31u)) & 1u) != 0u;
+              }
+              maybe = maybe && pool;
+              const uint32_t h = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pool));
+              if (mode == kMsModeCount && !pruning) {
+                if (lane == 0 && h != 0u) {
+                  const uint32_t tot = atomicAdd(&s.slot_hits[cur_slot], h) + h;
+                  if (tot > q.gte_floor) {
+                    __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (multi_item) __hip_atomic_store(my_prune_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                }
+              } else {
+                wave_hits += h;
+              }
+            }
+            uint64_t theta_now = theta;
+            while (__any(maybe)) {
+              const uint64_t key = pack_key(acc_score<true>(run1, fx_E), (uint32_t)(part.doc_base + (int32_t)d1));
+              const bool want = maybe && key > theta_now && key < after_key;
+              uint32_t pos = 0;
+              if (!__any(want)) break;
+              if (ms_reserve(s, lane, want ? 1u : 0u, pos)) {  // wave-uniform
+                if (want) s.cand[pos] = key;
+                if (PROF) pc_cand += want ? 1u : 0u;
+                break;
+              }
+              const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
+              (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
+              if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
+              theta_now = max(theta_now, s.theta);
+            }
+          };
+          bool collapsed = false;
+
+          // ---- the later clauses of the surviving docs, one clause at a time (a lane of clause c takes part from c + 1 on)
+          for (uint32_t j2 = c_first + 1u; j2 < n_terms; ++j2) {
+            if (!__any(alive != 0u)) break;
+            const uint64_t S_j = readlane_u64(my_suf, j2);
+            uint32_t am = c < j2 ? alive : 0u;
+            {
+              // "sum + S_j < thr_p" (DisjunctionMaxQuery: max(sum, S_j)) against a UNIFORM value: sum < thr_p - S_j -- one 64-bit
+              // compare per doc, no add; nothing is dropped while S_j alone reaches thr_p
+              const uint64_t short_of = S_j < thr_p ? (use_max ? thr_p : thr_p - S_j) : 0ull;
+              uint32_t kill = 0;
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) kill |= run[j] < short_of ? (1u << j) : 0u;
+              if (SHAPES && msm > 1u) {   // (uniform) too few clauses left to reach minimumNumberShouldMatch: no hit, whatever it scores
+                const uint32_t left = n_terms - j2;
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) kill |= ((ccnt >> (4 * j)) & 15u) + left < msm ? (1u << j) : 0u;
+              }
+              kill &= am;
+              alive &= ~kill;
+              am &= ~kill;
+            }
+            if (!__any(am != 0u)) continue;
+            if (kMsCollapse) {
+              // few docs of the instruction left: dealt out one per lane, the rest of the instruction runs on rows
+              const uint32_t n_left = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp((uint32_t)__popc(alive)), 63);
+              if (n_left <= 63u) {
+                uint32_t d1, meta1;
+                uint64_t run1;
+                collapse_to_rows<kSl>(d, run, alive, c, ccnt, d1, run1, meta1);
+                finish_rows(d1, run1, lane < n_left, meta1 & 15u, meta1 >> 4, j2);
+                collapsed = true;
+                break;
+              }
+            }
+            if (PROF) pc_look += (uint64_t)__popc(am);
+            const WClause& w2 = wcl[j2];  // uniform reads; the pointers as scalars: a gather is then base + 32-bit lane offset
+            const uint64_t bits2 = uniform_u64(w2.bits);
+            const uint32_t flags2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w2.flags);
+            const uint64_t start2 = uniform_u64(w2.start);
+            const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + start2 * 4u);  // packed: the code rides in the posting's word
+            uint32_t c2[kSl];
+            uint32_t pi2[kSl];  // packed postings: the looked-up postings' indices in their column (exception lookups)
+            uint32_t present = 0;
+  #ifdef NRT_MS_COUNT_ROUNDS
+            if (PROF) { if (bits2 != 0ull) pc_dense += 1; else pc_sparse += 1; }
+  #endif
+            if (bits2 != 0ull) {
+              // dense clause: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether
+              // the doc is there and where its posting is
+              const gvec2_ptr recs = (gvec2_ptr)bits2;
+              u32x2 r[kSl];
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
+              __builtin_amdgcn_sched_barrier(0);   // every record load is issued before the first one is waited for
+              uint32_t idx[kSl];
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) {
+                const uint32_t bb = d[j] & 31u;
+                const bool there = ((am >> j) & 1u) && ((r[j][0] >> bb) & 1u);
+                idx[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
+                present |= (there ? 1u : 0u) << j;
+              }
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
+              __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) pi2[j] = (uint32_t)start2 + idx[j];
+            } else {
+              // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
+              // lane advance in lockstep, so every step is one round of loads in flight instead of eight
+              const gu32_ptr cells2 = (gu32_ptr)uniform_u64(w2.cells);
+              const gu32_ptr docs2 = (gu32_ptr)(uniform_u64(w2.docids) + start2 * 4u);
+              const uint32_t cshift = flags2 >> 16;
+              uint32_t a[kSl], b[kSl];
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) {
+                const uint32_t cell = ((am >> j) & 1u) ? ((d[j] >> 10) >> cshift) : 0u;
+                a[j] = cells2[cell];
+                b[j] = cells2[cell + 1u];
+              }
+              uint32_t open = 0;
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) {
+                if (!((am >> j) & 1u)) b[j] = a[j];
+                open |= (a[j] < b[j] ? 1u : 0u) << j;
+              }
+              while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
+  #ifdef NRT_MS_COUNT_ROUNDS
+                if (PROF) pc_steps += 1;
+  #endif
+                uint32_t mid[kSl], vv[kSl];
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) {
+                  mid[j] = (a[j] + b[j]) >> 1;
+                  vv[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
+                }
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j)
+                  if ((open >> j) & 1u) {
+                    // (packed: doc offsets inside the cell's super-window -- the doc's own, a cell never spans two)
+                    const uint32_t dv = PACKED ? vv[j] >> kPackCodeBits : vv[j], dd = PACKED ? d[j] & kPackDocMask : d[j];
+                    if (dv < dd) a[j] = mid[j] + 1u;
+                    else b[j] = mid[j];
+                    if (dv == dd) {  // found: close the search on it
+                      a[j] = b[j] = mid[j];
+                      present |= 1u << j;
+                    }
+                    if (!(a[j] < b[j])) open &= ~(1u << j);
+                  }
+              }
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) {
+                c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];   // (packed: the posting's word again -- keeping the probe's word alive
+                                                                      //  through the search loop cost more than this gather)
+                pi2[j] = (uint32_t)start2 + a[j];
+              }
+            }
+            if (__any(present != 0u)) {
+              uint32_t v2[kSl];
+              if (PACKED) {
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) c2[j] = (c2[j] & kPackCodeMask) << 2;
+              }
+              values_of_codes<PACKED, kSl>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
+              const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
+              if (use_max) {   // (uniform)
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) run[j] = max(run[j], (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2);
+              } else {
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
+              }
+              if (SHAPES && msm > 1u) {   // (uniform) bit j of `present` -> nibble j
+                uint32_t x = present;
+                x = (x | (x << 12)) & 0x000F000Fu;
+                x = (x | (x << 6)) & 0x03030303u;
+                x = (x | (x << 3)) & 0x11111111u;
+                ccnt += x;
+              }
+            }
+          }
+
+          if (!collapsed) {
+          // ---- complete scores: the competitive ones go to the shared candidate buffer.  Rare once theta has
+          //      converged, so the key (a double conversion) is built only for sums that reach theta's score, one
+          //      posting per lane and round.
+          uint32_t maybe = 0;
+  #pragma unroll
+          for (int j = 0; j < kSl; ++j)
+            if (((alive >> j) & 1u) && run[j] >= thr) maybe |= 1u << j;
+          // ---- hits.  While nothing is being skipped every live matching doc reaches this point exactly once: the count is
+          //      exact.  Once bounds skip it is a lower bound, and only the docs that reach theta's score are looked at.
+          //      A hit lies inside the part's doc set (liveDocs that are not folded into the postings -- packed layout, forked
+          //      reader versions -- and FILTER / MUST_NOT masks: one dword gather per doc) and matches enough clauses.
+          {
+            uint32_t pool = pruning ? maybe : alive;
+            if (SHAPES && msm > 1u) {   // (uniform)
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j)
+                if (((ccnt >> (4 * j)) & 15u) < msm) pool &= ~(1u << j);
+            }
+            if (part.live_bits != nullptr && __any(pool != 0u)) {   // (uniform)
+              uint32_t lw[kSl];
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) lw[j] = ((const NRT_GLOBAL uint32_t*)part.live_bits)[((pool >> j) & 1u) ? (d[j] >> 5) : 0u];
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j)
+                if (!((lw[j] >> (d[j] & 31u)) & 1u)) pool &= ~(1u << j);
+            }
+            maybe &= pool;
+            uint32_t h = (uint32_t)__popc(pool);
+            h = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(h), 63);
             if (mode == kMsModeCount && !pruning) {
+              // counting towards the floor: into the slot at once, so that the item notices when a slice has passed it
               if (lane == 0 && h != 0u) {
                 const uint32_t tot = atomicAdd(&s.slot_hits[cur_slot], h) + h;
                 if (tot > q.gte_floor) {
@@ -805,342 +1015,148 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
             }
           }
           uint64_t theta_now = theta;
-          while (__any(maybe)) {
-            const uint64_t key = pack_key(acc_score<true>(run1, fx_E), (uint32_t)(part.doc_base + (int32_t)d1));
-            const bool want = maybe && key > theta_now && key < after_key;
+          while (__any(maybe != 0u)) {
+  #ifdef NRT_MS_COUNT_ROUNDS
+            if (PROF) pc_crounds += 1;
+  #endif
+            const uint32_t low = maybe & (0u - maybe);  // my lowest pending posting
+            uint64_t rsel = run[0];
+            uint32_t dsel = d[0];
+  #pragma unroll
+            for (int j = 1; j < kSl; ++j)
+              if (low == (1u << j)) {
+                rsel = run[j];
+                dsel = d[j];
+              }
+            const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
+            const bool want = low != 0u && key > theta_now && key < after_key;
             uint32_t pos = 0;
-            if (!__any(want)) break;
+            if (!__any(want)) {
+              maybe &= ~low;
+              continue;
+            }
             if (ms_reserve(s, lane, want ? 1u : 0u, pos)) {  // wave-uniform
               if (want) s.cand[pos] = key;
               if (PROF) pc_cand += want ? 1u : 0u;
-              break;
+              maybe &= ~low;
+              continue;
             }
+            // no room: everybody meets, the k best stay, theta rises; then the same postings again under the new theta
             const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
             (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
             if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
             theta_now = max(theta_now, s.theta);
           }
-        };
-        bool collapsed = false;
-
-        // ---- the later clauses of the surviving docs, one clause at a time (a lane of clause c takes part from c + 1 on)
-        for (uint32_t j2 = c_first + 1u; j2 < n_terms; ++j2) {
-          if (!__any(alive != 0u)) break;
-          const uint64_t S_j = readlane_u64(my_suf, j2);
-          uint32_t am = c < j2 ? alive : 0u;
-          {
-            // "sum + S_j < thr_p" (DisjunctionMaxQuery: max(sum, S_j)) against a UNIFORM value: sum < thr_p - S_j -- one 64-bit
-            // compare per doc, no add; nothing is dropped while S_j alone reaches thr_p
-            const uint64_t short_of = S_j < thr_p ? (use_max ? thr_p : thr_p - S_j) : 0ull;
-            uint32_t kill = 0;
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) kill |= run[j] < short_of ? (1u << j) : 0u;
-            if (SHAPES && msm > 1u) {   // (uniform) too few clauses left to reach minimumNumberShouldMatch: no hit, whatever it scores
-              const uint32_t left = n_terms - j2;
-#pragma unroll
-              for (int j = 0; j < kSl; ++j) kill |= ((ccnt >> (4 * j)) & 15u) + left < msm ? (1u << j) : 0u;
-            }
-            kill &= am;
-            alive &= ~kill;
-            am &= ~kill;
-          }
-          if (!__any(am != 0u)) continue;
-          if (kMsCollapse) {
-            // few docs of the instruction left: dealt out one per lane, the rest of the instruction runs on rows
-            const uint32_t n_left = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp((uint32_t)__popc(alive)), 63);
-            if (n_left <= 63u) {
-              uint32_t d1, meta1;
-              uint64_t run1;
-              collapse_to_rows<kSl>(d, run, alive, c, ccnt, d1, run1, meta1);
-              finish_rows(d1, run1, lane < n_left, meta1 & 15u, meta1 >> 4, j2);
-              collapsed = true;
-              break;
-            }
-          }
-          if (PROF) pc_look += (uint64_t)__popc(am);
-          const WClause& w2 = wcl[j2];  // uniform reads; the pointers as scalars: a gather is then base + 32-bit lane offset
-          const uint64_t bits2 = uniform_u64(w2.bits);
-          const uint32_t flags2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w2.flags);
-          const uint64_t start2 = uniform_u64(w2.start);
-          const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + start2 * 4u);  // packed: the code rides in the posting's word
-          uint32_t c2[kSl];
-          uint32_t pi2[kSl];  // packed postings: the looked-up postings' indices in their column (exception lookups)
-          uint32_t present = 0;
-#ifdef NRT_MS_COUNT_ROUNDS
-          if (PROF) { if (bits2 != 0ull) pc_dense += 1; else pc_sparse += 1; }
-#endif
-          if (bits2 != 0ull) {
-            // dense clause: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether
-            // the doc is there and where its posting is
-            const gvec2_ptr recs = (gvec2_ptr)bits2;
-            u32x2 r[kSl];
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
-            __builtin_amdgcn_sched_barrier(0);   // every record load is issued before the first one is waited for
-            uint32_t idx[kSl];
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) {
-              const uint32_t bb = d[j] & 31u;
-              const bool there = ((am >> j) & 1u) && ((r[j][0] >> bb) & 1u);
-              idx[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
-              present |= (there ? 1u : 0u) << j;
-            }
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
-            __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) pi2[j] = (uint32_t)start2 + idx[j];
-          } else {
-            // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
-            // lane advance in lockstep, so every step is one round of loads in flight instead of eight
-            const gu32_ptr cells2 = (gu32_ptr)uniform_u64(w2.cells);
-            const gu32_ptr docs2 = (gu32_ptr)(uniform_u64(w2.docids) + start2 * 4u);
-            const uint32_t cshift = flags2 >> 16;
-            uint32_t a[kSl], b[kSl];
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) {
-              const uint32_t cell = ((am >> j) & 1u) ? ((d[j] >> 10) >> cshift) : 0u;
-              a[j] = cells2[cell];
-              b[j] = cells2[cell + 1u];
-            }
-            uint32_t open = 0;
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) {
-              if (!((am >> j) & 1u)) b[j] = a[j];
-              open |= (a[j] < b[j] ? 1u : 0u) << j;
-            }
-            while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
-#ifdef NRT_MS_COUNT_ROUNDS
-              if (PROF) pc_steps += 1;
-#endif
-              uint32_t mid[kSl], vv[kSl];
-#pragma unroll
-              for (int j = 0; j < kSl; ++j) {
-                mid[j] = (a[j] + b[j]) >> 1;
-                vv[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
-              }
-#pragma unroll
-              for (int j = 0; j < kSl; ++j)
-                if ((open >> j) & 1u) {
-                  // (packed: doc offsets inside the cell's super-window -- the doc's own, a cell never spans two)
-                  const uint32_t dv = PACKED ? vv[j] >> kPackCodeBits : vv[j], dd = PACKED ? d[j] & kPackDocMask : d[j];
-                  if (dv < dd) a[j] = mid[j] + 1u;
-                  else b[j] = mid[j];
-                  if (dv == dd) {  // found: close the search on it
-                    a[j] = b[j] = mid[j];
-                    present |= 1u << j;
-                  }
-                  if (!(a[j] < b[j])) open &= ~(1u << j);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) {
-              c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];   // (packed: the posting's word again -- keeping the probe's word alive
-                                                                    //  through the search loop cost more than this gather)
-              pi2[j] = (uint32_t)start2 + a[j];
-            }
-          }
-          if (__any(present != 0u)) {
-            uint32_t v2[kSl];
-            if (PACKED) {
-#pragma unroll
-              for (int j = 0; j < kSl; ++j) c2[j] = (c2[j] & kPackCodeMask) << 2;
-            }
-            values_of_codes<PACKED, kSl>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
-            const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
-            if (use_max) {   // (uniform)
-#pragma unroll
-              for (int j = 0; j < kSl; ++j) run[j] = max(run[j], (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2);
-            } else {
-#pragma unroll
-              for (int j = 0; j < kSl; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
-            }
-            if (SHAPES && msm > 1u) {   // (uniform) bit j of `present` -> nibble j
-              uint32_t x = present;
-              x = (x | (x << 12)) & 0x000F000Fu;
-              x = (x | (x << 6)) & 0x03030303u;
-              x = (x | (x << 3)) & 0x11111111u;
-              ccnt += x;
-            }
+          }  // (!collapsed)
+          // somebody else asked for a compaction: join it between two instructions
+          if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
+            (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
+            if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
           }
         }
 
-        if (!collapsed) {
-        // ---- complete scores: the competitive ones go to the shared candidate buffer.  Rare once theta has
-        //      converged, so the key (a double conversion) is built only for sums that reach theta's score, one
-        //      posting per lane and round.
-        uint32_t maybe = 0;
-#pragma unroll
-        for (int j = 0; j < kSl; ++j)
-          if (((alive >> j) & 1u) && run[j] >= thr) maybe |= 1u << j;
-        // ---- hits.  While nothing is being skipped every live matching doc reaches this point exactly once: the count is
-        //      exact.  Once bounds skip it is a lower bound, and only the docs that reach theta's score are looked at.
-        //      A hit lies inside the part's doc set (liveDocs that are not folded into the postings -- packed layout, forked
-        //      reader versions -- and FILTER / MUST_NOT masks: one dword gather per doc) and matches enough clauses.
-        {
-          uint32_t pool = pruning ? maybe : alive;
-          if (SHAPES && msm > 1u) {   // (uniform)
-#pragma unroll
-            for (int j = 0; j < kSl; ++j)
-              if (((ccnt >> (4 * j)) & 15u) < msm) pool &= ~(1u << j);
-          }
-          if (part.live_bits != nullptr && __any(pool != 0u)) {   // (uniform)
-            uint32_t lw[kSl];
-#pragma unroll
-            for (int j = 0; j < kSl; ++j) lw[j] = ((const NRT_GLOBAL uint32_t*)part.live_bits)[((pool >> j) & 1u) ? (d[j] >> 5) : 0u];
-#pragma unroll
-            for (int j = 0; j < kSl; ++j)
-              if (!((lw[j] >> (d[j] & 31u)) & 1u)) pool &= ~(1u << j);
-          }
-          maybe &= pool;
-          uint32_t h = (uint32_t)__popc(pool);
-          h = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(h), 63);
-          if (mode == kMsModeCount && !pruning) {
-            // counting towards the floor: into the slot at once, so that the item notices when a slice has passed it
-            if (lane == 0 && h != 0u) {
-              const uint32_t tot = atomicAdd(&s.slot_hits[cur_slot], h) + h;
-              if (tot > q.gte_floor) {
-                __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (multi_item) __hip_atomic_store(my_prune_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-          } else {
-            wave_hits += h;
-          }
-        }
-        uint64_t theta_now = theta;
-        while (__any(maybe != 0u)) {
-#ifdef NRT_MS_COUNT_ROUNDS
-          if (PROF) pc_crounds += 1;
-#endif
-          const uint32_t low = maybe & (0u - maybe);  // my lowest pending posting
-          uint64_t rsel = run[0];
-          uint32_t dsel = d[0];
-#pragma unroll
-          for (int j = 1; j < kSl; ++j)
-            if (low == (1u << j)) {
-              rsel = run[j];
-              dsel = d[j];
-            }
-          const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
-          const bool want = low != 0u && key > theta_now && key < after_key;
-          uint32_t pos = 0;
-          if (!__any(want)) {
-            maybe &= ~low;
-            continue;
-          }
-          if (ms_reserve(s, lane, want ? 1u : 0u, pos)) {  // wave-uniform
-            if (want) s.cand[pos] = key;
-            if (PROF) pc_cand += want ? 1u : 0u;
-            maybe &= ~low;
-            continue;
-          }
-          // no room: everybody meets, the k best stay, theta rises; then the same postings again under the new theta
-          const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
-          (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
-          if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
-          theta_now = max(theta_now, s.theta);
-        }
-        }  // (!collapsed)
-        // somebody else asked for a compaction: join it between two instructions
-        if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-          const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
-          (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
-          if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
-        }
+        // ---- next window
+        if (PROF) tc_walk += __builtin_readcyclecounter() - t_win0;
+        g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
+        if (g >= win_base + part_wins) break;  // a later part (or past the item)
       }
-
-      // ---- next window
-      if (PROF) tc_walk += __builtin_readcyclecounter() - t_win0;
-      g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
-      if (g >= win_base + part_wins) break;  // a later part (or past the item)
     }
-  }
-  // ---- out of work: stay available for the others' compactions until everybody is done
-  const uint64_t t_idle0 = PROF ? __builtin_readcyclecounter() : 0ull;
-  while (ms_meet(s, k, fx_E, my_theta_g, xch, item.query)) {
-  }
-  const uint64_t t_epi0 = PROF ? __builtin_readcyclecounter() : 0ull;
-  if (PROF && lane == 0) {
-    atomicAdd((unsigned long long*)&s.prof[10], (unsigned long long)tc_meet);
-    atomicAdd((unsigned long long*)&s.prof[11], (unsigned long long)(t_epi0 - t_idle0));
-    atomicAdd((unsigned long long*)&s.prof[12], (unsigned long long)tc_part);
-    atomicAdd((unsigned long long*)&s.prof[13], (unsigned long long)(tc_walk - tc_meet));
-    atomicMax((unsigned long long*)&s.prof[14], (unsigned long long)(t_idle0 - t_item0));
-#ifdef NRT_MS_COUNT_ROUNDS
-    atomicAdd((unsigned long long*)&s.prof[11], (unsigned long long)pc_tas - (unsigned long long)(t_epi0 - t_idle0));
-    atomicAdd((unsigned long long*)&s.prof[12], (unsigned long long)pc_dense - (unsigned long long)tc_part);
-    atomicAdd((unsigned long long*)&s.prof[10], (unsigned long long)pc_sparse - (unsigned long long)tc_meet);
-    atomicAdd((unsigned long long*)&s.prof[13], (unsigned long long)pc_steps - (unsigned long long)(tc_walk - tc_meet));
-    atomicAdd((unsigned long long*)&s.prof[8], (unsigned long long)pc_crounds);
-#endif
-  }
+    // ---- out of work: stay available for the others' compactions until everybody is done
+    const uint64_t t_idle0 = PROF ? __builtin_readcyclecounter() : 0ull;
+    while (ms_meet(s, k, fx_E, my_theta_g, xch, item.query)) {
+    }
+    const uint64_t t_epi0 = PROF ? __builtin_readcyclecounter() : 0ull;
+    if (PROF && lane == 0) {
+      atomicAdd((unsigned long long*)&s.prof[10], (unsigned long long)tc_meet);
+      atomicAdd((unsigned long long*)&s.prof[11], (unsigned long long)(t_epi0 - t_idle0));
+      atomicAdd((unsigned long long*)&s.prof[12], (unsigned long long)tc_part);
+      atomicAdd((unsigned long long*)&s.prof[13], (unsigned long long)(tc_walk - tc_meet));
+      atomicMax((unsigned long long*)&s.prof[14], (unsigned long long)(t_idle0 - t_item0));
+  #ifdef NRT_MS_COUNT_ROUNDS
+      atomicAdd((unsigned long long*)&s.prof[11], (unsigned long long)pc_tas - (unsigned long long)(t_epi0 - t_idle0));
+      atomicAdd((unsigned long long*)&s.prof[12], (unsigned long long)pc_dense - (unsigned long long)tc_part);
+      atomicAdd((unsigned long long*)&s.prof[10], (unsigned long long)pc_sparse - (unsigned long long)tc_meet);
+      atomicAdd((unsigned long long*)&s.prof[13], (unsigned long long)pc_steps - (unsigned long long)(tc_walk - tc_meet));
+      atomicAdd((unsigned long long*)&s.prof[8], (unsigned long long)pc_crounds);
+  #endif
+    }
 
-  // ---- item epilogue
-  {
-    const uint32_t c = s.cnt;
+    // ---- item epilogue
+    {
+      const uint32_t c = s.cnt;
+      __syncthreads();
+      if (c > k) {
+        uint64_t thr = 0;
+        const uint32_t m = topk_compact<kMsThreads, kMsCandCap>(s.cand, c, k, &s.sc, &thr);
+        if (tid == 0) s.cnt = m;
+      }
+    }
+    if (lane == 0 && wave_hits) atomicAdd(&s.slot_hits[cur_slot], wave_hits);
+    if (PROF && lane == 0) {
+      atomicAdd((unsigned long long*)&s.prof[0], (unsigned long long)pc_wins);
+      atomicAdd((unsigned long long*)&s.prof[2], (unsigned long long)pc_chunks);
+    }
+    if (PROF) {
+      uint64_t v3 = pc_post, v4 = pc_surv, v6 = pc_look, v7 = pc_cand;
+  #pragma unroll
+      for (int dlt = 32; dlt > 0; dlt >>= 1) {
+        v3 += __shfl_xor(v3, dlt, 64);
+        v4 += __shfl_xor(v4, dlt, 64);
+        v6 += __shfl_xor(v6, dlt, 64);
+        v7 += __shfl_xor(v7, dlt, 64);
+      }
+      if (lane == 0) {
+        atomicAdd((unsigned long long*)&s.prof[3], (unsigned long long)v3);
+        atomicAdd((unsigned long long*)&s.prof[4], (unsigned long long)v4);
+        atomicAdd((unsigned long long*)&s.prof[6], (unsigned long long)v6);
+        atomicAdd((unsigned long long*)&s.prof[7], (unsigned long long)v7);
+      }
+    }
     __syncthreads();
-    if (c > k) {
-      uint64_t thr = 0;
-      const uint32_t m = topk_compact<kMsThreads, kMsCandCap>(s.cand, c, k, &s.sc, &thr);
-      if (tid == 0) s.cnt = m;
-    }
-  }
-  if (lane == 0 && wave_hits) atomicAdd(&s.slot_hits[cur_slot], wave_hits);
-  if (PROF && lane == 0) {
-    atomicAdd((unsigned long long*)&s.prof[0], (unsigned long long)pc_wins);
-    atomicAdd((unsigned long long*)&s.prof[2], (unsigned long long)pc_chunks);
-  }
-  if (PROF) {
-    uint64_t v3 = pc_post, v4 = pc_surv, v6 = pc_look, v7 = pc_cand;
-#pragma unroll
-    for (int dlt = 32; dlt > 0; dlt >>= 1) {
-      v3 += __shfl_xor(v3, dlt, 64);
-      v4 += __shfl_xor(v4, dlt, 64);
-      v6 += __shfl_xor(v6, dlt, 64);
-      v7 += __shfl_xor(v7, dlt, 64);
-    }
-    if (lane == 0) {
-      atomicAdd((unsigned long long*)&s.prof[3], (unsigned long long)v3);
-      atomicAdd((unsigned long long*)&s.prof[4], (unsigned long long)v4);
-      atomicAdd((unsigned long long*)&s.prof[6], (unsigned long long)v6);
-      atomicAdd((unsigned long long*)&s.prof[7], (unsigned long long)v7);
-    }
-  }
-  __syncthreads();
-  const uint32_t n = s.cnt;
-  uint64_t* out = item_keys + (size_t)out_slot * k_stride;
-  for (uint32_t i = tid; i < n; i += kMsThreads) out[i] = s.cand[i];
-  if (tid == 0) {
-    item_counts[out_slot] = n;
-    if (helper) {   // my slot joins the query's list (merge_topk_kernel walks it behind the items' slots)
-      const uint32_t h = out_slot - hp.slot_base;
-      hp.help_next[h] = atomicExch(hp.help_head + item.query, h + 1u);
-    }
-    // the item's hits, per slice into the query's sums (slice_relation_kernel) and in total
-    uint32_t hits = 0;
-    for (int i = 0; i < kSliceSlots; ++i) {
-      const uint32_t h = s.slot_hits[i];
-      hits += h;
-      if (h != 0u && q.gte_floor != 0xFFFFFFFFu) atomicAdd(&slice_sum[q.slice_base + s.slot_slice[i]], h);
-    }
-    // anything skipped?  Only a theta can skip, and only once the item may prune; with none the walk evaluated every live
-    // matching doc exactly once.
-    const bool pruned = s.prune_on != 0u && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
-    item_hits[out_slot] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
-    if (PROF && item_prof) {
-      s.prof[5] = hits;
-      const uint64_t t_end = __builtin_readcyclecounter();
-      s.prof[9] = t_end - t_item0;
-      s.prof[15] = t_end - t_epi0;
-      for (int i = 0; i < 16; ++i) item_prof[(size_t)out_slot * 16 + i] = s.prof[i];
-      if (hp.walls) {
-        hp.walls[(size_t)out_slot * 4 + 0] = wall0;
-        hp.walls[(size_t)out_slot * 4 + 1] = wall_clock64();
-        hp.walls[(size_t)out_slot * 4 + 2] = my_item;
-        hp.walls[(size_t)out_slot * 4 + 3] = s.prof[0];
+    const uint32_t n = s.cnt;
+    uint64_t* out = item_keys + (size_t)out_slot * k_stride;
+    for (uint32_t i = tid; i < n; i += kMsThreads) out[i] = s.cand[i];
+    if (tid == 0) {
+      item_counts[out_slot] = n;
+      if (helper) {   // my slot joins the query's list (merge_topk_kernel walks it behind the items' slots)
+        const uint32_t h = out_slot - hp.slot_base;
+        hp.help_next[h] = atomicExch(hp.help_head + item.query, h + 1u);
+      }
+      // the item's hits, per slice into the query's sums (slice_relation_kernel) and in total
+      uint32_t hits = 0;
+      for (int i = 0; i < kSliceSlots; ++i) {
+        const uint32_t h = s.slot_hits[i];
+        hits += h;
+        if (h != 0u && q.gte_floor != 0xFFFFFFFFu) atomicAdd(&slice_sum[q.slice_base + s.slot_slice[i]], h);
+      }
+      // anything skipped?  Only a theta can skip, and only once the item may prune; with none the walk evaluated every live
+      // matching doc exactly once.
+      const bool pruned = s.prune_on != 0u && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
+      item_hits[out_slot] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
+      if (PROF && item_prof) {
+        s.prof[5] = hits;
+        const uint64_t t_end = __builtin_readcyclecounter();
+        s.prof[9] = t_end - t_item0;
+        s.prof[15] = t_end - t_epi0;
+        for (int i = 0; i < 16; ++i) item_prof[(size_t)out_slot * 16 + i] = s.prof[i];
+        if (hp.walls) {
+          unsigned long long* const wr = hp.walls + (size_t)out_slot * 8;
+          wr[0] = wall0;                 // the item's prologue begins (role chosen, plan records read)
+          wr[1] = wall_clock64();        // the item is done
+          wr[2] = my_item;
+          wr[3] = s.prof[0];             // windows walked here
+          wr[4] = wall_entry;            // this round began (a fresh workgroup: its first instruction)
+          // which CU: XCC_ID[3:0] | HW_ID's se_id[15:13], sh_id[12], cu_id[11:8]
+          wr[5] = ((unsigned long long)((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 8) |
+                  (unsigned long long)(((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 255u);
+          wr[6] = round;
+          wr[7] = blockIdx.x;
+        }
       }
     }
+    if (hp.persistent == 0u) return;
+    __syncthreads();   // (everybody has read what the next round's prologue rewrites)
   }
 }
 
@@ -1222,9 +1238,11 @@ void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool sh
                           unsigned long long* theta_g, uint32_t* slice_sum, uint32_t* q_prune, const DExchange* xch, uint64_t* item_keys,
                           uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof, const DHelp& help, const DHelp* help_d) {
   if (n_items == 0) return;
+  // persistent: one workgroup per CU, each choosing work until none is left; else one workgroup per item + the helpers behind them
+  const uint32_t grid = help.persistent ? std::min(n_items + help.n_help, std::max(help.n_cus, 1u)) : n_items + help.n_help;
   // (help: the host's copy of *help_d, the record the kernel reads; help.n_own == n_items; the helper workgroups are launched BEHIND the items: the dispatcher hands workgroups out in index order)
 #define NRT_MS_LAUNCH(P, K, S)                                                                                                      \
-  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(n_items + help.n_help), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
+  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(grid), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
                      caches, theta_g, slice_sum, q_prune, xch, item_keys, item_counts, item_hits, k_stride, item_prof, help_d)
 #define NRT_MS_LAUNCH_S(P, K)          \
   do {                                 \

@@ -235,10 +235,11 @@ struct DHelp {
   uint32_t min_rem;              // bits 0-15: an item with fewer unassigned windows is not joined; bit 16: A/B, greedy choice
   uint32_t total_wins;           // windows of all items (the launch's progress = windows handed out / this)
   uint32_t alpha16;              // critical path: help while items are queued when an item's time left > alpha16 / 16 x the launch's; 0: never
-  uint32_t n_cus, pad;
-  unsigned long long* walls;     // instrumented kernel only, else nullptr: per output slot {start, end} on the 100 MHz wall clock and
-                                 // {item, windows walked} -- when every workgroup of the launch ran, on one time base
-                                 // (nrtgpu_get_maxscore_item_walls: the makespan against the balanced load)
+  uint32_t n_cus;
+  uint32_t persistent;           // 1: the launch has one workgroup per CU and each chooses work until none is left (maxscore.hip)
+  unsigned long long* walls;     // instrumented kernel only, else nullptr: per output slot 8 words -- {start, end} on the 100 MHz
+                                 // wall clock, item, windows walked, when the workgroup's round began, CU id, round, workgroup --
+                                 // when every piece of the launch ran, on one time base (nrtgpu_get_maxscore_item_walls)
 };
 
 // Cross-GPU bound exchange of one batch (nrtgpu_exchange_open): entry (rank r, query q) of the batch's

@@ -298,10 +298,10 @@ extern "C" int nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out16) {
 extern "C" int64_t nrtgpu_get_maxscore_item_walls(nrtgpu_ctx* ctx, uint64_t* out, int64_t cap_slots, int64_t* n_items) {
   if (!ctx) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
-  const int64_t n = (int64_t)(ctx->last_walls.size() / 4);
+  const int64_t n = (int64_t)(ctx->last_walls.size() / 8);
   if (n_items) *n_items = ctx->last_walls_items;
   if (out)
-    for (int64_t i = 0; i < std::min(n, cap_slots) * 4; ++i) out[i] = ctx->last_walls[(size_t)i];
+    for (int64_t i = 0; i < std::min(n, cap_slots) * 8; ++i) out[i] = ctx->last_walls[(size_t)i];
   return n;
 }
 

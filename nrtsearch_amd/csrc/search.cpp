@@ -103,7 +103,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const int ablation = hp.clause_counting ? 8 : ((hp.masked && flag_variant == 0 && !(ctx->cfg.flags & NRTGPU_FLAG_NO_MASK_VARIANT)) ? 9 : flag_variant);
   const bool profile = flag_variant == 7;
   const size_t o_prof = wc.take((ablation == 7 || profile) ? n_slots * 128 : 0);
-  const size_t o_walls = wc.take(profile ? n_slots * 32 : 0);
+  const size_t o_walls = wc.take(profile ? n_slots * 64 : 0);
   if (int rc = slot->d_work.reserve(wc.off)) return rc;
   char* db = (char*)slot->d_plan.p;
   char* wb = (char*)slot->d_work.p;
@@ -126,6 +126,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     help.total_wins = (uint32_t)std::min<uint64_t>(wins, 0xFFFFFFFFull);
     help.alpha16 = (uint32_t)std::max(env_help_alpha, 0);
     help.n_cus = (uint32_t)std::max(ctx->n_cus, 1);
+    // NRTGPU_MS_PERSISTENT=0: one workgroup per item + helper workgroups behind them (A/B)
+    static const bool env_persistent = getenv("NRTGPU_MS_PERSISTENT") == nullptr || atoi(getenv("NRTGPU_MS_PERSISTENT")) != 0;
+    help.persistent = env_persistent ? 1u : 0u;
   }
   help.n_own = (uint32_t)hp.n_ms_items;
   help.n_help = (uint32_t)n_help;
@@ -153,7 +156,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   if (ctx->last_knn_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_knn_turn, 0));   // (vector searches do not queue behind each other, the scorers queue behind them)
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
   if (profile && n_help) HIP_TRY(hipMemsetAsync(wb + o_prof + n_items * 128, 0, n_help * 128, st));   // (a helper that leaves at once writes nothing)
-  if (profile) HIP_TRY(hipMemsetAsync(wb + o_walls, 0, n_slots * 32, st));
+  if (profile) HIP_TRY(hipMemsetAsync(wb + o_walls, 0, n_slots * 64, st));
   launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, hp.ms_shapes, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
                        (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
                        (uint32_t*)(wb + o_ssum), (uint32_t*)(wb + o_qprune), use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
@@ -323,7 +326,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     for (size_t i = 0; i < run.n_slots; ++i)   // (slots behind the items: helpers of the MaxScore route)
       for (int j = 0; j < 16; ++j) ((i < run.n_ms_items || i >= run.n_items) ? ctx->ms_prof : ctx->prof)[j] += (double)hp_prof[i * 16 + j];
     if (run.walls) {   // the last instrumented launch's workgroups in time (nrtgpu_get_maxscore_item_walls)
-      std::vector<uint64_t> w(run.n_slots * 4);
+      std::vector<uint64_t> w(run.n_slots * 8);
       (void)hipMemcpy(w.data(), run.walls, w.size() * 8, hipMemcpyDeviceToHost);
       ctx->last_walls.swap(w);
       ctx->last_walls_items = (int64_t)run.n_ms_items;

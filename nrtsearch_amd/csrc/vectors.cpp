@@ -528,6 +528,42 @@ static bool knn_co_compatible(const KnnCoRequest* a, const KnnCoRequest* b) {
   return !a->doc_bases || memcmp(a->doc_bases, b->doc_bases, (size_t)a->n_segs * 4) == 0;
 }
 
+// TotalHits.relation of an exact vector query by the reference's rule (include/nrtgpu.h): one collector per searcher slice
+// (MyIndexSearcher.java:163-208), each flips to GREATER_THAN_OR_EQUAL_TO once it has collected more than
+// max(totalHitsThreshold, numHits) hits with its queue full (LazyQueueTopScoreDocCollector.java:176-199).  A slice collects the
+// live docs of its leaves that carry a vector.  Host only.
+extern "C" int nrtgpu_knn_exact_relation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                         int32_t field_id, int32_t k, int32_t total_hits_threshold) {
+  if (!ctx || (n_segs > 0 && !segs) || n_segs < 0 || k <= 0 || total_hits_threshold < 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn_exact_relation arguments");
+  if (total_hits_threshold == INT32_MAX) return 0;   // ScoreMode.COMPLETE: the collector never publishes a min competitive score
+  std::vector<int64_t> live((size_t)std::max(n_segs, 1), 0);
+  std::vector<hostmath::LeafInfo> all((size_t)n_segs);
+  int32_t base = 0;
+  for (int32_t i = 0; i < n_segs; ++i) {
+    if (!segs[i] || !segs[i]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", i);
+    auto fit = segs[i]->fields.find(field_id);
+    if (fit != segs[i]->fields.end() && fit->second.d_vectors) live[(size_t)i] = live_vector_count(segs[i], fit->second);
+    all[(size_t)i] = {i, segs[i]->max_doc, segs[i]->max_doc - segs[i]->n_deleted, doc_bases ? doc_bases[i] : base};
+    base += segs[i]->max_doc;
+  }
+  const int64_t floor_ = (int64_t)std::max(total_hits_threshold, k);
+  if (ctx->slice_max_docs.load() <= 0 || n_segs == 0) {   // the whole search counts as one slice
+    int64_t sum = 0;
+    for (int64_t v : live) sum += v;
+    return sum > floor_ ? 1 : 0;
+  }
+  const int32_t vs = ctx->virtual_shards.load();
+  const std::vector<std::vector<int32_t>> sl = vs > 1
+      ? hostmath::slices_for_shards(all, vs, ctx->slice_max_docs.load(), ctx->slice_max_segments.load(), nullptr)
+      : hostmath::slices(all, ctx->slice_max_docs.load(), ctx->slice_max_segments.load(), all);
+  for (const std::vector<int32_t>& s_ : sl) {
+    int64_t sum = 0;
+    for (int32_t li : s_) sum += live[(size_t)li];
+    if (sum > floor_) return 1;
+  }
+  return 0;
+}
+
 void nrtgpu_debug_knn_coalescer_wake(nrtgpu_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->kco_mu);
   if (ctx->kco_leader) ctx->kco_leader->cv.notify_one();

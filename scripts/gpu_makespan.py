@@ -42,26 +42,42 @@ def main():
         st = ctx.stats()
         walls, n_items = ctx.maxscore_item_walls()
         used = walls[:, 1] > 0
-        t0 = int(walls[used, 0].min())
-        start = (walls[:, 0].astype(np.int64) - t0) / 100.0      # us
+        t0 = int(walls[used, 4].min())                           # the first workgroup's first instruction
+        start = (walls[:, 0].astype(np.int64) - t0) / 100.0      # us: the piece's prologue begins (role chosen)
         end = (walls[:, 1].astype(np.int64) - t0) / 100.0
+        entry = (walls[:, 4].astype(np.int64) - t0) / 100.0      # the workgroup's round begins
         busy = np.where(used, end - start, 0.0)
         owners = np.arange(len(walls)) < n_items
         span = float(end[used].max())
         balanced = float(busy.sum()) / args.cus
         h_used = used & ~owners
         fin = np.sort(end[used & owners])
+        # per CU: the idle time between one piece's end and the next one's start on the same CU (dispatch of a fresh workgroup, or
+        # a persistent workgroup's next round), and from a round's begin to its piece's start (choosing what to do)
+        gaps = []
+        cu = walls[:, 5]
+        for c in np.unique(cu[used]):
+            idx = np.where(used & (cu == c))[0]
+            idx = idx[np.argsort(start[idx])]
+            gaps.extend((start[idx[1:]] - end[idx[:-1]]).tolist())
+        gaps = np.asarray(gaps) if gaps else np.zeros(1)
+        choose = (start - entry)[used]
         rec = {
             "batch": bi, "maxscore_ms_hip_events": round(st["maxscore_ms"] / max(1, st["maxscore_launches"]), 3),
             "items": int(n_items), "helper_slots": int((~owners).sum()), "helper_sessions": int(h_used.sum()),
             "helper_windows": int(walls[h_used, 3].sum()), "owner_windows": int(walls[used & owners, 3].sum()),
             "span_us": round(span, 1), "balanced_us": round(balanced, 1), "makespan_over_balanced": round(span / balanced, 3),
+            "cus_seen": int(len(np.unique(cu[used]))), "workgroups": int(len(np.unique(walls[used, 7]))), "max_round": int(walls[used, 6].max()),
+            "gap_between_pieces_on_a_cu_us": {"n": int(len(gaps)), "mean": round(float(gaps.mean()), 1), "p50": round(float(np.median(gaps)), 1),
+                                              "p90": round(float(np.percentile(gaps, 90)), 1), "max": round(float(gaps.max()), 1),
+                                              "sum_over_cus": round(float(gaps.sum()) / args.cus, 1)},
+            "choosing_us": {"mean": round(float(choose.mean()), 2), "p90": round(float(np.percentile(choose, 90)), 2), "max": round(float(choose.max()), 2)},
             "owner_busy_us": {"mean": round(float(busy[owners].mean()), 1), "p50": round(float(np.median(busy[owners])), 1),
                               "p90": round(float(np.percentile(busy[owners], 90)), 1), "max": round(float(busy[owners].max()), 1)},
             "owner_finish_us_deciles": [round(float(x), 1) for x in np.percentile(fin, [10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 99, 100])],
             "helper_busy_us": ({"mean": round(float(busy[h_used].mean()), 1), "max": round(float(busy[h_used].max()), 1),
                                 "first_start_us": round(float(start[h_used].min()), 1)} if h_used.any() else None),
-            # CUs busy over time: how many workgroups are running at 10 points of the span
+            # CUs busy over time: how many pieces are running at 10 points of the span
             "running_at_tenths": [int(((start <= span * f / 10) & (end > span * f / 10) & used).sum()) for f in range(1, 10)],
         }
         print(json.dumps(rec), flush=True)

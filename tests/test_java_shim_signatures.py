@@ -156,6 +156,29 @@ def test_server_patch_applies_to_the_reference():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def test_server_patch_adds_no_method_the_reference_already_has():
+    """A patch that applies cleanly can still break the build: round 3's added getWrapped() to SearchCutoffWrapper and
+    SearchStatsWrapper, which both declare it already (duplicate method = compile error).  Every method a hunk ADDS must be new to
+    its file by (name, arity)."""
+    decl = re.compile(r"^\s*(?:public|protected|private)\s+(?:static\s+)?(?:<[^>]+>\s+)?[\w<>\[\], ?.]+?\s+(\w+)\s*\(")
+    for rel, lines in patch_additions().items():
+        ref = strip_comments(open(os.path.join(REF, rel)).read())
+        text = "\n".join(lines)
+        for i, line in enumerate(lines):
+            m = decl.match(line)
+            if not m or m.group(1) in ("if", "for", "while", "switch", "return", "new"):
+                continue
+            name = m.group(1)
+            joined = "\n".join(lines[i:])
+            args = call_args(joined, joined.index("(", joined.index(name)))
+            arity = len(split_top(args))
+            for m2 in re.finditer(r"[\w>\]]\s+%s\s*\(" % re.escape(name), ref):
+                a2 = call_args(ref, m2.end() - 1)
+                after = ref[m2.end() + len(a2): m2.end() + len(a2) + 40]
+                if re.match(r"\)\s*(throws [\w., ]+)?\s*\{", after):
+                    assert len(split_top(a2)) != arity, f"{rel}: the patch adds {name}/{arity}, which the reference already declares"
+
+
 def test_every_nrtsearch_type_constructor_and_method_the_shim_uses_exists():
     added = patch_additions()
     cache = {}
