@@ -162,6 +162,24 @@ __device__ __forceinline__ void collapse_to_rows(const uint32_t (&d)[NS], const 
   meta1 = om;
 }
 
+// The launch record's pointer, laundered: what is loaded through it from here on is loaded again (see the kernel's head).
+// (Through a vector register and back: an asm output counts as divergent, readfirstlane makes it a scalar again.)
+// The record is read through the CONSTANT address space (scalar loads); the pointers it holds are global memory and are cast so
+// where they are loaded (NRT_GLOBAL): a pointer that comes out of memory is a generic one to the compiler, and every access
+// through it a flat vector instruction.
+typedef const __attribute__((address_space(4))) MsArgs* ms_args_ptr;
+// "this pointer, which came out of memory, points to GLOBAL memory": through the global address space and back, so that the
+// compiler's address-space inference turns what is accessed through it into global_* instructions
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) { return (T*)(NRT_GLOBAL T*)p; }
+__device__ __forceinline__ ms_args_ptr ms_fresh(const MsArgs* p) {
+  uint32_t lo = (uint32_t)(uintptr_t)p, hi = (uint32_t)((uintptr_t)p >> 32);
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+  hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+  return (ms_args_ptr)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+}
+
 // All waves: keep the k best candidates, raise theta.  Contains barriers.
 // xch (multi-GPU, nrtgpu_exchange_open): the item also publishes a score that ceil(k / (world - 1)) of ITS docs reach -- for free
 // from the selection's histogram -- and bounds itself by the smallest entry of the OTHER ranks (bm25_common.hiph:
@@ -253,14 +271,13 @@ __device__ __forceinline__ bool ms_reserve(MsSmem& s, uint32_t lane, uint32_t mi
 //     doc to max(ub_c+1 ..) instead of their sum.
 template <bool PROF, bool PACKED, bool SHAPES>
 __global__ __launch_bounds__(kMsThreads)
-void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restrict__ parts, const DTerm* __restrict__ terms,
-                          const DQuery* __restrict__ queries,
-                          const float* __restrict__ caches, unsigned long long* __restrict__ theta_g,
-                          uint32_t* __restrict__ slice_sum, uint32_t* __restrict__ q_prune, const DExchange* __restrict__ xch,
-                          uint64_t* __restrict__ item_keys, uint32_t* __restrict__ item_counts,
-                          uint64_t* __restrict__ item_hits, uint32_t k_stride, uint64_t* __restrict__ item_prof, const DHelp* __restrict__ hpp) {
+void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
   __shared__ MsSmem s;
-  const DHelp& hp = *hpp;   // (resident next to the plan: its fields are scalar loads where they are used, not kernel arguments held in registers)
+  // The launch record (plan.h: MsArgs) lives next to the plan; ONE pointer is the kernel's argument.  Its fields are scalar loads
+  // made where they are used -- the workgroup's round, then once more in front of the item's epilogue (ms_fresh: the compiler
+  // cannot tell that the pointer it returns is the one it was given) -- instead of fifteen kernel arguments held in scalar registers from the first
+  // instruction to the last: the walk between prologue and epilogue sits on the register edge (168 VGPRs, SGPR spills go to
+  // VGPR lanes), and what only the epilogue needs has no business being live there.
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
   // ---- what does this workgroup do?  The launch has n_own + n_help workgroups and a QUEUE of n_own items in launch order
@@ -281,6 +298,12 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
   // workgroups at any time while items were still queued (profiles/r04_makespan_*.log: 215-235 of 256 running).
   for (uint32_t round = 0;; ++round) {
     const uint64_t wall_entry = PROF ? wall_clock64() : 0ull;
+    const ms_args_ptr ap = ms_fresh(launch);
+    const __attribute__((address_space(4))) DHelp& hp = ap->help;
+    const DItem* const items = as_global(ap->items);
+    const DPart* const parts = as_global(ap->parts);
+    const DTerm* const terms = as_global(ap->terms);
+    const DExchange* const xch = as_global(ap->xch);
     bool helper = false;
     uint32_t my_item = 0, out_slot = 0;
     {
@@ -375,10 +398,10 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     uint32_t first_win = 0;
     if (helper && lane == 0) first_win = __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const DItem item = items[my_item];
-    const DQuery q = queries[item.query];
+    const DQuery q = as_global(ap->queries)[item.query];
     const uint32_t k = q.k;
     const int fx_E = item.fx_E;
-    unsigned long long* const my_theta_g = theta_g + item.query;
+    unsigned long long* const my_theta_g = as_global(ap->theta_g) + item.query;
     const bool multi_item = q.n_items > 1 || hp.n_help != 0u;   // (theta_g is how owner and helpers share theta as well)
     // When may bounds skip work (plan.h: kMsMode*)?  Exact: never.  Count: once a slice has collected more than gte_floor hits --
     // until then every live matching doc is evaluated and counted, as the reference's collector does before it first
@@ -386,12 +409,13 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     const uint32_t mode = item.flags & 3u;
     const uint32_t msm = SHAPES ? q.min_should_match : 0u;   // (> 1: clause counting)
     const bool use_max = SHAPES && q.combine_max != 0u;       // DisjunctionMaxQuery
-    unsigned int* const my_prune_g = q_prune + item.query;    // set by the first item of the query whose slice passed the floor
+    unsigned int* const my_prune_g = as_global(ap->q_prune) + item.query;    // set by the first item of the query whose slice passed the floor
     const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
 
     // ---- item prologue: normInverse tables, score tables
     {
       const uint32_t n_lds = min(item.n_caches, (uint32_t)kLdsCaches) * 256u;
+      const float* const caches = as_global(ap->caches);
       for (uint32_t i = tid; i < n_lds; i += kMsThreads) (&s.cache[0][0])[i] = caches[item.cache_off + i];
     }
     if (tid == 0) {
@@ -1115,33 +1139,35 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
     }
     __syncthreads();
     const uint32_t n = s.cnt;
-    uint64_t* out = item_keys + (size_t)out_slot * k_stride;
+    const ms_args_ptr ape = ms_fresh(launch);   // (the epilogue's fields of the launch record: loaded here, not held through the walk)
+    const __attribute__((address_space(4))) DHelp& hpe = ape->help;
+    uint64_t* out = as_global(ape->item_keys) + (size_t)out_slot * ape->k_stride;
     for (uint32_t i = tid; i < n; i += kMsThreads) out[i] = s.cand[i];
     if (tid == 0) {
-      item_counts[out_slot] = n;
+      as_global(ape->item_counts)[out_slot] = n;
       if (helper) {   // my slot joins the query's list (merge_topk_kernel walks it behind the items' slots)
-        const uint32_t h = out_slot - hp.slot_base;
-        hp.help_next[h] = atomicExch(hp.help_head + item.query, h + 1u);
+        const uint32_t h = out_slot - hpe.slot_base;
+        as_global(hpe.help_next)[h] = atomicExch(as_global(hpe.help_head) + item.query, h + 1u);
       }
       // the item's hits, per slice into the query's sums (slice_relation_kernel) and in total
       uint32_t hits = 0;
       for (int i = 0; i < kSliceSlots; ++i) {
         const uint32_t h = s.slot_hits[i];
         hits += h;
-        if (h != 0u && q.gte_floor != 0xFFFFFFFFu) atomicAdd(&slice_sum[q.slice_base + s.slot_slice[i]], h);
+        if (h != 0u && q.gte_floor != 0xFFFFFFFFu) atomicAdd(as_global(ape->slice_sum) + q.slice_base + s.slot_slice[i], h);
       }
       // anything skipped?  Only a theta can skip, and only once the item may prune; with none the walk evaluated every live
       // matching doc exactly once.
       const bool pruned = s.prune_on != 0u && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
-      item_hits[out_slot] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
-      if (PROF && item_prof) {
+      as_global(ape->item_hits)[out_slot] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
+      if (PROF && ape->item_prof) {
         s.prof[5] = hits;
         const uint64_t t_end = __builtin_readcyclecounter();
         s.prof[9] = t_end - t_item0;
         s.prof[15] = t_end - t_epi0;
-        for (int i = 0; i < 16; ++i) item_prof[(size_t)out_slot * 16 + i] = s.prof[i];
-        if (hp.walls) {
-          unsigned long long* const wr = hp.walls + (size_t)out_slot * 8;
+        for (int i = 0; i < 16; ++i) as_global(ape->item_prof)[(size_t)out_slot * 16 + i] = s.prof[i];
+        if (hpe.walls) {
+          unsigned long long* const wr = as_global(hpe.walls) + (size_t)out_slot * 8;
           wr[0] = wall0;                 // the item's prologue begins (role chosen, plan records read)
           wr[1] = wall_clock64();        // the item is done
           wr[2] = my_item;
@@ -1155,7 +1181,7 @@ void bm25_maxscore_kernel(const DItem* __restrict__ items, const DPart* __restri
         }
       }
     }
-    if (hp.persistent == 0u) return;
+    if (hpe.persistent == 0u) return;
     __syncthreads();   // (everybody has read what the next round's prologue rewrites)
   }
 }
@@ -1233,17 +1259,13 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, uint32_t n_items, const DItem* items, const DPart* parts,
-                          const DTerm* terms, const DQuery* queries, const float* caches,
-                          unsigned long long* theta_g, uint32_t* slice_sum, uint32_t* q_prune, const DExchange* xch, uint64_t* item_keys,
-                          uint32_t* item_counts, uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof, const DHelp& help, const DHelp* help_d) {
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, const MsArgs& args, const MsArgs* args_d) {
+  const uint32_t n_items = args.help.n_own;
   if (n_items == 0) return;
+  // (args: the host's copy of *args_d, the record the kernel reads)
   // persistent: one workgroup per CU, each choosing work until none is left; else one workgroup per item + the helpers behind them
-  const uint32_t grid = help.persistent ? std::min(n_items + help.n_help, std::max(help.n_cus, 1u)) : n_items + help.n_help;
-  // (help: the host's copy of *help_d, the record the kernel reads; help.n_own == n_items; the helper workgroups are launched BEHIND the items: the dispatcher hands workgroups out in index order)
-#define NRT_MS_LAUNCH(P, K, S)                                                                                                      \
-  hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(grid), dim3(kMsThreads), 0, stream, items, parts, terms, queries, \
-                     caches, theta_g, slice_sum, q_prune, xch, item_keys, item_counts, item_hits, k_stride, item_prof, help_d)
+  const uint32_t grid = args.help.persistent ? std::min(n_items + args.help.n_help, std::max(args.help.n_cus, 1u)) : n_items + args.help.n_help;
+#define NRT_MS_LAUNCH(P, K, S) hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(grid), dim3(kMsThreads), 0, stream, args_d)
 #define NRT_MS_LAUNCH_S(P, K)          \
   do {                                 \
     if (shapes) NRT_MS_LAUNCH(P, K, true); \

@@ -242,6 +242,27 @@ struct DHelp {
                                  // when every piece of the launch ran, on one time base (nrtgpu_get_maxscore_item_walls)
 };
 
+// What one launch of bm25_maxscore_kernel works on: ONE record next to the plan, the kernel's only argument (maxscore.hip reads
+// its fields where it uses them).
+struct DExchange;
+struct MsArgs {
+  const DItem* items;            // [help.n_own] in launch order
+  const DPart* parts;
+  const DTerm* terms;
+  const DQuery* queries;
+  const float* caches;           // the queries' normInverse tables
+  unsigned long long* theta_g;   // per query: the best theta any of its items (or their helpers) has published
+  uint32_t* slice_sum;           // per (query, searcher slice): hits counted
+  uint32_t* q_prune;             // per query: a slice has passed the floor (kMsModeCount)
+  const DExchange* xch;          // cross-GPU bound exchange, or nullptr
+  uint64_t* item_keys;           // per output slot k_stride keys ...
+  uint32_t* item_counts;         // ... how many ...
+  uint64_t* item_hits;           // ... and the hits counted there
+  uint64_t* item_prof;           // instrumented kernel: 16 counters per output slot, else nullptr
+  uint32_t k_stride, pad;
+  DHelp help;
+};
+
 // Cross-GPU bound exchange of one batch (nrtgpu_exchange_open): entry (rank r, query q) of the batch's
 // slot holds (tag << 32) | score word that at least ceil(k / world) docs of rank r's shard reach.
 constexpr int kExchangeSlots = 8;

@@ -40,10 +40,7 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       unsigned long long* quant_g, const DExchange* xch, uint32_t* slice_sum, uint64_t* item_keys, uint32_t* item_counts,
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
-void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, uint32_t n_items, const DItem* items, const DPart* parts,
-                          const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
-                          uint32_t* slice_sum, uint32_t* q_prune, const DExchange* xch, uint64_t* item_keys, uint32_t* item_counts,
-                          uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof, const DHelp& help, const DHelp* help_d);
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, const MsArgs& args, const MsArgs* args_d);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
                           const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,

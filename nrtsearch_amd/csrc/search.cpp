@@ -44,7 +44,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_lower = pc.take(ext_hits ? hp.q_lower.size() * 8 : 0);  // device-resident results: certain lower bounds
   const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
   const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
-  const size_t o_help = pc.take(sizeof(DHelp));   // filled in below, once the workspace is carved
+  const size_t o_help = pc.take(sizeof(MsArgs));   // the MaxScore launch's record (plan.h); filled in below, once the workspace is carved
   const size_t plan_bytes = pc.off;
   if (int rc = slot->h_plan.reserve(plan_bytes)) return rc;
   if (int rc = slot->d_plan.reserve(plan_bytes)) return rc;
@@ -125,7 +125,12 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     for (size_t i = 0; i < hp.n_ms_items; ++i) wins += hp.items[i].flags >> 8;
     help.total_wins = (uint32_t)std::min<uint64_t>(wins, 0xFFFFFFFFull);
     help.alpha16 = (uint32_t)std::max(env_help_alpha, 0);
-    help.n_cus = (uint32_t)std::max(ctx->n_cus, 1);
+    // NRTGPU_MS_SPARE_CUS: CUs a persistent launch leaves alone.  A persistent workgroup holds its CU (all of the LDS, 504 of
+    // the 512 vector registers of every SIMD) until the launch ends, so nothing else runs there -- and the NEXT batch's plan
+    // expansion and the memsets in front of it, which used to slip in between two workgroups of this launch, would queue
+    // behind it instead of overlapping it.
+    static const int env_spare = getenv("NRTGPU_MS_SPARE_CUS") ? atoi(getenv("NRTGPU_MS_SPARE_CUS")) : 0;
+    help.n_cus = (uint32_t)std::max(ctx->n_cus - std::max(env_spare, 0), 1);
     // NRTGPU_MS_PERSISTENT=0: one workgroup per item + helper workgroups behind them (A/B)
     static const bool env_persistent = getenv("NRTGPU_MS_PERSISTENT") == nullptr || atoi(getenv("NRTGPU_MS_PERSISTENT")) != 0;
     help.persistent = env_persistent ? 1u : 0u;
@@ -136,7 +141,23 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   static const bool env_help_greedy = getenv("NRTGPU_MS_HELP_GREEDY") != nullptr && atoi(getenv("NRTGPU_MS_HELP_GREEDY")) != 0;
   help.min_rem = (uint32_t)std::min(std::max(env_help_min, 1), 0xFFFF) | (env_help_greedy ? 1u << 16 : 0u);
   help.walls = profile ? (unsigned long long*)(wb + o_walls) : nullptr;
-  memcpy(hb + o_help, &help, sizeof(help));   // (the kernel reads the record from the plan: maxscore.hip)
+  MsArgs ms_args{};   // (the kernel reads the record from the plan: maxscore.hip)
+  ms_args.items = (const DItem*)(db + o_items);
+  ms_args.parts = (const DPart*)(db + o_parts);
+  ms_args.terms = (const DTerm*)(wb + o_terms);
+  ms_args.queries = (const DQuery*)(db + o_queries);
+  ms_args.caches = (const float*)(db + o_caches);
+  ms_args.theta_g = (unsigned long long*)(db + o_theta);
+  ms_args.slice_sum = (uint32_t*)(wb + o_ssum);
+  ms_args.q_prune = (uint32_t*)(wb + o_qprune);
+  ms_args.xch = use_xch ? (const DExchange*)(db + o_xch) : nullptr;
+  ms_args.item_keys = (uint64_t*)(wb + o_ikeys);
+  ms_args.item_counts = (uint32_t*)(wb + o_icnt);
+  ms_args.item_hits = (uint64_t*)(wb + o_ihits);
+  ms_args.item_prof = profile ? (uint64_t*)(wb + o_prof) : nullptr;
+  ms_args.k_stride = hp.k_stride;
+  ms_args.help = help;
+  memcpy(hb + o_help, &ms_args, sizeof(ms_args));
 
   hipStream_t st = slot->stream;
   HIP_TRY(hipMemcpyAsync(db, hb, plan_bytes, hipMemcpyHostToDevice, st));
@@ -157,10 +178,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
   if (profile && n_help) HIP_TRY(hipMemsetAsync(wb + o_prof + n_items * 128, 0, n_help * 128, st));   // (a helper that leaves at once writes nothing)
   if (profile) HIP_TRY(hipMemsetAsync(wb + o_walls, 0, n_slots * 64, st));
-  launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, hp.ms_shapes, (uint32_t)n_ms, (const DItem*)(db + o_items), (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
-                       (const DQuery*)(db + o_queries), (const float*)(db + o_caches), (unsigned long long*)(db + o_theta),
-                       (uint32_t*)(wb + o_ssum), (uint32_t*)(wb + o_qprune), use_xch ? (const DExchange*)(db + o_xch) : nullptr, (uint64_t*)(wb + o_ikeys), (uint32_t*)(wb + o_icnt), (uint64_t*)(wb + o_ihits), hp.k_stride,
-                       profile ? (uint64_t*)(wb + o_prof) : nullptr, help, (const DHelp*)(db + o_help));
+  launch_bm25_maxscore(st, profile, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, hp.ms_shapes, ms_args, (const MsArgs*)(db + o_help));
   if (timing) HIP_TRY(hipEventRecord(slot->ev0, st));
   launch_bm25_scan(st, hp.fixed_point, (ctx->cfg.flags & NRTGPU_FLAG_NO_PREFETCH) == 0, (ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) != 0, ablation, (uint32_t)(n_items - n_ms),
                    (const DItem*)(db + o_items) + n_ms, (const DPart*)(db + o_parts), (const DTerm*)(wb + o_terms),
