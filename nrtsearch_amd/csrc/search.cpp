@@ -118,9 +118,11 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   help.help_used = (uint32_t*)(wb + o_hused);
   help.t_start = (unsigned long long*)(wb + o_hstart);
   {
-    // NRTGPU_MS_HELP_ALPHA (x 16; default 16 = 1.0; 0: helpers only once the queue is empty): while items are queued a workgroup
-    // helps an item whose expected time left exceeds alpha x what is left of the launch
-    static const int env_help_alpha = getenv("NRTGPU_MS_HELP_ALPHA") ? atoi(getenv("NRTGPU_MS_HELP_ALPHA")) : 16;
+    // NRTGPU_MS_HELP_ALPHA (x 16; 0: helpers only once the queue is empty): while items are queued a workgroup helps an item
+    // whose expected time left exceeds alpha x what is left of the launch.  Measured at 8 spare CUs (same log): alpha 0 2.48 ms
+    // per step, 1.0 2.50, 1.5 2.42, 2.0 2.42, 3.0 2.46 -- the estimate of what is left runs high early in the launch (the
+    // heavy items lead), so the bar sits above 1: 1.5 is the default.
+    static const int env_help_alpha = getenv("NRTGPU_MS_HELP_ALPHA") ? atoi(getenv("NRTGPU_MS_HELP_ALPHA")) : 24;
     uint64_t wins = 0;
     for (size_t i = 0; i < hp.n_ms_items; ++i) wins += hp.items[i].flags >> 8;
     help.total_wins = (uint32_t)std::min<uint64_t>(wins, 0xFFFFFFFFull);
@@ -129,7 +131,9 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     // the 512 vector registers of every SIMD) until the launch ends, so nothing else runs there -- and the NEXT batch's plan
     // expansion and the memsets in front of it, which used to slip in between two workgroups of this launch, would queue
     // behind it instead of overlapping it.
-    static const int env_spare = getenv("NRTGPU_MS_SPARE_CUS") ? atoi(getenv("NRTGPU_MS_SPARE_CUS")) : 0;
+    // Measured (profiles/r04_persistent_spare_ab.log, 1024 C3 queries per step): 0 spare CUs 2.85 ms per step (kernel 2.34), 4: 2.72,
+    // 8: 2.50 (kernel 2.39), 16: 2.56, 32: 2.70 -- eight CUs of 256 is the default.
+    static const int env_spare = getenv("NRTGPU_MS_SPARE_CUS") ? atoi(getenv("NRTGPU_MS_SPARE_CUS")) : 8;
     help.n_cus = (uint32_t)std::max(ctx->n_cus - std::max(env_spare, 0), 1);
     // NRTGPU_MS_PERSISTENT=0: one workgroup per item + helper workgroups behind them (A/B)
     static const bool env_persistent = getenv("NRTGPU_MS_PERSISTENT") == nullptr || atoi(getenv("NRTGPU_MS_PERSISTENT")) != 0;

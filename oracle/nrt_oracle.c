@@ -606,6 +606,102 @@ float nrt_oracle_vector_score(int32_t sim, const float* q, const float* v, int32
   return dot + 1.0f;
 }
 
+/* Summation orders of the three sums (dot / squareMagnitudes / squareDistance):
+ *   order 0  scalar, left to right, one accumulator, multiply and add rounded separately.  THE PINNED ORDER: what the device
+ *            returns bit for bit (tests/test_vectors_gpu.py) and what the d = 3 goldens of VectorFieldDefTest.java check (order
+ *            1 gives the same bits at d <= 32 -- Lucene's scalar code does not unroll there; order 2 may not: fused rounding).
+ *   order 1  [Lucene-recall] lucene-core 10.4.0's DefaultVectorUtilSupport (the non-Panama code a stock JVM runs without
+ *            --add-modules jdk.incubator.vector): for d > 32 four accumulators striding the dimension (dotProduct,
+ *            squareDistance: acc_j += a[i + j] * b[i + j], i += 4; res = acc1 + acc2 + acc3 + acc4, then the tail left to
+ *            right), two for cosine (sum, norm1, norm2 each as a pair); multiply-add as two roundings
+ *            (Constants.HAS_FAST_SCALAR_FMA false).
+ *   order 2  the same with every multiply-add fused (Math.fma: HAS_FAST_SCALAR_FMA true, what an x86-64 JVM with FMA3 picks).
+ * Orders 1 and 2 are restated from memory of the Lucene sources -- not in /root/reference, not runnable here (no JVM) -- and
+ * exist to BOUND what "the oracle's bits" can differ from Lucene's by: scripts/cpu_vector_order_study.py counts the rank and
+ * score differences between the three at the C4 shape.  Parity claims name order 0. */
+static inline float mul_add(int fused, float a, float b, float c) {
+  if (fused) return fmaf(a, b, c);
+  volatile float p = a * b;
+  return p + c;
+}
+
+float nrt_oracle_vector_score_order(int32_t order, int32_t sim, const float* q, const float* v, int32_t dim) {
+  if (order == 0) return nrt_oracle_vector_score(sim, q, v, dim);
+  const int fused = order == 2;
+  int i = 0;
+  if (sim == 2) { /* squareDistance: 4 accumulators */
+    float res = 0.0f;
+    if (dim > 32) {
+      float a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+      const int ub = dim & ~3;
+      for (; i < ub; i += 4) {
+        volatile float d1 = q[i] - v[i], d2 = q[i + 1] - v[i + 1], d3 = q[i + 2] - v[i + 2], d4 = q[i + 3] - v[i + 3];
+        a1 = mul_add(fused, d1, d1, a1);
+        a2 = mul_add(fused, d2, d2, a2);
+        a3 = mul_add(fused, d3, d3, a3);
+        a4 = mul_add(fused, d4, d4, a4);
+      }
+      volatile float t = a1 + a2;
+      t = t + a3;
+      t = t + a4;
+      res = res + t;
+    }
+    for (; i < dim; ++i) {
+      volatile float d = q[i] - v[i];
+      res = mul_add(fused, d, d, res);
+    }
+    return 1.0f / (1.0f + res);
+  }
+  float dot = 0.0f, nq = 0.0f, nv = 0.0f;
+  if (sim == 0) { /* cosine: pairs of accumulators */
+    if (dim > 32) {
+      float s1 = 0.f, s2 = 0.f, q1 = 0.f, q2 = 0.f, v1 = 0.f, v2 = 0.f;
+      const int ub = dim & ~1;
+      for (; i < ub; i += 2) {
+        s1 = mul_add(fused, q[i], v[i], s1);
+        q1 = mul_add(fused, q[i], q[i], q1);
+        v1 = mul_add(fused, v[i], v[i], v1);
+        s2 = mul_add(fused, q[i + 1], v[i + 1], s2);
+        q2 = mul_add(fused, q[i + 1], q[i + 1], q2);
+        v2 = mul_add(fused, v[i + 1], v[i + 1], v2);
+      }
+      volatile float ts = s1 + s2, tq = q1 + q2, tv = v1 + v2;
+      dot = dot + ts;
+      nq = nq + tq;
+      nv = nv + tv;
+    }
+    for (; i < dim; ++i) {
+      dot = mul_add(fused, q[i], v[i], dot);
+      nq = mul_add(fused, q[i], q[i], nq);
+      nv = mul_add(fused, v[i], v[i], nv);
+    }
+    const float c = (float)((double)dot / sqrt((double)nq * (double)nv));
+    const float s_ = (1.0f + c) / 2.0f;
+    return s_ > 0.0f ? s_ : 0.0f;
+  }
+  if (dim > 32) { /* dotProduct: 4 accumulators */
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    const int ub = dim & ~3;
+    for (; i < ub; i += 4) {
+      a1 = mul_add(fused, q[i], v[i], a1);
+      a2 = mul_add(fused, q[i + 1], v[i + 1], a2);
+      a3 = mul_add(fused, q[i + 2], v[i + 2], a3);
+      a4 = mul_add(fused, q[i + 3], v[i + 3], a4);
+    }
+    volatile float t = a1 + a2;
+    t = t + a3;
+    t = t + a4;
+    dot = dot + t;
+  }
+  for (; i < dim; ++i) dot = mul_add(fused, q[i], v[i], dot);
+  if (sim == 1) {
+    const float s_ = (1.0f + dot) / 2.0f;
+    return s_ > 0.0f ? s_ : 0.0f;
+  }
+  if (dot < 0.0f) return 1.0f / (1.0f - dot);
+  return dot + 1.0f;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Exact vector search: ExactVectorQuery scores EVERY doc that has a vector
  * (src/main/java/com/yelp/nrtsearch/server/query/vector/ExactVectorQuery.java:137-173, VectorValuesScorer.score() =
@@ -618,6 +714,13 @@ float nrt_oracle_vector_score(int32_t sim, const float* q, const float* v, int32
 void nrt_oracle_knn_exact(int32_t sim, const float* queries, int32_t n_q, const float* vecs, int64_t n, int32_t dim,
                           const uint64_t* live, int32_t doc_base, float boost, int32_t k, int32_t n_threads,
                           int32_t* out_docs, float* out_scores, int32_t* out_n) {
+  nrt_oracle_knn_exact_order(0, sim, queries, n_q, vecs, n, dim, live, doc_base, boost, k, n_threads, out_docs, out_scores, out_n);
+}
+
+/* (order: the summation order of nrt_oracle_vector_score_order) */
+void nrt_oracle_knn_exact_order(int32_t order, int32_t sim, const float* queries, int32_t n_q, const float* vecs, int64_t n, int32_t dim,
+                                const uint64_t* live, int32_t doc_base, float boost, int32_t k, int32_t n_threads,
+                                int32_t* out_docs, float* out_scores, int32_t* out_n) {
   if (n_threads < 1) n_threads = 1;
   /* rows are cut into blocks so that one query also scales over the threads; per (query, block) a sorted top-k, merged after */
   const int64_t block = 1 << 16;
@@ -636,7 +739,7 @@ void nrt_oracle_knn_exact(int32_t sim, const float* queries, int32_t n_q, const 
     const int64_t r1 = (b + 1) * block < n ? (b + 1) * block : n;
     for (int64_t r = b * block; r < r1; ++r) {
       if (live && !((live[r >> 6] >> (r & 63)) & 1ull)) continue;
-      const float sc = nrt_oracle_vector_score(sim, queries + (size_t)q * (size_t)dim, vecs + (size_t)r * (size_t)dim, dim) * boost;
+      const float sc = nrt_oracle_vector_score_order(order, sim, queries + (size_t)q * (size_t)dim, vecs + (size_t)r * (size_t)dim, dim) * boost;
       if (m == k && !(sc > s[k - 1])) continue; /* rows come in docid order: an equal score loses to the earlier doc */
       int32_t i = m < k ? m : k - 1;
       while (i > 0 && s[i - 1] < sc) {

@@ -129,6 +129,14 @@ void nrt_oracle_knn_exact(int32_t sim, const float* queries, int32_t n_q, const 
                           const uint64_t* live, int32_t doc_base, float boost, int32_t k, int32_t n_threads,
                           int32_t* out_docs, float* out_scores, int32_t* out_n);
 
+/* The same under another summation order of the similarity's sums (nrt_oracle.c: 0 = the pinned scalar left-to-right order,
+ * 1 / 2 = [Lucene-recall] DefaultVectorUtilSupport's unrolled accumulators without / with fused multiply-add): how far
+ * "the oracle's bits" can be from a given Lucene build's.  Test infrastructure for scripts/cpu_vector_order_study.py. */
+float nrt_oracle_vector_score_order(int32_t order, int32_t sim, const float* q, const float* v, int32_t dim);
+void nrt_oracle_knn_exact_order(int32_t order, int32_t sim, const float* queries, int32_t n_q, const float* vecs, int64_t n, int32_t dim,
+                                const uint64_t* live, int32_t doc_base, float boost, int32_t k, int32_t n_threads,
+                                int32_t* out_docs, float* out_scores, int32_t* out_n);
+
 /* QueryRescorer.combine as overridden by QueryRescore.java:40-45:
  * (float)(queryWeight * firstPass + rescoreWeight * secondPass), double arithmetic. */
 float nrt_oracle_rescore_combine(float first_pass, int32_t matched, float second_pass,

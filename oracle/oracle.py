@@ -138,10 +138,20 @@ def vector_score(sim: int, q: np.ndarray, v: np.ndarray) -> np.float32:
     return np.float32(lib().nrt_oracle_vector_score(int(sim), q.ctypes.data, v.ctypes.data, int(q.shape[0])))
 
 
+def vector_score_order(order: int, sim: int, q: np.ndarray, v: np.ndarray) -> np.float32:
+    """vector_score under summation order `order` (nrt_oracle.c: 0 pinned scalar; 1 / 2 [Lucene-recall] DefaultVectorUtilSupport)."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    L = lib()
+    L.nrt_oracle_vector_score_order.restype = C.c_float
+    L.nrt_oracle_vector_score_order.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    return np.float32(L.nrt_oracle_vector_score_order(int(order), int(sim), q.ctypes.data, v.ctypes.data, int(q.shape[0])))
+
+
 def knn_exact(sim: int, queries: np.ndarray, vecs: np.ndarray, k: int, live_words: Optional[np.ndarray] = None,
-              doc_base: int = 0, boost: float = 1.0, n_threads: int = 1):
+              doc_base: int = 0, boost: float = 1.0, n_threads: int = 1, order: int = 0):
     """ExactVectorQuery + top-k collector over one matrix of rows (row r = doc doc_base + r).
-    -> (docs [n_q, k] int32, scores [n_q, k] float32, n [n_q])."""
+    -> (docs [n_q, k] int32, scores [n_q, k] float32, n [n_q]).  order: the summation order (0 = the pinned one)."""
     queries = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
     vecs = np.ascontiguousarray(vecs, dtype=np.float32)
     n_q, dim = queries.shape
@@ -149,9 +159,12 @@ def knn_exact(sim: int, queries: np.ndarray, vecs: np.ndarray, k: int, live_word
     scores = np.zeros((n_q, k), dtype=np.float32)
     cnt = np.zeros(n_q, dtype=np.int32)
     lw = None if live_words is None else np.ascontiguousarray(live_words, dtype=np.uint64)
-    lib().nrt_oracle_knn_exact(int(sim), queries.ctypes.data, n_q, vecs.ctypes.data, int(vecs.shape[0]), int(dim),
-                               None if lw is None else lw.ctypes.data, int(doc_base), C.c_float(boost), int(k), int(n_threads),
-                               docs.ctypes.data, scores.ctypes.data, cnt.ctypes.data)
+    L = lib()
+    L.nrt_oracle_knn_exact_order.restype = None
+    L.nrt_oracle_knn_exact_order.argtypes = [C.c_int32] + list(L.nrt_oracle_knn_exact.argtypes)
+    L.nrt_oracle_knn_exact_order(int(order), int(sim), queries.ctypes.data, n_q, vecs.ctypes.data, int(vecs.shape[0]), int(dim),
+                                 None if lw is None else lw.ctypes.data, int(doc_base), C.c_float(boost), int(k), int(n_threads),
+                                 docs.ctypes.data, scores.ctypes.data, cnt.ctypes.data)
     return docs, scores, cnt
 
 

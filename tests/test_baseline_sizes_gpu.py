@@ -1,6 +1,7 @@
 """Parity at BASELINE.json's configuration sizes, run by the driver (`-m gpu`): C3 (10M docs, 5-term disjunction,
-top-1000; 256 queries, plain and with 1 % deletes), C2 (1M docs, 2-term, top-100; 256 queries), a C4-shaped exact kNN
-(2M x 768 fp32 cosine, top-100) against an fp64 reference with a real rank assertion, and the C5-shaped hybrid
+top-1000; 256 queries, plain and with 1 % deletes), C2 (1M docs, 2-term, top-100; 256 queries), C4 at its full size
+(10M x 768 fp32 cosine, top-100: fp64 over every row + the oracle's score bits of the hits) and at 2M rows (the oracle's own
+top-k bit for bit), and the C5-shaped hybrid
 (5M docs, BM25 recall-1000 -> 768-d cosine rescore -> top-100; 32 queries).  BM25: docids, ranks and score bits
 bit-exact against the CPU oracle's EXHAUSTIVE scorer (one C call, OpenMP over queries).  Needs an MI355X."""
 import os
@@ -127,6 +128,92 @@ def test_knn_c4_shape_against_fp64(oracle):
             hits.sort()
             assert got[qi].docs.tolist() == [d for _, d, _ in hits[:k]]
             assert got[qi].scores.view(np.uint32).tolist() == np.array([s for _, _, s in hits[:k]], np.float32).view(np.uint32).tolist()
+        assert ctx.stats()["knn_second_passes"] == 0
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()
+
+
+def _normal_chunk(seed, chunk, rows, dim):
+    """Chunk `chunk` of the C4 row matrix: Normal(0, 1) fp32 (SURVEY 8d's row distribution; the stream is PCG64 seeded per
+    chunk from `seed`, so any chunk can be generated again on its own -- the 30.7 GB matrix is never held on the host)."""
+    return np.random.Generator(np.random.PCG64([seed, chunk])).standard_normal((rows, dim), dtype=np.float32)
+
+
+def test_knn_c4_full_size_against_fp64(oracle):
+    """BASELINE config 4 at its FULL size in the driver-run suite: 10 M x 768 fp32 rows ~ Normal(0, 1)
+    in 4 segments, 40 queries (PCG64(778)), cosine top-100 through nrtgpu_knn_exact --
+      * against the fp64 cosine score of EVERY row (host, 16 threads, chunk by chunk as the rows are generated): scores within
+        2e-5 relative, a docid off its fp64 rank only among near-ties, the sets equal but for <= 2 docs per query;
+      * the score BITS of every returned hit against the oracle's pinned summation order (its rows generated again from their
+        chunk seeds), and the order (score desc, doc asc) -- what tests at 2 M rows check against the oracle's own top-k.
+    bench.py --workload C4 verifies the same on its device-generated rows; this one needs no torch."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, dim, k, nq, n_seg, chunk_rows = 10_000_000, 768, 100, 40, 4, 250_000
+    per = n // n_seg
+    queries = np.random.Generator(np.random.PCG64(778)).standard_normal((nq, dim), dtype=np.float32)
+    check_q = (0, 19, 39)
+    q64 = queries[list(check_q)].astype(np.float64)
+    qn = np.linalg.norm(q64, axis=1)
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves = []
+    cand = [[] for _ in check_q]     # per checked query: (fp64 score, docid) candidates of every chunk
+
+    def make(args):
+        seg_buf, c, a0, rows = args
+        blk = _normal_chunk(777, c, rows, dim)
+        seg_buf[a0: a0 + rows] = blk
+        b64 = blk.astype(np.float64)
+        cos = (b64 @ q64.T) / (np.linalg.norm(b64, axis=1)[:, None] * qn[None, :])
+        sc = np.maximum((1.0 + cos) / 2.0, 0.0)
+        out = []
+        for j in range(len(check_q)):
+            top = np.argpartition(-sc[:, j], 2 * k)[: 2 * k]
+            out.append((sc[top, j], top))
+        return c, out
+
+    try:
+        with ThreadPoolExecutor(max_workers=_cpus()) as ex:
+            for si in range(n_seg):
+                seg_buf = np.empty((per, dim), dtype=np.float32)
+                jobs = [(seg_buf, si * (per // chunk_rows) + ci, ci * chunk_rows, chunk_rows) for ci in range(per // chunk_rows)]
+                for c, out in ex.map(make, jobs):
+                    for j, (sc, idx) in enumerate(out):
+                        cand[j].append((sc, idx.astype(np.int64) + c * chunk_rows))
+                leaf = api.GpuSegment(ctx, per, si * per)
+                leaf.add_vectors(0, seg_buf)
+                leaf.seal()
+                leaves.append(leaf)
+                del seg_buf
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics())
+        got = sr.knn_exact(0, "cosine", queries, k)
+        for j, qi in enumerate(check_q):
+            cs = np.concatenate([c[0] for c in cand[j]])
+            cd = np.concatenate([c[1] for c in cand[j]])
+            order = np.lexsort((cd, -cs))[:k]
+            ref_s, ref_d = cs[order], cd[order]
+            score_of = dict(zip(cd.tolist(), cs.tolist()))
+            gd, gs = got[qi].docs, got[qi].scores
+            assert got[qi].total_hits == n and len(gd) == k and len(set(gd.tolist())) == k
+            assert np.allclose(gs, ref_s, rtol=2e-5, atol=2e-6)
+            for r in range(k):   # a docid that differs at its rank must be a near-tie of the reference's doc there
+                if gd[r] != ref_d[r]:
+                    assert int(gd[r]) in score_of and abs(score_of[int(gd[r])] - ref_s[r]) <= 2e-5 * ref_s[r] + 2e-6, f"query {qi} rank {r}"
+            assert len(set(gd.tolist()) & set(ref_d.tolist())) >= k - 2
+        # the returned hits' score bits in the oracle's pinned order; their order (score desc, doc asc)
+        need = {}
+        for qi in check_q:
+            for d in got[qi].docs.tolist():
+                need.setdefault(d // chunk_rows, set()).add(d)
+        with ThreadPoolExecutor(max_workers=_cpus()) as ex:
+            chunks = dict(zip(need, ex.map(lambda c: _normal_chunk(777, c, chunk_rows, dim), list(need))))
+        for qi in check_q:
+            gd, gs = got[qi].docs.tolist(), got[qi].scores
+            exp = np.array([oracle.vector_score(0, queries[qi], chunks[d // chunk_rows][d % chunk_rows]) for d in gd], dtype=np.float32)
+            assert gs.view(np.uint32).tolist() == exp.view(np.uint32).tolist(), f"query {qi}: score bits differ from the oracle's order"
+            keys = [(-float(s_), d) for s_, d in zip(gs, gd)]
+            assert keys == sorted(keys)
         assert ctx.stats()["knn_second_passes"] == 0
     finally:
         for l in leaves:

@@ -15,7 +15,14 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 # scratch bytes a kernel may use: nothing, except where the table of profiles/ already shows it and DESIGN names it
 KNOWN_SCRATCH = {
-    "bm25_maxscore_kernel<true, true, *>": 48,        # instrumented (NRTGPU_FLAG_PROFILE_ITEMS) over packed postings: measurement only
+    # The MaxScore kernel's workgroups are persistent since round 4 (one per CU, round after round): a handful of values that live
+    # from one round to the next (thread / wave ids, the launch record's pointer halves) are parked in scratch at the round's head
+    # and fetched in its epilogue -- NOT inside the walk, which test_the_maxscore_walk_touches_no_scratch pins.  Same box, same
+    # run: identical launch times with and without them (profiles/r04_persistent_spare_ab.log: "record" vs "kargs").
+    "bm25_maxscore_kernel<false, false, *>": 32,
+    "bm25_maxscore_kernel<false, true, *>": 80,       # packed postings
+    "bm25_maxscore_kernel<true, false, *>": 96,       # instrumented (NRTGPU_FLAG_PROFILE): measurement only
+    "bm25_maxscore_kernel<true, true, *>": 160,
     "bm25_scan_kernel<*, true, 7, false>": 16,        # instrumented scan: measurement only
     "bm25_scan_kernel<true, true, 8, false>": 16,     # clause counting on the exhaustive route (COMPLETE mode): 2 VGPRs, outside the loop
 }
@@ -69,11 +76,31 @@ def test_hot_kernels_keep_their_occupancy(kernels):
         if edge is None:
             continue
         assert r["vgpr"] + r["agpr"] <= edge, f"{name}: {r['vgpr']} + {r['agpr']} registers, designed for {edge}"
-    # the default BM25 route and the exact-kNN pass at up to 48 queries: not one byte of scratch
-    for name in ("bm25_maxscore_kernel<false, false, false>", "bm25_maxscore_kernel<false, true, false>", "bm25_maxscore_kernel<false, false, true>",
-                 "bm25_scan_kernel<true, true, 0, false>", "knn_sketch_kernel<1, 8>", "knn_sketch_kernel<2, 8>", "knn_sketch_kernel<3, 8>",
-                 "knn_select_kernel<true>"):
+    # the exhaustive BM25 route and the exact-kNN pass at every panel width: not one byte of scratch (the MaxScore kernel: its
+    # WALK has none -- test_the_maxscore_walk_touches_no_scratch)
+    for name in ("bm25_scan_kernel<true, true, 0, false>", "knn_sketch_kernel<1, 8>", "knn_sketch_kernel<2, 8>", "knn_sketch_kernel<3, 8>",
+                 "knn_sketch_kernel<4, 8>", "knn_select_kernel<true>"):
         assert kernels[name]["scratch"] == 0 and kernels[name]["vgpr_spills"] == 0, name
+
+
+def test_the_maxscore_walk_touches_no_scratch():
+    """Where the MaxScore kernel's scratch traffic is: at a round's head and in its epilogue (values that live from one round of
+    a persistent workgroup to the next).  The walk -- from the first streamed posting column load (16-byte non-temporal loads)
+    to the first workgroup barrier behind it (a candidate-buffer meeting): bounds, window bits, lookups in the later clauses --
+    must not hold a single scratch instruction, in any product instantiation."""
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("the built library or the LLVM binutils are not here")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    isa = mod.disassembly_of(LIB, only="bm25_maxscore_kernelILb0E")   # (the mangled name: PROF = false)
+    assert len(isa) == 4, sorted(isa)
+    for name, lines in isa.items():
+        first = next(i for i, l in enumerate(lines) if l.startswith("global_load_dwordx4") and " nt" in l)
+        barrier = next(i for i in range(first, len(lines)) if lines[i].startswith("s_barrier"))
+        assert barrier - first > 1500, f"{name}: the walk is {barrier - first} instructions?"
+        walk = lines[first:barrier]
+        assert not [l for l in walk if l.startswith("scratch_")], f"{name}: scratch traffic inside the walk"
 
 
 def test_the_committed_table_is_the_built_library(kernels):
