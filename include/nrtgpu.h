@@ -50,6 +50,7 @@ typedef struct nrtgpu_seg nrtgpu_seg;
 /* Limits of the device fast path (queries outside them get NRTGPU_ERR_UNSUPPORTED). */
 #define NRTGPU_MAX_K 1024          /* numHits handled by the LDS top-k */
 #define NRTGPU_MAX_TERMS 32        /* SHOULD clauses per query */
+#define NRTGPU_MAX_MASKS 8         /* FILTER (and, separately, MUST_NOT) clauses per query */
 #define NRTGPU_TILE_DOCS 1024      /* docs per wave-private LDS accumulator sub-tile */
 
 typedef struct {
@@ -103,7 +104,10 @@ int  nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id, const uin
 int  nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64_t n_terms, const int64_t* term_hash,
                               const int64_t* offsets, const int32_t* docids, const int32_t* freqs);
 /* float vectors of one field (leaf.getFloatVectorValues): n rows of `dim` fp32, row-major;
- * ord_to_doc NULL => ordinal == docid (dense). */
+ * ord_to_doc NULL => ordinal == docid (dense).  Any dim <= 2048 (more: NRTGPU_ERR_UNSUPPORTED, the field stays on the
+ * caller's path): rows are kept zero-padded to a multiple of 16 elements and query vectors are padded alike inside the
+ * search calls -- zeros add nothing to a dot product, a squared norm or a squared distance, so scores are the field's own
+ * (the reference's vector tests run at dim = 3: VectorFieldDefTest.java:1885-1965).  Queries pass the field's dim. */
 int  nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int32_t dim, int32_t n,
                                 const int32_t* ord_to_doc, const float* row_major);
 /* builds the per-term doc-range tables; the segment becomes searchable */
@@ -184,6 +188,12 @@ typedef struct {
                                     * fixed-point accumulators for the whole batch (else NRTGPU_ERR_UNSUPPORTED),
                                     * min_should_match <= 1; a tie breaker > 0 or disjuncts that are not term queries
                                     * stay on the caller's path; not accepted by nrtgpu_search_bm25_coalesced */
+  int32_t n_more_filters;          /* further FILTER clauses next to filter_mask (QueryNodeMapper.java:257-283 builds any number): */
+  const int32_t* more_filters;     /* ... resident mask ids > 0; a hit lies in ALL of the query's filter masks */
+  int32_t n_more_must_not;         /* further MUST_NOT clauses next to must_not_mask: */
+  const int32_t* more_must_not;    /* ... resident mask ids > 0; a hit lies in NONE of the query's must_not masks.  The masks are
+                                    * combined at plan time (one AND / AND NOT pass over 64-bit words per leaf and combination,
+                                    * cached on the segment like a single pair); n_more_* = 0: the arrays are not read */
 } nrtgpu_bm25_query;
 
 typedef struct {

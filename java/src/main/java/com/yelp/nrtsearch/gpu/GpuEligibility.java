@@ -32,8 +32,10 @@ import org.apache.lucene.search.similarities.Similarity;
 final class GpuEligibility {
   record Clause(Term term, float boost) {}
 
-  /** The flattened query: scoring clauses, minimumNumberShouldMatch, DisjunctionMaxQuery?, and the non-scoring clauses (null = none). */
-  record Shape(List<Clause> clauses, int minShouldMatch, int disjunctionMax, Query filter, Query mustNot) {}
+  /** The flattened query: scoring clauses, minimumNumberShouldMatch, DisjunctionMaxQuery?, and the non-scoring clauses -- any
+   *  number of FILTER and MUST_NOT clauses, each a resident mask of its own (cached per clause like LRUQueryCache caches its
+   *  DocIdSet); the library ANDs / AND-NOTs them at plan time (nrtgpu_bm25_query.more_filters / more_must_not). */
+  record Shape(List<Clause> clauses, int minShouldMatch, int disjunctionMax, List<Query> filters, List<Query> mustNots) {}
 
   /** The collector behind the manager handed to search(), the request's timeoutSec (0 = none) and the wrapper that enforces it
    *  on the reference's path (null = none): a timeout on the device route is reported THROUGH it (GpuIndexSearcher.timedOut). */
@@ -73,10 +75,10 @@ final class GpuEligibility {
         if (cl == null) return null;                                  // disjuncts that are not (boosted) term queries
         out.add(cl);
       }
-      return out.isEmpty() ? null : new Shape(out, 0, 1, null, null);
+      return out.isEmpty() ? null : new Shape(out, 0, 1, List.of(), List.of());
     }
     if (q instanceof BooleanQuery bq) {
-      Query filter = null, mustNot = null;
+      List<Query> filters = new ArrayList<>(), mustNots = new ArrayList<>();
       int must = 0;
       for (BooleanClause c : bq.clauses()) {
         switch (c.occur()) {
@@ -86,26 +88,23 @@ final class GpuEligibility {
             out.add(cl);
             if (c.occur() == BooleanClause.Occur.MUST) must++;
           }
-          case FILTER -> {                                             // one resident mask per kind; more: the caller's path
-            if (filter != null) return null;
-            filter = c.query();
-          }
-          case MUST_NOT -> {
-            if (mustNot != null) return null;
-            mustNot = c.query();
-          }
+          case FILTER -> filters.add(c.query());                       // one resident mask per clause
+          case MUST_NOT -> mustNots.add(c.query());
         }
       }
       if (out.isEmpty()) return null;                                 // filter-only queries score 0 for every match: Lucene's business
-      if (must != 0 && must != out.size()) return null;               // mixed MUST / SHOULD: a nested shape
+      if (filters.size() > NrtGpu.MAX_MASKS || mustNots.size() > NrtGpu.MAX_MASKS) return null;
+      // mixed MUST / SHOULD: ReqOptSumScorer adds (float) required + (float) optional -- two separately rounded sums, not the one
+      // exact sum the device holds per doc -- the caller's path
+      if (must != 0 && must != out.size()) return null;
       int msm = must != 0 ? out.size() : bq.getMinimumNumberShouldMatch();
-      if (filter != null && must == 0 && msm == 0) return null;       // SHOULD clauses next to a FILTER are optional: filter-only docs match with score 0
-      return new Shape(out, msm, 0, filter, mustNot);
+      if (!filters.isEmpty() && must == 0 && msm == 0) return null;   // SHOULD clauses next to a FILTER are optional: filter-only docs match with score 0
+      return new Shape(out, msm, 0, filters, mustNots);
     }
     Clause cl = term(q, 1f);
     if (cl == null) return null;
     out.add(cl);
-    return new Shape(out, 0, 0, null, null);
+    return new Shape(out, 0, 0, List.of(), List.of());
   }
 
   private static Clause term(Query q, float boost) {
@@ -143,7 +142,7 @@ final class GpuEligibility {
     return new Eligible(rc, timeoutSec, cutoffWrapper);
   }
 
-  static Plan marshal(Arena a, IndexSearcher searcher, GpuSegmentStore store, Shape shape, int filterMask, int mustNotMask,
+  static Plan marshal(Arena a, IndexSearcher searcher, GpuSegmentStore store, Shape shape, int[] filterMasks, int[] mustNotMasks,
       int k, int totalHitsThreshold, ScoreDoc after) throws IOException {
     List<Clause> clauses = shape.clauses();
     int msm = shape.minShouldMatch(), disjunctionMax = shape.disjunctionMax();
@@ -182,8 +181,20 @@ final class GpuEligibility {
     q.set(JAVA_INT, NrtGpuLayouts.QUERY_AFTER_DOC, after != null ? after.doc : 0);
     q.set(JAVA_FLOAT, NrtGpuLayouts.QUERY_AFTER_SCORE, after != null ? after.score : 0f);
     q.set(JAVA_INT, NrtGpuLayouts.QUERY_MIN_SHOULD_MATCH, msm);
-    q.set(JAVA_INT, NrtGpuLayouts.QUERY_FILTER_MASK, filterMask);
-    q.set(JAVA_INT, NrtGpuLayouts.QUERY_MUST_NOT_MASK, mustNotMask);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_FILTER_MASK, filterMasks.length > 0 ? filterMasks[0] : 0);
+    q.set(JAVA_INT, NrtGpuLayouts.QUERY_MUST_NOT_MASK, mustNotMasks.length > 0 ? mustNotMasks[0] : 0);
+    if (filterMasks.length > 1) {        // further FILTER clauses: the library ANDs the masks at plan time
+      MemorySegment more = a.allocate(JAVA_INT, filterMasks.length - 1);
+      for (int i = 1; i < filterMasks.length; i++) more.setAtIndex(JAVA_INT, i - 1, filterMasks[i]);
+      q.set(JAVA_INT, NrtGpuLayouts.QUERY_N_MORE_FILTERS, filterMasks.length - 1);
+      q.set(ADDRESS, NrtGpuLayouts.QUERY_MORE_FILTERS, more);
+    }
+    if (mustNotMasks.length > 1) {
+      MemorySegment more = a.allocate(JAVA_INT, mustNotMasks.length - 1);
+      for (int i = 1; i < mustNotMasks.length; i++) more.setAtIndex(JAVA_INT, i - 1, mustNotMasks[i]);
+      q.set(JAVA_INT, NrtGpuLayouts.QUERY_N_MORE_MUST_NOT, mustNotMasks.length - 1);
+      q.set(ADDRESS, NrtGpuLayouts.QUERY_MORE_MUST_NOT, more);
+    }
     q.set(JAVA_INT, NrtGpuLayouts.QUERY_DISJUNCTION_MAX, disjunctionMax);
     MemorySegment docs = a.allocate(JAVA_INT, k), scores = a.allocate(JAVA_FLOAT, k), out = a.allocate(NrtGpu.TOPDOCS);
     out.set(JAVA_INT, NrtGpuLayouts.TOPDOCS_CAPACITY, k);

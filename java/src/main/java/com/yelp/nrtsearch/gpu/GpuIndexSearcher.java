@@ -153,10 +153,12 @@ public class GpuIndexSearcher extends MyIndexSearcher {
         bases.setAtIndex(JAVA_INT, i, leaves.get(i).docBase);
       }
       // FILTER / MUST_NOT clauses next to the scoring ones: resident doc-set masks (nrtgpu_segment_set_mask)
-      int filterMask = shape.filter() == null ? 0 : masks.maskOf(this, store, leaves, shape.filter());
-      int mustNotMask = shape.mustNot() == null ? 0 : masks.maskOf(this, store, leaves, shape.mustNot());
-      if (filterMask < 0 || mustNotMask < 0) return super.search(query, manager);
-      GpuEligibility.Plan plan = GpuEligibility.marshal(a, this, store, shape, filterMask, mustNotMask, rc.getNumHitsToCollect(),
+      int[] filterMasks = new int[shape.filters().size()], mustNotMasks = new int[shape.mustNots().size()];
+      for (int i = 0; i < filterMasks.length; i++)
+        if ((filterMasks[i] = masks.maskOf(this, store, leaves, shape.filters().get(i))) < 0) return super.search(query, manager);
+      for (int i = 0; i < mustNotMasks.length; i++)
+        if ((mustNotMasks[i] = masks.maskOf(this, store, leaves, shape.mustNots().get(i))) < 0) return super.search(query, manager);
+      GpuEligibility.Plan plan = GpuEligibility.marshal(a, this, store, shape, filterMasks, mustNotMasks, rc.getNumHitsToCollect(),
           rc.getTotalHitsThreshold(), rc.getSearchAfter());
       if (plan == null) return super.search(query, manager);
       // timeoutSec of the request (DocCollector's SearchCutoffWrapper) -> the thread's deadline inside the library

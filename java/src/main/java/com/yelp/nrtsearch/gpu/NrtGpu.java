@@ -16,7 +16,7 @@ final class NrtGpu {
   private NrtGpu() {}
 
   static final int OK = 0, ERR_INVALID_ARG = -1, ERR_HIP = -2, ERR_OOM = -3, ERR_UNSUPPORTED = -4, ERR_STATE = -5, ERR_TIMEOUT = -6;
-  static final int MAX_K = 1024, MAX_TERMS = 32;
+  static final int MAX_K = 1024, MAX_TERMS = 32, MAX_MASKS = 8;
 
   private static final Linker L = Linker.nativeLinker();
   private static final SymbolLookup LIB =
@@ -30,24 +30,26 @@ final class NrtGpu {
   static final StructLayout TERM =
       MemoryLayout.structLayout(JAVA_INT.withName("field_id"), JAVA_INT.withName("cache_slot"), JAVA_LONG.withName("term_hash"),
           JAVA_FLOAT.withName("weight"), JAVA_FLOAT.withName("reserved"));
-  // nrtgpu_bm25_query, 72 bytes
+  // nrtgpu_bm25_query
   static final StructLayout QUERY =
       MemoryLayout.structLayout(JAVA_INT.withName("n_terms"), MemoryLayout.paddingLayout(4), ADDRESS.withName("terms"),
           JAVA_INT.withName("n_caches"), MemoryLayout.paddingLayout(4), ADDRESS.withName("norm_cache"), JAVA_INT.withName("k"),
           JAVA_INT.withName("total_hits_threshold"), JAVA_INT.withName("has_after"), JAVA_INT.withName("after_doc"),
           JAVA_FLOAT.withName("after_score"), JAVA_INT.withName("min_should_match"), JAVA_FLOAT.withName("min_competitive_score"),
-          JAVA_INT.withName("filter_mask"), JAVA_INT.withName("must_not_mask"), JAVA_INT.withName("disjunction_max"));
-  // nrtgpu_topdocs, 40 bytes
+          JAVA_INT.withName("filter_mask"), JAVA_INT.withName("must_not_mask"), JAVA_INT.withName("disjunction_max"),
+          JAVA_INT.withName("n_more_filters"), MemoryLayout.paddingLayout(4), ADDRESS.withName("more_filters"),
+          JAVA_INT.withName("n_more_must_not"), MemoryLayout.paddingLayout(4), ADDRESS.withName("more_must_not"));
+  // nrtgpu_topdocs
   static final StructLayout TOPDOCS =
       MemoryLayout.structLayout(JAVA_INT.withName("n_hits"), JAVA_INT.withName("capacity"), ADDRESS.withName("docs"),
           ADDRESS.withName("scores"), JAVA_LONG.withName("total_hits"), JAVA_INT.withName("total_hits_is_lower_bound"),
           MemoryLayout.paddingLayout(4));
-  // nrtgpu_config, 24 bytes
+  // nrtgpu_config
   static final StructLayout CONFIG =
       MemoryLayout.structLayout(JAVA_INT.withName("device_id"), JAVA_INT.withName("max_batch"), JAVA_INT.withName("target_items"),
           JAVA_INT.withName("collect_timing"), JAVA_INT.withName("flags"), JAVA_INT.withName("host_threads"));
 
-  // nrtgpu_diagnostics, 56 bytes
+  // nrtgpu_diagnostics
   static final StructLayout DIAGNOSTICS =
       MemoryLayout.structLayout(JAVA_DOUBLE.withName("total_ms"), JAVA_DOUBLE.withName("plan_ms"), JAVA_DOUBLE.withName("queue_ms"),
           JAVA_DOUBLE.withName("device_ms"), JAVA_LONG.withName("postings"), JAVA_INT.withName("queries"),

@@ -29,6 +29,7 @@ NRTGPU_FLAG_PACKED_POSTINGS = 32
 NRTGPU_FLAG_BLOCKING_WAIT = 64
 NRTGPU_FLAG_NO_VECTOR_SKETCH = 128
 NRTGPU_FLAG_PROFILE = 7 << 8
+NRTGPU_MAX_MASKS = 8
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
 ABI_SYMBOLS = [
@@ -64,7 +65,9 @@ class Bm25Query(C.Structure):
                 ("norm_cache", C.POINTER(C.c_float)), ("k", C.c_int32), ("total_hits_threshold", C.c_int32),
                 ("has_after", C.c_int32), ("after_doc", C.c_int32), ("after_score", C.c_float),
                 ("min_should_match", C.c_int32), ("min_competitive_score", C.c_float), ("filter_mask", C.c_int32),
-                ("must_not_mask", C.c_int32), ("disjunction_max", C.c_int32)]
+                ("must_not_mask", C.c_int32), ("disjunction_max", C.c_int32),
+                ("n_more_filters", C.c_int32), ("more_filters", C.POINTER(C.c_int32)),
+                ("n_more_must_not", C.c_int32), ("more_must_not", C.POINTER(C.c_int32))]
 
 
 class TopDocs(C.Structure):

@@ -358,14 +358,10 @@ def _unsupported(msg: str):
     raise UnsupportedQuery(msg)
 
 
-def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, int, int, int]:
+def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, List[int], List[int], int]:
     """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost)], msm,
-    filter mask id, must_not mask id (0 = none), disjunction_max (1: best clause instead of the sum)."""
-    r = _flatten_sum(query)
-    return r if len(r) == 5 else (*r, 0)
-
-
-def _flatten_sum(query: Query):
+    filter mask ids, must_not mask ids (any number of FILTER / MUST_NOT clauses: the library combines their masks at plan
+    time), disjunction_max (1: best clause instead of the sum)."""
     def one(q) -> Tuple[int, int, float]:
         if isinstance(q, TermQuery):
             return (q.field, q.term, 1.0)
@@ -375,42 +371,45 @@ def _flatten_sum(query: Query):
 
     def dismax(q: DisjunctionMaxQuery):
         if q.tie_breaker_multiplier != 0.0:
+            # (float)(scoreMax + otherScoreSum * tieBreaker) needs the best clause AND the sum of the others per doc: a second
+            # accumulator the kernel does not carry -- the caller's path
             raise UnsupportedQuery("DisjunctionMaxQuery with a tie breaker")
         if not q.disjuncts:
             raise UnsupportedQuery("empty DisjunctionMaxQuery")
         return [one(c) for c in q.disjuncts]
 
+    def masks(q: BooleanQuery) -> Tuple[List[int], List[int]]:
+        if any(not isinstance(c, MaskFilter) or c.mask_id <= 0 for c in q.filter + q.must_not):
+            raise UnsupportedQuery("FILTER / MUST_NOT clauses must be resident masks")
+        if len(q.filter) > _lib.NRTGPU_MAX_MASKS or len(q.must_not) > _lib.NRTGPU_MAX_MASKS:
+            raise UnsupportedQuery(f"more than {_lib.NRTGPU_MAX_MASKS} FILTER or MUST_NOT clauses")
+        return [c.mask_id for c in q.filter], [c.mask_id for c in q.must_not]
+
     if isinstance(query, DisjunctionMaxQuery):
-        return dismax(query), 0, 0, 0, 1
+        return dismax(query), 0, [], [], 1
     if isinstance(query, BooleanQuery) and len(query.must) == 1 and isinstance(query.must[0], DisjunctionMaxQuery):
         # "+dismax #filter -must_not": one scoring clause, the masks add nothing to the score
-        if query.should or len(query.filter) > 1 or len(query.must_not) > 1:
-            raise UnsupportedQuery("a DisjunctionMaxQuery next to SHOULD clauses / several masks")
-        if any(not isinstance(c, MaskFilter) or c.mask_id <= 0 for c in query.filter + query.must_not):
-            raise UnsupportedQuery("FILTER / MUST_NOT clauses must be resident masks")
-        return (dismax(query.must[0]), 0, query.filter[0].mask_id if query.filter else 0,
-                query.must_not[0].mask_id if query.must_not else 0, 1)
+        if query.should:
+            raise UnsupportedQuery("a DisjunctionMaxQuery next to SHOULD clauses")
+        f, mn = masks(query)
+        return dismax(query.must[0]), 0, f, mn, 1
     if isinstance(query, BooleanQuery):
+        f, mn = masks(query)
         if query.must:
             # a conjunction of term clauses matches the docs all of them match and sums all their scores
             # (ConjunctionScorer: double sum, one cast): the disjunction with minimumNumberShouldMatch = n
             if query.should:
+                # ReqOptSumScorer returns (float)required + (float)optional -- two separately rounded sums added in float
+                # [Lucene-recall] -- not the one exact sum the kernel's accumulator holds: the caller's path
                 raise UnsupportedQuery("MUST and SHOULD term clauses mixed")
-            return ([one(c) for c in query.must], len(query.must),
-                    query.filter[0].mask_id if query.filter else 0, query.must_not[0].mask_id if query.must_not else 0) \
-                if len(query.filter) <= 1 and len(query.must_not) <= 1 else _unsupported("more than one FILTER / MUST_NOT clause")
+            return [one(c) for c in query.must], len(query.must), f, mn, 0
         if not query.should:
             raise UnsupportedQuery("empty BooleanQuery")
-        if len(query.filter) > 1 or len(query.must_not) > 1:
-            raise UnsupportedQuery("more than one FILTER / MUST_NOT clause (combine them into one mask)")
         if query.filter and query.minimum_number_should_match < 1:
             # with a FILTER clause Lucene makes the SHOULD clauses optional: filter-only docs would be hits of score 0
             raise UnsupportedQuery("FILTER with minimumNumberShouldMatch = 0")
-        if any(not isinstance(c, MaskFilter) or c.mask_id <= 0 for c in query.filter + query.must_not):
-            raise UnsupportedQuery("FILTER / MUST_NOT clauses must be resident masks")
-        return ([one(c) for c in query.should], query.minimum_number_should_match,
-                query.filter[0].mask_id if query.filter else 0, query.must_not[0].mask_id if query.must_not else 0)
-    return [one(query)], 0, 0, 0
+        return [one(c) for c in query.should], query.minimum_number_should_match, f, mn, 0
+    return [one(query)], 0, [], [], 0
 
 
 class _Marshalled:
@@ -443,7 +442,7 @@ class GpuIndexSearcher:
     def _marshal(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> _Marshalled:
         m = _Marshalled(len(queries))
         for qi, (query, mgr) in enumerate(zip(queries, managers)):
-            clauses, msm, filter_mask, must_not_mask, dis_max = _flatten(query)
+            clauses, msm, filters, must_nots, dis_max = _flatten(query)
             fields: List[int] = []
             terms = (_lib.Term * len(clauses))()
             for ti, (field, term, boost) in enumerate(clauses):
@@ -469,9 +468,15 @@ class GpuIndexSearcher:
             q.after_score = float(mgr.after.score) if mgr.after is not None else 0.0
             q.min_should_match = int(msm)
             q.min_competitive_score = float(mgr.min_competitive_score)
-            q.filter_mask = int(filter_mask)
-            q.must_not_mask = int(must_not_mask)
+            q.filter_mask = int(filters[0]) if filters else 0
+            q.must_not_mask = int(must_nots[0]) if must_nots else 0
             q.disjunction_max = int(dis_max)
+            for ids, n_name, p_name in ((filters[1:], "n_more_filters", "more_filters"), (must_nots[1:], "n_more_must_not", "more_must_not")):
+                if ids:   # further FILTER / MUST_NOT clauses: the library ANDs / AND-NOTs their masks at plan time
+                    arr = (C.c_int32 * len(ids))(*[int(x) for x in ids])
+                    m.keep.append(arr)
+                    setattr(q, n_name, len(ids))
+                    setattr(q, p_name, arr)
         return m
 
     def search_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> List[TopDocs]:

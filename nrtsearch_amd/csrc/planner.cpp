@@ -27,6 +27,14 @@ int nrtgpu::rt::validate_query(const nrtgpu_bm25_query& q, int qi) {
   }
   if (!(q.min_competitive_score >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: min_competitive_score must be >= 0", qi);
   if (q.filter_mask < 0 || q.must_not_mask < 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: mask ids must be >= 0", qi);
+  if (q.n_more_filters < 0 || q.n_more_must_not < 0 || (q.n_more_filters > 0 && !q.more_filters) || (q.n_more_must_not > 0 && !q.more_must_not))
+    return fail(NRTGPU_ERR_INVALID_ARG, "query %d: more_filters / more_must_not", qi);
+  if (q.n_more_filters + (q.filter_mask != 0) > NRTGPU_MAX_MASKS || q.n_more_must_not + (q.must_not_mask != 0) > NRTGPU_MAX_MASKS)
+    return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: more than %d FILTER or MUST_NOT clauses", qi, NRTGPU_MAX_MASKS);
+  for (int i = 0; i < q.n_more_filters; ++i)
+    if (q.more_filters[i] <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: more_filters[%d] must be a mask id > 0", qi, i);
+  for (int i = 0; i < q.n_more_must_not; ++i)
+    if (q.more_must_not[i] <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: more_must_not[%d] must be a mask id > 0", qi, i);
   return 0;
 }
 
@@ -317,7 +325,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     int64_t lower = 0;
     uint8_t route = kRouteScan;
     if (prune != 0 && fx_ok && q.n_terms <= kMsMaxTerms && !(q.min_competitive_score > 0.0f)) {
-      const bool shaped = q.min_should_match > 1 || q.filter_mask != 0 || q.must_not_mask != 0;
+      const bool shaped = q.min_should_match > 1 || q.filter_mask != 0 || q.must_not_mask != 0 || q.n_more_filters != 0 || q.n_more_must_not != 0;
       if (q.total_hits_threshold == INT32_MAX) {
         int64_t all = 0;
         for (int t = 0; t < q.n_terms; ++t) all += term_total[(size_t)t];
@@ -542,7 +550,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   for (int qi = 0; qi < n_queries; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
     if (q.min_should_match > 1 || q.disjunction_max == 1) (on_ms_kernel((uint32_t)qi) ? hp.ms_shapes : hp.clause_counting) = true;
-    if ((q.filter_mask != 0 || q.must_not_mask != 0) && on_ms_kernel((uint32_t)qi)) hp.ms_shapes = true;
+    if ((q.filter_mask != 0 || q.must_not_mask != 0 || q.n_more_filters != 0 || q.n_more_must_not != 0) && on_ms_kernel((uint32_t)qi)) hp.ms_shapes = true;
   }
   hp.n_slices = (uint32_t)n_slices;
   if (hp.clause_counting && !hp.fixed_point)
@@ -608,7 +616,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
         if (cur.n_parts > 0 && sl != cur.last_slice && cur.n_slices == (uint32_t)kSliceSlots) close_item();  // no slot left for another slice
         const double tile_cost = (double)qs.postings / (double)seg->n_tiles + (double)kTileCostPostings;
         const uint64_t* accept = nullptr;  // liveDocs, narrowed by the query's FILTER / MUST_NOT masks
-        if (int rc = accept_set_of(seg, queries[qi].filter_mask, queries[qi].must_not_mask, &accept)) { cut_rc = rc; return; }
+        if (int rc = accept_set_of(seg, queries[qi], &accept)) { cut_rc = rc; return; }
         uint32_t tb = 0;
         while (tb < seg->n_tiles) {
           double room = budget - filled;

@@ -236,7 +236,9 @@ struct FieldData {
   float* d_vnorm2 = nullptr;            // |v|^2 per row (cosine / euclidean)
   int32_t* d_ord_to_doc = nullptr;
   std::vector<int32_t> h_ord_to_doc;     // host copy: docid -> row lookups of the rescore path
-  int32_t dim = 0, n_vec = 0;
+  int32_t dim = 0, n_vec = 0;   // dim: the rows' dimension AS RESIDENT -- the field's own (dim_user) rounded up to a multiple of 16,
+                                // the extra elements zero (they add nothing to any of the four similarities' sums)
+  int32_t dim_user = 0;
   float vnorm2_max = 0.f;                // largest |v|^2 of the rows
   void* d_sketch = nullptr;              // the rows in fp16, matrix-core operand order (knn.hip); nullptr: none (yet)
   int sketch_state = -1;                 // 0: to be built by the first exact search over the field (segment.cpp: ensure_vector_sketch), 1: built, -1: never
@@ -312,7 +314,7 @@ struct nrtgpu_seg {
   void content_unlock_shared() const;       // may free the handle (content_released)
   std::map<int32_t, std::vector<uint64_t>> masks;
   mutable std::mutex accept_mu;
-  mutable std::map<std::pair<int32_t, int32_t>, uint64_t*> accept;
+  mutable std::map<std::vector<int32_t>, uint64_t*> accept;   // key: the filter mask ids ascending, 0, the must_not mask ids ascending
 };
 
 // Exclusive ownership of a segment's content (liveDocs, masks, the posting columns' liveness coding).
@@ -530,6 +532,7 @@ void release_slot(nrtgpu_ctx* ctx, Slot* s);
 // The doc set a query's hits must lie in: liveDocs & FILTER mask & ~MUST_NOT mask, resident in HBM
 // ((0, 0): liveDocs itself, or nullptr once they are folded into the posting columns).
 int accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out);
+int accept_set_of(const nrtgpu_seg* seg, const nrtgpu_bm25_query& q, const uint64_t** out);   // all of the query's FILTER / MUST_NOT masks
 // vectors of the field whose doc is live (the hits of an exact vector query over the segment)
 int64_t live_vector_count(const nrtgpu_seg* seg, const FieldData& f);
 int ensure_vector_sketch(const nrtgpu_seg* seg, int32_t field_id);
@@ -547,6 +550,15 @@ int merge_lists_on_device(nrtgpu_ctx* ctx, Slot* slot, int32_t n_lists, int32_t 
                           const void* g_counts, const void* g_hits, const int32_t* ks, void* d_keys, void* d_counts, void* d_hits);
 // The vector rescorer over device-resident first-pass lists (hybrid_rescore_kernel), enqueued on `slot`'s stream: uploads the leaf
 // table and the query vectors into the slot's aux buffers; windows -> d_win_keys (n_queries x w_stride), d_win_counts.
+// Query vectors of `dim_user` elements as the resident rows want them: padded with zeros to the field's resident dimension
+// (FieldData.dim).  p == the caller's array when nothing had to be padded.
+struct PaddedQueries {
+  std::vector<float> buf;
+  const float* p = nullptr;
+  int32_t dim = 0;
+};
+int pad_query_vectors(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field_id, const float* queries, int32_t n, int32_t dim_user,
+                      PaddedQueries* out);
 int hybrid_tail_on_device(nrtgpu_ctx* ctx, Slot* slot, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                           int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost, double qw, double rw,
                           int32_t window, int32_t n_queries, const void* d_first_keys, const void* d_first_counts, int32_t k_stride,

@@ -384,7 +384,7 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   const double plan_ms = now_ms() - t0;
   for (int si = 0; si < n_segs; ++si) {
     auto fit = segs[si]->fields.find(field_id);
-    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim_user != dim)
       return fail(NRTGPU_ERR_INVALID_ARG, "vector dimension mismatch");
   }
   Slot* slot = nullptr;
@@ -467,6 +467,10 @@ int nrtgpu::rt::hybrid_tail_on_device(nrtgpu_ctx* ctx, Slot* slot, const nrtgpu_
                                       int32_t window, int32_t n_queries, const void* d_first_keys, const void* d_first_counts,
                                       int32_t k_stride, int32_t drop_foreign, void* d_win_keys, void* d_win_counts, uint32_t w_stride) {
   const size_t nq = (size_t)n_queries;
+  PaddedQueries padded;   // (rows are resident padded to a multiple of 16 elements: the queries likewise)
+  if (int rc = pad_query_vectors(segs, n_segs, field_id, query_vectors, n_queries, dim, &padded)) return rc;
+  query_vectors = padded.p;
+  dim = padded.dim;
   Carver ac;
   const size_t o_segs = ac.take((size_t)std::max(n_segs, 1) * sizeof(DVecSeg)), o_qv = ac.take(nq * (size_t)dim * 4), o_qn = ac.take(nq * 4);
   if (int rc = slot->d_aux.reserve(ac.off)) return rc;

@@ -225,13 +225,24 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
   HIP_TRY(hipSetDevice(seg->ctx->device));
   FieldData& f = seg->fields[field_id];
   if (f.d_vectors) return fail(NRTGPU_ERR_STATE, "vectors of field %d already added", field_id);
+  // Resident rows are a multiple of 16 elements long (the matrix-core kernels' pieces): a field of another dimension is padded
+  // with zeros, which change none of the sums (x + 0 * 0 = x, (q - v)^2 = 0 for a zero pair) -- results are the field's own.
+  const int32_t dim_user = dim;
+  dim = (dim + 15) & ~15;
+  if (dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path takes <= 2048)", dim_user);
   f.dim = dim;
+  f.dim_user = dim_user;
   f.n_vec = n;
   if (n == 0) return NRTGPU_OK;
   void* p = nullptr;
   if (int rc = dev_alloc(seg, &p, (size_t)n * dim * 4 + 256)) return rc;
   f.d_vectors = (float*)p;
-  HIP_TRY(hipMemcpy(f.d_vectors, row_major, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+  if (dim == dim_user) {
+    HIP_TRY(hipMemcpy(f.d_vectors, row_major, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemset(f.d_vectors, 0, (size_t)n * dim * 4));
+    HIP_TRY(hipMemcpy2D(f.d_vectors, (size_t)dim * 4, row_major, (size_t)dim_user * 4, (size_t)dim_user * 4, (size_t)n, hipMemcpyHostToDevice));
+  }
   if (int rc = dev_alloc(seg, &p, (size_t)n * 4 + 64)) return rc;
   f.d_vnorm2 = (float*)p;
   launch_knn_row_norms(nullptr, f.d_vectors, dim, n, f.d_vnorm2);
@@ -536,13 +547,24 @@ extern "C" int nrtgpu_segment_set_mask(nrtgpu_seg* seg, int32_t mask_id, const u
 // The doc set a query's hits must lie in: liveDocs & FILTER mask & ~MUST_NOT mask, resident in HBM.
 // (0, 0) is liveDocs itself.  Built and uploaded on first use, then shared by every query that names
 // the same pair (the role LRUQueryCache plays for Lucene's non-scoring clauses).
-int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out) {
-  if (filter_mask == 0 && must_not_mask == 0) {
+// The doc set a query's hits must lie in on this leaf: liveDocs AND every FILTER mask AND NOT any MUST_NOT mask (nullptr: every
+// doc, or liveDocs folded into the postings).  Combined on the host -- one pass over 64-bit words -- the first time a combination
+// is asked for, resident from then on (until liveDocs or a mask change).
+static int accept_set_of_ids(const nrtgpu_seg* seg, std::vector<int32_t> filters, std::vector<int32_t> must_nots, const uint64_t** out) {
+  auto canon = [](std::vector<int32_t>& v) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  };
+  canon(filters);
+  canon(must_nots);
+  if (filters.empty() && must_nots.empty()) {
     *out = seg->live_folded ? nullptr : seg->d_live;
     return 0;
   }
+  std::vector<int32_t> key(filters);
+  key.push_back(0);
+  key.insert(key.end(), must_nots.begin(), must_nots.end());
   std::lock_guard<std::mutex> lk(seg->accept_mu);
-  const auto key = std::make_pair(filter_mask, must_not_mask);
   auto it = seg->accept.find(key);
   if (it != seg->accept.end()) {
     *out = it->second;
@@ -553,24 +575,23 @@ int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_
   // or a mask change (which drops every set).
   if (seg->accept.size() >= kMaxAcceptSets)
     return fail(NRTGPU_ERR_UNSUPPORTED, "%zu combined doc sets are resident on a segment already", seg->accept.size());
-  const std::vector<uint64_t>* f = nullptr;
-  const std::vector<uint64_t>* mn = nullptr;
-  if (filter_mask) {
-    auto m = seg->masks.find(filter_mask);
-    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "filter mask %d is not resident on a segment", filter_mask);
-    f = &m->second;
+  std::vector<const std::vector<uint64_t>*> f, mn;
+  for (int32_t id : filters) {
+    auto m = seg->masks.find(id);
+    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "filter mask %d is not resident on a segment", id);
+    f.push_back(&m->second);
   }
-  if (must_not_mask) {
-    auto m = seg->masks.find(must_not_mask);
-    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "must_not mask %d is not resident on a segment", must_not_mask);
-    mn = &m->second;
+  for (int32_t id : must_nots) {
+    auto m = seg->masks.find(id);
+    if (m == seg->masks.end()) return fail(NRTGPU_ERR_UNSUPPORTED, "must_not mask %d is not resident on a segment", id);
+    mn.push_back(&m->second);
   }
   const size_t need = (size_t)(seg->max_doc + 63) / 64;
   std::vector<uint64_t> w(need + kMaskPadBytes / 8, 0ull);  // padded like liveDocs
   for (size_t i = 0; i < need; ++i) {
     uint64_t v = seg->h_live.empty() ? ~0ull : seg->h_live[i];
-    if (f) v &= (*f)[i];
-    if (mn) v &= ~(*mn)[i];
+    for (const std::vector<uint64_t>* m : f) v &= (*m)[i];
+    for (const std::vector<uint64_t>* m : mn) v &= ~(*m)[i];
     w[i] = v;
   }
   void* p = nullptr;
@@ -584,6 +605,22 @@ int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_
   seg->accept[key] = (uint64_t*)p;
   *out = (uint64_t*)p;
   return 0;
+}
+
+int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, int32_t filter_mask, int32_t must_not_mask, const uint64_t** out) {
+  std::vector<int32_t> f, mn;
+  if (filter_mask) f.push_back(filter_mask);
+  if (must_not_mask) mn.push_back(must_not_mask);
+  return accept_set_of_ids(seg, std::move(f), std::move(mn), out);
+}
+
+int nrtgpu::rt::accept_set_of(const nrtgpu_seg* seg, const nrtgpu_bm25_query& q, const uint64_t** out) {
+  std::vector<int32_t> f, mn;
+  if (q.filter_mask) f.push_back(q.filter_mask);
+  if (q.must_not_mask) mn.push_back(q.must_not_mask);
+  for (int i = 0; i < q.n_more_filters; ++i) f.push_back(q.more_filters[i]);
+  for (int i = 0; i < q.n_more_must_not; ++i) mn.push_back(q.more_must_not[i]);
+  return accept_set_of_ids(seg, std::move(f), std::move(mn), out);
 }
 
 int64_t nrtgpu::rt::live_vector_count(const nrtgpu_seg* seg, const FieldData& f) {

@@ -11,6 +11,28 @@ static const int kKnnMaxQ = 64;   // queries per pass over the rows: two panels 
 // matches, boost inside the score).  knn_request = true: the `knn` request path -- pre-filter mask, score
 // threshold on the unboosted score (MinThresholdQuery's MinScoreWrapper), boost applied afterwards,
 // totalHits = the docs returned.
+int nrtgpu::rt::pad_query_vectors(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field_id, const float* queries, int32_t n,
+                                  int32_t dim_user, PaddedQueries* out) {
+  int32_t dim_dev = (dim_user + 15) & ~15;
+  for (int si = 0; si < n_segs; ++si) {
+    if (!segs[si]) continue;
+    auto fit = segs[si]->fields.find(field_id);
+    if (fit == segs[si]->fields.end() || !fit->second.d_vectors) continue;
+    if (fit->second.dim_user != dim_user)
+      return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim_user, dim_user);
+    dim_dev = fit->second.dim;
+  }
+  out->dim = dim_dev;
+  if (dim_dev == dim_user) {
+    out->p = queries;
+    return NRTGPU_OK;
+  }
+  out->buf.assign((size_t)n * (size_t)dim_dev, 0.0f);
+  for (int32_t q = 0; q < n; ++q) memcpy(out->buf.data() + (size_t)q * dim_dev, queries + (size_t)q * dim_user, (size_t)dim_user * 4);
+  out->p = out->buf.data();
+  return NRTGPU_OK;
+}
+
 static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                     int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
                     int32_t k, float boost, bool knn_request, int32_t filter_mask, float min_score, nrtgpu_topdocs* out,
@@ -20,18 +42,19 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   if (!ctx || !queries || (!out && !ext_keys) || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || k <= 0 || dim <= 0 || sim < 0 || sim > 3) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
-  if (dim % 16 != 0 || dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 2048)", dim);
+  if (dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path takes <= 2048)", dim);
   NRT_CHECK_DEADLINE("before the vector search started");
   HIP_TRY(hipSetDevice(ctx->device));
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
   SegReadLocks content(segs, n_segs);  // liveDocs / masks stay as they are until the kernels have finished
-  for (int si = 0; si < n_segs; ++si) {
+  for (int si = 0; si < n_segs; ++si)
     if (!segs[si] || !segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
-    auto fit = segs[si]->fields.find(field_id);
-    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
-      return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim, dim);
-  }
+  // from here on `dim` is the RESIDENT dimension (a multiple of 16) and the queries are padded like the rows
+  PaddedQueries padded;
+  if (int rc = pad_query_vectors(segs, n_segs, field_id, queries, n_queries, dim, &padded)) return rc;
+  queries = padded.p;
+  dim = padded.dim;
   for (int si = 0; si < n_segs; ++si)   // the fp16 sketches this search nominates from: built on a field's first exact search
     if (int rc = ensure_vector_sketch(segs[si], field_id)) return rc;
   const uint32_t k_stride = round_up((uint32_t)k, 16);
@@ -580,12 +603,12 @@ extern "C" int nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   // (what would fail the panel must fail this request alone)
   if (k <= 0 || dim <= 0 || sim < 0 || sim > 3 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn arguments");
   if (k > NRTGPU_MAX_K) return fail(NRTGPU_ERR_UNSUPPORTED, "k %d > %d", k, NRTGPU_MAX_K);
-  if (dim % 16 != 0 || dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path needs a multiple of 16, <= 2048)", dim);
+  if (dim > 2048) return fail(NRTGPU_ERR_UNSUPPORTED, "vector dimension %d (device path takes <= 2048)", dim);
   for (int si = 0; si < n_segs; ++si) {
     if (!segs[si] || !segs[si]->sealed) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", si);
     auto fit = segs[si]->fields.find(field_id);
-    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim != dim)
-      return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim, dim);
+    if (fit != segs[si]->fields.end() && fit->second.d_vectors && fit->second.dim_user != dim)
+      return fail(NRTGPU_ERR_INVALID_ARG, "segment %d: field %d has dimension %d, query has %d", si, field_id, fit->second.dim_user, dim);
   }
   NRT_CHECK_DEADLINE("before the request was queued");
   KnnCoRequest me{segs, doc_bases, n_segs, field_id, sim, dim, k, boost, query, out};
@@ -701,6 +724,10 @@ extern "C" int nrtgpu_rescore_vectors(nrtgpu_ctx* ctx, const nrtgpu_seg* const* 
     return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n < 0 || dim <= 0 || sim < 0 || sim > 3 || window <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad rescore arguments");
   HIP_TRY(hipSetDevice(ctx->device));
+  PaddedQueries padded;   // (rows are resident padded to a multiple of 16 elements: the query likewise)
+  if (int rc = pad_query_vectors(segs, n_segs, field_id, query, 1, dim, &padded)) return rc;
+  query = padded.p;
+  dim = padded.dim;
   float qn = 0.f;
   for (int d = 0; d < dim; ++d) {
     volatile float p2 = query[d] * query[d];

@@ -78,6 +78,69 @@ def test_filter_and_must_not_masks(ctx, deletes):
         ix.close()
 
 
+def test_several_filter_and_must_not_clauses(ctx):
+    """Any number of FILTER / MUST_NOT clauses (QueryNodeMapper.java:257-283 builds what the request holds): every clause is a
+    resident mask of its own, the library ANDs / AND-NOTs them at plan time (nrtgpu_bm25_query.more_filters / more_must_not).
+    Against the oracle with the combined accept set; on the pruned route; the combination is cached per leaf; in a batch next to
+    single-mask and unmasked queries; the coalesced single-query entry takes them too."""
+    ranks = [1, 2, 4, 9, 30, 120, 700, 4000]
+    corpus = synth.build_corpus(200_000, ranks, n_segments=3, delete_fraction=0.02)
+    ix = Index(ctx, corpus)
+    try:
+        masks = {}
+        spec = {3: 0.6, 4: 0.5, 5: 0.7, 6: 0.04, 7: 0.02, 8: 0.10}
+        for si, (seg, leaf) in enumerate(zip(corpus.segments, ix.leaves)):
+            for mid, frac in spec.items():
+                masks[(si, mid)] = random_mask(seg.max_doc, frac, 1000 * mid + si)
+                leaf.set_mask(mid, masks[(si, mid)])
+        should = tuple(api.TermQuery(0, r) for r in (2, 30, 700))
+        terms = [2, 30, 700]
+
+        def acc_of(f, mn):
+            out = []
+            for si, seg in enumerate(corpus.segments):
+                n = (seg.max_doc + 63) // 64
+                a = np.full(n, ~np.uint64(0), dtype=np.uint64) if seg.live_bits is None else seg.live_bits[:n].copy()
+                for i in f:
+                    a &= masks[(si, i)][:n]
+                for i in mn:
+                    a &= ~masks[(si, i)][:n]
+                out.append(a)
+            return out
+
+        cases = [((3, 4), ()), ((3, 4, 5), (6,)), ((), (6, 7, 8)), ((4,), (6, 7)), ((3, 4, 5), (6, 7, 8)), ((5, 3), (8, 6)), ((3, 3), (6, 6))]
+        ctx.reset_stats()
+        for f, mn in cases:
+            for k, thr in ((10, 1000), (300, 1000), (50, 2**31 - 1)):
+                q = api.BooleanQuery(should, 1, tuple(api.MaskFilter(i) for i in f), tuple(api.MaskFilter(i) for i in mn))
+                got = ix.searcher.search(q, api.TopScoreDocCollectorManager(k, None, thr))
+                exp = oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, accept=acc_of(f, mn))
+                assert_same(f"masks_{f}_{mn}_{k}", got, exp, k, thr)
+        st = ctx.stats()
+        assert st["maxscore_items"] >= 2 * len(cases), st
+        # (5, 3) / (8, 6) is the same combination as (3, 5) / (6, 8): one resident set per leaf, not two
+        b0 = [l.device_bytes for l in ix.leaves]
+        ix.searcher.search(api.BooleanQuery(should, 1, (api.MaskFilter(3), api.MaskFilter(5)), (api.MaskFilter(6), api.MaskFilter(8))),
+                           api.TopScoreDocCollectorManager(10))
+        assert [l.device_bytes for l in ix.leaves] == b0
+        # a batch: several masks, one mask, none
+        qs = [api.BooleanQuery(should, 1, (api.MaskFilter(3), api.MaskFilter(4)), (api.MaskFilter(6), api.MaskFilter(7))),
+              api.BooleanQuery(should, 1, (api.MaskFilter(5),)), api.BooleanQuery(should)]
+        mg = [api.TopScoreDocCollectorManager(100)] * 3
+        res = ix.searcher.search_batch(qs, mg)
+        accs = [acc_of((3, 4), (6, 7)), acc_of((5,), ()), acc_of((), ())]
+        for i in range(3):
+            assert_same(f"masks_batch_{i}", res[i], oracle.search_bm25(corpus, terms, 100, accept=accs[i]), 100, 1000)
+        got = ix.searcher.search_coalesced(qs[0], mg[0])
+        assert_same("masks_coalesced", got, oracle.search_bm25(corpus, terms, 100, accept=accs[0]), 100, 1000)
+        # a mask of the list that is not resident: this request's own error
+        with pytest.raises(_lib.NrtGpuError) as e:
+            ix.searcher.search(api.BooleanQuery(should, 1, (api.MaskFilter(3), api.MaskFilter(99))), api.TopScoreDocCollectorManager(10))
+        assert e.value.code == _lib.NRTGPU_ERR_UNSUPPORTED
+    finally:
+        ix.close()
+
+
 def test_mask_errors(ctx):
     corpus = synth.build_corpus(5_000, [3, 50], n_segments=1)
     ix = Index(ctx, corpus)

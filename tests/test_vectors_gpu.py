@@ -350,23 +350,60 @@ def test_knn_large_dimensions_one_panel(ctx, oracle):
             assert got[qi].scores.view(np.uint32).tolist() == oscores[j].view(np.uint32).tolist()
         g.release()
     g = api.GpuSegment(ctx, 8, 0)
-    g.add_vectors(0, np.ones((8, 2064), np.float32))
-    g.seal()
-    with pytest.raises(api.NrtGpuError) as e:
-        api.GpuIndexSearcher(ctx, [g], api.IndexStatistics()).knn_exact(0, "cosine", np.ones((1, 2064), np.float32), 5)
+    with pytest.raises(api.NrtGpuError) as e:   # more than 2048 dimensions: the field stays on the caller's path (refused at upload)
+        g.add_vectors(0, np.ones((8, 2064), np.float32))
     assert e.value.code == -4
     g.release()
 
 
-def test_knn_unsupported_dimension_falls_back(ctx):
-    g = api.GpuSegment(ctx, 10, 0)
-    g.add_vectors(0, np.ones((10, 3), np.float32))   # d = 3 as in VectorFieldDefTest: not a multiple of 8
-    g.seal()
-    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
-    with pytest.raises(api.NrtGpuError) as e:
-        sr.knn_exact(0, "cosine", np.ones((1, 3), np.float32), 5)
-    assert e.value.code == -4
-    g.release()
+def test_knn_dimensions_that_are_no_multiple_of_16(ctx, oracle):
+    """Round 3 refused them (NRTGPU_ERR_UNSUPPORTED -> Lucene); the reference's own vector tests run at d = 3
+    (VectorFieldDefTest.java:1885-1919: 10 000 docs, query (0.25, 0.5, 0.75), top 5, EUCLIDEAN; :1925-1965 normalized cosine).
+    Rows are resident zero-padded to a multiple of 16 elements and queries are padded alike: zeros add nothing to any of the four
+    similarities' sums, so the answers are the field's own -- the oracle's docids and score BITS at the field's dimension."""
+    rng = np.random.default_rng(1885)
+    for dim, n in ((3, 10_000), (5, 3_000), (17, 3_000), (100, 4_000), (770, 2_000)):
+        vecs = rng.standard_normal((n, dim)).astype(np.float32)
+        if dim == 3:
+            vecs[:64] = np.float32(0.5) * vecs[64:128]        # ties among the cosine scores, near-duplicates
+        unit = (vecs / np.linalg.norm(vecs, axis=1, keepdims=True)).astype(np.float32)
+        live = np.ones(((n + 63) // 64) * 64, dtype=bool)
+        live[n:] = False
+        live[rng.choice(n, n // 50, replace=False)] = False
+        live_words = np.packbits(live.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1)
+        g = api.GpuSegment(ctx, n, 7)
+        g.add_vectors(0, vecs)
+        g.add_vectors(1, unit)
+        g.seal()
+        g.set_live_docs(live_words)
+        sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics())
+        queries = np.concatenate([np.array([[0.25, 0.5, 0.75]], np.float32) if dim == 3 else rng.standard_normal((1, dim)).astype(np.float32),
+                                  rng.standard_normal((6, dim)).astype(np.float32)])
+        for sim_name, sim, field, rows in (("cosine", 0, 0, vecs), ("dot_product", 1, 1, unit), ("l2_norm", 2, 0, vecs), ("max_inner_product", 3, 0, vecs)):
+            qs = (queries / np.linalg.norm(queries, axis=1, keepdims=True)).astype(np.float32) if sim == 1 else queries
+            for k in (5, 100):
+                got = sr.knn_exact(field, sim_name, qs, k, boost=1.5)
+                od, os_, oc = oracle.knn_exact(sim, qs, rows, k, live_words=live_words, doc_base=7, boost=1.5, n_threads=4)
+                for qi in range(len(qs)):
+                    m = int(oc[qi])
+                    assert got[qi].docs.tolist() == od[qi][:m].tolist(), (dim, sim_name, k, qi)
+                    assert got[qi].scores.view(np.uint32).tolist() == os_[qi][:m].view(np.uint32).tolist(), (dim, sim_name, k, qi)
+                    assert got[qi].total_hits == int(live[:n].sum())
+        one = sr.knn_exact_coalesced(0, "l2_norm", queries[0], 5)
+        od, os_, _ = oracle.knn_exact(2, queries[:1], vecs, 5, live_words=live_words, doc_base=7, n_threads=2)
+        assert one.docs.tolist() == od[0].tolist() and one.scores.view(np.uint32).tolist() == os_[0].view(np.uint32).tolist()
+        # the vector rescorer at the same dimension (QueryRescore.combine in double, 1e-5: the one path with a tolerance)
+        hits = sr.knn_exact(0, "cosine", queries[:1], 20)[0]
+        first = np.linspace(2.0, 1.0, len(hits.docs)).astype(np.float32)
+        res = sr.rescore_vectors(api.TopDocs(hits.docs, first, hits.total_hits, False), 0, "cosine", queries[0], window=10, query_weight=1.0, rescore_weight=4.0)
+        exp = sorted(((float(oracle.rescore_combine(float(f), True, float(oracle.vector_score(0, queries[0], vecs[d - 7])), 1.0, 4.0)), int(d))
+                      for d, f in zip(hits.docs.tolist(), first.tolist())), key=lambda t: (-t[0], t[1]))[:10]
+        assert res.docs.tolist() == [d for _, d in exp]
+        assert np.allclose(res.scores, [s_ for s_, _ in exp], rtol=1e-5, atol=1e-6)
+        with pytest.raises(api.NrtGpuError) as e:      # a query of another dimension: this request's own error
+            sr.knn_exact(0, "cosine", np.ones((1, dim + 1), np.float32), 5)
+        assert e.value.code == -1
+        g.release()
 
 
 def test_knn_search_prefilter_and_threshold(ctx, oracle):
