@@ -996,6 +996,7 @@ def main():
         "p50_latency_ms": round(statistics.median(lat) * 1e3, 4),
         "p99_latency_ms": round(float(np.percentile(np.asarray(lat), 99)) * 1e3, 4),   # (of `steps` batch calls: the slowest one at --steps 20)
         "latency_samples": len(lat),
+        "max_latency_ms": round(max(lat) * 1e3, 4), "slowest_step": int(np.argmax(np.asarray(lat))),   # (a stall on the host or the device shows up here)
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,

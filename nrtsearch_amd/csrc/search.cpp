@@ -192,6 +192,14 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                    (uint32_t*)(wb + o_icnt) + n_ms, (uint64_t*)(wb + o_ihits) + n_ms, hp.k_stride,
                    ablation == 7 ? (uint64_t*)(wb + o_prof) + n_ms * 16 : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
+  // (experiment, NRTGPU_TURN_BEFORE_MERGE=1: the turn ends behind the scorers, so the next batch's scorers start while this
+  //  batch's merge runs on the CUs a persistent launch leaves alone -- the merge leaves the critical path of the throughput and
+  //  this batch's caller waits for it next to foreign workgroups)
+  static const bool turn_before_merge = getenv("NRTGPU_TURN_BEFORE_MERGE") != nullptr && atoi(getenv("NRTGPU_TURN_BEFORE_MERGE")) != 0;
+  if (turn_before_merge) {
+    HIP_TRY(hipEventRecord(slot->ev_turn, st));
+    ctx->last_turn = slot->ev_turn;
+  }
   uint64_t* okeys = ext_keys ? ext_keys : (uint64_t*)(wb + o_okeys);
   uint32_t* ocnt = ext_counts ? ext_counts : (uint32_t*)(wb + o_ocnt);
   uint64_t* ohits = ext_hits ? ext_hits : (uint64_t*)(wb + o_ohits);
@@ -205,8 +213,10 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
   // (the merge belongs to the turn: behind the next batch's scorers it would wait for a free CU until they drain, and this
   //  batch's caller with it)
-  HIP_TRY(hipEventRecord(slot->ev_turn, st));
-  ctx->last_turn = slot->ev_turn;
+  if (!turn_before_merge) {
+    HIP_TRY(hipEventRecord(slot->ev_turn, st));
+    ctx->last_turn = slot->ev_turn;
+  }
   gpu.unlock();
   HIP_TRY(hipGetLastError());
   run->out_keys = okeys;

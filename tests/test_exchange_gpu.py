@@ -273,3 +273,128 @@ def test_device_resident_search_in_two_halves(oracle):
         for l in leaves:
             l.release()
         ctx.close()
+
+
+def _small_begin_wait_index(max_batch=16):
+    from nrtsearch_amd import api
+
+    w = workload.Workload("begin-wait lifetime test", 250_000, 4, 100, 48, 3)
+    qr = synth.make_queries(48, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr)
+    ctx = api.GpuContext(0, max_batch=max_batch)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    return w, qr, corpus, ctx, leaves
+
+
+def test_segment_release_while_searches_are_in_flight():
+    """nrtgpu_segment_release under running searches (the reference closes readers while SEARCH-pool
+    threads run: ShardState.java:506-527).  Three batches are begun over forked reader versions (planned, enqueued, NOT waited
+    for), every handle they use -- the forks AND the base segments -- is released, then the batches are waited for: same keys,
+    counts and hit totals as the synchronous run before; nothing crashes; the last search to let go of a handle frees it (the
+    device's free memory comes back)."""
+    import torch
+
+    from nrtsearch_amd import api
+
+    w, qr, corpus, ctx, leaves = _small_begin_wait_index()
+    try:
+        forks = [l.fork(None) for l in leaves]
+        sr = api.GpuIndexSearcher(ctx, forks, api.IndexStatistics.from_corpus(corpus))
+        queries = workload.boolean_queries(qr)
+        mgr = api.TopScoreDocCollectorManager(w.k)
+        k_stride = 112
+        pbs = [api.PreparedBatch(sr, queries[i: i + 16], [mgr] * 16) for i in range(0, 48, 16)]
+        bufs = [(torch.zeros((16, k_stride), dtype=torch.int64, device="cuda"), torch.zeros((16,), dtype=torch.int32, device="cuda"),
+                 torch.zeros((16,), dtype=torch.int64, device="cuda")) for _ in range(6)]
+        for b, pb in enumerate(pbs):
+            pb.run_device(k_stride, *(t.data_ptr() for t in bufs[b]))
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        handles = [pb.begin_device(k_stride, *(t.data_ptr() for t in bufs[3 + b])) for b, pb in enumerate(pbs)]   # three in flight
+        for g in forks + leaves:      # the reader versions close, the segments are merged away: while the searches run
+            g.release()
+        for h in handles:
+            api.PreparedBatch.wait_device(h)
+        torch.cuda.synchronize()
+        for b in range(3):
+            for x, y in zip(bufs[b], bufs[3 + b]):
+                assert torch.equal(x, y)
+        assert int(bufs[3][1].sum().item()) > 0
+        # the handles are gone for good now (freed by the last search that held them): the index's device memory is back
+        assert torch.cuda.mem_get_info()[0] >= free_before + sum(s.docids.nbytes for s in corpus.segments)
+    finally:
+        ctx.close()
+
+
+def test_begin_wait_pipeline_against_a_writer_of_the_same_segments():
+    """a thread that begins search i + 1 before it waits for search i must not deadlock against a writer
+    (nrtgpu_segment_set_mask / set_live_docs) that waits for search i -- the old std::shared_mutex parked the second begin
+    behind the writer, and the wait that would have released the first never came.  And the wait may come from another thread
+    than the begin.  A writer thread rewrites a mask of every leaf in a loop while a pipeline of depth 3 runs 40 rounds, its waits
+    on a third thread; everything must finish, with the synchronous run's results."""
+    import queue
+    import threading
+
+    import torch
+
+    from nrtsearch_amd import api
+
+    w, qr, corpus, ctx, leaves = _small_begin_wait_index()
+    try:
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        queries = workload.boolean_queries(qr)
+        mgr = api.TopScoreDocCollectorManager(w.k)
+        k_stride = 112
+        pbs = [api.PreparedBatch(sr, queries[i: i + 16], [mgr] * 16) for i in range(0, 48, 16)]
+        bufs = [(torch.zeros((16, k_stride), dtype=torch.int64, device="cuda"), torch.zeros((16,), dtype=torch.int32, device="cuda"),
+                 torch.zeros((16,), dtype=torch.int64, device="cuda")) for _ in range(6)]
+        for b, pb in enumerate(pbs):
+            pb.run_device(k_stride, *(t.data_ptr() for t in bufs[b]))
+        torch.cuda.synchronize()
+        stop, errors, done = threading.Event(), [], threading.Event()
+        pending = queue.Queue()
+
+        def writer():
+            i = 0
+            while not stop.is_set():
+                for leaf, seg in zip(leaves, corpus.segments):
+                    leaf.set_mask(9, synth.random_mask(seg.max_doc, 0.5, i))   # (no query names mask 9: the results do not change)
+                i += 1
+
+        def waiter():
+            try:
+                while True:
+                    h = pending.get()
+                    if h is None:
+                        break
+                    api.PreparedBatch.wait_device(h)     # another thread than the one that began it
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+            done.set()
+
+        def pipeline():
+            try:
+                for rnd in range(40):
+                    hs = [pb.begin_device(k_stride, *(t.data_ptr() for t in bufs[3 + b])) for b, pb in enumerate(pbs)]   # i + 1, i + 2 begun before i is waited for
+                    for h in hs:
+                        pending.put(h)
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+            pending.put(None)
+
+        threads = [threading.Thread(target=writer, daemon=True), threading.Thread(target=waiter, daemon=True), threading.Thread(target=pipeline, daemon=True)]
+        for t in threads:
+            t.start()
+        finished = done.wait(timeout=180.0)
+        stop.set()
+        assert finished, "the begin / wait pipeline did not finish next to a mask writer (deadlock)"
+        threads[0].join(timeout=30.0)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        for b in range(3):
+            for x, y in zip(bufs[b], bufs[3 + b]):
+                assert torch.equal(x, y)
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()

@@ -15,6 +15,8 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def _dump(name, payload):
+    if os.environ.get("NRTGPU_TEST_NO_DUMPS"):   # (tests/test_planner_host.py: under the stand-in HIP runtime every comparison fails by design)
+        return
     try:
         os.makedirs(OUT, exist_ok=True)
         with open(os.path.join(OUT, f"parity_fail_{name}.json"), "w") as f:

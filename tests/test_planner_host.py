@@ -57,7 +57,7 @@ def test_host_paths_of_the_gpu_suites_run_through_when_the_kernels_do_nothing(mo
     -- what is asked here is only that the host side (uploads, seals, masks, slicing, every planner route and query shape,
     unpacking, the coalescer's threads) neither crashes nor hangs on a device that answers with zeros."""
     files = [os.path.join(ROOT, "tests", f) for f in ("test_parity_gpu.py", "test_maxscore_gpu.py", "test_filters_gpu.py", "test_packed_gpu.py")]
-    e = dict(os.environ, LD_PRELOAD=mockhip)
+    e = dict(os.environ, LD_PRELOAD=mockhip, NRTGPU_TEST_NO_DUMPS="1")   # (no gpurun_out/parity_fail_*.json from failures that are the point)
     e.pop("NRTGPU_LIB_PATH", None)
     r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-p", "no:cacheprovider", "--tb=no"], env=e, capture_output=True,
                        text=True, timeout=900, cwd=ROOT)

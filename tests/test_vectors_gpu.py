@@ -406,6 +406,46 @@ def test_knn_dimensions_that_are_no_multiple_of_16(ctx, oracle):
         g.release()
 
 
+def test_exact_vector_query_relation_is_the_reference_collectors():
+    """TotalHits.relation of an ExactVectorQuery: the scorer ignores min competitive scores, so every live doc
+    with a vector is collected and the COUNT is exact -- but the reference's collector still flips its relation to
+    GREATER_THAN_OR_EQUAL_TO once a slice has collected more than max(totalHitsThreshold, numHits) hits
+    (LazyQueueTopScoreDocCollector.java:176-199; one collector per slice: MyIndexSearcher.java:163-208).
+    nrtgpu_knn_exact_relation applies that rule to the live vectors of each slice (host only)."""
+    rng = np.random.default_rng(176)
+    c = api.GpuContext(device_id=0, max_batch=16)
+    leaves = []
+    try:
+        for si, n in enumerate((600, 600, 600)):
+            g = api.GpuSegment(c, n, si * 600)
+            g.add_vectors(3, rng.standard_normal((n, 16)).astype(np.float32))
+            g.seal()
+            leaves.append(g)
+        sr = api.GpuIndexSearcher(c, leaves, api.IndexStatistics())
+        # default slicing (250 000 docs / 5 segments per slice): the three leaves are ONE slice of 1800 vectors
+        assert sr.knn_exact_relation(3, 10, 1000) is True            # 1800 > max(1000, 10)
+        assert sr.knn_exact_relation(3, 10, 1800) is False           # not MORE than the threshold
+        assert sr.knn_exact_relation(3, 1024, 1000) is True          # max(threshold, numHits) = 1024 < 1800
+        assert sr.knn_exact_relation(3, 10, 2**31 - 1) is False      # ScoreMode.COMPLETE
+        assert sr.knn_exact_relation(7, 10, 1000) is False           # a field without vectors: nothing collected
+        c.set_slicing(500, 5, 1)                                       # every leaf exceeds sliceMaxDocs: three slices of 600
+        assert sr.knn_exact_relation(3, 10, 1000) is False           # 1800 hits in all, no slice above 1000: EQUAL_TO 1800
+        assert sr.knn_exact_relation(3, 10, 500) is True
+        live = np.ones(640, dtype=bool)
+        live[rng.choice(600, 150, replace=False)] = False              # 450 live vectors in leaf 0
+        live[600:] = False
+        leaves[0].set_live_docs(np.packbits(live.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1))
+        assert sr.knn_exact_relation(3, 10, 500) is True             # leaves 1 and 2 still hold 600
+        for leaf in leaves[1:]:
+            leaf.set_live_docs(np.packbits(live.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).reshape(-1))
+        assert sr.knn_exact_relation(3, 10, 500) is False            # 450 live vectors per slice
+        assert sr.knn_exact(3, "cosine", rng.standard_normal((1, 16)).astype(np.float32), 10)[0].total_hits == 3 * 450
+    finally:
+        for g in leaves:
+            g.release()
+        c.close()
+
+
 def test_knn_search_prefilter_and_threshold(ctx, oracle):
     """The `knn` request path answered exactly: pre-filter mask (KnnFloatVectorQuery's filter), score threshold
     on the unboosted score (MinThresholdQuery, MinThresholdQuery.java:201), boost afterwards."""
