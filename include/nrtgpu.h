@@ -243,6 +243,9 @@ int  nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us);
  * production callers: a held coalescer parks every request. */
 int  nrtgpu_debug_hold_coalescers(nrtgpu_ctx* ctx, int32_t hold);
 int  nrtgpu_debug_coalescer_pending(nrtgpu_ctx* ctx, int32_t which);
+/* TEST HOOK: segment handles of the context (uploads and forks) that have not been freed yet.  nrtgpu_segment_release under
+ * running searches defers the free to the last of them: this count is how a test observes that it happened. */
+int64_t nrtgpu_debug_live_segments(nrtgpu_ctx* ctx);
 
 /* Device-resident variant for the multi-GPU path (one process per GPU): results stay
  * in HBM as packed keys so the caller can RCCL all-gather them without a host round trip.

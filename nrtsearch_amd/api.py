@@ -243,6 +243,10 @@ class GpuContext:
             L.nrtgpu_get_maxscore_item_walls(self._h, out.ctypes.data, n, C.byref(n_items))
         return out, int(n_items.value)
 
+    def debug_live_segments(self) -> int:
+        """Segment handles of this context (uploads and forks) not freed yet (nrtgpu_debug_live_segments)."""
+        return int(_lib.load().nrtgpu_debug_live_segments(self._h))
+
     def debug_hold_coalescers(self, hold: bool) -> None:
         """Test hook (nrtgpu_debug_hold_coalescers): while held, coalescer leaders leave only with a full batch / panel."""
         _lib.check(_lib.load().nrtgpu_debug_hold_coalescers(self._h, 1 if hold else 0))

@@ -436,6 +436,7 @@ struct nrtgpu_ctx {
   int co_inflight_queries = 0;                // ... and how many queries they hold
   int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
   int32_t co_linger_us = 150;
+  std::atomic<int64_t> live_segments{0};   // segment handles (uploads and forks) that have not been freed yet (nrtgpu_debug_live_segments)
   std::atomic<int> co_hold{0};                          // nrtgpu_debug_hold_coalescers: no leader (of either coalescer) leaves with less than a full batch / panel
   // the same for exact vector searches (nrtgpu_knn_exact_coalesced, vectors.cpp)
   std::mutex kco_mu;

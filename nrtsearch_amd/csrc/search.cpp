@@ -192,10 +192,13 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                    (uint32_t*)(wb + o_icnt) + n_ms, (uint64_t*)(wb + o_ihits) + n_ms, hp.k_stride,
                    ablation == 7 ? (uint64_t*)(wb + o_prof) + n_ms * 16 : nullptr);
   if (timing) HIP_TRY(hipEventRecord(slot->ev1, st));
-  // (experiment, NRTGPU_TURN_BEFORE_MERGE=1: the turn ends behind the scorers, so the next batch's scorers start while this
-  //  batch's merge runs on the CUs a persistent launch leaves alone -- the merge leaves the critical path of the throughput and
-  //  this batch's caller waits for it next to foreign workgroups)
-  static const bool turn_before_merge = getenv("NRTGPU_TURN_BEFORE_MERGE") != nullptr && atoi(getenv("NRTGPU_TURN_BEFORE_MERGE")) != 0;
+  // The turn ends behind the SCORERS: the next batch's scorers start while this batch's merge (one workgroup per query, 0.05 ms
+  // of device time per 1024 queries) runs on the CUs the persistent MaxScore launch leaves alone.  Through round 3 the merge was
+  // part of the turn -- behind the next batch's one-workgroup-per-item launch it waited for a free CU until that launch drained
+  // (closed loop at 64 callers: p99 1.4 -> 4.0 ms) -- which the spare CUs have changed: measured, same box
+  // (profiles/r04_turn_before_merge_ab.log), 2.413 -> 2.357 ms per 1024-query step, batch p50 4.80 -> 4.69 ms, closed loop at
+  // 64 / 512 callers p99 1.20 / 2.61 -> 1.20 / 2.55 ms.  NRTGPU_TURN_BEFORE_MERGE=0: the old turn (A/B).
+  static const bool turn_before_merge = getenv("NRTGPU_TURN_BEFORE_MERGE") == nullptr || atoi(getenv("NRTGPU_TURN_BEFORE_MERGE")) != 0;
   if (turn_before_merge) {
     HIP_TRY(hipEventRecord(slot->ev_turn, st));
     ctx->last_turn = slot->ev_turn;
@@ -211,8 +214,6 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_slice_relation(st, (const uint32_t*)(wb + o_ssum), (const DQuery*)(db + o_queries), hp.n_slices, ohits, (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
   if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
-  // (the merge belongs to the turn: behind the next batch's scorers it would wait for a free CU until they drain, and this
-  //  batch's caller with it)
   if (!turn_before_merge) {
     HIP_TRY(hipEventRecord(slot->ev_turn, st));
     ctx->last_turn = slot->ev_turn;

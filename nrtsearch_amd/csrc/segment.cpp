@@ -85,9 +85,14 @@ extern "C" int nrtgpu_segment_begin(nrtgpu_ctx* ctx, int32_t max_doc, int32_t /*
   seg->uid = next_uid.fetch_add(1, std::memory_order_relaxed);
   seg->max_doc = max_doc;
   seg->n_tiles = (uint32_t)(((int64_t)max_doc + kTileDocs - 1) / kTileDocs);
+  ctx->live_segments.fetch_add(1, std::memory_order_relaxed);
   *out = seg;
   return NRTGPU_OK;
 }
+
+// Test hook: segment handles of the context (uploads and forks) not freed yet -- a handle released under running searches is
+// freed by the last of them (nrtgpu_segment_release), and this is how a test sees that it was.
+extern "C" int64_t nrtgpu_debug_live_segments(nrtgpu_ctx* ctx) { return ctx ? ctx->live_segments.load(std::memory_order_relaxed) : -1; }
 
 extern "C" int nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id, const uint8_t* norm_bytes) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
@@ -699,6 +704,7 @@ SegCore::~SegCore() {
 
 static void destroy_segment(nrtgpu_seg* seg) {
   (void)hipSetDevice(seg->ctx->device);
+  seg->ctx->live_segments.fetch_sub(1, std::memory_order_relaxed);
   drop_accept_sets(seg);
   if (seg->d_live) (void)hipFree(seg->d_live);
   delete seg;   // (the shared core -- columns, norms, vectors -- goes with its last handle)
@@ -730,6 +736,7 @@ extern "C" int nrtgpu_segment_fork(nrtgpu_seg* seg, const uint64_t* live_bits, i
   f->max_doc = seg->max_doc;
   f->n_tiles = seg->n_tiles;
   f->sealed = true;
+  f->ctx->live_segments.fetch_add(1, std::memory_order_relaxed);
   if (int rc = nrtgpu_segment_set_live_docs(f, live_bits, n_words)) {
     nrtgpu_segment_release(f);
     return rc;

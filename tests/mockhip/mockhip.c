@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <stdio.h>
 static long n_launch = 0;
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
@@ -27,7 +28,13 @@ hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSucc
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) { (void)st; memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned f) { (void)f; *s = (hipStream_t)malloc(8); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; return hipSuccess; }
+/* MOCKHIP_SYNC_US: how long a stream synchronisation "takes" (0 by default): lets a test keep searches in flight for a while */
+static void mock_sync_delay(void) {
+  static int us = -1;
+  if (us < 0) { const char* e = getenv("MOCKHIP_SYNC_US"); us = e ? atoi(e) : 0; }
+  if (us > 0) usleep((useconds_t)us);
+}
+hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; mock_sync_delay(); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned f) { (void)s; (void)e; (void)f; return hipSuccess; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
