@@ -266,6 +266,10 @@ int  nrtgpu_search_bm25_batch_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* s
  * nobody spins on a stream in between (a rank of a multi-GPU job: ~1 CPU instead of one per call in flight).  At most 4
  * batches in flight per context (a fifth _begin waits for a workspace); every handle must be waited for exactly once.
  * epoch: as nrtgpu_search_bm25_batch_device_epoch below (-1: no bound exchange). */
+/* Lifetime contract of a pending search: it holds its segments' content from begin to wait (set_live_docs / set_mask on those
+ * handles wait for it; nrtgpu_segment_release is deferred to it).  nrtgpu_pending_wait may be called from any thread.  A thread
+ * that holds un-waited pending searches may begin more (they pass a writer that is waiting for the earlier ones) but must not
+ * start a SYNCHRONOUS search over the same handles before it has waited: that one queues behind the waiting writer. */
 typedef struct nrtgpu_pending nrtgpu_pending;
 int  nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                            int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,

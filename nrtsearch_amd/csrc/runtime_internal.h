@@ -304,13 +304,18 @@ struct nrtgpu_seg {
   mutable std::mutex content_m;
   mutable std::condition_variable content_cv;
   mutable int content_readers = 0;          // searches in flight over this handle
-  mutable int content_writers_waiting = 0;  // pending exclusive owners: new searches let them go first (no writer starvation) ...
-  mutable int content_bypass = 0;           // ... except up to kContentBypass searches per waiting writer while others are still in
-                                            // flight: a pipeline that begins search i + 1 before it waits for search i must not
-                                            // deadlock against a writer that waits for search i
+  mutable int content_writers_waiting = 0;  // pending exclusive owners: new SYNCHRONOUS searches let them go first (no writer
+                                            // starvation under overlapping request threads).  A PIPELINED search
+                                            // (nrtgpu_search_bm25_batch_device_begin) passes a waiting writer while other searches
+                                            // are in flight: its thread may be the one that must still wait for one of them --
+                                            // begin i + 1 before wait i -- and parking it behind the writer that waits for search
+                                            // i is a deadlock (a bounded number of passes only postpones it:
+                                            // tests/test_exchange_gpu.py found that on the CPU).  The price: a pipeline that never
+                                            // drains can delay set_mask / set_live_docs on the handles it searches -- reader
+                                            // versions are forks (no writer), masks are registered before a handle is searched
   mutable bool content_writing = false;
   mutable bool content_released = false;    // nrtgpu_segment_release came while searches were in flight: the last one frees
-  void content_lock_shared() const;
+  void content_lock_shared(bool pipelined) const;
   void content_unlock_shared() const;       // may free the handle (content_released)
   std::map<int32_t, std::vector<uint64_t>> masks;
   mutable std::mutex accept_mu;
@@ -329,12 +334,14 @@ struct SegWriteLock {
 // Shared locks on the content of every (distinct) segment of a call, taken in address order.
 struct SegReadLocks {
   std::vector<const nrtgpu_seg*> held;
-  SegReadLocks(const nrtgpu_seg* const* segs, int32_t n) {
+  // pipelined: the caller returns to its own caller holding the locks (begin / wait); see nrtgpu_seg::content_writers_waiting.
+  // A thread must not start a synchronous search over handles it holds un-waited pipelined searches on.
+  SegReadLocks(const nrtgpu_seg* const* segs, int32_t n, bool pipelined = false) {
     for (int32_t i = 0; i < n; ++i)
       if (segs && segs[i]) held.push_back(segs[i]);
     std::sort(held.begin(), held.end());
     held.erase(std::unique(held.begin(), held.end()), held.end());
-    for (const nrtgpu_seg* s : held) s->content_lock_shared();
+    for (const nrtgpu_seg* s : held) s->content_lock_shared(pipelined);
   }
   ~SegReadLocks() {   // (any thread: nrtgpu_pending_wait may run on another one than the begin)
     for (const nrtgpu_seg* s : held) s->content_unlock_shared();

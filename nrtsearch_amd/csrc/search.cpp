@@ -808,7 +808,7 @@ extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtg
   auto p = std::make_unique<nrtgpu_pending>();
   p->ctx = ctx;
   p->n_queries = n_queries;
-  p->content = std::make_unique<SegReadLocks>(segs, n_segs);  // until this call's kernels have finished (nrtgpu_pending_wait)
+  p->content = std::make_unique<SegReadLocks>(segs, n_segs, true);  // until this call's kernels have finished (nrtgpu_pending_wait)
   // (both scorers take part in a bound exchange that is open: nrtgpu_exchange_open)
   if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, p->hp, 2)) return rc;
   if (k_stride < (int32_t)p->hp.k_stride && k_stride < NRTGPU_MAX_K) {

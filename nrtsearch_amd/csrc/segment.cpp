@@ -3,14 +3,11 @@
 #include "runtime_internal.h"
 
 static void destroy_segment(nrtgpu_seg* seg);
-constexpr int kContentBypass = 16;   // searches that may still start over a handle per waiting writer while others are in flight
-
 SegWriteLock::SegWriteLock(nrtgpu_seg* s) : seg(s) {
   std::unique_lock<std::mutex> lk(seg->content_m);
   seg->content_writers_waiting++;
   seg->content_cv.wait(lk, [&] { return seg->content_readers == 0 && !seg->content_writing; });
   seg->content_writers_waiting--;
-  seg->content_bypass = 0;
   seg->content_writing = true;
 }
 SegWriteLock::~SegWriteLock() {
@@ -26,18 +23,11 @@ SegWriteLock::~SegWriteLock() {
   }
   seg->content_cv.notify_all();
 }
-void nrtgpu_seg::content_lock_shared() const {
+void nrtgpu_seg::content_lock_shared(bool pipelined) const {
   std::unique_lock<std::mutex> lk(content_m);
-  for (;;) {
-    if (!content_writing && content_writers_waiting == 0) break;
-    // a writer waits for the searches in flight.  The caller may be the thread that must still wait for one of THEM (begin i + 1
-    // before wait i): let a bounded number through instead of parking it behind the writer
-    if (!content_writing && content_readers > 0 && content_bypass < kContentBypass) {
-      content_bypass++;
-      break;
-    }
-    content_cv.wait(lk);
-  }
+  // behind a writer that HOLDS the content: everybody.  Behind a writer that WAITS for the searches in flight: synchronous
+  // searches only -- a pipelined one may come from the thread that must still wait for one of those searches
+  content_cv.wait(lk, [&] { return !content_writing && (content_writers_waiting == 0 || (pipelined && content_readers > 0)); });
   content_readers++;
 }
 void nrtgpu_seg::content_unlock_shared() const {

@@ -66,3 +66,16 @@ def test_host_paths_of_the_gpu_suites_run_through_when_the_kernels_do_nothing(mo
     m = re.search(r"(\d+) failed", tail)
     assert m and int(m.group(1)) >= 30 and "error" not in tail, tail      # (they ran, and failed on their assertions, not on set-up)
     assert "Fatal Python error" not in r.stderr and "Segmentation" not in r.stderr
+
+
+def test_a_begin_wait_pipeline_does_not_deadlock_against_a_writer(mockhip):
+    """ADVICE round 3 (search.cpp: nrtgpu_pending keeps its segments' content locks from begin to wait): a thread that begins
+    search i + 1 before anybody waits for search i must not be parked behind a writer (nrtgpu_segment_set_mask) that waits for
+    search i.  The GPU test of the same name found the round's first fix (a bounded number of passes) wanting; this is its CPU
+    twin, against the stand-in HIP runtime with searches that stay in flight for 0.5 ms / 3 ms each."""
+    for us in ("500", "3000"):
+        e = dict(os.environ, LD_PRELOAD=mockhip, MOCKHIP_SYNC_US=us)
+        e.pop("NRTGPU_LIB_PATH", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "pipeline_vs_writer.py")], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "finished True" in r.stdout, (us, r.stdout[-500:], r.stderr[-1500:])
+        assert "'b': 120, 'wait': 120" in r.stdout, r.stdout[-300:]
