@@ -27,11 +27,16 @@
 // is below the theta it was dropped at, and theta only grows.  So every doc that can reach the final theta is
 // evaluated exactly once, with its complete score.
 //
-// Work decomposition: one work item (query x doc range) per workgroup of kMsWaves autonomous waves; a wave
-// takes windows of kMsWinDocs docs from an LDS counter and walks the clauses of its window on its own, so the
-// ordering argument above holds per wave with no barrier.  Competitive docs go to the workgroup's shared LDS
-// candidate buffer; when it overflows all waves meet, a bucket select (topk.hiph) keeps the k best and raises
-// theta -- the collector's pqTop / minCompetitiveScore.
+// Work decomposition: a work item is a query x doc range; a workgroup is kMsWaves autonomous waves that own a CU (160 KB of
+// LDS).  A wave takes windows of kMsWinDocs docs and walks the clauses of its window on its own, so the ordering argument
+// above holds per wave with no barrier.  Competitive docs go to the workgroup's shared LDS candidate buffer; when it overflows
+// all waves meet, a bucket select (topk.hiph) keeps the k best and raises theta -- the collector's pqTop /
+// minCompetitiveScore.
+// The launch (round 4; plan.h: MsArgs, DHelp; the head of the kernel): the items of a batch are a QUEUE; the launch has one
+// PERSISTENT workgroup per CU (minus a few spare CUs) that chooses work round after round -- start the next item, or HELP a
+// running one: an item's windows come from a counter in global memory, so its owner and any number of helpers share them; a
+// helper keeps its own candidate list and output slot, which the merge walks next to the item's.  Which doc is evaluated by
+// whom changes nothing of the argument above: windows partition an item's docs, theta only filters.
 // Roofline: HBM.  Reported both ways: effective = 9 B x the postings of the query's terms, physical
 // = what the kernel fetches (a few percent of that).
 #include <hip/hip_runtime.h>
