@@ -146,6 +146,10 @@ __device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t 
 #define NRT_MS_COLLAPSE 0
 #endif
 constexpr bool kMsCollapse = NRT_MS_COLLAPSE != 0;
+#ifndef NRT_MS_ROWS_SPEC
+#define NRT_MS_ROWS_SPEC 1
+#endif
+constexpr bool kMsRowsSpec = NRT_MS_ROWS_SPEC != 0;   // rows: every later dense clause's record, then code, requested at once
 template <int NS>
 __device__ __forceinline__ void collapse_to_rows(const uint32_t (&d)[NS], const uint64_t (&run)[NS], uint32_t alive, uint32_t c,
                                                  uint32_t ccnt, uint32_t& d1, uint64_t& run1, uint32_t& meta1) {
@@ -766,8 +770,54 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
           //      steps as the rounds below -- bound, lookup, sum, then hits and candidates -- on scalars, at an eighth of the
           //      vector instructions per round.
           auto finish_rows = [&](uint32_t d1, uint64_t run1, bool live1, uint32_t c1, uint32_t cnt1, uint32_t j2_begin) {
+            // Dense clauses: the record of EVERY later clause for my doc is requested before the first is used, then every code --
+            // two round trips for the rest of the instruction instead of two per clause.  What is requested for a doc that an
+            // earlier clause's bound drops was requested in vain (bytes, no results): bounds, sums and counts run clause by
+            // clause below exactly as in the rounds.  (A record table spans the segment: any doc's word is there.)
+            constexpr int kRest = kMsMaxTerms - 1;
+            uint32_t cc[kRest], at_[kRest], pres = 0;
+            if (kMsRowsSpec) {
+              u32x2 rr[kRest];
+  #pragma unroll
+              for (int i = 0; i < kRest; ++i) {
+                const uint32_t j2 = j2_begin + (uint32_t)i;
+                rr[i] = u32x2{0u, 0u};
+                if (j2 < n_terms) {   // (uniform)
+                  const uint64_t bits2 = uniform_u64(wcl[j2].bits);
+                  if (bits2 != 0ull) rr[i] = ((gvec2_ptr)bits2)[(live1 && c1 < j2) ? (d1 >> 5) : 0u];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+              for (int i = 0; i < kRest; ++i) {
+                const uint32_t j2 = j2_begin + (uint32_t)i;
+                cc[i] = at_[i] = 0u;
+                if (j2 < n_terms) {   // (uniform)
+                  const WClause& w2 = wcl[j2];
+                  if (uniform_u64(w2.bits) != 0ull) {
+                    const uint32_t bb = d1 & 31u;
+                    const bool there = live1 && c1 < j2 && ((rr[i][0] >> bb) & 1u);
+                    at_[i] = there ? rr[i][1] + (uint32_t)__popc(rr[i][0] & ((1u << bb) - 1u)) : 0u;
+                    pres |= (there ? 1u : 0u) << i;
+                    cc[i] = ((gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + uniform_u64(w2.start) * 4u))[at_[i]];
+                  }
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
             for (uint32_t j2 = j2_begin; j2 < n_terms; ++j2) {
               if (!__any(live1)) break;
+              // (the requested words of this clause: element 0; the arrays move down by one per clause, so that they stay registers)
+              const uint32_t code0 = kMsRowsSpec ? cc[0] : 0u, at0 = kMsRowsSpec ? at_[0] : 0u;
+              const bool pres0 = kMsRowsSpec && (pres & 1u) != 0u;
+              if (kMsRowsSpec) {
+  #pragma unroll
+                for (int i = 0; i + 1 < kRest; ++i) {
+                  cc[i] = cc[i + 1];
+                  at_[i] = at_[i + 1];
+                }
+                pres >>= 1;
+              }
               const uint64_t S_j = readlane_u64(my_suf, j2);
               bool am = live1 && c1 < j2;
               if (am && (use_max ? max(run1, S_j) : run1 + S_j) < thr_p) live1 = am = false;
@@ -780,7 +830,12 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
               const gu32_ptr codes2 = (gu32_ptr)((PACKED ? w2.docids : w2.fnorm) + w2.start * 4u);
               bool present = false;
               uint32_t at = 0;   // the doc's posting in the clause (index relative to the clause's first)
-              if (bits2 != 0ull) {
+              uint32_t code = 0;
+              if (bits2 != 0ull && kMsRowsSpec) {
+                present = am && pres0;
+                at = present ? at0 : 0u;
+                code = code0;
+              } else if (bits2 != 0ull) {
                 const u32x2 r = ((gvec2_ptr)bits2)[am ? (d1 >> 5) : 0u];
                 const uint32_t bb = d1 & 31u;
                 present = am && ((r[0] >> bb) & 1u);
@@ -809,7 +864,8 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                 at = present ? a : 0u;
               }
               if (__any(present)) {
-                uint32_t c2[1] = {codes2[at]}, pi2[1] = {(uint32_t)w2.start + at}, v2[1];
+                if (!(bits2 != 0ull && kMsRowsSpec)) code = codes2[at];
+                uint32_t c2[1] = {code}, pi2[1] = {(uint32_t)w2.start + at}, v2[1];
                 if (PACKED) c2[0] = (c2[0] & kPackCodeMask) << 2;
                 values_of_codes<PACKED, 1>(s, c2, present ? 1u : 0u, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
                 const uint64_t add = (uint64_t)(present ? v2[0] : 0u) * (uint64_t)(1u << ((flags2 >> 4) & 15u));
