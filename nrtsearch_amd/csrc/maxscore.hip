@@ -150,6 +150,24 @@ constexpr bool kMsCollapse = NRT_MS_COLLAPSE != 0;
 #define NRT_MS_ROWS_SPEC 1
 #endif
 constexpr bool kMsRowsSpec = NRT_MS_ROWS_SPEC != 0;   // rows: every later dense clause's record, then code, requested at once
+// -DNRT_MS_PHASE_CLOCKS (a measurement build, instrumented kernel only): where a wave's walk time goes.  At each mark the wave
+// waits for everything it has requested, reads the cycle counter and books the time since the last mark to a phase; the sums
+// over all waves replace the event counters in slots 0-8 of the item's profile row (scripts/gpu_phase_clocks.py names them).
+// The waits serialise what the product build overlaps within one phase -- the split is of THIS build's walk, which runs a few
+// percent longer.
+#ifdef NRT_MS_PHASE_CLOCKS
+#define NRT_PH_MARK(i)                                                          \
+  do {                                                                          \
+    if (PROF) {                                                                 \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
+      const uint64_t t_ph_ = __builtin_readcyclecounter();                      \
+      ph[i] += t_ph_ - ph_t;                                                    \
+      ph_t = t_ph_;                                                             \
+    }                                                                           \
+  } while (0)
+#else
+#define NRT_PH_MARK(i) do {} while (0)
+#endif
 template <int NS>
 __device__ __forceinline__ void collapse_to_rows(const uint32_t (&d)[NS], const uint64_t (&run)[NS], uint32_t alive, uint32_t c,
                                                  uint32_t ccnt, uint32_t& d1, uint64_t& run1, uint32_t& meta1) {
@@ -462,7 +480,9 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         s.tab[slot][e] = e < (uint32_t)kTabNorms ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)(e >> 7), cache[e & 127u]), scale);
     }
     __syncthreads();  // from here on the waves run on their own
+  #ifndef NRT_MS_PHASE_CLOCKS
     if (PROF && tid == 0) s.prof[8] = __builtin_readcyclecounter() - t_item0;
+  #endif
 
     uint32_t* const seen = &s.seen[wave][0];
     WClause* const wcl = &s.wc[wave][0];
@@ -470,6 +490,9 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
     uint32_t wave_hits = 0;    // hits of my current slot not yet added to s.slot_hits
     uint32_t cur_slot = 0;
     uint64_t pc_post = 0, pc_surv = 0, pc_look = 0, pc_cand = 0, pc_chunks = 0, pc_wins = 0;
+  #ifdef NRT_MS_PHASE_CLOCKS
+    uint64_t ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;   // 0 window head, 1 columns, 2 values + bounds, 3 test-and-set, 4 records, 5 codes, 6 sums, 7 sparse clause, 8 hits + candidates
+  #endif
   #ifdef NRT_MS_COUNT_ROUNDS   // experiment build: event counts instead of four of the cycle counters
     uint64_t pc_dense = 0, pc_sparse = 0, pc_steps = 0, pc_tas = 0, pc_crounds = 0;
   #endif
@@ -616,6 +639,10 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         for (int i = 0; i < kMsMaxTerms; ++i) pre[i] = (uint32_t)__builtin_amdgcn_readlane((int)incl, i);
         const uint32_t n_groups = pre[kMsMaxTerms - 1];
 
+  #ifdef NRT_MS_PHASE_CLOCKS
+        if (PROF) ph_t = t_win0;
+  #endif
+        NRT_PH_MARK(0);
         for (uint32_t v0 = 0; v0 < n_groups; v0 += 64u) {  // 64 groups = up to 512 postings per instruction
           const uint32_t v = v0 + lane;
           const bool act = v < n_groups;
@@ -673,6 +700,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
               }
             }
           }
+          NRT_PH_MARK(1);
           uint32_t vmask = 0;  // my postings inside the clause's range (one unsigned compare: positions before the range wrap) and the window
           {
             const uint32_t rel = q0 - ((uint32_t)p_begin & 3u), cnt = act ? r1[2] : 0u;
@@ -741,6 +769,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
             pc_post += (uint64_t)__popc(vmask);
             pc_surv += (uint64_t)__popc(alive);
           }
+          NRT_PH_MARK(2);
           // first clause to reach the doc?  Test-and-set, clause by clause in order: LDS executes a wave's operations
           // in order, so of two postings of one doc in this instruction the earlier clause's wins.  (Lanes without a
           // survivor OR a zero into a word of their own.)
@@ -764,6 +793,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                 if (((am >> j) & 1u) && ((old[j] >> (d[j] & 31u)) & 1u)) alive &= ~(1u << j);
             }
           }
+          NRT_PH_MARK(3);
           uint32_t ccnt = 0x11111111u;   // SHAPES, minimumNumberShouldMatch: clauses that matched the doc, 4 bits per posting slot
 
           // ---- One doc per lane: what is left of an instruction once few of its docs survive (collapse_to_rows).  The same
@@ -968,6 +998,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
   #pragma unroll
               for (int j = 0; j < kSl; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
               __builtin_amdgcn_sched_barrier(0);   // every record load is issued before the first one is waited for
+              NRT_PH_MARK(4);
               uint32_t idx[kSl];
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
@@ -979,6 +1010,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
   #pragma unroll
               for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
               __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
+              NRT_PH_MARK(5);
   #pragma unroll
               for (int j = 0; j < kSl; ++j) pi2[j] = (uint32_t)start2 + idx[j];
             } else {
@@ -1030,6 +1062,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                                                                       //  through the search loop cost more than this gather)
                 pi2[j] = (uint32_t)start2 + a[j];
               }
+              NRT_PH_MARK(7);
             }
             if (__any(present != 0u)) {
               uint32_t v2[kSl];
@@ -1054,6 +1087,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                 ccnt += x;
               }
             }
+            NRT_PH_MARK(6);
           }
 
           if (!collapsed) {
@@ -1133,6 +1167,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
             theta_now = max(theta_now, s.theta);
           }
           }  // (!collapsed)
+          NRT_PH_MARK(8);
           // somebody else asked for a compaction: join it between two instructions
           if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
             const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
@@ -1178,11 +1213,19 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       }
     }
     if (lane == 0 && wave_hits) atomicAdd(&s.slot_hits[cur_slot], wave_hits);
+  #ifdef NRT_MS_PHASE_CLOCKS
+    if (PROF && lane == 0) {
+  #pragma unroll
+      for (int i = 0; i < 9; ++i) atomicAdd((unsigned long long*)&s.prof[i], (unsigned long long)ph[i]);
+    }
+    if (false) {
+  #else
     if (PROF && lane == 0) {
       atomicAdd((unsigned long long*)&s.prof[0], (unsigned long long)pc_wins);
       atomicAdd((unsigned long long*)&s.prof[2], (unsigned long long)pc_chunks);
     }
     if (PROF) {
+  #endif
       uint64_t v3 = pc_post, v4 = pc_surv, v6 = pc_look, v7 = pc_cand;
   #pragma unroll
       for (int dlt = 32; dlt > 0; dlt >>= 1) {
@@ -1222,7 +1265,9 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       const bool pruned = s.prune_on != 0u && (s.theta != 0ull || __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
       as_global(ape->item_hits)[out_slot] = (uint64_t)hits + (pruned ? kHitsPrunedUnit : 0ull);
       if (PROF && ape->item_prof) {
+  #ifndef NRT_MS_PHASE_CLOCKS
         s.prof[5] = hits;
+  #endif
         const uint64_t t_end = __builtin_readcyclecounter();
         s.prof[9] = t_end - t_item0;
         s.prof[15] = t_end - t_epi0;

@@ -278,19 +278,39 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
 static int fold_live_docs(nrtgpu_seg* seg);
 
 // What the MaxScore route needs per term besides the columns (plan.h: DTermAux), built on the device from the
-// sealed columns: the impact frontier of every term, and for terms dense enough that a doc-indexed structure is
-// affordable (at least one posting per kBitsDocsPerPosting docs: the records then take at most 4x the term's
-// posting bytes) one membership + rank record per 32 docs.  Sparser terms are looked up through their cell table.
-static const int64_t kBitsDocsPerPosting = 128;
+// sealed columns: the impact frontier of every term, and for the terms a doc-indexed structure is affordable for one
+// membership + rank record per 32 docs (0.25 B per doc and term).  The other terms are looked up through their cell table
+// (a binary search in the docid column: 3.7 dependent probes per lookup round at C3 against one record read).
+// Which terms: at least one posting per kRecordDocsPerPosting docs, the kRecordMaxTerms largest of them.  Rounds 2-4 asked
+// for a posting per 128 docs (records <= 4x the term's posting bytes); measured in round 4 on C3 (profiles/
+// r04_record_threshold_ab.log): 128 -> 1024 -> 4096 -> 32768: kernel 2.33 -> 2.30 -> 2.245 -> 2.23 ms per 1024 queries.
+// 4096 it is: in a Zipf dictionary (df ~ max_doc / 2r) that is the 2048 most frequent terms = 512 B per doc, which the
+// term cap enforces for any other dictionary -- 5 GB at C3's 10 M docs, 26 GB at C5's 50 M, of 288 GB.
+// NRTGPU_RECORD_DOCS_PER_POSTING / NRTGPU_RECORD_MAX_TERMS (read when a segment is sealed) override both.
+static const int64_t kRecordDocsPerPosting = 4096;
+static const int64_t kRecordMaxTerms = 2048;
 static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   if (g.d_aux || g.n_terms == 0) return NRTGPU_OK;
+  int64_t docs_per_posting = kRecordDocsPerPosting, max_terms = kRecordMaxTerms;
+  if (const char* e = getenv("NRTGPU_RECORD_DOCS_PER_POSTING")) docs_per_posting = std::max<int64_t>(1, atoll(e));
+  if (const char* e = getenv("NRTGPU_RECORD_MAX_TERMS")) max_terms = std::max<int64_t>(0, atoll(e));
   const size_t nt = g.n_terms;
   const uint64_t n_blocks = ((uint64_t)seg->max_doc + 31) / 32 + 1;  // 8-byte records, one per 32 docs (+1 pad)
   std::vector<uint64_t> rec((size_t)nt, ~0ull);
   uint64_t n_recs = 0;
   uint32_t max_count = 0;
-  for (size_t t = 0; t < nt; ++t) {
-    if (g.h_count[t] > 0 && (int64_t)g.h_count[t] * kBitsDocsPerPosting >= (int64_t)seg->max_doc) {
+  {
+    std::vector<uint32_t> want;
+    for (size_t t = 0; t < nt; ++t)
+      if (g.h_count[t] > 0 && (int64_t)g.h_count[t] * docs_per_posting >= (int64_t)seg->max_doc) want.push_back((uint32_t)t);
+    if ((int64_t)want.size() > max_terms) {   // the largest terms (ties: the lower term id), then back into term order
+      std::nth_element(want.begin(), want.begin() + (ptrdiff_t)max_terms, want.end(), [&](uint32_t a, uint32_t b) {
+        return g.h_count[a] != g.h_count[b] ? g.h_count[a] > g.h_count[b] : a < b;
+      });
+      want.resize((size_t)max_terms);
+      std::sort(want.begin(), want.end());
+    }
+    for (uint32_t t : want) {
       rec[t] = n_recs;
       n_recs += n_blocks;
       max_count = std::max(max_count, g.h_count[t]);

@@ -2,7 +2,7 @@
 ragged sizes), random clause sets (1..10 terms, boosts, repeats), numHits, thresholds, paging, masks,
 minimumNumberShouldMatch, DisjunctionMaxQuery, min competitive scores -- mixed inside batches so that every kernel variant and the
 batch-level switches between them are exercised together.  Bit-exact like every BM25 test.
-NRT_FUZZ_ROUNDS scales the number of corpora (default 6)."""
+NRT_FUZZ_ROUNDS scales the number of corpora (default 8)."""
 import os
 
 import numpy as np
@@ -15,12 +15,17 @@ from tests.test_parity_gpu import Index, assert_same
 from tests.test_filters_gpu import accept_of, random_mask
 
 pytestmark = pytest.mark.gpu
-ROUNDS = int(os.environ.get("NRT_FUZZ_ROUNDS", "6"))
+ROUNDS = int(os.environ.get("NRT_FUZZ_ROUNDS", "8"))
 
 
 @pytest.mark.parametrize("round_", range(ROUNDS))
-def test_fuzz_query_shapes(round_):
+def test_fuzz_query_shapes(round_, monkeypatch):
     rng = np.random.Generator(np.random.PCG64(20260925 + round_))
+    # which terms get membership records (segment.cpp: build_term_aux) decides between the two lookup paths of the MaxScore walk:
+    # a posting per 16 docs (nearly every lookup a binary search), the default, or every term (no binary search at all)
+    monkeypatch.setenv("NRTGPU_RECORD_DOCS_PER_POSTING", ["16", "128", "4096", str(1 << 30)][round_ % 4])
+    if round_ % 8 >= 4:
+        monkeypatch.setenv("NRTGPU_RECORD_MAX_TERMS", "3")
     n_docs = int(rng.choice([900, 1024, 5_000, 33_000, 70_001, 200_000]))
     n_seg = int(rng.integers(1, 5))
     ranks = sorted(set(int(r) for r in np.floor(np.exp(rng.uniform(0, np.log(3000), size=14))).clip(1, 3000)))
