@@ -153,7 +153,13 @@ typedef struct {
   int32_t cache_slot;     /* which 256-float table of nrtgpu_bm25_query.norm_cache this term uses */
   int64_t term_hash;
   float   weight;         /* boost * idf, float (BM25Similarity.scorer) */
-  float   reserved;
+  int32_t occur;          /* 0: SHOULD; 1: MUST (BooleanClause.Occur, QueryNodeMapper.java:257-283).  Every clause MUST: the
+                           * conjunction (all clauses match, score = (float) of the double sum -- ConjunctionScorer), the same as
+                           * min_should_match = n_terms over SHOULD clauses.  MUST next to SHOULD clauses (min_should_match 0):
+                           * a hit matches every MUST clause and scores (float) sum of the MUST scores + (float) sum of its
+                           * matching SHOULD scores, the two added in float (ReqOptSumScorer [Lucene-recall]); MaxScore route
+                           * only (<= 8 clauses, fixed-point sums, not ScoreMode.COMPLETE on a large query), else
+                           * NRTGPU_ERR_UNSUPPORTED; with min_should_match > 0 or disjunction_max: NRTGPU_ERR_UNSUPPORTED */
 } nrtgpu_term;
 
 typedef struct {
@@ -180,20 +186,25 @@ typedef struct {
                                     * or "+(should clauses) #filter" -- either way a hit matches >= 1 scoring
                                     * clause and the filter adds nothing to the score */
   int32_t must_not_mask;           /* 0 = none; else hits must NOT lie in this mask (MUST_NOT clause) */
-  int32_t disjunction_max;         /* 0: BooleanQuery of SHOULD clauses, a doc scores the sum of its matching clauses.
-                                    * 1: DisjunctionMaxQuery over the same term clauses with tieBreakerMultiplier 0
-                                    * (src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:350-358; the
-                                    * reference's own test uses 0, src/test/java/com/yelp/nrtsearch/server/grpc/
-                                    * QueryTest.java:541-583): a doc scores its BEST matching clause.  Exhaustive route,
-                                    * fixed-point accumulators for the whole batch (else NRTGPU_ERR_UNSUPPORTED),
-                                    * min_should_match <= 1; a tie breaker > 0 or disjuncts that are not term queries
-                                    * stay on the caller's path; not accepted by nrtgpu_search_bm25_coalesced */
+  int32_t disjunction_max;         /* 0: BooleanQuery, a doc scores the sum of its matching clauses.
+                                    * 1: DisjunctionMaxQuery over the same term clauses (src/main/java/com/yelp/nrtsearch/
+                                    * server/query/QueryNodeMapper.java:350-358): a doc scores its BEST matching clause plus
+                                    * tie_breaker x the others.  Fixed-point accumulators for the whole batch (else
+                                    * NRTGPU_ERR_UNSUPPORTED), min_should_match <= 1, every clause SHOULD; disjuncts that are
+                                    * not term queries stay on the caller's path; not accepted by
+                                    * nrtgpu_search_bm25_coalesced */
   int32_t n_more_filters;          /* further FILTER clauses next to filter_mask (QueryNodeMapper.java:257-283 builds any number): */
   const int32_t* more_filters;     /* ... resident mask ids > 0; a hit lies in ALL of the query's filter masks */
   int32_t n_more_must_not;         /* further MUST_NOT clauses next to must_not_mask: */
   const int32_t* more_must_not;    /* ... resident mask ids > 0; a hit lies in NONE of the query's must_not masks.  The masks are
                                     * combined at plan time (one AND / AND NOT pass over 64-bit words per leaf and combination,
                                     * cached on the segment like a single pair); n_more_* = 0: the arrays are not read */
+  float   tie_breaker;             /* DisjunctionMaxQuery.tieBreakerMultiplier, 0..1 (disjunction_max = 1 only, else 0): the score
+                                    * is (float)(scoreMax + otherScoreSum * tieBreaker) in double, as DisjunctionMaxScorer
+                                    * computes it [Lucene-recall]; 0 is what the reference's own test uses (src/test/java/com/
+                                    * yelp/nrtsearch/server/grpc/QueryTest.java:541-583).  > 0: MaxScore route only (see
+                                    * nrtgpu_term.occur), else NRTGPU_ERR_UNSUPPORTED */
+  int32_t reserved;
 } nrtgpu_bm25_query;
 
 typedef struct {

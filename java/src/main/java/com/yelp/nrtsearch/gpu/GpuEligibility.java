@@ -21,21 +21,22 @@ import org.apache.lucene.search.similarities.Similarity;
 
 /**
  * The eligibility predicate of SURVEY 8b, Java half: recognise the shapes the native planner takes -- a (boosted)
- * TermQuery, a BooleanQuery of SHOULD (boosted) TermQuery clauses with at most one FILTER and one MUST_NOT clause next to them
+ * TermQuery, a BooleanQuery of SHOULD and / or MUST (boosted) TermQuery clauses with FILTER and MUST_NOT clauses next to them
  * (built at query/QueryNodeMapper.java:257-283,360-395; the non-scoring clauses become resident doc-set masks: GpuMaskCache) or a
- * DisjunctionMaxQuery over such term queries with tie breaker 0 (QueryNodeMapper.java:350-358),
+ * DisjunctionMaxQuery over such term queries with any tie breaker (QueryNodeMapper.java:350-358),
  * collected by a plain RelevanceCollector (search/collectors/RelevanceCollector.java:42-69) -- and marshal them into a
  * nrtgpu_bm25_query.  Whatever remains (clause counts, fields, fixed-point range, resident masks ...) is decided by the
  * library itself (nrtgpu_query_supported / NRTGPU_ERR_UNSUPPORTED), so this class carries no limits of its own.
  * NOT COMPILED here (no JDK).
  */
 final class GpuEligibility {
-  record Clause(Term term, float boost) {}
+  /** occur: 0 = SHOULD, 1 = MUST (nrtgpu_term.occur) */
+  record Clause(Term term, float boost, int occur) {}
 
   /** The flattened query: scoring clauses, minimumNumberShouldMatch, DisjunctionMaxQuery?, and the non-scoring clauses -- any
    *  number of FILTER and MUST_NOT clauses, each a resident mask of its own (cached per clause like LRUQueryCache caches its
    *  DocIdSet); the library ANDs / AND-NOTs them at plan time (nrtgpu_bm25_query.more_filters / more_must_not). */
-  record Shape(List<Clause> clauses, int minShouldMatch, int disjunctionMax, List<Query> filters, List<Query> mustNots) {}
+  record Shape(List<Clause> clauses, int minShouldMatch, int disjunctionMax, float tieBreaker, List<Query> filters, List<Query> mustNots) {}
 
   /** The collector behind the manager handed to search(), the request's timeoutSec (0 = none) and the wrapper that enforces it
    *  on the reference's path (null = none): a timeout on the device route is reported THROUGH it (GpuIndexSearcher.timedOut). */
@@ -69,13 +70,14 @@ final class GpuEligibility {
   static Shape shape(Query q) {
     List<Clause> out = new ArrayList<>();
     if (q instanceof DisjunctionMaxQuery dm) {                         // QueryNodeMapper.java:350-358
-      if (dm.getTieBreakerMultiplier() != 0f) return null;            // the device keeps the best clause only
+      float tb = dm.getTieBreakerMultiplier();                        // (float)(best + tieBreaker x the others): the kernel's second accumulator
+      if (!(tb >= 0f && tb <= 1f)) return null;
       for (Query d : dm.getDisjuncts()) {
-        Clause cl = term(d, 1f);
+        Clause cl = term(d, 1f, 0);
         if (cl == null) return null;                                  // disjuncts that are not (boosted) term queries
         out.add(cl);
       }
-      return out.isEmpty() ? null : new Shape(out, 0, 1, List.of(), List.of());
+      return out.isEmpty() ? null : new Shape(out, 0, 1, tb, List.of(), List.of());
     }
     if (q instanceof BooleanQuery bq) {
       List<Query> filters = new ArrayList<>(), mustNots = new ArrayList<>();
@@ -83,7 +85,7 @@ final class GpuEligibility {
       for (BooleanClause c : bq.clauses()) {
         switch (c.occur()) {
           case SHOULD, MUST -> {                                       // MUST term clauses: every one required (MatchQuery operator MUST)
-            Clause cl = term(c.query(), 1f);
+            Clause cl = term(c.query(), 1f, c.occur() == BooleanClause.Occur.MUST ? 1 : 0);
             if (cl == null) return null;
             out.add(cl);
             if (c.occur() == BooleanClause.Occur.MUST) must++;
@@ -94,22 +96,25 @@ final class GpuEligibility {
       }
       if (out.isEmpty()) return null;                                 // filter-only queries score 0 for every match: Lucene's business
       if (filters.size() > NrtGpu.MAX_MASKS || mustNots.size() > NrtGpu.MAX_MASKS) return null;
-      // mixed MUST / SHOULD: ReqOptSumScorer adds (float) required + (float) optional -- two separately rounded sums, not the one
-      // exact sum the device holds per doc -- the caller's path
-      if (must != 0 && must != out.size()) return null;
-      int msm = must != 0 ? out.size() : bq.getMinimumNumberShouldMatch();
+      // mixed MUST / SHOULD: ReqOptSumScorer adds (float) required + (float) optional -- two separately rounded sums: the clauses
+      // carry their occur and the kernel a second accumulator; with minimumNumberShouldMatch > 0 Lucene scores the SHOULD part as
+      // one more required scorer of a conjunction (another sum structure): the caller's path
+      boolean mixed = must != 0 && must != out.size();
+      if (mixed && bq.getMinimumNumberShouldMatch() > 0) return null;
+      int msm = mixed ? 0 : (must != 0 ? out.size() : bq.getMinimumNumberShouldMatch());
+      if (!mixed) out.replaceAll(cl -> new Clause(cl.term(), cl.boost(), 0));   // all MUST == minimumNumberShouldMatch = n over SHOULD clauses
       if (!filters.isEmpty() && must == 0 && msm == 0) return null;   // SHOULD clauses next to a FILTER are optional: filter-only docs match with score 0
-      return new Shape(out, msm, 0, filters, mustNots);
+      return new Shape(out, msm, 0, 0f, filters, mustNots);
     }
-    Clause cl = term(q, 1f);
+    Clause cl = term(q, 1f, 0);
     if (cl == null) return null;
     out.add(cl);
-    return new Shape(out, 0, 0, List.of(), List.of());
+    return new Shape(out, 0, 0, 0f, List.of(), List.of());
   }
 
-  private static Clause term(Query q, float boost) {
-    if (q instanceof BoostQuery b) return term(b.getQuery(), boost * b.getBoost());   // QueryNodeMapper.java:131-133
-    if (q instanceof TermQuery t) return new Clause(t.getTerm(), boost);
+  private static Clause term(Query q, float boost, int occur) {
+    if (q instanceof BoostQuery b) return term(b.getQuery(), boost * b.getBoost(), occur);   // QueryNodeMapper.java:131-133
+    if (q instanceof TermQuery t) return new Clause(t.getTerm(), boost, occur);
     return null;
   }
 
@@ -162,6 +167,7 @@ final class GpuEligibility {
       t.set(JAVA_INT, NrtGpuLayouts.TERM_CACHE_SLOT, fields.indexOf(c.term().field()));
       t.set(JAVA_LONG, NrtGpuLayouts.TERM_TERM_HASH, GpuSegmentStore.termHash(c.term().bytes()));
       t.set(JAVA_FLOAT, NrtGpuLayouts.TERM_WEIGHT, c.boost() * idf);
+      t.set(JAVA_INT, NrtGpuLayouts.TERM_OCCUR, c.occur());
     }
     MemorySegment cache = a.allocate(JAVA_FLOAT, fields.size() * 256L);
     for (int f = 0; f < fields.size(); f++) {
@@ -196,6 +202,7 @@ final class GpuEligibility {
       q.set(ADDRESS, NrtGpuLayouts.QUERY_MORE_MUST_NOT, more);
     }
     q.set(JAVA_INT, NrtGpuLayouts.QUERY_DISJUNCTION_MAX, disjunctionMax);
+    q.set(JAVA_FLOAT, NrtGpuLayouts.QUERY_TIE_BREAKER, shape.tieBreaker());
     MemorySegment docs = a.allocate(JAVA_INT, k), scores = a.allocate(JAVA_FLOAT, k), out = a.allocate(NrtGpu.TOPDOCS);
     out.set(JAVA_INT, NrtGpuLayouts.TOPDOCS_CAPACITY, k);
     out.set(ADDRESS, NrtGpuLayouts.TOPDOCS_DOCS, docs);

@@ -26,10 +26,10 @@ final class NrtGpu {
     return L.downcallHandle(LIB.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), d);
   }
 
-  // typedef struct { int32 field_id, cache_slot; int64 term_hash; float weight, reserved; } nrtgpu_term;
+  // typedef struct { int32 field_id, cache_slot; int64 term_hash; float weight; int32 occur; } nrtgpu_term;
   static final StructLayout TERM =
       MemoryLayout.structLayout(JAVA_INT.withName("field_id"), JAVA_INT.withName("cache_slot"), JAVA_LONG.withName("term_hash"),
-          JAVA_FLOAT.withName("weight"), JAVA_FLOAT.withName("reserved"));
+          JAVA_FLOAT.withName("weight"), JAVA_INT.withName("occur"));
   // nrtgpu_bm25_query
   static final StructLayout QUERY =
       MemoryLayout.structLayout(JAVA_INT.withName("n_terms"), MemoryLayout.paddingLayout(4), ADDRESS.withName("terms"),
@@ -38,7 +38,8 @@ final class NrtGpu {
           JAVA_FLOAT.withName("after_score"), JAVA_INT.withName("min_should_match"), JAVA_FLOAT.withName("min_competitive_score"),
           JAVA_INT.withName("filter_mask"), JAVA_INT.withName("must_not_mask"), JAVA_INT.withName("disjunction_max"),
           JAVA_INT.withName("n_more_filters"), MemoryLayout.paddingLayout(4), ADDRESS.withName("more_filters"),
-          JAVA_INT.withName("n_more_must_not"), MemoryLayout.paddingLayout(4), ADDRESS.withName("more_must_not"));
+          JAVA_INT.withName("n_more_must_not"), MemoryLayout.paddingLayout(4), ADDRESS.withName("more_must_not"),
+          JAVA_FLOAT.withName("tie_breaker"), JAVA_INT.withName("reserved"));
   // nrtgpu_topdocs
   static final StructLayout TOPDOCS =
       MemoryLayout.structLayout(JAVA_INT.withName("n_hits"), JAVA_INT.withName("capacity"), ADDRESS.withName("docs"),

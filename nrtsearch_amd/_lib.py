@@ -57,7 +57,7 @@ class Config(C.Structure):
 
 class Term(C.Structure):
     _fields_ = [("field_id", C.c_int32), ("cache_slot", C.c_int32), ("term_hash", C.c_int64),
-                ("weight", C.c_float), ("reserved", C.c_float)]
+                ("weight", C.c_float), ("occur", C.c_int32)]   # occur: 0 SHOULD, 1 MUST
 
 
 class Bm25Query(C.Structure):
@@ -67,7 +67,8 @@ class Bm25Query(C.Structure):
                 ("min_should_match", C.c_int32), ("min_competitive_score", C.c_float), ("filter_mask", C.c_int32),
                 ("must_not_mask", C.c_int32), ("disjunction_max", C.c_int32),
                 ("n_more_filters", C.c_int32), ("more_filters", C.POINTER(C.c_int32)),
-                ("n_more_must_not", C.c_int32), ("more_must_not", C.POINTER(C.c_int32))]
+                ("n_more_must_not", C.c_int32), ("more_must_not", C.POINTER(C.c_int32)),
+                ("tie_breaker", C.c_float), ("reserved", C.c_int32)]
 
 
 class TopDocs(C.Structure):

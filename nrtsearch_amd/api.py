@@ -71,7 +71,7 @@ class BooleanQuery:
 @dataclasses.dataclass(frozen=True)
 class DisjunctionMaxQuery:
     """DisjunctionMaxQuery over (boosted) term queries (S/query/QueryNodeMapper.java:350-358): a doc scores its best
-    disjunct plus tie_breaker_multiplier x the others.  The device route takes tie_breaker_multiplier == 0."""
+    disjunct plus tie_breaker_multiplier x the others (0..1)."""
 
     disjuncts: Tuple[Union[TermQuery, BoostQuery], ...] = ()
     tie_breaker_multiplier: float = 0.0
@@ -362,22 +362,20 @@ def _unsupported(msg: str):
     raise UnsupportedQuery(msg)
 
 
-def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, List[int], List[int], int]:
-    """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost)], msm,
+def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float, int]], int, List[int], List[int], int, float]:
+    """Eligibility predicate of SURVEY 8b on the rewritten query -> [(field, term, boost, occur: 0 SHOULD / 1 MUST)], msm,
     filter mask ids, must_not mask ids (any number of FILTER / MUST_NOT clauses: the library combines their masks at plan
-    time), disjunction_max (1: best clause instead of the sum)."""
-    def one(q) -> Tuple[int, int, float]:
+    time), disjunction_max (1: best clause + tie breaker x the others instead of the sum), tie breaker."""
+    def one(q, occur: int = 0) -> Tuple[int, int, float, int]:
         if isinstance(q, TermQuery):
-            return (q.field, q.term, 1.0)
+            return (q.field, q.term, 1.0, occur)
         if isinstance(q, BoostQuery) and isinstance(q.query, TermQuery):
-            return (q.query.field, q.query.term, float(q.boost))
+            return (q.query.field, q.query.term, float(q.boost), occur)
         raise UnsupportedQuery(f"clause {q!r} is not a (boosted) TermQuery")
 
     def dismax(q: DisjunctionMaxQuery):
-        if q.tie_breaker_multiplier != 0.0:
-            # (float)(scoreMax + otherScoreSum * tieBreaker) needs the best clause AND the sum of the others per doc: a second
-            # accumulator the kernel does not carry -- the caller's path
-            raise UnsupportedQuery("DisjunctionMaxQuery with a tie breaker")
+        if not 0.0 <= q.tie_breaker_multiplier <= 1.0:
+            raise UnsupportedQuery("DisjunctionMaxQuery with a tie breaker outside [0, 1]")
         if not q.disjuncts:
             raise UnsupportedQuery("empty DisjunctionMaxQuery")
         return [one(c) for c in q.disjuncts]
@@ -390,13 +388,13 @@ def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, List[int]
         return [c.mask_id for c in q.filter], [c.mask_id for c in q.must_not]
 
     if isinstance(query, DisjunctionMaxQuery):
-        return dismax(query), 0, [], [], 1
+        return dismax(query), 0, [], [], 1, float(query.tie_breaker_multiplier)
     if isinstance(query, BooleanQuery) and len(query.must) == 1 and isinstance(query.must[0], DisjunctionMaxQuery):
         # "+dismax #filter -must_not": one scoring clause, the masks add nothing to the score
         if query.should:
             raise UnsupportedQuery("a DisjunctionMaxQuery next to SHOULD clauses")
         f, mn = masks(query)
-        return dismax(query.must[0]), 0, f, mn, 1
+        return dismax(query.must[0]), 0, f, mn, 1, float(query.must[0].tie_breaker_multiplier)
     if isinstance(query, BooleanQuery):
         f, mn = masks(query)
         if query.must:
@@ -404,16 +402,18 @@ def _flatten(query: Query) -> Tuple[List[Tuple[int, int, float]], int, List[int]
             # (ConjunctionScorer: double sum, one cast): the disjunction with minimumNumberShouldMatch = n
             if query.should:
                 # ReqOptSumScorer returns (float)required + (float)optional -- two separately rounded sums added in float
-                # [Lucene-recall] -- not the one exact sum the kernel's accumulator holds: the caller's path
-                raise UnsupportedQuery("MUST and SHOULD term clauses mixed")
-            return [one(c) for c in query.must], len(query.must), f, mn, 0
+                # [Lucene-recall]: the clauses carry their occur, the kernel a second accumulator (plan.h: kMsSecReqOpt)
+                if query.minimum_number_should_match > 0:   # (Lucene then scores the SHOULD part as one more required scorer)
+                    raise UnsupportedQuery("MUST clauses next to minimumNumberShouldMatch > 0")
+                return [one(c, 1) for c in query.must] + [one(c, 0) for c in query.should], 0, f, mn, 0, 0.0
+            return [one(c) for c in query.must], len(query.must), f, mn, 0, 0.0
         if not query.should:
             raise UnsupportedQuery("empty BooleanQuery")
         if query.filter and query.minimum_number_should_match < 1:
             # with a FILTER clause Lucene makes the SHOULD clauses optional: filter-only docs would be hits of score 0
             raise UnsupportedQuery("FILTER with minimumNumberShouldMatch = 0")
-        return [one(c) for c in query.should], query.minimum_number_should_match, f, mn, 0
-    return [one(query)], 0, [], [], 0
+        return [one(c) for c in query.should], query.minimum_number_should_match, f, mn, 0, 0.0
+    return [one(query)], 0, [], [], 0, 0.0
 
 
 class _Marshalled:
@@ -446,10 +446,10 @@ class GpuIndexSearcher:
     def _marshal(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager]) -> _Marshalled:
         m = _Marshalled(len(queries))
         for qi, (query, mgr) in enumerate(zip(queries, managers)):
-            clauses, msm, filters, must_nots, dis_max = _flatten(query)
+            clauses, msm, filters, must_nots, dis_max, tie_breaker = _flatten(query)
             fields: List[int] = []
             terms = (_lib.Term * len(clauses))()
-            for ti, (field, term, boost) in enumerate(clauses):
+            for ti, (field, term, boost, occur) in enumerate(clauses):
                 if field not in self.stats.fields:
                     raise UnsupportedQuery(f"no statistics for field {field}")
                 if field not in fields:
@@ -457,7 +457,7 @@ class GpuIndexSearcher:
                 df = self.stats.doc_freq.get((field, term), 0)
                 cs = self.stats.fields[field]
                 w = np.float32(np.float32(boost) * self.similarity.idf(df, cs.doc_count)) if df > 0 else np.float32(0)
-                terms[ti] = _lib.Term(field, fields.index(field), term, float(w), 0.0)
+                terms[ti] = _lib.Term(field, fields.index(field), term, float(w), int(occur))
             cache = np.concatenate([self._norm_cache(f) for f in fields]).astype(np.float32)
             m.keep += [terms, cache]
             q = m.queries[qi]
@@ -475,6 +475,7 @@ class GpuIndexSearcher:
             q.filter_mask = int(filters[0]) if filters else 0
             q.must_not_mask = int(must_nots[0]) if must_nots else 0
             q.disjunction_max = int(dis_max)
+            q.tie_breaker = float(np.float32(tie_breaker))
             for ids, n_name, p_name in ((filters[1:], "n_more_filters", "more_filters"), (must_nots[1:], "n_more_must_not", "more_must_not")):
                 if ids:   # further FILTER / MUST_NOT clauses: the library ANDs / AND-NOTs their masks at plan time
                     arr = (C.c_int32 * len(ids))(*[int(x) for x in ids])

@@ -637,7 +637,7 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
     const uint32_t my_delta16 = PACKED ? 0xFFFFFFFFu : (uint32_t)(((uint64_t)mt.fnorm - (uint64_t)mt.docids) >> 4);  // same allocation
     const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
     const uint32_t my_shift = mt.shift;
-    const uint32_t my_flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | ((mt.shift != 0 ? 1u : 0u) << 3) |
+    const uint32_t my_flags = ((mt.tab_slot & 0xFFFFu) < (uint32_t)kTabTerms ? (mt.tab_slot & 0xFFFFu) : 7u) | ((mt.shift != 0 ? 1u : 0u) << 3) |
                               ((FX ? mt.fx_shift : 0u) << 4);
     const bool has_term = lane < n_terms;
 

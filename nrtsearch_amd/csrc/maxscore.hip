@@ -59,7 +59,7 @@ struct alignas(16) WClause {
   uint32_t count, pad0;     // ... and how many
   float    weight;
   int32_t  fx_scale;
-  uint32_t flags;           // score table (0-2, 7 = none) | fx_shift << 4 | normInverse table << 8 | cell shift << 16
+  uint32_t flags;           // score table (0-2, 7 = none) | MUST clause << 3 | fx_shift << 4 | normInverse table << 8 | cell shift << 16
   uint32_t pad;
   uint64_t u_after;         // what the later clauses can add at most: S_{c+1}
   uint64_t bits;            // membership + rank records, 0 = sparse clause
@@ -296,9 +296,20 @@ __device__ __forceinline__ bool ms_reserve(MsSmem& s, uint32_t lane, uint32_t mi
 //     competitive however many of them it matches;
 //   * DisjunctionMaxQuery: a doc scores its BEST clause -- `max` where the sum has `+`, and the clauses after c can lift a
 //     doc to max(ub_c+1 ..) instead of their sum.
-template <bool PROF, bool PACKED, bool SHAPES>
+// SHAPES == 2: some query's score is not ONE sum (plan.h: kMsSec*) -- a DisjunctionMaxQuery with a tie breaker > 0
+//   (QueryNodeMapper.java:350-358), MUST next to SHOULD clauses (:257-283).  Every posting slot carries a SECOND accumulator
+//   (sec[]: the best clause / the SHOULD clauses' sum) that enters the doc's final key only:
+//     (float)(best + (sum - best) * tieBreaker) in double -- DisjunctionMaxScorer;  (float)mustSum + (float)shouldSum --
+//     ReqOptSumScorer [Lucene-recall].  Both are at most what the plain sum scores (tieBreaker <= 1; the two-float addition up
+//     to 2 ulp, which its thresholds are lowered by: loosen()), so every bound of the walk stays a bound.
+//   MUST clauses: a doc first reached at clause c lacks every streamed clause before c -- a MUST clause among them and it is
+//   no hit; clauses behind the first MUST clause start no doc and are never streamed; a MUST clause whose lookup misses ends
+//   the doc.  (A leaf that lacks a MUST term is not planned at all.)
+//   Sixteen more registers than the kernel has: this instantiation spills inside the walk, the other two are untouched.
+template <bool PROF, bool PACKED, int SHAPES>
 __global__ __launch_bounds__(kMsThreads)
 void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
+  constexpr bool TWO = SHAPES == 2;
   __shared__ MsSmem s;
   // The launch record (plan.h: MsArgs) lives next to the plan; ONE pointer is the kernel's argument.  Its fields are scalar loads
   // made where they are used -- the workgroup's round, then once more in front of the item's epilogue (ms_fresh: the compiler
@@ -435,7 +446,11 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
     // publishes a min competitive score.  theta filters the candidates in every mode.
     const uint32_t mode = item.flags & 3u;
     const uint32_t msm = SHAPES ? q.min_should_match : 0u;   // (> 1: clause counting)
-    const bool use_max = SHAPES && q.combine_max != 0u;       // DisjunctionMaxQuery
+    const bool use_max = SHAPES && q.combine_max != 0u;       // DisjunctionMaxQuery, tie breaker 0
+    const uint32_t sec_mode = TWO ? q.sec_mode : kMsSecNone;  // (uniform) what the second accumulator holds
+    const float tie_breaker = TWO ? q.tie_breaker : 0.0f;
+    // kMsSecReqOpt: (float)a + (float)b may exceed (float)(a + b) by 2 float ulps: sums are compared with a threshold 2^-21 lower
+    auto loosen = [&](uint64_t t) { return (TWO && sec_mode == kMsSecReqOpt) ? max(t - (t >> 21), 2ull) - 1ull : t; };
     unsigned int* const my_prune_g = as_global(ap->q_prune) + item.query;    // set by the first item of the query whose slice passed the floor
     const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
 
@@ -579,7 +594,8 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         w.count = w.pad0 = 0;
         w.weight = mt.weight;
         w.fx_scale = mt.fx_scale;
-        w.flags = (mt.tab_slot < (uint32_t)kTabTerms ? mt.tab_slot : 7u) | (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
+        w.flags = ((mt.tab_slot & 0xFFFFu) < (uint32_t)kTabTerms ? (mt.tab_slot & 0xFFFFu) : 7u) | (TWO && (mt.tab_slot & kTabSlotRequired) ? 8u : 0u) |
+                  (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
         w.pad = 0;
         w.u_after = my_after;
         w.bits = (uint64_t)mt.aux->bits;
@@ -587,6 +603,9 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         w.start = mt.start;
         wcl[lane] = w;
       }
+      // (uniform) the part's MUST clauses, bit c = clause c; first_req: the last clause that may start a doc
+      const uint32_t req_mask = TWO ? (uint32_t)__builtin_amdgcn_ballot_w64(lane < n_terms && (mt.tab_slot & kTabSlotRequired) != 0u) : 0u;
+      const uint32_t first_req = req_mask != 0u ? (uint32_t)__builtin_ctz(req_mask) : 0xFFu;
       if (PROF) tc_part += __builtin_readcyclecounter() - t_part0;
 
       for (;;) {  // windows of this part
@@ -624,12 +643,12 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         // instruction instead of taking one each.  Clause c's groups come before clause c + 1's.
         uint32_t ng = 0;
         {
-          const uint64_t thr_w = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? max(s.thr, thr_other) : 0ull;
+          const uint64_t thr_w = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? loosen(max(s.thr, thr_other)) : 0ull;
           const uint64_t pb = mt.start + my_lo, pe = mt.start + my_hi;
           if (lane < n_terms) {
             // (minimumNumberShouldMatch: a doc is evaluated at the first clause that holds it, so one first met at clause c matches
             //  at most n_terms - c clauses: the last msm - 1 clauses cannot start a hit and are never streamed)
-            if (my_suf >= thr_w && pe > pb && (!SHAPES || msm <= 1u || lane + msm <= n_terms)) ng = (uint32_t)((pe - (pb & ~3ull) + (uint64_t)(kSl - 1)) / (uint64_t)kSl);
+            if (my_suf >= thr_w && pe > pb && (!SHAPES || msm <= 1u || lane + msm <= n_terms) && (!TWO || lane <= first_req)) ng = (uint32_t)((pe - (pb & ~3ull) + (uint64_t)(kSl - 1)) / (uint64_t)kSl);
             *(u32x4*)&wcl[lane].begin = u32x4{(uint32_t)pb, (uint32_t)(pb >> 32), (uint32_t)(pe - pb), 0u};
           }
         }
@@ -655,7 +674,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
           const uint32_t c_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
           // theta as of now (it only grows: a stale value costs work, never a result).  Has it passed what this
           // instruction's first clause and everything after it can reach?  Then the rest of the window is non-essential.
-          const uint64_t theta = max(s.theta, theta_other), thr = max(s.thr, thr_other);
+          const uint64_t theta = max(s.theta, theta_other), thr = loosen(max(s.thr, thr_other));
           const bool pruning = __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;   // (uniform)
           const uint64_t thr_p = pruning ? thr : 0ull;   // what the bounds are compared with
           if (readlane_u64(my_suf, c_first) < thr_p) break;
@@ -764,6 +783,14 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
               for (int j = 0; j < kSl; ++j)
                 if ((use_max ? max(run[j], u_after) : run[j] + u_after) < thr_p) alive &= ~(1u << j);
             }
+          }
+          uint64_t sec[TWO ? kSl : 1];
+          if (TWO) {
+            // a doc first reached at clause c is in no streamed clause before c: a MUST clause among them and it is no hit
+            if ((req_mask & ((1u << c) - 1u)) != 0u) alive = 0u;
+            const bool mine_counts = sec_mode == kMsSecTieBreaker || (sec_mode == kMsSecReqOpt && ((req_mask >> c) & 1u) == 0u);
+  #pragma unroll
+            for (int j = 0; j < kSl; ++j) sec[j] = mine_counts ? run[j] : 0ull;
           }
           if (PROF) {
             pc_post += (uint64_t)__popc(vmask);
@@ -966,7 +993,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
               am &= ~kill;
             }
             if (!__any(am != 0u)) continue;
-            if (kMsCollapse) {
+            if (kMsCollapse && !TWO) {
               // few docs of the instruction left: dealt out one per lane, the rest of the instruction runs on rows
               const uint32_t n_left = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp((uint32_t)__popc(alive)), 63);
               if (n_left <= 63u) {
@@ -1075,6 +1102,14 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
               if (use_max) {   // (uniform)
   #pragma unroll
                 for (int j = 0; j < kSl; ++j) run[j] = max(run[j], (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2);
+              } else if (TWO && sec_mode != kMsSecNone) {   // (uniform) the sum, and the best clause / the SHOULD clauses' sum next to it
+                const bool counts = sec_mode == kMsSecReqOpt && (flags2 & 8u) == 0u;
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) {
+                  const uint64_t add = (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;
+                  run[j] += add;
+                  sec[j] = sec_mode == kMsSecTieBreaker ? max(sec[j], add) : sec[j] + (counts ? add : 0ull);
+                }
               } else {
   #pragma unroll
                 for (int j = 0; j < kSl; ++j) run[j] += (uint64_t)(((present >> j) & 1u) ? v2[j] : 0u) * (uint64_t)mult2;  // v_mad_u64_u32
@@ -1087,6 +1122,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                 ccnt += x;
               }
             }
+            if (TWO && (flags2 & 8u) != 0u) alive &= ~(am & ~present);   // (uniform) a MUST clause the doc lacks: no hit
             NRT_PH_MARK(6);
           }
 
@@ -1139,15 +1175,21 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
             if (PROF) pc_crounds += 1;
   #endif
             const uint32_t low = maybe & (0u - maybe);  // my lowest pending posting
-            uint64_t rsel = run[0];
+            uint64_t rsel = run[0], ssel = TWO ? sec[0] : 0ull;
             uint32_t dsel = d[0];
   #pragma unroll
             for (int j = 1; j < kSl; ++j)
               if (low == (1u << j)) {
                 rsel = run[j];
                 dsel = d[j];
+                if (TWO) ssel = sec[j];
               }
-            const uint64_t key = pack_key(acc_score<true>(rsel, fx_E), (uint32_t)(part.doc_base + (int32_t)dsel));
+            float score = acc_score<true>(rsel, fx_E);
+            if (TWO && sec_mode == kMsSecTieBreaker)        // DisjunctionMaxScorer.score(): (float)(scoreMax + otherScoreSum * tieBreaker), doubles
+              score = (float)(ldexp((double)ssel, -fx_E) + ldexp((double)(rsel - ssel), -fx_E) * (double)tie_breaker);
+            else if (TWO && sec_mode == kMsSecReqOpt)       // ReqOptSumScorer.score(): req.score() + opt.score(), floats (an absent opt adds 0.0f)
+              score = acc_score<true>(rsel - ssel, fx_E) + acc_score<true>(ssel, fx_E);
+            const uint64_t key = pack_key(score, (uint32_t)(part.doc_base + (int32_t)dsel));
             const bool want = low != 0u && key > theta_now && key < after_key;
             uint32_t pos = 0;
             if (!__any(want)) {
@@ -1365,7 +1407,7 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, const MsArgs& args, const MsArgs* args_d) {
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int shapes, const MsArgs& args, const MsArgs* args_d) {
   const uint32_t n_items = args.help.n_own;
   if (n_items == 0) return;
   // (args: the host's copy of *args_d, the record the kernel reads)
@@ -1374,8 +1416,9 @@ void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool sh
 #define NRT_MS_LAUNCH(P, K, S) hipLaunchKernelGGL((bm25_maxscore_kernel<P, K, S>), dim3(grid), dim3(kMsThreads), 0, stream, args_d)
 #define NRT_MS_LAUNCH_S(P, K)          \
   do {                                 \
-    if (shapes) NRT_MS_LAUNCH(P, K, true); \
-    else NRT_MS_LAUNCH(P, K, false);   \
+    if (shapes == 2) NRT_MS_LAUNCH(P, K, 2);      \
+    else if (shapes == 1) NRT_MS_LAUNCH(P, K, 1); \
+    else NRT_MS_LAUNCH(P, K, 0);                  \
   } while (0)
   if (profile) {
     if (packed) NRT_MS_LAUNCH_S(true, true);

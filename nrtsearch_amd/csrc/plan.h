@@ -70,7 +70,7 @@ struct alignas(16) DTerm {
   uint32_t shift;            // cell = tile >> shift (0 for dense terms: one cell per tile)
   float    weight;           // boost * idf
   uint32_t cache_slot;       // per-query normInverse table index (< kLdsCaches)
-  uint32_t tab_slot;         // score table of this term in the item's LDS (< kTabTerms) or 0xFFFFFFFF
+  uint32_t tab_slot;         // bits 0-15: score table of this term in the item's LDS (< kTabTerms) or kTabSlotNone; bit 16: MUST clause
   int32_t  fx_scale;         // fixed-point batches: the term's scores are integers < 2^32 after * 2^fx_scale ...
   uint32_t fx_shift;         // ... and enter the query's common scale 2^-fx_E shifted left by fx_shift
 };
@@ -194,7 +194,8 @@ struct alignas(16) DQuery {
   uint32_t gte_floor;         // max(totalHitsThreshold, numHits): a slice that collects more hits makes the relation
                               // GREATER_THAN_OR_EQUAL_TO (LazyQueueTopScoreDocCollector.java:176-199); ~0: never (ScoreMode.COMPLETE)
   uint32_t slice_base;        // the query's per-slice hit sums: slice_sum[slice_base + slice]
-  uint32_t pad[2];
+  uint32_t sec_mode;          // MaxScore kernel, SHAPES == 2: the doc's score needs a SECOND accumulator next to the sum (kMsSec*)
+  float    tie_breaker;       // kMsSecTieBreaker: DisjunctionMaxQuery.tieBreakerMultiplier
 };
 static_assert(sizeof(DQuery) == 48, "DQuery layout");
 // Hit counting (both scorers): an item counts the live matching docs of each searcher slice it touches (at most kSliceSlots
@@ -209,6 +210,15 @@ constexpr int kSliceSlots = 8;
 //                  totalHits has passed the threshold) -- exact counting until some slice's count passes gte_floor, from
 //                  then on bounds skip and the count is a lower bound (relation GREATER_THAN_OR_EQUAL_TO)
 constexpr uint32_t kMsModePrune = 0, kMsModeExact = 1, kMsModeCount = 2;
+// DQuery.sec_mode: scores that are not ONE sum of the matching clauses' scores.  The walk's bounds stay bounds of the plain sum
+// (either score is at most what the sum scores, up to the float rounding kMsSecReqOpt's threshold allows for); the second
+// accumulator only enters the final key.
+//   kMsSecTieBreaker : DisjunctionMaxQuery with a tie breaker > 0: second = the best clause; score = (float)(best + (sum - best) * tb)
+//   kMsSecReqOpt     : MUST next to SHOULD clauses: second = the sum of the SHOULD clauses; score = (float)(sum - second) + (float)second;
+//                      a doc that lacks a MUST clause (DTerm.tab_slot bit 16) is no hit
+constexpr uint32_t kMsSecNone = 0, kMsSecTieBreaker = 1, kMsSecReqOpt = 2;
+// DTerm.tab_slot: bits 0-15 the score table (0xFFFF: none), bit 16: a MUST clause
+constexpr uint32_t kTabSlotNone = 0xFFFFu, kTabSlotRequired = 1u << 16;
 // minimumNumberShouldMatch > 1: the fixed-point accumulator carries the number of matching clauses above
 // the score sum (sum < 2^52: 32 clauses x 2^32 x 2^15)
 constexpr int kMsmCountShift = 56;

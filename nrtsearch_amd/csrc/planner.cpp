@@ -18,6 +18,18 @@ int nrtgpu::rt::validate_query(const nrtgpu_bm25_query& q, int qi) {
   if (q.disjunction_max != 0 && q.disjunction_max != 1) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: disjunction_max must be 0 or 1", qi);
   if (q.disjunction_max == 1 && q.min_should_match > 1)
     return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: a DisjunctionMaxQuery has no minimumNumberShouldMatch", qi);
+  if (!(q.tie_breaker >= 0.0f && q.tie_breaker <= 1.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: tie_breaker must be in [0, 1]", qi);
+  if (q.tie_breaker != 0.0f && q.disjunction_max != 1) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: tie_breaker without disjunction_max", qi);
+  {
+    int n_must = 0;
+    for (int t = 0; t < q.n_terms; ++t) {
+      if (q.terms[t].occur != 0 && q.terms[t].occur != 1) return fail(NRTGPU_ERR_INVALID_ARG, "query %d term %d: occur must be 0 (SHOULD) or 1 (MUST)", qi, t);
+      n_must += q.terms[t].occur;
+    }
+    if (n_must != 0 && q.disjunction_max == 1) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: the disjuncts of a DisjunctionMaxQuery have no occur", qi);
+    if (n_must != 0 && q.min_should_match > 0)   // (Lucene then scores the SHOULD part as one more required scorer: another sum structure)
+      return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: MUST clauses next to minimumNumberShouldMatch > 0", qi);
+  }
   if (q.n_caches <= 0 || !q.norm_cache) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: norm_cache missing", qi);
   if (q.n_caches > kLdsCaches) return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: %d scored fields > %d", qi, q.n_caches, kLdsCaches);
   for (int t = 0; t < q.n_terms; ++t) {
@@ -36,6 +48,20 @@ int nrtgpu::rt::validate_query(const nrtgpu_bm25_query& q, int qi) {
   for (int i = 0; i < q.n_more_must_not; ++i)
     if (q.more_must_not[i] <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "query %d: more_must_not[%d] must be a mask id > 0", qi, i);
   return 0;
+}
+
+// What the clauses' occur flags mean for the scorers (nrtgpu.h: nrtgpu_term.occur): every clause MUST = the conjunction = the
+// disjunction with minimumNumberShouldMatch = n; MUST next to SHOULD = the second-accumulator shape kMsSecReqOpt.
+static int n_must_of(const nrtgpu_bm25_query& q) {
+  int n = 0;
+  for (int t = 0; t < q.n_terms; ++t) n += q.terms[t].occur;
+  return n;
+}
+static int effective_msm(const nrtgpu_bm25_query& q) { return n_must_of(q) == q.n_terms ? q.n_terms : q.min_should_match; }
+static uint32_t sec_mode_of(const nrtgpu_bm25_query& q) {
+  if (q.disjunction_max == 1 && q.tie_breaker > 0.0f) return kMsSecTieBreaker;
+  const int nm = n_must_of(q);
+  return nm > 0 && nm < q.n_terms ? kMsSecReqOpt : kMsSecNone;
 }
 
 // Cost model for cutting a query into work items: postings streamed + a per-tile constant for the
@@ -325,7 +351,8 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     int64_t lower = 0;
     uint8_t route = kRouteScan;
     if (prune != 0 && fx_ok && q.n_terms <= kMsMaxTerms && !(q.min_competitive_score > 0.0f)) {
-      const bool shaped = q.min_should_match > 1 || q.filter_mask != 0 || q.must_not_mask != 0 || q.n_more_filters != 0 || q.n_more_must_not != 0;
+      const bool shaped = effective_msm(q) > 1 || q.filter_mask != 0 || q.must_not_mask != 0 || q.n_more_filters != 0 || q.n_more_must_not != 0 ||
+                          sec_mode_of(q) == kMsSecReqOpt;   // (how many docs hold every MUST clause: nothing the posting counts say)
       if (q.total_hits_threshold == INT32_MAX) {
         int64_t all = 0;
         for (int t = 0; t < q.n_terms; ++t) all += term_total[(size_t)t];
@@ -399,15 +426,23 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     qx.by_weight = route != kRouteScan ? 1u : 0u;
     qx.pad = 0;
     const uint32_t* cnt_of[kMaxTerms];
+    bool req_of[kMaxTerms];
     uint32_t n_live = 0;
+    const bool req_opt = sec_mode_of(q) == kMsSecReqOpt;
+    bool no_hits = false;   // a MUST clause that matches nothing anywhere
     for (int t = 0; t < q.n_terms; ++t) {
       const TermLeaves& tl = *ents[(size_t)t];
-      if (tl.total <= 0) continue;
+      if (tl.total <= 0) {
+        no_hits = no_hits || (req_opt && q.terms[t].occur == 1);
+        continue;
+      }
+      req_of[n_live] = req_opt && q.terms[t].occur == 1;
       DQTerm d{};
       d.table = tl.d_table;
       d.weight = q.terms[t].weight;
       d.cache_slot = (uint32_t)q.terms[t].cache_slot;
-      d.tab_slot = tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : 0xFFFFFFFFu;
+      d.tab_slot = (tab_of_term[(size_t)t] >= 0 ? (uint32_t)tab_of_term[(size_t)t] : kTabSlotNone) |
+                   (sec_mode_of(q) == kMsSecReqOpt && q.terms[t].occur == 1 ? kTabSlotRequired : 0u);
       d.fx_scale = term_scale[(size_t)t];
       d.fx_shift = fx_ok ? (uint32_t)(fx_E - term_scale[(size_t)t]) : 0u;
       pc.qterms.push_back(d);
@@ -418,11 +453,14 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
     for (int si = 0; si < n_segs; ++si) {
       uint32_t n = 0;
       int64_t postings = 0;
+      bool lacks_must = no_hits;   // (a leaf without one of the MUST terms has no hits: it is not planned at all)
       for (uint32_t t = 0; t < n_live; ++t) {
         const uint32_t c = cnt_of[t][si];
         n += c != 0u ? 1u : 0u;
         postings += c;
+        lacks_must = lacks_must || (req_of[t] && c == 0u);
       }
+      if (lacks_must) n = 0;
       qs_begin[(size_t)qi * (size_t)n_segs + (size_t)si] = n ? pc.n_dterms : 0xFFFFFFFFu;
       if (n == 0) continue;
       pc.qs.push_back(QS{pc.n_dterms, n, si, postings});
@@ -547,9 +585,19 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // in the fixed-point accumulator, so the scan's whole launch must be in fixed-point mode; otherwise the caller runs Lucene
   hp.clause_counting = false;
   hp.ms_shapes = false;
+  hp.ms_two = false;
   for (int qi = 0; qi < n_queries; ++qi) {
     const nrtgpu_bm25_query& q = queries[qi];
-    if (q.min_should_match > 1 || q.disjunction_max == 1) (on_ms_kernel((uint32_t)qi) ? hp.ms_shapes : hp.clause_counting) = true;
+    if (effective_msm(q) > 1 || q.disjunction_max == 1) (on_ms_kernel((uint32_t)qi) ? hp.ms_shapes : hp.clause_counting) = true;
+    if (sec_mode_of(q) != kMsSecNone) {
+      // a second accumulator per doc: the MaxScore kernel's SHAPES == 2 instantiation carries one, the exhaustive scan's LDS
+      // accumulators do not
+      if (!on_ms_kernel((uint32_t)qi) && q_qs_cnt[(size_t)qi] != 0)
+        return fail(NRTGPU_ERR_UNSUPPORTED, "query %d: a tie breaker > 0 / MUST next to SHOULD clauses run on the MaxScore route only (<= %d clauses, "
+                                            "fixed-point sums, no min_competitive_score, not ScoreMode.COMPLETE over more than %lld postings)",
+                    qi, kMsMaxTerms, (long long)kMsExactMaxPostings);
+      hp.ms_two = true;
+    }
     if ((q.filter_mask != 0 || q.must_not_mask != 0 || q.n_more_filters != 0 || q.n_more_must_not != 0) && on_ms_kernel((uint32_t)qi)) hp.ms_shapes = true;
   }
   hp.n_slices = (uint32_t)n_slices;
@@ -758,12 +806,13 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     dq.after_score = q.after_score;
     dq.item_begin = hp.q_base[(size_t)qi];
     dq.n_items = hp.q_nlists[(size_t)qi];
-    dq.min_should_match = (uint32_t)std::max(q.min_should_match, 0);
-    dq.combine_max = q.disjunction_max == 1 ? 1u : 0u;
+    dq.min_should_match = (uint32_t)std::max(effective_msm(q), 0);
+    dq.sec_mode = sec_mode_of(q);
+    dq.tie_breaker = q.tie_breaker;
+    dq.combine_max = q.disjunction_max == 1 && dq.sec_mode == kMsSecNone ? 1u : 0u;   // (tie breaker 0: the best clause IS the score)
     // what a slice's hits must exceed for GREATER_THAN_OR_EQUAL_TO; COMPLETE mode: nothing does
     dq.gte_floor = q.total_hits_threshold == INT32_MAX ? 0xFFFFFFFFu : (uint32_t)std::max(q.total_hits_threshold, q.k);
     dq.slice_base = (uint32_t)qi * hp.n_slices;
-    dq.pad[0] = dq.pad[1] = 0;
   }
   if (plan_trace) {   // the items as a SET (order-free) and in launch order: two plans of one batch under different launch orders agree on the first
     uint64_t h_set = 0, h_order = 0;

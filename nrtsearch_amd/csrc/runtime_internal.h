@@ -40,7 +40,7 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
                       const DPart* parts, const DTerm* terms, const DQuery* queries, const float* caches, unsigned long long* theta_g,
                       unsigned long long* quant_g, const DExchange* xch, uint32_t* slice_sum, uint64_t* item_keys, uint32_t* item_counts,
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
-void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, bool shapes, const MsArgs& args, const MsArgs* args_d);
+void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int shapes, const MsArgs& args, const MsArgs* args_d);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
                           const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
@@ -593,6 +593,7 @@ struct HostPlan {
   bool clause_counting = false;     // exhaustive scan: some query has minimumNumberShouldMatch > 1 / is a DisjunctionMaxQuery: count-carrying variant
   bool masked = false;              // exhaustive scan: some part reads a doc-set mask (liveDocs / FILTER / MUST_NOT)
   bool ms_shapes = false;           // MaxScore route: some query has a FILTER / MUST_NOT mask, minimumNumberShouldMatch > 1 or is a DisjunctionMaxQuery
+  bool ms_two = false;              // MaxScore route: some query's score needs the second accumulator (plan.h: kMsSec*)
   uint32_t n_slices = 1;            // searcher slices over the call's leaves (MyIndexSearcher.slices): per query that many hit sums
   // MaxScore route (maxscore.hip): items [0, n_ms_items) run it, the others the exhaustive scan
   uint32_t n_ms_items = 0;

@@ -289,6 +289,68 @@ void nrt_oracle_search_segment_msm(int32_t max_doc, int32_t doc_base, const uint
   free(cursor);
 }
 
+/* BooleanQuery with MUST and SHOULD term clauses, minimumNumberShouldMatch 0 (QueryNodeMapper.java:257-283 adds clauses of any
+ * occur).  lucene-core 10.4.0 [Lucene-recall, SURVEY A]: BooleanScorerSupplier scores it with ReqOptSumScorer(req, opt):
+ *   req = the MUST clauses: one -> its TermScorer (the float itself); several -> ConjunctionScorer, score() = (float) of the
+ *         double sum of the sub scores;
+ *   opt = the SHOULD clauses: one -> its TermScorer; several -> a disjunction whose score() is (float) of the double sum of
+ *         the MATCHING sub scores;
+ *   ReqOptSumScorer.score(): float score = req.score(); if (opt is on the doc) score += opt.score();  -- a FLOAT addition of
+ *         two separately rounded sums, not one sum.
+ * A hit matches every MUST clause; SHOULD clauses only add.  required[t] != 0: clause t is MUST.  A segment that lacks a MUST
+ * term has no hits.  Parity of this shape is pinned by recall only: the reference's tests hold no score of such a query. */
+void nrt_oracle_search_segment_reqopt(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                                      int32_t n_terms, const nrt_oracle_term* terms, const uint8_t* required,
+                                      nrt_oracle_collector* collector) {
+  double req[ORACLE_WINDOW], opt[ORACLE_WINDOW];
+  uint8_t n_req[ORACLE_WINDOW], n_opt[ORACLE_WINDOW];
+  int64_t* cursor = (int64_t*)calloc((size_t)(n_terms > 0 ? n_terms : 1), sizeof(int64_t));
+  int need = 0;
+  for (int t = 0; t < n_terms; ++t) need += required[t] ? 1 : 0;
+  nrt_oracle_collector_set_leaf(collector, doc_base);
+  for (int32_t base = 0; base < max_doc; base += ORACLE_WINDOW) {
+    int32_t end = base + ORACLE_WINDOW;
+    if (end > max_doc) end = max_doc;
+    int any = 0;
+    for (int t = 0; t < n_terms; ++t) {
+      const nrt_oracle_term* tm = &terms[t];
+      int64_t p = cursor[t];
+      if (p < tm->n && tm->docids[p] < end) {
+        if (!any) {
+          memset(req, 0, sizeof(double) * (size_t)(end - base));
+          memset(opt, 0, sizeof(double) * (size_t)(end - base));
+          memset(n_req, 0, (size_t)(end - base));
+          memset(n_opt, 0, (size_t)(end - base));
+          any = 1;
+        }
+        for (; p < tm->n && tm->docids[p] < end; ++p) {
+          int32_t d = tm->docids[p];
+          float freq = tm->freqs ? (float)tm->freqs[p] : 1.0f;
+          uint8_t norm = tm->norms ? tm->norms[d] : (uint8_t)1;
+          float s = nrt_oracle_bm25_score(tm->weight, freq, tm->cache[norm]);
+          if (required[t]) {
+            req[d - base] += (double)s;
+            n_req[d - base]++;
+          } else {
+            opt[d - base] += (double)s;
+            n_opt[d - base]++;
+          }
+        }
+        cursor[t] = p;
+      }
+    }
+    if (!any) continue;
+    for (int32_t d = base; d < end; ++d) {
+      if (n_req[d - base] != need || need == 0) continue;
+      if (live_bits && !((live_bits[d >> 6] >> (d & 63)) & 1ULL)) continue;
+      float score = (float)req[d - base];
+      if (n_opt[d - base]) score += (float)opt[d - base];
+      nrt_oracle_collector_collect(collector, d, score);
+    }
+  }
+  free(cursor);
+}
+
 /* DisjunctionMaxQuery over term clauses (src/main/java/com/yelp/nrtsearch/server/query/QueryNodeMapper.java:350-358
  * builds org.apache.lucene.search.DisjunctionMaxQuery(disjuncts, tieBreakerMultiplier)).  lucene-core 10.4.0's
  * DisjunctionMaxScorer.score() [Lucene-recall, SURVEY A]: over the matching sub-scorers keep scoreMax (float) and

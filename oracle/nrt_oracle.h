@@ -78,6 +78,11 @@ void nrt_oracle_search_segment(int32_t max_doc, int32_t doc_base, const uint64_t
 void nrt_oracle_search_segment_msm(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
                                    int32_t n_terms, const nrt_oracle_term* terms, int32_t min_should_match,
                                    nrt_oracle_collector* collector);
+/* MUST (required[t] != 0) and SHOULD term clauses, minimumNumberShouldMatch 0: hits match every MUST clause, score =
+ * (float) sum of the MUST scores + (float) sum of the matching SHOULD scores, added in float (ReqOptSumScorer) */
+void nrt_oracle_search_segment_reqopt(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
+                                      int32_t n_terms, const nrt_oracle_term* terms, const uint8_t* required,
+                                      nrt_oracle_collector* collector);
 /* DisjunctionMaxQuery over the same term clauses (QueryNodeMapper.java:350-358): best clause + tie_breaker * the others */
 void nrt_oracle_search_segment_dismax(int32_t max_doc, int32_t doc_base, const uint64_t* live_bits,
                                       int32_t n_terms, const nrt_oracle_term* terms, float tie_breaker,

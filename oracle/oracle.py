@@ -83,6 +83,9 @@ def lib():
         L.nrt_oracle_search_segment_dismax.restype = None
         L.nrt_oracle_search_segment_dismax.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_float,
                                                        C.c_void_p]
+        L.nrt_oracle_search_segment_reqopt.restype = None
+        L.nrt_oracle_search_segment_reqopt.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                                       C.c_void_p]
         L.nrt_oracle_block_max.restype = None
         L.nrt_oracle_block_max.argtypes = [C.c_void_p, C.c_void_p]
         L.nrt_oracle_search_segment_maxscore.restype = None
@@ -290,7 +293,7 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
                 segments: Optional[Sequence[int]] = None, omit_norms: bool = False, omit_freqs: bool = False,
                 maxscore: bool = False, stats: Optional[dict] = None,
                 accept: Optional[Sequence[Optional[np.ndarray]]] = None, min_should_match: int = 0,
-                slicing=DEFAULT_SLICING, dismax: Optional[float] = None):
+                slicing=DEFAULT_SLICING, dismax: Optional[float] = None, must: Optional[Sequence[bool]] = None):
     """IndexSearcher.search(BooleanQuery(SHOULD TermQuery...), TopScoreDocCollectorManager(k, after, thr)): one
     collector per slice of the searcher (corpus_slices; each visits its leaves in docBase order), reduced like
     LazyQueueTopScoreDocCollectorManager.reduce: TopDocs.merge of the slices' hits, totalHits summed, relation
@@ -301,12 +304,18 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
     liveDocs & FILTER doc set & ~MUST_NOT doc set -- what BooleanWeight's conjunction of a FILTER clause
     with the SHOULD disjunction (minimumNumberShouldMatch = 1) and its ReqExclScorer let through; such
     clauses add nothing to the score.
-    dismax = tie breaker: the clauses are the disjuncts of a DisjunctionMaxQuery instead (best clause + tie x the others)."""
+    dismax = tie breaker: the clauses are the disjuncts of a DisjunctionMaxQuery instead (best clause + tie x the others).
+    must[i]: clause i is a MUST clause, the others SHOULD (minimumNumberShouldMatch 0): ReqOptSumScorer's float sum of two sums;
+    all of them MUST: the conjunction == the disjunction with minimumNumberShouldMatch = n."""
+    if must is not None and all(must):
+        must, min_should_match = None, len(term_ids)
+    if must is not None and not any(must):
+        must = None
     if segments is None and slicing is not None:
         groups = corpus_slices(corpus, slicing)
         if len(groups) > 1:
             parts = [search_bm25(corpus, term_ids, k, boosts, after, total_hits_threshold, g, omit_norms, omit_freqs, maxscore,
-                                 stats, accept, min_should_match, None, dismax) for g in groups]
+                                 stats, accept, min_should_match, None, dismax, must) for g in groups]
             docs, scores = topdocs_merge(k, [(p[0], p[1]) for p in parts])
             return docs, scores, int(sum(p[2] for p in parts)), bool(any(p[3] for p in parts))
     weights, cache = bm25_query_stats(corpus, term_ids, boosts)
@@ -319,10 +328,14 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
         arr = (_Term * max(len(term_ids), 1))()
         n_present = 0
         present_ids = []
+        present_req = []
+        lacks_must = False
         for i, t in enumerate(term_ids):
             d, f = seg.postings(int(t))
             if len(d) == 0:
+                lacks_must = lacks_must or (must is not None and bool(must[i]))
                 continue
+            present_req.append(1 if (must is not None and must[i]) else 0)
             d = np.ascontiguousarray(d, dtype=np.int32)
             f = np.ascontiguousarray(f, dtype=np.int32)
             keep.append((d, f))
@@ -339,7 +352,11 @@ def search_bm25(corpus, term_ids: Sequence[int], k: int, boosts: Optional[Sequen
             acc_bits = np.ascontiguousarray(accept[si], dtype=np.uint64)
             keep.append(acc_bits)
             live = acc_bits.ctypes.data
-        if maxscore:
+        if must is not None:
+            if not lacks_must:   # (a leaf without one of the MUST terms has no hits)
+                rq = (C.c_uint8 * max(n_present, 1))(*present_req)
+                lib().nrt_oracle_search_segment_reqopt(seg.max_doc, seg.doc_base, live, n_present, C.byref(arr), rq, col._h)
+        elif maxscore:
             bms = [_block_max(corpus, si, present_ids[j], arr[j],
                               (float(arr[j].weight), omit_norms, omit_freqs)) for j in range(n_present)]
             ptrs = (C.c_void_p * max(n_present, 1))(*[b.ctypes.data for b in bms])

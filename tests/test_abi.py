@@ -51,7 +51,7 @@ def test_struct_sizes_match_header(lib):
     # layout pinned on both sides of the boundary (x86-64 SysV)
     assert C.sizeof(_lib.Config) == 24
     assert C.sizeof(_lib.Term) == 24
-    assert C.sizeof(_lib.Bm25Query) == 104
+    assert C.sizeof(_lib.Bm25Query) == 112
     assert C.sizeof(_lib.TopDocs) == 40
     assert C.sizeof(_lib.Stats) == 152
     assert C.sizeof(_lib.Diagnostics) == 56
@@ -184,25 +184,28 @@ def test_query_eligibility_mapping():
     """Host logic only: which rewritten queries the mirror sends to the device and how."""
     from nrtsearch_amd import api
     t = [api.TermQuery(0, i) for i in (3, 5, 8)]
-    assert api._flatten(t[0]) == ([(0, 3, 1.0)], 0, [], [], 0)
-    assert api._flatten(api.BoostQuery(t[1], 2.0)) == ([(0, 5, 2.0)], 0, [], [], 0)
-    assert api._flatten(api.BooleanQuery(tuple(t), 2)) == ([(0, 3, 1.0), (0, 5, 1.0), (0, 8, 1.0)], 2, [], [], 0)
-    assert api._flatten(api.BooleanQuery(tuple(t), 1, (api.MaskFilter(4),), (api.MaskFilter(9),)))[2:] == ([4], [9], 0)
+    assert api._flatten(t[0]) == ([(0, 3, 1.0, 0)], 0, [], [], 0, 0.0)
+    assert api._flatten(api.BoostQuery(t[1], 2.0)) == ([(0, 5, 2.0, 0)], 0, [], [], 0, 0.0)
+    assert api._flatten(api.BooleanQuery(tuple(t), 2)) == ([(0, 3, 1.0, 0), (0, 5, 1.0, 0), (0, 8, 1.0, 0)], 2, [], [], 0, 0.0)
+    assert api._flatten(api.BooleanQuery(tuple(t), 1, (api.MaskFilter(4),), (api.MaskFilter(9),)))[2:] == ([4], [9], 0, 0.0)
     # any number of FILTER / MUST_NOT clauses (QueryNodeMapper.java:257-283): the library combines their masks at plan time
-    assert api._flatten(api.BooleanQuery(tuple(t), 1, (api.MaskFilter(1), api.MaskFilter(2)), (api.MaskFilter(7), api.MaskFilter(5), api.MaskFilter(6))))[2:] == ([1, 2], [7, 5, 6], 0)
+    assert api._flatten(api.BooleanQuery(tuple(t), 1, (api.MaskFilter(1), api.MaskFilter(2)), (api.MaskFilter(7), api.MaskFilter(5), api.MaskFilter(6))))[2:] == ([1, 2], [7, 5, 6], 0, 0.0)
     # a pure-MUST conjunction of terms is the disjunction that needs every clause
     assert api._flatten(api.BooleanQuery(must=tuple(t)))[1] == 3
-    assert api._flatten(api.BooleanQuery(must=tuple(t), filter=(api.MaskFilter(2),)))[1:] == (3, [2], [], 0)
-    # DisjunctionMaxQuery over (boosted) term queries, tie breaker 0 (QueryNodeMapper.java:350-358): best clause, not the sum
+    assert api._flatten(api.BooleanQuery(must=tuple(t), filter=(api.MaskFilter(2),)))[1:] == (3, [2], [], 0, 0.0)
+    # MUST next to SHOULD clauses (minimumNumberShouldMatch 0): the clauses carry their occur, MUST first (ReqOptSumScorer)
+    assert api._flatten(api.BooleanQuery(tuple(t[:1]), must=tuple(t[1:]))) == ([(0, 5, 1.0, 1), (0, 8, 1.0, 1), (0, 3, 1.0, 0)], 0, [], [], 0, 0.0)
+    # DisjunctionMaxQuery over (boosted) term queries (QueryNodeMapper.java:350-358): best clause + tie breaker x the others
     dm = api.DisjunctionMaxQuery((t[0], api.BoostQuery(t[2], 3.0)))
-    assert api._flatten(dm) == ([(0, 3, 1.0), (0, 8, 3.0)], 0, [], [], 1)
-    assert api._flatten(api.BooleanQuery(must=(dm,), filter=(api.MaskFilter(6),)))[1:] == (0, [6], [], 1)
+    assert api._flatten(dm) == ([(0, 3, 1.0, 0), (0, 8, 3.0, 0)], 0, [], [], 1, 0.0)
+    assert api._flatten(api.BooleanQuery(must=(dm,), filter=(api.MaskFilter(6),)))[1:] == (0, [6], [], 1, 0.0)
+    assert api._flatten(api.DisjunctionMaxQuery(tuple(t), 0.25))[4:] == (1, 0.25)
     import pytest
     for bad in (api.BooleanQuery(tuple(t), 0, (api.MaskFilter(4),)),              # FILTER + optional SHOULD: score-0 hits
-                api.BooleanQuery(tuple(t[:1]), must=tuple(t[1:])),                 # MUST and SHOULD mixed
+                api.BooleanQuery(tuple(t[:1]), 1, must=tuple(t[1:])),              # MUST next to minimumNumberShouldMatch > 0
                 api.BooleanQuery((api.BooleanQuery(tuple(t)),)),                    # nested clause
                 api.BooleanQuery(tuple(t), 1, tuple(api.MaskFilter(i) for i in range(1, 10))),   # more masks than NRTGPU_MAX_MASKS
-                api.DisjunctionMaxQuery(tuple(t), 0.3),                             # tie breaker: the caller's path
+                api.DisjunctionMaxQuery(tuple(t), 1.5),                             # tie breaker outside [0, 1]
                 api.DisjunctionMaxQuery((api.BooleanQuery(tuple(t)),)),             # disjunct that is not a term query
                 api.BooleanQuery(tuple(t[:1]), must=(api.DisjunctionMaxQuery(tuple(t)),)),
                 api.BooleanQuery(())):

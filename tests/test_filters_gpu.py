@@ -263,9 +263,6 @@ def test_disjunction_max_query(ctx, deletes):
         assert_same("dismax_batch3", res[3], oracle.search_bm25(corpus, terms, 300, dismax=0.0, accept=acc), 300, 1000)
         assert_same("dismax_batch4", res[4], oracle.search_bm25(corpus, [50], 300), 300, 1000)
         assert ix.searcher.supported(dq, api.TopScoreDocCollectorManager(10))
-        # what stays on the caller's path
-        with pytest.raises(api.UnsupportedQuery):
-            ix.searcher.search(api.DisjunctionMaxQuery(should, 0.1), api.TopScoreDocCollectorManager(10))
         ctx.reset_stats()
         got = ix.searcher.search_coalesced(dq, api.TopScoreDocCollectorManager(10))
         assert_same("dismax_coalesced", got, oracle.search_bm25(corpus, terms, 10, dismax=0.0), 10, 1000)
@@ -326,6 +323,135 @@ def test_deletes_all_routes(flags):
     finally:
         ix.close()
         c.close()
+
+
+@pytest.mark.parametrize("deletes", [0.0, 0.03])
+def test_disjunction_max_query_with_a_tie_breaker(ctx, deletes):
+    """DisjunctionMaxQuery with tieBreakerMultiplier > 0 (QueryNodeMapper.java:350-358): (float)(best + tieBreaker x the others),
+    computed in double from the doc's best clause AND the sum of its clauses -- the MaxScore kernel's second accumulator.  Docids,
+    ranks, score bits == the oracle's DisjunctionMaxScorer restatement."""
+    ranks = [1, 2, 3, 6, 15, 50, 400, 3000]
+    corpus = synth.build_corpus(260_000, ranks, n_segments=3, delete_fraction=deletes)
+    ix = Index(ctx, corpus)
+    try:
+        terms = [1, 3, 15, 400, 3000]
+        should = tuple(api.TermQuery(0, t) for t in terms)
+        ctx.reset_stats()
+        for tb in (0.1, 0.5, 1.0, float(np.float32(0.3))):
+            dq = api.DisjunctionMaxQuery(should, tb)
+            for k, thr in ((10, 1000), (1000, 1000), (100, 10)):
+                got = ix.searcher.search(dq, api.TopScoreDocCollectorManager(k, None, thr))
+                assert_same(f"tie_{tb}_{k}_{thr}_{deletes}", got, oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, dismax=tb), k, thr)
+        st = ctx.stats()
+        assert st["maxscore_items"] > 0 and st["scan_items"] == 0
+        # tie breaker 1 is NOT the plain sum's float: best + others in double, one cast -- the same value here, and the oracle agrees
+        # boosted disjuncts, a repeated term, paging, a mask, mixed into one batch with the other shapes
+        boosts = [0.5, 3.0, 1.0, 2.0, 4.0]
+        bdq = api.DisjunctionMaxQuery(tuple(api.BoostQuery(api.TermQuery(0, t), b) for t, b in zip(terms, boosts)), 0.25)
+        first = ix.searcher.search(bdq, api.TopScoreDocCollectorManager(60))
+        assert_same("tie_boost_p1", first, oracle.search_bm25(corpus, terms, 60, boosts=boosts, dismax=0.25), 60, 1000)
+        after = api.ScoreDoc(int(first.docs[-1]), float(first.scores[-1]))
+        second = ix.searcher.search(bdq, api.TopScoreDocCollectorManager(60, after))
+        assert_same("tie_boost_p2", second, oracle.search_bm25(corpus, terms, 60, boosts=boosts, dismax=0.25, after=(after.doc, after.score)), 60, 1000)
+        dup = [2, 2, 50]
+        got = ix.searcher.search(api.DisjunctionMaxQuery(tuple(api.TermQuery(0, t) for t in dup), 0.7), api.TopScoreDocCollectorManager(50))
+        assert_same("tie_dup", got, oracle.search_bm25(corpus, dup, 50, dismax=0.7), 50, 1000)
+        masks = [random_mask(s.max_doc, 0.35, 900 + i) for i, s in enumerate(corpus.segments)]
+        for leaf, m in zip(ix.leaves, masks):
+            leaf.set_mask(6, m)
+        acc = [accept_of(s, masks[i], None) for i, s in enumerate(corpus.segments)]
+        dq = api.DisjunctionMaxQuery(should, 0.4)
+        qs = [dq, api.BooleanQuery(should), api.BooleanQuery(should, 3), api.BooleanQuery(must=(dq,), filter=(api.MaskFilter(6),)),
+              api.DisjunctionMaxQuery(should), api.DisjunctionMaxQuery((api.TermQuery(0, 50),), 0.9)]
+        res = ix.searcher.search_batch(qs, [api.TopScoreDocCollectorManager(300)] * len(qs))
+        assert_same("tie_batch0", res[0], oracle.search_bm25(corpus, terms, 300, dismax=0.4), 300, 1000)
+        assert_same("tie_batch1", res[1], oracle.search_bm25(corpus, terms, 300), 300, 1000)
+        assert_same("tie_batch2", res[2], oracle.search_bm25(corpus, terms, 300, min_should_match=3), 300, 1000)
+        assert_same("tie_batch3", res[3], oracle.search_bm25(corpus, terms, 300, dismax=0.4, accept=acc), 300, 1000)
+        assert_same("tie_batch4", res[4], oracle.search_bm25(corpus, terms, 300, dismax=0.0), 300, 1000)
+        assert_same("tie_batch5", res[5], oracle.search_bm25(corpus, [50], 300, dismax=0.9), 300, 1000)
+        got = ix.searcher.search_coalesced(dq, api.TopScoreDocCollectorManager(10))
+        assert_same("tie_coalesced", got, oracle.search_bm25(corpus, terms, 10, dismax=0.4), 10, 1000)
+        # ScoreMode.COMPLETE over a large query would need the exhaustive scan, which carries one accumulator: the caller's path
+        big = api.DisjunctionMaxQuery(tuple(api.TermQuery(0, t) for t in (1, 2, 3, 6, 15, 50)), 0.4)   # (> 2^18 postings)
+        with pytest.raises(api.NrtGpuError):
+            ix.searcher.search(big, api.TopScoreDocCollectorManager(10, None, 2**31 - 1))
+        got = ix.searcher.search(api.DisjunctionMaxQuery(should[2:], 0.4), api.TopScoreDocCollectorManager(10, None, 2**31 - 1))   # a small one: exact mode
+        assert_same("tie_complete_small", got, oracle.search_bm25(corpus, terms[2:], 10, total_hits_threshold=2**31 - 1, dismax=0.4), 10, 2**31 - 1)
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("deletes", [0.0, 0.03])
+def test_must_next_to_should_clauses(ctx, deletes):
+    """BooleanQuery with MUST and SHOULD term clauses (QueryNodeMapper.java:257-283; minimumNumberShouldMatch 0): a hit matches
+    every MUST clause, its score is (float) MUST sum + (float) SHOULD sum added in float (ReqOptSumScorer) -- the kernel's second
+    accumulator.  Docids, ranks, score bits and hit counts == the oracle's restatement."""
+    ranks = [1, 2, 3, 6, 15, 50, 400, 3000]
+    corpus = synth.build_corpus(260_000, ranks, n_segments=3, delete_fraction=deletes)
+    ix = Index(ctx, corpus)
+    try:
+        tq = lambda t: api.TermQuery(0, t)   # noqa: E731
+        cases = [([15], [1, 3, 400]),            # a mid-frequency MUST term, frequent and rare SHOULD terms
+                 ([1], [3000, 400]),             # the MUST term is the most frequent one: the rare SHOULD clauses are streamed first
+                 ([3000], [1, 2, 3]),            # a rare MUST term
+                 ([2, 50], [6, 400, 3000]),      # two MUST clauses (ConjunctionScorer's double sum) + three SHOULD
+                 ([6, 15, 400], [1]),            # three MUST + one SHOULD
+                 ([50], [50, 3]),                # the same term on both sides
+                 ([3, 9999], [1])]               # a MUST term the index does not hold: no hits
+        ctx.reset_stats()
+        for ci, (must, should) in enumerate(cases):
+            q = api.BooleanQuery(tuple(tq(t) for t in should), must=tuple(tq(t) for t in must))
+            terms, flags = must + should, [True] * len(must) + [False] * len(should)
+            for k, thr in ((10, 1000), (1000, 1000), (100, 10), (7, 1000)):
+                got = ix.searcher.search(q, api.TopScoreDocCollectorManager(k, None, thr))
+                assert_same(f"reqopt_{ci}_{k}_{thr}_{deletes}", got, oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, must=flags), k, thr)
+        st = ctx.stats()
+        assert st["maxscore_items"] > 0 and st["scan_items"] == 0
+        # ScoreMode.COMPLETE: a small query is counted exactly on the same route; a large one would need the exhaustive scan
+        small = api.BooleanQuery((tq(3000), tq(50)), must=(tq(400),))
+        got = ix.searcher.search(small, api.TopScoreDocCollectorManager(50, None, 2**31 - 1))
+        assert_same("reqopt_complete_small", got, oracle.search_bm25(corpus, [400, 3000, 50], 50, total_hits_threshold=2**31 - 1, must=[True, False, False]), 50, 2**31 - 1)
+        with pytest.raises(api.NrtGpuError):
+            ix.searcher.search(api.BooleanQuery((tq(1), tq(2), tq(3)), must=(tq(6),)), api.TopScoreDocCollectorManager(50, None, 2**31 - 1))
+        # it is not the one-sum score: somewhere in the top hits float(a) + float(b) != float(a + b)
+        must, should = [2, 50], [6, 400, 3000]
+        q = api.BooleanQuery(tuple(tq(t) for t in should), must=tuple(tq(t) for t in must))
+        got = ix.searcher.search(q, api.TopScoreDocCollectorManager(1000))
+        one_sum = ix.searcher.search(api.BooleanQuery(tuple(tq(t) for t in must + should)), api.TopScoreDocCollectorManager(1000, None, 2**31 - 1))
+        as_one = dict(zip(one_sum.docs.tolist(), one_sum.scores.view(np.uint32).tolist()))
+        both = [(d, b) for d, b in zip(got.docs.tolist(), got.scores.view(np.uint32).tolist()) if d in as_one]
+        assert both and any(as_one[d] != b for d, b in both), "every MUST + SHOULD score equals the one-sum score: the case proves nothing"
+        # boosts, paging, a FILTER and a MUST_NOT mask, one batch with the other shapes
+        boosts = [2.0, 0.5, 1.0, 3.0, 0.25]
+        boosted = api.BooleanQuery(tuple(api.BoostQuery(tq(t), b) for t, b in zip(should, boosts[2:])), must=tuple(api.BoostQuery(tq(t), b) for t, b in zip(must, boosts[:2])))
+        first = ix.searcher.search(boosted, api.TopScoreDocCollectorManager(40))
+        okw = dict(boosts=boosts, must=[True, True, False, False, False])
+        assert_same("reqopt_boost_p1", first, oracle.search_bm25(corpus, must + should, 40, **okw), 40, 1000)
+        after = api.ScoreDoc(int(first.docs[-1]), float(first.scores[-1]))
+        second = ix.searcher.search(boosted, api.TopScoreDocCollectorManager(40, after))
+        assert_same("reqopt_boost_p2", second, oracle.search_bm25(corpus, must + should, 40, after=(after.doc, after.score), **okw), 40, 1000)
+        masks = [random_mask(s.max_doc, 0.4, 700 + i) for i, s in enumerate(corpus.segments)]
+        masks2 = [random_mask(s.max_doc, 0.1, 800 + i) for i, s in enumerate(corpus.segments)]
+        for leaf, m, m2 in zip(ix.leaves, masks, masks2):
+            leaf.set_mask(7, m)
+            leaf.set_mask(8, m2)
+        acc = [accept_of(s, masks[i], masks2[i]) for i, s in enumerate(corpus.segments)]
+        qf = api.BooleanQuery(q.should, 0, (api.MaskFilter(7),), (api.MaskFilter(8),), q.must)
+        sh = tuple(tq(t) for t in must + should)
+        qs = [q, qf, api.BooleanQuery(sh), api.BooleanQuery(must=sh[:3]), api.DisjunctionMaxQuery(sh, 0.5), api.BooleanQuery(sh, 2)]
+        res = ix.searcher.search_batch(qs, [api.TopScoreDocCollectorManager(200)] * len(qs))
+        fl = [True, True, False, False, False]
+        assert_same("reqopt_batch0", res[0], oracle.search_bm25(corpus, must + should, 200, must=fl), 200, 1000)
+        assert_same("reqopt_batch1", res[1], oracle.search_bm25(corpus, must + should, 200, must=fl, accept=acc), 200, 1000)
+        assert_same("reqopt_batch2", res[2], oracle.search_bm25(corpus, must + should, 200), 200, 1000)
+        assert_same("reqopt_batch3", res[3], oracle.search_bm25(corpus, (must + should)[:3], 200, min_should_match=3), 200, 1000)
+        assert_same("reqopt_batch4", res[4], oracle.search_bm25(corpus, must + should, 200, dismax=0.5), 200, 1000)
+        assert_same("reqopt_batch5", res[5], oracle.search_bm25(corpus, must + should, 200, min_should_match=2), 200, 1000)
+        got = ix.searcher.search_coalesced(q, api.TopScoreDocCollectorManager(10))
+        assert_same("reqopt_coalesced", got, oracle.search_bm25(corpus, must + should, 10, must=fl), 10, 1000)
+    finally:
+        ix.close()
 
 
 def test_must_conjunction_of_terms(ctx):

@@ -53,15 +53,34 @@ def test_fuzz_query_shapes(round_, monkeypatch):
                 msm = int(rng.integers(2, nt + 2)) if (allow_msm and nt > 1 and rng.random() < 0.5) else 0
                 f = int(rng.choice([0, 0, 1, 2]))
                 mn = int(rng.choice([0, 0, 0, 1, 2]))
-                if f and msm == 0:
+                forced = bool(f) and msm == 0
+                if forced:
                     msm = 1
                 clauses = tuple(api.BoostQuery(api.TermQuery(0, t), b) if b != 1.0 else api.TermQuery(0, t) for t, b in zip(terms, boosts))
                 dismax = allow_msm and msm <= 1 and rng.random() < 0.25   # (same kernel variant as the clause counts: fixed point only)
+                tie = 0.0
+                must_flags = None
+                # the second-accumulator shapes (a tie breaker > 0, MUST next to SHOULD clauses): MaxScore route only -- at most 8
+                # clauses, and no ScoreMode.COMPLETE (a large query would need the exhaustive scan)
+                two_ok = allow_msm and nt <= 8 and thr != 2**31 - 1
+                if dismax and two_ok and rng.random() < 0.6:
+                    tie = float(np.float32(rng.choice([0.05, 0.3, 0.5, 1.0])))
+                if not dismax and two_ok and nt >= 2 and (msm == 0 or forced) and rng.random() < 0.3:
+                    must_flags = [bool(x) for x in rng.integers(0, 2, size=nt)]
+                    if all(must_flags) or not any(must_flags):
+                        must_flags[0], must_flags[1] = True, False
+                    msm = 0   # (MUST clauses make the hit: a FILTER next to them needs no minimumNumberShouldMatch)
                 if dismax:
-                    dq = api.DisjunctionMaxQuery(clauses)
+                    dq = api.DisjunctionMaxQuery(clauses, tie)
                     q = dq if not (f or mn) else api.BooleanQuery(must=(dq,), filter=(api.MaskFilter(f),) if f else (),
                                                                   must_not=(api.MaskFilter(mn),) if mn else ())
                     msm = 0
+                elif must_flags is not None:
+                    q = api.BooleanQuery(tuple(c for c, m_ in zip(clauses, must_flags) if not m_), 0, (api.MaskFilter(f),) if f else (),
+                                         (api.MaskFilter(mn),) if mn else (), tuple(c for c, m_ in zip(clauses, must_flags) if m_))
+                    # (the clauses as the mirror hands them over: MUST first)
+                    order = [i for i, m_ in enumerate(must_flags) if m_] + [i for i, m_ in enumerate(must_flags) if not m_]
+                    terms, boosts, must_flags = [terms[i] for i in order], [boosts[i] for i in order], [must_flags[i] for i in order]
                 elif nt == 1 and not f and not mn and msm == 0:
                     q = clauses[0]
                 else:
@@ -70,7 +89,7 @@ def test_fuzz_query_shapes(round_, monkeypatch):
                 if f or mn:
                     acc = [accept_of(s, masks[f][i] if f else None, masks[mn][i] if mn else None) for i, s in enumerate(corpus.segments)]
                 after = None
-                okw = dict(boosts=boosts, total_hits_threshold=thr, accept=acc, min_should_match=msm, dismax=0.0 if dismax else None)
+                okw = dict(boosts=boosts, total_hits_threshold=thr, accept=acc, min_should_match=msm, dismax=tie if dismax else None, must=must_flags)
                 if rng.random() < 0.25:
                     first = oracle.search_bm25(corpus, terms, k, **okw)
                     if len(first[0]):
