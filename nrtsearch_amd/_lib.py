@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile", "nrtgpu_set_slicing",
     "nrtgpu_blend", "nrtgpu_dist_unique_id", "nrtgpu_dist_init", "nrtgpu_dist_search_bm25_batch", "nrtgpu_dist_allgather_merge", "nrtgpu_segment_fork",
     "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_knn_exact", "nrtgpu_dist_search_hybrid_batch",
-    "nrtgpu_debug_hold_coalescers", "nrtgpu_debug_coalescer_pending", "nrtgpu_get_maxscore_item_walls", "nrtgpu_knn_exact_relation", "nrtgpu_debug_live_segments",
+    "nrtgpu_debug_hold_coalescers", "nrtgpu_debug_coalescer_pending", "nrtgpu_get_maxscore_item_walls", "nrtgpu_knn_exact_relation", "nrtgpu_debug_live_segments", "nrtgpu_debug_spec_counters", "nrtgpu_set_speculation",
 ]
 
 
@@ -165,6 +165,10 @@ def load() -> C.CDLL:
     L.nrtgpu_debug_hold_coalescers.argtypes = [vp, C.c_int32]
     L.nrtgpu_debug_live_segments.argtypes = [vp]
     L.nrtgpu_debug_live_segments.restype = C.c_int64
+    L.nrtgpu_set_speculation.argtypes = [vp, C.c_float]
+    L.nrtgpu_set_speculation.restype = C.c_int
+    L.nrtgpu_debug_spec_counters.argtypes = [vp, vp]
+    L.nrtgpu_debug_spec_counters.restype = C.c_int
     L.nrtgpu_knn_exact_relation.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.nrtgpu_get_maxscore_item_walls.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.nrtgpu_get_maxscore_item_walls.restype = C.c_int64

@@ -243,6 +243,16 @@ class GpuContext:
             L.nrtgpu_get_maxscore_item_walls(self._h, out.ctypes.data, n, C.byref(n_items))
         return out, int(n_items.value)
 
+    def set_speculation(self, margin: float) -> None:
+        """Speculative thresholds of the MaxScore route (nrtgpu_set_speculation): the guess's safety margin in standard deviations; 0 = off."""
+        _lib.check(_lib.load().nrtgpu_set_speculation(self._h, C.c_float(float(margin))))
+
+    def debug_spec_counters(self) -> dict:
+        """Speculative thresholds of the MaxScore route (nrtgpu_debug_spec_counters)."""
+        out = (C.c_int64 * 3)()
+        _lib.check(_lib.load().nrtgpu_debug_spec_counters(self._h, out))
+        return {"queries": int(out[0]), "reruns": int(out[1]), "switched_off": bool(out[2])}
+
     def debug_live_segments(self) -> int:
         """Segment handles of this context (uploads and forks) not freed yet (nrtgpu_debug_live_segments)."""
         return int(_lib.load().nrtgpu_debug_live_segments(self._h))

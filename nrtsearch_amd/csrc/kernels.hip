@@ -947,7 +947,7 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
                        const uint32_t* __restrict__ q_k, uint64_t* __restrict__ out_keys,
                        uint32_t* __restrict__ out_counts, uint64_t* __restrict__ out_hits,
                        uint32_t k_stride_out, const uint32_t* __restrict__ help_head, const uint32_t* __restrict__ help_next,
-                       uint32_t help_slot_base) {
+                       uint32_t help_slot_base, const unsigned long long* __restrict__ spec_g) {
   __shared__ MergeSmem s;
   const uint32_t tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
@@ -1004,7 +1004,12 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
   for (uint32_t i = tid; i < k_stride_out; i += kScanThreads) out[i] = (i < n) ? s.cand[i] : 0;
   if (tid == 0) {
     out_counts[q] = n;
-    out_hits[q] = s.hits;
+    // Speculative thresholds (plan.h: kHitsSpecInvalid): whatever the MaxScore walk skipped scores below the largest guess
+    // published for the query.  The merged list stands iff its k-th key reaches that guess -- then nothing skipped could have
+    // entered; otherwise the query is tagged and the host runs it again without speculation.
+    const unsigned long long guess = spec_g ? spec_g[q] : 0ull;
+    const bool failed = guess != 0ull && (n < k || s.cand[k - 1u] < guess);
+    out_hits[q] = s.hits | (failed ? kHitsSpecInvalid : 0ull);
   }
 }
 
@@ -1259,11 +1264,11 @@ void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* i
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
                        uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_head,
-                       const uint32_t* help_next, uint32_t help_slot_base) {
+                       const uint32_t* help_next, uint32_t help_slot_base, const unsigned long long* spec_g) {
   if (n_queries == 0) return;
   hipLaunchKernelGGL(merge_topk_kernel, dim3(n_queries), dim3(kScanThreads), 0, stream, in_keys, in_counts, in_hits,
                      list_idx, q_base, q_nlists, k_stride_in, q_k, out_keys, out_counts, out_hits, k_stride_out, help_head, help_next,
-                     help_slot_base);
+                     help_slot_base, spec_g);
 }
 
 void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,

@@ -78,7 +78,12 @@ struct MsSmem {
   uint64_t thr;          // acc_threshold(theta): what running sums are compared with
   uint32_t cnt;          // entries in cand
   uint32_t cnt_valid;    // entries of cand that are complete when cnt ran past kMsCandCap
-  uint32_t rz_flag;      // a wave could not reserve candidate slots: everybody meet
+  uint32_t rz_flag;      // a wave could not reserve candidate slots (or a new speculative theta is due): everybody meet
+  uint32_t wins_started; // doc windows this workgroup's waves have taken so far (of the item it works on)
+  uint32_t spec_at;      // speculation: the next estimate is due when wins_started reaches this (0: never)
+  uint32_t q_wins;       // doc windows of ALL items of the query
+  uint32_t spec_z16;     // speculation (plan.h: kHitsSpecInvalid): safety margin in standard deviations x 16; 0: off
+  unsigned long long* spec_slot;   // ... and where the query's largest speculative theta is published
   uint64_t pick;         // a helper's choice: float bits of its key (expected time left / an exponential variate) << 32 | item + 1
   uint32_t role[4];      // the workgroup's first decision (start the next item / help one): scratch values every thread reads
   uint32_t prune_on;     // bounds may skip work (kMsModeCount: raised once a slice's count has passed the query's gte_floor)
@@ -218,8 +223,22 @@ __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem
   const uint32_t cnt_raw = s.cnt;
   const uint32_t cnt0 = cnt_raw > (uint32_t)kMsCandCap ? s.cnt_valid : cnt_raw;  // failed reservations inflate cnt
   __syncthreads();
+  // Speculation (plan.h: kHitsSpecInvalid): this workgroup has taken wins_started of the query's q_wins doc windows, so about
+  // m = k x that fraction of the query's final top-k are among the keys it holds -- their (m + z sqrt(m) + 1)-th best is a
+  // guess at the final k-th key, z standard deviations on the safe side.  Windows that are only begun count as walked: the
+  // fraction errs high, the rank deep, the guess low.
+  const bool exchanging = xch && xch->world > 1u;
+  uint32_t r = 0;
+  // (only once bounds may skip: by then more than max(totalHitsThreshold, numHits) docs are known to match -- a query with
+  //  fewer than k hits would fail every guess)
+  if (s.spec_z16 != 0u && !exchanging && __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+    const float m = (float)k * fminf(1.0f, (float)s.wins_started / (float)max(s.q_wins, 1u));
+    const float rr = m + (float)s.spec_z16 * (1.0f / 16.0f) * sqrtf(m) + 2.0f;
+    r = rr < (float)k ? (uint32_t)rr : 0u;
+  }
+  uint64_t guess = 0;
   if (cnt0 > k) {  // uniform
-    const uint32_t k2 = (xch && xch->world > 1u) ? (k + xch->world - 2u) / (xch->world - 1u) : 0u;
+    const uint32_t k2 = exchanging ? (k + xch->world - 2u) / (xch->world - 1u) : r;
     const uint64_t thr = topk_kth_union<kMsThreads>(s.cand, cnt0, k, &s.sc, [](auto&&) {}, k2);
     const uint32_t q2_hi = s.sc.q2_hi;  // (stable until the next selection)
     const uint32_t kept = topk_keep_ge<kMsThreads, kMsCandCap>(s.cand, cnt0, thr, &s.sc);
@@ -232,6 +251,7 @@ __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem
       atomicMax(theta_g, (unsigned long long)thr);  // LazyMaxScoreAccumulator.accumulate analogue
       s.prof[1] += 1;
     }
+    if (!exchanging && r != 0u && q2_hi != 0u) guess = (uint64_t)q2_hi << 32;   // a score at least r of my keys reach (the histogram's bucket edge)
     if (xch && tid < 64u) {   // wave 0: publish my quantile, bound myself by the other ranks' entries
       const uint64_t pb = exchange_bound(*xch, query, q2_hi != 0u ? (uint64_t)q2_hi << 32 : 0ull, tid);
       if (tid == 0 && pb > s.theta) {
@@ -240,8 +260,20 @@ __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem
         atomicMax(theta_g, (unsigned long long)pb);   // (the query's other items on this GPU get it through theta_g)
       }
     }
-  } else if (tid == 0) {
-    s.cnt = cnt0;
+  } else {
+    if (r != 0u && cnt0 > r) guess = topk_kth_union<kMsThreads>(s.cand, cnt0, r, &s.sc, [](auto&&) {}, 0u);   // the r-th best key itself; nothing is dropped
+    if (tid == 0) s.cnt = cnt0;
+  }
+  if (tid == 0 && s.spec_z16 != 0u) {
+    if (guess > s.theta) {
+      s.theta = guess;
+      s.thr = acc_threshold<true>(guess, fx_E);
+      atomicMax(theta_g, (unsigned long long)guess);
+      atomicMax(s.spec_slot, (unsigned long long)guess);
+    }
+    // the next estimate: when twice as many windows have been taken (the guess moves with the fraction's square root)
+    const uint32_t ws = s.wins_started;
+    s.spec_at = ws >= s.q_wins ? 0u : max(2u * ws, ws + (uint32_t)kMsWaves);
   }
   __syncthreads();
   if (tid == 0) s.rz_flag = 0;
@@ -473,6 +505,13 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         if (my_item == 0u) __hip_atomic_store(hp.t_start, now0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       s.prune_on = mode == kMsModePrune ? 1u : 0u;
+      // speculation (plan.h: kHitsSpecInvalid): off unless the launch has somebody who re-runs a query whose guess failed
+      const bool spec = hp.spec_g != nullptr && hp.spec_z16 != 0u;
+      s.wins_started = 0;
+      s.q_wins = spec ? as_global(ap->q_wins)[item.query] : 0u;
+      s.spec_z16 = spec ? hp.spec_z16 : 0u;
+      s.spec_slot = spec ? as_global(hp.spec_g) + item.query : nullptr;
+      s.spec_at = spec ? 2u * (uint32_t)kMsWaves : 0u;   // the first estimate: when every wave has begun its second window
       for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
       for (int i = 0; i < 16; ++i) s.prof[i] = 0;
     }
@@ -616,6 +655,10 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         const uint32_t doc_lo = t0 * (uint32_t)kTileDocs;
         const uint32_t doc_span = min(t1 * (uint32_t)kTileDocs, part.max_doc) - doc_lo;
         if (PROF) pc_wins += 1;
+        if (lane == 0) {   // speculation: one more window begun; a new estimate is due every time their number has doubled
+          const uint32_t ws = atomicAdd(&s.wins_started, 1u) + 1u, at = s.spec_at;
+          if (at != 0u && ws >= at) __hip_atomic_store(&s.rz_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         // my next window: taken now, so that the counter's answer is there when this one is done
         uint32_t g_new = 0;
         if (lane == 0) g_new = (uint32_t)kMsWaves + __hip_atomic_fetch_add(win_next_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (global: shared with the item's helpers)

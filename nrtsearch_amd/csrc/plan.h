@@ -146,6 +146,14 @@ static_assert(kMsCandCap >= kMaxK + 512, "candidate buffer too small");
 // item_hits of a MaxScore item: the docs it evaluated, plus kHitsPrunedUnit when it skipped anything (the count is
 // then a lower bound).  The merge kernel's plain sum keeps both: low 48 bits = docs, high 16 = pruned items.
 constexpr uint64_t kHitsPrunedUnit = 1ull << 48;
+// Speculative thresholds (maxscore.hip: "speculation"; search.cpp: the re-run): a workgroup that has walked a fraction g of a
+// query's doc windows holds the exact top-k of THOSE docs; if docs are spread over windows like a random sample, about k x g of
+// the query's final top-k lie among them, so the (k g + z sqrt(k g))-th best key it holds is -- z standard deviations deep --
+// below the final k-th key, and a far better theta than the k-th best of the docs seen so far.  It is a GUESS: everything it
+// skips is only known to score below the guess.  The merge therefore checks it -- the merged list's k-th key must reach the
+// largest guess published for the query (then nothing skipped could have entered) -- and tags the query's count with
+// kHitsSpecInvalid otherwise; the host runs tagged queries again without speculation.  The results are exact either way.
+constexpr uint64_t kHitsSpecInvalid = 1ull << 47;
 
 // One part of a work item: a contiguous tile range of one segment (a LeafReaderContextPartition).
 struct alignas(16) DPart {
@@ -247,6 +255,9 @@ struct DHelp {
   uint32_t alpha16;              // critical path: help while items are queued when an item's time left > alpha16 / 16 x the launch's; 0: never
   uint32_t n_cus;
   uint32_t persistent;           // 1: the launch has one workgroup per CU and each chooses work until none is left (maxscore.hip)
+  unsigned long long* spec_g;    // [queries] the largest SPECULATIVE theta a workgroup has published for the query (kMsSpec*), 0 = none;
+                                 // nullptr: no speculation in this launch
+  uint32_t spec_z16, pad_spec;   // the estimate's safety margin in standard deviations x 16
   unsigned long long* walls;     // instrumented kernel only, else nullptr: per output slot 8 words -- {start, end} on the 100 MHz
                                  // wall clock, item, windows walked, when the workgroup's round began, CU id, round, workgroup --
                                  // when every piece of the launch ran, on one time base (nrtgpu_get_maxscore_item_walls)
@@ -269,6 +280,7 @@ struct MsArgs {
   uint32_t* item_counts;         // ... how many ...
   uint64_t* item_hits;           // ... and the hits counted there
   uint64_t* item_prof;           // instrumented kernel: 16 counters per output slot, else nullptr
+  const uint32_t* q_wins;        // per query: the doc windows of all its items (speculation: the denominator of "how much have I seen")
   uint32_t k_stride, pad;
   DHelp help;
 };

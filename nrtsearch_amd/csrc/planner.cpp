@@ -765,6 +765,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     for (int qi = 0; qi < n_queries; ++qi) { hp.q_base[(size_t)qi] = run; run += hp.q_nlists[(size_t)qi]; }
   }
   hp.list_idx.assign(pend.size(), 0);
+  hp.q_wins.assign((size_t)n_queries, 0u);
   std::vector<uint32_t> q_fill((size_t)n_queries, 0);
   for (size_t i = 0; i < pend.size(); ++i) {
     DItem it{};
@@ -792,6 +793,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
         wins += (p.tile_end - (p.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
       }
       it.flags |= std::min(wins, 0xFFFFFFu) << 8;
+      hp.q_wins[pend[i].query] += wins;
     }
     hp.items[i] = it;
     hp.list_idx[it.peer_slot] = (uint32_t)i;

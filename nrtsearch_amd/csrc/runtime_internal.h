@@ -54,7 +54,7 @@ void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* i
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
                        uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_head = nullptr,
-                       const uint32_t* help_next = nullptr, uint32_t help_slot_base = 0);
+                       const uint32_t* help_next = nullptr, uint32_t help_slot_base = 0, const unsigned long long* spec_g = nullptr);
 void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,
                        uint32_t* fnorm, uint64_t n, uint32_t* overflow);
 void launch_pack_count(hipStream_t stream, const uint32_t* fnorm, uint64_t n, uint32_t n_blocks, uint32_t* counts);
@@ -443,6 +443,11 @@ struct nrtgpu_ctx {
   int co_inflight_queries = 0;                // ... and how many queries they hold
   int co_last_batch = 0;                      // size of the batch formed last (a lone caller does not linger)
   int32_t co_linger_us = 150;
+  // speculative thresholds (plan.h: kHitsSpecInvalid; nrtgpu_debug_spec_counters): queries run under speculation, queries whose guess
+  // failed and were run again, and the switch the library throws itself when too many fail (docs not spread like a sample)
+  std::atomic<int64_t> spec_queries{0}, spec_reruns{0};
+  std::atomic<int> spec_off{0};
+  std::atomic<int> spec_z16{getenv("NRTGPU_MS_SPEC_Z") ? (int)(atof(getenv("NRTGPU_MS_SPEC_Z")) * 16.0 + 0.5) : 5 * 16};   // the guess's margin x 16 (nrtgpu_set_speculation)
   std::atomic<int64_t> live_segments{0};   // segment handles (uploads and forks) that have not been freed yet (nrtgpu_debug_live_segments)
   std::atomic<int> co_hold{0};                          // nrtgpu_debug_hold_coalescers: no leader (of either coalescer) leaves with less than a full batch / panel
   // the same for exact vector searches (nrtgpu_knn_exact_coalesced, vectors.cpp)
@@ -597,6 +602,7 @@ struct HostPlan {
   uint32_t n_slices = 1;            // searcher slices over the call's leaves (MyIndexSearcher.slices): per query that many hit sums
   // MaxScore route (maxscore.hip): items [0, n_ms_items) run it, the others the exhaustive scan
   uint32_t n_ms_items = 0;
+  std::vector<uint32_t> q_wins;     // per query: doc windows of its MaxScore items (plan.h: MsArgs.q_wins)
   std::vector<int64_t> q_lower;     // per query on that route in kMsModePrune: live docs certain to match (> totalHitsThreshold), else 0
   std::vector<uint8_t> q_route;     // per query: kRouteScan (exhaustive scan) or kRouteMs + its kMsMode* (plan.h)
   int64_t ms_postings = 0;          // postings of the queries on that route (algorithmic work, as `postings`)

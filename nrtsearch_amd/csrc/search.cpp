@@ -3,6 +3,12 @@
 #include "runtime_internal.h"
 
 
+// Speculative thresholds of the MaxScore route (plan.h: kHitsSpecInvalid): the guess's safety margin in standard deviations x 16
+// (nrtgpu_set_speculation; a context starts with NRTGPU_MS_SPEC_Z, default 5; 0: no speculation).  Measured on C3
+// (profiles/r04_speculation_ab.log): margin 6 / 4 / 3 -> kernel 1.94 / 1.92 / (1.9) ms against 2.29 without, 0 / 0 / 108 of
+// 122 880 queries run again.
+static uint32_t spec_margin16(const nrtgpu_ctx* ctx) { return (uint32_t)std::max(ctx->spec_z16.load(std::memory_order_relaxed), 0); }
+
 struct DeviceRun {
   // device pointers valid until the slot is reused
   uint64_t* out_keys = nullptr;
@@ -25,7 +31,7 @@ struct DeviceRun {
 // upload and expansion between any two scorer launches).
 static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
                           uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
-                          std::unique_lock<std::mutex>& gpu, int64_t epoch = -1) {
+                          std::unique_lock<std::mutex>& gpu, int64_t epoch = -1, bool allow_spec = false) {
   const size_t n_items = hp.items.size();
   Carver pc;
   const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
@@ -44,6 +50,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_lower = pc.take(ext_hits ? hp.q_lower.size() * 8 : 0);  // device-resident results: certain lower bounds
   const bool use_xch = epoch >= 0 && ctx->xch_dev != nullptr;
   const size_t o_xch = pc.take(use_xch ? sizeof(DExchange) : 0);
+  const size_t o_qwins = pc.take(hp.q_wins.size() * 4);
   const size_t o_help = pc.take(sizeof(MsArgs));   // the MaxScore launch's record (plan.h); filled in below, once the workspace is carved
   const size_t plan_bytes = pc.off;
   if (int rc = slot->h_plan.reserve(plan_bytes)) return rc;
@@ -61,6 +68,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_qnl, hp.q_nlists.data(), hp.q_nlists.size() * 4);
   memcpy(hb + o_qk, hp.q_k.data(), hp.q_k.size() * 4);
   memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
+  if (!hp.q_wins.empty()) memcpy(hb + o_qwins, hp.q_wins.data(), hp.q_wins.size() * 4);
   memset(hb + o_quant, 0, hp.list_idx.size() * 8);
   if (ext_hits) memcpy(hb + o_lower, hp.q_lower.data(), hp.q_lower.size() * 8);
   if (use_xch) {
@@ -97,6 +105,11 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_hwin = wc.take(hp.n_ms_items * 4), o_hcnt = wc.take(hp.n_ms_items * 4), o_ht0 = wc.take(hp.n_ms_items * 8);
   const size_t o_hhead = wc.take((size_t)n_queries * 4), o_hnext = wc.take(n_help * 4), o_hoff = wc.take(4);
   const size_t o_hqueue = wc.take(4), o_hused = wc.take(4), o_hstart = wc.take(8);
+  // speculative thresholds (plan.h: kHitsSpecInvalid): only where the caller can run a query again -- nrtgpu_search_bm25_batch.
+  // NRTGPU_MS_SPEC_Z: the guess's safety margin in standard deviations (0: no speculation)
+  const uint32_t spec_z16 = spec_margin16(ctx);
+  const bool spec = allow_spec && spec_z16 != 0u && hp.n_ms_items != 0 && !use_xch && ctx->spec_off.load(std::memory_order_relaxed) == 0;
+  const size_t o_spec = wc.take(spec ? (size_t)n_queries * 8 : 0);
   const size_t zero_bytes = wc.off - o_ssum;
   // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
   const int flag_variant = (ctx->cfg.flags >> 8) & 15;
@@ -145,6 +158,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   static const bool env_help_greedy = getenv("NRTGPU_MS_HELP_GREEDY") != nullptr && atoi(getenv("NRTGPU_MS_HELP_GREEDY")) != 0;
   help.min_rem = (uint32_t)std::min(std::max(env_help_min, 1), 0xFFFF) | (env_help_greedy ? 1u << 16 : 0u);
   help.walls = profile ? (unsigned long long*)(wb + o_walls) : nullptr;
+  help.spec_g = spec ? (unsigned long long*)(wb + o_spec) : nullptr;
+  help.spec_z16 = spec ? spec_z16 : 0u;
   MsArgs ms_args{};   // (the kernel reads the record from the plan: maxscore.hip)
   ms_args.items = (const DItem*)(db + o_items);
   ms_args.parts = (const DPart*)(db + o_parts);
@@ -159,6 +174,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   ms_args.item_counts = (uint32_t*)(wb + o_icnt);
   ms_args.item_hits = (uint64_t*)(wb + o_ihits);
   ms_args.item_prof = profile ? (uint64_t*)(wb + o_prof) : nullptr;
+  ms_args.q_wins = (const uint32_t*)(db + o_qwins);
   ms_args.k_stride = hp.k_stride;
   ms_args.help = help;
   memcpy(hb + o_help, &ms_args, sizeof(ms_args));
@@ -209,7 +225,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)(wb + o_ikeys), (const uint32_t*)(wb + o_icnt),
                     (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
                     (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
-                    k_stride_out, n_help ? help.help_head : nullptr, help.help_next, help.slot_base);
+                    k_stride_out, n_help ? help.help_head : nullptr, help.help_next, help.slot_base, help.spec_g);
   // TotalHits.relation by the reference's per-slice rule, tagged into the merged counts
   launch_slice_relation(st, (const uint32_t*)(wb + o_ssum), (const DQuery*)(db + o_queries), hp.n_slices, ohits, (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
@@ -298,9 +314,11 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
 // ------------------------------------------------------------------------------------------------
 // ABI: search
 // ------------------------------------------------------------------------------------------------
-extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
-                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                                        nrtgpu_topdocs* out) {
+// rerun: where the indices of the queries go whose speculative threshold failed the merge's check (plan.h: kHitsSpecInvalid);
+// nullptr: no speculation in this call.
+static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                             int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                             nrtgpu_topdocs* out, std::vector<int32_t>* rerun) {
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
   if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
@@ -329,7 +347,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   const double tc0 = call_trace ? now_ms() : 0.0;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
-    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) return rc;
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu, -1, rerun != nullptr)) return rc;
   }
   HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
   const double tc1 = call_trace ? now_ms() : 0.0;
@@ -346,9 +364,12 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     ctx->pool->run(n_chunks, [&](int c) {
       const int q0 = (int)((int64_t)n_queries * c / n_chunks), q1 = (int)((int64_t)n_queries * (c + 1) / n_chunks);
       for (int qi = q0; qi < q1; ++qi)
-        unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi], queries[qi].k, hp.q_lower[(size_t)qi], cnts[qi], &out[qi]);
+        unpack_topdocs(keys + (size_t)qi * hp.k_stride, cnts[qi], hits[qi] & ~kHitsSpecInvalid, queries[qi].k, hp.q_lower[(size_t)qi], cnts[qi], &out[qi]);
     });
   }
+  if (rerun)
+    for (int qi = 0; qi < n_queries; ++qi)
+      if (hits[qi] & kHitsSpecInvalid) rerun->push_back(qi);
   if (call_trace)
     fprintf(stderr, "[nrtgpu call] %d queries: plan %.3f ms, upload + kernels %.3f, results to host %.3f, unpack %.3f\n", n_queries, plan_ms,
             tc1 - tc0, tc2 - tc1, now_ms() - tc2);
@@ -366,6 +387,62 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     }
   }
   account(ctx, slot, hp, n_queries, plan_ms, t0, queue_ms);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                        nrtgpu_topdocs* out) {
+  // The MaxScore route may run under SPECULATIVE thresholds here (plan.h: kHitsSpecInvalid; NRTGPU_MS_SPEC_Z): a query whose guess
+  // the merge could not confirm comes back tagged and is run again without speculation -- behind the first pass, whose locks and
+  // workspace are released by then.  What the caller sees is exact either way; a failed guess costs that query a second pass.
+  std::vector<int32_t> rerun;
+  const bool spec = ctx && spec_margin16(ctx) != 0u && ctx->spec_off.load(std::memory_order_relaxed) == 0;
+  const int rc = search_batch_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, out, spec ? &rerun : nullptr);
+  if (rc != 0 || !spec) return rc;
+  const nrtgpu_diagnostics first = g_diag;
+  // the library's own switch: docs that are not spread over the index like a random sample (sorted by a field the score follows)
+  // make guesses fail wholesale -- every failure is a second pass
+  const int64_t seen = ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
+  const int64_t failed = ctx->spec_reruns.fetch_add((int64_t)rerun.size(), std::memory_order_relaxed) + (int64_t)rerun.size();
+  if (seen >= 2048 && failed * 50 > seen) ctx->spec_off.store(1, std::memory_order_relaxed);
+  if (rerun.empty()) return rc;
+  std::vector<nrtgpu_bm25_query> rq(rerun.size());
+  std::vector<nrtgpu_topdocs> ro(rerun.size());
+  for (size_t i = 0; i < rerun.size(); ++i) {
+    rq[i] = queries[rerun[i]];
+    ro[i] = out[rerun[i]];
+  }
+  const int rc2 = search_batch_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), ro.data(), nullptr);
+  if (rc2 != 0) return rc2;
+  for (size_t i = 0; i < rerun.size(); ++i) out[rerun[i]] = ro[i];
+  nrtgpu_diagnostics d = g_diag;   // both passes
+  d.total_ms += first.total_ms;
+  d.plan_ms += first.plan_ms;
+  d.queue_ms += first.queue_ms;
+  d.device_ms += first.device_ms;
+  d.postings += first.postings;
+  d.queries = first.queries;
+  d.items_maxscore += first.items_maxscore;
+  d.items_scan += first.items_scan;
+  g_diag = d;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_set_speculation(nrtgpu_ctx* ctx, float margin) {
+  if (!ctx || !(margin >= 0.0f)) return fail(NRTGPU_ERR_INVALID_ARG, "speculation: a margin >= 0 expected");
+  ctx->spec_z16.store((int)std::min(255.0f * 16.0f, margin * 16.0f + 0.5f), std::memory_order_relaxed);
+  ctx->spec_queries.store(0, std::memory_order_relaxed);
+  ctx->spec_reruns.store(0, std::memory_order_relaxed);
+  ctx->spec_off.store(0, std::memory_order_relaxed);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_debug_spec_counters(nrtgpu_ctx* ctx, int64_t* out3) {
+  if (!ctx || !out3) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
+  out3[0] = ctx->spec_queries.load(std::memory_order_relaxed);
+  out3[1] = ctx->spec_reruns.load(std::memory_order_relaxed);
+  out3[2] = ctx->spec_off.load(std::memory_order_relaxed);
   return NRTGPU_OK;
 }
 

@@ -19,13 +19,13 @@ KNOWN_SCRATCH = {
     # from one round to the next (thread / wave ids, the launch record's pointer halves) are parked in scratch at the round's head
     # and fetched in its epilogue -- NOT inside the walk, which test_the_maxscore_walk_touches_no_scratch pins.  Same box, same
     # run: identical launch times with and without them (profiles/r04_persistent_spare_ab.log: "record" vs "kargs").
-    "bm25_maxscore_kernel<false, false, 2>": 80,      # SHAPES == 2 (tie breaker / MUST + SHOULD): a second accumulator per posting slot,
+    "bm25_maxscore_kernel<false, false, 2>": 96,      # SHAPES == 2 (tie breaker / MUST + SHOULD): a second accumulator per posting slot,
     "bm25_maxscore_kernel<false, true, 2>": 144,      #   sixteen registers the kernel does not have -- spills INSIDE the walk, these shapes only
-    "bm25_maxscore_kernel<true, false, 2>": 160,
+    "bm25_maxscore_kernel<true, false, 2>": 176,
     "bm25_maxscore_kernel<true, true, 2>": 240,
     "bm25_maxscore_kernel<false, false, *>": 32,
     "bm25_maxscore_kernel<false, true, *>": 80,       # packed postings
-    "bm25_maxscore_kernel<true, false, *>": 96,       # instrumented (NRTGPU_FLAG_PROFILE): measurement only
+    "bm25_maxscore_kernel<true, false, *>": 112,      # instrumented (NRTGPU_FLAG_PROFILE): measurement only
     "bm25_maxscore_kernel<true, true, *>": 160,
     "bm25_scan_kernel<*, true, 7, false>": 16,        # instrumented scan: measurement only
     "bm25_scan_kernel<true, true, 8, false>": 16,     # clause counting on the exhaustive route (COMPLETE mode): 2 VGPRs, outside the loop

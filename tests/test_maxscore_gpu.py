@@ -238,3 +238,58 @@ def test_search_after_under_slicing_pins_the_documented_divergence(ctxs, oracle)
     finally:
         ix.close()
         ctx.set_slicing()
+
+
+def test_speculative_thresholds_are_checked_and_failed_guesses_run_again(oracle):
+    """Speculative thresholds (plan.h: kHitsSpecInvalid; nrtgpu_set_speculation): a workgroup guesses the final k-th score from the
+    best of the docs it has seen so far and skips what cannot reach the guess; the merge checks the guess, a query whose guess
+    failed is run again without speculation inside the call.  Three things: (1) on an index whose docs are spread like a sample
+    the guesses hold and the results are the oracle's; (2) on one where they are NOT -- every live doc in the first third of the
+    docid range, so a third of the way through a workgroup has seen every hit and still expects twice as many -- guesses fail,
+    the queries are run again, and the results are still the oracle's; (3) a context in which too many guesses fail switches
+    speculation off by itself."""
+    ctx = api.GpuContext(device_id=0, max_batch=64)
+    ranks = [1, 2, 5, 9, 20, 60, 150, 400]
+    corpus = synth.build_corpus(3_200_000, ranks, n_segments=1)    # one segment: 49 doc windows per query, one work item + helpers
+    ix = Index(ctx, corpus)
+    try:
+        ctx.set_speculation(5.0)
+        qs = [[1, 5, 20, 150, 400], [2, 9, 60], [1, 2, 5, 9, 20, 60, 150, 400], [5, 400], [9, 20, 150]]
+        for k, thr in ((1000, 1000), (100, 10), (10, 1000)):
+            got = ix.searcher.search_batch([bq(t) for t in qs], [api.TopScoreDocCollectorManager(k, None, thr)] * len(qs))
+            for i, t in enumerate(qs):
+                check(f"spec_{k}_{thr}_{i}", got[i], oracle.search_bm25(corpus, t, k, total_hits_threshold=thr), k, thr)
+        c = ctx.debug_spec_counters()
+        assert c["queries"] == 3 * len(qs) and not c["switched_off"]
+        assert c["reruns"] <= 1, c      # (five standard deviations: a failure here is a bug in the estimate, not bad luck)
+        # (2) only the first 30 % of the docids are live
+        seg = corpus.segments[0]
+        live = np.zeros((seg.max_doc + 63) // 64, dtype=np.uint64)
+        n_live = int(seg.max_doc * 0.3) // 64 * 64
+        live[: n_live // 64] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        seg.live_bits = live
+        ix.leaves[0].set_live_docs(live)
+        ctx.set_speculation(5.0)    # (resets the counters)
+        for k, thr in ((1000, 1000), (100, 10)):
+            got = ix.searcher.search_batch([bq(t) for t in qs], [api.TopScoreDocCollectorManager(k, None, thr)] * len(qs))
+            for i, t in enumerate(qs):
+                check(f"spec_skewed_{k}_{thr}_{i}", got[i], oracle.search_bm25(corpus, t, k, total_hits_threshold=thr), k, thr)
+        c = ctx.debug_spec_counters()
+        assert c["queries"] == 2 * len(qs) and c["reruns"] >= 3, c
+        # (3) ... and a context that keeps failing gives speculation up: 2048 queries seen, more than 2 % of them run again
+        rng = np.random.Generator(np.random.PCG64(99))
+        last = None
+        for _ in range(36):
+            batch = [[int(x) for x in rng.choice(ranks, size=int(rng.integers(2, 6)), replace=False)] for _ in range(64)]
+            got = ix.searcher.search_batch([bq(t) for t in batch], [api.TopScoreDocCollectorManager(100, None, 10)] * 64)
+            last = (batch, got)
+        c = ctx.debug_spec_counters()
+        assert c["switched_off"], c
+        for i in range(0, 64, 9):
+            check(f"spec_off_{i}", last[1][i], oracle.search_bm25(corpus, last[0][i], 100, total_hits_threshold=10), 100, 10)
+        before = ctx.debug_spec_counters()["reruns"]
+        ix.searcher.search_batch([bq(t) for t in qs], [api.TopScoreDocCollectorManager(100, None, 10)] * len(qs))
+        assert ctx.debug_spec_counters()["reruns"] == before     # nothing speculates any more
+    finally:
+        ix.close()
+        ctx.close()
