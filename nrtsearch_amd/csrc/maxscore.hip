@@ -83,6 +83,7 @@ struct MsSmem {
   uint32_t spec_at;      // speculation: the next estimate is due when wins_started reaches this (0: never)
   uint32_t q_wins;       // doc windows of ALL items of the query
   uint32_t spec_z16;     // speculation (plan.h: kHitsSpecInvalid): safety margin in standard deviations x 16; 0: off
+  uint32_t spec_grow16;  // ... the next estimate is due when wins_started has grown by this factor x 16
   unsigned long long* spec_slot;   // ... and where the query's largest speculative theta is published
   uint64_t pick;         // a helper's choice: float bits of its key (expected time left / an exponential variate) << 32 | item + 1
   uint32_t role[4];      // the workgroup's first decision (start the next item / help one): scratch values every thread reads
@@ -271,9 +272,9 @@ __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem
       atomicMax(theta_g, (unsigned long long)guess);
       atomicMax(s.spec_slot, (unsigned long long)guess);
     }
-    // the next estimate: when twice as many windows have been taken (the guess moves with the fraction's square root)
+    // the next estimate: when (by default) twice as many windows have been taken -- the guess moves with the fraction's square root
     const uint32_t ws = s.wins_started;
-    s.spec_at = ws >= s.q_wins ? 0u : max(2u * ws, ws + (uint32_t)kMsWaves);
+    s.spec_at = ws >= s.q_wins ? 0u : max(ws * s.spec_grow16 / 16u, ws + (uint32_t)kMsWaves);
   }
   __syncthreads();
   if (tid == 0) s.rz_flag = 0;
@@ -511,7 +512,8 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       s.q_wins = spec ? as_global(ap->q_wins)[item.query] : 0u;
       s.spec_z16 = spec ? hp.spec_z16 : 0u;
       s.spec_slot = spec ? as_global(hp.spec_g) + item.query : nullptr;
-      s.spec_at = spec ? 2u * (uint32_t)kMsWaves : 0u;   // the first estimate: when every wave has begun its second window
+      s.spec_at = spec ? max(hp.spec_sched & 255u, 1u) : 0u;   // the first estimate (default: when every wave has begun its second window)
+      s.spec_grow16 = max((hp.spec_sched >> 8) & 255u, 17u);
       for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
       for (int i = 0; i < 16; ++i) s.prof[i] = 0;
     }

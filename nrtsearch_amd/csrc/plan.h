@@ -257,7 +257,8 @@ struct DHelp {
   uint32_t persistent;           // 1: the launch has one workgroup per CU and each chooses work until none is left (maxscore.hip)
   unsigned long long* spec_g;    // [queries] the largest SPECULATIVE theta a workgroup has published for the query (kMsSpec*), 0 = none;
                                  // nullptr: no speculation in this launch
-  uint32_t spec_z16, pad_spec;   // the estimate's safety margin in standard deviations x 16
+  uint32_t spec_z16, spec_sched; // the estimate's safety margin in standard deviations x 16; when estimates are due: bits 0-7 the
+                                 // first one (doc windows begun by the workgroup), bits 8-15 the factor x 16 between one and the next
   unsigned long long* walls;     // instrumented kernel only, else nullptr: per output slot 8 words -- {start, end} on the 100 MHz
                                  // wall clock, item, windows walked, when the workgroup's round began, CU id, round, workgroup --
                                  // when every piece of the launch ran, on one time base (nrtgpu_get_maxscore_item_walls)

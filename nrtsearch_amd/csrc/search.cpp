@@ -160,6 +160,11 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   help.walls = profile ? (unsigned long long*)(wb + o_walls) : nullptr;
   help.spec_g = spec ? (unsigned long long*)(wb + o_spec) : nullptr;
   help.spec_z16 = spec ? spec_z16 : 0u;
+  {   // NRTGPU_MS_SPEC_FIRST / NRTGPU_MS_SPEC_GROW (x 16): when a workgroup's estimates are due (plan.h: DHelp.spec_sched)
+    static const int env_first = getenv("NRTGPU_MS_SPEC_FIRST") ? atoi(getenv("NRTGPU_MS_SPEC_FIRST")) : 2 * kMsWaves;
+    static const int env_grow = getenv("NRTGPU_MS_SPEC_GROW") ? atoi(getenv("NRTGPU_MS_SPEC_GROW")) : 32;
+    help.spec_sched = (uint32_t)std::min(std::max(env_first, 1), 255) | ((uint32_t)std::min(std::max(env_grow, 17), 255) << 8);
+  }
   MsArgs ms_args{};   // (the kernel reads the record from the plan: maxscore.hip)
   ms_args.items = (const DItem*)(db + o_items);
   ms_args.parts = (const DPart*)(db + o_parts);
