@@ -478,6 +478,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
     // until then every live matching doc is evaluated and counted, as the reference's collector does before it first
     // publishes a min competitive score.  theta filters the candidates in every mode.
     const uint32_t mode = item.flags & 3u;
+    const uint32_t win_tiles = (uint32_t)kMsWinTiles >> ((item.flags >> 2) & 3u);   // (uniform) sub-tiles per doc window of this item
     const uint32_t msm = SHAPES ? q.min_should_match : 0u;   // (> 1: clause counting)
     const bool use_max = SHAPES && q.combine_max != 0u;       // DisjunctionMaxQuery, tie breaker 0
     const uint32_t sec_mode = TWO ? q.sec_mode : kMsSecNone;  // (uniform) what the second accumulator holds
@@ -563,9 +564,9 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       for (;; ++pi) {
         if (pi >= item.n_parts) break;
         part = parts[item.part_begin + pi];
-        // windows start on kMsWinTiles boundaries of the SEGMENT (the first one of a part may be short): a window never
+        // windows start on win_tiles boundaries of the SEGMENT (the first one of a part may be short): a window never
         // spans two 2^20-doc super-windows, which is what packed doc offsets are relative to
-        part_wins = (part.tile_end - (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
+        part_wins = (part.tile_end - (part.tile_begin & ~(win_tiles - 1u)) + win_tiles - 1u) / win_tiles;
         if (g < win_base + part_wins) break;
         win_base += part_wins;
       }
@@ -651,9 +652,9 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
 
       for (;;) {  // windows of this part
         const uint64_t t_win0 = PROF ? __builtin_readcyclecounter() : 0ull;
-        const uint32_t ta = (part.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (g - win_base) * (uint32_t)kMsWinTiles;
+        const uint32_t ta = (part.tile_begin & ~(win_tiles - 1u)) + (g - win_base) * win_tiles;
         const uint32_t t0 = max(ta, part.tile_begin);
-        const uint32_t t1 = min(ta + (uint32_t)kMsWinTiles, part.tile_end);
+        const uint32_t t1 = min(ta + win_tiles, part.tile_end);
         const uint32_t doc_lo = t0 * (uint32_t)kTileDocs;
         const uint32_t doc_span = min(t1 * (uint32_t)kTileDocs, part.max_doc) - doc_lo;
         if (PROF) pc_wins += 1;
@@ -1363,13 +1364,13 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
           unsigned long long* const wr = as_global(hpe.walls) + (size_t)out_slot * 8;
           wr[0] = wall0;                 // the item's prologue begins (role chosen, plan records read)
           wr[1] = wall_clock64();        // the item is done
-          wr[2] = my_item;
+          wr[2] = (unsigned long long)my_item | ((unsigned long long)item.flags << 32);   // (+ the item's flags: mode, window size, windows)
           wr[3] = s.prof[0];             // windows walked here
           wr[4] = wall_entry;            // this round began (a fresh workgroup: its first instruction)
           // which CU: XCC_ID[3:0] | HW_ID's se_id[15:13], sh_id[12], cu_id[11:8]
           wr[5] = ((unsigned long long)((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 8) |
                   (unsigned long long)(((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 255u);
-          wr[6] = round;
+          wr[6] = (unsigned long long)round | ((unsigned long long)item.query << 32);
           wr[7] = blockIdx.x;
         }
       }

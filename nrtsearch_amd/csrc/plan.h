@@ -185,8 +185,9 @@ struct alignas(16) DItem {
   int32_t  tab_scale[kTabTerms];  // fixed-point batches: fx_scale of each score table's term
   int32_t  fx_E;                  // fixed-point batches: accumulators hold score * 2^fx_E
   uint32_t peer_slot;             // this item's slot among the query's items [DQuery.item_begin, + n_items)
-  uint32_t flags;                 // MaxScore kernel, bits 0-1: when bounds may skip work (kMsMode*); bits 8-31: the item's doc windows
-                                  // (kMsWinDocs docs each, summed over its parts): what helpers share with the owner
+  uint32_t flags;                 // MaxScore kernel, bits 0-1: when bounds may skip work (kMsMode*); bits 2-3: the item's doc windows hold
+                                  // kMsWinTiles >> that many sub-tiles (planner.cpp: the launch's heaviest queries get finer ones);
+                                  // bits 8-31: the item's doc windows (summed over its parts): what helpers share with the owner
 };
 static_assert(sizeof(DItem) == 96, "DItem layout");
 

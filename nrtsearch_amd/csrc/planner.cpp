@@ -755,6 +755,29 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   std::stable_partition(pend.begin(), pend.end(), [&](const Pending& a) { return on_ms_kernel(a.query); });
   hp.n_ms_items = 0;
   for (const Pending& a : pend) hp.n_ms_items += on_ms_kernel(a.query) ? 1u : 0u;
+  // Finer doc windows for the slowest queries of a launch (maxscore.hip: a window is what ONE wave walks alone -- the grain at
+  // which an item's owner and its helpers share work; a wave holds its current window and has its next one reserved).  Measured
+  // under speculative thresholds (scripts/gpu_tail_items.py, profiles/r04_tail_items.log): the launch's slowest item -- five
+  // frequent terms, nothing to prune by -- needs 154 us per 64-tile window and wave against a 2.0 ms launch; 24 of its 159
+  // windows are in its own waves' hands at any time, so helpers never find the 16 unassigned ones they ask for, and it ends
+  // 170 us after 99 % of the items: the launch's whole tail.  Such queries get windows of a quarter the size (plan.h:
+  // DItem.flags bits 2-3); the others keep theirs -- a window's head (cell lookups, bitset clear, clause ranges) is 7 % of an
+  // average item's time.  Which queries: by the postings of their two heaviest clauses -- what the walk must evaluate, +0.84
+  // with an item's cost where all postings have +0.26 (scripts/cpu_launch_order_sim.py) -- one MaxScore query in
+  // NRTGPU_MS_FINE_ITEMS (default 32; 0: none; profiles/r04_fine_windows_ab.log).
+  std::vector<uint8_t> q_fine((size_t)n_queries, 0);
+  {
+    static const int env_fine = getenv("NRTGPU_MS_FINE_ITEMS") ? atoi(getenv("NRTGPU_MS_FINE_ITEMS")) : 32;
+    static const int env_shift = getenv("NRTGPU_MS_FINE_SHIFT") ? std::min(std::max(atoi(getenv("NRTGPU_MS_FINE_SHIFT")), 1), 3) : 2;
+    if (env_fine > 0 && hp.n_ms_items >= 64) {
+      std::vector<std::pair<int64_t, int32_t>> by_key;
+      for (int qi = 0; qi < n_queries; ++qi)
+        if (on_ms_kernel((uint32_t)qi) && q_qs_cnt[(size_t)qi] != 0) by_key.emplace_back(-q_ms_key[(size_t)qi], qi);
+      const size_t n_fine = std::min(by_key.size(), std::max<size_t>(1, by_key.size() / (size_t)env_fine));
+      std::partial_sort(by_key.begin(), by_key.begin() + (ptrdiff_t)n_fine, by_key.end());
+      for (size_t i = 0; i < n_fine; ++i) q_fine[(size_t)by_key[i].second] = (uint8_t)env_shift;
+    }
+  }
   hp.items.resize(pend.size());
   // the items of a query, in launch order: counting sort by query (q_base = first slot of the query's list)
   hp.q_base.assign((size_t)n_queries, 0);
@@ -788,11 +811,12 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
       // its doc windows (maxscore.hip: windows start on kMsWinTiles boundaries of the segment, a part's first one may be short):
       // what the owner's waves and the item's helpers hand out from one counter (plan.h: DHelp)
       uint32_t wins = 0;
+      const uint32_t fine = q_fine[pend[i].query], wt = (uint32_t)kMsWinTiles >> fine;   // (every item of a query: one window size)
       for (uint32_t pi2 = 0; pi2 < it.n_parts; ++pi2) {
         const DPart& p = hp.parts[it.part_begin + pi2];
-        wins += (p.tile_end - (p.tile_begin & ~((uint32_t)kMsWinTiles - 1u)) + (uint32_t)kMsWinTiles - 1u) / (uint32_t)kMsWinTiles;
+        wins += (p.tile_end - (p.tile_begin & ~(wt - 1u)) + wt - 1u) / wt;
       }
-      it.flags |= std::min(wins, 0xFFFFFFu) << 8;
+      it.flags |= (fine << 2) | (std::min(wins, 0xFFFFFFu) << 8);
       hp.q_wins[pend[i].query] += wins;
     }
     hp.items[i] = it;

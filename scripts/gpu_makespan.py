@@ -41,6 +41,8 @@ def main():
         pb.run()
         st = ctx.stats()
         walls, n_items = ctx.maxscore_item_walls()
+        walls[:, 2] &= np.uint64(0xFFFFFFFF)    # (the upper halves: the item's flags / its query)
+        walls[:, 6] &= np.uint64(0xFFFFFFFF)
         used = walls[:, 1] > 0
         t0 = int(walls[used, 4].min())                           # the first workgroup's first instruction
         start = (walls[:, 0].astype(np.int64) - t0) / 100.0      # us: the piece's prologue begins (role chosen)
