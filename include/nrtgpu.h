@@ -257,8 +257,8 @@ int  nrtgpu_debug_coalescer_pending(nrtgpu_ctx* ctx, int32_t which);
 /* TEST HOOK: segment handles of the context (uploads and forks) that have not been freed yet.  nrtgpu_segment_release under
  * running searches defers the free to the last of them: this count is how a test observes that it happened. */
 int64_t nrtgpu_debug_live_segments(nrtgpu_ctx* ctx);
-/* Speculative thresholds of the MaxScore route (nrtgpu_search_bm25 / _batch / _coalesced -- the calls that can run
- * a query again): a workgroup that has walked a fraction of a query's docs guesses the final k-th score from the best of what
+/* Speculative thresholds of the MaxScore route (nrtgpu_search_bm25 / _batch / _coalesced / nrtgpu_search_hybrid_batch
+ * -- the calls that can run a query again): a workgroup that has walked a fraction of a query's docs guesses the final k-th score from the best of what
  * it has seen, `margin` standard deviations on the safe side, and skips what cannot reach the guess; the merge checks every
  * guess against the merged list and a query whose guess failed is run again without speculation inside the same call.  Results
  * are exact either way.  margin 0 switches it off; a context starts with 5 (or NRTGPU_MS_SPEC_Z).  Resets the counters. */

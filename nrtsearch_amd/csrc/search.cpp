@@ -455,10 +455,10 @@ extern "C" int nrtgpu_debug_spec_counters(nrtgpu_ctx* ctx, int64_t* out3) {
 // the stages (RescoreTask.java:47-50 -> QueryRescore.java:39-57 applied to the hits of
 // SearchHandler.java:1412-1413).  Same results as nrtgpu_search_bm25_batch followed per query by
 // nrtgpu_rescore_vectors.
-extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
-                                          int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                                          int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost,
-                                          double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out) {
+static int search_hybrid_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                              int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                              int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost,
+                              double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out, std::vector<int32_t>* rerun) {
   if (!ctx || !queries || !out || !query_vectors || (n_segs > 0 && (!segs || !doc_bases)))
     return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
@@ -527,7 +527,7 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   DeviceRun run;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
-    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu)) {
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu, -1, rerun != nullptr)) {
       (void)hipStreamSynchronize(st);   // the upload of the query vectors reads the slot's pinned buffer: not in flight when the slot is released
       return rc;
     }
@@ -548,10 +548,43 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   const uint64_t* hits = (const uint64_t*)(ha + oh_h);
   for (int qi = 0; qi < n_queries; ++qi) {
     // QueryRescorer keeps the first pass's TotalHits; the window only trims the hits
-    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi], std::min<int32_t>(window, NRTGPU_MAX_K), hp.q_lower[(size_t)qi],
+    unpack_topdocs(keys + (size_t)qi * w_stride, cnts[qi], hits[qi] & ~kHitsSpecInvalid, std::min<int32_t>(window, NRTGPU_MAX_K), hp.q_lower[(size_t)qi],
                    first_cnts[qi] == (uint32_t)queries[qi].k ? (uint32_t)std::min<int32_t>(window, NRTGPU_MAX_K) : 0xFFFFFFFFu, &out[qi]);
+    // (a first pass whose speculative threshold failed the merge's check fed the tail a wrong recall set: the query is run again)
+    if (rerun && (hits[qi] & kHitsSpecInvalid)) rerun->push_back(qi);
   }
   account(ctx, slot, hp, n_queries, plan_ms);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                          int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                          int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost,
+                                          double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out) {
+  // The first pass may run under speculative thresholds (plan.h: kHitsSpecInvalid), as in nrtgpu_search_bm25_batch: recall, tail
+  // and the copy back stay one stream with no host round trip; the merge's tags arrive with the results, and a tagged query --
+  // its recall set may lack docs -- is run again, first pass and tail, without speculation.
+  std::vector<int32_t> rerun;
+  const bool spec = ctx && spec_margin16(ctx) != 0u && ctx->spec_off.load(std::memory_order_relaxed) == 0;
+  const int rc = search_hybrid_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, field_id, sim, query_vectors, dim, boost, query_weight,
+                                    rescore_weight, window, out, spec ? &rerun : nullptr);
+  if (rc != 0 || !spec) return rc;
+  const int64_t seen = ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
+  const int64_t failed = ctx->spec_reruns.fetch_add((int64_t)rerun.size(), std::memory_order_relaxed) + (int64_t)rerun.size();
+  if (seen >= 2048 && failed * 50 > seen) ctx->spec_off.store(1, std::memory_order_relaxed);
+  if (rerun.empty()) return rc;
+  std::vector<nrtgpu_bm25_query> rq(rerun.size());
+  std::vector<nrtgpu_topdocs> ro(rerun.size());
+  std::vector<float> rv(rerun.size() * (size_t)dim);
+  for (size_t i = 0; i < rerun.size(); ++i) {
+    rq[i] = queries[rerun[i]];
+    ro[i] = out[rerun[i]];
+    memcpy(rv.data() + i * (size_t)dim, query_vectors + (size_t)rerun[i] * (size_t)dim, (size_t)dim * sizeof(float));
+  }
+  const int rc2 = search_hybrid_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), field_id, sim, rv.data(), dim, boost, query_weight,
+                                     rescore_weight, window, ro.data(), nullptr);
+  if (rc2 != 0) return rc2;
+  for (size_t i = 0; i < rerun.size(); ++i) out[rerun[i]] = ro[i];
   return NRTGPU_OK;
 }
 

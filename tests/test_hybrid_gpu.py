@@ -218,3 +218,42 @@ def test_coalesced_single_searches_from_many_threads(hybrid, oracle):
     # an invalid request fails alone, with its own message
     with pytest.raises(Exception):
         hybrid["sr"].search_coalesced(_bq([1, 20]), api.TopScoreDocCollectorManager(0))
+
+
+def test_fused_hybrid_under_speculative_thresholds_equals_the_unspeculated_answer():
+    """The fused hybrid's first pass runs under speculative thresholds too (plan.h: kHitsSpecInvalid): the merge's tags arrive with
+    the results and a query whose guess failed -- its recall set may lack docs -- is run again, first pass and tail.  On an index
+    whose live docs all sit in the first third of the docid range (guesses fail there: tests/test_maxscore_gpu.py) the fused
+    answer with speculation must be the fused answer without, docids and score bits, and the counters must show the re-runs."""
+    rng = np.random.default_rng(5)
+    ranks = [1, 2, 5, 9, 20, 60, 150, 400]
+    corpus = synth.build_corpus(3_200_000, ranks, n_segments=1)
+    seg = corpus.segments[0]
+    dim = 16
+    ctx = api.GpuContext(0, max_batch=64)
+    g = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
+    g.add_field_norms(0, seg.norms)
+    g.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+    g.add_vectors(VEC_FIELD, rng.standard_normal((seg.max_doc, dim)).astype(np.float32))
+    g.seal()
+    live = np.zeros((seg.max_doc + 63) // 64, dtype=np.uint64)
+    live[: int(seg.max_doc * 0.3) // 64] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    g.set_live_docs(live)
+    sr = api.GpuIndexSearcher(ctx, [g], api.IndexStatistics.from_corpus(corpus))
+    try:
+        qs = [_bq(t) for t in ([1, 5, 20, 150, 400], [2, 9, 60], [1, 2, 5, 9, 20, 60, 150, 400], [5, 400], [9, 20, 150])]
+        mg = [api.TopScoreDocCollectorManager(1000)] * len(qs)
+        qv = rng.standard_normal((len(qs), dim)).astype(np.float32)
+        ctx.set_speculation(5.0)
+        fused = sr.search_hybrid_batch(qs, mg, VEC_FIELD, "cosine", qv, 100, 1.0, 2.0)
+        c = ctx.debug_spec_counters()
+        assert c["queries"] == len(qs) and c["reruns"] >= 2, c
+        ctx.set_speculation(0.0)
+        plain = sr.search_hybrid_batch(qs, mg, VEC_FIELD, "cosine", qv, 100, 1.0, 2.0)
+        assert ctx.debug_spec_counters()["queries"] == 0
+        for a, b in zip(fused, plain):
+            assert a.docs.tolist() == b.docs.tolist() and a.scores.view(np.uint32).tolist() == b.scores.view(np.uint32).tolist()
+            assert len(a.docs) == 100 and a.relation_gte == b.relation_gte   # (the counts are lower bounds: what each run happened to evaluate)
+    finally:
+        g.release()
+        ctx.close()
