@@ -175,8 +175,8 @@ typedef struct {
   int32_t min_should_match;        /* minimumNumberShouldMatch (QueryNodeMapper.java:259-261): 0 and 1 are the plain
                                     * disjunction; > 1: only docs matched by that many clauses are hits, the score
                                     * is still the sum over all matching clauses (what Lucene's WANDScorer returns).
-                                    * > 1 needs the fixed-point accumulators for the whole batch, else
-                                    * NRTGPU_ERR_UNSUPPORTED; not accepted by nrtgpu_search_bm25_coalesced */
+                                    * > 1 on the exhaustive route needs the fixed-point accumulators for the whole batch,
+                                    * else NRTGPU_ERR_UNSUPPORTED (nrtgpu_search_bm25_coalesced: for that request only) */
   float   min_competitive_score;   /* Scorable.setMinCompetitiveScore across shards: a lower bound of the k-th best
                                     * score of the WHOLE search this call is one shard of (other GPUs' results so
                                     * far, LazyMaxScoreAccumulator).  Docs scoring strictly below it are counted in
@@ -189,10 +189,9 @@ typedef struct {
   int32_t disjunction_max;         /* 0: BooleanQuery, a doc scores the sum of its matching clauses.
                                     * 1: DisjunctionMaxQuery over the same term clauses (src/main/java/com/yelp/nrtsearch/
                                     * server/query/QueryNodeMapper.java:350-358): a doc scores its BEST matching clause plus
-                                    * tie_breaker x the others.  Fixed-point accumulators for the whole batch (else
-                                    * NRTGPU_ERR_UNSUPPORTED), min_should_match <= 1, every clause SHOULD; disjuncts that are
-                                    * not term queries stay on the caller's path; not accepted by
-                                    * nrtgpu_search_bm25_coalesced */
+                                    * tie_breaker x the others.  Fixed-point sums (on the exhaustive route: for the whole batch), else
+                                    * NRTGPU_ERR_UNSUPPORTED; min_should_match <= 1, every clause SHOULD; disjuncts that are
+                                    * not term queries stay on the caller's path */
   int32_t n_more_filters;          /* further FILTER clauses next to filter_mask (QueryNodeMapper.java:257-283 builds any number): */
   const int32_t* more_filters;     /* ... resident mask ids > 0; a hit lies in ALL of the query's filter masks */
   int32_t n_more_must_not;         /* further MUST_NOT clauses next to must_not_mask: */
