@@ -36,7 +36,12 @@
 // PERSISTENT workgroup per CU (minus a few spare CUs) that chooses work round after round -- start the next item, or HELP a
 // running one: an item's windows come from a counter in global memory, so its owner and any number of helpers share them; a
 // helper keeps its own candidate list and output slot, which the merge walks next to the item's.  Which doc is evaluated by
-// whom changes nothing of the argument above: windows partition an item's docs, theta only filters.
+// whom changes nothing of the argument above: windows partition an item's docs, theta only filters.  The launch's slowest
+// queries get windows of a quarter the size (DItem.flags bits 2-3): a window is the grain at which work is shared.
+// Speculative thresholds (plan.h: kHitsSpecInvalid; ms_compact): besides the guaranteed theta -- the k-th best of what has been
+// seen -- a workgroup publishes a GUESS at the final k-th key from the best of the docs it has walked; the merge checks every
+// guess against the merged list and the host runs a query whose guess failed again.  A guess therefore changes what is skipped
+// and, when it fails, how often a query is run -- never what is returned.
 // Roofline: HBM.  Reported both ways: effective = 9 B x the postings of the query's terms, physical
 // = what the kernel fetches (a few percent of that).
 #include <hip/hip_runtime.h>
