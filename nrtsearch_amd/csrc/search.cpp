@@ -8,6 +8,15 @@
 // (profiles/r04_speculation_ab.log): margin 6 / 4 / 3 -> kernel 1.94 / 1.92 / (1.9) ms against 2.29 without, 0 / 0 / 108 of
 // 122 880 queries run again.
 static uint32_t spec_margin16(const nrtgpu_ctx* ctx) { return (uint32_t)std::max(ctx->spec_z16.load(std::memory_order_relaxed), 0); }
+static bool speculating(const nrtgpu_ctx* ctx) { return ctx && spec_margin16(ctx) != 0u && ctx->spec_off.load(std::memory_order_relaxed) == 0; }
+// A call that ran under speculation has come back: count it, and throw the library's own switch when too many guesses fail -- docs
+// that are not spread over the index like a random sample (sorted by a field the score follows) make them fail wholesale, and
+// every failure is a second pass.
+static void note_speculation(nrtgpu_ctx* ctx, int64_t n_queries, int64_t n_rerun) {
+  const int64_t seen = ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
+  const int64_t failed = ctx->spec_reruns.fetch_add(n_rerun, std::memory_order_relaxed) + n_rerun;
+  if (seen >= 2048 && failed * 50 > seen) ctx->spec_off.store(1, std::memory_order_relaxed);
+}
 
 struct DeviceRun {
   // device pointers valid until the slot is reused
@@ -105,8 +114,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   const size_t o_hwin = wc.take(hp.n_ms_items * 4), o_hcnt = wc.take(hp.n_ms_items * 4), o_ht0 = wc.take(hp.n_ms_items * 8);
   const size_t o_hhead = wc.take((size_t)n_queries * 4), o_hnext = wc.take(n_help * 4), o_hoff = wc.take(4);
   const size_t o_hqueue = wc.take(4), o_hused = wc.take(4), o_hstart = wc.take(8);
-  // speculative thresholds (plan.h: kHitsSpecInvalid): only where the caller can run a query again -- nrtgpu_search_bm25_batch.
-  // NRTGPU_MS_SPEC_Z: the guess's safety margin in standard deviations (0: no speculation)
+  // speculative thresholds (plan.h: kHitsSpecInvalid): only where the caller can run a query again (allow_spec: the batch and the
+  // hybrid entry), never next to the cross-GPU bound exchange (its quantile uses the selection's second rank)
   const uint32_t spec_z16 = spec_margin16(ctx);
   const bool spec = allow_spec && spec_z16 != 0u && hp.n_ms_items != 0 && !use_xch && ctx->spec_off.load(std::memory_order_relaxed) == 0;
   const size_t o_spec = wc.take(spec ? (size_t)n_queries * 8 : 0);
@@ -402,15 +411,11 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   // the merge could not confirm comes back tagged and is run again without speculation -- behind the first pass, whose locks and
   // workspace are released by then.  What the caller sees is exact either way; a failed guess costs that query a second pass.
   std::vector<int32_t> rerun;
-  const bool spec = ctx && spec_margin16(ctx) != 0u && ctx->spec_off.load(std::memory_order_relaxed) == 0;
+  const bool spec = speculating(ctx);
   const int rc = search_batch_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, out, spec ? &rerun : nullptr);
   if (rc != 0 || !spec) return rc;
   const nrtgpu_diagnostics first = g_diag;
-  // the library's own switch: docs that are not spread over the index like a random sample (sorted by a field the score follows)
-  // make guesses fail wholesale -- every failure is a second pass
-  const int64_t seen = ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
-  const int64_t failed = ctx->spec_reruns.fetch_add((int64_t)rerun.size(), std::memory_order_relaxed) + (int64_t)rerun.size();
-  if (seen >= 2048 && failed * 50 > seen) ctx->spec_off.store(1, std::memory_order_relaxed);
+  note_speculation(ctx, n_queries, (int64_t)rerun.size());
   if (rerun.empty()) return rc;
   std::vector<nrtgpu_bm25_query> rq(rerun.size());
   std::vector<nrtgpu_topdocs> ro(rerun.size());
@@ -565,13 +570,11 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   // and the copy back stay one stream with no host round trip; the merge's tags arrive with the results, and a tagged query --
   // its recall set may lack docs -- is run again, first pass and tail, without speculation.
   std::vector<int32_t> rerun;
-  const bool spec = ctx && spec_margin16(ctx) != 0u && ctx->spec_off.load(std::memory_order_relaxed) == 0;
+  const bool spec = speculating(ctx);
   const int rc = search_hybrid_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, field_id, sim, query_vectors, dim, boost, query_weight,
                                     rescore_weight, window, out, spec ? &rerun : nullptr);
   if (rc != 0 || !spec) return rc;
-  const int64_t seen = ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
-  const int64_t failed = ctx->spec_reruns.fetch_add((int64_t)rerun.size(), std::memory_order_relaxed) + (int64_t)rerun.size();
-  if (seen >= 2048 && failed * 50 > seen) ctx->spec_off.store(1, std::memory_order_relaxed);
+  note_speculation(ctx, n_queries, (int64_t)rerun.size());
   if (rerun.empty()) return rc;
   std::vector<nrtgpu_bm25_query> rq(rerun.size());
   std::vector<nrtgpu_topdocs> ro(rerun.size());
