@@ -27,6 +27,12 @@ CASES = [
     {"terms": [1, 40, 1000], "k": 30, "threshold": 1000, "must_not": {"density": 0.1, "seed": 12}},
     {"terms": [1, 5, 13], "k": 12, "threshold": 1000, "msm": 2, "filter": {"density": 0.5, "seed": 13},
      "must_not": {"density": 0.05, "seed": 14}, "after_rank": 11},
+    # the shapes whose score is not one sum (round 4): DisjunctionMaxQuery (tie breaker 0 and > 0), MUST next to SHOULD clauses
+    {"terms": [1, 5, 40, 200], "k": 20, "threshold": 1000, "dismax": 0.0},
+    {"terms": [2, 13, 40, 1000], "boosts": [1.0, 2.0, 0.5, 3.0], "k": 20, "threshold": 1000, "dismax": 0.3},
+    {"terms": [13, 1, 40, 200], "k": 20, "threshold": 1000, "must": [True, False, False, False]},
+    {"terms": [2, 40, 1, 5, 1000], "boosts": [1.0, 0.5, 2.0, 1.0, 3.0], "k": 25, "threshold": 2**31 - 1, "must": [True, True, False, False, False],
+     "filter": {"density": 0.6, "seed": 15}},
 ]
 
 
@@ -44,7 +50,8 @@ def accept_of(corpus, c):
 
 def run_case(corpus, c):
     acc, _, _ = accept_of(corpus, c)
-    kw = dict(boosts=c.get("boosts"), total_hits_threshold=c["threshold"], min_should_match=c.get("msm", 0), accept=acc)
+    kw = dict(boosts=c.get("boosts"), total_hits_threshold=c["threshold"], min_should_match=c.get("msm", 0), accept=acc,
+              dismax=c.get("dismax"), must=c.get("must"))
     after = None
     if "after_rank" in c:   # page 2: searchAfter the hit at that rank of page 1
         d, s, _, _ = oracle.search_bm25(corpus, c["terms"], c["k"], **kw)

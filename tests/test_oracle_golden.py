@@ -422,7 +422,7 @@ def test_oracle_matches_its_frozen_fixture(oracle):
     spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(here, "make_oracle_fixtures.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
-    assert len(g["cases"]) >= 10
+    assert len(g["cases"]) >= 14
     for c in g["cases"]:
         (docs, scores, total, gte), _ = gen.run_case(corpus, c)
         assert docs.tolist() == c["docs"] and scores.view(np.uint32).tolist() == c["score_bits"]

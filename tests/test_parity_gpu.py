@@ -261,7 +261,7 @@ def test_frozen_oracle_fixture_through_the_device(ctx):
     try:
         for ci, c in enumerate(g["cases"]):
             q = bq(c["terms"], c.get("boosts"))
-            if "msm" in c or "filter" in c or "must_not" in c:   # masks: PCG64(seed + 100 * segment), as the generator
+            if "msm" in c or "filter" in c or "must_not" in c or "must" in c:   # masks: PCG64(seed + 100 * segment), as the generator
                 ids = {}
                 for name in ("filter", "must_not"):
                     if name in c:
@@ -271,6 +271,11 @@ def test_frozen_oracle_fixture_through_the_device(ctx):
                 cl = q.should if isinstance(q, api.BooleanQuery) else (q,)
                 q = api.BooleanQuery(cl, c.get("msm", 0), (api.MaskFilter(ids["filter"]),) if "filter" in ids else (),
                                      (api.MaskFilter(ids["must_not"]),) if "must_not" in ids else ())
+            if "dismax" in c:    # the clauses as the disjuncts of a DisjunctionMaxQuery
+                q = api.DisjunctionMaxQuery(q.should if isinstance(q, api.BooleanQuery) else (q,), c["dismax"])
+            if "must" in c:      # MUST next to SHOULD clauses (minimumNumberShouldMatch 0), the masks kept
+                cl = q.should
+                q = api.BooleanQuery(tuple(x for x, m in zip(cl, c["must"]) if not m), 0, q.filter, q.must_not, tuple(x for x, m in zip(cl, c["must"]) if m))
             after = None
             if "after" in c:
                 after = api.ScoreDoc(c["after"]["doc"], float(np.uint32(c["after"]["score_bits"]).view(np.float32)))
