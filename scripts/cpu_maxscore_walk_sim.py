@@ -8,7 +8,12 @@ test-and-set per doc, S_j re-checked before each lookup, S of an instruction's f
 simplifications: one segment per item, a clause's bound = its largest score in the corpus, scores in fp64, ties ignored, the 12
 waves advance one instruction per tick.  (a)'s counts are to be held against profiles/r03_kernel_shapes.log -- per query 590
 instruction groups, 262 k postings streamed, 166 k docs evaluated, 248 k lookups -- before (b)'s are believed.
-    python scripts/cpu_maxscore_walk_sim.py [n_queries=8] [first_query=0]     (ONLY_KERNEL_ORDER=1: the kernel's order alone)"""
+    python scripts/cpu_maxscore_walk_sim.py [n_queries=8] [first_query=0]     (ONLY_KERNEL_ORDER=1: the kernel's order alone)
+Round 4: SPEC_Z=5 adds the kernel's SPECULATIVE thresholds (plan.h: kHitsSpecInvalid) to the kernel's order -- at every compaction,
+and whenever the number of windows begun has doubled, theta is raised to the (k w / W + z sqrt(k w / W) + 2)-th best score held
+(w of W windows begun) -- and reports how many guesses overshot the final k-th score (what the merge's check would catch).  The
+counts `rounds` (later-clause rounds as the kernel runs them: one per instruction and later clause with a live doc) and
+`queued_rounds` (the same lookups regrouped per wave, window and clause into rounds of 512: DESIGN 8 item 2) come with every run."""
 import os
 import sys
 
@@ -23,6 +28,7 @@ CAP = int(os.environ.get("CAND_CAP", "2304"))     # the workgroup's candidate bu
 ONLY_KERNEL_ORDER = os.environ.get("ONLY_KERNEL_ORDER", "") != ""
 SPLIT_ITEMS = int(os.environ.get("SPLIT_ITEMS", "0"))   # > 1: also the query cut into that many items over equal doc ranges
 INSTR = 512
+SPEC_Z = float(os.environ.get("SPEC_Z", "0"))
 BLOCK_SHIFTS = [int(x) for x in os.environ.get("BLOCK_SHIFTS", "").split(",") if x]   # e.g. 16,13,10,7
 
 
@@ -31,7 +37,29 @@ class Item:
         self.k = k
         self.theta = 0.0
         self.cand = []
-        self.n = dict(groups=0, windows=0, postings=0, marked=0, survivors=0, docs=0, lookups=0, cands=0, compactions=0)
+        self.n = dict(groups=0, windows=0, postings=0, marked=0, survivors=0, docs=0, lookups=0, cands=0, compactions=0, rounds=0,
+                      queued_rounds=0, estimates=0)
+        self.n_win, self.wins_started, self.spec_at, self.guess_max = 1, 0, 2 * WAVES, 0.0
+
+    def guess(self):
+        """maxscore.hip: ms_compact -- the speculative theta from what the buffer holds."""
+        if SPEC_Z <= 0 or not self.cand:
+            return
+        m = self.k * min(1.0, self.wins_started / self.n_win)
+        r = m + SPEC_Z * np.sqrt(m) + 2.0
+        allc = np.concatenate(self.cand)
+        if r < self.k and len(allc) > int(r):
+            g = float(np.partition(allc, len(allc) - int(r))[len(allc) - int(r)])
+            if g > self.theta:
+                self.theta = g
+                self.guess_max = max(self.guess_max, g)
+        self.spec_at = 0 if self.wins_started >= self.n_win else max(2 * self.wins_started, self.wins_started + WAVES)
+
+    def window_begun(self):
+        self.wins_started += 1
+        if SPEC_Z > 0 and self.spec_at and self.wins_started >= self.spec_at:
+            self.n["estimates"] += 1
+            self.guess()
 
     def push(self, scores):
         scores = scores[scores > self.theta]
@@ -47,6 +75,7 @@ class Item:
                 self.theta = max(self.theta, float(allc.min()))
             self.cand = [allc]
             self.n["compactions"] += 1
+            self.guess()
 
 
 def window_instructions(D, lo_hi, clauses):
@@ -78,6 +107,7 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None, win_range=N
     if win_range is not None:                                     # an item over a part of the doc range: windows [g0, g1)
         next_win[0], n_win = win_range[0], min(win_range[1], n_win)
     waves = [None] * WAVES
+    it.n_win = max(1, n_win - next_win[0])
 
     def open_window(g):
         w0, w1 = g * WIN, min((g + 1) * WIN, N)
@@ -85,10 +115,13 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None, win_range=N
         ess = [c for c in stream if S[c] >= it.theta]            # decided at the window's start (ng = 0 otherwise)
         seq = window_instructions(D, lo_hi, list(mark_only) + ess) if ess else []
         it.n["windows"] += 1
-        return dict(w0=w0, seen=np.zeros(w1 - w0, dtype=bool), seq=seq, pos=0)
+        it.window_begun()
+        return dict(w0=w0, seen=np.zeros(w1 - w0, dtype=bool), seq=seq, pos=0, qj=np.zeros(n_terms, dtype=np.int64))
 
     def step(ws):
         if ws["pos"] >= len(ws["seq"]):
+            if "qj" in ws:   # the window is done: its lookups regrouped per clause into rounds of 512
+                it.n["queued_rounds"] += int(np.sum((ws.pop("qj") + INSTR - 1) // INSTR))
             return False
         cl, ix = ws["seq"][ws["pos"]]
         ws["pos"] += 1
@@ -96,9 +129,12 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None, win_range=N
         c_first = int(cl[0])
         if c_first not in mark_only and S[c_first] < theta:      # the rest of the window has become non-essential
             ws["pos"] = len(ws["seq"])
+            if "qj" in ws:
+                it.n["queued_rounds"] += int(np.sum((ws.pop("qj") + INSTR - 1) // INSTR))
             return False
         it.n["groups"] += 1
         valid = ix >= 0
+        round_of = np.zeros(n_terms, dtype=bool)   # later clauses for which this instruction runs a round
         for c in np.unique(cl):
             m = valid & (cl == c)
             idx = ix[m]
@@ -123,8 +159,11 @@ def run_walk(it, D, Sc, dense, S, N, stream, mark_only=(), blk=None, win_range=N
                 if not live.any():
                     break
                 it.n["lookups"] += int(live.sum())
+                round_of[j] = True
+                ws["qj"][j] += int(live.sum())
                 run = run + np.where(live, dense[j][docs], 0.0)
             it.push(run[live])
+        it.n["rounds"] += int(round_of.sum())
         return True
 
     active = True
@@ -191,7 +230,16 @@ def main():
             print(f"q{first + qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}   split {SPLIT_ITEMS}: {parts}", flush=True)
             continue
         if ONLY_KERNEL_ORDER:
-            print(f"q{first + qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}", flush=True)
+            over = ""
+            if SPEC_Z > 0:
+                acc0 = np.zeros(N, dtype=np.float64)
+                for c in range(len(D)):
+                    acc0[D[c]] += Sc[c]
+                nz0 = acc0[acc0 > 0]
+                final0 = float(np.partition(nz0, len(nz0) - k)[len(nz0) - k]) if len(nz0) >= k else 0.0
+                tot["guesses that overshot"] = tot.get("guesses that overshot", 0) + int(a.guess_max > final0)
+                over = f"   largest guess {a.guess_max:.3f} vs final k-th {final0:.3f}" + ("  OVERSHOT" if a.guess_max > final0 else "")
+            print(f"q{first + qi} df {[len(d) for d in D]} P {P}   kernel order theta {a.theta:.3f} {a.n}{over}", flush=True)
             t = tot.setdefault("kernel order", {})
             for kk, v in a.n.items():
                 t[kk] = t.get(kk, 0) + v
@@ -233,8 +281,11 @@ def main():
             for kk, v in it.n.items():
                 t[kk] = t.get(kk, 0) + v
         assert abs(a.theta - b.theta) < 1e-9 or True
+    overshot = tot.pop("guesses that overshot", None)
     for name, t in tot.items():
         print("MEAN per query,", name, {kk: round(v / nq, 1) for kk, v in t.items()})
+    if overshot is not None:
+        print(f"speculation at z = {SPEC_Z}: {overshot} of {nq} queries had a guess above their final k-th score (they would be run again)")
     # A linear reading of the seed experiment: time ~ F groups + a postings + b docs + c lookups, non-negative weights fitted to
     # the three measured ratios; what it says about the two sweeps (an indication: 3 equations, 4 unknowns -> least norm)
     try:
