@@ -96,6 +96,11 @@ final class NrtGpu {
   static final MethodHandle RESCORE = h("nrtgpu_rescore_vectors", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
       JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, JAVA_FLOAT, ADDRESS, ADDRESS, JAVA_INT, JAVA_DOUBLE, JAVA_DOUBLE, JAVA_INT, ADDRESS));
 
+  /** Speculative thresholds of the MaxScore route (results stay exact: a query whose guess fails is run again inside the call):
+   *  the guess's safety margin in standard deviations; 0 switches them off for the context -- e.g. a live setting for an index
+   *  sorted by a field the score follows (the library also gives up by itself when too many guesses fail). */
+  static final MethodHandle SET_SPECULATION = h("nrtgpu_set_speculation", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_FLOAT));
+
   static String lastError() {
     try {
       MemorySegment p = (MemorySegment) LAST_ERROR.invokeExact();
