@@ -79,3 +79,27 @@ def test_a_begin_wait_pipeline_does_not_deadlock_against_a_writer(mockhip):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "pipeline_vs_writer.py")], env=e, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "finished True" in r.stdout, (us, r.stdout[-500:], r.stderr[-1500:])
         assert "'b': 120, 'wait': 120" in r.stdout, r.stdout[-300:]
+
+
+def test_the_planner_on_the_second_accumulator_shapes(mockhip):
+    """What the planner decides for a DisjunctionMaxQuery with a tie breaker and for MUST next to SHOULD clauses (the MaxScore
+    kernel's second accumulator: that route or the caller's path) and the C ABI's argument checks around them -- host logic,
+    against the stand-in HIP runtime (tests/mockhip/plan_shapes.py)."""
+    e = dict(os.environ, LD_PRELOAD=mockhip)
+    e.pop("NRTGPU_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "plan_shapes.py")], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "done" in r.stdout, r.stderr[-2000:]
+    got = {}
+    for line in r.stdout.split("\n"):
+        if " " in line:
+            name, rest = line.split(" ", 1)
+            got[name] = rest
+    ok = ("tie_small", "tie_complete_small", "tie_zero_nine_clauses", "must_should", "all_must", "must_term_nowhere", "raw_plain", "raw_all_must")
+    assert all(got[n] == "ok" for n in ok), {n: got[n] for n in ok}
+    for n in ("tie_complete_large", "tie_nine_clauses", "must_should_complete_large"):     # would need the exhaustive scan: one accumulator there
+        assert got[n].startswith("unsupported:") and "MaxScore route only" in got[n], got[n]
+    assert got["tie_out_of_range"].startswith("mirror:") and got["must_should_with_msm"].startswith("mirror:")
+    for n, what in (("raw_occur_2", "occur must be 0"), ("raw_tie_without_dismax", "tie_breaker without disjunction_max"), ("raw_tie_negative", "[0, 1]"),
+                    ("raw_must_in_dismax", "have no occur")):
+        assert got[n].startswith("rc -1:") and what in got[n], got[n]      # NRTGPU_ERR_INVALID_ARG
+    assert got["raw_must_with_msm"].startswith("rc -4:")                     # NRTGPU_ERR_UNSUPPORTED: Lucene's third sum structure
