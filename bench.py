@@ -1021,7 +1021,7 @@ def main():
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
             "dynamic_pruning": not args.no_prune,
-            "speculation": ctx.debug_spec_counters(),   # speculative thresholds of the MaxScore route: queries run under them / run again
+            "speculation": ctx.spec_counters(),   # speculative thresholds of the MaxScore route: queries run under them / run again
             "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
             "host_threads": n_thr, "host_cpus_busy": round(host_cpu_busy, 2), "host_cpus_busy_by_thread_kind": cpu_by_kind,
             "corpus_build_s": round(t_build, 1),

@@ -60,6 +60,11 @@ typedef struct {
   int32_t collect_timing;   /* !=0: bracket the scan kernel with HIP events (nrtgpu_get_stats) */
   int32_t flags;            /* NRTGPU_FLAG_* */
   int32_t host_threads;     /* planner threads used inside one batch call (term-dictionary lookups); 0 => 4 */
+  int32_t lookup_budget_pct; /* HBM a segment may spend on doc -> posting lookup structures of the dynamic-pruning route (per term a
+                             * 16-bit code map or lookup cells), in percent of its resident posting bytes, granted to the largest
+                             * terms first; 0 => 150; < 0 => none (every lookup is a binary search in the postings: slower, same
+                             * results) */
+  int32_t reserved;
 } nrtgpu_config;
 
 #define NRTGPU_FLAG_NO_PREFETCH 1     /* scan kernel without the one-tile-ahead posting prefetch (A/B) */
@@ -246,26 +251,13 @@ int  nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, co
 int  nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                   const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);
 int  nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us);
-/* TEST HOOKS for the two coalescers (this one and nrtgpu_knn_exact_coalesced).  hold != 0: no leader leaves with less than a
- * full batch (max_batch queries) / panel (64 queries) until the hold is released -- a test queues a known set of callers behind
- * it, waits until nrtgpu_debug_coalescer_pending (which: 0 = BM25, 1 = exact vector search) reports all of them, releases,
- * and may then assert the batches formed BY CONSTRUCTION (what a batch is must not depend on the host's speed).  Not for
- * production callers: a held coalescer parks every request. */
-int  nrtgpu_debug_hold_coalescers(nrtgpu_ctx* ctx, int32_t hold);
-int  nrtgpu_debug_coalescer_pending(nrtgpu_ctx* ctx, int32_t which);
-/* TEST HOOK: segment handles of the context (uploads and forks) that have not been freed yet.  nrtgpu_segment_release under
- * running searches defers the free to the last of them: this count is how a test observes that it happened. */
-int64_t nrtgpu_debug_live_segments(nrtgpu_ctx* ctx);
 /* Speculative thresholds of the MaxScore route (nrtgpu_search_bm25 / _batch / _coalesced / nrtgpu_search_hybrid_batch
  * -- the calls that can run a query again): a workgroup that has walked a fraction of a query's docs guesses the final k-th score from the best of what
  * it has seen, `margin` standard deviations on the safe side, and skips what cannot reach the guess; the merge checks every
  * guess against the merged list and a query whose guess failed is run again without speculation inside the same call.  Results
- * are exact either way.  margin 0 switches it off; a context starts with 5 (or NRTGPU_MS_SPEC_Z).  Resets the counters. */
+ * are exact either way.  margin 0 switches it off; a context starts with 5.  Resets the counters nrtgpu_get_stats reports
+ * (spec_queries / spec_reruns / spec_disabled). */
 int  nrtgpu_set_speculation(nrtgpu_ctx* ctx, float margin);
-/* out3 = {queries
- * run under speculation, queries whose guess failed the merge's check and were run again, 1 once the library has switched
- * speculation off for this context because too many failed} */
-int  nrtgpu_debug_spec_counters(nrtgpu_ctx* ctx, int64_t* out3);
 
 /* Device-resident variant for the multi-GPU path (one process per GPU): results stay
  * in HBM as packed keys so the caller can RCCL all-gather them without a host round trip.
@@ -531,34 +523,12 @@ typedef struct {
   int64_t knn_rows;           /* sum over panels of the rows scored */
   int64_t knn_second_passes;  /* panels that needed a second pass over the rows: a query's nominations did not certify its answer */
   int64_t knn_sketch_launches; /* of knn_score_launches: passes that nominated from the fp16 sketch (half the bytes per row) */
+  int64_t spec_queries;       /* speculative thresholds (nrtgpu_set_speculation), since that call: queries run under them ... */
+  int64_t spec_reruns;        /* ... queries whose guess failed the merge's check and were run again inside their call ... */
+  int64_t spec_disabled;      /* ... 1 once the library has switched speculation off for this context: too many failed */
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);
-#define NRTGPU_FLAG_PROFILE (7 << 8)  /* instrumented kernels (same results): per-item phase cycle and event counters
-                                       * (nrtgpu_get_scan_profile, nrtgpu_get_maxscore_profile).  Bits 8-11 hold no other
-                                       * value in the product library: nrtgpu_create rejects them */
-/* sums over all items since the last reset, instrumented kernel only (wave 0 of each workgroup;
- * cycles = shader clock): [0] prologue cycles, [1] cycles waiting at the rendezvous barrier,
- * [2] rendezvous cycles incl. that wait, [3] walk cycles, [4] epilogue cycles, [5] rendezvous,
- * [6] compactions, [7] sub-tiles, [8] rendezvous: selection cycles, [9] sparse sub-tiles (collected
- * through the postings), [10] rendezvous: keep cycles, [11] rendezvous: publish + append cycles, [12] sub-tiles with candidates,
- * [13] sub-tiles with a possibly competitive doc, [14] last wave's finish cycle, [15] first wave's */
-int  nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16);
-/* the same flag, items of the MaxScore route; sums over items since the last reset: [0] doc windows walked, [1] top-k
- * compactions, [2] posting chunks (512 postings), [3] postings streamed, [4] postings whose bound reached theta,
- * [5] docs evaluated, [6] lookups in later clauses, [7] candidates collected; shader-clock cycles: [8] item prologue,
- * [9] whole item, [10] waves in meetings (waiting + compaction), [11] waves out of windows waiting for the item's end,
- * [12] waves in part prologues, [13] waves walking windows, [14] the item's last wave running out of windows, [15] item
- * epilogue ([10]-[13]: summed over the item's 12 waves) */
-int  nrtgpu_get_maxscore_profile(nrtgpu_ctx* ctx, double* out16);
-/* the same flag: WHEN the pieces of the last MaxScore launch ran.  Per output slot eight words -- {start, end} on the device's
- * 100 MHz wall clock, the item worked on, the doc windows walked, when the workgroup's round began (persistent workgroups choose
- * work round after round), the CU (XCC << 8 | SE, SH, CU), the round, the workgroup; a slot nobody used is all zeros.  The first
- * *n_items slots are the items' owners; slots beyond the call's items (MaxScore + scan) are HELPERS: workgroups that shared the
- * windows of an item someone else owns.  Returns the number of slots (<= cap_slots are written); the makespan of the
- * launch against its balanced load is max(end) - min(start) vs sum(end - start) / CUs. */
-int64_t nrtgpu_get_maxscore_item_walls(nrtgpu_ctx* ctx, uint64_t* out, int64_t cap_slots, int64_t* n_items);
-
 #ifdef __cplusplus
 }
 #endif

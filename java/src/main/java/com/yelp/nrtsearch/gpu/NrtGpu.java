@@ -48,7 +48,8 @@ final class NrtGpu {
   // nrtgpu_config
   static final StructLayout CONFIG =
       MemoryLayout.structLayout(JAVA_INT.withName("device_id"), JAVA_INT.withName("max_batch"), JAVA_INT.withName("target_items"),
-          JAVA_INT.withName("collect_timing"), JAVA_INT.withName("flags"), JAVA_INT.withName("host_threads"));
+          JAVA_INT.withName("collect_timing"), JAVA_INT.withName("flags"), JAVA_INT.withName("host_threads"),
+          JAVA_INT.withName("lookup_budget_pct"), JAVA_INT.withName("reserved"));
 
   // nrtgpu_diagnostics
   static final StructLayout DIAGNOSTICS =

@@ -28,7 +28,7 @@ NRTGPU_FLAG_NO_PRUNE = 16
 NRTGPU_FLAG_PACKED_POSTINGS = 32
 NRTGPU_FLAG_BLOCKING_WAIT = 64
 NRTGPU_FLAG_NO_VECTOR_SKETCH = 128
-NRTGPU_FLAG_PROFILE = 7 << 8
+NRTGPU_FLAG_PROFILE = 7 << 8   # include/nrtgpu_dev.h: the development library only
 NRTGPU_MAX_MASKS = 8
 
 # every symbol include/nrtgpu.h declares (tests/test_abi.py checks the header against this list)
@@ -43,16 +43,23 @@ ABI_SYMBOLS = [
     "nrtgpu_merge_topk_device", "nrtgpu_knn_exact", "nrtgpu_knn_exact_coalesced", "nrtgpu_knn_search", "nrtgpu_rescore_vectors", "nrtgpu_search_hybrid_batch",
     "nrtgpu_int_to_byte4", "nrtgpu_byte4_to_int", "nrtgpu_bm25_idf", "nrtgpu_bm25_avgdl",
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
-    "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile", "nrtgpu_set_slicing",
+    "nrtgpu_set_slicing",
     "nrtgpu_blend", "nrtgpu_dist_unique_id", "nrtgpu_dist_init", "nrtgpu_dist_search_bm25_batch", "nrtgpu_dist_allgather_merge", "nrtgpu_segment_fork",
     "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_knn_exact", "nrtgpu_dist_search_hybrid_batch",
-    "nrtgpu_debug_hold_coalescers", "nrtgpu_debug_coalescer_pending", "nrtgpu_get_maxscore_item_walls", "nrtgpu_knn_exact_relation", "nrtgpu_debug_live_segments", "nrtgpu_debug_spec_counters", "nrtgpu_set_speculation",
+    "nrtgpu_knn_exact_relation", "nrtgpu_set_speculation",
 ]
+# what include/nrtgpu_dev.h adds: test hooks and measurement helpers of the development library (libnrtgpu_dev.so) only
+DEV_SYMBOLS = [
+    "nrtgpu_bench_closed_loop", "nrtgpu_debug_hold_coalescers", "nrtgpu_debug_coalescer_pending", "nrtgpu_debug_live_segments",
+    "nrtgpu_debug_spec_counters", "nrtgpu_get_scan_profile", "nrtgpu_get_maxscore_profile", "nrtgpu_get_maxscore_item_walls",
+]
+DEV_LIB_PATH = os.path.join(_HERE, "libnrtgpu_dev.so")
 
 
 class Config(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("max_batch", C.c_int32), ("target_items", C.c_int32),
-                ("collect_timing", C.c_int32), ("flags", C.c_int32), ("host_threads", C.c_int32)]
+                ("collect_timing", C.c_int32), ("flags", C.c_int32), ("host_threads", C.c_int32),
+                ("lookup_budget_pct", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Term(C.Structure):
@@ -89,7 +96,8 @@ class Stats(C.Structure):
                 ("merge_ms", C.c_double), ("host_plan_ms", C.c_double), ("fixed_point_launches", C.c_int64),
                 ("maxscore_launches", C.c_int64), ("maxscore_ms", C.c_double), ("maxscore_postings", C.c_int64),
                 ("maxscore_items", C.c_int64), ("knn_panels", C.c_int64), ("knn_score_launches", C.c_int64),
-                ("knn_score_ms", C.c_double), ("knn_rows", C.c_int64), ("knn_second_passes", C.c_int64), ("knn_sketch_launches", C.c_int64)]
+                ("knn_score_ms", C.c_double), ("knn_rows", C.c_int64), ("knn_second_passes", C.c_int64), ("knn_sketch_launches", C.c_int64),
+                ("spec_queries", C.c_int64), ("spec_reruns", C.c_int64), ("spec_disabled", C.c_int64)]
 
 
 class NrtGpuError(RuntimeError):
@@ -99,18 +107,32 @@ class NrtGpuError(RuntimeError):
 
 
 _lib = None
+_dev = None
 
 
 def load() -> C.CDLL:
     """dlopen the in-tree library; raises if it has not been built (python -m nrtsearch_amd.build)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+def load_dev() -> C.CDLL:
+    """The development library (include/nrtgpu_dev.h: the product sources + test hooks, instrumented kernels, experiment knobs).
+    tests/conftest.py's `dev_lib` fixture makes it the library api.py talks to for the tests that need a hook."""
+    global _dev
+    if _dev is None:
+        _dev = _open(DEV_LIB_PATH)
+    return _dev
+
+
+def _open(path: str) -> C.CDLL:
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m nrtsearch_amd.build` "
+            f"{path} is missing: build it with `python -m nrtsearch_amd.build` "
             "(hipcc, gfx950). There is no Python/CPU fallback for the query path.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.nrtgpu_version.restype = C.c_char_p
     L.nrtgpu_last_error.restype = C.c_char_p
@@ -162,20 +184,21 @@ def load() -> C.CDLL:
     L.nrtgpu_slices.argtypes = [i32, vp, vp, vp, i32, i32, i32, vp, vp]
     L.nrtgpu_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.nrtgpu_reset_stats.argtypes = [vp]
-    L.nrtgpu_debug_hold_coalescers.argtypes = [vp, C.c_int32]
-    L.nrtgpu_debug_live_segments.argtypes = [vp]
-    L.nrtgpu_debug_live_segments.restype = C.c_int64
     L.nrtgpu_set_speculation.argtypes = [vp, C.c_float]
     L.nrtgpu_set_speculation.restype = C.c_int
-    L.nrtgpu_debug_spec_counters.argtypes = [vp, vp]
-    L.nrtgpu_debug_spec_counters.restype = C.c_int
     L.nrtgpu_knn_exact_relation.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
-    L.nrtgpu_get_maxscore_item_walls.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
-    L.nrtgpu_get_maxscore_item_walls.restype = C.c_int64
-    L.nrtgpu_debug_coalescer_pending.argtypes = [vp, C.c_int32]
     L.nrtgpu_reset_stats.restype = None
-    L.nrtgpu_get_scan_profile.argtypes = [vp, vp]
-    L.nrtgpu_get_maxscore_profile.argtypes = [vp, vp]
+    if hasattr(L, "nrtgpu_debug_hold_coalescers"):   # development build only (include/nrtgpu_dev.h)
+        L.nrtgpu_debug_hold_coalescers.argtypes = [vp, C.c_int32]
+        L.nrtgpu_debug_live_segments.argtypes = [vp]
+        L.nrtgpu_debug_live_segments.restype = C.c_int64
+        L.nrtgpu_debug_spec_counters.argtypes = [vp, vp]
+        L.nrtgpu_debug_spec_counters.restype = C.c_int
+        L.nrtgpu_get_maxscore_item_walls.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+        L.nrtgpu_get_maxscore_item_walls.restype = C.c_int64
+        L.nrtgpu_debug_coalescer_pending.argtypes = [vp, C.c_int32]
+        L.nrtgpu_get_scan_profile.argtypes = [vp, vp]
+        L.nrtgpu_get_maxscore_profile.argtypes = [vp, vp]
     L.nrtgpu_set_slicing.argtypes = [vp, i32, i32, i32]
     L.nrtgpu_blend.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_unique_id.argtypes = [vp]
@@ -198,7 +221,6 @@ def load() -> C.CDLL:
                                                   i32, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_close.argtypes = [vp]
     L.nrtgpu_dist_close.restype = None
-    _lib = L
     return L
 
 

@@ -157,12 +157,14 @@ class BM25Similarity:
 # ---- device context / segment store --------------------------------------------------------------
 class GpuContext:
     def __init__(self, device_id: int = 0, max_batch: int = 1024, target_items: int = 0,
-                 collect_timing: bool = False, flags: int = 0, host_threads: int = 0):
+                 collect_timing: bool = False, flags: int = 0, host_threads: int = 0, lookup_budget_pct: int = 0):
         L = _lib.load()
         if os.environ.get("NRTGPU_PACKED_POSTINGS", "") not in ("", "0"):   # run anything (the whole test suite) on the packed layout
             flags |= _lib.NRTGPU_FLAG_PACKED_POSTINGS
         self.flags = flags
-        cfg = _lib.Config(device_id, max_batch, target_items, int(collect_timing), flags, host_threads)
+        if lookup_budget_pct == 0 and os.environ.get("NRTGPU_TEST_LOOKUP_BUDGET_PCT"):   # run anything on another lookup budget (tests, A/B scripts)
+            lookup_budget_pct = int(os.environ["NRTGPU_TEST_LOOKUP_BUDGET_PCT"])
+        cfg = _lib.Config(device_id, max_batch, target_items, int(collect_timing), flags, host_threads, int(lookup_budget_pct), 0)
         h = C.c_void_p()
         _lib.check(L.nrtgpu_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -247,11 +249,11 @@ class GpuContext:
         """Speculative thresholds of the MaxScore route (nrtgpu_set_speculation): the guess's safety margin in standard deviations; 0 = off."""
         _lib.check(_lib.load().nrtgpu_set_speculation(self._h, C.c_float(float(margin))))
 
-    def debug_spec_counters(self) -> dict:
-        """Speculative thresholds of the MaxScore route (nrtgpu_debug_spec_counters)."""
-        out = (C.c_int64 * 3)()
-        _lib.check(_lib.load().nrtgpu_debug_spec_counters(self._h, out))
-        return {"queries": int(out[0]), "reruns": int(out[1]), "switched_off": bool(out[2])}
+    def spec_counters(self) -> dict:
+        """Speculative thresholds of the MaxScore route (nrtgpu_stats.spec_*): queries run under them since nrtgpu_set_speculation,
+        queries run again, whether the library has switched them off for this context."""
+        st = self.stats()
+        return {"queries": int(st["spec_queries"]), "reruns": int(st["spec_reruns"]), "switched_off": bool(st["spec_disabled"])}
 
     def debug_live_segments(self) -> int:
         """Segment handles of this context (uploads and forks) not freed yet (nrtgpu_debug_live_segments)."""

@@ -1251,8 +1251,8 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
     case 3: NRT_LAUNCH_K(false, true, 3, false); break;
     case 4: NRT_LAUNCH_K(false, true, 4, false); break;
     case 6: NRT_LAUNCH_K(false, true, 6, false); break;  // no candidate handling in sparse sub-tiles
+    case 7: NRT_LAUNCH_FX(true, 7); break;               // instrumented (same results; nrtgpu_get_scan_profile)
 #endif
-    case 7: NRT_LAUNCH_FX(true, 7); break;
     default: NRT_LAUNCH_FX(true, 0); break;
   }
 #undef NRT_LAUNCH_FX

@@ -64,11 +64,12 @@ struct alignas(16) WClause {
   uint32_t count, pad0;     // ... and how many
   float    weight;
   int32_t  fx_scale;
-  uint32_t flags;           // score table (0-2, 7 = none) | MUST clause << 3 | fx_shift << 4 | normInverse table << 8 | cell shift << 16
+  uint32_t flags;           // score table (0-2, 7 = none) | MUST clause << 3 | fx_shift << 4 | normInverse table << 8 | cell shift << 16 |
+                            // lookup kind (plan.h: kLook*) << 24 | log2 docs per lookup cell << 27
   uint32_t pad;
   uint64_t u_after;         // what the later clauses can add at most: S_{c+1}
-  uint64_t bits;            // membership + rank records, 0 = sparse clause
-  uint64_t cells, start;    // cell table, first posting of the term in the columns
+  uint64_t look;            // the term's lookup structure (plan.h: DTermAux.look): code map / lookup cells, 0 = none
+  uint64_t cells, start;    // cell table (kLookNibble: the field's norm bytes instead), first posting of the term in the columns
 };
 static_assert(sizeof(WClause) == 80, "WClause layout");
 
@@ -146,21 +147,33 @@ __device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t 
   }
 }
 
-// The docs a wave still follows -- at most 63, spread over the posting slots of its lanes (bit j of `alive`) -- dealt out one
-// per lane: the i-th of them (lane order, then slot order) goes to lane i, with its running sum and `c | clause count << 4`.
-// ds_permute_b32 is a PUSH (every lane names the lane its value goes to; a lane nobody names reads 0), so each slot takes one
-// push per register and the receiver ORs what arrives; a slot without a doc pushes to lane 63, which holds no doc.
-// Measured (round 3, profiles/r03_kernel_shapes.log): the collapse is correct (the whole parity suite passes with it) but
-// does not pay -- 3.00 vs 2.89 ms per 1024 C3 queries: the survivors of an instruction rarely fit one row before its last
-// lookup round, and the extra code costs registers.  A build-time option (-DNRT_MS_COLLAPSE=1), off by default.
-#ifndef NRT_MS_COLLAPSE
-#define NRT_MS_COLLAPSE 0
-#endif
-constexpr bool kMsCollapse = NRT_MS_COLLAPSE != 0;
-#ifndef NRT_MS_ROWS_SPEC
-#define NRT_MS_ROWS_SPEC 1
-#endif
-constexpr bool kMsRowsSpec = NRT_MS_ROWS_SPEC != 0;   // rows: every later dense clause's record, then code, requested at once
+// The same for the words of a term's CODE MAP (plan.h: kLookMap), one per looked-up doc: bit 15 clear -- (freq << 7) | norm
+// byte, x 4 the table offset; bit 15 set -- freq << 8 | norm byte of a posting no table serves, scored by the formula.  Only
+// slots in `need` hold a posting (and none of them the escape word).  Deleted docs are never looked up: no dead postings here.
+template <int NS>
+__device__ __forceinline__ void values_of_map(const MsSmem& s, const uint32_t (&mw)[NS], uint32_t need, uint32_t tab_slot, float w, int fx_scale,
+                                              uint32_t cache_slot, uint32_t (&val)[NS]) {
+  const uint32_t tab = tab_slot < (uint32_t)kTabTerms ? tab_slot : 7u;
+  const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
+  uint32_t cor = 0;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    val[j] = *(const uint32_t*)(tb + ((mw[j] << 2) & 0x1FFCu));
+    cor |= ((need >> j) & 1u) ? mw[j] : 0u;
+  }
+  const bool special = need != 0u && ((cor >> 15) != 0u || tab == 7u);
+  if (__any(special)) {
+    const float* cache = &s.cache[cache_slot][0];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const bool esc = (mw[j] >> 15) != 0u;
+      const uint32_t f = esc ? ((mw[j] >> 8) & 127u) : ((mw[j] >> 7) & 15u);
+      const uint32_t nb = esc ? (mw[j] & 255u) : (mw[j] & 127u);
+      if (((need >> j) & 1u) && (esc || tab == 7u)) val[j] = score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
+    }
+  }
+}
+
 // -DNRT_MS_PHASE_CLOCKS (a measurement build, instrumented kernel only): where a wave's walk time goes.  At each mark the wave
 // waits for everything it has requested, reads the cycle counter and books the time since the last mark to a phase; the sums
 // over all waves replace the event counters in slots 0-8 of the item's profile row (scripts/gpu_phase_clocks.py names them).
@@ -179,27 +192,6 @@ constexpr bool kMsRowsSpec = NRT_MS_ROWS_SPEC != 0;   // rows: every later dense
 #else
 #define NRT_PH_MARK(i) do {} while (0)
 #endif
-template <int NS>
-__device__ __forceinline__ void collapse_to_rows(const uint32_t (&d)[NS], const uint64_t (&run)[NS], uint32_t alive, uint32_t c,
-                                                 uint32_t ccnt, uint32_t& d1, uint64_t& run1, uint32_t& meta1) {
-  const uint32_t mine = (uint32_t)__popc(alive);
-  uint32_t p = scan64_dpp(mine) - mine;   // the lane my first doc goes to
-  uint32_t od = 0, olo = 0, ohi = 0, om = 0;
-#pragma unroll
-  for (int j = 0; j < NS; ++j) {
-    const bool a = (alive >> j) & 1u;
-    const int addr = (int)((a ? p : 63u) << 2);
-    p += a ? 1u : 0u;
-    od |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)d[j]);
-    olo |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)run[j]);
-    ohi |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)(run[j] >> 32));
-    om |= (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(c | (((ccnt >> (4 * j)) & 15u) << 4)));
-  }
-  d1 = od;
-  run1 = ((uint64_t)ohi << 32) | (uint64_t)olo;
-  meta1 = om;
-}
-
 // The launch record's pointer, laundered: what is loaded through it from here on is loaded again (see the kernel's head).
 // (Through a vector register and back: an asm output counts as divergent, readfirstlane makes it a scalar again.)
 // The record is read through the CONSTANT address space (scalar loads); the pointers it holds are global memory and are cast so
@@ -641,12 +633,14 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         w.count = w.pad0 = 0;
         w.weight = mt.weight;
         w.fx_scale = mt.fx_scale;
+        const DTermAux* const ax = mt.aux;
+        const uint32_t look_kind = ax->look_kind;
         w.flags = ((mt.tab_slot & 0xFFFFu) < (uint32_t)kTabTerms ? (mt.tab_slot & 0xFFFFu) : 7u) | (TWO && (mt.tab_slot & kTabSlotRequired) ? 8u : 0u) |
-                  (mt.fx_shift << 4) | (mt.cache_slot << 8) | (mt.shift << 16);
+                  (mt.fx_shift << 4) | (mt.cache_slot << 8) | ((mt.shift & 31u) << 16) | ((look_kind & 7u) << 24) | (((uint32_t)ax->look_shift & 31u) << 27);
         w.pad = 0;
         w.u_after = my_after;
-        w.bits = (uint64_t)mt.aux->bits;
-        w.cells = (uint64_t)mt.cell_off;
+        w.look = look_kind != kLookNone ? (uint64_t)ax->look : 0ull;
+        w.cells = look_kind == kLookNibble ? (uint64_t)ax->norms : (uint64_t)mt.cell_off;   // (a freq map's clause keeps its field's norms here)
         w.start = mt.start;
         wcl[lane] = w;
       }
@@ -874,154 +868,6 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
           NRT_PH_MARK(3);
           uint32_t ccnt = 0x11111111u;   // SHAPES, minimumNumberShouldMatch: clauses that matched the doc, 4 bits per posting slot
 
-          // ---- One doc per lane: what is left of an instruction once few of its docs survive (collapse_to_rows).  The same
-          //      steps as the rounds below -- bound, lookup, sum, then hits and candidates -- on scalars, at an eighth of the
-          //      vector instructions per round.
-          auto finish_rows = [&](uint32_t d1, uint64_t run1, bool live1, uint32_t c1, uint32_t cnt1, uint32_t j2_begin) {
-            // Dense clauses: the record of EVERY later clause for my doc is requested before the first is used, then every code --
-            // two round trips for the rest of the instruction instead of two per clause.  What is requested for a doc that an
-            // earlier clause's bound drops was requested in vain (bytes, no results): bounds, sums and counts run clause by
-            // clause below exactly as in the rounds.  (A record table spans the segment: any doc's word is there.)
-            constexpr int kRest = kMsMaxTerms - 1;
-            uint32_t cc[kRest], at_[kRest], pres = 0;
-            if (kMsRowsSpec) {
-              u32x2 rr[kRest];
-  #pragma unroll
-              for (int i = 0; i < kRest; ++i) {
-                const uint32_t j2 = j2_begin + (uint32_t)i;
-                rr[i] = u32x2{0u, 0u};
-                if (j2 < n_terms) {   // (uniform)
-                  const uint64_t bits2 = uniform_u64(wcl[j2].bits);
-                  if (bits2 != 0ull) rr[i] = ((gvec2_ptr)bits2)[(live1 && c1 < j2) ? (d1 >> 5) : 0u];
-                }
-              }
-              __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
-              for (int i = 0; i < kRest; ++i) {
-                const uint32_t j2 = j2_begin + (uint32_t)i;
-                cc[i] = at_[i] = 0u;
-                if (j2 < n_terms) {   // (uniform)
-                  const WClause& w2 = wcl[j2];
-                  if (uniform_u64(w2.bits) != 0ull) {
-                    const uint32_t bb = d1 & 31u;
-                    const bool there = live1 && c1 < j2 && ((rr[i][0] >> bb) & 1u);
-                    at_[i] = there ? rr[i][1] + (uint32_t)__popc(rr[i][0] & ((1u << bb) - 1u)) : 0u;
-                    pres |= (there ? 1u : 0u) << i;
-                    cc[i] = ((gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + uniform_u64(w2.start) * 4u))[at_[i]];
-                  }
-                }
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            for (uint32_t j2 = j2_begin; j2 < n_terms; ++j2) {
-              if (!__any(live1)) break;
-              // (the requested words of this clause: element 0; the arrays move down by one per clause, so that they stay registers)
-              const uint32_t code0 = kMsRowsSpec ? cc[0] : 0u, at0 = kMsRowsSpec ? at_[0] : 0u;
-              const bool pres0 = kMsRowsSpec && (pres & 1u) != 0u;
-              if (kMsRowsSpec) {
-  #pragma unroll
-                for (int i = 0; i + 1 < kRest; ++i) {
-                  cc[i] = cc[i + 1];
-                  at_[i] = at_[i + 1];
-                }
-                pres >>= 1;
-              }
-              const uint64_t S_j = readlane_u64(my_suf, j2);
-              bool am = live1 && c1 < j2;
-              if (am && (use_max ? max(run1, S_j) : run1 + S_j) < thr_p) live1 = am = false;
-              if (SHAPES && msm > 1u && am && cnt1 + (n_terms - j2) < msm) live1 = am = false;
-              if (!__any(am)) continue;
-              if (PROF) pc_look += (uint64_t)__popcll(__builtin_amdgcn_ballot_w64(am));
-              const WClause& w2 = wcl[j2];  // uniform reads
-              const uint64_t bits2 = w2.bits;
-              const uint32_t flags2 = w2.flags;
-              const gu32_ptr codes2 = (gu32_ptr)((PACKED ? w2.docids : w2.fnorm) + w2.start * 4u);
-              bool present = false;
-              uint32_t at = 0;   // the doc's posting in the clause (index relative to the clause's first)
-              uint32_t code = 0;
-              if (bits2 != 0ull && kMsRowsSpec) {
-                present = am && pres0;
-                at = present ? at0 : 0u;
-                code = code0;
-              } else if (bits2 != 0ull) {
-                const u32x2 r = ((gvec2_ptr)bits2)[am ? (d1 >> 5) : 0u];
-                const uint32_t bb = d1 & 31u;
-                present = am && ((r[0] >> bb) & 1u);
-                at = present ? r[1] + (uint32_t)__popc(r[0] & ((1u << bb) - 1u)) : 0u;
-              } else {
-                const gu32_ptr cells2 = (gu32_ptr)w2.cells;
-                const gu32_ptr docs2 = (gu32_ptr)(w2.docids + w2.start * 4u);
-                const uint32_t cell = am ? ((d1 >> 10) >> (flags2 >> 16)) : 0u;
-                uint32_t a = cells2[cell], b = cells2[cell + 1u];
-                if (!am) b = a;
-                bool open = a < b;
-                while (__any(open)) {
-                  const uint32_t mid = (a + b) >> 1;
-                  const uint32_t vv = docs2[open ? mid : 0u];
-                  if (open) {
-                    const uint32_t dv = PACKED ? vv >> kPackCodeBits : vv, dd = PACKED ? d1 & kPackDocMask : d1;
-                    if (dv < dd) a = mid + 1u;
-                    else b = mid;
-                    if (dv == dd) {
-                      a = b = mid;
-                      present = true;
-                    }
-                    open = a < b;
-                  }
-                }
-                at = present ? a : 0u;
-              }
-              if (__any(present)) {
-                if (!(bits2 != 0ull && kMsRowsSpec)) code = codes2[at];
-                uint32_t c2[1] = {code}, pi2[1] = {(uint32_t)w2.start + at}, v2[1];
-                if (PACKED) c2[0] = (c2[0] & kPackCodeMask) << 2;
-                values_of_codes<PACKED, 1>(s, c2, present ? 1u : 0u, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
-                const uint64_t add = (uint64_t)(present ? v2[0] : 0u) * (uint64_t)(1u << ((flags2 >> 4) & 15u));
-                run1 = use_max ? max(run1, add) : run1 + add;
-                cnt1 += present ? 1u : 0u;
-              }
-            }
-            bool maybe = live1 && run1 >= thr;
-            {
-              bool pool = pruning ? maybe : live1;
-              if (SHAPES && msm > 1u && cnt1 < msm) pool = false;
-              if (part.live_bits != nullptr && __any(pool)) {   // (uniform)
-                const uint32_t lw = ((const NRT_GLOBAL uint32_t*)part.live_bits)[pool ? (d1 >> 5) : 0u];
-                pool = pool && ((lw >> (d1 & 31u)) & 1u) != 0u;
-              }
-              maybe = maybe && pool;
-              const uint32_t h = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pool));
-              if (mode == kMsModeCount && !pruning) {
-                if (lane == 0 && h != 0u) {
-                  const uint32_t tot = atomicAdd(&s.slot_hits[cur_slot], h) + h;
-                  if (tot > q.gte_floor) {
-                    __hip_atomic_store(&s.prune_on, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (multi_item) __hip_atomic_store(my_prune_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  }
-                }
-              } else {
-                wave_hits += h;
-              }
-            }
-            uint64_t theta_now = theta;
-            while (__any(maybe)) {
-              const uint64_t key = pack_key(acc_score<true>(run1, fx_E), (uint32_t)(part.doc_base + (int32_t)d1));
-              const bool want = maybe && key > theta_now && key < after_key;
-              uint32_t pos = 0;
-              if (!__any(want)) break;
-              if (ms_reserve(s, lane, want ? 1u : 0u, pos)) {  // wave-uniform
-                if (want) s.cand[pos] = key;
-                if (PROF) pc_cand += want ? 1u : 0u;
-                break;
-              }
-              const uint64_t t_m0 = PROF ? __builtin_readcyclecounter() : 0ull;
-              (void)ms_meet(s, k, fx_E, my_theta_g, xch, item.query);
-              if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
-              theta_now = max(theta_now, s.theta);
-            }
-          };
-          bool collapsed = false;
-
           // ---- the later clauses of the surviving docs, one clause at a time (a lane of clause c takes part from c + 1 on)
           for (uint32_t j2 = c_first + 1u; j2 < n_terms; ++j2) {
             if (!__any(alive != 0u)) break;
@@ -1044,81 +890,116 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
               am &= ~kill;
             }
             if (!__any(am != 0u)) continue;
-            if (kMsCollapse && !TWO) {
-              // few docs of the instruction left: dealt out one per lane, the rest of the instruction runs on rows
-              const uint32_t n_left = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp((uint32_t)__popc(alive)), 63);
-              if (n_left <= 63u) {
-                uint32_t d1, meta1;
-                uint64_t run1;
-                collapse_to_rows<kSl>(d, run, alive, c, ccnt, d1, run1, meta1);
-                finish_rows(d1, run1, lane < n_left, meta1 & 15u, meta1 >> 4, j2);
-                collapsed = true;
-                break;
-              }
-            }
             if (PROF) pc_look += (uint64_t)__popc(am);
             const WClause& w2 = wcl[j2];  // uniform reads; the pointers as scalars: a gather is then base + 32-bit lane offset
-            const uint64_t bits2 = uniform_u64(w2.bits);
+            const uint64_t look2 = uniform_u64(w2.look);
             const uint32_t flags2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w2.flags);
-            const uint64_t start2 = uniform_u64(w2.start);
-            const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + start2 * 4u);  // packed: the code rides in the posting's word
-            uint32_t c2[kSl];
-            uint32_t pi2[kSl];  // packed postings: the looked-up postings' indices in their column (exception lookups)
+            const uint32_t kind2 = (flags2 >> 24) & 7u;   // (uniform) how a doc is looked up in this clause (plan.h: kLook*)
             uint32_t present = 0;
+            uint32_t v2[kSl];
+  #pragma unroll
+            for (int j = 0; j < kSl; ++j) v2[j] = 0u;
   #ifdef NRT_MS_COUNT_ROUNDS
-            if (PROF) { if (bits2 != 0ull) pc_dense += 1; else pc_sparse += 1; }
+            if (PROF) { if (kind2 == kLookMap || kind2 == kLookNibble || kind2 == kLookBits) pc_dense += 1; else pc_sparse += 1; }
   #endif
-            if (bits2 != 0ull) {
-              // dense clause: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether
-              // the doc is there and where its posting is
-              const gvec2_ptr recs = (gvec2_ptr)bits2;
+            uint32_t sm = am;   // the docs to be SEARCHED for in the clause's postings: all of them, or -- under a map -- the few it cannot name
+            uint32_t found = 0; // the docs whose posting is known by its index (records, search): a[] = the index, c2[] = its code word
+            uint32_t a[kSl], c2[kSl];
+            if (kind2 == kLookMap || kind2 == kLookNibble) {
+              uint32_t mw[kSl];   // per doc the code-map word: 0 = absent, kLookMapEscape = there, freq unknown
+              if (kind2 == kLookMap) {
+                // CODE MAP: one 16-bit word per doc says whether the doc is there and what it adds -- ONE gather per doc
+                const NRT_GLOBAL uint16_t* const cmap = (const NRT_GLOBAL uint16_t*)look2;
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) mw[j] = cmap[((am >> j) & 1u) ? d[j] : 0u];
+                __builtin_amdgcn_sched_barrier(0);   // every gather is issued before the first one is waited for
+              } else {
+                // FREQ MAP: 4 bits per doc = the term's freq there; the doc's norm byte comes with the same round of gathers
+                const gu32_ptr nmap = (gu32_ptr)look2;
+                const NRT_GLOBAL uint8_t* const norms2 = (const NRT_GLOBAL uint8_t*)uniform_u64(w2.cells);   // (this kind keeps the field's norms here)
+                uint32_t nw[kSl], nb[kSl];
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) {
+                  nw[j] = nmap[((am >> j) & 1u) ? (d[j] >> 3) : 0u];
+                  nb[j] = norms2 != nullptr ? (uint32_t)norms2[((am >> j) & 1u) ? d[j] : 0u] : 1u;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) {
+                  const uint32_t f = (nw[j] >> ((d[j] & 7u) << 2)) & 15u;
+                  const uint32_t plain = (f << 7) | nb[j], esc = 0x8000u | (f << 8) | nb[j];
+                  mw[j] = f == 0u ? 0u : (f == 15u ? kLookMapEscape : ((f <= (uint32_t)kTabMaxFreq && nb[j] < (uint32_t)kTabNorms) ? plain : esc));
+                }
+              }
+              NRT_PH_MARK(4);
+              sm = 0u;
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) {
+                const bool mine = ((am >> j) & 1u) != 0u;
+                present |= (mine && mw[j] != 0u && mw[j] != kLookMapEscape ? 1u : 0u) << j;
+                sm |= (mine && mw[j] == kLookMapEscape ? 1u : 0u) << j;   // (a freq the map cannot name: practically never)
+              }
+              values_of_map<kSl>(s, mw, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, v2);
+              NRT_PH_MARK(5);
+            } else if (kind2 == kLookBits) {
+              // RECORDS: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether the doc is
+              // there and where its posting is; the code is a second, dependent gather
+              const gvec2_ptr recs = (gvec2_ptr)look2;
+              const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + uniform_u64(w2.start) * 4u);
               u32x2 r[kSl];
   #pragma unroll
               for (int j = 0; j < kSl; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
-              __builtin_amdgcn_sched_barrier(0);   // every record load is issued before the first one is waited for
+              __builtin_amdgcn_sched_barrier(0);
               NRT_PH_MARK(4);
-              uint32_t idx[kSl];
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
                 const uint32_t bb = d[j] & 31u;
                 const bool there = ((am >> j) & 1u) && ((r[j][0] >> bb) & 1u);
-                idx[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
-                present |= (there ? 1u : 0u) << j;
+                a[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
+                found |= (there ? 1u : 0u) << j;
               }
   #pragma unroll
-              for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
-              __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
+              for (int j = 0; j < kSl; ++j) c2[j] = codes2[a[j]];
+              __builtin_amdgcn_sched_barrier(0);
               NRT_PH_MARK(5);
-  #pragma unroll
-              for (int j = 0; j < kSl; ++j) pi2[j] = (uint32_t)start2 + idx[j];
-            } else {
-              // sparse clause: its cell of the doc, then a short binary search in the docid column -- the 8 searches of a
-              // lane advance in lockstep, so every step is one round of loads in flight instead of eight
-              const gu32_ptr cells2 = (gu32_ptr)uniform_u64(w2.cells);
+              sm = 0u;
+            }
+            if (__any(sm != 0u)) {
+              // SEARCH: the doc's cell -- a lookup cell of 2^look_shift docs holding 0.5 - 1 posting on average (kLookCells), else
+              // its cell of the tile-granular table -- then a binary search among the cell's postings; the 8 searches of a lane
+              // advance in lockstep, so every step is one round of loads in flight instead of eight.  The code is fetched next to
+              // every probed docid (packed postings: it rides in the probed word): a search that ends on its first probe -- the
+              // rule under lookup cells -- has the posting's score code without a further dependent gather.
+              const uint64_t start2 = uniform_u64(w2.start);
+              const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + start2 * 4u);
+              // (the tile-granular table: kept in the wave's record unless the kind keeps something else there -- then from the plan)
+              const gu32_ptr cells2 = (gu32_ptr)(kind2 == kLookCells ? look2 : (kind2 == kLookNibble ? (uint64_t)part_terms[j2].cell_off : uniform_u64(w2.cells)));
               const gu32_ptr docs2 = (gu32_ptr)(uniform_u64(w2.docids) + start2 * 4u);
-              const uint32_t cshift = flags2 >> 16;
-              uint32_t a[kSl], b[kSl];
+              const uint32_t cshift = kind2 == kLookCells ? (flags2 >> 27) & 31u : 10u + ((flags2 >> 16) & 31u);
+              uint32_t b[kSl];
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
-                const uint32_t cell = ((am >> j) & 1u) ? ((d[j] >> 10) >> cshift) : 0u;
+                const uint32_t cell = ((sm >> j) & 1u) ? (d[j] >> cshift) : 0u;
                 a[j] = cells2[cell];
                 b[j] = cells2[cell + 1u];
+                c2[j] = 0u;
               }
               uint32_t open = 0;
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
-                if (!((am >> j) & 1u)) b[j] = a[j];
+                if (!((sm >> j) & 1u)) b[j] = a[j];
                 open |= (a[j] < b[j] ? 1u : 0u) << j;
               }
               while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
   #ifdef NRT_MS_COUNT_ROUNDS
                 if (PROF) pc_steps += 1;
   #endif
-                uint32_t mid[kSl], vv[kSl];
+                uint32_t mid[kSl], vv[kSl], cw[kSl];
   #pragma unroll
                 for (int j = 0; j < kSl; ++j) {
                   mid[j] = (a[j] + b[j]) >> 1;
                   vv[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
+                  cw[j] = PACKED ? vv[j] : codes2[((open >> j) & 1u) ? mid[j] : 0u];
                 }
   #pragma unroll
                 for (int j = 0; j < kSl; ++j)
@@ -1129,26 +1010,29 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                     else b[j] = mid[j];
                     if (dv == dd) {  // found: close the search on it
                       a[j] = b[j] = mid[j];
-                      present |= 1u << j;
+                      found |= 1u << j;
+                      c2[j] = cw[j];
                     }
                     if (!(a[j] < b[j])) open &= ~(1u << j);
                   }
               }
-  #pragma unroll
-              for (int j = 0; j < kSl; ++j) {
-                c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];   // (packed: the posting's word again -- keeping the probe's word alive
-                                                                      //  through the search loop cost more than this gather)
-                pi2[j] = (uint32_t)start2 + a[j];
-              }
               NRT_PH_MARK(7);
             }
-            if (__any(present != 0u)) {
-              uint32_t v2[kSl];
-              if (PACKED) {
+            if (__any(found != 0u)) {   // (uniform: only after records or a search)
+              uint32_t pi2[kSl], vs[kSl];   // pi2: packed postings: the postings' indices in their column (exception lookups)
+              const uint32_t start_lo = (uint32_t)uniform_u64(w2.start);
   #pragma unroll
-                for (int j = 0; j < kSl; ++j) c2[j] = (c2[j] & kPackCodeMask) << 2;
+              for (int j = 0; j < kSl; ++j) {
+                pi2[j] = start_lo + a[j];
+                if (PACKED) c2[j] = (c2[j] & kPackCodeMask) << 2;
               }
-              values_of_codes<PACKED, kSl>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
+              values_of_codes<PACKED, kSl>(s, c2, found, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, vs);
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j)
+                if ((found >> j) & 1u) v2[j] = vs[j];
+              present |= found;
+            }
+            if (__any(present != 0u)) {
               const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
               if (use_max) {   // (uniform)
   #pragma unroll
@@ -1177,7 +1061,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
             NRT_PH_MARK(6);
           }
 
-          if (!collapsed) {
+          {
           // ---- complete scores: the competitive ones go to the shared candidate buffer.  Rare once theta has
           //      converged, so the key (a double conversion) is built only for sums that reach theta's score, one
           //      posting per lane and round.
@@ -1259,7 +1143,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
             if (PROF) tc_meet += __builtin_readcyclecounter() - t_m0;
             theta_now = max(theta_now, s.theta);
           }
-          }  // (!collapsed)
+          }
           NRT_PH_MARK(8);
           // somebody else asked for a compaction: join it between two instructions
           if (__hip_atomic_load(&s.rz_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
@@ -1389,13 +1273,15 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
 // Seal-time kernels of the MaxScore route.
 //
 // term_frontier_kernel: per term its DTermAux record: the impact frontier (min_norm / esc_*) from the score codes
-// fold_norms_kernel wrote (before any liveDocs are folded in), and where its membership records are
-// (t_rec[t] = first record, ~0: none).  One workgroup per term.
+// fold_norms_kernel wrote (before any liveDocs are folded in), and where its lookup structure is
+// (t_look[t] = byte offset inside the group's lookup buffer, ~0: none; t_meta[t] = kind | log2 docs per cell << 8).
+// One workgroup per term.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
-                          const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_rec,
-                          const uint32_t* __restrict__ recs, DTermAux* __restrict__ out) {
+                          const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_look,
+                          const uint32_t* __restrict__ t_meta, const char* __restrict__ look_base, const uint8_t* __restrict__ norms,
+                          DTermAux* __restrict__ out) {
   __shared__ uint32_t mn[13];
   __shared__ uint32_t mf;
   const uint32_t t = blockIdx.x;
@@ -1427,33 +1313,106 @@ void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __
   __syncthreads();
   if (threadIdx.x == 0) {
     DTermAux a;
-    a.bits = t_rec[t] == ~0ull ? nullptr : (const void*)(recs + t_rec[t] * 2u);
+    const bool has = t_look[t] != ~0ull;
+    a.look = has ? (const void*)(look_base + t_look[t]) : nullptr;
     for (int i = 0; i < 12; ++i) a.min_norm[i] = (uint8_t)mn[i];
     a.esc_min_norm = (uint8_t)mn[12];
-    a.pad[0] = a.pad[1] = a.pad[2] = 0;
+    a.look_kind = has ? (uint8_t)(t_meta[t] & 255u) : (uint8_t)kLookNone;
+    a.look_shift = has ? (uint8_t)((t_meta[t] >> 8) & 255u) : (uint8_t)0;
+    a.pad = 0;
     a.esc_max_freq = mf;
     a.pad2 = 0;
+    a.norms = norms;   // (the field's norm bytes: what a freq map's lookups read next to it)
+    a.pad3 = 0;
     out[t] = a;
   }
 }
 
-// term_bits_kernel: membership + rank records of the dense terms (DTermAux.bits): per 32 docs {doc bits, postings of
-// the term before the block}.  Grid: (chunks, dense terms); the records were zeroed.  Postings are ascending in docid, so
-// the first posting of a block is the one whose predecessor lies in an earlier block: it records its index.
+// term_map_kernel: the CODE MAPS of the group's densest terms (plan.h: kLookMap): per doc of the segment one 16-bit word --
+// the score code of the doc's posting, 0 = none.  Grid: (chunks, terms with a map: `which`); the maps were zeroed.  Runs on the
+// two-column form, before liveDocs are folded into the codes.
 __global__ __launch_bounds__(256)
-void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ t_start,
-                      const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_rec, const uint32_t* __restrict__ dense,
-                      uint32_t* __restrict__ recs) {
-  const uint32_t t = dense[blockIdx.y];   // grid.y runs over the dense terms of the group
+void term_map_kernel(const uint32_t* __restrict__ docids, const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
+                     const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_look, const uint32_t* __restrict__ which,
+                     char* __restrict__ look_base) {
+  const uint32_t t = which[blockIdx.y];
   const uint64_t st = t_start[t];
   const uint32_t n = t_count[t];
-  uint32_t* const r = recs + t_rec[t] * 2u;
+  uint16_t* const m = (uint16_t*)(look_base + t_look[t]);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const uint32_t c = fnorm[st + p];
+    uint32_t v;
+    if (c >> 31) {
+      const uint32_t f = (c >> 8) & 0x3FFFFFu;
+      v = f <= 126u ? (0x8000u | (f << 8) | (c & 255u)) : kLookMapEscape;
+    } else {
+      v = (c >> 2) & 0x7FFu;   // (freq << 7) | norm byte
+    }
+    m[docids[st + p]] = (uint16_t)v;
+  }
+}
+
+// term_nibble_kernel: FREQ MAPS (plan.h: kLookNibble): 4 bits per doc = the term's freq there (15: fifteen or more).  Same grid;
+// the maps were zeroed; eight docs share a word, hence the atomic.
+__global__ __launch_bounds__(256)
+void term_nibble_kernel(const uint32_t* __restrict__ docids, const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
+                        const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_look, const uint32_t* __restrict__ which,
+                        char* __restrict__ look_base) {
+  const uint32_t t = which[blockIdx.y];
+  const uint64_t st = t_start[t];
+  const uint32_t n = t_count[t];
+  uint32_t* const m = (uint32_t*)(look_base + t_look[t]);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const uint32_t c = fnorm[st + p];
+    const uint32_t f = (c >> 31) ? ((c >> 8) & 0x3FFFFFu) : ((c >> 9) & 15u);
+    const uint32_t d = docids[st + p];
+    atomicOr(&m[d >> 3], (f < 15u ? f : 15u) << ((d & 7u) << 2));
+  }
+}
+
+// term_bits_kernel: MEMBERSHIP + RANK RECORDS (plan.h: kLookBits): per 32 docs {doc bits, postings of the term before the
+// block}.  Same grid; the records were zeroed.  Postings are ascending in docid, so the first posting of a block is the one
+// whose predecessor lies in an earlier block: it records its index.
+__global__ __launch_bounds__(256)
+void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ t_start, const uint32_t* __restrict__ t_count,
+                      const uint64_t* __restrict__ t_look, const uint32_t* __restrict__ which, char* __restrict__ look_base) {
+  const uint32_t t = which[blockIdx.y];
+  const uint64_t st = t_start[t];
+  const uint32_t n = t_count[t];
+  uint32_t* const r = (uint32_t*)(look_base + t_look[t]);
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
     const uint32_t d = docids[st + p];
     const uint32_t blk = d >> 5;
     atomicOr(&r[(size_t)blk * 2u], 1u << (d & 31u));
     if (p == 0u || (docids[st + p - 1u] >> 5) != blk) r[(size_t)blk * 2u + 1u] = p;
+  }
+}
+
+// term_cells_kernel: the LOOKUP CELLS of the other terms (plan.h: kLookCells): entry i = the term's postings with a docid
+// below i << shift (a lower bound in its docid column), for i = 0 .. cells.  Grid: (chunks, terms with cells).
+__global__ __launch_bounds__(256)
+void term_cells_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ t_start, const uint32_t* __restrict__ t_count,
+                       const uint64_t* __restrict__ t_look, const uint32_t* __restrict__ t_meta, const uint32_t* __restrict__ which,
+                       uint32_t max_doc, char* __restrict__ look_base) {
+  const uint32_t t = which[blockIdx.y];
+  const uint32_t* const dd = docids + t_start[t];
+  const uint32_t n = t_count[t];
+  const uint32_t shift = (t_meta[t] >> 8) & 255u;
+  const uint32_t n_cells = ((max_doc - 1u) >> shift) + 1u;
+  uint32_t* const out = (uint32_t*)(look_base + t_look[t]);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n_cells; i += stride) {
+    const uint64_t bound = (uint64_t)i << shift;   // (the last entry's bound may pass 2^32)
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint64_t)dd[mid] < bound) lo = mid + 1u;
+      else hi = mid;
+    }
+    out[i] = lo;
   }
 }
 
@@ -1471,31 +1430,54 @@ void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int sha
     else if (shapes == 1) NRT_MS_LAUNCH(P, K, 1); \
     else NRT_MS_LAUNCH(P, K, 0);                  \
   } while (0)
+#ifdef NRTGPU_DEV   // the instrumented instantiations exist in the development build only (include/nrtgpu_dev.h)
   if (profile) {
     if (packed) NRT_MS_LAUNCH_S(true, true);
     else NRT_MS_LAUNCH_S(true, false);
-  } else {
-    if (packed) NRT_MS_LAUNCH_S(false, true);
-    else NRT_MS_LAUNCH_S(false, false);
+    return;
   }
+#else
+  (void)profile;
+#endif
+  if (packed) NRT_MS_LAUNCH_S(false, true);
+  else NRT_MS_LAUNCH_S(false, false);
 #undef NRT_MS_LAUNCH_S
 #undef NRT_MS_LAUNCH
 }
 
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
-                          const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out) {
+                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, const uint8_t* norms, uint32_t n_terms, DTermAux* out) {
   if (n_terms == 0) return;
-  hipLaunchKernelGGL(term_frontier_kernel, dim3(n_terms), dim3(256), 0, stream, fnorm, t_start, t_count, t_rec, recs, out);
+  hipLaunchKernelGGL(term_frontier_kernel, dim3(n_terms), dim3(256), 0, stream, fnorm, t_start, t_count, t_look, t_meta, (const char*)look_base, norms, out);
 }
 
-void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
-                      const uint64_t* t_rec, const uint32_t* dense, uint32_t n_dense, uint32_t max_count, uint32_t* recs) {
-  if (n_dense == 0) return;
+// kind: kLookMap / kLookNibble / kLookBits -- the doc-indexed structures, written posting by posting
+void launch_term_doc_maps(hipStream_t stream, uint32_t kind, const uint32_t* docids, const uint32_t* fnorm, const uint64_t* t_start,
+                          const uint32_t* t_count, const uint64_t* t_look, const uint32_t* which, uint32_t n_which, uint32_t max_count,
+                          void* look_base) {
+  if (n_which == 0) return;
   uint32_t chunks = (max_count + 256u * 16u - 1u) / (256u * 16u);
   chunks = chunks < 1u ? 1u : (chunks > 1024u ? 1024u : chunks);
-  for (uint32_t off = 0; off < n_dense; off += 65535u) {   // (gridDim.y holds 65535 at most)
-    const uint32_t n = n_dense - off < 65535u ? n_dense - off : 65535u;
-    hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, t_start, t_count, t_rec, dense + off, recs);
+  for (uint32_t off = 0; off < n_which; off += 65535u) {   // (gridDim.y holds 65535 at most)
+    const uint32_t n = n_which - off < 65535u ? n_which - off : 65535u;
+    if (kind == kLookMap)
+      hipLaunchKernelGGL(term_map_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, fnorm, t_start, t_count, t_look, which + off, (char*)look_base);
+    else if (kind == kLookNibble)
+      hipLaunchKernelGGL(term_nibble_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, fnorm, t_start, t_count, t_look, which + off, (char*)look_base);
+    else
+      hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, t_start, t_count, t_look, which + off, (char*)look_base);
+  }
+}
+
+void launch_term_cells(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
+                       const uint32_t* t_meta, const uint32_t* which, uint32_t n_which, uint32_t max_cells, uint32_t max_doc, void* look_base) {
+  if (n_which == 0) return;
+  uint32_t chunks = (max_cells + 256u * 4u - 1u) / (256u * 4u);
+  chunks = chunks < 1u ? 1u : (chunks > 256u ? 256u : chunks);
+  for (uint32_t off = 0; off < n_which; off += 65535u) {
+    const uint32_t n = n_which - off < 65535u ? n_which - off : 65535u;
+    hipLaunchKernelGGL(term_cells_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, t_start, t_count, t_look, t_meta, which + off, max_doc,
+                       (char*)look_base);
   }
 }
 

@@ -99,20 +99,45 @@ struct alignas(16) DQExpand {
 static_assert(sizeof(DQExpand) == 16, "DQExpand layout");
 
 // What the MaxScore route (maxscore.hip) knows about a term besides its columns (one record per term of a segment,
-// written at seal): a doc -> posting map for lookups, and the term's impact frontier -- per freq the smallest norm byte it occurs
-// with -- from which the kernel takes the term's exact maximum score under the query's statistics (the role of
-// Lucene's competitive (freq, norm) impacts).
+// written at seal): the term's impact frontier -- per freq the smallest norm byte it occurs with -- from which the kernel
+// takes the term's exact maximum score under the query's statistics (the role of Lucene's competitive (freq, norm) impacts,
+// SURVEY 8a row a5) -- and a doc -> posting LOOKUP structure for the walk's later clauses.  A lookup round costs its
+// SLOWEST doc's chain of dependent gathers (a wave follows up to 512 docs at once), so what matters is the number of
+// dependent gathers EVERY lookup of the kind is sure to end within:
+//   kLookMap   : a CODE MAP, one 16-bit word per doc of the segment -- the doc's score code under this term, 0 = the doc lacks
+//                the term.  ONE gather answers "is it there, and what does it add".  2 B per doc.
+//                Word: bit 15 clear: (freq << 7) | norm byte, freq <= kTabMaxFreq, norm < kTabNorms (x 4 = the table offset);
+//                bit 15 set: 0x8000 | freq << 8 | norm byte for freq <= 126; 0xFFFF: freq > 126 (searched in the postings).
+//   kLookNibble: a FREQ MAP, 4 bits per doc -- the term's freq in the doc (1 .. 14; 0: the doc lacks the term; 15: a larger
+//                freq, searched in the postings); the doc's norm byte is one more gather of the same round (the field's norm
+//                bytes, 1 B per doc, shared by all terms).  ONE round of gathers, 0.5 B per doc.
+//   kLookBits  : MEMBERSHIP + RANK RECORDS (rounds 2-4), per 32 docs {doc bits, postings of the term before the block}: whether
+//                the doc is there and where its posting is; its score code is a second, dependent gather.  0.25 B per doc.
+//   kLookCells : LOOKUP CELLS, one posting offset per 2^look_shift docs with look_shift chosen so that a cell holds
+//                0.5 - 1 posting on average (4 - 8 B per POSTING): a search in the doc's cell, usually over no posting or one.
+//                Gathers: cells, then probes until the slowest doc of the round is done (2 - 3), the code rides with the probe.
+//   kLookNone  : the doc is searched for in its cell of the tile-granular table DTerm.cell_off (~4 - 8 postings per cell).
+// Which term gets what: segment.cpp: build_term_aux (the segment's lookup budget, nrtgpu_config.lookup_budget_pct).
+// Deleted docs need no care here: a doc whose postings were re-coded to score 0 (apply_live_kernel) never survives the stream
+// phase of the walk, so it is never looked up.
+constexpr uint32_t kLookNone = 0, kLookMap = 1, kLookCells = 2, kLookNibble = 3, kLookBits = 4;
+constexpr uint32_t kLookMapEscape = 0xFFFFu;
 struct alignas(16) DTermAux {
-  const void* bits;        // one 8-byte record per 32 docs: {doc bits, postings of the term before the block}; nullptr
-                           // for a sparse term (looked up through its cell table instead)
+  const void* look;        // the code map (uint16_t[max_doc + pad]) / freq map (uint32_t[max_doc / 8 + pad]) / records
+                           // (uint32_t[2][max_doc / 32 + pad]) / lookup cells (uint32_t[cells + 1], offsets relative to the
+                           // term's first posting); nullptr: kLookNone
   uint8_t  min_norm[12];   // postings a score table can serve (freq f = 1..12, norm byte < 128): smallest norm byte
                            // seen with freq f at [f - 1]; 0xFF = no such posting
   uint8_t  esc_min_norm;   // the other postings (freq > 12 or norm byte >= 128): smallest norm byte ...
-  uint8_t  pad[3];
+  uint8_t  look_kind;      // kLook*
+  uint8_t  look_shift;     // kLookCells: log2 of the docs per cell
+  uint8_t  pad;
   uint32_t esc_max_freq;   // ... and largest freq among them; 0 = none
   uint32_t pad2;
+  const uint8_t* norms;    // kLookNibble: the norm bytes of the term's field (nullptr: norms omitted, every doc's norm byte is 1)
+  uint64_t pad3;
 };
-static_assert(sizeof(DTermAux) == 32, "DTermAux layout");
+static_assert(sizeof(DTermAux) == 48, "DTermAux layout");
 
 // Workgroup shape of the MaxScore route: 12 autonomous waves (168 VGPRs each); a wave owns a window of kMsWinTiles
 // sub-tiles at a time (its docs' "already evaluated" bits: kMsWinDocs / 8 bytes of LDS).

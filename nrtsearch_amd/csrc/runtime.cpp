@@ -152,8 +152,8 @@ extern "C" int nrtgpu_create(const nrtgpu_config* cfg, nrtgpu_ctx** out) {
   if (c.max_batch <= 0) c.max_batch = 1024;
 #ifndef NRTGPU_DEV
   {
-    const int variant = (c.flags >> 8) & 15;  // 7 = instrumented kernels; the rest are timing ablations with wrong results
-    if (variant != 0 && variant != 7)
+    const int variant = (c.flags >> 8) & 15;  // 7 = instrumented kernels (include/nrtgpu_dev.h); the rest are timing ablations with wrong results
+    if (variant != 0)
       return fail(NRTGPU_ERR_INVALID_ARG, "flags: kernel variant %d exists only in the development build (-DNRTGPU_DEV)", variant);
   }
 #endif
@@ -272,6 +272,9 @@ extern "C" int nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out) {
   if (!ctx || !out) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
   *out = ctx->stats;
+  out->spec_queries = ctx->spec_queries.load(std::memory_order_relaxed);
+  out->spec_reruns = ctx->spec_reruns.load(std::memory_order_relaxed);
+  out->spec_disabled = ctx->spec_off.load(std::memory_order_relaxed);
   return NRTGPU_OK;
 }
 extern "C" void nrtgpu_reset_stats(nrtgpu_ctx* ctx) {
@@ -281,6 +284,7 @@ extern "C" void nrtgpu_reset_stats(nrtgpu_ctx* ctx) {
   for (double& p : ctx->prof) p = 0;
   for (double& p : ctx->ms_prof) p = 0;
 }
+#ifdef NRTGPU_DEV   // include/nrtgpu_dev.h: the instrumented kernels' counters
 extern "C" int nrtgpu_get_scan_profile(nrtgpu_ctx* ctx, double* out16) {
   if (!ctx || !out16) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   std::lock_guard<std::mutex> lk(ctx->stats_mu);
@@ -304,6 +308,7 @@ extern "C" int64_t nrtgpu_get_maxscore_item_walls(nrtgpu_ctx* ctx, uint64_t* out
     for (int64_t i = 0; i < std::min(n, cap_slots) * 8; ++i) out[i] = ctx->last_walls[(size_t)i];
   return n;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // ABI: host-side restatements

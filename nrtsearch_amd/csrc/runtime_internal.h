@@ -25,6 +25,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <optional>
 #include <shared_mutex>
 #include <string>
 #include <thread>
@@ -32,6 +33,9 @@
 #include <vector>
 
 #include "../../include/nrtgpu.h"
+#ifdef NRTGPU_DEV
+#include "../../include/nrtgpu_dev.h"
+#endif
 #include "host_math.h"
 #include "plan.h"
 
@@ -42,9 +46,12 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
 void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int shapes, const MsArgs& args, const MsArgs* args_d);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
-                          const uint64_t* t_rec, const uint32_t* recs, uint32_t n_terms, DTermAux* out);
-void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count,
-                      const uint64_t* t_rec, const uint32_t* dense, uint32_t n_dense, uint32_t max_count, uint32_t* recs);
+                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, const uint8_t* norms, uint32_t n_terms, DTermAux* out);
+void launch_term_doc_maps(hipStream_t stream, uint32_t kind, const uint32_t* docids, const uint32_t* fnorm, const uint64_t* t_start,
+                          const uint32_t* t_count, const uint64_t* t_look, const uint32_t* which, uint32_t n_which, uint32_t max_count,
+                          void* look_base);
+void launch_term_cells(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
+                       const uint32_t* t_meta, const uint32_t* which, uint32_t n_which, uint32_t max_cells, uint32_t max_doc, void* look_base);
 void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* qterms, const uint32_t* out_begin, uint32_t n_queries,
                          uint32_t n_leaves, DTerm* out);
 void launch_slice_relation(hipStream_t stream, const uint32_t* slice_sum, const DQuery* queries, uint32_t n_slices, uint64_t* out_hits,
@@ -110,6 +117,24 @@ inline bool deadline_passed(int64_t deadline_ns) { return deadline_ns != 0 && mo
   } while (0)
 int fail(int code, const char* fmt, ...);
 double now_ms();
+// Experiment knobs: the DEVELOPMENT build (-DNRTGPU_DEV, libnrtgpu_dev.so) reads them from the environment for A/B runs; the
+// product library is configured through nrtgpu_config and the nrtgpu_set_* calls only, and always takes the default.
+inline long dev_env_int(const char* name, long dflt) {
+#ifdef NRTGPU_DEV
+  if (const char* e = getenv(name)) return atol(e);
+#else
+  (void)name;
+#endif
+  return dflt;
+}
+inline const char* dev_env_str(const char* name, const char* dflt) {
+#ifdef NRTGPU_DEV
+  if (const char* e = getenv(name)) return e;
+#else
+  (void)name;
+#endif
+  return dflt;
+}
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
@@ -181,8 +206,10 @@ struct TermGroup {
   bool packed = false;           // NRTGPU_FLAG_PACKED_POSTINGS, after the seal: d_docids = packed column, d_fnorm = d_dict
   uint32_t* d_dict = nullptr;    // packed postings: the group's exception list (header, directory, escape words)
   uint32_t* d_cells = nullptr;   // concatenated per-term cell tables
-  DTermAux* d_aux = nullptr;     // MaxScore route: one record per term of the group (impact frontier, membership records), seal
-  uint32_t* d_bits = nullptr;    // membership + rank records of the group's dense terms (16 B per 64 docs and term)
+  DTermAux* d_aux = nullptr;     // MaxScore route: one record per term of the group (impact frontier, lookup structure), seal
+  char* d_look = nullptr;        // the lookup structures of the group's terms (plan.h: kLookMap / kLookCells), one buffer
+  uint64_t look_bytes = 0;
+  uint32_t n_look[5] = {0, 0, 0, 0, 0};   // terms per lookup kind (plan.h: kLook*; diagnostics)
   uint32_t n_terms = 0;
   std::vector<uint64_t> h_start;  // per term of the group (add order): first posting, postings -- kept until the seal
   std::vector<uint32_t> h_count;

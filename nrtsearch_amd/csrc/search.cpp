@@ -332,7 +332,7 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
 // nullptr: no speculation in this call.
 static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                              int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                             nrtgpu_topdocs* out, std::vector<int32_t>* rerun) {
+                             nrtgpu_topdocs* out, std::vector<int32_t>* rerun, bool content_held = false) {
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
   if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
@@ -342,7 +342,8 @@ static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
   HostPlan hp;
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
-  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
+  std::optional<SegReadLocks> content;   // until this call's kernels have finished (content_held: the caller holds them over both passes)
+  if (!content_held) content.emplace(segs, n_segs);
   if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, 1)) return rc;
   const double plan_ms = now_ms() - t0;
 
@@ -407,13 +408,20 @@ static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
 extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                         int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                                         nrtgpu_topdocs* out) {
-  // The MaxScore route may run under SPECULATIVE thresholds here (plan.h: kHitsSpecInvalid; NRTGPU_MS_SPEC_Z): a query whose guess
-  // the merge could not confirm comes back tagged and is run again without speculation -- behind the first pass, whose locks and
-  // workspace are released by then.  What the caller sees is exact either way; a failed guess costs that query a second pass.
+  // The MaxScore route may run under SPECULATIVE thresholds here (plan.h: kHitsSpecInvalid; nrtgpu_set_speculation): a query whose
+  // guess the merge could not confirm comes back tagged and is run again without speculation.  Both passes run under ONE set of
+  // content locks (a set_mask / set_live_docs between them would show the re-run queries other content than their batch mates,
+  // or evict a mask they name), and the second pass ignores the thread's deadline: its work is the tail of a search that was
+  // launched in time, and every untagged query of the call already holds its answer.
   std::vector<int32_t> rerun;
   const bool spec = speculating(ctx);
-  const int rc = search_batch_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, out, spec ? &rerun : nullptr);
-  if (rc != 0 || !spec) return rc;
+  if (!spec) return search_batch_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, out, nullptr);
+  if (ctx && segs)
+    for (int si = 0; si < n_segs; ++si)
+      if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);
+  const int rc = search_batch_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, out, &rerun, true);
+  if (rc != 0) return rc;
   const nrtgpu_diagnostics first = g_diag;
   note_speculation(ctx, n_queries, (int64_t)rerun.size());
   if (rerun.empty()) return rc;
@@ -423,7 +431,10 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
     rq[i] = queries[rerun[i]];
     ro[i] = out[rerun[i]];
   }
-  const int rc2 = search_batch_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), ro.data(), nullptr);
+  const int64_t deadline = g_deadline_ns;
+  g_deadline_ns = 0;
+  const int rc2 = search_batch_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), ro.data(), nullptr, true);
+  g_deadline_ns = deadline;
   if (rc2 != 0) return rc2;
   for (size_t i = 0; i < rerun.size(); ++i) out[rerun[i]] = ro[i];
   nrtgpu_diagnostics d = g_diag;   // both passes
@@ -448,6 +459,7 @@ extern "C" int nrtgpu_set_speculation(nrtgpu_ctx* ctx, float margin) {
   return NRTGPU_OK;
 }
 
+#ifdef NRTGPU_DEV   // include/nrtgpu_dev.h (the product reports the same three values in nrtgpu_stats)
 extern "C" int nrtgpu_debug_spec_counters(nrtgpu_ctx* ctx, int64_t* out3) {
   if (!ctx || !out3) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   out3[0] = ctx->spec_queries.load(std::memory_order_relaxed);
@@ -455,6 +467,7 @@ extern "C" int nrtgpu_debug_spec_counters(nrtgpu_ctx* ctx, int64_t* out3) {
   out3[2] = ctx->spec_off.load(std::memory_order_relaxed);
   return NRTGPU_OK;
 }
+#endif
 
 // Hybrid tail: BM25 recall -> exact-vector rescore -> window, one stream, no host round trip between
 // the stages (RescoreTask.java:47-50 -> QueryRescore.java:39-57 applied to the hits of
@@ -463,7 +476,8 @@ extern "C" int nrtgpu_debug_spec_counters(nrtgpu_ctx* ctx, int64_t* out3) {
 static int search_hybrid_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                               int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                               int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost,
-                              double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out, std::vector<int32_t>* rerun) {
+                              double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out, std::vector<int32_t>* rerun,
+                              bool content_held = false) {
   if (!ctx || !queries || !out || !query_vectors || (n_segs > 0 && (!segs || !doc_bases)))
     return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
@@ -477,7 +491,8 @@ static int search_hybrid_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, co
   HostPlan hp;
   for (int si = 0; si < n_segs; ++si)
     if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
-  SegReadLocks content(segs, n_segs);  // until this call's kernels have finished
+  std::optional<SegReadLocks> content;   // until this call's kernels have finished (content_held: the caller holds them over both passes)
+  if (!content_held) content.emplace(segs, n_segs);
   if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, 1)) return rc;
   const double plan_ms = now_ms() - t0;
   for (int si = 0; si < n_segs; ++si) {
@@ -569,11 +584,19 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   // The first pass may run under speculative thresholds (plan.h: kHitsSpecInvalid), as in nrtgpu_search_bm25_batch: recall, tail
   // and the copy back stay one stream with no host round trip; the merge's tags arrive with the results, and a tagged query --
   // its recall set may lack docs -- is run again, first pass and tail, without speculation.
+  // Both passes under one set of content locks, the second one without the thread's deadline: as nrtgpu_search_bm25_batch.
   std::vector<int32_t> rerun;
   const bool spec = speculating(ctx);
+  if (!spec)
+    return search_hybrid_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, field_id, sim, query_vectors, dim, boost, query_weight,
+                              rescore_weight, window, out, nullptr);
+  if (ctx && segs)
+    for (int si = 0; si < n_segs; ++si)
+      if (!segs[si]) return fail(NRTGPU_ERR_INVALID_ARG, "segment %d is NULL", si);
+  SegReadLocks content(segs, n_segs);
   const int rc = search_hybrid_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, field_id, sim, query_vectors, dim, boost, query_weight,
-                                    rescore_weight, window, out, spec ? &rerun : nullptr);
-  if (rc != 0 || !spec) return rc;
+                                    rescore_weight, window, out, &rerun, true);
+  if (rc != 0) return rc;
   note_speculation(ctx, n_queries, (int64_t)rerun.size());
   if (rerun.empty()) return rc;
   std::vector<nrtgpu_bm25_query> rq(rerun.size());
@@ -584,8 +607,11 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
     ro[i] = out[rerun[i]];
     memcpy(rv.data() + i * (size_t)dim, query_vectors + (size_t)rerun[i] * (size_t)dim, (size_t)dim * sizeof(float));
   }
+  const int64_t deadline = g_deadline_ns;
+  g_deadline_ns = 0;
   const int rc2 = search_hybrid_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), field_id, sim, rv.data(), dim, boost, query_weight,
-                                     rescore_weight, window, ro.data(), nullptr);
+                                     rescore_weight, window, ro.data(), nullptr, true);
+  g_deadline_ns = deadline;
   if (rc2 != 0) return rc2;
   for (size_t i = 0; i < rerun.size(); ++i) out[rerun[i]] = ro[i];
   return NRTGPU_OK;
@@ -725,8 +751,9 @@ extern "C" int nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us) {
   return NRTGPU_OK;
 }
 
-// Test hook (include/nrtgpu.h): while held, a coalescer's leader leaves only with a full batch / panel, so a test can queue a
-// known set of callers and assert what batches they form by construction instead of by the host's speed.
+#ifdef NRTGPU_DEV
+// Test hook (include/nrtgpu_dev.h): while held, a coalescer's leader leaves only with a full batch / panel, so a test can queue
+// a known set of callers and assert what batches they form by construction instead of by the host's speed.
 extern "C" int nrtgpu_debug_hold_coalescers(nrtgpu_ctx* ctx, int32_t hold) {
   if (!ctx) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   {
@@ -745,6 +772,7 @@ extern "C" int nrtgpu_debug_coalescer_pending(nrtgpu_ctx* ctx, int32_t which) {
   }
   return nrtgpu_debug_knn_coalescer_pending(ctx);
 }
+#endif
 
 extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                                             int32_t n_segs, const nrtgpu_bm25_query* q, nrtgpu_topdocs* out) {

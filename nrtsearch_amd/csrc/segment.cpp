@@ -15,13 +15,14 @@ SegWriteLock::~SegWriteLock() {
   {
     std::lock_guard<std::mutex> lk(seg->content_m);
     seg->content_writing = false;
-    free_now = seg->content_released && seg->content_readers == 0;   // released while this writer held it
+    // released while this writer held it: the LAST user frees -- not while readers run or another writer still waits on the
+    // condition variable (it is a user of the handle too: it wakes up, writes to a handle nobody will search, and frees here)
+    free_now = seg->content_released && seg->content_readers == 0 && seg->content_writers_waiting == 0;
+    // notify while the mutex is held: the moment it is dropped another thread may reach "last user" and delete the handle,
+    // condition variable included
+    if (!free_now) seg->content_cv.notify_all();
   }
-  if (free_now) {
-    destroy_segment(seg);
-    return;
-  }
-  seg->content_cv.notify_all();
+  if (free_now) destroy_segment(seg);
 }
 void nrtgpu_seg::content_lock_shared(bool pipelined) const {
   std::unique_lock<std::mutex> lk(content_m);
@@ -35,13 +36,12 @@ void nrtgpu_seg::content_unlock_shared() const {
   {
     std::lock_guard<std::mutex> lk(content_m);
     content_readers--;
-    last_of_released = content_readers == 0 && content_released && !content_writing;
+    // nrtgpu_segment_release came while this search ran: the last user frees (a writer that still waits counts as one: it is
+    // woken below and frees in ~SegWriteLock)
+    last_of_released = content_readers == 0 && content_released && !content_writing && content_writers_waiting == 0;
+    if (!last_of_released) content_cv.notify_all();   // (under the mutex: after it is dropped `this` may be gone)
   }
-  if (last_of_released) {
-    destroy_segment(const_cast<nrtgpu_seg*>(this));   // nrtgpu_segment_release came while this search ran
-    return;
-  }
-  content_cv.notify_all();
+  if (last_of_released) destroy_segment(const_cast<nrtgpu_seg*>(this));
 }
 
 static const size_t kMaxAcceptSets = 64;   // combined accept sets (liveDocs & filter & ~must_not) resident per segment
@@ -80,9 +80,11 @@ extern "C" int nrtgpu_segment_begin(nrtgpu_ctx* ctx, int32_t max_doc, int32_t /*
   return NRTGPU_OK;
 }
 
-// Test hook: segment handles of the context (uploads and forks) not freed yet -- a handle released under running searches is
-// freed by the last of them (nrtgpu_segment_release), and this is how a test sees that it was.
+#ifdef NRTGPU_DEV
+// Test hook (include/nrtgpu_dev.h): segment handles of the context (uploads and forks) not freed yet -- a handle released under
+// running searches is freed by the last of them (nrtgpu_segment_release), and this is how a test sees that it was.
 extern "C" int64_t nrtgpu_debug_live_segments(nrtgpu_ctx* ctx) { return ctx ? ctx->live_segments.load(std::memory_order_relaxed) : -1; }
+#endif
 
 extern "C" int nrtgpu_segment_add_field_norms(nrtgpu_seg* seg, int32_t field_id, const uint8_t* norm_bytes) {
   if (!seg) return fail(NRTGPU_ERR_INVALID_ARG, "seg is NULL");
@@ -277,84 +279,148 @@ extern "C" int nrtgpu_segment_add_vectors(nrtgpu_seg* seg, int32_t field_id, int
 
 static int fold_live_docs(nrtgpu_seg* seg);
 
-// What the MaxScore route needs per term besides the columns (plan.h: DTermAux), built on the device from the
-// sealed columns: the impact frontier of every term, and for the terms a doc-indexed structure is affordable for one
-// membership + rank record per 32 docs (0.25 B per doc and term).  The other terms are looked up through their cell table
-// (a binary search in the docid column: 3.7 dependent probes per lookup round at C3 against one record read).
-// Which terms: at least one posting per kRecordDocsPerPosting docs, the kRecordMaxTerms largest of them.  Rounds 2-4 asked
-// for a posting per 128 docs (records <= 4x the term's posting bytes); measured in round 4 on C3 (profiles/
-// r04_record_threshold_ab.log): 128 -> 1024 -> 4096 -> 32768: kernel 2.33 -> 2.30 -> 2.245 -> 2.23 ms per 1024 queries.
-// 4096 it is: in a Zipf dictionary (df ~ max_doc / 2r) that is the 2048 most frequent terms = 512 B per doc, which the
-// term cap enforces for any other dictionary -- 5 GB at C3's 10 M docs, 26 GB at C5's 50 M, of 288 GB.
-// NRTGPU_RECORD_DOCS_PER_POSTING / NRTGPU_RECORD_MAX_TERMS (read when a segment is sealed) override both.
-static const int64_t kRecordDocsPerPosting = 4096;
-static const int64_t kRecordMaxTerms = 2048;
-static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
-  if (g.d_aux || g.n_terms == 0) return NRTGPU_OK;
-  int64_t docs_per_posting = kRecordDocsPerPosting, max_terms = kRecordMaxTerms;
-  if (const char* e = getenv("NRTGPU_RECORD_DOCS_PER_POSTING")) docs_per_posting = std::max<int64_t>(1, atoll(e));
-  if (const char* e = getenv("NRTGPU_RECORD_MAX_TERMS")) max_terms = std::max<int64_t>(0, atoll(e));
-  const size_t nt = g.n_terms;
-  const uint64_t n_blocks = ((uint64_t)seg->max_doc + 31) / 32 + 1;  // 8-byte records, one per 32 docs (+1 pad)
-  std::vector<uint64_t> rec((size_t)nt, ~0ull);
-  uint64_t n_recs = 0;
-  uint32_t max_count = 0;
-  {
-    std::vector<uint32_t> want;
-    for (size_t t = 0; t < nt; ++t)
-      if (g.h_count[t] > 0 && (int64_t)g.h_count[t] * docs_per_posting >= (int64_t)seg->max_doc) want.push_back((uint32_t)t);
-    if ((int64_t)want.size() > max_terms) {   // the largest terms (ties: the lower term id), then back into term order
-      std::nth_element(want.begin(), want.begin() + (ptrdiff_t)max_terms, want.end(), [&](uint32_t a, uint32_t b) {
-        return g.h_count[a] != g.h_count[b] ? g.h_count[a] > g.h_count[b] : a < b;
-      });
-      want.resize((size_t)max_terms);
-      std::sort(want.begin(), want.end());
+// What the MaxScore route needs per term besides the columns (plan.h: DTermAux), built on the device from the sealed
+// columns: the impact frontier of every term and, for the terms the segment's LOOKUP BUDGET pays for, a doc -> posting lookup
+// structure for the walk's later clauses (plan.h: kLook*).  Terms are served in the order of their posting counts, largest
+// first -- lookups go to a query's densest clauses, so that is the order of benefit per byte -- by the first rule of the POLICY
+// that applies to the term and whose structure still fits the budget:
+//   kind:N  the N largest terms of the upload group        kind@D  terms with a posting per D docs or more        kind  every term
+// kinds: map (2 B per doc), nib (0.5 B per doc), bits (0.25 B per doc), cells (4 - 8 B per posting).  Terms under
+// kLookMinPostings postings, and whatever no rule or no budget covers, are searched in their cell of the tile-granular table.
+// The budget (nrtgpu_config.lookup_budget_pct, default kLookBudgetPct): lookup bytes <= that share of the upload group's
+// resident posting bytes (8 B per posting, 4 B under NRTGPU_FLAG_PACKED_POSTINGS).
+// Rounds 2-4 kept records ("bits") for "the 2048 largest terms" and no budget: 4.8 GB next to 0.7 GB of postings at C3.
+static const uint32_t kLookMinPostings = 64;
+static const int kLookBudgetPct = 150;
+static const char* const kLookPolicy = "map@32,cells";
+struct LookRule {
+  uint32_t kind;
+  int64_t rank_limit;   // < 0: none
+  int64_t density;      // docs per posting, < 0: none
+};
+static std::vector<LookRule> parse_look_policy(const char* text) {
+  std::vector<LookRule> out;
+  std::string t(text ? text : "");
+  size_t i = 0;
+  while (i < t.size()) {
+    size_t j = t.find(',', i);
+    if (j == std::string::npos) j = t.size();
+    const std::string item = t.substr(i, j - i);
+    i = j + 1;
+    const size_t sep = item.find_first_of(":@");
+    const std::string name = item.substr(0, sep);
+    LookRule r{kLookNone, -1, -1};
+    if (name == "map") r.kind = kLookMap;
+    else if (name == "nib") r.kind = kLookNibble;
+    else if (name == "bits") r.kind = kLookBits;
+    else if (name == "cells") r.kind = kLookCells;
+    else continue;
+    if (sep != std::string::npos) {
+      const int64_t v = atoll(item.c_str() + sep + 1);
+      if (item[sep] == ':') r.rank_limit = v;
+      else r.density = std::max<int64_t>(v, 1);
     }
-    for (uint32_t t : want) {
-      rec[t] = n_recs;
-      n_recs += n_blocks;
-      max_count = std::max(max_count, g.h_count[t]);
+    out.push_back(r);
+  }
+  return out;
+}
+static int build_term_aux(nrtgpu_seg* seg, TermGroup& g, const uint8_t* d_norms) {
+  if (g.d_aux || g.n_terms == 0) return NRTGPU_OK;
+  const size_t nt = g.n_terms;
+  const uint32_t max_doc = (uint32_t)seg->max_doc;
+  const int pct = seg->ctx->cfg.lookup_budget_pct == 0 ? kLookBudgetPct : std::max(seg->ctx->cfg.lookup_budget_pct, 0);
+  const uint64_t posting_bytes = g.n_postings * ((seg->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS) ? 4ull : 8ull);
+  uint64_t budget = posting_bytes / 100ull * (uint64_t)pct + posting_bytes % 100ull * (uint64_t)pct / 100ull;
+  const std::vector<LookRule> rules = parse_look_policy(dev_env_str("NRTGPU_LOOK_POLICY", kLookPolicy));
+  std::vector<uint64_t> look((size_t)nt, ~0ull);   // byte offset of the term's structure inside the group's buffer
+  std::vector<uint32_t> meta((size_t)nt, 0u);      // kind | log2 docs per cell << 8
+  std::vector<uint32_t> which[5];                  // per kind the terms that got it
+  uint64_t look_bytes = 0;
+  uint32_t max_count = 0, max_cells = 0;
+  {
+    std::vector<uint32_t> order;
+    for (size_t t = 0; t < nt; ++t)
+      if (g.h_count[t] >= kLookMinPostings) order.push_back((uint32_t)t);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g.h_count[a] != g.h_count[b] ? g.h_count[a] > g.h_count[b] : a < b; });
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+      const uint32_t t = order[oi];
+      const uint64_t cnt = g.h_count[t];
+      for (const LookRule& r : rules) {
+        if (r.rank_limit >= 0 && (int64_t)oi >= r.rank_limit) continue;
+        if (r.density >= 0 && cnt * (uint64_t)r.density < (uint64_t)max_doc) continue;
+        uint64_t cost = 0;
+        uint32_t shift = 0;
+        // (every structure: 16-byte aligned, entry 0 readable for idle slots, one entry of slack behind the last doc's)
+        if (r.kind == kLookMap) cost = (((uint64_t)max_doc * 2ull + 15ull) & ~15ull) + 16ull;
+        else if (r.kind == kLookNibble) cost = (((((uint64_t)max_doc + 7ull) / 8ull) * 4ull + 15ull) & ~15ull) + 16ull;
+        else if (r.kind == kLookBits) cost = (((((uint64_t)max_doc + 31ull) / 32ull + 1ull) * 8ull + 15ull) & ~15ull);
+        else {
+          // cells of 2^shift docs, the largest power of two with at most one posting per cell on average
+          while (shift < 31u && (cnt << (shift + 1u)) <= (uint64_t)max_doc) ++shift;
+          const uint64_t n_cells = (((uint64_t)max_doc - 1ull) >> shift) + 1ull;
+          cost = (((n_cells + 2ull) * 4ull + 15ull) & ~15ull);
+        }
+        if (cost > budget) continue;   // (a later rule's structure may fit)
+        budget -= cost;
+        look[t] = look_bytes;
+        look_bytes += cost;
+        meta[t] = r.kind | (shift << 8);
+        which[r.kind].push_back(t);
+        max_count = std::max(max_count, (uint32_t)cnt);
+        if (r.kind == kLookCells) max_cells = std::max<uint32_t>(max_cells, (uint32_t)((((uint64_t)max_doc - 1ull) >> shift) + 2ull));
+        break;
+      }
     }
   }
   void* p = nullptr;
   if (int rc = dev_alloc(seg, &p, nt * sizeof(DTermAux))) return rc;
   g.d_aux = (DTermAux*)p;
-  if (n_recs) {
-    if (int rc = dev_alloc(seg, &p, (size_t)n_recs * 8)) return rc;
-    g.d_bits = (uint32_t*)p;
-    HIP_TRY(hipMemset(g.d_bits, 0, (size_t)n_recs * 8));
+  if (look_bytes) {
+    if (int rc = dev_alloc(seg, &p, (size_t)look_bytes + 64)) return rc;
+    g.d_look = (char*)p;
+    g.look_bytes = look_bytes;
+    HIP_TRY(hipMemset(g.d_look, 0, (size_t)look_bytes + 64));
+  }
+  std::vector<uint32_t> flat;
+  size_t first_of[5] = {0, 0, 0, 0, 0};
+  for (uint32_t k = 1; k < 5; ++k) {
+    first_of[k] = flat.size();
+    flat.insert(flat.end(), which[k].begin(), which[k].end());
   }
   uint64_t* d_start = nullptr;
-  uint64_t* d_rec = nullptr;
+  uint64_t* d_look = nullptr;
   uint32_t* d_count = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_start, nt * 8));
-  HIP_TRY(hipMalloc((void**)&d_rec, nt * 8));
-  HIP_TRY(hipMalloc((void**)&d_count, nt * 4));
-  HIP_TRY(hipMemcpy(d_start, g.h_start.data(), nt * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_rec, rec.data(), nt * 8, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_count, g.h_count.data(), nt * 4, hipMemcpyHostToDevice));
-  launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_rec, g.d_bits, (uint32_t)nt, g.d_aux);
-  hipError_t e = hipGetLastError();
-  uint32_t* d_dense = nullptr;
-  if (e == hipSuccess && n_recs) {
-    // the record kernel runs over the DENSE terms only (a field's dictionary holds 10^5 - 10^6 terms, a few hundred of them dense)
-    std::vector<uint32_t> dense;
-    for (size_t t = 0; t < nt; ++t)
-      if (rec[t] != ~0ull) dense.push_back((uint32_t)t);
-    e = hipMalloc((void**)&d_dense, dense.size() * 4);
-    if (e == hipSuccess) e = hipMemcpy(d_dense, dense.data(), dense.size() * 4, hipMemcpyHostToDevice);
-    for (size_t i = 0; e == hipSuccess && i < dense.size(); i += 32768) {   // (grid.y stays far below 65535)
-      launch_term_bits(nullptr, g.d_docids, d_start, d_count, d_rec, d_dense + i, (uint32_t)std::min<size_t>(32768, dense.size() - i), max_count,
-                       g.d_bits);
-      e = hipGetLastError();
-    }
+  uint32_t* d_meta = nullptr;
+  uint32_t* d_which = nullptr;
+  auto free_tmp = [&] {
+    if (d_start) (void)hipFree(d_start);
+    if (d_look) (void)hipFree(d_look);
+    if (d_count) (void)hipFree(d_count);
+    if (d_meta) (void)hipFree(d_meta);
+    if (d_which) (void)hipFree(d_which);
+  };
+  hipError_t e = hipMalloc((void**)&d_start, nt * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_look, nt * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_count, nt * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_meta, nt * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_which, std::max<size_t>(flat.size(), 1) * 4);
+  if (e == hipSuccess) e = hipMemcpy(d_start, g.h_start.data(), nt * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_look, look.data(), nt * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_count, g.h_count.data(), nt * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_meta, meta.data(), nt * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && !flat.empty()) e = hipMemcpy(d_which, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_look, d_meta, g.d_look, d_norms, (uint32_t)nt, g.d_aux);
+    for (uint32_t k : {kLookMap, kLookNibble, kLookBits})
+      launch_term_doc_maps(nullptr, k, g.d_docids, g.d_fnorm, d_start, d_count, d_look, d_which + first_of[k], (uint32_t)which[k].size(), max_count, g.d_look);
+    launch_term_cells(nullptr, g.d_docids, d_start, d_count, d_look, d_meta, d_which + first_of[kLookCells], (uint32_t)which[kLookCells].size(), max_cells,
+                      max_doc, g.d_look);
+    e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (d_dense) (void)hipFree(d_dense);
-  (void)hipFree(d_start);
-  (void)hipFree(d_rec);
-  (void)hipFree(d_count);
-  if (e != hipSuccess) return fail(NRTGPU_ERR_HIP, "building the MaxScore term records failed: %s", hipGetErrorString(e));
+  free_tmp();
+  if (e != hipSuccess) return fail(NRTGPU_ERR_HIP, "building the MaxScore lookup structures failed: %s", hipGetErrorString(e));
+  for (uint32_t k = 1; k < 5; ++k) g.n_look[k] = (uint32_t)which[k].size();
   g.h_start.clear();
   g.h_start.shrink_to_fit();
   g.h_count.clear();
@@ -459,7 +525,7 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^22 does not fit the packed freq|norm column");
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
-      if (int rc2 = build_term_aux(seg, g)) return rc2;
+      if (int rc2 = build_term_aux(seg, g, kv.second.d_norms)) return rc2;
   if (seg->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS)   // (the seal-time builders above read the two-column form)
     for (auto& kv : seg->fields)
       for (auto& g : kv.second.groups)
@@ -707,7 +773,7 @@ SegCore::~SegCore() {
       if (g.d_freqs) (void)hipFree(g.d_freqs);
       if (g.d_cells) (void)hipFree(g.d_cells);
       if (g.d_aux) (void)hipFree(g.d_aux);
-      if (g.d_bits) (void)hipFree(g.d_bits);
+      if (g.d_look) (void)hipFree(g.d_look);
     }
   }
 }
@@ -727,7 +793,7 @@ extern "C" void nrtgpu_segment_release(nrtgpu_seg* seg) {
   if (!seg) return;
   {
     std::lock_guard<std::mutex> lk(seg->content_m);
-    if (seg->content_readers > 0 || seg->content_writing) {
+    if (seg->content_readers > 0 || seg->content_writing || seg->content_writers_waiting > 0) {   // (a parked set_mask / set_live_docs is a user too)
       seg->content_released = true;
       return;
     }

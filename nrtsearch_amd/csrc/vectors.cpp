@@ -559,6 +559,9 @@ extern "C" int nrtgpu_knn_exact_relation(nrtgpu_ctx* ctx, const nrtgpu_seg* cons
                                          int32_t field_id, int32_t k, int32_t total_hits_threshold) {
   if (!ctx || (n_segs > 0 && !segs) || n_segs < 0 || k <= 0 || total_hits_threshold < 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad knn_exact_relation arguments");
   if (total_hits_threshold == INT32_MAX) return 0;   // ScoreMode.COMPLETE: the collector never publishes a min competitive score
+  for (int32_t i = 0; i < n_segs; ++i)
+    if (!segs[i]) return fail(NRTGPU_ERR_STATE, "segment %d missing or not sealed", i);
+  SegReadLocks content(segs, n_segs);   // liveDocs of the handles are read: not under a set_live_docs on one of them
   std::vector<int64_t> live((size_t)std::max(n_segs, 1), 0);
   std::vector<hostmath::LeafInfo> all((size_t)n_segs);
   int32_t base = 0;

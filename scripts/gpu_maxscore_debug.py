@@ -1,9 +1,11 @@
+import os
 #!/usr/bin/env python3
 """Debug aid for the MaxScore route: pruned vs exhaustive vs oracle on the tests' mid-size corpus, with a diff of
 what is missing (rank, score, segment, tile)."""
 import json, sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("NRTGPU_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nrtsearch_amd", "libnrtgpu_dev.so"))   # instrumented kernels: the development library (include/nrtgpu_dev.h)
 from nrtsearch_amd import _lib, api, synth
 from oracle import oracle
 

@@ -32,3 +32,19 @@ def oracle():
 
     o.build()
     return o
+
+
+@pytest.fixture
+def dev_lib():
+    """The test talks to the DEVELOPMENT library (include/nrtgpu_dev.h: the product sources + test hooks) instead of the product
+    library: for the few GPU tests that park callers behind nrtgpu_debug_hold_coalescers or count live handles.  Everything the
+    test creates (contexts, segments) must be created and closed inside it -- handles of one library mean nothing to the other."""
+    from nrtsearch_amd import _lib, build
+
+    build.build_dev()
+    prev = _lib._lib
+    _lib._lib = _lib.load_dev()
+    try:
+        yield _lib._lib
+    finally:
+        _lib._lib = prev

@@ -33,6 +33,21 @@ def test_header_symbols_all_exported(lib):
         assert hasattr(lib, name), f"{name} declared in include/nrtgpu.h but not exported"
 
 
+def test_dev_symbols_are_not_part_of_the_product_boundary(lib):
+    """include/nrtgpu_dev.h (test hooks, instrumented kernels' counters, the closed-loop generator) belongs to the development
+    library only: the product library exports none of it, the development library all of it next to the product ABI."""
+    text = open(os.path.join(ROOT, "include", "nrtgpu_dev.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(nrtgpu_[a-z0-9_]+)\s*\(", text)))
+    assert declared == sorted(_lib.DEV_SYMBOLS)
+    for name in declared:
+        assert not hasattr(lib, name), f"{name} is a development symbol but the product library exports it"
+    build.build_dev()
+    dev = _lib.load_dev()
+    for name in declared + _lib.ABI_SYMBOLS:
+        assert hasattr(dev, name), f"{name} missing from the development library"
+
+
 def test_version_string(lib):
     assert b"gfx950" in lib.nrtgpu_version()
 
@@ -49,11 +64,11 @@ def test_create_fails_loudly_without_gpu(lib):
 
 def test_struct_sizes_match_header(lib):
     # layout pinned on both sides of the boundary (x86-64 SysV)
-    assert C.sizeof(_lib.Config) == 24
+    assert C.sizeof(_lib.Config) == 32
     assert C.sizeof(_lib.Term) == 24
     assert C.sizeof(_lib.Bm25Query) == 112
     assert C.sizeof(_lib.TopDocs) == 40
-    assert C.sizeof(_lib.Stats) == 152
+    assert C.sizeof(_lib.Stats) == 176
     assert C.sizeof(_lib.Diagnostics) == 56
 
 

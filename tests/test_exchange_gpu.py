@@ -286,7 +286,7 @@ def _small_begin_wait_index(max_batch=16):
     return w, qr, corpus, ctx, leaves
 
 
-def test_segment_release_while_searches_are_in_flight():
+def test_segment_release_while_searches_are_in_flight(dev_lib):
     """nrtgpu_segment_release under running searches (the reference closes readers while SEARCH-pool
     threads run: ShardState.java:506-527).  Three batches are begun over forked reader versions (planned, enqueued, NOT waited
     for), every handle they use -- the forks AND the base segments -- is released, then the batches are waited for: same keys,

@@ -13,8 +13,7 @@ pytestmark = pytest.mark.gpu
 VEC_FIELD, DIM = 7, 64
 
 
-@pytest.fixture(scope="module")
-def hybrid():
+def _hybrid_index():
     rng = np.random.default_rng(11)
     ranks = [1, 3, 8, 20, 60, 300, 2000]
     corpus = synth.build_corpus(60_000, ranks, n_segments=3)
@@ -30,10 +29,20 @@ def hybrid():
         leaves.append(g)
         vecs.append(v)
     sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
-    yield dict(corpus=corpus, ctx=ctx, leaves=leaves, vecs=vecs, sr=sr, rng=rng, ranks=ranks)
-    for g in leaves:
+    return dict(corpus=corpus, ctx=ctx, leaves=leaves, vecs=vecs, sr=sr, rng=rng, ranks=ranks)
+
+
+def _hybrid_close(h):
+    for g in h["leaves"]:
         g.release()
-    ctx.close()
+    h["ctx"].close()
+
+
+@pytest.fixture(scope="module")
+def hybrid():
+    h = _hybrid_index()
+    yield h
+    _hybrid_close(h)
 
 
 def _bq(terms):
@@ -182,42 +191,53 @@ def test_coalesced_single_searches_from_many_threads(hybrid, oracle):
     st = hybrid["ctx"].stats()
     assert st["queries"] == 32 * 25
     assert st["batches"] <= st["queries"]         # (how many batches the free-running callers formed is the host's business)
-    # merged into batches, by construction: 32 callers parked behind the test hook (include/nrtgpu.h:
-    # nrtgpu_debug_hold_coalescers), released together -> the same leaves, fewer than max_batch = 256 -> ONE batch
-    import time
-    ctx = hybrid["ctx"]
-    ctx.reset_stats()
-    ctx.debug_hold_coalescers(True)
-
-    def one(tix):
-        try:
-            i = tix % len(term_sets)
-            r = hybrid["sr"].search_coalesced(_bq(term_sets[i]), api.TopScoreDocCollectorManager(100))
-            ed, es, et, eg = expected[i]
-            if r.docs.tolist() != ed.tolist() or r.scores.view(np.uint32).tolist() != es.view(np.uint32).tolist() or not total_ok(r, et, eg, 100, 1000):
-                errors.append((tix, i))
-        except Exception as e:  # noqa: BLE001
-            errors.append((tix, repr(e)))
-
-    threads = [threading.Thread(target=one, args=(t,)) for t in range(32)]
-    try:
-        for t in threads:
-            t.start()
-        t_end = time.monotonic() + 60.0
-        while ctx.debug_coalescer_pending(0) < 32 and time.monotonic() < t_end and not errors:
-            time.sleep(0.001)
-        parked = ctx.debug_coalescer_pending(0)
-    finally:
-        ctx.debug_hold_coalescers(False)
-    for t in threads:
-        t.join()
-    assert not errors, errors[:5]
-    assert parked == 32
-    st = ctx.stats()
-    assert st["queries"] == 32 and st["batches"] == 1, st
     # an invalid request fails alone, with its own message
     with pytest.raises(Exception):
         hybrid["sr"].search_coalesced(_bq([1, 20]), api.TopScoreDocCollectorManager(0))
+
+
+def test_coalesced_single_searches_form_one_batch_by_construction(dev_lib, oracle):
+    """Merged into batches, BY CONSTRUCTION: 32 callers parked behind the test hook of the development library
+    (include/nrtgpu_dev.h: nrtgpu_debug_hold_coalescers), released together -> the same leaves, fewer than max_batch = 256 -> ONE
+    batch, whatever the host's speed."""
+    import time
+    term_sets = [[1, 20], [3, 60, 300], [8, 2000], [1, 3, 8, 20, 60], [300], [20, 2000, 1], [60, 8], [3, 1, 300, 2000]]
+    hybrid = _hybrid_index()
+    try:
+        expected = [oracle.search_bm25(hybrid["corpus"], t, 100) for t in term_sets]
+        errors = []
+        ctx = hybrid["ctx"]
+        ctx.reset_stats()
+        ctx.debug_hold_coalescers(True)
+
+        def one(tix):
+            try:
+                i = tix % len(term_sets)
+                r = hybrid["sr"].search_coalesced(_bq(term_sets[i]), api.TopScoreDocCollectorManager(100))
+                ed, es, et, eg = expected[i]
+                if r.docs.tolist() != ed.tolist() or r.scores.view(np.uint32).tolist() != es.view(np.uint32).tolist() or not total_ok(r, et, eg, 100, 1000):
+                    errors.append((tix, i))
+            except Exception as e:  # noqa: BLE001
+                errors.append((tix, repr(e)))
+
+        threads = [threading.Thread(target=one, args=(t,)) for t in range(32)]
+        try:
+            for t in threads:
+                t.start()
+            t_end = time.monotonic() + 60.0
+            while ctx.debug_coalescer_pending(0) < 32 and time.monotonic() < t_end and not errors:
+                time.sleep(0.001)
+            parked = ctx.debug_coalescer_pending(0)
+        finally:
+            ctx.debug_hold_coalescers(False)
+        for t in threads:
+            t.join()
+        assert not errors, errors[:5]
+        assert parked == 32
+        st = ctx.stats()
+        assert st["queries"] == 32 and st["batches"] == 1, st
+    finally:
+        _hybrid_close(hybrid)
 
 
 def test_fused_hybrid_under_speculative_thresholds_equals_the_unspeculated_answer():
@@ -246,11 +266,11 @@ def test_fused_hybrid_under_speculative_thresholds_equals_the_unspeculated_answe
         qv = rng.standard_normal((len(qs), dim)).astype(np.float32)
         ctx.set_speculation(5.0)
         fused = sr.search_hybrid_batch(qs, mg, VEC_FIELD, "cosine", qv, 100, 1.0, 2.0)
-        c = ctx.debug_spec_counters()
+        c = ctx.spec_counters()
         assert c["queries"] == len(qs) and c["reruns"] >= 2, c
         ctx.set_speculation(0.0)
         plain = sr.search_hybrid_batch(qs, mg, VEC_FIELD, "cosine", qv, 100, 1.0, 2.0)
-        assert ctx.debug_spec_counters()["queries"] == 0
+        assert ctx.spec_counters()["queries"] == 0
         for a, b in zip(fused, plain):
             assert a.docs.tolist() == b.docs.tolist() and a.scores.view(np.uint32).tolist() == b.scores.view(np.uint32).tolist()
             assert len(a.docs) == 100 and a.relation_gte == b.relation_gte   # (the counts are lower bounds: what each run happened to evaluate)

@@ -259,7 +259,7 @@ def test_speculative_thresholds_are_checked_and_failed_guesses_run_again(oracle)
             got = ix.searcher.search_batch([bq(t) for t in qs], [api.TopScoreDocCollectorManager(k, None, thr)] * len(qs))
             for i, t in enumerate(qs):
                 check(f"spec_{k}_{thr}_{i}", got[i], oracle.search_bm25(corpus, t, k, total_hits_threshold=thr), k, thr)
-        c = ctx.debug_spec_counters()
+        c = ctx.spec_counters()
         assert c["queries"] == 3 * len(qs) and not c["switched_off"]
         assert c["reruns"] <= 1, c      # (five standard deviations: a failure here is a bug in the estimate, not bad luck)
         # (2) only the first 30 % of the docids are live
@@ -274,7 +274,7 @@ def test_speculative_thresholds_are_checked_and_failed_guesses_run_again(oracle)
             got = ix.searcher.search_batch([bq(t) for t in qs], [api.TopScoreDocCollectorManager(k, None, thr)] * len(qs))
             for i, t in enumerate(qs):
                 check(f"spec_skewed_{k}_{thr}_{i}", got[i], oracle.search_bm25(corpus, t, k, total_hits_threshold=thr), k, thr)
-        c = ctx.debug_spec_counters()
+        c = ctx.spec_counters()
         assert c["queries"] == 2 * len(qs) and c["reruns"] >= 3, c
         # (3) ... and a context that keeps failing gives speculation up: 2048 queries seen, more than 2 % of them run again
         rng = np.random.Generator(np.random.PCG64(99))
@@ -283,13 +283,13 @@ def test_speculative_thresholds_are_checked_and_failed_guesses_run_again(oracle)
             batch = [[int(x) for x in rng.choice(ranks, size=int(rng.integers(2, 6)), replace=False)] for _ in range(64)]
             got = ix.searcher.search_batch([bq(t) for t in batch], [api.TopScoreDocCollectorManager(100, None, 10)] * 64)
             last = (batch, got)
-        c = ctx.debug_spec_counters()
+        c = ctx.spec_counters()
         assert c["switched_off"], c
         for i in range(0, 64, 9):
             check(f"spec_off_{i}", last[1][i], oracle.search_bm25(corpus, last[0][i], 100, total_hits_threshold=10), 100, 10)
-        before = ctx.debug_spec_counters()["reruns"]
+        before = ctx.spec_counters()["reruns"]
         ix.searcher.search_batch([bq(t) for t in qs], [api.TopScoreDocCollectorManager(100, None, 10)] * len(qs))
-        assert ctx.debug_spec_counters()["reruns"] == before     # nothing speculates any more
+        assert ctx.spec_counters()["reruns"] == before     # nothing speculates any more
     finally:
         ix.close()
         ctx.close()

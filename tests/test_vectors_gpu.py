@@ -557,7 +557,7 @@ def test_sketch_is_built_by_the_first_exact_search_only(oracle):
         c.close()
 
 
-def test_knn_coalesced_callers_share_passes(oracle):
+def test_knn_coalesced_callers_share_passes(dev_lib, oracle):
     """nrtgpu_knn_exact_coalesced: what a request thread calls with ONE query.  48 concurrent callers with their own queries and
     their own k (two similarities: requests that cannot share a panel) get exactly what nrtgpu_knn_exact gives each of them alone,
     from fewer passes over the rows than there were calls; a lone caller runs at once.
