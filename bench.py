@@ -44,6 +44,9 @@ def parse_args():
                          "cosine, top-100, --knn-queries per step (1 GPU)")
     ap.add_argument("--knn-queries", type=int, default=32, help="C4: queries per step (one panel = up to 32 queries)")
     ap.add_argument("--docs", type=int, default=0, help="override the number of docs (debug)")
+    ap.add_argument("--corpus-variant", default="iid", choices=["iid", "clustered", "sorted"],
+                    help="the synthetic corpus: iid = SURVEY 8d (every posting list an independent uniform draw: the headline); clustered = "
+                         "terms in docid bursts; sorted = docs numbered by length (nrtsearch_amd/synth.py: corpus_variant_arrays)")
     ap.add_argument("--target-items", type=int, default=0)
     ap.add_argument("--no-prefetch", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=8192, help="queries timed on the CPU oracle (0 = skip): ~10 s of CPU work on 16 cores")
@@ -643,7 +646,7 @@ def main():
     qranks = synth.make_queries(n_distinct, w.n_terms, w.max_rank)
     t_build = time.perf_counter()
     shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if (args.emulate_world > 1 and world == 1) else (world, rank)
-    corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank, layout=args.shard_layout)
+    corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank, layout=args.shard_layout, variant=args.corpus_variant)
     t_build = time.perf_counter() - t_build
 
     flags = ((_lib.NRTGPU_FLAG_NO_PREFETCH if args.no_prefetch else 0) | (_lib.NRTGPU_FLAG_NO_PRUNE if args.no_prune else 0)
@@ -693,7 +696,7 @@ def main():
         for r in range(shard_world):
             if r == shard_rank:
                 continue
-            c_r = workload.build_shard_corpus(w, qranks, shard_world, r, layout=args.shard_layout)
+            c_r = workload.build_shard_corpus(w, qranks, shard_world, r, layout=args.shard_layout, variant=args.corpus_variant)
             ctx_r = api.GpuContext(device_id=local_rank, max_batch=B, flags=flags, host_threads=planner_threads)
             leaves_r = [api.GpuSegment.from_data(ctx_r, s) for s in c_r.segments]
             sr_r = api.GpuIndexSearcher(ctx_r, leaves_r, api.IndexStatistics.from_corpus(c_r))
@@ -1024,7 +1027,7 @@ def main():
             "speculation": ctx.spec_counters(),   # speculative thresholds of the MaxScore route: queries run under them / run again
             "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
             "host_threads": n_thr, "host_cpus_busy": round(host_cpu_busy, 2), "host_cpus_busy_by_thread_kind": cpu_by_kind,
-            "corpus_build_s": round(t_build, 1),
+            "corpus_build_s": round(t_build, 1), "corpus_variant": args.corpus_variant,
             "dist_stage_ms": ({k_: round(v / max(1, stage["steps"]) * 1e3, 3) for k_, v in stage.items() if k_ != "steps"}
                               if use_dist else None),   # per step on this rank: scan call (per scan thread), exchange, merge call
         },

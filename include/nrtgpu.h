@@ -255,8 +255,10 @@ int  nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us);
  * -- the calls that can run a query again): a workgroup that has walked a fraction of a query's docs guesses the final k-th score from the best of what
  * it has seen, `margin` standard deviations on the safe side, and skips what cannot reach the guess; the merge checks every
  * guess against the merged list and a query whose guess failed is run again without speculation inside the same call.  Results
- * are exact either way.  margin 0 switches it off; a context starts with 5.  Resets the counters nrtgpu_get_stats reports
- * (spec_queries / spec_reruns / spec_disabled). */
+ * are exact either way.  margin 0 switches it off; a context starts with 5.  The library judges every leaf set (the segments of
+ * one searcher version) by its own failures: more than 2 % of >= 2048 queries run again moves the leaf set to a scattered window
+ * order, and if the guesses fail there too speculation is switched off for it.  Resets the counters nrtgpu_get_stats reports
+ * (spec_queries / spec_reruns / spec_scattered / spec_disabled) and every leaf set's verdict. */
 int  nrtgpu_set_speculation(nrtgpu_ctx* ctx, float margin);
 
 /* Device-resident variant for the multi-GPU path (one process per GPU): results stay
@@ -525,7 +527,10 @@ typedef struct {
   int64_t knn_sketch_launches; /* of knn_score_launches: passes that nominated from the fp16 sketch (half the bytes per row) */
   int64_t spec_queries;       /* speculative thresholds (nrtgpu_set_speculation), since that call: queries run under them ... */
   int64_t spec_reruns;        /* ... queries whose guess failed the merge's check and were run again inside their call ... */
-  int64_t spec_disabled;      /* ... 1 once the library has switched speculation off for this context: too many failed */
+  int64_t spec_disabled;      /* ... 1 once the library has switched speculation off for one of the context's leaf sets: too many failed
+                               * there even in the scattered order */
+  int64_t spec_scattered;     /* ... 1 once a leaf set was moved to the scattered window order (its guesses failed in docid order: docids
+                               * that are no sample of the index -- an index sort, time-ordered vocabulary) */
 } nrtgpu_stats;
 int  nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out);
 void nrtgpu_reset_stats(nrtgpu_ctx* ctx);

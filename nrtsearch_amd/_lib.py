@@ -97,7 +97,7 @@ class Stats(C.Structure):
                 ("maxscore_launches", C.c_int64), ("maxscore_ms", C.c_double), ("maxscore_postings", C.c_int64),
                 ("maxscore_items", C.c_int64), ("knn_panels", C.c_int64), ("knn_score_launches", C.c_int64),
                 ("knn_score_ms", C.c_double), ("knn_rows", C.c_int64), ("knn_second_passes", C.c_int64), ("knn_sketch_launches", C.c_int64),
-                ("spec_queries", C.c_int64), ("spec_reruns", C.c_int64), ("spec_disabled", C.c_int64)]
+                ("spec_queries", C.c_int64), ("spec_reruns", C.c_int64), ("spec_disabled", C.c_int64), ("spec_scattered", C.c_int64)]
 
 
 class NrtGpuError(RuntimeError):

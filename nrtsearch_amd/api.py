@@ -253,7 +253,8 @@ class GpuContext:
         """Speculative thresholds of the MaxScore route (nrtgpu_stats.spec_*): queries run under them since nrtgpu_set_speculation,
         queries run again, whether the library has switched them off for this context."""
         st = self.stats()
-        return {"queries": int(st["spec_queries"]), "reruns": int(st["spec_reruns"]), "switched_off": bool(st["spec_disabled"])}
+        return {"queries": int(st["spec_queries"]), "reruns": int(st["spec_reruns"]), "switched_off": bool(st["spec_disabled"]),
+                "scattered": bool(st["spec_scattered"])}
 
     def debug_live_segments(self) -> int:
         """Segment handles of this context (uploads and forks) not freed yet (nrtgpu_debug_live_segments)."""

@@ -68,8 +68,8 @@ struct alignas(16) WClause {
                             // lookup kind (plan.h: kLook*) << 24 | log2 docs per lookup cell << 27
   uint32_t pad;
   uint64_t u_after;         // what the later clauses can add at most: S_{c+1}
-  uint64_t look;            // the term's lookup structure (plan.h: DTermAux.look): code map / lookup cells, 0 = none
-  uint64_t cells, start;    // cell table (kLookNibble: the field's norm bytes instead), first posting of the term in the columns
+  uint64_t look;            // the term's lookup structure (plan.h: DTermAux.look): records / lookup cells, 0 = none
+  uint64_t cells, start;    // cell table, first posting of the term in the columns
 };
 static_assert(sizeof(WClause) == 80, "WClause layout");
 
@@ -143,33 +143,6 @@ __device__ __forceinline__ void values_of_codes(const MsSmem& s, const uint32_t 
       const uint32_t nb = esc ? (cj & 255u) : ((cj >> 2) & 127u);
       if (((need >> j) & 1u) && (esc || tab == 7u))
         val[j] = dead ? 0u : score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
-    }
-  }
-}
-
-// The same for the words of a term's CODE MAP (plan.h: kLookMap), one per looked-up doc: bit 15 clear -- (freq << 7) | norm
-// byte, x 4 the table offset; bit 15 set -- freq << 8 | norm byte of a posting no table serves, scored by the formula.  Only
-// slots in `need` hold a posting (and none of them the escape word).  Deleted docs are never looked up: no dead postings here.
-template <int NS>
-__device__ __forceinline__ void values_of_map(const MsSmem& s, const uint32_t (&mw)[NS], uint32_t need, uint32_t tab_slot, float w, int fx_scale,
-                                              uint32_t cache_slot, uint32_t (&val)[NS]) {
-  const uint32_t tab = tab_slot < (uint32_t)kTabTerms ? tab_slot : 7u;
-  const char* tb = (const char*)&s.tab[tab == 7u ? 0u : tab][0];
-  uint32_t cor = 0;
-#pragma unroll
-  for (int j = 0; j < NS; ++j) {
-    val[j] = *(const uint32_t*)(tb + ((mw[j] << 2) & 0x1FFCu));
-    cor |= ((need >> j) & 1u) ? mw[j] : 0u;
-  }
-  const bool special = need != 0u && ((cor >> 15) != 0u || tab == 7u);
-  if (__any(special)) {
-    const float* cache = &s.cache[cache_slot][0];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      const bool esc = (mw[j] >> 15) != 0u;
-      const uint32_t f = esc ? ((mw[j] >> 8) & 127u) : ((mw[j] >> 7) & 15u);
-      const uint32_t nb = esc ? (mw[j] & 255u) : (mw[j] & 127u);
-      if (((need >> j) & 1u) && (esc || tab == 7u)) val[j] = score_value<true>(bm25_score(w, (float)(int32_t)f, cache[nb]), fx_scale);
     }
   }
 }
@@ -550,7 +523,34 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
   #ifdef NRT_MS_COUNT_ROUNDS   // experiment build: event counts instead of four of the cycle counters
     uint64_t pc_dense = 0, pc_sparse = 0, pc_steps = 0, pc_tas = 0, pc_crounds = 0;
   #endif
-    uint32_t g = helper ? (uint32_t)kMsWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)first_win) : wave;   // my current window (flattened over the item's parts)
+    // The item's windows (flattened over its parts, item_wins of them) are handed out in a SCATTERED order: the i-th window taken
+    // (by anybody: the counter is shared with the item's helpers) is window (i x a) mod item_wins, a coprime to item_wins and near
+    // 0.618 item_wins -- consecutive takes land far apart and any prefix of the takes is spread evenly over the item's docs, whatever
+    // its parts are.  The speculative thresholds (ms_compact) read "the docs of the windows begun so far" as a sample of the query's
+    // docs: true of independently drawn docids in any order; true of time-ordered docids, of terms that come in bursts, of an index
+    // sorted by a field the score follows only in an order like this one.  A wave changes its part more often than in docid order (a
+    // part prologue each time); with a dozen windows per wave and item it met most parts anyway.
+    // (a = P mod n for a prime P > n: coprime; of four primes the one whose a / n is nearest the golden section.)
+    const uint32_t item_wins = item.flags >> 8;
+    uint32_t sc_mul = 1u;
+    if (ap->scatter != 0u && item_wins > 3u && item_wins < 65536u) {   // (uniform; i x a stays below 2^32)
+      const uint32_t primes[4] = {2654435761u, 2246822519u, 3266489917u, 668265263u};
+      uint32_t best = 0xFFFFFFFFu;
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t a = primes[i] % item_wins;
+        const uint32_t x = a * 1000u, y = item_wins * 618u;
+        const uint32_t dist = x > y ? x - y : y - x;
+        if (a > 1u && dist < best) {
+          best = dist;
+          sc_mul = a;
+        }
+      }
+    }
+    auto window_of_take = [&](uint32_t h) -> uint32_t {   // (uniform) the h-th take's window; takes past the item stay past it
+      return (sc_mul == 1u || h >= item_wins) ? h : (h * sc_mul) % item_wins;
+    };
+    uint32_t g = window_of_take(helper ? (uint32_t)kMsWaves + (uint32_t)__builtin_amdgcn_readfirstlane((int)first_win) : wave);   // my current window (flattened over the item's parts)
     uint32_t pi = 0;        // its part ...
     uint32_t win_base = 0;  // ... and the windows of the parts before that one
 
@@ -558,6 +558,10 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       // ---- the part that holds window g
       DPart part;
       uint32_t part_wins = 0;
+      if (sc_mul != 1u) {   // (scattered order: the next window may lie before the current part)
+        pi = 0;
+        win_base = 0;
+      }
       for (;; ++pi) {
         if (pi >= item.n_parts) break;
         part = parts[item.part_begin + pi];
@@ -640,7 +644,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         w.pad = 0;
         w.u_after = my_after;
         w.look = look_kind != kLookNone ? (uint64_t)ax->look : 0ull;
-        w.cells = look_kind == kLookNibble ? (uint64_t)ax->norms : (uint64_t)mt.cell_off;   // (a freq map's clause keeps its field's norms here)
+        w.cells = (uint64_t)mt.cell_off;
         w.start = mt.start;
         wcl[lane] = w;
       }
@@ -895,111 +899,66 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
             const uint64_t look2 = uniform_u64(w2.look);
             const uint32_t flags2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w2.flags);
             const uint32_t kind2 = (flags2 >> 24) & 7u;   // (uniform) how a doc is looked up in this clause (plan.h: kLook*)
+            const uint64_t start2 = uniform_u64(w2.start);
+            const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + start2 * 4u);  // packed: the code rides in the posting's word
+            uint32_t c2[kSl];
+            uint32_t pi2[kSl];  // packed postings: the looked-up postings' indices in their column (exception lookups)
             uint32_t present = 0;
-            uint32_t v2[kSl];
-  #pragma unroll
-            for (int j = 0; j < kSl; ++j) v2[j] = 0u;
   #ifdef NRT_MS_COUNT_ROUNDS
-            if (PROF) { if (kind2 == kLookMap || kind2 == kLookNibble || kind2 == kLookBits) pc_dense += 1; else pc_sparse += 1; }
+            if (PROF) { if (kind2 == kLookBits) pc_dense += 1; else pc_sparse += 1; }
   #endif
-            uint32_t sm = am;   // the docs to be SEARCHED for in the clause's postings: all of them, or -- under a map -- the few it cannot name
-            uint32_t found = 0; // the docs whose posting is known by its index (records, search): a[] = the index, c2[] = its code word
-            uint32_t a[kSl], c2[kSl];
-            if (kind2 == kLookMap || kind2 == kLookNibble) {
-              uint32_t mw[kSl];   // per doc the code-map word: 0 = absent, kLookMapEscape = there, freq unknown
-              if (kind2 == kLookMap) {
-                // CODE MAP: one 16-bit word per doc says whether the doc is there and what it adds -- ONE gather per doc
-                const NRT_GLOBAL uint16_t* const cmap = (const NRT_GLOBAL uint16_t*)look2;
-  #pragma unroll
-                for (int j = 0; j < kSl; ++j) mw[j] = cmap[((am >> j) & 1u) ? d[j] : 0u];
-                __builtin_amdgcn_sched_barrier(0);   // every gather is issued before the first one is waited for
-              } else {
-                // FREQ MAP: 4 bits per doc = the term's freq there; the doc's norm byte comes with the same round of gathers
-                const gu32_ptr nmap = (gu32_ptr)look2;
-                const NRT_GLOBAL uint8_t* const norms2 = (const NRT_GLOBAL uint8_t*)uniform_u64(w2.cells);   // (this kind keeps the field's norms here)
-                uint32_t nw[kSl], nb[kSl];
-  #pragma unroll
-                for (int j = 0; j < kSl; ++j) {
-                  nw[j] = nmap[((am >> j) & 1u) ? (d[j] >> 3) : 0u];
-                  nb[j] = norms2 != nullptr ? (uint32_t)norms2[((am >> j) & 1u) ? d[j] : 0u] : 1u;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
-                for (int j = 0; j < kSl; ++j) {
-                  const uint32_t f = (nw[j] >> ((d[j] & 7u) << 2)) & 15u;
-                  const uint32_t plain = (f << 7) | nb[j], esc = 0x8000u | (f << 8) | nb[j];
-                  mw[j] = f == 0u ? 0u : (f == 15u ? kLookMapEscape : ((f <= (uint32_t)kTabMaxFreq && nb[j] < (uint32_t)kTabNorms) ? plain : esc));
-                }
-              }
-              NRT_PH_MARK(4);
-              sm = 0u;
-  #pragma unroll
-              for (int j = 0; j < kSl; ++j) {
-                const bool mine = ((am >> j) & 1u) != 0u;
-                present |= (mine && mw[j] != 0u && mw[j] != kLookMapEscape ? 1u : 0u) << j;
-                sm |= (mine && mw[j] == kLookMapEscape ? 1u : 0u) << j;   // (a freq the map cannot name: practically never)
-              }
-              values_of_map<kSl>(s, mw, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, v2);
-              NRT_PH_MARK(5);
-            } else if (kind2 == kLookBits) {
+            if (kind2 == kLookBits) {
               // RECORDS: one 8-byte record per 32 docs {doc bits, postings of the term before the block} says whether the doc is
               // there and where its posting is; the code is a second, dependent gather
               const gvec2_ptr recs = (gvec2_ptr)look2;
-              const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + uniform_u64(w2.start) * 4u);
               u32x2 r[kSl];
   #pragma unroll
               for (int j = 0; j < kSl; ++j) r[j] = recs[((am >> j) & 1u) ? (d[j] >> 5) : 0u];
-              __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_sched_barrier(0);   // every record load is issued before the first one is waited for
               NRT_PH_MARK(4);
+              uint32_t idx[kSl];
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
                 const uint32_t bb = d[j] & 31u;
                 const bool there = ((am >> j) & 1u) && ((r[j][0] >> bb) & 1u);
-                a[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
-                found |= (there ? 1u : 0u) << j;
+                idx[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
+                present |= (there ? 1u : 0u) << j;
               }
   #pragma unroll
-              for (int j = 0; j < kSl; ++j) c2[j] = codes2[a[j]];
-              __builtin_amdgcn_sched_barrier(0);
+              for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
+              __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
               NRT_PH_MARK(5);
-              sm = 0u;
-            }
-            if (__any(sm != 0u)) {
+  #pragma unroll
+              for (int j = 0; j < kSl; ++j) pi2[j] = (uint32_t)start2 + idx[j];
+            } else {
               // SEARCH: the doc's cell -- a lookup cell of 2^look_shift docs holding 0.5 - 1 posting on average (kLookCells), else
-              // its cell of the tile-granular table -- then a binary search among the cell's postings; the 8 searches of a lane
-              // advance in lockstep, so every step is one round of loads in flight instead of eight.  The code is fetched next to
-              // every probed docid (packed postings: it rides in the probed word): a search that ends on its first probe -- the
-              // rule under lookup cells -- has the posting's score code without a further dependent gather.
-              const uint64_t start2 = uniform_u64(w2.start);
-              const gu32_ptr codes2 = (gu32_ptr)(uniform_u64(PACKED ? w2.docids : w2.fnorm) + start2 * 4u);
-              // (the tile-granular table: kept in the wave's record unless the kind keeps something else there -- then from the plan)
-              const gu32_ptr cells2 = (gu32_ptr)(kind2 == kLookCells ? look2 : (kind2 == kLookNibble ? (uint64_t)part_terms[j2].cell_off : uniform_u64(w2.cells)));
+              // its cell of the tile-granular table (~4 - 8 postings) -- then a binary search among the cell's postings; the 8
+              // searches of a lane advance in lockstep, so every step is one round of loads in flight instead of eight
+              const gu32_ptr cells2 = (gu32_ptr)(kind2 == kLookCells ? look2 : uniform_u64(w2.cells));
               const gu32_ptr docs2 = (gu32_ptr)(uniform_u64(w2.docids) + start2 * 4u);
               const uint32_t cshift = kind2 == kLookCells ? (flags2 >> 27) & 31u : 10u + ((flags2 >> 16) & 31u);
-              uint32_t b[kSl];
+              uint32_t a[kSl], b[kSl];
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
-                const uint32_t cell = ((sm >> j) & 1u) ? (d[j] >> cshift) : 0u;
+                const uint32_t cell = ((am >> j) & 1u) ? (d[j] >> cshift) : 0u;
                 a[j] = cells2[cell];
                 b[j] = cells2[cell + 1u];
-                c2[j] = 0u;
               }
               uint32_t open = 0;
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
-                if (!((sm >> j) & 1u)) b[j] = a[j];
+                if (!((am >> j) & 1u)) b[j] = a[j];
                 open |= (a[j] < b[j] ? 1u : 0u) << j;
               }
               while (__any(open != 0u)) {  // lower bound of d[j] in [a, b): b stays the first index known to hold a docid >= d[j]
   #ifdef NRT_MS_COUNT_ROUNDS
                 if (PROF) pc_steps += 1;
   #endif
-                uint32_t mid[kSl], vv[kSl], cw[kSl];
+                uint32_t mid[kSl], vv[kSl];
   #pragma unroll
                 for (int j = 0; j < kSl; ++j) {
                   mid[j] = (a[j] + b[j]) >> 1;
                   vv[j] = docs2[((open >> j) & 1u) ? mid[j] : 0u];
-                  cw[j] = PACKED ? vv[j] : codes2[((open >> j) & 1u) ? mid[j] : 0u];
                 }
   #pragma unroll
                 for (int j = 0; j < kSl; ++j)
@@ -1010,29 +969,26 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                     else b[j] = mid[j];
                     if (dv == dd) {  // found: close the search on it
                       a[j] = b[j] = mid[j];
-                      found |= 1u << j;
-                      c2[j] = cw[j];
+                      present |= 1u << j;
                     }
                     if (!(a[j] < b[j])) open &= ~(1u << j);
                   }
               }
-              NRT_PH_MARK(7);
-            }
-            if (__any(found != 0u)) {   // (uniform: only after records or a search)
-              uint32_t pi2[kSl], vs[kSl];   // pi2: packed postings: the postings' indices in their column (exception lookups)
-              const uint32_t start_lo = (uint32_t)uniform_u64(w2.start);
   #pragma unroll
               for (int j = 0; j < kSl; ++j) {
-                pi2[j] = start_lo + a[j];
-                if (PACKED) c2[j] = (c2[j] & kPackCodeMask) << 2;
+                c2[j] = codes2[((present >> j) & 1u) ? a[j] : 0u];   // (packed: the posting's word again -- keeping the probe's word alive
+                                                                      //  through the search loop cost more than this gather)
+                pi2[j] = (uint32_t)start2 + a[j];
               }
-              values_of_codes<PACKED, kSl>(s, c2, found, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, vs);
-  #pragma unroll
-              for (int j = 0; j < kSl; ++j)
-                if ((found >> j) & 1u) v2[j] = vs[j];
-              present |= found;
+              NRT_PH_MARK(7);
             }
             if (__any(present != 0u)) {
+              uint32_t v2[kSl];
+              if (PACKED) {
+  #pragma unroll
+                for (int j = 0; j < kSl; ++j) c2[j] = (c2[j] & kPackCodeMask) << 2;
+              }
+              values_of_codes<PACKED, kSl>(s, c2, present, flags2 & 7u, w2.weight, w2.fx_scale, (flags2 >> 8) & 255u, w2.fnorm, pi2, v2);
               const uint32_t mult2 = 1u << ((flags2 >> 4) & 15u);
               if (use_max) {   // (uniform)
   #pragma unroll
@@ -1155,8 +1111,8 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
 
         // ---- next window
         if (PROF) tc_walk += __builtin_readcyclecounter() - t_win0;
-        g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_new);
-        if (g >= win_base + part_wins) break;  // a later part (or past the item)
+        g = window_of_take((uint32_t)__builtin_amdgcn_readfirstlane((int)g_new));
+        if (g < win_base || g >= win_base + part_wins) break;  // another part (or past the item)
       }
     }
     // ---- out of work: stay available for the others' compactions until everybody is done
@@ -1280,8 +1236,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
 __global__ __launch_bounds__(256)
 void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
                           const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_look,
-                          const uint32_t* __restrict__ t_meta, const char* __restrict__ look_base, const uint8_t* __restrict__ norms,
-                          DTermAux* __restrict__ out) {
+                          const uint32_t* __restrict__ t_meta, const char* __restrict__ look_base, DTermAux* __restrict__ out) {
   __shared__ uint32_t mn[13];
   __shared__ uint32_t mf;
   const uint32_t t = blockIdx.x;
@@ -1322,58 +1277,12 @@ void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __
     a.pad = 0;
     a.esc_max_freq = mf;
     a.pad2 = 0;
-    a.norms = norms;   // (the field's norm bytes: what a freq map's lookups read next to it)
-    a.pad3 = 0;
     out[t] = a;
   }
 }
 
-// term_map_kernel: the CODE MAPS of the group's densest terms (plan.h: kLookMap): per doc of the segment one 16-bit word --
-// the score code of the doc's posting, 0 = none.  Grid: (chunks, terms with a map: `which`); the maps were zeroed.  Runs on the
-// two-column form, before liveDocs are folded into the codes.
-__global__ __launch_bounds__(256)
-void term_map_kernel(const uint32_t* __restrict__ docids, const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
-                     const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_look, const uint32_t* __restrict__ which,
-                     char* __restrict__ look_base) {
-  const uint32_t t = which[blockIdx.y];
-  const uint64_t st = t_start[t];
-  const uint32_t n = t_count[t];
-  uint16_t* const m = (uint16_t*)(look_base + t_look[t]);
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-    const uint32_t c = fnorm[st + p];
-    uint32_t v;
-    if (c >> 31) {
-      const uint32_t f = (c >> 8) & 0x3FFFFFu;
-      v = f <= 126u ? (0x8000u | (f << 8) | (c & 255u)) : kLookMapEscape;
-    } else {
-      v = (c >> 2) & 0x7FFu;   // (freq << 7) | norm byte
-    }
-    m[docids[st + p]] = (uint16_t)v;
-  }
-}
-
-// term_nibble_kernel: FREQ MAPS (plan.h: kLookNibble): 4 bits per doc = the term's freq there (15: fifteen or more).  Same grid;
-// the maps were zeroed; eight docs share a word, hence the atomic.
-__global__ __launch_bounds__(256)
-void term_nibble_kernel(const uint32_t* __restrict__ docids, const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
-                        const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_look, const uint32_t* __restrict__ which,
-                        char* __restrict__ look_base) {
-  const uint32_t t = which[blockIdx.y];
-  const uint64_t st = t_start[t];
-  const uint32_t n = t_count[t];
-  uint32_t* const m = (uint32_t*)(look_base + t_look[t]);
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-    const uint32_t c = fnorm[st + p];
-    const uint32_t f = (c >> 31) ? ((c >> 8) & 0x3FFFFFu) : ((c >> 9) & 15u);
-    const uint32_t d = docids[st + p];
-    atomicOr(&m[d >> 3], (f < 15u ? f : 15u) << ((d & 7u) << 2));
-  }
-}
-
 // term_bits_kernel: MEMBERSHIP + RANK RECORDS (plan.h: kLookBits): per 32 docs {doc bits, postings of the term before the
-// block}.  Same grid; the records were zeroed.  Postings are ascending in docid, so the first posting of a block is the one
+// block}.  Grid: (chunks, terms with records: `which`); the records were zeroed.  Postings are ascending in docid, so the first posting of a block is the one
 // whose predecessor lies in an earlier block: it records its index.
 __global__ __launch_bounds__(256)
 void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ t_start, const uint32_t* __restrict__ t_count,
@@ -1446,26 +1355,19 @@ void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int sha
 }
 
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
-                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, const uint8_t* norms, uint32_t n_terms, DTermAux* out) {
+                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, uint32_t n_terms, DTermAux* out) {
   if (n_terms == 0) return;
-  hipLaunchKernelGGL(term_frontier_kernel, dim3(n_terms), dim3(256), 0, stream, fnorm, t_start, t_count, t_look, t_meta, (const char*)look_base, norms, out);
+  hipLaunchKernelGGL(term_frontier_kernel, dim3(n_terms), dim3(256), 0, stream, fnorm, t_start, t_count, t_look, t_meta, (const char*)look_base, out);
 }
 
-// kind: kLookMap / kLookNibble / kLookBits -- the doc-indexed structures, written posting by posting
-void launch_term_doc_maps(hipStream_t stream, uint32_t kind, const uint32_t* docids, const uint32_t* fnorm, const uint64_t* t_start,
-                          const uint32_t* t_count, const uint64_t* t_look, const uint32_t* which, uint32_t n_which, uint32_t max_count,
-                          void* look_base) {
+void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
+                      const uint32_t* which, uint32_t n_which, uint32_t max_count, void* look_base) {
   if (n_which == 0) return;
   uint32_t chunks = (max_count + 256u * 16u - 1u) / (256u * 16u);
   chunks = chunks < 1u ? 1u : (chunks > 1024u ? 1024u : chunks);
   for (uint32_t off = 0; off < n_which; off += 65535u) {   // (gridDim.y holds 65535 at most)
     const uint32_t n = n_which - off < 65535u ? n_which - off : 65535u;
-    if (kind == kLookMap)
-      hipLaunchKernelGGL(term_map_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, fnorm, t_start, t_count, t_look, which + off, (char*)look_base);
-    else if (kind == kLookNibble)
-      hipLaunchKernelGGL(term_nibble_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, fnorm, t_start, t_count, t_look, which + off, (char*)look_base);
-    else
-      hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, t_start, t_count, t_look, which + off, (char*)look_base);
+    hipLaunchKernelGGL(term_bits_kernel, dim3(chunks, n), dim3(256), 0, stream, docids, t_start, t_count, t_look, which + off, (char*)look_base);
   }
 }
 

@@ -101,31 +101,26 @@ static_assert(sizeof(DQExpand) == 16, "DQExpand layout");
 // What the MaxScore route (maxscore.hip) knows about a term besides its columns (one record per term of a segment,
 // written at seal): the term's impact frontier -- per freq the smallest norm byte it occurs with -- from which the kernel
 // takes the term's exact maximum score under the query's statistics (the role of Lucene's competitive (freq, norm) impacts,
-// SURVEY 8a row a5) -- and a doc -> posting LOOKUP structure for the walk's later clauses.  A lookup round costs its
-// SLOWEST doc's chain of dependent gathers (a wave follows up to 512 docs at once), so what matters is the number of
-// dependent gathers EVERY lookup of the kind is sure to end within:
-//   kLookMap   : a CODE MAP, one 16-bit word per doc of the segment -- the doc's score code under this term, 0 = the doc lacks
-//                the term.  ONE gather answers "is it there, and what does it add".  2 B per doc.
-//                Word: bit 15 clear: (freq << 7) | norm byte, freq <= kTabMaxFreq, norm < kTabNorms (x 4 = the table offset);
-//                bit 15 set: 0x8000 | freq << 8 | norm byte for freq <= 126; 0xFFFF: freq > 126 (searched in the postings).
-//   kLookNibble: a FREQ MAP, 4 bits per doc -- the term's freq in the doc (1 .. 14; 0: the doc lacks the term; 15: a larger
-//                freq, searched in the postings); the doc's norm byte is one more gather of the same round (the field's norm
-//                bytes, 1 B per doc, shared by all terms).  ONE round of gathers, 0.5 B per doc.
-//   kLookBits  : MEMBERSHIP + RANK RECORDS (rounds 2-4), per 32 docs {doc bits, postings of the term before the block}: whether
-//                the doc is there and where its posting is; its score code is a second, dependent gather.  0.25 B per doc.
+// SURVEY 8a row a5) -- and a doc -> posting LOOKUP structure for the walk's later clauses:
+//   kLookBits  : MEMBERSHIP + RANK RECORDS, per 32 docs {doc bits, postings of the term before the block}: whether the doc is
+//                there and where its posting is; its score code is a second, dependent gather.  0.25 B per doc -- 16 KB per
+//                65 536-doc window, and 2.5 MB for a whole 10 M-doc segment: the records of the terms that hundreds of a
+//                batch's queries share stay in L2 / the Infinity Cache.
 //   kLookCells : LOOKUP CELLS, one posting offset per 2^look_shift docs with look_shift chosen so that a cell holds
 //                0.5 - 1 posting on average (4 - 8 B per POSTING): a search in the doc's cell, usually over no posting or one.
-//                Gathers: cells, then probes until the slowest doc of the round is done (2 - 3), the code rides with the probe.
 //   kLookNone  : the doc is searched for in its cell of the tile-granular table DTerm.cell_off (~4 - 8 postings per cell).
 // Which term gets what: segment.cpp: build_term_aux (the segment's lookup budget, nrtgpu_config.lookup_budget_pct).
+// Measured and dropped (round 5, profiles/r05_look_policy_matrix.log; kernel ms per 1024 C3 queries, same box): structures that
+// answer in ONE gather instead of two -- a 16-bit code map per doc (2 B per doc) 2.97, a 4-bit freq map + the field's norm bytes
+// (0.5 B per doc) 3.56 -- against 2.11 for the records: what a lookup costs is decided by how much of the structure the caches
+// hold (a map of a frequent term is 8x / 2x the records plus nothing saved on the absent docs, the common answer), not by the
+// number of dependent gathers.  No structure at all: 6.72; lookup cells for every term: 3.20.
 // Deleted docs need no care here: a doc whose postings were re-coded to score 0 (apply_live_kernel) never survives the stream
 // phase of the walk, so it is never looked up.
-constexpr uint32_t kLookNone = 0, kLookMap = 1, kLookCells = 2, kLookNibble = 3, kLookBits = 4;
-constexpr uint32_t kLookMapEscape = 0xFFFFu;
+constexpr uint32_t kLookNone = 0, kLookBits = 1, kLookCells = 2;
 struct alignas(16) DTermAux {
-  const void* look;        // the code map (uint16_t[max_doc + pad]) / freq map (uint32_t[max_doc / 8 + pad]) / records
-                           // (uint32_t[2][max_doc / 32 + pad]) / lookup cells (uint32_t[cells + 1], offsets relative to the
-                           // term's first posting); nullptr: kLookNone
+  const void* look;        // the records (uint32_t[2][max_doc / 32 + pad]) / the lookup cells (uint32_t[cells + 1], offsets
+                           // relative to the term's first posting); nullptr: kLookNone
   uint8_t  min_norm[12];   // postings a score table can serve (freq f = 1..12, norm byte < 128): smallest norm byte
                            // seen with freq f at [f - 1]; 0xFF = no such posting
   uint8_t  esc_min_norm;   // the other postings (freq > 12 or norm byte >= 128): smallest norm byte ...
@@ -134,10 +129,8 @@ struct alignas(16) DTermAux {
   uint8_t  pad;
   uint32_t esc_max_freq;   // ... and largest freq among them; 0 = none
   uint32_t pad2;
-  const uint8_t* norms;    // kLookNibble: the norm bytes of the term's field (nullptr: norms omitted, every doc's norm byte is 1)
-  uint64_t pad3;
 };
-static_assert(sizeof(DTermAux) == 48, "DTermAux layout");
+static_assert(sizeof(DTermAux) == 32, "DTermAux layout");
 
 // Workgroup shape of the MaxScore route: 12 autonomous waves (168 VGPRs each); a wave owns a window of kMsWinTiles
 // sub-tiles at a time (its docs' "already evaluated" bits: kMsWinDocs / 8 bytes of LDS).
@@ -308,7 +301,10 @@ struct MsArgs {
   uint64_t* item_hits;           // ... and the hits counted there
   uint64_t* item_prof;           // instrumented kernel: 16 counters per output slot, else nullptr
   const uint32_t* q_wins;        // per query: the doc windows of all its items (speculation: the denominator of "how much have I seen")
-  uint32_t k_stride, pad;
+  uint32_t k_stride;
+  uint32_t scatter;              // != 0: an item's doc windows are handed out in a SCATTERED order (maxscore.hip): whatever a workgroup
+                                 // has walked so far is spread over the item's docs like a sample -- what the speculative thresholds
+                                 // assume -- also where the docid order follows time or a sort key
   DHelp help;
 };
 

@@ -491,7 +491,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   for (int qi = 0; qi < n_queries; ++qi)  // lowest key with that score: a doc scoring exactly the bound still passes
     hp.theta_init[(size_t)qi] = queries[qi].min_competitive_score > 0.0f ? pack_key(queries[qi].min_competitive_score, 0xFFFFFFFFu) : 0ull;
 
-  static const bool plan_trace = getenv("NRTGPU_PLAN_TRACE") != nullptr;  // debug aid: phase times on stderr
+  static const bool plan_trace = dev_env_int("NRTGPU_PLAN_TRACE", 0) != 0;  // debug aid: phase times on stderr
   const double tp0 = plan_trace ? now_ms() : 0.0;
   // pass 1: resolve terms per (query, segment), densest term first; remember posting counts.
   // Queries are independent here, so the batch is cut into contiguous chunks resolved by
@@ -744,7 +744,7 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
     // interleaved (profiles/r04_helpers_v1_ab.log): the two-clause key is SLOWER than all postings -- 3.00 vs 2.85 ms per 1024 C3
     // queries without helper workgroups, 2.62 vs 2.51 with them.  The default is all postings again; NRTGPU_MS_LPT=1 keeps the
     // two-clause key for A/B.  Results do not depend on the launch order (an item's output slot is assigned after the sort).
-    static const bool ms_lpt = getenv("NRTGPU_MS_LPT") != nullptr && atoi(getenv("NRTGPU_MS_LPT")) != 0;
+    static const bool ms_lpt = dev_env_int("NRTGPU_MS_LPT", 0) != 0;
     if (ms_lpt)
       for (Pending& a : pend)
         if (on_ms_kernel(a.query) && q_costs[(size_t)a.query] > 0)   // an item's share of its query's key
@@ -767,8 +767,8 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // NRTGPU_MS_FINE_ITEMS (default 32; 0: none; profiles/r04_fine_windows_ab.log).
   std::vector<uint8_t> q_fine((size_t)n_queries, 0);
   {
-    static const int env_fine = getenv("NRTGPU_MS_FINE_ITEMS") ? atoi(getenv("NRTGPU_MS_FINE_ITEMS")) : 32;
-    static const int env_shift = getenv("NRTGPU_MS_FINE_SHIFT") ? std::min(std::max(atoi(getenv("NRTGPU_MS_FINE_SHIFT")), 1), 3) : 2;
+    static const int env_fine = (int)dev_env_int("NRTGPU_MS_FINE_ITEMS", 32);
+    static const int env_shift = std::min(std::max((int)dev_env_int("NRTGPU_MS_FINE_SHIFT", 2), 1), 3);
     if (env_fine > 0 && hp.n_ms_items >= 64) {
       std::vector<std::pair<int64_t, int32_t>> by_key;
       for (int qi = 0; qi < n_queries; ++qi)

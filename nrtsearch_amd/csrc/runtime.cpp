@@ -275,6 +275,7 @@ extern "C" int nrtgpu_get_stats(nrtgpu_ctx* ctx, nrtgpu_stats* out) {
   out->spec_queries = ctx->spec_queries.load(std::memory_order_relaxed);
   out->spec_reruns = ctx->spec_reruns.load(std::memory_order_relaxed);
   out->spec_disabled = ctx->spec_off.load(std::memory_order_relaxed);
+  out->spec_scattered = ctx->spec_scattered.load(std::memory_order_relaxed);
   return NRTGPU_OK;
 }
 extern "C" void nrtgpu_reset_stats(nrtgpu_ctx* ctx) {

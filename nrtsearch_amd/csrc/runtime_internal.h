@@ -46,10 +46,9 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
 void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int shapes, const MsArgs& args, const MsArgs* args_d);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
-                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, const uint8_t* norms, uint32_t n_terms, DTermAux* out);
-void launch_term_doc_maps(hipStream_t stream, uint32_t kind, const uint32_t* docids, const uint32_t* fnorm, const uint64_t* t_start,
-                          const uint32_t* t_count, const uint64_t* t_look, const uint32_t* which, uint32_t n_which, uint32_t max_count,
-                          void* look_base);
+                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, uint32_t n_terms, DTermAux* out);
+void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
+                      const uint32_t* which, uint32_t n_which, uint32_t max_count, void* look_base);
 void launch_term_cells(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
                        const uint32_t* t_meta, const uint32_t* which, uint32_t n_which, uint32_t max_cells, uint32_t max_doc, void* look_base);
 void launch_expand_terms(hipStream_t stream, const DQExpand* qx, const DQTerm* qterms, const uint32_t* out_begin, uint32_t n_queries,
@@ -209,7 +208,7 @@ struct TermGroup {
   DTermAux* d_aux = nullptr;     // MaxScore route: one record per term of the group (impact frontier, lookup structure), seal
   char* d_look = nullptr;        // the lookup structures of the group's terms (plan.h: kLookMap / kLookCells), one buffer
   uint64_t look_bytes = 0;
-  uint32_t n_look[5] = {0, 0, 0, 0, 0};   // terms per lookup kind (plan.h: kLook*; diagnostics)
+  uint32_t n_look[3] = {0, 0, 0};   // terms per lookup kind (plan.h: kLook*; diagnostics)
   uint32_t n_terms = 0;
   std::vector<uint64_t> h_start;  // per term of the group (add order): first posting, postings -- kept until the seal
   std::vector<uint32_t> h_count;
@@ -472,9 +471,11 @@ struct nrtgpu_ctx {
   int32_t co_linger_us = 150;
   // speculative thresholds (plan.h: kHitsSpecInvalid; nrtgpu_debug_spec_counters): queries run under speculation, queries whose guess
   // failed and were run again, and the switch the library throws itself when too many fail (docs not spread like a sample)
-  std::atomic<int64_t> spec_queries{0}, spec_reruns{0};
-  std::atomic<int> spec_off{0};
-  std::atomic<int> spec_z16{getenv("NRTGPU_MS_SPEC_Z") ? (int)(atof(getenv("NRTGPU_MS_SPEC_Z")) * 16.0 + 0.5) : 5 * 16};   // the guess's margin x 16 (nrtgpu_set_speculation)
+  std::atomic<int64_t> spec_queries{0}, spec_reruns{0};   // (sums over the context's leaf sets since nrtgpu_set_speculation: nrtgpu_stats)
+  std::atomic<int> spec_off{0};                            // ... 1 once SOME leaf set has had its speculation switched off
+  std::atomic<int> spec_scattered{0};                      // ... 1 once SOME leaf set has been moved to the scattered window order
+  std::atomic<uint64_t> spec_epoch{1};                     // nrtgpu_set_speculation calls (the leaf sets' verdicts start over)
+  std::atomic<int> spec_z16{5 * 16};   // the guess's margin x 16 (nrtgpu_set_speculation)
   std::atomic<int64_t> live_segments{0};   // segment handles (uploads and forks) that have not been freed yet (nrtgpu_debug_live_segments)
   std::atomic<int> co_hold{0};                          // nrtgpu_debug_hold_coalescers: no leader (of either coalescer) leaves with less than a full batch / panel
   // the same for exact vector searches (nrtgpu_knn_exact_coalesced, vectors.cpp)
@@ -558,6 +559,14 @@ struct LeafSetCache {
   // front cache and take no lock and no reference count on a hit (four threads bouncing the stripes' lock words cost
   // more than the lookups themselves).
   uint64_t id = 0;   // unique per cache object: tags the threads' front-cache entries
+  // Speculative thresholds (plan.h: kHitsSpecInvalid) are judged PER LEAF SET: the queries run under them over these leaves, the
+  // ones whose guess failed and were run again, and the switch the library throws for this leaf set when too many fail (an
+  // index whose docid order defeats the estimate must not cost the context's other indexes their speculation; a refresh brings
+  // a new leaf set and a fresh verdict).  spec_epoch: the context's nrtgpu_set_speculation count these numbers belong to.
+  std::atomic<int64_t> spec_queries{0}, spec_reruns{0};
+  std::atomic<int> spec_scattered{0};   // the leaf set's windows are walked in the scattered order (maxscore.hip): the second chance
+  std::atomic<int> spec_off{0};
+  std::atomic<uint64_t> spec_epoch{0};
   const TermLeaves* get(const nrtgpu_seg* const* segs, int32_t n_segs, int32_t field, int64_t hash);
   void get_many(const nrtgpu_seg* const* segs, int32_t n_segs, const Key* keys, size_t n, const TermLeaves** out);
   size_t entries();

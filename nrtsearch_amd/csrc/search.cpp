@@ -4,18 +4,61 @@
 
 
 // Speculative thresholds of the MaxScore route (plan.h: kHitsSpecInvalid): the guess's safety margin in standard deviations x 16
-// (nrtgpu_set_speculation; a context starts with NRTGPU_MS_SPEC_Z, default 5; 0: no speculation).  Measured on C3
+// (nrtgpu_set_speculation; a context starts with 5; 0: no speculation).  Measured on C3
 // (profiles/r04_speculation_ab.log): margin 6 / 4 / 3 -> kernel 1.94 / 1.92 / (1.9) ms against 2.29 without, 0 / 0 / 108 of
 // 122 880 queries run again.
 static uint32_t spec_margin16(const nrtgpu_ctx* ctx) { return (uint32_t)std::max(ctx->spec_z16.load(std::memory_order_relaxed), 0); }
-static bool speculating(const nrtgpu_ctx* ctx) { return ctx && spec_margin16(ctx) != 0u && ctx->spec_off.load(std::memory_order_relaxed) == 0; }
-// A call that ran under speculation has come back: count it, and throw the library's own switch when too many guesses fail -- docs
-// that are not spread over the index like a random sample (sorted by a field the score follows) make them fail wholesale, and
+// The verdict on speculation belongs to the LEAF SET (runtime_internal.h: LeafSetCache.spec_*), in two steps.  A leaf set starts
+// with its windows walked in docid order (the cheapest: a wave stays in a part for several windows).  When more than 2 % of
+// >= 2048 queries had to be run again -- docids that are no sample of the index: an index sorted by something the score follows,
+// time-ordered vocabulary -- it is given a second chance in the SCATTERED window order (maxscore.hip: any prefix of the windows
+// taken is spread over the item's docs; +8 % kernel time on independently drawn docids, measured), counters reset; when that
+// fails too, speculation is switched off for this leaf set alone.  Measured at C3's size (profiles/r05_scatter_*.log): an
+// index numbered by doc length -- docid order 2043 of 2048 queries run again, scattered 0.5 % and the kernel at 1.10 ms
+// against 2.34 without speculation; terms in docid bursts -- 17 % run again in docid order, 5 % scattered (the bursts'
+// variance is not a sample's): off.
+static void spec_sync_epoch(const nrtgpu_ctx* ctx, LeafSetCache* lsc) {
+  const uint64_t e = ctx->spec_epoch.load(std::memory_order_relaxed);
+  if (lsc->spec_epoch.exchange(e, std::memory_order_relaxed) != e) {   // nrtgpu_set_speculation since: start over
+    lsc->spec_queries.store(0, std::memory_order_relaxed);
+    lsc->spec_reruns.store(0, std::memory_order_relaxed);
+    lsc->spec_scattered.store(0, std::memory_order_relaxed);
+    lsc->spec_off.store(0, std::memory_order_relaxed);
+  }
+}
+static bool speculating(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs) {
+  if (!ctx || spec_margin16(ctx) == 0u || !segs || n_segs <= 0) return false;
+  for (int32_t i = 0; i < n_segs; ++i)
+    if (!segs[i]) return false;   // (the call fails with its own message)
+  std::shared_ptr<LeafSetCache> lsc = leaf_set_cache(ctx, segs, n_segs);
+  spec_sync_epoch(ctx, lsc.get());
+  return lsc->spec_off.load(std::memory_order_relaxed) == 0;
+}
+// A call that ran under speculation has come back: count it, and throw the leaf set's switch when too many guesses fail --
 // every failure is a second pass.
-static void note_speculation(nrtgpu_ctx* ctx, int64_t n_queries, int64_t n_rerun) {
-  const int64_t seen = ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
-  const int64_t failed = ctx->spec_reruns.fetch_add(n_rerun, std::memory_order_relaxed) + n_rerun;
-  if (seen >= 2048 && failed * 50 > seen) ctx->spec_off.store(1, std::memory_order_relaxed);
+static void note_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int64_t n_queries, int64_t n_rerun) {
+  std::shared_ptr<LeafSetCache> lsc = leaf_set_cache(ctx, segs, n_segs);
+  spec_sync_epoch(ctx, lsc.get());
+  const int64_t seen = lsc->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
+  const int64_t failed = lsc->spec_reruns.fetch_add(n_rerun, std::memory_order_relaxed) + n_rerun;
+  ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed);
+  ctx->spec_reruns.fetch_add(n_rerun, std::memory_order_relaxed);
+  if (seen >= 2048 && failed * 50 > seen) {
+    if (lsc->spec_scattered.exchange(1, std::memory_order_relaxed) == 0) {   // first: the scattered window order, a fresh count
+      lsc->spec_queries.store(0, std::memory_order_relaxed);
+      lsc->spec_reruns.store(0, std::memory_order_relaxed);
+      ctx->spec_scattered.store(1, std::memory_order_relaxed);
+    } else {
+      lsc->spec_off.store(1, std::memory_order_relaxed);
+      ctx->spec_off.store(1, std::memory_order_relaxed);
+    }
+  }
+}
+
+// NRTGPU_MS_PERSISTENT=0 (development build): one workgroup per item + helper workgroups behind them (A/B)
+static bool ms_persistent() {
+  static const bool v = dev_env_int("NRTGPU_MS_PERSISTENT", 1) != 0;
+  return v;
 }
 
 struct DeviceRun {
@@ -95,8 +138,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   // MaxScore route: helper workgroups behind the items (plan.h: DHelp; maxscore.hip) -- each with an output slot of its own
   // behind the items' slots.  NRTGPU_MS_HELPERS: how many (default 4 per CU; 0: none), NRTGPU_MS_HELP_MIN: an item with fewer
   // unassigned windows is not joined.
-  static const int env_helpers = getenv("NRTGPU_MS_HELPERS") ? atoi(getenv("NRTGPU_MS_HELPERS")) : -1;
-  static const int env_help_min = getenv("NRTGPU_MS_HELP_MIN") ? atoi(getenv("NRTGPU_MS_HELP_MIN")) : 16;
+  static const int env_helpers = (int)dev_env_int("NRTGPU_MS_HELPERS", -1);
+  static const int env_help_min = (int)dev_env_int("NRTGPU_MS_HELP_MIN", 16);
   const size_t n_help = hp.n_ms_items == 0 ? 0 : (size_t)(env_helpers >= 0 ? env_helpers : 4 * std::max(ctx->n_cus, 1));
   const size_t n_slots = n_items + n_help;
   Carver wc;
@@ -117,7 +160,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   // speculative thresholds (plan.h: kHitsSpecInvalid): only where the caller can run a query again (allow_spec: the batch and the
   // hybrid entry), never next to the cross-GPU bound exchange (its quantile uses the selection's second rank)
   const uint32_t spec_z16 = spec_margin16(ctx);
-  const bool spec = allow_spec && spec_z16 != 0u && hp.n_ms_items != 0 && !use_xch && ctx->spec_off.load(std::memory_order_relaxed) == 0;
+  const bool spec = allow_spec && spec_z16 != 0u && hp.n_ms_items != 0 && !use_xch && hp.lsc && hp.lsc->spec_off.load(std::memory_order_relaxed) == 0;
   const size_t o_spec = wc.take(spec ? (size_t)n_queries * 8 : 0);
   const size_t zero_bytes = wc.off - o_ssum;
   // kernel variant: clause counting (8), doc-set masks somewhere in the batch (9), else what the flags ask for
@@ -144,7 +187,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     // whose expected time left exceeds alpha x what is left of the launch.  Measured at 8 spare CUs (same log): alpha 0 2.48 ms
     // per step, 1.0 2.50, 1.5 2.42, 2.0 2.42, 3.0 2.46 -- the estimate of what is left runs high early in the launch (the
     // heavy items lead), so the bar sits above 1: 1.5 is the default.
-    static const int env_help_alpha = getenv("NRTGPU_MS_HELP_ALPHA") ? atoi(getenv("NRTGPU_MS_HELP_ALPHA")) : 24;
+    static const int env_help_alpha = (int)dev_env_int("NRTGPU_MS_HELP_ALPHA", 24);
     uint64_t wins = 0;
     for (size_t i = 0; i < hp.n_ms_items; ++i) wins += hp.items[i].flags >> 8;
     help.total_wins = (uint32_t)std::min<uint64_t>(wins, 0xFFFFFFFFull);
@@ -155,23 +198,22 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     // behind it instead of overlapping it.
     // Measured (profiles/r04_persistent_spare_ab.log, 1024 C3 queries per step): 0 spare CUs 2.85 ms per step (kernel 2.34), 4: 2.72,
     // 8: 2.50 (kernel 2.39), 16: 2.56, 32: 2.70 -- eight CUs of 256 is the default.
-    static const int env_spare = getenv("NRTGPU_MS_SPARE_CUS") ? atoi(getenv("NRTGPU_MS_SPARE_CUS")) : 8;
+    static const int env_spare = (int)dev_env_int("NRTGPU_MS_SPARE_CUS", 8);
     help.n_cus = (uint32_t)std::max(ctx->n_cus - std::max(env_spare, 0), 1);
     // NRTGPU_MS_PERSISTENT=0: one workgroup per item + helper workgroups behind them (A/B)
-    static const bool env_persistent = getenv("NRTGPU_MS_PERSISTENT") == nullptr || atoi(getenv("NRTGPU_MS_PERSISTENT")) != 0;
-    help.persistent = env_persistent ? 1u : 0u;
+    help.persistent = ms_persistent() ? 1u : 0u;
   }
   help.n_own = (uint32_t)hp.n_ms_items;
   help.n_help = (uint32_t)n_help;
   help.slot_base = (uint32_t)n_items;
-  static const bool env_help_greedy = getenv("NRTGPU_MS_HELP_GREEDY") != nullptr && atoi(getenv("NRTGPU_MS_HELP_GREEDY")) != 0;
+  static const bool env_help_greedy = dev_env_int("NRTGPU_MS_HELP_GREEDY", 0) != 0;
   help.min_rem = (uint32_t)std::min(std::max(env_help_min, 1), 0xFFFF) | (env_help_greedy ? 1u << 16 : 0u);
   help.walls = profile ? (unsigned long long*)(wb + o_walls) : nullptr;
   help.spec_g = spec ? (unsigned long long*)(wb + o_spec) : nullptr;
   help.spec_z16 = spec ? spec_z16 : 0u;
   {   // NRTGPU_MS_SPEC_FIRST / NRTGPU_MS_SPEC_GROW (x 16): when a workgroup's estimates are due (plan.h: DHelp.spec_sched)
-    static const int env_first = getenv("NRTGPU_MS_SPEC_FIRST") ? atoi(getenv("NRTGPU_MS_SPEC_FIRST")) : 2 * kMsWaves;
-    static const int env_grow = getenv("NRTGPU_MS_SPEC_GROW") ? atoi(getenv("NRTGPU_MS_SPEC_GROW")) : 32;
+    static const int env_first = (int)dev_env_int("NRTGPU_MS_SPEC_FIRST", 2 * kMsWaves);
+    static const int env_grow = (int)dev_env_int("NRTGPU_MS_SPEC_GROW", 32);
     help.spec_sched = (uint32_t)std::min(std::max(env_first, 1), 255) | ((uint32_t)std::min(std::max(env_grow, 17), 255) << 8);
   }
   MsArgs ms_args{};   // (the kernel reads the record from the plan: maxscore.hip)
@@ -189,6 +231,10 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   ms_args.item_hits = (uint64_t*)(wb + o_ihits);
   ms_args.item_prof = profile ? (uint64_t*)(wb + o_prof) : nullptr;
   ms_args.q_wins = (const uint32_t*)(db + o_qwins);
+  {   // the leaf set's window order (note_speculation); NRTGPU_MS_SCATTER = 0 / 1 (development build): forced, A/B
+    const long forced = dev_env_int("NRTGPU_MS_SCATTER", -1);
+    ms_args.scatter = forced >= 0 ? (forced != 0 ? 1u : 0u) : ((spec && hp.lsc->spec_scattered.load(std::memory_order_relaxed) != 0) ? 1u : 0u);
+  }
   ms_args.k_stride = hp.k_stride;
   ms_args.help = help;
   memcpy(hb + o_help, &ms_args, sizeof(ms_args));
@@ -206,7 +252,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   // (experiment, off unless NRTGPU_OVERLAP_SCORERS=1: no turn between consecutive calls' scorers -- nothing but the turn itself
   //  orders them: workspaces are per slot, term tables reach the device before they become visible -- so that the next batch's
   //  items fill the tail of this one's launch; needs its GPU run: the merge then queues behind foreign items)
-  static const bool overlap_scorers = getenv("NRTGPU_OVERLAP_SCORERS") != nullptr && atoi(getenv("NRTGPU_OVERLAP_SCORERS")) != 0;
+  static const bool overlap_scorers = dev_env_int("NRTGPU_OVERLAP_SCORERS", 0) != 0;
   if (ctx->last_turn && !overlap_scorers) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
   if (ctx->last_knn_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_knn_turn, 0));   // (vector searches do not queue behind each other, the scorers queue behind them)
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
@@ -228,7 +274,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   // (closed loop at 64 callers: p99 1.4 -> 4.0 ms) -- which the spare CUs have changed: measured, same box
   // (profiles/r04_turn_before_merge_ab.log), 2.413 -> 2.357 ms per 1024-query step, batch p50 4.80 -> 4.69 ms, closed loop at
   // 64 / 512 callers p99 1.20 / 2.61 -> 1.20 / 2.55 ms.  NRTGPU_TURN_BEFORE_MERGE=0: the old turn (A/B).
-  static const bool turn_before_merge = getenv("NRTGPU_TURN_BEFORE_MERGE") == nullptr || atoi(getenv("NRTGPU_TURN_BEFORE_MERGE")) != 0;
+  static const bool turn_before_merge = dev_env_int("NRTGPU_TURN_BEFORE_MERGE", 1) != 0;
   if (turn_before_merge) {
     HIP_TRY(hipEventRecord(slot->ev_turn, st));
     ctx->last_turn = slot->ev_turn;
@@ -358,7 +404,7 @@ static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
   const size_t o_k = oc.take(kb), o_c = oc.take(cb), o_h = oc.take(hb);
   if (int rc = slot->h_out.reserve(oc.off)) return rc;
   char* ho = (char*)slot->h_out.p;
-  static const bool call_trace = getenv("NRTGPU_PLAN_TRACE") != nullptr;  // debug aid: phase times on stderr
+  static const bool call_trace = dev_env_int("NRTGPU_PLAN_TRACE", 0) != 0;  // debug aid: phase times on stderr
   const double tc0 = call_trace ? now_ms() : 0.0;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
@@ -414,7 +460,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   // or evict a mask they name), and the second pass ignores the thread's deadline: its work is the tail of a search that was
   // launched in time, and every untagged query of the call already holds its answer.
   std::vector<int32_t> rerun;
-  const bool spec = speculating(ctx);
+  const bool spec = speculating(ctx, segs, n_segs);
   if (!spec) return search_batch_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, out, nullptr);
   if (ctx && segs)
     for (int si = 0; si < n_segs; ++si)
@@ -423,7 +469,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   const int rc = search_batch_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, out, &rerun, true);
   if (rc != 0) return rc;
   const nrtgpu_diagnostics first = g_diag;
-  note_speculation(ctx, n_queries, (int64_t)rerun.size());
+  note_speculation(ctx, segs, n_segs, n_queries, (int64_t)rerun.size());
   if (rerun.empty()) return rc;
   std::vector<nrtgpu_bm25_query> rq(rerun.size());
   std::vector<nrtgpu_topdocs> ro(rerun.size());
@@ -456,6 +502,8 @@ extern "C" int nrtgpu_set_speculation(nrtgpu_ctx* ctx, float margin) {
   ctx->spec_queries.store(0, std::memory_order_relaxed);
   ctx->spec_reruns.store(0, std::memory_order_relaxed);
   ctx->spec_off.store(0, std::memory_order_relaxed);
+  ctx->spec_scattered.store(0, std::memory_order_relaxed);
+  ctx->spec_epoch.fetch_add(1, std::memory_order_relaxed);   // (every leaf set's verdict starts over: LeafSetCache.spec_epoch)
   return NRTGPU_OK;
 }
 
@@ -586,7 +634,7 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   // its recall set may lack docs -- is run again, first pass and tail, without speculation.
   // Both passes under one set of content locks, the second one without the thread's deadline: as nrtgpu_search_bm25_batch.
   std::vector<int32_t> rerun;
-  const bool spec = speculating(ctx);
+  const bool spec = speculating(ctx, segs, n_segs);
   if (!spec)
     return search_hybrid_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, field_id, sim, query_vectors, dim, boost, query_weight,
                               rescore_weight, window, out, nullptr);
@@ -597,7 +645,7 @@ extern "C" int nrtgpu_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* con
   const int rc = search_hybrid_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, field_id, sim, query_vectors, dim, boost, query_weight,
                                     rescore_weight, window, out, &rerun, true);
   if (rc != 0) return rc;
-  note_speculation(ctx, n_queries, (int64_t)rerun.size());
+  note_speculation(ctx, segs, n_segs, n_queries, (int64_t)rerun.size());
   if (rerun.empty()) return rc;
   std::vector<nrtgpu_bm25_query> rq(rerun.size());
   std::vector<nrtgpu_topdocs> ro(rerun.size());

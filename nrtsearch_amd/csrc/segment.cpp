@@ -134,9 +134,8 @@ extern "C" int nrtgpu_segment_add_terms(nrtgpu_seg* seg, int32_t field_id, int64
     const int64_t cnt = hi - lo;
     if (cnt > 0xFFFFFFFFll) return fail(NRTGPU_ERR_UNSUPPORTED, "term with more than 2^32 postings");
     uint32_t shift = 0;
-    static const int64_t budget_div = [] {   // (experiment knob: postings per cell aimed for; default below)
-      const char* e = getenv("NRTGPU_CELL_POSTINGS");
-      const int64_t v = e ? atoll(e) : 0;
+    static const int64_t budget_div = [] {   // (development build: postings per cell aimed for, NRTGPU_CELL_POSTINGS)
+      const int64_t v = dev_env_int("NRTGPU_CELL_POSTINGS", kCellPostings);
       return v >= 1 && v <= 64 ? v : (int64_t)kCellPostings;
     }();
     const uint64_t budget = std::max<int64_t>(1, cnt / budget_div);
@@ -285,14 +284,18 @@ static int fold_live_docs(nrtgpu_seg* seg);
 // first -- lookups go to a query's densest clauses, so that is the order of benefit per byte -- by the first rule of the POLICY
 // that applies to the term and whose structure still fits the budget:
 //   kind:N  the N largest terms of the upload group        kind@D  terms with a posting per D docs or more        kind  every term
-// kinds: map (2 B per doc), nib (0.5 B per doc), bits (0.25 B per doc), cells (4 - 8 B per posting).  Terms under
-// kLookMinPostings postings, and whatever no rule or no budget covers, are searched in their cell of the tile-granular table.
+// kinds: bits (records, 0.25 B per doc), cells (4 - 8 B per posting).  Terms under kLookMinPostings postings, and whatever no
+// rule or no budget covers, are searched in their cell of the tile-granular table.
 // The budget (nrtgpu_config.lookup_budget_pct, default kLookBudgetPct): lookup bytes <= that share of the upload group's
 // resident posting bytes (8 B per posting, 4 B under NRTGPU_FLAG_PACKED_POSTINGS).
-// Rounds 2-4 kept records ("bits") for "the 2048 largest terms" and no budget: 4.8 GB next to 0.7 GB of postings at C3.
+// Rounds 2-4 kept records for "the 2048 largest terms", no budget, and the coarse tile cells behind them: 5.1 GB of records
+// next to 0.6 GB of postings at C3's 10 M docs.  Measured in round 5 (profiles/r05_look_policy_budget_curve.log, same box,
+// kernel ms per 1024 C3 queries / resident GB): records for 2048 terms 2.11 / 5.73; records for the terms with a posting per
+// 128 docs + lookup cells 2.13 / 1.15; per 256 docs 2.12 / 1.43; per 1024 docs (budget 300 %) 2.14 / 2.49 -- with fine cells
+// behind them, records beyond the ~250 most frequent terms buy nothing.
 static const uint32_t kLookMinPostings = 64;
 static const int kLookBudgetPct = 150;
-static const char* const kLookPolicy = "map@32,cells";
+static const char* const kLookPolicy = "bits@256,cells";
 struct LookRule {
   uint32_t kind;
   int64_t rank_limit;   // < 0: none
@@ -310,9 +313,7 @@ static std::vector<LookRule> parse_look_policy(const char* text) {
     const size_t sep = item.find_first_of(":@");
     const std::string name = item.substr(0, sep);
     LookRule r{kLookNone, -1, -1};
-    if (name == "map") r.kind = kLookMap;
-    else if (name == "nib") r.kind = kLookNibble;
-    else if (name == "bits") r.kind = kLookBits;
+    if (name == "bits") r.kind = kLookBits;
     else if (name == "cells") r.kind = kLookCells;
     else continue;
     if (sep != std::string::npos) {
@@ -324,7 +325,7 @@ static std::vector<LookRule> parse_look_policy(const char* text) {
   }
   return out;
 }
-static int build_term_aux(nrtgpu_seg* seg, TermGroup& g, const uint8_t* d_norms) {
+static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   if (g.d_aux || g.n_terms == 0) return NRTGPU_OK;
   const size_t nt = g.n_terms;
   const uint32_t max_doc = (uint32_t)seg->max_doc;
@@ -334,7 +335,7 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g, const uint8_t* d_norms)
   const std::vector<LookRule> rules = parse_look_policy(dev_env_str("NRTGPU_LOOK_POLICY", kLookPolicy));
   std::vector<uint64_t> look((size_t)nt, ~0ull);   // byte offset of the term's structure inside the group's buffer
   std::vector<uint32_t> meta((size_t)nt, 0u);      // kind | log2 docs per cell << 8
-  std::vector<uint32_t> which[5];                  // per kind the terms that got it
+  std::vector<uint32_t> which[3];                  // per kind the terms that got it
   uint64_t look_bytes = 0;
   uint32_t max_count = 0, max_cells = 0;
   {
@@ -351,9 +352,7 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g, const uint8_t* d_norms)
         uint64_t cost = 0;
         uint32_t shift = 0;
         // (every structure: 16-byte aligned, entry 0 readable for idle slots, one entry of slack behind the last doc's)
-        if (r.kind == kLookMap) cost = (((uint64_t)max_doc * 2ull + 15ull) & ~15ull) + 16ull;
-        else if (r.kind == kLookNibble) cost = (((((uint64_t)max_doc + 7ull) / 8ull) * 4ull + 15ull) & ~15ull) + 16ull;
-        else if (r.kind == kLookBits) cost = (((((uint64_t)max_doc + 31ull) / 32ull + 1ull) * 8ull + 15ull) & ~15ull);
+        if (r.kind == kLookBits) cost = (((((uint64_t)max_doc + 31ull) / 32ull + 1ull) * 8ull + 15ull) & ~15ull);
         else {
           // cells of 2^shift docs, the largest power of two with at most one posting per cell on average
           while (shift < 31u && (cnt << (shift + 1u)) <= (uint64_t)max_doc) ++shift;
@@ -382,8 +381,8 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g, const uint8_t* d_norms)
     HIP_TRY(hipMemset(g.d_look, 0, (size_t)look_bytes + 64));
   }
   std::vector<uint32_t> flat;
-  size_t first_of[5] = {0, 0, 0, 0, 0};
-  for (uint32_t k = 1; k < 5; ++k) {
+  size_t first_of[3] = {0, 0, 0};
+  for (uint32_t k = 1; k < 3; ++k) {
     first_of[k] = flat.size();
     flat.insert(flat.end(), which[k].begin(), which[k].end());
   }
@@ -410,9 +409,8 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g, const uint8_t* d_norms)
   if (e == hipSuccess) e = hipMemcpy(d_meta, meta.data(), nt * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess && !flat.empty()) e = hipMemcpy(d_which, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_look, d_meta, g.d_look, d_norms, (uint32_t)nt, g.d_aux);
-    for (uint32_t k : {kLookMap, kLookNibble, kLookBits})
-      launch_term_doc_maps(nullptr, k, g.d_docids, g.d_fnorm, d_start, d_count, d_look, d_which + first_of[k], (uint32_t)which[k].size(), max_count, g.d_look);
+    launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_look, d_meta, g.d_look, (uint32_t)nt, g.d_aux);
+    launch_term_bits(nullptr, g.d_docids, d_start, d_count, d_look, d_which + first_of[kLookBits], (uint32_t)which[kLookBits].size(), max_count, g.d_look);
     launch_term_cells(nullptr, g.d_docids, d_start, d_count, d_look, d_meta, d_which + first_of[kLookCells], (uint32_t)which[kLookCells].size(), max_cells,
                       max_doc, g.d_look);
     e = hipGetLastError();
@@ -420,7 +418,7 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g, const uint8_t* d_norms)
   if (e == hipSuccess) e = hipDeviceSynchronize();
   free_tmp();
   if (e != hipSuccess) return fail(NRTGPU_ERR_HIP, "building the MaxScore lookup structures failed: %s", hipGetErrorString(e));
-  for (uint32_t k = 1; k < 5; ++k) g.n_look[k] = (uint32_t)which[k].size();
+  for (uint32_t k = 1; k < 3; ++k) g.n_look[k] = (uint32_t)which[k].size();
   g.h_start.clear();
   g.h_start.shrink_to_fit();
   g.h_count.clear();
@@ -525,7 +523,7 @@ extern "C" int nrtgpu_segment_seal(nrtgpu_seg* seg) {
   if (overflow) return fail(NRTGPU_ERR_UNSUPPORTED, "a term frequency >= 2^22 does not fit the packed freq|norm column");
   for (auto& kv : seg->fields)
     for (auto& g : kv.second.groups)
-      if (int rc2 = build_term_aux(seg, g, kv.second.d_norms)) return rc2;
+      if (int rc2 = build_term_aux(seg, g)) return rc2;
   if (seg->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS)   // (the seal-time builders above read the two-column form)
     for (auto& kv : seg->fields)
       for (auto& g : kv.second.groups)

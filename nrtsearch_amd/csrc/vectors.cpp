@@ -239,7 +239,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
     // One pass over the rows of every leaf.  nominate: the estimates' running top-k_int, theta tightening (knn_select_kernel
     // <false>); else theta stays what the certification left and every nomination is rescored into the answer (<true>).
     // (rows of the first round: every row takes a slot of the list and the first selection scans them all)
-    static const int64_t kFirstRound = []() { const char* e = getenv("NRTGPU_KNN_FIRST_ROUND"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 1024 && v <= (1 << 18) ? (v & ~15L) : (1 << 16)); }();
+    static const int64_t kFirstRound = []() { const long v = dev_env_int("NRTGPU_KNN_FIRST_ROUND", 0); return (int64_t)(v >= 1024 && v <= (1 << 18) ? (v & ~15L) : (1 << 16)); }();
     int64_t sketch_launches = 0;
     auto rows_pass = [&](bool nominate, int safe) -> int {   // (the fp32 rows: a launch per leaf and round)
       int64_t seen = 0, round = kFirstRound;

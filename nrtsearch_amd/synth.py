@@ -104,6 +104,67 @@ def term_postings(n_docs: int, rank: int, seed: int = 1234) -> Tuple[np.ndarray,
     return docids, freqs
 
 
+# ---- corpora whose docids are NOT independent draws --------------------------------------------------------------
+# SURVEY 8d's corpus draws every posting list uniformly over [0, N): a workgroup's doc windows are then a random sample of the
+# query's docs BY CONSTRUCTION, which is what the MaxScore route's speculative thresholds assume (maxscore.hip: ms_compact).  Real
+# Lucene docids are insertion-ordered: terms come in bursts (time-clustered vocabulary), and an index may be sorted by something
+# the score follows.  Two variants for that; statistics (df, doc lengths) keep the same profile:
+#   "clustered": the docid axis is cut into CLUSTER_EPOCHS epochs; a term's density in an epoch is p x a weight drawn from a
+#                heavy-tailed law (Gamma(0.35), mean 1, per term) -- a few epochs hold most of a term's postings.
+#   "sorted"   : the same postings as the i.i.d. corpus, but docs are numbered by length, shortest first (an index sorted by a
+#                field the BM25 score follows: a posting in a short doc scores more) -- scores fall along the docid axis.
+CLUSTER_EPOCHS = 96
+
+
+def term_postings_clustered(n_docs: int, rank: int, seed: int = 1234) -> Tuple[np.ndarray, np.ndarray]:
+    """Global (docids, freqs) of the term of Zipf rank `rank` in the "clustered" corpus: E[df] = N / (rank + 1) as in
+    term_postings, but the density follows a per-term burst profile over CLUSTER_EPOCHS epochs of the docid axis."""
+    p = 1.0 / (rank + 1.0)
+    rng = np.random.Generator(np.random.PCG64((seed * 7919) ^ (rank * 104729 + 17)))
+    wts = rng.gamma(0.35, 1.0 / 0.35, size=CLUSTER_EPOCHS)
+    wts *= CLUSTER_EPOCHS / wts.sum()                       # mean 1 over the epochs
+    dens = np.minimum(p * wts, 0.95)
+    edges = np.linspace(0, n_docs, CLUSTER_EPOCHS + 1).astype(np.int64)
+    parts = []
+    for e in range(CLUSTER_EPOCHS):
+        lo, hi = int(edges[e]), int(edges[e + 1])
+        pe = float(dens[e])
+        if hi <= lo or pe < 1e-9:   # (an epoch the term practically skips; also keeps the geometric draws inside int64)
+            continue
+        exp = (hi - lo) * pe
+        m = int(exp + 6.0 * np.sqrt(exp) + 16)
+        pos = np.cumsum(rng.geometric(pe, size=m).astype(np.int64)) - 1
+        while pos[-1] < hi - lo:  # practically never
+            pos = np.concatenate([pos, pos[-1] + np.cumsum(rng.geometric(pe, size=m).astype(np.int64))])
+        parts.append(lo + pos[pos < hi - lo])
+    docids = (np.concatenate(parts) if parts else np.zeros(0, np.int64)).astype(np.int32)
+    freqs = np.minimum(255, rng.geometric(0.55, size=len(docids))).astype(np.int32)
+    return docids, freqs
+
+
+def corpus_variant_arrays(n_docs: int, variant: str, seed: int = 1234):
+    """-> (doc lengths in docid order, postings(rank) -> (docids, freqs)) of a corpus variant: "iid" (SURVEY 8d), "clustered",
+    "sorted" (see above)."""
+    lens = doc_lengths(n_docs, seed)
+    if variant in ("", "iid"):
+        return lens, lambda r: term_postings(n_docs, r, seed)
+    if variant == "clustered":
+        return lens, lambda r: term_postings_clustered(n_docs, r, seed)
+    if variant == "sorted":
+        order = np.argsort(lens, kind="stable")              # new docid -> old docid, shortest doc first
+        new_of_old = np.empty(n_docs, dtype=np.int64)
+        new_of_old[order] = np.arange(n_docs, dtype=np.int64)
+
+        def postings(r):
+            d, f = term_postings(n_docs, r, seed)
+            nd = new_of_old[d]
+            o = np.argsort(nd, kind="stable")
+            return nd[o].astype(np.int32), f[o]
+
+        return lens[order], postings
+    raise ValueError(f"unknown corpus variant {variant!r}")
+
+
 def tiered_segment_sizes(n_docs: int, n_segments: int) -> List[int]:
     """Tiered-merge profile: N/2, N/4, ... with the remainder in the last."""
     if n_segments <= 1:
@@ -139,10 +200,11 @@ def build_corpus(
     n_segments: int = 1,
     delete_fraction: float = 0.0,
     seed: int = 1234,
+    variant: str = "iid",
 ) -> Corpus:
-    """Materialise the postings of `ranks` only (the query set's terms), split into segments."""
+    """Materialise the postings of `ranks` only (the query set's terms), split into segments.  variant: corpus_variant_arrays."""
     ranks = sorted(set(int(r) for r in ranks))
-    lens = doc_lengths(n_docs, seed)
+    lens, postings_of = corpus_variant_arrays(n_docs, variant, seed)
     norms_all = int_to_byte4(lens)
     sizes = tiered_segment_sizes(n_docs, n_segments)
     bases = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
@@ -152,7 +214,7 @@ def build_corpus(
     per_seg_counts: List[List[int]] = [[] for _ in sizes]
     doc_freq: Dict[int, int] = {}
     for r in ranks:
-        d, f = term_postings(n_docs, r, seed)
+        d, f = postings_of(r)
         doc_freq[r] = int(len(d))
         cuts = np.searchsorted(d, bases)
         for s in range(len(sizes)):

@@ -111,10 +111,12 @@ def shard_pieces(w: Workload, world: int, rank: int, layout: str = "index"):
     return sorted(pieces[rank])
 
 
-def build_shard_corpus(w: Workload, queries: np.ndarray, world: int = 1, rank: int = 0, seed: int = 1234, layout: str = "index"):
-    """Corpus restricted to this rank's leaves, with index-global statistics."""
+def build_shard_corpus(w: Workload, queries: np.ndarray, world: int = 1, rank: int = 0, seed: int = 1234, layout: str = "index",
+                       variant: str = "iid"):
+    """Corpus restricted to this rank's leaves, with index-global statistics.  variant: "iid" (every posting list an
+    independent uniform draw), "clustered" (terms in docid bursts), "sorted" (docs numbered by length) -- synth.corpus_variant_arrays."""
     ranks = sorted(set(int(r) for r in queries.reshape(-1)))
-    lens = synth.doc_lengths(w.n_docs, seed)
+    lens, postings_of = synth.corpus_variant_arrays(w.n_docs, variant, seed)
     norms_all = synth.int_to_byte4(lens)
     pieces = shard_pieces(w, world, rank, layout)
     sizes = [g for _, g in pieces]
@@ -124,7 +126,7 @@ def build_shard_corpus(w: Workload, queries: np.ndarray, world: int = 1, rank: i
     per_freqs: List[List[np.ndarray]] = [[] for _ in sizes]
     doc_freq = {}
     for r in ranks:
-        d, f = synth.term_postings(w.n_docs, r, seed)
+        d, f = postings_of(r)
         doc_freq[r] = int(len(d))
         lo_cut, hi_cut = np.searchsorted(d, bases), np.searchsorted(d, ends)
         for s in range(len(sizes)):

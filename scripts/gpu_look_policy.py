@@ -33,25 +33,33 @@ def main():
     ap.add_argument("--oracle-queries", type=int, default=4)
     ap.add_argument("--packed", action="store_true")
     ap.add_argument("--workload", default="C3")
+    ap.add_argument("--profile", action="store_true", help="instrumented kernels (development library): event counts per query")
+    ap.add_argument("--variant", default="iid", help="corpus variant: iid | clustered | sorted (synth.corpus_variant_arrays)")
     ap.add_argument("--configs", default="map@32,cells|150;bits:2048|100000;nib:2048|100000;map:2048|100000;cells|100000;|0",
-                    help="';'-separated policy|budget_pct (budget 0 = the library's default, -1 = none)")
+                    help="';'-separated policy|budget_pct[|ENV=VAL,...] (budget 0 = the library's default, -1 = none)")
     args = ap.parse_args()
     w = {"C3": workload.C3, "C2": workload.C2}[args.workload]
     w.n_docs = args.docs if args.workload == "C3" else w.n_docs
     qr = synth.make_queries(args.queries, w.n_terms, w.max_rank)
     t0 = time.time()
-    corpus = workload.build_shard_corpus(w, qr, 1, 0)
-    log(json.dumps({"event": "corpus", "docs": w.n_docs, "postings": corpus.total_postings, "build_s": round(time.time() - t0, 1)}))
+    corpus = workload.build_shard_corpus(w, qr, 1, 0, variant=args.variant)
+    log(json.dumps({"event": "corpus", "variant": args.variant, "docs": w.n_docs, "postings": corpus.total_postings, "build_s": round(time.time() - t0, 1)}))
     queries = workload.boolean_queries(qr)
     mgr = api.TopScoreDocCollectorManager(w.k)
     B = args.batch
     nb = args.queries // B
     ref = None
     for ci, cfg in enumerate(args.configs.split(";")):
-        policy, pct = cfg.split("|")
+        parts = cfg.split("|")
+        policy, pct = parts[0], parts[1]
         os.environ["NRTGPU_LOOK_POLICY"] = policy
-        flags = api._lib.NRTGPU_FLAG_PACKED_POSTINGS if args.packed else 0
+        extra_env = dict(kv.split("=") for kv in parts[2].split(",")) if len(parts) > 2 and parts[2] else {}
+        for k_, v_ in extra_env.items():   # (development library: experiment knobs, read at every call)
+            os.environ[k_] = v_
+        flags = (api._lib.NRTGPU_FLAG_PACKED_POSTINGS if args.packed else 0) | (api._lib.NRTGPU_FLAG_PROFILE if args.profile else 0)
         ctx = api.GpuContext(0, max_batch=B, collect_timing=True, flags=flags, lookup_budget_pct=int(pct))
+        if "SPEC" in extra_env:   # (not an environment variable: the speculation margin of this context, 0 = off)
+            ctx.set_speculation(float(extra_env["SPEC"]))
         t1 = time.time()
         leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
         upload_s = time.time() - t1
@@ -85,10 +93,15 @@ def main():
         dt = time.perf_counter() - t2
         st = ctx.stats()
         L = max(1, st["maxscore_launches"])
-        log(json.dumps({"event": "config", "policy": policy, "budget_pct": int(pct), "device_GB": round(dev_bytes / 1e9, 3), "upload_s": round(upload_s, 1),
+        prof = None
+        if args.profile:
+            prof = {k_: round(v_ / max(1, st["queries"]), 1) for k_, v_ in ctx.maxscore_profile().items()}
+        for k_ in extra_env:
+            os.environ.pop(k_, None)
+        log(json.dumps({"event": "config", "policy": policy, "budget_pct": int(pct), "env": extra_env, "device_GB": round(dev_bytes / 1e9, 3), "upload_s": round(upload_s, 1),
                         "kernel_ms": round(st["maxscore_ms"] / L, 4), "launches": L, "step_ms": round(dt / args.steps * 1e3, 3),
                         "qps": round(args.steps * B / dt, 0), "oracle_mismatches": bad if ci == 0 else None, "answers_equal_first_config": same,
-                        "spec": ctx.spec_counters()}))
+                        "spec": ctx.spec_counters(), "profile_per_query": prof}))
         for l in leaves:
             l.release()
         ctx.close()

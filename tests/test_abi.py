@@ -68,7 +68,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(_lib.Term) == 24
     assert C.sizeof(_lib.Bm25Query) == 112
     assert C.sizeof(_lib.TopDocs) == 40
-    assert C.sizeof(_lib.Stats) == 176
+    assert C.sizeof(_lib.Stats) == 184
     assert C.sizeof(_lib.Diagnostics) == 56
 
 

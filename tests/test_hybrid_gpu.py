@@ -240,11 +240,12 @@ def test_coalesced_single_searches_form_one_batch_by_construction(dev_lib, oracl
         _hybrid_close(hybrid)
 
 
-def test_fused_hybrid_under_speculative_thresholds_equals_the_unspeculated_answer():
+def test_fused_hybrid_under_speculative_thresholds_equals_the_unspeculated_answer(dev_lib, monkeypatch):
     """The fused hybrid's first pass runs under speculative thresholds too (plan.h: kHitsSpecInvalid): the merge's tags arrive with
     the results and a query whose guess failed -- its recall set may lack docs -- is run again, first pass and tail.  On an index
     whose live docs all sit in the first third of the docid range (guesses fail there: tests/test_maxscore_gpu.py) the fused
     answer with speculation must be the fused answer without, docids and score bits, and the counters must show the re-runs."""
+    monkeypatch.setenv("NRTGPU_MS_SCATTER", "0")   # (development library: windows in docid order -- where this index defeats the guesses)
     rng = np.random.default_rng(5)
     ranks = [1, 2, 5, 9, 20, 60, 150, 400]
     corpus = synth.build_corpus(3_200_000, ranks, n_segments=1)

@@ -240,14 +240,18 @@ def test_search_after_under_slicing_pins_the_documented_divergence(ctxs, oracle)
         ctx.set_slicing()
 
 
-def test_speculative_thresholds_are_checked_and_failed_guesses_run_again(oracle):
+def test_speculative_thresholds_are_checked_and_failed_guesses_run_again(dev_lib, monkeypatch, oracle):
     """Speculative thresholds (plan.h: kHitsSpecInvalid; nrtgpu_set_speculation): a workgroup guesses the final k-th score from the
     best of the docs it has seen so far and skips what cannot reach the guess; the merge checks the guess, a query whose guess
     failed is run again without speculation inside the call.  Three things: (1) on an index whose docs are spread like a sample
     the guesses hold and the results are the oracle's; (2) on one where they are NOT -- every live doc in the first third of the
     docid range, so a third of the way through a workgroup has seen every hit and still expects twice as many -- guesses fail,
     the queries are run again, and the results are still the oracle's; (3) a context in which too many guesses fail switches
-    speculation off by itself."""
+    speculation off by itself.
+    The windows are walked in DOCID order here (development library, NRTGPU_MS_SCATTER=0): that is the order in which the skewed
+    index defeats the guess and exercises the re-run; the product's scattered order (round 5) is what
+    test_speculation_holds_on_docid_ordered_corpora checks."""
+    monkeypatch.setenv("NRTGPU_MS_SCATTER", "0")
     ctx = api.GpuContext(device_id=0, max_batch=64)
     ranks = [1, 2, 5, 9, 20, 60, 150, 400]
     corpus = synth.build_corpus(3_200_000, ranks, n_segments=1)    # one segment: 49 doc windows per query, one work item + helpers
@@ -290,6 +294,44 @@ def test_speculative_thresholds_are_checked_and_failed_guesses_run_again(oracle)
         before = ctx.spec_counters()["reruns"]
         ix.searcher.search_batch([bq(t) for t in qs], [api.TopScoreDocCollectorManager(100, None, 10)] * len(qs))
         assert ctx.spec_counters()["reruns"] == before     # nothing speculates any more
+    finally:
+        ix.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["clustered", "sorted"])
+def test_speculation_on_docid_ordered_corpora(variant, oracle):
+    """Docids that are NOT independent draws (synth.corpus_variant_arrays: terms in docid bursts; docs numbered by length, so that
+    scores fall along the docid axis).  The speculative thresholds read the windows a workgroup has begun as a sample of the
+    query's docs; in docid order that is false here and guesses fail.  What must hold: (1) every answer is the oracle's, docids and
+    score bits, whatever the guesses do (the merge checks each, failed queries are run again inside the call); (2) the library
+    judges the leaf set: after >= 2048 queries with more than 2 % run again it walks the windows in the SCATTERED order (any
+    prefix of the windows taken is spread over the docs) -- which cures the sorted index: few re-runs from then on, speculation
+    stays on -- and gives speculation up for the leaf set if that fails too (bursty terms may: their variance is no sample's)."""
+    ctx = api.GpuContext(device_id=0, max_batch=256)
+    ranks = [1, 2, 5, 9, 20, 60, 150, 400, 1500]
+    corpus = synth.build_corpus(3_200_000, ranks, n_segments=4, variant=variant)
+    ix = Index(ctx, corpus)
+    try:
+        ctx.set_speculation(5.0)
+        rng = np.random.Generator(np.random.PCG64(7))
+        history = []
+        for rep in range(30):
+            batch = [[int(x) for x in rng.choice(ranks, size=int(rng.integers(2, 6)), replace=False)] for _ in range(256)]
+            k, thr = ((1000, 1000), (100, 10), (1000, 10))[rep % 3]
+            got = ix.searcher.search_batch([bq(t) for t in batch], [api.TopScoreDocCollectorManager(k, None, thr)] * 256)
+            for i in range(0, 256, 37):
+                check(f"spec_{variant}_{rep}_{i}", got[i], oracle.search_bm25(corpus, batch[i], k, total_hits_threshold=thr), k, thr)
+            history.append(ctx.spec_counters())
+        c = history[-1]
+        if variant == "sorted":
+            assert c["scattered"] and not c["switched_off"], history[::6]
+            first = next(i for i, h in enumerate(history) if h["scattered"])
+            late = [h for h in history[first + 2:]]     # (batches that ran entirely in the scattered order)
+            assert len(late) >= 6
+            assert (late[-1]["reruns"] - late[0]["reruns"]) * 50 <= (late[-1]["queries"] - late[0]["queries"]), (late[0], late[-1])
+        else:
+            assert c["queries"] > 0    # (whatever the verdict on this leaf set: the answers above were exact)
     finally:
         ix.close()
         ctx.close()

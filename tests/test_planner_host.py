@@ -28,9 +28,13 @@ def mockhip(tmp_path_factory):
     return out
 
 
+DEV_LIB = os.path.join(ROOT, "nrtsearch_amd", "libnrtgpu_dev.so")   # the plan trace and the A/B keys are knobs of the development build
+
+
 def plan_of(mockhip, **env):
-    e = dict(os.environ, LD_PRELOAD=mockhip, NRTGPU_PLAN_TRACE="1", **env)
-    e.pop("NRTGPU_LIB_PATH", None)
+    from nrtsearch_amd import build
+    build.build_dev()
+    e = dict(os.environ, LD_PRELOAD=mockhip, NRTGPU_PLAN_TRACE="1", NRTGPU_LIB_PATH=DEV_LIB, **env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "plan_batch.py")], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "done" in r.stdout, r.stderr[-2000:]
     plans = [(m.group(1), m.group(2), [int(x) for x in m.group(3).split()])
