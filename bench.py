@@ -88,6 +88,8 @@ def parse_args():
     ap.add_argument("--exhaustive-steps", type=int, default=8,
                     help="C3 / C2, one GPU: steps of the EXHAUSTIVE route (every posting streamed) timed after the main run for "
                          "roofline.exhaustive (0 = skip)")
+    ap.add_argument("--c4-steps", type=int, default=8,
+                    help="C3 line: also run BASELINE config 4 (10 M x 768 exact kNN, 64 queries per pass) for that many passes -> roofline.c4 (0 = skip)")
     ap.add_argument("--no-sketch", action="store_true",
                     help="C4 A/B: NRTGPU_FLAG_NO_VECTOR_SKETCH -- no fp16 copy of the rows, the exact search nominates from the fp32 rows "
                          "(twice the bytes per pass); the answers are the same bits")
@@ -310,9 +312,11 @@ def closed_loop(ctx, searcher, queries, mgr, callers, duration_ms):
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md); v_mfma_f32_16x16x4_f32 is exact fp32
+FP16_MFMA_PEAK_TFLOPS = 2500.0   # dense fp16 matrix peak of an MI355X (MI355X_MICROARCH.md; the 2:1 sparsity figure is never priced against)
 
 
-def knn_roofline_record(rows_per_pass, dim, queries_per_pass, score_ms, sketched, score_launches_per_pass, second_passes):
+def knn_roofline_record(rows_per_pass, dim, queries_per_pass, score_ms, sketched, score_launches_per_pass, second_passes, traffic=None,
+                        traffic_source=None):
     """The `roofline` object of the exact-kNN line from measured numbers (pure: tests/test_bench_contract.py checks its arithmetic).
     A pass over the rows that nominates from the fp16 sketch STREAMS 2 bytes per element (steps of 32 dimensions padded to whole
     groups of four), half of SURVEY 8d's algorithmic fp32 bytes: `frac` is then the PHYSICAL fraction and the algorithmic rate
@@ -337,11 +341,31 @@ def knn_roofline_record(rows_per_pass, dim, queries_per_pass, score_ms, sketched
             "score_launches_per_panel": round(score_launches_per_pass, 2),
             "second_passes": int(second_passes),
             "avg_launch_ms": round(score_ms, 4),
-            "mfma_tflops": round(tflops, 2) if not sketched else None, "mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS if not sketched else None,
-            "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4) if not sketched else None, "traffic": None}
+            # the matrix cores: useful multiply-adds (rows x dim x queries of the pass, x 2) / launch time against the dense peak of the
+            # operand type -- fp16 for the sketch (v_mfma_f32_16x16x32_f16), fp32 for the fp32 rows (v_mfma_f32_16x16x4_f32).  The pass
+            # is bound by the bytes it streams: at 64 queries per pass the matrix rate is what the HBM rate allows.
+            "mfma_tflops": round(tflops, 2), "mfma_peak_tflops": FP16_MFMA_PEAK_TFLOPS if sketched else FP32_MFMA_PEAK_TFLOPS,
+            "mfma_dtype": "f16" if sketched else "f32",
+            "mfma_frac": round(tflops / (FP16_MFMA_PEAK_TFLOPS if sketched else FP32_MFMA_PEAK_TFLOPS), 4),
+            "traffic": traffic, "traffic_source": traffic_source}
 
 
-def run_c4(args):
+def knn_traffic_record(lib_id, q_per_pass):
+    """HBM bytes per pass of the sketch kernel from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, a run of its own), only
+    when the record was taken from THIS build's kernels."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        for rec in json.load(open(pmc)):
+            if rec.get("workload") == "C4" and rec.get("kernel") == "knn_sketch_kernel" and rec.get("queries_per_pass") == int(q_per_pass):
+                if rec.get("build_id") == lib_id:
+                    return rec.get("hbm_bytes_per_launch"), rec.get("note")
+                return None, f"profiles/pmc_traffic.json holds a C4 record of build {rec.get('build_id')}; the loaded library is {lib_id}: not reused"
+    except Exception:
+        pass
+    return None, None
+
+
+def run_c4(args, emit=True):
     """BASELINE.json config 4 at one GPU: N x 768 fp32 rows resident in HBM, exact (brute-force) cosine kNN top-100 --
     what KnnFloatVectorQuery / ExactVectorQuery compute, answered by nrtgpu_knn_exact.  A step = one call with
     --knn-queries queries (every <= 64 of them stream the rows once).  Roofline: HBM (N * dim * 4 bytes per pass), with the
@@ -496,9 +520,11 @@ def run_c4(args):
                                 f"(nrtgpu_dist_knn_exact, {'all-to-all' if mode == api.EXCHANGE_ALLTOALL else 'all-gather'})" if world > 1 else
                                 (f"[emulating rank {shard_rank} of {shard_world}: its rows, no exchange]" if shard_world > 1 else "one GPU"))},
         "roofline": knn_roofline_record(st["knn_rows"] / n_panels, dim, q_per_panel, score_ms, sketched, st["knn_score_launches"] / n_panels,
-                                        st["knn_second_passes"]),
+                                        st["knn_second_passes"],
+                                        *(knn_traffic_record(build.build_id(_lib.LIB_PATH), q_per_panel) if (sketched and world == 1 and shard_world == 1) else (None, None))),
     }
-    if rank == 0 and world == 1 and shard_world == 1 and args.closed_loop:
+    out["roofline"]["build_id"] = build.build_id(_lib.LIB_PATH)
+    if rank == 0 and world == 1 and shard_world == 1 and args.closed_loop and emit:
         # queries/s AND latency under concurrent clients: C native caller threads, ONE query per call through
         # nrtgpu_knn_exact_coalesced -- the library merges them into panels of up to 64 that share a pass over the rows
         import ctypes as C
@@ -562,6 +588,11 @@ def run_c4(args):
                                "sample": f"{nq_cpu} queries x the first {len(first_seg)} rows (oracle/nrt_oracle.c nrt_oracle_knn_exact, scalar fp32 "
                                          f"left to right, C + OpenMP, {cores} threads, {dt:.2f}s); value = queries/s extrapolated to {n} rows",
                                "agrees_with_device": bool(ok) and checked > 0, "device_hits_checked": checked}
+    if not emit:   # a leg of another workload's line (main: roofline.c4): hand the line back, leave nothing resident
+        for g in leaves:
+            g.release()
+        ctx.close()
+        return out
     if rank == 0:
         print(json.dumps(out), flush=True)
     os.dup2(2, 1)
@@ -570,6 +601,7 @@ def run_c4(args):
         ctx.dist_close()
         dist.destroy_process_group()
     ctx.close()
+    return out
 
 
 def main():
@@ -1072,6 +1104,26 @@ def main():
         for l in leaves_x:
             l.release()
         ctx_x.close()
+    if rank == 0 and world == 1 and not use_dist and args.c4_steps > 0 and args.workload == "C3" and not args.docs:
+        # The other half of the path in the same line: BASELINE config 4 -- 10 M x 768 fp32 rows, exact
+        # cosine top-100, 64 queries per pass -- for --c4-steps passes: the sketch kernel's physical HBM fraction, the matrix cores'
+        # rate against the fp16 peak, the fp64 check over every row, and the C port on the host cores.  (bench.py --workload C4 is
+        # the full line: closed loop, other panel widths.)
+        c4_args = argparse.Namespace(**vars(args))
+        c4_args.workload, c4_args.steps, c4_args.warmup, c4_args.knn_queries, c4_args.closed_loop = "C4", args.c4_steps, 2, 64, ""
+        c4_args.no_sketch, c4_args.c4_callers, c4_args.no_verify, c4_args.emulate_world = False, False, False, 0
+        c4 = run_c4(c4_args, emit=False)
+        r4 = c4["roofline"]
+        out["roofline"]["c4"] = {
+            "workload": c4["config"]["workload"], "kernel": r4["kernel"], "passes": args.c4_steps, "queries_per_pass": 64,
+            "queries_per_s": c4["value"], "ms_per_pass_call": c4["ms_per_step"], "avg_launch_ms": r4["avg_launch_ms"],
+            "bound": "hbm", "achieved": r4["achieved"], "peak": r4["peak"], "unit": "GB/s", "frac": r4["frac"], "achieved_is": r4["achieved_is"],
+            "streamed_bytes_per_launch": r4["streamed_bytes_per_launch"], "algorithmic_bytes_per_launch": r4["algorithmic_bytes_per_launch"],
+            "effective_frac": r4["effective_frac"], "traffic": r4["traffic"], "traffic_source": r4["traffic_source"],
+            "mfma_tflops": r4["mfma_tflops"], "mfma_peak_tflops": r4["mfma_peak_tflops"], "mfma_dtype": r4["mfma_dtype"], "mfma_frac": r4["mfma_frac"],
+            "second_passes": r4["second_passes"], "verify": c4.get("verify"), "cpu_baseline": c4.get("cpu_baseline"),
+            "corpus_build_s": c4["config"]["corpus_build_s"],
+        }
     if rank == 0 and world == 1 and not use_dist and args.closed_loop and args.workload in ("C3", "C2"):
         # queries/s AND latency (BASELINE.json's metric): the closed loop of SURVEY 8d, same index, same query set
         callers = [int(x) for x in args.closed_loop.split(",") if x.strip()]

@@ -231,6 +231,19 @@ typedef struct {
  * by that rule; dynamic pruning is used only where some slice certainly passes the threshold.  Defaults: 250000, 5, 1.
  * slice_max_docs == 0: the whole search counts as one slice. */
 int  nrtgpu_set_slicing(nrtgpu_ctx* ctx, int32_t slice_max_docs, int32_t slice_max_segments, int32_t virtual_shards);
+/* PARTIAL RESIDENCY ("non-resident segments are searched by Lucene and merged with TopDocs.merge").  Under NRT refresh a
+ * searcher usually holds a few young segments that are not resident yet (ShardState.java:506-527).  The caller then splits the
+ * searcher's SLICES (IndexSearcher.getSlices(), MyIndexSearcher.java:79-208): the slices whose leaves are all resident go to
+ * nrtgpu_search_bm25* in ONE call over their leaves, the other slices run through Lucene's own collectors, and the per-slice
+ * results are reduced as the reference reduces them -- TopDocs.merge, totalHits summed, GREATER_THAN_OR_EQUAL_TO if any part's is
+ * (LazyQueueTopScoreDocCollectorManager.java:137-144).  Statistics stay index-global (the weights the caller passes).
+ * A call over a SUBSET of the searcher's leaves must count its hits by the WHOLE searcher's slices: with the default slicing the
+ * library's own slicing of whole slices' leaves reproduces them (leaves are packed in size order; a removed slice removes a whole
+ * run), with virtual shards it does not (leaves are dealt to shards over all leaves first).  So the calling thread may state the
+ * slice of every leaf of its next calls: slice_of_leaf[i] >= 0 for the call's i-th leaf (any numbering; equal numbers = one slice),
+ * n_leaves = the call's leaf count (a call with another count ignores the override and slices by itself); NULL / 0 clears it.
+ * Thread-local, like the deadline: set before the search call, cleared after. */
+int  nrtgpu_set_thread_slices(const int32_t* slice_of_leaf, int32_t n_leaves);
 
 int  nrtgpu_search_bm25(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                         const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);

@@ -19,8 +19,12 @@ import org.apache.lucene.search.*;
  * Seam B2 (SURVEY 8b): the searcher ShardSearcherFactory.newSearcher builds when the plugin has installed its
  * MyIndexSearcher.SearcherHook (java/patches/nrtsearch-gpu-hook.diff; index/ShardState.java:506-527).
  * search(Query, CollectorManager) -- the single entry of the hot path (handler/SearchHandler.java:1412-1413, :556) -- goes
- * to the device when the rewritten query and the collector are eligible and every leaf is resident; anything else is
- * super.search, i.e. the untouched Lucene path.
+ * to the device when the rewritten query and the collector are eligible.  PARTIAL RESIDENCY (SURVEY 8b; under NRT refresh a searcher
+ * usually holds a young segment or two that are not resident yet, index/ShardState.java:506-527): the searcher's slices whose
+ * leaves are all resident are searched on the device in one call, the other slices by Lucene's own collectors, and the parts are
+ * reduced like the reference reduces its slices (TopDocs.merge, totalHits summed, GREATER_THAN_OR_EQUAL_TO if any part's is:
+ * LazyQueueTopScoreDocCollectorManager.java:137-144) -- tests/test_partial_residency_gpu.py runs exactly this split through the C
+ * ABI with the oracle in Lucene's place.  Anything else is super.search, i.e. the untouched Lucene path.
  * NOT COMPILED in this repository's image (no JDK); tests/test_java_shim_signatures.py checks every nrtsearch type, constructor
  * and method used here against the reference sources plus the patch.
  */
@@ -143,15 +147,42 @@ public class GpuIndexSearcher extends MyIndexSearcher {
     }
     GpuEligibility.Shape shape = GpuEligibility.shape(rewritten);
     if (shape == null) return super.search(query, manager);
-    List<LeafReaderContext> leaves = getIndexReader().leaves();
+    // the searcher's slices (MyIndexSearcher.slices): a slice goes to the device iff ALL its leaves are resident
+    LeafSlice[] slices = getSlices();
+    java.util.ArrayList<LeafReaderContext> leaves = new java.util.ArrayList<>();          // the device's leaves, in docBase order
+    java.util.ArrayList<Integer> sliceOfLeaf = new java.util.ArrayList<>();
+    java.util.ArrayList<LeafSlice> cold = new java.util.ArrayList<>();
+    for (int si = 0; si < slices.length; si++) {
+      boolean resident = true;
+      for (LeafReaderContextPartition p : slices[si].partitions) resident &= store.segmentOf(p.ctx) != null;
+      if (!resident) {
+        cold.add(slices[si]);
+        continue;
+      }
+      for (LeafReaderContextPartition p : slices[si].partitions) {
+        leaves.add(p.ctx);
+        sliceOfLeaf.add(si);
+      }
+    }
+    if (leaves.isEmpty()) return super.search(query, manager);          // nothing resident (yet): CPU path
+    if (!cold.isEmpty() && (rc.getSearchAfter() != null || !shape.filters().isEmpty() || !shape.mustNots().isEmpty()))
+      return super.search(query, manager);                              // (the split is built for the plain shapes; masks are keyed by the whole leaf set)
+    Integer[] order = new Integer[leaves.size()];
+    for (int i = 0; i < order.length; i++) order[i] = i;
+    java.util.Arrays.sort(order, java.util.Comparator.comparingInt(i -> leaves.get(i).docBase));
     try (Arena a = Arena.ofConfined()) {
       MemorySegment segs = a.allocate(ADDRESS, leaves.size()), bases = a.allocate(JAVA_INT, leaves.size());
-      for (int i = 0; i < leaves.size(); i++) {
-        MemorySegment s = store.segmentOf(leaves.get(i));
-        if (s == null) return super.search(query, manager);            // a leaf is not resident (yet): CPU path
-        segs.setAtIndex(ADDRESS, i, s);
-        bases.setAtIndex(JAVA_INT, i, leaves.get(i).docBase);
+      MemorySegment sliceIds = a.allocate(JAVA_INT, leaves.size());
+      List<LeafReaderContext> deviceLeaves = new java.util.ArrayList<>();
+      for (int i = 0; i < order.length; i++) {
+        LeafReaderContext leaf = leaves.get(order[i]);
+        deviceLeaves.add(leaf);
+        segs.setAtIndex(ADDRESS, i, store.segmentOf(leaf));
+        bases.setAtIndex(JAVA_INT, i, leaf.docBase);
+        sliceIds.setAtIndex(JAVA_INT, i, sliceOfLeaf.get(order[i]));
       }
+      leaves.clear();
+      leaves.addAll(deviceLeaves);
       // FILTER / MUST_NOT clauses next to the scoring ones: resident doc-set masks (nrtgpu_segment_set_mask)
       int[] filterMasks = new int[shape.filters().size()], mustNotMasks = new int[shape.mustNots().size()];
       for (int i = 0; i < filterMasks.length; i++)
@@ -166,9 +197,11 @@ public class GpuIndexSearcher extends MyIndexSearcher {
       int status;
       try {
         NrtGpu.SET_DEADLINE.invokeExact(deadline);
+        if (!cold.isEmpty()) NrtGpu.check((int) NrtGpu.SET_THREAD_SLICES.invokeExact(sliceIds, leaves.size()));   // count by the WHOLE searcher's slices
         status = (int) NrtGpu.SEARCH1.invokeExact(ctx, segs, bases, leaves.size(), plan.query(), plan.out());   // blocks; batched inside
       } finally {
         NrtGpu.SET_DEADLINE.invokeExact(0L);
+        int ignored = (int) NrtGpu.SET_THREAD_SLICES.invokeExact(MemorySegment.NULL, 0);
       }
       if (status == NrtGpu.ERR_TIMEOUT) return (T) timedOut(el);       // out of time before anything was launched
       if (status == NrtGpu.ERR_UNSUPPORTED) return super.search(query, manager);   // not a shape / size the device takes
@@ -178,7 +211,22 @@ public class GpuIndexSearcher extends MyIndexSearcher {
         LAST_DIAGNOSTICS.set(new double[] {d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_TOTAL_MS), d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_PLAN_MS),
             d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_QUEUE_MS), d.get(JAVA_DOUBLE, NrtGpuLayouts.DIAGNOSTICS_DEVICE_MS),
             (double) d.get(JAVA_LONG, NrtGpuLayouts.DIAGNOSTICS_POSTINGS)});
-      return (T) new SearcherResult(plan.toTopDocs(), Map.of());       // search/SearcherResult.java:31-34
+      TopDocs top = plan.toTopDocs();
+      if (!cold.isEmpty()) {
+        // the cold slices on Lucene's own path: one collector per slice (IndexSearcher.search(leaves, weight, collector)), reduced by
+        // the request's manager, then TopDocs.merge with the device's part -- (score desc, doc asc), totalHits summed, the relation
+        // GREATER_THAN_OR_EQUAL_TO if either part's is
+        Weight weight = createWeight(rewritten, ScoreMode.TOP_SCORES, 1.0f);
+        java.util.ArrayList<C> collectors = new java.util.ArrayList<>();
+        for (LeafSlice sl : cold) {
+          C c = manager.newCollector();
+          collectors.add(c);
+          search(sl.partitions, weight, c);
+        }
+        TopDocs cpu = ((SearcherResult) manager.reduce(collectors)).getTopDocs();
+        top = TopDocs.merge(0, rc.getNumHitsToCollect(), new TopDocs[] {top, cpu}, java.util.Comparator.comparingInt((ScoreDoc d) -> d.doc));
+      }
+      return (T) new SearcherResult(top, Map.of());       // search/SearcherResult.java:31-34
     } catch (IOException | RuntimeException e) {
       throw e;
     } catch (Throwable t) {

@@ -66,6 +66,8 @@ final class NrtGpu {
   static final MethodHandle DESTROY = h("nrtgpu_destroy", FunctionDescriptor.ofVoid(ADDRESS));
   static final MethodHandle LAST_ERROR = h("nrtgpu_last_error", FunctionDescriptor.of(ADDRESS));
   static final MethodHandle SET_SLICING = h("nrtgpu_set_slicing", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT));
+  /** Partial residency: the calling thread's next searches run over a subset of the searcher's leaves, counted by the whole searcher's slices. */
+  static final MethodHandle SET_THREAD_SLICES = h("nrtgpu_set_thread_slices", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT));
   static final MethodHandle SEG_BEGIN = h("nrtgpu_segment_begin", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS));
   static final MethodHandle ADD_NORMS = h("nrtgpu_segment_add_field_norms", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
   static final MethodHandle ADD_TERMS =

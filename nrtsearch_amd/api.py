@@ -245,6 +245,16 @@ class GpuContext:
             L.nrtgpu_get_maxscore_item_walls(self._h, out.ctypes.data, n, C.byref(n_items))
         return out, int(n_items.value)
 
+    @staticmethod
+    def set_thread_slices(slice_of_leaf: Optional[Sequence[int]]) -> None:
+        """Partial residency (nrtgpu_set_thread_slices): the calling thread's next searches run over a SUBSET of the searcher's leaves
+        and count their hits by the whole searcher's slices -- slice_of_leaf[i] = the slice of the call's i-th leaf; None clears."""
+        if slice_of_leaf is None:
+            _lib.check(_lib.load().nrtgpu_set_thread_slices(None, 0))
+        else:
+            a = np.ascontiguousarray(slice_of_leaf, dtype=np.int32)
+            _lib.check(_lib.load().nrtgpu_set_thread_slices(a.ctypes.data, len(a)))
+
     def set_speculation(self, margin: float) -> None:
         """Speculative thresholds of the MaxScore route (nrtgpu_set_speculation): the guess's safety margin in standard deviations; 0 = off."""
         _lib.check(_lib.load().nrtgpu_set_speculation(self._h, C.c_float(float(margin))))

@@ -385,7 +385,12 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
           }
           for (uint32_t i = tid; i < hp.n_own; i += kMsThreads) {
             const uint32_t fl = items[i].flags;
-            if ((fl & 3u) != kMsModePrune) continue;   // (counting items decide per workgroup when bounds may skip: not shared)
+            // Prune-mode items, and (round 5) COUNTING items -- masks, minimumNumberShouldMatch, DisjunctionMax, uncertain counts: a
+            // helper is to its item what a second item is to its query: it counts the live matching docs of ITS windows exactly, per
+            // slice, until its own count passes the floor or the query's q_prune flag is up (checked at every window's head), and adds
+            // its per-slice counts to the query's sums at its end -- the argument that makes a counting query of several items right
+            // covers it.  (Exact-mode items are small by construction: nobody needs help there.)
+            if ((fl & 3u) == kMsModeExact) continue;
             const uint32_t nw = fl >> 8;
             const uint32_t taken = (uint32_t)kMsWaves + __hip_atomic_load(hp.win_next + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (taken + min_rem > nw) continue;

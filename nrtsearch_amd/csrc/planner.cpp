@@ -520,7 +520,16 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // the searcher's slices over these leaves (MyIndexSearcher.slices / slicesForShards): relation and route depend on them
   std::vector<int32_t> slice_of_leaf((size_t)std::max(n_segs, 1), 0);
   int32_t n_slices = 1;
-  if (ctx->slice_max_docs.load() > 0 && n_segs > 0) {
+  if (n_segs > 0 && (int32_t)g_thread_slices.size() == n_segs) {
+    // the caller's slices (nrtgpu_set_thread_slices: a call over a subset of the searcher's leaves counts by the WHOLE searcher's
+    // slices), renumbered densely in order of first appearance
+    std::unordered_map<int32_t, int32_t> dense;
+    for (int32_t i = 0; i < n_segs; ++i) {
+      auto it = dense.emplace(g_thread_slices[(size_t)i], (int32_t)dense.size()).first;
+      slice_of_leaf[(size_t)i] = it->second;
+    }
+    n_slices = (int32_t)std::max<size_t>(dense.size(), 1);
+  } else if (ctx->slice_max_docs.load() > 0 && n_segs > 0) {
     std::vector<hostmath::LeafInfo> all((size_t)n_segs);
     int32_t base = 0;
     for (int32_t i = 0; i < n_segs; ++i) {

@@ -14,6 +14,7 @@ namespace rt {
 thread_local std::string g_last_error;
 thread_local int64_t g_deadline_ns = 0;
 thread_local nrtgpu_diagnostics g_diag{};
+thread_local std::vector<int32_t> g_thread_slices;
 int64_t monotonic_ns() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -265,6 +266,14 @@ extern "C" int nrtgpu_set_slicing(nrtgpu_ctx* ctx, int32_t slice_max_docs, int32
   ctx->slice_max_docs = slice_max_docs;
   ctx->slice_max_segments = slice_max_segments;
   ctx->virtual_shards = virtual_shards;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_set_thread_slices(const int32_t* slice_of_leaf, int32_t n_leaves) {
+  if (n_leaves < 0 || (n_leaves > 0 && !slice_of_leaf)) return fail(NRTGPU_ERR_INVALID_ARG, "bad thread slices");
+  for (int32_t i = 0; i < n_leaves; ++i)
+    if (slice_of_leaf[i] < 0) return fail(NRTGPU_ERR_INVALID_ARG, "slice_of_leaf[%d] = %d: slice numbers are >= 0", i, slice_of_leaf[i]);
+  g_thread_slices.assign(slice_of_leaf, slice_of_leaf + n_leaves);
   return NRTGPU_OK;
 }
 

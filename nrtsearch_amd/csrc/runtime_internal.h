@@ -108,6 +108,7 @@ namespace rt {
 extern thread_local std::string g_last_error;
 extern thread_local int64_t g_deadline_ns;           // nrtgpu_set_thread_deadline_ns: 0 = none
 extern thread_local nrtgpu_diagnostics g_diag;       // nrtgpu_last_diagnostics
+extern thread_local std::vector<int32_t> g_thread_slices;   // nrtgpu_set_thread_slices: the caller's slice of every leaf of its next calls
 int64_t monotonic_ns();
 inline bool deadline_passed(int64_t deadline_ns) { return deadline_ns != 0 && monotonic_ns() >= deadline_ns; }
 #define NRT_CHECK_DEADLINE(what)                                                                             \

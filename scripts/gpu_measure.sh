@@ -1,0 +1,88 @@
+#!/bin/bash
+# The standard measurements of a round on one MI355X box, one script instead of a script per call (scripts/history/ keeps the
+# one-shot ones of rounds 2-5).  Usage, through gpurun:
+#     gpurun --timeout 1500 -- 'bash scripts/gpu_measure.sh <tag> <step> [<step> ...]'
+# writes under gpurun_out/<tag>/ (copy what is to be judged into profiles/).  Steps:
+#   suite        the driver's GPU suite (pytest -m gpu) + smoke
+#   bench        the default bench line twice in the driver's form (--steps 20 --warmup 5) and once at 200 steps
+#   variants     bench lines: C2, packed postings, exhaustive route, clustered / sorted corpora
+#   trace        rocprofv3 --kernel-trace --stats of the driver's command -> <tag>_kernel_stats.csv
+#   pmc          rocprofv3 --pmc passes (each a run of its own): FETCH_SIZE of the default / exhaustive / packed lines, the SQ
+#                counters of the MaxScore kernel, FETCH_SIZE + matrix-core counters of the C4 sketch kernel -> <tag>_pmc.txt
+#   shapes       scripts/gpu_query_shapes.py (deletes, FILTER, MUST_NOT, minimumNumberShouldMatch, DisjunctionMax, hybrid tail)
+#   emulate8     one rank's share of an 8-GPU C3 job (bench.py --force-dist --emulate-world 8), peers' bounds present / silent
+#   c4           the full C4 lines (1 / 32 / 64 queries per pass)
+#   gather       scripts/ubench/gather_fetch under rocprofv3 --pmc FETCH_SIZE (what the counter tallies per access pattern)
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOT=$(pwd); export TMPDIR=/tmp
+TAG=${1:?tag}; shift
+O=$ROOT/gpurun_out/$TAG; mkdir -p $O
+export NRTGPU_BENCH_WATCHDOG=400
+T0=$(date +%s)
+el() { echo "== $1 ($(( $(date +%s) - T0 )) s)"; }
+show() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; c=d.get('config',{}); print(sys.argv[1], '| q/s', d['value'], '| ms/step', d['ms_per_step'], '|', r['kernel'], r['avg_launch_ms'], 'ms | frac', r.get('frac'), 'eff', r.get('effective_frac'), '| exh', (r.get('exhaustive') or {}).get('frac'), '| c4', {k: (r.get('c4') or {}).get(k) for k in ('frac', 'mfma_frac', 'queries_per_s')}, '| spec', c.get('speculation'), '| GB', round(c.get('device_bytes_per_gpu', 0) / 1e9, 2))" "$1" 2>/dev/null || echo "$1 FAILED"; }
+pmc() {  # name, kernel substring, counters..., then "--" and the command
+  n=$1; k=$2; shift 2; cs=""; while [ "$1" != "--" ]; do cs="$cs $1"; shift; done; shift
+  rm -rf /tmp/pmc1; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $cs -d /tmp/pmc1 -o p --output-format csv -- "$@" > /tmp/pmc1.log 2>&1 )
+  f=$(find /tmp/pmc1 -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python - "$f" "$n" "$k" <<'PY' | tee -a $O/${TAG}_pmc.txt
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    agg[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in agg.items():
+    if sys.argv[3] in k:
+        print(sys.argv[2], k, {c: (len(v), round(sum(v) / len(v), 1)) for c, v in d.items()}, '(launches, mean per launch)')
+PY
+}
+python -c "from nrtsearch_amd import build; print('build_id', build.build_id())"
+for step in "$@"; do case $step in
+suite)
+  el "GPU suite"
+  timeout 700 python -m pytest tests -m gpu -q --maxfail=8 --tb=short --durations=6 -p no:cacheprovider > $O/pytest_suite.log 2>&1
+  echo "pytest rc=$?"; grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" $O/pytest_suite.log | tail -14 | cut -c1-220
+  timeout 120 python __graft_entry__.py smoke 2>&1 | tail -1 ;;
+bench)
+  el "bench lines"
+  for rep in 1 2; do timeout 400 python bench.py --steps 20 --warmup 5 2>/dev/null | tee $O/${TAG}_bench_steps20_$rep.json | show "c3 --steps 20 --warmup 5 (driver's form)"; done
+  timeout 400 python bench.py --c4-steps 0 2>/dev/null | tee $O/${TAG}_bench_line.json | show "c3 default (200 steps)" ;;
+variants)
+  el "bench variants"
+  timeout 200 python bench.py --workload C2 --no-cpu-baseline 2>/dev/null | tee $O/${TAG}_bench_c2.json | show "c2"
+  timeout 200 python bench.py --packed --no-cpu-baseline --closed-loop '' --c4-steps 0 2>/dev/null | tee $O/${TAG}_bench_c3_packed.json | show "c3 packed"
+  timeout 200 python bench.py --no-prune --no-cpu-baseline --closed-loop '' --c4-steps 0 2>/dev/null | tee $O/${TAG}_bench_line_no_prune.json | show "c3 no-prune"
+  for v in clustered sorted; do
+    timeout 300 python bench.py --corpus-variant $v --steps 100 --warmup 10 --c4-steps 0 --exhaustive-steps 0 --no-cpu-baseline --closed-loop "64" 2>/dev/null | tee $O/${TAG}_bench_c3_$v.json | show "c3 $v"
+  done ;;
+trace)
+  el "kernel trace"
+  rm -rf /tmp/prof; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t --output-format csv -- python $ROOT/bench.py --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --steps 20 --warmup 5 > /tmp/prof_bench.log 2>&1 )
+  find /tmp/prof -name "*kernel_stats*" -exec cp {} $O/${TAG}_kernel_stats.csv \;
+  head -6 $O/${TAG}_kernel_stats.csv | cut -c1-60,200-420 ;;
+pmc)
+  el "PMC passes"
+  rm -f $O/${TAG}_pmc.txt
+  pmc fetch_default bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1
+  pmc fetch_noprune bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1 --no-prune
+  pmc fetch_packed bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1 --packed
+  pmc sq1_default bm25 SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1
+  pmc c4_fetch knn_sketch FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --workload C4 --knn-queries 64 --no-cpu-baseline --no-verify --closed-loop "" --warmup 1 --steps 4
+  pmc c4_mfma knn_sketch SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES -- python $ROOT/bench.py --workload C4 --knn-queries 64 --no-cpu-baseline --no-verify --closed-loop "" --warmup 1 --steps 4 ;;
+shapes)
+  el "query shapes"
+  timeout 400 python scripts/gpu_query_shapes.py --steps 6 2>&1 | grep -v "^RCCL\|amdgpu.ids" | tee $O/${TAG}_query_shapes.log | cut -c1-260 ;;
+emulate8)
+  el "one rank of eight"
+  timeout 300 python bench.py --force-dist --emulate-world 8 --emulate-peers final --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8.json | show "1 of 8, peers' bounds present"
+  timeout 300 python bench.py --force-dist --emulate-world 8 --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8_silent.json | show "1 of 8, peers silent" ;;
+c4)
+  el "C4 lines"
+  for q in 1 32 64; do timeout 400 python bench.py --workload C4 --knn-queries $q --steps 20 --warmup 4 2>/dev/null | tee $O/${TAG}_bench_c4_q$q.json | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('c4 q$q', d['value'], d['ms_per_step'], r['kernel'], r['avg_launch_ms'], 'frac', r['frac'], 'mfma', r['mfma_frac'], 'traffic', r['traffic'], 'verify', (d.get('verify') or {}).get('agrees_with_fp64'))"; done ;;
+gather)
+  el "gather calibration"
+  rm -rf /tmp/pmcg; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcg -o g --output-format csv -- $ROOT/scripts/ubench/gather_fetch 4 > $O/${TAG}_gather_fetch.txt 2>&1 )
+  grep "requested_bytes" $O/${TAG}_gather_fetch.txt | tail -5 ;;
+*) echo "unknown step $step" ;;
+esac; done
+el "done"

@@ -85,6 +85,40 @@ def test_bm25_full_size_against_the_exhaustive_oracle(oracle, wname):
         ctx.close()
 
 
+def test_bm25_c3_numbered_by_doc_length_is_cured_by_the_scattered_window_order(oracle):
+    """C3's size, docs numbered by length (synth.corpus_variant_arrays: "sorted" -- an index sorted by a field the BM25 score
+    follows: scores fall along the docid axis).  In docid order practically every speculative threshold fails there (the first
+    windows hold the best docs); the library then walks this leaf set's windows in the scattered order -- any prefix of the
+    windows taken is spread over the docs -- and from there the guesses hold: few queries are run again, speculation stays on.
+    Every answer on the way is the oracle's, whatever the guesses do."""
+    w = workload.C3
+    n_q = 1024
+    qr = synth.make_queries(5 * n_q, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr, variant="sorted")
+    ctx = api.GpuContext(0, max_batch=n_q)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    try:
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        mgr = api.TopScoreDocCollectorManager(w.k)
+        ctx.set_speculation(5.0)
+        history = []
+        for b in range(5):
+            rows = qr[b * n_q:(b + 1) * n_q]
+            got = sr.search_batch(workload.boolean_queries(rows), [mgr] * n_q)
+            history.append(ctx.spec_counters())
+            if b in (0, 4):    # the oracle's exhaustive answer for a slice of the batch: docids, ranks, score bits
+                exp = oracle.PreparedBatch(corpus, [q.tolist() for q in rows[:64]], w.k, slicing=oracle.DEFAULT_SLICING).run(False, _cpus())
+                _check_batch(got[:64], exp, w.k)
+        assert history[0]["reruns"] > 0.5 * n_q, history       # docid order: the guesses fail wholesale
+        assert history[-1]["scattered"] and not history[-1]["switched_off"], history
+        late = (history[-1]["reruns"] - history[2]["reruns"], history[-1]["queries"] - history[2]["queries"])   # batches 3 and 4: scattered order
+        assert late[1] == 2 * n_q and late[0] * 50 <= late[1], history
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()
+
+
 def test_knn_c4_shape_against_fp64(oracle):
     n, dim, k, nq = 2_000_000, 768, 100, 40
     rng = np.random.default_rng(777)

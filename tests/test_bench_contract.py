@@ -109,7 +109,11 @@ def test_knn_roofline_record_arithmetic():
     assert r["streamed_bytes_per_launch"] == 10_000_000 * 24 * 64 == 10_000_000 * 768 * 2
     assert r["algorithmic_bytes_per_launch"] == 10_000_000 * 768 * 4
     assert abs(r["achieved"] - 15.36e9 / 2.7e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
-    assert abs(r["effective_frac"] - 2 * r["frac"]) < 1e-3 and r["mfma_frac"] is None and r["second_passes"] == 0
+    assert abs(r["effective_frac"] - 2 * r["frac"]) < 1e-3 and r["second_passes"] == 0
+    # the sketch path's matrix-core figures (round 5): useful fp16 multiply-adds against the dense fp16 peak
+    assert r["mfma_dtype"] == "f16" and r["mfma_peak_tflops"] == 2500.0
+    assert abs(r["mfma_tflops"] - 2 * 10_000_000 * 768 * 32 / 2.7e-3 / 1e12) < 0.01 and abs(r["mfma_frac"] - r["mfma_tflops"] / 2500.0) < 1e-4
+    assert r["traffic"] is None
     # 96 dimensions: 3 steps of 32, padded to 4 -> 256 bytes per row streamed, 384 algorithmic
     r = bench.knn_roofline_record(1000, 96, 1, 1.0, True, 3.0, 1)
     assert r["streamed_bytes_per_launch"] == 1000 * 256 and r["algorithmic_bytes_per_launch"] == 1000 * 384 and r["second_passes"] == 1
@@ -117,4 +121,4 @@ def test_knn_roofline_record_arithmetic():
     assert r["kernel"] == "knn_score_kernel" and r["effective"] is False and r["effective_frac"] is None
     assert r["streamed_bytes_per_launch"] == r["algorithmic_bytes_per_launch"] == 10_000_000 * 768 * 4
     assert abs(r["mfma_tflops"] - 2 * 10_000_000 * 768 * 32 / 6e-3 / 1e12) < 0.01
-    assert abs(r["mfma_frac"] - r["mfma_tflops"] / 157.3) < 1e-3
+    assert abs(r["mfma_frac"] - r["mfma_tflops"] / 157.3) < 1e-3 and r["mfma_dtype"] == "f32"
