@@ -216,8 +216,15 @@ typedef struct {
   int32_t  capacity;                   /* in : capacity of docs/scores (>= k) */
   int32_t* docs;                       /* out: global docids (doc_base + leaf doc) */
   float*   scores;                     /* out: (score desc, doc asc) */
-  int64_t  total_hits;                 /* out: live matching docs: the exact number, or -- when the query ran with
-                                        * dynamic pruning (MaxScore route) -- a lower bound above totalHitsThreshold */
+  int64_t  total_hits;                 /* out: live matching docs: the exact number, or -- when the query ran with dynamic pruning
+                                        * (MaxScore route; total_hits_is_lower_bound = 1) -- a lower bound above totalHitsThreshold.
+                                        * WHICH lower bound: where the planner knew beforehand that some slice passes the threshold
+                                        * (a plain disjunction whose largest term alone does), the live docs it knew to match -- the
+                                        * same number on every run; where the query had to count its way to the threshold (masks,
+                                        * minimumNumberShouldMatch, DisjunctionMax, an uncertain count), the docs the walk had
+                                        * evaluated -- which depends on when its workgroups saw the threshold passed and on what the
+                                        * bounds then skipped: NOT the same from run to run (Lucene's own value there is an artefact
+                                        * of its traversal too).  The relation and the returned hits are deterministic either way. */
   int32_t  total_hits_is_lower_bound;  /* out: 1 == GREATER_THAN_OR_EQUAL_TO: some slice of the searcher (nrtgpu_set_slicing)
                                         * collected more than max(totalHitsThreshold, numHits) hits and numHits hits were returned */
 } nrtgpu_topdocs;

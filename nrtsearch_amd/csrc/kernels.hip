@@ -1201,7 +1201,8 @@ void launch_slice_relation(hipStream_t stream, const uint32_t* slice_sum, const 
 __global__ __launch_bounds__(256)
 void patch_hits_kernel(const uint64_t* __restrict__ lower, uint64_t* __restrict__ hits, uint32_t n) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < n && lower[q] != 0ull && (hits[q] >> 48) != 0ull) hits[q] = kHitsPrunedUnit + lower[q];
+  // (the merge's tag of a failed speculative threshold, kHitsSpecInvalid, stays: nrtgpu_pending_wait reads it)
+  if (q < n && lower[q] != 0ull && (hits[q] >> 48) != 0ull) hits[q] = kHitsPrunedUnit + lower[q] + (hits[q] & kHitsSpecInvalid);
 }
 void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits, uint32_t n) {
   if (n == 0) return;

@@ -36,9 +36,8 @@ static bool speculating(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t 
 }
 // A call that ran under speculation has come back: count it, and throw the leaf set's switch when too many guesses fail --
 // every failure is a second pass.
-static void note_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int64_t n_queries, int64_t n_rerun) {
-  std::shared_ptr<LeafSetCache> lsc = leaf_set_cache(ctx, segs, n_segs);
-  spec_sync_epoch(ctx, lsc.get());
+static void note_speculation_of(nrtgpu_ctx* ctx, LeafSetCache* lsc, int64_t n_queries, int64_t n_rerun) {
+  spec_sync_epoch(ctx, lsc);
   const int64_t seen = lsc->spec_queries.fetch_add(n_queries, std::memory_order_relaxed) + n_queries;
   const int64_t failed = lsc->spec_reruns.fetch_add(n_rerun, std::memory_order_relaxed) + n_rerun;
   ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed);
@@ -53,6 +52,10 @@ static void note_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int
       ctx->spec_off.store(1, std::memory_order_relaxed);
     }
   }
+}
+static void note_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int64_t n_queries, int64_t n_rerun) {
+  std::shared_ptr<LeafSetCache> lsc = leaf_set_cache(ctx, segs, n_segs);
+  note_speculation_of(ctx, lsc.get(), n_queries, n_rerun);
 }
 
 // NRTGPU_MS_PERSISTENT=0 (development build): one workgroup per item + helper workgroups behind them (A/B)
@@ -984,6 +987,13 @@ struct nrtgpu_pending {
   std::unique_ptr<SegReadLocks> content;
   int32_t n_queries = 0;
   double plan_ms = 0.0;
+  // speculative thresholds (plan.h: kHitsSpecInvalid) on this path: the launch ran under them; nrtgpu_pending_wait reads the merged
+  // counts' tags and, if a guess failed, runs the batch again without speculation into the same buffers before it returns
+  bool speculated = false;
+  uint32_t k_stride = 0;
+  uint64_t* d_keys = nullptr;
+  uint32_t* d_counts = nullptr;
+  uint64_t* d_hits = nullptr;
 };
 
 extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
@@ -1011,11 +1021,20 @@ extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtg
   }
   p->plan_ms = now_ms() - t0;
   acquire_slot(ctx, &p->slot);
+  // Speculative thresholds here too (round 5): every shard of a multi-GPU search computes ITS top-k under them, the tags are read
+  // in nrtgpu_pending_wait.  Not next to the cross-GPU bound exchange (epoch >= 0 with an exchange open: its quantile uses the
+  // selection's second rank).
+  p->speculated = epoch < 0 && p->hp.lsc && spec_margin16(ctx) != 0u && (spec_sync_epoch(ctx, p->hp.lsc.get()), p->hp.lsc->spec_off.load(std::memory_order_relaxed) == 0) &&
+                  p->hp.n_ms_items != 0;
+  p->k_stride = (uint32_t)k_stride;
+  p->d_keys = (uint64_t*)d_keys;
+  p->d_counts = (uint32_t*)d_counts;
+  p->d_hits = (uint64_t*)d_hits;
   DeviceRun run;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, p->slot, p->hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
-                                (uint64_t*)d_hits, &run, gpu, epoch)) {
+                                (uint64_t*)d_hits, &run, gpu, epoch, p->speculated)) {
       (void)hipStreamSynchronize(p->slot->stream);   // whatever was enqueued reads the slot's buffers
       release_slot(ctx, p->slot);
       return rc;
@@ -1030,7 +1049,35 @@ extern "C" int nrtgpu_pending_wait(nrtgpu_pending* pending) {
   std::unique_ptr<nrtgpu_pending> p(pending);
   nrtgpu_ctx* ctx = p->ctx;
   (void)hipSetDevice(ctx->device);
-  const hipError_t e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
+  hipError_t e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
+  if (e == hipSuccess && p->speculated) {
+    // the merge tagged the queries whose guess it could not confirm (kHitsSpecInvalid in the hit totals): read the totals, clear the
+    // tags for the caller, and -- if any -- run the batch again without speculation into the same buffers (the plan and the
+    // workspace are still this call's).  A re-run is a second pass of the batch; the leaf set's verdict bounds how often.
+    const size_t nq = (size_t)p->n_queries;
+    int64_t n_bad = 0;
+    if (p->slot->h_out.reserve(nq * 8) == 0) {
+      uint64_t* hh = (uint64_t*)p->slot->h_out.p;
+      e = hipMemcpyAsync(hh, p->d_hits, nq * 8, hipMemcpyDeviceToHost, p->slot->stream);
+      if (e == hipSuccess) e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
+      if (e == hipSuccess) {
+        for (size_t q = 0; q < nq; ++q)
+          if (hh[q] & kHitsSpecInvalid) {
+            hh[q] &= ~kHitsSpecInvalid;
+            ++n_bad;
+          }
+        note_speculation_of(ctx, p->hp.lsc.get(), (int64_t)nq, n_bad);
+        if (n_bad) {
+          DeviceRun run;
+          std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+          if (enqueue_search(ctx, p->slot, p->hp, p->n_queries, p->k_stride, p->d_keys, p->d_counts, p->d_hits, &run, gpu, -1, false) != 0)
+            e = hipErrorUnknown;
+          else
+            e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
+        }
+      }
+    }
+  }
   if (e == hipSuccess) account(ctx, p->slot, p->hp, p->n_queries, p->plan_ms);   // (fills the WAITING thread's diagnostics)
   release_slot(ctx, p->slot);
   if (e != hipSuccess) return fail(NRTGPU_ERR_HIP, "device-resident search failed: %s", hipGetErrorString(e));

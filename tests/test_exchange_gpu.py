@@ -414,3 +414,49 @@ def test_begin_wait_pipeline_against_a_writer_of_the_same_segments():
         for l in leaves:
             l.release()
         ctx.close()
+
+
+def test_device_resident_results_under_speculative_thresholds(dev_lib, monkeypatch, oracle):
+    """The device-resident path (what a rank of a multi-GPU search runs) speculates too since round 5: the merge's tags are read in
+    nrtgpu_pending_wait and a batch with a failed guess is run again without speculation into the same buffers.  On an index that
+    defeats the guesses -- every live doc in the first third of the docid range, windows walked in docid order (development library,
+    NRTGPU_MS_SCATTER=0) -- the keys left in HBM are the oracle's top-k all the same, no tag is left in the hit totals, and the
+    counters show the re-runs."""
+    import torch
+
+    from nrtsearch_amd import api
+
+    monkeypatch.setenv("NRTGPU_MS_SCATTER", "0")
+    ranks = [1, 2, 5, 9, 20, 60, 150, 400]
+    corpus = synth.build_corpus(3_200_000, ranks, n_segments=1)
+    seg = corpus.segments[0]
+    live = np.zeros((seg.max_doc + 63) // 64, dtype=np.uint64)
+    live[: int(seg.max_doc * 0.3) // 64] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    seg.live_bits = live
+    ctx = api.GpuContext(0, max_batch=16)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    try:
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        qs = [[1, 5, 20, 150, 400], [2, 9, 60], [1, 2, 5, 9, 20, 60, 150, 400], [5, 400], [9, 20, 150]]
+        k, k_stride = 1000, 1008
+        queries = [api.BooleanQuery(tuple(api.TermQuery(0, t) for t in q)) for q in qs]
+        pb = api.PreparedBatch(sr, queries, [api.TopScoreDocCollectorManager(k)] * len(qs))
+        keys = torch.zeros((len(qs), k_stride), dtype=torch.int64, device="cuda")
+        cnt = torch.zeros((len(qs),), dtype=torch.int32, device="cuda")
+        hits = torch.zeros((len(qs),), dtype=torch.int64, device="cuda")
+        ctx.set_speculation(5.0)
+        pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())
+        torch.cuda.synchronize()
+        c = ctx.spec_counters()
+        assert c["queries"] == len(qs) and c["reruns"] >= 2, c
+        hk, hc, hh = keys.cpu().numpy().view(np.uint64), cnt.cpu().numpy(), hits.cpu().numpy().view(np.uint64)
+        for j, q in enumerate(qs):
+            edocs, escores, _, _ = oracle.search_bm25(corpus, q, k)
+            docs = (0xFFFFFFFF - (hk[j, : hc[j]] & np.uint64(0xFFFFFFFF))).astype(np.int64)
+            bits = (hk[j, : hc[j]] >> np.uint64(32)).astype(np.uint32)
+            assert docs.tolist() == edocs.tolist() and bits.tolist() == escores.view(np.uint32).tolist(), j
+            assert (int(hh[j]) >> 47) & 1 == 0      # plan.h: kHitsSpecInvalid -- never handed to the caller
+    finally:
+        for l in leaves:
+            l.release()
+        ctx.close()
