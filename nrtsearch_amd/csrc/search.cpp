@@ -454,9 +454,11 @@ static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
   return NRTGPU_OK;
 }
 
-extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
-                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                                        nrtgpu_topdocs* out) {
+// after_first (the coalescer's): called between the two passes with the indices of the queries that are run again -- every OTHER
+// query of the batch holds its final answer in `out` at that moment, and its caller need not wait for the second pass.
+static int search_batch_spec(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                             const nrtgpu_bm25_query* queries, int32_t n_queries, nrtgpu_topdocs* out,
+                             const std::function<void(const std::vector<int32_t>&)>* after_first) {
   // The MaxScore route may run under SPECULATIVE thresholds here (plan.h: kHitsSpecInvalid; nrtgpu_set_speculation): a query whose
   // guess the merge could not confirm comes back tagged and is run again without speculation.  Both passes run under ONE set of
   // content locks (a set_mask / set_live_docs between them would show the re-run queries other content than their batch mates,
@@ -474,6 +476,7 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   const nrtgpu_diagnostics first = g_diag;
   note_speculation(ctx, segs, n_segs, n_queries, (int64_t)rerun.size());
   if (rerun.empty()) return rc;
+  if (after_first) (*after_first)(rerun);
   std::vector<nrtgpu_bm25_query> rq(rerun.size());
   std::vector<nrtgpu_topdocs> ro(rerun.size());
   for (size_t i = 0; i < rerun.size(); ++i) {
@@ -497,6 +500,12 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
   d.items_scan += first.items_scan;
   g_diag = d;
   return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                        int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                        nrtgpu_topdocs* out) {
+  return search_batch_spec(ctx, segs, doc_bases, n_segs, queries, n_queries, out, nullptr);
 }
 
 extern "C" int nrtgpu_set_speculation(nrtgpu_ctx* ctx, float margin) {
@@ -930,7 +939,26 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
     explicit DeadlineScope(bool clear) : saved(g_deadline_ns) { if (clear) g_deadline_ns = 0; }
     ~DeadlineScope() { g_deadline_ns = saved; }
   } deadline_scope(batch.size() > 1);
-  int rc = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data());
+  // A member whose query is run again (a speculative threshold failed the merge's check) must not hold up its batch mates: they
+  // are woken between the two passes with the answer they already have.
+  std::vector<char> released(batch.size(), 0);
+  const std::function<void(const std::vector<int32_t>&)> after_first = [&](const std::vector<int32_t>& rerun) {
+    std::vector<char> again(batch.size(), 0);
+    for (int32_t qi : rerun) again[(size_t)qi] = 1;
+    const nrtgpu_diagnostics first_diag = g_diag;
+    for (size_t i = 1; i < batch.size(); ++i) {   // (batch[0] is this caller: it runs the second pass)
+      if (again[i]) continue;
+      CoRequest* r = batch[i];
+      std::lock_guard<std::mutex> theirs(r->m);
+      *r->out = outs[i];
+      r->diag = first_diag;
+      r->rc = 0;
+      r->done = true;
+      r->cv.notify_one();
+      released[i] = 1;
+    }
+  };
+  int rc = search_batch_spec(ctx, segs, doc_bases, n_segs, qs.data(), (int32_t)qs.size(), outs.data(), &after_first);
   std::string err = rc ? g_last_error : std::string();
   const nrtgpu_diagnostics batch_diag = g_diag;
   // A request the planner rejects (a mask that is not resident on a leaf, a clause shape outside the fixed-point range ...)
@@ -939,6 +967,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
   std::vector<std::string> errs(batch.size(), err);
   if (rc != 0 && batch.size() > 1) {
     for (size_t i = 0; i < batch.size(); ++i) {
+      if (released[i]) continue;   // (left with its answer between the passes)
       rcs[i] = nrtgpu_search_bm25_batch(ctx, segs, doc_bases, n_segs, &qs[i], 1, &outs[i]);
       errs[i] = rcs[i] ? g_last_error : std::string();
     }
@@ -951,6 +980,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
       if (rcs[i] == 0) *out = outs[i];
       continue;
     }
+    if (released[i]) continue;   // (gone already: its request object may no longer exist)
     // (notified under the request's own lock: the woken caller cannot return -- and free its request -- before
     // we are done with it, and it contends with nobody but us)
     std::lock_guard<std::mutex> theirs(r->m);

@@ -1,0 +1,72 @@
+"""One rank of the two-rank test of the library's own multi-GPU path (tests/test_dist_two_ranks_gpu.py): a process with its own
+context on the one GPU of the box, holding ITS docid shard of the index, that calls nrtgpu_dist_search_bm25_batch_mode /
+nrtgpu_dist_knn_exact / nrtgpu_dist_search_hybrid_batch with the collective carried by tests/mockrccl (a stand-in librccl.so.1 on
+LD_LIBRARY_PATH: messages are /dev/shm files).  No torch here: its bundled RCCL must not be the one dist.cpp binds to."""
+import os
+import pickle
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, sync_dir, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    n_docs, n_queries, k = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    import numpy as np
+
+    from nrtsearch_amd import api, synth, workload
+
+    w = workload.Workload("two-rank dist test", n_docs, 4, k, n_queries, 4)
+    qr = synth.make_queries(n_queries, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr, world, rank)           # this rank's leaves, index-global statistics
+    ctx = api.GpuContext(0, max_batch=max(64, n_queries))
+    leaves = []
+    rng = np.random.default_rng(4242)                                  # the same rows on every rank: each keeps its docid range's
+    dim = 32
+    all_vecs = rng.standard_normal((n_docs, dim)).astype(np.float32)
+    for seg in corpus.segments:
+        g = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
+        g.add_field_norms(0, seg.norms)
+        g.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
+        g.add_vectors(1, all_vecs[seg.doc_base: seg.doc_base + seg.max_doc])
+        g.seal()
+        leaves.append(g)
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    # the unique id travels through the file system (a deployment would use its own means)
+    id_path = os.path.join(sync_dir, "unique_id")
+    if rank == 0:
+        uid = api.GpuContext.dist_unique_id()
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(id_path + ".tmp", id_path)
+    t0 = time.time()
+    while not os.path.exists(id_path):
+        if time.time() - t0 > 120:
+            sys.exit("rank 0 never published the unique id")
+        time.sleep(0.005)
+    uid = open(id_path, "rb").read()
+    ctx.dist_init(world, rank, uid)
+    queries = workload.boolean_queries(qr)
+    mgr = api.TopScoreDocCollectorManager(k)
+    out = {}
+    for name, mode in (("allgather", api.EXCHANGE_ALLGATHER), ("alltoall", api.EXCHANGE_ALLTOALL)):
+        got = sr.dist_search_batch(queries, [mgr] * n_queries, mode=mode)
+        out["bm25_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in got]
+        qv = all_vecs[:8] + np.float32(0.25)
+        kn = sr.dist_knn_exact(1, "cosine", qv, 10, mode=mode)
+        out["knn_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits) for g in kn]
+        hy = sr.dist_search_hybrid_batch(queries[:8], [mgr] * 8, 1, "cosine", qv, 20, 1.0, 2.0, mode=mode)
+        out["hybrid_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in hy]
+    out["stats"] = ctx.stats()
+    with open(out_path, "wb") as f:
+        pickle.dump(out, f)
+    ctx.dist_close()
+    for l in leaves:
+        l.release()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

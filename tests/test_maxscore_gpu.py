@@ -334,3 +334,49 @@ def test_speculation_on_docid_ordered_corpora(variant, oracle):
     finally:
         ix.close()
         ctx.close()
+
+
+def test_coalesced_callers_whose_mates_are_run_again_get_their_own_answer(dev_lib, monkeypatch, oracle):
+    """nrtgpu_search_bm25_coalesced over an index that defeats the speculative thresholds (every live doc in the first third of the
+    docid range; windows in docid order: development library): the batch a leader forms holds queries whose guess fails next to
+    queries whose guess holds.  The latter are handed their answer between the two passes (they do not wait for their mates'
+    re-run), the former after it -- and every caller gets the oracle's docids and score bits."""
+    import threading
+
+    monkeypatch.setenv("NRTGPU_MS_SCATTER", "0")
+    ctx = api.GpuContext(device_id=0, max_batch=64)
+    ranks = [1, 2, 5, 9, 20, 60, 150, 400]
+    corpus = synth.build_corpus(3_200_000, ranks, n_segments=1)
+    seg = corpus.segments[0]
+    live = np.zeros((seg.max_doc + 63) // 64, dtype=np.uint64)
+    live[: int(seg.max_doc * 0.3) // 64] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    seg.live_bits = live
+    ix = Index(ctx, corpus)
+    try:
+        ctx.set_speculation(5.0)
+        qs = [[1, 5, 20, 150, 400], [2, 9, 60], [1, 2, 5, 9, 20, 60, 150, 400], [5, 400], [9, 20, 150], [400], [150, 400], [60, 150]]
+        expected = [oracle.search_bm25(corpus, t, 1000) for t in qs]
+        errors = []
+
+        def caller(tix):
+            try:
+                for it in range(6):
+                    i = (tix + it) % len(qs)
+                    got = ix.searcher.search_coalesced(bq(qs[i]), api.TopScoreDocCollectorManager(1000))
+                    ed, es, _, eg = expected[i]
+                    if got.docs.tolist() != ed.tolist() or got.scores.view(np.uint32).tolist() != es.view(np.uint32).tolist() or got.relation_gte != eg:
+                        errors.append((tix, it, i))
+            except Exception as e:   # noqa: BLE001
+                errors.append((tix, repr(e)))
+
+        threads = [threading.Thread(target=caller, args=(t,)) for t in range(24)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:5]
+        c = ctx.spec_counters()
+        assert c["queries"] == 24 * 6 and c["reruns"] >= 6, c     # (guesses did fail: the second pass ran)
+    finally:
+        ix.close()
+        ctx.close()
