@@ -55,6 +55,12 @@ def parse_args():
                     help="N>1: do not share score bounds between the GPUs' shards (nrtgpu_exchange_open, on by default: a shard "
                          "stops collecting below the score that k docs of the OTHER shards already reach; results are identical)")
     ap.add_argument("--exchange", action="store_true", help="(accepted for older scripts: the exchange is the default at N>1)")
+    ap.add_argument("--shard-bounds", default="speculation", choices=["speculation", "exchange", "local"],
+                    help="N>1 (or --emulate-world): how a shard learns a threshold beyond its own k-th score.  speculation "
+                         "(default): every shard guesses the WHOLE search's k-th score from its own docs "
+                         "(nrtgpu_search_bm25_shard_device_begin), the guesses are checked against the merged lists and failed "
+                         "queries run again on every rank; exchange: the score-bound table in shared memory "
+                         "(nrtgpu_exchange_open; the default of rounds 3-4); local: neither (a shard's own speculation only)")
     ap.add_argument("--emulate-peers", default="none", choices=["none", "final"],
                     help="with --emulate-world: open the bound exchange for that job and play the other ranks' rows: none = they "
                          "never publish (the shard prunes on its own, the pessimistic end), final = each publishes from the start "
@@ -81,6 +87,8 @@ def parse_args():
                     help="N>1 (begin / wait submission): threads that plan and enqueue steps side by side (0 = 2 when the host has >= 6 CPUs "
                          "per rank, else 1): a rank whose planning takes longer than its kernel is bound by ONE submitting thread")
     ap.add_argument("--planner-threads", type=int, default=0, help="planner threads per in-flight call (0 = what the box's CPUs allow)")
+    ap.add_argument("--speculation-margin", type=float, default=-1.0,
+                    help="the speculative thresholds' safety margin in standard deviations (nrtgpu_set_speculation; < 0: the library's default, 5; 0: off)")
     ap.add_argument("--closed-loop", default="1,8,64,512",
                     help="N=1, C3: after the batch line, closed loop with that many concurrent callers, one query per call through "
                          "nrtgpu_search_bm25_coalesced (comma list; empty = skip): qps / p50 / p99 per caller count")
@@ -697,6 +705,8 @@ def main():
     planner_threads = args.planner_threads or max(1, min(4, usable_cpus() // max(1, max(world, shard_world) * submitters)))
     ctx = api.GpuContext(device_id=local_rank, max_batch=B, target_items=args.target_items, collect_timing=True, flags=flags,
                          host_threads=planner_threads)
+    if args.speculation_margin >= 0.0:
+        ctx.set_speculation(args.speculation_margin)
     leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
     searcher = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
     queries = workload.boolean_queries(qranks)
@@ -710,7 +720,9 @@ def main():
     emu_exchange = False
     lib_mode = api.EXCHANGE_ALLGATHER
     peer_words = None   # --emulate-peers final: [batch] -> (shard_world, B) uint32 score bits the other ranks would publish
-    if world > 1 and not args.no_exchange:
+    shard_spec = use_dist and max(world, shard_world) > 1 and args.shard_bounds == "speculation" and not args.no_prune and args.emulate_peers == "none"
+    shard_spec_stat = {"queries": 0, "failed": 0, "reran_batches": 0}
+    if world > 1 and not args.no_exchange and args.shard_bounds == "exchange":
         # cross-GPU bound exchange (include/nrtgpu.h): one shared-memory table per job, opened by every rank
         import uuid
         box = [f"/nrtgpu_bench_{uuid.uuid4().hex[:16]}" if rank == 0 else None]
@@ -758,6 +770,8 @@ def main():
         bufs = [(torch.zeros((B, k_stride), dtype=torch.int64, device="cuda"),
                  torch.zeros((B,), dtype=torch.int32, device="cuda"),
                  torch.zeros((B,), dtype=torch.int64, device="cuda")) for _ in range(NB)]
+        guess_bufs = [torch.zeros((B,), dtype=torch.int64, device="cuda") for _ in range(NB)]   # --shard-bounds speculation
+        guess_host = torch.zeros((B,), dtype=torch.int64).pin_memory()
         # Default (BASELINE.json's north star): RCCL all-gather of every rank's top-k (rank r's rows are
         # [r * B, (r + 1) * B)), every rank merges everything and holds every answer.  --all-to-all splits the reduce
         # instead: rank r receives every rank's lists for ITS B / world queries (rows [j * B/world, (j + 1) * B/world)
@@ -794,10 +808,14 @@ def main():
         if emu_exchange:
             W_e = shard_world
             mq_e = B // W_e if lib_mode == api.EXCHANGE_ALLTOALL else B
-            e_keys = torch.zeros((W_e, mq_e, k_stride), dtype=torch.int64, device="cuda")
-            e_cnt = torch.zeros((W_e, mq_e), dtype=torch.int32, device="cuda")
-            e_hits = torch.zeros((W_e, mq_e), dtype=torch.int64, device="cuda")
-            e_tag = (torch.arange(W_e, dtype=torch.int64, device="cuda") << 27).view(W_e, 1, 1)
+            # per batch of the query set: the W_e lists as the exchange would leave them.  The OTHER ranks' lists are staged once,
+            # before the warmup (below) -- in a real job they arrive over xGMI while this rank scans; list l of a batch is this
+            # rank's own list of that batch with bits 27-29 of the docid word flipped by (l - rank) mod W_e, so the merge sees W_e
+            # disjoint lists of the same shape and order -- and per step only this rank's own list is copied into its place.
+            e_keys = [torch.zeros((W_e, mq_e, k_stride), dtype=torch.int64, device="cuda") for _ in batches]
+            e_cnt = [torch.zeros((W_e, mq_e), dtype=torch.int32, device="cuda") for _ in batches]
+            e_hits = [torch.zeros((W_e, mq_e), dtype=torch.int64, device="cuda") for _ in batches]
+            e_tag = (((torch.arange(W_e, dtype=torch.int64, device="cuda") - shard_rank) % W_e) << 27).view(W_e, 1, 1)
             merger = api.PreparedMerge(ctx, W_e, mq_e, k_stride, [w.k] * mq_e, [api.TOTAL_HITS_THRESHOLD] * mq_e)
         if not (args.torch_collective or args.debug_same_gpu or split_reduce or emu_exchange):
             ok = 1
@@ -871,6 +889,19 @@ def main():
             return
         free = [threading.Semaphore(1) for _ in range(NB)]
         t_start = [0.0] * count
+        # --shard-bounds speculation needs somebody who checks the guesses: the library's exchange (run_dist_checked) or the
+        # emulated one below; with torch.distributed carrying the lists a shard speculates on its own list only
+        spec_on = [shard_spec and (emu_exchange or lib_collective) and not args.sync_submit]
+
+        def run_again(pb, bad):
+            """Queries whose guess failed the check against the merged list: every rank runs them again without speculation
+            (the whole batch here: a stand-in that overstates the cost) and the lists are exchanged and merged once more."""
+            shard_spec_stat["reran_batches"] += 1
+            keys, cnt, hits = bufs[0]
+            tmp = (torch.zeros_like(keys), torch.zeros_like(cnt), torch.zeros_like(hits))
+            h = pb.begin_shard_device(k_stride, tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(), 0, 0)
+            api.PreparedBatch.wait_device(h)
+            return tmp
 
         pending = [None] * count
 
@@ -881,7 +912,10 @@ def main():
             keys, cnt, hits = bufs[b]
             pb = batches[(first + i) % len(batches)]
             play_peers(first + i)
-            if args.sync_submit:
+            if spec_on[0]:   # this shard's thresholds: guesses at the whole search's k-th score, left in guess_bufs[b] for the check
+                pending[i] = pb.begin_shard_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), max(world, shard_world),
+                                                   guess_bufs[b].data_ptr())
+            elif args.sync_submit:
                 pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=(first + i) if exchange_name else -1)
             else:   # plan + enqueue only: the exchange thread waits for the results
                 pending[i] = pb.begin_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=(first + i) if exchange_name else -1)
@@ -904,17 +938,52 @@ def main():
                     # (a key is (score bits << 32) | ~docid and docids are unique across the shards of a real job: the stand-in
                     #  lists get distinct docids -- list l flips bits 27-29 of the docid word with l -- so the merge sees N disjoint
                     #  lists of the same shape and order; the selection kernels assume unique keys)
-                    torch.bitwise_xor(keys[:mq_e].unsqueeze(0), e_tag, out=e_keys)
-                    e_cnt.copy_(cnt[:mq_e].unsqueeze(0).expand(W_e, mq_e))
-                    e_hits.copy_(hits[:mq_e].unsqueeze(0).expand(W_e, mq_e))
+                    bi_ = (first + i) % len(batches)
+                    e_keys[bi_][shard_rank].copy_(keys[:mq_e])
+                    e_cnt[bi_][shard_rank].copy_(cnt[:mq_e])
+                    e_hits[bi_][shard_rank].copy_(hits[:mq_e])
+                    if spec_on[0]:
+                        guess_host[:mq_e].copy_(guess_bufs[b][:mq_e], non_blocking=True)
                     torch.cuda.current_stream().synchronize()
                     free[b].release()
                     te1 = time.perf_counter()
-                    merger.run(e_keys.data_ptr(), e_cnt.data_ptr(), e_hits.data_ptr())
+                    merger.run(e_keys[bi_].data_ptr(), e_cnt[bi_].data_ptr(), e_hits[bi_].data_ptr())
+                    if spec_on[0]:
+                        # the check of nrtgpu_dist_exchange_merge_checked, done here because the lists did not travel: the k-th key of
+                        # the merged list must reach the largest guess (the other ranks' guesses are stood in for by this one's)
+                        g_ = guess_host[:mq_e].numpy().view(np.uint64)
+                        bad = np.flatnonzero((g_ != 0) & (merger.kth_keys() < g_))
+                        shard_spec_stat["queries"] += mq_e
+                        shard_spec_stat["failed"] += len(bad)
+                        batches[(first + i) % len(batches)].note_shard_speculation(mq_e, len(bad))
+                        if len(bad):
+                            tk, tc, th_ = run_again(batches[(first + i) % len(batches)], bad)
+                            stage_lists(bi_, tk, tc, th_)
+                            torch.cuda.current_stream().synchronize()
+                            merger.run(e_keys[bi_].data_ptr(), e_cnt[bi_].data_ptr(), e_hits[bi_].data_ptr())
                     if record:
                         lat.append(time.perf_counter() - t_start[i])
                         stage["exchange_s"] += te1 - te0
                         stage["merge_call_s"] += time.perf_counter() - te1
+                        stage["steps"] += 1
+                    continue
+                if lib_collective and spec_on[0]:
+                    # exchange (the guesses ride along) + merge + the check of the guesses against the merged lists: the same
+                    # verdicts on every rank; what failed is run again by every rank without speculation, gathered whole
+                    bad = merger.run_dist_checked(keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), guess_bufs[b].data_ptr(), lib_mode)
+                    free[b].release()
+                    pb_ = batches[(first + i) % len(batches)]
+                    shard_spec_stat["queries"] += B
+                    shard_spec_stat["failed"] += len(bad)
+                    pb_.note_shard_speculation(B, len(bad))
+                    if len(bad):
+                        shard_spec_stat["reran_batches"] += 1
+                        q0 = ((first + i) % len(batches)) * B
+                        last["rerun"] = searcher.dist_search_batch([queries[q0 + int(j)] for j in bad], [mgr] * len(bad),
+                                                                   mode=api.EXCHANGE_ALLGATHER | api.EXCHANGE_NO_SPECULATION)
+                    if record:
+                        lat.append(time.perf_counter() - t_start[i])
+                        stage["exchange_s"] += time.perf_counter() - te0
                         stage["steps"] += 1
                     continue
                 if lib_collective:
@@ -953,6 +1022,19 @@ def main():
     if not use_dist:
         for pb in batches:
             pb.run()
+
+    def stage_lists(bi_, keys, cnt, hits):
+        """The emulated exchange's W_e lists of batch bi_ from this rank's own (see e_keys above)."""
+        torch.bitwise_xor(keys[:mq_e].unsqueeze(0), e_tag, out=e_keys[bi_])
+        e_cnt[bi_].copy_(cnt[:mq_e].unsqueeze(0).expand(W_e, mq_e))
+        e_hits[bi_].copy_(hits[:mq_e].unsqueeze(0).expand(W_e, mq_e))
+
+    if use_dist and emu_exchange:
+        for bi_, pb in enumerate(batches):   # (outside the bound exchange: a shard's top-k is the same list with or without bounds)
+            keys, cnt, hits = bufs[0]
+            pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=-1)
+            stage_lists(bi_, keys, cnt, hits)
+        torch.cuda.synchronize()
     run_steps(0, args.warmup, False)
     ctx.reset_stats()
     import gc
@@ -1047,16 +1129,19 @@ def main():
             "sharding": "contiguous docid ranges, 1 process per GPU" + ((", RCCL all-to-all of per-GPU top-k, each rank merges its slice of the batch" if split_reduce else
                                                                            (", RCCL all-to-all of per-GPU top-k, each rank merges and delivers its slice of the batch" if (lib_collective and lib_mode == api.EXCHANGE_ALLTOALL)
                                                                             else ", RCCL all-gather of per-GPU top-k + merge on every rank")) if use_dist else "")
-                        + (f" (exchange stage emulated: merge of {shard_world} lists for {'this rank' + chr(39) + 's slice of the batch' if lib_mode == api.EXCHANGE_ALLTOALL else 'every query'})" if (use_dist and emu_exchange) else "")
+                        + (f" (exchange stage emulated: merge of {shard_world} lists for {'this rank' + chr(39) + 's slice of the batch' if lib_mode == api.EXCHANGE_ALLTOALL else 'every query'}; the other ranks' lists staged before the warmup, the transfer itself not in it)" if (use_dist and emu_exchange) else "")
                         + ((f" (collective inside the library: nrtgpu_dist_exchange_merge, {'all-to-all' if lib_mode == api.EXCHANGE_ALLTOALL else 'all-gather'})"
                             if lib_collective else ("" if emu_exchange else " (collective: torch.distributed)")) if use_dist else "")
                         + (", score-bound exchange between shards" if exchange_name else "")
+                        + (", shard-level speculative thresholds (guesses at the whole search's k-th score, checked against the merged lists)"
+                           if (shard_spec and (emu_exchange or lib_collective) and not args.sync_submit) else "")
                         + (f" (the other ranks' rows played by this process: --emulate-peers {args.emulate_peers})" if peer_words is not None else "")
                         + (f" [emulating rank {shard_rank} of {shard_world}]" if shard_world != world else ""),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
             "dynamic_pruning": not args.no_prune,
             "speculation": ctx.spec_counters(),   # speculative thresholds of the MaxScore route: queries run under them / run again
+            "shard_speculation": (shard_spec_stat if (shard_spec and use_dist) else None),   # ... checked against the MERGED lists (timed steps + warmup)
             "prefetch": not args.no_prefetch, "planner_threads": planner_threads, "host_cpus": usable_cpus(),
             "host_threads": n_thr, "host_cpus_busy": round(host_cpu_busy, 2), "host_cpus_busy_by_thread_kind": cpu_by_kind,
             "corpus_build_s": round(t_build, 1), "corpus_variant": args.corpus_variant,

@@ -310,6 +310,20 @@ int  nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* co
                                            int32_t k_stride, void* d_keys, void* d_counts, void* d_hits, int64_t epoch,
                                            nrtgpu_pending** out);
 int  nrtgpu_pending_wait(nrtgpu_pending* pending);
+/* One SHARD of a search that `spec_world` GPUs share by equal docid ranges (the multi-GPU form below, for callers that pipeline
+ * it themselves): as nrtgpu_search_bm25_batch_device_begin without an epoch, but the speculative thresholds of this call are
+ * guesses at the k-th score of the WHOLE search -- a shard's docs are a 1 / spec_world sample of the index, so after a fraction f
+ * of its windows it holds about k f / spec_world of the final top-k and the (that + z sd + 2)-th best key it has seen is the
+ * guess (csrc/maxscore.hip: ms_compact).  Every shard then collects about k / spec_world candidates instead of k and no bound
+ * travels between the GPUs while they walk.  A guess can only be checked against the MERGED list: the largest guess per query is
+ * left in d_guess (n_queries x u64 in HBM, 0: none) -- nrtgpu_dist_exchange_merge_checked takes it along, checks it and says
+ * which queries every shard has to run again (spec_world 0: without speculation).  The results are exact either way.
+ * nrtgpu_note_shard_speculation tells the leaf set's verdict (nrtgpu_stats.spec_*) how a batch went, for callers that do the
+ * check themselves; nrtgpu_dist_search_bm25_batch_mode does all of this itself. */
+int  nrtgpu_search_bm25_shard_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                           const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t k_stride, void* d_keys,
+                                           void* d_counts, void* d_hits, int32_t spec_world, void* d_guess, nrtgpu_pending** out);
+int  nrtgpu_note_shard_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int32_t n_queries, int32_t n_failed);
 /* Cross-GPU bound exchange (the LazyMaxScoreAccumulator idea across processes, SURVEY 8e "optional cross-GPU
  * theta sharing").  When one search is sharded over `world` GPUs, every shard alone would converge on the
  * k-th best of ITS docs.  With an exchange open, each shard publishes a score that at least
@@ -352,12 +366,22 @@ int  nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_s
  * ncclSend / ncclRecv, is gathered whole: nrtgpu_dist_owned_range says what a call will deliver. */
 #define NRTGPU_EXCHANGE_ALLGATHER 0
 #define NRTGPU_EXCHANGE_ALLTOALL 1
+#define NRTGPU_EXCHANGE_NO_SPECULATION 0x100   /* or-ed into nrtgpu_dist_search_bm25_batch_mode's mode: no shard-level guesses */
 int  nrtgpu_dist_owned_range(nrtgpu_ctx* ctx, int32_t n_queries, int32_t mode, int32_t* first_query, int32_t* n_owned);
 int  nrtgpu_dist_search_bm25_batch_mode(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                         const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t mode, nrtgpu_topdocs* out);
 int  nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
                                 const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, int32_t mode,
                                 nrtgpu_topdocs* out);
+/* The same with the shards' speculative thresholds (d_guess of nrtgpu_search_bm25_shard_device_begin; NULL: the call above): the
+ * guesses travel in the same grouped collective as the lists, and after the merge the k-th key of every merged list is checked
+ * against the largest guess any shard published for the query.  failed[n_queries] / *n_failed: the queries whose answer does
+ * NOT stand -- the same verdicts on every rank (all-to-all: the owners' verdicts are all-gathered, one byte per query) -- to be
+ * run again by EVERY rank without speculation (nrtgpu_dist_search_bm25_batch_mode with NRTGPU_EXCHANGE_NO_SPECULATION over
+ * those queries, in the same order on every rank). */
+int  nrtgpu_dist_exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
+                                        const void* d_hits, const void* d_guess, const int32_t* ks, const int32_t* total_hits_thresholds,
+                                        int32_t mode, nrtgpu_topdocs* out, uint8_t* failed, int32_t* n_failed);
 /* Exact vector search over a row-partitioned field (BASELINE config 4: 10M x 768 over 1..8 GPUs): every rank scores the rows of
  * ITS leaves (nrtgpu_knn_exact on its shard, results kept in HBM), the per-rank top-k lists are exchanged and merged like the
  * BM25 ones -- NrtKnnFloatVectorQuery's per-leaf merge (src/main/java/com/yelp/nrtsearch/server/query/vector/

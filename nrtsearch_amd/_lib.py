@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "nrtgpu_bm25_norm_cache", "nrtgpu_slices", "nrtgpu_plan_item_counts", "nrtgpu_fixed_point_scale", "nrtgpu_get_stats", "nrtgpu_reset_stats",
     "nrtgpu_set_slicing",
     "nrtgpu_blend", "nrtgpu_dist_unique_id", "nrtgpu_dist_init", "nrtgpu_dist_search_bm25_batch", "nrtgpu_dist_allgather_merge", "nrtgpu_segment_fork",
-    "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_knn_exact", "nrtgpu_dist_search_hybrid_batch",
+    "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_exchange_merge_checked", "nrtgpu_search_bm25_shard_device_begin", "nrtgpu_note_shard_speculation", "nrtgpu_dist_knn_exact", "nrtgpu_dist_search_hybrid_batch",
     "nrtgpu_knn_exact_relation", "nrtgpu_set_speculation", "nrtgpu_set_thread_slices",
 ]
 # what include/nrtgpu_dev.h adds: test hooks and measurement helpers of the development library (libnrtgpu_dev.so) only
@@ -217,6 +217,9 @@ def _open(path: str) -> C.CDLL:
     L.nrtgpu_dist_owned_range.argtypes = [vp, i32, i32, vp, vp]
     L.nrtgpu_dist_search_bm25_batch_mode.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_exchange_merge.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(TopDocs)]
+    L.nrtgpu_dist_exchange_merge_checked.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(TopDocs), vp, vp]
+    L.nrtgpu_search_bm25_shard_device_begin.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, vp, vp, vp, i32, vp, vp]
+    L.nrtgpu_note_shard_speculation.argtypes = [vp, vp, i32, i32, i32]
     L.nrtgpu_dist_knn_exact.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, C.c_float, i32, C.POINTER(TopDocs)]
     L.nrtgpu_dist_search_hybrid_batch.argtypes = [vp, vp, vp, i32, C.POINTER(Bm25Query), i32, i32, i32, vp, i32, C.c_float, C.c_double, C.c_double,
                                                   i32, i32, C.POINTER(TopDocs)]

@@ -34,6 +34,7 @@ TOTAL_HITS_THRESHOLD = 1000  # S/search/SearchRequestProcessor.java:102
 
 # ---- queries (only the shapes eligible for the device route) ------------------------
 EXCHANGE_ALLGATHER, EXCHANGE_ALLTOALL = 0, 1   # nrtgpu.h: NRTGPU_EXCHANGE_*
+EXCHANGE_NO_SPECULATION = 0x100               # ... or-ed into dist_search_batch's mode: no shard-level guesses
 
 
 @dataclasses.dataclass(frozen=True)
@@ -782,6 +783,21 @@ class PreparedBatch:
             C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits), int(epoch), C.byref(h)))
         return h.value
 
+    def begin_shard_device(self, k_stride: int, d_keys: int, d_counts: int, d_hits: int, spec_world: int, d_guess: int) -> int:
+        """begin_device for ONE SHARD of a search that `spec_world` GPUs share (nrtgpu_search_bm25_shard_device_begin): the
+        speculative thresholds are guesses at the whole search's k-th score, the largest per query is left in d_guess (n x u64 in
+        HBM) for the check against the merged list (PreparedMerge.run_dist_checked).  spec_world 0: no speculation."""
+        s = self.searcher
+        h = C.c_void_p()
+        _lib.check(_lib.load().nrtgpu_search_bm25_shard_device_begin(
+            s.ctx._h, s._segs, s._bases, len(s.leaves), self._m.queries, self.n, int(k_stride),
+            C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits), int(spec_world), C.c_void_p(d_guess or None), C.byref(h)))
+        return h.value
+
+    def note_shard_speculation(self, n_queries: int, n_failed: int) -> None:
+        s = self.searcher
+        _lib.check(_lib.load().nrtgpu_note_shard_speculation(s.ctx._h, s._segs, len(s.leaves), int(n_queries), int(n_failed)))
+
     @staticmethod
     def wait_device(handle: int) -> None:
         _lib.check(_lib.load().nrtgpu_pending_wait(C.c_void_p(handle)))
@@ -823,6 +839,27 @@ class PreparedMerge:
         _lib.check(_lib.load().nrtgpu_dist_exchange_merge(
             self.ctx._h, self.n, self.k_stride, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits),
             self._ks.ctypes.data, self._thr.ctypes.data, int(mode), self._outs))
+
+    def run_dist_checked(self, d_keys: int, d_counts: int, d_hits: int, d_guess: int, mode: int = EXCHANGE_ALLGATHER) -> np.ndarray:
+        """run_dist with the shards' speculative thresholds (PreparedBatch.begin_shard_device's d_guess) checked against the
+        merged lists (nrtgpu_dist_exchange_merge_checked) -> the indices of the queries EVERY rank has to run again without
+        speculation (the same on every rank)."""
+        failed = np.zeros(self.n, dtype=np.uint8)
+        n_failed = C.c_int32(0)
+        _lib.check(_lib.load().nrtgpu_dist_exchange_merge_checked(
+            self.ctx._h, self.n, self.k_stride, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_void_p(d_hits), C.c_void_p(d_guess),
+            self._ks.ctypes.data, self._thr.ctypes.data, int(mode), self._outs, failed.ctypes.data, C.byref(n_failed)))
+        return np.flatnonzero(failed) if n_failed.value else np.zeros(0, dtype=np.int64)
+
+    def kth_keys(self) -> np.ndarray:
+        """Per query the key -- (score bits << 32) | (0xFFFFFFFF - docid), as the device packs it (csrc/plan.h: pack_key) -- of
+        rank k of the merged list, 0 where the list is shorter: what a shard's guess is checked against (bench.py's emulated
+        exchange does the check itself; the library's is nrtgpu_dist_exchange_merge_checked)."""
+        n_hits = np.frombuffer(self._outs, dtype=np.int32).reshape(self.n, C.sizeof(_lib.TopDocs) // 4)[:, 0]
+        rows = np.arange(self.n)
+        col = self._ks.astype(np.int64) - 1
+        keys = (self.scores.view(np.uint32)[rows, col].astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - self.docs[rows, col].astype(np.uint64))
+        return np.where(n_hits >= self._ks, keys, np.uint64(0))
 
     def owned(self, qi: int) -> bool:
         return self._outs[qi].total_hits >= 0

@@ -18,7 +18,7 @@ typedef int (*RecvFn)(void*, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*CommDestroyFn)(NcclComm);
 typedef int (*GroupFn)(void);
 typedef const char* (*ErrStrFn)(int);
-const int kNcclInt32 = 2, kNcclInt64 = 4;   // rccl.h: ncclDataType_t
+const int kNcclInt8 = 0, kNcclInt32 = 2, kNcclInt64 = 4;   // rccl.h: ncclDataType_t
 
 struct Rccl {
   void* lib = nullptr;
@@ -66,6 +66,8 @@ struct nrtgpu_dist {
   hipEvent_t ev_wait = nullptr;   // NRTGPU_FLAG_BLOCKING_WAIT
   DevBuf local, gathered;   // [keys | hits | counts] of this rank / of every rank
   DevBuf stage;             // hybrid: the merged first pass and this rank's rescored windows
+  DevBuf my_guess;          // BM25: this rank's largest speculative threshold per query (nrtgpu_dist_search_bm25_batch_mode)
+  DevBuf guess;             // ... the verdicts on them: mine, then every rank's (all-to-all form)
   std::mutex mu;            // one collective (one user of `gathered`) at a time per communicator
   std::mutex call_mu;       // one whole search call (one user of `local`) at a time: taken before `mu`
 };
@@ -116,6 +118,8 @@ extern "C" void nrtgpu_dist_close(nrtgpu_ctx* ctx) {
   d->local.release();
   d->gathered.release();
   d->stage.release();
+  d->guess.release();
+  d->my_guess.release();
   delete d;
 }
 
@@ -135,6 +139,7 @@ struct Gathered {
   char* cnt = nullptr;
   char* hits = nullptr;
   int32_t first_q = 0, n_q = 0;   // the queries this rank merges
+  std::vector<uint64_t> guess;    // [world][n_q] the shards' largest speculative thresholds for them (host; empty: none travelled)
 };
 
 static void owned_range(int32_t world, int32_t rank, int32_t n_queries, int32_t mode, int32_t* first, int32_t* count) {
@@ -157,31 +162,37 @@ extern "C" int nrtgpu_dist_owned_range(nrtgpu_ctx* ctx, int32_t n_queries, int32
 }
 
 // (d->mu held by the caller)
+// d_guess (may be NULL): this rank's largest speculative threshold per query (search.cpp: search_bm25_shard_device); they travel in
+// the same group as the lists -- no collective, no wait of their own -- and arrive on the host in g->guess.
 static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
-                          const void* d_hits, int32_t mode, Gathered* g) {
+                          const void* d_hits, const void* d_guess, int32_t mode, Gathered* g) {
   Rccl* r = rccl();
   const size_t W = (size_t)d->world;
   if (mode == NRTGPU_EXCHANGE_ALLTOALL && !(r->send && r->recv)) mode = NRTGPU_EXCHANGE_ALLGATHER;
   owned_range(d->world, d->rank, n_queries, mode, &g->first_q, &g->n_q);
   const bool sliced = g->n_q != n_queries;
   const size_t nq = (size_t)g->n_q, kb = nq * (size_t)k_stride * 8, hb = nq * 8, cb = nq * 4;
-  if (int rc = d->gathered.reserve((kb + hb + ((cb + 7) & ~(size_t)7)) * W)) return rc;
+  const size_t cb8 = (cb + 7) & ~(size_t)7;
+  if (int rc = d->gathered.reserve((kb + hb + cb8 + hb) * W)) return rc;
   char* gb = (char*)d->gathered.p;
   g->keys = gb;
   g->hits = gb + W * kb;
   g->cnt = gb + W * (kb + hb);
+  char* gg = gb + W * (kb + hb + cb8);   // the guesses: [world][n_q] like the hit totals
   if (!sliced) {
     if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
     int rc1 = r->all_gather(d_keys, g->keys, kb / 8, kNcclInt64, d->comm, d->stream);
     int rc2 = r->all_gather(d_hits, g->hits, hb / 8, kNcclInt64, d->comm, d->stream);
     int rc3 = r->all_gather(d_counts, g->cnt, cb / 4, kNcclInt32, d->comm, d->stream);
+    int rc4 = d_guess ? r->all_gather(d_guess, gg, hb / 8, kNcclInt64, d->comm, d->stream) : 0;
     if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
-    if (rc1 || rc2 || rc3) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : rc3));
+    if (rc1 || rc2 || rc3 || rc4) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : (rc3 ? rc3 : rc4)));
   } else {
     // my lists for peer p's slice go to p; p's lists for my slice arrive as list p.  My own slice: a device copy.
     const char* lk = (const char*)d_keys;
     const char* lh = (const char*)d_hits;
     const char* lc = (const char*)d_counts;
+    const char* lg = (const char*)d_guess;
     int bad = 0;
     if (W > 1) {
       if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
@@ -193,6 +204,10 @@ static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, in
         bad |= r->recv(g->hits + (size_t)p * hb, hb / 8, kNcclInt64, p, d->comm, d->stream);
         bad |= r->send(lc + (size_t)p * cb, cb / 4, kNcclInt32, p, d->comm, d->stream);
         bad |= r->recv(g->cnt + (size_t)p * cb, cb / 4, kNcclInt32, p, d->comm, d->stream);
+        if (lg) {
+          bad |= r->send(lg + (size_t)p * hb, hb / 8, kNcclInt64, p, d->comm, d->stream);
+          bad |= r->recv(gg + (size_t)p * hb, hb / 8, kNcclInt64, p, d->comm, d->stream);
+        }
       }
       if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
       if (bad) return nccl_fail("ncclSend / ncclRecv", bad);
@@ -201,6 +216,12 @@ static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, in
     HIP_TRY(hipMemcpyAsync(g->keys + me * kb, lk + me * kb, kb, hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemcpyAsync(g->hits + me * hb, lh + me * hb, hb, hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemcpyAsync(g->cnt + me * cb, lc + me * cb, cb, hipMemcpyDeviceToDevice, d->stream));
+    if (lg) HIP_TRY(hipMemcpyAsync(gg + me * hb, lg + me * hb, hb, hipMemcpyDeviceToDevice, d->stream));
+  }
+  g->guess.clear();
+  if (d_guess) {
+    g->guess.resize(W * nq);
+    HIP_TRY(hipMemcpyAsync(g->guess.data(), gg, W * hb, hipMemcpyDeviceToHost, d->stream));
   }
   HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, d->stream, d->ev_wait));
   return NRTGPU_OK;
@@ -217,21 +238,68 @@ static void mark_not_owned(nrtgpu_topdocs* out, int32_t n_queries, const Gathere
     }
 }
 
-extern "C" int nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
-                                          const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, int32_t mode,
-                                          nrtgpu_topdocs* out) {
+// The exchange, TopDocs.merge of the shards' lists, and -- with d_guess -- the check of the shards' speculative thresholds against
+// the MERGED lists: the k-th key of a query's merged list must reach the largest guess any shard published for it; then nothing
+// any shard skipped could have entered (kernels.hip: merge_topk_kernel applies the same rule to one call's list).  failed
+// [n_queries]: the same verdicts on every rank (all-gather form: every rank holds every list and every guess; all-to-all: the
+// owners' verdicts are all-gathered, one byte per query).
+extern "C" int nrtgpu_dist_exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys,
+                                                  const void* d_counts, const void* d_hits, const void* d_guess, const int32_t* ks,
+                                                  const int32_t* total_hits_thresholds, int32_t mode, nrtgpu_topdocs* out,
+                                                  uint8_t* failed, int32_t* n_failed) {
   if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
   if (!d_keys || !d_counts || !d_hits || !ks || !total_hits_thresholds || !out || n_queries <= 0 || k_stride <= 0 || k_stride % 16 != 0)
     return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
+  if (d_guess && (!failed || !n_failed)) return fail(NRTGPU_ERR_INVALID_ARG, "guesses without a place for the verdicts");
   if (mode != NRTGPU_EXCHANGE_ALLGATHER && mode != NRTGPU_EXCHANGE_ALLTOALL) return fail(NRTGPU_ERR_INVALID_ARG, "unknown exchange mode %d", mode);
   nrtgpu_dist* d = ctx->dist;
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> lk(d->mu);   // one collective (and one user of the gathered buffer) at a time per communicator
   Gathered g;
-  if (int rc = exchange_lists(ctx, d, n_queries, k_stride, d_keys, d_counts, d_hits, mode, &g)) return rc;
+  if (int rc = exchange_lists(ctx, d, n_queries, k_stride, d_keys, d_counts, d_hits, d_guess, mode, &g)) return rc;
   mark_not_owned(out, n_queries, g);
-  return nrtgpu_merge_topk_device(ctx, d->world, g.n_q, k_stride, g.keys, g.cnt, g.hits, ks + g.first_q, total_hits_thresholds + g.first_q,
-                                  out + g.first_q);
+  if (int rc = nrtgpu_merge_topk_device(ctx, d->world, g.n_q, k_stride, g.keys, g.cnt, g.hits, ks + g.first_q, total_hits_thresholds + g.first_q,
+                                        out + g.first_q))
+    return rc;
+  if (n_failed) *n_failed = 0;
+  if (!d_guess) return NRTGPU_OK;
+  const size_t W = (size_t)d->world, nq = (size_t)g.n_q;
+  memset(failed, 0, (size_t)n_queries);
+  for (size_t q = 0; q < nq; ++q) {
+    uint64_t gmax = 0;
+    for (size_t w = 0; w < W; ++w) gmax = std::max(gmax, g.guess[w * nq + q]);
+    if (gmax == 0) continue;   // (nobody guessed)
+    const nrtgpu_topdocs& o = out[(size_t)g.first_q + q];
+    const int32_t k = ks[(size_t)g.first_q + q];
+    failed[(size_t)g.first_q + q] = (o.n_hits < k || pack_key(o.scores[k - 1], (uint32_t)o.docs[k - 1]) < gmax) ? 1 : 0;
+  }
+  if (g.n_q != n_queries) {   // (sliced: every rank learns every owner's verdicts; the slices are disjoint, so their OR is their union)
+    Rccl* r = rccl();
+    if (int rc = d->guess.reserve((size_t)n_queries * (W + 1))) return rc;
+    unsigned char* d_mine = (unsigned char*)d->guess.p;
+    unsigned char* d_all = d_mine + (size_t)n_queries;
+    std::vector<unsigned char> all((size_t)n_queries * W);
+    HIP_TRY(hipMemcpyAsync(d_mine, failed, (size_t)n_queries, hipMemcpyHostToDevice, d->stream));
+    if (int rc = r->group_start()) return nccl_fail("ncclGroupStart", rc);
+    const int rc1 = r->all_gather(d_mine, d_all, (size_t)n_queries, kNcclInt8, d->comm, d->stream);
+    if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
+    if (rc1) return nccl_fail("ncclAllGather", rc1);
+    HIP_TRY(hipMemcpyAsync(all.data(), d_all, all.size(), hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, d->stream, d->ev_wait));
+    for (size_t w = 0; w < W; ++w)
+      for (size_t q = 0; q < (size_t)n_queries; ++q) failed[q] |= all[w * (size_t)n_queries + q];
+  }
+  int32_t nf = 0;
+  for (int32_t q = 0; q < n_queries; ++q) nf += failed[q] != 0;
+  *n_failed = nf;
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
+                                          const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, int32_t mode,
+                                          nrtgpu_topdocs* out) {
+  return nrtgpu_dist_exchange_merge_checked(ctx, n_queries, k_stride, d_keys, d_counts, d_hits, nullptr, ks, total_hits_thresholds, mode, out, nullptr,
+                                            nullptr);
 }
 
 extern "C" int nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys,
@@ -257,6 +325,8 @@ extern "C" int nrtgpu_dist_search_bm25_batch_mode(nrtgpu_ctx* ctx, const nrtgpu_
                                                   const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t mode, nrtgpu_topdocs* out) {
   if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
   if (!queries || !out || n_queries <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
+  const bool no_spec = (mode & NRTGPU_EXCHANGE_NO_SPECULATION) != 0;
+  mode &= ~NRTGPU_EXCHANGE_NO_SPECULATION;
   nrtgpu_dist* d = ctx->dist;
   HIP_TRY(hipSetDevice(ctx->device));
   int32_t kmax = 1;
@@ -265,15 +335,62 @@ extern "C" int nrtgpu_dist_search_bm25_batch_mode(nrtgpu_ctx* ctx, const nrtgpu_
   std::lock_guard<std::mutex> call(d->call_mu);   // the local buffer is this call's until its exchange is over
   char *lk = nullptr, *lh = nullptr, *lc = nullptr;
   if (int rc = local_lists(d, n_queries, k_stride, &lk, &lh, &lc)) return rc;
-  // 1. this rank's shard: top-k per query stays in HBM (synchronous: complete when it returns)
-  if (int rc = nrtgpu_search_bm25_batch_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lk, lc, lh)) return rc;
-  // 2 + 3. the exchange over xGMI, TopDocs.merge of the shards' lists
   std::vector<int32_t> ks((size_t)n_queries), thr((size_t)n_queries);
   for (int32_t q = 0; q < n_queries; ++q) {
     ks[(size_t)q] = queries[q].k;
     thr[(size_t)q] = queries[q].total_hits_threshold;
   }
-  return nrtgpu_dist_exchange_merge(ctx, n_queries, k_stride, lk, lc, lh, ks.data(), thr.data(), mode, out);
+  // 1. this rank's shard: top-k per query stays in HBM (synchronous: complete when it returns).  Its speculative thresholds are
+  //    guesses at the k-th score of the WHOLE search (a shard's docs are a 1 / world sample of the index; search.cpp:
+  //    enqueue_search, spec_world): every rank converges on the global threshold from its own docs, collects about k / world
+  //    candidates instead of k, and nothing is exchanged for it.  A guess is only a guess: the largest one of any rank is checked
+  //    against the list merged over all ranks (step 2), and a query whose guess failed is run again on every rank without
+  //    speculation (step 3) -- the answer is exact either way.
+  const bool may_speculate = d->world > 1 && !no_spec;
+  uint64_t* d_guess = nullptr;
+  if (may_speculate) {
+    if (int rc = d->my_guess.reserve((size_t)n_queries * 8)) return rc;
+    d_guess = (uint64_t*)d->my_guess.p;
+  }
+  bool speculated = false;
+  if (int rc = search_bm25_shard_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lk, lc, lh, may_speculate ? d->world : 0, d_guess,
+                                        &speculated))
+    return rc;
+  // 2. the exchange over xGMI (the guesses ride in the same group), TopDocs.merge of the shards' lists, the check
+  std::vector<uint8_t> failed((size_t)n_queries, 0);
+  int32_t n_failed = 0;
+  if (int rc = nrtgpu_dist_exchange_merge_checked(ctx, n_queries, k_stride, lk, lc, lh, d_guess, ks.data(), thr.data(), mode, out,
+                                                  d_guess ? failed.data() : nullptr, d_guess ? &n_failed : nullptr))
+    return rc;
+  if (speculated) note_shard_speculation(ctx, segs, n_segs, n_queries, n_failed);   // (this rank's verdict on ITS leaf set)
+  if (n_failed == 0) return NRTGPU_OK;
+  // 3. the queries whose guess failed (the same ones on every rank): every rank runs them again on its shard without speculation;
+  //    the lists are gathered whole (a handful of queries: no point in slicing them) and the answers replace the first ones where
+  //    this rank holds them
+  std::vector<int32_t> again;
+  for (int32_t q = 0; q < n_queries; ++q)
+    if (failed[(size_t)q]) again.push_back(q);
+  std::vector<nrtgpu_bm25_query> rq(again.size());
+  std::vector<nrtgpu_topdocs> ro(again.size());
+  std::vector<int32_t> rks(again.size()), rthr(again.size());
+  for (size_t i = 0; i < again.size(); ++i) {
+    rq[i] = queries[again[i]];
+    ro[i] = out[again[i]];
+    rks[i] = rq[i].k;
+    rthr[i] = rq[i].total_hits_threshold;
+  }
+  if (int rc = local_lists(d, (int32_t)again.size(), k_stride, &lk, &lh, &lc)) return rc;
+  if (int rc = search_bm25_shard_device(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), k_stride, lk, lc, lh, 0, nullptr, nullptr)) return rc;
+  if (int rc = nrtgpu_dist_exchange_merge(ctx, (int32_t)rq.size(), k_stride, lk, lc, lh, rks.data(), rthr.data(), NRTGPU_EXCHANGE_ALLGATHER, ro.data()))
+    return rc;
+  for (size_t i = 0; i < again.size(); ++i)
+    if (out[again[i]].total_hits >= 0) {   // (mine: held after the first exchange)
+      nrtgpu_topdocs& o = out[again[i]];
+      o.n_hits = ro[i].n_hits;
+      o.total_hits = ro[i].total_hits;
+      o.total_hits_is_lower_bound = ro[i].total_hits_is_lower_bound;
+    }
+  return NRTGPU_OK;
 }
 
 extern "C" int nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
@@ -351,7 +468,7 @@ extern "C" int nrtgpu_dist_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg
     std::lock_guard<std::mutex> lk_(d->mu);
     // 2. the global first pass: every rank needs every merged list (its docs may be anywhere in it)
     Gathered g;
-    if (int rc = exchange_lists(ctx, d, n_queries, k_stride, lk, lc, lh, NRTGPU_EXCHANGE_ALLGATHER, &g)) return rc;
+    if (int rc = exchange_lists(ctx, d, n_queries, k_stride, lk, lc, lh, nullptr, NRTGPU_EXCHANGE_ALLGATHER, &g)) return rc;
     if (int rc = merge_lists_on_device(ctx, slot, d->world, n_queries, k_stride, g.keys, g.cnt, g.hits, ks.data(), mk, mc, mh)) return rc;
     HIP_TRY(hipStreamSynchronize(slot->stream));   // (`gathered` is free again)
   }

@@ -135,6 +135,38 @@ void WorkPool::run(int n, const std::function<void(int)>& fn) {
   jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));
 }
 
+Launcher::Launcher(int device) {
+  th = std::thread([this, device] {
+    (void)hipSetDevice(device);
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return;   // (stop, and nothing left to enqueue)
+        f = std::move(q.front());
+        q.pop_front();
+      }
+      f();
+    }
+  });
+}
+Launcher::~Launcher() {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = true;
+  }
+  cv.notify_all();
+  if (th.joinable()) th.join();
+}
+void Launcher::push(std::function<void()> f) {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    q.push_back(std::move(f));
+  }
+  cv.notify_one();
+}
+
 extern "C" const char* nrtgpu_version(void) { return "nrtgpu 0.1 (gfx950)"; }
 extern "C" const char* nrtgpu_last_error(void) { return g_last_error.c_str(); }
 extern "C" void nrtgpu_set_thread_deadline_ns(int64_t deadline_ns) { g_deadline_ns = deadline_ns; }
@@ -238,6 +270,7 @@ extern "C" int nrtgpu_exchange_open(nrtgpu_ctx* ctx, const char* shm_name, int32
 
 extern "C" void nrtgpu_destroy(nrtgpu_ctx* ctx) {
   if (!ctx) return;
+  ctx->launcher.reset();   // (joins: nothing is enqueued behind the streams' last synchronisation below)
   nrtgpu_dist_close(ctx);
   nrtgpu_exchange_close(ctx);
   (void)hipSetDevice(ctx->device);

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -442,6 +443,21 @@ class WorkPool {
 
 struct nrtgpu_dist;   // dist.cpp: RCCL communicator of this context (nrtgpu_dist_init)
 
+// The context's LAUNCHER: one thread that enqueues the searches begun with nrtgpu_search_bm25_*_begin, in the order they were begun
+// (search.cpp: device_begin_impl).  A submitting thread then only PLANS -- the plan of batch i + 1 is being built while batch i's
+// plan is packed, copied and its seven launches are issued (0.1 ms per 1024-query batch: a quarter of a step of one rank of an
+// 8-GPU job, whose scorer runs for 0.3 ms).  Created by the first _begin, joined by nrtgpu_destroy.
+struct Launcher {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  bool stop = false;
+  explicit Launcher(int device);
+  ~Launcher();
+  void push(std::function<void()> f);
+};
+
 struct nrtgpu_ctx {
   nrtgpu_config cfg{};
   nrtgpu_dist* dist = nullptr;
@@ -487,6 +503,8 @@ struct nrtgpu_ctx {
   // MyIndexSearcher.SlicingParams of the searcher this context serves (nrtgpu_set_slicing)
   std::atomic<int32_t> slice_max_docs{250000}, slice_max_segments{5}, virtual_shards{1};
   std::unique_ptr<nrtgpu::rt::WorkPool> pool;   // helper threads of the host side (planning, unpacking results)
+  std::mutex launcher_mu;
+  std::unique_ptr<Launcher> launcher;           // (search.cpp: device_begin_impl)
   // planner caches, one per leaf set seen lately (most recent first)
   std::mutex lsc_mu;
   std::vector<std::shared_ptr<nrtgpu::rt::LeafSetCache>> leaf_sets;
@@ -593,7 +611,13 @@ int knn_exact_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32
                      int32_t sim, const float* queries, int32_t n_queries, int32_t dim, int32_t k, float boost, int32_t k_stride,
                      void* d_keys, void* d_counts, void* d_hits);
 
-// ---- search (search.cpp): pieces of the hybrid path the multi-GPU entry reuses -------------------
+// ---- search (search.cpp): pieces the multi-GPU entry (dist.cpp) reuses ------------------------------
+// one shard's BM25 search with device-resident results and speculative thresholds guessed against the WHOLE search (search.cpp)
+int search_bm25_shard_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                             const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
+                             int32_t spec_world, void* d_guess, bool* speculated);
+// a call that ran under speculation has come back: count it for its leaf set (the verdict: search.cpp)
+void note_shard_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int64_t n_queries, int64_t n_failed);
 // TopDocs.merge of n_lists gathered lists per query (layout [list][query]) into DEVICE arrays (keys n_queries x k_stride, counts,
 // hit totals), enqueued on `slot`'s stream; the caller synchronises.
 int merge_lists_on_device(nrtgpu_ctx* ctx, Slot* slot, int32_t n_lists, int32_t n_queries, int32_t k_stride, const void* g_keys,

@@ -58,6 +58,10 @@ static void note_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int
   note_speculation_of(ctx, lsc.get(), n_queries, n_rerun);
 }
 
+void nrtgpu::rt::note_shard_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int64_t n_queries, int64_t n_failed) {
+  note_speculation(ctx, segs, n_segs, n_queries, n_failed);
+}
+
 // NRTGPU_MS_PERSISTENT=0 (development build): one workgroup per item + helper workgroups behind them (A/B)
 static bool ms_persistent() {
   static const bool v = dev_env_int("NRTGPU_MS_PERSISTENT", 1) != 0;
@@ -86,7 +90,13 @@ struct DeviceRun {
 // upload and expansion between any two scorer launches).
 static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
                           uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
-                          std::unique_lock<std::mutex>& gpu, int64_t epoch = -1, bool allow_spec = false) {
+                          std::unique_lock<std::mutex>& gpu, int64_t epoch = -1, bool allow_spec = false, int32_t spec_world = 1,
+                          uint64_t* ext_guess = nullptr) {
+  // spec_world > 1 (the library's multi-GPU search, dist.cpp): this call is ONE SHARD of a spec_world-way search over equal docid
+  // ranges, and its speculative thresholds are guesses at the k-th score of the WHOLE search -- a shard's docs are a 1 / world
+  // sample of the index, so the guess rule holds with the windows of all shards in its denominator.  Such a guess cannot be
+  // checked against this shard's list: the largest one per query goes to ext_guess and the caller checks it against the list
+  // merged over all shards (and runs a failed query again on every shard).
   const size_t n_items = hp.items.size();
   Carver pc;
   const size_t o_queries = pc.take(hp.queries.size() * sizeof(DQuery));
@@ -124,6 +134,10 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_qk, hp.q_k.data(), hp.q_k.size() * 4);
   memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
   if (!hp.q_wins.empty()) memcpy(hb + o_qwins, hp.q_wins.data(), hp.q_wins.size() * 4);
+  if (spec_world > 1) {   // the denominator of "how much of the query's docs have I seen": the windows of ALL shards
+    uint32_t* qw = (uint32_t*)(hb + o_qwins);
+    for (size_t i = 0; i < hp.q_wins.size(); ++i) qw[i] = (uint32_t)std::min<uint64_t>((uint64_t)qw[i] * (uint64_t)spec_world, 0xFFFFFFFFull);
+  }
   memset(hb + o_quant, 0, hp.list_idx.size() * 8);
   if (ext_hits) memcpy(hb + o_lower, hp.q_lower.data(), hp.q_lower.size() * 8);
   if (use_xch) {
@@ -288,7 +302,11 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)(wb + o_ikeys), (const uint32_t*)(wb + o_icnt),
                     (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
                     (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
-                    k_stride_out, n_help ? help.help_head : nullptr, help.help_next, help.slot_base, help.spec_g);
+                    k_stride_out, n_help ? help.help_head : nullptr, help.help_next, help.slot_base, spec_world > 1 ? nullptr : help.spec_g);
+  if (ext_guess) {   // (spec_world > 1: the guesses are checked by the caller, against the list merged over all shards)
+    if (spec) HIP_TRY(hipMemcpyAsync(ext_guess, wb + o_spec, (size_t)n_queries * 8, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemsetAsync(ext_guess, 0, (size_t)n_queries * 8, st));
+  }
   // TotalHits.relation by the reference's per-slice rule, tagged into the merged counts
   launch_slice_relation(st, (const uint32_t*)(wb + o_ssum), (const DQuery*)(db + o_queries), hp.n_slices, ohits, (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
@@ -1020,16 +1038,26 @@ struct nrtgpu_pending {
   // speculative thresholds (plan.h: kHitsSpecInvalid) on this path: the launch ran under them; nrtgpu_pending_wait reads the merged
   // counts' tags and, if a guess failed, runs the batch again without speculation into the same buffers before it returns
   bool speculated = false;
+  bool shard_spec = false;      // one shard of the library's multi-GPU search: guesses against the global k-th score, checked by dist.cpp
   uint32_t k_stride = 0;
   uint64_t* d_keys = nullptr;
   uint32_t* d_counts = nullptr;
   uint64_t* d_hits = nullptr;
+  // the enqueue of a search begun through the context's launcher thread (runtime_internal.h: Launcher): done, how it went (shared
+  // with the launcher's job: the handle may be freed the moment the job has said "done")
+  struct Enqueue {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int rc = 0;
+    std::string err;
+  };
+  std::shared_ptr<Enqueue> enq;   // null: enqueued by the thread that began it
 };
 
-extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
-                                                     int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits, int64_t epoch,
-                                                     nrtgpu_pending** out) {
+static int device_begin_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                             const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
+                             int64_t epoch, int32_t spec_world, uint64_t* d_guess, nrtgpu_pending** out, bool through_launcher = false) {
   if (!ctx || !queries || !d_keys || !d_counts || !d_hits || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   *out = nullptr;
   NRT_CHECK_DEADLINE("before the search was planned");
@@ -1054,17 +1082,50 @@ extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtg
   // Speculative thresholds here too (round 5): every shard of a multi-GPU search computes ITS top-k under them, the tags are read
   // in nrtgpu_pending_wait.  Not next to the cross-GPU bound exchange (epoch >= 0 with an exchange open: its quantile uses the
   // selection's second rank).
-  p->speculated = epoch < 0 && p->hp.lsc && spec_margin16(ctx) != 0u && (spec_sync_epoch(ctx, p->hp.lsc.get()), p->hp.lsc->spec_off.load(std::memory_order_relaxed) == 0) &&
+  // (spec_world: 1 = this call alone, checked and re-run in nrtgpu_pending_wait; >= 2 = one shard of that many, checked by the
+  //  caller; 0 = no speculation)
+  p->speculated = spec_world != 0 && epoch < 0 && p->hp.lsc && spec_margin16(ctx) != 0u && (spec_sync_epoch(ctx, p->hp.lsc.get()), p->hp.lsc->spec_off.load(std::memory_order_relaxed) == 0) &&
                   p->hp.n_ms_items != 0;
+  p->shard_spec = spec_world > 1;   // (then nrtgpu_pending_wait neither reads tags nor re-runs: the caller checks the guesses)
   p->k_stride = (uint32_t)k_stride;
   p->d_keys = (uint64_t*)d_keys;
   p->d_counts = (uint32_t*)d_counts;
   p->d_hits = (uint64_t*)d_hits;
+  static const bool use_launcher = dev_env_int("NRTGPU_LAUNCHER", 1) != 0;   // (development build: 0 = the caller enqueues, A/B)
+  if (through_launcher && use_launcher) {
+    // the caller goes on planning its next batch; the launcher packs and enqueues this one (in the order of the _begin calls).
+    // What the enqueue says is read by nrtgpu_pending_wait.
+    Launcher* l = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(ctx->launcher_mu);
+      if (!ctx->launcher) ctx->launcher = std::make_unique<Launcher>(ctx->device);
+      l = ctx->launcher.get();
+    }
+    nrtgpu_pending* pp = p.release();
+    std::shared_ptr<nrtgpu_pending::Enqueue> enq = pp->enq = std::make_shared<nrtgpu_pending::Enqueue>();
+    const int32_t sw = std::max(spec_world, 1);
+    l->push([pp, enq, n_queries, k_stride, epoch, sw, d_guess] {
+      DeviceRun run;
+      int rc;
+      {
+        std::unique_lock<std::mutex> gpu(pp->ctx->gpu_mu, std::defer_lock);
+        rc = enqueue_search(pp->ctx, pp->slot, pp->hp, n_queries, (uint32_t)k_stride, pp->d_keys, pp->d_counts, pp->d_hits, &run, gpu, epoch,
+                            pp->speculated, sw, d_guess);
+      }
+      std::lock_guard<std::mutex> lk(enq->mu);   // (from here on `pp` may be gone)
+      enq->rc = rc;
+      if (rc) enq->err = g_last_error;
+      enq->done = true;
+      enq->cv.notify_all();
+    });
+    *out = pp;
+    return NRTGPU_OK;
+  }
   DeviceRun run;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, p->slot, p->hp, n_queries, (uint32_t)k_stride, (uint64_t*)d_keys, (uint32_t*)d_counts,
-                                (uint64_t*)d_hits, &run, gpu, epoch, p->speculated)) {
+                                (uint64_t*)d_hits, &run, gpu, epoch, p->speculated, std::max(spec_world, 1), d_guess)) {
       (void)hipStreamSynchronize(p->slot->stream);   // whatever was enqueued reads the slot's buffers
       release_slot(ctx, p->slot);
       return rc;
@@ -1074,13 +1135,61 @@ extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtg
   return NRTGPU_OK;
 }
 
+extern "C" int nrtgpu_search_bm25_batch_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
+                                                     int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
+                                                     int32_t k_stride, void* d_keys, void* d_counts, void* d_hits, int64_t epoch,
+                                                     nrtgpu_pending** out) {
+  return device_begin_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts, d_hits, epoch, 1, nullptr, out, true);
+}
+
+extern "C" int nrtgpu_search_bm25_shard_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                                     const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t k_stride, void* d_keys,
+                                                     void* d_counts, void* d_hits, int32_t spec_world, void* d_guess, nrtgpu_pending** out) {
+  if (spec_world >= 2 && !d_guess) return fail(NRTGPU_ERR_INVALID_ARG, "a shard of %d needs a place for its guesses", spec_world);
+  if (spec_world < 0 || spec_world > 4096) return fail(NRTGPU_ERR_INVALID_ARG, "spec_world %d", spec_world);
+  return device_begin_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts, d_hits, -1, spec_world >= 2 ? spec_world : 0,
+                           (uint64_t*)d_guess, out, true);
+}
+
+extern "C" int nrtgpu_note_shard_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int32_t n_queries, int32_t n_failed) {
+  if (!ctx || (n_segs > 0 && !segs) || n_queries < 0 || n_failed < 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
+  nrtgpu::rt::note_shard_speculation(ctx, segs, n_segs, n_queries, n_failed);
+  return NRTGPU_OK;
+}
+
+extern "C" int nrtgpu_pending_wait(nrtgpu_pending* pending);
+// One shard of the library's multi-GPU search (dist.cpp): device-resident results as nrtgpu_search_bm25_batch_device, with the
+// speculative thresholds guessed against the WHOLE search's k-th score (spec_world shards of equal docid ranges) and the largest
+// guess per query left in d_guess (0: none) for the caller to check against the merged list.  spec_world <= 1: no speculation
+// at all (the re-run of the queries whose guess failed).  *speculated: whether guesses were made (the leaf set's verdict allows).
+int nrtgpu::rt::search_bm25_shard_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
+                                         const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t k_stride, void* d_keys, void* d_counts,
+                                         void* d_hits, int32_t spec_world, void* d_guess, bool* speculated) {
+  nrtgpu_pending* p = nullptr;
+  if (int rc = device_begin_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts, d_hits, -1, spec_world >= 2 ? spec_world : 0,
+                                 (uint64_t*)d_guess, &p))
+    return rc;
+  if (speculated) *speculated = p->speculated;
+  return nrtgpu_pending_wait(p);
+}
+
 extern "C" int nrtgpu_pending_wait(nrtgpu_pending* pending) {
   if (!pending) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   std::unique_ptr<nrtgpu_pending> p(pending);
   nrtgpu_ctx* ctx = p->ctx;
   (void)hipSetDevice(ctx->device);
+  if (p->enq) {   // begun through the launcher: its enqueue first
+    std::unique_lock<std::mutex> lk(p->enq->mu);
+    p->enq->cv.wait(lk, [&] { return p->enq->done; });
+    if (p->enq->rc) {
+      lk.unlock();
+      (void)hipStreamSynchronize(p->slot->stream);   // whatever was enqueued reads the slot's buffers
+      release_slot(ctx, p->slot);
+      return fail(p->enq->rc, "%s", p->enq->err.c_str());
+    }
+  }
   hipError_t e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
-  if (e == hipSuccess && p->speculated) {
+  if (e == hipSuccess && p->speculated && !p->shard_spec) {
     // the merge tagged the queries whose guess it could not confirm (kHitsSpecInvalid in the hit totals): read the totals, clear the
     // tags for the caller, and -- if any -- run the batch again without speculation into the same buffers (the plan and the
     // workspace are still this call's).  A re-run is a second pass of the batch; the leaf set's verdict bounds how often.
@@ -1173,7 +1282,7 @@ extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_
   const uint32_t* cnts = (const uint32_t*)(ho + o_ocnt);
   const uint64_t* hits = (const uint64_t*)(ho + o_ohits);
   {
-    const int n_chunks = n_queries >= 256 ? std::min(8, ctx->pool->helpers() + 1) : 1;
+    const int n_chunks = n_queries >= 64 ? std::min(std::min(8, n_queries / 32), ctx->pool->helpers() + 1) : 1;
     ctx->pool->run(n_chunks, [&](int c) {
       const int q0 = (int)((int64_t)n_queries * c / n_chunks), q1 = (int)((int64_t)n_queries * (c + 1) / n_chunks);
       for (int qi = q0; qi < q1; ++qi)

@@ -10,7 +10,8 @@
 #   pmc          rocprofv3 --pmc passes (each a run of its own): FETCH_SIZE of the default / exhaustive / packed lines, the SQ
 #                counters of the MaxScore kernel, FETCH_SIZE + matrix-core counters of the C4 sketch kernel -> <tag>_pmc.txt
 #   shapes       scripts/gpu_query_shapes.py (deletes, FILTER, MUST_NOT, minimumNumberShouldMatch, DisjunctionMax, hybrid tail)
-#   emulate8     one rank's share of an 8-GPU C3 job (bench.py --force-dist --emulate-world 8), peers' bounds present / silent
+#   emulate8     one rank's share of an 8-GPU C3 job (bench.py --force-dist --emulate-world 8): peers' bounds present / shard-level
+#                speculation / the shard on its own;  trace8: rocprofv3 --kernel-trace --stats of the speculation line
 #   c4           the full C4 lines (1 / 32 / 64 queries per pass)
 #   gather       scripts/ubench/gather_fetch under rocprofv3 --pmc FETCH_SIZE (what the counter tallies per access pattern)
 set -u
@@ -75,7 +76,16 @@ shapes)
 emulate8)
   el "one rank of eight"
   timeout 300 python bench.py --force-dist --emulate-world 8 --emulate-peers final --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8.json | show "1 of 8, peers' bounds present"
-  timeout 300 python bench.py --force-dist --emulate-world 8 --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8_silent.json | show "1 of 8, peers silent" ;;
+  timeout 300 python bench.py --force-dist --emulate-world 8 --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8_speculation.json | show "1 of 8, shard-level speculation (nothing travels)"
+  python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print('   shard speculation', d['config'].get('shard_speculation'), 'stages', d['config'].get('dist_stage_ms'))" $O/${TAG}_bench_emulate8_speculation.json
+  timeout 300 python bench.py --force-dist --emulate-world 8 --shard-bounds local --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8_silent.json | show "1 of 8, peers silent, the shard's own speculation only" ;;
+trace8)
+  el "kernel trace, one rank of eight"
+  rm -rf /tmp/prof8; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof8 -o t --output-format csv -- python $ROOT/bench.py --force-dist --emulate-world 8 --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 > /tmp/prof8_bench.log 2>&1 )
+  find /tmp/prof8 -name "*kernel_stats*" -exec cp {} $O/${TAG}_emulate8_kernel_stats.csv \;
+  python -c "
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])): print(r['Name'][:60].ljust(60), r['Calls'], round(float(r['AverageNs'])/1e3,1), 'us', r['Percentage'])" $O/${TAG}_emulate8_kernel_stats.csv | head -14 ;;
 c4)
   el "C4 lines"
   for q in 1 32 64; do timeout 400 python bench.py --workload C4 --knn-queries $q --steps 20 --warmup 4 2>/dev/null | tee $O/${TAG}_bench_c4_q$q.json | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('c4 q$q', d['value'], d['ms_per_step'], r['kernel'], r['avg_launch_ms'], 'frac', r['frac'], 'mfma', r['mfma_frac'], 'traffic', r['traffic'], 'verify', (d.get('verify') or {}).get('agrees_with_fp64'))"; done ;;

@@ -14,13 +14,14 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, sync_dir, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     n_docs, n_queries, k = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    variant = sys.argv[8] if len(sys.argv) > 8 else "iid"
     import numpy as np
 
     from nrtsearch_amd import api, synth, workload
 
     w = workload.Workload("two-rank dist test", n_docs, 4, k, n_queries, 4)
     qr = synth.make_queries(n_queries, w.n_terms, w.max_rank)
-    corpus = workload.build_shard_corpus(w, qr, world, rank)           # this rank's leaves, index-global statistics
+    corpus = workload.build_shard_corpus(w, qr, world, rank, variant=variant)   # this rank's leaves, index-global statistics
     ctx = api.GpuContext(0, max_batch=max(64, n_queries))
     leaves = []
     rng = np.random.default_rng(4242)                                  # the same rows on every rank: each keeps its docid range's
@@ -52,13 +53,51 @@ def main():
     mgr = api.TopScoreDocCollectorManager(k)
     out = {}
     for name, mode in (("allgather", api.EXCHANGE_ALLGATHER), ("alltoall", api.EXCHANGE_ALLTOALL)):
+        c0 = ctx.spec_counters()
         got = sr.dist_search_batch(queries, [mgr] * n_queries, mode=mode)
+        c1 = ctx.spec_counters()
         out["bm25_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in got]
+        out["spec_" + name] = {k_: c1[k_] - c0[k_] for k_ in ("queries", "reruns")}   # the shard-level guesses of this call
+        got = sr.dist_search_batch(queries, [mgr] * n_queries, mode=mode | api.EXCHANGE_NO_SPECULATION)
+        out["bm25_nospec_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in got]
+        if variant != "iid":
+            continue
         qv = all_vecs[:8] + np.float32(0.25)
         kn = sr.dist_knn_exact(1, "cosine", qv, 10, mode=mode)
         out["knn_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits) for g in kn]
         hy = sr.dist_search_hybrid_batch(queries[:8], [mgr] * 8, 1, "cosine", qv, 20, 1.0, 2.0, mode=mode)
         out["hybrid_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in hy]
+    # the same search as a caller that pipelines would run it (bench.py at N > 1): nrtgpu_search_bm25_shard_device_begin leaves this
+    # shard's lists and guesses in HBM, nrtgpu_dist_exchange_merge_checked exchanges, merges and checks them; what fails is run
+    # again by every rank without speculation
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+        assert hip.hipMemset(p, 0, C.c_size_t(nbytes)) == 0
+        return p.value
+
+    ks = (k + 15) // 16 * 16
+    d_keys, d_cnt, d_hits, d_guess = dmalloc(n_queries * ks * 8), dmalloc(n_queries * 4), dmalloc(n_queries * 8), dmalloc(n_queries * 8)
+    pb = api.PreparedBatch(sr, queries, [mgr] * n_queries)
+    for name, mode in (("allgather", api.EXCHANGE_ALLGATHER), ("alltoall", api.EXCHANGE_ALLTOALL)):
+        h = pb.begin_shard_device(ks, d_keys, d_cnt, d_hits, world, d_guess)
+        api.PreparedBatch.wait_device(h)
+        pm = api.PreparedMerge(ctx, world, n_queries, ks, [k] * n_queries, [api.TOTAL_HITS_THRESHOLD] * n_queries)
+        bad = pm.run_dist_checked(d_keys, d_cnt, d_hits, d_guess, mode)
+        pb.note_shard_speculation(n_queries, len(bad))
+        got = [pm.topdocs(qi) if pm.owned(qi) else None for qi in range(n_queries)]
+        if len(bad):
+            again = sr.dist_search_batch([queries[int(j)] for j in bad], [mgr] * len(bad), mode=api.EXCHANGE_ALLGATHER | api.EXCHANGE_NO_SPECULATION)
+            for i, j in enumerate(bad):
+                if got[int(j)] is not None:
+                    got[int(j)] = again[i]
+        out["bm25_pipelined_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in got]
+        out["pipelined_failed_" + name] = [int(j) for j in bad]
+    for p_ in (d_keys, d_cnt, d_hits, d_guess):
+        hip.hipFree(C.c_void_p(p_))
     out["stats"] = ctx.stats()
     with open(out_path, "wb") as f:
         pickle.dump(out, f)

@@ -34,7 +34,12 @@ def mockrccl(tmp_path_factory):
     return str(d)
 
 
-def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrccl):
+@pytest.mark.parametrize("variant", ["iid", "sorted"])
+def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrccl, variant):
+    """variant "iid": every posting list an independent draw -- a shard IS a sample of the index, the shards' speculative
+    thresholds (guesses at the WHOLE search's k-th score, search.cpp: spec_world) stand.  "sorted": docs numbered by length, so
+    rank 0's docid range holds the short docs and with them most of every top-k -- its guesses are too high, the check against
+    the merged lists catches them and every rank runs those queries again: the answers are the whole-index answers either way."""
     from nrtsearch_amd import api
 
     world, n_docs, n_q, k = 2, 600_000, 32, 100
@@ -43,7 +48,7 @@ def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrcc
     env = dict(os.environ, LD_LIBRARY_PATH=mockrccl + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     env.pop("NRTGPU_LIB_PATH", None)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(r), str(world), sync_dir, outs[r],
-                               str(n_docs), str(n_q), str(k)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                               str(n_docs), str(n_q), str(k), variant], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     try:
         for p in procs:
@@ -59,7 +64,7 @@ def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrcc
     # the whole index in ONE context: what the merged answers must equal
     w = workload.Workload("two-rank dist test", n_docs, 4, k, n_q, 4)
     qr = synth.make_queries(n_q, w.n_terms, w.max_rank)
-    pieces = [workload.build_shard_corpus(w, qr, world, r) for r in range(world)]
+    pieces = [workload.build_shard_corpus(w, qr, world, r, variant=variant) for r in range(world)]
     ctx = api.GpuContext(0, max_batch=64)
     rng = np.random.default_rng(4242)
     dim = 32
@@ -89,7 +94,25 @@ def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrcc
                 assert got[3] == exp.relation_gte
                 assert got[2] > 0 if exp.relation_gte else got[2] == exp.total_hits   # (GTE: each shard's lower bound, summed)
 
-        for what, exp_list, rel in (("bm25", whole, True), ("knn", whole_knn, False), ("hybrid", whole_hy, True)):
+        # the shards speculated (every rank the same verdicts: the re-runs are collective calls); a shard that is no sample of the
+        # index had its guesses caught
+        for r in range(world):
+            for form in ("allgather", "alltoall"):
+                sp = ranks[r]["spec_" + form]
+                assert sp == ranks[0]["spec_" + form] or sp["queries"] == 0 or ranks[0]["spec_" + form]["queries"] == 0, (r, form, sp)
+        print("shard-level speculation", variant, [(ranks[r]["spec_allgather"], ranks[r]["spec_alltoall"]) for r in range(world)])
+        assert any(ranks[r]["spec_allgather"]["queries"] == n_q for r in range(world)), [ranks[r]["spec_allgather"] for r in range(world)]
+        reruns = max(ranks[r]["spec_allgather"]["reruns"] for r in range(world))
+        assert (reruns <= 2) if variant == "iid" else (reruns >= 1), reruns
+        # (the pipelined form: both ranks must have been told the same queries to run again)
+        for form in ("allgather", "alltoall"):
+            assert ranks[0]["pipelined_failed_" + form] == ranks[1]["pipelined_failed_" + form]
+        if variant == "sorted":
+            assert len(ranks[0]["pipelined_failed_allgather"]) >= 1
+        cases = [("bm25", whole, True), ("bm25_nospec", whole, True), ("bm25_pipelined", whole, True)]
+        if variant == "iid":
+            cases += [("knn", whole_knn, False), ("hybrid", whole_hy, True)]
+        for what, exp_list, rel in cases:
             n = len(exp_list)
             # all-gather: every rank holds every answer
             for r in range(world):

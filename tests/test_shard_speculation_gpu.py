@@ -1,0 +1,102 @@
+"""SHARD-LEVEL speculative thresholds (include/nrtgpu.h: nrtgpu_search_bm25_shard_device_begin): one search shared by W
+GPUs in equal docid ranges, every shard guessing the k-th score of the WHOLE search from its own docs -- a 1 / W sample of the
+index -- so that it collects about k / W candidates instead of k, with nothing exchanged while the shards walk.  A guess is checked
+against the list MERGED over the shards (the k-th merged key must reach the largest guess any shard published), and a query whose
+guess fails is run again on every shard without speculation.
+
+The pool has one GPU: the W shards are played one after another on it, each in a context of its own over ITS leaves with
+index-global statistics -- the same calls a rank of a W-GPU job makes, the lists "exchanged" by copying them side by side.  What
+must hold: the merged answers are the whole-index answers (docids, ranks, score bits; the relation; totalHits exact where the
+relation is EQUAL_TO) on a corpus whose shards are samples of the index AND on one whose shards are not (docs numbered by length:
+the first shard holds the short docs and most of every top-k; its guesses are too high and must be caught).  Needs a real
+MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nrtsearch_amd import api, synth, workload
+
+pytestmark = pytest.mark.gpu
+
+
+def play_shards(w, qr, world, variant, spec_world, k, queries=None):
+    """Every shard's device-resident lists and guesses, gathered [list][query] as the exchange leaves them -> torch tensors."""
+    import torch
+
+    n_q = len(qr)
+    k_stride = (k + 15) // 16 * 16
+    keys = torch.zeros((world, n_q, k_stride), dtype=torch.int64, device="cuda")
+    cnt = torch.zeros((world, n_q), dtype=torch.int32, device="cuda")
+    hits = torch.zeros((world, n_q), dtype=torch.int64, device="cuda")
+    guess = torch.zeros((world, n_q), dtype=torch.int64, device="cuda")
+    counters = []
+    for r in range(world):
+        corpus = workload.build_shard_corpus(w, qr, world, r, variant=variant)
+        ctx = api.GpuContext(0, max_batch=max(64, n_q))
+        leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+        sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+        try:
+            pb = api.PreparedBatch(sr, queries if queries is not None else workload.boolean_queries(qr), [api.TopScoreDocCollectorManager(k)] * n_q)
+            h = pb.begin_shard_device(k_stride, keys[r].data_ptr(), cnt[r].data_ptr(), hits[r].data_ptr(), spec_world, guess[r].data_ptr() if spec_world else 0)
+            api.PreparedBatch.wait_device(h)
+            torch.cuda.synchronize()
+            counters.append(ctx.stats())
+        finally:
+            for g in leaves:
+                g.release()
+            ctx.close()
+    return keys, cnt, hits, guess, k_stride, counters
+
+
+@pytest.mark.parametrize("variant,world", [("iid", 8), ("iid", 2), ("sorted", 4), ("clustered", 4)])
+def test_shards_guessing_the_global_threshold_merge_to_the_whole_index_answer(variant, world):
+    import torch
+
+    n_docs, n_q, k = 2_400_000, 64, 200
+    w = workload.Workload("shard speculation test", n_docs, 4, k, n_q, 3, max_rank=3000)
+    qr = synth.make_queries(n_q, w.n_terms, w.max_rank)
+    queries = workload.boolean_queries(qr)
+    mgr = api.TopScoreDocCollectorManager(k)
+    # the whole index in one context: what the merged answers must equal
+    pieces = [workload.build_shard_corpus(w, qr, world, r, variant=variant) for r in range(world)]
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves = [api.GpuSegment.from_data(ctx, s) for c in pieces for s in c.segments]
+    try:
+        ctx.set_speculation(0)
+        whole = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(pieces[0])).search_batch(queries, [mgr] * n_q)
+        del pieces
+        keys, cnt, hits, guess, k_stride, _ = play_shards(w, qr, world, variant, world, k, queries)
+        g = guess.cpu().numpy().view(np.uint64)
+        assert (g != 0).any(), "no shard speculated"
+        merged = api.PreparedMerge(ctx, world, n_q, k_stride, [k] * n_q, [api.TOTAL_HITS_THRESHOLD] * n_q)
+        merged.run(keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())
+        gmax = g.max(axis=0)
+        failed = np.flatnonzero((gmax != 0) & (merged.kth_keys() < gmax))   # (nrtgpu_dist_exchange_merge_checked's rule)
+        print(f"shard speculation {variant} x{world}: {int((gmax != 0).sum())} of {n_q} queries guessed, {len(failed)} failed the check")
+        if variant == "iid":
+            assert len(failed) <= 1, failed
+        if variant == "sorted":
+            assert len(failed) >= n_q // 4, "a shard that holds most of every top-k guessed too high and nobody noticed?"
+        got = [merged.topdocs(qi) for qi in range(n_q)]
+        if len(failed):   # every shard runs them again without speculation; the lists are merged again
+            sub = [queries[int(j)] for j in failed]
+            keys2, cnt2, hits2, _, _, _ = play_shards(w, qr[failed], world, variant, 0, k, sub)
+            again = api.PreparedMerge(ctx, world, len(failed), k_stride, [k] * len(failed), [api.TOTAL_HITS_THRESHOLD] * len(failed))
+            again.run(keys2.data_ptr(), cnt2.data_ptr(), hits2.data_ptr())
+            for i, j in enumerate(failed):
+                got[int(j)] = again.topdocs(i)
+        # a guess that PASSED the check left an exact answer; a failed one was replaced by an exact one
+        for qi in range(n_q):
+            e, t = whole[qi], got[qi]
+            assert t.docs.tolist() == e.docs.tolist(), f"query {qi}: docids / ranks"
+            assert t.scores.view(np.uint32).tolist() == e.scores.view(np.uint32).tolist(), f"query {qi}: score bits"
+            assert t.relation_gte == e.relation_gte or t.relation_gte, f"query {qi}: relation"
+            if not t.relation_gte:
+                assert t.total_hits == e.total_hits, f"query {qi}: totalHits"
+        del keys, cnt, hits, guess
+        torch.cuda.empty_cache()
+    finally:
+        for g_ in leaves:
+            g_.release()
+        ctx.close()
