@@ -347,7 +347,14 @@ struct nrtgpu_seg {
   void content_unlock_shared() const;       // may free the handle (content_released)
   std::map<int32_t, std::vector<uint64_t>> masks;
   mutable std::mutex accept_mu;
-  mutable std::map<std::vector<int32_t>, uint64_t*> accept;   // key: the filter mask ids ascending, 0, the must_not mask ids ascending
+  struct AcceptSet { uint64_t* bits; uint64_t used; };        // used: the cache's clock at the last lookup (least recently used goes first)
+  mutable std::map<std::vector<int32_t>, AcceptSet> accept;   // key: the filter mask ids ascending, 0, the must_not mask ids ascending
+  mutable uint64_t accept_clock = 0;
+  mutable std::vector<uint64_t*> accept_retired;              // evicted, maybe still read by a search in flight: freed by the last reader out
+  bool accept_retired_empty() const {
+    std::lock_guard<std::mutex> lk(accept_mu);
+    return accept_retired.empty();
+  }
 };
 
 // Exclusive ownership of a segment's content (liveDocs, masks, the posting columns' liveness coding).

@@ -31,10 +31,14 @@ void nrtgpu_seg::content_lock_shared(bool pipelined) const {
   content_cv.wait(lk, [&] { return !content_writing && (content_writers_waiting == 0 || (pipelined && content_readers > 0)); });
   content_readers++;
 }
+static void free_retired_accept_sets(const nrtgpu_seg* seg);
 void nrtgpu_seg::content_unlock_shared() const {
   bool last_of_released = false;
   {
     std::lock_guard<std::mutex> lk(content_m);
+    // the last reader out frees what the accept-set cache evicted while searches were in flight (under content_m: a search that
+    // begins now cannot have been handed one of those sets -- they left the cache before they were retired)
+    if (content_readers == 1 && !accept_retired_empty()) free_retired_accept_sets(this);
     content_readers--;
     // nrtgpu_segment_release came while this search ran: the last user frees (a writer that still waits counts as one: it is
     // woken below and frees in ~SegWriteLock)
@@ -47,13 +51,34 @@ void nrtgpu_seg::content_unlock_shared() const {
 static const size_t kMaxAcceptSets = 64;   // combined accept sets (liveDocs & filter & ~must_not) resident per segment
 static const size_t kMaskPadBytes = 256;  // doc-set masks are readable one sub-tile (128 bytes) past max_doc
 
+static const size_t kMaxRetiredAcceptSets = 64;   // evicted sets that wait for the searches in flight to end (then: refuse instead of evict)
+
+// (no search is in flight over the handle: the caller holds the content exclusively, or is its last reader, or destroys it)
 static void drop_accept_sets(nrtgpu_seg* seg) {
   std::lock_guard<std::mutex> lk(seg->accept_mu);
+  const int64_t set_bytes = (int64_t)((seg->max_doc + 63) / 64) * 8;
   for (auto& kv : seg->accept) {
-    (void)hipFree(kv.second);
-    seg->device_bytes -= (int64_t)((seg->max_doc + 63) / 64) * 8;
+    (void)hipFree(kv.second.bits);
+    seg->device_bytes -= set_bytes;
   }
   seg->accept.clear();
+  for (uint64_t* p : seg->accept_retired) {
+    (void)hipFree(p);
+    seg->device_bytes -= set_bytes;
+  }
+  seg->accept_retired.clear();
+}
+// The last search in flight over the handle has ended: what the cache evicted while searches ran can go.
+static void free_retired_accept_sets(const nrtgpu_seg* seg) {
+  std::vector<uint64_t*> gone;
+  {
+    std::lock_guard<std::mutex> lk(seg->accept_mu);
+    gone.swap(seg->accept_retired);
+    const_cast<nrtgpu_seg*>(seg)->device_bytes -= (int64_t)gone.size() * (int64_t)((seg->max_doc + 63) / 64) * 8;
+  }
+  if (gone.empty()) return;
+  (void)hipSetDevice(seg->ctx->device);
+  for (uint64_t* p : gone) (void)hipFree(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -646,14 +671,25 @@ static int accept_set_of_ids(const nrtgpu_seg* seg, std::vector<int32_t> filters
   std::lock_guard<std::mutex> lk(seg->accept_mu);
   auto it = seg->accept.find(key);
   if (it != seg->accept.end()) {
-    *out = it->second;
+    it->second.used = ++seg->accept_clock;
+    *out = it->second.bits;
     return 0;
   }
-  // Bounded like the reference's LRUQueryCache -- but an entry may be in use by a search in flight, so the bound refuses
-  // rather than evicts: further (filter, must_not) combinations of this leaf run on the caller's own path until liveDocs
-  // or a mask change (which drops every set).
-  if (seg->accept.size() >= kMaxAcceptSets)
-    return fail(NRTGPU_ERR_UNSUPPORTED, "%zu combined doc sets are resident on a segment already", seg->accept.size());
+  // Bounded like the reference's LRUQueryCache, and like it the least recently used set makes room -- but a set
+  // may be in use by a search in flight (the caller's own plan included: it holds the content like every search), so an evicted
+  // set is RETIRED: out of the cache at once, freed by the last search to leave the handle (content_unlock_shared).  Only when
+  // as many retired sets wait as the cache holds -- a handle that is never idle, under more combinations than it can keep -- the
+  // bound refuses, and that combination runs on the caller's own path.
+  if (seg->accept.size() >= kMaxAcceptSets) {
+    if (seg->accept_retired.size() >= kMaxRetiredAcceptSets)
+      return fail(NRTGPU_ERR_UNSUPPORTED, "%zu combined doc sets are resident on a segment and %zu evicted ones wait for searches in flight",
+                  seg->accept.size(), seg->accept_retired.size());
+    auto lru = seg->accept.begin();
+    for (auto a = seg->accept.begin(); a != seg->accept.end(); ++a)
+      if (a->second.used < lru->second.used) lru = a;
+    seg->accept_retired.push_back(lru->second.bits);
+    seg->accept.erase(lru);
+  }
   std::vector<const std::vector<uint64_t>*> f, mn;
   for (int32_t id : filters) {
     auto m = seg->masks.find(id);
@@ -681,7 +717,7 @@ static int accept_set_of_ids(const nrtgpu_seg* seg, std::vector<int32_t> filters
     return fail(NRTGPU_ERR_HIP, "upload of an accept set failed");
   }
   const_cast<nrtgpu_seg*>(seg)->device_bytes += (int64_t)need * 8;
-  seg->accept[key] = (uint64_t*)p;
+  seg->accept[key] = nrtgpu_seg::AcceptSet{(uint64_t*)p, ++seg->accept_clock};
   *out = (uint64_t*)p;
   return 0;
 }

@@ -11,7 +11,8 @@
 #                counters of the MaxScore kernel, FETCH_SIZE + matrix-core counters of the C4 sketch kernel -> <tag>_pmc.txt
 #   shapes       scripts/gpu_query_shapes.py (deletes, FILTER, MUST_NOT, minimumNumberShouldMatch, DisjunctionMax, hybrid tail)
 #   emulate8     one rank's share of an 8-GPU C3 job (bench.py --force-dist --emulate-world 8): peers' bounds present / shard-level
-#                speculation / the shard on its own;  trace8: rocprofv3 --kernel-trace --stats of the speculation line
+#                speculation / the shard on its own;  trace8: rocprofv3 --kernel-trace --stats of the speculation line;
+#                emulate24: the same for one rank of two / of four (peers' bounds present, shard-level speculation)
 #   c4           the full C4 lines (1 / 32 / 64 queries per pass)
 #   gather       scripts/ubench/gather_fetch under rocprofv3 --pmc FETCH_SIZE (what the counter tallies per access pattern)
 set -u
@@ -79,6 +80,12 @@ emulate8)
   timeout 300 python bench.py --force-dist --emulate-world 8 --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8_speculation.json | show "1 of 8, shard-level speculation (nothing travels)"
   python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print('   shard speculation', d['config'].get('shard_speculation'), 'stages', d['config'].get('dist_stage_ms'))" $O/${TAG}_bench_emulate8_speculation.json
   timeout 300 python bench.py --force-dist --emulate-world 8 --shard-bounds local --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate8_silent.json | show "1 of 8, peers silent, the shard's own speculation only" ;;
+emulate24)
+  el "one rank of two / of four"
+  for W in 2 4; do
+    timeout 400 python bench.py --force-dist --emulate-world $W --emulate-peers final --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate${W}.json | show "1 of $W, peers' bounds present"
+    timeout 400 python bench.py --force-dist --emulate-world $W --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 2>/dev/null | tee $O/${TAG}_bench_emulate${W}_speculation.json | show "1 of $W, shard-level speculation"
+  done ;;
 trace8)
   el "kernel trace, one rank of eight"
   rm -rf /tmp/prof8; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof8 -o t --output-format csv -- python $ROOT/bench.py --force-dist --emulate-world 8 --steps 100 --warmup 10 --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --submitters 1 > /tmp/prof8_bench.log 2>&1 )

@@ -141,6 +141,75 @@ def test_several_filter_and_must_not_clauses(ctx):
         ix.close()
 
 
+def test_more_combinations_than_the_accept_set_cache_holds(ctx):
+    """The resident combined doc sets of a leaf are a bounded cache (64 per leaf, like the reference's LRUQueryCache bounds its
+    entries): the least recently used combination makes room (an evicted set may still be read by a search in flight, so it is
+    freed by the last search to leave the handle -- segment.cpp: accept_set_of_ids), instead of every new combination being
+    refused once the cache is full.  150 distinct combinations of 8 masks, then the first ones again: every
+    answer is the oracle's, and the leaves hold at most 64 sets afterwards."""
+    import itertools
+
+    ranks = [2, 30, 700]
+    corpus = synth.build_corpus(60_000, ranks, n_segments=2, delete_fraction=0.01)
+    ix = Index(ctx, corpus)
+    try:
+        masks = {}
+        ids = list(range(11, 19))
+        for si, (seg, leaf) in enumerate(zip(corpus.segments, ix.leaves)):
+            for mid in ids:
+                masks[(si, mid)] = random_mask(seg.max_doc, 0.5 + 0.05 * (mid - 11), 77 * mid + si)
+                leaf.set_mask(mid, masks[(si, mid)])
+        b_masks = [l.device_bytes for l in ix.leaves]
+        should = tuple(api.TermQuery(0, r) for r in ranks)
+
+        def acc_of(f, mn):
+            out = []
+            for si, seg in enumerate(corpus.segments):
+                n = (seg.max_doc + 63) // 64
+                a = np.full(n, ~np.uint64(0), dtype=np.uint64) if seg.live_bits is None else seg.live_bits[:n].copy()
+                for i in f:
+                    a &= masks[(si, i)][:n]
+                for i in mn:
+                    a &= ~masks[(si, i)][:n]
+                out.append(a)
+            return out
+
+        combos = ([((a,), (b,)) for a, b in itertools.permutations(ids, 2)] +
+                  [((a, b), (c,)) for a, b in itertools.combinations(ids, 2) for c in ids if c not in (a, b)])[:150]
+        assert len(set(combos)) == 150
+        for f, mn in combos + combos[:10]:
+            q = api.BooleanQuery(should, 1, tuple(api.MaskFilter(i) for i in f), tuple(api.MaskFilter(i) for i in mn))
+            got = ix.searcher.search(q, api.TopScoreDocCollectorManager(20))
+            assert_same(f"lru_{f}_{mn}", got, oracle.search_bm25(corpus, ranks, 20, accept=acc_of(f, mn)), 20, 1000)
+        for l, b0, seg in zip(ix.leaves, b_masks, corpus.segments):
+            set_bytes = (seg.max_doc + 63) // 64 * 8
+            assert l.device_bytes - b0 <= 64 * set_bytes, (l.device_bytes - b0, set_bytes)   # (the evicted ones were freed: nothing was in flight)
+        # the same while a search is IN FLIGHT over the leaves (begun, not waited for): its combination is evicted by the 70 that
+        # follow -- retired, not freed -- its answer is still the oracle's, and the retired sets are gone once it has left
+        import torch
+        f0, mn0 = combos[120]
+        q0 = api.BooleanQuery(should, 1, tuple(api.MaskFilter(i) for i in f0), tuple(api.MaskFilter(i) for i in mn0))
+        pb = api.PreparedBatch(ix.searcher, [q0], [api.TopScoreDocCollectorManager(20)])
+        keys = torch.zeros((1, 32), dtype=torch.int64, device="cuda")
+        cnt = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        hits = torch.zeros((1,), dtype=torch.int64, device="cuda")
+        h = pb.begin_device(32, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())
+        for f, mn in combos[:70]:
+            q = api.BooleanQuery(should, 1, tuple(api.MaskFilter(i) for i in f), tuple(api.MaskFilter(i) for i in mn))
+            got = ix.searcher.search(q, api.TopScoreDocCollectorManager(20))
+            assert_same(f"lru_in_flight_{f}_{mn}", got, oracle.search_bm25(corpus, ranks, 20, accept=acc_of(f, mn)), 20, 1000)
+        api.PreparedBatch.wait_device(h)
+        torch.cuda.synchronize()
+        kk = keys.cpu().numpy().view(np.uint64)[0, : int(cnt.cpu()[0])]
+        edocs, escores, _, _ = oracle.search_bm25(corpus, ranks, 20, accept=acc_of(f0, mn0))
+        assert (0xFFFFFFFF - (kk & np.uint64(0xFFFFFFFF))).astype(np.int64).tolist() == edocs.tolist()
+        assert (kk >> np.uint64(32)).astype(np.uint32).tolist() == escores.view(np.uint32).tolist()
+        for l, b0, seg in zip(ix.leaves, b_masks, corpus.segments):
+            assert l.device_bytes - b0 <= 64 * ((seg.max_doc + 63) // 64 * 8)
+    finally:
+        ix.close()
+
+
 def test_mask_errors(ctx):
     corpus = synth.build_corpus(5_000, [3, 50], n_segments=1)
     ix = Index(ctx, corpus)
