@@ -15,6 +15,7 @@ def main():
     rank, world, sync_dir, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     n_docs, n_queries, k = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     variant = sys.argv[8] if len(sys.argv) > 8 else "iid"
+    host_only = os.environ.get("NRTGPU_TEST_HOST_ONLY") == "1"   # tests/test_dist_two_ranks_host.py: against tests/mockhip, BM25 only
     import numpy as np
 
     from nrtsearch_amd import api, synth, workload
@@ -31,7 +32,8 @@ def main():
         g = api.GpuSegment(ctx, seg.max_doc, seg.doc_base)
         g.add_field_norms(0, seg.norms)
         g.add_terms(0, seg.term_ids, seg.offsets, seg.docids, seg.freqs)
-        g.add_vectors(1, all_vecs[seg.doc_base: seg.doc_base + seg.max_doc])
+        if not host_only:
+            g.add_vectors(1, all_vecs[seg.doc_base: seg.doc_base + seg.max_doc])
         g.seal()
         leaves.append(g)
     sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
@@ -60,7 +62,7 @@ def main():
         out["spec_" + name] = {k_: c1[k_] - c0[k_] for k_ in ("queries", "reruns")}   # the shard-level guesses of this call
         got = sr.dist_search_batch(queries, [mgr] * n_queries, mode=mode | api.EXCHANGE_NO_SPECULATION)
         out["bm25_nospec_" + name] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in got]
-        if variant != "iid":
+        if variant != "iid" or host_only:
             continue
         qv = all_vecs[:8] + np.float32(0.25)
         kn = sr.dist_knn_exact(1, "cosine", qv, 10, mode=mode)
@@ -71,7 +73,7 @@ def main():
     # shard's lists and guesses in HBM, nrtgpu_dist_exchange_merge_checked exchanges, merges and checks them; what fails is run
     # again by every rank without speculation
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    hip = C.CDLL(os.environ.get("NRTGPU_TEST_HIP_LIB", "libamdhip64.so"))
 
     def dmalloc(nbytes):
         p = C.c_void_p()

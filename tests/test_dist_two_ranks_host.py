@@ -1,0 +1,63 @@
+"""The HOST side of the library's own multi-GPU path at world = 2 on a box without a GPU: two processes, each a rank with its own
+context and its docid shard, call nrtgpu_dist_search_bm25_batch_mode (both exchange forms, with and without shard-level
+speculation) and the pipelined pair nrtgpu_search_bm25_shard_device_begin + nrtgpu_dist_exchange_merge_checked -- against
+tests/mockhip (a HIP runtime whose kernels do nothing) with the collective carried by tests/mockrccl (messages are /dev/shm files; a
+size the two ranks disagree about is an error).  Results under the stand-in are empty; what is asked is that dist.cpp's control
+flow -- buffers, the grouped exchange with the guesses riding along, the verdicts' all-gather, who owns which answer -- runs to
+the end on both ranks, without a protocol mismatch and without a hang.  The answers themselves: tests/test_dist_two_ranks_gpu.py."""
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "nrtsearch_amd", "libnrtgpu.so")
+
+
+@pytest.fixture(scope="module")
+def stand_ins(tmp_path_factory):
+    if not (shutil.which("gcc") and shutil.which("g++") and os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h") and os.path.exists(LIB)):
+        pytest.skip("gcc, the HIP headers or the built library are not here")
+    d = tmp_path_factory.mktemp("standins")
+    mockhip = str(d / "libmockhip.so")
+    subprocess.run(["gcc", "-O1", "-w", "-fPIC", "-shared", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "mockhip", "mockhip.c"), "-o", mockhip], check=True)
+    rccl_dir = d / "rccl"
+    rccl_dir.mkdir()
+    subprocess.run(["g++", "-O1", "-w", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-Wl,-soname,librccl.so.1",
+                    os.path.join(ROOT, "tests", "mockrccl", "mockrccl.cpp"), "-o", str(rccl_dir / "librccl.so.1")], check=True)
+    return mockhip, str(rccl_dir)
+
+
+def test_two_ranks_run_the_librarys_exchange_to_the_end_without_a_gpu(stand_ins):
+    mockhip, rccl_dir = stand_ins
+    world, n_docs, n_q, k = 2, 120_000, 16, 50
+    sync_dir = tempfile.mkdtemp(prefix="nrtgpu_dist2h_")
+    outs = [os.path.join(sync_dir, f"rank{r}.pkl") for r in range(world)]
+    env = dict(os.environ, LD_PRELOAD=mockhip, LD_LIBRARY_PATH=rccl_dir + ":" + os.environ.get("LD_LIBRARY_PATH", ""), NRTGPU_TEST_HOST_ONLY="1",
+               NRTGPU_TEST_HIP_LIB=mockhip)
+    env.pop("NRTGPU_LIB_PATH", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(r), str(world), sync_dir, outs[r], str(n_docs), str(n_q),
+                               str(k), "iid"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=300)
+            logs.append(o)
+        assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+        ranks = [pickle.load(open(o, "rb")) for o in outs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(sync_dir, ignore_errors=True)
+    for r in range(world):
+        for what in ("bm25", "bm25_nospec", "bm25_pipelined"):
+            got = ranks[r][what + "_allgather"]
+            assert len(got) == n_q and all(g is not None and len(g[0]) == 0 for g in got)           # every answer on every rank (empty: the kernels did nothing)
+            owned = [g is not None for g in ranks[r][what + "_alltoall"]]
+            assert owned == [qi * world // n_q == r for qi in range(n_q)], (what, r, owned)          # its slice of the batch, nothing else
+        assert ranks[r]["pipelined_failed_allgather"] == [] and ranks[r]["pipelined_failed_alltoall"] == []
