@@ -268,7 +268,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   gpu.lock();
   // (experiment, off unless NRTGPU_OVERLAP_SCORERS=1: no turn between consecutive calls' scorers -- nothing but the turn itself
   //  orders them: workspaces are per slot, term tables reach the device before they become visible -- so that the next batch's
-  //  items fill the tail of this one's launch; needs its GPU run: the merge then queues behind foreign items)
+  //  items fill the tail of this one's launch.  Measured, round 5 (profiles/r05_overlap_scorers_ab.log): SLOWER, 2.50 against 1.95 ms
+  //  per step -- the batch's merge queues behind the next batch's items, 0.09 -> 0.98 ms)
   static const bool overlap_scorers = dev_env_int("NRTGPU_OVERLAP_SCORERS", 0) != 0;
   if (ctx->last_turn && !overlap_scorers) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
   if (ctx->last_knn_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_knn_turn, 0));   // (vector searches do not queue behind each other, the scorers queue behind them)
