@@ -817,7 +817,10 @@ def main():
             e_hits = [torch.zeros((W_e, mq_e), dtype=torch.int64, device="cuda") for _ in batches]
             e_tag = (((torch.arange(W_e, dtype=torch.int64, device="cuda") - shard_rank) % W_e) << 27).view(W_e, 1, 1)
             merger = api.PreparedMerge(ctx, W_e, mq_e, k_stride, [w.k] * mq_e, [api.TOTAL_HITS_THRESHOLD] * mq_e)
-        if not (args.torch_collective or args.debug_same_gpu or split_reduce or emu_exchange):
+        # (NRTGPU_BENCH_DEBUG_LIB_COLLECTIVE=1: the library's collective under --debug-same-gpu too -- tests/test_bench_two_ranks_gpu.py
+        #  binds it to tests/mockrccl, which carries messages between processes that share a GPU)
+        debug_lib = args.debug_same_gpu and os.environ.get("NRTGPU_BENCH_DEBUG_LIB_COLLECTIVE") == "1"
+        if not (args.torch_collective or (args.debug_same_gpu and not debug_lib) or split_reduce or emu_exchange):
             ok = 1
             try:
                 box = [api.GpuContext.dist_unique_id() if rank == 0 else None]
@@ -849,7 +852,7 @@ def main():
                 print(f"[rank {rank}] library collective unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
                 ok = 0
             if world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if args.debug_same_gpu else "cuda")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
             lib_collective = bool(ok)

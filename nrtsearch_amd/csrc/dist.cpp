@@ -35,10 +35,13 @@ Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    // a process that already holds RCCL (e.g. torch's bundled copy) resolves to that one
+    // a process that already holds RCCL (e.g. torch's bundled copy) resolves to that one.  NRTGPU_RCCL_LIB (development build
+    // only): the file to bind instead -- tests/mockrccl under a process that holds torch's RCCL as well (a path with a slash is
+    // opened as that file, whatever library of the same soname is loaded)
+    if (const char* forced = dev_env_str("NRTGPU_RCCL_LIB", nullptr)) r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (r.lib) break;
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.lib) return;
     r.get_unique_id = (GetUniqueIdFn)dlsym(r.lib, "ncclGetUniqueId");

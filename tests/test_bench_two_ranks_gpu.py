@@ -1,0 +1,51 @@
+"""bench.py at N = 2 on the one GPU of the pool, through the path the driver's N > 1 runs take: one process per rank
+(torch.distributed.run), each holding its docid shard, scan threads that begin shard searches under SHARD-LEVEL speculative
+thresholds (nrtgpu_search_bm25_shard_device_begin), one thread that issues nrtgpu_dist_exchange_merge_checked in batch order
+and has every rank run failed queries again -- the library's own collective, carried here by tests/mockrccl (the two ranks share
+the GPU: --debug-same-gpu; the development library binds the stand-in by path, NRTGPU_RCCL_LIB, because the process holds
+torch's RCCL too).  What is asked: rank 0 prints ONE well-formed line that says the library's collective and the shard-level
+speculation were what ran, with every owned query's guess checked.  No rate is read from it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "allgather"])
+def test_bench_two_ranks_through_the_librarys_collective(tmp_path, dev_lib, mode):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc is not here")
+    mock = str(tmp_path / "librccl_mock.so")
+    subprocess.run([HIPCC, "-O1", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "mockrccl", "mockrccl.cpp"), "-o", mock],
+                   check=True)
+    env = dict(os.environ, NRTGPU_LIB_PATH=os.path.join(ROOT, "nrtsearch_amd", "libnrtgpu_dev.so"), NRTGPU_RCCL_LIB=mock,
+               NRTGPU_BENCH_DEBUG_LIB_COLLECTIVE="1", NRTGPU_BENCH_COLLECTIVE_TIMEOUT="60", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-same-gpu", "--workload", "C2", "--steps", "12", "--warmup", "3",
+           "--no-cpu-baseline", "--closed-loop", "", "--exhaustive-steps", "0", "--c4-steps", "0", "--exchange-mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
+    c = d["config"]
+    assert "collective inside the library" in c["sharding"] and "shard-level speculative thresholds" in c["sharding"], c["sharding"]
+    sp = c["shard_speculation"]
+    assert sp and sp["queries"] == (12 + 3) * c["batch_queries"], sp        # every step's batch went through the checked exchange
+    assert sp["failed"] <= sp["queries"] // 50, sp                          # (i.i.d. shards: guesses stand)
