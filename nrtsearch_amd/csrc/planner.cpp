@@ -78,8 +78,14 @@ static const int32_t kNoFixed = INT32_MIN;  // QTabs.fx_E: the query needs the f
 // weight bounds them from above.  Returns false when the range does not fit.
 bool nrtgpu::rt::fixed_scale_of_term(float weight, const float* cache256, uint32_t max_norm, int32_t* scale) {
   const float s_min = nrtgpu::hostmath::bm25_score(weight, 1.0f, cache256[max_norm & 255u]);
-  if (!(s_min > 0.0f) || !std::isnormal(s_min) || !std::isnormal(weight)) return false;
-  const int e_min = std::ilogb(s_min), e_w = std::ilogb(weight);
+  // (the binary exponents straight from the bits -- what ilogb returns for a normal number; this runs once per clause of every
+  //  query planned: two libm calls per clause were a fifth of the planner's first pass)
+  uint32_t sb, wb;
+  memcpy(&sb, &s_min, 4);
+  memcpy(&wb, &weight, 4);
+  const uint32_t se = (sb >> 23) & 0xFFu, we = (wb >> 23) & 0xFFu;
+  if ((sb >> 31) != 0u || (wb >> 31) != 0u || se == 0u || se == 0xFFu || we == 0u || we == 0xFFu) return false;   // not positive and normal
+  const int e_min = (int)se - 127, e_w = (int)we - 127;
   if (e_w - e_min > 7) return false;  // 24 mantissa bits + 8 binades of range fill the 32-bit table entry
   *scale = 23 - e_min;
   return *scale > -64 && *scale < 64;
@@ -283,9 +289,10 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
                             uint32_t* q_qs_cnt, uint32_t* qs_begin, DQExpand* qexpand,
                             std::vector<uint32_t>& cache_base, std::vector<QTabs>& qtabs, int prune,
                             std::vector<int64_t>& q_lower, std::vector<uint8_t>& q_route, std::vector<int64_t>& q_ms_key) {
-  std::vector<int64_t> term_total;
-  std::vector<int32_t> tab_of_term, term_scale;
-  std::vector<const TermLeaves*> ents;
+  // (per query, on the stack: validate_query bounds n_terms by NRTGPU_MAX_TERMS)
+  int64_t term_total[NRTGPU_MAX_TERMS];
+  int32_t tab_of_term[NRTGPU_MAX_TERMS], term_scale[NRTGPU_MAX_TERMS];
+  const TermLeaves* ents[NRTGPU_MAX_TERMS];
   std::vector<int64_t> slice_sum((size_t)std::max(n_slices, 1));
   bool any_deleted = false;
   for (int si = 0; si < n_segs; ++si) any_deleted = any_deleted || n_deleted[si] != 0;
@@ -315,15 +322,13 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
       cache_base[(size_t)qi] = (uint32_t)prev_cache_off;
       pc.caches.insert(pc.caches.end(), q.norm_cache, q.norm_cache + cache_len);
     }
-    ents.resize((size_t)q.n_terms);
-    term_total.assign((size_t)q.n_terms, 0);
     for (int t = 0; t < q.n_terms; ++t) {
       ents[(size_t)t] = all_ents[ent_at++];
       if (ents[(size_t)t]->total < 0) pc.oom = true;
       term_total[(size_t)t] = std::max<int64_t>(ents[(size_t)t]->total, 0);
     }
     // fixed-point analysis: per clause the scale of its scores, per query the common scale
-    term_scale.assign((size_t)q.n_terms, 0);
+    for (int t = 0; t < q.n_terms; ++t) term_scale[t] = 0;
     bool fx_ok = true;
     int32_t fx_E = kNoFixed;
     for (int t = 0; t < q.n_terms && fx_ok; ++t) {
@@ -405,7 +410,7 @@ static void resolve_queries(LeafSetCache& lsc, const nrtgpu_seg* const* segs, in
       }
       q_ms_key[(size_t)qi] = p0 + p1;
     }
-    tab_of_term.assign((size_t)q.n_terms, -1);
+    for (int t = 0; t < q.n_terms; ++t) tab_of_term[t] = -1;
     QTabs& qt_ = qtabs[(size_t)qi];
     qt_.n = 0;
     qt_.fx_E = fx_E;
@@ -502,6 +507,14 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   std::vector<QTabs> qtabs((size_t)n_queries);
   int n_thr = ctx->cfg.host_threads > 0 ? ctx->cfg.host_threads : 4;
   n_thr = std::max(1, std::min(n_thr, n_queries / 64));
+  // A helper thread has to be woken (tens of microseconds, twice per plan) and the caller then waits for the slowest of them: over
+  // a batch's (query, leaf) pairs that costs more than it brings.  Measured on the GPU boxes' hosts without the GPU
+  // (profiles/r05_planner_host_ab.log, scripts/cpu_plan_bench.py): 1024 C3 queries over ONE leaf (the shard of one rank of eight)
+  // 1 thread 0.25-0.30 ms per plan, 2 threads 0.20-0.33; over the whole index's 10 leaves 1 thread 0.60-0.74 ms, 2 threads
+  // 0.80-0.83, 4 threads 0.80-0.87 -- and in the bench the runs whose helpers never got a chunk planned fastest (0.50 against
+  // 0.77-0.91 ms).  One thread per 16384 pairs, at most the configured: a batch of 1024 queries is planned by its caller alone,
+  // and callers that pipeline (two submitting threads, or _begin / wait) overlap whole plans instead.
+  n_thr = std::max(1, std::min<int>(n_thr, (int)(((int64_t)n_queries * std::max(n_segs, 1)) / 16384)));
   // More chunks than threads, handed out by a counter (WorkPool::run; the caller works too): a helper thread that wakes late --
   // tens of microseconds on a busy or virtualised host, of a phase that takes a few hundred -- then costs the batch one small
   // chunk, not its whole share.  Measured without a GPU (scripts/cpu_plan_bench.py, 1024 C3 queries over one leaf): one share

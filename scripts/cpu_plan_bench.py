@@ -31,16 +31,19 @@ keys = np.zeros((B, ks), dtype=np.int64)
 cnt = np.zeros(B, dtype=np.int32)
 hits = np.zeros(B, dtype=np.int64)
 guess = np.zeros(B, dtype=np.int64)
+best = 1e9
 for rep in range(3):
-    n = 40
+    n = 60
     t0 = time.perf_counter()
     prev = None
     for i in range(n):   # one submitting thread, two searches in flight: the next one is begun before the last one is waited for
+        tb = time.perf_counter()
         h = pbs[i % len(pbs)].begin_shard_device(ks, keys.ctypes.data, cnt.ctypes.data, hits.ctypes.data, world if world > 1 else 0, guess.ctypes.data)
+        best = min(best, time.perf_counter() - tb)
         if prev is not None:
             api.PreparedBatch.wait_device(prev)
         prev = h
     api.PreparedBatch.wait_device(prev)
     dt = (time.perf_counter() - t0) / n * 1e3
     st = ctx.stats()
-    print(f"begin + wait: {dt:.3f} ms per 1024-query batch; plan {st['host_plan_ms'] / max(1, st['batches']):.3f} ms", flush=True)
+    print(f"begin + wait: {dt:.3f} ms per 1024-query batch (mean); plan {st['host_plan_ms'] / max(1, st['batches']):.3f} ms (mean); fastest begin {best * 1e3:.3f} ms", flush=True)
