@@ -508,13 +508,13 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   int n_thr = ctx->cfg.host_threads > 0 ? ctx->cfg.host_threads : 4;
   n_thr = std::max(1, std::min(n_thr, n_queries / 64));
   // A helper thread has to be woken (tens of microseconds, twice per plan) and the caller then waits for the slowest of them: over
-  // a batch's (query, leaf) pairs that costs more than it brings.  Measured on the GPU boxes' hosts without the GPU
+  // few (query, leaf) pairs that costs what it brings.  Measured on the GPU boxes' hosts without the GPU
   // (profiles/r05_planner_host_ab.log, scripts/cpu_plan_bench.py): 1024 C3 queries over ONE leaf (the shard of one rank of eight)
-  // 1 thread 0.25-0.30 ms per plan, 2 threads 0.20-0.33; over the whole index's 10 leaves 1 thread 0.60-0.74 ms, 2 threads
-  // 0.80-0.83, 4 threads 0.80-0.87 -- and in the bench the runs whose helpers never got a chunk planned fastest (0.50 against
-  // 0.77-0.91 ms).  One thread per 16384 pairs, at most the configured: a batch of 1024 queries is planned by its caller alone,
-  // and callers that pipeline (two submitting threads, or _begin / wait) overlap whole plans instead.
-  n_thr = std::max(1, std::min<int>(n_thr, (int)(((int64_t)n_queries * std::max(n_segs, 1)) / 16384)));
+  // 1 thread 0.25-0.30 ms per plan, 2 threads 0.20-0.33: below 8192 pairs the caller plans alone.  Over the whole index's 10
+  // leaves the plan alone is no faster with helpers either (1 thread 0.60-0.74 ms, 2 / 4 threads 0.80-0.87) -- but a pipeline
+  // that starts empty waits for its FIRST plan, and the driver's 20-step form shows it: planned by the caller alone 487-493 k
+  // queries/s (profiles/r05_bench_steps20_*.json of r05p), with the configured helpers 498-505 k (r05g, r05j).  The helpers stay.
+  if ((int64_t)n_queries * std::max(n_segs, 1) < 8192) n_thr = 1;
   // More chunks than threads, handed out by a counter (WorkPool::run; the caller works too): a helper thread that wakes late --
   // tens of microseconds on a busy or virtualised host, of a phase that takes a few hundred -- then costs the batch one small
   // chunk, not its whole share.  Measured without a GPU (scripts/cpu_plan_bench.py, 1024 C3 queries over one leaf): one share
