@@ -1228,9 +1228,8 @@ extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtg
                                                      int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                                                      int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
                                                      int64_t epoch) {
-  nrtgpu_pending* p = nullptr;
-  if (int rc = nrtgpu_search_bm25_batch_device_begin(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts, d_hits, epoch, &p))
-    return rc;
+  nrtgpu_pending* p = nullptr;   // (the synchronous form enqueues itself: a hand-off to the launcher thread would only add its latency)
+  if (int rc = device_begin_impl(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, d_keys, d_counts, d_hits, epoch, 1, nullptr, &p)) return rc;
   return nrtgpu_pending_wait(p);
 }
 
