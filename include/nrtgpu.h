@@ -318,6 +318,9 @@ int  nrtgpu_pending_wait(nrtgpu_pending* pending);
  * travels between the GPUs while they walk.  A guess can only be checked against the MERGED list: the largest guess per query is
  * left in d_guess (n_queries x u64 in HBM, 0: none) -- nrtgpu_dist_exchange_merge_checked takes it along, checks it and says
  * which queries every shard has to run again (spec_world 0: without speculation).  The results are exact either way.
+ * spec_world counts shards OF THIS SHARD'S SIZE: total docs / this shard's docs, rounded down.  A shard that holds more of the
+ * index than it says guesses too high -- its guesses are caught by the check and cost re-runs, never a wrong answer
+ * (nrtgpu_dist_search_bm25_batch_mode passes the communicator's size: docid-range shards are equal to within a segment boundary).
  * nrtgpu_note_shard_speculation tells the leaf set's verdict (nrtgpu_stats.spec_*) how a batch went, for callers that do the
  * check themselves; nrtgpu_dist_search_bm25_batch_mode does all of this itself. */
 int  nrtgpu_search_bm25_shard_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
