@@ -507,6 +507,7 @@ struct nrtgpu_ctx {
   std::vector<struct KnnCoRequest*> kco_pending;
   struct KnnCoRequest* kco_leader = nullptr;   // the caller that will run the next panel
   int kco_inflight = 0;                        // panels executing right now (at most two)
+  int kco_last_panel = 0;                      // members of the panel formed last (a leader that finds the device free waits for that cohort)
   // MyIndexSearcher.SlicingParams of the searcher this context serves (nrtgpu_set_slicing)
   std::atomic<int32_t> slice_max_docs{250000}, slice_max_segments{5}, virtual_shards{1};
   std::unique_ptr<nrtgpu::rt::WorkPool> pool;   // helper threads of the host side (planning, unpacking results)

@@ -621,7 +621,9 @@ extern "C" int nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* con
     std::unique_lock<std::mutex> lk(ctx->kco_mu);
     ctx->kco_pending.push_back(&me);
     if (ctx->kco_leader) {   // follower: the leader (or a later one) takes this request
-      if (ctx->kco_pending.size() >= (size_t)kKnnMaxQ) ctx->kco_leader->cv.notify_one();
+      if (ctx->kco_pending.size() >= (size_t)kKnnMaxQ ||
+          (ctx->kco_inflight == 0 && ctx->kco_last_panel > 1 && ctx->kco_pending.size() >= (size_t)ctx->kco_last_panel))
+        ctx->kco_leader->cv.notify_one();   // a whole panel waits, or (device free) the last panel's cohort is back
       lk.unlock();
       {
         std::unique_lock<std::mutex> mine(me.m);
@@ -639,7 +641,26 @@ extern "C" int nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* con
     // whose launches fill the tails of the first one's -- as soon as a whole panel is waiting
     // (NO linger: a caller that finds the device free runs alone -- company comes from the callers that arrive while a panel is
     //  running.  co_hold: the test hook of nrtgpu_debug_hold_coalescers.)
-    while (!((ctx->kco_inflight == 0 && !ctx->co_hold) || ((ctx->kco_inflight == 1 || ctx->co_hold) && ctx->kco_pending.size() >= (size_t)kKnnMaxQ))) me.cv.wait(lk);
+    // The cohort of a closed loop: the members of a panel come back within tens of microseconds of each other, and the first one
+    // back used to find the device free and leave alone -- the others then waited a whole pass (2.7 ms at C4) for theirs: 8
+    // callers ran at 1.8 k queries/s with p50 5.5 ms where one panel of 8 per pass gives 2.9 k at 2.8 ms.  So a leader that finds
+    // the device free after a panel of N > 1 waits until N callers are pending again, for at most kKnnCohortLingerUs; a lone
+    // stream of callers (last panel 1) never waits.  NRTGPU_KCO_COHORT=0 (development build): leave at once, A/B.
+    static const bool cohort_rule = dev_env_int("NRTGPU_KCO_COHORT", 1) != 0;
+    constexpr int kKnnCohortLingerUs = 150;
+    const auto cohort_deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(kKnnCohortLingerUs);
+    for (;;) {
+      const size_t waiting = ctx->kco_pending.size();
+      if ((ctx->kco_inflight == 1 || ctx->co_hold) && waiting >= (size_t)kKnnMaxQ) break;
+      if (ctx->kco_inflight == 0 && !ctx->co_hold) {
+        const bool cohort_due = cohort_rule && ctx->kco_last_panel > 1 && waiting < (size_t)std::min(ctx->kco_last_panel, kKnnMaxQ) &&
+                                std::chrono::steady_clock::now() < cohort_deadline;
+        if (!cohort_due) break;
+        me.cv.wait_until(lk, cohort_deadline);
+        continue;
+      }
+      me.cv.wait(lk);
+    }
     std::vector<KnnCoRequest*> rest, expired;
     batch.push_back(&me);
     for (KnnCoRequest* r : ctx->kco_pending) {
@@ -665,6 +686,7 @@ extern "C" int nrtgpu_knn_exact_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* con
       next->cv.notify_one();
     }
     ctx->kco_inflight++;
+    ctx->kco_last_panel = (int)batch.size();
   }
   // the panel, outside the lock: the members' queries side by side, the largest k; every member's buffers take its own k
   int32_t kmax = 0;
