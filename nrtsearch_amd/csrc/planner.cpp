@@ -510,11 +510,12 @@ int nrtgpu::rt::build_plan(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const
   // A helper thread has to be woken (tens of microseconds, twice per plan) and the caller then waits for the slowest of them: over
   // few (query, leaf) pairs that costs what it brings.  Measured on the GPU boxes' hosts without the GPU
   // (profiles/r05_planner_host_ab.log, scripts/cpu_plan_bench.py): 1024 C3 queries over ONE leaf (the shard of one rank of eight)
-  // 1 thread 0.25-0.30 ms per plan, 2 threads 0.20-0.33: below 8192 pairs the caller plans alone.  Over the whole index's 10
+  // 1 thread 0.25-0.30 ms per plan, 2 threads 0.20-0.33: below 2048 pairs the caller plans alone.  Over the whole index's 10
   // leaves the plan alone is no faster with helpers either (1 thread 0.60-0.74 ms, 2 / 4 threads 0.80-0.87) -- but a pipeline
   // that starts empty waits for its FIRST plan, and the driver's 20-step form shows it: planned by the caller alone 487-493 k
   // queries/s (profiles/r05_bench_steps20_*.json of r05p), with the configured helpers 498-505 k (r05g, r05j).  The helpers stay.
-  if ((int64_t)n_queries * std::max(n_segs, 1) < 8192) n_thr = 1;
+  static const long alone_below = dev_env_int("NRTGPU_PLAN_ALONE_PAIRS", 2048);   // (development build: A/B)
+  if ((int64_t)n_queries * std::max(n_segs, 1) < alone_below) n_thr = 1;
   // More chunks than threads, handed out by a counter (WorkPool::run; the caller works too): a helper thread that wakes late --
   // tens of microseconds on a busy or virtualised host, of a phase that takes a few hundred -- then costs the batch one small
   // chunk, not its whole share.  Measured without a GPU (scripts/cpu_plan_bench.py, 1024 C3 queries over one leaf): one share
