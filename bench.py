@@ -926,9 +926,19 @@ def main():
                 stage["scan_call_s"] += time.perf_counter() - t_start[i]
             return b
 
+        def step_failed(exc):
+            """A step of the exchange stage failed: the scan threads wait for buffers nobody will hand back, the other ranks for a
+            collective this one will not issue -- say what happened and leave at once (the launcher ends the other ranks)."""
+            import traceback
+            print(f"[rank {rank}] the exchange stage failed at a step: {exc!r}", file=sys.stderr, flush=True)
+            traceback.print_exc(file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(1)
+
         with ThreadPoolExecutor(max_workers=max(1, args.host_threads) if args.sync_submit else submitters) as ex:  # FIFO: steps start in order
             futs = [ex.submit(produce, i) for i in range(count)]
             for i in range(count):
+              try:
                 b = futs[i].result()
                 if pending[i] is not None:
                     tw0 = time.perf_counter()
@@ -1010,6 +1020,8 @@ def main():
                     stage["exchange_s"] += te1 - te0
                     stage["merge_call_s"] += time.perf_counter() - te1
                     stage["steps"] += 1
+              except Exception as exc_:   # noqa: BLE001
+                step_failed(exc_)
         last["td"] = merger
 
     def fence():
