@@ -266,7 +266,8 @@ int  nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, co
 
 /* The same single search, but concurrent callers (the SEARCH / gRPC pool's threads, each blocked in its own
  * call: SearchHandler.java:1412 runs on the request thread) are coalesced by the library into device batches:
- * a caller that finds no batch forming waits `linger_us` (default 150) for company, then runs everybody's
+ * a caller that finds no batch forming waits at most `linger_us` (default 150) for company -- less when, with nothing in
+ * flight, as many callers wait as the last batch held (the cohort of a closed loop is back) -- then runs everybody's
  * queries over the same leaves as one batch.  No extra thread; results identical to nrtgpu_search_bm25. */
 int  nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                   const nrtgpu_bm25_query* q, nrtgpu_topdocs* out);
