@@ -408,6 +408,11 @@ struct Slot {
 // The caller's wait for its stream: a spin inside hipStreamSynchronize by default (lowest latency; it keeps a CPU busy), a
 // sleep on a blocking event under NRTGPU_FLAG_BLOCKING_WAIT (several ranks sharing the host's CPUs: one process per GPU
 // with a few calls in flight each would otherwise spin on more CPUs than the box has).
+// hipGetLastError() is the CALLING THREAD's: a runtime call of somebody else on this thread (the caller's own GPU code, another
+// library) that failed and was never asked about leaves its error there, and the first of OUR functions that checks its launches
+// with hipGetLastError() would report it as its own.  Entry points that launch kernels forget it first.
+inline void forget_foreign_hip_error() { (void)hipGetLastError(); }
+
 inline hipError_t wait_for_stream(bool blocking, hipStream_t st, hipEvent_t blocking_event) {
   if (!blocking) return hipStreamSynchronize(st);
   const hipError_t e = hipEventRecord(blocking_event, st);

@@ -92,6 +92,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                           uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
                           std::unique_lock<std::mutex>& gpu, int64_t epoch = -1, bool allow_spec = false, int32_t spec_world = 1,
                           uint64_t* ext_guess = nullptr) {
+  forget_foreign_hip_error();
   // spec_world > 1 (the library's multi-GPU search, dist.cpp): this call is ONE SHARD of a spec_world-way search over equal docid
   // ranges, and its speculative thresholds are guesses at the k-th score of the WHOLE search -- a shard's docs are a 1 / world
   // sample of the index, so the guess rule holds with the windows of all shards in its denominator.  Such a guess cannot be
@@ -557,6 +558,7 @@ static int search_hybrid_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, co
                               int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost,
                               double query_weight, double rescore_weight, int32_t window, nrtgpu_topdocs* out, std::vector<int32_t>* rerun,
                               bool content_held = false) {
+  forget_foreign_hip_error();
   if (!ctx || !queries || !out || !query_vectors || (n_segs > 0 && (!segs || !doc_bases)))
     return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
@@ -700,6 +702,7 @@ int nrtgpu::rt::hybrid_tail_on_device(nrtgpu_ctx* ctx, Slot* slot, const nrtgpu_
                                       int32_t field_id, int32_t sim, const float* query_vectors, int32_t dim, float boost, double qw, double rw,
                                       int32_t window, int32_t n_queries, const void* d_first_keys, const void* d_first_counts,
                                       int32_t k_stride, int32_t drop_foreign, void* d_win_keys, void* d_win_counts, uint32_t w_stride) {
+  forget_foreign_hip_error();
   const size_t nq = (size_t)n_queries;
   PaddedQueries padded;   // (rows are resident padded to a multiple of 16 elements: the queries likewise)
   if (int rc = pad_query_vectors(segs, n_segs, field_id, query_vectors, n_queries, dim, &padded)) return rc;
@@ -747,6 +750,7 @@ int nrtgpu::rt::hybrid_tail_on_device(nrtgpu_ctx* ctx, Slot* slot, const nrtgpu_
 
 int nrtgpu::rt::merge_lists_on_device(nrtgpu_ctx* ctx, Slot* slot, int32_t n_lists, int32_t n_queries, int32_t k_stride, const void* g_keys,
                                       const void* g_counts, const void* g_hits, const int32_t* ks, void* d_keys, void* d_counts, void* d_hits) {
+  forget_foreign_hip_error();
   const size_t nq = (size_t)n_queries, nl = (size_t)n_lists;
   Carver pc;
   const size_t o_lidx = pc.take(nq * nl * 4), o_qbase = pc.take(nq * 4), o_qnl = pc.take(nq * 4), o_qk = pc.take(nq * 4);
@@ -1251,6 +1255,7 @@ extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtg
 extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride,
                                         const void* d_keys_in, const void* d_counts_in, const void* d_hits_in,
                                         const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
+  forget_foreign_hip_error();
   if (!ctx || !d_keys_in || !d_counts_in || !d_hits_in || !ks || !total_hits_thresholds || !out)
     return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_lists <= 0 || n_queries <= 0 || k_stride <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad sizes");

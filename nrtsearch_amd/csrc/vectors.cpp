@@ -37,6 +37,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
                     int32_t field_id, int32_t sim, const float* queries, int32_t n_queries, int32_t dim,
                     int32_t k, float boost, bool knn_request, int32_t filter_mask, float min_score, nrtgpu_topdocs* out,
                     char* ext_keys = nullptr, char* ext_cnts = nullptr, char* ext_hits = nullptr) {
+  forget_foreign_hip_error();
   // ext_*: device-resident results instead of `out` (the multi-GPU path): per query k_stride sorted keys, its count, and the live
   // vectors of these leaves as the hit total -- the layout the exchange stage takes
   if (!ctx || !queries || (!out && !ext_keys) || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
@@ -745,6 +746,7 @@ extern "C" int nrtgpu_rescore_vectors(nrtgpu_ctx* ctx, const nrtgpu_seg* const* 
                                       int32_t field_id, int32_t sim, const float* query, int32_t dim, float boost,
                                       const int32_t* docs, const float* first_scores, int32_t n, double query_weight,
                                       double rescore_weight, int32_t window, nrtgpu_topdocs* out) {
+  forget_foreign_hip_error();
   if (!ctx || !query || !out || (n > 0 && (!docs || !first_scores)) || (n_segs > 0 && (!segs || !doc_bases)))
     return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n < 0 || dim <= 0 || sim < 0 || sim > 3 || window <= 0) return fail(NRTGPU_ERR_INVALID_ARG, "bad rescore arguments");
