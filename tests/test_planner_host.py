@@ -107,3 +107,18 @@ def test_the_planner_on_the_second_accumulator_shapes(mockhip):
                     ("raw_must_in_dismax", "have no occur")):
         assert got[n].startswith("rc -1:") and what in got[n], got[n]      # NRTGPU_ERR_INVALID_ARG
     assert got["raw_must_with_msm"].startswith("rc -4:")                     # NRTGPU_ERR_UNSUPPORTED: Lucene's third sum structure
+
+
+def test_coalesced_callers_in_a_closed_loop_form_cohorts(mockhip):
+    """nrtgpu_search_bm25_coalesced against the stand-in HIP runtime (a stream synchronisation "takes" 300 us): a lone caller's
+    queries run alone, one batch each -- it never lingers; C callers in a closed loop are served as cohorts (a few batches per
+    round, not one per query), and the loop ends (no caller is left behind by the leader's leave-when-the-cohort-is-back rule,
+    search.cpp)."""
+    e = dict(os.environ, LD_PRELOAD=mockhip, MOCKHIP_SYNC_US="300")
+    e.pop("NRTGPU_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "coalesce_cohort.py")], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout, r.stderr[-2000:]
+    rows = {int(m.group(1)): (int(m.group(2)), int(m.group(3))) for m in re.finditer(r"callers (\d+) calls (\d+) batches (\d+)", r.stdout)}
+    assert rows[1][1] == rows[1][0], rows                    # alone: one batch per query
+    assert rows[8][1] <= rows[8][0] // 3, rows               # cohorts
+    assert rows[24][1] <= rows[24][0] // 6, rows
