@@ -43,10 +43,23 @@ hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { (void)e; (void)s; return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t e) { (void)e; return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { (void)a; (void)b; *ms = 0.001f; return hipSuccess; }
-hipError_t hipGetLastError(void) { return hipSuccess; }
+// mockhip_fail_next_launches(n): the next n kernel launches fail (hipErrorLaunchFailure, also what the launching thread's next
+// hipGetLastError() says, once): how a test sees what the library does with a launch that failed
+static int fail_launches = 0;
+static __thread hipError_t sticky_error = hipSuccess;
+void mockhip_fail_next_launches(int n) { __atomic_store_n(&fail_launches, n, __ATOMIC_SEQ_CST); }
+hipError_t hipGetLastError(void) { hipError_t e = sticky_error; sticky_error = hipSuccess; return e; }
 const char* hipGetErrorString(hipError_t e) { (void)e; return "mock hip"; }
 hipError_t hipFuncSetAttribute(const void* f, hipFuncAttribute a, int v) { (void)f; (void)a; (void)v; return hipSuccess; }
-hipError_t hipLaunchKernel(const void* f, dim3 g, dim3 b, void** args, size_t sm, hipStream_t s) { (void)f; (void)g; (void)b; (void)args; (void)sm; (void)s; ++n_launch; return hipSuccess; }
+hipError_t hipLaunchKernel(const void* f, dim3 g, dim3 b, void** args, size_t sm, hipStream_t s) {
+  (void)f; (void)g; (void)b; (void)args; (void)sm; (void)s;
+  ++n_launch;
+  if (__atomic_load_n(&fail_launches, __ATOMIC_SEQ_CST) > 0 && __atomic_fetch_sub(&fail_launches, 1, __ATOMIC_SEQ_CST) > 0) {
+    sticky_error = hipErrorLaunchFailure;
+    return hipErrorLaunchFailure;
+  }
+  return hipSuccess;
+}
 static void* fat_handle[4];
 void** __hipRegisterFatBinary(const void* data) { (void)data; return fat_handle; }
 void __hipRegisterFunction(void** m, const void* hf, char* df, const char* dn, unsigned tl, void* tid, void* bid, void* bd, void* gd, int* ws) { (void)m; (void)hf; (void)df; (void)dn; (void)tl; (void)tid; (void)bid; (void)bd; (void)gd; (void)ws; }

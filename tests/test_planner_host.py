@@ -122,3 +122,13 @@ def test_coalesced_callers_in_a_closed_loop_form_cohorts(mockhip):
     assert rows[1][1] == rows[1][0], rows                    # alone: one batch per query
     assert rows[8][1] <= rows[8][0] // 3, rows               # cohorts
     assert rows[24][1] <= rows[24][0] // 6, rows
+
+
+def test_a_launch_that_fails_behind_begin_is_reported_by_wait(mockhip):
+    """nrtgpu_search_bm25_batch_device_begin hands the enqueue to the context's launcher thread: a launch that fails there is what
+    nrtgpu_pending_wait returns (code and message), the workspace is free again, later searches run (tests/mockhip/launcher_error.py:
+    the stand-in HIP runtime makes one launch fail)."""
+    e = dict(os.environ, LD_PRELOAD=mockhip)
+    e.pop("NRTGPU_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "launcher_error.py")], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout and "wait reported: nrtgpu error" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
