@@ -87,6 +87,13 @@ def main():
     for name, mode in (("allgather", api.EXCHANGE_ALLGATHER), ("alltoall", api.EXCHANGE_ALLTOALL)):
         h = pb.begin_shard_device(ks, d_keys, d_cnt, d_hits, world, d_guess)
         api.PreparedBatch.wait_device(h)
+        if host_only and os.environ.get("NRTGPU_TEST_POKE_GUESSES") == "1":
+            # (against the stand-in HIP runtime "device" memory is host memory and no kernel ran: plant guesses -- rank 0 for queries
+            #  1 and 5, rank 1 for 5 and 9 -- that no merged list can reach: every rank must come to know all three, whoever owns them)
+            planted = (C.c_uint64 * n_queries)()
+            for q_ in ((1, 5) if rank == 0 else (5, 9)):
+                planted[q_] = 1 << 62
+            C.memmove(d_guess, planted, n_queries * 8)
         pm = api.PreparedMerge(ctx, world, n_queries, ks, [k] * n_queries, [api.TOTAL_HITS_THRESHOLD] * n_queries)
         bad = pm.run_dist_checked(d_keys, d_cnt, d_hits, d_guess, mode)
         pb.note_shard_speculation(n_queries, len(bad))

@@ -4,7 +4,9 @@ speculation) and the pipelined pair nrtgpu_search_bm25_shard_device_begin + nrtg
 tests/mockhip (a HIP runtime whose kernels do nothing) with the collective carried by tests/mockrccl (messages are /dev/shm files; a
 size the two ranks disagree about is an error).  Results under the stand-in are empty; what is asked is that dist.cpp's control
 flow -- buffers, the grouped exchange with the guesses riding along, the verdicts' all-gather, who owns which answer -- runs to
-the end on both ranks, without a protocol mismatch and without a hang.  The answers themselves: tests/test_dist_two_ranks_gpu.py."""
+the end on both ranks, without a protocol mismatch and without a hang; and, with guesses PLANTED in the ranks' buffers that no merged
+list can reach, that every rank comes to know the same set of failed queries and runs them again together.  The answers themselves:
+tests/test_dist_two_ranks_gpu.py."""
 import os
 import pickle
 import shutil
@@ -38,7 +40,7 @@ def test_two_ranks_run_the_librarys_exchange_to_the_end_without_a_gpu(stand_ins)
     sync_dir = tempfile.mkdtemp(prefix="nrtgpu_dist2h_")
     outs = [os.path.join(sync_dir, f"rank{r}.pkl") for r in range(world)]
     env = dict(os.environ, LD_PRELOAD=mockhip, LD_LIBRARY_PATH=rccl_dir + ":" + os.environ.get("LD_LIBRARY_PATH", ""), NRTGPU_TEST_HOST_ONLY="1",
-               NRTGPU_TEST_HIP_LIB=mockhip)
+               NRTGPU_TEST_HIP_LIB=mockhip, NRTGPU_TEST_POKE_GUESSES="1")
     env.pop("NRTGPU_LIB_PATH", None)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), str(r), str(world), sync_dir, outs[r], str(n_docs), str(n_q),
                                str(k), "iid"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -60,4 +62,7 @@ def test_two_ranks_run_the_librarys_exchange_to_the_end_without_a_gpu(stand_ins)
             assert len(got) == n_q and all(g is not None and len(g[0]) == 0 for g in got)           # every answer on every rank (empty: the kernels did nothing)
             owned = [g is not None for g in ranks[r][what + "_alltoall"]]
             assert owned == [qi * world // n_q == r for qi in range(n_q)], (what, r, owned)          # its slice of the batch, nothing else
-        assert ranks[r]["pipelined_failed_allgather"] == [] and ranks[r]["pipelined_failed_alltoall"] == []
+        # the planted guesses (tests/_dist_worker.py: rank 0's for queries 1 and 5, rank 1's for 5 and 9; no merged list reaches them):
+        # every rank is told all three, in both forms -- all-gather: every rank holds every guess; all-to-all: the owners' verdicts are
+        # all-gathered -- and the re-run of those three (a collective call of its own) went through
+        assert ranks[r]["pipelined_failed_allgather"] == [1, 5, 9] and ranks[r]["pipelined_failed_alltoall"] == [1, 5, 9], ranks[r]
