@@ -144,3 +144,13 @@ def test_the_leaf_sets_verdict_on_speculation(mockhip):
     e.pop("NRTGPU_LIB_PATH", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "spec_verdict.py")], env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "done" in r.stdout and "after set_speculation (1024, 0, False, False)" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_the_accept_set_cache_evicts_and_retires(mockhip):
+    """The per-leaf cache of combined doc sets (segment.cpp: accept_set_of_ids) without a GPU: 150 combinations leave 64 sets
+    resident; sets evicted while a begun search is in flight wait for it (64 + 50 resident) and are freed when it has been waited
+    for (tests/mockhip/accept_lru.py reads the leaves' device bytes at every step)."""
+    e = dict(os.environ, LD_PRELOAD=mockhip)
+    e.pop("NRTGPU_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "accept_lru.py")], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout and "after the wait: [64, 64]" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
