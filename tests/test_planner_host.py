@@ -154,3 +154,14 @@ def test_the_accept_set_cache_evicts_and_retires(mockhip):
     e.pop("NRTGPU_LIB_PATH", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "accept_lru.py")], env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "done" in r.stdout and "after the wait: [64, 64]" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_two_submitting_threads_a_launcher_and_the_planners_helpers(mockhip):
+    """The shape of bench.py's multi-GPU loop without a GPU (tests/mockhip/pipeline_stress.py): two threads begin shard searches
+    over three result buffers -- 1024 queries over 3 leaves, so the planner's helper threads take part, and every enqueue goes
+    through the context's launcher thread -- while the main thread waits in step order, merges and hands the buffers back; 400
+    steps with searches that stay in flight for 100 us.  45 000 steps of it ran clean by hand in round 5."""
+    e = dict(os.environ, LD_PRELOAD=mockhip, MOCKHIP_SYNC_US="100", STEPS="400", WATCHDOG="120")
+    e.pop("NRTGPU_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mockhip", "pipeline_stress.py")], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
