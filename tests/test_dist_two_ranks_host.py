@@ -66,3 +66,30 @@ def test_two_ranks_run_the_librarys_exchange_to_the_end_without_a_gpu(stand_ins)
         # every rank is told all three, in both forms -- all-gather: every rank holds every guess; all-to-all: the owners' verdicts are
         # all-gathered -- and the re-run of those three (a collective call of its own) went through
         assert ranks[r]["pipelined_failed_allgather"] == [1, 5, 9] and ranks[r]["pipelined_failed_alltoall"] == [1, 5, 9], ranks[r]
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "allgather"])
+def test_two_ranks_pipeline_with_planted_failures(stand_ins, mode):
+    """bench.py's loop at N = 2 without a GPU (tests/mockhip/dist_pipeline_stress.py): per rank two submitting threads, the launcher,
+    the planner's helpers, and the main thread running nrtgpu_dist_exchange_merge_checked per step; every fifth step guesses are
+    planted that no merged list reaches -- both ranks must name the same failed queries (the worker asserts the exact set) and
+    re-run them together.  200 steps here; 12 000 steps with 2 300 re-run calls ran clean by hand in round 5."""
+    mockhip, rccl_dir = stand_ins
+    sync_dir = tempfile.mkdtemp(prefix="nrtgpu_dist2s_")
+    env = dict(os.environ, LD_PRELOAD=mockhip, LD_LIBRARY_PATH=rccl_dir + ":" + os.environ.get("LD_LIBRARY_PATH", ""), MOCKHIP_SYNC_US="50", PLANT="5",
+               WATCHDOG="150")
+    env.pop("NRTGPU_LIB_PATH", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mockhip", "dist_pipeline_stress.py"), str(r), "2", sync_dir, mode, "200"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=300)
+            logs.append(o)
+        assert all(p.returncode == 0 for p in procs) and all("done" in l for l in logs), "\n".join(l[-3000:] for l in logs)
+        assert all("200 steps, 40 re-run calls" in l for l in logs), [l[-200:] for l in logs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(sync_dir, ignore_errors=True)
