@@ -65,3 +65,49 @@ def test_what_the_merge_checks_is_the_overshoot():
         assert stands == bool(guess <= true_kth)
         if stands:
             assert kept[:k].tolist() == np.sort(scores)[::-1][:k].tolist()     # ... and then the list IS the exact top-k
+
+
+def shard_trial(rng, n_docs, k, world, f, z, sizes=None):
+    """One search shared by `world` shards (search.cpp: enqueue_search, spec_world): every shard guesses the k-th score of the WHOLE
+    search from the fraction f of ITS docs it has seen -- the windows of all shards in the denominator, g = f / world -- and the
+    largest guess is checked against the merged list.  -> did any shard's guess overshoot the global k-th best?"""
+    scores = rng.lognormal(size=n_docs).astype(np.float32)
+    kth = np.partition(scores, n_docs - k)[n_docs - k]
+    bounds = np.linspace(0, n_docs, world + 1).astype(int) if sizes is None else np.concatenate([[0], np.cumsum(sizes)])
+    worst = 0.0
+    for s in range(world):
+        mine = scores[bounds[s]: bounds[s + 1]]
+        seen = mine[: int(len(mine) * f)]
+        r = guess_rank(k, f / world, z)
+        if r == 0 or r > len(seen):
+            continue
+        worst = max(worst, float(np.partition(seen, len(seen) - r)[len(seen) - r]))
+    return worst > kth
+
+
+def test_shards_guessing_the_global_threshold():
+    """a shard's docs are a 1 / W sample of the index.  Equal shards, five standard deviations: at most one overshoot in 8 x 240
+    shard-guesses; without the margin most searches have a shard that overshoots (which is why the margin is there); and a shard
+    that holds more of the index than it says -- spec_world counts shards OF THIS SHARD'S SIZE (include/nrtgpu.h) -- guesses too
+    high: what the check against the merged list and the re-run are for."""
+    rng = np.random.Generator(np.random.PCG64(23))
+    n_docs, k, world = 160_000, 1000, 8
+    over = {0.0: 0, 5.0: 0}
+    trials = 0
+    for f in (0.1, 0.25, 0.5, 1.0):
+        for _ in range(60):
+            trials += 1
+            for z in over:
+                over[z] += int(shard_trial(rng, n_docs, k, world, f, z))
+    # (with this seed ONE of the 1920 shard-guesses overshoots: a shard that had seen 61 of the top 1000 where 31 were expected,
+    #  5.3 standard deviations -- a count's tail is heavier than a normal's; 60 000 further guesses, other seeds: none.  The check
+    #  against the merged list is what makes such a guess cost a re-run instead of an answer.)
+    assert over[5.0] <= 1, over
+    assert over[0.0] > trials // 2, over
+    # the guess at the end of a shard's walk: rank k / W + z sqrt(k / W) + 2 of its own docs (183 of 1000 at W = 8, z = 5)
+    assert guess_rank(1000, 1.0 / 8, 5.0) == 182 and guess_rank(1000, 1.0 / 2, 5.0) == 613
+    # unequal shards under the equal-shards assumption: the first shard holds half of the index and says "one of eight"
+    sizes = [n_docs // 2] + [n_docs // 14] * 7
+    sizes[-1] += n_docs - sum(sizes)
+    lopsided = sum(int(shard_trial(rng, n_docs, k, world, 1.0, 5.0, sizes)) for _ in range(40))
+    assert lopsided >= 36, lopsided      # it holds ~500 of the top 1000 and guesses its 182nd best: caught by the check, paid as a re-run
