@@ -71,6 +71,7 @@ struct nrtgpu_dist {
   DevBuf stage;             // hybrid: the merged first pass and this rank's rescored windows
   DevBuf my_guess;          // BM25: this rank's largest speculative threshold per query (nrtgpu_dist_search_bm25_batch_mode)
   DevBuf guess;             // ... the verdicts on them: mine, then every rank's (all-to-all form)
+  DevBuf status;            // this rank's status word of an exchange (exchange_lists), then every rank's
   std::mutex mu;            // one collective (one user of `gathered`) at a time per communicator
   std::mutex call_mu;       // one whole search call (one user of `local`) at a time: taken before `mu`
 };
@@ -123,6 +124,7 @@ extern "C" void nrtgpu_dist_close(nrtgpu_ctx* ctx) {
   d->stage.release();
   d->guess.release();
   d->my_guess.release();
+  d->status.release();
   delete d;
 }
 
@@ -143,6 +145,7 @@ struct Gathered {
   char* hits = nullptr;
   int32_t first_q = 0, n_q = 0;   // the queries this rank merges
   std::vector<uint64_t> guess;    // [world][n_q] the shards' largest speculative thresholds for them (host; empty: none travelled)
+  std::vector<int32_t> status;    // [world] what every rank said about ITS part of the call (0: fine; empty: no status travelled)
 };
 
 static void owned_range(int32_t world, int32_t rank, int32_t n_queries, int32_t mode, int32_t* first, int32_t* count) {
@@ -167,10 +170,22 @@ extern "C" int nrtgpu_dist_owned_range(nrtgpu_ctx* ctx, int32_t n_queries, int32
 // (d->mu held by the caller)
 // d_guess (may be NULL): this rank's largest speculative threshold per query (search.cpp: search_bm25_shard_device); they travel in
 // the same group as the lists -- no collective, no wait of their own -- and arrive on the host in g->guess.
+// my_status (kNoStatus: none travels): how this rank's part of the call went BEFORE the exchange -- the one-call entries
+// (nrtgpu_dist_search_bm25_batch_mode ...) enter the exchange even when their local search failed (with empty lists), so that no peer
+// is left waiting in a collective this rank would never issue; one more 4-byte all-gather in the same group, read on the host
+// behind the same wait.  Every rank then sees every status and all of them return an error together (peers_failed).
+const int32_t kNoStatus = INT32_MIN;
 static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
-                          const void* d_hits, const void* d_guess, int32_t mode, Gathered* g) {
+                          const void* d_hits, const void* d_guess, int32_t mode, Gathered* g, int32_t my_status = kNoStatus) {
   Rccl* r = rccl();
   const size_t W = (size_t)d->world;
+  int32_t* d_status = nullptr;   // [mine | every rank's]
+  g->status.clear();
+  if (my_status != kNoStatus) {
+    if (int rc = d->status.reserve((W + 1) * 4)) return rc;
+    d_status = (int32_t*)d->status.p;
+    HIP_TRY(hipMemcpyAsync(d_status, &my_status, 4, hipMemcpyHostToDevice, d->stream));
+  }
   if (mode == NRTGPU_EXCHANGE_ALLTOALL && !(r->send && r->recv)) mode = NRTGPU_EXCHANGE_ALLGATHER;
   owned_range(d->world, d->rank, n_queries, mode, &g->first_q, &g->n_q);
   const bool sliced = g->n_q != n_queries;
@@ -188,8 +203,9 @@ static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, in
     int rc2 = r->all_gather(d_hits, g->hits, hb / 8, kNcclInt64, d->comm, d->stream);
     int rc3 = r->all_gather(d_counts, g->cnt, cb / 4, kNcclInt32, d->comm, d->stream);
     int rc4 = d_guess ? r->all_gather(d_guess, gg, hb / 8, kNcclInt64, d->comm, d->stream) : 0;
+    int rc5 = d_status ? r->all_gather(d_status, d_status + 1, 1, kNcclInt32, d->comm, d->stream) : 0;
     if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
-    if (rc1 || rc2 || rc3 || rc4) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : (rc3 ? rc3 : rc4)));
+    if (rc1 || rc2 || rc3 || rc4 || rc5) return nccl_fail("ncclAllGather", rc1 ? rc1 : (rc2 ? rc2 : (rc3 ? rc3 : (rc4 ? rc4 : rc5))));
   } else {
     // my lists for peer p's slice go to p; p's lists for my slice arrive as list p.  My own slice: a device copy.
     const char* lk = (const char*)d_keys;
@@ -211,6 +227,10 @@ static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, in
           bad |= r->send(lg + (size_t)p * hb, hb / 8, kNcclInt64, p, d->comm, d->stream);
           bad |= r->recv(gg + (size_t)p * hb, hb / 8, kNcclInt64, p, d->comm, d->stream);
         }
+        if (d_status) {
+          bad |= r->send(d_status, 1, kNcclInt32, p, d->comm, d->stream);
+          bad |= r->recv(d_status + 1 + p, 1, kNcclInt32, p, d->comm, d->stream);
+        }
       }
       if (int rc = r->group_end()) return nccl_fail("ncclGroupEnd", rc);
       if (bad) return nccl_fail("ncclSend / ncclRecv", bad);
@@ -220,6 +240,11 @@ static int exchange_lists(nrtgpu_ctx* ctx, nrtgpu_dist* d, int32_t n_queries, in
     HIP_TRY(hipMemcpyAsync(g->hits + me * hb, lh + me * hb, hb, hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemcpyAsync(g->cnt + me * cb, lc + me * cb, cb, hipMemcpyDeviceToDevice, d->stream));
     if (lg) HIP_TRY(hipMemcpyAsync(gg + me * hb, lg + me * hb, hb, hipMemcpyDeviceToDevice, d->stream));
+    if (d_status) HIP_TRY(hipMemcpyAsync(d_status + 1 + me, d_status, 4, hipMemcpyDeviceToDevice, d->stream));
+  }
+  if (d_status) {
+    g->status.resize(W);
+    HIP_TRY(hipMemcpyAsync(g->status.data(), d_status + 1, W * 4, hipMemcpyDeviceToHost, d->stream));
   }
   g->guess.clear();
   if (d_guess) {
@@ -241,15 +266,28 @@ static void mark_not_owned(nrtgpu_topdocs* out, int32_t n_queries, const Gathere
     }
 }
 
+// After an exchange that carried the ranks' statuses: did anybody's part of the call fail?  Then EVERY rank returns an error --
+// its own where it has one, else one that names the first failed peer -- and nobody goes on to a collective the failed rank
+// would not issue.
+static int peers_failed(const nrtgpu_dist* d, const Gathered& g, int32_t my_status, const std::string& my_error) {
+  for (size_t w = 0; w < g.status.size(); ++w)
+    if (g.status[w] != 0) {
+      if (my_status != 0) return fail(my_status, "%s", my_error.c_str());
+      return fail(NRTGPU_ERR_STATE, "rank %d of %d failed its part of the search (status %d): the call fails on every rank", (int)w, d->world, g.status[w]);
+    }
+  return NRTGPU_OK;
+}
+
 // The exchange, TopDocs.merge of the shards' lists, and -- with d_guess -- the check of the shards' speculative thresholds against
 // the MERGED lists: the k-th key of a query's merged list must reach the largest guess any shard published for it; then nothing
 // any shard skipped could have entered (kernels.hip: merge_topk_kernel applies the same rule to one call's list).  failed
 // [n_queries]: the same verdicts on every rank (all-gather form: every rank holds every list and every guess; all-to-all: the
 // owners' verdicts are all-gathered, one byte per query).
-extern "C" int nrtgpu_dist_exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys,
-                                                  const void* d_counts, const void* d_hits, const void* d_guess, const int32_t* ks,
-                                                  const int32_t* total_hits_thresholds, int32_t mode, nrtgpu_topdocs* out,
-                                                  uint8_t* failed, int32_t* n_failed) {
+// my_status / my_error: how this rank's part of the call went before the exchange (kNoStatus: the caller vouches for it, nothing
+// travels): see exchange_lists.
+static int exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts, const void* d_hits,
+                                  const void* d_guess, const int32_t* ks, const int32_t* total_hits_thresholds, int32_t mode, nrtgpu_topdocs* out,
+                                  uint8_t* failed, int32_t* n_failed, int32_t my_status, const std::string& my_error) {
   if (!ctx || !ctx->dist) return fail(NRTGPU_ERR_STATE, "nrtgpu_dist_init has not been called on this context");
   if (!d_keys || !d_counts || !d_hits || !ks || !total_hits_thresholds || !out || n_queries <= 0 || k_stride <= 0 || k_stride % 16 != 0)
     return fail(NRTGPU_ERR_INVALID_ARG, "bad arguments");
@@ -259,10 +297,14 @@ extern "C" int nrtgpu_dist_exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_que
   HIP_TRY(hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> lk(d->mu);   // one collective (and one user of the gathered buffer) at a time per communicator
   Gathered g;
-  if (int rc = exchange_lists(ctx, d, n_queries, k_stride, d_keys, d_counts, d_hits, d_guess, mode, &g)) return rc;
+  if (int rc = exchange_lists(ctx, d, n_queries, k_stride, d_keys, d_counts, d_hits, d_guess, mode, &g, my_status)) return rc;
+  if (int rc = peers_failed(d, g, my_status, my_error)) return rc;
   mark_not_owned(out, n_queries, g);
-  if (int rc = nrtgpu_merge_topk_device(ctx, d->world, g.n_q, k_stride, g.keys, g.cnt, g.hits, ks + g.first_q, total_hits_thresholds + g.first_q,
-                                        out + g.first_q))
+  // (the verdicts below are taken from the MERGED keys -- the same on every rank that holds the same lists -- never from the caller's
+  //  output arrays: those may be absent or shorter than k, and then differ from rank to rank.  ADVICE round 5.)
+  std::vector<uint64_t> kth(d_guess ? (size_t)g.n_q : 0);
+  if (int rc = merge_topk_device_kth(ctx, d->world, g.n_q, k_stride, g.keys, g.cnt, g.hits, ks + g.first_q, total_hits_thresholds + g.first_q,
+                                     out + g.first_q, d_guess ? kth.data() : nullptr))
     return rc;
   if (n_failed) *n_failed = 0;
   if (!d_guess) return NRTGPU_OK;
@@ -272,9 +314,7 @@ extern "C" int nrtgpu_dist_exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_que
     uint64_t gmax = 0;
     for (size_t w = 0; w < W; ++w) gmax = std::max(gmax, g.guess[w * nq + q]);
     if (gmax == 0) continue;   // (nobody guessed)
-    const nrtgpu_topdocs& o = out[(size_t)g.first_q + q];
-    const int32_t k = ks[(size_t)g.first_q + q];
-    failed[(size_t)g.first_q + q] = (o.n_hits < k || pack_key(o.scores[k - 1], (uint32_t)o.docs[k - 1]) < gmax) ? 1 : 0;
+    failed[(size_t)g.first_q + q] = kth[q] < gmax ? 1 : 0;   // (kth 0: fewer than k hits in the merged list)
   }
   if (g.n_q != n_queries) {   // (sliced: every rank learns every owner's verdicts; the slices are disjoint, so their OR is their union)
     Rccl* r = rccl();
@@ -298,6 +338,14 @@ extern "C" int nrtgpu_dist_exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_que
   return NRTGPU_OK;
 }
 
+extern "C" int nrtgpu_dist_exchange_merge_checked(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys,
+                                                  const void* d_counts, const void* d_hits, const void* d_guess, const int32_t* ks,
+                                                  const int32_t* total_hits_thresholds, int32_t mode, nrtgpu_topdocs* out,
+                                                  uint8_t* failed, int32_t* n_failed) {
+  return exchange_merge_checked(ctx, n_queries, k_stride, d_keys, d_counts, d_hits, d_guess, ks, total_hits_thresholds, mode, out, failed, n_failed,
+                                kNoStatus, std::string());
+}
+
 extern "C" int nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_stride, const void* d_keys, const void* d_counts,
                                           const void* d_hits, const int32_t* ks, const int32_t* total_hits_thresholds, int32_t mode,
                                           nrtgpu_topdocs* out) {
@@ -309,6 +357,16 @@ extern "C" int nrtgpu_dist_allgather_merge(nrtgpu_ctx* ctx, int32_t n_queries, i
                                            const void* d_counts, const void* d_hits, const int32_t* ks,
                                            const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
   return nrtgpu_dist_exchange_merge(ctx, n_queries, k_stride, d_keys, d_counts, d_hits, ks, total_hits_thresholds, NRTGPU_EXCHANGE_ALLGATHER, out);
+}
+
+// A rank whose part of the call failed enters the exchange with EMPTY lists (counts, hit totals and guesses zeroed; the keys behind
+// a zero count are never read) next to its status word.
+static int empty_lists(nrtgpu_ctx* ctx, int32_t n_queries, void* d_counts, void* d_hits, void* d_guess) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemset(d_counts, 0, (size_t)n_queries * 4));
+  HIP_TRY(hipMemset(d_hits, 0, (size_t)n_queries * 8));
+  if (d_guess) HIP_TRY(hipMemset(d_guess, 0, (size_t)n_queries * 8));
+  return NRTGPU_OK;
 }
 
 // This rank's buffer for a whole call: [keys | hits | counts] of n_queries queries.  Calls on one communicator are serialised
@@ -356,14 +414,22 @@ extern "C" int nrtgpu_dist_search_bm25_batch_mode(nrtgpu_ctx* ctx, const nrtgpu_
     d_guess = (uint64_t*)d->my_guess.p;
   }
   bool speculated = false;
+  // (a rank whose shard search fails -- its thread's deadline, a planner refusal, a device error -- still enters the exchange, with
+  //  empty lists and its status: the peers are already on their way into that collective and would wait in it for ever.  Every rank
+  //  then returns an error from step 2.  ADVICE round 5.)
+  int32_t my_status = 0;
+  std::string my_error;
   if (int rc = search_bm25_shard_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lk, lc, lh, may_speculate ? d->world : 0, d_guess,
-                                        &speculated))
-    return rc;
-  // 2. the exchange over xGMI (the guesses ride in the same group), TopDocs.merge of the shards' lists, the check
+                                        &speculated)) {
+    my_status = rc;
+    my_error = g_last_error;
+    if (int rc2 = empty_lists(ctx, n_queries, lc, lh, d_guess)) return rc2;
+  }
+  // 2. the exchange over xGMI (the guesses and the statuses ride in the same group), TopDocs.merge of the shards' lists, the check
   std::vector<uint8_t> failed((size_t)n_queries, 0);
   int32_t n_failed = 0;
-  if (int rc = nrtgpu_dist_exchange_merge_checked(ctx, n_queries, k_stride, lk, lc, lh, d_guess, ks.data(), thr.data(), mode, out,
-                                                  d_guess ? failed.data() : nullptr, d_guess ? &n_failed : nullptr))
+  if (int rc = exchange_merge_checked(ctx, n_queries, k_stride, lk, lc, lh, d_guess, ks.data(), thr.data(), mode, out, d_guess ? failed.data() : nullptr,
+                                      d_guess ? &n_failed : nullptr, my_status, my_error))
     return rc;
   if (speculated) note_shard_speculation(ctx, segs, n_segs, n_queries, n_failed);   // (this rank's verdict on ITS leaf set)
   if (n_failed == 0) return NRTGPU_OK;
@@ -382,9 +448,23 @@ extern "C" int nrtgpu_dist_search_bm25_batch_mode(nrtgpu_ctx* ctx, const nrtgpu_
     rks[i] = rq[i].k;
     rthr[i] = rq[i].total_hits_threshold;
   }
+  // (the re-run is the tail of a search that was launched in time: it ignores the thread's deadline, as the second pass of a single
+  //  GPU's speculative call does -- a rank that timed out HERE would leave between two collectives; and its status travels with
+  //  the lists like the first pass's)
+  struct DeadlineOff {
+    int64_t saved;
+    DeadlineOff() : saved(g_deadline_ns) { g_deadline_ns = 0; }
+    ~DeadlineOff() { g_deadline_ns = saved; }
+  } deadline_off;
   if (int rc = local_lists(d, (int32_t)again.size(), k_stride, &lk, &lh, &lc)) return rc;
-  if (int rc = search_bm25_shard_device(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), k_stride, lk, lc, lh, 0, nullptr, nullptr)) return rc;
-  if (int rc = nrtgpu_dist_exchange_merge(ctx, (int32_t)rq.size(), k_stride, lk, lc, lh, rks.data(), rthr.data(), NRTGPU_EXCHANGE_ALLGATHER, ro.data()))
+  my_status = 0;
+  if (int rc = search_bm25_shard_device(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), k_stride, lk, lc, lh, 0, nullptr, nullptr)) {
+    my_status = rc;
+    my_error = g_last_error;
+    if (int rc2 = empty_lists(ctx, (int32_t)again.size(), lc, lh, nullptr)) return rc2;
+  }
+  if (int rc = exchange_merge_checked(ctx, (int32_t)rq.size(), k_stride, lk, lc, lh, nullptr, rks.data(), rthr.data(), NRTGPU_EXCHANGE_ALLGATHER, ro.data(),
+                                      nullptr, nullptr, my_status, my_error))
     return rc;
   for (size_t i = 0; i < again.size(); ++i)
     if (out[again[i]].total_hits >= 0) {   // (mine: held after the first exchange)
@@ -417,9 +497,15 @@ extern "C" int nrtgpu_dist_knn_exact(nrtgpu_ctx* ctx, const nrtgpu_seg* const* s
   std::lock_guard<std::mutex> call(d->call_mu);
   char *lk = nullptr, *lh = nullptr, *lc = nullptr;
   if (int rc = local_lists(d, n_queries, k_stride, &lk, &lh, &lc)) return rc;
-  if (int rc = knn_exact_device(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, k_stride, lk, lc, lh)) return rc;
+  int32_t my_status = 0;
+  std::string my_error;
+  if (int rc = knn_exact_device(ctx, segs, doc_bases, n_segs, field_id, sim, queries, n_queries, dim, k, boost, k_stride, lk, lc, lh)) {
+    my_status = rc;   // (enters the exchange with empty lists and its status: nrtgpu_dist_search_bm25_batch_mode)
+    my_error = g_last_error;
+    if (int rc2 = empty_lists(ctx, n_queries, lc, lh, nullptr)) return rc2;
+  }
   std::vector<int32_t> ks((size_t)n_queries, k), thr((size_t)n_queries, INT32_MAX);
-  return nrtgpu_dist_exchange_merge(ctx, n_queries, k_stride, lk, lc, lh, ks.data(), thr.data(), mode, out);
+  return exchange_merge_checked(ctx, n_queries, k_stride, lk, lc, lh, nullptr, ks.data(), thr.data(), mode, out, nullptr, nullptr, my_status, my_error);
 }
 
 // The hybrid (BASELINE config 5) over docid-range shards: BM25 recall on every shard -> ONE all-gather + merge on every rank
@@ -448,7 +534,13 @@ extern "C" int nrtgpu_dist_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg
   char *lk = nullptr, *lh = nullptr, *lc = nullptr;
   if (int rc = local_lists(d, n_queries, k_stride, &lk, &lh, &lc)) return rc;
   // 1. the first pass on this shard
-  if (int rc = nrtgpu_search_bm25_batch_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lk, lc, lh)) return rc;
+  int32_t my_status = 0;
+  std::string my_error;
+  if (int rc = nrtgpu_search_bm25_batch_device(ctx, segs, doc_bases, n_segs, queries, n_queries, k_stride, lk, lc, lh)) {
+    my_status = rc;   // (enters the exchange with empty lists and its status: nrtgpu_dist_search_bm25_batch_mode)
+    my_error = g_last_error;
+    if (int rc2 = empty_lists(ctx, n_queries, lc, lh, nullptr)) return rc2;
+  }
   std::vector<int32_t> ks(nq), thr(nq), wins(nq, win);
   for (size_t q = 0; q < nq; ++q) {
     ks[q] = queries[q].k;
@@ -471,23 +563,32 @@ extern "C" int nrtgpu_dist_search_hybrid_batch(nrtgpu_ctx* ctx, const nrtgpu_seg
     std::lock_guard<std::mutex> lk_(d->mu);
     // 2. the global first pass: every rank needs every merged list (its docs may be anywhere in it)
     Gathered g;
-    if (int rc = exchange_lists(ctx, d, n_queries, k_stride, lk, lc, lh, nullptr, NRTGPU_EXCHANGE_ALLGATHER, &g)) return rc;
+    if (int rc = exchange_lists(ctx, d, n_queries, k_stride, lk, lc, lh, nullptr, NRTGPU_EXCHANGE_ALLGATHER, &g, my_status)) return rc;
+    if (int rc = peers_failed(d, g, my_status, my_error)) return rc;
     if (int rc = merge_lists_on_device(ctx, slot, d->world, n_queries, k_stride, g.keys, g.cnt, g.hits, ks.data(), mk, mc, mh)) return rc;
     HIP_TRY(hipStreamSynchronize(slot->stream));   // (`gathered` is free again)
   }
   // 3. this rank's docs of the merged lists, rescored; rank 0 carries the first pass's hit totals
   SegReadLocks content(segs, n_segs);
-  if (int rc = hybrid_tail_on_device(ctx, slot, segs, doc_bases, n_segs, field_id, sim, query_vectors, dim, boost, query_weight, rescore_weight,
-                                     win, n_queries, mk, mc, k_stride, d->world > 1 ? 1 : 0, wk, wc, w_stride))
-    return rc;
-  {
+  auto tail = [&]() -> int {
+    if (int rc = hybrid_tail_on_device(ctx, slot, segs, doc_bases, n_segs, field_id, sim, query_vectors, dim, boost, query_weight, rescore_weight,
+                                       win, n_queries, mk, mc, k_stride, d->world > 1 ? 1 : 0, wk, wc, w_stride))
+      return rc;
     std::vector<uint32_t> hk(nq);
     for (size_t q = 0; q < nq; ++q) hk[q] = (uint32_t)ks[q];
     HIP_TRY(hipMemcpyAsync(qk, hk.data(), nq * 4, hipMemcpyHostToDevice, slot->stream));
     launch_hybrid_hits(slot->stream, (const uint64_t*)mh, (const uint32_t*)mc, (const uint32_t*)qk, d->rank == 0 ? 1 : 0, (uint64_t*)wh, (uint32_t)n_queries);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(slot->stream));   // (hk is a stack vector; the windows must be complete before the exchange reads them)
+    return NRTGPU_OK;
+  };
+  if (int rc = tail()) {   // (a tail that failed on this rank still enters step 4: the peers are on their way into it)
+    my_status = rc;
+    my_error = g_last_error;
+    (void)hipStreamSynchronize(slot->stream);
+    if (int rc2 = empty_lists(ctx, n_queries, wc, wh, nullptr)) return rc2;
   }
   // 4. the windows: exchanged and merged like any per-rank top-k
-  return nrtgpu_dist_exchange_merge(ctx, n_queries, (int32_t)w_stride, wk, wc, wh, wins.data(), thr.data(), mode, out);
+  return exchange_merge_checked(ctx, n_queries, (int32_t)w_stride, wk, wc, wh, nullptr, wins.data(), thr.data(), mode, out, nullptr, nullptr, my_status,
+                                my_error);
 }

@@ -47,7 +47,9 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
 void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int shapes, const MsArgs& args, const MsArgs* args_d);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
-                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, uint32_t n_terms, DTermAux* out);
+                          const uint64_t* t_look, const uint32_t* t_meta, const uint32_t* t_nib, const void* look_base, uint32_t n_terms, DTermAux* out);
+void launch_term_nibs(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
+                      const uint32_t* t_nib, const uint32_t* which, uint32_t n_which, uint32_t max_count, void* look_base);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
                       const uint32_t* which, uint32_t n_which, uint32_t max_count, void* look_base);
 void launch_term_cells(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
@@ -629,6 +631,9 @@ int knn_exact_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32
 int search_bm25_shard_device(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                              const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t k_stride, void* d_keys, void* d_counts, void* d_hits,
                              int32_t spec_world, void* d_guess, bool* speculated);
+// nrtgpu_merge_topk_device + per query the packed key of rank k of the merged list (0: shorter), read from the merged keys
+int merge_topk_device_kth(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride, const void* d_keys_in, const void* d_counts_in,
+                          const void* d_hits_in, const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out, uint64_t* kth);
 // a call that ran under speculation has come back: count it for its leaf set (the verdict: search.cpp)
 void note_shard_speculation(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, int32_t n_segs, int64_t n_queries, int64_t n_failed);
 // TopDocs.merge of n_lists gathered lists per query (layout [list][query]) into DEVICE arrays (keys n_queries x k_stride, counts,

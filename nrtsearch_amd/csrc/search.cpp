@@ -806,6 +806,7 @@ struct CoRequest {
   const nrtgpu_bm25_query* q;
   nrtgpu_topdocs* out;
   int64_t deadline_ns = 0;        // the calling thread's (nrtgpu_set_thread_deadline_ns)
+  std::vector<int32_t> slices;    // the calling thread's slice of every leaf (nrtgpu_set_thread_slices; empty: the library slices the leaves itself)
   nrtgpu_diagnostics diag{};      // of the batch the request travelled in
   int rc = 0;
   bool done = false;   // results (or the error) are in place
@@ -824,7 +825,12 @@ static bool same_leaves(const CoRequest* a, const CoRequest* b) {
   if (a->n_segs == 0) return true;
   if (memcmp(a->segs, b->segs, (size_t)a->n_segs * sizeof(void*)) != 0) return false;
   if ((a->doc_bases == nullptr) != (b->doc_bases == nullptr)) return false;
-  return !a->doc_bases || memcmp(a->doc_bases, b->doc_bases, (size_t)a->n_segs * 4) == 0;
+  if (a->doc_bases && memcmp(a->doc_bases, b->doc_bases, (size_t)a->n_segs * 4) != 0) return false;
+  // The batch is planned on its LEADER's thread, under the leader's slices (planner.cpp reads the planning thread's
+  // nrtgpu_set_thread_slices): a follower travels with a leader only if its own slices are the same -- two searcher versions that
+  // share a resident subset, or virtual shards dealt over different leaf lists, slice the same leaves differently, and the
+  // per-slice hit counts (the totalHits relation, the route) follow the slices.
+  return a->slices == b->slices;
 }
 
 extern "C" int nrtgpu_set_coalescing(nrtgpu_ctx* ctx, int32_t linger_us) {
@@ -873,6 +879,7 @@ extern "C" int nrtgpu_search_bm25_coalesced(nrtgpu_ctx* ctx, const nrtgpu_seg* c
   NRT_CHECK_DEADLINE("before the request was queued");
   CoRequest me{segs, doc_bases, n_segs, q, out};
   me.deadline_ns = g_deadline_ns;
+  if ((int32_t)g_thread_slices.size() == n_segs) me.slices = g_thread_slices;   // (a list of another length is ignored by the planner as well)
   std::vector<CoRequest*> batch;
   {
     std::unique_lock<std::mutex> lk(ctx->co_mu);
@@ -1255,6 +1262,16 @@ extern "C" int nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtg
 extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride,
                                         const void* d_keys_in, const void* d_counts_in, const void* d_hits_in,
                                         const int32_t* ks, const int32_t* total_hits_thresholds, nrtgpu_topdocs* out) {
+  return nrtgpu::rt::merge_topk_device_kth(ctx, n_lists, n_queries, k_stride, d_keys_in, d_counts_in, d_hits_in, ks, total_hits_thresholds, out, nullptr);
+}
+
+// nrtgpu_merge_topk_device, and per query the packed key of rank k of the MERGED list (kth[q]; 0: the list is shorter than k) --
+// read from the merged keys themselves, not from the caller's output arrays: those may be absent or shorter than k
+// (unpack_topdocs copies what fits), and a verdict taken from them would differ between ranks whose callers sized them
+// differently (dist.cpp: the check of the shards' speculative thresholds).
+int nrtgpu::rt::merge_topk_device_kth(nrtgpu_ctx* ctx, int32_t n_lists, int32_t n_queries, int32_t k_stride, const void* d_keys_in,
+                                      const void* d_counts_in, const void* d_hits_in, const int32_t* ks, const int32_t* total_hits_thresholds,
+                                      nrtgpu_topdocs* out, uint64_t* kth) {
   forget_foreign_hip_error();
   if (!ctx || !d_keys_in || !d_counts_in || !d_hits_in || !ks || !total_hits_thresholds || !out)
     return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
@@ -1305,8 +1322,10 @@ extern "C" int nrtgpu_merge_topk_device(nrtgpu_ctx* ctx, int32_t n_lists, int32_
     const int n_chunks = n_queries >= 64 ? std::min(std::min(8, n_queries / 32), ctx->pool->helpers() + 1) : 1;
     ctx->pool->run(n_chunks, [&](int c) {
       const int q0 = (int)((int64_t)n_queries * c / n_chunks), q1 = (int)((int64_t)n_queries * (c + 1) / n_chunks);
-      for (int qi = q0; qi < q1; ++qi)
+      for (int qi = q0; qi < q1; ++qi) {
         unpack_topdocs(keys + (size_t)qi * k_stride, cnts[qi], hits[qi], ks[qi], 0, cnts[qi], &out[qi]);
+        if (kth) kth[qi] = cnts[qi] >= (uint32_t)ks[qi] ? keys[(size_t)qi * k_stride + (size_t)ks[qi] - 1u] : 0ull;
+      }
     });
   }
   return NRTGPU_OK;

@@ -15,6 +15,11 @@
 #                emulate24: the same for one rank of two / of four (peers' bounds present, shard-level speculation)
 #   c4           the full C4 lines (1 / 32 / 64 queries per pass)
 #   gather       scripts/ubench/gather_fetch under rocprofv3 --pmc FETCH_SIZE (what the counter tallies per access pattern)
+#   cache        (round 6) the cache path of the MaxScore kernel, one --pmc pass per counter block: L2 hits / misses / requests,
+#                fabric-side read requests by size and target, what the vector L1s ask the L2 for and how long it takes, texture
+#                addresser busy / stalled cycles, L1 TLB -> <tag>_pmc_cache.txt
+#   gathersweep  scripts/ubench/gather_fetch sweep: G lines/s of random 8-byte gathers by footprint (2 MiB ... 4 GiB), alone and
+#                under --pmc (L2 hits / misses, fabric-side requests per launch, launches in the printed order)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOT=$(pwd); export TMPDIR=/tmp
 TAG=${1:?tag}; shift
@@ -96,6 +101,37 @@ for r in csv.DictReader(open(sys.argv[1])): print(r['Name'][:60].ljust(60), r['C
 c4)
   el "C4 lines"
   for q in 1 32 64; do timeout 400 python bench.py --workload C4 --knn-queries $q --steps 20 --warmup 4 2>/dev/null | tee $O/${TAG}_bench_c4_q$q.json | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('c4 q$q', d['value'], d['ms_per_step'], r['kernel'], r['avg_launch_ms'], 'frac', r['frac'], 'mfma', r['mfma_frac'], 'traffic', r['traffic'], 'verify', (d.get('verify') or {}).get('agrees_with_fp64'))"; done ;;
+cache)
+  el "cache-path PMC passes"
+  rm -f $O/${TAG}_pmc_cache.txt
+  cpmc() { n=$1; shift; pmc $n bm25_maxscore "$@" -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1 | tee -a $O/${TAG}_pmc_cache.txt; }
+  cpmc tcc_hit TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum GRBM_GUI_ACTIVE
+  cpmc tcc_ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum
+  cpmc tcc_stall TCC_TAG_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum
+  cpmc tcp_req TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum
+  cpmc tcp_stall TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
+  cpmc tcp_stall2 TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_READ_sum
+  cpmc ta TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
+  cpmc ta2 TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_BUSY_max TA_BUSY_min
+  cpmc tlb TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum
+  cpmc sq_mem SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY
+  ;;
+gathersweep)
+  el "gather ceiling by footprint"
+  ( cd /tmp && timeout 200 $ROOT/scripts/ubench/gather_fetch sweep ) 2>&1 | grep "^sweep" | tee $O/${TAG}_gather_sweep.txt
+  for cs in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"; do
+    rm -rf /tmp/pmcs; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $cs -d /tmp/pmcs -o g --output-format csv -- $ROOT/scripts/ubench/gather_fetch sweep > /tmp/pmcs.log 2>&1 )
+    f=$(find /tmp/pmcs -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python - "$f" <<'PY' | tee -a $O/${TAG}_gather_sweep.txt
+import csv, sys, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'gather_mod' in r['Kernel_Name']]
+by = collections.OrderedDict()
+for r in rows:
+    by.setdefault(r['Dispatch_Id'], {})[r['Counter_Name']] = float(r['Counter_Value'])
+for i, (d, c) in enumerate(sorted(by.items(), key=lambda kv: int(kv[0]))):
+    print('sweep_pmc launch', i, '(footprint', i // 3, 'rep', i % 3, ')', {k: round(v) for k, v in c.items()})
+PY
+  done ;;
 gather)
   el "gather calibration"
   rm -rf /tmp/pmcg; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmcg -o g --output-format csv -- $ROOT/scripts/ubench/gather_fetch 4 > $O/${TAG}_gather_fetch.txt 2>&1 )

@@ -43,7 +43,63 @@ __global__ __launch_bounds__(256) void gather(const char* __restrict__ base, uin
   if (acc == 0x12345u) *sink = acc;
 }
 
+// `gather_fetch sweep [MiB ...]` (round 6): the gather ceiling as a function of the FOOTPRINT the gathers fall into -- 2^26 8-byte
+// gathers per launch at line (i x P) mod n_lines (P prime: a bijection on any n_lines it does not divide; every line is asked for
+// 2^26 / n_lines times per launch, scattered over the launch) -- from a footprint one XCD's L2 holds to one far beyond the Infinity
+// Cache.  1536 MiB is bm25_maxscore_kernel's resident index at C3.  Under `rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum ...` the
+// launches are told apart by their order (the program prints the footprints in launch order).
+__global__ __launch_bounds__(256) void gather_mod(const char* __restrict__ base, uint64_t n_loads, uint64_t n_lines, uint32_t* sink) {
+  uint32_t acc = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_loads; i += stride) {
+    const uint64_t line = (i * 2654435761ull) % n_lines;
+    const u32x2 v = *(const u32x2*)(base + line * 64ull + ((i * 5ull) & 7ull) * 8ull);
+    acc += v[0] ^ v[1];
+  }
+  if (acc == 0x12345u) *sink = acc;
+}
+
+static int sweep(int argc, char** argv) {
+  uint64_t mibs[16] = {2, 16, 64, 128, 256, 512, 1024, 1536, 4096};
+  int n = 9;
+  if (argc > 2) {
+    n = 0;
+    for (int i = 2; i < argc && n < 16; ++i) mibs[n++] = strtoull(argv[i], nullptr, 10);
+  }
+  uint64_t max_mib = 0;
+  for (int i = 0; i < n; ++i) max_mib = mibs[i] > max_mib ? mibs[i] : max_mib;
+  char* buf = nullptr;
+  uint32_t* sink = nullptr;
+  CHECK(hipMalloc((void**)&buf, max_mib << 20));
+  CHECK(hipMalloc((void**)&sink, 4));
+  CHECK(hipMemset(buf, 1, max_mib << 20));
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const uint64_t n_loads = 1ull << 26;
+  for (int i = 0; i < n; ++i) {
+    const uint64_t n_lines = (mibs[i] << 20) / 64ull;
+    float ms = 0.f, best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {   // (three launches per footprint: the first warms TLBs and caches)
+      CHECK(hipEventRecord(e0));
+      hipLaunchKernelGGL(gather_mod, dim3(256 * 16), dim3(256), 0, 0, (const char*)buf, n_loads, n_lines, sink);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      best = ms < best ? ms : best;
+    }
+    printf("sweep footprint_MiB %llu loads %llu visits_per_line %.2f best_ms %.3f G_lines_per_s %.1f line_GBps %.1f\n", (unsigned long long)mibs[i],
+           (unsigned long long)n_loads, (double)n_loads / (double)n_lines, best, (double)n_loads / (best * 1e-3) / 1e9, (double)n_loads * 64.0 / (best * 1e-3) / 1e9);
+  }
+  CHECK(hipGetLastError());
+  CHECK(hipFree(buf));
+  CHECK(hipFree(sink));
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 's') return sweep(argc, argv);
   const uint64_t gib = argc > 1 ? strtoull(argv[1], nullptr, 10) : 4ull;
   const uint64_t bytes = gib << 30;                 // a power of two: the scramble is a bijection on its lines
   const uint64_t n_lines = bytes / 64ull;

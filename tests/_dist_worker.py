@@ -107,6 +107,22 @@ def main():
         out["pipelined_failed_" + name] = [int(j) for j in bad]
     for p_ in (d_keys, d_cnt, d_hits, d_guess):
         hip.hipFree(C.c_void_p(p_))
+    # ONE rank's part of a one-call search fails (rank 1: its thread's deadline has passed before the shard search is planned):
+    # it must still enter the exchange -- with empty lists and its status -- so that the other rank is not left waiting in the
+    # collective; EVERY rank gets an error (the failed one its own, the others one that names it), in both exchange forms, and the
+    # communicator is usable afterwards ("a failing rank strands the others")
+    for name, mode in (("allgather", api.EXCHANGE_ALLGATHER), ("alltoall", api.EXCHANGE_ALLTOALL)):
+        if rank == 1:
+            api.GpuContext.set_thread_deadline(-1.0)
+        try:
+            sr.dist_search_batch(queries, [mgr] * n_queries, mode=mode)
+            out["one_rank_fails_" + name] = "no error"
+        except Exception as e:   # noqa: BLE001
+            out["one_rank_fails_" + name] = str(e)
+        finally:
+            api.GpuContext.set_thread_deadline(None)
+    got = sr.dist_search_batch(queries, [mgr] * n_queries, mode=api.EXCHANGE_ALLGATHER)
+    out["after_failure_allgather"] = [None if g is None else (g.docs, g.scores, g.total_hits, g.relation_gte) for g in got]
     out["stats"] = ctx.stats()
     with open(out_path, "wb") as f:
         pickle.dump(out, f)

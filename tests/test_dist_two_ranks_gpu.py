@@ -35,7 +35,7 @@ def mockrccl(tmp_path_factory):
 
 
 @pytest.mark.parametrize("variant", ["iid", "sorted"])
-def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrccl, variant):
+def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrccl, variant, oracle):
     """variant "iid": every posting list an independent draw -- a shard IS a sample of the index, the shards' speculative
     thresholds (guesses at the WHOLE search's k-th score, search.cpp: spec_world) stand.  "sorted": docs numbered by length, so
     rank 0's docid range holds the short docs and with them most of every top-k -- its guesses are too high, the check against
@@ -109,6 +109,30 @@ def test_two_ranks_through_the_librarys_collective_equal_the_whole_index(mockrcc
             assert ranks[0]["pipelined_failed_" + form] == ranks[1]["pipelined_failed_" + form]
         if variant == "sorted":
             assert len(ranks[0]["pipelined_failed_allgather"]) >= 1
+        # ... and against the ORACLE directly (the lists nrtgpu_dist_* merged were only ever compared with another HIP
+        # run): docids, ranks and score bits of every form on every rank that holds the answer equal the CPU restatement's exhaustive
+        # search over the whole index (one corpus object over all leaves, index-global statistics); the relation is the oracle's too
+        whole_corpus = synth.Corpus(n_docs=pieces[0].n_docs, doc_count=pieces[0].doc_count, sum_total_term_freq=pieces[0].sum_total_term_freq,
+                                    segments=[seg for c in pieces for seg in c.segments], doc_freq=pieces[0].doc_freq)   # the leaves the ranks hold
+        for qi in range(n_q):
+            edocs, escores, etotal, egte = oracle.search_bm25(whole_corpus, [int(t) for t in qr[qi]], k)
+            for what in ("bm25", "bm25_nospec", "bm25_pipelined"):
+                for form in ("allgather", "alltoall"):
+                    for r in range(world):
+                        g = ranks[r][f"{what}_{form}"][qi]
+                        if g is None:
+                            continue
+                        assert g[0].tolist() == edocs.tolist(), f"{what} {form} rank {r} query {qi}: docids / ranks differ from the oracle's"
+                        assert g[1].view(np.uint32).tolist() == escores.view(np.uint32).tolist(), f"{what} {form} rank {r} query {qi}: score bits"
+                        assert (max(k, 1000) < g[2] <= etotal) if g[3] else (g[2] == etotal and not egte), (what, form, r, qi, g[2], g[3], etotal, egte)
+        # a rank whose part of a call failed (tests/_dist_worker.py: rank 1's deadline) entered the exchange with its status: nobody
+        # hung, both ranks got an error (rank 0's names rank 1), and the next call went through with the whole-index answers
+        for r in range(world):
+            for form in ("allgather", "alltoall"):
+                msg = ranks[r]["one_rank_fails_" + form]
+                assert ("deadline" in msg) if r == 1 else ("rank 1 of 2 failed" in msg), (r, form, msg)
+            for qi in range(n_q):
+                same(ranks[r]["after_failure_allgather"][qi], whole[qi])
         cases = [("bm25", whole, True), ("bm25_nospec", whole, True), ("bm25_pipelined", whole, True)]
         if variant == "iid":
             cases += [("knn", whole_knn, False), ("hybrid", whole_hy, True)]

@@ -66,6 +66,12 @@ def test_two_ranks_run_the_librarys_exchange_to_the_end_without_a_gpu(stand_ins)
         # every rank is told all three, in both forms -- all-gather: every rank holds every guess; all-to-all: the owners' verdicts are
         # all-gathered -- and the re-run of those three (a collective call of its own) went through
         assert ranks[r]["pipelined_failed_allgather"] == [1, 5, 9] and ranks[r]["pipelined_failed_alltoall"] == [1, 5, 9], ranks[r]
+        # rank 1's shard search timed out before it was planned: it entered the exchange all the same (empty lists + its status), so
+        # nobody hung; rank 1 reports its own error, rank 0 one that names rank 1; the next call on the communicator goes through
+        for name in ("allgather", "alltoall"):
+            msg = ranks[r]["one_rank_fails_" + name]
+            assert ("deadline" in msg) if r == 1 else ("rank 1 of 2 failed" in msg), (r, name, msg)
+        assert len(ranks[r]["after_failure_allgather"]) == n_q and all(g is not None for g in ranks[r]["after_failure_allgather"])
 
 
 @pytest.mark.parametrize("mode", ["alltoall", "allgather"])

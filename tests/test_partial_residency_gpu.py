@@ -116,3 +116,75 @@ def test_virtual_shards_need_the_callers_slices(oracle):
         for g in leaves:
             g.release()
         ctx.close()
+
+
+def test_coalesced_callers_with_different_slices_do_not_share_a_batch(dev_lib, oracle):
+    """nrtgpu_search_bm25_coalesced plans a batch on its LEADER's thread, under the leader's nrtgpu_set_thread_slices.  Two searcher
+    versions over the same resident leaves may slice them differently (virtual shards dealt over different leaf lists, a cold leaf
+    in one of them): callers whose slices differ must not travel in one batch, or the followers' per-slice hit counts -- the
+    totalHits relation -- would be the leader's.  Sixteen callers parked behind the development library's hook,
+    eight with "every leaf its own slice", eight with "all leaves one slice", the same leaves: TWO batches, and every caller gets
+    the relation of ITS slices -- one collector per leaf never passes the threshold (exact count), one collector over all leaves
+    does (lower bound)."""
+    import threading
+    import time
+
+    ranks = [200, 400, 2000]   # rank 200: 1592 postings, 796 of them in the largest leaf: above the threshold together, below it leaf by leaf
+    corpus = synth.build_corpus(320_000, ranks, n_segments=8)
+    n_leaves = len(corpus.segments)
+    ctx = api.GpuContext(device_id=0, max_batch=64)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    k, thr = 10, 1000
+    slicings = {"per_leaf": list(range(n_leaves)), "one": [0] * n_leaves}
+    try:
+        expected = {}
+        for name, sl in slicings.items():
+            for terms in ([200], [400, 2000]):
+                groups = [[li for li in range(n_leaves) if sl[li] == s] for s in sorted(set(sl))]
+                parts = [oracle.search_bm25(corpus, terms, k, total_hits_threshold=thr, segments=g) for g in groups]
+                expected[(name, tuple(terms))] = reduce_parts(oracle, k, parts)
+        # (the point of the test: the two slicings disagree about the relation of the frequent term)
+        assert expected[("per_leaf", (200,))][3] is False and expected[("one", (200,))][3] is True
+        errors, results = [], {}
+        ctx.reset_stats()
+        ctx.debug_hold_coalescers(True)
+
+        def one(tix):
+            name = "per_leaf" if tix % 2 == 0 else "one"
+            terms = [200] if (tix // 2) % 2 == 0 else [400, 2000]
+            try:
+                api.GpuContext.set_thread_slices(slicings[name])
+                try:
+                    r = sr.search_coalesced(bq(terms), api.TopScoreDocCollectorManager(k, total_hits_threshold=thr))
+                finally:
+                    api.GpuContext.set_thread_slices(None)
+                results[tix] = (name, tuple(terms), r)
+            except Exception as e:  # noqa: BLE001
+                errors.append((tix, repr(e)))
+
+        threads = [threading.Thread(target=one, args=(t,)) for t in range(16)]
+        try:
+            for t in threads:
+                t.start()
+            t_end = time.monotonic() + 60.0
+            while ctx.debug_coalescer_pending(0) < 16 and time.monotonic() < t_end and not errors:
+                time.sleep(0.001)
+            parked = ctx.debug_coalescer_pending(0)
+        finally:
+            ctx.debug_hold_coalescers(False)
+        for t in threads:
+            t.join()
+        assert not errors, errors[:5]
+        assert parked == 16
+        st = ctx.stats()
+        assert st["queries"] == 16 and st["batches"] == 2, st     # one batch per slicing, not one for all
+        for tix, (name, terms, r) in results.items():
+            docs, scores, total, gte = expected[(name, terms)]
+            assert r.docs.tolist() == docs.tolist() and r.scores.view(np.uint32).tolist() == scores.view(np.uint32).tolist(), (tix, name, terms)
+            assert r.relation_gte == gte, (tix, name, terms, r.relation_gte, gte)
+            assert (max(thr, k) < r.total_hits <= total) if gte else r.total_hits == total, (tix, name, terms, r.total_hits, total)
+    finally:
+        for g in leaves:
+            g.release()
+        ctx.close()
