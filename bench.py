@@ -109,6 +109,12 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="debug, 1 GPU: index only rank 0's docid range of an N-GPU job (per-rank step time at --gpus N)")
     ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's shard (the last rank holds the small segments)")
+    ap.add_argument("--doc-shards", type=int, default=0,
+                    help="N > 1: the topology N = D doc-shards x R query-groups.  D ranks share the index by docid range and exchange their "
+                         "top-k (one communicator per group of D consecutive ranks); the R = N / D groups hold the same index and take "
+                         "DIFFERENT batches of the query set.  0 = N (every GPU a shard of ONE search: BASELINE.json's north-star form); "
+                         "1 = N replicas, no exchange.  Sharding buys latency, replication throughput (DESIGN 7: every BASELINE config "
+                         "fits one MI355X); value counts the queries of all groups")
     ap.add_argument("--shard-layout", default="index", choices=["index", "per_shard", "balanced"],
                     help="N>1: a rank owns the pieces of the index's segments inside its docid range (default); per_shard (rounds 1-2): "
                          "its range cut into a full set of tiered segments of its own; balanced: the index's small segments are dealt "
@@ -637,6 +643,13 @@ def main():
         args.gpus = world
     if args.workload == "C4":
         return run_c4(args)
+    # the topology (--doc-shards): D ranks per doc-shard group, R groups; rank = group * D + its place in the group
+    from nrtsearch_amd import dist as nd
+
+    try:
+        D, R, group, grank = nd.topology(world, rank, args.doc_shards)
+    except ValueError as e_:
+        sys.exit(f"--doc-shards: {e_}")
 
     import torch  # first: its bundled HIP runtime must be the one libnrtgpu.so binds to
     import torch.distributed as dist
@@ -655,21 +668,25 @@ def main():
 
             stdout_to_stderr(_init)
 
+    # the doc-shard group's own process group (torch.distributed collectives of the exchange stay inside it); every rank creates
+    # every group, in the same order
+    pg = nd.doc_shard_groups(world, D) if world > 1 else None
+
     def all_gather(dst, src):
         if args.debug_same_gpu:   # gloo: stage through the host
             tmp = torch.empty(dst.shape, dtype=dst.dtype)
-            dist.all_gather_into_tensor(tmp, src.cpu())
+            dist.all_gather_into_tensor(tmp, src.cpu(), group=pg)
             dst.copy_(tmp)
         else:
-            dist.all_gather_into_tensor(dst, src)
+            dist.all_gather_into_tensor(dst, src, group=pg)
 
     def all_to_all(dst, src):
         if args.debug_same_gpu:
             tmp = torch.empty(dst.shape, dtype=dst.dtype)
-            dist.all_to_all_single(tmp, src.cpu())
+            dist.all_to_all_single(tmp, src.cpu(), group=pg)
             dst.copy_(tmp)
         else:
-            dist.all_to_all_single(dst, src)
+            dist.all_to_all_single(dst, src, group=pg)
 
     import numpy as np
 
@@ -685,7 +702,8 @@ def main():
     n_distinct = max(B, (w.n_queries // B) * B)
     qranks = synth.make_queries(n_distinct, w.n_terms, w.max_rank)
     t_build = time.perf_counter()
-    shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if (args.emulate_world > 1 and world == 1) else (world, rank)
+    # (a real job: this rank's docid shard is its place in its doc-shard group; one GPU emulating a rank of a larger job: that rank's)
+    shard_world, shard_rank = (args.emulate_world, args.emulate_rank) if (args.emulate_world > 1 and world == 1) else (D, grank)
     corpus = workload.build_shard_corpus(w, qranks, shard_world, shard_rank, layout=args.shard_layout, variant=args.corpus_variant)
     t_build = time.perf_counter() - t_build
 
@@ -697,7 +715,7 @@ def main():
     # planner threads per in-flight call: what the box's CPUs allow once every rank has its submitting threads
     # (the node's ranks share the host; 4 is the library's default and enough at one rank)
     # (a rank of an N-GPU job has ONE submitting thread unless --sync-submit)
-    if args.sync_submit or not (world > 1 or args.force_dist):
+    if args.sync_submit or not (D > 1 or args.force_dist):
         submitters = max(1, args.host_threads)
     else:   # begin / wait: one submitting thread per rank, two where the host can afford them
         submitters = args.submitters if args.submitters > 0 else (2 if usable_cpus() >= 6 * max(world, shard_world) else 1)
@@ -715,21 +733,26 @@ def main():
     ppq = workload.postings_per_query(corpus.doc_freq, qranks)   # index-global P per query
 
     k_stride = (w.k + 15) // 16 * 16
-    use_dist = world > 1 or args.force_dist
+    use_dist = D > 1 or args.force_dist   # (D == 1 at N > 1: replicas -- every rank runs the one-GPU loop over ITS batches, nothing is exchanged)
+
+    def batch_index(step):
+        """Which batch of the query set this rank's doc-shard group runs at its step `step`: the groups interleave (group g takes
+        batches g, g + R, ...), so that at any time the R groups work on R different batches."""
+        return (step * R + group) % len(batches)
     exchange_name = None
     emu_exchange = False
     lib_mode = api.EXCHANGE_ALLGATHER
     peer_words = None   # --emulate-peers final: [batch] -> (shard_world, B) uint32 score bits the other ranks would publish
-    shard_spec = use_dist and max(world, shard_world) > 1 and args.shard_bounds == "speculation" and not args.no_prune and args.emulate_peers == "none"
+    shard_spec = use_dist and shard_world > 1 and args.shard_bounds == "speculation" and not args.no_prune and args.emulate_peers == "none"
     shard_spec_stat = {"queries": 0, "failed": 0, "reran_batches": 0}
-    if world > 1 and not args.no_exchange and args.shard_bounds == "exchange":
-        # cross-GPU bound exchange (include/nrtgpu.h): one shared-memory table per job, opened by every rank
+    if D > 1 and world > 1 and not args.no_exchange and args.shard_bounds == "exchange":
+        # cross-GPU bound exchange (include/nrtgpu.h): one shared-memory table per doc-shard group, opened by every rank of it
         import uuid
         box = [f"/nrtgpu_bench_{uuid.uuid4().hex[:16]}" if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        exchange_name = box[0]
+        exchange_name = box[0] + f"_g{group}"
         try:
-            ctx.exchange_open(exchange_name, world, rank)
+            ctx.exchange_open(exchange_name, D, grank)
         except Exception as e:   # a rank without the table only misses the pruning; results do not depend on it
             print(f"[rank {rank}] bound exchange unavailable: {e}", file=sys.stderr, flush=True)
         dist.barrier()
@@ -777,11 +800,11 @@ def main():
         # instead: rank r receives every rank's lists for ITS B / world queries (rows [j * B/world, (j + 1) * B/world)
         # came from rank j) and merges only those -- 1/world of the bytes and of the merge work; the exchange stage
         # is overlapped with the scans either way, so this changes latency, not throughput.
-        split_reduce = (B % world == 0) and args.all_to_all and args.torch_collective
+        split_reduce = (B % D == 0) and args.all_to_all and args.torch_collective
         if split_reduce and world > 1:   # probe the collective once; every rank must take the same path
             ok = 1
             try:
-                probe = torch.zeros((world * 2,), dtype=torch.int64, device="cuda")
+                probe = torch.zeros((D * 2,), dtype=torch.int64, device="cuda")
                 all_to_all(torch.empty_like(probe), probe)
                 torch.cuda.synchronize()
             except Exception as e:   # noqa: BLE001
@@ -790,16 +813,15 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if args.debug_same_gpu else "cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             split_reduce = bool(flag.item())
-        rows = B if split_reduce else world * B
+        rows = B if split_reduce else D * B
         g_keys = torch.zeros((rows, k_stride), dtype=torch.int64, device="cuda")
         g_cnt = torch.zeros((rows,), dtype=torch.int32, device="cuda")
         g_hits = torch.zeros((rows,), dtype=torch.int64, device="cuda")
-        mq = B // world if split_reduce else B
-        shard_exchange_world = shard_world if shard_world != world else world   # (emulation: the slice a rank of that job would own)
-        merger = api.PreparedMerge(ctx, world, mq, k_stride, [w.k] * mq, [api.TOTAL_HITS_THRESHOLD] * mq)
+        mq = B // D if split_reduce else B
+        merger = api.PreparedMerge(ctx, D, mq, k_stride, [w.k] * mq, [api.TOTAL_HITS_THRESHOLD] * mq)
         # The exchange stage through the C ABI (what a JVM caller has): the library's own RCCL communicator, one grouped
         # all-gather + merge per batch.  Every rank must take the same path: agree on it once.
-        lib_mode = api.EXCHANGE_ALLTOALL if (args.exchange_mode == "alltoall" and B % world == 0) else api.EXCHANGE_ALLGATHER
+        lib_mode = api.EXCHANGE_ALLTOALL if (args.exchange_mode == "alltoall" and B % D == 0) else api.EXCHANGE_ALLGATHER
         # One GPU playing rank r of an N-GPU job (--emulate-world): the exchange stage does the work THAT rank would do -- the
         # merge of N lists for its slice of the batch (all-to-all) or for every query (all-gather), the result copy and the
         # unpacking -- with the other ranks' lists stood in for by copies of its own (the xGMI transfer itself, ~1 MB per link and
@@ -823,9 +845,14 @@ def main():
         if not (args.torch_collective or (args.debug_same_gpu and not debug_lib) or split_reduce or emu_exchange):
             ok = 1
             try:
-                box = [api.GpuContext.dist_unique_id() if rank == 0 else None]
+                # one communicator per doc-shard group: its first rank makes the id, every rank learns every group's
+                ids = [None] * world
+                mine = api.GpuContext.dist_unique_id() if grank == 0 else None
                 if world > 1:
-                    dist.broadcast_object_list(box, src=0)
+                    dist.all_gather_object(ids, mine)
+                else:
+                    ids = [mine]
+                box = [ids[group * D]]
                 # communicator + one exchange of the real shape, under a watchdog: a setup that never returns must cost
                 # this run the library path, not the measurement (the ranks then agree on torch.distributed below)
                 import threading as _th
@@ -834,7 +861,7 @@ def main():
 
                 def _probe():
                     try:
-                        stdout_to_stderr(lambda: ctx.dist_init(world, rank, box[0]))
+                        stdout_to_stderr(lambda: ctx.dist_init(D, grank, box[0]))
                         keys0, cnt0, hits0 = bufs[0]
                         merger.run_dist(keys0.data_ptr(), cnt0.data_ptr(), hits0.data_ptr(), lib_mode)   # (zero counts: merges nothing)
                     except Exception as e_:   # noqa: BLE001
@@ -875,7 +902,7 @@ def main():
             def worker(tix):
                 for i in range(tix, count, n_thr):
                     ts = time.perf_counter()
-                    pb = batches[(first + i) % len(batches)]
+                    pb = batches[batch_index(first + i)]
                     pb.run()
                     if record:
                         lat.append(time.perf_counter() - ts)
@@ -913,10 +940,10 @@ def main():
             free[b].acquire()          # the exchange thread has gathered this buffer's previous contents
             t_start[i] = time.perf_counter()
             keys, cnt, hits = bufs[b]
-            pb = batches[(first + i) % len(batches)]
+            pb = batches[batch_index(first + i)]
             play_peers(first + i)
             if spec_on[0]:   # this shard's thresholds: guesses at the whole search's k-th score, left in guess_bufs[b] for the check
-                pending[i] = pb.begin_shard_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), max(world, shard_world),
+                pending[i] = pb.begin_shard_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), shard_world,
                                                    guess_bufs[b].data_ptr())
             elif args.sync_submit:
                 pb.run_device(k_stride, keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), epoch=(first + i) if exchange_name else -1)
@@ -951,7 +978,7 @@ def main():
                     # (a key is (score bits << 32) | ~docid and docids are unique across the shards of a real job: the stand-in
                     #  lists get distinct docids -- list l flips bits 27-29 of the docid word with l -- so the merge sees N disjoint
                     #  lists of the same shape and order; the selection kernels assume unique keys)
-                    bi_ = (first + i) % len(batches)
+                    bi_ = batch_index(first + i)
                     e_keys[bi_][shard_rank].copy_(keys[:mq_e])
                     e_cnt[bi_][shard_rank].copy_(cnt[:mq_e])
                     e_hits[bi_][shard_rank].copy_(hits[:mq_e])
@@ -968,9 +995,9 @@ def main():
                         bad = np.flatnonzero((g_ != 0) & (merger.kth_keys() < g_))
                         shard_spec_stat["queries"] += mq_e
                         shard_spec_stat["failed"] += len(bad)
-                        batches[(first + i) % len(batches)].note_shard_speculation(mq_e, len(bad))
+                        batches[batch_index(first + i)].note_shard_speculation(mq_e, len(bad))
                         if len(bad):
-                            tk, tc, th_ = run_again(batches[(first + i) % len(batches)], bad)
+                            tk, tc, th_ = run_again(batches[batch_index(first + i)], bad)
                             stage_lists(bi_, tk, tc, th_)
                             torch.cuda.current_stream().synchronize()
                             merger.run(e_keys[bi_].data_ptr(), e_cnt[bi_].data_ptr(), e_hits[bi_].data_ptr())
@@ -985,13 +1012,13 @@ def main():
                     # verdicts on every rank; what failed is run again by every rank without speculation, gathered whole
                     bad = merger.run_dist_checked(keys.data_ptr(), cnt.data_ptr(), hits.data_ptr(), guess_bufs[b].data_ptr(), lib_mode)
                     free[b].release()
-                    pb_ = batches[(first + i) % len(batches)]
+                    pb_ = batches[batch_index(first + i)]
                     shard_spec_stat["queries"] += B
                     shard_spec_stat["failed"] += len(bad)
                     pb_.note_shard_speculation(B, len(bad))
                     if len(bad):
                         shard_spec_stat["reran_batches"] += 1
-                        q0 = ((first + i) % len(batches)) * B
+                        q0 = batch_index(first + i) * B
                         last["rerun"] = searcher.dist_search_batch([queries[q0 + int(j)] for j in bad], [mgr] * len(bad),
                                                                    mode=api.EXCHANGE_ALLGATHER | api.EXCHANGE_NO_SPECULATION)
                     if record:
@@ -1008,9 +1035,9 @@ def main():
                         stage["steps"] += 1
                     continue
                 exchange = all_to_all if split_reduce else all_gather
-                exchange(g_keys, keys) if world > 1 else g_keys.copy_(keys)
-                exchange(g_cnt, cnt) if world > 1 else g_cnt.copy_(cnt)
-                exchange(g_hits, hits) if world > 1 else g_hits.copy_(hits)
+                exchange(g_keys, keys) if (world > 1 and D > 1) else g_keys.copy_(keys)
+                exchange(g_cnt, cnt) if (world > 1 and D > 1) else g_cnt.copy_(cnt)
+                exchange(g_hits, hits) if (world > 1 and D > 1) else g_hits.copy_(hits)
                 torch.cuda.current_stream().synchronize()   # only this stream: the next scan keeps running
                 free[b].release()
                 te1 = time.perf_counter()
@@ -1081,7 +1108,7 @@ def main():
         elapsed = float(t.item())
 
     st = ctx.stats()
-    n_q = args.steps * B
+    n_q = args.steps * B * R   # (every doc-shard group ran `steps` batches of its own)
     qps = n_q / elapsed
     # Dominant kernel: whichever of the two scorers took more device time -- bm25_maxscore_kernel (dynamic pruning;
     # the default for this workload) or bm25_scan_kernel (exhaustive).  achieved = algorithmic bytes per launch / avg
@@ -1141,6 +1168,9 @@ def main():
             "n_docs": w.n_docs, "terms_per_query": w.n_terms, "k": w.k, "batch_queries": B,
             "total_hits_threshold": api.TOTAL_HITS_THRESHOLD,
             "segments_per_gpu": len(corpus.segments),
+            "topology": {"doc_shards": D, "query_groups": R,
+                         "note": "N = D x R: D GPUs share the index by docid range and exchange their top-k; R such groups hold the same index and "
+                                 "take different batches (value counts all groups' queries; latencies are one group's batch calls)"},
             "sharding": "contiguous docid ranges, 1 process per GPU" + ((", RCCL all-to-all of per-GPU top-k, each rank merges its slice of the batch" if split_reduce else
                                                                            (", RCCL all-to-all of per-GPU top-k, each rank merges and delivers its slice of the batch" if (lib_collective and lib_mode == api.EXCHANGE_ALLTOALL)
                                                                             else ", RCCL all-gather of per-GPU top-k + merge on every rank")) if use_dist else "")
@@ -1151,7 +1181,8 @@ def main():
                         + (", shard-level speculative thresholds (guesses at the whole search's k-th score, checked against the merged lists)"
                            if (shard_spec and (emu_exchange or lib_collective) and not args.sync_submit) else "")
                         + (f" (the other ranks' rows played by this process: --emulate-peers {args.emulate_peers})" if peer_words is not None else "")
-                        + (f" [emulating rank {shard_rank} of {shard_world}]" if shard_world != world else ""),
+                        + (f" [emulating rank {shard_rank} of {shard_world}]" if (world == 1 and shard_world > 1) else "")
+                        + (f" [{R} replicas, no exchange]" if (world > 1 and D == 1) else (f" [{R} query groups of {D} doc shards]" if R > 1 else "")),
             "mean_postings_per_query": float(ppq.mean()),
             "scan_items_per_step": (st["scan_items"] + st["maxscore_items"]) / max(1, st["batches"]),
             "dynamic_pruning": not args.no_prune,

@@ -66,7 +66,7 @@ struct alignas(16) WClause {
   int32_t  fx_scale;
   uint32_t flags;           // score table (0-2, 7 = none) | MUST clause << 3 | fx_shift << 4 | normInverse table << 8 | cell shift << 16 |
                             // lookup kind (plan.h: kLook*) << 24 | log2 docs per lookup cell << 27
-  uint32_t nib_off;         // kLookBits: byte offset from `look` of the term's freq nibbles (plan.h: DTermAux.nib_off), 0 = the code column is read
+  uint32_t pad;
   uint64_t u_after;         // what the later clauses can add at most: S_{c+1}
   uint64_t look;            // the term's lookup structure (plan.h: DTermAux.look): records / lookup cells, 0 = none
   uint64_t cells, start;    // cell table, first posting of the term in the columns
@@ -634,10 +634,6 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       }
       const gu32_ptr my_cells = (gu32_ptr)mt.cell_off;
       const uint32_t my_shift = mt.shift;
-      // (uniform) every clause of the part scores against ONE field's norms: the norm byte of a doc is then the one in the code of the
-      // posting that started it, and a later clause's lookup needs the posting's freq only (plan.h: kLookBits, freq nibbles)
-      const bool one_field = !PACKED && __builtin_amdgcn_ballot_w64(lane < n_terms && mt.cache_slot != (uint32_t)__builtin_amdgcn_readfirstlane((int)mt.cache_slot)) == 0ull;
-      uint32_t my_nib = 0;
       if (lane < n_terms) {
         WClause w;
         w.docids = (uint64_t)mt.docids;
@@ -650,15 +646,13 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
         const uint32_t look_kind = ax->look_kind;
         w.flags = ((mt.tab_slot & 0xFFFFu) < (uint32_t)kTabTerms ? (mt.tab_slot & 0xFFFFu) : 7u) | (TWO && (mt.tab_slot & kTabSlotRequired) ? 8u : 0u) |
                   (mt.fx_shift << 4) | (mt.cache_slot << 8) | ((mt.shift & 31u) << 16) | ((look_kind & 7u) << 24) | (((uint32_t)ax->look_shift & 31u) << 27);
-        w.nib_off = (!PACKED && one_field && look_kind == kLookBits) ? ax->nib_off : 0u;
+        w.pad = 0;
         w.u_after = my_after;
         w.look = look_kind != kLookNone ? (uint64_t)ax->look : 0ull;
         w.cells = (uint64_t)mt.cell_off;
         w.start = mt.start;
         wcl[lane] = w;
-        my_nib = w.nib_off;
       }
-      const bool part_nibs = !PACKED && __builtin_amdgcn_ballot_w64(my_nib != 0u) != 0ull;   // (uniform) some clause of the part is looked up through nibbles
       // (uniform) the part's MUST clauses, bit c = clause c; first_req: the last clause that may start a doc
       const uint32_t req_mask = TWO ? (uint32_t)__builtin_amdgcn_ballot_w64(lane < n_terms && (mt.tab_slot & kTabSlotRequired) != 0u) : 0u;
       const uint32_t first_req = req_mask != 0u ? (uint32_t)__builtin_ctz(req_mask) : 0xFFu;
@@ -780,16 +774,6 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
             }
           }
           NRT_PH_MARK(1);
-          // the norm bytes of my postings' docs (from their codes: table form bits 2-8, escape form bits 0-7), four to a register: what a
-          // later clause's freq nibble is put together with
-          uint32_t nrm4[2] = {0u, 0u};
-          if (!PACKED && part_nibs) {   // (uniform)
-  #pragma unroll
-            for (int j = 0; j < kSl; ++j) {
-              const uint32_t nb = (cd[j] >> 31) ? (cd[j] & 255u) : ((cd[j] >> 2) & 127u);
-              nrm4[j >> 2] |= nb << (8 * (j & 3));
-            }
-          }
           uint32_t vmask = 0;  // my postings inside the clause's range (one unsigned compare: positions before the range wrap) and the window
           {
             const uint32_t rel = q0 - ((uint32_t)p_begin & 3u), cnt = act ? r1[2] : 0u;
@@ -945,34 +929,10 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
                 idx[j] = there ? r[j][1] + (uint32_t)__popc(r[j][0] & ((1u << bb) - 1u)) : 0u;
                 present |= (there ? 1u : 0u) << j;
               }
-              const uint32_t nib_off2 = PACKED ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)w2.nib_off);
-              if (!PACKED && nib_off2 != 0u) {   // (uniform)
-                // FREQ NIBBLES: the posting's freq out of the term's nibble array (an eighth of the code column's bytes: it stays in
-                // the L2s), the doc's norm byte out of the code that started the doc -- together the score code fold_norms_kernel wrote
-                const NRT_GLOBAL uint8_t* const nibs2 = (const NRT_GLOBAL uint8_t*)(look2 + (uint64_t)nib_off2);
   #pragma unroll
-                for (int j = 0; j < kSl; ++j) c2[j] = (uint32_t)nibs2[idx[j] >> 1];
-                __builtin_amdgcn_sched_barrier(0);   // (every nibble load is issued before the first one is waited for)
-                NRT_PH_MARK(5);
-                uint32_t full = 0;   // freq > kTabMaxFreq: the code column after all
-  #pragma unroll
-                for (int j = 0; j < kSl; ++j) {
-                  const uint32_t f = (c2[j] >> ((idx[j] & 1u) << 2)) & 15u;
-                  const uint32_t nb = (nrm4[j >> 2] >> (8 * (j & 3))) & 255u;
-                  c2[j] = nb < (uint32_t)kTabNorms ? (((f << 7) | nb) << 2) : (0x80000000u | (f << 8) | nb);
-                  if (((present >> j) & 1u) && f == 0u) full |= 1u << j;
-                }
-                if (__any(full != 0u)) {
-  #pragma unroll
-                  for (int j = 0; j < kSl; ++j)
-                    if ((full >> j) & 1u) c2[j] = codes2[idx[j]];
-                }
-              } else {
-  #pragma unroll
-                for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
-                __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
-                NRT_PH_MARK(5);
-              }
+              for (int j = 0; j < kSl; ++j) c2[j] = codes2[idx[j]];
+              __builtin_amdgcn_sched_barrier(0);   // (the same for the code loads)
+              NRT_PH_MARK(5);
   #pragma unroll
               for (int j = 0; j < kSl; ++j) pi2[j] = (uint32_t)start2 + idx[j];
             } else {
@@ -1281,8 +1241,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
 __global__ __launch_bounds__(256)
 void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start,
                           const uint32_t* __restrict__ t_count, const uint64_t* __restrict__ t_look,
-                          const uint32_t* __restrict__ t_meta, const uint32_t* __restrict__ t_nib, const char* __restrict__ look_base,
-                          DTermAux* __restrict__ out) {
+                          const uint32_t* __restrict__ t_meta, const char* __restrict__ look_base, DTermAux* __restrict__ out) {
   __shared__ uint32_t mn[13];
   __shared__ uint32_t mf;
   const uint32_t t = blockIdx.x;
@@ -1322,7 +1281,7 @@ void term_frontier_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __
     a.look_shift = has ? (uint8_t)((t_meta[t] >> 8) & 255u) : (uint8_t)0;
     a.pad = 0;
     a.esc_max_freq = mf;
-    a.nib_off = has ? t_nib[t] : 0u;
+    a.pad2 = 0;
     out[t] = a;
   }
 }
@@ -1343,29 +1302,6 @@ void term_bits_kernel(const uint32_t* __restrict__ docids, const uint64_t* __res
     const uint32_t blk = d >> 5;
     atomicOr(&r[(size_t)blk * 2u], 1u << (d & 31u));
     if (p == 0u || (docids[st + p - 1u] >> 5) != blk) r[(size_t)blk * 2u + 1u] = p;
-  }
-}
-
-// term_nibs_kernel: the FREQ NIBBLES behind a term's records (plan.h: kLookBits): posting p's freq (1 - kTabMaxFreq; 0: larger --
-// the walk then reads the code column) in nibble p of the term's array, two postings per byte, low nibble first.  Read from the
-// code column as fold_norms_kernel wrote it (before any liveDocs are folded in).  Grid: (chunks, terms with nibbles).
-__global__ __launch_bounds__(256)
-void term_nibs_kernel(const uint32_t* __restrict__ fnorm, const uint64_t* __restrict__ t_start, const uint32_t* __restrict__ t_count,
-                      const uint64_t* __restrict__ t_look, const uint32_t* __restrict__ t_nib, const uint32_t* __restrict__ which,
-                      char* __restrict__ look_base) {
-  const uint32_t t = which[blockIdx.y];
-  if (t_nib[t] == 0u) return;
-  const uint32_t* const cc = fnorm + t_start[t];
-  const uint32_t n = t_count[t];
-  uint8_t* const out = (uint8_t*)(look_base + t_look[t] + t_nib[t]);
-  const uint32_t stride = gridDim.x * blockDim.x;
-  auto nib = [](uint32_t c) -> uint32_t {
-    const uint32_t f = (c >> 31) ? ((c >> 8) & 0x3FFFFFu) : ((c >> 9) & 15u);
-    return (f >= 1u && f <= (uint32_t)kTabMaxFreq) ? f : 0u;
-  };
-  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < (n + 1u) / 2u; b += stride) {
-    const uint32_t lo = nib(cc[2u * b]), hi = 2u * b + 1u < n ? nib(cc[2u * b + 1u]) : 0u;
-    out[b] = (uint8_t)(lo | (hi << 4));
   }
 }
 
@@ -1424,20 +1360,9 @@ void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int sha
 }
 
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
-                          const uint64_t* t_look, const uint32_t* t_meta, const uint32_t* t_nib, const void* look_base, uint32_t n_terms, DTermAux* out) {
+                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, uint32_t n_terms, DTermAux* out) {
   if (n_terms == 0) return;
-  hipLaunchKernelGGL(term_frontier_kernel, dim3(n_terms), dim3(256), 0, stream, fnorm, t_start, t_count, t_look, t_meta, t_nib, (const char*)look_base, out);
-}
-
-void launch_term_nibs(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
-                      const uint32_t* t_nib, const uint32_t* which, uint32_t n_which, uint32_t max_count, void* look_base) {
-  if (n_which == 0) return;
-  uint32_t chunks = (max_count / 2u + 256u * 16u - 1u) / (256u * 16u);
-  chunks = chunks < 1u ? 1u : (chunks > 1024u ? 1024u : chunks);
-  for (uint32_t off = 0; off < n_which; off += 65535u) {
-    const uint32_t n = n_which - off < 65535u ? n_which - off : 65535u;
-    hipLaunchKernelGGL(term_nibs_kernel, dim3(chunks, n), dim3(256), 0, stream, fnorm, t_start, t_count, t_look, t_nib, which + off, (char*)look_base);
-  }
+  hipLaunchKernelGGL(term_frontier_kernel, dim3(n_terms), dim3(256), 0, stream, fnorm, t_start, t_count, t_look, t_meta, (const char*)look_base, out);
 }
 
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,

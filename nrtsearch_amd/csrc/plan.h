@@ -106,16 +106,6 @@ static_assert(sizeof(DQExpand) == 16, "DQExpand layout");
 //                there and where its posting is; its score code is a second, dependent gather.  0.25 B per doc -- 16 KB per
 //                65 536-doc window, and 2.5 MB for a whole 10 M-doc segment: the records of the terms that hundreds of a
 //                batch's queries share stay in L2 / the Infinity Cache.
-//                FREQ NIBBLES behind the records (round 6; DTermAux.nib_off != 0): the second gather of a present doc used to read
-//                its 4-byte score code out of the term's code COLUMN -- 20 MB for a term half the docs hold, a random line of it per
-//                lookup, practically always an L2 miss (profiles/r06_pmc_cache.txt: 65 M fabric-side lines per launch against
-//                24 M L2 hits; the cache-path counters put the walk at two thirds of the chip's all-miss gather rate).  A score
-//                code is (freq, the DOC's norm byte), and the walk already holds the doc's norm byte: it is in the code of the
-//                posting that started the doc (same field).  So the second gather only needs the posting's FREQ: 4 bits per
-//                posting (1 - 12; 0: a larger freq -- the code column after all), 2.5 MB for that same term, 12 MB for the fifteen
-//                most frequent terms of a 10 M-doc segment together: what the walk asks for again and again now fits the L2s.
-//                The code is put together from the nibble and the norm exactly as fold_norms_kernel wrote it.  Two-column layout
-//                only; a part whose clauses name several fields reads the code column as before (maxscore.hip).
 //   kLookCells : LOOKUP CELLS, one posting offset per 2^look_shift docs with look_shift chosen so that a cell holds
 //                0.5 - 1 posting on average (4 - 8 B per POSTING): a search in the doc's cell, usually over no posting or one.
 //   kLookNone  : the doc is searched for in its cell of the tile-granular table DTerm.cell_off (~4 - 8 postings per cell).
@@ -138,7 +128,7 @@ struct alignas(16) DTermAux {
   uint8_t  look_shift;     // kLookCells: log2 of the docs per cell
   uint8_t  pad;
   uint32_t esc_max_freq;   // ... and largest freq among them; 0 = none
-  uint32_t nib_off;        // kLookBits: byte offset from `look` of the term's freq nibbles (two postings per byte, low nibble first); 0 = none
+  uint32_t pad2;
 };
 static_assert(sizeof(DTermAux) == 32, "DTermAux layout");
 

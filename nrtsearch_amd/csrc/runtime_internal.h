@@ -47,9 +47,7 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
                       uint64_t* item_hits, uint32_t k_stride, uint64_t* item_prof);
 void launch_bm25_maxscore(hipStream_t stream, bool profile, bool packed, int shapes, const MsArgs& args, const MsArgs* args_d);
 void launch_term_frontier(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count,
-                          const uint64_t* t_look, const uint32_t* t_meta, const uint32_t* t_nib, const void* look_base, uint32_t n_terms, DTermAux* out);
-void launch_term_nibs(hipStream_t stream, const uint32_t* fnorm, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
-                      const uint32_t* t_nib, const uint32_t* which, uint32_t n_which, uint32_t max_count, void* look_base);
+                          const uint64_t* t_look, const uint32_t* t_meta, const void* look_base, uint32_t n_terms, DTermAux* out);
 void launch_term_bits(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,
                       const uint32_t* which, uint32_t n_which, uint32_t max_count, void* look_base);
 void launch_term_cells(hipStream_t stream, const uint32_t* docids, const uint64_t* t_start, const uint32_t* t_count, const uint64_t* t_look,

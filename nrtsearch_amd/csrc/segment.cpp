@@ -360,11 +360,6 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   const std::vector<LookRule> rules = parse_look_policy(dev_env_str("NRTGPU_LOOK_POLICY", kLookPolicy));
   std::vector<uint64_t> look((size_t)nt, ~0ull);   // byte offset of the term's structure inside the group's buffer
   std::vector<uint32_t> meta((size_t)nt, 0u);      // kind | log2 docs per cell << 8
-  std::vector<uint32_t> nib((size_t)nt, 0u);       // kLookBits: byte offset of the term's freq nibbles behind its records (0: none)
-  // freq nibbles behind the records (plan.h: kLookBits): the two-column layout only (a packed posting's code rides in its word);
-  // NRTGPU_LOOK_NIBS=0 (development build): none, A/B
-  static const bool want_nibs = dev_env_int("NRTGPU_LOOK_NIBS", 1) != 0;
-  const bool with_nibs = want_nibs && !(seg->ctx->cfg.flags & NRTGPU_FLAG_PACKED_POSTINGS);
   std::vector<uint32_t> which[3];                  // per kind the terms that got it
   uint64_t look_bytes = 0;
   uint32_t max_count = 0, max_cells = 0;
@@ -382,24 +377,14 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
         uint64_t cost = 0;
         uint32_t shift = 0;
         // (every structure: 16-byte aligned, entry 0 readable for idle slots, one entry of slack behind the last doc's)
-        uint64_t nib_bytes = 0;
-        if (r.kind == kLookBits) {
-          cost = (((((uint64_t)max_doc + 31ull) / 32ull + 1ull) * 8ull + 15ull) & ~15ull);
-          // (+ the nibbles: half a byte per posting, byte 0 readable for idle slots, 16 bytes of slack; dropped when only the
-          //  records fit the budget)
-          if (with_nibs && cost < (1ull << 32)) {
-            nib_bytes = ((cnt + 1ull) / 2ull + 16ull + 15ull) & ~15ull;
-            if (cost + nib_bytes > budget) nib_bytes = 0;
-          }
-        } else {
+        if (r.kind == kLookBits) cost = (((((uint64_t)max_doc + 31ull) / 32ull + 1ull) * 8ull + 15ull) & ~15ull);
+        else {
           // cells of 2^shift docs, the largest power of two with at most one posting per cell on average
           while (shift < 31u && (cnt << (shift + 1u)) <= (uint64_t)max_doc) ++shift;
           const uint64_t n_cells = (((uint64_t)max_doc - 1ull) >> shift) + 1ull;
           cost = (((n_cells + 2ull) * 4ull + 15ull) & ~15ull);
         }
         if (cost > budget) continue;   // (a later rule's structure may fit)
-        if (nib_bytes) nib[t] = (uint32_t)cost;
-        cost += nib_bytes;
         budget -= cost;
         look[t] = look_bytes;
         look_bytes += cost;
@@ -431,9 +416,7 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   uint32_t* d_count = nullptr;
   uint32_t* d_meta = nullptr;
   uint32_t* d_which = nullptr;
-  uint32_t* d_nib = nullptr;
   auto free_tmp = [&] {
-    if (d_nib) (void)hipFree(d_nib);
     if (d_start) (void)hipFree(d_start);
     if (d_look) (void)hipFree(d_look);
     if (d_count) (void)hipFree(d_count);
@@ -445,19 +428,14 @@ static int build_term_aux(nrtgpu_seg* seg, TermGroup& g) {
   if (e == hipSuccess) e = hipMalloc((void**)&d_count, nt * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&d_meta, nt * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&d_which, std::max<size_t>(flat.size(), 1) * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_nib, nt * 4);
-  if (e == hipSuccess) e = hipMemcpy(d_nib, nib.data(), nt * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_start, g.h_start.data(), nt * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_look, look.data(), nt * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_count, g.h_count.data(), nt * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_meta, meta.data(), nt * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess && !flat.empty()) e = hipMemcpy(d_which, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_look, d_meta, d_nib, g.d_look, (uint32_t)nt, g.d_aux);
+    launch_term_frontier(nullptr, g.d_fnorm, d_start, d_count, d_look, d_meta, g.d_look, (uint32_t)nt, g.d_aux);
     launch_term_bits(nullptr, g.d_docids, d_start, d_count, d_look, d_which + first_of[kLookBits], (uint32_t)which[kLookBits].size(), max_count, g.d_look);
-    if (with_nibs)
-      launch_term_nibs(nullptr, g.d_fnorm, d_start, d_count, d_look, d_nib, d_which + first_of[kLookBits], (uint32_t)which[kLookBits].size(), max_count,
-                       g.d_look);
     launch_term_cells(nullptr, g.d_docids, d_start, d_count, d_look, d_meta, d_which + first_of[kLookCells], (uint32_t)which[kLookCells].size(), max_cells,
                       max_doc, g.d_look);
     e = hipGetLastError();

@@ -38,39 +38,67 @@ def unpack_keys(keys: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:
     return docs, scores
 
 
-def all_gather_topk(keys, counts, hits):
+def topology(world: int, rank: int, doc_shards: int = 0):
+    """N = D doc-shards x R query-groups (bench.py --doc-shards): D consecutive ranks share the index by docid range and
+    exchange their top-k among themselves; the R = N / D groups hold the same index and take different batches.  doc_shards 0 = N
+    (every GPU a shard of ONE search: BASELINE.json's north-star form); 1 = N replicas.  -> (D, R, group, rank within the group).
+    The reference's analogue: virtual shards balance the leaves over D searcher threads (MyIndexSearcher.java:117-160) while R
+    replicas of the index serve different requests (nrtsearch's replica nodes)."""
+    d = doc_shards if doc_shards > 0 else world
+    if d > world or world % d != 0:
+        raise ValueError(f"doc_shards {d} does not divide the world size {world}")
+    return d, world // d, rank // d, rank % d
+
+
+def doc_shard_groups(world: int, doc_shards: int):
+    """torch.distributed process groups of a D x R topology: every rank creates every group (in the same order) and gets ITS
+    group back (None: the whole world, D == N; or no exchange at all, D == 1)."""
+    import torch.distributed as dist
+
+    d, r, group, _ = topology(world, dist.get_rank(), doc_shards)
+    if d == world or d == 1:
+        return None
+    mine = None
+    for g in range(r):
+        h = dist.new_group(list(range(g * d, (g + 1) * d)))
+        if g == group:
+            mine = h
+    return mine
+
+
+def all_gather_topk(keys, counts, hits, group=None):
     """keys [B, k_stride] int64, counts [B] int32, hits [B] int64 (same device on every rank)
-    -> gathered ([W, B, k_stride], [W, B], [W, B]) on every rank."""
+    -> gathered ([W, B, k_stride], [W, B], [W, B]) on every rank (of `group`: a doc-shard group, doc_shard_groups)."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     b = keys.shape[0]
     # concatenation form (world * B rows): accepted by both RCCL and gloo
     g_keys = torch.empty((world * b,) + tuple(keys.shape[1:]), dtype=keys.dtype, device=keys.device)
     g_cnt = torch.empty((world * b,), dtype=counts.dtype, device=counts.device)
     g_hits = torch.empty((world * b,), dtype=hits.dtype, device=hits.device)
-    dist.all_gather_into_tensor(g_keys, keys.contiguous())
-    dist.all_gather_into_tensor(g_cnt, counts.contiguous())
-    dist.all_gather_into_tensor(g_hits, hits.contiguous())
+    dist.all_gather_into_tensor(g_keys, keys.contiguous(), group=group)
+    dist.all_gather_into_tensor(g_cnt, counts.contiguous(), group=group)
+    dist.all_gather_into_tensor(g_hits, hits.contiguous(), group=group)
     return g_keys.view((world, b) + tuple(keys.shape[1:])), g_cnt.view(world, b), g_hits.view(world, b)
 
 
-def all_to_all_topk(keys, counts, hits):
+def all_to_all_topk(keys, counts, hits, group=None):
     """keys [B, k_stride] int64, counts [B] int32, hits [B] int64 with B % world == 0.  Rank r receives every
     rank's lists for queries [r * B/W, (r + 1) * B/W): ([W, B/W, k_stride], [W, B/W], [W, B/W])."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     b = keys.shape[0]
     if b % world != 0:
         raise ValueError(f"batch of {b} queries does not divide by world size {world}")
     o_keys = torch.empty_like(keys)
     o_cnt = torch.empty_like(counts)
     o_hits = torch.empty_like(hits)
-    dist.all_to_all_single(o_keys, keys.contiguous())
-    dist.all_to_all_single(o_cnt, counts.contiguous())
-    dist.all_to_all_single(o_hits, hits.contiguous())
+    dist.all_to_all_single(o_keys, keys.contiguous(), group=group)
+    dist.all_to_all_single(o_cnt, counts.contiguous(), group=group)
+    dist.all_to_all_single(o_hits, hits.contiguous(), group=group)
     per = b // world
     return o_keys.view((world, per) + tuple(keys.shape[1:])), o_cnt.view(world, per), o_hits.view(world, per)

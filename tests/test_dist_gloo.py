@@ -128,6 +128,97 @@ def test_two_rank_partition_and_allgather():
         assert ret.get(0) is True and ret.get(1) is True
 
 
+def _topology_worker(rank: int, world: int, doc_shards: int, port: int, ret):
+    """N = D doc-shards x R query-groups (bench.py --doc-shards): the D ranks of a group share the index and all-gather their lists
+    inside the group's process group; group g runs batches g, g + R, ... of the query set.  Every group's merged answers for ITS
+    batches are the oracle's whole-index answers; together the groups cover every batch exactly once."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from nrtsearch_amd import dist as nd
+    from nrtsearch_amd import synth, workload
+    from oracle import oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D, R, group, grank = nd.topology(world, rank, doc_shards)
+        pg = nd.doc_shard_groups(world, doc_shards)
+        w = workload.Workload("topology-test", 40_000, 3, 20, 8, 2, max_rank=300)
+        qr = synth.make_queries(w.n_queries, w.n_terms, w.max_rank)
+        B = 2                                                        # queries per batch: 4 batches
+        n_batches = w.n_queries // B
+        shard = workload.build_shard_corpus(w, qr, D, grank)         # my docid range of the index, global statistics
+        full = workload.build_shard_corpus(w, qr, 1, 0)
+        k, k_stride = w.k, 32
+        ok, ran = True, []
+        for step in range(n_batches // R):
+            bi = (step * R + group) % n_batches                       # bench.py: batch_index
+            ran.append(bi)
+            keys = np.zeros((B, k_stride), dtype=np.int64)
+            cnt = np.zeros(B, dtype=np.int32)
+            hits = np.zeros(B, dtype=np.int64)
+            for j in range(B):
+                d, s_, total, _ = oracle.search_bm25(shard, qr[bi * B + j].tolist(), k, total_hits_threshold=2**31 - 1)
+                keys[j] = nd.pack_keys(d, s_, k_stride)
+                cnt[j], hits[j] = len(d), total
+            if D > 1:
+                g_keys, g_cnt, g_hits = nd.all_gather_topk(torch.from_numpy(keys), torch.from_numpy(cnt), torch.from_numpy(hits), group=pg)
+            else:                                                     # replicas: nothing is exchanged
+                g_keys, g_cnt, g_hits = torch.from_numpy(keys)[None], torch.from_numpy(cnt)[None], torch.from_numpy(hits)[None]
+            ok &= g_keys.shape[0] == D
+            for j in range(B):
+                lists = [nd.unpack_keys(g_keys[r, j].numpy(), int(g_cnt[r, j])) for r in range(D)]
+                md, ms = oracle.topdocs_merge(k, lists)
+                ed, es, etotal, _ = oracle.search_bm25(full, qr[bi * B + j].tolist(), k, total_hits_threshold=2**31 - 1)
+                ok &= md.tolist() == ed.tolist() and ms.view(np.uint32).tolist() == es.view(np.uint32).tolist()
+                ok &= int(g_hits[:, j].sum()) == etotal
+        ret[rank] = (bool(ok), group, grank, ran)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,doc_shards", [(4, 2), (2, 1), (4, 4)])
+def test_doc_shards_times_query_groups(world, doc_shards):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = 31500 + (os.getpid() % 2000) + world * 7 + doc_shards
+        procs = [ctx.Process(target=_topology_worker, args=(r, world, doc_shards, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        res = [ret.get(r) for r in range(world)]
+        assert all(x is not None and x[0] is True for x in res), res
+        R = world // doc_shards
+        assert [x[1] for x in res] == [r // doc_shards for r in range(world)] and [x[2] for x in res] == [r % doc_shards for r in range(world)]
+        # the ranks of a group ran the same batches; the groups together every batch once
+        by_group = {}
+        for x in res:
+            by_group.setdefault(x[1], []).append(tuple(x[3]))
+        assert all(len(set(v)) == 1 for v in by_group.values()), by_group
+        assert sorted(b for g in range(R) for b in by_group[g][0]) == list(range(4)), by_group
+
+
+def test_topology_arithmetic():
+    sys.path.insert(0, ROOT)
+    from nrtsearch_amd import dist as nd
+
+    assert nd.topology(8, 5, 0) == (8, 1, 0, 5)
+    assert nd.topology(8, 5, 2) == (2, 4, 2, 1)
+    assert nd.topology(8, 5, 1) == (1, 8, 5, 0)
+    assert nd.topology(1, 0, 0) == (1, 1, 0, 0)
+    for bad in (3, 16):
+        with pytest.raises(ValueError):
+            nd.topology(8, 0, bad)
+
+
 def test_shard_ranges_cover_the_index():
     sys.path.insert(0, ROOT)
     from nrtsearch_amd import workload
