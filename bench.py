@@ -96,6 +96,13 @@ def parse_args():
     ap.add_argument("--exhaustive-steps", type=int, default=8,
                     help="C3 / C2, one GPU: steps of the EXHAUSTIVE route (every posting streamed) timed after the main run for "
                          "roofline.exhaustive (0 = skip)")
+    ap.add_argument("--c2-steps", type=int, default=20,
+                    help="C3 line, one GPU: also time this many steps of BASELINE config 2 (1 M docs, 2-term, top-100) in the same run "
+                         "(roofline.c2; 0 = skip)")
+    ap.add_argument("--c5-steps", type=int, default=4,
+                    help="C3 line, one GPU: also time this many 256-query batches of BASELINE config 5's shape at 5 M docs -- BM25 "
+                         "recall-1000 + exact cosine rescore over 768-d vectors, top-100, fused on the device (roofline.c5; 0 = skip; "
+                         "the 50 M-doc run: scripts/gpu_c5_hybrid.py)")
     ap.add_argument("--c4-steps", type=int, default=8,
                     help="C3 line: also run BASELINE config 4 (10 M x 768 exact kNN, 64 queries per pass) for that many passes -> roofline.c4 (0 = skip)")
     ap.add_argument("--no-sketch", action="store_true",
@@ -618,6 +625,167 @@ def run_c4(args, emit=True):
     return out
 
 
+def c2_leg(args, device, flags, planner_threads):
+    """BASELINE config 2 inside the C3 line (every BASELINE config on the round's build, in the driver's
+    line): 1 M docs, Zipf terms, 2-term BooleanQuery, top-100, 1024 queries per step, two submitting threads -- the same loop as the
+    headline's.  (bench.py --workload C2 is the full line.)"""
+    import threading
+
+    from nrtsearch_amd import api, synth, workload
+
+    w = workload.C2
+    B = args.batch
+    n_distinct = max(B, (w.n_queries // B) * B)
+    qr = synth.make_queries(n_distinct, w.n_terms, w.max_rank)
+    corpus = workload.build_shard_corpus(w, qr, 1, 0)
+    ctx = api.GpuContext(device_id=device, max_batch=B, collect_timing=True, flags=flags, host_threads=planner_threads)
+    leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
+    sr = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
+    queries = workload.boolean_queries(qr)
+    mgr = api.TopScoreDocCollectorManager(w.k)
+    batches = [api.PreparedBatch(sr, queries[i: i + B], [mgr] * B) for i in range(0, n_distinct, B)]
+    for pb in batches:
+        pb.run()
+    n_thr = max(1, args.host_threads)
+
+    def run(first, count):
+        def worker(tix):
+            for i in range(tix, count, n_thr):
+                batches[(first + i) % len(batches)].run()
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    run(0, 4)
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    run(4, args.c2_steps)
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    pruned = st["maxscore_ms"] > st["scan_ms"]
+    launches = max(1, st["maxscore_launches"] if pruned else st["scan_launches"])
+    k_ms = (st["maxscore_ms"] if pruned else st["scan_ms"]) / launches
+    algo = (st["maxscore_postings"] if pruned else st["scan_postings"]) / launches * BYTES_PER_POSTING
+    rate = algo / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    rec = {
+        "workload": w.name, "kernel": "bm25_maxscore_kernel" if pruned else "bm25_scan_kernel", "steps": args.c2_steps, "batch_queries": B,
+        "queries_per_s": round(args.c2_steps * B / dt, 1), "ms_per_step": round(dt / args.c2_steps * 1e3, 4), "avg_launch_ms": round(k_ms, 4),
+        "algorithmic_bytes_per_launch": int(algo), "effective_achieved": round(rate, 1), "effective_frac": round(rate / HBM_PEAK_GBS, 4),
+        "unit": "GB/s", "peak": HBM_PEAK_GBS, "host_plan_ms_per_step": round(st["host_plan_ms"] / max(1, st["batches"]), 4),
+        "device_bytes": int(sum(l.device_bytes for l in leaves)), "mean_postings_per_query": float(workload.postings_per_query(corpus.doc_freq, qr).mean()),
+        "note": "effective = 9 B x the postings of the queries' terms / the kernel's average launch (the pruned kernel streams a few per cent of "
+                "them); a step is host-bound at this size when ms_per_step exceeds avg_launch_ms",
+    }
+    for l in leaves:
+        l.release()
+    ctx.close()
+    return rec
+
+
+def c5_leg(args, device, planner_threads, n_docs=5_000_000, seg_docs=2_500_000, dim=768, B=256):
+    """BASELINE config 5's shape inside the C3 line, at the 5 M-doc size the GPU suite checks against the oracle
+    (tests/test_baseline_sizes_gpu.py::test_hybrid_c5_shape): BM25 recall-1000 over a 5-term disjunction -> exact cosine rescore of
+    the 1000 recalled docs against their 768-d fp32 vectors -> top-100, first pass and tail fused on the device
+    (nrtgpu_search_hybrid_batch; QueryRescore.java:40-57).  The vectors of every segment are one random block (the tail gathers
+    1000 rows per query: their values do not matter for the timing).  50 M docs: scripts/gpu_c5_hybrid.py."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from nrtsearch_amd import _lib, api, synth
+
+    t0 = time.perf_counter()
+    qr = synth.make_queries(B, 5, 10000)
+    ranks = sorted(set(int(r) for r in qr.reshape(-1)))
+    lens = synth.doc_lengths(n_docs)
+    norms_all = synth.int_to_byte4(lens)
+    n_seg = (n_docs + seg_docs - 1) // seg_docs
+    bases = np.minimum(np.arange(n_seg + 1, dtype=np.int64) * seg_docs, n_docs)
+    per_docs = [[] for _ in range(n_seg)]
+    per_freqs = [[] for _ in range(n_seg)]
+    doc_freq = {}
+    for r in ranks:
+        d, f = synth.term_postings(n_docs, r)
+        doc_freq[r] = int(len(d))
+        cuts = np.searchsorted(d, bases)
+        for s_ in range(n_seg):
+            a, b = int(cuts[s_]), int(cuts[s_ + 1])
+            per_docs[s_].append((d[a:b] - bases[s_]).astype(np.int32))
+            per_freqs[s_].append(f[a:b])
+    # (the block comes from the device's generator: 7.7 GB of normal variates take the host's tens of seconds)
+    block = torch.randn((seg_docs, dim), dtype=torch.float32, device=f"cuda:{device}", generator=torch.Generator(device=f"cuda:{device}").manual_seed(7)).cpu().numpy()
+    ctx = api.GpuContext(device_id=device, max_batch=B, collect_timing=True, host_threads=planner_threads)
+    leaves = []
+    for s_ in range(n_seg):
+        counts = np.asarray([len(x) for x in per_docs[s_]], dtype=np.int64)
+        g = api.GpuSegment(ctx, int(bases[s_ + 1] - bases[s_]), int(bases[s_]))
+        g.add_field_norms(0, norms_all[bases[s_]: bases[s_ + 1]].copy())
+        g.add_terms(0, np.asarray(ranks, dtype=np.int64), np.concatenate([[0], np.cumsum(counts)]).astype(np.int64),
+                    np.ascontiguousarray(np.concatenate(per_docs[s_]), dtype=np.int32), np.ascontiguousarray(np.concatenate(per_freqs[s_]), dtype=np.int32))
+        g.add_vectors(7, block[: int(bases[s_ + 1] - bases[s_])])
+        g.seal()
+        leaves.append(g)
+    del block
+    stats = api.IndexStatistics()
+    stats.fields[0] = api.CollectionStatistics(n_docs, int(lens.astype(np.int64).sum()))
+    for t_, df_ in doc_freq.items():
+        stats.doc_freq[(0, int(t_))] = int(df_)
+    sr = api.GpuIndexSearcher(ctx, leaves, stats)
+    build_s = time.perf_counter() - t0
+    queries = [api.BooleanQuery(tuple(api.TermQuery(0, int(t)) for t in row)) for row in qr]
+    mgr = api.TopScoreDocCollectorManager(1000)
+    qv = np.random.default_rng(8).standard_normal((B, dim), dtype=np.float32)
+    L = _lib.load()
+    m = sr._marshal(queries, [mgr] * B)
+    outs = (_lib.TopDocs * B)()
+    od = np.zeros((B, 1000), np.int32)
+    os_ = np.zeros((B, 1000), np.float32)
+    for qi in range(B):
+        outs[qi].capacity = 1000
+        outs[qi].docs = od[qi].ctypes.data_as(C.POINTER(C.c_int32))
+        outs[qi].scores = os_[qi].ctypes.data_as(C.POINTER(C.c_float))
+
+    def fused():
+        _lib.check(L.nrtgpu_search_hybrid_batch(ctx._h, sr._segs, sr._bases, len(leaves), m.queries, B, 7, 0, qv.ctypes.data, dim, C.c_float(1.0), 1.0, 2.0,
+                                                100, outs))
+
+    def first_pass():
+        _lib.check(L.nrtgpu_search_bm25_batch(ctx._h, sr._segs, sr._bases, len(leaves), m.queries, B, outs))
+
+    fused()
+    first_pass()
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.c5_steps):
+        fused()
+    dt_f = (time.perf_counter() - t0) / args.c5_steps
+    st = ctx.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.c5_steps):
+        first_pass()
+    dt_1 = (time.perf_counter() - t0) / args.c5_steps
+    pruned = st["maxscore_ms"] > st["scan_ms"]
+    k_ms = (st["maxscore_ms"] / max(1, st["maxscore_launches"])) if pruned else (st["scan_ms"] / max(1, st["scan_launches"]))
+    ppq = float(np.mean([sum(doc_freq[int(t)] for t in row) for row in qr]))
+    rec = {
+        "workload": f"C5 shape: {n_docs // 1_000_000}M docs BM25 recall-1000 + {dim}-d exact cosine rescore top-100, fused on the device",
+        "docs": n_docs, "dim": dim, "batch_queries": B, "batches": args.c5_steps,
+        "queries_per_s": round(B / dt_f, 1), "ms_per_batch": round(dt_f * 1e3, 3), "first_pass_ms_per_batch": round(dt_1 * 1e3, 3),
+        "tail_ms_per_batch": round((dt_f - dt_1) * 1e3, 3), "first_pass_kernel": "bm25_maxscore_kernel" if pruned else "bm25_scan_kernel",
+        "first_pass_kernel_ms": round(k_ms, 4), "mean_postings_per_query": ppq,
+        "effective_frac": round(9.0 * ppq * B / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+        "rescore_gather_bytes_per_batch": B * 1000 * dim * 4, "device_bytes": int(sum(l.device_bytes for l in leaves)), "setup_s": round(build_s, 1),
+        "note": "parity of this shape against the oracle: tests/test_baseline_sizes_gpu.py::test_hybrid_c5_shape; tail = fused call - first pass alone",
+    }
+    for l in leaves:
+        l.release()
+    ctx.close()
+    return rec
+
+
 def main():
     args = parse_args()
     if os.environ.get("NRTGPU_BENCH_WATCHDOG"):   # debug aid: every thread's Python stack on stderr after that many seconds
@@ -923,13 +1091,18 @@ def main():
         # emulated one below; with torch.distributed carrying the lists a shard speculates on its own list only
         spec_on = [shard_spec and (emu_exchange or lib_collective) and not args.sync_submit]
 
-        def run_again(pb, bad):
-            """Queries whose guess failed the check against the merged list: every rank runs them again without speculation
-            (the whole batch here: a stand-in that overstates the cost) and the lists are exchanged and merged once more."""
+        def run_again(bi_, bad):
+            """Queries whose guess failed the check against the merged list: every rank runs THOSE again without speculation -- a small
+            launch of its own behind the batch, whose other answers stand -- and their lists are exchanged and merged once more
+            (round 6; through round 5 the whole batch was run and merged again here: a stand-in that overstated the cost)."""
             shard_spec_stat["reran_batches"] += 1
-            keys, cnt, hits = bufs[0]
-            tmp = (torch.zeros_like(keys), torch.zeros_like(cnt), torch.zeros_like(hits))
-            h = pb.begin_shard_device(k_stride, tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(), 0, 0)
+            shard_spec_stat["reran_queries"] = shard_spec_stat.get("reran_queries", 0) + len(bad)
+            nb_ = len(bad)
+            q0 = bi_ * B
+            pb2 = api.PreparedBatch(searcher, [queries[q0 + int(j)] for j in bad], [mgr] * nb_)
+            tmp = (torch.zeros((nb_, k_stride), dtype=torch.int64, device="cuda"), torch.zeros((nb_,), dtype=torch.int32, device="cuda"),
+                   torch.zeros((nb_,), dtype=torch.int64, device="cuda"))
+            h = pb2.begin_shard_device(k_stride, tmp[0].data_ptr(), tmp[1].data_ptr(), tmp[2].data_ptr(), 0, 0)
             api.PreparedBatch.wait_device(h)
             return tmp
 
@@ -997,10 +1170,14 @@ def main():
                         shard_spec_stat["failed"] += len(bad)
                         batches[batch_index(first + i)].note_shard_speculation(mq_e, len(bad))
                         if len(bad):
-                            tk, tc, th_ = run_again(batches[batch_index(first + i)], bad)
-                            stage_lists(bi_, tk, tc, th_)
+                            # the failed queries alone: run again, their W_e lists stood in for as at the setup, merged on their own
+                            tk, tc, th_ = run_again(bi_, bad)
+                            nb_ = len(bad)
+                            rk = torch.bitwise_xor(tk.unsqueeze(0), e_tag).contiguous()
+                            rc = tc.unsqueeze(0).expand(W_e, nb_).contiguous()
+                            rh = th_.unsqueeze(0).expand(W_e, nb_).contiguous()
                             torch.cuda.current_stream().synchronize()
-                            merger.run(e_keys[bi_].data_ptr(), e_cnt[bi_].data_ptr(), e_hits[bi_].data_ptr())
+                            api.PreparedMerge(ctx, W_e, nb_, k_stride, [w.k] * nb_, [api.TOTAL_HITS_THRESHOLD] * nb_).run(rk.data_ptr(), rc.data_ptr(), rh.data_ptr())
                     if record:
                         lat.append(time.perf_counter() - t_start[i])
                         stage["exchange_s"] += te1 - te0
@@ -1225,16 +1402,35 @@ def main():
         x_ms = sx["scan_ms"] / lx
         x_bytes = sx["scan_postings"] / lx * bpp
         x_rate = x_bytes / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
+        # what the kernel physically streams: 8 B per posting (docid + score code: the norm byte was folded into the code at seal,
+        # so SURVEY 8d's ninth byte is never read); the PMC record of this build beside it when there is one
+        x_phys = sx["scan_postings"] / lx * bpp_fused / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
+        x_traffic = None
+        try:
+            for rec in json.load(open(pmc)):
+                if (rec.get("workload") == args.workload and rec.get("batch") == B and rec.get("kernel") == "bm25_scan_kernel"
+                        and bool(rec.get("packed", False)) == bool(args.packed) and rec.get("build_id") == lib_id):
+                    x_traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            x_traffic = None
         out["roofline"]["exhaustive"] = {
+            "physical_bytes_per_launch": int(sx["scan_postings"] / lx * bpp_fused), "physical_achieved": round(x_phys, 1),
+            "physical_frac": round(x_phys / HBM_PEAK_GBS, 4),
+            "traffic": x_traffic, "traffic_frac": (round(x_traffic / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (x_traffic and x_ms > 0) else None),
             "kernel": "bm25_scan_kernel", "steps": args.exhaustive_steps, "avg_launch_ms": round(x_ms, 4),
             "algorithmic_bytes_per_launch": int(x_bytes), "achieved": round(x_rate, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "frac": round(x_rate / HBM_PEAK_GBS, 4), "queries_per_s": round(args.exhaustive_steps * B / tx, 1),
             "note": "every posting of the queries' terms streamed (NRTGPU_FLAG_NO_PRUNE), same index and batches, same run; achieved = "
-                    "9 B x postings / the kernel's average launch",
+                    "9 B x postings / the kernel's average launch; physical_* = the 8 B per posting the kernel streams (norm folded into "
+                    "the code at seal) / the same launch time; traffic = PMC FETCH_SIZE x 2 (profiles/pmc_traffic.json) when the record is this build's",
         }
         for l in leaves_x:
             l.release()
         ctx_x.close()
+    if rank == 0 and world == 1 and not use_dist and args.c2_steps > 0 and args.workload == "C3" and not args.docs and not args.no_prune:
+        out["roofline"]["c2"] = c2_leg(args, local_rank, flags, planner_threads)
+    if rank == 0 and world == 1 and not use_dist and args.c5_steps > 0 and args.workload == "C3" and not args.docs and not args.no_prune and not args.packed:
+        out["roofline"]["c5"] = c5_leg(args, local_rank, planner_threads)
     if rank == 0 and world == 1 and not use_dist and args.c4_steps > 0 and args.workload == "C3" and not args.docs:
         # The other half of the path in the same line: BASELINE config 4 -- 10 M x 768 fp32 rows, exact
         # cosine top-100, 64 queries per pass -- for --c4-steps passes: the sketch kernel's physical HBM fraction, the matrix cores'

@@ -708,6 +708,11 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
       if (lane == 0) g_new = atomicAdd(&s.next_tile, 1u);
       theta_other = theta_other_next;
       if (multi_item) theta_other_next = __hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ---- (2b) the next sub-tile's first posting pairs: requested here, in front of this sub-tile's LDS adds and swaps (through
+      //      round 5 behind them: "in flight while this one is collected"; in front of them the loads also cover the sixteen LDS
+      //      atomics per lane -- same registers, 10.30 -> 10.22 ms per 1024 C3 queries, profiles/r06_scan_early_load_ab.log)
+      group_locate_load<PACKED>(s, wave, n_terms, lane, total_groups, pre, pf);
+      if (!PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A/B: no overlap of the column loads
 
       // ---- (3) LDS accumulate; sparse sub-tiles: then each posting swaps the "unmatched" marker into its
       //      doc's slot.  LDS executes a wave's operations in order, so the first posting of a doc to do
@@ -732,9 +737,6 @@ void bm25_scan_kernel(const DItem* __restrict__ items, const DPart* __restrict__
         }
       }
 
-      // ---- (2b) the next sub-tile's first posting pairs: in flight while this one is collected
-      group_locate_load<PACKED>(s, wave, n_terms, lane, total_groups, pre, pf);
-      if (!PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A/B: no overlap of the column loads
 
       if (cur_groups != 0) {
         const uint64_t theta_l = s.theta;

@@ -91,8 +91,17 @@ struct DeviceRun {
 static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32_t n_queries, uint32_t k_stride_out,
                           uint64_t* ext_keys, uint32_t* ext_counts, uint64_t* ext_hits, DeviceRun* run,
                           std::unique_lock<std::mutex>& gpu, int64_t epoch = -1, bool allow_spec = false, int32_t spec_world = 1,
-                          uint64_t* ext_guess = nullptr) {
+                          uint64_t* ext_guess = nullptr, bool follow_up = false) {
   forget_foreign_hip_error();
+  // follow_up (round 6): the second pass of a speculative call -- the handful of queries whose guess failed the merge's check, run
+  // again without speculation.  As a launch of the usual kind it took a TURN of its own: the whole device waited while five items
+  // ran on five CUs, and the batch behind it with them (sorted-by-length corpus at C3's size: 2.7 ms per 1024-query step around a
+  // 1.1 ms kernel).  A follow-up takes no turn: its few persistent workgroups (kFollowUpCus) run on the CUs every big launch
+  // leaves alone, beside whatever batch is running; its queries answer a little later, nobody else waits for them.
+  // Only MaxScore items (the exhaustive scan launches a workgroup per item and wants the whole device).
+  static const bool follow_up_on = dev_env_int("NRTGPU_FOLLOW_UP", 1) != 0;   // (development build: 0 = a turn of its own, A/B)
+  constexpr int kFollowUpCus = 4;
+  const bool small = follow_up && follow_up_on && hp.n_ms_items != 0 && hp.n_ms_items == hp.items.size() && ms_persistent();
   // spec_world > 1 (the library's multi-GPU search, dist.cpp): this call is ONE SHARD of a spec_world-way search over equal docid
   // ranges, and its speculative thresholds are guesses at the k-th score of the WHOLE search -- a shard's docs are a 1 / world
   // sample of the index, so the guess rule holds with the windows of all shards in its denominator.  Such a guess cannot be
@@ -218,6 +227,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     // 8: 2.50 (kernel 2.39), 16: 2.56, 32: 2.70 -- eight CUs of 256 is the default.
     static const int env_spare = (int)dev_env_int("NRTGPU_MS_SPARE_CUS", 8);
     help.n_cus = (uint32_t)std::max(ctx->n_cus - std::max(env_spare, 0), 1);
+    if (small) help.n_cus = (uint32_t)std::min<int>(kFollowUpCus, std::max(env_spare, 1));
     // NRTGPU_MS_PERSISTENT=0: one workgroup per item + helper workgroups behind them (A/B)
     help.persistent = ms_persistent() ? 1u : 0u;
   }
@@ -251,7 +261,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   ms_args.q_wins = (const uint32_t*)(db + o_qwins);
   {   // the leaf set's window order (note_speculation); NRTGPU_MS_SCATTER = 0 / 1 (development build): forced, A/B
     const long forced = dev_env_int("NRTGPU_MS_SCATTER", -1);
-    ms_args.scatter = forced >= 0 ? (forced != 0 ? 1u : 0u) : ((spec && hp.lsc->spec_scattered.load(std::memory_order_relaxed) != 0) ? 1u : 0u);
+    // (the second chance is BOTH the scattered order and the measured dispersion: plan.h: MsArgs.scatter; forced: the bits as given)
+    ms_args.scatter = forced >= 0 ? (uint32_t)(forced & 3) : ((spec && hp.lsc->spec_scattered.load(std::memory_order_relaxed) != 0) ? 3u : 0u);
   }
   ms_args.k_stride = hp.k_stride;
   ms_args.help = help;
@@ -272,7 +283,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   //  items fill the tail of this one's launch.  Measured, round 5 (profiles/r05_overlap_scorers_ab.log): SLOWER, 2.50 against 1.95 ms
   //  per step -- the batch's merge queues behind the next batch's items, 0.09 -> 0.98 ms)
   static const bool overlap_scorers = dev_env_int("NRTGPU_OVERLAP_SCORERS", 0) != 0;
-  if (ctx->last_turn && !overlap_scorers) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
+  if (ctx->last_turn && !overlap_scorers && !small) HIP_TRY(hipStreamWaitEvent(st, ctx->last_turn, 0));
   if (ctx->last_knn_turn) HIP_TRY(hipStreamWaitEvent(st, ctx->last_knn_turn, 0));   // (vector searches do not queue behind each other, the scorers queue behind them)
   if (timing) HIP_TRY(hipEventRecord(slot->ev3, st));
   if (profile && n_help) HIP_TRY(hipMemsetAsync(wb + o_prof + n_items * 128, 0, n_help * 128, st));   // (a helper that leaves at once writes nothing)
@@ -294,7 +305,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   // (profiles/r04_turn_before_merge_ab.log), 2.413 -> 2.357 ms per 1024-query step, batch p50 4.80 -> 4.69 ms, closed loop at
   // 64 / 512 callers p99 1.20 / 2.61 -> 1.20 / 2.55 ms.  NRTGPU_TURN_BEFORE_MERGE=0: the old turn (A/B).
   static const bool turn_before_merge = dev_env_int("NRTGPU_TURN_BEFORE_MERGE", 1) != 0;
-  if (turn_before_merge) {
+  if (turn_before_merge && !small) {
     HIP_TRY(hipEventRecord(slot->ev_turn, st));
     ctx->last_turn = slot->ev_turn;
   }
@@ -313,7 +324,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_slice_relation(st, (const uint32_t*)(wb + o_ssum), (const DQuery*)(db + o_queries), hp.n_slices, ohits, (uint32_t)n_queries);
   if (ext_hits && hp.n_ms_items) launch_patch_hits(st, (const uint64_t*)(db + o_lower), ohits, (uint32_t)n_queries);
   if (timing) HIP_TRY(hipEventRecord(slot->ev2, st));
-  if (!turn_before_merge) {
+  if (!turn_before_merge && !small) {
     HIP_TRY(hipEventRecord(slot->ev_turn, st));
     ctx->last_turn = slot->ev_turn;
   }
@@ -401,7 +412,7 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
 // nullptr: no speculation in this call.
 static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                              int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                             nrtgpu_topdocs* out, std::vector<int32_t>* rerun, bool content_held = false) {
+                             nrtgpu_topdocs* out, std::vector<int32_t>* rerun, bool content_held = false, bool follow_up = false) {
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
   if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
@@ -431,7 +442,7 @@ static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
   const double tc0 = call_trace ? now_ms() : 0.0;
   {
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
-    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu, -1, rerun != nullptr)) return rc;
+    if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu, -1, rerun != nullptr, 1, nullptr, follow_up)) return rc;
   }
   HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
   const double tc1 = call_trace ? now_ms() : 0.0;
@@ -505,7 +516,8 @@ static int search_batch_spec(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
   }
   const int64_t deadline = g_deadline_ns;
   g_deadline_ns = 0;
-  const int rc2 = search_batch_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), ro.data(), nullptr, true);
+  // (a few queries: a follow-up launch beside the next batch -- enqueue_search; more than that and it is a batch of its own)
+  const int rc2 = search_batch_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), ro.data(), nullptr, true, rq.size() <= 32);
   g_deadline_ns = deadline;
   if (rc2 != 0) return rc2;
   for (size_t i = 0; i < rerun.size(); ++i) out[rerun[i]] = ro[i];
@@ -1220,27 +1232,35 @@ extern "C" int nrtgpu_pending_wait(nrtgpu_pending* pending) {
     // the merge tagged the queries whose guess it could not confirm (kHitsSpecInvalid in the hit totals): read the totals, clear the
     // tags for the caller, and -- if any -- run the batch again without speculation into the same buffers (the plan and the
     // workspace are still this call's).  A re-run is a second pass of the batch; the leaf set's verdict bounds how often.
+    // (A batch with a failed guess is run again WHOLE: the handle keeps the batch's plan, not the caller's queries -- those were
+    //  borrowed for the _begin call only -- so there is nothing to plan a sub-batch from.  The synchronous entries, which still hold
+    //  the queries, re-run the tagged ones alone: search_batch_spec.)
     const size_t nq = (size_t)p->n_queries;
     int64_t n_bad = 0;
-    if (p->slot->h_out.reserve(nq * 8) == 0) {
-      uint64_t* hh = (uint64_t*)p->slot->h_out.p;
-      e = hipMemcpyAsync(hh, p->d_hits, nq * 8, hipMemcpyDeviceToHost, p->slot->stream);
-      if (e == hipSuccess) e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
-      if (e == hipSuccess) {
-        for (size_t q = 0; q < nq; ++q)
-          if (hh[q] & kHitsSpecInvalid) {
-            hh[q] &= ~kHitsSpecInvalid;
-            ++n_bad;
-          }
-        note_speculation_of(ctx, p->hp.lsc.get(), (int64_t)nq, n_bad);
-        if (n_bad) {
-          DeviceRun run;
-          std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
-          if (enqueue_search(ctx, p->slot, p->hp, p->n_queries, p->k_stride, p->d_keys, p->d_counts, p->d_hits, &run, gpu, -1, false) != 0)
-            e = hipErrorUnknown;
-          else
-            e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
+    if (int rc = p->slot->h_out.reserve(nq * 8)) {   // (the tags could not be read: the results are unverified, not an answer)
+      release_slot(ctx, p->slot);
+      return rc;
+    }
+    uint64_t* hh = (uint64_t*)p->slot->h_out.p;
+    e = hipMemcpyAsync(hh, p->d_hits, nq * 8, hipMemcpyDeviceToHost, p->slot->stream);
+    if (e == hipSuccess) e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
+    if (e == hipSuccess) {
+      for (size_t q = 0; q < nq; ++q)
+        if (hh[q] & kHitsSpecInvalid) {
+          hh[q] &= ~kHitsSpecInvalid;
+          ++n_bad;
         }
+      note_speculation_of(ctx, p->hp.lsc.get(), (int64_t)nq, n_bad);
+      if (n_bad) {
+        DeviceRun run;
+        std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
+        if (int rc = enqueue_search(ctx, p->slot, p->hp, p->n_queries, p->k_stride, p->d_keys, p->d_counts, p->d_hits, &run, gpu, -1, false)) {
+          gpu = std::unique_lock<std::mutex>();   // (its message is this thread's g_last_error: kept)
+          (void)hipStreamSynchronize(p->slot->stream);
+          release_slot(ctx, p->slot);
+          return rc;
+        }
+        e = wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, p->slot->stream, p->slot->ev_wait);
       }
     }
   }

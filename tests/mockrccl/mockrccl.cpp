@@ -8,7 +8,7 @@
 //   ncclSend : synchronises the stream, copies the buffer to the host, writes <dir>/m_<src>_<dst>_<seq> (tmp + rename); never blocks
 //   ncclRecv : waits for the peer's message with its own sequence number, CHECKS ITS SIZE against what the caller expects
 //              (a protocol mismatch between the ranks is an error, not a hang), copies it into device memory
-//   ncclAllGather : a send to every peer + a recv from every peer + a device copy of the rank's own block
+//   ncclAllGather : a send to every peer + a recv from every peer + a device copy of the rank's own block (on the caller's stream)
 //   groups   : calls run at once (sends never block, so any order of sends and recvs inside a group completes)
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
@@ -140,8 +140,10 @@ int ncclRecv(void* buf, size_t count, int dtype, int peer, ncclComm_t c, hipStre
   fclose(f);
   (void)unlink(name.c_str());
   if (!ok) return 2;
-  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-  if (bytes && hipMemcpy(buf, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  // ON THE CALLER'S STREAM, like the collective this stands in for: the library waits for that stream and then reads the buffer
+  // from another one (see ncclAllGather below)
+  if (bytes && hipMemcpyAsync(buf, host.data(), bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+  if (hipStreamSynchronize(stream) != hipSuccess) return 1;   // (`host` goes out of scope)
   return 0;
 }
 
@@ -154,8 +156,15 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, ncclCom
   for (int p = 0; p < c->world; ++p) {
     char* dst = (char*)recv + (size_t)p * bytes;
     if (p == c->rank) {
+      // The rank's own block: copied ON THE CALLER'S STREAM.  Through round 5 this was a plain hipMemcpy(..., DeviceToDevice): a
+      // device-to-device hipMemcpy returns before the copy has run and is ordered against the NULL stream only -- dist.cpp waits
+      // for ITS stream (RCCL's contract) and then launches TopDocs.merge on another non-blocking stream, which could read the
+      // PREVIOUS exchange's own block.  The two ranks then merged different lists, reached different verdicts on the shards'
+      // speculative thresholds, and one of them entered the re-run's collective alone: the "unexplained failure of the N = 2 bench
+      // loop, all-gather form only" of round 5 (3 of 32 runs of scripts/gpu_two_rank_loop.sh before this fix; the all-to-all form
+      // copies its own slice itself, on its stream, and never failed).  A race of this stand-in, not of the library.
+      if (bytes && hipMemcpyAsync(dst, send, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
       if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-      if (bytes && hipMemcpy(dst, send, bytes, hipMemcpyDeviceToDevice) != hipSuccess) return 1;
     } else if (int rc = ncclRecv(dst, count, dtype, p, c, stream)) {
       return rc;
     }

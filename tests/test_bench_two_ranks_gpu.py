@@ -35,23 +35,21 @@ def test_bench_two_ranks_through_the_librarys_collective(tmp_path, dev_lib, mode
                    check=True)
     env = dict(os.environ, NRTGPU_LIB_PATH=os.path.join(ROOT, "nrtsearch_amd", "libnrtgpu_dev.so"), NRTGPU_RCCL_LIB=mock,
                NRTGPU_BENCH_DEBUG_LIB_COLLECTIVE="1", NRTGPU_BENCH_COLLECTIVE_TIMEOUT="60", MASTER_ADDR="127.0.0.1", NRTGPU_BENCH_WATCHDOG="120")
-    # Two attempts: this is three layers of stand-ins (two ranks on one GPU, gloo beside a file-based collective, a launcher that
-    # picks a port) and it failed once in some thirty runs of the round without leaving its reason (bench.py then waited for its
-    # watchdog; it now says what failed and leaves at once).  A first failure is written to gpurun_out/ and printed; the test is
-    # red only if the path fails twice in a row.
-    r, err = None, ""
-    for attempt in (1, 2):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-               str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-same-gpu", "--workload", "C2", "--steps", "12", "--warmup", "3",
-               "--no-cpu-baseline", "--closed-loop", "", "--exhaustive-steps", "0", "--c4-steps", "0", "--exchange-mode", mode]
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
-        err = "\n".join(l for l in r.stderr.split("\n") if not l.startswith(("RCCL", "HIP", "ROCm", "Host", "Libr")) and "amdgpu.ids" not in l)
-        if r.returncode == 0:
-            break
-        print(f"attempt {attempt} of the two-rank bench ({mode}) failed with {r.returncode}:\n{err[:3000]}\n[...]\n{err[-3000:]}")
+    # ONE attempt (round 6).  Round 5 tried twice after one unexplained failure in ~30 runs; reproduced in round 6 (3 of 32 runs of
+    # scripts/gpu_two_rank_loop.sh, all-gather form only) and traced to the stand-in collective: tests/mockrccl copied the rank's own
+    # block with a device-to-device hipMemcpy -- not host-synchronous, ordered against the NULL stream only -- so the merge (another
+    # stream) could read the previous exchange's block, the ranks reached different verdicts on the shards' guesses and one entered
+    # the re-run's collective alone.  The copy is stream-ordered now (mockrccl.cpp: ncclAllGather); the loop ran clean after it
+    # (profiles/r06_two_rank_loop.log).
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-same-gpu", "--workload", "C2", "--steps", "12", "--warmup", "3",
+           "--no-cpu-baseline", "--closed-loop", "", "--exhaustive-steps", "0", "--c4-steps", "0", "--exchange-mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    err = "\n".join(l for l in r.stderr.split("\n") if not l.startswith(("RCCL", "HIP", "ROCm", "Host", "Libr")) and "amdgpu.ids" not in l)
+    if r.returncode != 0:
         try:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", f"bench_two_ranks_failure_{mode}_{attempt}.log"), "w") as f:
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_two_ranks_failure_{mode}.log"), "w") as f:
                 f.write(err)
         except OSError:
             pass
