@@ -351,7 +351,14 @@ int  nrtgpu_search_bm25_batch_device_epoch(nrtgpu_ctx* ctx, const nrtgpu_seg* co
  * rank calls nrtgpu_dist_search_bm25_batch with the same queries in the same order (index-global statistics in the
  * weights) over ITS leaves: local search -> ONE grouped RCCL all-gather of keys / counts / hit totals over xGMI ->
  * TopDocs.merge on every rank; every rank receives every answer.  total_hits sums the shards' counts; the relation is
- * GREATER_THAN_OR_EQUAL_TO iff some shard's is. */
+ * GREATER_THAN_OR_EQUAL_TO iff some shard's is.
+ * Failure of ONE rank's part of a one-call search (nrtgpu_dist_search_bm25_batch[_mode], nrtgpu_dist_knn_exact,
+ * nrtgpu_dist_search_hybrid_batch): a rank whose shard search fails -- its thread's deadline, a planner refusal, a device
+ * error -- still enters the exchange, with empty lists and its status word in the same grouped collective, so that no peer is
+ * left waiting in a collective this rank would never issue; EVERY rank then returns an error (the failed rank its own, the
+ * others NRTGPU_ERR_STATE naming the first failed rank), and the communicator stays usable.  The re-run of queries whose
+ * speculative threshold failed ignores the thread's deadline (it is the tail of a search that was launched in time).  A caller
+ * that pipelines with the two halves below vouches for its own ranks: nothing of this travels there. */
 int  nrtgpu_dist_unique_id(void* out128);
 int  nrtgpu_dist_init(nrtgpu_ctx* ctx, int32_t world, int32_t rank, const void* id128);
 int  nrtgpu_dist_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
@@ -379,7 +386,8 @@ int  nrtgpu_dist_exchange_merge(nrtgpu_ctx* ctx, int32_t n_queries, int32_t k_st
                                 nrtgpu_topdocs* out);
 /* The same with the shards' speculative thresholds (d_guess of nrtgpu_search_bm25_shard_device_begin; NULL: the call above): the
  * guesses travel in the same grouped collective as the lists, and after the merge the k-th key of every merged list is checked
- * against the largest guess any shard published for the query.  failed[n_queries] / *n_failed: the queries whose answer does
+ * against the largest guess any shard published for the query (the k-th key is read from the MERGED keys, never from `out`'s
+ * arrays: those may be NULL or shorter than k).  failed[n_queries] / *n_failed: the queries whose answer does
  * NOT stand -- the same verdicts on every rank (all-to-all: the owners' verdicts are all-gathered, one byte per query) -- to be
  * run again by EVERY rank without speculation (nrtgpu_dist_search_bm25_batch_mode with NRTGPU_EXCHANGE_NO_SPECULATION over
  * those queries, in the same order on every rank). */

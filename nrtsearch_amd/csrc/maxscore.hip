@@ -90,9 +90,6 @@ struct MsSmem {
   uint32_t q_wins;       // doc windows of ALL items of the query
   uint32_t spec_z16;     // speculation (plan.h: kHitsSpecInvalid): safety margin in standard deviations x 16; 0: off
   uint32_t spec_grow16;  // ... the next estimate is due when wins_started has grown by this factor x 16
-  uint32_t spec_disp;    // ... 1: the guess's margin follows the MEASURED dispersion of the candidates over the doc windows (ms_compact)
-  uint32_t win_shift;    // log2 of the docs per window of the item the workgroup works on
-  uint32_t spec_sumsq;   // ms_compact: sum over doc granules of (candidates in the granule)^2
   unsigned long long* spec_slot;   // ... and where the query's largest speculative theta is published
   uint64_t pick;         // a helper's choice: float bits of its key (expected time left / an exponential variate) << 32 | item + 1
   uint32_t role[4];      // the workgroup's first decision (start the next item / help one): scratch values every thread reads
@@ -206,37 +203,8 @@ __device__ __noinline__ void ms_compact(__attribute__((address_space(3))) MsSmem
   // (only once bounds may skip: by then more than max(totalHitsThreshold, numHits) docs are known to match -- a query with
   //  fewer than k hits would fail every guess)
   if (s.spec_z16 != 0u && !exchanging && __hip_atomic_load(&s.prune_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
-    const float ws = (float)s.wins_started;
-    const float m = (float)k * fminf(1.0f, ws / (float)max(s.q_wins, 1u));
-    float var = m;   // docs spread over the windows like a sample: the count of the final top-k among mine is ~ Poisson(m)
-    if (s.spec_disp != 0u && cnt0 != 0u) {   // (uniform)
-      // MEASURED dispersion (round 6; the leaf set's second chance, search.cpp: note_speculation_of).  Where terms come in docid
-      // bursts the query's best docs sit in a few windows, and how many of the final top-k lie among the windows begun varies far
-      // more than a sample's sqrt(m): a guess z sqrt(m) deep failed for 17 % of the queries of the clustered corpus (5 % in the
-      // scattered order).  The candidates held say how uneven the windows are: c_i of them in doc granule i (a window's worth of
-      // docids), S2 = their sample variance over the ws windows begun (empty ones count).  The final top-k among them is a
-      // p = m / n thinning of the n candidates, so per window its count has variance p^2 S2 + p (1 - p) n / ws, and over ws
-      // windows drawn from the item (the scattered order draws them evenly) the total has about ws times that:
-      //     var = ws p^2 S2 + m (1 - p)        (= m where S2 = n / ws: the Poisson case)
-      // never taken below m.  The guess stays a guess: the merge checks it.
-      for (uint32_t i = tid; i < 256u; i += (uint32_t)kMsThreads) s.sc.hist[i] = 0u;
-      if (tid == 0) s.spec_sumsq = 0u;
-      __syncthreads();
-      const uint32_t sh = s.win_shift;
-      for (uint32_t i = tid; i < cnt0; i += (uint32_t)kMsThreads) atomicAdd(&s.sc.hist[(key_doc(s.cand[i]) >> sh) & 255u], 1u);
-      __syncthreads();
-      if (tid < 256u) {
-        const uint32_t c = s.sc.hist[tid];
-        uint32_t sq = c * c;
-        sq = (uint32_t)__builtin_amdgcn_readlane((int)scan64_dpp(sq), 63);
-        if ((tid & 63u) == 0u && sq != 0u) atomicAdd(&s.spec_sumsq, sq);
-      }
-      __syncthreads();
-      const float n = (float)cnt0, p = fminf(1.0f, m / n);
-      const float s2 = ws > 1.5f ? fmaxf(((float)s.spec_sumsq - n * n / ws) / (ws - 1.0f), 0.0f) : n;
-      var = fmaxf(m, ws * p * p * s2 + m * (1.0f - p));
-    }
-    const float rr = m + (float)s.spec_z16 * (1.0f / 16.0f) * sqrtf(var) + 2.0f;
+    const float m = (float)k * fminf(1.0f, (float)s.wins_started / (float)max(s.q_wins, 1u));
+    const float rr = m + (float)s.spec_z16 * (1.0f / 16.0f) * sqrtf(m) + 2.0f;
     r = rr < (float)k ? (uint32_t)rr : 0u;
   }
   uint64_t guess = 0;
@@ -522,8 +490,6 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       s.spec_slot = spec ? as_global(hp.spec_g) + item.query : nullptr;
       s.spec_at = spec ? max(hp.spec_sched & 255u, 1u) : 0u;   // the first estimate (default: when every wave has begun its second window)
       s.spec_grow16 = max((hp.spec_sched >> 8) & 255u, 17u);
-      s.spec_disp = (spec && (ap->scatter & 2u) != 0u) ? 1u : 0u;
-      s.win_shift = 16u - ((item.flags >> 2) & 3u);   // (kMsWinDocs = 2^16 docs, a quarter ... of it for the launch's heaviest queries)
       for (int i = 0; i < kSliceSlots; ++i) s.slot_hits[i] = s.slot_slice[i] = 0u;
       for (int i = 0; i < 16; ++i) s.prof[i] = 0;
     }
@@ -572,7 +538,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
     // (a = P mod n for a prime P > n: coprime; of four primes the one whose a / n is nearest the golden section.)
     const uint32_t item_wins = item.flags >> 8;
     uint32_t sc_mul = 1u;
-    if ((ap->scatter & 1u) != 0u && item_wins > 3u && item_wins < 65536u) {   // (uniform; i x a stays below 2^32)
+    if (ap->scatter != 0u && item_wins > 3u && item_wins < 65536u) {   // (uniform; i x a stays below 2^32)
       const uint32_t primes[4] = {2654435761u, 2246822519u, 3266489917u, 668265263u};
       uint32_t best = 0xFFFFFFFFu;
   #pragma unroll

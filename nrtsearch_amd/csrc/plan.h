@@ -302,11 +302,9 @@ struct MsArgs {
   uint64_t* item_prof;           // instrumented kernel: 16 counters per output slot, else nullptr
   const uint32_t* q_wins;        // per query: the doc windows of all its items (speculation: the denominator of "how much have I seen")
   uint32_t k_stride;
-  uint32_t scatter;              // bit 0: an item's doc windows are handed out in a SCATTERED order (maxscore.hip): whatever a workgroup
+  uint32_t scatter;              // != 0: an item's doc windows are handed out in a SCATTERED order (maxscore.hip): whatever a workgroup
                                  // has walked so far is spread over the item's docs like a sample -- what the speculative thresholds
-                                 // assume -- also where the docid order follows time or a sort key;  bit 1: the guess's margin follows
-                                 // the MEASURED dispersion of the candidates over the doc windows instead of a sample's sqrt(m)
-                                 // (ms_compact): terms that come in docid bursts
+                                 // assume -- also where the docid order follows time or a sort key
   DHelp help;
 };
 

@@ -596,6 +596,7 @@ struct LeafSetCache {
   // index whose docid order defeats the estimate must not cost the context's other indexes their speculation; a refresh brings
   // a new leaf set and a fresh verdict).  spec_epoch: the context's nrtgpu_set_speculation count these numbers belong to.
   std::atomic<int64_t> spec_queries{0}, spec_reruns{0};
+  std::atomic<int64_t> spec_calls{0}, spec_calls_rerun{0};   // calls judged, calls that needed a second pass (a second pass costs per CALL)
   std::atomic<int> spec_scattered{0};   // the leaf set's windows are walked in the scattered order (maxscore.hip): the second chance
   std::atomic<int> spec_off{0};
   std::atomic<uint64_t> spec_epoch{0};

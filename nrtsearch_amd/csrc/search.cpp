@@ -22,6 +22,8 @@ static void spec_sync_epoch(const nrtgpu_ctx* ctx, LeafSetCache* lsc) {
   if (lsc->spec_epoch.exchange(e, std::memory_order_relaxed) != e) {   // nrtgpu_set_speculation since: start over
     lsc->spec_queries.store(0, std::memory_order_relaxed);
     lsc->spec_reruns.store(0, std::memory_order_relaxed);
+    lsc->spec_calls.store(0, std::memory_order_relaxed);
+    lsc->spec_calls_rerun.store(0, std::memory_order_relaxed);
     lsc->spec_scattered.store(0, std::memory_order_relaxed);
     lsc->spec_off.store(0, std::memory_order_relaxed);
   }
@@ -42,10 +44,26 @@ static void note_speculation_of(nrtgpu_ctx* ctx, LeafSetCache* lsc, int64_t n_qu
   const int64_t failed = lsc->spec_reruns.fetch_add(n_rerun, std::memory_order_relaxed) + n_rerun;
   ctx->spec_queries.fetch_add(n_queries, std::memory_order_relaxed);
   ctx->spec_reruns.fetch_add(n_rerun, std::memory_order_relaxed);
-  if (seen >= 2048 && failed * 50 > seen) {
+  // Two ways to fail the verdict.  By QUERIES: more than 2 % of >= 2048 run again.  By CALLS (round 6): a second pass costs per
+  // call -- plan, launch, a wait of its own -- whether it re-runs one query or fifty, so what decides is how many CALLS need
+  // one: more than a quarter of >= 32 calls.  Measured at C3's size with 1024-query batches (profiles/r06_followup_seeded_reruns.log):
+  // the sorted corpus in the scattered order fails 0.45 % of its queries -- under the first rule "cured" -- which is a failed
+  // query in 99 % of its batches: 2.32 - 2.62 ms per step under speculation against 2.08 with it off, although the scorer
+  // itself runs 1.05 ms against 2.04.  A closed loop's small batches keep their speculation under the same failure rate (8-query
+  // batches: one call in 28 needs a second pass).
+  const int64_t calls = lsc->spec_calls.fetch_add(1, std::memory_order_relaxed) + 1;
+  const int64_t calls_bad = lsc->spec_calls_rerun.fetch_add(n_rerun > 0 ? 1 : 0, std::memory_order_relaxed) + (n_rerun > 0 ? 1 : 0);
+  static const bool no_verdict = dev_env_int("NRTGPU_SPEC_NO_VERDICT", 0) != 0;   // (development build: measure a fixed setting)
+  // (A third step was tried in round 6 -- the guess's margin from the MEASURED dispersion of the candidates over the doc windows
+  //  instead of a sample's sqrt(m): re-runs fell to 0.2 - 0.5 % on the clustered corpus and to none on the sorted one, and the
+  //  deeper guesses gave the gain back: clustered 2.92 ms per step against 2.46 with speculation off, sorted 2.17 against 2.09.
+  //  profiles/r06_dispersion_experiment.patch, r06_dispersion_second_pass.log.)
+  if (((seen >= 2048 && failed * 50 > seen) || (calls >= 32 && calls_bad * 4 > calls)) && !no_verdict) {
     if (lsc->spec_scattered.exchange(1, std::memory_order_relaxed) == 0) {   // first: the scattered window order, a fresh count
       lsc->spec_queries.store(0, std::memory_order_relaxed);
       lsc->spec_reruns.store(0, std::memory_order_relaxed);
+      lsc->spec_calls.store(0, std::memory_order_relaxed);
+      lsc->spec_calls_rerun.store(0, std::memory_order_relaxed);
       ctx->spec_scattered.store(1, std::memory_order_relaxed);
     } else {
       lsc->spec_off.store(1, std::memory_order_relaxed);
@@ -94,13 +112,12 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
                           uint64_t* ext_guess = nullptr, bool follow_up = false) {
   forget_foreign_hip_error();
   // follow_up (round 6): the second pass of a speculative call -- the handful of queries whose guess failed the merge's check, run
-  // again without speculation.  As a launch of the usual kind it took a TURN of its own: the whole device waited while five items
-  // ran on five CUs, and the batch behind it with them (sorted-by-length corpus at C3's size: 2.7 ms per 1024-query step around a
-  // 1.1 ms kernel).  A follow-up takes no turn: its few persistent workgroups (kFollowUpCus) run on the CUs every big launch
-  // leaves alone, beside whatever batch is running; its queries answer a little later, nobody else waits for them.
+  // again (seeded: search_batch_spec).  As a launch of the usual kind it took a TURN of its own, and BEHIND whatever batch another
+  // thread had enqueued meanwhile: its caller waited a whole batch for five queries (sorted-by-length corpus at C3's size, two
+  // submitting threads: 2.6 ms per 1024-query step around a 1.05 ms kernel -- slower than with speculation off).  A follow-up takes
+  // no turn: its few persistent workgroups run on the CUs every big launch leaves alone, beside whatever batch is running.
   // Only MaxScore items (the exhaustive scan launches a workgroup per item and wants the whole device).
   static const bool follow_up_on = dev_env_int("NRTGPU_FOLLOW_UP", 1) != 0;   // (development build: 0 = a turn of its own, A/B)
-  constexpr int kFollowUpCus = 4;
   const bool small = follow_up && follow_up_on && hp.n_ms_items != 0 && hp.n_ms_items == hp.items.size() && ms_persistent();
   // spec_world > 1 (the library's multi-GPU search, dist.cpp): this call is ONE SHARD of a spec_world-way search over equal docid
   // ranges, and its speculative thresholds are guesses at the k-th score of the WHOLE search -- a shard's docs are a 1 / world
@@ -227,7 +244,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
     // 8: 2.50 (kernel 2.39), 16: 2.56, 32: 2.70 -- eight CUs of 256 is the default.
     static const int env_spare = (int)dev_env_int("NRTGPU_MS_SPARE_CUS", 8);
     help.n_cus = (uint32_t)std::max(ctx->n_cus - std::max(env_spare, 0), 1);
-    if (small) help.n_cus = (uint32_t)std::min<int>(kFollowUpCus, std::max(env_spare, 1));
+    if (small) help.n_cus = (uint32_t)std::max(env_spare, 1);   // (a follow-up: the spare CUs are its whole device)
     // NRTGPU_MS_PERSISTENT=0: one workgroup per item + helper workgroups behind them (A/B)
     help.persistent = ms_persistent() ? 1u : 0u;
   }
@@ -261,8 +278,8 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   ms_args.q_wins = (const uint32_t*)(db + o_qwins);
   {   // the leaf set's window order (note_speculation); NRTGPU_MS_SCATTER = 0 / 1 (development build): forced, A/B
     const long forced = dev_env_int("NRTGPU_MS_SCATTER", -1);
-    // (the second chance is BOTH the scattered order and the measured dispersion: plan.h: MsArgs.scatter; forced: the bits as given)
-    ms_args.scatter = forced >= 0 ? (uint32_t)(forced & 3) : ((spec && hp.lsc->spec_scattered.load(std::memory_order_relaxed) != 0) ? 3u : 0u);
+    // (the leaf set's step: search.cpp: note_speculation_of; forced: the bits as given)
+    ms_args.scatter = forced >= 0 ? (forced != 0 ? 1u : 0u) : ((spec && hp.lsc->spec_scattered.load(std::memory_order_relaxed) != 0) ? 1u : 0u);
   }
   ms_args.k_stride = hp.k_stride;
   ms_args.help = help;
@@ -412,7 +429,8 @@ static void unpack_topdocs(const uint64_t* keys, uint32_t n, uint64_t hits, cons
 // nullptr: no speculation in this call.
 static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases,
                              int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
-                             nrtgpu_topdocs* out, std::vector<int32_t>* rerun, bool content_held = false, bool follow_up = false) {
+                             nrtgpu_topdocs* out, std::vector<int32_t>* rerun, bool content_held = false, const uint64_t* seeds = nullptr,
+                             bool follow_up = false) {
   if (!ctx || !queries || !out || (n_segs > 0 && !segs)) return fail(NRTGPU_ERR_INVALID_ARG, "NULL argument");
   if (n_queries <= 0 || n_segs < 0) return fail(NRTGPU_ERR_INVALID_ARG, "n_queries must be > 0");
   if (n_queries > ctx->cfg.max_batch) return fail(NRTGPU_ERR_INVALID_ARG, "batch of %d exceeds max_batch %d", n_queries, ctx->cfg.max_batch);
@@ -425,6 +443,10 @@ static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
   std::optional<SegReadLocks> content;   // until this call's kernels have finished (content_held: the caller holds them over both passes)
   if (!content_held) content.emplace(segs, n_segs);
   if (int rc = build_plan(ctx, segs, doc_bases, n_segs, queries, n_queries, hp, 1)) return rc;
+  // seeds (search_batch_spec's second pass): per query a key that k docs of the search are KNOWN to exceed -- the walk starts from
+  // it as from a threshold another item of the query had published (theta_g), and collects nothing at or below it
+  if (seeds)
+    for (int qi = 0; qi < n_queries; ++qi) hp.theta_init[(size_t)qi] = std::max(hp.theta_init[(size_t)qi], seeds[qi]);
   const double plan_ms = now_ms() - t0;
 
   Slot* slot = nullptr;
@@ -510,14 +532,30 @@ static int search_batch_spec(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
   if (after_first) (*after_first)(rerun);
   std::vector<nrtgpu_bm25_query> rq(rerun.size());
   std::vector<nrtgpu_topdocs> ro(rerun.size());
+  // The second pass starts where the first one ended (round 6).  A guess that failed was too HIGH: the first pass skipped docs it
+  // should have kept -- but every hit it returned is a real doc with its real score, so a query that came back with k hits has k
+  // docs at or above its k-th key, and the final k-th key cannot lie below that one.  The re-run takes "the first pass's k-th key
+  // minus one" as its initial threshold (strictly below the final k-th key: keys are distinct integers, and a collector keeps only
+  // what EXCEEDS its threshold) and prunes from its first posting the way a converged walk does, where an unseeded re-run --
+  // no speculation, theta from zero -- was the slowest kind of walk there is: on the sorted-by-length corpus the five queries of
+  // a batch that are run again cost the step 1.6 ms around a 1.1 ms kernel (profiles/r05_bench_c3_sorted.json).
+  // (Only from the caller's own arrays where they hold the k-th hit: a NULL or short array seeds nothing.)
+  std::vector<uint64_t> seeds(rerun.size(), 0ull);
+  static const bool seed_reruns = dev_env_int("NRTGPU_SEED_RERUNS", 1) != 0;   // (development build: 0 = from zero, A/B)
   for (size_t i = 0; i < rerun.size(); ++i) {
     rq[i] = queries[rerun[i]];
     ro[i] = out[rerun[i]];
+    const nrtgpu_topdocs& o = out[rerun[i]];
+    const int32_t k = rq[i].k;
+    if (seed_reruns && k > 0 && o.n_hits >= k && o.docs && o.scores && (o.capacity <= 0 || o.capacity >= k)) {
+      const uint64_t kth = pack_key(o.scores[k - 1], (uint32_t)o.docs[k - 1]);
+      seeds[i] = kth > 0 ? kth - 1 : 0ull;
+    }
   }
   const int64_t deadline = g_deadline_ns;
   g_deadline_ns = 0;
   // (a few queries: a follow-up launch beside the next batch -- enqueue_search; more than that and it is a batch of its own)
-  const int rc2 = search_batch_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), ro.data(), nullptr, true, rq.size() <= 32);
+  const int rc2 = search_batch_impl(ctx, segs, doc_bases, n_segs, rq.data(), (int32_t)rq.size(), ro.data(), nullptr, true, seeds.data(), rq.size() <= 32);
   g_deadline_ns = deadline;
   if (rc2 != 0) return rc2;
   for (size_t i = 0; i < rerun.size(); ++i) out[rerun[i]] = ro[i];

@@ -34,6 +34,24 @@ assert state()[2:] == (True, True), state()
 # (the context's flags say "some leaf set"; the other leaf set's own verdict is untouched: it still speculates)
 pb_one.note_shard_speculation(4096, 0)
 ctx.set_speculation(5.0)                            # the verdicts start over
+assert state() == (0, 0, False, False), state()
+# the verdict by CALLS (round 6): a second pass costs per call.  1024-query calls of which every one re-runs 3 queries: 0.3 % of
+# the queries -- the query rule never fires -- but every call pays a second pass: after 32 calls the scattered order, after 32
+# more speculation is off.  (pb_one's leaf set: 200 calls of 8 queries with one re-run in ten of them keep their speculation.)
+for i in range(31):
+    pb_all.note_shard_speculation(1024, 3)
+assert state()[2:] == (False, False), state()
+pb_all.note_shard_speculation(1024, 3)
+assert state()[2:] == (True, False), state()
+for i in range(31):
+    pb_all.note_shard_speculation(1024, 3)
+assert state()[2:] == (True, False), state()
+pb_all.note_shard_speculation(1024, 3)
+assert state()[2:] == (True, True), state()
+ctx.set_speculation(5.0)
+for i in range(200):
+    pb_one.note_shard_speculation(8, 1 if i % 10 == 0 else 0)
+assert state()[2:] == (False, False), state()
 pb_all.note_shard_speculation(1024, 0)
 print("after set_speculation", state())
 for g in leaves:

@@ -63,3 +63,39 @@ def test_bench_two_ranks_through_the_librarys_collective(tmp_path, dev_lib, mode
     sp = c["shard_speculation"]
     assert sp and sp["queries"] == (12 + 3) * c["batch_queries"], sp        # every step's batch went through the checked exchange
     assert sp["failed"] <= sp["queries"] // 50, sp                          # (i.i.d. shards: guesses stand)
+
+
+@pytest.mark.parametrize("n_gpus,doc_shards", [(2, 1), (4, 2)])
+def test_bench_topology_doc_shards_times_query_groups(tmp_path, dev_lib, n_gpus, doc_shards):
+    """bench.py --gpus N --doc-shards D (round 6): N = D doc-shards x R query-groups on the one GPU of the pool.  (2, 1): two
+    replicas, nothing exchanged, each runs ITS batches; (4, 2): two groups of two doc shards, ONE library communicator per group
+    (carried by tests/mockrccl: two directories under /dev/shm), the groups take different batches.  The line counts every
+    group's queries and says what ran."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc is not here")
+    mock = str(tmp_path / "librccl_mock.so")
+    subprocess.run([HIPCC, "-O1", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "mockrccl", "mockrccl.cpp"), "-o", mock],
+                   check=True)
+    env = dict(os.environ, NRTGPU_LIB_PATH=os.path.join(ROOT, "nrtsearch_amd", "libnrtgpu_dev.so"), NRTGPU_RCCL_LIB=mock,
+               NRTGPU_BENCH_DEBUG_LIB_COLLECTIVE="1", NRTGPU_BENCH_COLLECTIVE_TIMEOUT="90", MASTER_ADDR="127.0.0.1", NRTGPU_BENCH_WATCHDOG="200")
+    steps, warmup = 8, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1", "--master-port",
+           str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_gpus), "--doc-shards", str(doc_shards), "--debug-same-gpu", "--workload", "C2",
+           "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--closed-loop", "", "--exhaustive-steps", "0", "--c4-steps", "0",
+           "--exchange-mode", "allgather"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    err = "\n".join(l for l in r.stderr.split("\n") if not l.startswith(("RCCL", "HIP", "ROCm", "Host", "Libr")) and "amdgpu.ids" not in l)
+    assert r.returncode == 0, err[:3000] + "\n[...]\n" + err[-3000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    R = n_gpus // doc_shards
+    assert d["n_gpus"] == n_gpus and d["steps"] == steps and c["topology"]["doc_shards"] == doc_shards and c["topology"]["query_groups"] == R
+    # value counts every group's queries: steps x batch x R over the slowest rank's time
+    assert abs(d["value"] - steps * c["batch_queries"] * R / (d["ms_per_step"] * steps * 1e-3)) / d["value"] < 0.01
+    if doc_shards == 1:
+        assert "replicas, no exchange" in c["sharding"] and c["shard_speculation"] is None
+    else:
+        assert "collective inside the library" in c["sharding"] and f"{R} query groups of {doc_shards} doc shards" in c["sharding"], c["sharding"]
+        assert c["shard_speculation"]["queries"] == (steps + warmup) * c["batch_queries"]   # rank 0's group: every step's batch checked
