@@ -53,7 +53,7 @@ static void note_speculation_of(nrtgpu_ctx* ctx, LeafSetCache* lsc, int64_t n_qu
   // batches: one call in 28 needs a second pass).
   const int64_t calls = lsc->spec_calls.fetch_add(1, std::memory_order_relaxed) + 1;
   const int64_t calls_bad = lsc->spec_calls_rerun.fetch_add(n_rerun > 0 ? 1 : 0, std::memory_order_relaxed) + (n_rerun > 0 ? 1 : 0);
-  static const bool no_verdict = dev_env_int("NRTGPU_SPEC_NO_VERDICT", 0) != 0;   // (development build: measure a fixed setting)
+  const bool no_verdict = dev_env_int("NRTGPU_SPEC_NO_VERDICT", 0) != 0;   // (development build: a fixed setting; read per call: tests set it)
   // (A third step was tried in round 6 -- the guess's margin from the MEASURED dispersion of the candidates over the doc windows
   //  instead of a sample's sqrt(m): re-runs fell to 0.2 - 0.5 % on the clustered corpus and to none on the sorted one, and the
   //  deeper guesses gave the gain back: clustered 2.92 ms per step against 2.46 with speculation off, sorted 2.17 against 2.09.

@@ -64,16 +64,16 @@ variants)
   done ;;
 trace)
   el "kernel trace"
-  rm -rf /tmp/prof; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t --output-format csv -- python $ROOT/bench.py --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --steps 20 --warmup 5 > /tmp/prof_bench.log 2>&1 )
+  rm -rf /tmp/prof; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t --output-format csv -- python $ROOT/bench.py --no-cpu-baseline --closed-loop '' --exhaustive-steps 0 --c4-steps 0 --c2-steps 0 --c5-steps 0 --steps 20 --warmup 5 > /tmp/prof_bench.log 2>&1 )
   find /tmp/prof -name "*kernel_stats*" -exec cp {} $O/${TAG}_kernel_stats.csv \;
   head -6 $O/${TAG}_kernel_stats.csv | cut -c1-60,200-420 ;;
 pmc)
   el "PMC passes"
   rm -f $O/${TAG}_pmc.txt
-  pmc fetch_default bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1
-  pmc fetch_noprune bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1 --no-prune
-  pmc fetch_packed bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1 --packed
-  pmc sq1_default bm25 SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1
+  pmc fetch_default bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --c2-steps 0 --c5-steps 0 --warmup 1 --steps 4 --host-threads 1
+  pmc fetch_noprune bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --c2-steps 0 --c5-steps 0 --warmup 1 --steps 4 --host-threads 1 --no-prune
+  pmc fetch_packed bm25 FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --c2-steps 0 --c5-steps 0 --warmup 1 --steps 4 --host-threads 1 --packed
+  pmc sq1_default bm25 SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --c2-steps 0 --c5-steps 0 --warmup 1 --steps 4 --host-threads 1
   pmc c4_fetch knn_sketch FETCH_SIZE GRBM_GUI_ACTIVE -- python $ROOT/bench.py --workload C4 --knn-queries 64 --no-cpu-baseline --no-verify --closed-loop "" --warmup 1 --steps 4
   pmc c4_mfma knn_sketch SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES -- python $ROOT/bench.py --workload C4 --knn-queries 64 --no-cpu-baseline --no-verify --closed-loop "" --warmup 1 --steps 4 ;;
 shapes)
@@ -104,7 +104,7 @@ c4)
 cache)
   el "cache-path PMC passes"
   rm -f $O/${TAG}_pmc_cache.txt
-  cpmc() { n=$1; shift; pmc $n bm25_maxscore "$@" -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --warmup 1 --steps 4 --host-threads 1 | tee -a $O/${TAG}_pmc_cache.txt; }
+  cpmc() { n=$1; shift; pmc $n bm25_maxscore "$@" -- python $ROOT/bench.py --no-cpu-baseline --closed-loop "" --exhaustive-steps 0 --c4-steps 0 --c2-steps 0 --c5-steps 0 --warmup 1 --steps 4 --host-threads 1 | tee -a $O/${TAG}_pmc_cache.txt; }
   cpmc tcc_hit TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum GRBM_GUI_ACTIVE
   cpmc tcc_ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum
   cpmc tcc_stall TCC_TAG_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum

@@ -105,8 +105,8 @@ def test_the_maxscore_walk_touches_no_scratch():
 
 
 def test_the_committed_table_is_the_built_library(kernels):
-    """profiles/r05_kernel_resources.txt is this build's table (re-run scripts/kernel_resources.py after a kernel change)."""
-    path = os.path.join(ROOT, "profiles", "r05_kernel_resources.txt")
+    """profiles/r06_kernel_resources.txt is this build's table (re-run scripts/kernel_resources.py after a kernel change)."""
+    path = os.path.join(ROOT, "profiles", "r06_kernel_resources.txt")
     seen = {}
     for line in open(path):
         if line.startswith("#") or not line.strip():

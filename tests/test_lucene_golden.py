@@ -129,9 +129,9 @@ def device_query(api, shape, param, terms):
     if shape == "msm":
         return api.BooleanQuery(tq, minimum_number_should_match=int(param))
     if shape == "filter":
-        return api.BooleanQuery(tq, minimum_number_should_match=1, filter=(api.MaskFilter(0),))
+        return api.BooleanQuery(tq, minimum_number_should_match=1, filter=(api.MaskFilter(1),))
     if shape == "must_not":
-        return api.BooleanQuery(tq, must_not=(api.MaskFilter(0),))
+        return api.BooleanQuery(tq, must_not=(api.MaskFilter(1),))
     return api.BooleanQuery((api.BoostQuery(tq[0], float(param)),) + tq[1:])
 
 
@@ -144,7 +144,7 @@ def _device_fixture():
     ctx = api.GpuContext(device_id=0, max_batch=8)
     leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
     for leaf, fw in zip(leaves, words):
-        leaf.set_mask(0, fw)
+        leaf.set_mask(1, fw)
     return api, corpus, words, ctx, leaves, api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
 
 

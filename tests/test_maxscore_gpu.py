@@ -344,6 +344,7 @@ def test_coalesced_callers_whose_mates_are_run_again_get_their_own_answer(dev_li
     import threading
 
     monkeypatch.setenv("NRTGPU_MS_SCATTER", "0")
+    monkeypatch.setenv("NRTGPU_SPEC_NO_VERDICT", "1")   # (every batch here needs a second pass: the leaf set's verdict by calls would end the experiment)
     ctx = api.GpuContext(device_id=0, max_batch=64)
     ranks = [1, 2, 5, 9, 20, 60, 150, 400]
     corpus = synth.build_corpus(3_200_000, ranks, n_segments=1)
