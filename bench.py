@@ -520,11 +520,13 @@ def run_c4(args, emit=True):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ctx.stats()
-    # Two callers taking the steps in turn ("staging overlapped with the previous panel"): the library runs
-    # one call's nomination launches at a time, a caller's staging, small selection / rescoring kernels, result copy and unpacking
-    # overlap the other caller's stream of the rows -- the rate a server with more than one request in flight sees; a call's
-    # latency is then about two steps.  (Kernel times come from the one-caller loop above: with overlapping launches a launch's
-    # HIP-event time is no longer its own.)
+    # Two callers taking the steps in turn ("staging overlapped with the previous panel"): a caller's
+    # staging, small selection / rescoring kernels, result copy and unpacking can overlap the other caller's stream of the rows.
+    # Measured (round 6, 10 M x 768): NO gain -- 64 queries per pass 3.41 ms with one caller, 3.51 with two; 32: 3.08 / 3.10 -- the
+    # pass is bandwidth-bound and two panels' streams of the rows share nothing (two passes in flight read the sketch twice); what
+    # is left between a call's device time (2.98 ms: three nomination launches 2.77, three selections 0.12, rescoring 0.09) and the
+    # call (3.41) is launch gaps and the host's staging, which only fewer launches per panel would take out.  Reported as measured.
+    # (Kernel times come from the one-caller loop above: with overlapping launches a launch's HIP-event time is no longer its own.)
     two = None
     if world == 1 and n_thr == 1 and args.steps >= 4 and not args.c4_callers:
         import threading
@@ -652,7 +654,7 @@ def run_c4(args, emit=True):
 
 def c2_leg(args, device, flags, planner_threads):
     """BASELINE config 2 inside the C3 line (every BASELINE config on the round's build, in the driver's
-    line): 1 M docs, Zipf terms, 2-term BooleanQuery, top-100, 1024 queries per step, two submitting threads -- the same loop as the
+    line): 1 M docs, Zipf terms, 2-term BooleanQuery, top-100, 1024 queries per step, FOUR submitting threads (the host's share decides this size) -- otherwise the same loop as the
     headline's.  (bench.py --workload C2 is the full line.)"""
     import threading
 
@@ -671,7 +673,9 @@ def c2_leg(args, device, flags, planner_threads):
     batches = [api.PreparedBatch(sr, queries[i: i + B], [mgr] * B) for i in range(0, n_distinct, B)]
     for pb in batches:
         pb.run()
-    n_thr = max(1, args.host_threads)
+    # (four submitting threads: at this size a step is the host's -- 0.31 ms of kernel under 0.36 ms of planning -- and two threads
+    #  leave the device idle a third of the time: measured 1.96 M queries/s with two, 2.68 M with three, 2.99 M with four at 6.6 CPUs)
+    n_thr = max(4, args.host_threads)
 
     def run(first, count):
         def worker(tix):
@@ -695,7 +699,7 @@ def c2_leg(args, device, flags, planner_threads):
     algo = (st["maxscore_postings"] if pruned else st["scan_postings"]) / launches * BYTES_PER_POSTING
     rate = algo / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     rec = {
-        "workload": w.name, "kernel": "bm25_maxscore_kernel" if pruned else "bm25_scan_kernel", "steps": args.c2_steps, "batch_queries": B,
+        "workload": w.name, "kernel": "bm25_maxscore_kernel" if pruned else "bm25_scan_kernel", "steps": args.c2_steps, "batch_queries": B, "host_threads": n_thr,
         "queries_per_s": round(args.c2_steps * B / dt, 1), "ms_per_step": round(dt / args.c2_steps * 1e3, 4), "avg_launch_ms": round(k_ms, 4),
         "algorithmic_bytes_per_launch": int(algo), "effective_achieved": round(rate, 1), "effective_frac": round(rate / HBM_PEAK_GBS, 4),
         "unit": "GB/s", "peak": HBM_PEAK_GBS, "host_plan_ms_per_step": round(st["host_plan_ms"] / max(1, st["batches"]), 4),
