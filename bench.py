@@ -96,7 +96,7 @@ def parse_args():
     ap.add_argument("--exhaustive-steps", type=int, default=8,
                     help="C3 / C2, one GPU: steps of the EXHAUSTIVE route (every posting streamed) timed after the main run for "
                          "roofline.exhaustive (0 = skip)")
-    ap.add_argument("--c2-steps", type=int, default=20,
+    ap.add_argument("--c2-steps", type=int, default=200,
                     help="C3 line, one GPU: also time this many steps of BASELINE config 2 (1 M docs, 2-term, top-100) in the same run "
                          "(roofline.c2; 0 = skip)")
     ap.add_argument("--c5-steps", type=int, default=4,
@@ -522,10 +522,11 @@ def run_c4(args, emit=True):
     st = ctx.stats()
     # Two callers taking the steps in turn ("staging overlapped with the previous panel"): a caller's
     # staging, small selection / rescoring kernels, result copy and unpacking can overlap the other caller's stream of the rows.
-    # Measured (round 6, 10 M x 768): NO gain -- 64 queries per pass 3.41 ms with one caller, 3.51 with two; 32: 3.08 / 3.10 -- the
-    # pass is bandwidth-bound and two panels' streams of the rows share nothing (two passes in flight read the sketch twice); what
-    # is left between a call's device time (2.98 ms: three nomination launches 2.77, three selections 0.12, rescoring 0.09) and the
-    # call (3.41) is launch gaps and the host's staging, which only fewer launches per panel would take out.  Reported as measured.
+    # Measured (round 6, 10 M x 768, 64 queries per pass; profiles/r06_c2_threads_c4_two_callers.log): 3.26 - 3.31 ms per pass call
+    # against 3.41 - 3.48 with one caller (-5 %; one call saw none, the default line's short leg 2.99 - 3.24): the pass is
+    # bandwidth-bound and two panels' streams of the rows share nothing, so what overlaps is only what lies between a call's device
+    # time (2.98 ms: three nomination launches 2.77, three selections 0.12, rescoring 0.09) and the call -- launch gaps and the
+    # host's staging.  Fewer launches per panel would take that out for ONE caller too: not built.
     # (Kernel times come from the one-caller loop above: with overlapping launches a launch's HIP-event time is no longer its own.)
     two = None
     if world == 1 and n_thr == 1 and args.steps >= 4 and not args.c4_callers:
