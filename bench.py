@@ -923,6 +923,8 @@ def main():
                          host_threads=planner_threads)
     if args.speculation_margin >= 0.0:
         ctx.set_speculation(args.speculation_margin)
+    if shard_world > 1:   # this shard's real share of the index (the "balanced" layout and the index's last shard are not 1 / N)
+        ctx.set_shard_share(sum(s_.max_doc for s_ in corpus.segments), w.n_docs)
     leaves = [api.GpuSegment.from_data(ctx, s) for s in corpus.segments]
     searcher = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(corpus))
     queries = workload.boolean_queries(qranks)

@@ -324,6 +324,13 @@ int  nrtgpu_pending_wait(nrtgpu_pending* pending);
  * (nrtgpu_dist_search_bm25_batch_mode passes the communicator's size: docid-range shards are equal to within a segment boundary).
  * nrtgpu_note_shard_speculation tells the leaf set's verdict (nrtgpu_stats.spec_*) how a batch went, for callers that do the
  * check themselves; nrtgpu_dist_search_bm25_batch_mode does all of this itself. */
+/* The share of a sharded index this context holds (round 6): shard_docs of index_docs live docs.  Where it is set, the guesses of
+ * the shard-level speculation (nrtgpu_search_bm25_shard_device_begin with spec_world >= 2, nrtgpu_dist_search_bm25_batch[_mode])
+ * count "the windows of all shards" as this shard's windows x index_docs / shard_docs instead of x spec_world: the reference's
+ * virtual shards balance LIVE docs by greedy LPT over whole segments (MyIndexSearcher.java:117-160), which leaves shards of 40 %
+ * and 20 % of an index side by side, and a shard that holds more than 1 / spec_world of the docs guesses too high (caught by the
+ * check, but every catch is a second pass).  (0, 0): equal shards again.  Changes nothing but how often guesses fail. */
+int  nrtgpu_set_shard_share(nrtgpu_ctx* ctx, int64_t shard_docs, int64_t index_docs);
 int  nrtgpu_search_bm25_shard_device_begin(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_t* doc_bases, int32_t n_segs,
                                            const nrtgpu_bm25_query* queries, int32_t n_queries, int32_t k_stride, void* d_keys,
                                            void* d_counts, void* d_hits, int32_t spec_world, void* d_guess, nrtgpu_pending** out);

@@ -103,6 +103,8 @@ final class NrtGpu {
    *  the guess's safety margin in standard deviations; 0 switches them off for the context -- e.g. a live setting for an index
    *  sorted by a field the score follows (the library also gives up by itself when too many guesses fail). */
   static final MethodHandle SET_SPECULATION = h("nrtgpu_set_speculation", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_FLOAT));
+  // one process per GPU over virtual shards: reader.numDocs() of this shard's leaves against the whole searcher's
+  static final MethodHandle SET_SHARD_SHARE = h("nrtgpu_set_shard_share", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, JAVA_LONG));
 
   static String lastError() {
     try {

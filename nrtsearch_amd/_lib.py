@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "nrtgpu_set_slicing",
     "nrtgpu_blend", "nrtgpu_dist_unique_id", "nrtgpu_dist_init", "nrtgpu_dist_search_bm25_batch", "nrtgpu_dist_allgather_merge", "nrtgpu_segment_fork",
     "nrtgpu_search_bm25_batch_device_begin", "nrtgpu_pending_wait", "nrtgpu_set_thread_deadline_ns", "nrtgpu_monotonic_ns", "nrtgpu_last_diagnostics", "nrtgpu_dist_close", "nrtgpu_dist_owned_range", "nrtgpu_dist_search_bm25_batch_mode", "nrtgpu_dist_exchange_merge", "nrtgpu_dist_exchange_merge_checked", "nrtgpu_search_bm25_shard_device_begin", "nrtgpu_note_shard_speculation", "nrtgpu_dist_knn_exact", "nrtgpu_dist_search_hybrid_batch",
-    "nrtgpu_knn_exact_relation", "nrtgpu_set_speculation", "nrtgpu_set_thread_slices",
+    "nrtgpu_knn_exact_relation", "nrtgpu_set_speculation", "nrtgpu_set_shard_share", "nrtgpu_set_thread_slices",
 ]
 # what include/nrtgpu_dev.h adds: test hooks and measurement helpers of the development library (libnrtgpu_dev.so) only
 DEV_SYMBOLS = [
@@ -187,6 +187,8 @@ def _open(path: str) -> C.CDLL:
     L.nrtgpu_set_thread_slices.argtypes = [vp, i32]
     L.nrtgpu_set_speculation.argtypes = [vp, C.c_float]
     L.nrtgpu_set_speculation.restype = C.c_int
+    L.nrtgpu_set_shard_share.argtypes = [vp, C.c_int64, C.c_int64]
+    L.nrtgpu_set_shard_share.restype = C.c_int
     L.nrtgpu_knn_exact_relation.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.nrtgpu_reset_stats.restype = None
     if hasattr(L, "nrtgpu_debug_hold_coalescers"):   # development build only (include/nrtgpu_dev.h)

@@ -260,6 +260,11 @@ class GpuContext:
         """Speculative thresholds of the MaxScore route (nrtgpu_set_speculation): the guess's safety margin in standard deviations; 0 = off."""
         _lib.check(_lib.load().nrtgpu_set_speculation(self._h, C.c_float(float(margin))))
 
+    def set_shard_share(self, shard_docs: int, index_docs: int) -> None:
+        """This context's share of a sharded index (nrtgpu_set_shard_share): the shard-level guesses then count the other shards'
+        docs by it instead of assuming equal shards; (0, 0): equal shards."""
+        _lib.check(_lib.load().nrtgpu_set_shard_share(self._h, int(shard_docs), int(index_docs)))
+
     def spec_counters(self) -> dict:
         """Speculative thresholds of the MaxScore route (nrtgpu_stats.spec_*): queries run under them since nrtgpu_set_speculation,
         queries run again, whether the library has switched them off for this context."""

@@ -505,6 +505,7 @@ struct nrtgpu_ctx {
   std::atomic<int> spec_scattered{0};                      // ... 1 once SOME leaf set has been moved to the scattered window order
   std::atomic<uint64_t> spec_epoch{1};                     // nrtgpu_set_speculation calls (the leaf sets' verdicts start over)
   std::atomic<int> spec_z16{5 * 16};   // the guess's margin x 16 (nrtgpu_set_speculation)
+  std::atomic<int64_t> shard_docs{0}, index_docs{0};   // nrtgpu_set_shard_share: this context's share of a sharded index (0: equal shards)
   std::atomic<int64_t> live_segments{0};   // segment handles (uploads and forks) that have not been freed yet (nrtgpu_debug_live_segments)
   std::atomic<int> co_hold{0};                          // nrtgpu_debug_hold_coalescers: no leader (of either coalescer) leaves with less than a full batch / panel
   // the same for exact vector searches (nrtgpu_knn_exact_coalesced, vectors.cpp)

@@ -162,8 +162,16 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   memcpy(hb + o_theta, hp.theta_init.data(), hp.theta_init.size() * 8);
   if (!hp.q_wins.empty()) memcpy(hb + o_qwins, hp.q_wins.data(), hp.q_wins.size() * 4);
   if (spec_world > 1) {   // the denominator of "how much of the query's docs have I seen": the windows of ALL shards
+    // (this shard's REAL share of the index where the caller has stated it -- nrtgpu_set_shard_share: virtual shards balance
+    //  live docs, not docid ranges, and a shard that holds 40 % of the index is no "one of two" -- else spec_world equal shards)
+    uint64_t num = (uint64_t)spec_world, den = 1;
+    const int64_t sd = ctx->shard_docs.load(std::memory_order_relaxed), id = ctx->index_docs.load(std::memory_order_relaxed);
+    if (sd > 0 && id >= sd) {
+      num = (uint64_t)id;
+      den = (uint64_t)sd;
+    }
     uint32_t* qw = (uint32_t*)(hb + o_qwins);
-    for (size_t i = 0; i < hp.q_wins.size(); ++i) qw[i] = (uint32_t)std::min<uint64_t>((uint64_t)qw[i] * (uint64_t)spec_world, 0xFFFFFFFFull);
+    for (size_t i = 0; i < hp.q_wins.size(); ++i) qw[i] = (uint32_t)std::min<uint64_t>(((uint64_t)qw[i] * num + den - 1) / den, 0xFFFFFFFFull);
   }
   memset(hb + o_quant, 0, hp.list_idx.size() * 8);
   if (ext_hits) memcpy(hb + o_lower, hp.q_lower.data(), hp.q_lower.size() * 8);
@@ -576,6 +584,14 @@ extern "C" int nrtgpu_search_bm25_batch(nrtgpu_ctx* ctx, const nrtgpu_seg* const
                                         int32_t n_segs, const nrtgpu_bm25_query* queries, int32_t n_queries,
                                         nrtgpu_topdocs* out) {
   return search_batch_spec(ctx, segs, doc_bases, n_segs, queries, n_queries, out, nullptr);
+}
+
+extern "C" int nrtgpu_set_shard_share(nrtgpu_ctx* ctx, int64_t shard_docs, int64_t index_docs) {
+  if (!ctx || shard_docs < 0 || index_docs < 0 || (shard_docs > 0 && index_docs < shard_docs))
+    return fail(NRTGPU_ERR_INVALID_ARG, "shard share: 0 <= shard_docs <= index_docs expected");
+  ctx->shard_docs.store(shard_docs, std::memory_order_relaxed);
+  ctx->index_docs.store(index_docs, std::memory_order_relaxed);
+  return NRTGPU_OK;
 }
 
 extern "C" int nrtgpu_set_speculation(nrtgpu_ctx* ctx, float margin) {

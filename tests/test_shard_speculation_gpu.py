@@ -100,3 +100,80 @@ def test_shards_guessing_the_global_threshold_merge_to_the_whole_index_answer(va
         for g_ in leaves:
             g_.release()
         ctx.close()
+
+
+def test_unequal_shards_guess_by_their_real_share():
+    """Virtual shards balance live docs over whole segments (MyIndexSearcher.java:117-160): shards of very different sizes are
+    ordinary -- here 70 %, 20 % and 10 % of an index.  spec_world can only say "one of N equal shards": the 70 % shard says 2, assumes
+    it holds half of every top-k where it holds 70 %, and guesses too high.  nrtgpu_set_shard_share states the real share (round 6): the guesses that
+    fail the check against the merged lists must not become more, and the merged answers are the whole-index answers either way
+    (failed queries run again without speculation)."""
+    import torch
+
+    n_docs, n_q, k = 2_400_000, 32, 1000    # (k = 1000: at k = 200 the guess's five-sigma margin still covers a 70 % shard that says "half")
+    w = workload.Workload("unequal shards", n_docs, 4, k, n_q, 3, max_rank=3000)
+    qr = synth.make_queries(n_q, w.n_terms, w.max_rank)
+    queries = workload.boolean_queries(qr)
+    mgr = api.TopScoreDocCollectorManager(k)
+    pieces = [workload.build_shard_corpus(w, qr, 10, r) for r in range(10)]
+    groups = [[0, 1, 2, 3, 4, 5, 6], [7, 8], [9]]        # 70 % / 20 % / 10 % of the docid space
+    ctx = api.GpuContext(0, max_batch=64)
+    leaves = [api.GpuSegment.from_data(ctx, s) for c in pieces for s in c.segments]
+    k_stride = (k + 15) // 16 * 16
+    try:
+        ctx.set_speculation(0)
+        whole = api.GpuIndexSearcher(ctx, leaves, api.IndexStatistics.from_corpus(pieces[0])).search_batch(queries, [mgr] * n_q)
+
+        def play(with_share, spec, qsub=None, qrsub=None):
+            qs = queries if qsub is None else qsub
+            n = len(qs)
+            keys = torch.zeros((len(groups), n, k_stride), dtype=torch.int64, device="cuda")
+            cnt = torch.zeros((len(groups), n), dtype=torch.int32, device="cuda")
+            hits = torch.zeros((len(groups), n), dtype=torch.int64, device="cuda")
+            guess = torch.zeros((len(groups), n), dtype=torch.int64, device="cuda")
+            for gi, grp in enumerate(groups):
+                segs = [s for r in grp for s in pieces[r].segments]
+                docs = sum(s.max_doc for s in segs)
+                c2 = api.GpuContext(0, max_batch=64)
+                lv = [api.GpuSegment.from_data(c2, s) for s in segs]
+                sr = api.GpuIndexSearcher(c2, lv, api.IndexStatistics.from_corpus(pieces[0]))
+                try:
+                    if with_share:
+                        c2.set_shard_share(docs, n_docs)
+                    pb = api.PreparedBatch(sr, qs, [mgr] * n)
+                    sw = max(2, n_docs // docs) if spec else 0    # what spec_world can say: "one of N equal shards", N >= 2
+                    h = pb.begin_shard_device(k_stride, keys[gi].data_ptr(), cnt[gi].data_ptr(), hits[gi].data_ptr(), sw, guess[gi].data_ptr() if sw else 0)
+                    api.PreparedBatch.wait_device(h)
+                    torch.cuda.synchronize()
+                finally:
+                    for g in lv:
+                        g.release()
+                    c2.close()
+            return keys, cnt, hits, guess
+
+        n_failed = {}
+        for with_share in (False, True):
+            keys, cnt, hits, guess = play(with_share, True)
+            g = guess.cpu().numpy().view(np.uint64)
+            assert (g != 0).any(), "no shard speculated"
+            merged = api.PreparedMerge(ctx, len(groups), n_q, k_stride, [k] * n_q, [api.TOTAL_HITS_THRESHOLD] * n_q)
+            merged.run(keys.data_ptr(), cnt.data_ptr(), hits.data_ptr())
+            gmax = g.max(axis=0)
+            failed = np.flatnonzero((gmax != 0) & (merged.kth_keys() < gmax))
+            n_failed[with_share] = len(failed)
+            got = [merged.topdocs(qi) for qi in range(n_q)]
+            if len(failed):
+                keys2, cnt2, hits2, _ = play(with_share, False, [queries[int(j)] for j in failed])
+                again = api.PreparedMerge(ctx, len(groups), len(failed), k_stride, [k] * len(failed), [api.TOTAL_HITS_THRESHOLD] * len(failed))
+                again.run(keys2.data_ptr(), cnt2.data_ptr(), hits2.data_ptr())
+                for i, j in enumerate(failed):
+                    got[int(j)] = again.topdocs(i)
+            for qi in range(n_q):
+                e, t = whole[qi], got[qi]
+                assert t.docs.tolist() == e.docs.tolist() and t.scores.view(np.uint32).tolist() == e.scores.view(np.uint32).tolist(), f"query {qi} (shares stated: {with_share})"
+        print(f"unequal shards 70 / 20 / 10 %: {n_failed[False]} of {n_q} guesses failed under spec_world alone, {n_failed[True]} with the real shares")
+        assert n_failed[True] <= n_failed[False] and n_failed[True] <= 2, n_failed
+    finally:
+        for g_ in leaves:
+            g_.release()
+        ctx.close()
