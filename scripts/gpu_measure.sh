@@ -18,6 +18,7 @@
 #   cache        (round 6) the cache path of the MaxScore kernel, one --pmc pass per counter block: L2 hits / misses / requests,
 #                fabric-side read requests by size and target, what the vector L1s ask the L2 for and how long it takes, texture
 #                addresser busy / stalled cycles, L1 TLB -> <tag>_pmc_cache.txt
+#   gatherruns   scripts/ubench/gather_fetch runs: what a gather instruction costs by the distinct lines its lanes ask for (16 KiB / 2 MiB / 64 MiB)
 #   gathersweep  scripts/ubench/gather_fetch sweep: G lines/s of random 8-byte gathers by footprint (2 MiB ... 4 GiB), alone and
 #                under --pmc (L2 hits / misses, fabric-side requests per launch, launches in the printed order)
 set -u
@@ -115,6 +116,10 @@ cache)
   cpmc ta2 TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_BUSY_max TA_BUSY_min
   cpmc tlb TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum
   cpmc sq_mem SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY
+  ;;
+gatherruns)
+  el "gather cost by distinct lines per instruction"
+  ( cd /tmp && timeout 120 $ROOT/scripts/ubench/gather_fetch runs ) 2>&1 | grep "^runs" | tee $O/${TAG}_gather_runs.txt
   ;;
 gathersweep)
   el "gather ceiling by footprint"

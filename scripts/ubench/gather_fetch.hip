@@ -59,6 +59,58 @@ __global__ __launch_bounds__(256) void gather_mod(const char* __restrict__ base,
   if (acc == 0x12345u) *sink = acc;
 }
 
+// `gather_fetch runs` (round 6): what a gather instruction costs as a function of the DISTINCT LINES its 64 lanes ask for -- lanes
+// in runs of `run` share a 64-byte line (8-byte words of it), the runs' lines scattered over the footprint -- at a footprint the
+// vector L1 holds (16 KiB), one the L2 holds (2 MiB) and the walk's mix (64 MiB).  If the time follows the lines and not the lanes,
+// the vector L1's tag path is what a gather occupies, and lanes that walk adjacent docids are worth arranging.
+__global__ __launch_bounds__(256) void gather_runs(const char* __restrict__ base, uint64_t n_loads, uint64_t n_lines, uint32_t run, uint32_t* sink) {
+  // (32-bit address arithmetic, powers of two only: a shift, a multiply, a mask per load -- the loop must not be what is measured)
+  uint32_t acc = 0;
+  const uint32_t stride = gridDim.x * blockDim.x, mask = (uint32_t)n_lines - 1u, sh = 31u - (uint32_t)__builtin_clz(run);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)n_loads; i += stride) {
+    const uint32_t line = ((i >> sh) * 2654435761u) & mask;
+    const u32x2 v = *(const u32x2*)(base + (line * 64u + ((i & (run - 1u)) & 7u) * 8u));
+    acc += v[0] ^ v[1];
+  }
+  if (acc == 0x12345u) *sink = acc;
+}
+
+static int runs(int, char**) {
+  const uint64_t kibs[3] = {16, 2048, 65536};
+  const uint32_t rr[6] = {1, 2, 4, 8, 16, 64};
+  char* buf = nullptr;
+  uint32_t* sink = nullptr;
+  CHECK(hipMalloc((void**)&buf, 65536ull << 10));
+  CHECK(hipMalloc((void**)&sink, 4));
+  CHECK(hipMemset(buf, 1, 65536ull << 10));
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const uint64_t n_loads = 1ull << 26;
+  for (int f = 0; f < 3; ++f)
+    for (int r = 0; r < 6; ++r) {
+      const uint64_t n_lines = (kibs[f] << 10) / 64ull;
+      float ms = 0.f, best = 1e30f;
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(gather_runs, dim3(256 * 16), dim3(256), 0, 0, (const char*)buf, n_loads, n_lines, rr[r], sink);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+      }
+      const double clk = 2.33e9 * 256.0;   // CU-clocks per second
+      printf("runs footprint_KiB %llu lanes_per_line %u best_ms %.3f G_loads_per_s %.1f G_lines_per_s %.1f wave_instr_per_CU_clk %.4f lines_per_CU_clk %.3f\n",
+             (unsigned long long)kibs[f], rr[r], best, (double)n_loads / (best * 1e-3) / 1e9, (double)n_loads / rr[r] / (best * 1e-3) / 1e9,
+             (double)n_loads / 64.0 / (best * 1e-3) / clk, (double)n_loads / rr[r] / (best * 1e-3) / clk);
+    }
+  CHECK(hipGetLastError());
+  CHECK(hipFree(buf));
+  CHECK(hipFree(sink));
+  return 0;
+}
+
 static int sweep(int argc, char** argv) {
   uint64_t mibs[16] = {2, 16, 64, 128, 256, 512, 1024, 1536, 4096};
   int n = 9;
@@ -100,6 +152,7 @@ static int sweep(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc > 1 && argv[1][0] == 's') return sweep(argc, argv);
+  if (argc > 1 && argv[1][0] == 'r') return runs(argc, argv);
   const uint64_t gib = argc > 1 ? strtoull(argv[1], nullptr, 10) : 4ull;
   const uint64_t bytes = gib << 30;                 // a power of two: the scramble is a bijection on its lines
   const uint64_t n_lines = bytes / 64ull;
