@@ -527,6 +527,8 @@ def run_c4(args, emit=True):
     # bandwidth-bound and two panels' streams of the rows share nothing, so what overlaps is only what lies between a call's device
     # time (2.98 ms: three nomination launches 2.77, three selections 0.12, rescoring 0.09) and the call -- launch gaps and the
     # host's staging.  Fewer launches per panel would take that out for ONE caller too: not built.
+    # (Later in round 6 most of that "host's staging" turned out to be the Python mirror's per-call pointer set-up -- now kept per
+    #  thread, api._topdocs_outputs: one caller 3.16 - 3.22 ms per pass call at 64 queries, profiles/r06_c4_wrapper.log.)
     # (Kernel times come from the one-caller loop above: with overlapping launches a launch's HIP-event time is no longer its own.)
     two = None
     if world == 1 and n_thr == 1 and args.steps >= 4 and not args.c4_callers:

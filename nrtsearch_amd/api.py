@@ -21,6 +21,7 @@ from __future__ import annotations
 import ctypes as C
 import dataclasses
 import os
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -106,6 +107,51 @@ class TopDocs:
     scores: np.ndarray          # float32
     total_hits: int
     relation_gte: bool          # True == TotalHits.Relation.GREATER_THAN_OR_EQUAL_TO
+
+
+_OUT_ARRAYS = threading.local()
+
+
+def _topdocs_outputs(nq: int, k: int):
+    """(outs, docs, scores) for a call that returns nq lists of up to k hits: an array of nrtgpu_topdocs whose docs / scores pointers
+    address the rows of two numpy arrays.  Built once per thread and shape and used again -- 2 x nq pointer objects through
+    numpy's ctypes bridge cost 0.3 ms at 64 queries, a tenth of an exact vector search's pass; the caller copies what it returns."""
+    cache = getattr(_OUT_ARRAYS, "by_shape", None)
+    if cache is None:
+        cache = _OUT_ARRAYS.by_shape = {}
+    got = cache.get((nq, k))
+    if got is None:
+        outs = (_lib.TopDocs * nq)()
+        docs = np.zeros((nq, k), dtype=np.int32)
+        scores = np.zeros((nq, k), dtype=np.float32)
+        d0, s0 = docs.ctypes.data, scores.ctypes.data
+        for qi in range(nq):
+            outs[qi].capacity = k
+            outs[qi].docs = C.cast(d0 + qi * k * 4, C.POINTER(C.c_int32))
+            outs[qi].scores = C.cast(s0 + qi * k * 4, C.POINTER(C.c_float))
+        if len(cache) >= 8:
+            cache.clear()
+        got = cache[(nq, k)] = (outs, docs, scores)
+    outs = got[0]
+    for qi in range(nq):
+        outs[qi].n_hits = 0
+        outs[qi].total_hits = 0
+    return got
+
+
+def _topdocs_lists(outs, docs, scores, n: int, none_if_negative: bool = False):
+    """The call's answers as TopDocs: ONE copy of each array (the arrays of _topdocs_outputs are used again), a row's hits as a view of it."""
+    dc, sc = docs.copy(), scores.copy()
+    res = []
+    for qi in range(n):
+        o = outs[qi]
+        th = int(o.total_hits)
+        if none_if_negative and th < 0:
+            res.append(None)
+            continue
+        m = o.n_hits
+        res.append(TopDocs(dc[qi, :m], sc[qi, :m], th, bool(o.total_hits_is_lower_bound)))
+    return res
 
 
 # ---- statistics / similarity ---------------------------------------------------------------------
@@ -570,19 +616,11 @@ class GpuIndexSearcher:
         if similarity == "normalized_cosine":
             queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True).astype(np.float32), dtype=np.float32)
         nq, dim = queries.shape
-        outs = (_lib.TopDocs * nq)()
-        docs = np.zeros((nq, k), dtype=np.int32)
-        scores = np.zeros((nq, k), dtype=np.float32)
-        for qi in range(nq):
-            outs[qi].capacity = k
-            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
-            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        outs, docs, scores = _topdocs_outputs(nq, int(k))
         _lib.check(_lib.load().nrtgpu_dist_knn_exact(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
                                                      self.SIMILARITY[similarity], queries.ctypes.data, nq, dim, int(k),
                                                      C.c_float(boost), int(mode), outs))
-        return [None if outs[qi].total_hits < 0 else
-                TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
-                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
+        return _topdocs_lists(outs, docs, scores, nq, none_if_negative=True)
 
     def supported(self, query: Query, manager: TopScoreDocCollectorManager) -> bool:
         """The eligibility predicate alone (nrtgpu_query_supported): would the device route take this query?"""
@@ -620,18 +658,11 @@ class GpuIndexSearcher:
             queries = queries / np.linalg.norm(queries, axis=1, keepdims=True).astype(np.float32)
             queries = np.ascontiguousarray(queries, dtype=np.float32)
         nq, dim = queries.shape
-        outs = (_lib.TopDocs * nq)()
-        docs = np.zeros((nq, k), dtype=np.int32)
-        scores = np.zeros((nq, k), dtype=np.float32)
-        for qi in range(nq):
-            outs[qi].capacity = k
-            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
-            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        outs, docs, scores = _topdocs_outputs(nq, int(k))
         _lib.check(_lib.load().nrtgpu_knn_exact(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
                                                 self.SIMILARITY[similarity], queries.ctypes.data, nq, dim, int(k),
                                                 C.c_float(boost), outs))
-        return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
-                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
+        return _topdocs_lists(outs, docs, scores, nq)
 
     def knn_exact_coalesced(self, field: int, similarity: str, query: np.ndarray, k: int, boost: float = 1.0) -> TopDocs:
         """What a request thread calls with ONE exact vector query: concurrent callers are merged into panels of up to 64 queries
@@ -665,19 +696,12 @@ class GpuIndexSearcher:
         if similarity == "normalized_cosine":
             queries = np.ascontiguousarray(queries / np.linalg.norm(queries, axis=1, keepdims=True).astype(np.float32), dtype=np.float32)
         nq, dim = queries.shape
-        outs = (_lib.TopDocs * nq)()
-        docs = np.zeros((nq, k), dtype=np.int32)
-        scores = np.zeros((nq, k), dtype=np.float32)
-        for qi in range(nq):
-            outs[qi].capacity = k
-            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
-            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        outs, docs, scores = _topdocs_outputs(nq, int(k))
         _lib.check(_lib.load().nrtgpu_knn_search(self.ctx._h, self._segs, self._bases, len(self.leaves), int(field),
                                                  self.SIMILARITY[similarity], queries.ctypes.data, nq, dim, int(k),
                                                  C.c_float(boost), int(filter.mask_id) if filter else 0,
                                                  C.c_float(min_score), outs))
-        return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
-                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(nq)]
+        return _topdocs_lists(outs, docs, scores, nq)
 
     def rescore_vectors(self, hits: TopDocs, field: int, similarity: str, query: np.ndarray, window: int,
                         query_weight: float = 1.0, rescore_weight: float = 1.0, boost: float = 1.0) -> TopDocs:
@@ -708,18 +732,20 @@ class GpuIndexSearcher:
         if qv.shape[0] != n:
             raise ValueError("one query vector per query")
         m = self._marshal(queries, managers)
-        outs = (_lib.TopDocs * n)()
-        docs = np.zeros((n, max(window, 1)), dtype=np.int32)
-        scores = np.zeros((n, max(window, 1)), dtype=np.float32)
-        for qi in range(n):
-            outs[qi].capacity = window
-            outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
-            outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
+        if window >= 1:
+            outs, docs, scores = _topdocs_outputs(n, int(window))
+        else:
+            outs = (_lib.TopDocs * n)()
+            docs = np.zeros((n, 1), dtype=np.int32)
+            scores = np.zeros((n, 1), dtype=np.float32)
+            for qi in range(n):
+                outs[qi].capacity = window
+                outs[qi].docs = docs[qi].ctypes.data_as(C.POINTER(C.c_int32))
+                outs[qi].scores = scores[qi].ctypes.data_as(C.POINTER(C.c_float))
         _lib.check(_lib.load().nrtgpu_search_hybrid_batch(
             self.ctx._h, self._segs, self._bases, len(self.leaves), m.queries, n, int(field), self.SIMILARITY[similarity],
             qv.ctypes.data, qv.shape[1], C.c_float(boost), float(query_weight), float(rescore_weight), int(window), outs))
-        return [TopDocs(docs[qi, : outs[qi].n_hits].copy(), scores[qi, : outs[qi].n_hits].copy(), int(outs[qi].total_hits),
-                        bool(outs[qi].total_hits_is_lower_bound)) for qi in range(n)]
+        return _topdocs_lists(outs, docs, scores, n)
 
 
     def dist_search_hybrid_batch(self, queries: Sequence[Query], managers: Sequence[TopScoreDocCollectorManager], field: int,
