@@ -342,6 +342,7 @@ void knn_score_kernel(const float* __restrict__ vecs, const float* __restrict__ 
 // coalesced, N * dim * 2 bytes per pass, and up to 64 queries (4 panels of 16, fp16 in LDS) ride on one pass because the fp16
 // matrix rate is 16x the fp32 one.  |estimate - result| <= 2^-10 |q||v| (+ fp32 accumulation + flushed tiny elements): vectors.cpp.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr size_t kKnnSketchStaticLds = 1280;   // knn_sketch_kernel's per-query tables (static LDS next to the dynamic panel + queue)
 
 // max |element| of the matrix as float bits (atomicMax on uints: magnitudes order like their bits)
 __global__ __launch_bounds__(256) void knn_absmax_kernel(const float* __restrict__ vecs, int64_t n_elems, uint32_t* __restrict__ out) {
@@ -417,9 +418,16 @@ __device__ __forceinline__ void sk_wait(f16x8& slot) {
 }
 template <int P, int D, int I>
 __device__ __forceinline__ void sk_step(f16x8 (&abuf)[D], f32x4 (&acc)[P], const f16x8* qs_step, const f16x8* nxt_lo, const f16x8* nxt_hi) {
+  // the step's P query operands are asked of the LDS together and BEFORE the wait for the row piece: one LDS round trip per
+  // step, under the ring's wait -- read one by one between the matrix instructions (what the compiler does when it has no P x 4
+  // registers to spare) each of them waits for its own (round 6: the whole cost of more queries per pass, see the epilogue)
+  f16x8 b[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) b[p] = qs_step[(I * P + p) * 64];
+  __builtin_amdgcn_sched_barrier(0);
   sk_wait<D - 1>(abuf[I]);
 #pragma unroll
-  for (int p = 0; p < P; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[I], qs_step[(I * P + p) * 64], acc[p], 0, 0, 0);
+  for (int p = 0; p < P; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(abuf[I], b[p], acc[p], 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   // into the registers the matrix instructions above have just read: no copy, D - 1 requests stay in flight
   if (I < 4) sk_request<(I & 3) * 1024>(abuf[I], nxt_lo);
@@ -466,23 +474,36 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
   uint32_t* const q_n = (uint32_t*)(smem + (size_t)steps * P * 1024);
   uint64_t* const q_e = (uint64_t*)(smem + (size_t)steps * P * 1024 + 16);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  __shared__ float sk_nq[64], sk_dsc[64], sk_thhi[64];
+  __shared__ unsigned long long sk_th[64];
+  static_assert(sizeof(float) * 64 * 3 + sizeof(unsigned long long) * 64 == kKnnSketchStaticLds, "launch_knn_sketch sizes the queue by this");
   if (tid == 0) *q_n = 0u;
+  if (tid < 64u) {
+    const int32_t q = (int32_t)tid;
+    const unsigned long long th_q = q < n_q ? theta[q] : ~0ull;
+    sk_nq[q] = q < n_q ? qnorm2[q] : 0.f;
+    sk_dsc[q] = q < n_q ? 1.0f / qscale[q] : 0.f;   // a power of two: exact
+    sk_th[q] = th_q;
+    // a key above theta carries a score >= theta's (equal scores: the docid decides): rows strictly below are rejected on the
+    // score alone (theta = ~0, "nothing passes", is a NaN score: every compare with it is false)
+    const uint32_t tsb = __float_as_uint(key_score(th_q));
+    sk_thhi[q] = tsb ? __uint_as_float(tsb - 1u) : -1.0f;   // (a theta of score 0: ties among zero scores are the docid's business)
+  }
   for (int32_t i = (int32_t)tid; i < steps * P * 64; i += kKnnThreads) qs[i] = panel16[i];   // (knn_panel_fp16_kernel's layout)
   __syncthreads();
   const uint32_t j = lane & 15u, kk = lane >> 4;
-  float nq[P], th_hi[P], dsc[P];
-  unsigned long long th[P];
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int32_t q = (int32_t)j + 16 * p;
-    nq[p] = q < n_q ? qnorm2[q] : 0.f;
-    dsc[p] = q < n_q ? 1.0f / qscale[q] : 0.f;   // a power of two: exact
-    th[p] = q < n_q ? theta[q] : ~0ull;
-    // a key above theta carries a score >= theta's (equal scores: the docid decides): rows strictly below are rejected on the
-    // score alone (theta = ~0, "nothing passes", is a NaN score: every compare with it is false)
-    const uint32_t tsb = __float_as_uint(key_score(th[p]));
-    th_hi[p] = tsb ? __uint_as_float(tsb - 1u) : -1.0f;   // (a theta of score 0: ties among zero scores are the docid's business)
-  }
+  // What the epilogue needs of query q = j + 16 p: |q|^2, 1 / its fp16 scale (a power of two: exact), theta and the largest score
+  // theta rejects.  NOT held in registers through the stream (20 of the 128 a wave has: without them the compiler keeps a step's
+  // P query operands in registers instead of reading them one by one): read where they are used -- per leaf for the filter's
+  // thresholds, and in the epilogue proper, which few lanes reach once theta is known.  From LDS (kKnnSketchStaticLds bytes next to
+  // the dynamic panel + queue): a vector load there would have the wave wait for its whole ring of row pieces.
+  auto query_consts = [&](int p, float& nq_p, float& dsc_p, unsigned long long& th_p, float& th_hi_p) {
+    const uint32_t q = j + 16u * (uint32_t)p;   // (< 64: the tables hold neutral values behind the panel's last query)
+    nq_p = sk_nq[q];
+    dsc_p = sk_dsc[q];
+    th_p = sk_th[q];
+    th_hi_p = sk_thhi[q];
+  };
   const int64_t padded_rows = (tile_end - tile_begin) << 4;   // of this launch
   // a contiguous run of tiles per wave: one sequential stream of 1 KiB pieces per leaf it crosses
   const int64_t n_tiles = tile_end - tile_begin;
@@ -500,6 +521,40 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
     const float leaf_inv = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lf.inv_rows_scale)));
     const int32_t* const ord_to_doc = (const int32_t*)u_o2d;
     const uint64_t* const live_bits = (const uint64_t*)u_accept;
+    // Can any of a lane's 4 P estimates of a tile pass?  The estimate is a non-decreasing function of acc x (a per-row factor) for
+    // COSINE, DOT_PRODUCT and MAXIMUM_INNER_PRODUCT, so "estimate > theta's score" has a necessary condition that costs one
+    // multiply and one compare per element: acc x factor > xthr[p] -- xthr lowered by 2^-16 of the scale the estimate's own
+    // roundings (a handful of ulps: 2^-22) live on.  A lane none of whose elements meets it skips the epilogue below; a lane
+    // with one runs it UNCHANGED, so what is nominated is exactly what was (the filter is a superset test).  The epilogue was the
+    // whole cost of more queries per pass: 2.76 ms at 64 queries against 2.50 without it and 2.50 at one query
+    // (profiles/r06_knn_epilogue.log).  -inf: everything passes (no theta yet, EUCLIDEAN, a zero query, a boost <= 0) -- pass_all,
+    // because a NaN product compares false with anything; +inf: nothing can (a column without a query, theta = "nothing passes").
+    float xthr[P];
+    bool pass_all = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      xthr[p] = -INFINITY;
+      float nq_p, dsc_p, ts;   // ts: scores <= ts are rejected
+      unsigned long long th_p;
+      query_consts(p, nq_p, dsc_p, th_p, ts);
+      const float c = dsc_p * leaf_inv * (sim == 0 ? (nq_p > 0.f ? __builtin_amdgcn_rsqf(nq_p) : 0.f) : 1.0f);   // estimate's dot = acc x c (x rsq|v|^2)
+      if ((int32_t)j + 16 * p >= n_q || (th_p != 0ull && ts != ts)) {
+        xthr[p] = INFINITY;
+      } else if (th_p != 0ull && ts >= 0.0f && boost > 0.0f && c > 0.0f && c < INFINITY && sim != 2) {
+        const float s = ts / boost;   // the estimate before the boost must exceed about this
+        float x, scale;               // the dot product (cosine: the cosine) must exceed x; scale: what its roundings are relative to
+        if (sim == 3) {               // dot < 0 ? 1 / (1 - dot) : dot + 1
+          x = s >= 1.0f ? s - 1.0f : (s > 0.0f ? 1.0f - 1.0f / s : -INFINITY);
+          scale = fabsf(x) + 1.0f;
+        } else {                      // max((1 + dot) / 2, 0)
+          x = 2.0f * s - 1.0f;
+          scale = fabsf(x) + 1.0f;
+        }
+        if (x > -INFINITY && x < INFINITY) xthr[p] = (x - scale * 0x1p-16f) / c;   // (NaN / inf: stays -inf)
+        if (!(xthr[p] == xthr[p])) xthr[p] = -INFINITY;
+      }
+      pass_all |= xthr[p] == -INFINITY;
+    }
     // The norms' pointer.  Rebuilt from the leaf record it would be a GENERIC pointer to the compiler, which then loads a tile's
     // norms with flat VECTOR loads (vmcnt) and drains the ring at the tile's first use of one (round 3's build:
     // profiles/r03_knn_sketch_isa_note.txt).  In the constant address space the same loads are scalar (s_load, lgkmcnt), as they
@@ -564,31 +619,47 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) rn4[reg] = __builtin_amdgcn_rsqf(nv4[reg]);
       }
+      bool maybe = pass_all;   // some element of mine may pass (see xthr above; a NaN product -- a zero row -- counts as "may")
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) maybe |= !(acc[p][reg] * (sim == 0 ? rn4[reg] : 1.0f) <= xthr[p]);
+      if (maybe)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int32_t q = (int32_t)j + 16 * p;
         if (q < n_q) {
-          const float inv_nq = nq[p] > 0.f ? __builtin_amdgcn_rsqf(nq[p]) : 0.f;
-          const bool slot_round = th[p] == 0ull && !append_only;   // no theta yet: every padded row owns a slot, see knn_score_kernel
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
+            // element by element: the same test, then the estimate proper for the few that meet it
+            if (!(xthr[p] == -INFINITY || !(acc[p][reg] * (sim == 0 ? rn4[reg] : 1.0f) <= xthr[p]))) continue;
+            float nq_p, dsc_p, th_hi_p;
+            unsigned long long th_p;
+            query_consts(p, nq_p, dsc_p, th_p, th_hi_p);
+            const float inv_nq = nq_p > 0.f ? __builtin_amdgcn_rsqf(nq_p) : 0.f;
+            const bool slot_round = th_p == 0ull && !append_only;   // no theta yet: every padded row owns a slot, see knn_score_kernel
+            // (the query's number, opaque to the optimiser from here on: the addresses of its list and counter are then computed
+            //  HERE, where a row is written straight to the list -- hoisted out of the tile loop they cost the stream four registers
+            //  it does not have: 20 B of scratch in the <4, 8> instantiation)
+            uint32_t qv = (uint32_t)q;
+            asm volatile("" : "+v"(qv));
             const int64_t drow = r0 + 4 * (int32_t)kk + reg;
             const int64_t gpos = g0 + 4 * (int32_t)kk + reg;
             const bool valid = drow < (int64_t)leaf_rows;
             float sc = 0.f;
             if (valid) {
-              const float dot = acc[p][reg] * dsc[p] * leaf_inv;
+              const float dot = acc[p][reg] * dsc_p * leaf_inv;
               const float nv = nv4[reg];
               float est;
               if (sim == 0) est = fmaxf((1.0f + dot * inv_nq * rn4[reg]) * 0.5f, 0.0f);
               else if (sim == 1) est = fmaxf((1.0f + dot) * 0.5f, 0.0f);
-              else if (sim == 2) est = __builtin_amdgcn_rcpf(1.0f + fmaxf(nq[p] + nv - 2.0f * dot, 0.0f));
+              else if (sim == 2) est = __builtin_amdgcn_rcpf(1.0f + fmaxf(nq_p + nv - 2.0f * dot, 0.0f));
               else est = dot < 0.0f ? __builtin_amdgcn_rcpf(1.0f - dot) : dot + 1.0f;
               // this estimate IS the nomination's score (hardware rsq / rcp, a few fp32 roundings: the bound's e_rel covers
               // them): nothing in double, nothing but compares until a row passes
               sc = est * boost;
             }
-            if (slot_round || (valid && sc > th_hi[p])) {
+            if (slot_round || (valid && sc > th_hi_p)) {
               uint32_t qi = 0xFFFFFFFFu;
               if (!slot_round) qi = atomicAdd(q_n, 1u);
               if (qi < qcap) {
@@ -602,11 +673,11 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
                   if (live) key = pack_key(sc, (uint32_t)(doc_base + ldoc));
                 }
                 if (slot_round) {
-                  if ((uint64_t)gpos < (uint64_t)cap) cand[(size_t)q * cap + (size_t)gpos] = key;
-                  if (gpos == padded_rows - 1) cand_cnt[q] = (uint32_t)min<int64_t>(padded_rows, (int64_t)0xFFFFFFFFll);
-                } else if (key > th[p]) {
-                  const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
-                  if (pos < cap) cand[(size_t)q * cap + pos] = key;
+                  if ((uint64_t)gpos < (uint64_t)cap) cand[(size_t)qv * cap + (size_t)gpos] = key;
+                  if (gpos == padded_rows - 1) cand_cnt[qv] = (uint32_t)min<int64_t>(padded_rows, (int64_t)0xFFFFFFFFll);
+                } else if (key > th_p) {
+                  const uint32_t pos = atomicAdd(&cand_cnt[qv], 1u);
+                  if (pos < cap) cand[(size_t)qv * cap + pos] = key;
                 }
                 // (its loads and stores are complete here as far as the compiler's bookkeeping goes: with vector memory events
                 // pending at the next tile's loop it waits vmcnt(0) in front of it -- the ring with them)
@@ -921,14 +992,16 @@ void launch_knn_panel_fp16(hipStream_t st, const float* qpanel, const float* qsc
                      (f16x8*)panel16);
 }
 size_t knn_sketch_lds_bytes(int32_t dim, int32_t n_q) { return (size_t)knn_sketch_steps(dim) * (size_t)((n_q + 15) >> 4) * 1024; }
+// the panel in fp16, the queue's counter, at least a small queue and the kernel's static tables must fit the CU's 160 KB
+bool knn_sketch_fits(int32_t dim, int32_t n_q) { return knn_sketch_lds_bytes(dim, n_q) + 16 + 256 * 8 + kKnnSketchStaticLds <= 160 * 1024; }
 int launch_knn_sketch(hipStream_t st, uint32_t blocks, const DKnnLeaf* leaves, int32_t n_leaves, int32_t dim, int64_t tile_begin,
                       int64_t tile_end, const void* panel16, const float* qnorm2, const float* qscale, int32_t n_q, int32_t sim,
                       float boost, const unsigned long long* theta, uint64_t* cand, uint32_t* cand_cnt, uint32_t cap, int32_t append_only) {
   if (tile_end <= tile_begin || n_leaves <= 0) return 0;
   const int32_t steps = knn_sketch_steps(dim), panels = (n_q + 15) >> 4;
   const size_t panel_bytes = knn_sketch_lds_bytes(dim, n_q);
-  if (panel_bytes + 16 + 256 * 8 > 160 * 1024) return (int)hipErrorInvalidValue;   // (vectors.cpp only comes here when it fits)
-  const uint32_t qcap = (uint32_t)std::min<size_t>(4096, (160 * 1024 - panel_bytes - 16) / 8);   // the nomination queue behind the panel
+  if (!knn_sketch_fits(dim, n_q)) return (int)hipErrorInvalidValue;   // (vectors.cpp only comes here when it fits)
+  const uint32_t qcap = (uint32_t)std::min<size_t>(4096, (160 * 1024 - kKnnSketchStaticLds - panel_bytes - 16) / 8);   // the nomination queue behind the panel
   const size_t lds = panel_bytes + 16 + (size_t)qcap * 8;
 #define NRT_SKETCH_LAUNCH(PANELS, DEPTH)                                                                                            \
   {                                                                                                                                 \

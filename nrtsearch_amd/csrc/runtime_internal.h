@@ -86,6 +86,7 @@ void launch_knn_norm_min(hipStream_t st, const float* norm2, int64_t n, uint32_t
 void launch_knn_absmax(hipStream_t st, const float* vecs, int64_t n_elems, uint32_t* out_bits);
 size_t knn_sketch_bytes(int32_t dim, int64_t n);
 size_t knn_sketch_lds_bytes(int32_t dim, int32_t n_q);
+bool knn_sketch_fits(int32_t dim, int32_t n_q);   // the sketch kernel's LDS: panel + queue + its static tables within 160 KB
 void launch_knn_panel_fp16(hipStream_t st, const float* qpanel, const float* qscale, int32_t dim, int32_t n_q, void* panel16);
 void launch_knn_sketch_build(hipStream_t st, const float* vecs, int32_t dim, int64_t n, float scale, void* sketch);
 int launch_knn_sketch(hipStream_t st, uint32_t blocks, const DKnnLeaf* leaves, int32_t n_leaves, int32_t dim, int64_t tile_begin,

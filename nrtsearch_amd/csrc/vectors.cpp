@@ -176,7 +176,7 @@ static int knn_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, const int32_
   // the flush terms need the smallest non-zero |v| of the leaves.  On top: the fp32 bound above (the estimate's norms are fp32).
   // (the query panel in fp16 and at least a small nomination queue behind it must fit the CU's 160 KB of LDS)
   const bool sketch_ok = all_sketched && any_vectors && std::isfinite(nv_max) &&
-                         knn_sketch_lds_bytes(dim, std::min(n_queries, dim > 1280 ? 16 : kKnnMaxQ)) + 16 + 256 * 8 <= 160 * 1024;
+                         knn_sketch_fits(dim, std::min(n_queries, dim > 1280 ? 16 : kKnnMaxQ));
   auto bound16_of = [&](double nq, double q_l1, double q_unit, double e32) {
     // (4 gamma for the accumulation: the matrix cores' internal summation tree is not specified to round to nearest at every node)
     const double e16 = std::ldexp(1.0, -10) + std::ldexp(1.0, -22) + 4.0 * gam;
