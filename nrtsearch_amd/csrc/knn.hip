@@ -693,23 +693,56 @@ void knn_sketch_kernel(const DKnnLeaf* __restrict__ leaves, int32_t n_leaves, in
     ++li;
   }
   __syncthreads();
+  // The queue goes out: a nomination's place in its query's list comes from the list's counter in global memory -- ONE atomic per
+  // (workgroup, query) for all of the workgroup's nominations of that query, not one per nomination: with 64 queries the second
+  // launch of a pass (theta still that of the first 65 k rows) queues ~560 nominations per workgroup, 144 k atomics on 64 words
+  // of four cache lines, and the launch ended behind them (profiles/r06_knn_epilogue.log).  A thread keeps its (<= kFlushPerThread)
+  // entries in registers between the count and the write.
+  constexpr int kFlushPerThread = 4;   // qcap <= 4096 = 4 x kKnnThreads (launch_knn_sketch)
+  static_assert(kFlushPerThread * kKnnThreads >= 4096, "the queue's capacity is bounded by what the flush holds in registers");
   const uint32_t n_queued = min(*q_n, qcap);
-  for (uint32_t i = tid; i < n_queued; i += kKnnThreads) {
-    const uint64_t e = q_e[i];
-    const uint32_t q = (uint32_t)(e & 63ull);
-    const int64_t gpos = (int64_t)((e >> 6) & 0x3FFFFFFull);
-    const int64_t tile = tile_begin + (gpos >> 4);
-    const DKnnLeaf lf = leaves[knn_leaf_of_tile(leaves, n_leaves, tile)];
-    const int64_t drow = ((tile - lf.tile_begin) << 4) + (gpos & 15);
-    const int32_t ldoc = lf.ord_to_doc ? lf.ord_to_doc[drow] : (int32_t)drow;
-    bool live = true;
-    if (lf.accept) live = (lf.accept[ldoc >> 6] >> (ldoc & 63)) & 1ull;
-    const uint64_t key = pack_key(__uint_as_float((uint32_t)(e >> 32)), (uint32_t)(lf.doc_base + ldoc));
-    if (live && key > theta[q]) {
-      const uint32_t pos = atomicAdd(&cand_cnt[q], 1u);
-      if (pos < cap) cand[(size_t)q * cap + pos] = key;
+  uint32_t* const f_cnt = (uint32_t*)sk_nq;    // (the per-query tables are done with: their LDS holds the counts and the bases)
+  uint32_t* const f_base = (uint32_t*)sk_dsc;
+  if (tid < 64u) f_cnt[tid] = 0u;
+  __syncthreads();
+  uint64_t my_key[kFlushPerThread];
+  uint32_t my_q[kFlushPerThread], my_rank[kFlushPerThread];
+#pragma unroll
+  for (int r = 0; r < kFlushPerThread; ++r) {
+    const uint32_t i = tid + (uint32_t)r * kKnnThreads;
+    my_q[r] = 0xFFFFFFFFu;
+    my_key[r] = 0ull;
+    my_rank[r] = 0u;
+    if (i < n_queued) {
+      const uint64_t e = q_e[i];
+      const uint32_t q = (uint32_t)(e & 63ull);
+      const int64_t gpos = (int64_t)((e >> 6) & 0x3FFFFFFull);
+      const int64_t tile = tile_begin + (gpos >> 4);
+      const DKnnLeaf lf = leaves[knn_leaf_of_tile(leaves, n_leaves, tile)];
+      const int64_t drow = ((tile - lf.tile_begin) << 4) + (gpos & 15);
+      const int32_t ldoc = lf.ord_to_doc ? lf.ord_to_doc[drow] : (int32_t)drow;
+      bool live = true;
+      if (lf.accept) live = (lf.accept[ldoc >> 6] >> (ldoc & 63)) & 1ull;
+      const uint64_t key = pack_key(__uint_as_float((uint32_t)(e >> 32)), (uint32_t)(lf.doc_base + ldoc));
+      if (live && key > theta[q]) {
+        my_q[r] = q;
+        my_key[r] = key;
+        my_rank[r] = atomicAdd(&f_cnt[q], 1u);
+      }
     }
   }
+  __syncthreads();
+  if (tid < 64u) {
+    const uint32_t c = f_cnt[tid];
+    f_base[tid] = c ? atomicAdd(&cand_cnt[tid], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kFlushPerThread; ++r)
+    if (my_q[r] != 0xFFFFFFFFu) {
+      const uint32_t pos = f_base[my_q[r]] + my_rank[r];
+      if (pos < cap) cand[(size_t)my_q[r] * cap + pos] = my_key[r];
+    }
 }
 
 // Per query: top-k of (running top-k  UNION  the round's candidate list) -> running top-k (sorted),
