@@ -916,6 +916,58 @@ void rescore_vectors_kernel(const float* __restrict__ vecs, const float* __restr
 // both paths give the same bits), QueryRescore.combine in double, then QueryRescorer's sort
 // (combined score desc, doc asc) in LDS and the window.
 constexpr int kHybridThreads = 1024;
+constexpr int kHybridRows = 4;   // hits a wave scores side by side (their rows' loads in flight together)
+// knn_wave_score's partial sums for R rows at once: per row and lane the SAME additions in the same order (k = lane, lane + 64,
+// ...), the R rows' loads issued together -- one wave, one row at a time waited a memory round trip per hit
+template <int R>
+__device__ __forceinline__ void knn_wave_partials(int sim, const float* const (&vp)[R], const float* __restrict__ q, int32_t dim, uint32_t lane,
+                                                  float (&acc)[R]) {
+  // (the rows' addresses come out of LDS: generic pointers to the compiler, flat loads -- they are global memory)
+  typedef const __attribute__((address_space(1))) float* gfloat_ptr;
+  gfloat_ptr v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = (gfloat_ptr)vp[r];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
+  int32_t k = (int32_t)lane;
+  for (; k + 192 < dim; k += 256) {   // four strided elements per row and lane
+    float x[R][4], qq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qq[u] = q[k + 64 * u];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[r][u] = v[r] ? v[r][k + 64 * u] : 0.f;   // (v[r]: wave-uniform)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (sim == 2) {
+          const float d = qq[u] - x[r][u];
+          acc[r] += d * d;
+        } else {
+          acc[r] += x[r][u] * qq[u];
+        }
+      }
+  }
+  for (; k < dim; k += 64) {
+    const float qk = q[k];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float xv = v[r] ? v[r][k] : 0.f;
+      if (sim == 2) {
+        const float d = qk - xv;
+        acc[r] += d * d;
+      } else {
+        acc[r] += xv * qk;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc[r] += __shfl_xor(acc[r], d, 64);
+}
 __global__ __launch_bounds__(kHybridThreads)
 void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32_t* __restrict__ first_counts,
                            uint32_t k_stride, const DVecSeg* __restrict__ segs, int32_t n_segs, int32_t dim,
@@ -924,23 +976,28 @@ void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32
                            uint32_t* __restrict__ out_counts, uint32_t w_stride, int32_t drop_foreign) {
   // drop_foreign (multi-GPU: the list is the MERGED first pass of all shards): a hit whose doc lies in none of these leaves
   // belongs to another rank -- that rank rescores it; here it is dropped (key 0 sorts last and is not counted)
-  __shared__ uint64_t cand[1024];
+  // Two phases (round 6; through round 5 a wave took a hit from its key to its score on its own, 63 hits one after the other, each
+  // a chain of dependent loads -- key, leaf records, norm, row: 0.46 ms per 256 queries x 1000 hits, 1.7 TB/s):
+  //   1. a THREAD per hit: key -> (leaf, row) -> the row's address and norm into LDS -- every hit's chain at once;
+  //   2. a wave per FOUR hits: their rows' loads in flight together, knn_wave_score's sums and reduction per row unchanged.
+  __shared__ uint64_t cand[1024];      // phase 1: the first-pass keys; phase 2: the combined keys
+  __shared__ const float* h_v[1024];   // the hit's row (nullptr: the doc has no vector)
+  __shared__ float h_nv[1024];
+  __shared__ uint8_t h_mine[1024];
   __shared__ uint32_t n_foreign;
   if (threadIdx.x == 0) n_foreign = 0;
-  __syncthreads();
   const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t n = min(first_counts[q], 1024u);
   const float* qv = qvecs + (size_t)q * dim;
   const float nq = qnorm2[q];
-  for (uint32_t i = wave; i < n; i += (uint32_t)(kHybridThreads / 64)) {
+  for (uint32_t i = tid; i < n; i += (uint32_t)kHybridThreads) {
     const uint64_t key = first_keys[(size_t)q * k_stride + i];
     const uint32_t gdoc = 0xFFFFFFFFu - (uint32_t)key;
-    const float first = key_score(key);
     int64_t row = -1;
     const float* v = nullptr;
     float nv = 0.f;
     bool mine = false;
-    for (int32_t si = 0; si < n_segs; ++si) {  // wave-uniform
+    for (int32_t si = 0; si < n_segs; ++si) {
       const DVecSeg sg = segs[si];
       const int64_t local = (int64_t)gdoc - (int64_t)sg.doc_base;
       if (local < 0 || local >= (int64_t)sg.max_doc) continue;
@@ -963,13 +1020,40 @@ void hybrid_rescore_kernel(const uint64_t* __restrict__ first_keys, const uint32
       }
       break;
     }
-    float second = 0.f;
-    if (row >= 0) second = knn_wave_score(sim, v, qv, dim, lane, nq, nv, boost);
+    cand[i] = key;
+    h_v[i] = v;
+    h_nv[i] = nv;
+    h_mine[i] = mine ? 1u : 0u;
+  }
+  __syncthreads();
+  constexpr uint32_t kWaves = (uint32_t)(kHybridThreads / 64);
+  for (uint32_t i0 = wave; i0 < n; i0 += kWaves * (uint32_t)kHybridRows) {
+    const float* v[kHybridRows];
+    uint32_t idx[kHybridRows];
+#pragma unroll
+    for (int r = 0; r < kHybridRows; ++r) {
+      idx[r] = i0 + (uint32_t)r * kWaves;
+      const float* p = idx[r] < n ? h_v[idx[r]] : nullptr;   // (uniform LDS reads: a pointer as scalars)
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32));
+      v[r] = (const float*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    }
+    float acc[kHybridRows];
+    knn_wave_partials<kHybridRows>(sim, v, qv, dim, lane, acc);
     if (lane == 0) {
-      const double comb = row >= 0 ? qw * (double)first + rw * (double)second : qw * (double)first;
-      const bool foreign = drop_foreign != 0 && !mine;
-      cand[i] = foreign ? 0ull : pack_key((float)comb, gdoc);
-      if (foreign) atomicAdd(&n_foreign, 1u);
+#pragma unroll
+      for (int r = 0; r < kHybridRows; ++r)
+        if (idx[r] < n) {
+          const uint64_t key = cand[idx[r]];
+          const uint32_t gdoc = 0xFFFFFFFFu - (uint32_t)key;
+          const float first = key_score(key);
+          float second = 0.f;
+          if (v[r]) second = sim == 2 ? (1.0f / (1.0f + acc[r])) * boost : knn_map_score(sim, acc[r], nq, h_nv[idx[r]], boost);
+          const double comb = v[r] ? qw * (double)first + rw * (double)second : qw * (double)first;
+          const bool foreign = drop_foreign != 0 && h_mine[idx[r]] == 0u;
+          cand[idx[r]] = foreign ? 0ull : pack_key((float)comb, gdoc);
+          if (foreign) atomicAdd(&n_foreign, 1u);
+        }
     }
   }
   uint32_t n2 = 1;
