@@ -474,11 +474,18 @@ static int search_batch_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, con
     std::unique_lock<std::mutex> gpu(ctx->gpu_mu, std::defer_lock);
     if (int rc = enqueue_search(ctx, slot, hp, n_queries, hp.k_stride, nullptr, nullptr, nullptr, &run, gpu, -1, rerun != nullptr, 1, nullptr, follow_up)) return rc;
   }
-  HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
+  // The answers come back behind the kernels on the same stream: ONE copy where the workspace lays keys, counts and hits out as the
+  // host buffer does (both are carved by the same rule), and one wait for everything -- through round 5 the call waited for the
+  // kernels, then issued three copies and waited again: a second wake-up and two more copy launches, a fifth of a one-query call
+  // (profiles/r06_single_query_timeline.txt).
   const double tc1 = call_trace ? now_ms() : 0.0;
-  HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
-  HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
-  HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
+  if ((const char*)run.out_counts - (const char*)run.out_keys == (ptrdiff_t)(o_c - o_k) && (const char*)run.out_hits - (const char*)run.out_keys == (ptrdiff_t)(o_h - o_k)) {
+    HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, (o_h - o_k) + hb, hipMemcpyDeviceToHost, slot->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(ho + o_k, run.out_keys, kb, hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipMemcpyAsync(ho + o_c, run.out_counts, cb, hipMemcpyDeviceToHost, slot->stream));
+    HIP_TRY(hipMemcpyAsync(ho + o_h, run.out_hits, hb, hipMemcpyDeviceToHost, slot->stream));
+  }
   HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, slot->stream, slot->ev_wait));
   const double tc2 = call_trace ? now_ms() : 0.0;
   const uint64_t* keys = (const uint64_t*)(ho + o_k);
@@ -702,8 +709,8 @@ static int search_hybrid_impl(nrtgpu_ctx* ctx, const nrtgpu_seg* const* segs, co
                           dim, (const float*)(da + o_qv), (const float*)(da + o_qn), sim, boost, query_weight, rescore_weight,
                           (uint32_t)window, (uint64_t*)(da + o_wk), (uint32_t*)(da + o_wc), w_stride);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(wait_for_stream((ctx->cfg.flags & NRTGPU_FLAG_BLOCKING_WAIT) != 0, st, slot->ev_wait));
   }
+  // (the answers behind the kernels on the same stream, ONE wait: see search_batch_impl)
   HIP_TRY(hipMemcpyAsync(ha + oh_k, da + o_wk, kb, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(ha + oh_c, da + o_wc, cb, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(ha + oh_fc, run.out_counts, cb, hipMemcpyDeviceToHost, st));
