@@ -459,7 +459,7 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
     const uint32_t sec_mode = TWO ? q.sec_mode : kMsSecNone;  // (uniform) what the second accumulator holds
     const float tie_breaker = TWO ? q.tie_breaker : 0.0f;
     // kMsSecReqOpt: (float)a + (float)b may exceed (float)(a + b) by 2 float ulps: sums are compared with a threshold 2^-21 lower
-    auto loosen = [&](uint64_t t) { return (TWO && sec_mode == kMsSecReqOpt) ? max(t - (t >> 21), 2ull) - 1ull : t; };
+    auto loosen = [&](uint64_t t) { return (TWO && sec_mode == kMsSecReqOpt) ? max(t - (t >> 21), (uint64_t)2) - (uint64_t)1 : t; };   // (both uint64_t: max(uint64_t, unsigned long long) is HIP's DOUBLE overload)
     unsigned int* const my_prune_g = as_global(ap->q_prune) + item.query;    // set by the first item of the query whose slice passed the floor
     const uint64_t after_key = q.has_after ? pack_key(q.after_score, (uint32_t)q.after_doc) : ~0ull;
 
@@ -1180,11 +1180,30 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
       }
     }
     __syncthreads();
-    const uint32_t n = s.cnt;
+    const uint32_t n_held = s.cnt;
     const ms_args_ptr ape = ms_fresh(launch);   // (the epilogue's fields of the launch record: loaded here, not held through the walk)
     const __attribute__((address_space(4))) DHelp& hpe = ape->help;
     uint64_t* out = as_global(ape->item_keys) + (size_t)out_slot * ape->k_stride;
-    for (uint32_t i = tid; i < n; i += kMsThreads) out[i] = s.cand[i];
+    // What leaves the workgroup: the keys that still reach the query's threshold AS IT STANDS NOW (theta_g: what the query's other
+    // items and this item's other workgroups have published since these keys were collected -- a key below it is in nobody's
+    // top-k).  A helper that walked a few early windows holds up to k keys from when theta was low; with one query per call and
+    // 250 helpers the merge read them all (43 - 88 us of a 230 us call, profiles/r06_single_query_timeline.txt).
+    if (tid == 0) {
+      uint64_t th_end = s.theta;   // (compared as 64-bit INTEGERS: no max() overload that would take them through a double)
+      if (multi_item) {
+        const uint64_t tg = (uint64_t)__hip_atomic_load(my_theta_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tg > th_end) th_end = tg;
+      }
+      s.thr = th_end;     // (s.thr: free after the walk)
+      s.cnt_valid = 0u;   // (free since the walk's last compaction: the output's counter)
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_held; i += kMsThreads) {
+      const uint64_t key = s.cand[i];
+      if (key >= s.thr) out[atomicAdd(&s.cnt_valid, 1u)] = key;
+    }
+    __syncthreads();
+    const uint32_t n = s.cnt_valid;
     if (tid == 0) {
       as_global(ape->item_counts)[out_slot] = n;
       if (helper) {   // my slot joins the query's list (merge_topk_kernel walks it behind the items' slots)

@@ -22,7 +22,7 @@ KNOWN_SCRATCH = {
     "bm25_maxscore_kernel<false, false, 2>": 112,     # SHAPES == 2 (tie breaker / MUST + SHOULD): a second accumulator per posting slot,
     "bm25_maxscore_kernel<false, true, 2>": 144,      #   sixteen registers the kernel does not have -- spills INSIDE the walk, these shapes only
     "bm25_maxscore_kernel<false, false, *>": 48,      # (round 5: +16 B for the scattered window order's multiplier, at the round's head)
-    "bm25_maxscore_kernel<false, true, *>": 80,       # packed postings
+    "bm25_maxscore_kernel<false, true, *>": 96,       # packed postings (round 6: +16 B where the epilogue writes out the keys that still reach theta)
     "bm25_scan_kernel<true, true, 8, false>": 16,     # clause counting on the exhaustive route (COMPLETE mode): 2 VGPRs, outside the loop
 }
 VGPR_EDGE = {"bm25_maxscore_kernel<*>": 168, "bm25_scan_kernel<*>": 168, "knn_sketch_kernel<*>": 128, "knn_score_kernel": 128,
