@@ -930,6 +930,11 @@ struct MergeSmem {
   unsigned long long hits;
   uint32_t cnt;
   uint32_t pad;
+  // a block of the query's lists, one per thread: its record, where its keys begin among the block's (exclusive prefix of the
+  // counts; [kScanThreads] = the block's total), the waves' totals of the scan
+  uint32_t lrec[kScanThreads];
+  uint32_t loff[kScanThreads + 1];
+  uint32_t wtot[kScanThreads / 64];
 };
 
 __device__ __noinline__ void merge_compact(MergeSmem& s, uint32_t n, uint32_t k) {
@@ -948,7 +953,7 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
                        const uint32_t* __restrict__ q_base, const uint32_t* __restrict__ q_nlists, uint32_t k_stride_in,
                        const uint32_t* __restrict__ q_k, uint64_t* __restrict__ out_keys,
                        uint32_t* __restrict__ out_counts, uint64_t* __restrict__ out_hits,
-                       uint32_t k_stride_out, const uint32_t* __restrict__ help_head, const uint32_t* __restrict__ help_next,
+                       uint32_t k_stride_out, const uint32_t* __restrict__ help_query, uint32_t n_help,
                        uint32_t help_slot_base, const unsigned long long* __restrict__ spec_g) {
   __shared__ MergeSmem s;
   const uint32_t tid = threadIdx.x;
@@ -962,34 +967,62 @@ void merge_topk_kernel(const uint64_t* __restrict__ in_keys, const uint32_t* __r
     s.cnt = 0;
   }
   __syncthreads();
-  unsigned long long h = 0;
-  for (uint32_t l = tid; l < nl; l += kScanThreads) h += in_hits[list_idx[base + l]];
-  if (h) atomicAdd(&s.hits, h);
-
-  // the query's lists: its items' records, then the slots of the helpers that joined them (maxscore.hip, plan.h: DHelp --
-  // a linked list per query, slot = help_slot_base + helper number)
-  uint32_t hnext = help_head ? help_head[q] : 0u;
-  for (uint32_t l = 0; l < nl || hnext != 0u; ++l) {
-    uint32_t rec;
+  // The query's lists: its items' records, then the slots of the helpers that worked for it (maxscore.hip, plan.h: DHelp --
+  // help_query[h] = the query of helper slot h, + 1; slot = help_slot_base + h).  Through round 5 the helpers' slots were a linked
+  // list per query, walked one dependent load after the other, and every list cost the workgroup two barriers: with ONE query per
+  // call and 250 helpers the merge took as long as the scorer (profiles/r06_single_query_timeline.txt).  Now a thread per list:
+  // record and count at once, an exclusive scan of the counts, and the lists' keys as ONE sequence -- barriers per 768 keys.
+  const uint32_t n_lists = nl + (help_query ? n_help : 0u);
+  for (uint32_t l0 = 0; l0 < n_lists; l0 += kScanThreads) {
+    const uint32_t l = l0 + tid;
+    uint32_t rec = 0xFFFFFFFFu, c = 0;
     if (l < nl) {
       rec = list_idx[base + l];
-    } else {
-      rec = help_slot_base + hnext - 1u;
-      hnext = help_next[hnext - 1u];
-      if (tid == 0) atomicAdd(&s.hits, (unsigned long long)in_hits[rec]);
+    } else if (l < n_lists && help_query[l - nl] == q + 1u) {
+      rec = help_slot_base + (l - nl);
     }
-    const uint32_t c = min(in_counts[rec], k_stride_in);
-    const uint64_t* src = in_keys + (size_t)rec * k_stride_in;
-    for (uint32_t off = 0; off < c; off += kScanThreads) {
-      const uint32_t i = off + tid;
-      const uint64_t key = (i < c) ? src[i] : 0;
-      const bool want = (i < c) && (key > s.theta);
+    if (rec != 0xFFFFFFFFu) {
+      c = min(in_counts[rec], k_stride_in);
+      const unsigned long long h = in_hits[rec];
+      if (h) atomicAdd(&s.hits, h);
+    }
+    // exclusive scan of c over the workgroup: DPP scan per wave, the waves' totals through LDS
+    const uint32_t incl = scan64_dpp(c);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (lane == 63u) s.wtot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < (uint32_t)(kScanThreads / 64); ++w) {
+      const uint32_t t = s.wtot[w];
+      before += w < wave ? t : 0u;
+      total += t;
+    }
+    s.lrec[tid] = rec;
+    s.loff[tid] = before + incl - c;
+    if (tid == 0) s.loff[kScanThreads] = total;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < total; i0 += kScanThreads) {
+      const uint32_t i = i0 + tid;
+      uint64_t key = 0;
+      bool want = false;
+      if (i < total) {
+        // the last list whose keys begin at or before i (lists without keys share their successor's offset: the last of such a
+        // run is the one that has keys)
+        uint32_t lo = 0, hi = kScanThreads;   // loff[lo] <= i < loff[hi] (loff[kScanThreads] = total > i)
+        while (hi - lo > 1u) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s.loff[mid] <= i) lo = mid; else hi = mid;
+        }
+        key = in_keys[(size_t)s.lrec[lo] * k_stride_in + (i - s.loff[lo])];
+        want = key > s.theta;
+      }
       topk_append(s.cand, &s.cnt, want, key);
       __syncthreads();
       const uint32_t cn = s.cnt;
       __syncthreads();
       if (cn > (uint32_t)(kMergeCap - kScanThreads)) merge_compact(s, cn, k);
     }
+    __syncthreads();   // (lrec / loff / wtot are rewritten by the next block of lists)
   }
   __syncthreads();
   {
@@ -1266,11 +1299,11 @@ void launch_bm25_scan(hipStream_t stream, bool fixed_point, bool pipelined, bool
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
-                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_head,
-                       const uint32_t* help_next, uint32_t help_slot_base, const unsigned long long* spec_g) {
+                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_query,
+                       uint32_t n_help, uint32_t help_slot_base, const unsigned long long* spec_g) {
   if (n_queries == 0) return;
   hipLaunchKernelGGL(merge_topk_kernel, dim3(n_queries), dim3(kScanThreads), 0, stream, in_keys, in_counts, in_hits,
-                     list_idx, q_base, q_nlists, k_stride_in, q_k, out_keys, out_counts, out_hits, k_stride_out, help_head, help_next,
+                     list_idx, q_base, q_nlists, k_stride_in, q_k, out_keys, out_counts, out_hits, k_stride_out, help_query, n_help,
                      help_slot_base, spec_g);
 }
 

@@ -1206,10 +1206,8 @@ void bm25_maxscore_kernel(const MsArgs* __restrict__ launch) {
     const uint32_t n = s.cnt_valid;
     if (tid == 0) {
       as_global(ape->item_counts)[out_slot] = n;
-      if (helper) {   // my slot joins the query's list (merge_topk_kernel walks it behind the items' slots)
-        const uint32_t h = out_slot - hpe.slot_base;
-        as_global(hpe.help_next)[h] = atomicExch(as_global(hpe.help_head) + item.query, h + 1u);
-      }
+      if (helper)   // my slot is one of the query's lists (merge_topk_kernel reads the helpers' slots behind the items')
+        as_global(hpe.help_query)[out_slot - hpe.slot_base] = item.query + 1u;
       // the item's hits, per slice into the query's sums (slice_relation_kernel) and in total
       uint32_t hits = 0;
       for (int i = 0; i < kSliceSlots; ++i) {

@@ -256,13 +256,13 @@ constexpr int kMsmCountShift = 56;
 // the launch's critical path while the queue still holds items, any unfinished item once it is empty -- the tail of a launch
 // (1024 items of very different cost on 256 CUs, one workgroup per CU) is shared instead of waited for.  A helper has its own
 // score tables, candidate list and output slot (slot_base + its number), starts from the theta the query's items have
-// published (theta_g) and links its slot into the query's list for the merge.
+// published (theta_g) and notes its query beside its slot (help_query) for the merge.
 struct DHelp {
   uint32_t* win_next;            // [n_own]   windows handed out beyond the owner's first kMsWaves (zeroed per launch)
   uint32_t* help_cnt;            // [n_own]   helpers that joined the item
   unsigned long long* item_t0;   // [n_own]   wall clock (100 MHz) at which the item's owner started; 0: not yet
-  uint32_t* help_head;           // [queries] the query's helper slots: number of the first + 1, 0 = none
-  uint32_t* help_next;           // [n_help]  ... and the next one
+  uint32_t* help_head;           // [queries] (unused since round 6: the helpers' slots were a linked list per query)
+  uint32_t* help_query;          // [n_help]  the query helper slot h worked for, + 1 (0: the slot was not used): what the merge reads
   uint32_t* help_off;            // [1]       a helper found nothing left worth joining: the later ones leave at once
   uint32_t* item_next;           // [1]       the next item of the launch order to be started
   uint32_t* help_used;           // [1]       helper slots handed out

@@ -60,8 +60,8 @@ void launch_patch_hits(hipStream_t stream, const uint64_t* lower, uint64_t* hits
 void launch_merge_topk(hipStream_t stream, uint32_t n_queries, const uint64_t* in_keys, const uint32_t* in_counts,
                        const uint64_t* in_hits, const uint32_t* list_idx, const uint32_t* q_base,
                        const uint32_t* q_nlists, uint32_t k_stride_in, const uint32_t* q_k, uint64_t* out_keys,
-                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_head = nullptr,
-                       const uint32_t* help_next = nullptr, uint32_t help_slot_base = 0, const unsigned long long* spec_g = nullptr);
+                       uint32_t* out_counts, uint64_t* out_hits, uint32_t k_stride_out, const uint32_t* help_query = nullptr,
+                       uint32_t n_help = 0, uint32_t help_slot_base = 0, const unsigned long long* spec_g = nullptr);
 void launch_fold_norms(hipStream_t stream, const uint32_t* docids, const uint32_t* freqs, const uint8_t* norms,
                        uint32_t* fnorm, uint64_t n, uint32_t* overflow);
 void launch_pack_count(hipStream_t stream, const uint32_t* fnorm, uint64_t n, uint32_t n_blocks, uint32_t* counts);

@@ -229,7 +229,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   help.help_cnt = (uint32_t*)(wb + o_hcnt);
   help.item_t0 = (unsigned long long*)(wb + o_ht0);
   help.help_head = (uint32_t*)(wb + o_hhead);
-  help.help_next = (uint32_t*)(wb + o_hnext);
+  help.help_query = (uint32_t*)(wb + o_hnext);
   help.help_off = (uint32_t*)(wb + o_hoff);
   help.item_next = (uint32_t*)(wb + o_hqueue);
   help.help_used = (uint32_t*)(wb + o_hused);
@@ -340,7 +340,7 @@ static int enqueue_search(nrtgpu_ctx* ctx, Slot* slot, const HostPlan& hp, int32
   launch_merge_topk(st, (uint32_t)n_queries, (const uint64_t*)(wb + o_ikeys), (const uint32_t*)(wb + o_icnt),
                     (const uint64_t*)(wb + o_ihits), (const uint32_t*)(db + o_lidx), (const uint32_t*)(db + o_qbase),
                     (const uint32_t*)(db + o_qnl), hp.k_stride, (const uint32_t*)(db + o_qk), okeys, ocnt, ohits,
-                    k_stride_out, n_help ? help.help_head : nullptr, help.help_next, help.slot_base, spec_world > 1 ? nullptr : help.spec_g);
+                    k_stride_out, n_help ? help.help_query : nullptr, (uint32_t)n_help, help.slot_base, spec_world > 1 ? nullptr : help.spec_g);
   if (ext_guess) {   // (spec_world > 1: the guesses are checked by the caller, against the list merged over all shards)
     if (spec) HIP_TRY(hipMemcpyAsync(ext_guess, wb + o_spec, (size_t)n_queries * 8, hipMemcpyDeviceToDevice, st));
     else HIP_TRY(hipMemsetAsync(ext_guess, 0, (size_t)n_queries * 8, st));
